@@ -1,0 +1,206 @@
+// Fused BPR step + negative sampler.
+//
+// Replaces: Model/LightGCN.py:97-121 (variant 0: log(sigmoid(d)+1e-5) + L2 means),
+//           Model/FREEDOM.py:185-192 (variant 1: logsigmoid), Model/MMGCN.py:188-202
+//           (variant 2: log(sigmoid)), their autograd backward, and the python rejection
+//           sampler dataload.py:74-79.
+//
+// One wave64 per (user,pos,neg) triple: at D=64 a lane owns one feature, a row gather is one
+// 256-B coalesced read, the three dot products are wave butterflies (no LDS).  The batch is
+// launch/latency-bound (0.79 MB gathered at B=1024), so the forward is two launches with a
+// fixed reduction order (bit-reproducible loss) and the backward is one launch of 256-B
+// atomic row adds (the full-rate atomic shape on gfx950).
+#include "common.h"
+
+namespace chaorec {
+
+__device__ __forceinline__ float sigmoidf_acc(float d) { return 1.0f / (1.0f + expf(-d)); }
+
+__global__ __launch_bounds__(256) void bpr_fwd_terms_kernel(
+    const float *__restrict__ tab_u, const float *__restrict__ tab_i,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
+    const int64_t *__restrict__ neg, int B, int D, int variant, float *__restrict__ coef,
+    float *__restrict__ ws) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float *pu = tab_u + (size_t)users[b] * D;
+  const float *pp = tab_i + (size_t)pos[b] * D;
+  const float *pn = tab_i + (size_t)neg[b] * D;
+  float sp = 0.f, sn = 0.f, ru = 0.f, rp = 0.f, rn = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float u = pu[k], p = pp[k], n = pn[k];
+    sp += u * p;
+    sn += u * n;
+    ru += u * u;
+    rp += p * p;
+    rn += n * n;
+  }
+  sp = wave_sum(sp);
+  sn = wave_sum(sn);
+  ru = wave_sum(ru);
+  rp = wave_sum(rp);
+  rn = wave_sum(rn);
+  if (lane == 0) {
+    const float d = sp - sn;
+    const float invB = 1.0f / (float)B;
+    float term, c;
+    if (variant == CHAOREC_BPR_LOG_SIGMOID_EPS) {
+      const float s = sigmoidf_acc(d);
+      term = logf(s + 1e-5f);
+      c = -invB * (s * (1.0f - s)) / (s + 1e-5f);
+    } else if (variant == CHAOREC_BPR_LOGSIGMOID) {
+      // logsigmoid(d) = min(d,0) - log1p(exp(-|d|))
+      term = fminf(d, 0.f) - log1pf(expf(-fabsf(d)));
+      c = -invB * sigmoidf_acc(-d);
+    } else {
+      const float s = sigmoidf_acc(d);
+      term = logf(s);
+      c = -invB * (1.0f - s);
+    }
+    coef[b] = c;
+    ws[b] = term;
+    ws[B + b] = ru;
+    ws[2 * B + b] = rp;
+    ws[3 * B + b] = rn;
+  }
+}
+
+// One block, fixed order: thread t sums elements t, t+256, ... then a fixed LDS tree.
+__global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__restrict__ ws, int B,
+                                                               int D, float reg_weight,
+                                                               float *__restrict__ out_loss) {
+  __shared__ float red[4][256];
+  const int t = threadIdx.x;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = t; i < B; i += 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] += ws[q * B + i];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[q][t] = a[q];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[q][t] += red[q][t + s];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const float bpr = -red[0][0] / (float)B;
+    const float denom = (float)B * (float)D;
+    float reg = 0.f;
+    if (reg_weight != 0.f) reg = reg_weight * (red[1][0] / denom + red[2][0] / denom + red[3][0] / denom);
+    out_loss[0] = bpr + reg;
+    out_loss[1] = bpr;
+    out_loss[2] = reg;
+  }
+}
+
+__global__ __launch_bounds__(256) void bpr_bwd_kernel(
+    const float *__restrict__ tab_u, const float *__restrict__ tab_i,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
+    const int64_t *__restrict__ neg, int B, int D, const float *__restrict__ coef,
+    float reg_weight, const float *__restrict__ grad_out, float *g_u, float *g_i) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float go = grad_out ? grad_out[0] : 1.0f;
+  const float c = coef[b] * go;
+  const float r2 = go * 2.0f * reg_weight / ((float)B * (float)D);
+  const size_t ou = (size_t)users[b] * D, op = (size_t)pos[b] * D, on = (size_t)neg[b] * D;
+  for (int k = lane; k < D; k += 64) {
+    const float u = tab_u[ou + k], p = tab_i[op + k], n = tab_i[on + k];
+    atomicAdd(g_u + ou + k, c * (p - n) + r2 * u);
+    atomicAdd(g_i + op + k, c * u + r2 * p);
+    atomicAdd(g_i + on + k, -c * u + r2 * n);
+  }
+}
+
+// ---- sampler -------------------------------------------------------------------------------
+// Counter-based generator: splitmix64 finaliser over (seed, step, b, attempt).  Stateless, so a
+// draw does not depend on launch geometry or on how many draws other samples needed.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t sampler_draw(uint64_t seed, uint64_t step, uint32_t b,
+                                                 uint32_t attempt, uint32_t num_item) {
+  uint64_t h = mix64(seed ^ mix64(step ^ mix64(((uint64_t)b << 32) | attempt)));
+  // Lemire multiply-shift onto [0, num_item): bias <= num_item / 2^32, far below test resolution
+  return (uint32_t)(((h >> 32) * (uint64_t)num_item) >> 32);
+}
+
+__global__ __launch_bounds__(256) void sample_negatives_kernel(
+    const int64_t *__restrict__ hist_rowptr, const int32_t *__restrict__ hist_col,
+    const int64_t *__restrict__ users, int B, uint32_t num_item, uint64_t seed, uint64_t step,
+    int64_t id_offset, int64_t *__restrict__ out_neg) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int64_t u = users[b];
+  const int64_t h0 = hist_rowptr[u], h1 = hist_rowptr[u + 1];
+  uint32_t cand = 0;
+  for (uint32_t attempt = 0;; ++attempt) {
+    cand = sampler_draw(seed, step, (uint32_t)b, attempt, num_item);
+    // binary search in the user's ascending history row
+    int64_t lo = h0, hi = h1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint32_t)hist_col[mid] < cand) lo = mid + 1; else hi = mid;
+    }
+    const bool seen = (lo < h1) && ((uint32_t)hist_col[lo] == cand);
+    if (!seen) break;
+    if (attempt >= 4096u) break;  // a user who interacted with ~every item: give up, bounded
+  }
+  out_neg[b] = (int64_t)cand + id_offset;
+}
+
+}  // namespace chaorec
+
+using namespace chaorec;
+
+extern "C" int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i, const int64_t *users,
+                                   const int64_t *pos, const int64_t *neg, int32_t B, int32_t D,
+                                   int32_t variant, float reg_weight, float *out_loss, float *coef,
+                                   float *workspace, void *stream) {
+  if (!tab_u || !tab_i || !users || !pos || !neg || !out_loss || !coef || !workspace)
+    return fail(CHAOREC_E_INVALID, "bpr_fwd: NULL argument");
+  if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd: B=%d D=%d", B, D);
+  if (variant < 0 || variant > 2) return fail(CHAOREC_E_INVALID, "bpr_fwd: variant %d", variant);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bpr_fwd_terms_kernel, dim3((B + 3) / 4), dim3(256), 0, st, tab_u, tab_i, users,
+                     pos, neg, B, D, variant, coef, workspace);
+  int rc = check_launch("bpr_fwd_terms_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight,
+                     out_loss);
+  return check_launch("bpr_fwd_finalize_kernel");
+}
+
+extern "C" int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i, const int64_t *users,
+                                   const int64_t *pos, const int64_t *neg, int32_t B, int32_t D,
+                                   const float *coef, float reg_weight, const float *grad_out,
+                                   float *g_u, float *g_i, void *stream) {
+  if (!tab_u || !tab_i || !users || !pos || !neg || !coef || !g_u || !g_i)
+    return fail(CHAOREC_E_INVALID, "bpr_bwd: NULL argument");
+  if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_bwd: B=%d D=%d", B, D);
+  hipLaunchKernelGGL(bpr_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u,
+                     tab_i, users, pos, neg, B, D, coef, reg_weight, grad_out, g_u, g_i);
+  return check_launch("bpr_bwd_kernel");
+}
+
+extern "C" int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col,
+                                        const int64_t *users, int32_t B, int32_t num_item,
+                                        uint64_t seed, uint64_t step, int64_t id_offset,
+                                        int64_t *out_neg, void *stream) {
+  if (!hist_rowptr || !users || !out_neg) return fail(CHAOREC_E_INVALID, "sample: NULL argument");
+  if (B <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "sample: B=%d num_item=%d", B, num_item);
+  hipLaunchKernelGGL(sample_negatives_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     hist_rowptr, hist_col, users, B, (uint32_t)num_item, seed, step, id_offset,
+                     out_neg);
+  return check_launch("sample_negatives_kernel");
+}

@@ -1,0 +1,61 @@
+// Shared helpers for libchaorec_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/chaorec_hip.h"
+
+namespace chaorec {
+
+// Per-thread last-error text returned by chaorec_last_error().
+inline char *err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CHAOREC_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return CHAOREC_OK;
+}
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+// Separately rounded fp32 product and sum: the compiler must not contract these into an FMA,
+// the reference's message()/scatter_add_ pair rounds twice (Model/LightGCN.py:40-43).
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+
+__device__ __forceinline__ float4 mul_rn4(float s, float4 v) {
+  return make_float4(mul_rn(s, v.x), mul_rn(s, v.y), mul_rn(s, v.z), mul_rn(s, v.w));
+}
+__device__ __forceinline__ float4 add_rn4(float4 a, float4 b) {
+  return make_float4(add_rn(a.x, b.x), add_rn(a.y, b.y), add_rn(a.z, b.z), add_rn(a.w, b.w));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  // fixed butterfly order -> identical result on every lane and every run
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+}  // namespace chaorec

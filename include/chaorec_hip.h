@@ -1,0 +1,177 @@
+/*
+ * chaorec_hip.h -- C-ABI of libchaorec_hip.so: the MI355X (gfx950) kernels under
+ * ChaoRec's GCN-propagation + BPR-training + full-rank-evaluation hot path.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
+ *     only ENQUEUED, nothing here synchronises or allocates;
+ *   - the caller owns every buffer, including workspaces (sizes from the *_workspace_bytes
+ *     queries, which are host-only and launch nothing);
+ *   - return value: 0 = ok, <0 = error (CHAOREC_E_*); chaorec_last_error() returns a
+ *     host string describing the last failure on the calling thread;
+ *   - row-major dense tables, fp32, leading dimension == D unless an ld* argument exists.
+ *
+ * The reference (Ricardo-Ping/ChaoRec) is pure Python with no FFI layer: each entry point
+ * below names the reference library call it replaces (file:line relative to the reference
+ * root).  The Python binding a maintainer adds is shown in INTEGRATION.md.
+ */
+#ifndef CHAOREC_HIP_H
+#define CHAOREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHAOREC_ABI_VERSION 1
+
+#define CHAOREC_OK 0
+#define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
+#define CHAOREC_E_LAUNCH (-2)      /* hipLaunch / hipMemsetAsync reported an error */
+#define CHAOREC_E_WORKSPACE (-3)   /* workspace too small */
+
+int chaorec_abi_version(void);
+const char *chaorec_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * P1/P7/P12: normalised-adjacency propagate  y = alpha * (A x) [+ beta * z],  A in CSR.
+ *
+ * Replaces: PyG MessagePassing.propagate = index_select + message (norm * x_j) + scatter_add
+ *           (Model/LightGCN.py:40-43, BasicGCN.py:48-53,78-82) and torch.sparse.mm(adj, x)
+ *           (Model/FREEDOM.py:168,174).
+ *
+ * Row r of the CSR is the DESTINATION node; its entries are the incoming edges in the
+ * reference's edge order (stable sort by destination), so mode 0 reproduces the reference
+ * CPU accumulation order:  s = 0; for e in row: s = s + (val[e] * x[col[e]])  -- product and
+ * sum rounded separately (no FMA), exactly what message() then scatter_add_ do.
+ * Epilogue, in this order, every step rounded to fp32:
+ *     s = alpha * s                       (alpha == 1 is exact)
+ *     if z:   s = s + (beta * z[r])
+ *     y[r] = s                            (y may be NULL when only acc is wanted)
+ *     if acc: a0 = acc_init ? (acc_w * acc_init[r]) : acc[r];   acc[r] = a0 + (acc_w * s)
+ * The acc epilogue is LightGCN.forward's layer mean (Model/LightGCN.py:86-93):
+ * final += (1/(L+1)) * x_l, with acc_init = x_0 on the first layer.
+ * Backward (A symmetric for LightGCN/FREEDOM-ui/BasicGCN) is the same call with the
+ * transposed CSR:  g_l = A^T g_{l+1} + beta * G.
+ *
+ * D must be a multiple of 4, 4 <= D <= 1024.  rowptr is int64 (nnz of config 5 > 2^31).
+ * mode: 0 = ordered (bit-reproducible, reference order).
+ * ------------------------------------------------------------------------------------- */
+int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
+                         const float *x, float *y, int64_t n_rows, int64_t n_cols, int32_t D,
+                         float alpha, const float *z, float beta,
+                         float *acc, const float *acc_init, float acc_w,
+                         int32_t mode, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * P4/P5/P9/P13: fused BPR step on a batch of (user, pos, neg) triples.
+ *
+ * Replaces: three row gathers + mul + sum + log(sigmoid) + mean (+ L2 means)
+ *           Model/LightGCN.py:97-121 (variant 0), Model/FREEDOM.py:185-192 (variant 1),
+ *           Model/MMGCN.py:188-202 (variant 2) and their autograd backward (index_add).
+ *
+ * users[b] indexes rows of tab_u, pos[b]/neg[b] index rows of tab_i (LOCAL row ids).
+ *   d_b  = sum_k u*p - sum_k u*n
+ *   variant 0: t_b = log(sigmoid(d_b) + 1e-5)     variant 1: t_b = logsigmoid(d_b)
+ *   variant 2: t_b = log(sigmoid(d_b))
+ *   bpr  = -(1/B) sum_b t_b
+ *   reg  = reg_weight * (mean(u^2) + mean(p^2) + mean(n^2)),  means over B*D  (0 if reg_weight==0)
+ *   out_loss[0] = bpr + reg, out_loss[1] = bpr, out_loss[2] = reg
+ *   coef[b] = d(bpr)/d(d_b)   (kept for the backward)
+ * workspace: 4*B floats.  Reductions run in a fixed order: results are run-to-run identical.
+ *
+ * bwd: g_u[users[b]] += go*(coef_b*(p-n) + (2*reg_weight/(B*D))*u), g_i[pos[b]] += go*(coef_b*u + ..*p),
+ *      g_i[neg[b]] += go*(-coef_b*u + ..*n);  go = *grad_out (device scalar) or 1 if NULL.
+ *      Accumulated with fp32 atomics (duplicates inside a batch); g_u/g_i must be zeroed or
+ *      hold the gradient being accumulated.
+ * ------------------------------------------------------------------------------------- */
+#define CHAOREC_BPR_LOG_SIGMOID_EPS 0
+#define CHAOREC_BPR_LOGSIGMOID 1
+#define CHAOREC_BPR_LOG_SIGMOID 2
+
+int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i,
+                        const int64_t *users, const int64_t *pos, const int64_t *neg,
+                        int32_t B, int32_t D, int32_t variant, float reg_weight,
+                        float *out_loss, float *coef, float *workspace, void *stream);
+
+int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i,
+                        const int64_t *users, const int64_t *pos, const int64_t *neg,
+                        int32_t B, int32_t D, const float *coef, float reg_weight,
+                        const float *grad_out, float *g_u, float *g_i, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * S: uniform negative sampler with history rejection.
+ *
+ * Replaces: TrainingDataset.__getitem__'s `random.sample(all_set,1)` rejection loop
+ *           (dataload.py:74-79).  Parity is distributional (uniform over items the user has
+ *           not interacted with), not bit-wise: the reference uses Python's Mersenne Twister.
+ * hist_* is the user -> interacted LOCAL item ids CSR, ids ascending inside a row.
+ * Draws are a pure function of (seed, step, b, attempt): reproducible and order-free.
+ * out_neg[b] = local item id + id_offset (the reference hands out GLOBAL ids = item + num_user).
+ * ------------------------------------------------------------------------------------- */
+int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col,
+                             const int64_t *users, int32_t B, int32_t num_item,
+                             uint64_t seed, uint64_t step, int64_t id_offset,
+                             int64_t *out_neg, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * R: all-items scoring + history mask + top-K, never materialising the [U, I] matrix.
+ *
+ * Replaces: torch.matmul(user, item.T) + per-user python mask loop + torch.topk
+ *           (Model/LightGCN.py:147-155, Model/FREEDOM.py:230-238, Model/MMGCN.py:220-230)
+ *           and the kNN build torch.mm + topk (Model/FREEDOM.py:114-118) with hist == NULL.
+ *
+ *   score[u][i] = sum_k user_emb[u][k] * item_emb[i][k]          (precision below)
+ *   score[u][i] = mask_value   for every i in hist row u          (1e-6 / 1e-5 in the reference)
+ *   out = the K largest per user, descending; ties -> LOWEST item index first.
+ *   out_idx = item index + id_offset (int64), out_val = the (masked) score.
+ *
+ * precision 0 ("f32"): v_mfma_f32_32x32x2_f32, i.e. a k-ordered fp32 fmaf chain
+ *     acc = 0; for s in [0, D/2): acc = fmaf(u[s], i[s], acc); acc = fmaf(u[D/2+s], i[D/2+s], acc)
+ *   bit-identical to oracle/chaorec_oracle.c:oracle_score_dot().
+ * D in {32, 64, 128};  1 <= K <= 64;  n_items >= K.
+ * hist_rowptr may be NULL (no mask).  hist_col ascending inside a row.
+ * ------------------------------------------------------------------------------------- */
+size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K);
+
+int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
+                           int64_t n_users, int64_t n_items, int32_t D,
+                           const int64_t *hist_rowptr, const int32_t *hist_col,
+                           float mask_value, int32_t K, int64_t id_offset,
+                           int64_t *out_idx, float *out_val,
+                           void *workspace, size_t workspace_bytes,
+                           int32_t precision, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense fp32 GEMM on the f32 MFMA pipe (exact fp32 products, fp32 accumulate):
+ *   C[M,N] = op(A) * op(B) (+ bias[N]) (+ C if accumulate)
+ * transA/transB: 0 = as stored [M,K]/[K,N], 1 = stored transposed [K,M]/[N,K].
+ *
+ * Replaces: nn.Linear forward/backward on modality features and MMGCN's per-layer Linears
+ *           (Model/FREEDOM.py:59-60,209,212; Model/MMGCN.py:40,97,102-131; BasicGCN.py:40).
+ *   forward  y = x W^T + b      : transA=0, transB=1 (W stored [N,K])
+ *   grad x   = gy W             : transA=0, transB=0
+ *   grad W   = gy^T x           : transA=1, transB=0
+ * act: 0 none, 1 leaky_relu(0.01) applied to the result (F.leaky_relu default slope).
+ * ------------------------------------------------------------------------------------- */
+int chaorec_gemm_f32(const float *A, const float *B, float *C, const float *bias,
+                     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                     int32_t transA, int32_t transB, int32_t accumulate, int32_t act,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused Adam step over one flat fp32 parameter (torch.optim.Adam defaults, main.py:397):
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * ------------------------------------------------------------------------------------- */
+int chaorec_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                          int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int32_t step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHAOREC_HIP_H */

@@ -1,0 +1,62 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def baby():
+    g = load_golden("baby_interactions.npz")
+    val = [g["val_flat"][g["val_off"][i]:g["val_off"][i + 1]].tolist() for i in range(len(g["val_off"]) - 1)]
+    test = [g["test_flat"][g["test_off"][i]:g["test_off"][i + 1]].tolist() for i in range(len(g["test_off"]) - 1)]
+    return dict(U=int(g["U"]), I=int(g["I"]), train=g["train"], val=val, test=test)
+
+
+def tie_aware_rank_equal(idx_a, val_a, idx_b, val_b, rtol=0.0, atol=0.0):
+    """Top-K lists agree when the value sequences agree (within tol) and, inside every group of
+    (near-)equal values, the index SETS agree (torch.topk tie order is unspecified).
+    Groups cut off by the K boundary may differ in membership; only their values are compared."""
+    idx_a, idx_b = np.asarray(idx_a), np.asarray(idx_b)
+    val_a, val_b = np.asarray(val_a, np.float64), np.asarray(val_b, np.float64)
+    if idx_a.shape != idx_b.shape:
+        return False, "shape"
+    if not np.allclose(val_a, val_b, rtol=rtol, atol=atol):
+        return False, f"values differ max {np.abs(val_a - val_b).max()}"
+    bad = 0
+    for r in range(idx_a.shape[0]):
+        if np.array_equal(idx_a[r], idx_b[r]):
+            continue
+        v = val_a[r]
+        tol = atol + rtol * np.abs(v)
+        K = len(v)
+        s = 0
+        while s < K:
+            e = s + 1
+            while e < K and abs(v[e] - v[e - 1]) <= max(tol[e], tol[e - 1]):
+                e += 1
+            if e < K and set(idx_a[r, s:e]) != set(idx_b[r, s:e]):
+                bad += 1
+                break
+            s = e
+    return bad == 0, f"{bad} rows differ outside tie groups"

@@ -1,0 +1,130 @@
+"""Pins the CPU oracle (oracle/) against outputs of the reference's own classes
+(tests/golden/*.npz, produced by tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, tie_aware_rank_equal
+
+
+def test_csr_equals_edge_scatter(oracle):
+    g = load_golden("lightgcn_tiny.npz")
+    N = int(g["U"]) + int(g["I"])
+    src, dst = oracle.bidirectional_edges(g["edges"])
+    w = oracle.sym_norm_weights(src, dst, N)
+    csr = oracle.csr_from_edges(src, dst, w, N)
+    a = oracle.spmm(csr, g["x0"])
+    b = oracle.scatter_edges(src, dst, w, g["x0"], N)
+    assert np.array_equal(a, b)
+    # isolated item 4 (global node 10) stays exactly zero
+    assert np.all(a[10] == 0)
+
+
+def test_lightgcn_tiny_forward_bit_exact(oracle):
+    g = load_golden("lightgcn_tiny.npz")
+    N = int(g["U"]) + int(g["I"])
+    csr = oracle.lightgcn_csr(g["edges"], N)
+    final, layers = oracle.lightgcn_forward(g["x0"], csr, int(g["L"]))
+    for l, x in enumerate(layers):
+        assert np.array_equal(x, g["layers"][l]), f"layer {l}"
+    assert np.array_equal(final, g["result"])
+
+
+def test_lightgcn_tiny_loss_grad_rank(oracle):
+    g = load_golden("lightgcn_tiny.npz")
+    U, I = int(g["U"]), int(g["I"])
+    csr = oracle.lightgcn_csr(g["edges"], U + I)
+    out, grad = oracle.lightgcn_loss(g["x0"], csr, int(g["L"]), U, g["users"], g["pos"] - U, g["neg"] - U,
+                                     float(g["reg"]))
+    assert out[0] == pytest.approx(float(g["loss"]), rel=1e-6)
+    assert out[1] == pytest.approx(float(g["bpr"]), rel=1e-6)
+    assert out[2] == pytest.approx(float(g["reg_loss"]), rel=1e-5)
+    ref = np.concatenate([g["g_user"], g["g_item"]], 0)
+    assert np.allclose(grad, ref, rtol=1e-4, atol=1e-7)
+    hist = oracle.user_hist_csr(g["edges"], U)
+    idx, val = oracle.gene_ranklist(g["result"], U, I, hist, 1e-6, int(g["topk"]))
+    ok, why = tie_aware_rank_equal(idx, val, g["rank"], g["rank_val"], rtol=1e-5, atol=1e-7)
+    assert ok, why
+
+
+def test_lightgcn_baby(oracle, baby):
+    g = load_golden("lightgcn_baby.npz")
+    U, I, D, L = baby["U"], baby["I"], int(g["D"]), int(g["L"])
+    x0 = (np.random.default_rng(int(g["x0_seed"])).standard_normal((U + I, D)) * float(g["x0_scale"])).astype(np.float32)
+    csr = oracle.lightgcn_csr(baby["train"], U + I)
+    final, layers = oracle.lightgcn_forward(x0, csr, L)
+    rows = g["rows"]
+    # torch's CPU scatter_add_ order is the edge order: the restatement is bit-exact on real data too
+    for l in range(L + 1):
+        assert np.array_equal(layers[l][rows], g["layer_rows"][l]), f"layer {l}"
+    assert np.array_equal(final[rows], g["result_rows"])
+    assert final.astype(np.float64).sum() == pytest.approx(float(g["result_sum"]), rel=1e-9)
+    out, grad = oracle.lightgcn_loss(x0, csr, L, U, g["users"], g["pos"] - U, g["neg"] - U, float(g["reg"]))
+    assert out[0] == pytest.approx(float(g["loss"]), rel=2e-6)
+    assert np.allclose(grad[rows], g["g_rows"], rtol=2e-4, atol=1e-9)
+    assert np.abs(grad).sum() == pytest.approx(float(g["g_abs_sum"]), rel=1e-4)
+    # ranking on a user subset
+    hist = oracle.user_hist_csr(baby["train"], U)
+    urows = g["urows"]
+    sub_rowptr = np.zeros(len(urows) + 1, np.int64)
+    cols = []
+    for k, u in enumerate(urows):
+        c = hist[1][hist[0][u]:hist[0][u + 1]]
+        cols.append(c)
+        sub_rowptr[k + 1] = sub_rowptr[k] + len(c)
+    sub_hist = (sub_rowptr, np.concatenate(cols).astype(np.int32))
+    idx, val = oracle.score_topk(final[:U][urows], final[U:], sub_hist, 1e-6, 50, U)
+    ok, why = tie_aware_rank_equal(idx, val, g["rank_rows"].astype(np.int64), g["rank_val_rows"], rtol=2e-5, atol=1e-8)
+    assert ok, why
+
+
+def test_metrics_pinned(oracle, baby):
+    g = load_golden("metrics_baby_fixed_rank.npz")
+    U, I = baby["U"], baby["I"]
+    fixed_rank = np.stack([np.random.default_rng(1000 + u).permutation(I)[:50] + U for u in range(U)])
+    k_list = [int(k) for k in g["k_list"]]
+    m = oracle.gene_metrics(baby["val"], fixed_rank, k_list)
+    got = np.array([[m[k][n] for n in g["metric_names"]] for k in k_list])
+    assert np.allclose(got, g["val_metrics"], rtol=1e-12, atol=0)
+
+
+def test_metrics_of_reference_ranklist(oracle, baby):
+    """Recall/NDCG of the oracle's rank list vs the reference's numbers on the reference's list."""
+    g = load_golden("lightgcn_baby.npz")
+    U, I, D, L = baby["U"], baby["I"], int(g["D"]), int(g["L"])
+    x0 = (np.random.default_rng(int(g["x0_seed"])).standard_normal((U + I, D)) * float(g["x0_scale"])).astype(np.float32)
+    csr = oracle.lightgcn_csr(baby["train"], U + I)
+    final, _ = oracle.lightgcn_forward(x0, csr, L)
+    hist = oracle.user_hist_csr(baby["train"], U)
+    idx, _ = oracle.gene_ranklist(final, U, I, hist, 1e-6, 50)
+    k_list = [int(k) for k in g["k_list"]]
+    names = list(g["metric_names"])
+    for split, key in ((baby["val"], "val_metrics"), (baby["test"], "test_metrics")):
+        m = oracle.gene_metrics(split, idx, k_list)
+        got = np.array([[m[k][n] for n in names] for k in k_list])
+        assert np.abs(got - g[key]).max() < 1e-4  # north_star tolerance on Recall/NDCG@20
+
+
+def test_user_item_dict_rule(oracle, baby):
+    d = oracle.user_item_dict_from_edges(baby["train"])
+    assert list(d.keys()) == sorted(d.keys()) and len(d) == baby["U"]
+    rowptr, col = oracle.user_hist_csr(baby["train"], baby["U"])
+    for u in (0, 1, 777, baby["U"] - 1):
+        assert sorted(i - baby["U"] for i in d[u]) == col[rowptr[u]:rowptr[u + 1]].tolist()
+
+
+def test_sampler_matches_reference_support(oracle):
+    """dataload.py:74-79: negatives are uniform over the items the user never touched."""
+    g = load_golden("sampler_tiny.npz")
+    U, I = int(g["U"]), int(g["I"])
+    hist = oracle.user_hist_csr(g["edges"], U)
+    ref_hist = g["neg_hist"]
+    users = np.repeat(np.arange(U), 4000).astype(np.int64)
+    neg = oracle.sample_negatives(hist, users, I, seed=42, step=0, id_offset=U) - U
+    mine = np.zeros((U, I), np.int64)
+    np.add.at(mine, (users, neg), 1)
+    assert np.array_equal(mine > 0, ref_hist > 0)  # same support as the reference sampler
+    for u in range(U):
+        allowed = mine[u] > 0
+        exp = 4000 / allowed.sum()
+        chi2 = ((mine[u][allowed] - exp) ** 2 / exp).sum()
+        assert chi2 < 30, (u, chi2)  # dof <= 4: p(chi2 > 30) ~ 5e-6
