@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline numbers on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): LightGCN, Amazon-sports shape (U=28940, I=15207,
+E=158554 -> 317108 directed edges), dim=64, n_layers=3, batch 1024.  The reference's Data/
+does not exist on the GPU box, so the graph is synthetic with the same shape and degree profile
+(chaorec_amd/synthetic.py) and the embeddings are xavier-initialised under seed 42.
+
+A "step" is one reference training iteration (train_and_evaluate.py:43-48): negative sampling,
+model.loss() = full-graph 3-layer propagate + BPR + L2, loss.backward(), Adam step.  `value` is
+directed-edge messages per second through that step, counting the forward AND backward SpMM
+(2 * L * E_dir per step), with all inputs resident in HBM.  users_scored_per_s times
+gene_ranklist() (scoring + mask + top-50 for every user).
+
+At N > 1 the graph shards by user rows (weak scaling: every rank owns a sports-sized user shard
+over the same item set), items replicated, item-row partial sums all-reduced over RCCL per layer.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+F32_MFMA_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--dataset", default="sports")
+    p.add_argument("--n-layers", type=int, default=3)
+    p.add_argument("--dim", type=int, default=64)
+    p.add_argument("--batch", type=int, default=1024)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    return p.parse_args()
+
+
+def spmm_model_bytes(nnz, n_rows, D):
+    """no-reuse CSR model, fp32: per nonzero a D-float source row + 4 B col + 4 B val;
+    per output row a D-float store + 8 B row pointer."""
+    return nnz * (4 * D + 8) + n_rows * (4 * D + 8)
+
+
+def cpu_baseline(edges, U, I, D, L, B, reg, budget_s):
+    """The reference CPU path restated in plain torch (oracle/torch_ref.py), timed on this box's
+    host cores on a bounded number of steps."""
+    from oracle.torch_ref import TorchRefLightGCN
+    from chaorec_amd.graph import user_item_dict_from_edges
+    torch.manual_seed(42)
+    uid = user_item_dict_from_edges(edges)
+    m = TorchRefLightGCN(U, I, edges, uid, D, reg, L)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    rng = np.random.default_rng(0)
+    E = len(edges)
+
+    def batch():
+        b = rng.integers(0, E, B)
+        return (torch.from_numpy(edges[b, 0].astype(np.int64)), torch.from_numpy(edges[b, 1].astype(np.int64)),
+                torch.from_numpy(rng.integers(U, U + I, B)))
+
+    def step():
+        u, p, n = batch()
+        opt.zero_grad()
+        loss = m.loss(u, p, n)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n_steps = 0
+    while n_steps < 3 or (time.perf_counter() - t0 < budget_s * 0.75 and n_steps < 200):
+        step()
+        n_steps += 1
+    dt = (time.perf_counter() - t0) / n_steps
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        m.gene_ranklist()
+    t_rank = time.perf_counter() - t1
+    e_dir = 2 * E
+    return {
+        "value": 2 * L * e_dir / dt, "unit": "directed-edge messages/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{n_steps} train steps of the same workload ({dt * 1e3:.1f} ms/step) + 1 gene_ranklist "
+                  f"({t_rank:.2f} s) with oracle/torch_ref.py (reference op sequence in plain torch, CPU)",
+        "ms_per_step": dt * 1e3, "users_scored_per_s": U / t_rank,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from chaorec_amd import _lib, graph, ops
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+    _lib.load()
+
+    U1, I, E1 = DATASET_SHAPES[args.dataset]
+    D, L, B, reg = args.dim, args.n_layers, args.batch, 1e-3
+
+    if world == 1:
+        U = U1
+        edges = synthetic_interactions(U1, I, E1, seed=42)
+        torch.manual_seed(42)
+        model = LightGCN(U, I, edges, None if False else graph.user_item_dict_from_edges(edges), D, reg, L, "add",
+                         dev).to(dev)
+        sharded = None
+    else:
+        from chaorec_amd import dist as cdist
+        sharded = cdist.build_weak_scaling_job(U1, I, E1, world, rank, D, L, reg, dev, seed=42)
+        model, edges, U = sharded.model, sharded.local_edges, sharded.num_user_local
+
+    E = len(edges)
+    e_dir = 2 * E
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42 + rank)
+    loss_sum = torch.zeros((), device=dev)
+
+    def step(i):
+        sel = torch.randint(0, E, (B,), device=dev, generator=gen)   # DataLoader(shuffle=True) stand-in
+        users, pos = edges_dev[sel, 0], edges_dev[sel, 1]
+        neg = ops.sample_negatives(model.hist, users if sharded is None else sharded.local_user_ids(users), I,
+                                   42, i, model.num_user)
+        opt.zero_grad(set_to_none=True)
+        loss = model.loss(users, pos, neg)
+        loss.backward()
+        opt.step()
+        loss_sum.add_(loss.detach())   # the reference's per-batch loss.item() sync is kept off the device path
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    msgs_per_step_all = 2 * L * e_dir * world
+    value = msgs_per_step_all / (dt / args.steps)
+
+    # --- SpMM roofline: events around every SpMM launch of further, identical steps ---------------
+    spmm_times = []
+    orig = ops.spmm_raw
+
+    def timed_spmm(*a, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = orig(*a, **k)
+        e.record()
+        spmm_times.append((s, e))
+        return out
+
+    ops.spmm_raw = timed_spmm
+    for i in range(min(args.steps, 50)):
+        step(args.warmup + args.steps + i)
+    ops.spmm_raw = orig
+    torch.cuda.synchronize()
+    avg_spmm_ms = float(np.mean([s.elapsed_time(e) for s, e in spmm_times]))
+    nnz, n_rows = model.graph.nnz, model.graph.n_rows
+    model_bytes = spmm_model_bytes(nnz, n_rows, D)
+    achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "spmm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "spmm_csr_ordered_kernel<16,1>", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": model_bytes, "avg_launch_us": avg_spmm_ms * 1e3,
+                "compulsory_bytes_per_launch": 2 * n_rows * 4 * D + nnz * 8,
+                "note": "embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is "
+                        "against the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)"
+                        % (n_rows * D * 4 / 1e6)}
+
+    # --- full-rank evaluation: users scored per second ---------------------------------------------
+    torch.cuda.synchronize()
+    reps = 5
+    model.gene_ranklist()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    with torch.no_grad():
+        res = model.result.detach()
+        for s, e in ev:
+            s.record()
+            ops.score_topk(res[:U], res[model.num_user:model.num_user + I], model.hist, 1e-6, 50,
+                           id_offset=model.num_user)
+            e.record()
+    torch.cuda.synchronize()
+    score_ms = float(np.median([s.elapsed_time(e) for s, e in ev]))
+    if world > 1:
+        t = torch.tensor([score_ms], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        score_ms = float(t.item())
+    users_per_s = U * world / (score_ms * 1e-3)
+    score_flops = 2.0 * U * I * D
+    roofline_scoring = {"bound": "mfma", "kernel": "score_topk_f32_kernel<64>", "achieved": score_flops / (score_ms * 1e-3) / 1e12,
+                        "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": score_flops / (score_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                        "note": "exact-fp32 path (v_mfma_f32_32x32x2_f32, 157 TF dense peak); kernel + merge launch"}
+
+    out = {
+        "metric": "GCN edges/sec + full-rank users-scored/sec, dim=64",
+        "value": value, "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
+        "users_scored_per_s": users_per_s,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"LightGCN train step on {args.dataset}-shaped synthetic graph "
+                               f"(U={U}x{world}, I={I}, E_dir={e_dir}x{world}), dim={D}, n_layers={L}, batch={B}; "
+                               f"gene_ranklist top-50 over all users",
+                   "messages_per_step": msgs_per_step_all, "gene_ranklist_ms": score_ms,
+                   "parallelism": "single GPU" if world == 1 else f"user-row shards x{world}, item all-reduce per layer"},
+        "roofline": roofline, "roofline_scoring": roofline_scoring,
+        "loss_mean": float(loss_sum.item()) / (args.steps + args.warmup + min(args.steps, 50)),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(edges, U, I, D, L, B, reg, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

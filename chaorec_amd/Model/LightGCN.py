@@ -1,0 +1,81 @@
+"""LightGCN with the reference's surface (Model/LightGCN.py:49-162), compute on HIP kernels.
+
+Same constructor, `forward()`, `bpr_loss()`, `regularization_loss()`, `loss()` and
+`gene_ranklist()`; same parameters (`user_embedding.weight`, `item_embedding.weight`), same
+initialisation calls in the same order (so the same torch seed gives the same weights).
+What changed underneath:
+  * the graph is normalised ONCE into a CSR in HBM instead of degree()+gathers every forward
+    (reference: Model/LightGCN.py:36-38 inside every conv call);
+  * the L propagate layers and the layer mean are L fused SpMM launches (ops.layer_mean_propagate);
+  * BPR + L2 is one fused kernel pair; gene_ranklist never materialises the [U, I] matrix.
+"""
+import torch
+import torch.nn as nn
+
+from .. import graph, ops
+
+
+class LightGCN(nn.Module):
+    def __init__(self, num_user, num_item, edge_index, user_item_dict, dim_E, reg_weight, n_layers, aggr_mode,
+                 device):
+        super(LightGCN, self).__init__()
+        self.result = None
+        self.device = device
+        self.num_user = num_user
+        self.num_item = num_item
+        self.aggr_mode = aggr_mode
+        self.user_item_dict = user_item_dict
+        self.reg_weight = reg_weight
+        self.dim_embedding = dim_E
+        self.n_layers = n_layers
+        # reference keeps the raw bidirectional edge list (Model/LightGCN.py:63-64); kept for callers
+        # that read it, the kernels use the CSR below
+        self.edge_index = graph.bidirectional_edge_index(edge_index)
+        self.graph = graph.lightgcn_csr(edge_index, num_user + num_item).to(device)
+        rowptr, col = graph.user_hist_csr(user_item_dict, num_user)
+        self.hist = (rowptr.to(device), col.to(device))
+
+        self.user_embedding = nn.Embedding(num_user, dim_E)
+        self.item_embedding = nn.Embedding(num_item, dim_E)
+        nn.init.xavier_uniform_(self.user_embedding.weight)
+        nn.init.xavier_uniform_(self.item_embedding.weight)
+
+    def forward(self):
+        """Model/LightGCN.py:76-95; side effect: self.result (read later by gene_ranklist)."""
+        x = torch.cat((self.user_embedding.weight, self.item_embedding.weight), dim=0)
+        self.result = ops.layer_mean_propagate(x, self.graph, self.n_layers)
+        return self.result
+
+    def _fused(self, users, pos_items, neg_items, embeddings):
+        return ops.bpr_loss(embeddings, None, users, pos_items, neg_items, ops.VARIANT_LOG_SIGMOID_EPS,
+                            self.reg_weight, item_offset=self.num_user)
+
+    def bpr_loss(self, users, pos_items, neg_items, embeddings):
+        """Model/LightGCN.py:97-110 (items are LOCAL ids here, as in the reference)."""
+        return ops.bpr_loss(embeddings, None, users, pos_items, neg_items, ops.VARIANT_LOG_SIGMOID_EPS, 0.0,
+                            item_offset=self.num_user)[0]
+
+    def regularization_loss(self, users, pos_items, neg_items, embeddings):
+        """Model/LightGCN.py:112-121."""
+        return self._fused(users, pos_items, neg_items, embeddings)[2]
+
+    def loss(self, users, pos_items, neg_items):
+        """Model/LightGCN.py:123-135: global item ids in, full-graph forward, BPR + L2 out."""
+        pos_items = pos_items - self.num_user
+        neg_items = neg_items - self.num_user
+        users, pos_items, neg_items = users.to(self.device), pos_items.to(self.device), neg_items.to(self.device)
+        embeddings = self.forward()
+        return self._fused(users, pos_items, neg_items, embeddings)[0]
+
+    def gene_ranklist(self, topk=50):
+        """Model/LightGCN.py:137-162 -> LongTensor [U, topk] of GLOBAL item ids on the CPU.
+        Uses the stale self.result of the last training forward, as the reference does."""
+        with torch.no_grad():
+            result = self.result.detach()
+            user_tensor = result[:self.num_user]
+            item_tensor = result[self.num_user:self.num_user + self.num_item]
+            idx, _ = ops.score_topk(user_tensor, item_tensor, self.hist, 1e-6, topk, id_offset=self.num_user)
+        return idx.cpu()
+
+    # north_star names full_sort_predict(); the reference method is gene_ranklist
+    full_sort_predict = gene_ranklist

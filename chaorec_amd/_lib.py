@@ -1,0 +1,87 @@
+"""ctypes binding of libchaorec_hip.so (include/chaorec_hip.h).
+
+The HIP library IS the product's compute path: there is no CPU or eager-PyTorch fallback.
+`load()` raises if the shared object is missing, and every op in chaorec_amd.ops raises on
+non-CUDA tensors.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libchaorec_hip.so")
+SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off"]
+
+_lib = None
+
+c_i64p = ctypes.c_void_p
+c_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/chaorec_hip.h one to one
+SIGNATURES = {
+    "chaorec_abi_version": (ctypes.c_int, []),
+    "chaorec_last_error": (ctypes.c_char_p, []),
+    "chaorec_spmm_csr_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr, c_ptr,
+                                            ctypes.c_float, c_ptr, ctypes.c_int32, c_ptr]),
+    "chaorec_spmm_rows_per_wave": (ctypes.c_int, [ctypes.c_int32]),
+    "chaorec_bpr_fwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "chaorec_bpr_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
+                                           c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "chaorec_sample_negatives": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, c_ptr, c_ptr]),
+    "chaorec_score_topk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32]),
+    "chaorec_score_topk_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                              c_ptr, c_ptr, ctypes.c_float, ctypes.c_int32, ctypes.c_int64,
+                                              c_ptr, c_ptr, c_ptr, ctypes.c_size_t, ctypes.c_int32, c_ptr]),
+    "chaorec_gemm_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_ptr]),
+    "chaorec_adam_step_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_float,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                             ctypes.c_int32, c_ptr]),
+}
+
+
+def build(force=False, verbose=False):
+    """Cross-compile the HIP kernels for gfx950 into csrc/libchaorec_hip.so (no GPU needed)."""
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(_CSRC, "common.h"),
+                   os.path.join(os.path.dirname(_CSRC), "..", "include", "chaorec_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or chaorec_amd._lib.build()).  chaorec_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    if lib.chaorec_abi_version() != 1:
+        raise RuntimeError("libchaorec_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().chaorec_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -315,10 +315,12 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
 #define CHAOREC_ST_ARGS user_emb, item_emb, n_users, n_items, hist_rowptr, hist_col, mask_value, K, \
                         id_offset, out_idx, out_val, partial, splits, per
   switch (D) {
+    case 8: hipLaunchKernelGGL(score_topk_f32_kernel<8>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
+    case 16: hipLaunchKernelGGL(score_topk_f32_kernel<16>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
     case 32: hipLaunchKernelGGL(score_topk_f32_kernel<32>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
     case 64: hipLaunchKernelGGL(score_topk_f32_kernel<64>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
     case 128: hipLaunchKernelGGL(score_topk_f32_kernel<128>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
-    default: return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {32,64,128}", D);
+    default: return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {8,16,32,64,128}", D);
   }
 #undef CHAOREC_ST_ARGS
   int rc = check_launch("score_topk_f32_kernel");

@@ -16,19 +16,30 @@
 
 namespace chaorec {
 
+__device__ __forceinline__ float4 shfl4(float4 v, int src) {
+  return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
+}
+
 template <int LPR, int CPL>
 __global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, float *__restrict__ y,
     int64_t n_rows, int D4, float alpha, const float *__restrict__ z, float beta,
-    float *acc, const float *__restrict__ acc_init, float acc_w) {
-  constexpr int RPW = kWave / LPR;  // destination rows per wave
-  constexpr int UNR = 4;            // gathered rows in flight per group
+    float *acc, const float *__restrict__ acc_init, float acc_w,
+    const int32_t *__restrict__ group_order, int64_t n_groups) {
+  constexpr int NG = kWave / LPR;   // lane groups = destination rows per wave
+  constexpr int UNR = 8;            // gathered rows in flight per group (short-row phase)
+  constexpr int UNR2 = (kWave / NG) < 16 ? (kWave / NG) : 16;  // per group in the long-row phase
+  constexpr int LONG_T = 4 * UNR;   // rows above this are walked by the whole wave
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR;
   const int li = lane % LPR;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t r = wave * RPW + sub;
+  const int64_t wslot = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wslot >= n_groups) return;  // wave-uniform
+  // longest-first schedule: the host sorts the NG-row groups by their heaviest row so the long
+  // rows start at t=0 instead of stretching the tail (the output location is unchanged)
+  const int64_t wave = group_order ? (int64_t)group_order[wslot] : wslot;
+  const int64_t r = wave * NG + sub;
   const bool row_ok = r < n_rows;
 
   int64_t e0 = 0, e1 = 0;
@@ -37,7 +48,9 @@ __global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
     e1 = rowptr[r + 1];
   }
   const int deg = (int)(e1 - e0);
-  const int dmax = wave_max_i32(deg);  // wave-uniform trip counts keep every shuffle fully active
+  const bool is_long = (NG > 1) && deg > LONG_T;
+  const int deg1 = is_long ? 0 : deg;
+  const int dmax = wave_max_i32(deg1);  // wave-uniform trip counts keep every shuffle fully active
 
   float4 sum[CPL];
 #pragma unroll
@@ -45,16 +58,16 @@ __global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
 
   const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
 
+  // ---- phase 1: every group walks its own (short) row, UNR source rows in flight -----------
   for (int base = 0; base < dmax; base += LPR) {
-    // one coalesced (col,val) load per group, broadcast below
     int c = 0;
     float v = 0.f;
-    if (base + li < deg) {
+    if (base + li < deg1) {  // one coalesced (col,val) load per group, broadcast below
       c = col[e0 + base + li];
       v = val[e0 + base + li];
     }
-    const int n = min(LPR, deg - base);          // this group's entries in the block (may be <= 0)
-    const int nmax = min(LPR, dmax - base);      // wave-uniform
+    const int n = min(LPR, deg1 - base);
+    const int nmax = min(LPR, dmax - base);
     for (int j = 0; j < nmax; j += UNR) {
       int cj[UNR];
       float vj[UNR];
@@ -86,6 +99,144 @@ __global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
     }
   }
 
+  // ---- phase 2: long rows, one at a time, gathered by ALL groups ---------------------------
+  // The sum stays the sequential CSR-order sum: the groups only share the LOADS.  A long row's
+  // time is set by how many source rows one wave keeps in flight, so for D = 64 / 128 the walk is
+  // software-pipelined: two register buffers of HALF = 8*NG source rows ping-pong (one in flight
+  // while the other is reduced), (col,val) blocks of 64 entries are fetched a block ahead, and
+  // the ordered reduction goes through an 8 KiB LDS tile (every lane reads entry e of its own
+  // float4 column, a broadcast read) instead of NG x 4 lane shuffles per entry.
+  if constexpr (NG == 2 || NG == 4) {
+    constexpr int UH = 8;
+    constexpr int HALF = NG * UH;     // entries per half-step
+    constexpr int HPB = 64 / HALF;    // half-steps per 64-entry (col,val) block
+    __shared__ float4 red_all[4][HALF * LPR];
+    float4 *red = red_all[threadIdx.x >> 6];
+    unsigned long long lm = __ballot(is_long && li == 0);
+    while (lm) {
+      const int gl = (int)(__builtin_ctzll(lm) / LPR);
+      lm &= lm - 1;
+      const int owner = gl * LPR;
+      const int n = __shfl(deg, owner, 64);
+      const int64_t le0 = ((int64_t)__shfl((int)(e0 >> 32), owner, 64) << 32) |
+                          (int64_t)(unsigned int)__shfl((int)(e0 & 0xffffffffll), owner, 64);
+      const int nh = (n + HALF - 1) / HALF;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      int bcur = 0;
+      int c0 = 0, c1 = 0;
+      float v0 = 0.f, v1 = 0.f;
+      if (lane < n) {
+        c0 = col[le0 + lane];
+        v0 = val[le0 + lane];
+      }
+      if (64 + lane < n) {
+        c1 = col[le0 + 64 + lane];
+        v1 = val[le0 + 64 + lane];
+      }
+      float4 xa[UH], xb[UH];
+      float va[UH], vb[UH];
+      auto gather = [&](int h, float4(&xv)[UH], float(&vv)[UH]) {
+        const int blk = h / HPB;
+        const int off = (h % HPB) * HALF;
+        const int cs = (blk == bcur) ? c0 : c1;
+        const float vs = (blk == bcur) ? v0 : v1;
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+          const int idx = off + u * NG + sub;
+          const int cj = __shfl(cs, idx, 64);
+          vv[u] = __shfl(vs, idx, 64);
+          xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (h * HALF + u * NG + sub < n && li < D4) xv[u] = x4[(size_t)cj * (size_t)D4 + li];
+        }
+      };
+      auto reduce = [&](int h, float4(&xv)[UH], float(&vv)[UH]) {
+#pragma unroll
+        for (int u = 0; u < UH; ++u) red[(u * NG + sub) * LPR + li] = mul_rn4(vv[u], xv[u]);
+        __builtin_amdgcn_wave_barrier();
+        const int cntv = min(HALF, n - h * HALF);
+#pragma unroll 8
+        for (int e = 0; e < cntv; ++e) a = add_rn4(a, red[e * LPR + li]);
+        __builtin_amdgcn_wave_barrier();
+      };
+      gather(0, xa, va);
+      if (1 < nh) gather(1, xb, vb);
+      for (int h = 0; h < nh; h += 2) {
+        reduce(h, xa, va);
+        if (h + 2 < nh) gather(h + 2, xa, va);
+        if (h + 1 < nh) reduce(h + 1, xb, vb);
+        if (h + 3 < nh) gather(h + 3, xb, vb);
+        if ((h + 2) / HPB > bcur) {  // every half of block bcur has been gathered: rotate
+          ++bcur;
+          c0 = c1;
+          v0 = v1;
+          c1 = 0;
+          v1 = 0.f;
+          const int nb = (bcur + 1) * 64 + lane;
+          if (nb < n) {
+            c1 = col[le0 + nb];
+            v1 = val[le0 + nb];
+          }
+        }
+      }
+      if (sub == gl) sum[0] = a;
+    }
+  } else if constexpr (NG > 1) {
+    unsigned long long lm = __ballot(is_long && li == 0);
+    while (lm) {
+      const int gl = (int)(__builtin_ctzll(lm) / LPR);
+      lm &= lm - 1;
+      const int owner = gl * LPR;
+      const int n = __shfl(deg, owner, 64);
+      const int64_t le0 = ((int64_t)__shfl((int)(e0 >> 32), owner, 64) << 32) |
+                          (int64_t)(unsigned int)__shfl((int)(e0 & 0xffffffffll), owner, 64);
+      float4 a[CPL];
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int base = 0; base < n; base += NG * UNR2) {
+        int c = 0;
+        float v = 0.f;
+        if (lane < NG * UNR2 && base + lane < n) {
+          c = col[le0 + base + lane];
+          v = val[le0 + base + lane];
+        }
+        float vv[UNR2];
+        float4 xv[UNR2][CPL];
+#pragma unroll
+        for (int u = 0; u < UNR2; ++u) {
+          const int idx = u * NG + sub;
+          const int cj = __shfl(c, idx, 64);
+          vv[u] = __shfl(v, idx, 64);
+          const bool p = base + idx < n;
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const int chunk = li + q * LPR;
+            xv[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p && chunk < D4) xv[u][q] = x4[(size_t)cj * (size_t)D4 + chunk];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR2; ++u) {
+          float4 t[CPL];
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) t[q] = mul_rn4(vv[u], xv[u][q]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const bool p = base + u * NG + g < n;  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const float4 tg = shfl4(t[q], g * LPR + li);
+              if (p) a[q] = add_rn4(a[q], tg);
+            }
+          }
+        }
+      }
+      if (sub == gl) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) sum[q] = a[q];
+      }
+    }
+  }
+
   if (!row_ok) return;
   const float4 *z4 = reinterpret_cast<const float4 *>(z);
   const float4 *init4 = reinterpret_cast<const float4 *>(acc_init);
@@ -109,13 +260,15 @@ __global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
 template <int LPR, int CPL>
 static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                        float *y, int64_t n_rows, int D4, float alpha, const float *z, float beta,
-                       float *acc, const float *acc_init, float acc_w, hipStream_t st) {
+                       float *acc, const float *acc_init, float acc_w, const int32_t *group_order,
+                       hipStream_t st) {
   constexpr int RPW = kWave / LPR;
   const int64_t waves = (n_rows + RPW - 1) / RPW;
   const int64_t blocks = (waves + 3) / 4;
   if (blocks > 0x7fffffffLL) return fail(CHAOREC_E_INVALID, "spmm: grid too large");
   hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL>), dim3((unsigned)blocks), dim3(256), 0, st,
-                     rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w);
+                     rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, group_order,
+                     waves);
   return check_launch("spmm_csr_ordered_kernel");
 }
 
@@ -126,7 +279,8 @@ using namespace chaorec;
 extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                                     const float *x, float *y, int64_t n_rows, int64_t n_cols,
                                     int32_t D, float alpha, const float *z, float beta, float *acc,
-                                    const float *acc_init, float acc_w, int32_t mode, void *stream) {
+                                    const float *acc_init, float acc_w, const int32_t *group_order,
+                                    int32_t mode, void *stream) {
   if (!rowptr || !x || (!y && !acc)) return fail(CHAOREC_E_INVALID, "spmm: NULL rowptr/x or no output");
   if (n_rows < 0 || n_cols < 0) return fail(CHAOREC_E_INVALID, "spmm: negative size");
   if (D < 4 || D > 1024 || (D & 3)) return fail(CHAOREC_E_INVALID, "spmm: D=%d must be a multiple of 4 in [4,1024]", D);
@@ -135,7 +289,7 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
   if (n_rows == 0) return CHAOREC_OK;
   hipStream_t st = (hipStream_t)stream;
   const int D4 = D / 4;
-#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, st
+#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, group_order, st
   if (D4 <= 1) return launch_spmm<1, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 2) return launch_spmm<2, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 4) return launch_spmm<4, 1>(CHAOREC_SPMM_ARGS);
@@ -147,4 +301,11 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
   if (D4 <= 192) return launch_spmm<64, 3>(CHAOREC_SPMM_ARGS);
   return launch_spmm<64, 4>(CHAOREC_SPMM_ARGS);
 #undef CHAOREC_SPMM_ARGS
+}
+
+extern "C" int chaorec_spmm_rows_per_wave(int32_t D) {
+  if (D < 4 || (D & 3)) return 0;
+  int lpr = 1;
+  while (lpr < D / 4 && lpr < 64) lpr <<= 1;
+  return 64 / lpr;
 }

@@ -1,0 +1,146 @@
+"""Host-side graph setup: edge lists -> destination-major CSR resident in HBM.
+
+Done once per model (or once per epoch for FREEDOM's pruned graph); the per-batch work is all
+in the HIP kernels.  The normalisation values are computed with the same torch CPU ops the
+reference uses, so they are bit-identical to the reference's (torch's pow(-0.5) etc.).
+
+HBM layout of a graph: rowptr int64 [n_rows+1], col int32 [nnz], val fp32 [nnz]; row = the
+DESTINATION node, entries in the reference's edge order (stable sort by destination), which is
+what makes the ordered SpMM reproduce scatter_add_'s accumulation order.
+"""
+import numpy as np
+import torch
+
+
+class CSR:
+    """Destination-major CSR (+ optional transpose for the backward pass)."""
+
+    def __init__(self, rowptr, col, val, n_rows, n_cols, symmetric=False, transpose=None):
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.symmetric = bool(symmetric)
+        self._t = transpose
+        self._orders = {}
+
+    @property
+    def nnz(self):
+        return int(self.col.numel())
+
+    def to(self, device):
+        t = self._t.to(device) if self._t is not None else None
+        return CSR(self.rowptr.to(device), self.col.to(device), self.val.to(device), self.n_rows,
+                   self.n_cols, self.symmetric, t)
+
+    def group_order(self, rows_per_wave):
+        """Longest-first schedule for the SpMM kernel: permutation (int32, on the graph's device) of the
+        groups of `rows_per_wave` consecutive rows, sorted by their heaviest row, descending."""
+        g = int(rows_per_wave)
+        if g <= 0:
+            return None
+        if g not in self._orders:
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).cpu()
+            n_groups = (self.n_rows + g - 1) // g
+            pad = n_groups * g - self.n_rows
+            if pad:
+                deg = torch.cat([deg, torch.zeros(pad, dtype=deg.dtype)])
+            heavy = deg.view(n_groups, g).max(dim=1).values
+            order = torch.argsort(heavy, descending=True, stable=True).to(torch.int32)
+            self._orders[g] = order.to(self.rowptr.device)
+        return self._orders[g]
+
+    def t(self):
+        """CSR of A^T (the backward operator).  A symmetric graph is its own transpose."""
+        if self.symmetric:
+            return self
+        if self._t is None:
+            self._t = transpose_csr(self)
+            self._t._t = self
+        return self._t
+
+
+def coo_to_csr(dst, src, val, n_rows, n_cols, symmetric=False):
+    """Stable counting sort by destination: per-row entry order == edge-list order."""
+    dst = torch.as_tensor(dst, dtype=torch.int64).cpu()
+    src = torch.as_tensor(src, dtype=torch.int64).cpu()
+    val = torch.as_tensor(val, dtype=torch.float32).cpu()
+    order = torch.argsort(dst, stable=True)
+    counts = torch.bincount(dst, minlength=n_rows)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    return CSR(rowptr, src[order].to(torch.int32).contiguous(), val[order].contiguous(), n_rows, n_cols,
+               symmetric)
+
+
+def transpose_csr(csr):
+    rowptr = csr.rowptr.cpu()
+    rows = torch.repeat_interleave(torch.arange(csr.n_rows, dtype=torch.int64), rowptr[1:] - rowptr[:-1])
+    out = coo_to_csr(csr.col.cpu().to(torch.int64), rows, csr.val.cpu(), csr.n_cols, csr.n_rows)
+    return out.to(csr.col.device)
+
+
+def bidirectional_edge_index(edge_index):
+    """Model/LightGCN.py:63-64: [E,2] int32 ndarray -> LongTensor [2, 2E] = cat(E^T, E^T[[1,0]])."""
+    e = torch.as_tensor(np.asarray(edge_index)).t().contiguous()
+    return torch.cat((e, e[[1, 0]]), dim=1).long()
+
+
+def lightgcn_csr(edge_index, n_nodes):
+    """LightGCNConv.forward (Model/LightGCN.py:28-40): deg = degree(row); norm = d^-1/2[row] d^-1/2[col];
+    out[col] += norm * x[row].  No self loops.  Symmetric by construction."""
+    ei = bidirectional_edge_index(edge_index)
+    row, col = ei[0], ei[1]
+    deg = torch.zeros(n_nodes, dtype=torch.float32).scatter_add_(0, row, torch.ones(row.numel()))
+    dis = deg.pow(-0.5)
+    norm = dis[row] * dis[col]
+    return coo_to_csr(col, row, norm, n_nodes, n_nodes, symmetric=True)
+
+
+def basicgcn_csr(edge_index, n_nodes):
+    """BasicGCN.forward (BasicGCN.py:33-48): add_self_loops appended AFTER the edges, degree counted on
+    the looped list, same symmetric normalisation."""
+    ei = bidirectional_edge_index(edge_index)
+    loop = torch.arange(n_nodes, dtype=torch.int64)
+    row = torch.cat([ei[0], loop])
+    col = torch.cat([ei[1], loop])
+    deg = torch.zeros(n_nodes, dtype=torch.float32).scatter_add_(0, row, torch.ones(row.numel()))
+    dis = deg.pow(-0.5)
+    norm = dis[row] * dis[col]
+    return coo_to_csr(col, row, norm, n_nodes, n_nodes, symmetric=True)
+
+
+def user_hist_csr(user_item_dict, num_user):
+    """user_item_dict {user: [global item ids]} -> (rowptr int64 [U+1], col int32 ascending LOCAL ids).
+
+    This is the mask of gene_ranklist (Model/LightGCN.py:150-152) and the rejection set of the
+    sampler (dataload.py:76-79)."""
+    counts = np.zeros(num_user, dtype=np.int64)
+    for u, items in user_item_dict.items():
+        counts[int(u)] = len(set(int(i) for i in items))
+    rowptr = np.zeros(num_user + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    col = np.empty(int(rowptr[-1]), dtype=np.int32)
+    for u, items in user_item_dict.items():
+        u = int(u)
+        loc = np.unique(np.asarray([int(i) for i in items], dtype=np.int64)) - num_user
+        col[rowptr[u]:rowptr[u + 1]] = loc
+    return torch.from_numpy(rowptr), torch.from_numpy(col)
+
+
+def user_hist_csr_from_edges(edge_index, num_user):
+    """Vectorised form for large graphs (config 5): edges [E,2] with global item ids."""
+    e = np.asarray(edge_index, dtype=np.int64)
+    u, i = e[:, 0], e[:, 1] - num_user
+    key = np.unique(u * (1 << 32) + i)
+    u, i = key >> 32, key & 0xFFFFFFFF
+    rowptr = np.zeros(num_user + 1, dtype=np.int64)
+    np.cumsum(np.bincount(u, minlength=num_user), out=rowptr[1:])
+    return torch.from_numpy(rowptr), torch.from_numpy(i.astype(np.int32))
+
+
+def user_item_dict_from_edges(edge_index):
+    """the missing user_item_dict.npy blobs are the train edges grouped by user in
+    file order (verified against the shipped dicts by tests/golden/gen_golden.py)."""
+    d = {}
+    for u, i in np.asarray(edge_index).tolist():
+        d.setdefault(u, []).append(i)
+    return d

@@ -1,0 +1,252 @@
+"""torch-facing wrappers over the C-ABI kernels (include/chaorec_hip.h).
+
+PyTorch here is plumbing: it owns HBM allocations, the current HIP stream and autograd's tape.
+Every op takes CUDA (ROCm) tensors, passes raw device pointers + the current stream to
+libchaorec_hip.so and returns immediately.  There is no CPU implementation: a CPU tensor or a
+missing library raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .graph import CSR
+
+VARIANT_LOG_SIGMOID_EPS = 0   # LightGCN  (Model/LightGCN.py:108)
+VARIANT_LOGSIGMOID = 1        # FREEDOM   (Model/FREEDOM.py:189)
+VARIANT_LOG_SIGMOID = 2       # MMGCN     (Model/MMGCN.py:196)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("chaorec_amd ops run on the MI355X only (got a CPU tensor); there is no CPU fallback")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# SpMM
+# --------------------------------------------------------------------------------------------
+def spmm_raw(csr, x, y=None, alpha=1.0, z=None, beta=0.0, acc=None, acc_init=None, acc_w=0.0, want_y=True):
+    """y = alpha * (A x) [+ beta z]; optional acc epilogue (see chaorec_spmm_csr_f32)."""
+    _need_cuda(csr.rowptr, x, z, acc, acc_init)
+    x = _f32c(x)
+    D = x.shape[1]
+    if x.shape[0] != csr.n_cols:
+        raise ValueError(f"spmm: x has {x.shape[0]} rows, graph has {csr.n_cols} columns")
+    if want_y and y is None:
+        y = torch.empty((csr.n_rows, D), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    order = csr.group_order(lib.chaorec_spmm_rows_per_wave(D))
+    rc = lib.chaorec_spmm_csr_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x),
+                                  _ptr(y if want_y else None), csr.n_rows, csr.n_cols, D, alpha,
+                                  _ptr(z), beta, _ptr(acc), _ptr(acc_init), acc_w, _ptr(order), 0, _stream())
+    _lib.check(rc, "chaorec_spmm_csr_f32")
+    return y
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, csr):
+        ctx.csr = csr
+        return spmm_raw(csr, x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return spmm_raw(ctx.csr.t(), gy.contiguous()), None
+
+
+def spmm(csr, x):
+    """Differentiable y = A x (replaces propagate / torch.sparse.mm)."""
+    return _SpMM.apply(x, csr)
+
+
+class _LayerMeanPropagate(torch.autograd.Function):
+    """LightGCN.forward (Model/LightGCN.py:76-95) as L fused launches:
+    x_{l+1} = A x_l, final = sum_l w x_l with w = 1/(L+1), the mean folded into each SpMM's
+    epilogue.  Backward: g_L = w G; g_l = A^T g_{l+1} + w G."""
+
+    @staticmethod
+    def forward(ctx, x0, csr, n_layers):
+        x0 = _f32c(x0)
+        w = 1.0 / (n_layers + 1)
+        final = torch.empty_like(x0)
+        if n_layers == 0:
+            final.copy_(x0)
+        x = x0
+        for l in range(n_layers):
+            y = torch.empty_like(x0)
+            spmm_raw(csr, x, y=y, acc=final, acc_init=x0 if l == 0 else None, acc_w=w)
+            x = y
+        ctx.csr, ctx.n_layers, ctx.w = csr, n_layers, w
+        return final
+
+    @staticmethod
+    def backward(ctx, G):
+        G = _f32c(G)
+        L, w, At = ctx.n_layers, ctx.w, ctx.csr.t()
+        if L == 0:
+            return G, None, None
+        # g_{L-1} = w * (A^T G) + w * G, then g_l = A^T g_{l+1} + w * G
+        g = spmm_raw(At, G, alpha=w, z=G, beta=w)
+        for _ in range(L - 1):
+            g = spmm_raw(At, g, z=G, beta=w)
+        return g, None, None
+
+
+def layer_mean_propagate(x0, csr, n_layers):
+    return _LayerMeanPropagate.apply(x0, csr, n_layers)
+
+
+# --------------------------------------------------------------------------------------------
+# BPR
+# --------------------------------------------------------------------------------------------
+class _BPR(torch.autograd.Function):
+    """out = [total, bpr, reg]; tab_i=None means "items live in tab_u from row item_offset on"
+    (LightGCN/MMGCN keep users and items in one [N,D] table: one gradient buffer, no slicing)."""
+
+    @staticmethod
+    def forward(ctx, tab_u, tab_i, users, pos, neg, variant, reg_weight, item_offset):
+        _need_cuda(tab_u, tab_i, users, pos, neg)
+        tab_u = _f32c(tab_u)
+        D = tab_u.shape[1]
+        if tab_i is None:
+            pi = ctypes.c_void_p(tab_u.data_ptr() + item_offset * D * 4)
+        else:
+            tab_i = _f32c(tab_i)
+            pi = _ptr(tab_i)
+        users, pos, neg = (t.to(torch.int64).contiguous() for t in (users, pos, neg))
+        B = users.numel()
+        dev = tab_u.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        coef = torch.empty(B, dtype=torch.float32, device=dev)
+        ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
+        rc = _lib.load().chaorec_bpr_fwd_f32(_ptr(tab_u), pi, _ptr(users), _ptr(pos), _ptr(neg), B, D,
+                                             variant, reg_weight, _ptr(out), _ptr(coef), _ptr(ws), _stream())
+        _lib.check(rc, "chaorec_bpr_fwd_f32")
+        ctx.save_for_backward(tab_u, tab_i, users, pos, neg, coef)
+        ctx.reg_weight, ctx.item_offset = reg_weight, item_offset
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        tab_u, tab_i, users, pos, neg, coef = ctx.saved_tensors
+        B, D = users.numel(), tab_u.shape[1]
+        g_u = torch.zeros_like(tab_u)
+        if tab_i is None:
+            g_i = None
+            pi = ctypes.c_void_p(tab_u.data_ptr() + ctx.item_offset * D * 4)
+            pgi = ctypes.c_void_p(g_u.data_ptr() + ctx.item_offset * D * 4)
+        else:
+            g_i = torch.zeros_like(tab_i)
+            pi, pgi = _ptr(tab_i), _ptr(g_i)
+        go = g_out[0:1].contiguous()  # d/d(total); [bpr, reg] are reporting outputs only
+        rc = _lib.load().chaorec_bpr_bwd_f32(_ptr(tab_u), pi, _ptr(users), _ptr(pos), _ptr(neg), B, D,
+                                             _ptr(coef), ctx.reg_weight, _ptr(go), _ptr(g_u), pgi, _stream())
+        _lib.check(rc, "chaorec_bpr_bwd_f32")
+        return g_u, g_i, None, None, None, None, None, None
+
+
+def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset=0):
+    """Fused BPR(+L2) over a batch of LOCAL row ids -> tensor [total, bpr, reg]; differentiate [0]."""
+    return _BPR.apply(tab_u, tab_i, users, pos, neg, int(variant), float(reg_weight), int(item_offset))
+
+
+def sample_negatives(hist, users, num_item, seed, step, id_offset):
+    rowptr, col = hist
+    _need_cuda(rowptr, col, users)
+    users = users.to(torch.int64).contiguous()
+    out = torch.empty_like(users)
+    rc = _lib.load().chaorec_sample_negatives(_ptr(rowptr), _ptr(col), _ptr(users), users.numel(), num_item,
+                                              seed, step, id_offset, _ptr(out), _stream())
+    _lib.check(rc, "chaorec_sample_negatives")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# scoring + top-K
+# --------------------------------------------------------------------------------------------
+def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0):
+    """Top-K of user_emb @ item_emb.T with history masking, without the [U,I] matrix.
+    Returns (idx int64 [U,K] = item + id_offset, val fp32 [U,K])."""
+    _need_cuda(user_emb, item_emb)
+    user_emb, item_emb = _f32c(user_emb), _f32c(item_emb)
+    U, D = user_emb.shape
+    I = item_emb.shape[0]
+    dev = user_emb.device
+    idx = torch.empty((U, K), dtype=torch.int64, device=dev)
+    val = torch.empty((U, K), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.chaorec_score_topk_workspace_bytes(U, I, K)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
+    rowptr, col = hist if hist is not None else (None, None)
+    _need_cuda(rowptr, col)
+    rc = lib.chaorec_score_topk_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
+                                    mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
+                                    precision, _stream())
+    _lib.check(rc, "chaorec_score_topk_f32")
+    return idx, val
+
+
+# --------------------------------------------------------------------------------------------
+# dense layers
+# --------------------------------------------------------------------------------------------
+def gemm_raw(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False, act=0):
+    _need_cuda(A, B, bias, out)
+    A, B = _f32c(A), _f32c(B)
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    Kb, N = (B.shape[1], B.shape[0]) if transB else B.shape
+    if K != Kb:
+        raise ValueError(f"gemm: inner dims {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    rc = _lib.load().chaorec_gemm_f32(_ptr(A), _ptr(B), _ptr(out), _ptr(bias), M, N, K, A.shape[1], B.shape[1],
+                                      out.shape[1], int(transA), int(transB), int(accumulate), act, _stream())
+    _lib.check(rc, "chaorec_gemm_f32")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) (nn.Linear [+ F.leaky_relu]) on the f32 MFMA pipe."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        y = gemm_raw(x, weight, transB=True, bias=bias, act=act)
+        ctx.save_for_backward(x, weight, y if act else None)
+        ctx.has_bias, ctx.act = bias is not None, act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        if ctx.act:
+            gy = torch.where(y > 0, gy, gy * 0.01)
+        gx = gemm_raw(gy, weight) if ctx.needs_input_grad[0] else None
+        gw = gemm_raw(gy, x, transA=True) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None
+
+
+def linear(x, weight, bias=None, act=0):
+    return _Linear.apply(x, weight, bias, act)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+    rc = _lib.load().chaorec_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+                                           lr, betas[0], betas[1], eps, weight_decay, step, _stream())
+    _lib.check(rc, "chaorec_adam_step_f32")

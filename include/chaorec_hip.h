@@ -58,13 +58,20 @@ const char *chaorec_last_error(void);
  * transposed CSR:  g_l = A^T g_{l+1} + beta * G.
  *
  * D must be a multiple of 4, 4 <= D <= 1024.  rowptr is int64 (nnz of config 5 > 2^31).
+ * group_order (optional, may be NULL): a permutation of the row groups [0, ceil(n_rows/G)),
+ *   G = chaorec_spmm_rows_per_wave(D), giving the order in which wave slots pick up groups --
+ *   the host sorts groups longest-row-first so heavy rows do not stretch the tail.  It changes
+ *   scheduling only, never results.
  * mode: 0 = ordered (bit-reproducible, reference order).
  * ------------------------------------------------------------------------------------- */
 int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                          const float *x, float *y, int64_t n_rows, int64_t n_cols, int32_t D,
                          float alpha, const float *z, float beta,
                          float *acc, const float *acc_init, float acc_w,
-                         int32_t mode, void *stream);
+                         const int32_t *group_order, int32_t mode, void *stream);
+
+/* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
+int chaorec_spmm_rows_per_wave(int32_t D);
 
 /* ---------------------------------------------------------------------------------------
  * P4/P5/P9/P13: fused BPR step on a batch of (user, pos, neg) triples.
@@ -132,7 +139,7 @@ int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col
  * precision 0 ("f32"): v_mfma_f32_32x32x2_f32, i.e. a k-ordered fp32 fmaf chain
  *     acc = 0; for s in [0, D/2): acc = fmaf(u[s], i[s], acc); acc = fmaf(u[D/2+s], i[D/2+s], acc)
  *   bit-identical to oracle/chaorec_oracle.c:oracle_score_dot().
- * D in {32, 64, 128};  1 <= K <= 64;  n_items >= K.
+ * D in {8, 16, 32, 64, 128};  1 <= K <= 64;  n_items >= K.
  * hist_rowptr may be NULL (no mask).  hist_col ascending inside a row.
  * ------------------------------------------------------------------------------------- */
 size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K);

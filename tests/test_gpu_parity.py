@@ -1,0 +1,429 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the reference goldens.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+Bars: bit-exact for SpMM / scoring / GEMM / sampler / top-K indices (order-defined arithmetic);
+stated tolerances where libm or reduction order differs (BPR exp/log, atomics in the backward).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, tie_aware_rank_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from chaorec_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _rand_graph(U, I, deg_lo, deg_hi, seed, skew=False):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for u in range(U):
+        k = int(rng.integers(deg_lo, deg_hi + 1))
+        if skew and u % 97 == 0:
+            k = min(I, 40 * k)
+        for i in rng.choice(I, min(k, I), replace=False):
+            rows.append((u, int(i) + U))
+    return np.array(rows, dtype=np.int32)
+
+
+def graph_dict(edges):
+    from chaorec_amd import graph
+    return graph.user_item_dict_from_edges(edges)
+
+
+def _csr_to_dev(csr_np, n, dev, symmetric=True):
+    from chaorec_amd.graph import CSR
+    rowptr, col, val = csr_np
+    return CSR(torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
+               n, n, symmetric)
+
+
+# ------------------------------------------------------------------------------------------ SpMM
+@pytest.mark.parametrize("D", [4, 8, 32, 64, 128, 256, 384, 768])
+def test_spmm_bit_exact_random_graph(dev, oracle, D):
+    from chaorec_amd import ops
+    U, I = 301, 157
+    e = _rand_graph(U, I, 0, 9, seed=D, skew=True)  # empty rows, ragged rows, a few long rows
+    N = U + I
+    csr = oracle.lightgcn_csr(e, N)
+    x = np.random.default_rng(D + 1).standard_normal((N, D)).astype(np.float32)
+    want = oracle.spmm(csr, x)
+    got = ops.spmm_raw(_csr_to_dev(csr, N, dev), torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_spmm_epilogues_bit_exact(dev, oracle):
+    from chaorec_amd import ops
+    U, I, D = 200, 120, 64
+    e = _rand_graph(U, I, 1, 12, seed=3)
+    N = U + I
+    csr = oracle.lightgcn_csr(e, N)
+    g = _csr_to_dev(csr, N, dev)
+    rng = np.random.default_rng(0)
+    x, z, a0 = (rng.standard_normal((N, D)).astype(np.float32) for _ in range(3))
+    tx, tz = torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)
+    # alpha/beta epilogue
+    want = oracle.spmm(csr, x, alpha=0.25, z=z, beta=1.0 / 3.0)
+    got = ops.spmm_raw(g, tx, alpha=0.25, z=tz, beta=1.0 / 3.0).cpu().numpy()
+    assert np.array_equal(got, want)
+    # acc epilogue, first layer (acc_init) then running
+    acc_w = np.float32(1.0 / 3.0)
+    acc_np = np.zeros((N, D), np.float32)
+    y1 = oracle.spmm(csr, x, acc=acc_np, acc_init=x, acc_w=acc_w)
+    y2 = oracle.spmm(csr, y1, acc=acc_np, acc_w=acc_w)
+    acc_t = torch.empty((N, D), dtype=torch.float32, device=dev)
+    t1 = ops.spmm_raw(g, tx, acc=acc_t, acc_init=tx, acc_w=float(acc_w))
+    t2 = ops.spmm_raw(g, t1, acc=acc_t, acc_w=float(acc_w))
+    assert np.array_equal(t2.cpu().numpy(), y2)
+    assert np.array_equal(acc_t.cpu().numpy(), acc_np)
+    # acc only (y == NULL)
+    acc2 = acc_t.clone()
+    ops.spmm_raw(g, t2, acc=acc2, acc_w=0.5, want_y=False)
+    acc_np2 = acc_np.copy()
+    oracle.spmm(csr, y2, acc=acc_np2, acc_w=0.5, want_y=False)
+    assert np.array_equal(acc2.cpu().numpy(), acc_np2)
+
+
+def test_spmm_empty_and_errors(dev):
+    from chaorec_amd import ops
+    from chaorec_amd.graph import CSR
+    rowptr = torch.zeros(5, dtype=torch.int64, device=dev)
+    g = CSR(rowptr, torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, device=dev), 4, 4, True)
+    y = ops.spmm_raw(g, torch.ones(4, 8, device=dev))
+    assert torch.all(y == 0)
+    with pytest.raises(RuntimeError):
+        ops.spmm_raw(g, torch.ones(4, 6, device=dev))  # D % 4 != 0
+    with pytest.raises(RuntimeError):
+        ops.spmm_raw(g, torch.ones(4, 8))  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------ LightGCN
+def _make_lightgcn(g, U, I, edges, D, L, reg, x0, dev):
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd import graph
+    m = LightGCN(U, I, edges, graph.user_item_dict_from_edges(edges), D, reg, L, "add", dev)
+    with torch.no_grad():
+        m.user_embedding.weight.copy_(torch.from_numpy(x0[:U]))
+        m.item_embedding.weight.copy_(torch.from_numpy(x0[U:]))
+    return m.to(dev)
+
+
+def test_lightgcn_tiny_golden(dev):
+    g = load_golden("lightgcn_tiny.npz")
+    U, I, D, L = int(g["U"]), int(g["I"]), int(g["D"]), int(g["L"])
+    m = _make_lightgcn(g, U, I, g["edges"], D, L, float(g["reg"]), g["x0"], dev)
+    loss = m.loss(torch.from_numpy(g["users"]), torch.from_numpy(g["pos"]), torch.from_numpy(g["neg"]))
+    loss.backward()
+    assert np.array_equal(m.result.detach().cpu().numpy(), g["result"])  # forward: bit-exact vs reference
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=2e-6)
+    assert np.allclose(m.user_embedding.weight.grad.cpu().numpy(), g["g_user"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(m.item_embedding.weight.grad.cpu().numpy(), g["g_item"], rtol=1e-4, atol=1e-7)
+    with torch.no_grad():
+        emb = m.result
+        u, p, n = (torch.from_numpy(g[k]).to(dev) for k in ("users", "pos", "neg"))
+        assert float(m.bpr_loss(u, p - U, n - U, emb)) == pytest.approx(float(g["bpr"]), rel=2e-6)
+        assert float(m.regularization_loss(u, p - U, n - U, emb)) == pytest.approx(float(g["reg_loss"]), rel=1e-5)
+    rank = m.gene_ranklist(topk=int(g["topk"]))
+    assert rank.dtype == torch.int64 and rank.device.type == "cpu"
+    sc = g["result"][:U] @ g["result"][U:].T
+    for u, items in graph_dict(g["edges"]).items():
+        sc[u, np.asarray(items) - U] = 1e-6
+    got_val = np.take_along_axis(sc, rank.numpy() - U, 1)
+    ok, why = tie_aware_rank_equal(rank.numpy(), got_val, g["rank"], g["rank_val"], rtol=1e-5, atol=1e-7)
+    assert ok, why
+
+
+def test_lightgcn_baby_golden_and_metrics(dev, baby, oracle):
+    from chaorec_amd import utils
+    g = load_golden("lightgcn_baby.npz")
+    U, I, D, L = baby["U"], baby["I"], int(g["D"]), int(g["L"])
+    x0 = (np.random.default_rng(int(g["x0_seed"])).standard_normal((U + I, D)) * float(g["x0_scale"])).astype(np.float32)
+    m = _make_lightgcn(g, U, I, baby["train"], D, L, float(g["reg"]), x0, dev)
+    loss = m.loss(torch.from_numpy(g["users"]), torch.from_numpy(g["pos"]), torch.from_numpy(g["neg"]))
+    loss.backward()
+    rows = g["rows"]
+    res = m.result.detach().cpu().numpy()
+    assert np.array_equal(res[rows], g["result_rows"])
+    assert res.astype(np.float64).sum() == pytest.approx(float(g["result_sum"]), rel=1e-9)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=2e-6)
+    grad = np.concatenate([m.user_embedding.weight.grad.cpu().numpy(), m.item_embedding.weight.grad.cpu().numpy()], 0)
+    assert np.allclose(grad[rows], g["g_rows"], rtol=2e-4, atol=1e-9)
+    assert np.abs(grad).sum() == pytest.approx(float(g["g_abs_sum"]), rel=1e-4)
+    # ranking: HIP top-50 == oracle top-50 exactly (same dot-product order), and == reference up to near-ties
+    rank = m.gene_ranklist().numpy()
+    hist = oracle.user_hist_csr(baby["train"], U)
+    o_idx, o_val = oracle.gene_ranklist(res, U, I, hist, 1e-6, 50)
+    assert np.array_equal(rank, o_idx)
+    urows = g["urows"]
+    ok, why = tie_aware_rank_equal(rank[urows], o_val[urows], g["rank_rows"].astype(np.int64), g["rank_val_rows"],
+                                   rtol=2e-5, atol=1e-8)
+    assert ok, why
+    # Recall/NDCG within 1e-4 of the reference's numbers (north_star bar)
+    k_list = [int(k) for k in g["k_list"]]
+    names = list(g["metric_names"])
+    for split, key in ((baby["val"], "val_metrics"), (baby["test"], "test_metrics")):
+        mt = utils.gene_metrics(split, torch.from_numpy(rank), k_list)
+        got = np.array([[mt[k][n] for n in names] for k in k_list])
+        assert np.abs(got - g[key]).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ BPR / sampler
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("D", [64, 128, 16])
+def test_bpr_fwd_bwd_vs_oracle(dev, oracle, variant, D):
+    from chaorec_amd import ops
+    rng = np.random.default_rng(variant * 10 + D)
+    U, I, B = 97, 55, 300  # duplicates inside the batch are certain
+    tu = (rng.standard_normal((U, D)) * 0.3).astype(np.float32)
+    ti = (rng.standard_normal((I, D)) * 0.3).astype(np.float32)
+    users, pos, neg = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+    reg = 1e-3 if variant == 0 else 0.0
+    out, coef = oracle.bpr_fwd(tu, ti, users, pos, neg, variant, reg)
+    g_u, g_i = oracle.bpr_bwd(tu, ti, users, pos, neg, coef, reg, grad_out=0.7)
+    a = torch.from_numpy(tu).to(dev).requires_grad_(True)
+    b = torch.from_numpy(ti).to(dev).requires_grad_(True)
+    res = ops.bpr_loss(a, b, *(torch.from_numpy(t).to(dev) for t in (users, pos, neg)), variant, reg)
+    (res[0] * 0.7).backward()
+    assert np.allclose(res.detach().cpu().numpy(), out, rtol=3e-6, atol=1e-8)
+    assert np.allclose(a.grad.cpu().numpy(), g_u, rtol=2e-5, atol=1e-8)
+    assert np.allclose(b.grad.cpu().numpy(), g_i, rtol=2e-5, atol=1e-8)
+
+
+def test_bpr_single_table_offset(dev, oracle):
+    from chaorec_amd import ops
+    rng = np.random.default_rng(5)
+    U, I, B, D = 40, 30, 64, 64
+    tab = (rng.standard_normal((U + I, D)) * 0.3).astype(np.float32)
+    users, pos, neg = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+    out, coef = oracle.bpr_fwd(tab[:U], tab[U:], users, pos, neg, 0, 1e-3)
+    g_u, g_i = oracle.bpr_bwd(tab[:U], tab[U:], users, pos, neg, coef, 1e-3)
+    t = torch.from_numpy(tab).to(dev).requires_grad_(True)
+    res = ops.bpr_loss(t, None, *(torch.from_numpy(x).to(dev) for x in (users, pos, neg)), 0, 1e-3, item_offset=U)
+    res[0].backward()
+    assert np.allclose(res.detach().cpu().numpy(), out, rtol=3e-6)
+    assert np.allclose(t.grad.cpu().numpy(), np.concatenate([g_u, g_i]), rtol=2e-5, atol=1e-8)
+
+
+def test_bpr_loss_is_run_to_run_identical(dev):
+    from chaorec_amd import ops
+    rng = np.random.default_rng(1)
+    tab = torch.from_numpy((rng.standard_normal((500, 64)) * 0.3).astype(np.float32)).to(dev)
+    idx = [torch.from_numpy(rng.integers(0, 250, 1024)).to(dev) for _ in range(3)]
+    a = ops.bpr_loss(tab, None, *idx, 0, 1e-3, item_offset=250)
+    b = ops.bpr_loss(tab, None, *idx, 0, 1e-3, item_offset=250)
+    assert torch.equal(a, b)
+
+
+def test_sampler_bit_exact_and_never_in_history(dev, oracle, baby):
+    from chaorec_amd import ops
+    U, I = baby["U"], baby["I"]
+    hist = oracle.user_hist_csr(baby["train"], U)
+    users = baby["train"][:8192, 0].astype(np.int64)
+    want = oracle.sample_negatives(hist, users, I, seed=42, step=7, id_offset=U)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    got = ops.sample_negatives(dh, torch.from_numpy(users).to(dev), I, 42, 7, U).cpu().numpy()
+    assert np.array_equal(got, want)
+    for u, n in zip(users[:2000], got[:2000]):
+        row = hist[1][hist[0][u]:hist[0][u + 1]]
+        assert (n - U) not in row and U <= n < U + I
+    other = ops.sample_negatives(dh, torch.from_numpy(users).to(dev), I, 42, 8, U).cpu().numpy()
+    assert (other != got).mean() > 0.99  # a new step is a new draw
+
+
+def test_sampler_uniform_over_unseen(dev, oracle):
+    from chaorec_amd import ops
+    g = load_golden("sampler_tiny.npz")
+    U, I = int(g["U"]), int(g["I"])
+    hist = oracle.user_hist_csr(g["edges"], U)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    users = np.repeat(np.arange(U), 4000).astype(np.int64)
+    neg = ops.sample_negatives(dh, torch.from_numpy(users).to(dev), I, 1, 0, U).cpu().numpy() - U
+    mine = np.zeros((U, I), np.int64)
+    np.add.at(mine, (users, neg), 1)
+    assert np.array_equal(mine > 0, g["neg_hist"] > 0)  # same support as the reference's sampler
+    for u in range(U):
+        allowed = mine[u] > 0
+        exp = 4000 / allowed.sum()
+        assert ((mine[u][allowed] - exp) ** 2 / exp).sum() < 30
+
+
+# ------------------------------------------------------------------------------------------ scoring + top-K
+def _hist_random(U, I, max_deg, seed):
+    rng = np.random.default_rng(seed)
+    rowptr = np.zeros(U + 1, np.int64)
+    cols = []
+    for u in range(U):
+        k = int(rng.integers(0, max_deg + 1))
+        c = np.sort(rng.choice(I, min(k, I), replace=False)).astype(np.int32)
+        cols.append(c)
+        rowptr[u + 1] = rowptr[u] + len(c)
+    return rowptr, (np.concatenate(cols) if cols else np.zeros(0, np.int32)).astype(np.int32)
+
+
+@pytest.mark.parametrize("U,I,D,K", [(1, 64, 64, 50), (33, 50, 64, 50), (70, 1000, 64, 50), (257, 4794, 64, 50),
+                                     (40, 3000, 128, 10), (40, 2000, 32, 64), (5, 9000, 64, 1)])
+def test_score_topk_bit_exact_vs_oracle(dev, oracle, U, I, D, K):
+    from chaorec_amd import ops
+    rng = np.random.default_rng(U * 7 + I)
+    ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
+    hist = _hist_random(U, I, 20, seed=I)
+    want_i, want_v = oracle.score_topk(ue, ie, hist, 1e-6, K, id_offset=U)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    got_i, got_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), dh, 1e-6, K, id_offset=U)
+    assert np.array_equal(got_v.cpu().numpy(), want_v)   # same fmaf chain -> same bits
+    assert np.array_equal(got_i.cpu().numpy(), want_i)
+
+
+def test_score_topk_integer_ties_lowest_index_first(dev, oracle):
+    """Integer-valued embeddings: every score is exact in any summation order, ties are massive."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(0)
+    U, I, D, K = 64, 3000, 64, 50
+    ue = rng.integers(-2, 3, (U, D)).astype(np.float32)
+    ie = rng.integers(-1, 2, (I, D)).astype(np.float32)
+    hist = _hist_random(U, I, 30, seed=1)
+    want_i, want_v = oracle.score_topk(ue, ie, hist, 1e-6, K, 0)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    got_i, got_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), dh, 1e-6, K)
+    assert np.array_equal(got_v.cpu().numpy(), want_v)
+    assert np.array_equal(got_i.cpu().numpy(), want_i)
+    # and against a plain fp32 matmul + stable sort (what torch.matmul gives on exact integers)
+    sc = ue @ ie.T
+    for u in range(U):
+        sc[u, hist[1][hist[0][u]:hist[0][u + 1]]] = 1e-6
+    ref = np.argsort(-sc, axis=1, kind="stable")[:, :K]
+    assert np.array_equal(got_i.cpu().numpy(), ref)
+
+
+def test_score_topk_mask_quirk_and_no_hist(dev, oracle):
+    """Q7: the mask value 1e-6 outranks negative scores; hist=None is the kNN use."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(3)
+    U, I, D, K = 8, 200, 64, 50
+    ue = np.abs(rng.standard_normal((U, D))).astype(np.float32)
+    ie = -np.abs(rng.standard_normal((I, D))).astype(np.float32)  # all scores negative
+    hist = _hist_random(U, I, 10, seed=2)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    got_i, got_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), dh, 1e-6, K)
+    got_i, got_v = got_i.cpu().numpy(), got_v.cpu().numpy()
+    for u in range(U):
+        h = hist[1][hist[0][u]:hist[0][u + 1]]
+        assert np.array_equal(got_i[u, :len(h)], h)           # history first, ascending index
+        assert np.all(got_v[u, :len(h)] == np.float32(1e-6))
+    want_i, want_v = oracle.score_topk(ue, ie, None, 0.0, 10, 0)
+    gi, gv = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), None, 0.0, 10)
+    assert np.array_equal(gi.cpu().numpy(), want_i) and np.array_equal(gv.cpu().numpy(), want_v)
+
+
+def test_score_topk_errors(dev):
+    from chaorec_amd import ops
+    a = torch.zeros(4, 64, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.score_topk(a, torch.zeros(10, 64, device=dev), None, 0.0, 50)  # K > n_items, like torch.topk
+    with pytest.raises(RuntimeError):
+        ops.score_topk(torch.zeros(4, 48, device=dev), torch.zeros(100, 48, device=dev), None, 0.0, 10)
+
+
+# ------------------------------------------------------------------------------------------ GEMM / Adam
+@pytest.mark.parametrize("M,N,K", [(300, 64, 128), (1, 1, 1), (129, 65, 17), (515, 256, 320), (64, 64, 4096)])
+@pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False)])
+def test_gemm_bit_exact(dev, oracle, M, N, K, tA, tB):
+    from chaorec_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    want = oracle.gemm(A, B, bias=bias, transA=tA, transB=tB, act=1)
+    got = ops.gemm_raw(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), transA=tA, transB=tB,
+                       bias=torch.from_numpy(bias).to(dev), act=1)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_linear_autograd_vs_torch(dev):
+    from chaorec_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(333, 96, device=dev, requires_grad=True)
+    w = torch.randn(64, 96, device=dev, requires_grad=True)
+    b = torch.randn(64, device=dev, requires_grad=True)
+    y = ops.linear(x, w, b, act=1)
+    y.square().sum().backward()
+    gx, gw, gb = x.grad.clone(), w.grad.clone(), b.grad.clone()
+    x.grad = w.grad = b.grad = None
+    yr = torch.nn.functional.leaky_relu(torch.nn.functional.linear(x.double(), w.double(), b.double()))
+    yr.square().sum().backward()
+    assert torch.allclose(y.double(), yr, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(gx.double(), x.grad.double(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(gw.double(), w.grad.double(), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(gb.double(), b.grad.double(), rtol=1e-4, atol=1e-3)
+
+
+def test_adam_matches_oracle_and_torch(dev, oracle):
+    from chaorec_amd import ops
+    rng = np.random.default_rng(0)
+    n = 10007
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p_np, m_np, v_np = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    p_t = torch.from_numpy(p0.copy()).to(dev)
+    m_t, v_t = torch.zeros_like(p_t), torch.zeros_like(p_t)
+    p_ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([p_ref], lr=1e-3)
+    for step in range(1, 6):
+        g = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        oracle.adam_step(p_np, g, m_np, v_np, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
+        ops.adam_step(p_t, torch.from_numpy(g).to(dev), m_t, v_t, step)
+        p_ref.grad = torch.from_numpy(g.copy())
+        opt.step()
+    assert np.allclose(p_t.cpu().numpy(), p_np, rtol=0, atol=2e-7)
+    assert np.allclose(p_t.cpu().numpy(), p_ref.detach().numpy(), rtol=0, atol=5e-7)
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_sports_size_properties(dev):
+    """BASELINE configs[1] sizes (U=28940, I=15207, E=158554, D=64): size-independent checks."""
+    from chaorec_amd import ops, graph
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D = 28940, 15207, 158554, 64
+    edges = synthetic_interactions(U, I, E, seed=42)
+    N = U + I
+    A = graph.lightgcn_csr(edges, N).to(dev)
+    torch.manual_seed(0)
+    x = torch.randn(N, D, device=dev)
+    y = torch.randn(N, D, device=dev)
+    # determinism: same launch twice is bit-identical
+    a1, a2 = ops.spmm_raw(A, x), ops.spmm_raw(A, x)
+    assert torch.equal(a1, a2)
+    # linearity within rounding, symmetry <Ax, y> == <x, Ay>
+    lhs = ops.spmm_raw(A, x + y)
+    rhs = a1 + ops.spmm_raw(A, y)
+    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-5)
+    d1 = (a1.double() * y.double()).sum()
+    d2 = (x.double() * ops.spmm_raw(A, y).double()).sum()
+    assert abs(float(d1 - d2)) <= 1e-6 * abs(float(d1)) + 1e-6
+    # spectral bound: ||A x|| <= ||x|| for the symmetric-normalised adjacency
+    assert float(a1.norm()) <= float(x.norm()) * (1 + 1e-5)
+    # top-K: sorted descending, indices unique and in range, history never above an unmasked positive score
+    hist = tuple(t.to(dev) for t in graph.user_hist_csr_from_edges(edges, U))
+    emb = torch.randn(N, D, device=dev) * 0.1
+    idx, val = ops.score_topk(emb[:U], emb[U:], hist, 1e-6, 50, id_offset=U)
+    assert torch.all(val[:, :-1] >= val[:, 1:])
+    assert int(idx.min()) >= U and int(idx.max()) < N
+    srt = torch.sort(idx, dim=1).values
+    assert torch.all(srt[:, 1:] != srt[:, :-1])
+    # spot-check 64 users against a dense fp32 matmul + topk
+    sel = torch.arange(0, U, U // 64, device=dev)[:64]
+    sc = emb[:U][sel] @ emb[U:].T
+    rp, col = hist
+    for k, u in enumerate(sel.tolist()):
+        sc[k, col[rp[u]:rp[u + 1]].long()] = 1e-6
+    tv, ti = torch.topk(sc, 50)
+    assert torch.allclose(tv, val[sel], rtol=1e-5, atol=1e-7)
+    assert (ti + U == idx[sel]).float().mean() > 0.999
