@@ -20,17 +20,27 @@ __device__ __forceinline__ float4 shfl4(float4 v, int src) {
   return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
 }
 
+#ifndef CHAOREC_SPMM_UNR
+#define CHAOREC_SPMM_UNR 8
+#endif
+#ifndef CHAOREC_SPMM_LONG_T
+#define CHAOREC_SPMM_LONG_T (4 * CHAOREC_SPMM_UNR)
+#endif
+#ifndef CHAOREC_SPMM_MINW
+#define CHAOREC_SPMM_MINW 1
+#endif
+
 template <int LPR, int CPL>
-__global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
+__global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, float *__restrict__ y,
     int64_t n_rows, int D4, float alpha, const float *__restrict__ z, float beta,
     float *acc, const float *__restrict__ acc_init, float acc_w,
     const int32_t *__restrict__ group_order, int64_t n_groups) {
   constexpr int NG = kWave / LPR;   // lane groups = destination rows per wave
-  constexpr int UNR = 8;            // gathered rows in flight per group (short-row phase)
+  constexpr int UNR = CHAOREC_SPMM_UNR;  // gathered rows in flight per group (short-row phase)
   constexpr int UNR2 = (kWave / NG) < 16 ? (kWave / NG) : 16;  // per group in the long-row phase
-  constexpr int LONG_T = 4 * UNR;   // rows above this are walked by the whole wave
+  constexpr int LONG_T = CHAOREC_SPMM_LONG_T;  // rows above this are walked by the whole wave
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR;
   const int li = lane % LPR;
@@ -121,7 +131,13 @@ __global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
       const int64_t le0 = ((int64_t)__shfl((int)(e0 >> 32), owner, 64) << 32) |
                           (int64_t)(unsigned int)__shfl((int)(e0 & 0xffffffffll), owner, 64);
       const int nh = (n + HALF - 1) / HALF;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      // ordered sum, one (or two) FEATURES per lane: entry e of the LDS tile is D consecutive
+      // floats, lane l adds floats [l*FPL, l*FPL+FPL) -- one v_add per entry instead of four
+      constexpr int FPL = LPR * 4 / 64;
+      float a[FPL];
+#pragma unroll
+      for (int f = 0; f < FPL; ++f) a[f] = 0.f;
+      const float *redf = reinterpret_cast<const float *>(red);
       int bcur = 0;
       int c0 = 0, c1 = 0;
       float v0 = 0.f, v1 = 0.f;
@@ -155,7 +171,10 @@ __global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
         __builtin_amdgcn_wave_barrier();
         const int cntv = min(HALF, n - h * HALF);
 #pragma unroll 8
-        for (int e = 0; e < cntv; ++e) a = add_rn4(a, red[e * LPR + li]);
+        for (int e = 0; e < cntv; ++e) {
+#pragma unroll
+          for (int f = 0; f < FPL; ++f) a[f] = add_rn(a[f], redf[e * (LPR * 4) + lane * FPL + f]);
+        }
         __builtin_amdgcn_wave_barrier();
       };
       gather(0, xa, va);
@@ -178,7 +197,14 @@ __global__ __launch_bounds__(256) void spmm_csr_ordered_kernel(
           }
         }
       }
-      if (sub == gl) sum[0] = a;
+      // back to the float4-per-lane row layout of the owning group
+      float *redw = reinterpret_cast<float *>(red);
+#pragma unroll
+      for (int f = 0; f < FPL; ++f) redw[lane * FPL + f] = a[f];
+      __builtin_amdgcn_wave_barrier();
+      const float4 arow = red[li];
+      __builtin_amdgcn_wave_barrier();
+      if (sub == gl) sum[0] = arow;
     }
   } else if constexpr (NG > 1) {
     unsigned long long lm = __ballot(is_long && li == 0);
