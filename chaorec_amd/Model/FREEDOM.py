@@ -1,0 +1,200 @@
+"""FREEDOM with the reference's surface (Model/FREEDOM.py:16-244), compute on HIP kernels.
+
+Same constructor arguments, parameters (user/item embeddings, trainable image/text feature
+tables, image_trs / text_trs Linears), `pre_epoch_processing()`, `forward(adj)`, `bpr_loss`,
+`loss()` and `gene_ranklist()`.  Reference quirks kept on purpose:
+  Q5  main.py passes args.lambda_coeff in the mm_image_weight slot -- the constructor takes what it is given;
+  Q6  get_norm_adj_mat counts degrees on the already bidirectional list (doubled degrees);
+  Q4  gene_ranklist ranks the stale self.result of the last training forward (pruned graph).
+What changed underneath: every sparse product is the CSR SpMM kernel, the kNN graph is built by
+the scoring+top-K kernel (no [I, I] similarity matrix), the three BPR terms are the fused BPR
+kernel, the modality projections run on the f32 MFMA GEMM.
+"""
+import torch
+import torch.nn.functional as F  # noqa: F401  (kept: reference module namespace)
+from torch import nn
+
+from .. import graph, ops
+
+
+class FREEDOM(nn.Module):
+    def __init__(self, num_user, num_item, edge_index, user_item_dict, v_feat, t_feat, dim_E, dim_feat, reg_weight,
+                 dropout, n_layers, mm_layers, ii_topk, mm_image_weight, device):
+        super(FREEDOM, self).__init__()
+        self.result = None
+        self.num_user = num_user
+        self.num_item = num_item
+        self.n_nodes = self.num_user + self.num_item
+        self.user_item_dict = user_item_dict
+        self.dim_E = dim_E
+        self.dim_feat = dim_feat
+        self.reg_weight = reg_weight
+        self.n_layers = n_layers
+        self.mm_layers = mm_layers
+        self.mm_image_weight = mm_image_weight
+        self.dropout = dropout
+        self.knn_k = ii_topk
+        self.v_feat = v_feat
+        self.t_feat = t_feat
+        self.device = device
+
+        self.edge_index_clone = torch.as_tensor(edge_index).t().contiguous().long()          # [2, E] u -> i
+        self.edge_index = torch.cat((self.edge_index_clone, self.edge_index_clone[[1, 0]]), dim=1)
+
+        self.norm_adj = self.get_norm_adj_mat(self.edge_index).to(self.device)
+        self.masked_adj, self.mm_adj = None, None
+
+        self.edge_indices, self.edge_values = self.get_edge_info(self.edge_index_clone)
+        self.edge_indices, self.edge_values = self.edge_indices.to(self.device), self.edge_values.to(self.device)
+
+        self.user_embedding = nn.Embedding(self.num_user, self.dim_E)
+        self.item_embedding = nn.Embedding(self.num_item, self.dim_E)
+        nn.init.xavier_uniform_(self.user_embedding.weight)
+        nn.init.xavier_uniform_(self.item_embedding.weight)
+
+        self.image_embedding = nn.Embedding.from_pretrained(self.v_feat, freeze=False)
+        self.text_embedding = nn.Embedding.from_pretrained(self.t_feat, freeze=False)
+        self.image_trs = nn.Linear(self.v_feat.shape[1], self.dim_feat)
+        self.text_trs = nn.Linear(self.t_feat.shape[1], self.dim_feat)
+
+        rowptr, col = graph.user_hist_csr(user_item_dict, num_user)
+        self.hist = (rowptr.to(device), col.to(device))
+
+        image_adj = text_adj = None
+        if self.v_feat is not None:
+            image_adj = self.get_knn_adj_mat(self.image_embedding.weight.detach())
+            self.mm_adj = graph.coo_to_csr_coalesced(image_adj[0][0], image_adj[0][1], image_adj[1], num_item,
+                                                     num_item).to(self.device)
+        if self.t_feat is not None:
+            text_adj = self.get_knn_adj_mat(self.text_embedding.weight.detach())
+            self.mm_adj = graph.coo_to_csr_coalesced(text_adj[0][0], text_adj[0][1], text_adj[1], num_item,
+                                                     num_item).to(self.device)
+        if self.v_feat is not None and self.t_feat is not None:
+            # Model/FREEDOM.py:69: mm_adj = w * image_adj + (1 - w) * text_adj (sparse add = union of entries)
+            self.mm_adj = graph.add_scaled_coo(image_adj, self.mm_image_weight, text_adj, 1.0 - self.mm_image_weight,
+                                               self.num_item).to(self.device)
+
+    # ---- graph construction (host, once) -------------------------------------------------
+    def get_norm_adj_mat(self, edge_index):
+        """Model/FREEDOM.py:73-83 (Q6: bincount over cat(row, col) of the bidirectional list)."""
+        row, col = edge_index.long()
+        deg = torch.bincount(torch.cat([row, col]))
+        deg_inv_sqrt = deg.pow(-0.5)
+        norm = deg_inv_sqrt[row] * deg_inv_sqrt[col]
+        # torch.sparse.mm(adj, x): out[row] += v * x[col]; entries coalesced (column-ascending per row)
+        return graph.coo_to_csr_coalesced(row, col, norm, self.n_nodes, self.n_nodes, symmetric=True)
+
+    def _normalize_adj_m(self, indices, adj_size):
+        """Model/FREEDOM.py:85-99: 1e-7 + degree, ^-1/2, product per edge (fp32)."""
+        ones = torch.ones_like(indices[0])
+        row_sum = 1e-7 + torch.zeros(adj_size[0], dtype=ones.dtype, device=indices.device).scatter_add_(0, indices[0], ones)
+        col_sum = 1e-7 + torch.zeros(adj_size[1], dtype=ones.dtype, device=indices.device).scatter_add_(0, indices[1], ones)
+        r_inv_sqrt = torch.pow(row_sum, -0.5)
+        c_inv_sqrt = torch.pow(col_sum, -0.5)
+        return r_inv_sqrt[indices[0]] * c_inv_sqrt[indices[1]]
+
+    def get_edge_info(self, edge_index):
+        """Model/FREEDOM.py:101-108."""
+        rows, cols = edge_index
+        cols = cols - self.num_user
+        edges = torch.stack([rows, cols]).type(torch.LongTensor)
+        values = self._normalize_adj_m(edges, torch.Size((self.num_user, self.num_item)))
+        return edges, values
+
+    def get_knn_adj_mat(self, mm_embeddings):
+        """Model/FREEDOM.py:111-126: cosine kNN (self included) -> D^-1/2 A D^-1/2 with row-sum degrees.
+        The [I, I] similarity matrix is never materialised: scoring + top-K are one kernel."""
+        dev = self.device
+        emb = mm_embeddings.to(dev)
+        context_norm = emb.div(torch.norm(emb, p=2, dim=-1, keepdim=True))
+        d = context_norm.shape[1]
+        d_pad = next(c for c in (8, 16, 32, 64, 128) if c >= d) if d <= 128 else (d + 63) // 64 * 64
+        context_norm = F.pad(context_norm, (0, d_pad - d)).contiguous()   # zero columns leave the cosine unchanged
+        knn_ind, _ = ops.score_topk(context_norm, context_norm, None, 0.0, self.knn_k)
+        n = context_norm.shape[0]
+        rows = torch.arange(n, device=dev).unsqueeze(1).expand(-1, self.knn_k).reshape(-1)
+        cols = knn_ind.reshape(-1)
+        return self.compute_normalized_laplacian(torch.stack((rows, cols), 0).cpu(), (n, n))
+
+    def compute_normalized_laplacian(self, indices, adj_size):
+        """Model/FREEDOM.py:128-138 -> (indices [2, nnz], values [nnz]) on the host."""
+        ones = torch.ones_like(indices[0])
+        row_sum = 1e-7 + torch.zeros(adj_size[0], dtype=ones.dtype).scatter_add_(0, indices[0], ones)
+        r_inv_sqrt = torch.pow(row_sum, -0.5)
+        values = r_inv_sqrt[indices[0]] * r_inv_sqrt[indices[1]]
+        return indices, values
+
+    # ---- per-epoch pruning ----------------------------------------------------------------
+    def pre_epoch_processing(self):
+        """Model/FREEDOM.py:143-162: degree-sensitive edge pruning, re-normalised and symmetrised."""
+        if self.dropout <= .0:
+            self.masked_adj = self.norm_adj
+            return
+        degree_len = int(self.edge_values.size(0) * (1. - self.dropout))
+        degree_idx = torch.multinomial(self.edge_values, degree_len)
+        self._set_masked_adj(self.edge_indices[:, degree_idx])
+
+    def _set_masked_adj(self, keep_indices):
+        keep_values = self._normalize_adj_m(keep_indices, torch.Size((self.num_user, self.num_item)))
+        all_values = torch.cat((keep_values, keep_values))
+        keep_indices = keep_indices.clone()
+        keep_indices[1] += self.num_user
+        all_indices = torch.cat((keep_indices, torch.flip(keep_indices, [0])), 1)
+        self.masked_adj = graph.coo_to_csr_coalesced(all_indices[0], all_indices[1], all_values, self.n_nodes,
+                                                     self.n_nodes, symmetric=True).to(self.device)
+
+    # ---- hot path ---------------------------------------------------------------------------
+    def forward(self, adj):
+        """Model/FREEDOM.py:164-183."""
+        ego_embeddings = torch.cat((self.user_embedding.weight, self.item_embedding.weight), dim=0)
+        all_embeddings = ops.layer_mean_propagate(ego_embeddings, adj, self.n_layers)
+        u_g_embeddings = all_embeddings[:self.num_user]
+        i_g_embeddings = all_embeddings[self.num_user:]
+        h = self.item_embedding.weight
+        if self.mm_layers == 0:
+            i_g_embeddings = i_g_embeddings + h
+        for i in range(self.mm_layers):
+            if i + 1 < self.mm_layers:
+                h = ops.spmm(self.mm_adj, h)
+            else:  # last item-item layer fused with `i_g_embeddings + h`
+                i_g_embeddings = ops.spmm_add(self.mm_adj, h, i_g_embeddings)
+        self.result = torch.cat((u_g_embeddings, i_g_embeddings), dim=0)
+        return u_g_embeddings, i_g_embeddings
+
+    def bpr_loss(self, users, pos_items, neg_items):
+        """Model/FREEDOM.py:185-192 on already gathered rows (API parity; the training path below uses
+        the fused gather+loss kernel and never materialises the gathers)."""
+        B = users.shape[0]
+        idx = torch.arange(B, device=users.device)
+        tab_i = torch.cat((pos_items, neg_items), 0)
+        return ops.bpr_loss(users, tab_i, idx, idx, idx + B, ops.VARIANT_LOGSIGMOID, 0.0)[0]
+
+    def loss(self, users, pos_items, neg_items):
+        """Model/FREEDOM.py:194-217."""
+        pos_items = pos_items - self.num_user
+        neg_items = neg_items - self.num_user
+        users, pos_items, neg_items = users.to(self.device), pos_items.to(self.device), neg_items.to(self.device)
+
+        ua_embeddings, ia_embeddings = self.forward(self.masked_adj)
+        batch_mf_loss = ops.bpr_loss(ua_embeddings, ia_embeddings, users, pos_items, neg_items,
+                                     ops.VARIANT_LOGSIGMOID, 0.0)[0]
+        mf_v_loss, mf_t_loss = 0.0, 0.0
+        if self.t_feat is not None:
+            text_feats = ops.linear(self.text_embedding.weight, self.text_trs.weight, self.text_trs.bias)
+            mf_t_loss = ops.bpr_loss(ua_embeddings, text_feats, users, pos_items, neg_items,
+                                     ops.VARIANT_LOGSIGMOID, 0.0)[0]
+        if self.v_feat is not None:
+            image_feats = ops.linear(self.image_embedding.weight, self.image_trs.weight, self.image_trs.bias)
+            mf_v_loss = ops.bpr_loss(ua_embeddings, image_feats, users, pos_items, neg_items,
+                                     ops.VARIANT_LOGSIGMOID, 0.0)[0]
+        return batch_mf_loss + self.reg_weight * (mf_t_loss + mf_v_loss)
+
+    def gene_ranklist(self, topk=50):
+        """Model/FREEDOM.py:219-244 (mask value 1e-6, stale self.result)."""
+        with torch.no_grad():
+            result = self.result.detach()
+            idx, _ = ops.score_topk(result[:self.num_user], result[self.num_user:self.num_user + self.num_item],
+                                    self.hist, 1e-6, topk, id_offset=self.num_user)
+        return idx.cpu()
+
+    full_sort_predict = gene_ranklist

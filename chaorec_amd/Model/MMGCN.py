@@ -1,0 +1,140 @@
+"""MMGCN with the reference's surface (Model/MMGCN.py:19-244), compute on HIP kernels.
+
+Reference quirks kept on purpose:
+  Q1  main.py passes concate='False' (a non-empty string, truthy): the CONCAT branch runs;
+  Q2  preference / id_embedding / v_feat / t_feat are plain tensors, not Parameters: Adam never
+      updates them, model.parameters() yields only the Linear layers;
+  Q3  the visual branch has dim_latent=256 + an MLP, the textual branch has neither;
+  two modality branches (visual, textual), four hard-coded layers each; eval mask value 1e-5.
+Underneath: every BasicGCN conv is Linear (f32 MFMA GEMM) + one CSR SpMM over D^-1/2 (A+I) D^-1/2 built once
+in HBM; every other Linear(+leaky_relu) is one fused GEMM launch; BPR is the fused kernel (variant 2).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import graph, ops
+from ..BasicGCN import BasicGCN
+
+
+class GCN(torch.nn.Module):
+    def __init__(self, edge_index, num_user, num_item, dim_feat, dim_id, aggr_mode, concate, has_id, dim_latent=None,
+                 device=None):
+        super(GCN, self).__init__()
+        self.num_user = num_user
+        self.num_item = num_item
+        self.dim_id = dim_id
+        self.dim_feat = dim_feat
+        self.dim_latent = dim_latent
+        self.edge_index = edge_index          # a graph.CSR (D^-1/2 (A+I) D^-1/2) shared by all convs
+        self.aggr_mode = aggr_mode
+        self.concate = concate
+        self.has_id = has_id
+        self.device = device
+
+        if self.dim_latent:
+            self.preference = nn.init.xavier_normal_(torch.rand((self.num_user, self.dim_latent))).to(self.device)
+            self.MLP = nn.Linear(self.dim_feat, self.dim_latent)
+            first = self.dim_latent
+        else:
+            self.preference = nn.init.xavier_normal_(torch.rand((num_user, self.dim_feat))).to(self.device)
+            first = self.dim_feat
+        self.conv_embed_1 = BasicGCN(first, first, aggr=self.aggr_mode)
+        nn.init.xavier_normal_(self.conv_embed_1.lin.weight)
+        self.linear_layer1 = nn.Linear(first, self.dim_id)
+        nn.init.xavier_normal_(self.linear_layer1.weight)
+        self.g_layer1 = nn.Linear(first + self.dim_id, self.dim_id) if self.concate else nn.Linear(first, self.dim_id)
+        nn.init.xavier_normal_(self.g_layer1.weight)
+
+        for k in (2, 3, 4):
+            conv = BasicGCN(self.dim_id, self.dim_id, aggr=self.aggr_mode)
+            nn.init.xavier_normal_(conv.lin.weight)
+            lin = nn.Linear(self.dim_id, self.dim_id)
+            nn.init.xavier_normal_(lin.weight)
+            g = nn.Linear(self.dim_id + self.dim_id, self.dim_id) if self.concate else nn.Linear(self.dim_id, self.dim_id)
+            setattr(self, f"conv_embed_{k}", conv)
+            setattr(self, f"linear_layer{k}", lin)
+            setattr(self, f"g_layer{k}", g)
+
+    def _layer(self, k, x, id_embedding):
+        conv, lin, g = (getattr(self, f"conv_embed_{k}"), getattr(self, f"linear_layer{k}"), getattr(self, f"g_layer{k}"))
+        h = F.leaky_relu(conv(x, self.edge_index))                                   # equation 1
+        u_hat = ops.linear(x, lin.weight, lin.bias, act=1)                           # equation 5
+        if self.has_id:
+            u_hat = u_hat + id_embedding
+        if self.concate:
+            return ops.linear(torch.cat((h, u_hat), dim=1), g.weight, g.bias, act=1)
+        return F.leaky_relu(ops.linear(h, g.weight, g.bias) + u_hat)
+
+    def forward(self, features, id_embedding):
+        """Model/MMGCN.py:96-143."""
+        temp_features = ops.linear(features, self.MLP.weight, self.MLP.bias) if self.dim_latent else features
+        x = torch.cat((self.preference, temp_features), dim=0)
+        x = F.normalize(x)
+        for k in (1, 2, 3, 4):
+            x = self._layer(k, x, id_embedding)
+        return x
+
+
+class MMGCN(torch.nn.Module):
+    def __init__(self, num_user, num_item, edge_index, user_item_dict, v_feat, t_feat, dim_x, reg_weight, aggr_mode,
+                 concate, has_id, device):
+        super(MMGCN, self).__init__()
+        self.device = device
+        self.num_user = num_user
+        self.num_item = num_item
+        self.aggr_mode = aggr_mode
+        self.concate = concate
+        self.user_item_dict = user_item_dict
+        self.weight = torch.tensor([[1.0], [-1.0]]).to(self.device)
+        self.reg_weight = reg_weight
+
+        self.edge_index = graph.bidirectional_edge_index(edge_index)
+        self.graph = graph.basicgcn_csr(edge_index, num_user + num_item).to(device)
+        rowptr, col = graph.user_hist_csr(user_item_dict, num_user)
+        self.hist = (rowptr.to(device), col.to(device))
+
+        self.v_feat = v_feat.clone().detach().to(self.device)
+        self.v_gcn = GCN(self.graph, num_user, num_item, self.v_feat.size(1), dim_x, self.aggr_mode, self.concate,
+                         has_id=has_id, dim_latent=256, device=device)
+        self.t_feat = t_feat.clone().detach().to(self.device)
+        self.t_gcn = GCN(self.graph, num_user, num_item, self.t_feat.size(1), dim_x, self.aggr_mode, self.concate,
+                         has_id=has_id, device=device)
+
+        self.id_embedding = nn.init.xavier_normal_(torch.rand((num_user + num_item, dim_x))).to(self.device)
+        self.result = nn.init.xavier_normal_(torch.rand((num_user + num_item, dim_x))).to(self.device)
+
+    def forward(self):
+        """Model/MMGCN.py:176-186."""
+        v_rep = self.v_gcn(self.v_feat, self.id_embedding)
+        t_rep = self.t_gcn(self.t_feat, self.id_embedding)
+        representation = (v_rep + t_rep) / 2
+        self.result = representation
+        return representation
+
+    def loss(self, user_tensor, item_tensor):
+        """Model/MMGCN.py:188-202: user_tensor [B,2] = (u,u), item_tensor [B,2] = (pos,neg), GLOBAL ids."""
+        user_tensor = user_tensor.to(self.device)
+        item_tensor = item_tensor.to(self.device)
+        users = user_tensor[:, 0].contiguous()
+        pos = item_tensor[:, 0].contiguous()
+        neg = item_tensor[:, 1].contiguous()
+        out = self.forward()
+        # rows of ONE table [N, D] indexed by global ids: item_offset = 0
+        loss = ops.bpr_loss(out, None, users, pos, neg, ops.VARIANT_LOG_SIGMOID, 0.0, item_offset=0)[0]
+        with torch.no_grad():  # regulariser over tensors no optimizer owns (Q2): a reported constant
+            ut, it = user_tensor.reshape(-1), item_tensor.reshape(-1)
+            reg_embedding_loss = (self.id_embedding[ut] ** 2 + self.id_embedding[it] ** 2).mean() + (
+                self.v_gcn.preference ** 2).mean()
+        return loss + self.reg_weight * reg_embedding_loss
+
+    def gene_ranklist(self, step=200, topk=50):
+        """Model/MMGCN.py:204-244: mask value 1e-5.  The reference batches 200 users to bound its [200, I]
+        score matrix; the fused kernel has no such matrix, `step` is accepted and ignored."""
+        with torch.no_grad():
+            result = self.result.detach()
+            idx, _ = ops.score_topk(result[:self.num_user], result[self.num_user:self.num_user + self.num_item],
+                                    self.hist, 1e-5, topk, id_offset=self.num_user)
+        return idx.cpu()
+
+    full_sort_predict = gene_ranklist

@@ -1,1 +1,3 @@
 from .LightGCN import LightGCN  # noqa: F401
+from .FREEDOM import FREEDOM  # noqa: F401
+from .MMGCN import MMGCN  # noqa: F401

@@ -96,10 +96,13 @@ __device__ __forceinline__ void load_item_frag(float (&a)[D / 2], const float *_
   }
 }
 
+// D > 0: K-dim known at compile time, the users' fragment lives in registers for the whole stream.
+// D == 0 ("stream"): K-dim = Dk at run time (multiple of 64; the kNN build over 384/4096-wide
+// modality features): both operands are re-read per 64-wide k-chunk, B from L1/L2.
 template <int D>
 __global__ __launch_bounds__(64) void score_topk_f32_kernel(
     const float *__restrict__ user_emb, const float *__restrict__ item_emb, int64_t n_users,
-    int64_t n_items, const int64_t *__restrict__ hist_rowptr, const int32_t *__restrict__ hist_col,
+    int64_t n_items, int Dk, const int64_t *__restrict__ hist_rowptr, const int32_t *__restrict__ hist_col,
     float mask_value, int K, int64_t id_offset, int64_t *__restrict__ out_idx,
     float *__restrict__ out_val, uint64_t *__restrict__ partial, int splits,
     int64_t items_per_split) {
@@ -113,12 +116,14 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(
   const int64_t i_begin = (int64_t)split * items_per_split;
   const int64_t i_end = min(n_items, i_begin + items_per_split);
 
+  constexpr int DR = D > 0 ? D : 64;  // register fragment width
   // users' B fragment: lane (ur, h) holds k = h*D/2 + s
-  float bu[D / 2];
-  if (u_ok) {
-    const float4 *src = reinterpret_cast<const float4 *>(user_emb + (size_t)u * D + h * (D / 2));
+  float bu[DR / 2];
+  if (D == 0) {
+  } else if (u_ok) {
+    const float4 *src = reinterpret_cast<const float4 *>(user_emb + (size_t)u * DR + h * (DR / 2));
 #pragma unroll
-    for (int q = 0; q < D / 8; ++q) {
+    for (int q = 0; q < DR / 8; ++q) {
       const float4 v = src[q];
       bu[4 * q + 0] = v.x;
       bu[4 * q + 1] = v.y;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(
     }
   } else {
 #pragma unroll
-    for (int s = 0; s < D / 2; ++s) bu[s] = 0.f;
+    for (int s = 0; s < DR / 2; ++s) bu[s] = 0.f;
   }
 
   // history cursor: first interacted item >= i_begin
@@ -149,18 +154,38 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(
   int cnt = 0;  // identical on both lanes of a user
   uint64_t *my = cand + ur * kCandStride;
 
-  float a_cur[D / 2], a_nxt[D / 2];
-  load_item_frag<D>(a_cur, item_emb, i_begin + ur, i_end, h);
+  float a_cur[DR / 2], a_nxt[DR / 2];
+  if (D > 0) load_item_frag<DR>(a_cur, item_emb, i_begin + ur, i_end, h);
 
   for (int64_t j0 = i_begin; j0 < i_end; j0 += 32) {
-    load_item_frag<D>(a_nxt, item_emb, j0 + 32 + ur, i_end, h);
-
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (D > 0) {
+      load_item_frag<DR>(a_nxt, item_emb, j0 + 32 + ur, i_end, h);
 #pragma unroll
-    for (int s = 0; s < D / 2; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], bu[s], acc, 0, 0, 0);
+      for (int s = 0; s < DR / 2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], bu[s], acc, 0, 0, 0);
+    } else {
+      const int64_t j = j0 + ur;
+      for (int kc = 0; kc < Dk; kc += 64) {
+        float4 av[8], bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          bv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j < i_end) av[q] = reinterpret_cast<const float4 *>(item_emb + (size_t)j * Dk + kc + h * 32)[q];
+          if (u_ok) bv[q] = reinterpret_cast<const float4 *>(user_emb + (size_t)u * Dk + kc + h * 32)[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
+        }
+      }
+    }
 
     // prune the lists that a full tile could overflow (wave-uniform loop over such users)
     {
@@ -216,8 +241,10 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(
       cnt += nq + nqp;
     }
 
+    if (D > 0) {
 #pragma unroll
-    for (int s = 0; s < D / 2; ++s) a_cur[s] = a_nxt[s];
+      for (int s = 0; s < DR / 2; ++s) a_cur[s] = a_nxt[s];
+    }
   }
 
   // final ordering of every user's list
@@ -312,7 +339,7 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)((n_users + 31) / 32), (unsigned)splits);
   uint64_t *partial = (uint64_t *)workspace;
-#define CHAOREC_ST_ARGS user_emb, item_emb, n_users, n_items, hist_rowptr, hist_col, mask_value, K, \
+#define CHAOREC_ST_ARGS user_emb, item_emb, n_users, n_items, (int)D, hist_rowptr, hist_col, mask_value, K, \
                         id_offset, out_idx, out_val, partial, splits, per
   switch (D) {
     case 8: hipLaunchKernelGGL(score_topk_f32_kernel<8>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
@@ -320,7 +347,12 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     case 32: hipLaunchKernelGGL(score_topk_f32_kernel<32>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
     case 64: hipLaunchKernelGGL(score_topk_f32_kernel<64>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
     case 128: hipLaunchKernelGGL(score_topk_f32_kernel<128>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
-    default: return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {8,16,32,64,128}", D);
+    default:
+      if (D > 128 && (D % 64) == 0) {
+        hipLaunchKernelGGL(score_topk_f32_kernel<0>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS);
+        break;
+      }
+      return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {8,16,32,64,128} and not a multiple of 64 above 128", D);
   }
 #undef CHAOREC_ST_ARGS
   int rc = check_launch("score_topk_f32_kernel");

@@ -144,3 +144,33 @@ def user_item_dict_from_edges(edge_index):
     for u, i in np.asarray(edge_index).tolist():
         d.setdefault(u, []).append(i)
     return d
+
+
+def coo_to_csr_coalesced(row, col, val, n_rows, n_cols, symmetric=False):
+    """COO (destination=row, source=col) -> CSR with COALESCED rows: entries sorted by column, duplicates
+    summed -- the form torch.sparse.mm works on (Model/FREEDOM.py:168,174 coalesce their operand first).
+    Runs on whatever device the inputs live on (FREEDOM re-prunes its graph on the GPU every epoch)."""
+    row = torch.as_tensor(row).long()
+    col = torch.as_tensor(col).long()
+    val = torch.as_tensor(val, dtype=torch.float32, device=row.device)
+    key = row * n_cols + col
+    order = torch.argsort(key, stable=True)
+    key, val = key[order], val[order]
+    uniq, inverse = torch.unique_consecutive(key, return_inverse=True)
+    if uniq.numel() != key.numel():
+        val = torch.zeros(uniq.numel(), dtype=torch.float32, device=val.device).index_add_(0, inverse, val)
+    r = torch.div(uniq, n_cols, rounding_mode="floor")
+    c = uniq - r * n_cols
+    counts = torch.bincount(r, minlength=n_rows)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=row.device)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    return CSR(rowptr, c.to(torch.int32).contiguous(), val.contiguous(), n_rows, n_cols, symmetric)
+
+
+def add_scaled_coo(a, wa, b, wb, n):
+    """wa * A + wb * B for two (indices [2,nnz], values [nnz]) COO pairs over an n x n matrix -> coalesced CSR
+    (Model/FREEDOM.py:69: mm_adj = w * image_adj + (1 - w) * text_adj)."""
+    (ia, va), (ib, vb) = a, b
+    idx = torch.cat([ia, ib], dim=1)
+    val = torch.cat([wa * va, wb * vb])
+    return coo_to_csr_coalesced(idx[0], idx[1], val, n, n, symmetric=False)

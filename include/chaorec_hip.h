@@ -136,10 +136,12 @@ int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col
  *   out = the K largest per user, descending; ties -> LOWEST item index first.
  *   out_idx = item index + id_offset (int64), out_val = the (masked) score.
  *
- * precision 0 ("f32"): v_mfma_f32_32x32x2_f32, i.e. a k-ordered fp32 fmaf chain
- *     acc = 0; for s in [0, D/2): acc = fmaf(u[s], i[s], acc); acc = fmaf(u[D/2+s], i[D/2+s], acc)
+ * precision 0 ("f32"): v_mfma_f32_32x32x2_f32, i.e. a k-ordered fp32 fmaf chain.  With the K-dim
+ *   cut into chunks of C floats (C = D for D <= 128, C = 64 above), per chunk base b:
+ *     for s in [0, C/2): acc = fmaf(u[b+s], i[b+s], acc); acc = fmaf(u[b+C/2+s], i[b+C/2+s], acc)
  *   bit-identical to oracle/chaorec_oracle.c:oracle_score_dot().
- * D in {8, 16, 32, 64, 128};  1 <= K <= 64;  n_items >= K.
+ * D in {8, 16, 32, 64, 128} (users' fragment register-resident) or a multiple of 64 above 128
+ * (streamed; the kNN build over modality features);  1 <= K <= 64;  n_items >= K.
  * hist_rowptr may be NULL (no mask).  hist_col ascending inside a row.
  * ------------------------------------------------------------------------------------- */
 size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K);

@@ -175,10 +175,13 @@ void oracle_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col
  * so kernel and oracle agree bit-for-bit; vs torch the difference is rounding-level. */
 float oracle_score_dot(const float *u, const float *i, int32_t D) {
   float acc = 0.0f;
-  const int32_t half = D / 2;
-  for (int32_t s = 0; s < half; ++s) {
-    acc = fmaf(i[s], u[s], acc);
-    acc = fmaf(i[half + s], u[half + s], acc);
+  const int32_t chunk = D <= 128 ? D : 64; /* K-dim chunking of the kernel, see chaorec_hip.h */
+  const int32_t half = chunk / 2;
+  for (int32_t b = 0; b < D; b += chunk) {
+    for (int32_t s = 0; s < half; ++s) {
+      acc = fmaf(i[b + s], u[b + s], acc);
+      acc = fmaf(i[b + half + s], u[b + half + s], acc);
+    }
   }
   return acc;
 }
