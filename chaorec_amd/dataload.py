@@ -1,0 +1,134 @@
+"""Data loading + negative sampling for the hot path (reference dataload.py:21-106).
+
+`data_load` reads the reference's file formats (train.npy int32 [E,2] with GLOBAL item ids, val/test.npy
+object arrays of [user, pos...], user_item_dict.npy) and fills the documented gaps: a missing
+user_item_dict.npy is rebuilt from train.npy, missing v_feat/t_feat blobs are replaced by
+seeded synthetic features, and nothing is moved to the GPU unconditionally.
+
+Two samplers produce the reference's batch format:
+  * TrainingDataset  -- the DataLoader-compatible host sampler (same __getitem__ contract);
+  * DeviceBatchSampler -- the MI355X path: edge permutation + rejection sampling in one HIP kernel, batches
+    never leave HBM.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import graph, ops
+from .synthetic import DATASET_SHAPES, synthetic_eval_lists, synthetic_interactions
+
+DATASET_SIZES = {  # dataload.py:36-56
+    'netfilx': (14971, 7444), 'clothing': (18072, 11384), 'baby': (12351, 4794), 'sports': (28940, 15207),
+    'beauty': (15482, 8643), 'electronics': (150179, 51901), 'microlens': (46420, 14079),
+}
+SYNTHETIC_FEATURE_DIMS = {"default": (4096, 384), "microlens": (128, 768)}  # SURVEY 8(d) assumptions
+
+
+def synthetic_features(num_item, dataset, seed=0):
+    dv, dt = SYNTHETIC_FEATURE_DIMS.get(dataset, SYNTHETIC_FEATURE_DIMS["default"])
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(num_item, dv, generator=g), torch.randn(num_item, dt, generator=g)
+
+
+def data_load(dataset, has_v=True, has_t=True, data_root='./Data', synthetic=False):
+    """-> train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat (dataload.py:21-58)."""
+    num_user, num_item = DATASET_SIZES[dataset]
+    dir_str = os.path.join(data_root, dataset)
+    if synthetic or not os.path.exists(os.path.join(dir_str, 'train.npy')):
+        if not synthetic:
+            raise FileNotFoundError(f"{dir_str}/train.npy not found (pass --synthetic for a generated graph)")
+        _, _, E = DATASET_SHAPES[dataset]
+        train_data = synthetic_interactions(num_user, num_item, E, seed=42)
+        val_data = synthetic_eval_lists(num_user, num_item, train_data, 1, seed=7)
+        test_data = synthetic_eval_lists(num_user, num_item, train_data, 1, seed=8)
+        user_item_dict = graph.user_item_dict_from_edges(train_data)
+    else:
+        train_data = np.load(os.path.join(dir_str, 'train.npy'), allow_pickle=True)
+        val_data = np.load(os.path.join(dir_str, 'val.npy'), allow_pickle=True)
+        test_data = np.load(os.path.join(dir_str, 'test.npy'), allow_pickle=True)
+        uid_path = os.path.join(dir_str, 'user_item_dict.npy')
+        if os.path.exists(uid_path):
+            user_item_dict = np.load(uid_path, allow_pickle=True).item()
+        else:
+            user_item_dict = graph.user_item_dict_from_edges(train_data)
+    v_feat = t_feat = None
+    if has_v or has_t:
+        vp, tp = os.path.join(dir_str, 'v_feat.npy'), os.path.join(dir_str, 't_feat.npy')
+        sv, st = synthetic_features(num_item, dataset)
+        if has_v:
+            v_feat = torch.tensor(np.load(vp, allow_pickle=True), dtype=torch.float) if os.path.exists(vp) else sv
+        if has_t:
+            t_feat = torch.tensor(np.load(tp, allow_pickle=True), dtype=torch.float) if os.path.exists(tp) else st
+    return train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat
+
+
+class TrainingDataset(Dataset):
+    """dataload.py:61-106: one uniform negative per positive, rejected while it is in the user's history.
+    Same return contract ([user, pos, neg] ints, or (LongTensor[u,u], LongTensor[pos,neg]) for MMGCN);
+    the draw itself is O(1) (randrange + set lookup) instead of the reference's O(I) random.sample(set)."""
+
+    def __init__(self, num_user, num_item, user_item_dict, edge_index, model_name="LightGCN"):
+        self.edge_index = edge_index
+        self.num_user = num_user
+        self.num_item = num_item
+        self.user_item_dict = user_item_dict
+        self._sets = {}
+        self.model_name = model_name
+
+    def __len__(self):
+        return len(self.edge_index)
+
+    def _seen(self, user):
+        s = self._sets.get(user)
+        if s is None:
+            s = self._sets[user] = set(int(i) for i in self.user_item_dict[user])
+        return s
+
+    def __getitem__(self, index):
+        user, pos_item = self.edge_index[index]
+        user, pos_item = int(user), int(pos_item)
+        seen = self._seen(user)
+        while True:
+            neg_item = random.randrange(self.num_user, self.num_user + self.num_item)
+            if neg_item not in seen:
+                break
+        if self.model_name in ["MMGCN", "GRCN"]:
+            return torch.LongTensor([user, user]), torch.LongTensor([pos_item, neg_item])
+        return [user, pos_item, neg_item]
+
+
+class DeviceBatchSampler:
+    """Epoch iterator over (users, pos, neg) batches of GLOBAL ids that live in HBM.
+
+    Stands in for DataLoader(TrainingDataset, batch_size, shuffle=True): a device-side permutation of the
+    edge list per epoch and chaorec_sample_negatives for the rejection draw (counter-based RNG keyed by
+    (seed, global step, position), so a run is reproducible regardless of launch geometry)."""
+
+    def __init__(self, num_user, num_item, user_item_dict, edge_index, batch_size, device, model_name="LightGCN",
+                 seed=42):
+        self.num_user, self.num_item, self.batch_size = num_user, num_item, batch_size
+        self.device, self.model_name, self.seed = device, model_name, seed
+        self.edges = torch.as_tensor(np.asarray(edge_index), dtype=torch.int64).to(device)
+        rowptr, col = graph.user_hist_csr(user_item_dict, num_user)
+        self.hist = (rowptr.to(device), col.to(device))
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed)
+        self.global_step = 0
+
+    def __len__(self):
+        return (self.edges.shape[0] + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        perm = torch.randperm(self.edges.shape[0], device=self.device, generator=self.gen)
+        for s in range(0, perm.numel(), self.batch_size):
+            e = self.edges[perm[s:s + self.batch_size]]
+            users, pos = e[:, 0].contiguous(), e[:, 1].contiguous()
+            neg = ops.sample_negatives(self.hist, users, self.num_item, self.seed, self.global_step, self.num_user)
+            self.global_step += 1
+            if self.model_name in ["MMGCN", "GRCN"]:
+                yield torch.stack((users, users), 1), torch.stack((pos, neg), 1)
+            else:
+                yield users, pos, neg

@@ -1,0 +1,98 @@
+"""Entry point: `python -m chaorec_amd.main --Model LightGCN --data_path sports` (reference main.py:73-442).
+
+Same flow: parse flags, seed, load data, build the sampler, cartesian product over the model's YAML grid,
+construct the model, Adam, train_and_evaluate, keep the best combination by Recall@20.  Out of scope and
+dropped: the 51 other constructors and the dense U x I DiffusionData the reference builds for every model
+(main.py:202; 1.76 GB for sports)."""
+import logging
+import os
+from itertools import product
+
+import torch
+from torch.utils.data import DataLoader
+
+from . import dataload
+from .Model import FREEDOM, LightGCN, MMGCN
+from .arg_parser import load_yaml_config, parse_args
+from .train_and_evaluate import train_and_evaluate
+from .utils import get_local_time, gpu, setup_seed
+
+
+def setup_logging(args):
+    log_dir = "log"
+    os.makedirs(log_dir, exist_ok=True)
+    log_filename = os.path.join(log_dir, f"{args.Model}_{args.data_path}").replace("\\", "/") + ".log"
+    fmt = logging.Formatter('%(asctime)s %(levelname)s %(message)s', '%a %d %b %Y %H:%M:%S')
+    logger = logging.getLogger()
+    logger.setLevel(logging.INFO)
+    for h in (logging.StreamHandler(), logging.FileHandler(log_filename, mode='w')):
+        h.setLevel(logging.INFO)
+        h.setFormatter(fmt)
+        logger.addHandler(h)
+
+
+def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_feat, device):
+    """The three rows of the reference's constructor table (main.py:261-263, :269-270, :287-289)."""
+    dim_E, aggr_mode = args.dim_E, args.aggr_mode
+    table = {
+        'MMGCN': lambda: MMGCN(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
+                               aggr_mode, 'False', True, device),
+        'LightGCN': lambda: LightGCN(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight,
+                                     args.n_layers, aggr_mode, device),
+        'FREEDOM': lambda: FREEDOM(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E,
+                                   args.feature_embed, args.reg_weight, args.dropout, args.n_layers, args.mm_layers,
+                                   args.ii_topk, args.lambda_coeff, device),
+    }
+    if args.Model not in table:
+        raise SystemExit(f"--Model {args.Model}: only {sorted(table)} are on the MI355X hot path")
+    return table[args.Model]()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    setup_logging(args)
+    logging.info('============Arguments==============')
+    for arg, value in vars(args).items():
+        logging.info('%s: %s', arg, value)
+    logging.info('local time：%s', get_local_time())
+    setup_seed(args.seed)
+    device = gpu()
+    if device.type != "cuda":
+        raise SystemExit("chaorec_amd runs on the MI355X only: no GPU visible")
+    config = load_yaml_config(args.Model)
+    needs_feat = args.Model in ("MMGCN", "FREEDOM")
+    train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat = dataload.data_load(
+        args.data_path, has_v=needs_feat, has_t=needs_feat, data_root=args.data_root, synthetic=args.synthetic)
+    if args.host_sampler:
+        ds = dataload.TrainingDataset(num_user, num_item, user_item_dict, train_data, args.Model)
+        train_loader = DataLoader(ds, args.batch_size, shuffle=True, num_workers=args.num_workers)
+    else:
+        train_loader = dataload.DeviceBatchSampler(num_user, num_item, user_item_dict, train_data, args.batch_size,
+                                                   device, args.Model, args.seed)
+    args.num_user, args.num_item = num_user, num_item
+
+    combinators = list(product(*[config[p] for p in config['hyper_parameters']]))
+    best_performance, best_params, best_metrics = None, None, None
+    for idx, combo in enumerate(combinators):
+        hyper = dict(zip(config['hyper_parameters'], combo))
+        logging.info('========={}/{}: Parameters:{}========='.format(idx + 1, len(combinators), hyper))
+        for key, value in hyper.items():
+            setattr(args, key, value)
+        model = build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_feat, device)
+        model.to(device)
+        optimizer = torch.optim.Adam([{'params': model.parameters(), 'lr': args.learning_rate}])
+        current = train_and_evaluate(model, train_loader, val_data, test_data, optimizer, args.num_epoch,
+                                     model_name=args.Model, topk=args.topk, patience=args.patience)
+        recall = current[20]['recall'] if 20 in current else current[max(current)]['recall']
+        if best_performance is None or recall > best_performance:
+            best_performance, best_params, best_metrics = recall, hyper.copy(), current
+    logging.info("Best performance: {:.5f}".format(best_performance))
+    logging.info("Best parameters: {}".format(best_params))
+    logging.info("Best metrics:")
+    for k, m in best_metrics.items():
+        logging.info(f"{k}: {' | '.join(f'{name}: {value:.5f}' for name, value in m.items())}")
+    return best_metrics
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,68 @@
+"""Train / evaluate loop for the hot-path models (reference train_and_evaluate.py:25-48, :516-520, :523-686).
+
+Kept: the generic (users, pos, neg) branch, the MMGCN (user_tensor, item_tensor) branch, FREEDOM's
+pre_epoch_processing hook, per-epoch gene_ranklist + val/test metrics at K in topk, early stopping on test
+Recall@max(topk) with patience 20, the same log lines.  Changed: the per-batch `loss.item()` host sync
+(reference :48) becomes one device-side accumulation and a single .item() per epoch."""
+import logging
+
+import torch
+
+from .utils import EarlyStopping, gene_metrics
+
+MMGCN_STYLE = ("MMGCN", "GRCN")
+PRE_EPOCH = ("FREEDOM",)
+
+
+def train(model, train_loader, optimizer, model_name="LightGCN"):
+    model.train()
+    sum_loss = None
+    for batch in train_loader:
+        optimizer.zero_grad()
+        loss = model.loss(*batch)
+        loss.backward()
+        optimizer.step()
+        d = loss.detach()
+        sum_loss = d.clone() if sum_loss is None else sum_loss.add_(d)
+    return float(sum_loss.item()) if sum_loss is not None else 0.0
+
+
+def evaluate(model, data, ranklist, topk):
+    model.eval()
+    with torch.no_grad():
+        return gene_metrics(data, ranklist, topk)
+
+
+def _log_metrics(title, metrics):
+    logging.info(title)
+    for k, m in metrics.items():
+        logging.info(f"{k}: {' | '.join(f'{name}: {value:.5f}' for name, value in m.items())}")
+
+
+def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epochs, model_name="LightGCN",
+                       topk=(5, 10, 20), patience=20):
+    model.train()
+    early_stopping = EarlyStopping(patience=patience, verbose=True)
+    topk = [int(k) for k in topk]
+    for epoch in range(epochs):
+        if model_name in PRE_EPOCH:
+            model.pre_epoch_processing()
+        loss = train(model, train_loader, optimizer, model_name)
+        logging.info("Epoch {}, Loss: {:.5f}".format(epoch + 1, loss))
+
+        model.eval()
+        rank_list = model.gene_ranklist()
+        val_metrics = evaluate(model, val_data, rank_list, topk)
+        test_metrics = evaluate(model, test_data, rank_list, topk)
+        _log_metrics('Validation Metrics:', val_metrics)
+        _log_metrics('Test Metrics:', test_metrics)
+
+        recall = test_metrics[max(topk)]['recall']
+        early_stopping(recall, test_metrics)
+        if early_stopping.early_stop:
+            print("Early stopping")
+            break
+
+    best_metrics = early_stopping.best_metrics
+    _log_metrics('Best Test Metrics:', best_metrics)
+    return best_metrics

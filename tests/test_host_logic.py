@@ -1,0 +1,190 @@
+"""CPU-only: host-side logic of chaorec_amd (graph setup, metrics, samplers, CLI) and the C-ABI surface.
+No kernel runs here: the product has no CPU compute path (asserted below)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_abi_exports_every_declared_symbol():
+    from chaorec_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "chaorec_hip.h")).read()
+    declared = set(re.findall(r"\b(chaorec_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "header parse failed"
+    _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/chaorec_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes table and header drifted"
+    assert _lib.load().chaorec_abi_version() == 1
+    assert _lib.load().chaorec_spmm_rows_per_wave(64) == 4
+    assert _lib.load().chaorec_spmm_rows_per_wave(128) == 2
+    assert _lib.load().chaorec_score_topk_workspace_bytes(28940, 15207, 50) > 0
+
+
+def test_no_cpu_fallback():
+    from chaorec_amd import ops, graph
+    g = load_golden("lightgcn_tiny.npz")
+    csr = graph.lightgcn_csr(g["edges"], int(g["U"]) + int(g["I"]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.spmm_raw(csr, torch.from_numpy(g["x0"]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.score_topk(torch.zeros(4, 64), torch.zeros(100, 64), None, 0.0, 10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.bpr_loss(torch.zeros(4, 64), None, torch.zeros(2, dtype=torch.long), torch.zeros(2, dtype=torch.long),
+                     torch.zeros(2, dtype=torch.long), 0, 0.0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "chaorec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle_", "").lower() or f == "__init__.py" or \
+                    "import oracle" not in src and "from oracle" not in src, f
+
+
+@pytest.mark.parametrize("builder", ["lightgcn", "basicgcn"])
+def test_csr_builders_match_oracle(oracle, baby, builder):
+    from chaorec_amd import graph
+    U, I = baby["U"], baby["I"]
+    mine = getattr(graph, builder + "_csr")(baby["train"], U + I)
+    want = getattr(oracle, builder + "_csr")(baby["train"], U + I)
+    assert np.array_equal(mine.rowptr.numpy(), want[0])
+    assert np.array_equal(mine.col.numpy(), want[1])
+    assert np.array_equal(mine.val.numpy(), want[2])       # torch pow(-0.5) == 1/sqrt in fp32, bit for bit
+    assert mine.symmetric and mine.t() is mine
+
+
+def test_group_order_longest_first(baby):
+    from chaorec_amd import graph
+    csr = graph.lightgcn_csr(baby["train"], baby["U"] + baby["I"])
+    order = csr.group_order(4).numpy()
+    n_groups = (csr.n_rows + 3) // 4
+    assert sorted(order.tolist()) == list(range(n_groups))
+    deg = np.diff(csr.rowptr.numpy())
+    deg = np.concatenate([deg, np.zeros(n_groups * 4 - len(deg), deg.dtype)]).reshape(n_groups, 4).max(1)
+    assert np.all(np.diff(deg[order]) <= 0)
+    assert csr.group_order(4) is csr.group_order(4)
+
+
+def test_transpose_and_coalesce():
+    from chaorec_amd import graph
+    rng = np.random.default_rng(0)
+    n, m, nnz = 40, 30, 300
+    r, c = rng.integers(0, n, nnz), rng.integers(0, m, nnz)
+    v = rng.standard_normal(nnz).astype(np.float32)
+    dense = np.zeros((n, m), np.float64)
+    np.add.at(dense, (r, c), v)
+    csr = graph.coo_to_csr_coalesced(r, c, v, n, m)
+
+    def to_dense(x):
+        out = np.zeros((x.n_rows, x.n_cols))
+        rp, col, val = x.rowptr.numpy(), x.col.numpy(), x.val.numpy()
+        for i in range(x.n_rows):
+            assert np.all(np.diff(col[rp[i]:rp[i + 1]]) > 0)       # coalesced: strictly ascending columns
+            out[i, col[rp[i]:rp[i + 1]]] = val[rp[i]:rp[i + 1]]
+        return out
+    assert np.allclose(to_dense(csr), dense, atol=1e-6)
+    t = csr.t()
+    assert np.allclose(to_dense(t), dense.T, atol=1e-6) and t.t() is csr
+
+
+def test_user_hist_and_dict(oracle, baby):
+    from chaorec_amd import graph
+    d = graph.user_item_dict_from_edges(baby["train"])
+    rp, col = graph.user_hist_csr(d, baby["U"])
+    want = oracle.user_hist_csr(baby["train"], baby["U"])
+    assert np.array_equal(rp.numpy(), want[0]) and np.array_equal(col.numpy(), want[1])
+    rp2, col2 = graph.user_hist_csr_from_edges(baby["train"], baby["U"])
+    assert np.array_equal(rp2.numpy(), want[0]) and np.array_equal(col2.numpy(), want[1])
+
+
+def test_gene_metrics_matches_reference_and_oracle(oracle, baby):
+    from chaorec_amd import utils
+    g = load_golden("metrics_baby_fixed_rank.npz")
+    U, I = baby["U"], baby["I"]
+    fixed_rank = np.stack([np.random.default_rng(1000 + u).permutation(I)[:50] + U for u in range(U)])
+    k_list = [int(k) for k in g["k_list"]]
+    m = utils.gene_metrics(baby["val"], torch.from_numpy(fixed_rank), k_list)
+    got = np.array([[m[k][n] for n in g["metric_names"]] for k in k_list])
+    assert np.allclose(got, g["val_metrics"], rtol=1e-12, atol=0)          # the reference's own numbers
+    # ragged / edge cases against the loop-form oracle: empty positive lists, duplicates, k > hits
+    rng = np.random.default_rng(1)
+    data = [[u] + rng.integers(U, U + 60, rng.integers(0, 6)).tolist() for u in range(200)]
+    data[3] = [3]
+    data[4] = [4, U + 1, U + 1, U + 2]
+    rank = rng.integers(U, U + 60, (200, 50))
+    rank[7] = np.arange(U, U + 50)
+    mine = utils.gene_metrics(data, rank, [1, 5, 20, 50])
+    ref = oracle.gene_metrics(data, rank, [1, 5, 20, 50])
+    for k in ref:
+        for name in ref[k]:
+            assert mine[k][name] == pytest.approx(ref[k][name], rel=1e-12, abs=1e-15), (k, name)
+
+
+def test_per_user_metric_functions(oracle):
+    from chaorec_amd import metrics
+    ranked, test = [5, 3, 9, 1, 7], [9, 7, 2]
+    assert metrics.precision_at_k(ranked, test, 5) == 2 / 5
+    assert metrics.recall_at_k(ranked, test, 5) == 2 / 3
+    assert metrics.recall_at_k(ranked, [], 5) == 0
+    assert metrics.hit_rate_at_k(ranked, test, 2) == 0 and metrics.hit_rate_at_k(ranked, test, 3) == 1
+    idcg = sum(1 / np.log(i + 2) for i in range(3))
+    assert metrics.ndcg_at_k(ranked, test, 5) == pytest.approx((1 / np.log(4) + 1 / np.log(6)) / idcg)
+    assert metrics.map_at_k(ranked, test, 5) == pytest.approx((1 / 3 + 2 / 5) / 3)
+
+
+def test_training_dataset_contract():
+    import random
+    from chaorec_amd import dataload, graph
+    g = load_golden("sampler_tiny.npz")
+    U, I, e = int(g["U"]), int(g["I"]), g["edges"]
+    d = graph.user_item_dict_from_edges(e)
+    ds = dataload.TrainingDataset(U, I, d, e)
+    random.seed(0)
+    hist = np.zeros((U, I), np.int64)
+    for _ in range(300):
+        for idx in range(len(ds)):
+            u, p, n = ds[idx]
+            assert (u, p) == tuple(e[idx]) and n not in d[u] and U <= n < U + I
+            hist[u, n - U] += 1
+    assert np.array_equal(hist > 0, g["neg_hist"] > 0)      # same support as the reference's sampler
+    mm = dataload.TrainingDataset(U, I, d, e, "MMGCN")[0]
+    assert mm[0].tolist() == [0, 0] and mm[1][0].item() == e[0][1] and mm[0].dtype == torch.int64
+
+
+def test_cli_and_yaml():
+    from chaorec_amd.arg_parser import parse_args, load_yaml_config
+    a = parse_args(["--Model", "FREEDOM", "--data_path", "clothing", "--topk", "5", "10"])
+    assert a.topk == [5, 10] and a.batch_size == 1024 and a.dim_E == 64 and a.seed == 42
+    assert load_yaml_config("LightGCN")["n_layers"] == [1, 2, 3]
+    f = load_yaml_config("FREEDOM")
+    assert f["lambda_coeff"] == [0.8] and f["dropout"] == [0.1] and f["ii_topk"] == [10]
+    assert load_yaml_config("MMGCN")["reg_weight"] == [0.0001]
+
+
+def test_synthetic_graph_shape():
+    from chaorec_amd.synthetic import synthetic_interactions, synthetic_eval_lists
+    e = synthetic_interactions(2000, 900, 9000, seed=3)
+    assert e.shape == (9000, 2) and e.dtype == np.int32
+    assert np.all(np.diff(e[:, 0]) >= 0) and e[:, 1].min() >= 2000 and e[:, 1].max() < 2900
+    assert len(np.unique(e[:, 0].astype(np.int64) * 10000 + e[:, 1])) == 9000
+    assert np.bincount(e[:, 0], minlength=2000).min() >= 3
+    ev = synthetic_eval_lists(50, 900, e[e[:, 0] < 50], 2)
+    seen = set(map(tuple, e.tolist()))
+    assert all((r[0], i) not in seen for r in ev for i in r[1:])
+
+
+def test_early_stopping():
+    from chaorec_amd.utils import EarlyStopping
+    es = EarlyStopping(patience=2, verbose=False)
+    for s in (0.1, 0.2, 0.15, 0.2, 0.1, 0.05):
+        es(s, {"s": s})
+    assert es.early_stop and es.best_score == 0.2
