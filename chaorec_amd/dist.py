@@ -1,0 +1,197 @@
+"""User-row sharding of the hot path over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference is single-process; this is the MI355X-native scale-out of the same
+arithmetic.  With A = [[0, B], [B^T, 0]] (B = normalised user x item block):
+  * rank g owns a contiguous range of users (balanced by nnz), their embedding rows / Adam state, and the
+    rows B_g of B; the item table [I, D] is replicated;
+  * a layer is   y_u(g) = B_g x_i            -- local CSR SpMM, no communication
+                 y_i    = sum_g B_g^T x_u(g)  -- local CSR SpMM into an [I, D] partial, then ONE all-reduce;
+  * backward mirrors it (g_xu(g) = B_g g_yi local; g_xi = all-reduce of B_g^T g_yu(g)), which is also the
+    "all-reduce on gradients" of the replicated item table;
+  * BPR terms are evaluated by the rank that owns the user; the loss is the mean over ranks;
+  * evaluation is embarrassingly parallel over users (each rank ranks its users against the replicated items).
+Sums over ranks change the fp32 association, so N>1 equals N=1 to rounding (1e-6), not bit for bit.
+
+`spmm_fn` is injectable so the communication pattern is covered by world_size-2 gloo tests on CPU
+(tests/test_dist_gloo.py pass an oracle-backed stand-in; the product default is the HIP kernel).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import graph, ops
+
+
+def partition_users_by_nnz(user_deg, world):
+    """Contiguous user ranges with ~equal edge counts (degrees are heavy-tailed: SURVEY 8(e))."""
+    csum = np.concatenate([[0], np.cumsum(np.asarray(user_deg, dtype=np.int64))])
+    total = csum[-1]
+    bounds = [0]
+    for g in range(1, world):
+        bounds.append(int(np.searchsorted(csum, total * g / world, side="left")))
+    bounds.append(len(user_deg))
+    for g in range(1, len(bounds)):
+        bounds[g] = max(bounds[g], bounds[g - 1])
+    return bounds
+
+
+class UserShard:
+    """Rank-local graph blocks: `ui` rows = local users / cols = items, `iu` rows = items / cols = local users."""
+
+    def __init__(self, edges, num_user, num_item, world, rank, device):
+        e = np.asarray(edges, dtype=np.int64)
+        u, i = e[:, 0], e[:, 1] - num_user
+        deg_u = np.bincount(u, minlength=num_user)
+        deg_i = np.bincount(i, minlength=num_item)
+        self.bounds = partition_users_by_nnz(deg_u, world)
+        self.u0, self.u1 = self.bounds[rank], self.bounds[rank + 1]
+        self.num_user_global, self.num_item, self.world, self.rank = num_user, num_item, world, rank
+        sel = (u >= self.u0) & (u < self.u1)
+        ul, il = u[sel] - self.u0, i[sel]
+        # same fp32 normalisation as graph.lightgcn_csr, with GLOBAL degrees
+        dis_u = torch.from_numpy(deg_u.astype(np.float32)).pow(-0.5)
+        dis_i = torch.from_numpy(deg_i.astype(np.float32)).pow(-0.5)
+        w = dis_u[torch.from_numpy(u[sel])] * dis_i[torch.from_numpy(il)]
+        n_local = self.u1 - self.u0
+        self.ui = graph.coo_to_csr(ul, il, w, n_local, num_item).to(device)        # y_u = B_g x_i
+        self.iu = graph.coo_to_csr(il, ul, w, num_item, n_local).to(device)        # p_i = B_g^T x_u
+        self.ui._t, self.iu._t = self.iu, self.ui
+        self.local_edges = np.stack([ul, il + n_local], 1).astype(np.int32)        # shard-local id convention
+        self.num_user_local = n_local
+
+
+def _all_reduce(t, group):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class _ShardedLayerMean(torch.autograd.Function):
+    """LightGCN.forward (Model/LightGCN.py:76-95) on a user shard: L x (2 local SpMM + 1 all-reduce)."""
+
+    @staticmethod
+    def forward(ctx, xu, xi, shard, n_layers, spmm_fn, group):
+        w = 1.0 / (n_layers + 1)
+        fu, fi = xu * w, xi * w
+        cu, ci = xu, xi
+        for _ in range(n_layers):
+            yu = spmm_fn(shard.ui, ci)
+            pi = spmm_fn(shard.iu, cu)
+            _all_reduce(pi, group)
+            fu = fu.add_(yu, alpha=w)
+            fi = fi.add_(pi, alpha=w)
+            cu, ci = yu, pi
+        ctx.shard, ctx.n_layers, ctx.w, ctx.spmm_fn, ctx.group = shard, n_layers, w, spmm_fn, group
+        return fu, fi
+
+    @staticmethod
+    def backward(ctx, Gu, Gi):
+        # Gi is this rank's PARTIAL gradient of the replicated item rows (its own batch terms); the rank sum is
+        # folded into the per-layer all-reduce:  g_i <- allreduce(B_g^T g_u + w * Gi_partial)
+        shard, L, w, spmm_fn, group = ctx.shard, ctx.n_layers, ctx.w, ctx.spmm_fn, ctx.group
+        Gu, Gi = Gu.contiguous(), Gi.contiguous()
+        Gi_full = _all_reduce(Gi.clone(), group)       # layer-L seed needs the full item gradient
+        gu, gi = Gu * w, Gi_full * w
+        for _ in range(L):
+            nu = spmm_fn(shard.ui, gi).add_(Gu, alpha=w)
+            pi = spmm_fn(shard.iu, gu).add_(Gi, alpha=w)
+            _all_reduce(pi, group)
+            gu, gi = nu, pi
+        return gu, gi, None, None, None, None
+
+
+def sharded_layer_mean_propagate(xu, xi, shard, n_layers, spmm_fn=None, group=None):
+    return _ShardedLayerMean.apply(xu, xi, shard, n_layers, spmm_fn or ops.spmm_raw, group)
+
+
+class ShardedLightGCN(nn.Module):
+    """LightGCN on one user shard.  Ids are shard-local: users [0, U_g), items U_g + [0, I) (the reference's
+    'global item id = item + num_user' convention, per shard).  Item parameters are replicated: their
+    gradient leaves backward already summed over ranks, so every rank applies the same Adam update."""
+
+    def __init__(self, shard, user_item_dict_local, dim_E, reg_weight, n_layers, device, seed=42, spmm_fn=None,
+                 bpr_fn=None, group=None):
+        super().__init__()
+        self.shard, self.device, self.group = shard, device, group
+        self.num_user, self.num_item = shard.num_user_local, shard.num_item
+        self.reg_weight, self.n_layers, self.dim_embedding = reg_weight, n_layers, dim_E
+        self.user_item_dict = user_item_dict_local
+        self.spmm_fn, self.bpr_fn = spmm_fn, bpr_fn
+        # one global initialisation, sliced: identical to the single-GPU model under the same seed
+        g = torch.Generator().manual_seed(seed)
+        bound_u = (6.0 / (shard.num_user_global + dim_E)) ** 0.5     # nn.init.xavier_uniform_ bounds
+        bound_i = (6.0 / (shard.num_item + dim_E)) ** 0.5
+        full_u = (torch.rand(shard.num_user_global, dim_E, generator=g) * 2 - 1) * bound_u
+        full_i = (torch.rand(shard.num_item, dim_E, generator=g) * 2 - 1) * bound_i
+        self.user_embedding = nn.Embedding.from_pretrained(full_u[shard.u0:shard.u1].clone(), freeze=False)
+        self.item_embedding = nn.Embedding.from_pretrained(full_i, freeze=False)
+        rowptr, col = graph.user_hist_csr(user_item_dict_local, self.num_user)
+        self.hist = (rowptr.to(device), col.to(device))
+        self.graph = shard.ui
+        self.result_u = self.result_i = self.result = None
+
+    def forward(self):
+        fu, fi = sharded_layer_mean_propagate(self.user_embedding.weight, self.item_embedding.weight, self.shard,
+                                              self.n_layers, self.spmm_fn, self.group)
+        self.result_u, self.result_i = fu, fi
+        self.result = torch.cat((fu, fi), 0)
+        return fu, fi
+
+    def loss(self, users, pos_items, neg_items):
+        pos_items = pos_items - self.num_user
+        neg_items = neg_items - self.num_user
+        users, pos_items, neg_items = users.to(self.device), pos_items.to(self.device), neg_items.to(self.device)
+        fu, fi = self.forward()
+        bpr = self.bpr_fn or ops.bpr_loss
+        out = bpr(fu, fi, users, pos_items, neg_items, ops.VARIANT_LOG_SIGMOID_EPS, self.reg_weight)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        return out[0] / world          # global loss = mean over ranks; item grads are SUMMED by the all-reduce
+
+    def gene_ranklist(self, topk=50, gather=False):
+        """Rank this shard's users against the replicated item table; ids are GLOBAL (item + U_global)."""
+        with torch.no_grad():
+            idx, _ = ops.score_topk(self.result_u.detach(), self.result_i.detach(), self.hist, 1e-6, topk,
+                                    id_offset=self.shard.num_user_global)
+        if gather and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return gather_ranklists(idx, self.shard, self.group)
+        return idx.cpu()
+
+    def local_user_ids(self, users):
+        return users
+
+
+def gather_ranklists(idx_local, shard, group=None):
+    """all_gather of the per-rank [U_g, K] lists into [U, K] in user order (no exchange inside the scoring)."""
+    world = dist.get_world_size(group)
+    K = idx_local.shape[1]
+    sizes = [shard.bounds[g + 1] - shard.bounds[g] for g in range(world)]
+    pad = max(sizes)
+    buf = torch.zeros((pad, K), dtype=idx_local.dtype, device=idx_local.device)
+    buf[:idx_local.shape[0]] = idx_local
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], 0).cpu()
+
+
+class WeakScalingJob:
+    pass
+
+
+def build_weak_scaling_job(U1, I, E1, world, rank, D, L, reg, device, seed=42):
+    """bench.py at N GPUs: one synthetic graph with N x U1 users over the same I items (every rank generates it
+    from the same seed), sharded by user rows; per-rank work stays that of the N=1 configuration."""
+    from .synthetic import synthetic_interactions
+    U = U1 * world
+    edges = synthetic_interactions(U, I, E1 * world, seed=seed)
+    shard = UserShard(edges, U, I, world, rank, device)
+    uid_local = graph.user_item_dict_from_edges(shard.local_edges)
+    for u in range(shard.num_user_local):
+        uid_local.setdefault(u, [])
+    job = WeakScalingJob()
+    job.model = ShardedLightGCN(shard, uid_local, D, reg, L, device, seed=seed).to(device)
+    job.local_edges = shard.local_edges
+    job.num_user_local = shard.num_user_local
+    job.shard = shard
+    job.local_user_ids = lambda users: users
+    return job

@@ -1,0 +1,128 @@
+"""N>1 path on CPU: world_size-2 gloo processes run the user-sharded LightGCN propagate / loss / backward
+with an oracle-backed stand-in for the HIP kernels (the product has no CPU kernels), and must reproduce the
+single-process oracle on the full graph.  Covers the partition, the per-layer all-reduce pattern and the
+gradient all-reduce."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _oracle_spmm(csr, x):
+    from oracle import oracle
+    y = oracle.spmm((csr.rowptr.numpy(), csr.col.numpy(), csr.val.numpy()), x.detach().numpy())
+    return torch.from_numpy(y)
+
+
+class _OracleBPR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tu, ti, users, pos, neg, variant, reg):
+        from oracle import oracle
+        out, coef = oracle.bpr_fwd(tu.detach().numpy(), ti.detach().numpy(), users.numpy(), pos.numpy(), neg.numpy(),
+                                   variant, reg)
+        ctx.save_for_backward(tu, ti, users, pos, neg)
+        ctx.coef, ctx.reg = coef, reg
+        return torch.tensor(out, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import oracle
+        tu, ti, users, pos, neg = ctx.saved_tensors
+        gu, gi = oracle.bpr_bwd(tu.detach().numpy(), ti.detach().numpy(), users.numpy(), pos.numpy(), neg.numpy(),
+                                ctx.coef, ctx.reg, float(g[0]))
+        return torch.from_numpy(gu).float(), torch.from_numpy(gi).float(), None, None, None, None, None
+
+
+def _bpr(tu, ti, users, pos, neg, variant, reg):
+    return _OracleBPR.apply(tu, ti, users, pos, neg, variant, reg)
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from chaorec_amd import dist as cdist, graph
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D, L, B = 600, 250, 3000, 16, 2, 64
+    edges = synthetic_interactions(U, I, E, seed=5)
+    shard = cdist.UserShard(edges, U, I, world, rank, torch.device("cpu"))
+    uid = graph.user_item_dict_from_edges(shard.local_edges)
+    for u in range(shard.num_user_local):
+        uid.setdefault(u, [])
+    m = cdist.ShardedLightGCN(shard, uid, D, 1e-3, L, torch.device("cpu"), seed=9, spmm_fn=_oracle_spmm, bpr_fn=_bpr)
+    # per-rank batch drawn from the rank's own edges
+    rng = np.random.default_rng(100 + rank)
+    sel = rng.choice(len(shard.local_edges), B, replace=False)
+    users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64))
+    pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64))
+    neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + I, B))
+    loss = m.loss(users, pos, neg)
+    loss.backward()
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), u0=shard.u0, u1=shard.u1, bounds=np.array(shard.bounds),
+             fu=m.result_u.detach().numpy(), fi=m.result_i.detach().numpy(), loss=float(loss),
+             gu=m.user_embedding.weight.grad.numpy(), gi=m.item_embedding.weight.grad.numpy(),
+             xu=m.user_embedding.weight.detach().numpy(), xi=m.item_embedding.weight.detach().numpy(),
+             users=users.numpy() + shard.u0, pos=pos.numpy() - shard.num_user_local,
+             neg=neg.numpy() - shard.num_user_local, nnz=shard.ui.nnz)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_lightgcn_matches_single_process_oracle(oracle):
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
+        r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D, L = 600, 250, 3000, 16, 2
+    edges = synthetic_interactions(U, I, E, seed=5)
+    # partition: contiguous, covering, balanced by nnz
+    assert r[0]["u0"] == 0 and r[0]["u1"] == r[1]["u0"] and r[1]["u1"] == U
+    assert abs(int(r[0]["nnz"]) - int(r[1]["nnz"])) < 0.1 * E
+    # same replicated item parameters on both ranks, user parameters are slices of one global init
+    assert np.array_equal(r[0]["xi"], r[1]["xi"])
+    x0 = np.concatenate([r[0]["xu"], r[1]["xu"], r[0]["xi"]], 0)
+    csr = oracle.lightgcn_csr(edges, U + I)
+    final, _ = oracle.lightgcn_forward(x0, csr, L)
+    fu = np.concatenate([r[0]["fu"], r[1]["fu"]], 0)
+    assert np.allclose(fu, final[:U], rtol=1e-5, atol=1e-7)
+    for k in range(world):
+        assert np.allclose(r[k]["fi"], final[U:], rtol=1e-5, atol=1e-7)      # replicated after the all-reduce
+    # global loss = mean over ranks of the per-rank batch losses; gradients = d(global loss)
+    outs, g_tot = [], np.zeros((U + I, D))
+    for k in range(world):
+        out, g = oracle.lightgcn_loss(x0, csr, L, U, r[k]["users"], r[k]["pos"], r[k]["neg"], 1e-3)
+        outs.append(out[0])
+        g_tot += g / world
+        assert r[k]["loss"] == pytest.approx(out[0] / world, rel=1e-5)
+    gu = np.concatenate([r[0]["gu"], r[1]["gu"]], 0)
+    assert np.allclose(gu, g_tot[:U], rtol=2e-4, atol=1e-9)
+    assert np.allclose(r[0]["gi"], g_tot[U:], rtol=2e-4, atol=1e-9)
+    assert np.array_equal(r[0]["gi"], r[1]["gi"])                              # identical item update on every rank
+
+
+def test_partition_users_by_nnz():
+    from chaorec_amd.dist import partition_users_by_nnz
+    deg = np.array([1000] + [1] * 999)
+    b = partition_users_by_nnz(deg, 4)
+    assert b[0] == 0 and b[-1] == 1000 and all(b[i] <= b[i + 1] for i in range(4))
+    deg = np.full(800, 5)
+    assert partition_users_by_nnz(deg, 8) == [100 * k for k in range(9)]
