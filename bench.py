@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--dim", type=int, default=64)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph step")
+    p.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP Adam")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     return p.parse_args()
 
@@ -111,11 +113,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    local_rank %= torch.cuda.device_count()     # (lets a 1-GPU box exercise the N>1 code path with gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from chaorec_amd import _lib, graph, ops
     from chaorec_amd.Model import LightGCN
@@ -129,8 +136,7 @@ def main():
         U = U1
         edges = synthetic_interactions(U1, I, E1, seed=42)
         torch.manual_seed(42)
-        model = LightGCN(U, I, edges, None if False else graph.user_item_dict_from_edges(edges), D, reg, L, "add",
-                         dev).to(dev)
+        model = LightGCN(U, I, edges, graph.user_item_dict_from_edges(edges), D, reg, L, "add", dev).to(dev)
         sharded = None
     else:
         from chaorec_amd import dist as cdist
@@ -139,22 +145,35 @@ def main():
 
     E = len(edges)
     e_dir = 2 * E
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else FusedAdam(model.parameters(), lr=1e-3)
     edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
     loss_sum = torch.zeros((), device=dev)
 
-    def step(i):
+    def draw(i):
         sel = torch.randint(0, E, (B,), device=dev, generator=gen)   # DataLoader(shuffle=True) stand-in
         users, pos = edges_dev[sel, 0], edges_dev[sel, 1]
-        neg = ops.sample_negatives(model.hist, users if sharded is None else sharded.local_user_ids(users), I,
-                                   42, i, model.num_user)
-        opt.zero_grad(set_to_none=True)
-        loss = model.loss(users, pos, neg)
-        loss.backward()
-        opt.step()
-        loss_sum.add_(loss.detach())   # the reference's per-batch loss.item() sync is kept off the device path
+        neg = ops.sample_negatives(model.hist, users, I, 42 + rank, i, model.num_user)
+        return users, pos, neg
+
+    # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph (the sharded path
+    # holds RCCL calls and stays eager)
+    use_graph = not args.no_graph and not args.torch_adam and sharded is None
+    graphed = GraphedTrainStep(model, opt, draw(0)) if use_graph else None
+
+    def step(i, force_eager=False):
+        users, pos, neg = draw(i)
+        if graphed is not None and not force_eager:
+            loss = graphed(users, pos, neg)
+        else:
+            opt.zero_grad(set_to_none=True)
+            loss = model.loss(users, pos, neg)
+            loss.backward()
+            opt.step()
+            loss = loss.detach()
+        loss_sum.add_(loss)   # the reference's per-batch loss.item() sync is kept off the device path
 
     def barrier():
         torch.cuda.synchronize()
@@ -175,29 +194,40 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    msgs_per_step_all = 2 * L * e_dir * world
+    e_dir_all = e_dir
+    if world > 1:
+        t = torch.tensor([float(e_dir)], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t)
+        e_dir_all = int(t.item())
+    msgs_per_step_all = 2 * L * e_dir_all
     value = msgs_per_step_all / (dt / args.steps)
 
     # --- SpMM roofline: events around every SpMM launch of further, identical steps ---------------
     spmm_times = []
     orig = ops.spmm_raw
 
-    def timed_spmm(*a, **k):
+    def timed_spmm(csr, x, *a, **k):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        out = orig(*a, **k)
+        out = orig(csr, x, *a, **k)
         e.record()
-        spmm_times.append((s, e))
+        spmm_times.append((s, e, spmm_model_bytes(csr.nnz, csr.n_rows, x.shape[1]),
+                           2 * csr.n_rows * 4 * x.shape[1] + csr.nnz * 8))
         return out
 
     ops.spmm_raw = timed_spmm
+    if sharded is not None:
+        sharded.model.spmm_fn = timed_spmm
     for i in range(min(args.steps, 50)):
-        step(args.warmup + args.steps + i)
+        step(args.warmup + args.steps + i, force_eager=True)
     ops.spmm_raw = orig
+    if sharded is not None:
+        sharded.model.spmm_fn = None
     torch.cuda.synchronize()
-    avg_spmm_ms = float(np.mean([s.elapsed_time(e) for s, e in spmm_times]))
-    nnz, n_rows = model.graph.nnz, model.graph.n_rows
-    model_bytes = spmm_model_bytes(nnz, n_rows, D)
+    avg_spmm_ms = float(np.mean([s.elapsed_time(e) for s, e, _, _ in spmm_times]))
+    model_bytes = float(np.mean([b for _, _, b, _ in spmm_times]))
+    compulsory = float(np.mean([c for _, _, _, c in spmm_times]))
+    n_rows = model.graph.n_rows
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "spmm_traffic.json")
@@ -209,7 +239,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "spmm_csr_ordered_kernel<16,1>", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": model_bytes, "avg_launch_us": avg_spmm_ms * 1e3,
-                "compulsory_bytes_per_launch": 2 * n_rows * 4 * D + nnz * 8,
+                "compulsory_bytes_per_launch": compulsory,
                 "note": "embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is "
                         "against the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)"
                         % (n_rows * D * 4 / 1e6)}
@@ -224,7 +254,7 @@ def main():
         res = model.result.detach()
         for s, e in ev:
             s.record()
-            ops.score_topk(res[:U], res[model.num_user:model.num_user + I], model.hist, 1e-6, 50,
+            ops.score_topk(res[:model.num_user], res[model.num_user:model.num_user + I], model.hist, 1e-6, 50,
                            id_offset=model.num_user)
             e.record()
     torch.cuda.synchronize()
@@ -233,7 +263,12 @@ def main():
         t = torch.tensor([score_ms], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         score_ms = float(t.item())
-    users_per_s = U * world / (score_ms * 1e-3)
+    n_scored = U
+    if world > 1:
+        t = torch.tensor([float(U)], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t)
+        n_scored = float(t.item())
+    users_per_s = n_scored / (score_ms * 1e-3)
     score_flops = 2.0 * U * I * D
     roofline_scoring = {"bound": "mfma", "kernel": "score_topk_f32_kernel<64>", "achieved": score_flops / (score_ms * 1e-3) / 1e12,
                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -247,9 +282,11 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"LightGCN train step on {args.dataset}-shaped synthetic graph "
-                               f"(U={U}x{world}, I={I}, E_dir={e_dir}x{world}), dim={D}, n_layers={L}, batch={B}; "
+                               f"(U={U1}x{world}, I={I}, E_dir={e_dir_all}), dim={D}, n_layers={L}, batch={B}x{world}; "
                                f"gene_ranklist top-50 over all users",
                    "messages_per_step": msgs_per_step_all, "gene_ranklist_ms": score_ms,
+                   "launch": "captured hipGraph per step" if graphed is not None else "eager launches",
+                   "optimizer": "torch.optim.Adam" if args.torch_adam else "FusedAdam (chaorec_adam_step_f32)",
                    "parallelism": "single GPU" if world == 1 else f"user-row shards x{world}, item all-reduce per layer"},
         "roofline": roofline, "roofline_scoring": roofline_scoring,
         "loss_mean": float(loss_sum.item()) / (args.steps + args.warmup + min(args.steps, 50)),

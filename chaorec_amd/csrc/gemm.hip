@@ -103,7 +103,18 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p,
                                                         const float *__restrict__ g,
                                                         float *__restrict__ m, float *__restrict__ v,
                                                         int64_t n, float lr, float b1, float b2,
-                                                        float eps, float wd, float bc1, float bc2_sqrt) {
+                                                        float eps, float wd, int step_host,
+                                                        const int32_t *__restrict__ step_dev) {
+  // bias corrections in double, as torch does with python floats; once per block.  The step count may
+  // live in device memory so a captured hipGraph replays with the right correction every time.
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const int step = step_dev ? step_dev[0] : step_host;
+    bc[0] = (float)(1.0 - pow((double)b1, (double)step));
+    bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  }
+  __syncthreads();
+  const float bc1 = bc[0], bc2_sqrt = bc[1];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float gi = g[i];
@@ -140,18 +151,14 @@ extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const 
 extern "C" int chaorec_adam_step_f32(float *param, const float *grad, float *exp_avg,
                                      float *exp_avg_sq, int64_t n, float lr, float beta1,
                                      float beta2, float eps, float weight_decay, int32_t step,
-                                     void *stream) {
+                                     const int32_t *step_dev, void *stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(CHAOREC_E_INVALID, "adam: NULL argument");
-  if (n < 0 || step < 1) return fail(CHAOREC_E_INVALID, "adam: n=%lld step=%d", (long long)n, step);
+  if (n < 0 || (!step_dev && step < 1)) return fail(CHAOREC_E_INVALID, "adam: n=%lld step=%d", (long long)n, step);
   if (n == 0) return CHAOREC_OK;
-  // bias corrections in double on the host, as torch does with python floats
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048 * 4) blocks = 2048 * 4;
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
-                     grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-                     (float)sqrt(bc2));
+                     grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, step_dev);
   return check_launch("adam_step_kernel");
 }
 

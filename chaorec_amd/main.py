@@ -15,6 +15,7 @@ from . import dataload
 from .Model import FREEDOM, LightGCN, MMGCN
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
+from .optim import FusedAdam
 from .utils import get_local_time, gpu, setup_seed
 
 
@@ -80,7 +81,8 @@ def main(argv=None):
             setattr(args, key, value)
         model = build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_feat, device)
         model.to(device)
-        optimizer = torch.optim.Adam([{'params': model.parameters(), 'lr': args.learning_rate}])
+        # reference: torch.optim.Adam (main.py:397); same update, one fused launch per tensor
+        optimizer = FusedAdam([{'params': model.parameters(), 'lr': args.learning_rate}])
         current = train_and_evaluate(model, train_loader, val_data, test_data, optimizer, args.num_epoch,
                                      model_name=args.Model, topk=args.topk, patience=args.patience)
         recall = current[20]['recall'] if 20 in current else current[max(current)]['recall']

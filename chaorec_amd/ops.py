@@ -245,26 +245,12 @@ def linear(x, weight, bias=None, act=0):
     return _Linear.apply(x, weight, bias, act)
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+              step_dev=None):
+    """One fused Adam launch over a flat fp32 tensor.  `step_dev` (int32 device scalar) overrides `step` so the
+    launch can be captured in a hipGraph."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq, step_dev)
     rc = _lib.load().chaorec_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
-                                           lr, betas[0], betas[1], eps, weight_decay, step, _stream())
+                                           lr, betas[0], betas[1], eps, weight_decay, int(step), _ptr(step_dev),
+                                           _stream())
     _lib.check(rc, "chaorec_adam_step_f32")
-
-
-class _SpMMAdd(torch.autograd.Function):
-    """y = A x + z in one launch (FREEDOM's `i_g_embeddings + h`, Model/FREEDOM.py:168,181)."""
-
-    @staticmethod
-    def forward(ctx, x, z, csr):
-        ctx.csr = csr
-        return spmm_raw(csr, x, z=_f32c(z), beta=1.0)
-
-    @staticmethod
-    def backward(ctx, gy):
-        gy = gy.contiguous()
-        return spmm_raw(ctx.csr.t(), gy), gy, None
-
-
-def spmm_add(csr, x, z):
-    return _SpMMAdd.apply(x, z, csr)

@@ -1,0 +1,82 @@
+"""Adam on the fused HIP kernel + whole-step hipGraph capture.
+
+FusedAdam: torch.optim.Adam's update (defaults of main.py:397) as ONE launch per parameter tensor instead of
+the ~8 foreach kernels torch issues; the step counter lives on the device so the launch is capturable.
+
+GraphedTrainStep: captures zero_grad -> model.loss -> backward -> optimizer.step into one hipGraph (via
+torch.cuda.CUDAGraph: every chaorec kernel is enqueued on the capturing stream) and replays it per batch from
+static input buffers: the launch-bound inner loop of train_and_evaluate.py:43-48 without per-kernel host cost.
+"""
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._step_dev = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if self._step_dev is None:
+                    self._step_dev = torch.zeros(1, dtype=torch.int32, device=p.device)
+                break
+        if self._step_dev is not None:
+            self._step_dev.add_(1)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
+                              group["eps"], group["weight_decay"], step_dev=self._step_dev)
+        return loss
+
+
+class GraphedTrainStep:
+    """step(*batch) == { optimizer.zero_grad(); loss = model.loss(*batch); loss.backward(); optimizer.step() },
+    replayed from one captured hipGraph.  Batch tensors must keep their shapes (the last, short batch of an
+    epoch falls back to the eager path).  Returns the (device) loss of the step."""
+
+    def __init__(self, model, optimizer, example_batch, warmup=3):
+        self.model, self.optimizer = model, optimizer
+        dev = next(model.parameters()).device
+        self.static = [b.to(dev).clone() for b in example_batch]
+        self.shapes = [tuple(b.shape) for b in self.static]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):   # also builds lazily cached state (graph orders, Adam moments)
+                self._eager(self.static)
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._eager(self.static)
+        self.replays = 0
+
+    def _eager(self, batch):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.model.loss(*batch)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, *batch):
+        if [tuple(b.shape) for b in batch] != self.shapes:
+            return self._eager([b.to(self.static[0].device) for b in batch])
+        for dst, src in zip(self.static, batch):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        self.replays += 1
+        return self.static_loss

@@ -14,15 +14,19 @@ MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM",)
 
 
-def train(model, train_loader, optimizer, model_name="LightGCN"):
+def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):
+    """One epoch.  `graphed` (optim.GraphedTrainStep) replays the captured step for full-size batches."""
     model.train()
     sum_loss = None
     for batch in train_loader:
-        optimizer.zero_grad()
-        loss = model.loss(*batch)
-        loss.backward()
-        optimizer.step()
-        d = loss.detach()
+        if graphed is not None:
+            d = graphed(*batch)
+        else:
+            optimizer.zero_grad()
+            loss = model.loss(*batch)
+            loss.backward()
+            optimizer.step()
+            d = loss.detach()
         sum_loss = d.clone() if sum_loss is None else sum_loss.add_(d)
     return float(sum_loss.item()) if sum_loss is not None else 0.0
 

@@ -175,10 +175,12 @@ int chaorec_gemm_f32(const float *A, const float *B, float *C, const float *bias
  * Fused Adam step over one flat fp32 parameter (torch.optim.Adam defaults, main.py:397):
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * t = *step_dev when step_dev != NULL (a device counter, so the launch can sit in a captured hipGraph),
+ * else `step`.
  * ------------------------------------------------------------------------------------- */
 int chaorec_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                           int64_t n, float lr, float beta1, float beta2, float eps,
-                          float weight_decay, int32_t step, void *stream);
+                          float weight_decay, int32_t step, const int32_t *step_dev, void *stream);
 
 #ifdef __cplusplus
 }

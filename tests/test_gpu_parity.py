@@ -427,3 +427,55 @@ def test_sports_size_properties(dev):
     tv, ti = torch.topk(sc, 50)
     assert torch.allclose(tv, val[sel], rtol=1e-5, atol=1e-7)
     assert (ti + U == idx[sel]).float().mean() > 0.999
+
+
+# ------------------------------------------------------------------------------------------ fused Adam / hipGraph step
+def test_graphed_step_equals_eager_and_torch_adam(dev):
+    """FusedAdam + the captured hipGraph step follow the same trajectory as eager torch.optim.Adam."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D, L, B = 1500, 800, 7000, 64, 2, 256
+    edges = synthetic_interactions(U, I, E, seed=2)
+    uid = graph.user_item_dict_from_edges(edges)
+    rng = np.random.default_rng(0)
+    batches = []
+    for _ in range(6):
+        b = rng.choice(E, B, replace=False)
+        batches.append((torch.from_numpy(edges[b, 0].astype(np.int64)).to(dev),
+                        torch.from_numpy(edges[b, 1].astype(np.int64)).to(dev),
+                        torch.from_numpy(rng.integers(U, U + I, B)).to(dev)))
+    results = {}
+    for mode in ("torch", "fused", "graph"):
+        torch.manual_seed(0)
+        m = LightGCN(U, I, edges, uid, D, 1e-3, L, "add", dev).to(dev)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2) if mode == "torch" else FusedAdam(m.parameters(), lr=1e-2)
+        losses = []
+        if mode == "graph":
+            w0 = [p.detach().clone() for p in m.parameters()]
+            g = GraphedTrainStep(m, opt, batches[0], warmup=2)
+            # capture warm-up stepped the model: restore parameters and optimizer state
+            with torch.no_grad():
+                for p, w in zip(m.parameters(), w0):
+                    p.copy_(w)
+                for st in opt.state.values():
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+                opt._step_dev.zero_()
+            for b in batches:
+                losses.append(float(g(*b)))
+            assert g.replays == len(batches)
+        else:
+            for b in batches:
+                opt.zero_grad()
+                loss = m.loss(*b)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        results[mode] = (losses, torch.cat([p.detach().flatten() for p in m.parameters()]).cpu().numpy())
+    for mode in ("fused", "graph"):
+        assert np.allclose(results[mode][0], results["torch"][0], rtol=1e-5), mode
+        assert np.allclose(results[mode][1], results["torch"][1], rtol=0, atol=5e-6), mode
+    assert np.array_equal(results["graph"][1], results["fused"][1]) or \
+        np.allclose(results["graph"][1], results["fused"][1], rtol=0, atol=1e-6)
