@@ -45,10 +45,10 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   const int sub = lane / LPR;
   const int li = lane % LPR;
   const int64_t wslot = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (wslot >= n_groups) return;  // wave-uniform
   // longest-first schedule: the host sorts the NG-row groups by their heaviest row so the long
-  // rows start at t=0 instead of stretching the tail (the output location is unchanged)
-  const int64_t wave = group_order ? (int64_t)group_order[wslot] : wslot;
+  // rows start at t=0 instead of stretching the tail (the output location is unchanged).
+  // Surplus waves of the last block stay (they take part in the block barriers below) with no rows.
+  const int64_t wave = wslot < n_groups ? (group_order ? (int64_t)group_order[wslot] : wslot) : n_groups;
   const int64_t r = wave * NG + sub;
   const bool row_ok = r < n_rows;
 
@@ -117,95 +117,85 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   // the ordered reduction goes through an 8 KiB LDS tile (every lane reads entry e of its own
   // float4 column, a broadcast read) instead of NG x 4 lane shuffles per entry.
   if constexpr (NG == 2 || NG == 4) {
+    // Block-cooperative, still sequential: the 4 waves of the workgroup take the row's 32-entry chunks
+    // round-robin.  Each wave gathers its chunk and parks the products in its own 8 KiB LDS tile while
+    // the previous chunks are being summed; the running sum is then handed from chunk to chunk through
+    // LDS (`carry`, ordered by the `seq` ticket), so only the adds -- ~8 cycles per entry -- are serial,
+    // not the memory latency.  The additions happen in entry order: bit-identical to one lane walking
+    // the row alone.
     constexpr int UH = 8;
-    constexpr int HALF = NG * UH;     // entries per half-step
-    constexpr int HPB = 64 / HALF;    // half-steps per 64-entry (col,val) block
-    __shared__ float4 red_all[4][HALF * LPR];
-    float4 *red = red_all[threadIdx.x >> 6];
-    unsigned long long lm = __ballot(is_long && li == 0);
-    while (lm) {
-      const int gl = (int)(__builtin_ctzll(lm) / LPR);
-      lm &= lm - 1;
-      const int owner = gl * LPR;
-      const int n = __shfl(deg, owner, 64);
-      const int64_t le0 = ((int64_t)__shfl((int)(e0 >> 32), owner, 64) << 32) |
-                          (int64_t)(unsigned int)__shfl((int)(e0 & 0xffffffffll), owner, 64);
-      const int nh = (n + HALF - 1) / HALF;
-      // ordered sum, one (or two) FEATURES per lane: entry e of the LDS tile is D consecutive
-      // floats, lane l adds floats [l*FPL, l*FPL+FPL) -- one v_add per entry instead of four
-      constexpr int FPL = LPR * 4 / 64;
-      float a[FPL];
-#pragma unroll
-      for (int f = 0; f < FPL; ++f) a[f] = 0.f;
-      const float *redf = reinterpret_cast<const float *>(red);
-      int bcur = 0;
-      int c0 = 0, c1 = 0;
-      float v0 = 0.f, v1 = 0.f;
-      if (lane < n) {
-        c0 = col[le0 + lane];
-        v0 = val[le0 + lane];
-      }
-      if (64 + lane < n) {
-        c1 = col[le0 + 64 + lane];
-        v1 = val[le0 + 64 + lane];
-      }
-      float4 xa[UH], xb[UH];
-      float va[UH], vb[UH];
-      auto gather = [&](int h, float4(&xv)[UH], float(&vv)[UH]) {
-        const int blk = h / HPB;
-        const int off = (h % HPB) * HALF;
-        const int cs = (blk == bcur) ? c0 : c1;
-        const float vs = (blk == bcur) ? v0 : v1;
+    constexpr int HALF = NG * UH;       // entries per chunk (32 for D=64, 16 for D=128)
+    constexpr int FPL = LPR * 4 / 64;   // features per lane in the ordered sum (1 or 2)
+    constexpr int MAXL = 4 * NG;        // rows per block
+    __shared__ float4 tile_all[4][HALF * LPR];
+    __shared__ float carry[64 * FPL];
+    __shared__ float4 long_sum[MAXL][LPR];
+    __shared__ long long long_e0[MAXL];
+    __shared__ int long_n[MAXL];
+    __shared__ int n_long_s, seq_s;
+    const int wv = threadIdx.x >> 6;
+    float4 *tile = tile_all[wv];
+    const float *tilef = reinterpret_cast<const float *>(tile);
+    if (threadIdx.x == 0) n_long_s = 0;
+    __syncthreads();
+    int my_slot = -1;
+    if (is_long && li == 0) {
+      my_slot = atomicAdd(&n_long_s, 1);
+      long_e0[my_slot] = e0;
+      long_n[my_slot] = deg;
+    }
+    my_slot = __shfl(my_slot, sub * LPR, 64);
+    __syncthreads();
+    const int nl = n_long_s;  // block-uniform
+    for (int t = 0; t < nl; ++t) {
+      const int n = long_n[t];
+      const int64_t le0 = long_e0[t];
+      const int nchunks = (n + HALF - 1) / HALF;
+      if (threadIdx.x == 0) seq_s = 0;
+      __syncthreads();
+      float4 xv[UH];
+      float vv[UH];
+      auto gather = [&](int k) {
+        int c = 0;
+        float v = 0.f;
+        if (lane < HALF && k * HALF + lane < n) {
+          c = col[le0 + k * HALF + lane];
+          v = val[le0 + k * HALF + lane];
+        }
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
-          const int idx = off + u * NG + sub;
-          const int cj = __shfl(cs, idx, 64);
-          vv[u] = __shfl(vs, idx, 64);
+          const int idx = u * NG + sub;
+          const int cj = __shfl(c, idx, 64);
+          vv[u] = __shfl(v, idx, 64);
           xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (h * HALF + u * NG + sub < n && li < D4) xv[u] = x4[(size_t)cj * (size_t)D4 + li];
+          if (k * HALF + idx < n && li < D4) xv[u] = x4[(size_t)cj * (size_t)D4 + li];
         }
       };
-      auto reduce = [&](int h, float4(&xv)[UH], float(&vv)[UH]) {
+      if (wv < nchunks) gather(wv);
+      for (int k = wv; k < nchunks; k += 4) {
 #pragma unroll
-        for (int u = 0; u < UH; ++u) red[(u * NG + sub) * LPR + li] = mul_rn4(vv[u], xv[u]);
-        __builtin_amdgcn_wave_barrier();
-        const int cntv = min(HALF, n - h * HALF);
+        for (int u = 0; u < UH; ++u) tile[(u * NG + sub) * LPR + li] = mul_rn4(vv[u], xv[u]);
+        if (k + 4 < nchunks) gather(k + 4);  // next chunk's loads fly while we wait for the carry
+        while (__hip_atomic_load(&seq_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k)
+          __builtin_amdgcn_s_sleep(1);
+        float a[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) a[f] = k == 0 ? 0.f : carry[lane * FPL + f];
+        const int cntv = min(HALF, n - k * HALF);
 #pragma unroll 8
         for (int e = 0; e < cntv; ++e) {
 #pragma unroll
-          for (int f = 0; f < FPL; ++f) a[f] = add_rn(a[f], redf[e * (LPR * 4) + lane * FPL + f]);
+          for (int f = 0; f < FPL; ++f) a[f] = add_rn(a[f], tilef[e * (LPR * 4) + lane * FPL + f]);
         }
-        __builtin_amdgcn_wave_barrier();
-      };
-      gather(0, xa, va);
-      if (1 < nh) gather(1, xb, vb);
-      for (int h = 0; h < nh; h += 2) {
-        reduce(h, xa, va);
-        if (h + 2 < nh) gather(h + 2, xa, va);
-        if (h + 1 < nh) reduce(h + 1, xb, vb);
-        if (h + 3 < nh) gather(h + 3, xb, vb);
-        if ((h + 2) / HPB > bcur) {  // every half of block bcur has been gathered: rotate
-          ++bcur;
-          c0 = c1;
-          v0 = v1;
-          c1 = 0;
-          v1 = 0.f;
-          const int nb = (bcur + 1) * 64 + lane;
-          if (nb < n) {
-            c1 = col[le0 + nb];
-            v1 = val[le0 + nb];
-          }
-        }
-      }
-      // back to the float4-per-lane row layout of the owning group
-      float *redw = reinterpret_cast<float *>(red);
+        float *dst = (k == nchunks - 1) ? reinterpret_cast<float *>(long_sum[t]) : carry;
 #pragma unroll
-      for (int f = 0; f < FPL; ++f) redw[lane * FPL + f] = a[f];
-      __builtin_amdgcn_wave_barrier();
-      const float4 arow = red[li];
-      __builtin_amdgcn_wave_barrier();
-      if (sub == gl) sum[0] = arow;
+        for (int f = 0; f < FPL; ++f) dst[lane * FPL + f] = a[f];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&seq_s, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __syncthreads();
     }
+    if (my_slot >= 0) sum[0] = long_sum[my_slot][li];
   } else if constexpr (NG > 1) {
     unsigned long long lm = __ballot(is_long && li == 0);
     while (lm) {

@@ -31,9 +31,12 @@ class CSR:
         return CSR(self.rowptr.to(device), self.col.to(device), self.val.to(device), self.n_rows,
                    self.n_cols, self.symmetric, t)
 
-    def group_order(self, rows_per_wave):
-        """Longest-first schedule for the SpMM kernel: permutation (int32, on the graph's device) of the
-        groups of `rows_per_wave` consecutive rows, sorted by their heaviest row, descending."""
+    def group_order(self, rows_per_wave, waves_per_block=4):
+        """Schedule for the SpMM kernel: permutation (int32, on the graph's device) of the groups of
+        `rows_per_wave` consecutive rows.  Groups are sorted by their heaviest row, then dealt out so that
+        block b (= `waves_per_block` consecutive wave slots) receives the b-th heaviest group plus one group
+        from each lighter quantile: long rows start first AND land in different workgroups (a workgroup walks
+        its long rows one at a time)."""
         g = int(rows_per_wave)
         if g <= 0:
             return None
@@ -44,7 +47,13 @@ class CSR:
             if pad:
                 deg = torch.cat([deg, torch.zeros(pad, dtype=deg.dtype)])
             heavy = deg.view(n_groups, g).max(dim=1).values
-            order = torch.argsort(heavy, descending=True, stable=True).to(torch.int32)
+            order = torch.argsort(heavy, descending=True, stable=True)
+            w = int(waves_per_block)
+            nb = (n_groups + w - 1) // w
+            slots = torch.full((nb * w,), -1, dtype=torch.int64)
+            slots[:n_groups] = order
+            order = slots.view(w, nb).t().reshape(-1)      # slot 4*b + j  <-  sorted[j*nb + b]
+            order = order[order >= 0].to(torch.int32)
             self._orders[g] = order.to(self.rowptr.device)
         return self._orders[g]
 

@@ -70,7 +70,13 @@ def test_group_order_longest_first(baby):
     assert sorted(order.tolist()) == list(range(n_groups))
     deg = np.diff(csr.rowptr.numpy())
     deg = np.concatenate([deg, np.zeros(n_groups * 4 - len(deg), deg.dtype)]).reshape(n_groups, 4).max(1)
-    assert np.all(np.diff(deg[order]) <= 0)
+    # the first slot of every block walks the heaviest groups in descending order ...
+    lead = deg[order[0::4]]
+    assert lead[0] == deg.max() and np.all(np.diff(lead[:n_groups // 4]) <= 0)
+    # ... and the other three slots of a block are lighter than its lead
+    nb = n_groups // 4
+    for j in (1, 2, 3):
+        assert np.all(deg[order[j:4 * nb:4]] <= lead[:nb])
     assert csr.group_order(4) is csr.group_order(4)
 
 
