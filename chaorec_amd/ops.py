@@ -254,3 +254,21 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999
                                            lr, betas[0], betas[1], eps, weight_decay, int(step), _ptr(step_dev),
                                            _stream())
     _lib.check(rc, "chaorec_adam_step_f32")
+
+
+class _SpMMAdd(torch.autograd.Function):
+    """y = A x + z in one launch (FREEDOM's `i_g_embeddings + h`, Model/FREEDOM.py:168,181)."""
+
+    @staticmethod
+    def forward(ctx, x, z, csr):
+        ctx.csr = csr
+        return spmm_raw(csr, x, z=_f32c(z), beta=1.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        return spmm_raw(ctx.csr.t(), gy), gy, None
+
+
+def spmm_add(csr, x, z):
+    return _SpMMAdd.apply(x, z, csr)
