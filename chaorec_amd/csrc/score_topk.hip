@@ -22,8 +22,8 @@ namespace chaorec {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kCand = 128;            // candidate capacity per user (>= K + 32)
-constexpr int kCandStride = kCand + 1;  // 64-bit entries; odd stride spreads users over banks
+constexpr int kHalf = 64;               // candidate capacity per LANE (a user has two lanes = 128)
+constexpr int kHalfStride = kHalf + 1;  // 64-bit entries; odd stride spreads lanes over banks
 constexpr int kMaxK = 64;
 
 __device__ __forceinline__ uint32_t f32_to_ord(float f) {
@@ -77,10 +77,47 @@ __device__ __forceinline__ void sort128_desc(uint64_t &e0, uint64_t &e1, int lan
   }
 }
 
+// ---- item packing ---------------------------------------------------------------------------
+// The A fragment of lane (r, h) for tile t is D/2 consecutive floats of item row 32t + r: read in
+// place that is 64 different 128-B lines per load instruction.  pack_items_kernel rewrites the table
+// once per call into the kernel's own order, P[(t * D/8 + q) * 64 + lane] (float4), so every fragment
+// load is one fully coalesced 1 KiB wave access; rows past n_items are zero.
+__global__ __launch_bounds__(256) void pack_items_kernel(const float *__restrict__ item_emb,
+                                                         float4 *__restrict__ packed, int64_t n_items,
+                                                         int D, int64_t n_tiles) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the packed table
+  const int Q = D / 8;
+  if (i >= n_tiles * Q * 64) return;
+  const int lane = (int)(i & 63);
+  const int64_t tq = i >> 6;
+  const int q = (int)(tq % Q);
+  const int64_t t = tq / Q;
+  const int64_t j = t * 32 + (lane & 31);
+  const int h = lane >> 5;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < n_items) v = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D + h * (D / 2))[q];
+  packed[i] = v;
+}
+
 template <int D>
 __device__ __forceinline__ void load_item_frag(float (&a)[D / 2], const float *__restrict__ item_emb,
-                                               int64_t j, int64_t i_end, int h) {
-  if (j < i_end) {
+                                               const float4 *__restrict__ packed, int64_t t, int64_t n_items,
+                                               int lane) {
+  if (packed) {
+    const float4 *src = packed + (size_t)t * (D / 8) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < D / 8; ++q) {
+      const float4 v = src[q * 64];
+      a[4 * q + 0] = v.x;
+      a[4 * q + 1] = v.y;
+      a[4 * q + 2] = v.z;
+      a[4 * q + 3] = v.w;
+    }
+    return;
+  }
+  const int64_t j = t * 32 + (lane & 31);
+  const int h = lane >> 5;
+  if (j < n_items) {
     const float4 *src = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D + h * (D / 2));
 #pragma unroll
     for (int q = 0; q < D / 8; ++q) {
@@ -96,32 +133,72 @@ __device__ __forceinline__ void load_item_frag(float (&a)[D / 2], const float *_
   }
 }
 
+enum { kModeMain = 0, kModeSample = 1, kModeFallback = 2 };
+
+struct ScoreArgs {
+  const float *user_emb;
+  const float *item_emb;
+  const float4 *packed;        // packed item table or NULL
+  int64_t n_users, n_items;
+  int Dk;                      // run-time K-dim of the streamed variant
+  const int64_t *hist_rowptr;
+  const int32_t *hist_col;
+  float mask_value;
+  int K;
+  int64_t id_offset;
+  int64_t *out_idx;
+  float *out_val;
+  uint64_t *partial;           // [splits][n_users][K] keys when splits > 1
+  int splits;
+  int64_t tiles_per_split;
+  int mode;
+  int tile_stride;             // kModeSample: every tile_stride-th tile
+  float *tau;                  // kModeSample: out; kModeMain: in (may be NULL)
+  int *certify;                // kModeMain, splits == 1: out per-user "threshold was too high" flags
+  const int *fail;             // kModeFallback: per-user flags
+};
+
 // D > 0: K-dim known at compile time, the users' fragment lives in registers for the whole stream.
 // D == 0 ("stream"): K-dim = Dk at run time (multiple of 64; the kNN build over 384/4096-wide
 // modality features): both operands are re-read per 64-wide k-chunk, B from L1/L2.
+//
+// Selection is the expensive part (the MFMA chain of a 32x32 tile is 32*D cycles; a naive
+// compare/append pass over the 16 scores a lane holds was 3x that), so the per-tile VALU work is kept
+// to ~10 instructions per score: each lane owns its OWN 64-entry candidate list (no slot arithmetic
+// between the two lanes of a user), a score is appended under one exec-masked compare, the history
+// mask and the range check only run on tiles that need them (wave-uniform branches).
 template <int D>
-__global__ __launch_bounds__(64) void score_topk_f32_kernel(
-    const float *__restrict__ user_emb, const float *__restrict__ item_emb, int64_t n_users,
-    int64_t n_items, int Dk, const int64_t *__restrict__ hist_rowptr, const int32_t *__restrict__ hist_col,
-    float mask_value, int K, int64_t id_offset, int64_t *__restrict__ out_idx,
-    float *__restrict__ out_val, uint64_t *__restrict__ partial, int splits,
-    int64_t items_per_split) {
-  __shared__ uint64_t cand[32 * kCandStride];
+__global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
+  __shared__ uint64_t cand[64 * kHalfStride];
   const int lane = threadIdx.x;
   const int ur = lane & 31;
   const int h = lane >> 5;
   const int64_t u = (int64_t)blockIdx.x * 32 + ur;
-  const bool u_ok = u < n_users;
+  const bool u_ok = u < A.n_users;
+  const int K = A.K;
+  const uint32_t n_items = (uint32_t)A.n_items;
+  const int n_tiles = (int)((A.n_items + 31) / 32);
   const int split = blockIdx.y;
-  const int64_t i_begin = (int64_t)split * items_per_split;
-  const int64_t i_end = min(n_items, i_begin + items_per_split);
+  int t_begin = (int)((int64_t)split * A.tiles_per_split);
+  int t_end = (int)min((int64_t)n_tiles, (int64_t)t_begin + A.tiles_per_split);
+  int t_stride = 1;
+  if (A.mode == kModeSample) {
+    t_begin = 0;
+    t_end = n_tiles;
+    t_stride = A.tile_stride;
+  } else if (A.mode == kModeFallback) {
+    // only the groups that hold a user whose thresholded pass came up short re-run, unthresholded
+    if (!__any(u_ok && A.fail[u] != 0)) return;
+    t_begin = 0;
+    t_end = n_tiles;
+  }
 
   constexpr int DR = D > 0 ? D : 64;  // register fragment width
   // users' B fragment: lane (ur, h) holds k = h*D/2 + s
   float bu[DR / 2];
   if (D == 0) {
   } else if (u_ok) {
-    const float4 *src = reinterpret_cast<const float4 *>(user_emb + (size_t)u * DR + h * (DR / 2));
+    const float4 *src = reinterpret_cast<const float4 *>(A.user_emb + (size_t)u * DR + h * (DR / 2));
 #pragma unroll
     for (int q = 0; q < DR / 8; ++q) {
       const float4 v = src[q];
@@ -135,47 +212,135 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(
     for (int s = 0; s < DR / 2; ++s) bu[s] = 0.f;
   }
 
-  // history cursor: first interacted item >= i_begin
+  // history cursor: first interacted item >= first item of the range
   int64_t hp = 0, hend = 0;
-  int64_t hnext = LLONG_MAX;
-  if (hist_rowptr && u_ok) {
-    int64_t lo = hist_rowptr[u];
-    hend = hist_rowptr[u + 1];
+  uint32_t hnext = 0xFFFFFFFFu;
+  if (A.hist_rowptr && u_ok) {
+    int64_t lo = A.hist_rowptr[u];
+    hend = A.hist_rowptr[u + 1];
     int64_t hi = hend;
+    const uint32_t first = (uint32_t)t_begin * 32u;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
-      if ((int64_t)hist_col[mid] < i_begin) lo = mid + 1; else hi = mid;
+      if ((uint32_t)A.hist_col[mid] < first) lo = mid + 1; else hi = mid;
     }
     hp = lo;
-    if (hp < hend) hnext = hist_col[hp];
+    if (hp < hend) hnext = (uint32_t)A.hist_col[hp];
   }
 
-  float tau = -INFINITY;
-  int cnt = 0;  // identical on both lanes of a user
-  uint64_t *my = cand + ur * kCandStride;
+  // tau0: a lower bound of the user's K-th best score from the sampling pass (exclusive: s > tau0
+  // keeps every score >= the sampled rank value because the sampler stores the next float below it)
+  float tau0 = -INFINITY;
+  if (A.mode == kModeMain && A.tau && u_ok) tau0 = A.tau[u];
+  float tau = u_ok ? tau0 : INFINITY;  // padding users never qualify
+  int cnt = 0;                         // entries in THIS lane's list
+  uint64_t *my = cand + lane * kHalfStride;
 
-  float a_cur[DR / 2], a_nxt[DR / 2];
-  if (D > 0) load_item_frag<DR>(a_cur, item_emb, i_begin + ur, i_end, h);
+  // prune user tu's two half lists back to the K best (wave-wide register bitonic sort)
+  auto prune = [&](int tu) {
+    const int c0 = __shfl(cnt, tu, 64), c1 = __shfl(cnt, tu + 32, 64);
+    uint64_t *b0 = cand + tu * kHalfStride, *b1 = cand + (tu + 32) * kHalfStride;
+    uint64_t e0 = lane < c0 ? b0[lane] : 0ull;
+    uint64_t e1 = lane < c1 ? b1[lane] : 0ull;
+    sort128_desc(e0, e1, lane);
+    const int keep = min(c0 + c1, K);
+    if (lane < keep) ((lane & 1) ? b1 : b0)[lane >> 1] = e0;
+    const uint64_t kth = shfl_u64(e0, K - 1);
+    if (ur == tu) {
+      cnt = h ? keep / 2 : (keep + 1) / 2;
+      if (c0 + c1 >= K) tau = fmaxf(tau, ord_to_f32((uint32_t)(kth >> 32)));
+    }
+  };
 
-  for (int64_t j0 = i_begin; j0 < i_end; j0 += 32) {
-    f32x16 acc;
+  auto select = [&](f32x16 &acc, int t) {
+    const uint32_t j0 = (uint32_t)t * 32u;
+    // lists that a full tile could overflow (wave-uniform loop over such users)
+    {
+      // (the shuffle must run with every lane active: no short-circuit in front of it)
+      const int mine = cnt > kHalf - 16 ? 1 : 0;
+      const int partner = __shfl_xor(mine, 32, 64);
+      const bool need = (mine | partner) != 0;
+      uint32_t m = (uint32_t)(__ballot(need) & 0xFFFFFFFFull);
+      while (m) {
+        const int tu = __builtin_ctz(m);
+        m &= m - 1;
+        prune(tu);
+      }
+    }
+    // history mask for this tile (entries of skipped tiles are stepped over)
+    uint32_t mbits = 0;
+    while (hnext < j0 + 32u) {
+      if (hnext >= j0) mbits |= 1u << (hnext - j0);
+      ++hp;
+      hnext = hp < hend ? (uint32_t)A.hist_col[hp] : 0xFFFFFFFFu;
+    }
+    if (__any(mbits != 0)) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (D > 0) {
-      load_item_frag<DR>(a_nxt, item_emb, j0 + 32 + ur, i_end, h);
+      for (int reg = 0; reg < 16; ++reg) {
+        const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if ((mbits >> off) & 1u) acc[reg] = A.mask_value;
+      }
+    }
+    if (j0 + 32u > n_items) {  // last, partial tile: rows past n_items never qualify
 #pragma unroll
-      for (int s = 0; s < DR / 2; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], bu[s], acc, 0, 0, 0);
-    } else {
-      const int64_t j = j0 + ur;
-      for (int kc = 0; kc < Dk; kc += 64) {
+      for (int reg = 0; reg < 16; ++reg) {
+        const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (j0 + off >= n_items) acc[reg] = -INFINITY;
+      }
+    }
+    // strictly better than the current K-th (later equal scores lose: lowest index first)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      if (acc[reg] > tau) {
+        const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        my[cnt++] = make_key(acc[reg], j0 + off);
+      }
+    }
+  };
+
+  if (D > 0) {
+    float a0[DR / 2], a1[DR / 2];
+    int t = t_begin;
+    if (t < t_end) load_item_frag<DR>(a0, A.item_emb, A.packed, t, A.n_items, lane);
+    while (t < t_end) {
+      {
+        const int tn = t + t_stride < t_end ? t + t_stride : t;
+        load_item_frag<DR>(a1, A.item_emb, A.packed, tn, A.n_items, lane);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DR / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bu[s], acc, 0, 0, 0);
+        select(acc, t);
+        t += t_stride;
+      }
+      if (t >= t_end) break;
+      {
+        const int tn = t + t_stride < t_end ? t + t_stride : t;
+        load_item_frag<DR>(a0, A.item_emb, A.packed, tn, A.n_items, lane);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DR / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bu[s], acc, 0, 0, 0);
+        select(acc, t);
+        t += t_stride;
+      }
+    }
+  } else {
+    for (int t = t_begin; t < t_end; t += t_stride) {
+      const int64_t j = (int64_t)t * 32 + ur;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      for (int kc = 0; kc < A.Dk; kc += 64) {
         float4 av[8], bv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
           bv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j < i_end) av[q] = reinterpret_cast<const float4 *>(item_emb + (size_t)j * Dk + kc + h * 32)[q];
-          if (u_ok) bv[q] = reinterpret_cast<const float4 *>(user_emb + (size_t)u * Dk + kc + h * 32)[q];
+          if (j < A.n_items) av[q] = reinterpret_cast<const float4 *>(A.item_emb + (size_t)j * A.Dk + kc + h * 32)[q];
+          if (u_ok) bv[q] = reinterpret_cast<const float4 *>(A.user_emb + (size_t)u * A.Dk + kc + h * 32)[q];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -185,101 +350,69 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
         }
       }
-    }
-
-    // prune the lists that a full tile could overflow (wave-uniform loop over such users)
-    {
-      const bool need = cnt > kCand - 32;
-      uint32_t m = (uint32_t)(__ballot(need) & 0xFFFFFFFFull);
-      while (m) {
-        const int t = __builtin_ctz(m);
-        m &= m - 1;
-        const int ct = __shfl(cnt, t, 64);
-        uint64_t *buf = cand + t * kCandStride;
-        uint64_t e0 = lane < ct ? buf[lane] : 0ull;
-        uint64_t e1 = lane + 64 < ct ? buf[lane + 64] : 0ull;
-        sort128_desc(e0, e1, lane);
-        if (lane < K) buf[lane] = e0;
-        const uint64_t kth = shfl_u64(e0, K - 1);
-        if (ur == t) {
-          cnt = K;  // ct > 96 >= K here
-          tau = ord_to_f32((uint32_t)(kth >> 32));
-        }
-      }
-    }
-
-    // history mask bits for this tile
-    uint32_t mbits = 0;
-    while (hnext < j0 + 32) {
-      mbits |= 1u << (uint32_t)(hnext - j0);
-      ++hp;
-      hnext = hp < hend ? (int64_t)hist_col[hp] : LLONG_MAX;
-    }
-
-    // qualify: strictly better than the current K-th (later equal scores lose: lowest index first)
-    uint32_t qbits = 0;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      float s = acc[reg];
-      if ((mbits >> off) & 1u) s = mask_value;
-      acc[reg] = s;
-      const bool q = u_ok && (j0 + off < i_end) && (s > tau || cnt < K);
-      qbits |= q ? (1u << reg) : 0u;
-    }
-    if (__any(qbits != 0)) {
-      const int nq = __popc(qbits);
-      const int nqp = __shfl_xor(nq, 32, 64);
-      int slot = cnt + (h ? nqp : 0);
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        if ((qbits >> reg) & 1u) {
-          const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          my[slot++] = make_key(acc[reg], (uint32_t)(j0 + off - 0));
-        }
-      }
-      cnt += nq + nqp;
-    }
-
-    if (D > 0) {
-#pragma unroll
-      for (int s = 0; s < DR / 2; ++s) a_cur[s] = a_nxt[s];
+      select(acc, t);
     }
   }
 
   // final ordering of every user's list
-  for (int t = 0; t < 32; ++t) {
-    const int ct = __shfl(cnt, t, 64);
-    const int64_t ut = (int64_t)blockIdx.x * 32 + t;
-    if (ut >= n_users) break;
-    uint64_t *buf = cand + t * kCandStride;
-    uint64_t e0 = lane < ct ? buf[lane] : 0ull;
-    uint64_t e1 = lane + 64 < ct ? buf[lane + 64] : 0ull;
+  for (int tu = 0; tu < 32; ++tu) {
+    const int64_t ut = (int64_t)blockIdx.x * 32 + tu;
+    if (ut >= A.n_users) break;
+    const int c0 = __shfl(cnt, tu, 64), c1 = __shfl(cnt, tu + 32, 64);
+    const uint64_t *b0 = cand + tu * kHalfStride, *b1 = cand + (tu + 32) * kHalfStride;
+    uint64_t e0 = lane < c0 ? b0[lane] : 0ull;
+    uint64_t e1 = lane < c1 ? b1[lane] : 0ull;
     sort128_desc(e0, e1, lane);
+    const uint64_t kth = shfl_u64(e0, K - 1);
+    const float kth_val = (c0 + c1 >= K) ? ord_to_f32((uint32_t)(kth >> 32)) : -INFINITY;
+    if (A.mode == kModeSample) {
+      // K-th best of the sample, one float below (so `s > tau0` keeps equal scores); -inf if the
+      // sample holds fewer than K valid items
+      if (lane == 0) A.tau[ut] = (c0 + c1 >= K) ? nextafterf(kth_val, -INFINITY) : -INFINITY;
+      continue;
+    }
+    if (A.mode == kModeFallback && A.fail[ut] == 0) continue;
+    if (A.mode == kModeMain && A.certify && A.splits == 1 && lane == 0) {
+      // exact iff at least K scores lie above the sampled threshold, i.e. the K-th best does
+      const float t0 = A.tau ? A.tau[ut] : -INFINITY;
+      A.certify[ut] = (c0 + c1 >= K && kth_val > t0) || t0 == -INFINITY ? 0 : 1;
+    }
     if (lane < K) {
-      if (splits > 1) {
-        partial[((size_t)split * n_users + ut) * K + lane] = e0;
+      if (A.splits > 1 && A.mode == kModeMain) {
+        A.partial[((size_t)split * A.n_users + ut) * K + lane] = e0;
       } else {
         const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
-        out_idx[(size_t)ut * K + lane] = (int64_t)item + id_offset;
-        out_val[(size_t)ut * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
+        A.out_idx[(size_t)ut * K + lane] = (int64_t)item + A.id_offset;
+        A.out_val[(size_t)ut * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
       }
     }
   }
 }
 
-// Merge the per-split top-K lists: one wave per user, running best-64 in e0.
+// Merge the per-split top-K lists: one wave per user, running best-64 in e0.  With a sampled
+// threshold in play it also certifies the result: the merged K-th best must lie above tau0 (= at
+// least K scores passed the threshold), else the user is flagged for the unthresholded fallback.
 __global__ __launch_bounds__(64) void score_topk_merge_kernel(const uint64_t *__restrict__ partial,
                                                               int64_t n_users, int K, int splits,
                                                               int64_t id_offset,
                                                               int64_t *__restrict__ out_idx,
-                                                              float *__restrict__ out_val) {
+                                                              float *__restrict__ out_val,
+                                                              const float *__restrict__ tau,
+                                                              int *__restrict__ fail) {
   const int lane = threadIdx.x;
   const int64_t u = blockIdx.x;
   uint64_t e0 = 0ull;
   for (int s = 0; s < splits; ++s) {
     uint64_t e1 = lane < K ? partial[((size_t)s * n_users + u) * K + lane] : 0ull;
     sort128_desc(e0, e1, lane);
+  }
+  if (fail) {
+    const uint64_t kth = shfl_u64(e0, K - 1);
+    if (lane == 0) {
+      const float t0 = tau[u];
+      const bool ok = t0 == -INFINITY || (kth != 0ull && ord_to_f32((uint32_t)(kth >> 32)) > t0);
+      fail[u] = ok ? 0 : 1;
+    }
   }
   if (lane < K) {
     const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
@@ -288,32 +421,80 @@ __global__ __launch_bounds__(64) void score_topk_merge_kernel(const uint64_t *__
   }
 }
 
-static void plan_splits(int64_t n_users, int64_t n_items, int K, int *splits, int64_t *per_split) {
+// ---- launch plan -----------------------------------------------------------------------------
+struct ScorePlan {
+  int splits;
+  int64_t tiles_per_split;
+  bool pack;        // packed item table (register-resident variants only)
+  bool sample;      // sampled per-user threshold + certification + fallback
+  int sample_rank;  // r: tau0 = r-th best of the sample
+  int tile_stride;
+  size_t off_packed, off_tau, off_fail, off_partial, total;
+};
+
+static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
+  ScorePlan p;
+  const int64_t n_tiles = (n_items + 31) / 32;
   const int64_t groups = (n_users + 31) / 32;
   int64_t s = (2048 + groups - 1) / groups;  // aim for >= 2 waves per SIMD over 256 CUs
   if (s < 1) s = 1;
   if (s > 16) s = 16;
-  int64_t per = (n_items + s - 1) / s;
-  per = (per + 31) / 32 * 32;
-  const int64_t min_per = ((int64_t)(K > 256 ? K : 256) + 31) / 32 * 32;
+  int64_t per = (n_tiles + s - 1) / s;
+  const int64_t min_per = ((int64_t)(K > 256 ? K : 256) + 31) / 32;
   if (per < min_per) per = min_per;
-  s = (n_items + per - 1) / per;
+  s = (n_tiles + per - 1) / per;
   if (s < 1) s = 1;
-  *splits = (int)s;
-  *per_split = per;
+  p.splits = (int)s;
+  p.tiles_per_split = per;
+  const bool reg_variant = D <= 128;
+  p.pack = reg_variant && n_users >= 64;
+  // Sampling: tau0 = r-th best of every `stride`-th tile.  Expected items above tau0 over the full
+  // range = r * stride; r * stride ~ 6K keeps P(fewer than K) below 1e-5 per user (relative spread
+  // ~ 1/sqrt(r)), and those users are caught by the certification and re-run without a threshold.
+  p.sample_rank = 32;
+  p.tile_stride = (int)((6 * (int64_t)K + p.sample_rank - 1) / p.sample_rank);
+  if (p.tile_stride < 2) p.tile_stride = 2;
+  const int64_t sample_tiles = n_tiles / p.tile_stride;
+  p.sample = reg_variant && K <= 64 && sample_tiles * 32 >= 8 * p.sample_rank && n_tiles >= 4 * p.tile_stride;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+  p.off_packed = take(p.pack ? (size_t)n_tiles * 32 * (size_t)D * 4 : 0);
+  p.off_tau = take(p.sample ? (size_t)n_users * 4 : 0);
+  p.off_fail = take(p.sample ? (size_t)n_users * 4 : 0);
+  p.off_partial = take(p.splits > 1 ? (size_t)p.splits * (size_t)n_users * (size_t)K * 8 : 0);
+  p.total = o;
+  return p;
+}
+
+template <int D>
+static void launch_score(const ScoreArgs &a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL(score_topk_f32_kernel<D>, grid, dim3(64), 0, st, a);
+}
+
+static int dispatch_score(int D, const ScoreArgs &a, dim3 grid, hipStream_t st) {
+  switch (D) {
+    case 8: launch_score<8>(a, grid, st); break;
+    case 16: launch_score<16>(a, grid, st); break;
+    case 32: launch_score<32>(a, grid, st); break;
+    case 64: launch_score<64>(a, grid, st); break;
+    case 128: launch_score<128>(a, grid, st); break;
+    default:
+      if (D > 128 && (D % 64) == 0) {
+        launch_score<0>(a, grid, st);
+        break;
+      }
+      return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {8,16,32,64,128} and not a multiple of 64 above 128", D);
+  }
+  return check_launch("score_topk_f32_kernel");
 }
 
 }  // namespace chaorec
 
 using namespace chaorec;
 
-extern "C" size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K) {
-  if (n_users <= 0 || n_items <= 0 || K <= 0) return 0;
-  int splits;
-  int64_t per;
-  plan_splits(n_users, n_items, K, &splits, &per);
-  if (splits <= 1) return 0;
-  return (size_t)splits * (size_t)n_users * (size_t)K * sizeof(uint64_t);
+extern "C" size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K, int32_t D) {
+  if (n_users <= 0 || n_items <= 0 || K <= 0 || D <= 0) return 0;
+  return plan_score(n_users, n_items, K, D).total;
 }
 
 extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_emb, int64_t n_users,
@@ -327,40 +508,84 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
   if (K < 1 || K > kMaxK) return fail(CHAOREC_E_INVALID, "score_topk: K=%d must be in [1,%d]", K, kMaxK);
   if (n_items < K) return fail(CHAOREC_E_INVALID, "score_topk: n_items=%lld < K=%d (torch.topk would raise)", (long long)n_items, K);
   if (n_items > 0xFFFFFFF0ll) return fail(CHAOREC_E_INVALID, "score_topk: n_items too large");
-  if (precision != 0) return fail(CHAOREC_E_INVALID, "score_topk: precision %d not built", precision);
+  if (precision != 0 && precision != 1) return fail(CHAOREC_E_INVALID, "score_topk: precision %d not built", precision);
   if (hist_rowptr && !hist_col) return fail(CHAOREC_E_INVALID, "score_topk: hist_rowptr without hist_col");
+  if (!((D == 8 || D == 16 || D == 32 || D == 64 || D == 128) || (D > 128 && D % 64 == 0)))
+    return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {8,16,32,64,128} and not a multiple of 64 above 128", D);
   if (n_users == 0) return CHAOREC_OK;
-  int splits;
-  int64_t per;
-  plan_splits(n_users, n_items, K, &splits, &per);
-  const size_t need = splits > 1 ? (size_t)splits * (size_t)n_users * (size_t)K * sizeof(uint64_t) : 0;
-  if (need > workspace_bytes || (need && !workspace))
-    return fail(CHAOREC_E_WORKSPACE, "score_topk: workspace %zu < %zu", workspace_bytes, need);
+  ScorePlan p = plan_score(n_users, n_items, K, D);
+  if (precision == 1) p.sample = false;  // precision 1: single exact pass, no sampled threshold (A/B + tests)
+  if (p.total > workspace_bytes || (p.total && !workspace))
+    return fail(CHAOREC_E_WORKSPACE, "score_topk: workspace %zu < %zu", workspace_bytes, p.total);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)((n_users + 31) / 32), (unsigned)splits);
-  uint64_t *partial = (uint64_t *)workspace;
-#define CHAOREC_ST_ARGS user_emb, item_emb, n_users, n_items, (int)D, hist_rowptr, hist_col, mask_value, K, \
-                        id_offset, out_idx, out_val, partial, splits, per
-  switch (D) {
-    case 8: hipLaunchKernelGGL(score_topk_f32_kernel<8>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
-    case 16: hipLaunchKernelGGL(score_topk_f32_kernel<16>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
-    case 32: hipLaunchKernelGGL(score_topk_f32_kernel<32>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
-    case 64: hipLaunchKernelGGL(score_topk_f32_kernel<64>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
-    case 128: hipLaunchKernelGGL(score_topk_f32_kernel<128>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS); break;
-    default:
-      if (D > 128 && (D % 64) == 0) {
-        hipLaunchKernelGGL(score_topk_f32_kernel<0>, grid, dim3(64), 0, st, CHAOREC_ST_ARGS);
-        break;
-      }
-      return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {8,16,32,64,128} and not a multiple of 64 above 128", D);
+  char *ws = (char *)workspace;
+  const int64_t n_tiles = (n_items + 31) / 32;
+  const unsigned groups = (unsigned)((n_users + 31) / 32);
+
+  ScoreArgs a;
+  a.user_emb = user_emb;
+  a.item_emb = item_emb;
+  a.packed = nullptr;
+  a.n_users = n_users;
+  a.n_items = n_items;
+  a.Dk = D;
+  a.hist_rowptr = hist_rowptr;
+  a.hist_col = hist_col;
+  a.mask_value = mask_value;
+  a.K = K;
+  a.id_offset = id_offset;
+  a.out_idx = out_idx;
+  a.out_val = out_val;
+  a.partial = p.splits > 1 ? (uint64_t *)(ws + p.off_partial) : nullptr;
+  a.splits = p.splits;
+  a.tiles_per_split = p.tiles_per_split;
+  a.mode = kModeMain;
+  a.tile_stride = 1;
+  a.tau = nullptr;
+  a.certify = nullptr;
+  a.fail = nullptr;
+
+  int rc;
+  if (p.pack) {
+    float4 *packed = (float4 *)(ws + p.off_packed);
+    const int64_t n4 = n_tiles * (D / 8) * 64;
+    hipLaunchKernelGGL(pack_items_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, item_emb,
+                       packed, n_items, (int)D, n_tiles);
+    rc = check_launch("pack_items_kernel");
+    if (rc) return rc;
+    a.packed = packed;
   }
-#undef CHAOREC_ST_ARGS
-  int rc = check_launch("score_topk_f32_kernel");
+  float *tau = p.sample ? (float *)(ws + p.off_tau) : nullptr;
+  int *failf = p.sample ? (int *)(ws + p.off_fail) : nullptr;
+  if (p.sample) {
+    ScoreArgs s = a;
+    s.mode = kModeSample;
+    s.K = p.sample_rank;
+    s.tile_stride = p.tile_stride;
+    s.tau = tau;
+    s.splits = 1;
+    rc = dispatch_score(D, s, dim3(groups, 1), st);
+    if (rc) return rc;
+    a.tau = tau;
+    a.certify = failf;
+  }
+  rc = dispatch_score(D, a, dim3(groups, (unsigned)p.splits), st);
   if (rc) return rc;
-  if (splits > 1) {
-    hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, partial,
-                       n_users, K, splits, id_offset, out_idx, out_val);
+  if (p.splits > 1) {
+    hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, a.partial, n_users,
+                       K, p.splits, id_offset, out_idx, out_val, (const float *)tau, failf);
     rc = check_launch("score_topk_merge_kernel");
+    if (rc) return rc;
   }
-  return rc;
+  if (p.sample) {
+    ScoreArgs f = a;
+    f.mode = kModeFallback;
+    f.tau = nullptr;
+    f.certify = nullptr;
+    f.fail = failf;
+    f.splits = 1;
+    rc = dispatch_score(D, f, dim3(groups, 1), st);
+    if (rc) return rc;
+  }
+  return CHAOREC_OK;
 }

@@ -190,7 +190,7 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     idx = torch.empty((U, K), dtype=torch.int64, device=dev)
     val = torch.empty((U, K), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    nbytes = lib.chaorec_score_topk_workspace_bytes(U, I, K)
+    nbytes = lib.chaorec_score_topk_workspace_bytes(U, I, K, D)
     ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
     rowptr, col = hist if hist is not None else (None, None)
     _need_cuda(rowptr, col)

@@ -143,8 +143,12 @@ int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col
  * D in {8, 16, 32, 64, 128} (users' fragment register-resident) or a multiple of 64 above 128
  * (streamed; the kNN build over modality features);  1 <= K <= 64;  n_items >= K.
  * hist_rowptr may be NULL (no mask).  hist_col ascending inside a row.
+ * precision 0 may use a sampled per-user threshold to cut selection work: tau0 = 32nd best score over every
+ *   s-th 32-item tile, the full pass keeps only scores above it, a certification step counts them and any
+ *   user with fewer than K is re-ranked without a threshold -- the RESULT is always the exact top-K.
+ * precision 1: the same exact arithmetic in a single unthresholded pass (for A/B runs and tests).
  * ------------------------------------------------------------------------------------- */
-size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K);
+size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K, int32_t D);
 
 int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
                            int64_t n_users, int64_t n_items, int32_t D,

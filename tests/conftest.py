@@ -28,8 +28,9 @@ def oracle():
 @pytest.fixture(scope="session")
 def baby():
     g = load_golden("baby_interactions.npz")
-    val = [g["val_flat"][g["val_off"][i]:g["val_off"][i + 1]].tolist() for i in range(len(g["val_off"]) - 1)]
-    test = [g["test_flat"][g["test_off"][i]:g["test_off"][i + 1]].tolist() for i in range(len(g["test_off"]) - 1)]
+    vf, vo, tf, to = g["val_flat"], g["val_off"], g["test_flat"], g["test_off"]   # NpzFile re-reads on every access
+    val = [vf[vo[i]:vo[i + 1]].tolist() for i in range(len(vo) - 1)]
+    test = [tf[to[i]:to[i + 1]].tolist() for i in range(len(to) - 1)]
     return dict(U=int(g["U"]), I=int(g["I"]), train=g["train"], val=val, test=test)
 
 

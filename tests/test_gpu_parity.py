@@ -324,6 +324,38 @@ def test_score_topk_mask_quirk_and_no_hist(dev, oracle):
     assert np.array_equal(gi.cpu().numpy(), want_i) and np.array_equal(gv.cpu().numpy(), want_v)
 
 
+def test_score_topk_sampled_threshold_fallback(dev, oracle):
+    """Adversarial for the sampled threshold: the sampled tiles (every 10th at K=50) hold all the big scores, so
+    tau0 is far too high, fewer than K items pass and the certification must send every user through the
+    unthresholded fallback.  The answer is still the exact top-K."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(11)
+    U, I, D, K = 100, 6400, 64, 50
+    ue = np.abs(rng.standard_normal((U, D))).astype(np.float32) * 0.2
+    ie = (rng.standard_normal((I, D)) * 0.01).astype(np.float32)
+    tiles = np.arange(I) // 32
+    hot = (tiles % 10 == 0) & (np.arange(I) % 32 < 3)          # 3 hot items in every sampled tile: 60 in total
+    ie[hot] = np.abs(rng.standard_normal((hot.sum(), D))).astype(np.float32)
+    hist = _hist_random(U, I, 20, seed=4)
+    want_i, want_v = oracle.score_topk(ue, ie, hist, 1e-6, K, 7)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    tu, ti = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
+    for precision in (0, 1):
+        got_i, got_v = ops.score_topk(tu, ti, dh, 1e-6, K, id_offset=7, precision=precision)
+        assert np.array_equal(got_v.cpu().numpy(), want_v), precision
+        assert np.array_equal(got_i.cpu().numpy(), want_i), precision
+
+
+def test_score_topk_single_pass_equals_sampled(dev):
+    from chaorec_amd import ops
+    torch.manual_seed(3)
+    U, I, D = 3000, 9000, 64
+    emb_u, emb_i = torch.randn(U, D, device=dev) * 0.1, torch.randn(I, D, device=dev) * 0.1
+    a = ops.score_topk(emb_u, emb_i, None, 0.0, 50, precision=0)
+    b = ops.score_topk(emb_u, emb_i, None, 0.0, 50, precision=1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_score_topk_errors(dev):
     from chaorec_amd import ops
     a = torch.zeros(4, 64, device=dev)

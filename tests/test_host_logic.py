@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol():
     assert _lib.load().chaorec_abi_version() == 1
     assert _lib.load().chaorec_spmm_rows_per_wave(64) == 4
     assert _lib.load().chaorec_spmm_rows_per_wave(128) == 2
-    assert _lib.load().chaorec_score_topk_workspace_bytes(28940, 15207, 50) > 0
+    assert _lib.load().chaorec_score_topk_workspace_bytes(28940, 15207, 50, 64) > 0
 
 
 def test_no_cpu_fallback():

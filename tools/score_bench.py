@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Time gene_ranklist's kernel sequence on a dataset-shaped random problem (run under rocprofv3 for a breakdown)."""
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chaorec_amd import graph, ops
+from chaorec_amd.synthetic import synthetic_interactions, DATASET_SHAPES
+ds = os.environ.get("DATASET", "sports")
+U, I, E = DATASET_SHAPES[ds]
+dev = torch.device("cuda:0")
+edges = synthetic_interactions(U, I, E, seed=42)
+hist = tuple(t.to(dev) for t in graph.user_hist_csr_from_edges(edges, U))
+torch.manual_seed(0)
+emb = torch.randn(U + I, 64, device=dev) * 0.1
+for prec in (0, 1):
+    for _ in range(2):
+        ops.score_topk(emb[:U], emb[U:], hist, 1e-6, 50, id_offset=U, precision=prec)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5):
+        ops.score_topk(emb[:U], emb[U:], hist, 1e-6, 50, id_offset=U, precision=prec)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 5
+    print(f"{ds} precision={prec}: {ms:.3f} ms  {U / ms * 1e3 / 1e6:.1f} M users/s  {2 * U * I * 64 / ms / 1e9:.1f} TF")
