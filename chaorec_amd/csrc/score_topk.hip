@@ -77,6 +77,42 @@ __device__ __forceinline__ void sort128_desc(uint64_t &e0, uint64_t &e1, int lan
   }
 }
 
+// The same network over NB independent (e0,e1) pairs at once: a lone sort is a chain of 27 dependent
+// cross-lane shuffles (~100 cycles of latency each); interleaving four of them fills that latency.
+template <int NB>
+__device__ __forceinline__ void sort128_desc_batch(uint64_t (&e0)[NB], uint64_t (&e1)[NB], int lane) {
+#pragma unroll
+  for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j == 64) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const uint64_t hi = e0[b] > e1[b] ? e0[b] : e1[b], lo = e0[b] > e1[b] ? e1[b] : e0[b];
+          e0[b] = hi;
+          e1[b] = lo;
+        }
+      } else {
+        uint64_t p0[NB], p1[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          p0[b] = shfl_xor_u64(e0[b], j);
+          p1[b] = shfl_xor_u64(e1[b], j);
+        }
+        const bool lower = (lane & j) == 0;
+        const bool desc0 = (k == 128) ? true : ((lane & k) == 0);
+        const bool desc1 = (k == 128) ? true : (k == 64 ? false : ((lane & k) == 0));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          // keep the larger iff (this lane holds the lower index) == (block is descending)
+          e0[b] = ((e0[b] > p0[b]) == (lower == desc0)) ? e0[b] : p0[b];
+          e1[b] = ((e1[b] > p1[b]) == (lower == desc1)) ? e1[b] : p1[b];
+        }
+      }
+    }
+  }
+}
+
 // ---- item packing ---------------------------------------------------------------------------
 // The A fragment of lane (r, h) for tile t is D/2 consecutive floats of item row 32t + r: read in
 // place that is 64 different 128-B lines per load instruction.  pack_items_kernel rewrites the table
@@ -236,19 +272,32 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
   int cnt = 0;                         // entries in THIS lane's list
   uint64_t *my = cand + lane * kHalfStride;
 
-  // prune user tu's two half lists back to the K best (wave-wide register bitonic sort)
-  auto prune = [&](int tu) {
-    const int c0 = __shfl(cnt, tu, 64), c1 = __shfl(cnt, tu + 32, 64);
-    uint64_t *b0 = cand + tu * kHalfStride, *b1 = cand + (tu + 32) * kHalfStride;
-    uint64_t e0 = lane < c0 ? b0[lane] : 0ull;
-    uint64_t e1 = lane < c1 ? b1[lane] : 0ull;
-    sort128_desc(e0, e1, lane);
-    const int keep = min(c0 + c1, K);
-    if (lane < keep) ((lane & 1) ? b1 : b0)[lane >> 1] = e0;
-    const uint64_t kth = shfl_u64(e0, K - 1);
-    if (ur == tu) {
-      cnt = h ? keep / 2 : (keep + 1) / 2;
-      if (c0 + c1 >= K) tau = fmaxf(tau, ord_to_f32((uint32_t)(kth >> 32)));
+  // prune up to NB users' half-list pairs back to their K best (wave-wide register bitonic sorts,
+  // NB of them interleaved); tus[b] < 0 = unused slot
+  constexpr int NB = 4;
+  auto prune_batch = [&](const int (&tus)[NB]) {
+    uint64_t e0[NB], e1[NB];
+    int tot[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int tu = tus[b] < 0 ? 0 : tus[b];
+      const int c0 = tus[b] < 0 ? 0 : __shfl(cnt, tu, 64), c1 = tus[b] < 0 ? 0 : __shfl(cnt, tu + 32, 64);
+      e0[b] = lane < c0 ? cand[tu * kHalfStride + lane] : 0ull;
+      e1[b] = lane < c1 ? cand[(tu + 32) * kHalfStride + lane] : 0ull;
+      tot[b] = c0 + c1;
+    }
+    sort128_desc_batch<NB>(e0, e1, lane);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (tus[b] < 0) continue;  // wave-uniform
+      const int tu = tus[b];
+      const int keep = min(tot[b], K);
+      if (lane < keep) cand[(tu + 32 * (lane & 1)) * kHalfStride + (lane >> 1)] = e0[b];
+      const uint64_t kth = shfl_u64(e0[b], K - 1);
+      if (ur == tu) {
+        cnt = h ? keep / 2 : (keep + 1) / 2;
+        if (tot[b] >= K) tau = fmaxf(tau, ord_to_f32((uint32_t)(kth >> 32)));
+      }
     }
   };
 
@@ -262,9 +311,13 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
       const bool need = (mine | partner) != 0;
       uint32_t m = (uint32_t)(__ballot(need) & 0xFFFFFFFFull);
       while (m) {
-        const int tu = __builtin_ctz(m);
-        m &= m - 1;
-        prune(tu);
+        int tus[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          tus[b] = m ? __builtin_ctz(m) : -1;
+          m &= m - 1;
+        }
+        prune_batch(tus);
       }
     }
     // history mask for this tile (entries of skipped tiles are stepped over)
@@ -354,36 +407,46 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
     }
   }
 
-  // final ordering of every user's list
-  for (int tu = 0; tu < 32; ++tu) {
-    const int64_t ut = (int64_t)blockIdx.x * 32 + tu;
-    if (ut >= A.n_users) break;
-    const int c0 = __shfl(cnt, tu, 64), c1 = __shfl(cnt, tu + 32, 64);
-    const uint64_t *b0 = cand + tu * kHalfStride, *b1 = cand + (tu + 32) * kHalfStride;
-    uint64_t e0 = lane < c0 ? b0[lane] : 0ull;
-    uint64_t e1 = lane < c1 ? b1[lane] : 0ull;
-    sort128_desc(e0, e1, lane);
-    const uint64_t kth = shfl_u64(e0, K - 1);
-    const float kth_val = (c0 + c1 >= K) ? ord_to_f32((uint32_t)(kth >> 32)) : -INFINITY;
-    if (A.mode == kModeSample) {
-      // K-th best of the sample, one float below (so `s > tau0` keeps equal scores); -inf if the
-      // sample holds fewer than K valid items
-      if (lane == 0) A.tau[ut] = (c0 + c1 >= K) ? nextafterf(kth_val, -INFINITY) : -INFINITY;
-      continue;
+  // final ordering of every user's list, NB users per pass
+  for (int base = 0; base < 32; base += NB) {
+    if ((int64_t)blockIdx.x * 32 + base >= A.n_users) break;
+    uint64_t e0[NB], e1[NB];
+    int tot[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int tu = base + b;
+      const int c0 = __shfl(cnt, tu, 64), c1 = __shfl(cnt, tu + 32, 64);
+      e0[b] = lane < c0 ? cand[tu * kHalfStride + lane] : 0ull;
+      e1[b] = lane < c1 ? cand[(tu + 32) * kHalfStride + lane] : 0ull;
+      tot[b] = c0 + c1;
     }
-    if (A.mode == kModeFallback && A.fail[ut] == 0) continue;
-    if (A.mode == kModeMain && A.certify && A.splits == 1 && lane == 0) {
-      // exact iff at least K scores lie above the sampled threshold, i.e. the K-th best does
-      const float t0 = A.tau ? A.tau[ut] : -INFINITY;
-      A.certify[ut] = (c0 + c1 >= K && kth_val > t0) || t0 == -INFINITY ? 0 : 1;
-    }
-    if (lane < K) {
-      if (A.splits > 1 && A.mode == kModeMain) {
-        A.partial[((size_t)split * A.n_users + ut) * K + lane] = e0;
-      } else {
-        const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
-        A.out_idx[(size_t)ut * K + lane] = (int64_t)item + A.id_offset;
-        A.out_val[(size_t)ut * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
+    sort128_desc_batch<NB>(e0, e1, lane);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int64_t ut = (int64_t)blockIdx.x * 32 + base + b;
+      if (ut >= A.n_users) continue;
+      const uint64_t kth = shfl_u64(e0[b], K - 1);
+      const float kth_val = (tot[b] >= K) ? ord_to_f32((uint32_t)(kth >> 32)) : -INFINITY;
+      if (A.mode == kModeSample) {
+        // K-th best of the sample, one float below (so `s > tau0` keeps equal scores); -inf if the
+        // sample holds fewer than K valid items
+        if (lane == 0) A.tau[ut] = (tot[b] >= K) ? nextafterf(kth_val, -INFINITY) : -INFINITY;
+        continue;
+      }
+      if (A.mode == kModeFallback && A.fail[ut] == 0) continue;
+      if (A.mode == kModeMain && A.certify && A.splits == 1 && lane == 0) {
+        // exact iff at least K scores lie above the sampled threshold, i.e. the K-th best does
+        const float t0 = A.tau ? A.tau[ut] : -INFINITY;
+        A.certify[ut] = ((tot[b] >= K && kth_val > t0) || t0 == -INFINITY) ? 0 : 1;
+      }
+      if (lane < K) {
+        if (A.splits > 1 && A.mode == kModeMain) {
+          A.partial[((size_t)split * A.n_users + ut) * K + lane] = e0[b];
+        } else {
+          const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0[b] & 0xFFFFFFFFull);
+          A.out_idx[(size_t)ut * K + lane] = (int64_t)item + A.id_offset;
+          A.out_val[(size_t)ut * K + lane] = ord_to_f32((uint32_t)(e0[b] >> 32));
+        }
       }
     }
   }

@@ -11,7 +11,7 @@ edges = synthetic_interactions(U, I, E, seed=42)
 hist = tuple(t.to(dev) for t in graph.user_hist_csr_from_edges(edges, U))
 torch.manual_seed(0)
 emb = torch.randn(U + I, 64, device=dev) * 0.1
-for prec in (0, 1):
+for prec in [int(x) for x in os.environ.get("PREC", "0,1").split(",")]:
     for _ in range(2):
         ops.score_topk(emb[:U], emb[U:], hist, 1e-6, 50, id_offset=U, precision=prec)
     torch.cuda.synchronize()
