@@ -80,3 +80,59 @@ def reference_sampler_step(user_item_dict, all_items_tuple, user, rng):
         neg = rng.sample(all_items_tuple, 1)[0]
         if neg not in user_item_dict[user]:
             return neg
+
+
+def freedom_reference_loss(model, users, pos_items, neg_items):
+    """Model/FREEDOM.py:164-217 restated in plain torch ops (torch.sparse.mm, F.linear, F.logsigmoid) on the
+    SAME parameters / graphs as a chaorec_amd FREEDOM instance: an independent check of the fused path at
+    full dataset sizes.  Returns (loss, result)."""
+    import torch.nn.functional as F
+
+    def to_sparse(csr):
+        rp = csr.rowptr
+        rows = torch.repeat_interleave(torch.arange(csr.n_rows, device=rp.device), rp[1:] - rp[:-1])
+        return torch.sparse_coo_tensor(torch.stack([rows, csr.col.long()]), csr.val, (csr.n_rows, csr.n_cols))
+
+    adj, mm = to_sparse(model.masked_adj), to_sparse(model.mm_adj)
+    U = model.num_user
+    h = model.item_embedding.weight
+    for _ in range(model.mm_layers):
+        h = torch.sparse.mm(mm, h)
+    ego = torch.cat((model.user_embedding.weight, model.item_embedding.weight), 0)
+    alls = [ego]
+    for _ in range(model.n_layers):
+        ego = torch.sparse.mm(adj, ego)
+        alls.append(ego)
+    allm = torch.stack(alls, 1).mean(1)
+    ug, ig = allm[:U], allm[U:] + h
+    pos, neg = pos_items - U, neg_items - U
+
+    def bpr(u, p, n):
+        return -torch.mean(F.logsigmoid((u * p).sum(1) - (u * n).sum(1)))
+
+    mf = bpr(ug[users], ig[pos], ig[neg])
+    tf = F.linear(model.text_embedding.weight, model.text_trs.weight, model.text_trs.bias)
+    vf = F.linear(model.image_embedding.weight, model.image_trs.weight, model.image_trs.bias)
+    loss = mf + model.reg_weight * (bpr(ug[users], tf[pos], tf[neg]) + bpr(ug[users], vf[pos], vf[neg]))
+    return loss, torch.cat((ug, ig), 0)
+
+
+def mmgcn_reference_forward(model):
+    """Model/MMGCN.py:96-143,176-186 restated in plain torch ops on a chaorec_amd MMGCN instance."""
+    import torch.nn.functional as F
+    csr = model.graph
+    rp = csr.rowptr
+    rows = torch.repeat_interleave(torch.arange(csr.n_rows, device=rp.device), rp[1:] - rp[:-1])
+    A = torch.sparse_coo_tensor(torch.stack([rows, csr.col.long()]), csr.val, (csr.n_rows, csr.n_cols))
+
+    def branch(g, feat):
+        temp = F.linear(feat, g.MLP.weight, g.MLP.bias) if g.dim_latent else feat
+        x = F.normalize(torch.cat((g.preference, temp), 0))
+        for k in (1, 2, 3, 4):
+            conv, lin, gl = getattr(g, f"conv_embed_{k}"), getattr(g, f"linear_layer{k}"), getattr(g, f"g_layer{k}")
+            hh = F.leaky_relu(torch.sparse.mm(A, F.linear(x, conv.lin.weight, conv.lin.bias)))
+            u_hat = F.leaky_relu(F.linear(x, lin.weight, lin.bias)) + model.id_embedding
+            x = F.leaky_relu(F.linear(torch.cat((hh, u_hat), 1), gl.weight, gl.bias))
+        return x
+
+    return (branch(model.v_gcn, model.v_feat) + branch(model.t_gcn, model.t_feat)) / 2

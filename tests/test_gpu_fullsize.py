@@ -1,0 +1,102 @@
+"""Full-size checks on the GPU box for the multimodal configs of BASELINE.json (configs[2], configs[3]) and the
+entry points.  The reference's Data/ and feature blobs do not exist here: graphs are dataset-shaped synthetic,
+features synthetic.  The fused HIP path is compared with a plain-torch restatement of the
+reference op sequence (torch.sparse.mm / F.linear on the same parameters) -- fp32, tolerance stated per check."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from chaorec_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _batch(edges, U, I, B, seed, dev):
+    rng = np.random.default_rng(seed)
+    b = rng.choice(len(edges), B, replace=False)
+    return (torch.from_numpy(edges[b, 0].astype(np.int64)).to(dev), torch.from_numpy(edges[b, 1].astype(np.int64)).to(dev),
+            torch.from_numpy(rng.integers(U, U + I, B)).to(dev))
+
+
+def test_freedom_clothing_size_vs_torch(dev):
+    """configs[2]: FREEDOM on a clothing-shaped graph (U=18072, I=11384, E=76054), dim 64, L=2, mm_layers=1,
+    kNN 10, dropout 0.1, w=0.8, batch 1024; feature widths reduced to 512/384 to keep the test in seconds."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import FREEDOM
+    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+    from oracle.torch_ref import freedom_reference_loss
+    U, I, E = DATASET_SHAPES["clothing"]
+    edges = synthetic_interactions(U, I, E, seed=3)
+    g = torch.Generator().manual_seed(0)
+    v_feat, t_feat = torch.randn(I, 512, generator=g), torch.randn(I, 384, generator=g)
+    torch.manual_seed(1)
+    m = FREEDOM(U, I, edges, graph.user_item_dict_from_edges(edges), v_feat, t_feat, 64, 64, 1e-3, 0.1, 2, 1, 10, 0.8,
+                dev).to(dev)
+    # kNN graph: every item has exactly 10 neighbours incl. itself, normalised weights 1/10
+    mm = m.mm_adj
+    assert mm.n_rows == I and float(mm.val.sum()) > 0
+    m.pre_epoch_processing()
+    assert m.masked_adj.nnz == 2 * int(E * 0.9)
+    users, pos, neg = _batch(edges, U, I, 1024, 0, dev)
+    loss = m.loss(users, pos, neg)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    ref_loss, ref_result = freedom_reference_loss(m, users, pos, neg)
+    ref_loss.backward()
+    assert torch.allclose(m.result, ref_result, rtol=1e-4, atol=1e-6)
+    assert float(loss.detach()) == pytest.approx(float(ref_loss.detach()), rel=1e-5)
+    for n, p in m.named_parameters():
+        scale = float(p.grad.abs().max()) + 1e-12
+        # (the trs biases get +c*u for the positive and -c*u for the negative row: analytically zero, pure rounding)
+        assert float((grads[n] - p.grad).abs().max()) <= 2e-4 * scale + 1e-10, n
+    rank = m.gene_ranklist()
+    assert rank.shape == (U, 50) and int(rank.min()) >= U and int(rank.max()) < U + I
+
+
+def test_mmgcn_microlens_size_vs_torch(dev):
+    """configs[3] (single-GPU part): MMGCN on a microlens-shaped graph (U=46420, I=14079, E=210567), dim 64,
+    visual 128-d / textual 768-d synthetic features, 2 branches x 4 layers."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MMGCN
+    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+    from oracle.torch_ref import mmgcn_reference_forward
+    U, I, E = DATASET_SHAPES["microlens"]
+    edges = synthetic_interactions(U, I, E, seed=4)
+    g = torch.Generator().manual_seed(0)
+    v_feat, t_feat = torch.randn(I, 128, generator=g), torch.randn(I, 768, generator=g)
+    torch.manual_seed(2)
+    m = MMGCN(U, I, edges, graph.user_item_dict_from_edges(edges), v_feat, t_feat, 64, 1e-4, "add", "False", True, dev).to(dev)
+    users, pos, neg = _batch(edges, U, I, 1024, 1, dev)
+    loss = m.loss(torch.stack((users, users), 1), torch.stack((pos, neg), 1))
+    loss.backward()
+    with torch.no_grad():
+        ref = mmgcn_reference_forward(m)
+    assert torch.allclose(m.result, ref, rtol=2e-3, atol=2e-5)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    assert len(list(m.parameters())) == 50       # only the Linear layers train
+    rank = m.gene_ranklist()
+    assert rank.shape == (U, 50)
+
+
+@pytest.mark.parametrize("model", ["LightGCN", "FREEDOM", "MMGCN"])
+def test_main_entry_point_two_epochs(dev, model, tmp_path, monkeypatch):
+    """python -m chaorec_amd.main --Model X --data_path baby --synthetic: grid search, train, evaluate."""
+    import logging
+    from chaorec_amd import main as cmain, dataload
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setitem(dataload.SYNTHETIC_FEATURE_DIMS, "default", (96, 64))
+    logging.getLogger().handlers.clear()
+    best = cmain.main(["--Model", model, "--data_path", "baby", "--synthetic", "--num_epoch", "2"])
+    assert set(best.keys()) == {5, 10, 20}
+    for k in best:
+        assert set(best[k]) == {"precision", "recall", "ndcg", "hit_rate", "map"}
+        assert 0.0 <= best[k]["recall"] <= 1.0
+    assert (tmp_path / "log" / f"{model}_baby.log").exists()
