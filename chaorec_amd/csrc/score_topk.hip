@@ -188,7 +188,8 @@ struct ScoreArgs {
   int splits;
   int64_t tiles_per_split;
   int mode;
-  int tile_stride;             // kModeSample: every tile_stride-th tile
+  int tile_stride;             // sampling passes: every tile_stride-th tile
+  int max_tiles;               // kModeSample: stop after this many sampled tiles (0 = no limit)
   float *tau;                  // kModeSample: out; kModeMain: in (may be NULL)
   int *certify;                // kModeMain, splits == 1: out per-user "threshold was too high" flags
   const int *fail;             // kModeFallback: per-user flags
@@ -222,11 +223,11 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
     t_begin = 0;
     t_end = n_tiles;
     t_stride = A.tile_stride;
+    if (A.max_tiles > 0) t_end = min(t_end, A.max_tiles * t_stride);
   } else if (A.mode == kModeFallback) {
     // only the groups that hold a user whose thresholded pass came up short re-run, unthresholded
+    // (same item splits as the main sweep, merged afterwards for the flagged users only)
     if (!__any(u_ok && A.fail[u] != 0)) return;
-    t_begin = 0;
-    t_end = n_tiles;
   }
 
   constexpr int DR = D > 0 ? D : 64;  // register fragment width
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
         A.certify[ut] = ((tot[b] >= K && kth_val > t0) || t0 == -INFINITY) ? 0 : 1;
       }
       if (lane < K) {
-        if (A.splits > 1 && A.mode == kModeMain) {
+        if (A.splits > 1) {
           A.partial[((size_t)split * A.n_users + ut) * K + lane] = e0[b];
         } else {
           const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0[b] & 0xFFFFFFFFull);
@@ -461,9 +462,11 @@ __global__ __launch_bounds__(64) void score_topk_merge_kernel(const uint64_t *__
                                                               int64_t *__restrict__ out_idx,
                                                               float *__restrict__ out_val,
                                                               const float *__restrict__ tau,
-                                                              int *__restrict__ fail) {
+                                                              int *__restrict__ fail,
+                                                              const int *__restrict__ only_if) {
   const int lane = threadIdx.x;
   const int64_t u = blockIdx.x;
+  if (only_if && only_if[u] == 0) return;
   uint64_t e0 = 0ull;
   for (int s = 0; s < splits; ++s) {
     uint64_t e1 = lane < K ? partial[((size_t)s * n_users + u) * K + lane] : 0ull;
@@ -484,6 +487,294 @@ __global__ __launch_bounds__(64) void score_topk_merge_kernel(const uint64_t *__
   }
 }
 
+// ---- thresholded candidate pass (the fast main pass) ---------------------------------------
+// With a per-user threshold tau0 in hand (sampling pass) the full sweep needs no selection at all:
+// a score above tau0 is appended to the lane's own list in GLOBAL memory, [split][user][half][kCandCap]
+// 64-bit keys, and the exact top-K is taken afterwards from the ~6K survivors per user
+// (score_select_kernel).  No LDS lists, no prunes, no sorts here, so two waves fit per SIMD and the
+// compare/append work of one hides under the other's MFMA chain.  Per tile: 16 compares build a hit mask;
+// the tile's scores are parked in a 4 KiB LDS scratch ([reg][lane], conflict-free both ways) so a lane can
+// fetch "its" hit by a run-time register index; a short wave-uniform loop drains the hits.
+constexpr int kCandCap = 96;  // keys per (split, user, half), <= 128; expected ~6K / (2 * splits)
+
+#ifndef CHAOREC_CAND_MINW
+#define CHAOREC_CAND_MINW 1
+#endif
+template <int D>
+__global__ __launch_bounds__(64, CHAOREC_CAND_MINW) void score_candidates_kernel(const ScoreArgs A, uint64_t *__restrict__ cand_buf,
+                                                              int *__restrict__ cand_cnt) {
+  __shared__ float scratch[16 * 64];
+  const int lane = threadIdx.x;
+  const int ur = lane & 31;
+  const int h = lane >> 5;
+  const int64_t u = (int64_t)blockIdx.x * 32 + ur;
+  const bool u_ok = u < A.n_users;
+  const uint32_t n_items = (uint32_t)A.n_items;
+  const int n_tiles = (int)((A.n_items + 31) / 32);
+  const int split = blockIdx.y;
+  // tile index = i * stride for i in this split's range of the (sampled) tile list
+  const int t_stride = A.tile_stride > 0 ? A.tile_stride : 1;
+  int n_samp = (n_tiles + t_stride - 1) / t_stride;
+  if (A.max_tiles > 0) n_samp = min(n_samp, A.max_tiles);
+  const int i_begin = (int)((int64_t)split * A.tiles_per_split);
+  const int i_end = (int)min((int64_t)n_samp, (int64_t)i_begin + A.tiles_per_split);
+  const int t_begin = i_begin * t_stride;
+  const int t_end = min(n_tiles, (i_end - 1) * t_stride + 1);
+
+  float bu[D / 2];
+  if (u_ok) {
+    const float4 *src = reinterpret_cast<const float4 *>(A.user_emb + (size_t)u * D + h * (D / 2));
+#pragma unroll
+    for (int q = 0; q < D / 8; ++q) {
+      const float4 v = src[q];
+      bu[4 * q + 0] = v.x;
+      bu[4 * q + 1] = v.y;
+      bu[4 * q + 2] = v.z;
+      bu[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) bu[s] = 0.f;
+  }
+
+  int64_t hp = 0, hend = 0;
+  uint32_t hnext = 0xFFFFFFFFu;
+  if (A.hist_rowptr && u_ok) {
+    int64_t lo = A.hist_rowptr[u];
+    hend = A.hist_rowptr[u + 1];
+    int64_t hi = hend;
+    const uint32_t first = (uint32_t)t_begin * 32u;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint32_t)A.hist_col[mid] < first) lo = mid + 1; else hi = mid;
+    }
+    hp = lo;
+    if (hp < hend) hnext = (uint32_t)A.hist_col[hp];
+  }
+
+  float tau0 = u_ok ? (A.tau ? A.tau[u] : -INFINITY) : INFINITY;   // only ever raised (overflow prune below)
+  int cnt = 0;
+  uint64_t *mine = cand_buf + (((size_t)split * A.n_users + (u_ok ? u : 0)) * 2 + h) * kCandCap;
+  const int K = A.K;
+
+  auto select = [&](f32x16 &acc, int t) {
+    const uint32_t j0 = (uint32_t)t * 32u;
+    // A list that the next tile could overflow (scores bunched in this item range, or a loose tau0) is cut
+    // back to the lane's own K best and the lane's threshold raised to its K-th: still exact, because the K
+    // entries kept all beat anything rejected later.  Rare; wave-wide bitonic sort of the list.
+    {
+      unsigned long long m = __ballot(cnt > kCandCap - 16);
+      if (m) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // our own global stores, read back below
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        while (m) {
+          const int src = __builtin_ctzll(m);
+          m &= m - 1;
+          const int c = __shfl(cnt, src, 64);
+          const unsigned long long base = ((unsigned long long)__shfl((int)((unsigned long long)mine >> 32), src, 64) << 32) |
+                                          (unsigned int)__shfl((int)((unsigned long long)mine & 0xffffffffull), src, 64);
+          uint64_t *lst = (uint64_t *)base;
+          uint64_t e0 = lane < c ? lst[lane] : 0ull;
+          uint64_t e1 = lane + 64 < c ? lst[lane + 64] : 0ull;
+          sort128_desc(e0, e1, lane);
+          if (lane < K) lst[lane] = e0;
+          const uint64_t kth = shfl_u64(e0, K - 1);
+          if (lane == src) {
+            cnt = K;
+            tau0 = fmaxf(tau0, ord_to_f32((uint32_t)(kth >> 32)));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      }
+    }
+    uint32_t mbits = 0;
+    while (hnext < j0 + 32u) {
+      if (hnext >= j0) mbits |= 1u << (hnext - j0);
+      ++hp;
+      hnext = hp < hend ? (uint32_t)A.hist_col[hp] : 0xFFFFFFFFu;
+    }
+    if (__any(mbits != 0)) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if ((mbits >> off) & 1u) acc[reg] = A.mask_value;
+      }
+    }
+    if (j0 + 32u > n_items) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (j0 + off >= n_items) acc[reg] = -INFINITY;
+      }
+    }
+    uint32_t qbits = 0;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) qbits |= (acc[reg] > tau0) ? (1u << reg) : 0u;
+    if (__any(qbits != 0)) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) scratch[reg * 64 + lane] = acc[reg];
+      __builtin_amdgcn_wave_barrier();
+      while (__any(qbits != 0)) {
+        if (qbits) {
+          const int reg = __ffs(qbits) - 1;
+          qbits &= qbits - 1;
+          const float sc = scratch[reg * 64 + lane];
+          const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          mine[cnt++] = make_key(sc, j0 + off);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+
+  float a0[D / 2], a1[D / 2];
+  int t = t_begin;
+  if (t < t_end) load_item_frag<D>(a0, A.item_emb, A.packed, t, A.n_items, lane);
+  while (t < t_end) {
+    {
+      const int tn = t + t_stride < t_end ? t + t_stride : t;
+      load_item_frag<D>(a1, A.item_emb, A.packed, tn, A.n_items, lane);
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < D / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bu[s], acc, 0, 0, 0);
+      select(acc, t);
+      t += t_stride;
+    }
+    if (t >= t_end) break;
+    {
+      const int tn = t + t_stride < t_end ? t + t_stride : t;
+      load_item_frag<D>(a0, A.item_emb, A.packed, tn, A.n_items, lane);
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < D / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bu[s], acc, 0, 0, 0);
+      select(acc, t);
+      t += t_stride;
+    }
+  }
+  if (u_ok) cand_cnt[((size_t)split * A.n_users + u) * 2 + h] = cnt;
+}
+
+// Exact top-K of one user's candidate lists (one wave per user).  The ~6K candidates are held 8 per lane; the
+// K-th largest score is found by a 32-step bitwise search with wave ballots and scalar popcounts (no LDS
+// traffic, no sort), the survivors (score >= that value: K plus ties) are compacted through LDS and ONE
+// register bitonic sort orders them.  Certifies the threshold: at least K candidates in total <=> the K best
+// scores all lie above tau0 <=> the answer is exact; otherwise the user is flagged for the unthresholded
+// fallback.  tau_out != NULL: sampling stage -- write the K-th best (one float below; the incoming threshold if
+// there are fewer than K candidates) as the user's threshold and nothing else.
+constexpr int kSelNR = 8;  // candidates per lane held in registers (512 per user), more -> streaming path
+
+__global__ __launch_bounds__(64) void score_select_kernel(const uint64_t *__restrict__ cand_buf,
+                                                          const int *__restrict__ cand_cnt, int64_t n_users,
+                                                          int K, int splits, int64_t id_offset,
+                                                          const float *__restrict__ tau,
+                                                          int64_t *__restrict__ out_idx,
+                                                          float *__restrict__ out_val, int *__restrict__ fail,
+                                                          float *__restrict__ tau_out) {
+  __shared__ uint64_t stage[64 * kSelNR];
+  const int lane = threadIdx.x;
+  const int64_t u = blockIdx.x;
+  const int n_lists = 2 * splits;
+  int total = 0;
+  for (int l = 0; l < n_lists; ++l) total += cand_cnt[((size_t)(l >> 1) * n_users + u) * 2 + (l & 1)];
+
+  uint64_t e0 = 0ull, e1 = 0ull;
+  bool sorted = false;
+  if (total <= 64 * kSelNR) {
+    // stage every list contiguously in LDS, then 8 keys per lane in registers
+    int base = 0;
+    for (int l = 0; l < n_lists; ++l) {
+      const size_t li = ((size_t)(l >> 1) * n_users + u) * 2 + (l & 1);
+      const int c = cand_cnt[li];
+      const uint64_t *src = cand_buf + li * kCandCap;
+      for (int j = lane; j < c; j += 64) stage[base + j] = src[j];
+      base += c;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint64_t k[kSelNR];
+#pragma unroll
+    for (int r = 0; r < kSelNR; ++r) k[r] = (lane + 64 * r < total) ? stage[lane + 64 * r] : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    int count_ge = total;
+    uint32_t T = 0;
+    if (total > 128) {
+      // K-th largest 32-bit score key (ties counted): bitwise search, counts via ballot + scalar popcount
+      uint32_t prefix = 0;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t candv = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < kSelNR; ++r) c += __popcll(__ballot((uint32_t)(k[r] >> 32) >= candv && k[r] != 0ull));
+        if (c >= K) prefix = candv;
+      }
+      T = prefix;
+      count_ge = 0;
+#pragma unroll
+      for (int r = 0; r < kSelNR; ++r) count_ge += __popcll(__ballot((uint32_t)(k[r] >> 32) >= T && k[r] != 0ull));
+    }
+    if (count_ge <= 128) {
+      // compact the survivors into the first count_ge LDS slots (wave prefix popcounts), one sort orders them
+      int base2 = 0;
+#pragma unroll
+      for (int r = 0; r < kSelNR; ++r) {
+        const bool keep = k[r] != 0ull && (uint32_t)(k[r] >> 32) >= T;
+        const unsigned long long m = __ballot(keep);
+        const int pos = base2 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (keep) stage[pos] = k[r];
+        base2 += __popcll(m);
+      }
+      __builtin_amdgcn_wave_barrier();
+      e0 = lane < count_ge ? stage[lane] : 0ull;
+      e1 = lane + 64 < count_ge ? stage[lane + 64] : 0ull;
+      sort128_desc(e0, e1, lane);
+      sorted = true;
+    }
+  }
+  if (!sorted) {
+    // streaming path (more than 512 candidates, or more than 128 tied at the K-th score): running best-64 in
+    // e0, 64 new keys per bitonic pass
+    e0 = 0ull;
+    e1 = 0ull;
+    int fill = 0;
+    for (int l = 0; l < n_lists; ++l) {
+      const size_t li = ((size_t)(l >> 1) * n_users + u) * 2 + (l & 1);
+      const int c = cand_cnt[li];
+      const uint64_t *src = cand_buf + li * kCandCap;
+      int done = 0;
+      while (done < c) {
+        const int take = min(c - done, 64 - fill);
+        if (lane >= fill && lane < fill + take) e1 = src[done + lane - fill];
+        fill += take;
+        done += take;
+        if (fill == 64) {
+          sort128_desc(e0, e1, lane);
+          e1 = 0ull;
+          fill = 0;
+        }
+      }
+    }
+    if (fill > 0) sort128_desc(e0, e1, lane);
+  }
+  if (tau_out) {
+    const uint64_t kth = shfl_u64(e0, K - 1);
+    if (lane == 0) {
+      // fewer than K candidates passed the incoming threshold: that threshold is already tight enough
+      const float inc = tau ? tau[u] : -INFINITY;
+      tau_out[u] = total >= K ? nextafterf(ord_to_f32((uint32_t)(kth >> 32)), -INFINITY) : inc;
+    }
+    return;
+  }
+  if (lane == 0) fail[u] = (total < K) ? 1 : 0;
+  if (lane < K) {
+    const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
+    out_idx[(size_t)u * K + lane] = (int64_t)item + id_offset;
+    out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
+  }
+}
+
 // ---- launch plan -----------------------------------------------------------------------------
 struct ScorePlan {
   int splits;
@@ -492,7 +783,7 @@ struct ScorePlan {
   bool sample;      // sampled per-user threshold + certification + fallback
   int sample_rank;  // r: tau0 = r-th best of the sample
   int tile_stride;
-  size_t off_packed, off_tau, off_fail, off_partial, total;
+  size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
 };
 
 static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
@@ -519,12 +810,25 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   if (p.tile_stride < 2) p.tile_stride = 2;
   const int64_t sample_tiles = n_tiles / p.tile_stride;
   p.sample = reg_variant && K <= 64 && sample_tiles * 32 >= 8 * p.sample_rank && n_tiles >= 4 * p.tile_stride;
+  if (p.sample) {
+    // the candidate sweep keeps ~6K scores per user in 2*splits lists of kCandCap: aim for <= 40 expected per
+    // list so the overflow prune stays a rarity
+    int64_t want = (6 * (int64_t)K + 79) / 80;
+    if (want > p.splits && n_tiles / want >= 8) {
+      p.splits = (int)want;
+      p.tiles_per_split = (n_tiles + want - 1) / want;
+      p.splits = (int)((n_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
+    }
+  }
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_packed = take(p.pack ? (size_t)n_tiles * 32 * (size_t)D * 4 : 0);
   p.off_tau = take(p.sample ? (size_t)n_users * 4 : 0);
+  p.off_tau1 = take(p.sample ? (size_t)n_users * 4 : 0);
   p.off_fail = take(p.sample ? (size_t)n_users * 4 : 0);
   p.off_partial = take(p.splits > 1 ? (size_t)p.splits * (size_t)n_users * (size_t)K * 8 : 0);
+  p.off_cand = take(p.sample ? (size_t)p.splits * (size_t)n_users * 2 * kCandCap * 8 : 0);
+  p.off_cnt = take(p.sample ? (size_t)p.splits * (size_t)n_users * 2 * 4 : 0);
   p.total = o;
   return p;
 }
@@ -604,6 +908,7 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
   a.tiles_per_split = p.tiles_per_split;
   a.mode = kModeMain;
   a.tile_stride = 1;
+  a.max_tiles = 0;
   a.tau = nullptr;
   a.certify = nullptr;
   a.fail = nullptr;
@@ -618,36 +923,85 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     if (rc) return rc;
     a.packed = packed;
   }
-  float *tau = p.sample ? (float *)(ws + p.off_tau) : nullptr;
-  int *failf = p.sample ? (int *)(ws + p.off_fail) : nullptr;
   if (p.sample) {
-    ScoreArgs s = a;
-    s.mode = kModeSample;
-    s.K = p.sample_rank;
-    s.tile_stride = p.tile_stride;
-    s.tau = tau;
-    s.splits = 1;
-    rc = dispatch_score(D, s, dim3(groups, 1), st);
+    // sampled threshold -> sort-free candidate sweep -> exact selection + certification -> fallback
+    float *tau = (float *)(ws + p.off_tau);
+    int *failf = (int *)(ws + p.off_fail);
+    uint64_t *cand_buf = (uint64_t *)(ws + p.off_cand);
+    int *cand_cnt = (int *)(ws + p.off_cnt);
+    // Sampling: two sort-free candidate sweeps + two selections instead of one prune-heavy streaming top-r:
+    //  S1  candidate sweep of the first 4 sampled tiles with no threshold (128 scores per user);
+    //      tau1 = their 6th best
+    //  S2  candidate sweep of ALL sampled tiles against tau1 (~5 % pass), item range in 4 splits;
+    //      tau0 = the r-th best of those
+    float *tau1 = (float *)(ws + p.off_tau1);
+    auto launch_cand = [&](const ScoreArgs &x, unsigned sp) -> int {
+      const dim3 g(groups, sp);
+      switch (D) {
+        case 8: hipLaunchKernelGGL(score_candidates_kernel<8>, g, dim3(64), 0, st, x, cand_buf, cand_cnt); break;
+        case 16: hipLaunchKernelGGL(score_candidates_kernel<16>, g, dim3(64), 0, st, x, cand_buf, cand_cnt); break;
+        case 32: hipLaunchKernelGGL(score_candidates_kernel<32>, g, dim3(64), 0, st, x, cand_buf, cand_cnt); break;
+        case 64: hipLaunchKernelGGL(score_candidates_kernel<64>, g, dim3(64), 0, st, x, cand_buf, cand_cnt); break;
+        default: hipLaunchKernelGGL(score_candidates_kernel<128>, g, dim3(64), 0, st, x, cand_buf, cand_cnt); break;
+      }
+      return check_launch("score_candidates_kernel");
+    };
+    ScoreArgs s1 = a;
+    s1.K = 6;
+    s1.tile_stride = p.tile_stride;
+    s1.max_tiles = 4;
+    s1.tiles_per_split = 4;
+    s1.tau = nullptr;
+    rc = launch_cand(s1, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(score_select_kernel, dim3((unsigned)n_users), dim3(64), 0, st, cand_buf, cand_cnt, n_users, 6,
+                       1, id_offset, (const float *)nullptr, out_idx, out_val, failf, tau1);
+    rc = check_launch("score_select_kernel(S1)");
+    if (rc) return rc;
+    const int n_samp = (int)((n_tiles + p.tile_stride - 1) / p.tile_stride);
+    const int samp_splits = (n_samp >= 16 && p.splits >= 4) ? 4 : 1;  // (the candidate region holds p.splits lists)
+    ScoreArgs s2 = a;
+    s2.K = p.sample_rank;
+    s2.tile_stride = p.tile_stride;
+    s2.tiles_per_split = (n_samp + samp_splits - 1) / samp_splits;
+    s2.tau = tau1;
+    rc = launch_cand(s2, (unsigned)samp_splits);
+    if (rc) return rc;
+    hipLaunchKernelGGL(score_select_kernel, dim3((unsigned)n_users), dim3(64), 0, st, cand_buf, cand_cnt, n_users,
+                       p.sample_rank, samp_splits, id_offset, (const float *)tau1, out_idx, out_val, failf, tau);
+    rc = check_launch("score_select_kernel(S2)");
     if (rc) return rc;
     a.tau = tau;
-    a.certify = failf;
-  }
-  rc = dispatch_score(D, a, dim3(groups, (unsigned)p.splits), st);
-  if (rc) return rc;
-  if (p.splits > 1) {
-    hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, a.partial, n_users,
-                       K, p.splits, id_offset, out_idx, out_val, (const float *)tau, failf);
-    rc = check_launch("score_topk_merge_kernel");
+    rc = launch_cand(a, (unsigned)p.splits);
     if (rc) return rc;
-  }
-  if (p.sample) {
+    hipLaunchKernelGGL(score_select_kernel, dim3((unsigned)n_users), dim3(64), 0, st, cand_buf, cand_cnt, n_users,
+                       K, p.splits, id_offset, (const float *)tau, out_idx, out_val, failf, (float *)nullptr);
+    rc = check_launch("score_select_kernel");
+    if (rc) return rc;
+    // users with fewer than K scores above their sampled threshold (expected: a handful per million) re-run
+    // unthresholded: their groups sweep the same item splits with the LDS-list kernel, then a merge
     ScoreArgs f = a;
     f.mode = kModeFallback;
     f.tau = nullptr;
     f.certify = nullptr;
     f.fail = failf;
-    f.splits = 1;
-    rc = dispatch_score(D, f, dim3(groups, 1), st);
+    rc = dispatch_score(D, f, dim3(groups, (unsigned)p.splits), st);
+    if (rc) return rc;
+    if (p.splits > 1) {
+      hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, a.partial, n_users, K,
+                         p.splits, id_offset, out_idx, out_val, (const float *)nullptr, (int *)nullptr,
+                         (const int *)failf);
+      rc = check_launch("score_topk_merge_kernel");
+    }
+    return rc;
+  }
+  rc = dispatch_score(D, a, dim3(groups, (unsigned)p.splits), st);
+  if (rc) return rc;
+  if (p.splits > 1) {
+    hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, a.partial, n_users,
+                       K, p.splits, id_offset, out_idx, out_val, (const float *)nullptr, (int *)nullptr,
+                       (const int *)nullptr);
+    rc = check_launch("score_topk_merge_kernel");
     if (rc) return rc;
   }
   return CHAOREC_OK;
