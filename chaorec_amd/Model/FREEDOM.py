@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F  # noqa: F401  (kept: reference module namespace)
 from torch import nn
 
-from .. import graph, ops
+from .. import graph, ops, ranking
 
 
 class FREEDOM(nn.Module):
@@ -191,10 +191,6 @@ class FREEDOM(nn.Module):
 
     def gene_ranklist(self, topk=50):
         """Model/FREEDOM.py:219-244 (mask value 1e-6, stale self.result)."""
-        with torch.no_grad():
-            result = self.result.detach()
-            idx, _ = ops.score_topk(result[:self.num_user], result[self.num_user:self.num_user + self.num_item],
-                                    self.hist, 1e-6, topk, id_offset=self.num_user)
-        return idx.cpu()
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk)
 
     full_sort_predict = gene_ranklist

@@ -12,7 +12,7 @@ What changed underneath:
 import torch
 import torch.nn as nn
 
-from .. import graph, ops
+from .. import graph, ops, ranking
 
 
 class LightGCN(nn.Module):
@@ -70,12 +70,7 @@ class LightGCN(nn.Module):
     def gene_ranklist(self, topk=50):
         """Model/LightGCN.py:137-162 -> LongTensor [U, topk] of GLOBAL item ids on the CPU.
         Uses the stale self.result of the last training forward, as the reference does."""
-        with torch.no_grad():
-            result = self.result.detach()
-            user_tensor = result[:self.num_user]
-            item_tensor = result[self.num_user:self.num_user + self.num_item]
-            idx, _ = ops.score_topk(user_tensor, item_tensor, self.hist, 1e-6, topk, id_offset=self.num_user)
-        return idx.cpu()
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk)
 
     # north_star names full_sort_predict(); the reference method is gene_ranklist (SURVEY fact 3)
     full_sort_predict = gene_ranklist

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import graph, ops
+from .. import graph, ops, ranking
 from ..BasicGCN import BasicGCN
 
 
@@ -131,10 +131,6 @@ class MMGCN(torch.nn.Module):
     def gene_ranklist(self, step=200, topk=50):
         """Model/MMGCN.py:204-244: mask value 1e-5.  The reference batches 200 users to bound its [200, I]
         score matrix; the fused kernel has no such matrix, `step` is accepted and ignored."""
-        with torch.no_grad():
-            result = self.result.detach()
-            idx, _ = ops.score_topk(result[:self.num_user], result[self.num_user:self.num_user + self.num_item],
-                                    self.hist, 1e-5, topk, id_offset=self.num_user)
-        return idx.cpu()
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-5, topk)
 
     full_sort_predict = gene_ranklist

@@ -1,0 +1,24 @@
+"""The one `gene_ranklist` behind the 49 near-identical copies in the reference's Model/*.py:
+score = user @ item.T, history -> mask_value (1e-6 in 46 models, 1e-5 in 3), top-k, + num_user, LongTensor on CPU.
+
+    from chaorec_amd.ranking import gene_ranklist, history_csr
+    self.hist = history_csr(user_item_dict, num_user, device)          # once, in __init__
+    return gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk)
+"""
+import torch
+
+from . import graph, ops
+
+
+def history_csr(user_item_dict, num_user, device):
+    rowptr, col = graph.user_hist_csr(user_item_dict, num_user)
+    return rowptr.to(device), col.to(device)
+
+
+def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50):
+    """result [N, D] (users first) on the GPU -> LongTensor [num_user, topk] of GLOBAL item ids on the CPU."""
+    with torch.no_grad():
+        result = result.detach()
+        idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
+                                id_offset=num_user)
+    return idx.cpu()

@@ -161,3 +161,55 @@ def test_knn_streamed_kdim_bit_exact(dev, oracle):
     assert np.array_equal(got_v.cpu().numpy(), want_v)
     assert np.array_equal(got_i.cpu().numpy(), want_i)
     assert np.array_equal(got_i[:, 0].cpu().numpy(), np.arange(n))   # self is the nearest neighbour (kept, FREEDOM.py:116)
+
+
+def test_sparse_mm_adapter_matches_torch_sparse_mm(dev):
+    """the `torch.sparse.mm(norm_adj, x)` family.  Adjacency built the way Model/SimGCL.py:64-104
+    does (scipy D^-1/2 A D^-1/2 -> torch COO), multiplied by our adapter and by torch, forward and backward."""
+    import scipy.sparse as sp
+    from chaorec_amd import sparse
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D = 3000, 1700, 20000, 64
+    e = synthetic_interactions(U, I, E, seed=9)
+    inter = sp.coo_matrix((np.ones(E, np.float32), (e[:, 0], e[:, 1] - U)), shape=(U, I))
+    A = sp.bmat([[None, inter], [inter.T, None]], format="csr", dtype=np.float32)
+    diag = np.power(np.asarray((A > 0).sum(axis=1)).flatten() + 1e-7, -0.5)
+    L = sp.coo_matrix(sp.diags(diag) @ A @ sp.diags(diag))
+    adj = torch.sparse_coo_tensor(torch.tensor(np.array([L.row, L.col]), dtype=torch.long),
+                                  torch.FloatTensor(L.data), torch.Size(L.shape), dtype=torch.float32).to(dev)
+    x = torch.randn(U + I, D, device=dev, requires_grad=True)
+    w = torch.randn(U + I, D, device=dev)
+    y = sparse.mm(adj, x)
+    (y * w).sum().backward()
+    gx = x.grad.clone()
+    x.grad = None
+    yr = torch.sparse.mm(adj, x)
+    (yr * w).sum().backward()
+    assert torch.allclose(y, yr, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gx, x.grad, rtol=1e-5, atol=1e-6)
+    assert getattr(adj, "_chaorec_csr").symmetric           # converted once, cached, recognised as symmetric
+    # a non-symmetric matrix goes through the transposed CSR in the backward
+    idx = torch.stack([torch.randint(0, 500, (4000,)), torch.randint(0, 300, (4000,))]).to(dev)
+    m = torch.sparse_coo_tensor(idx, torch.randn(4000, device=dev), (500, 300))
+    x2 = torch.randn(300, 32, device=dev, requires_grad=True)
+    y2 = sparse.mm(m, x2)
+    y2.square().sum().backward()
+    g2 = x2.grad.clone()
+    x2.grad = None
+    torch.sparse.mm(m, x2).square().sum().backward()
+    assert torch.allclose(g2, x2.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_shared_gene_ranklist_helper(dev, oracle):
+    """the shared ranking helper, both mask values."""
+    from chaorec_amd import ranking, graph
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D = 500, 3000, 4000, 64
+    e = synthetic_interactions(U, I, E, seed=10)
+    uid = graph.user_item_dict_from_edges(e)
+    hist = ranking.history_csr(uid, U, dev)
+    res = (np.random.default_rng(0).standard_normal((U + I, D)) * 0.1).astype(np.float32)
+    for mask in (1e-6, 1e-5):
+        got = ranking.gene_ranklist(torch.from_numpy(res).to(dev), U, I, hist, mask, 50)
+        want, _ = oracle.gene_ranklist(res, U, I, oracle.user_hist_csr(e, U), mask, 50)
+        assert got.dtype == torch.int64 and got.device.type == "cpu" and np.array_equal(got.numpy(), want)
