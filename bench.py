@@ -152,24 +152,29 @@ def main():
     gen.manual_seed(42 + rank)
     loss_sum = torch.zeros((), device=dev)
 
-    def draw(i):
-        sel = torch.randint(0, E, (B,), device=dev, generator=gen)   # DataLoader(shuffle=True) stand-in
-        users, pos = edges_dev[sel, 0], edges_dev[sel, 1]
-        neg = ops.sample_negatives(model.hist, users, I, 42 + rank, i, model.num_user)
-        return users, pos, neg
+    batch_counter = torch.zeros(1, dtype=torch.int64, device=dev)   # device-resident: advances inside the graph
+
+    def draw(i=None):
+        """One batch in ONE launch (chaorec_draw_batch): B training edges picked uniformly (DataLoader(shuffle=True)
+        stand-in) + one sampled negative each, LOCAL item ids.  i=None: graph-capturable form, the batch index
+        comes from the device counter."""
+        if i is None:
+            batch_counter.add_(1)
+            return ops.draw_batch(edges_dev, model.hist, B, model.num_user, I, 42 + rank, 0, step_dev=batch_counter)
+        return ops.draw_batch(edges_dev, model.hist, B, model.num_user, I, 42 + rank, 1_000_000 + i)
 
     # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph (the sharded path
     # holds RCCL calls and stays eager)
     use_graph = not args.no_graph and not args.torch_adam and sharded is None
-    graphed = GraphedTrainStep(model, opt, draw(0)) if use_graph else None
+    graphed = GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local) if use_graph else None
 
     def step(i, force_eager=False):
-        users, pos, neg = draw(i)
         if graphed is not None and not force_eager:
-            loss = graphed(users, pos, neg)
+            loss = graphed()          # sampling + loss + backward + Adam: one hipGraph replay, no inputs
         else:
+            users, pos, neg = draw(i)
             opt.zero_grad(set_to_none=True)
-            loss = model.loss(users, pos, neg)
+            loss = model.loss_local(users, pos, neg)
             loss.backward()
             opt.step()
             loss = loss.detach()

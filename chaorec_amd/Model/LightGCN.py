@@ -67,6 +67,11 @@ class LightGCN(nn.Module):
         embeddings = self.forward()
         return self._fused(users, pos_items, neg_items, embeddings)[0]
 
+    def loss_local(self, users, pos_items, neg_items):
+        """loss() for batches that already hold LOCAL item ids on the device (ops.draw_batch): same arithmetic,
+        without the id shift and the host->device copies."""
+        return self._fused(users, pos_items, neg_items, self.forward())[0]
+
     def gene_ranklist(self, topk=50):
         """Model/LightGCN.py:137-162 -> LongTensor [U, topk] of GLOBAL item ids on the CPU.
         Uses the stale self.result of the last training forward, as the reference does."""

@@ -28,11 +28,14 @@ SIGNATURES = {
                                             ctypes.c_float, c_ptr, ctypes.c_int32, c_ptr]),
     "chaorec_spmm_rows_per_wave": (ctypes.c_int, [ctypes.c_int32]),
     "chaorec_bpr_fwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
-                                           ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
+                                           ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_bpr_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
                                            c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_sample_negatives": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
-                                                ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, c_ptr, c_ptr]),
+                                                ctypes.c_uint64, ctypes.c_uint64, c_ptr, ctypes.c_int64, c_ptr, c_ptr]),
+    "chaorec_draw_batch": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int64,
+                                          ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr,
+                                          c_ptr]),
     "chaorec_score_topk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                             ctypes.c_int32]),
     "chaorec_score_topk_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,

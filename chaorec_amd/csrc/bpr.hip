@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void bpr_fwd_terms_kernel(
 // One block, fixed order: thread t sums elements t, t+256, ... then a fixed LDS tree.
 __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__restrict__ ws, int B,
                                                                int D, float reg_weight,
-                                                               float *__restrict__ out_loss) {
+                                                               float *__restrict__ out_loss,
+                                                               float *__restrict__ out_total) {
   __shared__ float red[4][256];
   const int t = threadIdx.x;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__re
     out_loss[0] = bpr + reg;
     out_loss[1] = bpr;
     out_loss[2] = reg;
+    if (out_total) out_total[0] = bpr + reg;
   }
 }
 
@@ -138,9 +140,10 @@ __device__ __forceinline__ uint32_t sampler_draw(uint64_t seed, uint64_t step, u
 __global__ __launch_bounds__(256) void sample_negatives_kernel(
     const int64_t *__restrict__ hist_rowptr, const int32_t *__restrict__ hist_col,
     const int64_t *__restrict__ users, int B, uint32_t num_item, uint64_t seed, uint64_t step,
-    int64_t id_offset, int64_t *__restrict__ out_neg) {
+    const int64_t *__restrict__ step_dev, int64_t id_offset, int64_t *__restrict__ out_neg) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (step_dev) step += (uint64_t)step_dev[0];  // device-resident batch counter: the launch is graph-capturable
   const int64_t u = users[b];
   const int64_t h0 = hist_rowptr[u], h1 = hist_rowptr[u + 1];
   uint32_t cand = 0;
@@ -159,14 +162,60 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
   out_neg[b] = (int64_t)cand + id_offset;
 }
 
+// One launch per batch: pick B training edges uniformly (counter-based, with replacement across batches),
+// gather (user, positive) and draw one negative each -- the DataLoader(shuffle) + TrainingDataset.__getitem__
+// pair of main.py:194-195 / dataload.py:74-79 for a streaming trainer.  Outputs LOCAL ids (item - num_user),
+// what Model.loss() computes first anyway.  The negative stream is sample_negatives_kernel's.
+__global__ __launch_bounds__(256) void draw_batch_kernel(
+    const int64_t *__restrict__ edges, int64_t n_edges, const int64_t *__restrict__ hist_rowptr,
+    const int32_t *__restrict__ hist_col, int B, int64_t num_user, uint32_t num_item, uint64_t seed, uint64_t step,
+    const int64_t *__restrict__ step_dev, int64_t *__restrict__ out_users, int64_t *__restrict__ out_pos,
+    int64_t *__restrict__ out_neg) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (step_dev) step += (uint64_t)step_dev[0];
+  const uint64_t hsel = mix64(seed ^ mix64(step ^ mix64(0xED6E5ull ^ ((uint64_t)b << 32))));
+  // 64x64 -> high 64 multiply-shift onto [0, n_edges)
+  const uint64_t idx = (uint64_t)(((unsigned __int128)hsel * (unsigned __int128)(uint64_t)n_edges) >> 64);
+  const int64_t u = edges[2 * idx];
+  out_users[b] = u;
+  out_pos[b] = edges[2 * idx + 1] - num_user;
+  const int64_t h0 = hist_rowptr[u], h1 = hist_rowptr[u + 1];
+  uint32_t cand = 0;
+  for (uint32_t attempt = 0;; ++attempt) {
+    cand = sampler_draw(seed, step, (uint32_t)b, attempt, num_item);
+    int64_t lo = h0, hi = h1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint32_t)hist_col[mid] < cand) lo = mid + 1; else hi = mid;
+    }
+    const bool seen = (lo < h1) && ((uint32_t)hist_col[lo] == cand);
+    if (!seen || attempt >= 4096u) break;
+  }
+  out_neg[b] = (int64_t)cand;
+}
+
 }  // namespace chaorec
 
 using namespace chaorec;
 
+extern "C" int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *hist_rowptr,
+                                  const int32_t *hist_col, int32_t B, int64_t num_user, int32_t num_item,
+                                  uint64_t seed, uint64_t step, const int64_t *step_dev, int64_t *out_users,
+                                  int64_t *out_pos, int64_t *out_neg, void *stream) {
+  if (!edges || !hist_rowptr || !out_users || !out_pos || !out_neg)
+    return fail(CHAOREC_E_INVALID, "draw_batch: NULL argument");
+  if (B <= 0 || n_edges <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "draw_batch: bad sizes");
+  hipLaunchKernelGGL(draw_batch_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, edges, n_edges,
+                     hist_rowptr, hist_col, B, num_user, (uint32_t)num_item, seed, step, step_dev, out_users,
+                     out_pos, out_neg);
+  return check_launch("draw_batch_kernel");
+}
+
 extern "C" int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i, const int64_t *users,
                                    const int64_t *pos, const int64_t *neg, int32_t B, int32_t D,
-                                   int32_t variant, float reg_weight, float *out_loss, float *coef,
-                                   float *workspace, void *stream) {
+                                   int32_t variant, float reg_weight, float *out_loss, float *out_total,
+                                   float *coef, float *workspace, void *stream) {
   if (!tab_u || !tab_i || !users || !pos || !neg || !out_loss || !coef || !workspace)
     return fail(CHAOREC_E_INVALID, "bpr_fwd: NULL argument");
   if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd: B=%d D=%d", B, D);
@@ -177,7 +226,7 @@ extern "C" int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i, const
   int rc = check_launch("bpr_fwd_terms_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight,
-                     out_loss);
+                     out_loss, out_total);
   return check_launch("bpr_fwd_finalize_kernel");
 }
 
@@ -195,12 +244,12 @@ extern "C" int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i, const
 
 extern "C" int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col,
                                         const int64_t *users, int32_t B, int32_t num_item,
-                                        uint64_t seed, uint64_t step, int64_t id_offset,
-                                        int64_t *out_neg, void *stream) {
+                                        uint64_t seed, uint64_t step, const int64_t *step_dev,
+                                        int64_t id_offset, int64_t *out_neg, void *stream) {
   if (!hist_rowptr || !users || !out_neg) return fail(CHAOREC_E_INVALID, "sample: NULL argument");
   if (B <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "sample: B=%d num_item=%d", B, num_item);
   hipLaunchKernelGGL(sample_negatives_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     hist_rowptr, hist_col, users, B, (uint32_t)num_item, seed, step, id_offset,
+                     hist_rowptr, hist_col, users, B, (uint32_t)num_item, seed, step, step_dev, id_offset,
                      out_neg);
   return check_launch("sample_negatives_kernel");
 }

@@ -148,6 +148,14 @@ class ShardedLightGCN(nn.Module):
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         return out[0] / world          # global loss = mean over ranks; item grads are SUMMED by the all-reduce
 
+    def loss_local(self, users, pos_items, neg_items):
+        """loss() for device batches that already hold LOCAL item ids (ops.draw_batch)."""
+        fu, fi = self.forward()
+        bpr = self.bpr_fn or ops.bpr_loss
+        out = bpr(fu, fi, users, pos_items, neg_items, ops.VARIANT_LOG_SIGMOID_EPS, self.reg_weight)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        return out[0] / world
+
     def gene_ranklist(self, topk=50, gather=False):
         """Rank this shard's users against the replicated item table; ids are GLOBAL (item + U_global)."""
         with torch.no_grad():

@@ -115,7 +115,7 @@ def layer_mean_propagate(x0, csr, n_layers):
 # BPR
 # --------------------------------------------------------------------------------------------
 class _BPR(torch.autograd.Function):
-    """out = [total, bpr, reg]; tab_i=None means "items live in tab_u from row item_offset on"
+    """-> (total loss, tensor[total, bpr, reg]); tab_i=None means "items live in tab_u from row item_offset on"
     (LightGCN/MMGCN keep users and items in one [N,D] table: one gradient buffer, no slicing)."""
 
     @staticmethod
@@ -132,17 +132,20 @@ class _BPR(torch.autograd.Function):
         B = users.numel()
         dev = tab_u.device
         out = torch.empty(3, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)   # own allocation: its gradient arrives 0-dim
         coef = torch.empty(B, dtype=torch.float32, device=dev)
         ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
         rc = _lib.load().chaorec_bpr_fwd_f32(_ptr(tab_u), pi, _ptr(users), _ptr(pos), _ptr(neg), B, D,
-                                             variant, reg_weight, _ptr(out), _ptr(coef), _ptr(ws), _stream())
+                                             variant, reg_weight, _ptr(out), _ptr(loss), _ptr(coef), _ptr(ws),
+                                             _stream())
         _lib.check(rc, "chaorec_bpr_fwd_f32")
         ctx.save_for_backward(tab_u, tab_i, users, pos, neg, coef)
         ctx.reg_weight, ctx.item_offset = reg_weight, item_offset
-        return out
+        ctx.mark_non_differentiable(out)
+        return loss, out
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_loss, _g_parts):
         tab_u, tab_i, users, pos, neg, coef = ctx.saved_tensors
         B, D = users.numel(), tab_u.shape[1]
         g_u = torch.zeros_like(tab_u)
@@ -153,27 +156,57 @@ class _BPR(torch.autograd.Function):
         else:
             g_i = torch.zeros_like(tab_i)
             pi, pgi = _ptr(tab_i), _ptr(g_i)
-        go = g_out[0:1].contiguous()  # d/d(total); [bpr, reg] are reporting outputs only
+        go = g_loss.contiguous()
         rc = _lib.load().chaorec_bpr_bwd_f32(_ptr(tab_u), pi, _ptr(users), _ptr(pos), _ptr(neg), B, D,
                                              _ptr(coef), ctx.reg_weight, _ptr(go), _ptr(g_u), pgi, _stream())
         _lib.check(rc, "chaorec_bpr_bwd_f32")
         return g_u, g_i, None, None, None, None, None, None
 
 
+class _LossParts:
+    """What bpr_loss returns: indexable like the old [total, bpr, reg] tensor; [0] is the differentiable total."""
+
+    def __init__(self, loss, parts):
+        self.loss, self.parts = loss, parts
+
+    def __getitem__(self, i):
+        return self.loss if i == 0 else self.parts[i]
+
+    def detach(self):
+        return self.parts.detach()
+
+
 def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset=0):
-    """Fused BPR(+L2) over a batch of LOCAL row ids -> tensor [total, bpr, reg]; differentiate [0]."""
-    return _BPR.apply(tab_u, tab_i, users, pos, neg, int(variant), float(reg_weight), int(item_offset))
+    """Fused BPR(+L2) over a batch of LOCAL row ids -> [total, bpr, reg]; differentiate [0]."""
+    loss, parts = _BPR.apply(tab_u, tab_i, users, pos, neg, int(variant), float(reg_weight), int(item_offset))
+    return _LossParts(loss, parts)
 
 
-def sample_negatives(hist, users, num_item, seed, step, id_offset):
+def sample_negatives(hist, users, num_item, seed, step, id_offset, step_dev=None):
+    """One uniform negative per user, never in the user's history.  `step_dev` (int64 device scalar) is added to
+    `step`: lets a captured hipGraph draw a fresh batch on every replay."""
     rowptr, col = hist
-    _need_cuda(rowptr, col, users)
+    _need_cuda(rowptr, col, users, step_dev)
     users = users.to(torch.int64).contiguous()
     out = torch.empty_like(users)
     rc = _lib.load().chaorec_sample_negatives(_ptr(rowptr), _ptr(col), _ptr(users), users.numel(), num_item,
-                                              seed, step, id_offset, _ptr(out), _stream())
+                                              seed, step, _ptr(step_dev), id_offset, _ptr(out), _stream())
     _lib.check(rc, "chaorec_sample_negatives")
     return out
+
+
+def draw_batch(edges, hist, B, num_user, num_item, seed, step, step_dev=None):
+    """(users, pos_local, neg_local) for one batch in ONE launch: uniform edge pick + gather + negative draw."""
+    rowptr, col = hist
+    _need_cuda(edges, rowptr, col, step_dev)
+    if edges.dtype != torch.int64 or not edges.is_contiguous():
+        raise TypeError("draw_batch: edges must be a contiguous int64 [E, 2] tensor")
+    out = torch.empty((3, B), dtype=torch.int64, device=edges.device)
+    rc = _lib.load().chaorec_draw_batch(_ptr(edges), edges.shape[0], _ptr(rowptr), _ptr(col), B, num_user, num_item,
+                                        seed, step, _ptr(step_dev), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                        _stream())
+    _lib.check(rc, "chaorec_draw_batch")
+    return out[0], out[1], out[2]
 
 
 # --------------------------------------------------------------------------------------------

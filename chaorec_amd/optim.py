@@ -48,11 +48,14 @@ class GraphedTrainStep:
     replayed from one captured hipGraph.  Batch tensors must keep their shapes (the last, short batch of an
     epoch falls back to the eager path).  Returns the (device) loss of the step."""
 
-    def __init__(self, model, optimizer, example_batch, warmup=3):
-        self.model, self.optimizer = model, optimizer
+    def __init__(self, model, optimizer, example_batch=None, warmup=3, batch_fn=None, loss_fn=None):
+        """`batch_fn` (optional): a capturable callable returning the batch tensors; it is captured INSIDE the
+        graph (device-side sampling from a device counter), and the step is then called with no arguments."""
+        self.model, self.optimizer, self.batch_fn = model, optimizer, batch_fn
+        self.loss_fn = loss_fn or model.loss
         dev = next(model.parameters()).device
-        self.static = [b.to(dev).clone() for b in example_batch]
-        self.shapes = [tuple(b.shape) for b in self.static]
+        self.static = [b.to(dev).clone() for b in example_batch] if example_batch is not None else None
+        self.shapes = [tuple(b.shape) for b in self.static] if self.static is not None else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -66,13 +69,19 @@ class GraphedTrainStep:
         self.replays = 0
 
     def _eager(self, batch):
+        if self.batch_fn is not None:
+            batch = self.batch_fn()
         self.optimizer.zero_grad(set_to_none=True)
-        loss = self.model.loss(*batch)
+        loss = self.loss_fn(*batch)
         loss.backward()
         self.optimizer.step()
         return loss.detach()
 
     def __call__(self, *batch):
+        if self.batch_fn is not None:
+            self.graph.replay()
+            self.replays += 1
+            return self.static_loss
         if [tuple(b.shape) for b in batch] != self.shapes:
             return self._eager([b.to(self.static[0].device) for b in batch])
         for dst, src in zip(self.static, batch):

@@ -86,7 +86,8 @@ int chaorec_spmm_rows_per_wave(int32_t D);
  *   variant 2: t_b = log(sigmoid(d_b))
  *   bpr  = -(1/B) sum_b t_b
  *   reg  = reg_weight * (mean(u^2) + mean(p^2) + mean(n^2)),  means over B*D  (0 if reg_weight==0)
- *   out_loss[0] = bpr + reg, out_loss[1] = bpr, out_loss[2] = reg
+ *   out_loss[0] = bpr + reg, out_loss[1] = bpr, out_loss[2] = reg;  out_total (optional, may be NULL) also
+ *   receives bpr + reg as a stand-alone scalar (a separate allocation keeps the host-side autograd simple)
  *   coef[b] = d(bpr)/d(d_b)   (kept for the backward)
  * workspace: 4*B floats.  Reductions run in a fixed order: results are run-to-run identical.
  *
@@ -102,7 +103,7 @@ int chaorec_spmm_rows_per_wave(int32_t D);
 int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i,
                         const int64_t *users, const int64_t *pos, const int64_t *neg,
                         int32_t B, int32_t D, int32_t variant, float reg_weight,
-                        float *out_loss, float *coef, float *workspace, void *stream);
+                        float *out_loss, float *out_total, float *coef, float *workspace, void *stream);
 
 int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i,
                         const int64_t *users, const int64_t *pos, const int64_t *neg,
@@ -117,12 +118,23 @@ int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i,
  *           not interacted with), not bit-wise: the reference uses Python's Mersenne Twister.
  * hist_* is the user -> interacted LOCAL item ids CSR, ids ascending inside a row.
  * Draws are a pure function of (seed, step, b, attempt): reproducible and order-free.
+ * step_dev (optional device int64 scalar) is added to `step`, so a captured hipGraph can advance the stream
+ * of draws from a device-resident batch counter.
  * out_neg[b] = local item id + id_offset (the reference hands out GLOBAL ids = item + num_user).
  * ------------------------------------------------------------------------------------- */
 int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col,
                              const int64_t *users, int32_t B, int32_t num_item,
-                             uint64_t seed, uint64_t step, int64_t id_offset,
+                             uint64_t seed, uint64_t step, const int64_t *step_dev, int64_t id_offset,
                              int64_t *out_neg, void *stream);
+
+/* One launch per training batch for a streaming trainer: B edges picked uniformly from `edges` ([n_edges, 2]
+ * int64, GLOBAL item ids, device), their (user, positive) gathered and one negative drawn for each by the rule
+ * above (same draw stream as chaorec_sample_negatives).  Replaces DataLoader(shuffle=True) +
+ * TrainingDataset.__getitem__ (main.py:194-195, dataload.py:74-106).  Outputs LOCAL item ids. */
+int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *hist_rowptr,
+                       const int32_t *hist_col, int32_t B, int64_t num_user, int32_t num_item,
+                       uint64_t seed, uint64_t step, const int64_t *step_dev, int64_t *out_users,
+                       int64_t *out_pos, int64_t *out_neg, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * R: all-items scoring + history mask + top-K, never materialising the [U, I] matrix.

@@ -219,7 +219,7 @@ def test_bpr_loss_is_run_to_run_identical(dev):
     idx = [torch.from_numpy(rng.integers(0, 250, 1024)).to(dev) for _ in range(3)]
     a = ops.bpr_loss(tab, None, *idx, 0, 1e-3, item_offset=250)
     b = ops.bpr_loss(tab, None, *idx, 0, 1e-3, item_offset=250)
-    assert torch.equal(a, b)
+    assert torch.equal(a.detach(), b.detach())
 
 
 def test_sampler_bit_exact_and_never_in_history(dev, oracle, baby):
@@ -511,3 +511,68 @@ def test_graphed_step_equals_eager_and_torch_adam(dev):
         assert np.allclose(results[mode][1], results["torch"][1], rtol=0, atol=5e-6), mode
     assert np.array_equal(results["graph"][1], results["fused"][1]) or \
         np.allclose(results["graph"][1], results["fused"][1], rtol=0, atol=1e-6)
+
+
+def test_graphed_step_with_in_graph_sampling(dev, oracle):
+    """batch_fn captured inside the hipGraph: every replay draws a fresh batch from the device counter, and the
+    draws are the oracle's (seed, step) function of that counter."""
+    from chaorec_amd import graph, ops
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D, B = 900, 500, 4000, 64, 128
+    edges = synthetic_interactions(U, I, E, seed=6)
+    torch.manual_seed(0)
+    m = LightGCN(U, I, edges, graph.user_item_dict_from_edges(edges), D, 1e-3, 2, "add", dev).to(dev)
+    opt = FusedAdam(m.parameters(), lr=1e-2)
+    edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    seen = {}
+
+    def draw():
+        sel = torch.randint(0, E, (B,), device=dev)
+        counter.add_(1)
+        users, pos = edges_dev[sel, 0], edges_dev[sel, 1]
+        neg = ops.sample_negatives(m.hist, users, I, 11, 0, U, step_dev=counter)
+        seen["users"], seen["neg"] = users, neg
+        return users, pos, neg
+
+    g = GraphedTrainStep(m, opt, batch_fn=draw, warmup=2)
+    c0 = int(counter.item())
+    hist = oracle.user_hist_csr(edges, U)
+    losses, negs = [], []
+    for k in range(4):
+        losses.append(float(g()))
+        assert int(counter.item()) == c0 + k + 1
+        u_np, n_np = seen["users"].cpu().numpy(), seen["neg"].cpu().numpy()
+        want = oracle.sample_negatives(hist, u_np, I, seed=11, step=c0 + k + 1, id_offset=U)
+        assert np.array_equal(n_np, want)
+        negs.append(n_np.copy())
+    assert g.replays == 4 and len(set(losses)) == 4
+    assert not np.array_equal(negs[0], negs[1])
+
+
+def test_draw_batch_one_launch(dev, oracle, baby):
+    """chaorec_draw_batch: edges are real training edges, local ids, negatives follow the sampler's stream."""
+    from chaorec_amd import ops
+    U, I = baby["U"], baby["I"]
+    edges = torch.from_numpy(baby["train"].astype(np.int64)).to(dev)
+    hist = oracle.user_hist_csr(baby["train"], U)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    B = 4096
+    counter = torch.tensor([5], dtype=torch.int64, device=dev)
+    u, p, n = ops.draw_batch(edges, dh, B, U, I, 42, 2, step_dev=counter)          # effective step 7
+    u, p, n = u.cpu().numpy(), p.cpu().numpy(), n.cpu().numpy()
+    train = set(map(tuple, baby["train"].tolist()))
+    assert all((int(a), int(b) + U) in train for a, b in zip(u[:500], p[:500]))    # picked pairs are training edges
+    assert np.array_equal(n, oracle.sample_negatives(hist, u, I, seed=42, step=7, id_offset=0))
+    assert len(np.unique(u)) > B // 4                                               # spread over the edge list
+    u2, _, _ = ops.draw_batch(edges, dh, B, U, I, 42, 8)
+    assert (u2.cpu().numpy() != u).mean() > 0.9
+    # uniform over edges: users appear in proportion to their degree (chi-square on degree buckets)
+    big = torch.cat([ops.draw_batch(edges, dh, 65536, U, I, 1, s)[0] for s in range(4)]).cpu().numpy()
+    deg = np.bincount(baby["train"][:, 0], minlength=U)
+    got = np.bincount(deg[big], minlength=deg.max() + 1).astype(np.float64)
+    exp = np.bincount(deg, weights=deg.astype(np.float64), minlength=deg.max() + 1) / deg.sum() * len(big)
+    keep = exp > 50
+    assert ((got[keep] - exp[keep]) ** 2 / exp[keep]).sum() < 3 * keep.sum()
