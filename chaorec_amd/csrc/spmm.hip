@@ -13,12 +13,18 @@
 //     the adds themselves stay in CSR order with separately rounded product and sum, so the
 //     result is bit-identical to a sequential scatter_add_ in the reference's edge order.
 #include "common.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 namespace chaorec {
 
 __device__ __forceinline__ float4 shfl4(float4 v, int src) {
   return make_float4(__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64), __shfl(v.w, src, 64));
 }
+
+constexpr int kInline = 6;      // (col,val) pairs carried inside a row descriptor
+constexpr int kDescDwords = 16;  // 64-B descriptor: row, deg|flag, e0 lo/hi, 6 cols, 6 vals
 
 #ifndef CHAOREC_SPMM_UNR
 #define CHAOREC_SPMM_UNR 8
@@ -36,7 +42,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     const float *__restrict__ val, const float *__restrict__ x, float *__restrict__ y,
     int64_t n_rows, int D4, float alpha, const float *__restrict__ z, float beta,
     float *acc, const float *__restrict__ acc_init, float acc_w,
-    const int32_t *__restrict__ group_order, int64_t n_groups) {
+    const int32_t *__restrict__ sched, int64_t n_groups) {
   constexpr int NG = kWave / LPR;   // lane groups = destination rows per wave
   constexpr int UNR = CHAOREC_SPMM_UNR;  // gathered rows in flight per group (short-row phase)
   constexpr int UNR2 = (kWave / NG) < 16 ? (kWave / NG) : 16;  // per group in the long-row phase
@@ -45,22 +51,65 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   const int sub = lane / LPR;
   const int li = lane % LPR;
   const int64_t wslot = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  // longest-first schedule: the host sorts the NG-row groups by their heaviest row so the long
-  // rows start at t=0 instead of stretching the tail (the output location is unchanged).
-  // Surplus waves of the last block stay (they take part in the block barriers below) with no rows.
-  const int64_t wave = wslot < n_groups ? (group_order ? (int64_t)group_order[wslot] : wslot) : n_groups;
-  const int64_t r = wave * NG + sub;
-  const bool row_ok = r < n_rows;
-
-  int64_t e0 = 0, e1 = 0;
-  if (row_ok) {
-    e0 = rowptr[r];
-    e1 = rowptr[r + 1];
+  // The index chain of a plain CSR walk, schedule -> rowptr -> (col,val) -> x, is four dependent loads and
+  // the waves of this kernel spend ~3/4 of their life waiting on exactly that (SQ_WAIT_ANY), not on bandwidth.
+  // So the host packs a 64-B ROW DESCRIPTOR per row, stored in schedule order: {row, deg|flag, e0, the first
+  // kInline (col,val) pairs}.  One coalesced load per wave fetches its 4 descriptors; rows of <= kInline
+  // entries (the median row) then need only descriptor -> x -> store.  Entry order is unchanged.
+  int64_t r = -1, e0 = 0;
+  int deg = 0;
+  bool blk_long = true;   // without a schedule every block runs the cooperative section
+  int icol[kInline];
+  float ival[kInline];
+#pragma unroll
+  for (int j = 0; j < kInline; ++j) {
+    icol[j] = 0;
+    ival[j] = 0.f;
   }
-  const int deg = (int)(e1 - e0);
+  int n_inl = 0;          // entries of this row already in registers
+  if (sched) {
+    constexpr int LD = LPR >= 16 ? 16 : LPR;      // lanes of a group that hold descriptor dwords
+    constexpr int DW = 16 / LD;                    // dwords per such lane
+    const int32_t *dp = sched + ((size_t)wslot * NG + sub) * 16;
+    int dws[DW];
+#pragma unroll
+    for (int k = 0; k < DW; ++k) dws[k] = (li < LD) ? dp[li + k * LD] : 0;
+    auto dword = [&](int j) { return __shfl(dws[j / LD], sub * LPR + (j % LD), 64); };
+    r = dword(0);
+    const int d1 = dword(1);
+    deg = d1 & 0x7fffffff;
+    blk_long = d1 < 0;
+    e0 = ((int64_t)dword(3) << 32) | (int64_t)(unsigned int)dword(2);
+#pragma unroll
+    for (int j = 0; j < kInline; ++j) {
+      icol[j] = dword(4 + j);
+      ival[j] = __int_as_float(dword(4 + kInline + j));
+    }
+    n_inl = kInline;
+  } else {
+    // Surplus waves of the last block stay (they take part in the block barriers below) with no rows.
+    r = wslot < n_groups ? wslot * NG + sub : -1;
+    if (r >= n_rows) r = -1;
+    if (r >= 0) {
+      e0 = rowptr[r];
+      deg = (int)(rowptr[r + 1] - e0);
+    }
+  }
+#ifdef CHAOREC_EXP_NOLONG
+  blk_long = false;
+#endif
+#ifdef CHAOREC_EXP_EMPTY
+  if (n_rows >= 0) return;
+#endif
+  const bool row_ok = r >= 0;
+#ifdef CHAOREC_EXP_NOLONG
+  const bool is_long = false;
+#else
   const bool is_long = (NG > 1) && deg > LONG_T;
+#endif
   const int deg1 = is_long ? 0 : deg;
-  const int dmax = wave_max_i32(deg1);  // wave-uniform trip counts keep every shuffle fully active
+  const int rest = max(deg1 - n_inl, 0);            // entries still to be fetched from the CSR arrays
+  const int dmax = wave_max_i32(rest);  // wave-uniform trip counts keep every shuffle fully active
 
   float4 sum[CPL];
 #pragma unroll
@@ -68,15 +117,71 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
 
   const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
 
-  // ---- phase 1: every group walks its own (short) row, UNR source rows in flight -----------
-  for (int base = 0; base < dmax; base += LPR) {
-    int c = 0;
-    float v = 0.f;
-    if (base + li < deg1) {  // one coalesced (col,val) load per group, broadcast below
-      c = col[e0 + base + li];
-      v = val[e0 + base + li];
+  // epilogue operands (beta*z, the running layer mean) only depend on the row: fetch them now, under the
+  // gathers, instead of as one more dependent load at the very end of the wave
+  const float4 *z4 = reinterpret_cast<const float4 *>(z);
+  const float4 *init4 = reinterpret_cast<const float4 *>(acc_init);
+  float4 *acc4 = reinterpret_cast<float4 *>(acc);
+  float4 zpre[CPL], apre[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int chunk = li + q * LPR;
+    zpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    apre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_ok && chunk < D4) {
+      const size_t o = (size_t)r * (size_t)D4 + chunk;
+      if (z) zpre[q] = z4[o];
+      if (acc) apre[q] = acc_init ? init4[o] : acc4[o];
     }
-    const int n = min(LPR, deg1 - base);
+  }
+
+  // ---- phase 1: every group walks its own (short) row -----------------------------------------
+  // the first (col,val) block of the remainder is requested BEFORE the inline gathers so that its round trip
+  // overlaps theirs
+  const int64_t e0r = e0 + n_inl;
+  int c_first = 0;
+  float v_first = 0.f;
+  if (li < rest) {
+    c_first = col[e0r + li];
+    v_first = val[e0r + li];
+  }
+  // first the entries that came with the descriptor (all in flight at once) ...
+  if (sched) {
+    float4 xin[kInline][CPL];
+#pragma unroll
+    for (int j = 0; j < kInline; ++j) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int chunk = li + q * LPR;
+        xin[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef CHAOREC_EXP_NOGATHER
+        if (j < deg1 && chunk < D4) xin[j][q] = x4[(size_t)icol[j] * (size_t)D4 + chunk];
+#else
+        xin[j][q] = make_float4((float)icol[j], 1.f, 2.f, 3.f);
+#endif
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kInline; ++j) {
+      if (j < deg1) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) sum[q] = add_rn4(sum[q], mul_rn4(ival[j], xin[j][q]));
+      }
+    }
+  }
+  // ... then the rest of the row from the CSR arrays, UNR source rows in flight
+  for (int base = 0; base < dmax; base += LPR) {
+    int c = c_first;
+    float v = v_first;
+    if (base > 0) {
+      c = 0;
+      v = 0.f;
+      if (base + li < rest) {  // one coalesced (col,val) load per group, broadcast below
+        c = col[e0r + base + li];
+        v = val[e0r + base + li];
+      }
+    }
+    const int n = min(LPR, rest - base);
     const int nmax = min(LPR, dmax - base);
     for (int j = 0; j < nmax; j += UNR) {
       int cj[UNR];
@@ -96,7 +201,11 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
         for (int q = 0; q < CPL; ++q) {
           const int chunk = li + q * LPR;
           xv[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef CHAOREC_EXP_NOGATHER
           if (p[u] && chunk < D4) xv[u][q] = x4[(size_t)cj[u] * (size_t)D4 + chunk];
+#else
+          xv[u][q] = make_float4((float)cj[u], 1.f, 2.f, 3.f);
+#endif
         }
       }
 #pragma unroll
@@ -136,9 +245,11 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     const int wv = threadIdx.x >> 6;
     float4 *tile = tile_all[wv];
     const float *tilef = reinterpret_cast<const float *>(tile);
+    int my_slot = -1;
+    int nl = 0;
+    if (blk_long) {   // block-uniform (the host sets the flag on all descriptors of a block)
     if (threadIdx.x == 0) n_long_s = 0;
     __syncthreads();
-    int my_slot = -1;
     if (is_long && li == 0) {
       my_slot = atomicAdd(&n_long_s, 1);
       long_e0[my_slot] = e0;
@@ -146,7 +257,8 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     }
     my_slot = __shfl(my_slot, sub * LPR, 64);
     __syncthreads();
-    const int nl = n_long_s;  // block-uniform
+    nl = n_long_s;  // block-uniform
+    }
     for (int t = 0; t < nl; ++t) {
       const int n = long_n[t];
       const int64_t le0 = long_e0[t];
@@ -254,20 +366,21 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   }
 
   if (!row_ok) return;
-  const float4 *z4 = reinterpret_cast<const float4 *>(z);
-  const float4 *init4 = reinterpret_cast<const float4 *>(acc_init);
   float4 *y4 = reinterpret_cast<float4 *>(y);
-  float4 *acc4 = reinterpret_cast<float4 *>(acc);
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
     const int chunk = li + q * LPR;
     if (chunk >= D4) continue;
     const size_t o = (size_t)r * (size_t)D4 + chunk;
     float4 s = mul_rn4(alpha, sum[q]);
-    if (z) s = add_rn4(s, mul_rn4(beta, z4[o]));
+    if (z) s = add_rn4(s, mul_rn4(beta, zpre[q]));
+#ifndef CHAOREC_EXP_NOSTORE
     if (y) y4[o] = s;
+#else
+    if (y && s.x == 12345.678f) y4[o] = s;
+#endif
     if (acc) {
-      const float4 a0 = acc_init ? mul_rn4(acc_w, init4[o]) : acc4[o];
+      const float4 a0 = acc_init ? mul_rn4(acc_w, apre[q]) : apre[q];
       acc4[o] = add_rn4(a0, mul_rn4(acc_w, s));
     }
   }
@@ -276,16 +389,23 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
 template <int LPR, int CPL>
 static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                        float *y, int64_t n_rows, int D4, float alpha, const float *z, float beta,
-                       float *acc, const float *acc_init, float acc_w, const int32_t *group_order,
+                       float *acc, const float *acc_init, float acc_w, const int32_t *sched,
                        hipStream_t st) {
   constexpr int RPW = kWave / LPR;
   const int64_t waves = (n_rows + RPW - 1) / RPW;
-  const int64_t blocks = (waves + 3) / 4;
+  const int64_t blocks = (waves + 3) / 4;     // the schedule has exactly 4 * blocks wave slots
   if (blocks > 0x7fffffffLL) return fail(CHAOREC_E_INVALID, "spmm: grid too large");
   hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL>), dim3((unsigned)blocks), dim3(256), 0, st,
-                     rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, group_order,
+                     rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
                      waves);
   return check_launch("spmm_csr_ordered_kernel");
+}
+
+static int rows_per_wave(int D) {
+  if (D < 4 || (D & 3)) return 0;
+  int lpr = 1;
+  while (lpr < D / 4 && lpr < 64) lpr <<= 1;
+  return 64 / lpr;
 }
 
 }  // namespace chaorec
@@ -295,7 +415,7 @@ using namespace chaorec;
 extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                                     const float *x, float *y, int64_t n_rows, int64_t n_cols,
                                     int32_t D, float alpha, const float *z, float beta, float *acc,
-                                    const float *acc_init, float acc_w, const int32_t *group_order,
+                                    const float *acc_init, float acc_w, const int32_t *schedule,
                                     int32_t mode, void *stream) {
   if (!rowptr || !x || (!y && !acc)) return fail(CHAOREC_E_INVALID, "spmm: NULL rowptr/x or no output");
   if (n_rows < 0 || n_cols < 0) return fail(CHAOREC_E_INVALID, "spmm: negative size");
@@ -305,7 +425,7 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
   if (n_rows == 0) return CHAOREC_OK;
   hipStream_t st = (hipStream_t)stream;
   const int D4 = D / 4;
-#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, group_order, st
+#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, st
   if (D4 <= 1) return launch_spmm<1, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 2) return launch_spmm<2, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 4) return launch_spmm<4, 1>(CHAOREC_SPMM_ARGS);
@@ -319,9 +439,68 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
 #undef CHAOREC_SPMM_ARGS
 }
 
-extern "C" int chaorec_spmm_rows_per_wave(int32_t D) {
-  if (D < 4 || (D & 3)) return 0;
-  int lpr = 1;
-  while (lpr < D / 4 && lpr < 64) lpr <<= 1;
-  return 64 / lpr;
+extern "C" int chaorec_spmm_rows_per_wave(int32_t D) { return rows_per_wave(D); }
+
+// ---- host-side schedule builder (no GPU work) --------------------------------------------------
+// Wave slot s (4 per workgroup) handles the G = rows_per_wave(D) consecutive rows of one group.  Groups are
+// sorted by their heaviest row and dealt out so that workgroup b receives the b-th heaviest group plus one
+// group from each lighter quantile: long rows start first AND land in different workgroups (a workgroup walks
+// its long rows one at a time).  Every row gets a 64-B descriptor in slot order.
+extern "C" int64_t chaorec_spmm_schedule_len(int64_t n_rows, int32_t D) {
+  const int g = rows_per_wave(D);
+  if (g == 0 || n_rows <= 0) return 0;
+  const int64_t groups = (n_rows + g - 1) / g;
+  const int64_t blocks = (groups + 3) / 4;
+  return blocks * 4 * g * kDescDwords;
+}
+
+extern "C" int chaorec_spmm_build_schedule(const int64_t *rowptr, const int32_t *col, const float *val,
+                                           int64_t n_rows, int32_t D, int32_t *out, int64_t out_len) {
+  const int g = rows_per_wave(D);
+  if (!rowptr || !out || g == 0 || n_rows <= 0) return fail(CHAOREC_E_INVALID, "build_schedule: bad argument");
+  const int64_t need = chaorec_spmm_schedule_len(n_rows, D);
+  if (out_len < need) return fail(CHAOREC_E_WORKSPACE, "build_schedule: out_len %lld < %lld", (long long)out_len, (long long)need);
+  const int64_t groups = (n_rows + g - 1) / g;
+  const int64_t nb = (groups + 3) / 4;
+  std::vector<int64_t> heavy(groups, 0), order(groups);
+  for (int64_t gi = 0; gi < groups; ++gi) {
+    order[gi] = gi;
+    for (int s = 0; s < g; ++s) {
+      const int64_t r = gi * g + s;
+      if (r < n_rows) heavy[gi] = std::max(heavy[gi], rowptr[r + 1] - rowptr[r]);
+    }
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return heavy[a] > heavy[b]; });
+  std::memset(out, 0, (size_t)need * sizeof(int32_t));
+  for (int64_t b = 0; b < nb; ++b) {
+    bool any_long = false;
+    int64_t grp[4];
+    for (int j = 0; j < 4; ++j) {
+      const int64_t k = (int64_t)j * nb + b;   // slot 4*b + j  <-  sorted[j*nb + b]
+      grp[j] = k < groups ? order[k] : -1;
+      if (grp[j] >= 0 && g > 1 && heavy[grp[j]] > CHAOREC_SPMM_LONG_T) any_long = true;
+    }
+    for (int j = 0; j < 4; ++j) {
+      for (int s = 0; s < g; ++s) {
+        int32_t *d = out + (((size_t)(4 * b + j)) * g + s) * kDescDwords;
+        const int64_t r = grp[j] >= 0 ? grp[j] * g + s : -1;
+        if (r < 0 || r >= n_rows) {
+          d[0] = -1;
+          d[1] = any_long ? (int32_t)0x80000000u : 0;
+          continue;
+        }
+        const int64_t e0 = rowptr[r], deg = rowptr[r + 1] - e0;
+        if (deg > 0x7fffffffLL) return fail(CHAOREC_E_INVALID, "build_schedule: row %lld too long", (long long)r);
+        d[0] = (int32_t)r;
+        d[1] = (int32_t)deg | (any_long ? (int32_t)0x80000000u : 0);
+        d[2] = (int32_t)(e0 & 0xffffffffll);
+        d[3] = (int32_t)(e0 >> 32);
+        for (int q = 0; q < kInline && q < deg; ++q) {
+          d[4 + q] = col[e0 + q];
+          std::memcpy(&d[4 + kInline + q], &val[e0 + q], 4);
+        }
+      }
+    }
+  }
+  return CHAOREC_OK;
 }

@@ -31,30 +31,27 @@ class CSR:
         return CSR(self.rowptr.to(device), self.col.to(device), self.val.to(device), self.n_rows,
                    self.n_cols, self.symmetric, t)
 
-    def group_order(self, rows_per_wave, waves_per_block=4):
-        """Schedule for the SpMM kernel: permutation (int32, on the graph's device) of the groups of
-        `rows_per_wave` consecutive rows.  Groups are sorted by their heaviest row, then dealt out so that
-        block b (= `waves_per_block` consecutive wave slots) receives the b-th heaviest group plus one group
-        from each lighter quantile: long rows start first AND land in different workgroups (a workgroup walks
-        its long rows one at a time)."""
-        g = int(rows_per_wave)
-        if g <= 0:
+    def schedule(self, D):
+        """The SpMM kernel's schedule for feature width D (int32 tensor on the graph's device, cached): row
+        descriptors in workgroup order, built on the host by chaorec_spmm_build_schedule -- longest rows first,
+        one heavy group per workgroup, the first (col,val) pairs of every row inline."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        g = lib.chaorec_spmm_rows_per_wave(int(D))
+        if g <= 0 or self.n_rows == 0:
             return None
         if g not in self._orders:
-            deg = (self.rowptr[1:] - self.rowptr[:-1]).cpu()
-            n_groups = (self.n_rows + g - 1) // g
-            pad = n_groups * g - self.n_rows
-            if pad:
-                deg = torch.cat([deg, torch.zeros(pad, dtype=deg.dtype)])
-            heavy = deg.view(n_groups, g).max(dim=1).values
-            order = torch.argsort(heavy, descending=True, stable=True)
-            w = int(waves_per_block)
-            nb = (n_groups + w - 1) // w
-            slots = torch.full((nb * w,), -1, dtype=torch.int64)
-            slots[:n_groups] = order
-            order = slots.view(w, nb).t().reshape(-1)      # slot 4*b + j  <-  sorted[j*nb + b]
-            order = order[order >= 0].to(torch.int32)
-            self._orders[g] = order.to(self.rowptr.device)
+            rowptr = self.rowptr.cpu().contiguous()
+            col = self.col.cpu().contiguous()
+            val = self.val.cpu().contiguous()
+            n = lib.chaorec_spmm_schedule_len(self.n_rows, int(D))
+            out = torch.empty(n, dtype=torch.int32)
+            rc = lib.chaorec_spmm_build_schedule(ctypes.c_void_p(rowptr.data_ptr()), ctypes.c_void_p(col.data_ptr()),
+                                                 ctypes.c_void_p(val.data_ptr()), self.n_rows, int(D),
+                                                 ctypes.c_void_p(out.data_ptr()), n)
+            _lib.check(rc, "chaorec_spmm_build_schedule")
+            self._orders[g] = out.to(self.rowptr.device)
         return self._orders[g]
 
     def t(self):

@@ -50,7 +50,7 @@ def spmm_raw(csr, x, y=None, alpha=1.0, z=None, beta=0.0, acc=None, acc_init=Non
     if want_y and y is None:
         y = torch.empty((csr.n_rows, D), dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    order = csr.group_order(lib.chaorec_spmm_rows_per_wave(D))
+    order = csr.schedule(D)
     rc = lib.chaorec_spmm_csr_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x),
                                   _ptr(y if want_y else None), csr.n_rows, csr.n_cols, D, alpha,
                                   _ptr(z), beta, _ptr(acc), _ptr(acc_init), acc_w, _ptr(order), 0, _stream())

@@ -58,20 +58,27 @@ const char *chaorec_last_error(void);
  * transposed CSR:  g_l = A^T g_{l+1} + beta * G.
  *
  * D must be a multiple of 4, 4 <= D <= 1024.  rowptr is int64 (nnz of config 5 > 2^31).
- * group_order (optional, may be NULL): a permutation of the row groups [0, ceil(n_rows/G)),
- *   G = chaorec_spmm_rows_per_wave(D), giving the order in which wave slots pick up groups --
- *   the host sorts groups longest-row-first so heavy rows do not stretch the tail.  It changes
- *   scheduling only, never results.
+ * schedule (optional, may be NULL): the array built by chaorec_spmm_build_schedule() for this graph and D,
+ *   copied to the device.  It fixes which workgroup walks which rows (longest rows first, one heavy group per
+ *   workgroup) and carries a 64-B descriptor per row {row, degree, first entry, first 6 (col,val) pairs} so the
+ *   kernel's dependent-load chain is descriptor -> x instead of order -> rowptr -> (col,val) -> x.  It changes
+ *   scheduling and latency only, never results.
  * mode: 0 = ordered (bit-reproducible, reference order).
  * ------------------------------------------------------------------------------------- */
 int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                          const float *x, float *y, int64_t n_rows, int64_t n_cols, int32_t D,
                          float alpha, const float *z, float beta,
                          float *acc, const float *acc_init, float acc_w,
-                         const int32_t *group_order, int32_t mode, void *stream);
+                         const int32_t *schedule, int32_t mode, void *stream);
 
 /* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
 int chaorec_spmm_rows_per_wave(int32_t D);
+
+/* Host-side schedule builder for chaorec_spmm_csr_f32 (HOST pointers, no GPU work): int32 elements needed,
+ * and the build itself.  Graph-static: build once per (graph, D), keep the copy in HBM next to the CSR. */
+int64_t chaorec_spmm_schedule_len(int64_t n_rows, int32_t D);
+int chaorec_spmm_build_schedule(const int64_t *rowptr, const int32_t *col, const float *val,
+                                int64_t n_rows, int32_t D, int32_t *out, int64_t out_len);
 
 /* ---------------------------------------------------------------------------------------
  * P4/P5/P9/P13: fused BPR step on a batch of (user, pos, neg) triples.

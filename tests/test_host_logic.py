@@ -62,22 +62,34 @@ def test_csr_builders_match_oracle(oracle, baby, builder):
     assert mine.symmetric and mine.t() is mine
 
 
-def test_group_order_longest_first(baby):
+def test_spmm_schedule_descriptors(baby):
+    """chaorec_spmm_build_schedule: every row appears exactly once; descriptors carry degree, first entry and the
+    first 6 (col,val) pairs; the lead slot of every workgroup walks the heaviest groups in descending order; the
+    long-row flag is block-uniform."""
     from chaorec_amd import graph
     csr = graph.lightgcn_csr(baby["train"], baby["U"] + baby["I"])
-    order = csr.group_order(4).numpy()
-    n_groups = (csr.n_rows + 3) // 4
-    assert sorted(order.tolist()) == list(range(n_groups))
-    deg = np.diff(csr.rowptr.numpy())
-    deg = np.concatenate([deg, np.zeros(n_groups * 4 - len(deg), deg.dtype)]).reshape(n_groups, 4).max(1)
-    # the first slot of every block walks the heaviest groups in descending order ...
-    lead = deg[order[0::4]]
-    assert lead[0] == deg.max() and np.all(np.diff(lead[:n_groups // 4]) <= 0)
-    # ... and the other three slots of a block are lighter than its lead
-    nb = n_groups // 4
-    for j in (1, 2, 3):
-        assert np.all(deg[order[j:4 * nb:4]] <= lead[:nb])
-    assert csr.group_order(4) is csr.group_order(4)
+    sched = csr.schedule(64)
+    assert sched is csr.schedule(64) and sched.dtype == torch.int32
+    d = sched.numpy().reshape(-1, 16)
+    rows = d[:, 0]
+    valid = rows >= 0
+    assert sorted(rows[valid].tolist()) == list(range(csr.n_rows))
+    rp, col, val = csr.rowptr.numpy(), csr.col.numpy(), csr.val.numpy()
+    deg = d[:, 1] & 0x7fffffff
+    assert np.array_equal(deg[valid], np.diff(rp)[rows[valid]])
+    e0 = (d[:, 3].astype(np.int64) << 32) | (d[:, 2].astype(np.int64) & 0xffffffff)
+    assert np.array_equal(e0[valid], rp[rows[valid]])
+    for k in np.nonzero(valid)[0][::97]:
+        n = min(int(deg[k]), 6)
+        assert np.array_equal(d[k, 4:4 + n], col[e0[k]:e0[k] + n])
+        assert np.array_equal(d[k, 10:10 + n].view(np.float32), val[e0[k]:e0[k] + n])
+    # 4 rows per wave slot, 4 slots per workgroup
+    heavy = np.where(valid, deg, 0).reshape(-1, 4).max(1).reshape(-1, 4)      # [workgroup, slot]
+    assert heavy[0, 0] == np.diff(rp).max() and np.all(np.diff(heavy[:, 0]) <= 0)
+    assert np.all(heavy[:, 1:] <= heavy[:, :1])
+    flag = (d[:, 1] < 0).reshape(-1, 16)
+    assert np.all(flag == flag[:, :1])                                        # block-uniform
+    assert np.array_equal(flag[:, 0], heavy.max(1) > 32)
 
 
 def test_transpose_and_coalesce():

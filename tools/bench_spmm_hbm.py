@@ -34,11 +34,11 @@ else:
     edges = synthetic_interactions(U, I, E, seed=42)
     t1 = time.time()
     A = graph.lightgcn_csr(edges, N)
-order = A.group_order(ops._lib.load().chaorec_spmm_rows_per_wave(D))
+order = A.schedule(D)
 t2 = time.time()
 dev = torch.device("cuda:0")
 A = A.to(dev)
-A._orders = {k: v.to(dev) for k, v in [(ops._lib.load().chaorec_spmm_rows_per_wave(D), order)]}
+A._orders = {ops._lib.load().chaorec_spmm_rows_per_wave(D): order.to(dev)}
 torch.manual_seed(0)
 x = torch.randn(N, D, device=dev)
 y = torch.empty_like(x)

@@ -31,7 +31,7 @@ for path in sys.argv[1:]:
     lib.chaorec_spmm_rows_per_wave.restype = ctypes.c_int
     lib.chaorec_spmm_rows_per_wave.argtypes = [ctypes.c_int32]
     libs.append((os.path.basename(path), lib))
-order = A.group_order(libs[0][1].chaorec_spmm_rows_per_wave(D))
+order = A.schedule(D)
 st = torch.cuda.current_stream().cuda_stream
 
 
