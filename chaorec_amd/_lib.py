@@ -44,9 +44,11 @@ SIGNATURES = {
     "chaorec_score_topk_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                               c_ptr, c_ptr, ctypes.c_float, ctypes.c_int32, ctypes.c_int64,
                                               c_ptr, c_ptr, c_ptr, ctypes.c_size_t, ctypes.c_int32, c_ptr]),
+    "chaorec_gemm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "chaorec_gemm_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
-                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_ptr]),
+                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_ptr,
+                                        ctypes.c_size_t, c_ptr]),
     "chaorec_adam_step_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_float,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                              ctypes.c_int32, c_ptr]),

@@ -4,99 +4,256 @@
 // Replaces nn.Linear forward/backward on the modality features and MMGCN's per-layer Linears
 // (Model/FREEDOM.py:59-60,209,212; Model/MMGCN.py:40,97,102-131; BasicGCN.py:40).
 //
-// Block tile 128 x 64 x 16, 4 waves, each wave a 32 x 64 strip (two 32x32 accumulators).
-// Operand tiles are staged k-major in LDS ([k][row] with a +1 pad), so the MFMA fragment read
-// "lane (r, h) -> element [k = 2s + h][r]" walks consecutive banks.
 #include "common.h"
 
 namespace chaorec {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 64, BK = 16;
+// Block tile BM x BN x BK = 128 x {64,128} x 16, 4 waves.  BN=128: waves 2x2, each a 64x64 patch (2x2 MFMA
+// 32x32 accumulators); BN=64: waves 4x1, each 32x64 (1x2).  Operand tiles are staged k-major in LDS
+// ([k][row], rows padded by 4 floats), double-buffered: the next tile is fetched global -> registers (float4
+// along whichever dimension is contiguous in memory) while the current one feeds the MFMAs.  A k-step of the
+// f32 MFMA consumes k = 2s (lanes 0-31) and 2s+1 (lanes 32-63): the per-element sum is the k-ascending fmaf
+// chain of oracle_gemm_f32 -- also across split-K slabs only up to the order of the final slab sum.
+constexpr int BM = 128, BK = 16, PAD = 4;
 
+template <int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
     const float *__restrict__ bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-    int64_t ldc, int transA, int transB, int accumulate, int act) {
-  __shared__ float As[BK][BM + 1];
-  __shared__ float Bs[BK][BN + 1];
+    int64_t ldc, int transA, int transB, int accumulate, int act, int64_t k_per_split,
+    float *__restrict__ slabs) {
+  constexpr int WM = BN == 128 ? 2 : 1;   // 32-row accumulator blocks per wave
+  constexpr int WN = 2;                   // 32-col accumulator blocks per wave
+  __shared__ float As[2][BK][BM + PAD];
+  __shared__ float Bs[2][BK][BN + PAD];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
+  const int wrow = BN == 128 ? (wave >> 1) * 64 : wave * 32;
+  const int wcol = BN == 128 ? (wave & 1) * 64 : 0;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int64_t n0 = (int64_t)blockIdx.y * BN;
+  const int64_t kb = (int64_t)blockIdx.z * k_per_split;
+  const int64_t ke = min(K, kb + k_per_split);
 
-  f32x16 acc0, acc1;
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    acc0[i] = 0.f;
-    acc1[i] = 0.f;
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // which float4 of the tile this thread fetches; the vector runs along the memory-contiguous dimension
+  const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  constexpr int A_V = BM * BK / 4 / 256;  // float4 per thread per A tile (2)
+  constexpr int B_V = BN * BK / 4 / 256;  // (2 for BN=128, 1 for BN=64)
+  float4 ra[A_V], rb[B_V];
+
+  auto fetch_a = [&](int64_t k0) {
+#pragma unroll
+    for (int p = 0; p < A_V; ++p) {
+      const int v = t + p * 256;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!transA) {  // A[m][k]: vector along k
+        const int mm = v >> 2, k4 = (v & 3) * 4;
+        const int64_t gm = m0 + mm, gk = k0 + k4;
+        if (gm < M) {
+          const float *src = A + gm * lda + gk;
+          if (a_vec && gk + 3 < ke) x = *reinterpret_cast<const float4 *>(src);
+          else {
+            if (gk + 0 < ke) x.x = src[0];
+            if (gk + 1 < ke) x.y = src[1];
+            if (gk + 2 < ke) x.z = src[2];
+            if (gk + 3 < ke) x.w = src[3];
+          }
+        }
+      } else {        // A[k][m]: vector along m
+        const int kk = v / (BM / 4), m4 = (v % (BM / 4)) * 4;
+        const int64_t gk = k0 + kk, gm = m0 + m4;
+        if (gk < ke) {
+          const float *src = A + gk * lda + gm;
+          if (a_vec && gm + 3 < M) x = *reinterpret_cast<const float4 *>(src);
+          else {
+            if (gm + 0 < M) x.x = src[0];
+            if (gm + 1 < M) x.y = src[1];
+            if (gm + 2 < M) x.z = src[2];
+            if (gm + 3 < M) x.w = src[3];
+          }
+        }
+      }
+      ra[p] = x;
+    }
+  };
+  auto fetch_b = [&](int64_t k0) {
+#pragma unroll
+    for (int p = 0; p < B_V; ++p) {
+      const int v = t + p * 256;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (transB) {   // B stored [n][k]: vector along k
+        const int nn = v >> 2, k4 = (v & 3) * 4;
+        const int64_t gn = n0 + nn, gk = k0 + k4;
+        if (gn < N) {
+          const float *src = B + gn * ldb + gk;
+          if (b_vec && gk + 3 < ke) x = *reinterpret_cast<const float4 *>(src);
+          else {
+            if (gk + 0 < ke) x.x = src[0];
+            if (gk + 1 < ke) x.y = src[1];
+            if (gk + 2 < ke) x.z = src[2];
+            if (gk + 3 < ke) x.w = src[3];
+          }
+        }
+      } else {        // B stored [k][n]: vector along n
+        const int kk = v / (BN / 4), n4 = (v % (BN / 4)) * 4;
+        const int64_t gk = k0 + kk, gn = n0 + n4;
+        if (gk < ke) {
+          const float *src = B + gk * ldb + gn;
+          if (b_vec && gn + 3 < N) x = *reinterpret_cast<const float4 *>(src);
+          else {
+            if (gn + 0 < N) x.x = src[0];
+            if (gn + 1 < N) x.y = src[1];
+            if (gn + 2 < N) x.z = src[2];
+            if (gn + 3 < N) x.w = src[3];
+          }
+        }
+      }
+      rb[p] = x;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < A_V; ++p) {
+      const int v = t + p * 256;
+      if (!transA) {
+        const int mm = v >> 2, k4 = (v & 3) * 4;
+        As[buf][k4 + 0][mm] = ra[p].x;
+        As[buf][k4 + 1][mm] = ra[p].y;
+        As[buf][k4 + 2][mm] = ra[p].z;
+        As[buf][k4 + 3][mm] = ra[p].w;
+      } else {
+        const int kk = v / (BM / 4), m4 = (v % (BM / 4)) * 4;
+        *reinterpret_cast<float4 *>(&As[buf][kk][m4]) = ra[p];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < B_V; ++p) {
+      const int v = t + p * 256;
+      if (transB) {
+        const int nn = v >> 2, k4 = (v & 3) * 4;
+        Bs[buf][k4 + 0][nn] = rb[p].x;
+        Bs[buf][k4 + 1][nn] = rb[p].y;
+        Bs[buf][k4 + 2][nn] = rb[p].z;
+        Bs[buf][k4 + 3][nn] = rb[p].w;
+      } else {
+        const int kk = v / (BN / 4), n4 = (v % (BN / 4)) * 4;
+        *reinterpret_cast<float4 *>(&Bs[buf][kk][n4]) = rb[p];
+      }
+    }
+  };
+
+  int buf = 0;
+  if (kb < ke) {
+    fetch_a(kb);
+    fetch_b(kb);
+    stash(0);
   }
-
-  for (int64_t k0 = 0; k0 < K; k0 += BK) {
-    // stage A tile (BM x BK) -> As[k][m]; keep the stored-contiguous dimension on adjacent threads
-    if (!transA) {
-#pragma unroll
-      for (int p = 0; p < (BM * BK) / 256; ++p) {
-        const int kk = t & (BK - 1), mm = (t >> 4) + p * 16;
-        const int64_t gm = m0 + mm, gk = k0 + kk;
-        As[kk][mm] = (gm < M && gk < K) ? A[gm * lda + gk] : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < (BM * BK) / 256; ++p) {
-        const int mm = t & (BM - 1), kk = (t >> 7) + p * 2;
-        const int64_t gm = m0 + mm, gk = k0 + kk;
-        As[kk][mm] = (gm < M && gk < K) ? A[gk * lda + gm] : 0.f;
-      }
+  __syncthreads();
+  for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+    const bool more = k0 + BK < ke;
+    if (more) {
+      fetch_a(k0 + BK);
+      fetch_b(k0 + BK);
     }
-    // stage B tile (BK x BN) -> Bs[k][n]
-    if (!transB) {
-#pragma unroll
-      for (int p = 0; p < (BN * BK) / 256; ++p) {
-        const int nn = t & (BN - 1), kk = (t >> 6) + p * 4;
-        const int64_t gn = n0 + nn, gk = k0 + kk;
-        Bs[kk][nn] = (gn < N && gk < K) ? B[gk * ldb + gn] : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < (BN * BK) / 256; ++p) {
-        const int kk = t & (BK - 1), nn = (t >> 4) + p * 16;
-        const int64_t gn = n0 + nn, gk = k0 + kk;
-        Bs[kk][nn] = (gn < N && gk < K) ? B[gn * ldb + gk] : 0.f;
-      }
-    }
-    __syncthreads();
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      const float a = As[2 * s + h][wave * 32 + r];
-      const float b0 = Bs[2 * s + h][r];
-      const float b1 = Bs[2 * s + h][32 + r];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = As[buf][2 * s + h][wrow + 32 * i + r];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[buf][2 * s + h][wcol + 32 * j + r];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (more) stash(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
   }
 
   // epilogue: C/D layout col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float *out = slabs ? slabs + (size_t)blockIdx.z * (size_t)M * (size_t)N : C;
+  const int64_t ldo = slabs ? N : ldc;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int64_t gn = n0 + half * 32 + r;
-    if (gn >= N) continue;
-    const float bv = bias ? bias[gn] : 0.f;
+  for (int i = 0; i < WM; ++i) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      const int64_t gm = m0 + wave * 32 + row;
-      if (gm >= M) continue;
-      float v = half ? acc1[reg] : acc0[reg];
-      if (bias) v = v + bv;
-      if (accumulate) v = C[gm * ldc + gn] + v;
-      if (act == 1) v = v > 0.f ? v : v * 0.01f;
-      C[gm * ldc + gn] = v;
+    for (int j = 0; j < WN; ++j) {
+      const int64_t gn = n0 + wcol + 32 * j + r;
+      if (gn >= N) continue;
+      const float bv = (bias && !slabs) ? bias[gn] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int64_t gm = m0 + wrow + 32 * i + row;
+        if (gm >= M) continue;
+        float v = acc[i][j][reg];
+        if (!slabs) {
+          if (bias) v = v + bv;
+          if (accumulate) v = out[gm * ldo + gn] + v;
+          if (act == 1) v = v > 0.f ? v : v * 0.01f;
+        }
+        out[gm * ldo + gn] = v;
+      }
     }
   }
+}
+
+// split-K second pass: C = sum_z slab[z] (z ascending, fixed order) (+ bias) (+ C) (+ act)
+__global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits,
+                                                                float *__restrict__ C, const float *__restrict__ bias,
+                                                                int64_t M, int64_t N, int64_t ldc, int accumulate,
+                                                                int act) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int64_t m = i / N, n = i % N;
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v = v + slabs[(size_t)z * (size_t)M * (size_t)N + i];
+  if (bias) v = v + bias[n];
+  if (accumulate) v = C[m * ldc + n] + v;
+  if (act == 1) v = v > 0.f ? v : v * 0.01f;
+  C[m * ldc + n] = v;
+}
+
+struct GemmPlan {
+  int bn;
+  int splits;
+  int64_t k_per_split;
+};
+
+static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
+  GemmPlan p;
+  p.bn = N <= 64 ? 64 : 128;
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + p.bn - 1) / p.bn);
+  p.splits = 1;
+  // few output tiles and a long reduction (weight gradients: K = number of graph nodes): split K so that the
+  // chip is filled, partial sums go to slabs and are added in a fixed order
+  if (tiles < 128 && K >= 4096) {
+    int64_t s = (512 + tiles - 1) / tiles;
+    if (s > K / 1024) s = K / 1024;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    p.splits = (int)s;
+  }
+  int64_t per = (K + p.splits - 1) / p.splits;
+  per = (per + BK - 1) / BK * BK;
+  p.k_per_split = per < BK ? BK : per;
+  p.splits = (int)((K + p.k_per_split - 1) / p.k_per_split);
+  if (p.splits < 1) p.splits = 1;
+  return p;
 }
 
 __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p,
@@ -134,18 +291,39 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p,
 
 using namespace chaorec;
 
+extern "C" size_t chaorec_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const GemmPlan p = plan_gemm(M, N, K);
+  return p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
 extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const float *bias,
                                 int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                 int64_t ldc, int32_t transA, int32_t transB, int32_t accumulate,
-                                int32_t act, void *stream) {
+                                int32_t act, void *workspace, size_t workspace_bytes, void *stream) {
   if (!A || !B || !C) return fail(CHAOREC_E_INVALID, "gemm: NULL argument");
   if (M < 0 || N < 0 || K < 0) return fail(CHAOREC_E_INVALID, "gemm: negative size");
   if (act < 0 || act > 1) return fail(CHAOREC_E_INVALID, "gemm: act %d", act);
   if (M == 0 || N == 0) return CHAOREC_OK;
-  const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, bias, M, N, K,
-                     lda, ldb, ldc, transA, transB, accumulate, act);
-  return check_launch("gemm_f32_kernel");
+  GemmPlan p = plan_gemm(M, N, K > 0 ? K : 1);
+  if (K == 0) p.splits = 1;
+  const size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace))
+    return fail(CHAOREC_E_WORKSPACE, "gemm: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
+  const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + p.bn - 1) / p.bn), (unsigned)p.splits);
+  if (p.bn == 64)
+    hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
+                       transB, accumulate, act, p.k_per_split, slabs);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
+                       transB, accumulate, act, p.k_per_split, slabs);
+  int rc = check_launch("gemm_f32_kernel");
+  if (rc || p.splits == 1) return rc;
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, slabs,
+                     p.splits, C, bias, M, N, ldc, accumulate, act);
+  return check_launch("gemm_reduce_slabs_kernel");
 }
 
 extern "C" int chaorec_adam_step_f32(float *param, const float *grad, float *exp_avg,

@@ -246,8 +246,12 @@ def gemm_raw(A, B, transA=False, transB=False, bias=None, out=None, accumulate=F
         raise ValueError(f"gemm: inner dims {K} vs {Kb}")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    rc = _lib.load().chaorec_gemm_f32(_ptr(A), _ptr(B), _ptr(out), _ptr(bias), M, N, K, A.shape[1], B.shape[1],
-                                      out.shape[1], int(transA), int(transB), int(accumulate), act, _stream())
+    lib = _lib.load()
+    nbytes = lib.chaorec_gemm_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device) if nbytes else None
+    rc = lib.chaorec_gemm_f32(_ptr(A), _ptr(B), _ptr(out), _ptr(bias), M, N, K, A.shape[1], B.shape[1],
+                              out.shape[1], int(transA), int(transB), int(accumulate), act, _ptr(ws), nbytes,
+                              _stream())
     _lib.check(rc, "chaorec_gemm_f32")
     return out
 

@@ -188,11 +188,14 @@ int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
  *   grad x   = gy W             : transA=0, transB=0
  *   grad W   = gy^T x           : transA=1, transB=0
  * act: 0 none, 1 leaky_relu(0.01) applied to the result (F.leaky_relu default slope).
- * ------------------------------------------------------------------------------------- */
+ * Few output tiles with a long reduction (weight gradients: K = number of graph nodes) are split along K into
+ * slabs in `workspace` (size from chaorec_gemm_workspace_bytes) and summed in a fixed order by a second launch:
+ * deterministic, equal to the unsplit chain to rounding. */
+size_t chaorec_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int chaorec_gemm_f32(const float *A, const float *B, float *C, const float *bias,
                      int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                      int32_t transA, int32_t transB, int32_t accumulate, int32_t act,
-                     void *stream);
+                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused Adam step over one flat fp32 parameter (torch.optim.Adam defaults, main.py:397):

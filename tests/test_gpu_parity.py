@@ -366,7 +366,8 @@ def test_score_topk_errors(dev):
 
 
 # ------------------------------------------------------------------------------------------ GEMM / Adam
-@pytest.mark.parametrize("M,N,K", [(300, 64, 128), (1, 1, 1), (129, 65, 17), (515, 256, 320), (64, 64, 4096)])
+@pytest.mark.parametrize("M,N,K", [(300, 64, 128), (1, 1, 1), (129, 65, 17), (515, 256, 320), (64, 64, 4000),
+                                   (260, 130, 70)])
 @pytest.mark.parametrize("tA,tB", [(False, True), (False, False), (True, False)])
 def test_gemm_bit_exact(dev, oracle, M, N, K, tA, tB):
     from chaorec_amd import ops
@@ -378,6 +379,26 @@ def test_gemm_bit_exact(dev, oracle, M, N, K, tA, tB):
     got = ops.gemm_raw(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), transA=tA, transB=tB,
                        bias=torch.from_numpy(bias).to(dev), act=1)
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("tA,tB", [(False, True), (True, False)])
+def test_gemm_split_k_deterministic_and_close(dev, oracle, tA, tB):
+    """Long reductions with few output tiles (the weight-gradient shape) go through split-K slabs summed in
+    a fixed order: bit-identical run to run, equal to the oracle's single chain to fp32 rounding."""
+    from chaorec_amd import ops, _lib
+    M, N, K = 96, 200, 20000
+    assert _lib.load().chaorec_gemm_workspace_bytes(M, N, K) > 0
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    want = oracle.gemm(A, B, bias=bias, transA=tA, transB=tB, act=1)
+    a, b, bb = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(bias).to(dev)
+    got = ops.gemm_raw(a, b, transA=tA, transB=tB, bias=bb, act=1)
+    again = ops.gemm_raw(a, b, transA=tA, transB=tB, bias=bb, act=1)
+    assert torch.equal(got, again)
+    # fp32 tolerance: |sum| ~ sqrt(K) ~ 141, eps 6e-8 * sqrt(K) terms
+    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-3)
 
 
 def test_linear_autograd_vs_torch(dev):

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Step / epoch timing of the three models on dataset-shaped synthetic graphs (BASELINE configs 2-4 shapes)."""
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chaorec_amd import graph, dataload
+from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN
+from chaorec_amd.optim import FusedAdam
+from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+dev = torch.device("cuda:0")
+which = sys.argv[1:] or ["LightGCN:sports", "FREEDOM:clothing", "MMGCN:microlens"]
+for spec in which:
+    name, ds = spec.split(":")
+    U, I, E = DATASET_SHAPES[ds]
+    edges = synthetic_interactions(U, I, E, seed=42)
+    uid = graph.user_item_dict_from_edges(edges)
+    v_feat, t_feat = dataload.synthetic_features(I, ds)
+    torch.manual_seed(0)
+    t0 = time.time()
+    if name == "LightGCN":
+        m = LightGCN(U, I, edges, uid, 64, 1e-3, 3, "add", dev)
+    elif name == "FREEDOM":
+        m = FREEDOM(U, I, edges, uid, v_feat, t_feat, 64, 64, 1e-3, 0.1, 2, 1, 10, 0.8, dev)
+    else:
+        m = MMGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, "add", "False", True, dev)
+    m = m.to(dev)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    sampler = dataload.DeviceBatchSampler(U, I, uid, edges, 1024, dev, name)
+    if name == "FREEDOM":
+        m.pre_epoch_processing()
+    it = iter(sampler)
+    batches = [next(it) for _ in range(12)]
+    def step(b):
+        opt.zero_grad()
+        loss = m.loss(*b)
+        loss.backward()
+        opt.step()
+    for b in batches[:2]:
+        step(b)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for b in batches[2:]:
+        step(b)
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) / 10 * 1e3
+    t0 = time.time(); m.gene_ranklist(); torch.cuda.synchronize(); t_rank = time.time() - t0
+    print(f"{name:9s} {ds:10s} feat=({v_feat.shape[1]},{t_feat.shape[1]}) build {t_build:6.2f} s  step {ms:8.2f} ms  "
+          f"epoch({len(sampler)} batches) {ms * len(sampler) / 1e3:6.2f} s  gene_ranklist {t_rank * 1e3:7.2f} ms")
