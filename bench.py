@@ -116,9 +116,15 @@ def main():
     local_rank %= torch.cuda.device_count()     # (lets a 1-GPU box exercise the N>1 code path with gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CHAOREC_FORCE_SHARDED=1: run the N>1 code path (sharded model, RCCL calls, graph capture of them) on one rank
+    force_sharded = world == 1 and os.environ.get("CHAOREC_FORCE_SHARDED", "0") == "1"
+    backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    if world > 1 or force_sharded:
         import torch.distributed as dist
-        backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -132,7 +138,7 @@ def main():
     U1, I, E1 = DATASET_SHAPES[args.dataset]
     D, L, B, reg = args.dim, args.n_layers, args.batch, 1e-3
 
-    if world == 1:
+    if world == 1 and not force_sharded:
         U = U1
         edges = synthetic_interactions(U1, I, E1, seed=42)
         torch.manual_seed(42)
@@ -163,10 +169,28 @@ def main():
             return ops.draw_batch(edges_dev, model.hist, B, model.num_user, I, 42 + rank, 0, step_dev=batch_counter)
         return ops.draw_batch(edges_dev, model.hist, B, model.num_user, I, 42 + rank, 1_000_000 + i)
 
-    # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph (the sharded path
-    # holds RCCL calls and stays eager)
-    use_graph = not args.no_graph and not args.torch_adam and sharded is None
-    graphed = GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local) if use_graph else None
+    # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph.  The sharded step holds
+    # RCCL all-reduces; they are captured with it when the backend is RCCL (CHAOREC_DIST_GRAPH=0 keeps it eager).
+    # Every rank must run the same launch mode: if the capture fails anywhere, all ranks fall back to eager.
+    use_graph = not args.no_graph and not args.torch_adam
+    if sharded is not None:
+        use_graph = use_graph and backend == "nccl" and os.environ.get("CHAOREC_DIST_GRAPH", "1") == "1"
+    graphed = None
+    if use_graph:
+        try:
+            graphed = GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local)
+        except Exception as exc:      # noqa: BLE001 -- any capture failure means "launch eagerly", never a wrong result
+            if sharded is None:
+                raise
+            print(f"[bench rank {rank}] hipGraph capture of the sharded step failed ({exc!r}); eager launches",
+                  file=sys.stderr)
+            graphed = None
+        if sharded is not None:
+            torch.cuda.synchronize()
+            ok = torch.tensor([1.0 if graphed is not None else 0.0], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                graphed = None
 
     def step(i, force_eager=False):
         if graphed is not None and not force_eager:
@@ -246,7 +270,7 @@ def main():
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "spmm_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and sharded is None:     # measured on the N=1 kernel (full graph); not the shard blocks
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
@@ -304,13 +328,13 @@ def main():
                    "optimizer": "torch.optim.Adam" if args.torch_adam else "FusedAdam (chaorec_adam_step_f32)",
                    "parallelism": "single GPU" if world == 1 else f"user-row shards x{world}, item all-reduce per layer"},
         "roofline": roofline, "roofline_scoring": roofline_scoring,
-        "loss_mean": float(loss_sum.item()) / (args.steps + args.warmup + min(args.steps, 50)),
+        "loss_mean": float(loss_sum.item()) / (args.steps + args.warmup + 1),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(edges, U, I, D, L, B, reg, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_sharded:
         torch.distributed.destroy_process_group()
 
 

@@ -62,25 +62,53 @@ class UserShard:
 
 
 def _all_reduce(t, group):
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
+class _Pending:
+    """Handle of an all-reduce issued with async_op=True (RCCL runs it on its own stream, so the SpMM launched
+    next on the compute stream overlaps it; wait() makes the compute stream depend on the result)."""
+
+    def __init__(self, work):
+        self.work = work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+
+
+def _all_reduce_async(t, group):
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES):
+        return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return _Pending(None)
+
+
+# CHAOREC_FORCE_COLLECTIVES=1: issue the all-reduces on a 1-rank group too, so that a 1-GPU box exercises the
+# RCCL launch (and hipGraph capture of it) that the N>1 job uses
+import os as _os
+_FORCE_COLLECTIVES = _os.environ.get("CHAOREC_FORCE_COLLECTIVES", "0") == "1"
+
+
 class _ShardedLayerMean(torch.autograd.Function):
-    """LightGCN.forward (Model/LightGCN.py:76-95) on a user shard: L x (2 local SpMM + 1 all-reduce)."""
+    """LightGCN.forward (Model/LightGCN.py:76-95) on a user shard: L x (2 local SpMM + 1 all-reduce).
+    `spmm_fn(csr, x, **epilogue)` has ops.spmm_raw's keyword contract (alpha / z,beta / acc,acc_init,acc_w): the
+    layer mean of the user rows and the `+ w G` terms of the backward ride in the SpMM epilogues."""
 
     @staticmethod
     def forward(ctx, xu, xi, shard, n_layers, spmm_fn, group):
         w = 1.0 / (n_layers + 1)
-        fu, fi = xu * w, xi * w
+        xu, xi = xu.contiguous(), xi.contiguous()
+        fu = torch.empty_like(xu) if n_layers else xu * w
+        fi = xi * w
         cu, ci = xu, xi
-        for _ in range(n_layers):
-            yu = spmm_fn(shard.ui, ci)
+        for l in range(n_layers):
             pi = spmm_fn(shard.iu, cu)
-            _all_reduce(pi, group)
-            fu = fu.add_(yu, alpha=w)
-            fi = fi.add_(pi, alpha=w)
+            pending = _all_reduce_async(pi, group)       # item partials travel while the user rows are computed
+            yu = spmm_fn(shard.ui, ci, acc=fu, acc_init=xu if l == 0 else None, acc_w=w)
+            pending.wait()
+            fi.add_(pi, alpha=w)
             cu, ci = yu, pi
         ctx.shard, ctx.n_layers, ctx.w, ctx.spmm_fn, ctx.group = shard, n_layers, w, spmm_fn, group
         return fu, fi
@@ -92,11 +120,12 @@ class _ShardedLayerMean(torch.autograd.Function):
         shard, L, w, spmm_fn, group = ctx.shard, ctx.n_layers, ctx.w, ctx.spmm_fn, ctx.group
         Gu, Gi = Gu.contiguous(), Gi.contiguous()
         Gi_full = _all_reduce(Gi.clone(), group)       # layer-L seed needs the full item gradient
-        gu, gi = Gu * w, Gi_full * w
+        gu, gi = Gu * w, Gi_full.mul_(w)
         for _ in range(L):
-            nu = spmm_fn(shard.ui, gi).add_(Gu, alpha=w)
-            pi = spmm_fn(shard.iu, gu).add_(Gi, alpha=w)
-            _all_reduce(pi, group)
+            pi = spmm_fn(shard.iu, gu, z=Gi, beta=w)
+            pending = _all_reduce_async(pi, group)
+            nu = spmm_fn(shard.ui, gi, z=Gu, beta=w)
+            pending.wait()
             gu, gi = nu, pi
         return gu, gi, None, None, None, None
 
@@ -129,14 +158,18 @@ class ShardedLightGCN(nn.Module):
         rowptr, col = graph.user_hist_csr(user_item_dict_local, self.num_user)
         self.hist = (rowptr.to(device), col.to(device))
         self.graph = shard.ui
-        self.result_u = self.result_i = self.result = None
+        self.result_u = self.result_i = None
 
     def forward(self):
         fu, fi = sharded_layer_mean_propagate(self.user_embedding.weight, self.item_embedding.weight, self.shard,
                                               self.n_layers, self.spmm_fn, self.group)
         self.result_u, self.result_i = fu, fi
-        self.result = torch.cat((fu, fi), 0)
         return fu, fi
+
+    @property
+    def result(self):
+        """[U_g + I, D] in the reference's row convention (users then items), built on demand."""
+        return None if self.result_u is None else torch.cat((self.result_u, self.result_i), 0)
 
     def loss(self, users, pos_items, neg_items):
         pos_items = pos_items - self.num_user

@@ -15,10 +15,17 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _oracle_spmm(csr, x):
+def _oracle_spmm(csr, x, alpha=1.0, z=None, beta=0.0, acc=None, acc_init=None, acc_w=0.0):
+    """ops.spmm_raw's keyword contract (include/chaorec_hip.h, chaorec_spmm_csr_f32) on the CPU oracle."""
     from oracle import oracle
-    y = oracle.spmm((csr.rowptr.numpy(), csr.col.numpy(), csr.val.numpy()), x.detach().numpy())
-    return torch.from_numpy(y)
+    s = torch.from_numpy(oracle.spmm((csr.rowptr.numpy(), csr.col.numpy(), csr.val.numpy()), x.detach().numpy()))
+    if acc is not None:
+        a0 = acc_w * acc_init if acc_init is not None else acc
+        acc.copy_(a0 + acc_w * s)
+    y = alpha * s
+    if z is not None:
+        y = y + beta * z
+    return y
 
 
 class _OracleBPR(torch.autograd.Function):
