@@ -44,6 +44,8 @@ SIGNATURES = {
     "chaorec_score_topk_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                               c_ptr, c_ptr, ctypes.c_float, ctypes.c_int32, ctypes.c_int64,
                                               c_ptr, c_ptr, c_ptr, ctypes.c_size_t, ctypes.c_int32, c_ptr]),
+    "chaorec_score_topk_stats": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                c_ptr, c_ptr]),
     "chaorec_gemm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "chaorec_gemm_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -58,13 +60,13 @@ SIGNATURES = {
 def build(force=False, verbose=False):
     """Cross-compile the HIP kernels for gfx950 into csrc/libchaorec_hip.so (no GPU needed)."""
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(_CSRC, "common.h"),
-                   os.path.join(os.path.dirname(_CSRC), "..", "include", "chaorec_hip.h")]
+    deps = srcs + [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".h", ".hpp"))]
+    deps += [os.path.join(os.path.dirname(_CSRC), "..", "include", "chaorec_hip.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+    cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("CHAOREC_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

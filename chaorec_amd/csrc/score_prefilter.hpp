@@ -1,0 +1,625 @@
+// bf16-MFMA prefilter for the all-items scoring (included by score_topk.hip, inside namespace chaorec).
+//
+// The exact fp32 sweep costs 32*D MFMA cycles per 32x32 tile (v_mfma_f32_32x32x2_f32); the bf16 pipe does the same
+// tile in 2*D cycles (v_mfma_f32_32x32x16_bf16).  So the [U, I] sweep runs in bf16 and only decides WHICH items can
+// be in a user's top-K; the handful that can are re-scored in exact fp32 (the same k-ascending fmaf chain as the
+// f32 MFMA kernel / oracle_score_dot) and ranked on those values.  The result is bit-identical to the fp32 path:
+//
+//   |s~(u,j) - s(u,j)| <= m_u := c * ||u||_2 * max_j ||i_j||_2,   c = 1.02 * 2^-8
+//     (two RNE bf16 roundings, 2^-9 relative each, + fp32 accumulation; Cauchy-Schwarz on sum_d |u_d||i_d|).
+//   Let a_K = K-th largest approximate score of the user.  An item with s~ < a_K - 2 m_u has true score
+//   < a_K - m_u <= the true score of each of the K items whose approximate score is >= a_K: K items beat it
+//   strictly, it is not in the top-K whatever the tie order.  So R = { j : s~_j >= a_K - 2 m_u } holds the whole
+//   exact top-K; R is K plus the few items inside the 2 m_u band.
+//   Masked (history) items carry mask_value exactly in both domains (error 0).
+//
+// Pipeline (all on one stream, no host round trip):
+//   pack      items -> bf16 MFMA A-fragments (one coalesced 1 KiB wave load per k-step), max item norm
+//   sample    per user a threshold tau0 from every 4th tile: list-free lane-local group maxima give a loose tau1,
+//             scores above tau1 go to a per-lane LDS list, a lane-local bisection finds a value with >= r_l
+//             sample scores above it; min over the user's two lanes and the sample splits (atomicMin)
+//   sweep     one wave = UB x 32 users (UB fragments in registers, each item fragment feeds UB MFMA groups),
+//             tiles interleaved over the splits; approximate scores above theta_u = tau0 - 2 m_u are appended
+//             to the lane's own global list as (ord(score) << 32 | ~item) keys
+//   select    one wave per user: a_K by ballot/popcount radix select over the ~200 keys, certification
+//             (>= K keys, a_K - 2 m_u > theta_u, no list overflow, |R| <= 128), exact fp32 re-score of R, one
+//             register bitonic sort, top-K out.  Uncertified users are flagged and re-run by the exact fp32
+//             fallback sweep (score_topk_f32_kernel, kModeFallback).
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+union Frag16 {
+  uint4 u;
+  bf16x8 v;
+};
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t bf16_pack2(float lo, float hi) {
+  return bf16_rne_bits(lo) | (bf16_rne_bits(hi) << 16);
+}
+__device__ __forceinline__ uint4 bf16_pack8(const float4 a, const float4 b) {
+  return make_uint4(bf16_pack2(a.x, a.y), bf16_pack2(a.z, a.w), bf16_pack2(b.x, b.y), bf16_pack2(b.z, b.w));
+}
+
+constexpr float kBf16ErrCoef = 1.02f / 256.0f;
+constexpr int kPfCap = 64;        // keys per (split, user, half) list of the sweep
+constexpr int kPfSampleCap = 64;  // scores per lane in the sampler's LDS list
+constexpr int kPfMaxRescore = 128;
+
+struct PrefArgs {
+  const float *user_emb;
+  const float *item_emb;
+  const uint4 *packed;          // [n_tiles][D/16][64] bf16x8 fragments
+  int64_t n_users, n_items;
+  const int64_t *hist_rowptr;
+  const int32_t *hist_col;
+  float mask_value;
+  int K;
+  int64_t id_offset;
+  uint32_t *imax2_bits;         // max_j ||i_j||^2 as float bits
+  float *tau_sum;               // [U] sampled threshold: mean over the sample splits (atomicAdd of est / splits)
+  float *theta;                 // [U] sweep threshold (written by sweep split 0)
+  float *margin;                // [U] m_u
+  uint64_t *cand;               // [splits][U][2][kPfCap] raw entries: low word item, high word score bits
+  int *cand_cnt;                // [splits][U][2]
+  int splits;                   // sweep splits (tiles interleaved)
+  int sample_stride;            // every sample_stride-th tile is sampled ...
+  int sample_splits;            // ... dealt round-robin to this many sampler waves per user block
+  int sample_rank;              // r_l: per-lane rank
+  int64_t *out_idx;
+  float *out_val;
+  int *fail;
+};
+
+// ---- pack ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_items_bf16_kernel(const float *__restrict__ item_emb,
+                                                              uint4 *__restrict__ packed, int64_t n_items, int D,
+                                                              int64_t n_tiles, uint32_t *__restrict__ imax2_bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-element fragment
+  const int Q = D / 16;
+  const bool in = i < n_tiles * Q * 64;
+  const int lane = (int)(i & 63);
+  const int64_t tq = i >> 6;
+  const int q = (int)(tq % Q);
+  const int64_t t = tq / Q;
+  const int64_t j = t * 32 + (lane & 31);
+  const int h = lane >> 5;
+  float n2 = 0.f;
+  if (in) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (j < n_items) {
+      const float4 *src = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D + 16 * q + 8 * h);
+      v = bf16_pack8(src[0], src[1]);
+      if (q == 0 && h == 0) {
+        const float4 *row = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D);
+        for (int d = 0; d < D / 4; ++d) {
+          const float4 x = row[d];
+          n2 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        }
+      }
+    }
+    packed[i] = v;
+  }
+  // one atomic per wave (norms are >= 0: float order == uint order)
+  for (int o = 32; o > 0; o >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, o, 64));
+  if ((threadIdx.x & 63) == 0 && n2 > 0.f) atomicMax(imax2_bits, __float_as_uint(n2));
+}
+
+template <int D>
+__device__ __forceinline__ void load_user_frags(bf16x8 (&bu)[D / 16], float &norm2_half, const float *__restrict__ user_emb,
+                                                int64_t u, bool ok, int h) {
+  norm2_half = 0.f;
+#pragma unroll
+  for (int q = 0; q < D / 16; ++q) {
+    Frag16 f;
+    f.u = make_uint4(0u, 0u, 0u, 0u);
+    if (ok) {
+      const float4 *src = reinterpret_cast<const float4 *>(user_emb + (size_t)u * D + 16 * q + 8 * h);
+      const float4 a = src[0], b = src[1];
+      f.u = bf16_pack8(a, b);
+      norm2_half += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    }
+    bu[q] = f.v;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void load_item_frags_bf16(uint4 (&a)[D / 16], const uint4 *__restrict__ packed, int64_t t,
+                                                     int lane) {
+  const uint4 *src = packed + (size_t)t * (D / 16) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < D / 16; ++q) a[q] = src[q * 64];
+}
+
+template <int D>
+__device__ __forceinline__ f32x16 tile_scores_bf16(const uint4 (&a)[D / 16], const bf16x8 (&bu)[D / 16]) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int q = 0; q < D / 16; ++q) {
+    Frag16 f;
+    f.u = a[q];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v, bu[q], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// history cursor of one user over an ascending tile walk.  Two entries are kept in registers ahead of the walk,
+// so stepping over an entry never waits on the load it issues (a vmcnt wait here also drains the item-fragment
+// prefetch and every pending list store: it was half of the sweep's wall time).
+struct HistCursor {
+  int64_t hp, hend;       // hp: index of the entry after h1
+  uint32_t h0, h1;        // next two entries, 0xFFFFFFFF = none
+  __device__ __forceinline__ void init(const int64_t *rowptr, const int32_t *col, int64_t u, bool ok) {
+    hp = hend = 0;
+    h0 = h1 = 0xFFFFFFFFu;
+    if (rowptr && ok) {
+      hp = rowptr[u];
+      hend = rowptr[u + 1];
+      if (hp < hend) h0 = (uint32_t)col[hp];
+      if (hp + 1 < hend) h1 = (uint32_t)col[hp + 1];
+      hp += 2;
+    }
+  }
+  // bit `off` set <=> item j0 + off is in the history; entries of skipped tiles are stepped over
+  __device__ __forceinline__ uint32_t tile_bits(const int32_t *col, uint32_t j0) {
+    uint32_t mbits = 0;
+    while (h0 < j0 + 32u) {
+      if (h0 >= j0) mbits |= 1u << (h0 - j0);
+      h0 = h1;
+      h1 = hp < hend ? (uint32_t)col[hp] : 0xFFFFFFFFu;
+      ++hp;
+    }
+    return mbits;
+  }
+};
+
+__device__ __forceinline__ void apply_mask_and_range(f32x16 &acc, uint32_t mbits, uint32_t j0, uint32_t n_items, int h,
+                                                     float mask_value) {
+  if (__any(mbits != 0)) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if ((mbits >> off) & 1u) acc[reg] = mask_value;
+    }
+  }
+  if (j0 + 32u > n_items) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (j0 + off >= n_items) acc[reg] = -INFINITY;
+    }
+  }
+}
+
+// ---- sample --------------------------------------------------------------------------------------------------
+// grid (user blocks of 32, sample_splits).  Sample tile i of this wave is tile (i * sample_splits + split) * stride.
+// Each wave estimates, per user, a score with about r sampled scores at or above it (r = sample_rank, pooled
+// over the user's two lanes); the user's threshold is the mean of the sample splits' estimates.
+template <int D>
+__global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P) {
+  __shared__ float lst[kPfSampleCap * 64];  // [slot][lane]: conflict-free for lane-local walks
+  __shared__ float park[16 * 64];
+  const int lane = threadIdx.x;
+  const int ur = lane & 31, h = lane >> 5;
+  const int64_t u = (int64_t)blockIdx.x * 32 + ur;
+  const bool u_ok = u < P.n_users;
+  const uint32_t n_items = (uint32_t)P.n_items;
+  const int n_tiles = (int)((P.n_items + 31) / 32);
+  const int split = blockIdx.y;
+  const int step = P.sample_stride * P.sample_splits;
+  const int t_first = split * P.sample_stride;
+
+  bf16x8 bu[D / 16];
+  float n2;
+  load_user_frags<D>(bu, n2, P.user_emb, u, u_ok, h);
+
+  // The sample is taken on RAW scores (no history mask: a cursor over the history costs a dependent load in the
+  // tile loop).  Interacted items usually score high, so the rank is shifted by h_s = the number of the user's
+  // history items inside this wave's sampled tiles: the (r + h_s)-th best raw score is at most the r-th best
+  // masked one whenever mask_value does not matter, and any value is a valid threshold anyway (certification).
+  int h_s = 0;
+  if (P.hist_rowptr && u_ok) {
+    const int64_t hb = P.hist_rowptr[u], he = P.hist_rowptr[u + 1];
+    for (int64_t i = hb + h; i < he; i += 2) {   // the user's two lanes take alternate entries
+      const int tt = (int)((uint32_t)P.hist_col[i] >> 5);
+      h_s += (tt >= t_first && (tt - t_first) % step == 0) ? 1 : 0;
+    }
+  }
+  h_s += __shfl_xor(h_s, 32, 64);
+
+  // phase 1: the first 8 sampled tiles (128 scores per lane), lane-local top-4 by median-of-3 insertion; tau1 = the
+  // smaller of the two lanes' 4th best: at least 8 of the user's 256 scores reach it (expected: the top ~4 %)
+  float tau1;
+  {
+    float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY, b3 = -INFINITY;
+    int t = t_first;
+    uint4 a[D / 16], an[D / 16];
+    if (t < n_tiles) load_item_frags_bf16<D>(a, P.packed, t, lane);
+    for (int g = 0; g < 8 && t < n_tiles; ++g, t += step) {
+      load_item_frags_bf16<D>(an, P.packed, t + step < n_tiles ? t + step : t, lane);
+      f32x16 acc = tile_scores_bf16<D>(a, bu);
+      const uint32_t j0 = (uint32_t)t * 32u;
+      apply_mask_and_range(acc, 0u, j0, n_items, h, P.mask_value);
+#pragma unroll
+      for (int q = 0; q < D / 16; ++q) a[q] = an[q];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float x = acc[reg];
+        b3 = __builtin_amdgcn_fmed3f(b2, b3, x);
+        b2 = __builtin_amdgcn_fmed3f(b1, b2, x);
+        b1 = __builtin_amdgcn_fmed3f(b0, b1, x);
+        b0 = fmaxf(b0, x);
+      }
+    }
+    tau1 = fminf(b3, __shfl_xor(b3, 32, 64));
+  }
+
+  // phase 2: every sampled tile; scores above tau1 go to the lane's LDS list (a full list drops the rest: the
+  // value found below is then a lower bound of the intended one -- still a valid, merely looser, threshold).
+  // Same compact hit handling as the sweep: bit mask per lane, scores parked in LDS, one drain loop.
+  int cnt = 0;
+  {
+    const float tl = nextafterf(tau1, -INFINITY);   // strict compare below keeps scores == tau1
+    uint4 a[D / 16], an[D / 16];
+    int t = t_first;
+    if (t < n_tiles) load_item_frags_bf16<D>(a, P.packed, t, lane);
+    for (; t < n_tiles; t += step) {
+      load_item_frags_bf16<D>(an, P.packed, t + step < n_tiles ? t + step : t, lane);
+      f32x16 acc = tile_scores_bf16<D>(a, bu);
+      const uint32_t j0 = (uint32_t)t * 32u;
+      apply_mask_and_range(acc, 0u, j0, n_items, h, P.mask_value);
+      uint32_t qbits = 0;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(tl - acc[reg]), 31);
+      if (__any(qbits != 0)) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) park[reg * 64 + lane] = acc[reg];
+        __builtin_amdgcn_wave_barrier();
+        while (__any(qbits != 0)) {
+          if (qbits) {
+            const int bit = 31 - __clz(qbits);
+            qbits &= ~(1u << bit);
+            const float sc = park[(15 - bit) * 64 + lane];
+            if (cnt < kPfSampleCap) lst[(cnt++) * 64 + lane] = sc;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int q = 0; q < D / 16; ++q) a[q] = an[q];
+    }
+  }
+
+  // phase 3: bisection on the value, counts pooled over the user's two lanes: the largest of 2^8 grid values in
+  // [tau1, max] with at least r list entries at or above it (any such value is a valid lower bound of the r-th best)
+  float lo = tau1;  // invariant: pooled count(>= lo) >= r, or the lists are shorter than r
+  const int r = P.sample_rank + h_s;
+  const int pooled = cnt + __shfl_xor(cnt, 32, 64);
+  if (pooled >= r && lo > -INFINITY) {
+    float hi = -INFINITY;
+    for (int i = 0; i < cnt; ++i) hi = fmaxf(hi, lst[i * 64 + lane]);
+    hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+    const int nmax = max(cnt, __shfl_xor(cnt, 32, 64));
+    for (int it = 0; it < 8; ++it) {
+      const float mid = lo + (hi - lo) * 0.5f;
+      int c = 0;
+      for (int i = 0; i < nmax; ++i) c += (i < cnt && lst[i * 64 + lane] >= mid) ? 1 : 0;
+      c += __shfl_xor(c, 32, 64);
+      if (c >= r) lo = mid; else hi = mid;
+    }
+  }
+  // one float below, so that the sweep's strict compare keeps equal scores; the user's threshold is the mean of
+  // the splits' estimates (two commutative float adds: deterministic)
+  if (u_ok && h == 0) atomicAdd(P.tau_sum + u, nextafterf(lo, -INFINITY) * (1.0f / (float)P.sample_splits));
+}
+
+// ---- sweep ---------------------------------------------------------------------------------------------------
+// No history handling here: an interacted item is swept like any other (its raw score may or may not pass the
+// threshold); the selection drops every history member from the candidates and adds the user's whole history
+// back with mask_value, which is exactly the masked score row restricted to what can matter.
+//
+// The loop body has to stay small: with the hit handling unrolled per accumulator register (16 x UB x 2 copies of
+// compare / branch / key / store) the loop was ~45 KB of ISA and the waves starved on instruction fetch.  Here a
+// tile's 16 compares become one bit mask per lane (v_sub + v_alignbit each), the scores are parked in a 4 KiB LDS
+// scratch ([reg][lane]) and ONE drain loop per user block stores the hits: every iteration is one store
+// instruction for all lanes that still hold a hit.
+template <int D, int UB>
+__global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) {
+  __shared__ float park[16 * 64];
+  const int lane = threadIdx.x;
+  const int ur = lane & 31, h = lane >> 5;
+  const uint32_t n_items = (uint32_t)P.n_items;
+  const int n_tiles = (int)((P.n_items + 31) / 32);
+  const int split = blockIdx.y;
+  const int splits = P.splits;
+
+  bf16x8 bu[UB][D / 16];
+  float theta[UB];
+  int cnt[UB];
+  uint2 *mine[UB];
+  const float imax = sqrtf(__uint_as_float(*P.imax2_bits));
+#pragma unroll
+  for (int b = 0; b < UB; ++b) {
+    const int64_t u = ((int64_t)blockIdx.x * UB + b) * 32 + ur;
+    const bool ok = u < P.n_users;
+    float n2;
+    load_user_frags<D>(bu[b], n2, P.user_emb, u, ok, h);
+    n2 += __shfl_xor(n2, 32, 64);
+    const float m = kBf16ErrCoef * sqrtf(n2) * imax + 1e-30f;
+    float th = INFINITY;  // padding users never qualify
+    if (ok) {
+      th = P.tau_sum[u] - 2.0f * m;
+      if (split == 0 && h == 0) {
+        P.theta[u] = th;
+        P.margin[u] = m;
+      }
+    }
+    theta[b] = th;
+    cnt[b] = 0;
+    mine[b] = reinterpret_cast<uint2 *>(P.cand) + (((size_t)split * P.n_users + (ok ? u : 0)) * 2 + h) * kPfCap;
+  }
+
+  uint4 a[D / 16], an[D / 16];
+  int t = split;
+  if (t < n_tiles) load_item_frags_bf16<D>(a, P.packed, t, lane);
+  for (; t < n_tiles; t += splits) {
+    load_item_frags_bf16<D>(an, P.packed, t + splits < n_tiles ? t + splits : t, lane);
+    const uint32_t j0 = (uint32_t)t * 32u;
+#pragma unroll
+    for (int b = 0; b < UB; ++b) {
+      f32x16 acc = tile_scores_bf16<D>(a, bu[b]);
+      if (j0 + 32u > n_items) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          if (j0 + off >= n_items) acc[reg] = -INFINITY;
+        }
+      }
+      // bit (15 - reg) <=> acc[reg] > theta: the sign of theta - acc shifted in (== gives +0, -inf gives +inf)
+      uint32_t qbits = 0;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(theta[b] - acc[reg]), 31);
+      if (__any(qbits != 0)) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) park[reg * 64 + lane] = acc[reg];
+        __builtin_amdgcn_wave_barrier();
+        while (__any(qbits != 0)) {
+          if (qbits) {
+            const int bit = 31 - __clz(qbits);
+            qbits &= ~(1u << bit);
+            const int reg = 15 - bit;
+            const float sc = park[reg * 64 + lane];
+            const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            // raw (item, score bits): the order-preserving key is built by the selection, 64 keys per instruction;
+            // past kPfCap entries are counted, not stored: the selection sees the overflow and flags the user
+            if (cnt[b] < kPfCap) mine[b][cnt[b]] = make_uint2(j0 + off, __float_as_uint(sc));
+            ++cnt[b];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) a[q] = an[q];
+  }
+#pragma unroll
+  for (int b = 0; b < UB; ++b) {
+    const int64_t u = ((int64_t)blockIdx.x * UB + b) * 32 + ur;
+    if (u < P.n_users) P.cand_cnt[((size_t)split * P.n_users + u) * 2 + h] = cnt[b];
+  }
+}
+
+// ---- select + exact re-score -----------------------------------------------------------------------------------
+// exact fp32 score of (u, item): the chain of the f32 MFMA kernel for D <= 128 (k = s and D/2 + s alternate)
+template <int D>
+__device__ __forceinline__ float exact_score(const float *__restrict__ urow, const float *__restrict__ irow) {
+  float acc = 0.f;
+  const float4 *i0 = reinterpret_cast<const float4 *>(irow), *i1 = reinterpret_cast<const float4 *>(irow + D / 2);
+  const float4 *u0 = reinterpret_cast<const float4 *>(urow), *u1 = reinterpret_cast<const float4 *>(urow + D / 2);
+#pragma unroll
+  for (int q = 0; q < D / 8; ++q) {
+    const float4 a = i0[q], b = i1[q], x = u0[q], y = u1[q];
+    acc = __fmaf_rn(x.x, a.x, acc);
+    acc = __fmaf_rn(y.x, b.x, acc);
+    acc = __fmaf_rn(x.y, a.y, acc);
+    acc = __fmaf_rn(y.y, b.y, acc);
+    acc = __fmaf_rn(x.z, a.z, acc);
+    acc = __fmaf_rn(y.z, b.z, acc);
+    acc = __fmaf_rn(x.w, a.w, acc);
+    acc = __fmaf_rn(y.w, b.w, acc);
+  }
+  return acc;
+}
+
+// A value with at least K keys at or above it: the K-th largest score key truncated to its top BITS bits (a coarser
+// grid only widens the re-score band by 2^-(BITS-9) relative; the count condition is what the proof needs).
+template <int NR, int NRmax, int BITS>
+__device__ __forceinline__ uint32_t kth_largest_ord(const uint64_t (&k)[NRmax], int K) {
+  uint32_t prefix = 0;
+  for (int bit = 31; bit >= 32 - BITS; --bit) {
+    const uint32_t candv = prefix | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) c += __popcll(__ballot((uint32_t)(k[r] >> 32) >= candv && k[r] != 0ull));
+    if (c >= K) prefix = candv;
+  }
+  return prefix;
+}
+
+// Wave-wide descending bitonic sort of 64 keys, one per lane.
+__device__ __forceinline__ void sort64_desc(uint64_t &e, int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t p = shfl_xor_u64(e, j);
+      const bool lower = (lane & j) == 0;
+      const bool desc = (k == 64) ? true : ((lane & k) == 0);
+      const uint64_t mx = e > p ? e : p, mn = e > p ? p : e;
+      e = (lower == desc) ? mx : mn;
+    }
+  }
+}
+
+constexpr int kPfHistLds = 1024;
+
+template <int D>
+__global__ __launch_bounds__(64) void score_select_rescore_kernel(const PrefArgs P) {
+  constexpr int NRmax = 16;
+  __shared__ int incl_s[64];
+  __shared__ uint32_t keep_item[kPfMaxRescore];
+  __shared__ uint32_t hist_s[kPfHistLds];
+  const int lane = threadIdx.x;
+  const int64_t u = blockIdx.x;
+  const int K = P.K;
+  const int n_lists = 2 * P.splits;  // <= 64
+
+  // list lengths: lane l owns list l = (split, half)
+  int c = 0;
+  if (lane < n_lists) c = P.cand_cnt[((size_t)(lane >> 1) * P.n_users + u) * 2 + (lane & 1)];
+  int64_t hb = 0, he = 0;
+  if (P.hist_rowptr) {
+    hb = P.hist_rowptr[u];
+    he = P.hist_rowptr[u + 1];
+  }
+  const int deg = (int)(he - hb);
+  const float m = P.margin[u], theta = P.theta[u];
+  const bool overflow = __any(c > kPfCap);
+  int incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  // reason codes (nonzero = re-run on the fp32 route): 1 list overflow, 2 fewer than K candidates, 3 more than 1024,
+  // 4 band reaches below the sweep threshold, 5 more than 128 items inside the band
+  // (the user's history is appended to the candidates below: both must fit the 1024 key slots / the LDS copy)
+  int why = overflow ? 1 : (total + deg < K ? 2 : ((total + deg > 64 * NRmax || deg > kPfHistLds) ? 3 : 0));
+  uint64_t e0 = 0ull, e1 = 0ull;
+  if (why == 0) {
+    incl_s[lane] = incl;
+    for (int i = lane; i < deg; i += 64) hist_s[i] = (uint32_t)P.hist_col[hb + i];
+    __builtin_amdgcn_wave_barrier();
+    // every candidate key straight into registers: entry e of the user's concatenated lists sits in list
+    // l = first list with incl[l] > e (lane-local binary search in LDS), all loads in flight together
+    const uint2 *cand2 = reinterpret_cast<const uint2 *>(P.cand);
+    uint64_t k[NRmax];
+#pragma unroll
+    for (int r = 0; r < NRmax; ++r) {
+      k[r] = 0ull;
+      if (64 * r >= total + deg) continue;   // wave-uniform: cost follows the actual key count
+      const int e = lane + 64 * r;
+      if (e < total) {
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+          const int mid = (lo + hi) >> 1;
+          if (incl_s[mid] > e) hi = mid; else lo = mid + 1;
+        }
+        const int pos = e - (lo ? incl_s[lo - 1] : 0);
+        const uint2 raw = cand2[(((size_t)(lo >> 1) * P.n_users + u) * 2 + (lo & 1)) * kPfCap + pos];
+        const uint32_t ob = (raw.y & 0x80000000u) ? ~raw.y : (raw.y | 0x80000000u);
+        k[r] = ((uint64_t)ob << 32) | (uint64_t)(0xFFFFFFFFu - raw.x);
+        // the sweep ran unmasked: a history member leaves the candidates here ...
+        int l2 = 0, h2 = deg;
+        while (l2 < h2) {
+          const int mid = (l2 + h2) >> 1;
+          if (hist_s[mid] < raw.x) l2 = mid + 1; else h2 = mid;
+        }
+        if (l2 < deg && hist_s[l2] == raw.x) k[r] = 0ull;
+      } else if (e < total + deg) {
+        // ... and the whole history comes back with the mask value, the masked row's exact entries
+        k[r] = make_key(P.mask_value, hist_s[e - total]);
+      }
+    }
+    const int total2 = total + deg;
+    int valid = 0;
+#pragma unroll
+    for (int r = 0; r < NRmax; ++r) valid += __popcll(__ballot(k[r] != 0ull));
+    uint32_t T = 0;
+    if (valid < K) why = 2;
+    else if (total2 <= 128) T = kth_largest_ord<2, NRmax, 20>(k, K);
+    else if (total2 <= 256) T = kth_largest_ord<4, NRmax, 20>(k, K);
+    else if (total2 <= 512) T = kth_largest_ord<8, NRmax, 20>(k, K);
+    else T = kth_largest_ord<NRmax, NRmax, 20>(k, K);
+    const float a_k = ord_to_f32(T);
+    const float cutoff = a_k - 2.0f * m;
+    if (why == 0 && !(cutoff > theta)) why = 4;  // items the sweep rejected could lie inside the band
+    // survivors: approximate score >= cutoff
+    int base2 = 0;
+#pragma unroll
+    for (int r = 0; r < NRmax; ++r) {
+      if (64 * r >= total2) continue;
+      const bool keep = k[r] != 0ull && ord_to_f32((uint32_t)(k[r] >> 32)) >= cutoff;
+      const unsigned long long mk = __ballot(keep);
+      const int pos = base2 + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+      if (keep && pos < kPfMaxRescore) keep_item[pos] = 0xFFFFFFFFu - (uint32_t)(k[r] & 0xFFFFFFFFull);
+      base2 += __popcll(mk);
+    }
+    if (base2 > kPfMaxRescore && why == 0) why = 5;
+    __builtin_amdgcn_wave_barrier();
+    if (why == 0) {
+      const float *urow = P.user_emb + (size_t)u * D;
+      auto rescore = [&](int idx) -> uint64_t {
+        if (idx >= base2) return 0ull;
+        const uint32_t item = keep_item[idx];
+        int lo = 0, hi = deg;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (hist_s[mid] < item) lo = mid + 1; else hi = mid;
+        }
+        const bool masked = lo < deg && hist_s[lo] == item;
+        const float s = masked ? P.mask_value : exact_score<D>(urow, P.item_emb + (size_t)item * D);
+        return make_key(s, item);
+      };
+      e0 = rescore(lane);
+      if (base2 > 64) {
+        e1 = rescore(lane + 64);
+        sort128_desc(e0, e1, lane);
+      } else {
+        sort64_desc(e0, lane);
+      }
+    }
+  }
+  if (lane == 0) P.fail[u] = why;
+  if (why == 0 && lane < K) {
+    const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
+    P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;
+    P.out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
+  }
+}
+
+// ---- statistics of the last prefilter call (monitoring / tuning) ------------------------------------------------
+// out[0] users sent to the fp32 fallback, out[1] candidate keys in total, out[2] longest list, out[3] users,
+// out[4..8] fallback users by reason code 1..5 (score_select_rescore_kernel)
+__global__ __launch_bounds__(256) void score_prefilter_stats_kernel(const int *__restrict__ fail,
+                                                                    const int *__restrict__ cand_cnt, int64_t n_users,
+                                                                    int splits, unsigned long long *__restrict__ out) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_users) return;
+  unsigned long long tot = 0;
+  int mx = 0;
+  for (int l = 0; l < 2 * splits; ++l) {
+    const int c = cand_cnt[((size_t)(l >> 1) * n_users + u) * 2 + (l & 1)];
+    tot += (unsigned long long)c;
+    mx = max(mx, c);
+  }
+  if (fail[u]) {
+#ifdef CHAOREC_PF_DEBUG
+    const unsigned long long slot = atomicAdd(out + 9, 1ull);
+    if (slot < 16) { out[10 + 2 * slot] = (unsigned long long)u; out[11 + 2 * slot] = tot; }
+#endif
+    atomicAdd(out + 0, 1ull);
+    atomicAdd(out + 3 + min(fail[u], 5), 1ull);
+  }
+  atomicAdd(out + 1, tot);
+  atomicMax(out + 2, (unsigned long long)mx);
+  atomicAdd(out + 3, 1ull);
+}

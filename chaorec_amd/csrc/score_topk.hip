@@ -775,6 +775,8 @@ __global__ __launch_bounds__(64) void score_select_kernel(const uint64_t *__rest
   }
 }
 
+#include "score_prefilter.hpp"
+
 // ---- launch plan -----------------------------------------------------------------------------
 struct ScorePlan {
   int splits;
@@ -783,8 +785,35 @@ struct ScorePlan {
   bool sample;      // sampled per-user threshold + certification + fallback
   int sample_rank;  // r: tau0 = r-th best of the sample
   int tile_stride;
+  // bf16 prefilter path (score_prefilter.hpp)
+  bool prefilter;
+  int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
+  int fb_splits;            // item splits of the fp32 fallback behind the prefilter (few groups: many splits)
+  int64_t fb_tiles_per_split;
+  size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_margin, off_pf_cand, off_pf_cnt;
   size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
 };
+
+// Wave slots of the sweep kernel on this device (waves per CU x CUs), queried once; without a device (the CPU-side
+// workspace query) the gfx950 defaults.
+static int sweep_wave_slots(int D) {
+  static int cached[2] = {0, 0};
+  int &c = cached[D == 64 ? 0 : 1];
+  if (c) return c;
+  int per_cu = 0, cus = 0, dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e == hipSuccess) {
+    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, 4>, 64, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, 2>, 64, 0);
+  }
+  if (e != hipSuccess || per_cu <= 0 || cus <= 0) {
+    (void)hipGetLastError();
+    return 2048;   // not cached: a later call with a device asks again
+  }
+  c = per_cu * cus;
+  return c;
+}
 
 static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   ScorePlan p;
@@ -820,13 +849,47 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
       p.splits = (int)((n_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
     }
   }
+  // bf16 prefilter + exact re-score: D in {64, 128}, enough tiles for the sampler's statistics
+  p.prefilter = (D == 64 || D == 128) && K <= 64 && n_tiles >= 256;
+  p.pf_ub = D == 64 ? 4 : 2;
+  {
+    const int64_t ublocks = (groups + p.pf_ub - 1) / p.pf_ub;
+    // one full round of 2 waves per SIMD (2048 slots) when the user blocks allow it: a second, partly filled
+    // round costs a whole wave time
+    int64_t sp = sweep_wave_slots(D) / ublocks;
+    if (sp > 16) sp = 16;
+    if (sp > n_tiles / 16) sp = n_tiles / 16;
+    if (sp < 1) sp = 1;
+    p.pf_splits = (int)sp;
+  }
+  {
+    int64_t fs = n_tiles / 24;
+    if (fs > 16) fs = 16;
+    if (fs < 1) fs = 1;
+    p.fb_tiles_per_split = (n_tiles + fs - 1) / fs;
+    p.fb_splits = (int)((n_tiles + p.fb_tiles_per_split - 1) / p.fb_tiles_per_split);
+  }
+  p.pf_sample_stride = 4;
+  p.pf_sample_splits = 2;
+  p.pf_sample_rank = 20;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
+  p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 32 * (size_t)D * 2 : 0);
+  p.off_pf_scalars = take(p.prefilter ? 256 : 0);
+  p.off_pf_tau = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_margin = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  // (sized for the most splits any device plan uses, so that the CPU-side query and the device plan agree)
+  p.off_pf_cand = take(p.prefilter ? (size_t)16 * (size_t)n_users * 2 * kPfCap * 8 : 0);
+  p.off_pf_cnt = take(p.prefilter ? (size_t)16 * (size_t)n_users * 2 * 4 : 0);
   p.off_packed = take(p.pack ? (size_t)n_tiles * 32 * (size_t)D * 4 : 0);
   p.off_tau = take(p.sample ? (size_t)n_users * 4 : 0);
   p.off_tau1 = take(p.sample ? (size_t)n_users * 4 : 0);
-  p.off_fail = take(p.sample ? (size_t)n_users * 4 : 0);
-  p.off_partial = take(p.splits > 1 ? (size_t)p.splits * (size_t)n_users * (size_t)K * 8 : 0);
+  p.off_fail = take((p.sample || p.prefilter) ? (size_t)n_users * 4 : 0);
+  {
+    const int ps = p.prefilter && p.fb_splits > p.splits ? p.fb_splits : p.splits;
+    p.off_partial = take(ps > 1 ? (size_t)ps * (size_t)n_users * (size_t)K * 8 : 0);
+  }
   p.off_cand = take(p.sample ? (size_t)p.splits * (size_t)n_users * 2 * kCandCap * 8 : 0);
   p.off_cnt = take(p.sample ? (size_t)p.splits * (size_t)n_users * 2 * 4 : 0);
   p.total = o;
@@ -864,6 +927,21 @@ extern "C" size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_
   return plan_score(n_users, n_items, K, D).total;
 }
 
+extern "C" int chaorec_score_topk_stats(const void *workspace, int64_t n_users, int64_t n_items, int32_t K, int32_t D,
+                                        uint64_t *out9, void *stream) {
+  if (!workspace || !out9) return fail(CHAOREC_E_INVALID, "score_topk_stats: NULL argument");
+  if (n_users <= 0 || n_items <= 0 || K <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "score_topk_stats: bad sizes");
+  const ScorePlan p = plan_score(n_users, n_items, K, D);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out9, 0, 9 * sizeof(uint64_t), st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "stats: memset");
+  if (!p.prefilter) return CHAOREC_OK;   // all zeros: the call did not take the prefilter route
+  const char *ws = (const char *)workspace;
+  hipLaunchKernelGGL(score_prefilter_stats_kernel, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, st,
+                     (const int *)(ws + p.off_fail), (const int *)(ws + p.off_pf_cnt), n_users, p.pf_splits,
+                     (unsigned long long *)out9);
+  return check_launch("score_prefilter_stats_kernel");
+}
+
 extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_emb, int64_t n_users,
                                       int64_t n_items, int32_t D, const int64_t *hist_rowptr,
                                       const int32_t *hist_col, float mask_value, int32_t K,
@@ -875,13 +953,14 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
   if (K < 1 || K > kMaxK) return fail(CHAOREC_E_INVALID, "score_topk: K=%d must be in [1,%d]", K, kMaxK);
   if (n_items < K) return fail(CHAOREC_E_INVALID, "score_topk: n_items=%lld < K=%d (torch.topk would raise)", (long long)n_items, K);
   if (n_items > 0xFFFFFFF0ll) return fail(CHAOREC_E_INVALID, "score_topk: n_items too large");
-  if (precision != 0 && precision != 1) return fail(CHAOREC_E_INVALID, "score_topk: precision %d not built", precision);
+  if (precision < 0 || precision > 2) return fail(CHAOREC_E_INVALID, "score_topk: precision %d not built", precision);
   if (hist_rowptr && !hist_col) return fail(CHAOREC_E_INVALID, "score_topk: hist_rowptr without hist_col");
   if (!((D == 8 || D == 16 || D == 32 || D == 64 || D == 128) || (D > 128 && D % 64 == 0)))
     return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {8,16,32,64,128} and not a multiple of 64 above 128", D);
   if (n_users == 0) return CHAOREC_OK;
   ScorePlan p = plan_score(n_users, n_items, K, D);
   if (precision == 1) p.sample = false;  // precision 1: single exact pass, no sampled threshold (A/B + tests)
+  if (precision != 0) p.prefilter = false;  // precision 2: fp32 sweep with sampled thresholds (the pre-bf16 path)
   if (p.total > workspace_bytes || (p.total && !workspace))
     return fail(CHAOREC_E_WORKSPACE, "score_topk: workspace %zu < %zu", workspace_bytes, p.total);
   hipStream_t st = (hipStream_t)stream;
@@ -914,6 +993,71 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
   a.fail = nullptr;
 
   int rc;
+  if (p.prefilter) {
+    PrefArgs P;
+    P.user_emb = user_emb;
+    P.item_emb = item_emb;
+    P.packed = (const uint4 *)(ws + p.off_pf_packed);
+    P.n_users = n_users;
+    P.n_items = n_items;
+    P.hist_rowptr = hist_rowptr;
+    P.hist_col = hist_col;
+    P.mask_value = mask_value;
+    P.K = K;
+    P.id_offset = id_offset;
+    P.imax2_bits = (uint32_t *)(ws + p.off_pf_scalars);
+    P.tau_sum = (float *)(ws + p.off_pf_tau);
+    P.theta = (float *)(ws + p.off_pf_theta);
+    P.margin = (float *)(ws + p.off_pf_margin);
+    P.cand = (uint64_t *)(ws + p.off_pf_cand);
+    P.cand_cnt = (int *)(ws + p.off_pf_cnt);
+    P.splits = p.pf_splits;
+    P.sample_stride = p.pf_sample_stride;
+    P.sample_splits = p.pf_sample_splits;
+    P.sample_rank = p.pf_sample_rank;
+    P.out_idx = out_idx;
+    P.out_val = out_val;
+    int *failf = (int *)(ws + p.off_fail);
+    P.fail = failf;
+    if (hipMemsetAsync(P.imax2_bits, 0, 256, st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
+    if (hipMemsetAsync(P.tau_sum, 0, (size_t)n_users * 4, st) != hipSuccess)
+      return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
+    const int64_t nfrag = n_tiles * (D / 16) * 64;
+    hipLaunchKernelGGL(pack_items_bf16_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, item_emb,
+                       (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.imax2_bits);
+    rc = check_launch("pack_items_bf16_kernel");
+    if (rc) return rc;
+    const dim3 gs(groups, (unsigned)p.pf_sample_splits);
+    const dim3 gw((unsigned)((groups + p.pf_ub - 1) / p.pf_ub), (unsigned)p.pf_splits);
+    if (D == 64) {
+      hipLaunchKernelGGL(score_sample_bf16_kernel<64>, gs, dim3(64), 0, st, P);
+      hipLaunchKernelGGL((score_sweep_bf16_kernel<64, 4>), gw, dim3(64), 0, st, P);
+      hipLaunchKernelGGL(score_select_rescore_kernel<64>, dim3((unsigned)n_users), dim3(64), 0, st, P);
+    } else {
+      hipLaunchKernelGGL(score_sample_bf16_kernel<128>, gs, dim3(64), 0, st, P);
+      hipLaunchKernelGGL((score_sweep_bf16_kernel<128, 2>), gw, dim3(64), 0, st, P);
+      hipLaunchKernelGGL(score_select_rescore_kernel<128>, dim3((unsigned)n_users), dim3(64), 0, st, P);
+    }
+    rc = check_launch("score prefilter kernels");
+    if (rc) return rc;
+    // uncertified users (list overflow, fewer than K above the threshold, band wider than the lists): exact fp32
+    // sweep of their groups over the item splits, unpacked item table, then the merge for those users only
+    ScoreArgs f = a;
+    f.mode = kModeFallback;
+    f.fail = failf;
+    f.splits = p.fb_splits;
+    f.tiles_per_split = p.fb_tiles_per_split;
+    f.partial = p.fb_splits > 1 ? (uint64_t *)(ws + p.off_partial) : nullptr;
+    rc = dispatch_score(D, f, dim3(groups, (unsigned)p.fb_splits), st);
+    if (rc) return rc;
+    if (p.fb_splits > 1) {
+      hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, f.partial, n_users, K,
+                         p.fb_splits, id_offset, out_idx, out_val, (const float *)nullptr, (int *)nullptr,
+                         (const int *)failf);
+      rc = check_launch("score_topk_merge_kernel");
+    }
+    return rc;
+  }
   if (p.pack) {
     float4 *packed = (float4 *)(ws + p.off_packed);
     const int64_t n4 = n_tiles * (D / 8) * 64;

@@ -212,9 +212,10 @@ def draw_batch(edges, hist, B, num_user, num_item, seed, step, step_dev=None):
 # --------------------------------------------------------------------------------------------
 # scoring + top-K
 # --------------------------------------------------------------------------------------------
-def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0):
+def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0, stats=None):
     """Top-K of user_emb @ item_emb.T with history masking, without the [U,I] matrix.
-    Returns (idx int64 [U,K] = item + id_offset, val fp32 [U,K])."""
+    Returns (idx int64 [U,K] = item + id_offset, val fp32 [U,K]).  `stats`: a dict to fill with the prefilter
+    route's counters (chaorec_score_topk_stats; costs a device sync)."""
     _need_cuda(user_emb, item_emb)
     user_emb, item_emb = _f32c(user_emb), _f32c(item_emb)
     U, D = user_emb.shape
@@ -231,6 +232,13 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
                                     mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
                                     precision, _stream())
     _lib.check(rc, "chaorec_score_topk_f32")
+    if stats is not None:
+        out9 = torch.zeros(9, dtype=torch.int64, device=dev)
+        _lib.check(lib.chaorec_score_topk_stats(_ptr(ws), U, I, K, D, _ptr(out9), _stream()), "chaorec_score_topk_stats")
+        v = out9.tolist()
+        stats.update(fallback_users=v[0], candidates=v[1], longest_list=v[2], prefilter_users=v[3],
+                     fallback_reasons=dict(overflow=v[4], too_few=v[5], too_many=v[6], band_below_threshold=v[7],
+                                           band_too_wide=v[8]))
     return idx, val
 
 

@@ -155,17 +155,25 @@ int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *his
  *   out = the K largest per user, descending; ties -> LOWEST item index first.
  *   out_idx = item index + id_offset (int64), out_val = the (masked) score.
  *
- * precision 0 ("f32"): v_mfma_f32_32x32x2_f32, i.e. a k-ordered fp32 fmaf chain.  With the K-dim
- *   cut into chunks of C floats (C = D for D <= 128, C = 64 above), per chunk base b:
+ * The RESULT is the same for every `precision` value: the exact top-K of the fp32 scores defined by the
+ * k-ordered fmaf chain below (what v_mfma_f32_32x32x2_f32 computes), bit-identical to
+ * oracle/chaorec_oracle.c:oracle_score_dot().  With the K-dim cut into chunks of C floats (C = D for
+ * D <= 128, C = 64 above), per chunk base b:
  *     for s in [0, C/2): acc = fmaf(u[b+s], i[b+s], acc); acc = fmaf(u[b+C/2+s], i[b+C/2+s], acc)
- *   bit-identical to oracle/chaorec_oracle.c:oracle_score_dot().
+ * `precision` selects the route to it:
+ *   0  fastest exact route.  D in {64, 128} and >= 8192 items: the [U, I] sweep runs on the bf16 MFMA pipe
+ *      (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) as a PREFILTER with a proven error bound
+ *      |s~ - s| <= m_u = 1.02 * 2^-8 * ||u|| * max_j ||i_j||; every item within 2 m_u of the K-th best
+ *      approximate score is re-scored with the exact fp32 chain and the top-K is ranked on those values; a user
+ *      the bound cannot certify (list overflow, too few candidates, band too wide) is re-run on the fp32 route.
+ *      Otherwise: route 2.
+ *   1  one unthresholded fp32 MFMA pass (A/B runs and tests).
+ *   2  fp32 MFMA sweep with a sampled per-user threshold: tau0 = 32nd best score over every s-th 32-item tile,
+ *      the full pass keeps only scores above it, a certification step counts them and any user with fewer
+ *      than K is re-ranked without a threshold.
  * D in {8, 16, 32, 64, 128} (users' fragment register-resident) or a multiple of 64 above 128
  * (streamed; the kNN build over modality features);  1 <= K <= 64;  n_items >= K.
  * hist_rowptr may be NULL (no mask).  hist_col ascending inside a row.
- * precision 0 may use a sampled per-user threshold to cut selection work: tau0 = 32nd best score over every
- *   s-th 32-item tile, the full pass keeps only scores above it, a certification step counts them and any
- *   user with fewer than K is re-ranked without a threshold -- the RESULT is always the exact top-K.
- * precision 1: the same exact arithmetic in a single unthresholded pass (for A/B runs and tests).
  * ------------------------------------------------------------------------------------- */
 size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K, int32_t D);
 
@@ -176,6 +184,14 @@ int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
                            int64_t *out_idx, float *out_val,
                            void *workspace, size_t workspace_bytes,
                            int32_t precision, void *stream);
+
+/* Monitoring: what the prefilter route of the LAST chaorec_score_topk_f32 call on this workspace did (same sizes).
+ * out9 (device, 9 x uint64): [0] users re-run on the fp32 route, [1] candidate keys kept by the bf16 sweep in
+ * total, [2] longest per-lane list, [3] users, [4..8] re-run users by reason (list overflow, fewer than K
+ * candidates, more than 512, error band below the sweep threshold, more than 128 items in the band).
+ * All zeros if that call did not take the prefilter route. */
+int chaorec_score_topk_stats(const void *workspace, int64_t n_users, int64_t n_items, int32_t K, int32_t D,
+                             uint64_t *out9, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Dense fp32 GEMM on the f32 MFMA pipe (exact fp32 products, fp32 accumulate):

@@ -340,10 +340,71 @@ def test_score_topk_sampled_threshold_fallback(dev, oracle):
     want_i, want_v = oracle.score_topk(ue, ie, hist, 1e-6, K, 7)
     dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
     tu, ti = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
-    for precision in (0, 1):
+    for precision in (0, 1, 2):
         got_i, got_v = ops.score_topk(tu, ti, dh, 1e-6, K, id_offset=7, precision=precision)
         assert np.array_equal(got_v.cpu().numpy(), want_v), precision
         assert np.array_equal(got_i.cpu().numpy(), want_i), precision
+
+
+# ---- bf16 prefilter + exact fp32 re-score (precision 0 at >= 8192 items, D in {64, 128}) -------------------
+def _check_all_precisions(dev, oracle, ue, ie, hist, mask, K, id_offset=0):
+    from chaorec_amd import ops
+    want_i, want_v = oracle.score_topk(ue, ie, hist, mask, K, id_offset)
+    dh = None if hist is None else (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    tu, ti = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
+    for precision in (0, 2, 1):
+        got_i, got_v = ops.score_topk(tu, ti, dh, mask, K, id_offset=id_offset, precision=precision)
+        assert np.array_equal(got_v.cpu().numpy(), want_v), precision     # exact fp32 values, not bf16 ones
+        assert np.array_equal(got_i.cpu().numpy(), want_i), precision
+
+
+@pytest.mark.parametrize("U,I,D,K", [(150, 9000, 64, 50), (70, 8200, 128, 20), (33, 12000, 64, 64),
+                                     (129, 8192, 64, 1), (300, 15207, 64, 50)])
+def test_score_topk_prefilter_bit_exact_vs_oracle(dev, oracle, U, I, D, K):
+    rng = np.random.default_rng(U + I + D)
+    ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
+    ie *= (0.3 + rng.pareto(3.0, (I, 1))).astype(np.float32)        # heavy-tailed item norms, like trained tables
+    _check_all_precisions(dev, oracle, ue, ie, _hist_random(U, I, 40, seed=I), 1e-6, K, id_offset=U)
+
+
+def test_score_topk_prefilter_adversarial(dev, oracle):
+    """Inputs built against each assumption of the prefilter; every one must still give the exact top-K
+    (through the certification + fp32 fallback where the bf16 pass cannot decide)."""
+    rng = np.random.default_rng(21)
+    U, I, D, K = 96, 9600, 64, 50
+    base_u = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    base_i = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
+    hist = _hist_random(U, I, 25, seed=9)
+    # (a) massive exact ties: integer embeddings
+    _check_all_precisions(dev, oracle, rng.integers(-2, 3, (U, D)).astype(np.float32),
+                          rng.integers(-1, 2, (I, D)).astype(np.float32), hist, 1e-6, K)
+    # (b) all scores equal (zero users) and all-zero tables
+    ue = base_u.copy()
+    ue[::3] = 0.0
+    _check_all_precisions(dev, oracle, ue, base_i, hist, 1e-6, K)
+    _check_all_precisions(dev, oracle, np.zeros((U, D), np.float32), np.zeros((I, D), np.float32), hist, 1e-6, K)
+    # (c) the sampled tiles (every 4th) hold all the big scores: threshold far too high
+    ie = (base_i * 0.05).astype(np.float32)
+    tiles = np.arange(I) // 32
+    hot = (tiles % 4 == 0) & (np.arange(I) % 32 < 2)
+    ie[hot] = np.abs(rng.standard_normal((hot.sum(), D))).astype(np.float32)
+    _check_all_precisions(dev, oracle, np.abs(base_u), ie, hist, 1e-6, K)
+    # (d) the big scores sit in NO sampled tile and in one narrow item range: threshold far too low, lists overflow
+    ie = (base_i * 0.05).astype(np.float32)
+    ie[33:33 + 3 * 32] = np.abs(rng.standard_normal((96, D))).astype(np.float32) * 3
+    _check_all_precisions(dev, oracle, np.abs(base_u), ie, hist, 1e-6, K)
+    # (e) one item with a huge norm blows up the error bound: the 2m band swallows far more than 128 candidates
+    ie = base_i.copy()
+    ie[777] *= 1e4
+    _check_all_precisions(dev, oracle, base_u, ie, hist, 1e-6, K)
+    # (f) scores that differ only below bf16 resolution: items are tiny perturbations of one vector
+    v = rng.standard_normal(D).astype(np.float32)
+    ie = (v[None, :] * (1.0 + 1e-4 * rng.standard_normal((I, 1)))).astype(np.float32)
+    _check_all_precisions(dev, oracle, base_u, ie, hist, 1e-6, K)
+    # (g) negative scores everywhere with the positive mask value (Q7) and no history at all
+    _check_all_precisions(dev, oracle, np.abs(base_u), -np.abs(base_i), hist, 1e-6, K)
+    _check_all_precisions(dev, oracle, base_u, base_i, None, 0.0, K)
 
 
 def test_score_topk_single_pass_equals_sampled(dev):
@@ -353,7 +414,9 @@ def test_score_topk_single_pass_equals_sampled(dev):
     emb_u, emb_i = torch.randn(U, D, device=dev) * 0.1, torch.randn(I, D, device=dev) * 0.1
     a = ops.score_topk(emb_u, emb_i, None, 0.0, 50, precision=0)
     b = ops.score_topk(emb_u, emb_i, None, 0.0, 50, precision=1)
+    c = ops.score_topk(emb_u, emb_i, None, 0.0, 50, precision=2)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
 
 
 def test_score_topk_errors(dev):
