@@ -5,7 +5,7 @@
 // be in a user's top-K; the handful that can are re-scored in exact fp32 (the same k-ascending fmaf chain as the
 // f32 MFMA kernel / oracle_score_dot) and ranked on those values.  The result is bit-identical to the fp32 path:
 //
-//   |s~(u,j) - s(u,j)| <= m_u := c * ||u||_2 * max_j ||i_j||_2,   c = 1.02 * 2^-8
+//   |s~(u,j) - s(u,j)| <= m_u := c * ||u||_2 * max_j ||i_j||_2,   c = 1.03 * 2^-8
 //     (two RNE bf16 roundings, 2^-9 relative each, + fp32 accumulation; Cauchy-Schwarz on sum_d |u_d||i_d|).
 //   Let a_K = K-th largest approximate score of the user.  An item with s~ < a_K - 2 m_u has true score
 //   < a_K - m_u <= the true score of each of the K items whose approximate score is >= a_K: K items beat it
@@ -15,16 +15,19 @@
 //
 // Pipeline (all on one stream, no host round trip):
 //   pack      items -> bf16 MFMA A-fragments (one coalesced 1 KiB wave load per k-step), max item norm
-//   sample    per user a threshold tau0 from every 4th tile: list-free lane-local group maxima give a loose tau1,
-//             scores above tau1 go to a per-lane LDS list, a lane-local bisection finds a value with >= r_l
-//             sample scores above it; min over the user's two lanes and the sample splits (atomicMin)
-//   sweep     one wave = UB x 32 users (UB fragments in registers, each item fragment feeds UB MFMA groups),
-//             tiles interleaved over the splits; approximate scores above theta_u = tau0 - 2 m_u are appended
-//             to the lane's own global list as (ord(score) << 32 | ~item) keys
-//   select    one wave per user: a_K by ballot/popcount radix select over the ~200 keys, certification
-//             (>= K keys, a_K - 2 m_u > theta_u, no list overflow, |R| <= 128), exact fp32 re-score of R, one
-//             register bitonic sort, top-K out.  Uncertified users are flagged and re-run by the exact fp32
-//             fallback sweep (score_topk_f32_kernel, kModeFallback).
+//   sample    per user a threshold tau0 from every 4th tile, RAW scores (the rank is shifted by the number of
+//             history items in the sample): lane-local top-4 of the first 8 tiles gives a loose tau1, scores above
+//             it go to a 24-entry per-lane LDS list, a bisection pooled over the user's two lanes finds a value
+//             with >= r sample scores above it; mean over 4 sample splits (4 waves per user block)
+//   sweep     one wave = UB x 32 users (fragments in registers, stored negated), tiles interleaved over the
+//             splits; a 5th k-step adds the bf16 threshold, so a hit is the accumulator's sign bit; hits
+//             s~ > theta_u = bf16_floor(tau0 - 2 m_u) are appended to the lane's own global list as raw
+//             (item, score bits) pairs -- unmasked: the history is reconciled by the selection
+//   select    one wave per user: history members leave the candidates and the whole history returns with
+//             mask_value; a_K by ballot/popcount radix select; certification (>= K keys, a_K - 2 m_u > theta_u,
+//             no list overflow, |R| <= 128); exact fp32 re-score of R; one register bitonic sort; top-K out.
+//             Users with more than 512 keys are queued on the device for a 1024-slot instantiation; uncertified
+//             users are flagged and re-run by the exact fp32 sweep (score_topk_f32_kernel, kModeFallback).
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -45,9 +48,9 @@ __device__ __forceinline__ uint4 bf16_pack8(const float4 a, const float4 b) {
   return make_uint4(bf16_pack2(a.x, a.y), bf16_pack2(a.z, a.w), bf16_pack2(b.x, b.y), bf16_pack2(b.z, b.w));
 }
 
-constexpr float kBf16ErrCoef = 1.02f / 256.0f;
+constexpr float kBf16ErrCoef = 1.03f / 256.0f;
 constexpr int kPfCap = 64;        // keys per (split, user, half) list of the sweep
-constexpr int kPfSampleCap = 64;  // scores per lane in the sampler's LDS list
+constexpr int kPfSampleCap = 24;  // scores per lane in the sampler's LDS list (6 KiB per wave: 4 waves per SIMD)
 constexpr int kPfMaxRescore = 128;
 
 struct PrefArgs {
@@ -73,6 +76,10 @@ struct PrefArgs {
   int64_t *out_idx;
   float *out_val;
   int *fail;
+  int *heavy_cnt;               // users queued for the 1024-slot selection
+  int *heavy_list;              // [U]
+  int *fb_cnt;                  // users queued for the exact per-user route
+  int *fb_list;                 // [U]
 };
 
 // ---- pack ----------------------------------------------------------------------------------------------------
@@ -223,18 +230,35 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   // tile loop).  Interacted items usually score high, so the rank is shifted by h_s = the number of the user's
   // history items inside this wave's sampled tiles: the (r + h_s)-th best raw score is at most the r-th best
   // masked one whenever mask_value does not matter, and any value is a valid threshold anyway (certification).
+  // (counted by the whole wave over the block's contiguous CSR range: a per-lane walk of the own row is a chain of
+  //  dependent loads as long as the heaviest user's history)
+  __shared__ int64_t rp_s[33];
+  __shared__ int hs_s[32];
   int h_s = 0;
-  if (P.hist_rowptr && u_ok) {
-    const int64_t hb = P.hist_rowptr[u], he = P.hist_rowptr[u + 1];
-    for (int64_t i = hb + h; i < he; i += 2) {   // the user's two lanes take alternate entries
-      const int tt = (int)((uint32_t)P.hist_col[i] >> 5);
-      h_s += (tt >= t_first && (tt - t_first) % step == 0) ? 1 : 0;
+  if (P.hist_rowptr) {
+    const int64_t ub = (int64_t)blockIdx.x * 32;
+    if (lane < 33) rp_s[lane] = P.hist_rowptr[min(ub + lane, P.n_users)];
+    if (lane < 32) hs_s[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t e0 = rp_s[0], e1 = rp_s[32];
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+      const int tt = (int)((uint32_t)P.hist_col[e] >> 5);
+      if (tt >= t_first && (tt - t_first) % step == 0) {
+        int lo = 0, hi = 31;   // owner row: last r with rp_s[r] <= e
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (rp_s[mid] <= e) lo = mid; else hi = mid - 1;
+        }
+        atomicAdd(&hs_s[lo], 1);
+      }
     }
+    __builtin_amdgcn_wave_barrier();
+    h_s = hs_s[ur];
   }
-  h_s += __shfl_xor(h_s, 32, 64);
 
   // phase 1: the first 8 sampled tiles (128 scores per lane), lane-local top-4 by median-of-3 insertion; tau1 = the
-  // smaller of the two lanes' 4th best: at least 8 of the user's 256 scores reach it (expected: the top ~4 %)
+  // larger of the two lanes' 4th best: at least 4 of the user's 256 scores reach it (expected: the top ~2.5 %)
   float tau1;
   {
     float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY, b3 = -INFINITY;
@@ -257,7 +281,7 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
         b0 = fmaxf(b0, x);
       }
     }
-    tau1 = fminf(b3, __shfl_xor(b3, 32, 64));
+    tau1 = fmaxf(b3, __shfl_xor(b3, 32, 64));
   }
 
   // phase 2: every sampled tile; scores above tau1 go to the lane's LDS list (a full list drops the rest: the
@@ -266,13 +290,16 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   int cnt = 0;
   {
     const float tl = nextafterf(tau1, -INFINITY);   // strict compare below keeps scores == tau1
-    uint4 a[D / 16], an[D / 16];
+    // item fragments three tiles ahead: one tile of this kernel is short (one user block), a single tile of
+    // lookahead does not cover the L2 latency
+    uint4 ring[3][D / 16];
     int t = t_first;
-    if (t < n_tiles) load_item_frags_bf16<D>(a, P.packed, t, lane);
-    for (; t < n_tiles; t += step) {
-      load_item_frags_bf16<D>(an, P.packed, t + step < n_tiles ? t + step : t, lane);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      load_item_frags_bf16<D>(ring[i], P.packed, t + i * step < n_tiles ? t + i * step : (n_tiles - 1), lane);
+    auto consume = [&](const uint4 (&a)[D / 16], int tt) __attribute__((always_inline)) {
       f32x16 acc = tile_scores_bf16<D>(a, bu);
-      const uint32_t j0 = (uint32_t)t * 32u;
+      const uint32_t j0 = (uint32_t)tt * 32u;
       apply_mask_and_range(acc, 0u, j0, n_items, h, P.mask_value);
       uint32_t qbits = 0;
 #pragma unroll
@@ -291,8 +318,20 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
         }
         __builtin_amdgcn_wave_barrier();
       }
+    };
+    while (t < n_tiles) {
 #pragma unroll
-      for (int q = 0; q < D / 16; ++q) a[q] = an[q];
+      for (int i = 0; i < 3; ++i) {
+        if (t < n_tiles) {
+          uint4 cur[D / 16];
+#pragma unroll
+          for (int q = 0; q < D / 16; ++q) cur[q] = ring[i][q];
+          const int tp = t + 3 * step;
+          load_item_frags_bf16<D>(ring[i], P.packed, tp < n_tiles ? tp : (n_tiles - 1), lane);
+          consume(cur, t);
+          t += step;
+        }
+      }
     }
   }
 
@@ -329,9 +368,20 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
 // tile's 16 compares become one bit mask per lane (v_sub + v_alignbit each), the scores are parked in a 4 KiB LDS
 // scratch ([reg][lane]) and ONE drain loop per user block stores the hits: every iteration is one store
 // instruction for all lanes that still hold a hit.
+// The threshold compare rides on the MFMA: the users' fragments are stored NEGATED and a fifth k-step multiplies a
+// constant 1 on the item side with the (bf16, rounded toward -inf) threshold on the user side, so the accumulator
+// holds theta~ - s~ and a hit is its sign bit (1 VALU op per score instead of a subtract and a shift-in).  The list
+// keeps s~' = theta~ - acc; the extra rounding (2^-23 relative) is inside kBf16ErrCoef.
+__device__ __forceinline__ float bf16_floor(float x) {  // largest bf16-representable value <= x
+  const uint32_t b = __float_as_uint(x);
+  uint32_t t = b & 0xFFFF0000u;
+  if ((b & 0x80000000u) && (b & 0xFFFFu)) t += 0x10000u;
+  return __uint_as_float(t);
+}
+
 template <int D, int UB>
 __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) {
-  __shared__ float park[16 * 64];
+  __shared__ float4 park[4 * 64];   // [quad][lane]: registers 4*quad .. 4*quad+3 of the lane
   const int lane = threadIdx.x;
   const int ur = lane & 31, h = lane >> 5;
   const uint32_t n_items = (uint32_t)P.n_items;
@@ -339,75 +389,129 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
   const int split = blockIdx.y;
   const int splits = P.splits;
 
-  bf16x8 bu[UB][D / 16];
+  bf16x8 bu[UB][D / 16], bth[UB];
   float theta[UB];
   int cnt[UB];
   uint2 *mine[UB];
   const float imax = sqrtf(__uint_as_float(*P.imax2_bits));
+  Frag16 one;   // item-side constant of the threshold k-step: A[row][k = 0] = 1
+  one.u = make_uint4(h == 0 ? 0x3F80u : 0u, 0u, 0u, 0u);
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
     const int64_t u = ((int64_t)blockIdx.x * UB + b) * 32 + ur;
     const bool ok = u < P.n_users;
     float n2;
     load_user_frags<D>(bu[b], n2, P.user_emb, u, ok, h);
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) {   // negate: exact, and RNE is symmetric, so the chain gives -s~ bit for bit
+      Frag16 f;
+      f.v = bu[b][q];
+      f.u.x ^= 0x80008000u;
+      f.u.y ^= 0x80008000u;
+      f.u.z ^= 0x80008000u;
+      f.u.w ^= 0x80008000u;
+      bu[b][q] = f.v;
+    }
     n2 += __shfl_xor(n2, 32, 64);
     const float m = kBf16ErrCoef * sqrtf(n2) * imax + 1e-30f;
     float th = INFINITY;  // padding users never qualify
     if (ok) {
-      th = P.tau_sum[u] - 2.0f * m;
+      th = bf16_floor(P.tau_sum[u] - 2.0f * m);
       if (split == 0 && h == 0) {
         P.theta[u] = th;
         P.margin[u] = m;
       }
     }
     theta[b] = th;
+    Frag16 ft;
+    ft.u = make_uint4(h == 0 ? (__float_as_uint(th) >> 16) : 0u, 0u, 0u, 0u);
+    bth[b] = ft.v;
     cnt[b] = 0;
     mine[b] = reinterpret_cast<uint2 *>(P.cand) + (((size_t)split * P.n_users + (ok ? u : 0)) * 2 + h) * kPfCap;
   }
 
-  uint4 a[D / 16], an[D / 16];
-  int t = split;
-  if (t < n_tiles) load_item_frags_bf16<D>(a, P.packed, t, lane);
-  for (; t < n_tiles; t += splits) {
-    load_item_frags_bf16<D>(an, P.packed, t + splits < n_tiles ? t + splits : t, lane);
+  auto consume = [&](const uint4 (&a)[D / 16], int t) __attribute__((always_inline)) {
     const uint32_t j0 = (uint32_t)t * 32u;
+    // all UB accumulation chains first, k-step major: UB independent MFMAs between two dependent ones
+    f32x16 accs[UB];
+#pragma unroll
+    for (int b = 0; b < UB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accs[b][i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) {
+      Frag16 f;
+      f.u = a[q];
+#pragma unroll
+      for (int b = 0; b < UB; ++b) accs[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v, bu[b][q], accs[b], 0, 0, 0);  // -s~
+    }
+#pragma unroll
+    for (int b = 0; b < UB; ++b)
+      accs[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one.v, bth[b], accs[b], 0, 0, 0);  // theta~ - s~
 #pragma unroll
     for (int b = 0; b < UB; ++b) {
-      f32x16 acc = tile_scores_bf16<D>(a, bu[b]);
+      f32x16 &acc = accs[b];
       if (j0 + 32u > n_items) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          if (j0 + off >= n_items) acc[reg] = -INFINITY;
+          if (j0 + off >= n_items) acc[reg] = INFINITY;   // rows past the table never qualify
         }
       }
-      // bit (15 - reg) <=> acc[reg] > theta: the sign of theta - acc shifted in (== gives +0, -inf gives +inf)
+      // bit (15 - reg) <=> s~ > theta~: the accumulator's sign bit
       uint32_t qbits = 0;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(theta[b] - acc[reg]), 31);
+      for (int reg = 0; reg < 16; ++reg) qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(acc[reg]), 31);
       if (__any(qbits != 0)) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) park[reg * 64 + lane] = acc[reg];
+        for (int q4 = 0; q4 < 4; ++q4)
+          park[q4 * 64 + lane] = make_float4(acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]);
         __builtin_amdgcn_wave_barrier();
-        while (__any(qbits != 0)) {
-          if (qbits) {
-            const int bit = 31 - __clz(qbits);
-            qbits &= ~(1u << bit);
-            const int reg = 15 - bit;
-            const float sc = park[reg * 64 + lane];
-            const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            // raw (item, score bits): the order-preserving key is built by the selection, 64 keys per instruction;
-            // past kPfCap entries are counted, not stored: the selection sees the overflow and flags the user
-            if (cnt[b] < kPfCap) mine[b][cnt[b]] = make_uint2(j0 + off, __float_as_uint(sc));
-            ++cnt[b];
-          }
-        }
+        const float *pk = reinterpret_cast<const float *>(park);
+        do {
+          // up to two hits per lane and round, both LDS reads in flight together; raw (item, score bits) entries:
+          // the order-preserving key is built by the selection, 64 keys per instruction.  Past kPfCap entries are
+          // counted, not stored: the selection sees the overflow and flags the user.
+          const bool h1 = qbits != 0;
+          const int bit1 = h1 ? 31 - __clz(qbits) : 0;
+          const uint32_t q1 = h1 ? (qbits & ~(1u << bit1)) : 0u;
+          const bool h2 = q1 != 0;
+          const int bit2 = h2 ? 31 - __clz(q1) : 0;
+          qbits = h2 ? (q1 & ~(1u << bit2)) : 0u;
+          const int r1 = 15 - bit1, r2 = 15 - bit2;
+          const float v1 = pk[((r1 >> 2) * 64 + lane) * 4 + (r1 & 3)];
+          const float v2 = pk[((r2 >> 2) * 64 + lane) * 4 + (r2 & 3)];
+          if (h1 && cnt[b] < kPfCap)
+            mine[b][cnt[b]] = make_uint2(j0 + (r1 & 3) + 8 * (r1 >> 2) + 4 * h, __float_as_uint(theta[b] - v1));
+          if (h2 && cnt[b] + 1 < kPfCap)
+            mine[b][cnt[b] + 1] = make_uint2(j0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * h, __float_as_uint(theta[b] - v2));
+          cnt[b] += (h1 ? 1 : 0) + (h2 ? 1 : 0);
+        } while (__any(qbits != 0));
         __builtin_amdgcn_wave_barrier();
       }
     }
+  };
+
+  // item fragments three tiles ahead of the MFMAs (a tile of the sweep is ~1 us of work, an L2 round trip under
+  // load is longer than that)
+  uint4 ring[3][D / 16];
+  int t = split;
 #pragma unroll
-    for (int q = 0; q < D / 16; ++q) a[q] = an[q];
+  for (int i = 0; i < 3; ++i)
+    load_item_frags_bf16<D>(ring[i], P.packed, t + i * splits < n_tiles ? t + i * splits : (n_tiles - 1), lane);
+  while (t < n_tiles) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (t < n_tiles) {
+        uint4 cur[D / 16];
+#pragma unroll
+        for (int q = 0; q < D / 16; ++q) cur[q] = ring[i][q];
+        const int tp = t + 3 * splits;
+        load_item_frags_bf16<D>(ring[i], P.packed, tp < n_tiles ? tp : (n_tiles - 1), lane);
+        consume(cur, t);
+        t += splits;
+      }
+    }
   }
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
@@ -470,14 +574,12 @@ __device__ __forceinline__ void sort64_desc(uint64_t &e, int lane) {
 
 constexpr int kPfHistLds = 1024;
 
-template <int D>
-__global__ __launch_bounds__(64) void score_select_rescore_kernel(const PrefArgs P) {
-  constexpr int NRmax = 16;
-  __shared__ int incl_s[64];
-  __shared__ uint32_t keep_item[kPfMaxRescore];
-  __shared__ uint32_t hist_s[kPfHistLds];
+// NRmax = 8 keys per lane (512 per user) runs at 8 waves per SIMD; the rare user with more (a long history on top of
+// the candidates) is flagged 3 and picked up by a second launch with NRmax = 16 (`second` = only flagged users).
+template <int D, int NRmax>
+__device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int64_t u, int *incl_s, uint32_t *keep_item,
+                                                    uint32_t *hist_s) {
   const int lane = threadIdx.x;
-  const int64_t u = blockIdx.x;
   const int K = P.K;
   const int n_lists = 2 * P.splits;  // <= 64
 
@@ -498,9 +600,9 @@ __global__ __launch_bounds__(64) void score_select_rescore_kernel(const PrefArgs
     if (lane >= o) incl += v;
   }
   const int total = __shfl(incl, 63, 64);
-  // reason codes (nonzero = re-run on the fp32 route): 1 list overflow, 2 fewer than K candidates, 3 more than 1024,
+  // reason codes (nonzero = re-run on the fp32 route): 1 list overflow, 2 fewer than K candidates, 3 more than 64*NRmax,
   // 4 band reaches below the sweep threshold, 5 more than 128 items inside the band
-  // (the user's history is appended to the candidates below: both must fit the 1024 key slots / the LDS copy)
+  // (the user's history is appended to the candidates below: both must fit the 64*NRmax key slots / the LDS copy)
   int why = overflow ? 1 : (total + deg < K ? 2 : ((total + deg > 64 * NRmax || deg > kPfHistLds) ? 3 : 0));
   uint64_t e0 = 0ull, e1 = 0ull;
   if (why == 0) {
@@ -547,7 +649,7 @@ __global__ __launch_bounds__(64) void score_select_rescore_kernel(const PrefArgs
     if (valid < K) why = 2;
     else if (total2 <= 128) T = kth_largest_ord<2, NRmax, 20>(k, K);
     else if (total2 <= 256) T = kth_largest_ord<4, NRmax, 20>(k, K);
-    else if (total2 <= 512) T = kth_largest_ord<8, NRmax, 20>(k, K);
+    else if (total2 <= 512 || NRmax <= 8) T = kth_largest_ord<8, NRmax, 20>(k, K);
     else T = kth_largest_ord<NRmax, NRmax, 20>(k, K);
     const float a_k = ord_to_f32(T);
     const float cutoff = a_k - 2.0f * m;
@@ -588,11 +690,169 @@ __global__ __launch_bounds__(64) void score_select_rescore_kernel(const PrefArgs
       }
     }
   }
-  if (lane == 0) P.fail[u] = why;
+  if (lane == 0) {
+    P.fail[u] = why;
+    // more keys than this instantiation holds: queue the user for the wide one instead of the fp32 route
+    if (why == 3 && NRmax <= 8 && deg <= kPfHistLds) P.heavy_list[atomicAdd(P.heavy_cnt, 1)] = (int)u;
+    else if (why != 0) P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;   // not certifiable: exact per-user route
+  }
   if (why == 0 && lane < K) {
     const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
     P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;
     P.out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
+  }
+}
+
+// One wave per user, 512 key slots, 8 waves per SIMD.
+template <int D>
+__global__ __launch_bounds__(64, 8) void score_select_rescore_kernel(const PrefArgs P) {
+  __shared__ int incl_s[64];
+  __shared__ uint32_t keep_item[kPfMaxRescore];
+  __shared__ uint32_t hist_s[kPfHistLds];
+  select_rescore_user<D, 8>(P, (int64_t)blockIdx.x, incl_s, keep_item, hist_s);
+}
+
+// The users the narrow pass queued (a long history on top of the candidates): 1024 key slots, a fixed small grid
+// walking the device-side queue -- no host round trip, no launch of one idle wave per user.
+template <int D>
+__global__ __launch_bounds__(64, 4) void score_select_rescore_wide_kernel(const PrefArgs P) {
+  __shared__ int incl_s[64];
+  __shared__ uint32_t keep_item[kPfMaxRescore];
+  __shared__ uint32_t hist_s[kPfHistLds];
+  const int n = *P.heavy_cnt;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    select_rescore_user<D, 16>(P, (int64_t)P.heavy_list[i], incl_s, keep_item, hist_s);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- exact per-user route for the users the prefilter could not certify ------------------------------------------
+// One 256-thread block per queued user (fixed grid walking the device-side queue).  All n_items scores are computed
+// with the exact fp32 chain on the VALU (exact_score), in chunks of kExChunk items whose order-preserving keys stay
+// in the threads' registers; the K best 64-bit keys (score, lowest index first) of "chunk + best so far" are found
+// by a block-wide radix select (32 steps on the score word, 32 more on the index word only when a tie straddles
+// the K-th place) and kept as the running best; one wave sorts the final K.  Cost per user and block is
+// independent of how many users need it (a 32-user group of the fp32 MFMA sweep costs ~0.5 ms of latency).
+constexpr int kExChunk = 8192;
+constexpr int kExThreads = 256;
+constexpr int kExPer = kExChunk / kExThreads;   // chunk keys per thread, held in registers
+
+template <int D>
+__global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const PrefArgs P) {
+  __shared__ uint64_t best[kMaxK];           // running K best keys, 0 = empty
+  __shared__ uint32_t hist_s[kPfHistLds];
+  __shared__ int red[2][kExThreads / 64];
+  __shared__ int slot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = P.K;
+  const int n_fb = *P.fb_cnt;
+  int flip = 0;
+  // block-wide sum (two alternating LDS rows: one barrier per call)
+  auto block_sum = [&](int c) -> int {
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) red[flip][wave] = c;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < kExThreads / 64; ++w) tot += red[flip][w];
+    flip ^= 1;
+    return tot;
+  };
+  for (int qi = blockIdx.x; qi < n_fb; qi += gridDim.x) {
+    const int64_t u = P.fb_list[qi];
+    const float *urow = P.user_emb + (size_t)u * D;
+    int64_t hb = 0, he = 0;
+    if (P.hist_rowptr) {
+      hb = P.hist_rowptr[u];
+      he = P.hist_rowptr[u + 1];
+    }
+    const int deg = (int)(he - hb);
+    const bool hist_lds = deg <= kPfHistLds;
+    __syncthreads();
+    if (hist_lds)
+      for (int i = tid; i < deg; i += kExThreads) hist_s[i] = (uint32_t)P.hist_col[hb + i];
+    if (tid < kMaxK) best[tid] = 0ull;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < P.n_items; c0 += kExChunk) {
+      // this thread's keys of the chunk: items c0 + tid + 256 j; high word = ord(score), low word = ~item
+      uint32_t so[kExPer];
+#pragma unroll
+      for (int j = 0; j < kExPer; ++j) {
+        const int64_t it = c0 + tid + (int64_t)kExThreads * j;
+        so[j] = 0u;   // ord of any real score is > 0 (ord(-inf) = 0x007FFFFF); 0 marks "no item"
+        if (it < P.n_items) {
+          const uint32_t item = (uint32_t)it;
+          int lo = 0, hi = deg;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t hv = hist_lds ? hist_s[mid] : (uint32_t)P.hist_col[hb + mid];
+            if (hv < item) lo = mid + 1; else hi = mid;
+          }
+          const bool masked = lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
+          const float sv = masked ? P.mask_value : exact_score<D>(urow, P.item_emb + (size_t)item * D);
+          so[j] = f32_to_ord(sv);
+        }
+      }
+      const uint64_t bk = tid < kMaxK ? best[tid] : 0ull;   // one running-best key per thread of the first wave
+      const uint32_t bo = (uint32_t)(bk >> 32), bl = (uint32_t)bk;
+      int have = bk != 0ull ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < kExPer; ++j) have += so[j] != 0u ? 1 : 0;
+      have = block_sum(have);
+      const int want = min(K, have);
+      // stage 1: K-th largest score word
+      uint32_t T = 0;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = T | (1u << bit);
+        int c = (bk != 0ull && bo >= cand) ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < kExPer; ++j) c += so[j] >= cand ? 1 : 0;
+        if (block_sum(c) >= want) T = cand;
+      }
+      int gt = (bk != 0ull && bo > T) ? 1 : 0, eq = (bk != 0ull && bo == T) ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < kExPer; ++j) {
+        gt += so[j] > T ? 1 : 0;
+        eq += so[j] == T ? 1 : 0;
+      }
+      gt = block_sum(gt);
+      eq = block_sum(eq);
+      // stage 2 (only when more items tie at T than fit): the `need` lowest indices among the ties = the largest
+      // inverted-index words
+      const int need = want - gt;
+      uint32_t L = 0;
+      if (eq > need) {
+        for (int bit = 31; bit >= 0; --bit) {
+          const uint32_t cand = L | (1u << bit);
+          int c = (bk != 0ull && bo == T && bl >= cand) ? 1 : 0;
+#pragma unroll
+          for (int j = 0; j < kExPer; ++j)
+            c += (so[j] == T && (0xFFFFFFFFu - (uint32_t)(c0 + tid + (int64_t)kExThreads * j)) >= cand) ? 1 : 0;
+          if (block_sum(c) >= need) L = cand;
+        }
+      }
+      const uint64_t thr = ((uint64_t)T << 32) | (uint64_t)L;   // exactly `want` keys are >= thr
+      if (tid == 0) slot = 0;
+      __syncthreads();
+      if (tid < kMaxK) best[tid] = 0ull;
+      __syncthreads();
+      if (bk != 0ull && bk >= thr) best[atomicAdd(&slot, 1)] = bk;
+#pragma unroll
+      for (int j = 0; j < kExPer; ++j) {
+        const uint64_t key = ((uint64_t)so[j] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(c0 + tid + (int64_t)kExThreads * j));
+        if (so[j] != 0u && key >= thr) best[atomicAdd(&slot, 1)] = key;
+      }
+      __syncthreads();
+    }
+    if (wave == 0) {
+      uint64_t e = lane < kMaxK ? best[lane] : 0ull;
+      sort64_desc(e, lane);
+      if (lane < K) {
+        const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull);
+        P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;
+        P.out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e >> 32));
+      }
+    }
   }
 }
 
@@ -612,10 +872,6 @@ __global__ __launch_bounds__(256) void score_prefilter_stats_kernel(const int *_
     mx = max(mx, c);
   }
   if (fail[u]) {
-#ifdef CHAOREC_PF_DEBUG
-    const unsigned long long slot = atomicAdd(out + 9, 1ull);
-    if (slot < 16) { out[10 + 2 * slot] = (unsigned long long)u; out[11 + 2 * slot] = tot; }
-#endif
     atomicAdd(out + 0, 1ull);
     atomicAdd(out + 3 + min(fail[u], 5), 1ull);
   }

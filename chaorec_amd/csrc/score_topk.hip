@@ -788,12 +788,17 @@ struct ScorePlan {
   // bf16 prefilter path (score_prefilter.hpp)
   bool prefilter;
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
-  int fb_splits;            // item splits of the fp32 fallback behind the prefilter (few groups: many splits)
-  int64_t fb_tiles_per_split;
+  size_t off_pf_heavy, off_pf_fb;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_margin, off_pf_cand, off_pf_cnt;
   size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
 };
 
+#ifndef CHAOREC_PF_UB64
+#define CHAOREC_PF_UB64 2
+#endif
+#ifndef CHAOREC_PF_UB128
+#define CHAOREC_PF_UB128 2
+#endif
 // Wave slots of the sweep kernel on this device (waves per CU x CUs), queried once; without a device (the CPU-side
 // workspace query) the gfx950 defaults.
 static int sweep_wave_slots(int D) {
@@ -804,8 +809,8 @@ static int sweep_wave_slots(int D) {
   hipError_t e = hipGetDevice(&dev);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e == hipSuccess) {
-    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, 4>, 64, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, 2>, 64, 0);
+    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>, 64, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>, 64, 0);
   }
   if (e != hipSuccess || per_cu <= 0 || cus <= 0) {
     (void)hipGetLastError();
@@ -851,7 +856,7 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   }
   // bf16 prefilter + exact re-score: D in {64, 128}, enough tiles for the sampler's statistics
   p.prefilter = (D == 64 || D == 128) && K <= 64 && n_tiles >= 256;
-  p.pf_ub = D == 64 ? 4 : 2;
+  p.pf_ub = D == 64 ? CHAOREC_PF_UB64 : CHAOREC_PF_UB128;
   {
     const int64_t ublocks = (groups + p.pf_ub - 1) / p.pf_ub;
     // one full round of 2 waves per SIMD (2048 slots) when the user blocks allow it: a second, partly filled
@@ -862,21 +867,16 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
     if (sp < 1) sp = 1;
     p.pf_splits = (int)sp;
   }
-  {
-    int64_t fs = n_tiles / 24;
-    if (fs > 16) fs = 16;
-    if (fs < 1) fs = 1;
-    p.fb_tiles_per_split = (n_tiles + fs - 1) / fs;
-    p.fb_splits = (int)((n_tiles + p.fb_tiles_per_split - 1) / p.fb_tiles_per_split);
-  }
   p.pf_sample_stride = 4;
-  p.pf_sample_splits = 2;
-  p.pf_sample_rank = 20;
+  p.pf_sample_splits = 4;
+  p.pf_sample_rank = 10;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 32 * (size_t)D * 2 : 0);
   p.off_pf_scalars = take(p.prefilter ? 256 : 0);
   p.off_pf_tau = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_heavy = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_fb = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_margin = take(p.prefilter ? (size_t)n_users * 4 : 0);
   // (sized for the most splits any device plan uses, so that the CPU-side query and the device plan agree)
@@ -886,10 +886,7 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.off_tau = take(p.sample ? (size_t)n_users * 4 : 0);
   p.off_tau1 = take(p.sample ? (size_t)n_users * 4 : 0);
   p.off_fail = take((p.sample || p.prefilter) ? (size_t)n_users * 4 : 0);
-  {
-    const int ps = p.prefilter && p.fb_splits > p.splits ? p.fb_splits : p.splits;
-    p.off_partial = take(ps > 1 ? (size_t)ps * (size_t)n_users * (size_t)K * 8 : 0);
-  }
+  p.off_partial = take(p.splits > 1 ? (size_t)p.splits * (size_t)n_users * (size_t)K * 8 : 0);
   p.off_cand = take(p.sample ? (size_t)p.splits * (size_t)n_users * 2 * kCandCap * 8 : 0);
   p.off_cnt = take(p.sample ? (size_t)p.splits * (size_t)n_users * 2 * 4 : 0);
   p.total = o;
@@ -1006,6 +1003,10 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.K = K;
     P.id_offset = id_offset;
     P.imax2_bits = (uint32_t *)(ws + p.off_pf_scalars);
+    P.heavy_cnt = (int *)(ws + p.off_pf_scalars + 64);
+    P.heavy_list = (int *)(ws + p.off_pf_heavy);
+    P.fb_cnt = (int *)(ws + p.off_pf_scalars + 128);
+    P.fb_list = (int *)(ws + p.off_pf_fb);
     P.tau_sum = (float *)(ws + p.off_pf_tau);
     P.theta = (float *)(ws + p.off_pf_theta);
     P.margin = (float *)(ws + p.off_pf_margin);
@@ -1031,32 +1032,22 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     const dim3 gw((unsigned)((groups + p.pf_ub - 1) / p.pf_ub), (unsigned)p.pf_splits);
     if (D == 64) {
       hipLaunchKernelGGL(score_sample_bf16_kernel<64>, gs, dim3(64), 0, st, P);
-      hipLaunchKernelGGL((score_sweep_bf16_kernel<64, 4>), gw, dim3(64), 0, st, P);
+      hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_kernel<64>, dim3((unsigned)n_users), dim3(64), 0, st, P);
+      hipLaunchKernelGGL(score_select_rescore_wide_kernel<64>, dim3(512), dim3(64), 0, st, P);
     } else {
       hipLaunchKernelGGL(score_sample_bf16_kernel<128>, gs, dim3(64), 0, st, P);
-      hipLaunchKernelGGL((score_sweep_bf16_kernel<128, 2>), gw, dim3(64), 0, st, P);
+      hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_kernel<128>, dim3((unsigned)n_users), dim3(64), 0, st, P);
+      hipLaunchKernelGGL(score_select_rescore_wide_kernel<128>, dim3(512), dim3(64), 0, st, P);
     }
     rc = check_launch("score prefilter kernels");
     if (rc) return rc;
-    // uncertified users (list overflow, fewer than K above the threshold, band wider than the lists): exact fp32
-    // sweep of their groups over the item splits, unpacked item table, then the merge for those users only
-    ScoreArgs f = a;
-    f.mode = kModeFallback;
-    f.fail = failf;
-    f.splits = p.fb_splits;
-    f.tiles_per_split = p.fb_tiles_per_split;
-    f.partial = p.fb_splits > 1 ? (uint64_t *)(ws + p.off_partial) : nullptr;
-    rc = dispatch_score(D, f, dim3(groups, (unsigned)p.fb_splits), st);
-    if (rc) return rc;
-    if (p.fb_splits > 1) {
-      hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, f.partial, n_users, K,
-                         p.fb_splits, id_offset, out_idx, out_val, (const float *)nullptr, (int *)nullptr,
-                         (const int *)failf);
-      rc = check_launch("score_topk_merge_kernel");
-    }
-    return rc;
+    // uncertified users (list overflow, fewer than K above the threshold, band wider than the re-score slots) were
+    // queued on the device: exact fp32 scores of all items for each of them, one block per user
+    if (D == 64) hipLaunchKernelGGL(score_exact_user_kernel<64>, dim3(1024), dim3(kExThreads), 0, st, P);
+    else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(1024), dim3(kExThreads), 0, st, P);
+    return check_launch("score_exact_user_kernel");
   }
   if (p.pack) {
     float4 *packed = (float4 *)(ws + p.off_packed);
