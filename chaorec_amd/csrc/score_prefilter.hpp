@@ -80,6 +80,8 @@ struct PrefArgs {
   int *heavy_list;              // [U]
   int *fb_cnt;                  // users queued for the exact per-user route
   int *fb_list;                 // [U]
+  int *fb_done;                 // [U] slices finished per queued user (zeroed per call)
+  uint64_t *fb_partial;         // [U][kExSlices][kMaxK] per-slice best keys
 };
 
 // ---- pack ----------------------------------------------------------------------------------------------------
@@ -727,38 +729,92 @@ __global__ __launch_bounds__(64, 4) void score_select_rescore_wide_kernel(const 
 }
 
 // ---- exact per-user route for the users the prefilter could not certify ------------------------------------------
-// One 256-thread block per queued user (fixed grid walking the device-side queue).  All n_items scores are computed
-// with the exact fp32 chain on the VALU (exact_score), in chunks of kExChunk items whose order-preserving keys stay
-// in the threads' registers; the K best 64-bit keys (score, lowest index first) of "chunk + best so far" are found
-// by a block-wide radix select (32 steps on the score word, 32 more on the index word only when a tie straddles
-// the K-th place) and kept as the running best; one wave sorts the final K.  Cost per user and block is
-// independent of how many users need it (a 32-user group of the fp32 MFMA sweep costs ~0.5 ms of latency).
-constexpr int kExChunk = 8192;
-constexpr int kExThreads = 256;
-constexpr int kExPer = kExChunk / kExThreads;   // chunk keys per thread, held in registers
+// kExSlices 1024-thread blocks per queued user (fixed grid walking the device-side queue), each taking a contiguous
+// slice of the items.  All scores are computed with the exact fp32 chain on the VALU (exact_score); every wave keeps
+// its own K best 64-bit keys (score, lowest index first) in registers, updated per round by a barrier-free
+// ballot/popcount radix select; wave 0 merges the block's 16 lists, the last slice to finish merges the slices'
+// lists and sorts the final K.  Cost is per user, independent of how many users need it (a 32-user group of the
+// fp32 MFMA sweep costs ~0.5 ms of latency).
+constexpr int kExThreads = 1024;
+constexpr int kExPer = 2;                         // keys per lane and round
+constexpr int kExSlices = 8;                      // blocks per user: one CU's vector-memory path cannot stream the
+                                                  // item table (a thread per row = 64 cache lines per load) fast enough
+
+// The K largest of one wave's keys (NK per lane, 0 = none) plus its running best `bk` (one key per lane): radix
+// select with ballots and scalar popcounts -- 32 steps on the score word, 32 more on the index word only when a tie
+// straddles the K-th place -- no barriers.  Returns the lane's new running-best key (unordered over the lanes, 0 =
+// empty).  Keys are unique, so exactly min(K, #keys) keys are >= the threshold found.  `stage` = 64 LDS slots of
+// this wave.
+template <int NK>
+__device__ __forceinline__ uint64_t wave_select_topk(const uint64_t (&key)[NK], uint64_t bk, int K, uint64_t *stage) {
+  const int lane = threadIdx.x & 63;
+  int have = __popcll(__ballot(bk != 0ull));
+#pragma unroll
+  for (int j = 0; j < NK; ++j) have += __popcll(__ballot(key[j] != 0ull));
+  const int want = min(K, have);
+  uint32_t T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = T | (1u << bit);
+    int c = __popcll(__ballot(bk != 0ull && (uint32_t)(bk >> 32) >= cand));
+#pragma unroll
+    for (int j = 0; j < NK; ++j) c += __popcll(__ballot(key[j] != 0ull && (uint32_t)(key[j] >> 32) >= cand));
+    if (c >= want) T = cand;
+  }
+  int gt = __popcll(__ballot(bk != 0ull && (uint32_t)(bk >> 32) > T));
+  int eq = __popcll(__ballot(bk != 0ull && (uint32_t)(bk >> 32) == T));
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    gt += __popcll(__ballot(key[j] != 0ull && (uint32_t)(key[j] >> 32) > T));
+    eq += __popcll(__ballot(key[j] != 0ull && (uint32_t)(key[j] >> 32) == T));
+  }
+  const int need = want - gt;
+  uint32_t L = 0;
+  if (eq > need) {   // the `need` lowest indices among the ties = the largest inverted-index words
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t cand = L | (1u << bit);
+      int c = __popcll(__ballot(bk != 0ull && (uint32_t)(bk >> 32) == T && (uint32_t)bk >= cand));
+#pragma unroll
+      for (int j = 0; j < NK; ++j)
+        c += __popcll(__ballot(key[j] != 0ull && (uint32_t)(key[j] >> 32) == T && (uint32_t)key[j] >= cand));
+      if (c >= need) L = cand;
+    }
+  }
+  const uint64_t thr = ((uint64_t)T << 32) | (uint64_t)L;
+  // compact the winners into the wave's stage, lane i takes slot i
+  stage[lane] = 0ull;
+  __builtin_amdgcn_wave_barrier();
+  int base = 0;
+  {
+    const bool w = bk != 0ull && bk >= thr;
+    const unsigned long long m = __ballot(w);
+    if (w) stage[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = bk;
+    base = __popcll(m);
+  }
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const bool w = key[j] != 0ull && key[j] >= thr;
+    const unsigned long long m = __ballot(w);
+    if (w) stage[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = key[j];
+    base += __popcll(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint64_t out = stage[lane];
+  __builtin_amdgcn_wave_barrier();
+  return out;
+}
 
 template <int D>
 __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const PrefArgs P) {
-  __shared__ uint64_t best[kMaxK];           // running K best keys, 0 = empty
+  constexpr int NW = kExThreads / 64;
+  __shared__ uint64_t stage[NW][64];         // per-wave staging / the waves' lists for the block merge
   __shared__ uint32_t hist_s[kPfHistLds];
-  __shared__ int red[2][kExThreads / 64];
-  __shared__ int slot;
+  __shared__ int last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = P.K;
   const int n_fb = *P.fb_cnt;
-  int flip = 0;
-  // block-wide sum (two alternating LDS rows: one barrier per call)
-  auto block_sum = [&](int c) -> int {
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if (lane == 0) red[flip][wave] = c;
-    __syncthreads();
-    int tot = 0;
-#pragma unroll
-    for (int w = 0; w < kExThreads / 64; ++w) tot += red[flip][w];
-    flip ^= 1;
-    return tot;
-  };
-  for (int qi = blockIdx.x; qi < n_fb; qi += gridDim.x) {
+  const int64_t per_slice = (P.n_items + kExSlices - 1) / kExSlices;
+  for (int w = blockIdx.x; w < n_fb * kExSlices; w += gridDim.x) {
+    const int qi = w / kExSlices, slice = w % kExSlices;
     const int64_t u = P.fb_list[qi];
     const float *urow = P.user_emb + (size_t)u * D;
     int64_t hb = 0, he = 0;
@@ -771,16 +827,17 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
     __syncthreads();
     if (hist_lds)
       for (int i = tid; i < deg; i += kExThreads) hist_s[i] = (uint32_t)P.hist_col[hb + i];
-    if (tid < kMaxK) best[tid] = 0ull;
     __syncthreads();
-    for (int64_t c0 = 0; c0 < P.n_items; c0 += kExChunk) {
-      // this thread's keys of the chunk: items c0 + tid + 256 j; high word = ord(score), low word = ~item
-      uint32_t so[kExPer];
+    // this block's contiguous slice of the items, kExThreads * kExPer per round; every wave keeps its own K best
+    const int64_t i_begin = (int64_t)slice * per_slice, i_end = min(P.n_items, i_begin + per_slice);
+    uint64_t bk = 0ull;
+    for (int64_t c0 = i_begin; c0 < i_end; c0 += (int64_t)kExThreads * kExPer) {
+      uint64_t key[kExPer];
 #pragma unroll
       for (int j = 0; j < kExPer; ++j) {
         const int64_t it = c0 + tid + (int64_t)kExThreads * j;
-        so[j] = 0u;   // ord of any real score is > 0 (ord(-inf) = 0x007FFFFF); 0 marks "no item"
-        if (it < P.n_items) {
+        key[j] = 0ull;
+        if (it < i_end) {
           const uint32_t item = (uint32_t)it;
           int lo = 0, hi = deg;
           while (lo < hi) {
@@ -790,62 +847,32 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
           }
           const bool masked = lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
           const float sv = masked ? P.mask_value : exact_score<D>(urow, P.item_emb + (size_t)item * D);
-          so[j] = f32_to_ord(sv);
+          key[j] = make_key(sv, item);
         }
       }
-      const uint64_t bk = tid < kMaxK ? best[tid] : 0ull;   // one running-best key per thread of the first wave
-      const uint32_t bo = (uint32_t)(bk >> 32), bl = (uint32_t)bk;
-      int have = bk != 0ull ? 1 : 0;
-#pragma unroll
-      for (int j = 0; j < kExPer; ++j) have += so[j] != 0u ? 1 : 0;
-      have = block_sum(have);
-      const int want = min(K, have);
-      // stage 1: K-th largest score word
-      uint32_t T = 0;
-      for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = T | (1u << bit);
-        int c = (bk != 0ull && bo >= cand) ? 1 : 0;
-#pragma unroll
-        for (int j = 0; j < kExPer; ++j) c += so[j] >= cand ? 1 : 0;
-        if (block_sum(c) >= want) T = cand;
-      }
-      int gt = (bk != 0ull && bo > T) ? 1 : 0, eq = (bk != 0ull && bo == T) ? 1 : 0;
-#pragma unroll
-      for (int j = 0; j < kExPer; ++j) {
-        gt += so[j] > T ? 1 : 0;
-        eq += so[j] == T ? 1 : 0;
-      }
-      gt = block_sum(gt);
-      eq = block_sum(eq);
-      // stage 2 (only when more items tie at T than fit): the `need` lowest indices among the ties = the largest
-      // inverted-index words
-      const int need = want - gt;
-      uint32_t L = 0;
-      if (eq > need) {
-        for (int bit = 31; bit >= 0; --bit) {
-          const uint32_t cand = L | (1u << bit);
-          int c = (bk != 0ull && bo == T && bl >= cand) ? 1 : 0;
-#pragma unroll
-          for (int j = 0; j < kExPer; ++j)
-            c += (so[j] == T && (0xFFFFFFFFu - (uint32_t)(c0 + tid + (int64_t)kExThreads * j)) >= cand) ? 1 : 0;
-          if (block_sum(c) >= need) L = cand;
-        }
-      }
-      const uint64_t thr = ((uint64_t)T << 32) | (uint64_t)L;   // exactly `want` keys are >= thr
-      if (tid == 0) slot = 0;
-      __syncthreads();
-      if (tid < kMaxK) best[tid] = 0ull;
-      __syncthreads();
-      if (bk != 0ull && bk >= thr) best[atomicAdd(&slot, 1)] = bk;
-#pragma unroll
-      for (int j = 0; j < kExPer; ++j) {
-        const uint64_t key = ((uint64_t)so[j] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(c0 + tid + (int64_t)kExThreads * j));
-        if (so[j] != 0u && key >= thr) best[atomicAdd(&slot, 1)] = key;
-      }
-      __syncthreads();
+      bk = wave_select_topk<kExPer>(key, bk, K, stage[wave]);
     }
+    // block merge: the NW wave lists -> wave 0 (NW keys per lane)
+    stage[wave][lane] = bk;
+    __syncthreads();
+    uint64_t *part = P.fb_partial + (size_t)qi * kExSlices * kMaxK;
     if (wave == 0) {
-      uint64_t e = lane < kMaxK ? best[lane] : 0ull;
+      uint64_t mk[NW];
+#pragma unroll
+      for (int j = 0; j < NW; ++j) mk[j] = stage[j][lane];
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t bb = wave_select_topk<NW>(mk, 0ull, K, stage[0]);
+      part[slice * kMaxK + lane] = bb;   // kMaxK == 64
+      __threadfence();
+      if (lane == 0) last = atomicAdd(P.fb_done + qi, 1) == kExSlices - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (last && wave == 0) {   // the last slice to arrive merges the user's kExSlices lists
+      __threadfence();
+      uint64_t mk[kExSlices];
+#pragma unroll
+      for (int j = 0; j < kExSlices; ++j) mk[j] = __builtin_nontemporal_load(part + j * kMaxK + lane);
+      uint64_t e = wave_select_topk<kExSlices>(mk, 0ull, K, stage[0]);
       sort64_desc(e, lane);
       if (lane < K) {
         const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull);

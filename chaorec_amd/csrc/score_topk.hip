@@ -788,7 +788,7 @@ struct ScorePlan {
   // bf16 prefilter path (score_prefilter.hpp)
   bool prefilter;
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
-  size_t off_pf_heavy, off_pf_fb;
+  size_t off_pf_heavy, off_pf_fb, off_pf_fbdone, off_pf_fbpart;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_margin, off_pf_cand, off_pf_cnt;
   size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
 };
@@ -877,6 +877,8 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.off_pf_tau = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_heavy = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fb = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_fbdone = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_fbpart = take(p.prefilter ? (size_t)n_users * kExSlices * kMaxK * 8 : 0);
   p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_margin = take(p.prefilter ? (size_t)n_users * 4 : 0);
   // (sized for the most splits any device plan uses, so that the CPU-side query and the device plan agree)
@@ -1007,6 +1009,9 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.heavy_list = (int *)(ws + p.off_pf_heavy);
     P.fb_cnt = (int *)(ws + p.off_pf_scalars + 128);
     P.fb_list = (int *)(ws + p.off_pf_fb);
+    P.fb_done = (int *)(ws + p.off_pf_fbdone);
+    P.fb_partial = (uint64_t *)(ws + p.off_pf_fbpart);
+    if (hipMemsetAsync(P.fb_done, 0, (size_t)n_users * 4, st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
     P.tau_sum = (float *)(ws + p.off_pf_tau);
     P.theta = (float *)(ws + p.off_pf_theta);
     P.margin = (float *)(ws + p.off_pf_margin);
@@ -1045,8 +1050,8 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     if (rc) return rc;
     // uncertified users (list overflow, fewer than K above the threshold, band wider than the re-score slots) were
     // queued on the device: exact fp32 scores of all items for each of them, one block per user
-    if (D == 64) hipLaunchKernelGGL(score_exact_user_kernel<64>, dim3(1024), dim3(kExThreads), 0, st, P);
-    else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(1024), dim3(kExThreads), 0, st, P);
+    if (D == 64) hipLaunchKernelGGL(score_exact_user_kernel<64>, dim3(512), dim3(kExThreads), 0, st, P);
+    else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(512), dim3(kExThreads), 0, st, P);
     return check_launch("score_exact_user_kernel");
   }
   if (p.pack) {
