@@ -189,8 +189,8 @@ class FREEDOM(nn.Module):
                                      ops.VARIANT_LOGSIGMOID, 0.0)[0]
         return batch_mf_loss + self.reg_weight * (mf_t_loss + mf_v_loss)
 
-    def gene_ranklist(self, topk=50):
+    def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/FREEDOM.py:219-244 (mask value 1e-6, stale self.result)."""
-        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk)
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu)
 
     full_sort_predict = gene_ranklist

@@ -11,7 +11,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libchaorec_hip.so")
-SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip"]
+SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip", "metrics.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
@@ -47,6 +47,9 @@ SIGNATURES = {
                                               c_ptr, c_ptr, c_ptr, ctypes.c_size_t, ctypes.c_int32, c_ptr]),
     "chaorec_score_topk_stats": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                 c_ptr, c_ptr]),
+    "chaorec_rank_metrics_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32]),
+    "chaorec_rank_metrics_f64": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int64, c_ptr, c_ptr, c_ptr, ctypes.c_int64,
+                                                c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
     "chaorec_gemm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "chaorec_gemm_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,

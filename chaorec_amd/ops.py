@@ -242,6 +242,28 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     return idx, val
 
 
+def rank_metrics(rank_idx, row_user, pos_rowptr, pos_items, k_list):
+    """[len(k_list), 5] fp64 on the device: precision, recall, ndcg, hit_rate, map averaged over the evaluation rows
+    (chaorec_rank_metrics_f64).  rank_idx [U, K] int64 device; the rows' positives as a device CSR."""
+    import ctypes
+    import numpy as np
+    _need_cuda(rank_idx, row_user, pos_rowptr, pos_items)
+    if rank_idx.dtype != torch.int64 or not rank_idx.is_contiguous():
+        raise TypeError("rank_metrics: rank_idx must be a contiguous int64 tensor")
+    k = np.asarray([int(x) for x in k_list], dtype=np.int32)
+    disc = 1.0 / np.log(np.arange(int(k.max())) + 2.0)          # the reference's own discount table (metrics.py:31,34)
+    n_rows = int(row_user.shape[0])
+    lib = _lib.load()
+    nbytes = lib.chaorec_rank_metrics_workspace_bytes(n_rows, len(k))
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=rank_idx.device)
+    out = torch.empty((len(k), 5), dtype=torch.float64, device=rank_idx.device)
+    rc = lib.chaorec_rank_metrics_f64(_ptr(rank_idx), rank_idx.shape[0], rank_idx.shape[1], _ptr(row_user), _ptr(pos_rowptr),
+                                      _ptr(pos_items), n_rows, k.ctypes.data_as(ctypes.c_void_p), len(k),
+                                      disc.ctypes.data_as(ctypes.c_void_p), _ptr(out), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "chaorec_rank_metrics_f64")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # dense layers
 # --------------------------------------------------------------------------------------------

@@ -15,10 +15,11 @@ def history_csr(user_item_dict, num_user, device):
     return rowptr.to(device), col.to(device)
 
 
-def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50):
-    """result [N, D] (users first) on the GPU -> LongTensor [num_user, topk] of GLOBAL item ids on the CPU."""
+def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to_cpu=True):
+    """result [N, D] (users first) on the GPU -> LongTensor [num_user, topk] of GLOBAL item ids on the CPU (the
+    reference's contract); to_cpu=False keeps it in HBM for utils.gene_metrics_device."""
     with torch.no_grad():
         result = result.detach()
         idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                 id_offset=num_user)
-    return idx.cpu()
+    return idx.cpu() if to_cpu else idx

@@ -8,7 +8,7 @@ import logging
 
 import torch
 
-from .utils import EarlyStopping, gene_metrics
+from .utils import EarlyStopping, EvalLists, gene_metrics, gene_metrics_device
 
 MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM",)
@@ -32,8 +32,12 @@ def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):
 
 
 def evaluate(model, data, ranklist, topk):
+    """train_and_evaluate.py:655-659.  `data` may be an EvalLists and `ranklist` a device tensor: the metrics are then
+    computed in HBM (chaorec_rank_metrics_f64), otherwise by the host restatement."""
     model.eval()
     with torch.no_grad():
+        if isinstance(data, EvalLists):
+            return gene_metrics_device(data, ranklist, topk)
         return gene_metrics(data, ranklist, topk)
 
 
@@ -48,6 +52,10 @@ def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epoc
     model.train()
     early_stopping = EarlyStopping(patience=patience, verbose=True)
     topk = [int(k) for k in topk]
+    # evaluation stays on the device when the model can hand the rank list over in HBM
+    on_device = getattr(model, "device", None) is not None and torch.device(model.device).type == "cuda" and max(topk) <= 64
+    if on_device:
+        val_data, test_data = EvalLists(val_data, model.device), EvalLists(test_data, model.device)
     for epoch in range(epochs):
         if model_name in PRE_EPOCH:
             model.pre_epoch_processing()
@@ -55,7 +63,7 @@ def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epoc
         logging.info("Epoch {}, Loss: {:.5f}".format(epoch + 1, loss))
 
         model.eval()
-        rank_list = model.gene_ranklist()
+        rank_list = model.gene_ranklist(to_cpu=False) if on_device else model.gene_ranklist()
         val_metrics = evaluate(model, val_data, rank_list, topk)
         test_metrics = evaluate(model, test_data, rank_list, topk)
         _log_metrics('Validation Metrics:', val_metrics)

@@ -95,3 +95,30 @@ def gene_metrics(val_data, rank_list, k_list):
         ap = (hit[:, :k] * cum / np.arange(1, k + 1)).sum(1)
         out[k]["map"] = float(np.where(has, ap / safe_len, 0.0).sum() / n)
     return out
+
+
+class EvalLists:
+    """val.npy / test.npy rows ([user, pos...]) as a device CSR, built once per split (the lists never change)."""
+
+    def __init__(self, data, device):
+        n = len(data)
+        users = np.fromiter((int(d[0]) for d in data), dtype=np.int64, count=n)
+        lens = np.fromiter((len(d) - 1 for d in data), dtype=np.int64, count=n)
+        items = np.fromiter((int(x) for d in data for x in d[1:]), dtype=np.int64, count=int(lens.sum()))
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        self.n = n
+        self.row_user = torch.from_numpy(users).to(device)
+        self.rowptr = torch.from_numpy(rowptr).to(device)
+        self.items = torch.from_numpy(items if len(items) else np.zeros(1, np.int64)).to(device)
+
+
+_NAMES = ("precision", "recall", "ndcg", "hit_rate", "map")
+
+
+def gene_metrics_device(eval_lists, rank_idx, k_list):
+    """utils.gene_metrics (utils.py:112-139) on the GPU: rank_idx [U, >=max(k)] int64 in HBM (gene_ranklist(to_cpu=False)),
+    eval_lists an EvalLists.  One launch + a 3x5 fp64 read-back instead of the [U, 50] transfer and the host loop."""
+    from . import ops
+    k_list = [int(k) for k in k_list]
+    out = ops.rank_metrics(rank_idx, eval_lists.row_user, eval_lists.rowptr, eval_lists.items, k_list).cpu().numpy()
+    return {k: {name: float(out[i, j]) for j, name in enumerate(_NAMES)} for i, k in enumerate(k_list)}

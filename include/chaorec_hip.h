@@ -194,6 +194,29 @@ int chaorec_score_topk_stats(const void *workspace, int64_t n_users, int64_t n_i
                              uint64_t *out9, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * M: ranking metrics of every evaluation row in one launch.
+ *
+ * Replaces: utils.gene_metrics' python loop over users x K x {precision, recall, ndcg, hit_rate, map}
+ *           (utils.py:112-139) with the per-user formulas of metrics.py:13-57 and their corner cases: set()
+ *           semantics for precision / recall / hit_rate, `item in test_list` per position for ndcg / map,
+ *           len(test_list) (duplicates included) as denominator, 0 for an empty list, natural-log discounts.
+ *
+ *   rank_idx   [n_users, rank_stride] int64 global item ids, best first (chaorec_score_topk_f32's out_idx)
+ *   row_user   [n_rows] user of each evaluation row; pos_rowptr/pos_items: the rows' positives as a CSR
+ *              (val.npy / test.npy rows [user, pos...]), global item ids, duplicates allowed
+ *   k_list     HOST array of n_k <= 8 cut-offs, each <= min(64, rank_stride)
+ *   discount   HOST array, discount[p] = 1 / log(p + 2) for p < max(k) as the caller's libm gives it (the
+ *              per-user terms are then bit-identical to a host evaluation with the same table)
+ *   out        DEVICE [n_k][5] fp64: precision, recall, ndcg, hit_rate, map, each averaged over n_rows
+ * fp64 throughout; the sums over rows are reduced in a fixed order (run-to-run identical).
+ * ------------------------------------------------------------------------------------- */
+size_t chaorec_rank_metrics_workspace_bytes(int64_t n_rows, int32_t n_k);
+int chaorec_rank_metrics_f64(const int64_t *rank_idx, int64_t n_users, int64_t rank_stride,
+                             const int64_t *row_user, const int64_t *pos_rowptr, const int64_t *pos_items,
+                             int64_t n_rows, const int32_t *k_list, int32_t n_k, const double *discount,
+                             double *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Dense fp32 GEMM on the f32 MFMA pipe (exact fp32 products, fp32 accumulate):
  *   C[M,N] = op(A) * op(B) (+ bias[N]) (+ C if accumulate)
  * transA/transB: 0 = as stored [M,K]/[K,N], 1 = stored transposed [K,M]/[N,K].

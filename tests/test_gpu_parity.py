@@ -502,6 +502,59 @@ def test_adam_matches_oracle_and_torch(dev, oracle):
     assert np.allclose(p_t.cpu().numpy(), p_ref.detach().numpy(), rtol=0, atol=5e-7)
 
 
+# ------------------------------------------------------------------------------------------ ranking metrics
+def test_rank_metrics_device_vs_reference_golden_and_oracle(dev, oracle, baby):
+    """chaorec_rank_metrics_f64 against the reference's own numbers (real baby val/test lists, fixed rank list) and
+    against the per-user python restatement on lists with every corner case: empty rows, duplicate positives,
+    duplicate ranked ids, rows in arbitrary user order, k up to 64."""
+    from chaorec_amd import utils
+    from conftest import load_golden
+    g = load_golden("metrics_baby_fixed_rank.npz")
+    k_list = [int(k) for k in g["k_list"]]
+    fixed_rank = np.stack([np.random.default_rng(1000 + u).permutation(baby["I"])[:50] + baby["U"]
+                           for u in range(baby["U"])]).astype(np.int64)     # the rank list the golden was made with
+    rank = torch.from_numpy(fixed_rank).to(dev)
+    m = utils.gene_metrics_device(utils.EvalLists(baby["val"], dev), rank, k_list)
+    got = np.array([[m[k][n] for n in g["metric_names"]] for k in k_list])
+    assert np.allclose(got, g["val_metrics"], rtol=1e-12, atol=0)          # the reference's own numbers
+    rng = np.random.default_rng(3)
+    U, I, K = 300, 400, 64
+    rank_np = np.stack([rng.permutation(I)[:K] for _ in range(U)]).astype(np.int64) + U
+    rank_np[5, 3] = rank_np[5, 1]                       # duplicate id inside a ranked list
+    rank_np[6, :4] = rank_np[6, 0]
+    data = []
+    for u in rng.permutation(U)[:250]:
+        n = int(rng.integers(0, 6))
+        pos = list((rng.integers(0, I, n) + U).tolist())
+        if n and rng.random() < 0.3:
+            pos.append(pos[0])                          # duplicate positive
+        if rng.random() < 0.5 and n:
+            pos[0] = int(rank_np[u, rng.integers(0, 10)])   # make hits likely
+        data.append([int(u)] + pos)
+    data.append([5, int(rank_np[5, 1])])
+    data.append([6, int(rank_np[6, 0]), int(rank_np[6, 9])])
+    ks = [1, 5, 10, 20, 50, 64]
+    ref = oracle.gene_metrics(data, rank_np, ks)
+    got = utils.gene_metrics_device(utils.EvalLists(data, dev), torch.from_numpy(rank_np).to(dev), ks)
+    again = utils.gene_metrics_device(utils.EvalLists(data, dev), torch.from_numpy(rank_np).to(dev), ks)
+    for k in ks:
+        for n in ref[k]:
+            assert got[k][n] == pytest.approx(ref[k][n], rel=1e-12, abs=1e-15), (k, n)
+            assert got[k][n] == again[k][n]             # fixed-order reduction
+
+
+def test_rank_metrics_errors(dev):
+    from chaorec_amd import ops
+    rank = torch.zeros((4, 10), dtype=torch.int64, device=dev)
+    ru = torch.zeros(2, dtype=torch.int64, device=dev)
+    rp = torch.tensor([0, 1, 1], dtype=torch.int64, device=dev)
+    it = torch.zeros(1, dtype=torch.int64, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.rank_metrics(rank, ru, rp, it, [20])         # k beyond the rank list
+    with pytest.raises(RuntimeError):
+        ops.rank_metrics(rank, ru, rp, it, list(range(1, 10)))   # more than 8 cut-offs
+
+
 # ------------------------------------------------------------------------------------------ full-size properties
 def test_sports_size_properties(dev):
     """BASELINE configs[1] sizes (U=28940, I=15207, E=158554, D=64): size-independent checks."""
