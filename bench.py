@@ -187,6 +187,23 @@ def main():
                   file=sys.stderr)
             graphed = None
         if sharded is not None:
+            if graphed is not None:
+                # first replays of a graph holding RCCL kernels, under a watchdog: a launch mode that cannot make
+                # progress must end the job with a message, not sit on the GPUs until an outer timeout
+                import threading
+                done = threading.Event()
+
+                def watchdog():
+                    if not done.wait(float(os.environ.get("CHAOREC_GRAPH_WATCHDOG_S", "180"))):
+                        print(f"[bench rank {rank}] captured sharded step did not complete; rerun with "
+                              f"CHAOREC_DIST_GRAPH=0", file=sys.stderr, flush=True)
+                        os._exit(17)
+
+                threading.Thread(target=watchdog, daemon=True).start()
+                for _ in range(2):
+                    graphed()
+                torch.cuda.synchronize()
+                done.set()
             torch.cuda.synchronize()
             ok = torch.tensor([1.0 if graphed is not None else 0.0], device=dev)
             torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
