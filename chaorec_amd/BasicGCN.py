@@ -44,6 +44,8 @@ class BasicGCN(torch.nn.Module):
 
     def forward(self, x, edge_index):
         x = x.unsqueeze(-1) if x.dim() == 1 else x
+        if hasattr(edge_index, "propagate"):      # a graph operator (chaorec_amd.dist.ShardedGraph): rows are sharded
+            return edge_index.propagate(ops.linear(x, self.lin.weight, self.lin.bias))
         csr = _as_csr(edge_index, x.size(0), lambda ei, n: _sym_norm_csr(ei, n, True), self._cache)
         x = ops.linear(x, self.lin.weight, self.lin.bias)
         return ops.spmm(csr, x)

@@ -133,3 +133,116 @@ def test_partition_users_by_nnz():
     assert b[0] == 0 and b[-1] == 1000 and all(b[i] <= b[i + 1] for i in range(4))
     deg = np.full(800, 5)
     assert partition_users_by_nnz(deg, 8) == [100 * k for k in range(9)]
+
+
+# ---------------------------------------------------------------------------------------------------- MMGCN
+def _cpu_standins():
+    """CPU stand-ins with the ops.* contracts (the product has no CPU kernels): plain torch / the oracle."""
+    import torch.nn.functional as F
+    from chaorec_amd import ops
+
+    def linear(x, w, b=None, act=0):
+        y = F.linear(x, w, b)
+        return F.leaky_relu(y) if act == 1 else y
+
+    class _Spmm(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, csr):
+            ctx.csr = csr
+            return _oracle_spmm(csr, x)
+
+        @staticmethod
+        def backward(ctx, g):
+            return _oracle_spmm(ctx.csr.t(), g.contiguous()), None
+
+    def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset=0):
+        assert tab_i is None and variant == ops.VARIANT_LOG_SIGMOID and reg_weight == 0.0
+        s = (tab_u[users] * tab_u[pos]).sum(1) - (tab_u[users] * tab_u[neg]).sum(1)
+        return (-torch.mean(torch.log(torch.sigmoid(s))),)
+
+    ops.linear = linear
+    ops.spmm = lambda csr, x: _Spmm.apply(x, csr)
+    ops.spmm_raw = _oracle_spmm
+    ops.bpr_loss = bpr_loss
+
+
+def _mmgcn_problem():
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E = 300, 120, 1500
+    edges = synthetic_interactions(U, I, E, seed=8)
+    g = torch.Generator().manual_seed(1)
+    return U, I, edges, torch.randn(I, 32, generator=g), torch.randn(I, 24, generator=g)
+
+
+def _mmgcn_full(U, I, edges, v_feat, t_feat):
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MMGCN
+    torch.manual_seed(77)
+    return MMGCN(U, I, edges, graph.user_item_dict_from_edges(edges), v_feat, t_feat, 16, 1e-4, "add", "False", True,
+                 torch.device("cpu"))
+
+
+def _mmgcn_batch(shard_edges, n_local, I, rank, B=48):
+    rng = np.random.default_rng(200 + rank)
+    sel = rng.choice(len(shard_edges), B, replace=False)
+    u = torch.from_numpy(shard_edges[sel, 0].astype(np.int64))
+    pos = torch.from_numpy(shard_edges[sel, 1].astype(np.int64))
+    neg = torch.from_numpy(rng.integers(n_local, n_local + I, B))
+    return torch.stack((u, u), 1), torch.stack((pos, neg), 1)
+
+
+def _mmgcn_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    _cpu_standins()
+    from chaorec_amd import dist as cdist
+    U, I, edges, v_feat, t_feat = _mmgcn_problem()
+    full = _mmgcn_full(U, I, edges, v_feat, t_feat)
+    shard = cdist.UserShard(edges, U, I, world, rank, torch.device("cpu"), self_loops=True)
+    m = cdist.ShardedMMGCN(full, shard, torch.device("cpu"))
+    ut, it = _mmgcn_batch(shard.local_edges, shard.num_user_local, I, rank)
+    loss = m.loss(ut, it)
+    loss.backward()
+    m.sync_grads()
+    np.savez(os.path.join(tmp, f"mm{rank}.npz"), u0=shard.u0, u1=shard.u1, loss=float(loss), ut=ut.numpy(), it=it.numpy(),
+             res=m.result.detach().numpy(), **{"g_" + n: p.grad.numpy() for n, p in m.named_parameters()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mmgcn_matches_single_process():
+    """BASELINE configs[3]: MMGCN sharded by user rows (2 gloo ranks, CPU stand-ins for the kernels) reproduces the
+    single-process model: representations, loss, and the summed gradients of every Linear."""
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_mmgcn_worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(tmp, f"mm{k}.npz"))) for k in range(world)]
+    from chaorec_amd import ops
+    saved = (ops.linear, ops.spmm, ops.spmm_raw, ops.bpr_loss)
+    try:
+        _cpu_standins()
+        U, I, edges, v_feat, t_feat = _mmgcn_problem()
+        full = _mmgcn_full(U, I, edges, v_feat, t_feat)
+        # the ranks' batches in global ids: users + u0, items - U_g + U
+        uts, its = [], []
+        for k in range(world):
+            n_local = int(r[k]["u1"] - r[k]["u0"])
+            uts.append(torch.from_numpy(r[k]["ut"] + int(r[k]["u0"])))
+            its.append(torch.from_numpy(r[k]["it"] - n_local + U))
+        loss = full.loss(torch.cat(uts), torch.cat(its))
+        loss.backward()
+        assert sum(float(x["loss"]) for x in r) == pytest.approx(float(loss.detach()), rel=2e-5)
+        ref = full.result.detach().numpy()
+        for k in range(world):
+            u0, u1 = int(r[k]["u0"]), int(r[k]["u1"])
+            assert np.allclose(r[k]["res"][:u1 - u0], ref[u0:u1], rtol=2e-4, atol=1e-6)
+            assert np.allclose(r[k]["res"][u1 - u0:], ref[U:], rtol=2e-4, atol=1e-6)
+        for n, p in full.named_parameters():
+            g = p.grad.numpy()
+            assert np.allclose(r[0]["g_" + n], g, rtol=2e-3, atol=1e-7 + 1e-4 * np.abs(g).max()), n
+            assert np.array_equal(r[0]["g_" + n], r[1]["g_" + n]), n       # identical update on every rank
+    finally:
+        ops.linear, ops.spmm, ops.spmm_raw, ops.bpr_loss = saved

@@ -148,6 +148,37 @@ def test_mmgcn_golden(dev):
     assert ok, why
 
 
+def test_sharded_mmgcn_one_rank_equals_mmgcn_on_the_kernels(dev):
+    """dist.ShardedMMGCN (BASELINE configs[3]) with a single shard covering every user, on the HIP kernels, against
+    the reference golden of the unsharded model: the sharded propagate (two block SpMMs + diagonal self-loop terms)
+    and its partial-gradient backward give the same representation, loss and Linear gradients."""
+    from chaorec_amd.Model import MMGCN
+    from chaorec_amd import graph, dist as cdist
+    g = load_golden("mmgcn_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = MMGCN(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+              torch.from_numpy(g["t_feat"]), int(g["dim_x"]), float(g["reg"]), "add", "False", True, dev)
+    names = [str(n) for n in g["param_names"]]
+    m.load_state_dict({n: torch.from_numpy(g["p_" + n]) for n in names})
+    m = m.to(dev)
+    m.v_gcn.preference = torch.from_numpy(g["v_pref"]).to(dev)
+    m.t_gcn.preference = torch.from_numpy(g["t_pref"]).to(dev)
+    m.id_embedding = torch.from_numpy(g["id_embedding"]).to(dev)
+    shard = cdist.UserShard(g["edges"], U, I, 1, 0, dev, self_loops=True)
+    sm = cdist.ShardedMMGCN(m, shard, dev)
+    loss = sm.loss(torch.from_numpy(g["user_tensor"]), torch.from_numpy(g["item_tensor"]))
+    loss.backward()
+    sm.sync_grads()
+    assert np.allclose(sm.result.detach().cpu().numpy(), g["result"], rtol=2e-4, atol=2e-6)
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-5)
+    for n, p in sm.named_parameters():
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 3e-4 * (np.abs(ref).max() + 1e-12), n
+    rank = sm.gene_ranklist(topk=int(g["topk"])).numpy()
+    assert rank.shape == (U, int(g["topk"])) and rank.min() >= U
+
+
 def test_knn_streamed_kdim_bit_exact(dev, oracle):
     """The kNN build over wide modality features (K-dim 384 here, streamed path) vs the oracle."""
     from chaorec_amd import ops
