@@ -26,6 +26,8 @@ def build_parser():
     parser.add_argument('--dropout', type=float, default=0.2, help='Dropout.')
     parser.add_argument('--n_layers', type=int, default=2, help='conv_layers.')
     parser.add_argument('--mm_layers', type=int, default=2, help='the number of multimodal layer.')
+    parser.add_argument('--no_graph', action='store_true',
+                        help='eager launches instead of one captured hipGraph replay per training batch')
     parser.add_argument('--ii_topk', type=int, default=10, help='the number of item-item graph topk.')
     parser.add_argument('--lambda_coeff', type=float, default=0.9, help='the number of jump connection factor.')
     parser.add_argument('--seed', type=int, default=42, help='Number of seed')

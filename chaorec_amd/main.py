@@ -84,7 +84,8 @@ def main(argv=None):
         # reference: torch.optim.Adam (main.py:397); same update, one fused launch per tensor
         optimizer = FusedAdam([{'params': model.parameters(), 'lr': args.learning_rate}])
         current = train_and_evaluate(model, train_loader, val_data, test_data, optimizer, args.num_epoch,
-                                     model_name=args.Model, topk=args.topk, patience=args.patience)
+                                     model_name=args.Model, topk=args.topk, patience=args.patience,
+                                     graph=not args.no_graph)
         recall = current[20]['recall'] if 20 in current else current[max(current)]['recall']
         if best_performance is None or recall > best_performance:
             best_performance, best_params, best_metrics = recall, hyper.copy(), current

@@ -56,12 +56,29 @@ class GraphedTrainStep:
         dev = next(model.parameters()).device
         self.static = [b.to(dev).clone() for b in example_batch] if example_batch is not None else None
         self.shapes = [tuple(b.shape) for b in self.static] if self.static is not None else None
+        # The warm-up steps (they build lazily cached state: graph schedules, Adam moments, allocator pools) must
+        # not count as training: parameters and optimizer state are put back afterwards.
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        saved_p = [p.detach().clone() for p in params]
+        had_state = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()}
+                     for p in params if optimizer.state.get(p)}
+        saved_step = optimizer._step_dev.clone() if getattr(optimizer, "_step_dev", None) is not None else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(warmup):   # also builds lazily cached state (graph orders, Adam moments)
+            for _ in range(warmup):
                 self._eager(self.static)
         torch.cuda.current_stream().wait_stream(s)
+        with torch.no_grad():
+            for p, q in zip(params, saved_p):
+                p.copy_(q)
+            for p in params:
+                for k, v in optimizer.state.get(p, {}).items():
+                    if torch.is_tensor(v):                 # in place: the captured graph holds these addresses
+                        old = had_state.get(id(p), {}).get(k)
+                        v.copy_(old) if old is not None else v.zero_()
+            if getattr(optimizer, "_step_dev", None) is not None:
+                optimizer._step_dev.copy_(saved_step) if saved_step is not None else optimizer._step_dev.zero_()
         self.graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):

@@ -624,14 +624,10 @@ def test_graphed_step_equals_eager_and_torch_adam(dev):
         if mode == "graph":
             w0 = [p.detach().clone() for p in m.parameters()]
             g = GraphedTrainStep(m, opt, batches[0], warmup=2)
-            # capture warm-up stepped the model: restore parameters and optimizer state
-            with torch.no_grad():
-                for p, w in zip(m.parameters(), w0):
-                    p.copy_(w)
-                for st in opt.state.values():
-                    st["exp_avg"].zero_()
-                    st["exp_avg_sq"].zero_()
-                opt._step_dev.zero_()
+            # the capture's warm-up steps must not count as training
+            assert all(torch.equal(p.detach(), w) for p, w in zip(m.parameters(), w0))
+            assert int(opt._step_dev.item()) == 0
+            assert all(float(st["exp_avg"].abs().max()) == 0.0 for st in opt.state.values())
             for b in batches:
                 losses.append(float(g(*b)))
             assert g.replays == len(batches)
