@@ -56,6 +56,11 @@ class GraphedTrainStep:
         dev = next(model.parameters()).device
         self.static = [b.to(dev).clone() for b in example_batch] if example_batch is not None else None
         self.shapes = [tuple(b.shape) for b in self.static] if self.static is not None else None
+        # A model that already trained eagerly keeps its last autograd graph alive through `self.result` (the
+        # reference's stale-result quirk), and with it AccumulateGrad nodes bound to the default stream: capturing
+        # a backward that reuses them on the capture stream breaks the capture.  Cut that reference first.
+        if torch.is_tensor(getattr(model, "result", None)) and model.result.grad_fn is not None:
+            model.result = model.result.detach()     # (no local name may keep the old tensor alive either)
         # The warm-up steps (they build lazily cached state: graph schedules, Adam moments, allocator pools) must
         # not count as training: parameters and optimizer state are put back afterwards.
         params = [p for g in optimizer.param_groups for p in g["params"]]

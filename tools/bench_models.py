@@ -47,3 +47,14 @@ for spec in which:
     t0 = time.time(); m.gene_ranklist(); torch.cuda.synchronize(); t_rank = time.time() - t0
     print(f"{name:9s} {ds:10s} feat=({v_feat.shape[1]},{t_feat.shape[1]}) build {t_build:6.2f} s  step {ms:8.2f} ms  "
           f"epoch({len(sampler)} batches) {ms * len(sampler) / 1e3:6.2f} s  gene_ranklist {t_rank * 1e3:7.2f} ms")
+    # the real loop of train_and_evaluate.train_and_evaluate: one epoch incl. evaluation and device metrics
+    from chaorec_amd import train_and_evaluate as tae
+    from chaorec_amd.synthetic import synthetic_eval_lists
+    val, test = synthetic_eval_lists(U, I, edges, seed=1), synthetic_eval_lists(U, I, edges, seed=2)
+    import logging
+    logging.disable(logging.CRITICAL)
+    t0 = time.time()
+    tae.train_and_evaluate(m, sampler, val, test, opt, 3, model_name=name, topk=(5, 10, 20), patience=100)
+    torch.cuda.synchronize()
+    print(f"          train_and_evaluate: {(time.time() - t0) / 3:6.3f} s per epoch (train + gene_ranklist + val/test metrics, "
+          f"{'captured step' if name != 'FREEDOM' else 'eager step'}; includes one-off capture)")
