@@ -15,6 +15,21 @@ import torch.nn as nn
 from .. import graph, ops, ranking
 
 
+class _JoinTables(torch.autograd.Function):
+    """torch.cat((user_embedding.weight, item_embedding.weight)) (Model/LightGCN.py:77-78) without the copy: both
+    weights are views of ONE [N, D] buffer, the joined table is that buffer and the gradient splits into two views."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, flat):
+        ctx.n_user = user_w.shape[0]
+        return flat.detach()
+
+    @staticmethod
+    def backward(ctx, G):
+        G = G.contiguous()
+        return G[:ctx.n_user], G[ctx.n_user:], None
+
+
 class LightGCN(nn.Module):
     def __init__(self, num_user, num_item, edge_index, user_item_dict, dim_E, reg_weight, n_layers, aggr_mode,
                  device):
@@ -39,10 +54,28 @@ class LightGCN(nn.Module):
         self.item_embedding = nn.Embedding(num_item, dim_E)
         nn.init.xavier_uniform_(self.user_embedding.weight)
         nn.init.xavier_uniform_(self.item_embedding.weight)
+        self._flat = None
+        self._join_tables()
+
+    def _join_tables(self):
+        """Re-home the two embedding tables as views of one contiguous [N, D] buffer (same Parameters, same
+        state_dict): the propagate then reads the joined table in place instead of concatenating every step."""
+        uw, iw = self.user_embedding.weight, self.item_embedding.weight
+        flat = torch.cat((uw.data, iw.data), 0)
+        uw.data, iw.data = flat[:self.num_user], flat[self.num_user:]
+        self._flat = flat
+
+    def _apply(self, fn, *args, **kwargs):     # .to(device) / .float() / ... replace the Parameters' storage
+        out = super()._apply(fn, *args, **kwargs)
+        self._join_tables()
+        return out
 
     def forward(self):
         """Model/LightGCN.py:76-95; side effect: self.result (read later by gene_ranklist)."""
-        x = torch.cat((self.user_embedding.weight, self.item_embedding.weight), dim=0)
+        uw, iw = self.user_embedding.weight, self.item_embedding.weight
+        if uw.data_ptr() != self._flat.data_ptr() or iw.data_ptr() != self._flat[self.num_user:].data_ptr():
+            self._join_tables()                # someone re-assigned a weight's storage (e.g. weight.data = ...)
+        x = _JoinTables.apply(uw, iw, self._flat)
         self.result = ops.layer_mean_propagate(x, self.graph, self.n_layers)
         return self.result
 
