@@ -50,7 +50,6 @@ __device__ __forceinline__ uint4 bf16_pack8(const float4 a, const float4 b) {
 
 constexpr float kBf16ErrCoef = 1.03f / 256.0f;
 constexpr int kPfCap = 64;        // keys per (split, user, half) list of the sweep
-constexpr int kPfSampleCap = 24;  // scores per lane in the sampler's LDS list (6 KiB per wave: 4 waves per SIMD)
 constexpr int kPfMaxRescore = 128;
 
 struct PrefArgs {
@@ -206,13 +205,42 @@ __device__ __forceinline__ void apply_mask_and_range(f32x16 &acc, uint32_t mbits
   }
 }
 
+// Streaming top-r of the sampler: every lane tightens its own threshold to a value that keeps `keep` of its list
+// entries and compacts the list (register copy of the list: one LDS round trip, no dependent LDS loops).
+template <int CAP>
+__device__ __forceinline__ void sample_prune(float *lst, int lane, int &cnt, float &tl, int keep) {
+  float e[CAP];
+#pragma unroll
+  for (int i = 0; i < CAP; ++i) e[i] = i < cnt ? lst[i * 64 + lane] : -INFINITY;
+  if (cnt > keep) {
+    float lo2 = tl, hi2 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i) hi2 = fmaxf(hi2, e[i]);
+    for (int it = 0; it < 8; ++it) {
+      const float mid = lo2 + (hi2 - lo2) * 0.5f;
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < CAP; ++i) c += e[i] >= mid ? 1 : 0;
+      if (c >= keep) lo2 = mid; else hi2 = mid;
+    }
+    int j = 0;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+      if (e[i] >= lo2) lst[(j++) * 64 + lane] = e[i];   // (-inf padding never passes: lo2 > -inf)
+    cnt = j;
+    tl = fmaxf(tl, nextafterf(lo2, -INFINITY));
+  }
+}
+
 // ---- sample --------------------------------------------------------------------------------------------------
 // grid (user blocks of 32, sample_splits).  Sample tile i of this wave is tile (i * sample_splits + split) * stride.
 // Each wave estimates, per user, a score with about r sampled scores at or above it (r = sample_rank, pooled
 // over the user's two lanes); the user's threshold is the mean of the sample splits' estimates.
-template <int D>
+// CAP / PRUNE: short item ranges (a wave's sample fits the list) run without the streaming-top-r code -- it doubles
+// the kernel's size and costs more than it saves there; long ranges need it (see sample_prune).
+template <int D, int CAP, bool PRUNE>
 __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P) {
-  __shared__ float lst[kPfSampleCap * 64];  // [slot][lane]: conflict-free for lane-local walks
+  __shared__ float lst[CAP * 64];  // [slot][lane]: conflict-free for lane-local walks
   __shared__ float park[16 * 64];
   const int lane = threadIdx.x;
   const int ur = lane & 31, h = lane >> 5;
@@ -286,12 +314,15 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
     tau1 = fmaxf(b3, __shfl_xor(b3, 32, 64));
   }
 
-  // phase 2: every sampled tile; scores above tau1 go to the lane's LDS list (a full list drops the rest: the
-  // value found below is then a lower bound of the intended one -- still a valid, merely looser, threshold).
-  // Same compact hit handling as the sweep: bit mask per lane, scores parked in LDS, one drain loop.
+  // phase 2: every sampled tile; scores above the lane's threshold go to its LDS list.  Same compact hit handling as
+  // the sweep: bit mask per lane, scores parked in LDS, one drain loop.  When a list could overflow on the next tile,
+  // every lane tightens its own threshold to a value that keeps `keep` of its entries (lane-local bisection) and
+  // compacts: a streaming top-r, so the sample may be arbitrarily long (millions of items) with 32 slots per lane.
   int cnt = 0;
+  const int r = P.sample_rank + h_s;
+  const int keep = min(r, CAP / 4);   // well below the trigger level: a prune buys room for many tiles
+  float tl = nextafterf(tau1, -INFINITY);   // strict compare below keeps scores == tau1
   {
-    const float tl = nextafterf(tau1, -INFINITY);   // strict compare below keeps scores == tau1
     // item fragments three tiles ahead: one tile of this kernel is short (one user block), a single tile of
     // lookahead does not cover the L2 latency
     uint4 ring[3][D / 16];
@@ -315,10 +346,11 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
             const int bit = 31 - __clz(qbits);
             qbits &= ~(1u << bit);
             const float sc = park[(15 - bit) * 64 + lane];
-            if (cnt < kPfSampleCap) lst[(cnt++) * 64 + lane] = sc;
+            if (cnt < CAP) lst[(cnt++) * 64 + lane] = sc;
           }
         }
         __builtin_amdgcn_wave_barrier();
+        if (PRUNE && __any(cnt > CAP - 16)) sample_prune<CAP>(lst, lane, cnt, tl, keep);
       }
     };
     while (t < n_tiles) {
@@ -338,10 +370,12 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   }
 
   // phase 3: bisection on the value, counts pooled over the user's two lanes: the largest of 2^8 grid values in
-  // [tau1, max] with at least r list entries at or above it (any such value is a valid lower bound of the r-th best)
-  float lo = tau1;  // invariant: pooled count(>= lo) >= r, or the lists are shorter than r
-  const int r = P.sample_rank + h_s;
-  const int pooled = cnt + __shfl_xor(cnt, 32, 64);
+  // [lo, max] with at least r list entries at or above it (any such value is a valid lower bound of the r-th best).
+  // lo starts at the larger of the two lanes' thresholds: above it both lists are complete.
+  float lo = fmaxf(tl, __shfl_xor(tl, 32, 64));
+  int pooled = 0;
+  for (int i = 0; i < cnt; ++i) pooled += lst[i * 64 + lane] >= lo ? 1 : 0;
+  pooled += __shfl_xor(pooled, 32, 64);
   if (pooled >= r && lo > -INFINITY) {
     float hi = -INFINITY;
     for (int i = 0; i < cnt; ++i) hi = fmaxf(hi, lst[i * 64 + lane]);

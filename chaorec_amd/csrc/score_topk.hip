@@ -788,6 +788,7 @@ struct ScorePlan {
   // bf16 prefilter path (score_prefilter.hpp)
   bool prefilter;
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
+  bool pf_sample_long;
   size_t off_pf_heavy, off_pf_fb, off_pf_fbdone, off_pf_fbpart;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_margin, off_pf_cand, off_pf_cnt;
   size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
@@ -862,14 +863,18 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
     // one full round of 2 waves per SIMD (2048 slots) when the user blocks allow it: a second, partly filled
     // round costs a whole wave time
     int64_t sp = sweep_wave_slots(D) / ublocks;
+    if (sp < 6) sp = 6;     // ~200 candidates per user over 2 * splits lists of kPfCap = 64: keep the lists short
     if (sp > 16) sp = 16;
     if (sp > n_tiles / 16) sp = n_tiles / 16;
     if (sp < 1) sp = 1;
     p.pf_splits = (int)sp;
   }
   p.pf_sample_stride = 4;
-  p.pf_sample_splits = 4;
-  p.pf_sample_rank = 10;
+  // a sampler wave's share of the sample fits its 24-slot lists up to ~16 k items; longer ranges take the
+  // streaming-top-r instantiation (32 slots, fewer and longer waves)
+  p.pf_sample_long = n_tiles > 512;
+  p.pf_sample_splits = p.pf_sample_long ? 3 : 4;
+  p.pf_sample_rank = p.pf_sample_long ? 14 : 10;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 32 * (size_t)D * 2 : 0);
@@ -1036,12 +1041,14 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);
     const dim3 gw((unsigned)((groups + p.pf_ub - 1) / p.pf_ub), (unsigned)p.pf_splits);
     if (D == 64) {
-      hipLaunchKernelGGL(score_sample_bf16_kernel<64>, gs, dim3(64), 0, st, P);
+      if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true>), gs, dim3(64), 0, st, P);
+      else hipLaunchKernelGGL((score_sample_bf16_kernel<64, 24, false>), gs, dim3(64), 0, st, P);
       hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_kernel<64>, dim3((unsigned)n_users), dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_wide_kernel<64>, dim3(512), dim3(64), 0, st, P);
     } else {
-      hipLaunchKernelGGL(score_sample_bf16_kernel<128>, gs, dim3(64), 0, st, P);
+      if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true>), gs, dim3(64), 0, st, P);
+      else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false>), gs, dim3(64), 0, st, P);
       hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_kernel<128>, dim3((unsigned)n_users), dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_wide_kernel<128>, dim3(512), dim3(64), 0, st, P);

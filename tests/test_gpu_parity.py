@@ -359,13 +359,22 @@ def _check_all_precisions(dev, oracle, ue, ie, hist, mask, K, id_offset=0):
 
 
 @pytest.mark.parametrize("U,I,D,K", [(150, 9000, 64, 50), (70, 8200, 128, 20), (33, 12000, 64, 64),
-                                     (129, 8192, 64, 1), (300, 15207, 64, 50)])
+                                     (129, 8192, 64, 1), (300, 15207, 64, 50), (64, 150000, 64, 50)])
 def test_score_topk_prefilter_bit_exact_vs_oracle(dev, oracle, U, I, D, K):
     rng = np.random.default_rng(U + I + D)
     ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
     ie = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
     ie *= (0.3 + rng.pareto(3.0, (I, 1))).astype(np.float32)        # heavy-tailed item norms, like trained tables
     _check_all_precisions(dev, oracle, ue, ie, _hist_random(U, I, 40, seed=I), 1e-6, K, id_offset=U)
+    if I >= 100000:
+        # a long item range must not degrade the sampled thresholds (streaming top-r in the sampler): the prefilter
+        # route has to certify (nearly) everyone itself
+        from chaorec_amd import ops
+        st = {}
+        ie = (np.random.default_rng(1).standard_normal((I, D)) * 0.2).astype(np.float32)   # (no norm outliers here)
+        ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), None, 0.0, K, stats=st)
+        assert st["prefilter_users"] == U and st["fallback_users"] <= U // 8, st
+        assert st["candidates"] / U < 600, st
 
 
 def test_score_topk_prefilter_adversarial(dev, oracle):
