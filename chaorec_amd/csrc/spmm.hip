@@ -95,18 +95,8 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
       deg = (int)(rowptr[r + 1] - e0);
     }
   }
-#ifdef CHAOREC_EXP_NOLONG
-  blk_long = false;
-#endif
-#ifdef CHAOREC_EXP_EMPTY
-  if (n_rows >= 0) return;
-#endif
   const bool row_ok = r >= 0;
-#ifdef CHAOREC_EXP_NOLONG
-  const bool is_long = false;
-#else
   const bool is_long = (NG > 1) && deg > LONG_T;
-#endif
   const int deg1 = is_long ? 0 : deg;
   const int rest = max(deg1 - n_inl, 0);            // entries still to be fetched from the CSR arrays
   const int dmax = wave_max_i32(rest);  // wave-uniform trip counts keep every shuffle fully active
@@ -154,11 +144,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
       for (int q = 0; q < CPL; ++q) {
         const int chunk = li + q * LPR;
         xin[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef CHAOREC_EXP_NOGATHER
         if (j < deg1 && chunk < D4) xin[j][q] = x4[(size_t)icol[j] * (size_t)D4 + chunk];
-#else
-        xin[j][q] = make_float4((float)icol[j], 1.f, 2.f, 3.f);
-#endif
       }
     }
 #pragma unroll
@@ -201,11 +187,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
         for (int q = 0; q < CPL; ++q) {
           const int chunk = li + q * LPR;
           xv[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef CHAOREC_EXP_NOGATHER
           if (p[u] && chunk < D4) xv[u][q] = x4[(size_t)cj[u] * (size_t)D4 + chunk];
-#else
-          xv[u][q] = make_float4((float)cj[u], 1.f, 2.f, 3.f);
-#endif
         }
       }
 #pragma unroll
@@ -232,7 +214,10 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     // LDS (`carry`, ordered by the `seq` ticket), so only the adds -- ~8 cycles per entry -- are serial,
     // not the memory latency.  The additions happen in entry order: bit-identical to one lane walking
     // the row alone.
-    constexpr int UH = 8;
+#ifndef CHAOREC_SPMM_UH
+#define CHAOREC_SPMM_UH 8
+#endif
+    constexpr int UH = CHAOREC_SPMM_UH;
     constexpr int HALF = NG * UH;       // entries per chunk (32 for D=64, 16 for D=128)
     constexpr int FPL = LPR * 4 / 64;   // features per lane in the ordered sum (1 or 2)
     constexpr int MAXL = 4 * NG;        // rows per block
@@ -374,11 +359,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     const size_t o = (size_t)r * (size_t)D4 + chunk;
     float4 s = mul_rn4(alpha, sum[q]);
     if (z) s = add_rn4(s, mul_rn4(beta, zpre[q]));
-#ifndef CHAOREC_EXP_NOSTORE
     if (y) y4[o] = s;
-#else
-    if (y && s.x == 12345.678f) y4[o] = s;
-#endif
     if (acc) {
       const float4 a0 = acc_init ? mul_rn4(acc_w, apre[q]) : apre[q];
       acc4[o] = add_rn4(a0, mul_rn4(acc_w, s));
