@@ -12,6 +12,8 @@ DATASET_SHAPES = {  # dataload.py:36-56 + measured E of train.npy
     "sports": (28940, 15207, 158554),
     "clothing": (18072, 11384, 76054),
     "microlens": (46420, 14079, 210567),
+    # one GPU's share of BASELINE configs[4] (10 M users x 2 M items, ~200 M edges over 8 GPUs): the HBM-bound regime
+    "config5_shard": (1_250_000, 2_000_000, 25_000_000),
 }
 
 
