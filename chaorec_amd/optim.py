@@ -88,6 +88,9 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.static_loss = self._eager(self.static)
+        # the captured forward's output buffer: every replay rewrites it, and model.result must keep pointing at it
+        # (an eager step in between -- the short last batch of an epoch -- rebinds model.result to its own tensor)
+        self._captured_result = getattr(model, "result", None) if torch.is_tensor(getattr(model, "result", None)) else None
         self.replays = 0
 
     def _eager(self, batch):
@@ -103,6 +106,8 @@ class GraphedTrainStep:
         if self.batch_fn is not None:
             self.graph.replay()
             self.replays += 1
+            if self._captured_result is not None:
+                self.model.result = self._captured_result
             return self.static_loss
         if [tuple(b.shape) for b in batch] != self.shapes:
             return self._eager([b.to(self.static[0].device) for b in batch])
@@ -110,4 +115,6 @@ class GraphedTrainStep:
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
         self.replays += 1
+        if self._captured_result is not None:
+            self.model.result = self._captured_result
         return self.static_loss
