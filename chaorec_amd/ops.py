@@ -313,11 +313,13 @@ def linear(x, weight, bias=None, act=0):
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-              step_dev=None):
+              step_dev=None, numel=None):
     """One fused Adam launch over a flat fp32 tensor.  `step_dev` (int32 device scalar) overrides `step` so the
-    launch can be captured in a hipGraph."""
+    launch can be captured in a hipGraph.  `numel` > param.numel(): the four arrays continue contiguously past this
+    tensor (adjacent parameters updated by one launch, see optim.FusedAdam)."""
     _need_cuda(param, grad, exp_avg, exp_avg_sq, step_dev)
-    rc = _lib.load().chaorec_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+    rc = _lib.load().chaorec_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                           param.numel() if numel is None else int(numel),
                                            lr, betas[0], betas[1], eps, weight_decay, int(step), _ptr(step_dev),
                                            _stream())
     _lib.check(rc, "chaorec_adam_step_f32")

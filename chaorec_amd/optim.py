@@ -12,6 +12,22 @@ import torch
 from . import ops
 
 
+def _adjacent_run(first, candidates):
+    """The parameters of `candidates` (in order) that continue `first`'s storage without a gap, `first` included."""
+    run, end = [], None
+    started = False
+    for q in candidates:
+        if q is first:
+            started = True
+            run, end = [q], q.data_ptr() + q.numel() * q.element_size()
+        elif started and q.data_ptr() == end:
+            run.append(q)
+            end += q.numel() * q.element_size()
+        elif started:
+            break
+    return run or [first]
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -30,16 +46,43 @@ class FusedAdam(torch.optim.Optimizer):
         if self._step_dev is not None:
             self._step_dev.add_(1)
         for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
+            live = [p for p in group["params"] if p.grad is not None]
+            for p in live:
                 st = self.state[p]
                 if not st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    # parameters that sit back to back in one buffer (LightGCN's joined embedding tables) get their
+                    # moments back to back too, so the whole run can be updated by ONE launch
+                    run = [q for q in live if not self.state[q] and q.dtype == p.dtype and q.is_contiguous()]
+                    run = _adjacent_run(p, run)
+                    total = sum(q.numel() for q in run)
+                    flat_m = torch.zeros(total, dtype=p.dtype, device=p.device)
+                    flat_v = torch.zeros(total, dtype=p.dtype, device=p.device)
+                    o = 0
+                    for q in run:
+                        self.state[q]["exp_avg"] = flat_m[o:o + q.numel()].view_as(q)
+                        self.state[q]["exp_avg_sq"] = flat_v[o:o + q.numel()].view_as(q)
+                        o += q.numel()
+            i = 0
+            while i < len(live):
+                p = live[i]
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                n, j = p.numel(), i + 1
+                # extend over parameters whose data, gradient and moments all continue where this one ends
+                while j < len(live):
+                    q = live[j]
+                    gq, sq = q.grad, self.state[q]
+                    esz = p.element_size()
+                    if not (q.is_contiguous() and gq.is_contiguous() and q.dtype == p.dtype
+                            and q.data_ptr() == p.data_ptr() + n * esz and gq.data_ptr() == g.data_ptr() + n * esz
+                            and sq["exp_avg"].data_ptr() == st["exp_avg"].data_ptr() + n * esz
+                            and sq["exp_avg_sq"].data_ptr() == st["exp_avg_sq"].data_ptr() + n * esz):
+                        break
+                    n += q.numel()
+                    j += 1
                 ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
-                              group["eps"], group["weight_decay"], step_dev=self._step_dev)
+                              group["eps"], group["weight_decay"], step_dev=self._step_dev, numel=n)
+                i = j
         return loss
 
 
