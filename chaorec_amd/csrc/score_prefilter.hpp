@@ -638,8 +638,9 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
   const int total = __shfl(incl, 63, 64);
   // reason codes (nonzero = re-run on the fp32 route): 1 list overflow, 2 fewer than K candidates, 3 more than 64*NRmax,
   // 4 band reaches below the sweep threshold, 5 more than 128 items inside the band
-  // (the user's history is appended to the candidates below: both must fit the 64*NRmax key slots / the LDS copy)
-  int why = overflow ? 1 : (total + deg < K ? 2 : ((total + deg > 64 * NRmax || deg > kPfHistLds) ? 3 : 0));
+  // (the user's history is copied to LDS for the membership tests; it joins the candidates only when mask_value can
+  //  reach the top-K, see below)
+  int why = overflow ? 1 : (total + deg < K ? 2 : ((total > 64 * NRmax || deg > kPfHistLds) ? 3 : 0));
   uint64_t e0 = 0ull, e1 = 0ull;
   if (why == 0) {
     incl_s[lane] = incl;
@@ -652,7 +653,7 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
 #pragma unroll
     for (int r = 0; r < NRmax; ++r) {
       k[r] = 0ull;
-      if (64 * r >= total + deg) continue;   // wave-uniform: cost follows the actual key count
+      if (64 * r >= total) continue;   // wave-uniform: cost follows the actual key count
       const int e = lane + 64 * r;
       if (e < total) {
         int lo = 0, hi = 63;
@@ -665,28 +666,46 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
         const uint2 raw = cand2[(((size_t)(lo >> 1) * P.n_users + u) * 2 + (lo & 1)) * kPfCap + pos];
         const uint32_t ob = (raw.y & 0x80000000u) ? ~raw.y : (raw.y | 0x80000000u);
         k[r] = ((uint64_t)ob << 32) | (uint64_t)(0xFFFFFFFFu - raw.x);
-        // the sweep ran unmasked: a history member leaves the candidates here ...
+        // the sweep ran unmasked: a history member leaves the candidates here
         int l2 = 0, h2 = deg;
         while (l2 < h2) {
           const int mid = (l2 + h2) >> 1;
           if (hist_s[mid] < raw.x) l2 = mid + 1; else h2 = mid;
         }
         if (l2 < deg && hist_s[l2] == raw.x) k[r] = 0ull;
-      } else if (e < total + deg) {
-        // ... and the whole history comes back with the mask value, the masked row's exact entries
-        k[r] = make_key(P.mask_value, hist_s[e - total]);
       }
     }
-    const int total2 = total + deg;
+    // A value that at least K entries of the masked row reach.  First over the unmasked candidates alone: the
+    // history's entries (all equal to mask_value) can only raise the row's K-th best, so this is a valid, possibly
+    // low, a_K.  Only if mask_value itself reaches the band below it (the reference's 1e-6 / 1e-5 does when every
+    // real score is tiny or negative: quirk Q7) does the history join the keys, and a_K is taken again.
+    int total2 = total;
+    auto kth = [&](int n_keys) -> uint32_t {
+      if (n_keys <= 128) return kth_largest_ord<2, NRmax, 20>(k, K);
+      if (n_keys <= 256) return kth_largest_ord<4, NRmax, 20>(k, K);
+      if (n_keys <= 512 || NRmax <= 8) return kth_largest_ord<8, NRmax, 20>(k, K);
+      return kth_largest_ord<NRmax, NRmax, 20>(k, K);
+    };
     int valid = 0;
 #pragma unroll
     for (int r = 0; r < NRmax; ++r) valid += __popcll(__ballot(k[r] != 0ull));
-    uint32_t T = 0;
-    if (valid < K) why = 2;
-    else if (total2 <= 128) T = kth_largest_ord<2, NRmax, 20>(k, K);
-    else if (total2 <= 256) T = kth_largest_ord<4, NRmax, 20>(k, K);
-    else if (total2 <= 512 || NRmax <= 8) T = kth_largest_ord<8, NRmax, 20>(k, K);
-    else T = kth_largest_ord<NRmax, NRmax, 20>(k, K);
+    uint32_t T = valid >= K ? kth(total) : 0u;
+    const bool hist_matters = deg > 0 && (valid < K || P.mask_value >= ord_to_f32(T) - 2.0f * m);
+    if (hist_matters) {   // wave-uniform
+      if (total + deg > 64 * NRmax) {
+        why = 3;
+      } else {
+#pragma unroll
+        for (int r = 0; r < NRmax; ++r) {
+          const int e = lane + 64 * r;
+          if (e >= total && e < total + deg) k[r] = make_key(P.mask_value, hist_s[e - total]);
+        }
+        total2 = total + deg;
+        valid += deg;
+        T = valid >= K ? kth(total2) : 0u;
+      }
+    }
+    if (why == 0 && valid < K) why = 2;
     const float a_k = ord_to_f32(T);
     const float cutoff = a_k - 2.0f * m;
     if (why == 0 && !(cutoff > theta)) why = 4;  // items the sweep rejected could lie inside the band
