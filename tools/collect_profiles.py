@@ -31,9 +31,9 @@ def run(tag, name, extra):
     shutil.rmtree(out, ignore_errors=True)
     cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", name] + extra + \
           ["--", "python3", os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--no-cpu-baseline",
-           "--no-graph"]
+           "--no-graph", "--no-trained-state"]
     env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not line:
         sys.stderr.write(r.stdout[-2000:] + r.stderr[-2000:])
