@@ -290,8 +290,9 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   // phase 1: the first 8 sampled tiles (128 scores per lane), lane-local top-4 by median-of-3 insertion; tau1 = the
   // larger of the two lanes' 4th best: at least 4 of the user's 256 scores reach it (expected: the top ~2.5 %)
   float tau1;
+  float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY, b3 = -INFINITY;
+  int t_phase2 = t_first;
   {
-    float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY, b3 = -INFINITY;
     int t = t_first;
     uint4 a[D / 16], an[D / 16];
     if (t < n_tiles) load_item_frags_bf16<D>(a, P.packed, t, lane);
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
       }
     }
     tau1 = fmaxf(b3, __shfl_xor(b3, 32, 64));
+    t_phase2 = t;
   }
 
   // phase 2: every sampled tile; scores above the lane's threshold go to its LDS list.  Same compact hit handling as
@@ -322,11 +324,17 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   const int r = P.sample_rank + h_s;
   const int keep = min(r, CAP / 4);   // well below the trigger level: a prune buys room for many tiles
   float tl = nextafterf(tau1, -INFINITY);   // strict compare below keeps scores == tau1
+  // the phase-1 tiles are not visited again: every score of theirs that reaches tau1 is one of the lane's top 4
+  // (tau1 >= the lane's own 4th best), so the list starts with those
+  if (b0 >= tau1) lst[(cnt++) * 64 + lane] = b0;
+  if (b1 >= tau1) lst[(cnt++) * 64 + lane] = b1;
+  if (b2 >= tau1) lst[(cnt++) * 64 + lane] = b2;
+  if (b3 >= tau1) lst[(cnt++) * 64 + lane] = b3;
   {
     // item fragments three tiles ahead: one tile of this kernel is short (one user block), a single tile of
     // lookahead does not cover the L2 latency
     uint4 ring[3][D / 16];
-    int t = t_first;
+    int t = t_phase2;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       load_item_frags_bf16<D>(ring[i], P.packed, t + i * step < n_tiles ? t + i * step : (n_tiles - 1), lane);
