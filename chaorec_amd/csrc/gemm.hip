@@ -53,7 +53,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
   constexpr int B_V = BN * BK / 4 / 256;  // (2 for BN=128, 1 for BN=64)
   float4 ra[A_V], rb[B_V];
 
+  // Interior tiles (the whole BM x BK / BN x BK window inside the matrix, 16-B aligned rows) take a branch with
+  // unconditional float4 loads; only edge tiles run the element-guarded path.  The test is block-uniform.
+  const bool a_rows_in = m0 + BM <= M, b_rows_in = n0 + BN <= N;
   auto fetch_a = [&](int64_t k0) {
+    if (a_vec && a_rows_in && k0 + BK <= ke) {
+#pragma unroll
+      for (int p = 0; p < A_V; ++p) {
+        const int v = t + p * 256;
+        if (!transA) {
+          const int mm = v >> 2, k4 = (v & 3) * 4;
+          ra[p] = *reinterpret_cast<const float4 *>(A + (m0 + mm) * lda + k0 + k4);
+        } else {
+          const int kk = v / (BM / 4), m4 = (v % (BM / 4)) * 4;
+          ra[p] = *reinterpret_cast<const float4 *>(A + (k0 + kk) * lda + m0 + m4);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < A_V; ++p) {
       const int v = t + p * 256;
@@ -89,6 +106,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     }
   };
   auto fetch_b = [&](int64_t k0) {
+    if (b_vec && b_rows_in && k0 + BK <= ke) {
+#pragma unroll
+      for (int p = 0; p < B_V; ++p) {
+        const int v = t + p * 256;
+        if (transB) {
+          const int nn = v >> 2, k4 = (v & 3) * 4;
+          rb[p] = *reinterpret_cast<const float4 *>(B + (n0 + nn) * ldb + k0 + k4);
+        } else {
+          const int kk = v / (BN / 4), n4 = (v % (BN / 4)) * 4;
+          rb[p] = *reinterpret_cast<const float4 *>(B + (k0 + kk) * ldb + n0 + n4);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < B_V; ++p) {
       const int v = t + p * 256;
