@@ -206,3 +206,48 @@ def test_early_stopping():
     for s in (0.1, 0.2, 0.15, 0.2, 0.1, 0.05):
         es(s, {"s": s})
     assert es.early_stop and es.best_score == 0.2
+
+
+def test_fused_adam_adjacent_runs():
+    """optim._adjacent_run: parameters that continue each other's storage form one launch run."""
+    from chaorec_amd.optim import _adjacent_run
+    flat = torch.zeros(10 * 4 + 6 * 4 + 3)
+    a, b, c = flat[:40].view(10, 4), flat[40:64].view(6, 4), flat[64:67]
+    lone = torch.zeros(5)
+    assert [id(x) for x in _adjacent_run(a, [a, b, c, lone])] == [id(a), id(b), id(c)]
+    assert [id(x) for x in _adjacent_run(b, [a, b, lone, c])] == [id(b)]          # lone breaks the run
+    assert [id(x) for x in _adjacent_run(lone, [a, b, c, lone])] == [id(lone)]
+
+
+def test_eval_lists_csr_layout():
+    from chaorec_amd.utils import EvalLists
+    data = [[3, 10, 11], [0], [7, 12, 12, 13]]
+    ev = EvalLists(data, torch.device("cpu"))
+    assert ev.n == 3
+    assert ev.row_user.tolist() == [3, 0, 7]
+    assert ev.rowptr.tolist() == [0, 2, 2, 5]
+    assert ev.items.tolist() == [10, 11, 12, 12, 13]          # duplicates kept: len(test_list) counts them
+
+
+def test_lightgcn_tables_share_one_buffer_and_keep_their_names(baby):
+    """Model/LightGCN.py keeps two nn.Embedding parameters; here they are views of one [N, D] buffer (no per-step
+    concatenation).  Names, shapes, values and load_state_dict behave as before; .to()/.float() re-join."""
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd import graph
+    edges = baby["train"][:2000]
+    U, I = baby["U"], baby["I"]
+    torch.manual_seed(3)
+    m = LightGCN(U, I, edges, graph.user_item_dict_from_edges(edges), 8, 1e-3, 2, "add", torch.device("cpu"))
+    assert [n for n, _ in m.named_parameters()] == ["user_embedding.weight", "item_embedding.weight"]
+    uw, iw = m.user_embedding.weight, m.item_embedding.weight
+    assert uw.shape == (U, 8) and iw.shape == (I, 8)
+    assert uw.data_ptr() == m._flat.data_ptr() and iw.data_ptr() == m._flat[U:].data_ptr()
+    torch.manual_seed(3)
+    eu, ei = torch.nn.Embedding(U, 8), torch.nn.Embedding(I, 8)                 # same init order as the reference
+    ref_u, ref_i = torch.nn.init.xavier_uniform_(eu.weight), torch.nn.init.xavier_uniform_(ei.weight)
+    assert torch.equal(uw.detach(), ref_u.detach()) and torch.equal(iw.detach(), ref_i.detach())
+    sd = {k: v.clone() + 1.0 for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    assert torch.equal(m._flat[:U], sd["user_embedding.weight"]) and torch.equal(m._flat[U:], sd["item_embedding.weight"])
+    m = m.double()
+    assert m._flat.dtype == torch.float64 and m.user_embedding.weight.data_ptr() == m._flat.data_ptr()
