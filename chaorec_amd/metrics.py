@@ -1,40 +1,50 @@
 """Per-user ranking metrics with the reference's names and semantics (metrics.py:13-57).
 
-Kept as plain functions for API parity; the evaluation loop uses the vectorised
-utils.gene_metrics, which computes the same numbers for all users at once."""
+Kept as plain functions for API parity; the evaluation loop uses utils.gene_metrics (vectorised, host) or
+utils.gene_metrics_device (one launch on the GPU), which compute the same numbers for all users at once.
+All five are derived from one helper: the positions of ranked[:k] that hit the test list."""
 import numpy as np
 
 
+def _hit_positions(ranked_list, test_list, k):
+    """0-based ranks p < k with ranked_list[p] in test_list (membership per position, duplicates included)."""
+    wanted = set(test_list)
+    return [p for p, item in enumerate(ranked_list[:k]) if item in wanted]
+
+
+def _distinct_hits(ranked_list, test_list, k):
+    """|set(ranked[:k]) & set(test)|: a repeated id in the ranking counts once."""
+    return len({ranked_list[p] for p in _hit_positions(ranked_list, test_list, k)})
+
+
 def precision_at_k(ranked_list, test_list, k):
-    return len(set(ranked_list[:k]) & set(test_list)) / k
+    return _distinct_hits(ranked_list, test_list, k) / k
 
 
 def recall_at_k(ranked_list, test_list, k):
-    if len(test_list) == 0:
-        return 0
-    return len(set(ranked_list[:k]) & set(test_list)) / len(test_list)
-
-
-def ndcg_at_k(ranked_list, test_list, k):
-    if not test_list:
-        return 0
-    test = set(test_list)
-    idcg = sum(1.0 / np.log(i + 2) for i in range(min(len(test_list), k)))
-    dcg = sum(1.0 / np.log(i + 2) for i, item in enumerate(ranked_list[:k]) if item in test)
-    return dcg / idcg
+    n = len(test_list)
+    return _distinct_hits(ranked_list, test_list, k) / n if n else 0
 
 
 def hit_rate_at_k(ranked_list, test_list, k):
-    return int(bool(set(ranked_list[:k]) & set(test_list)))
+    return 1 if _hit_positions(ranked_list, test_list, k) else 0
+
+
+def ndcg_at_k(ranked_list, test_list, k):
+    n = len(test_list)
+    if n == 0:
+        return 0
+    gain = 1.0 / np.log(np.arange(k) + 2.0)                      # natural log, as the reference; the base cancels
+    ideal = sum(float(gain[i]) for i in range(min(n, k)))        # left-to-right, like the reference's sum()
+    got = sum(float(gain[p]) for p in _hit_positions(ranked_list, test_list, k))
+    return got / ideal
 
 
 def map_at_k(ranked_list, test_list, k):
-    if not test_list:
+    n = len(test_list)
+    if n == 0:
         return 0
-    test = set(test_list)
-    scores, num_hits = 0, 0
-    for i, item in enumerate(ranked_list[:k]):
-        if item in test:
-            num_hits += 1
-            scores += num_hits / (i + 1)
-    return scores / len(test_list)
+    total = 0
+    for seen, p in enumerate(_hit_positions(ranked_list, test_list, k), start=1):
+        total += seen / (p + 1)
+    return total / n
