@@ -198,18 +198,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
       fetch_a(k0 + BK);
       fetch_b(k0 + BK);
     }
+    // all fragments of the tile first (8 k-pairs x (WM + WN) LDS reads in flight), then the MFMA chain: the reads
+    // of a k-pair are not waited on right in front of its MFMAs
+    float af[BK / 2][WM], bf[BK / 2][WN];
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      float a[WM], b[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = As[buf][2 * s + h][wrow + 32 * i + r];
+      for (int i = 0; i < WM; ++i) af[s][i] = As[buf][2 * s + h][wrow + 32 * i + r];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = Bs[buf][2 * s + h][wcol + 32 * j + r];
+      for (int j = 0; j < WN; ++j) bf[s][j] = Bs[buf][2 * s + h][wcol + 32 * j + r];
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
     }
     if (more) stash(buf ^ 1);
     __syncthreads();
