@@ -5,12 +5,17 @@
 // be in a user's top-K; the handful that can are re-scored in exact fp32 (the same k-ascending fmaf chain as the
 // f32 MFMA kernel / oracle_score_dot) and ranked on those values.  The result is bit-identical to the fp32 path:
 //
-//   |s~(u,j) - s(u,j)| <= m_u := c * ||u||_2 * max_j ||i_j||_2,   c = 1.03 * 2^-8
-//     (two RNE bf16 roundings, 2^-9 relative each, + fp32 accumulation; Cauchy-Schwarz on sum_d |u_d||i_d|).
-//   Let a_K = K-th largest approximate score of the user.  An item with s~ < a_K - 2 m_u has true score
-//   < a_K - m_u <= the true score of each of the K items whose approximate score is >= a_K: K items beat it
-//   strictly, it is not in the top-K whatever the tie order.  So R = { j : s~_j >= a_K - 2 m_u } holds the whole
-//   exact top-K; R is K plus the few items inside the 2 m_u band.
+//   |s~(u,j) - s(u,j)| <= e_uj := c * ||u||_2 * ||i_j||_2,   c = 1.05 * 2^-8
+//     (two RNE bf16 roundings, 2^-9 relative each, + fp32 accumulation; Cauchy-Schwarz on sum_d |u_d||i_d|, PER ITEM:
+//      a table with a few outsized item norms does not widen the band of every other item).
+//   With e~_uj >= e_uj (bf16-rounded-up factors) let v_j = s~_j + e~_uj and w_j = s~_j - e~_uj, so w_j <= s_j <= v_j.
+//   The sweep keeps C = { j : v_j > T_u }.  If C holds >= K items, L = the K-th largest w_j over C is a lower bound
+//   of the K-th best TRUE score.  If L > T_u, every item outside C has s_j <= v_j <= T_u < L and every item of C
+//   with v_j < L has s_j < L: K items beat them strictly, none is in the top-K whatever the tie order.  So
+//   R = { j in C : v_j >= L } holds the whole exact top-K.  T_u comes from the sampler, which ranks w_j.
+//   Both v and w come out of the MFMA: the item side of an extra k-step carries (1, ||i_j||), the user side
+//   (T_u, -c||u||) in the sweep -- the accumulator is T_u - v_j, a hit is its sign bit -- and (0, -c||u||) in the
+//   sampler -- the accumulator is w_j.
 //   Masked (history) items carry mask_value exactly in both domains (error 0).
 //
 // Pipeline (all on one stream, no host round trip):
@@ -41,6 +46,11 @@ __device__ __forceinline__ uint32_t bf16_rne_bits(float f) {
   const uint32_t b = __float_as_uint(f);
   return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
 }
+// smallest bf16-representable value >= x, for x >= 0 (as a float)
+__device__ __forceinline__ float bf16_ceil_pos(float x) {
+  const uint32_t b = __float_as_uint(x);
+  return __uint_as_float(((b >> 16) + ((b & 0xFFFFu) ? 1u : 0u)) << 16);
+}
 __device__ __forceinline__ uint32_t bf16_pack2(float lo, float hi) {
   return bf16_rne_bits(lo) | (bf16_rne_bits(hi) << 16);
 }
@@ -48,7 +58,7 @@ __device__ __forceinline__ uint4 bf16_pack8(const float4 a, const float4 b) {
   return make_uint4(bf16_pack2(a.x, a.y), bf16_pack2(a.z, a.w), bf16_pack2(b.x, b.y), bf16_pack2(b.z, b.w));
 }
 
-constexpr float kBf16ErrCoef = 1.03f / 256.0f;
+constexpr float kBf16ErrCoef = 1.05f / 256.0f;
 constexpr int kPfCap = 64;        // keys per (split, user, half) list of the sweep
 constexpr int kPfMaxRescore = 128;
 
@@ -62,10 +72,10 @@ struct PrefArgs {
   float mask_value;
   int K;
   int64_t id_offset;
-  uint32_t *imax2_bits;         // max_j ||i_j||^2 as float bits
+  float *item_norm;             // [n_tiles * 32] ||i_j||_2 rounded UP to a bf16 value (0 for padding rows)
   float *tau_sum;               // [U] sampled threshold: mean over the sample splits (atomicAdd of est / splits)
   float *theta;                 // [U] sweep threshold (written by sweep split 0)
-  float *margin;                // [U] m_u
+  float *margin;                // [U] c * ||u||_2 rounded UP to a bf16 value: e~_uj = margin[u] * item_norm[j]
   uint64_t *cand;               // [splits][U][2][kPfCap] raw entries: low word item, high word score bits
   int *cand_cnt;                // [splits][U][2]
   int splits;                   // sweep splits (tiles interleaved)
@@ -86,35 +96,40 @@ struct PrefArgs {
 // ---- pack ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_items_bf16_kernel(const float *__restrict__ item_emb,
                                                               uint4 *__restrict__ packed, int64_t n_items, int D,
-                                                              int64_t n_tiles, uint32_t *__restrict__ imax2_bits) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-element fragment
+                                                              int64_t n_tiles, float *__restrict__ item_norm) {
+  // per tile Q = D/16 data fragments + ONE bound fragment: lane (r, h=0) holds k=0: 1.0, k=1: ||i_j|| (rounded up)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-element data fragment
   const int Q = D / 16;
-  const bool in = i < n_tiles * Q * 64;
+  if (i >= n_tiles * Q * 64) return;
   const int lane = (int)(i & 63);
   const int64_t tq = i >> 6;
   const int q = (int)(tq % Q);
   const int64_t t = tq / Q;
   const int64_t j = t * 32 + (lane & 31);
   const int h = lane >> 5;
-  float n2 = 0.f;
-  if (in) {
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (j < n_items) {
-      const float4 *src = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D + 16 * q + 8 * h);
-      v = bf16_pack8(src[0], src[1]);
-      if (q == 0 && h == 0) {
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (j < n_items) {
+    const float4 *src = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D + 16 * q + 8 * h);
+    v = bf16_pack8(src[0], src[1]);
+  }
+  packed[(t * (Q + 1) + q) * 64 + lane] = v;
+  if (q == 0) {
+    uint4 b = make_uint4(0u, 0u, 0u, 0u);
+    if (h == 0) {
+      float n2 = 0.f;
+      if (j < n_items) {
         const float4 *row = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D);
         for (int d = 0; d < D / 4; ++d) {
           const float4 x = row[d];
           n2 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
         }
       }
+      const float nu = bf16_ceil_pos(sqrtf(n2) * 1.0001f);   // (the fp32 sum / sqrt may round down: 1e-4 covers it)
+      item_norm[j] = nu;
+      b.x = 0x3F80u | ((__float_as_uint(nu) >> 16) << 16);
     }
-    packed[i] = v;
+    packed[(t * (Q + 1) + Q) * 64 + lane] = b;
   }
-  // one atomic per wave (norms are >= 0: float order == uint order)
-  for (int o = 32; o > 0; o >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, o, 64));
-  if ((threadIdx.x & 63) == 0 && n2 > 0.f) atomicMax(imax2_bits, __float_as_uint(n2));
 }
 
 template <int D>
@@ -136,15 +151,15 @@ __device__ __forceinline__ void load_user_frags(bf16x8 (&bu)[D / 16], float &nor
 }
 
 template <int D>
-__device__ __forceinline__ void load_item_frags_bf16(uint4 (&a)[D / 16], const uint4 *__restrict__ packed, int64_t t,
+__device__ __forceinline__ void load_item_frags_bf16(uint4 (&a)[D / 16 + 1], const uint4 *__restrict__ packed, int64_t t,
                                                      int lane) {
-  const uint4 *src = packed + (size_t)t * (D / 16) * 64 + lane;
+  const uint4 *src = packed + (size_t)t * (D / 16 + 1) * 64 + lane;
 #pragma unroll
-  for (int q = 0; q < D / 16; ++q) a[q] = src[q * 64];
+  for (int q = 0; q <= D / 16; ++q) a[q] = src[q * 64];   // a[D/16] = the bound fragment (1, ||i_j||)
 }
 
 template <int D>
-__device__ __forceinline__ f32x16 tile_scores_bf16(const uint4 (&a)[D / 16], const bf16x8 (&bu)[D / 16]) {
+__device__ __forceinline__ f32x16 tile_scores_bf16(const uint4 (&a)[D / 16 + 1], const bf16x8 (&bu)[D / 16]) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -255,6 +270,19 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   bf16x8 bu[D / 16];
   float n2;
   load_user_frags<D>(bu, n2, P.user_emb, u, u_ok, h);
+  n2 += __shfl_xor(n2, 32, 64);
+  // user side of the bound k-step: (0, -c||u||): with the items' (1, ||i_j||) the accumulator becomes the lower
+  // bound w_j = s~_j - e~_uj, which is what the threshold is estimated on
+  Frag16 fw;
+  fw.u = make_uint4(h == 0 ? (((__float_as_uint(bf16_ceil_pos(kBf16ErrCoef * sqrtf(n2) + 1e-30f)) >> 16) | 0x8000u) << 16) : 0u,
+                    0u, 0u, 0u);
+  const bf16x8 bw = fw.v;
+  auto tile_w = [&](const uint4 (&a)[D / 16 + 1]) __attribute__((always_inline)) {
+    f32x16 acc = tile_scores_bf16<D>(a, bu);
+    Frag16 fa;
+    fa.u = a[D / 16];
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bw, acc, 0, 0, 0);
+  };
 
   // The sample is taken on RAW scores (no history mask: a cursor over the history costs a dependent load in the
   // tile loop).  Interacted items usually score high, so the rank is shifted by h_s = the number of the user's
@@ -294,15 +322,15 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   int t_phase2 = t_first;
   {
     int t = t_first;
-    uint4 a[D / 16], an[D / 16];
+    uint4 a[D / 16 + 1], an[D / 16 + 1];
     if (t < n_tiles) load_item_frags_bf16<D>(a, P.packed, t, lane);
     for (int g = 0; g < 8 && t < n_tiles; ++g, t += step) {
       load_item_frags_bf16<D>(an, P.packed, t + step < n_tiles ? t + step : t, lane);
-      f32x16 acc = tile_scores_bf16<D>(a, bu);
+      f32x16 acc = tile_w(a);
       const uint32_t j0 = (uint32_t)t * 32u;
       apply_mask_and_range(acc, 0u, j0, n_items, h, P.mask_value);
 #pragma unroll
-      for (int q = 0; q < D / 16; ++q) a[q] = an[q];
+      for (int q = 0; q <= D / 16; ++q) a[q] = an[q];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const float x = acc[reg];
@@ -333,13 +361,13 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   {
     // item fragments three tiles ahead: one tile of this kernel is short (one user block), a single tile of
     // lookahead does not cover the L2 latency
-    uint4 ring[3][D / 16];
+    uint4 ring[3][D / 16 + 1];
     int t = t_phase2;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       load_item_frags_bf16<D>(ring[i], P.packed, t + i * step < n_tiles ? t + i * step : (n_tiles - 1), lane);
-    auto consume = [&](const uint4 (&a)[D / 16], int tt) __attribute__((always_inline)) {
-      f32x16 acc = tile_scores_bf16<D>(a, bu);
+    auto consume = [&](const uint4 (&a)[D / 16 + 1], int tt) __attribute__((always_inline)) {
+      f32x16 acc = tile_w(a);
       const uint32_t j0 = (uint32_t)tt * 32u;
       apply_mask_and_range(acc, 0u, j0, n_items, h, P.mask_value);
       uint32_t qbits = 0;
@@ -365,9 +393,9 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         if (t < n_tiles) {
-          uint4 cur[D / 16];
+          uint4 cur[D / 16 + 1];
 #pragma unroll
-          for (int q = 0; q < D / 16; ++q) cur[q] = ring[i][q];
+          for (int q = 0; q <= D / 16; ++q) cur[q] = ring[i][q];
           const int tp = t + 3 * step;
           load_item_frags_bf16<D>(ring[i], P.packed, tp < n_tiles ? tp : (n_tiles - 1), lane);
           consume(cur, t);
@@ -412,10 +440,11 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
 // tile's 16 compares become one bit mask per lane (v_sub + v_alignbit each), the scores are parked in a 4 KiB LDS
 // scratch ([reg][lane]) and ONE drain loop per user block stores the hits: every iteration is one store
 // instruction for all lanes that still hold a hit.
-// The threshold compare rides on the MFMA: the users' fragments are stored NEGATED and a fifth k-step multiplies a
-// constant 1 on the item side with the (bf16, rounded toward -inf) threshold on the user side, so the accumulator
-// holds theta~ - s~ and a hit is its sign bit (1 VALU op per score instead of a subtract and a shift-in).  The list
-// keeps s~' = theta~ - acc; the extra rounding (2^-23 relative) is inside kBf16ErrCoef.
+// The threshold compare rides on the MFMA: the users' fragments are stored NEGATED and an extra k-step multiplies the
+// items' (1, ||i_j||) with the users' (T_u, -c||u||) (bf16, T_u rounded toward -inf, the norms rounded up), so the
+// accumulator holds T_u - v_j, v_j = s~_j + e~_uj the upper bound of the score, and a hit is its sign bit (1 VALU op
+// per score instead of a subtract and a shift-in).  The list keeps v_j = T_u - acc; the extra rounding (2^-23
+// relative) is inside kBf16ErrCoef.
 __device__ __forceinline__ float bf16_floor(float x) {  // largest bf16-representable value <= x
   const uint32_t b = __float_as_uint(x);
   uint32_t t = b & 0xFFFF0000u;
@@ -437,9 +466,6 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
   float theta[UB];
   int cnt[UB];
   uint2 *mine[UB];
-  const float imax = sqrtf(__uint_as_float(*P.imax2_bits));
-  Frag16 one;   // item-side constant of the threshold k-step: A[row][k = 0] = 1
-  one.u = make_uint4(h == 0 ? 0x3F80u : 0u, 0u, 0u, 0u);
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
     const int64_t u = ((int64_t)blockIdx.x * UB + b) * 32 + ur;
@@ -457,24 +483,25 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
       bu[b][q] = f.v;
     }
     n2 += __shfl_xor(n2, 32, 64);
-    const float m = kBf16ErrCoef * sqrtf(n2) * imax + 1e-30f;
+    const float cu = bf16_ceil_pos(kBf16ErrCoef * sqrtf(n2) + 1e-30f);   // e~_uj = cu * item_norm[j]
     float th = INFINITY;  // padding users never qualify
     if (ok) {
-      th = bf16_floor(P.tau_sum[u] - 2.0f * m);
+      th = bf16_floor(P.tau_sum[u]);     // T_u: the sampler's estimate already lives in the lower-bound (w) domain
       if (split == 0 && h == 0) {
         P.theta[u] = th;
-        P.margin[u] = m;
+        P.margin[u] = cu;
       }
     }
     theta[b] = th;
+    // user side of the bound k-step: (T_u, -c||u||) against the items' (1, ||i_j||)
     Frag16 ft;
-    ft.u = make_uint4(h == 0 ? (__float_as_uint(th) >> 16) : 0u, 0u, 0u, 0u);
+    ft.u = make_uint4(h == 0 ? ((__float_as_uint(th) >> 16) | (((__float_as_uint(cu) >> 16) | 0x8000u) << 16)) : 0u, 0u, 0u, 0u);
     bth[b] = ft.v;
     cnt[b] = 0;
     mine[b] = reinterpret_cast<uint2 *>(P.cand) + (((size_t)split * P.n_users + (ok ? u : 0)) * 2 + h) * kPfCap;
   }
 
-  auto consume = [&](const uint4 (&a)[D / 16], int t) __attribute__((always_inline)) {
+  auto consume = [&](const uint4 (&a)[D / 16 + 1], int t) __attribute__((always_inline)) {
     const uint32_t j0 = (uint32_t)t * 32u;
     // all UB accumulation chains first, k-step major: UB independent MFMAs between two dependent ones
     f32x16 accs[UB];
@@ -489,9 +516,13 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
 #pragma unroll
       for (int b = 0; b < UB; ++b) accs[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v, bu[b][q], accs[b], 0, 0, 0);  // -s~
     }
+    {
+      Frag16 fa;
+      fa.u = a[D / 16];
 #pragma unroll
-    for (int b = 0; b < UB; ++b)
-      accs[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one.v, bth[b], accs[b], 0, 0, 0);  // theta~ - s~
+      for (int b = 0; b < UB; ++b)
+        accs[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bth[b], accs[b], 0, 0, 0);  // T_u - (s~ + e~) = T_u - v_j
+    }
 #pragma unroll
     for (int b = 0; b < UB; ++b) {
       f32x16 &acc = accs[b];
@@ -538,7 +569,7 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
 
   // item fragments three tiles ahead of the MFMAs (a tile of the sweep is ~1 us of work, an L2 round trip under
   // load is longer than that)
-  uint4 ring[3][D / 16];
+  uint4 ring[3][D / 16 + 1];
   int t = split;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -547,9 +578,9 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (t < n_tiles) {
-        uint4 cur[D / 16];
+        uint4 cur[D / 16 + 1];
 #pragma unroll
-        for (int q = 0; q < D / 16; ++q) cur[q] = ring[i][q];
+        for (int q = 0; q <= D / 16; ++q) cur[q] = ring[i][q];
         const int tp = t + 3 * splits;
         load_item_frags_bf16<D>(ring[i], P.packed, tp < n_tiles ? tp : (n_tiles - 1), lane);
         consume(cur, t);
@@ -636,7 +667,7 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
     he = P.hist_rowptr[u + 1];
   }
   const int deg = (int)(he - hb);
-  const float m = P.margin[u], theta = P.theta[u];
+  const float cu = P.margin[u], theta = P.theta[u];   // e~_uj = cu * item_norm[j];  theta = T_u
   const bool overflow = __any(c > kPfCap);
   int incl = c;
   for (int o = 1; o < 64; o <<= 1) {
@@ -645,7 +676,7 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
   }
   const int total = __shfl(incl, 63, 64);
   // reason codes (nonzero = re-run on the fp32 route): 1 list overflow, 2 fewer than K candidates, 3 more than 64*NRmax,
-  // 4 band reaches below the sweep threshold, 5 more than 128 items inside the band
+  // 4 L does not clear the sweep threshold, 5 more than 128 items whose upper bound reaches L
   // (the user's history is copied to LDS for the membership tests; it joins the candidates only when mask_value can
   //  reach the top-K, see below)
   int why = overflow ? 1 : (total + deg < K ? 2 : ((total > 64 * NRmax || deg > kPfHistLds) ? 3 : 0));
@@ -657,10 +688,13 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
     // every candidate key straight into registers: entry e of the user's concatenated lists sits in list
     // l = first list with incl[l] > e (lane-local binary search in LDS), all loads in flight together
     const uint2 *cand2 = reinterpret_cast<const uint2 *>(P.cand);
+    // key = (ord(w_j) << 32) | ~item with w_j = v_j - 2 e~_uj the lower bound of the score; vv = the stored upper bound
     uint64_t k[NRmax];
+    float vv[NRmax];
 #pragma unroll
     for (int r = 0; r < NRmax; ++r) {
       k[r] = 0ull;
+      vv[r] = -INFINITY;
       if (64 * r >= total) continue;   // wave-uniform: cost follows the actual key count
       const int e = lane + 64 * r;
       if (e < total) {
@@ -672,8 +706,8 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
         }
         const int pos = e - (lo ? incl_s[lo - 1] : 0);
         const uint2 raw = cand2[(((size_t)(lo >> 1) * P.n_users + u) * 2 + (lo & 1)) * kPfCap + pos];
-        const uint32_t ob = (raw.y & 0x80000000u) ? ~raw.y : (raw.y | 0x80000000u);
-        k[r] = ((uint64_t)ob << 32) | (uint64_t)(0xFFFFFFFFu - raw.x);
+        vv[r] = __uint_as_float(raw.y);
+        k[r] = make_key(vv[r] - 2.0f * (cu * P.item_norm[raw.x]), raw.x);
         // the sweep ran unmasked: a history member leaves the candidates here
         int l2 = 0, h2 = deg;
         while (l2 < h2) {
@@ -683,10 +717,10 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
         if (l2 < deg && hist_s[l2] == raw.x) k[r] = 0ull;
       }
     }
-    // A value that at least K entries of the masked row reach.  First over the unmasked candidates alone: the
-    // history's entries (all equal to mask_value) can only raise the row's K-th best, so this is a valid, possibly
-    // low, a_K.  Only if mask_value itself reaches the band below it (the reference's 1e-6 / 1e-5 does when every
-    // real score is tiny or negative: quirk Q7) does the history join the keys, and a_K is taken again.
+    // L: a value that the lower bounds w of at least K entries of the masked row reach.  First over the unmasked
+    // candidates alone: the history's entries (all equal to mask_value, error 0) can only raise the row's K-th best,
+    // so this is a valid, possibly low, L.  Only if mask_value itself reaches L (the reference's 1e-6 / 1e-5 does when
+    // every real score is tiny or negative: quirk Q7) does the history join the keys, and L is taken again.
     int total2 = total;
     auto kth = [&](int n_keys) -> uint32_t {
       if (n_keys <= 128) return kth_largest_ord<2, NRmax, 20>(k, K);
@@ -698,7 +732,7 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
 #pragma unroll
     for (int r = 0; r < NRmax; ++r) valid += __popcll(__ballot(k[r] != 0ull));
     uint32_t T = valid >= K ? kth(total) : 0u;
-    const bool hist_matters = deg > 0 && (valid < K || P.mask_value >= ord_to_f32(T) - 2.0f * m);
+    const bool hist_matters = deg > 0 && (valid < K || P.mask_value >= ord_to_f32(T));
     if (hist_matters) {   // wave-uniform
       if (total + deg > 64 * NRmax) {
         why = 3;
@@ -706,7 +740,10 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
 #pragma unroll
         for (int r = 0; r < NRmax; ++r) {
           const int e = lane + 64 * r;
-          if (e >= total && e < total + deg) k[r] = make_key(P.mask_value, hist_s[e - total]);
+          if (e >= total && e < total + deg) {
+            k[r] = make_key(P.mask_value, hist_s[e - total]);
+            vv[r] = P.mask_value;
+          }
         }
         total2 = total + deg;
         valid += deg;
@@ -714,15 +751,14 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
       }
     }
     if (why == 0 && valid < K) why = 2;
-    const float a_k = ord_to_f32(T);
-    const float cutoff = a_k - 2.0f * m;
-    if (why == 0 && !(cutoff > theta)) why = 4;  // items the sweep rejected could lie inside the band
+    const float cutoff = ord_to_f32(T);   // L (20-bit grid: at or below the exact K-th largest w)
+    if (why == 0 && !(cutoff > theta)) why = 4;  // L <= T_u: an item the sweep rejected (v <= T_u) could reach L
     // survivors: approximate score >= cutoff
     int base2 = 0;
 #pragma unroll
     for (int r = 0; r < NRmax; ++r) {
       if (64 * r >= total2) continue;
-      const bool keep = k[r] != 0ull && ord_to_f32((uint32_t)(k[r] >> 32)) >= cutoff;
+      const bool keep = k[r] != 0ull && vv[r] >= cutoff;   // upper bound reaches L
       const unsigned long long mk = __ballot(keep);
       const int pos = base2 + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
       if (keep && pos < kPfMaxRescore) keep_item[pos] = 0xFFFFFFFFu - (uint32_t)(k[r] & 0xFFFFFFFFull);

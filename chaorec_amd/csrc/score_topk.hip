@@ -789,7 +789,7 @@ struct ScorePlan {
   bool prefilter;
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
   bool pf_sample_long;
-  size_t off_pf_heavy, off_pf_fb, off_pf_fbdone, off_pf_fbpart;
+  size_t off_pf_heavy, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_margin, off_pf_cand, off_pf_cnt;
   size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
 };
@@ -877,7 +877,8 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.pf_sample_rank = p.pf_sample_long ? 14 : 10;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
-  p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 32 * (size_t)D * 2 : 0);
+  p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 64 * (size_t)(D / 16 + 1) * 16 : 0);
+  p.off_pf_inorm = take(p.prefilter ? (size_t)n_tiles * 32 * 4 : 0);
   p.off_pf_scalars = take(p.prefilter ? 256 : 0);
   p.off_pf_tau = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_heavy = take(p.prefilter ? (size_t)n_users * 4 : 0);
@@ -1009,7 +1010,7 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.mask_value = mask_value;
     P.K = K;
     P.id_offset = id_offset;
-    P.imax2_bits = (uint32_t *)(ws + p.off_pf_scalars);
+    P.item_norm = (float *)(ws + p.off_pf_inorm);
     P.heavy_cnt = (int *)(ws + p.off_pf_scalars + 64);
     P.heavy_list = (int *)(ws + p.off_pf_heavy);
     P.fb_cnt = (int *)(ws + p.off_pf_scalars + 128);
@@ -1030,12 +1031,12 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.out_val = out_val;
     int *failf = (int *)(ws + p.off_fail);
     P.fail = failf;
-    if (hipMemsetAsync(P.imax2_bits, 0, 256, st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
+    if (hipMemsetAsync(ws + p.off_pf_scalars, 0, 256, st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
     if (hipMemsetAsync(P.tau_sum, 0, (size_t)n_users * 4, st) != hipSuccess)
       return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
     const int64_t nfrag = n_tiles * (D / 16) * 64;
     hipLaunchKernelGGL(pack_items_bf16_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, item_emb,
-                       (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.imax2_bits);
+                       (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.item_norm);
     rc = check_launch("pack_items_bf16_kernel");
     if (rc) return rc;
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);

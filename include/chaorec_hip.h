@@ -162,11 +162,11 @@ int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *his
  *     for s in [0, C/2): acc = fmaf(u[b+s], i[b+s], acc); acc = fmaf(u[b+C/2+s], i[b+C/2+s], acc)
  * `precision` selects the route to it:
  *   0  fastest exact route.  D in {64, 128} and >= 8192 items: the [U, I] sweep runs on the bf16 MFMA pipe
- *      (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) as a PREFILTER with a proven error bound
- *      |s~ - s| <= m_u = 1.02 * 2^-8 * ||u|| * max_j ||i_j||; every item within 2 m_u of the K-th best
- *      approximate score is re-scored with the exact fp32 chain and the top-K is ranked on those values; a user
- *      the bound cannot certify (list overflow, too few candidates, band too wide) is re-run on the fp32 route.
- *      Otherwise: route 2.
+ *      (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) as a PREFILTER with a proven per-item error bound
+ *      |s~ - s| <= e_uj = 1.05 * 2^-8 * ||u|| * ||i_j||: with L a lower bound of the K-th best exact score (the K-th
+ *      largest s~ - e over the candidates), every item with s~ + e >= L is re-scored with the exact fp32 chain and
+ *      the top-K is ranked on those values; a user the bound cannot certify (list overflow, too few candidates, more
+ *      than 128 items to re-score) gets all its scores computed exactly.  Otherwise: route 2.
  *   1  one unthresholded fp32 MFMA pass (A/B runs and tests).
  *   2  fp32 MFMA sweep with a sampled per-user threshold: tau0 = 32nd best score over every s-th 32-item tile,
  *      the full pass keeps only scores above it, a certification step counts them and any user with fewer
@@ -188,7 +188,7 @@ int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
 /* Monitoring: what the prefilter route of the LAST chaorec_score_topk_f32 call on this workspace did (same sizes).
  * out9 (device, 9 x uint64): [0] users re-run on the fp32 route, [1] candidate keys kept by the bf16 sweep in
  * total, [2] longest per-lane list, [3] users, [4..8] re-run users by reason (list overflow, fewer than K
- * candidates, more than 512, error band below the sweep threshold, more than 128 items in the band).
+ * candidates, more than the key slots, lower bound L not above the sweep threshold, more than 128 items to re-score).
  * All zeros if that call did not take the prefilter route. */
 int chaorec_score_topk_stats(const void *workspace, int64_t n_users, int64_t n_items, int32_t K, int32_t D,
                              uint64_t *out9, void *stream);
