@@ -578,12 +578,9 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (t < n_tiles) {
-        uint4 cur[D / 16 + 1];
-#pragma unroll
-        for (int q = 0; q <= D / 16; ++q) cur[q] = ring[i][q];
+        consume(ring[i], t);          // (reload after use: no register copy of the fragment set, two tiles of lookahead)
         const int tp = t + 3 * splits;
         load_item_frags_bf16<D>(ring[i], P.packed, tp < n_tiles ? tp : (n_tiles - 1), lane);
-        consume(cur, t);
         t += splits;
       }
     }
