@@ -789,7 +789,7 @@ struct ScorePlan {
   bool prefilter;
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
   bool pf_sample_long;
-  size_t off_pf_heavy, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm;
+  size_t off_pf_heavy, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_margin, off_pf_cand, off_pf_cnt;
   size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
 };
@@ -879,11 +879,13 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 64 * (size_t)(D / 16 + 1) * 16 : 0);
   p.off_pf_inorm = take(p.prefilter ? (size_t)n_tiles * 32 * 4 : 0);
+  // scalars | tau_sum | fb_done sit back to back: zeroed by ONE memset per call
   p.off_pf_scalars = take(p.prefilter ? 256 : 0);
   p.off_pf_tau = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_fbdone = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.pf_zero_bytes = o - p.off_pf_scalars;
   p.off_pf_heavy = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fb = take(p.prefilter ? (size_t)n_users * 4 : 0);
-  p.off_pf_fbdone = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fbpart = take(p.prefilter ? (size_t)n_users * kExSlices * kMaxK * 8 : 0);
   p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_margin = take(p.prefilter ? (size_t)n_users * 4 : 0);
@@ -1017,7 +1019,6 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.fb_list = (int *)(ws + p.off_pf_fb);
     P.fb_done = (int *)(ws + p.off_pf_fbdone);
     P.fb_partial = (uint64_t *)(ws + p.off_pf_fbpart);
-    if (hipMemsetAsync(P.fb_done, 0, (size_t)n_users * 4, st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
     P.tau_sum = (float *)(ws + p.off_pf_tau);
     P.theta = (float *)(ws + p.off_pf_theta);
     P.margin = (float *)(ws + p.off_pf_margin);
@@ -1031,8 +1032,7 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.out_val = out_val;
     int *failf = (int *)(ws + p.off_fail);
     P.fail = failf;
-    if (hipMemsetAsync(ws + p.off_pf_scalars, 0, 256, st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
-    if (hipMemsetAsync(P.tau_sum, 0, (size_t)n_users * 4, st) != hipSuccess)
+    if (hipMemsetAsync(ws + p.off_pf_scalars, 0, p.pf_zero_bytes, st) != hipSuccess)
       return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
     const int64_t nfrag = n_tiles * (D / 16) * 64;
     hipLaunchKernelGGL(pack_items_bf16_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, item_emb,
