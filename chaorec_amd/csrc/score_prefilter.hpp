@@ -452,11 +452,22 @@ __device__ __forceinline__ float bf16_floor(float x) {  // largest bf16-represen
   return __uint_as_float(t);
 }
 
+// A workgroup is kSweepWaves waves = kSweepWaves x UB x 32 users that walk the SAME tiles: every item fragment is
+// fetched from L2/HBM once per workgroup into an LDS stage (kSweepStage tiles per barrier, double-buffered) and read
+// from there by all its waves -- with one wave per workgroup the sweep streamed the whole packed item table once per
+// 64 users (1.1 GB per sports sweep, 11 TB at 1.25 M users x 2 M items).
+constexpr int kSweepWaves = 4;
+constexpr int kSweepStage = 2;
+
 template <int D, int UB>
-__global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) {
-  __shared__ float4 park[4 * 64];   // [quad][lane]: registers 4*quad .. 4*quad+3 of the lane
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(const PrefArgs P) {
+  constexpr int FR = D / 16 + 1;                       // fragments (1 KiB each) per tile
+  __shared__ float4 park_all[kSweepWaves][4 * 64];     // per wave: [quad][lane], registers 4*quad .. 4*quad+3
+  __shared__ uint4 stage[2][kSweepStage][FR * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float4 *park = park_all[wv];
   const int ur = lane & 31, h = lane >> 5;
+  const int64_t ublock0 = ((int64_t)blockIdx.x * kSweepWaves + wv) * UB;
   const uint32_t n_items = (uint32_t)P.n_items;
   const int n_tiles = (int)((P.n_items + 31) / 32);
   const int split = blockIdx.y;
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
   uint2 *mine[UB];
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
-    const int64_t u = ((int64_t)blockIdx.x * UB + b) * 32 + ur;
+    const int64_t u = (ublock0 + b) * 32 + ur;
     const bool ok = u < P.n_users;
     float n2;
     load_user_frags<D>(bu[b], n2, P.user_emb, u, ok, h);
@@ -567,27 +578,54 @@ __global__ __launch_bounds__(64) void score_sweep_bf16_kernel(const PrefArgs P) 
     }
   };
 
-  // item fragments three tiles ahead of the MFMAs (a tile of the sweep is ~1 us of work, an L2 round trip under
-  // load is longer than that)
-  uint4 ring[3][D / 16 + 1];
-  int t = split;
+  // stage s = tiles split + (kSweepStage * s + i) * splits, i < kSweepStage.  Global -> registers for stage s + 1
+  // while stage s is consumed from LDS; one barrier per stage.
+  constexpr int PER = (kSweepStage * FR * 64 + 64 * kSweepWaves - 1) / (64 * kSweepWaves);   // uint4 per thread and stage
+  uint4 pre[PER];
+  auto fetch = [&](int s0) __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-    load_item_frags_bf16<D>(ring[i], P.packed, t + i * splits < n_tiles ? t + i * splits : (n_tiles - 1), lane);
-  while (t < n_tiles) {
+    for (int p = 0; p < PER; ++p) {
+      const int e = threadIdx.x + p * 64 * kSweepWaves;          // element of the stage: tile slot i, fragment word w
+      const int i = e / (FR * 64), w = e % (FR * 64);
+      int tt = split + (kSweepStage * s0 + i) * splits;
+      if (tt >= n_tiles) tt = n_tiles - 1;                        // (a slot past the end is loaded, never consumed)
+      pre[p] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < kSweepStage) pre[p] = P.packed[(size_t)tt * (FR * 64) + w];
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (t < n_tiles) {
-        consume(ring[i], t);          // (reload after use: no register copy of the fragment set, two tiles of lookahead)
-        const int tp = t + 3 * splits;
-        load_item_frags_bf16<D>(ring[i], P.packed, tp < n_tiles ? tp : (n_tiles - 1), lane);
-        t += splits;
+    for (int p = 0; p < PER; ++p) {
+      const int e = threadIdx.x + p * 64 * kSweepWaves;
+      if (e < kSweepStage * FR * 64) (&stage[buf][0][0])[e] = pre[p];
+    }
+  };
+  const int n_mine = split < n_tiles ? (n_tiles - split + splits - 1) / splits : 0;   // tiles of this split
+  const int n_stages = (n_mine + kSweepStage - 1) / kSweepStage;
+  if (n_stages > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int s0 = 0; s0 < n_stages; ++s0) {
+    const int buf = s0 & 1;
+    if (s0 + 1 < n_stages) fetch(s0 + 1);
+#pragma unroll
+    for (int i = 0; i < kSweepStage; ++i) {
+      const int t = split + (kSweepStage * s0 + i) * splits;
+      if (t < n_tiles) {                                          // block-uniform
+        uint4 a[FR];
+#pragma unroll
+        for (int q = 0; q < FR; ++q) a[q] = stage[buf][i][q * 64 + lane];
+        consume(a, t);
       }
     }
+    if (s0 + 1 < n_stages) stash(buf ^ 1);
+    __syncthreads();
   }
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
-    const int64_t u = ((int64_t)blockIdx.x * UB + b) * 32 + ur;
+    const int64_t u = (ublock0 + b) * 32 + ur;
     if (u < P.n_users) P.cand_cnt[((size_t)split * P.n_users + u) * 2 + h] = cnt[b];
   }
 }

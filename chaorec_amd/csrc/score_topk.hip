@@ -810,14 +810,14 @@ static int sweep_wave_slots(int D) {
   hipError_t e = hipGetDevice(&dev);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e == hipSuccess) {
-    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>, 64, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>, 64, 0);
+    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>, 64 * kSweepWaves, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>, 64 * kSweepWaves, 0);
   }
   if (e != hipSuccess || per_cu <= 0 || cus <= 0) {
     (void)hipGetLastError();
-    return 2048;   // not cached: a later call with a device asks again
+    return 1024;   // (4 workgroups x 256 CUs) not cached: a later call with a device asks again
   }
-  c = per_cu * cus;
+  c = per_cu * cus;      // workgroup slots (kSweepWaves waves each)
   return c;
 }
 
@@ -859,22 +859,27 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.prefilter = (D == 64 || D == 128) && K <= 64 && n_tiles >= 256;
   p.pf_ub = D == 64 ? CHAOREC_PF_UB64 : CHAOREC_PF_UB128;
   {
-    const int64_t ublocks = (groups + p.pf_ub - 1) / p.pf_ub;
+    const int64_t ublocks = (groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves);   // workgroups per split
     // one full round of 2 waves per SIMD (2048 slots) when the user blocks allow it: a second, partly filled
     // round costs a whole wave time
     int64_t sp = sweep_wave_slots(D) / ublocks;
-    if (sp < 6) sp = 6;     // ~200 candidates per user over 2 * splits lists of kPfCap = 64: keep the lists short
+    // ~200 candidates per user (~300 with the coarser sample of very long item ranges) over 2 * splits lists of
+    // kPfCap = 64: keep the lists short
+    const int64_t sp_min = n_tiles > 16384 ? 10 : 6;
+    if (sp < sp_min) sp = sp_min;
     if (sp > 16) sp = 16;
     if (sp > n_tiles / 16) sp = n_tiles / 16;
     if (sp < 1) sp = 1;
     p.pf_splits = (int)sp;
   }
-  p.pf_sample_stride = 4;
+  // very long item ranges: every 8th tile still samples >= 64 k items per user, and the sampler streams the packed
+  // table once per 32 users
+  p.pf_sample_stride = n_tiles > 16384 ? 8 : 4;
   // a sampler wave's share of the sample fits its 24-slot lists up to ~16 k items; longer ranges take the
   // streaming-top-r instantiation (32 slots, fewer and longer waves)
   p.pf_sample_long = n_tiles > 512;
   p.pf_sample_splits = p.pf_sample_long ? 3 : 4;
-  p.pf_sample_rank = p.pf_sample_long ? 14 : 10;
+  p.pf_sample_rank = p.pf_sample_long ? (p.pf_sample_stride == 8 ? 10 : 14) : 10;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 64 * (size_t)(D / 16 + 1) * 16 : 0);
@@ -1040,17 +1045,17 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     rc = check_launch("pack_items_bf16_kernel");
     if (rc) return rc;
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);
-    const dim3 gw((unsigned)((groups + p.pf_ub - 1) / p.pf_ub), (unsigned)p.pf_splits);
+    const dim3 gw((unsigned)((groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves)), (unsigned)p.pf_splits);
     if (D == 64) {
       if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true>), gs, dim3(64), 0, st, P);
       else hipLaunchKernelGGL((score_sample_bf16_kernel<64, 24, false>), gs, dim3(64), 0, st, P);
-      hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64), 0, st, P);
+      hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64 * kSweepWaves), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_kernel<64>, dim3((unsigned)n_users), dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_wide_kernel<64>, dim3(512), dim3(64), 0, st, P);
     } else {
       if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true>), gs, dim3(64), 0, st, P);
       else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false>), gs, dim3(64), 0, st, P);
-      hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64), 0, st, P);
+      hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_kernel<128>, dim3((unsigned)n_users), dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_wide_kernel<128>, dim3(512), dim3(64), 0, st, P);
     }
