@@ -278,9 +278,9 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   // few output tiles and a long reduction (weight gradients: K = number of graph nodes): split K so that the
   // chip is filled, partial sums go to slabs and are added in a fixed order
   if (tiles < 128 && K >= 4096) {
-    int64_t s = (512 + tiles - 1) / tiles;
-    if (s > K / 1024) s = K / 1024;
-    if (s > 64) s = 64;
+    int64_t s = (1024 + tiles - 1) / tiles;     // ~4 workgroups per CU
+    if (s > K / 256) s = K / 256;               // at least 16 k-tiles per workgroup
+    if (s > 256) s = 256;
     if (s < 1) s = 1;
     p.splits = (int)s;
   }
