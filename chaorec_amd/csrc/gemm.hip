@@ -16,23 +16,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // along whichever dimension is contiguous in memory) while the current one feeds the MFMAs.  A k-step of the
 // f32 MFMA consumes k = 2s (lanes 0-31) and 2s+1 (lanes 32-63): the per-element sum is the k-ascending fmaf
 // chain of oracle_gemm_f32 -- also across split-K slabs only up to the order of the final slab sum.
-constexpr int BM = 128, BK = 16, PAD = 4;
+constexpr int BK = 16, PAD = 4;
 
-template <int BN>
+// <BM, BN> in {(128,128): waves 2x2 of 64x64; (128,64): waves 4x1 of 32x64; (64,128): waves 2x2 of 32x64 -- the last
+// for outputs with <= 64 rows (weight gradients of 64-wide layers), where a 128-row tile would be half padding}
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
     const float *__restrict__ bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
     int64_t ldc, int transA, int transB, int accumulate, int act, int64_t k_per_split,
     float *__restrict__ slabs) {
-  constexpr int WM = BN == 128 ? 2 : 1;   // 32-row accumulator blocks per wave
+  constexpr int WM = (BM == 128 && BN == 128) ? 2 : 1;   // 32-row accumulator blocks per wave
   constexpr int WN = 2;                   // 32-col accumulator blocks per wave
   __shared__ float As[2][BK][BM + PAD];
   __shared__ float Bs[2][BK][BN + PAD];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int wrow = BN == 128 ? (wave >> 1) * 64 : wave * 32;
-  const int wcol = BN == 128 ? (wave & 1) * 64 : 0;
+  const int wrow = BN == 64 ? wave * 32 : (wave >> 1) * (BM / 2);
+  const int wcol = BN == 64 ? 0 : (wave & 1) * 64;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int64_t n0 = (int64_t)blockIdx.y * BN;
   const int64_t kb = (int64_t)blockIdx.z * k_per_split;
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float *__r
 }
 
 struct GemmPlan {
+  int bm;
   int bn;
   int splits;
   int64_t k_per_split;
@@ -273,7 +276,8 @@ struct GemmPlan {
 static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   GemmPlan p;
   p.bn = N <= 64 ? 64 : 128;
-  const int64_t tiles = ((M + BM - 1) / BM) * ((N + p.bn - 1) / p.bn);
+  p.bm = (M <= 64 && p.bn == 128) ? 64 : 128;
+  const int64_t tiles = ((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn);
   p.splits = 1;
   // few output tiles and a long reduction (weight gradients: K = number of graph nodes): split K so that the
   // chip is filled, partial sums go to slabs and are added in a fixed order
@@ -376,12 +380,15 @@ extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const 
     return fail(CHAOREC_E_WORKSPACE, "gemm: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
-  const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + p.bn - 1) / p.bn), (unsigned)p.splits);
+  const dim3 grid((unsigned)((M + p.bm - 1) / p.bm), (unsigned)((N + p.bn - 1) / p.bn), (unsigned)p.splits);
   if (p.bn == 64)
-    hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 64>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
+                       transB, accumulate, act, p.k_per_split, slabs);
+  else if (p.bm == 64)
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 128>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
                        transB, accumulate, act, p.k_per_split, slabs);
   else
-    hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
                        transB, accumulate, act, p.k_per_split, slabs);
   int rc = check_launch("gemm_f32_kernel");
   if (rc || p.splits == 1) return rc;
