@@ -102,7 +102,8 @@ class GraphedTrainStep:
         # A model that already trained eagerly keeps its last autograd graph alive through `self.result` (the
         # reference's stale-result quirk), and with it AccumulateGrad nodes bound to the default stream: capturing
         # a backward that reuses them on the capture stream breaks the capture.  Cut that reference first.
-        if torch.is_tensor(getattr(model, "result", None)) and model.result.grad_fn is not None:
+        if (not isinstance(getattr(type(model), "result", None), property)
+                and torch.is_tensor(getattr(model, "result", None)) and model.result.grad_fn is not None):
             model.result = model.result.detach()     # (no local name may keep the old tensor alive either)
         # The warm-up steps (they build lazily cached state: graph schedules, Adam moments, allocator pools) must
         # not count as training: parameters and optimizer state are put back afterwards.
@@ -133,7 +134,9 @@ class GraphedTrainStep:
             self.static_loss = self._eager(self.static)
         # the captured forward's output buffer: every replay rewrites it, and model.result must keep pointing at it
         # (an eager step in between -- the short last batch of an epoch -- rebinds model.result to its own tensor)
-        self._captured_result = getattr(model, "result", None) if torch.is_tensor(getattr(model, "result", None)) else None
+        plain_attr = not isinstance(getattr(type(model), "result", None), property)   # (a sharded model derives it)
+        res = getattr(model, "result", None) if plain_attr else None
+        self._captured_result = res if torch.is_tensor(res) else None
         self.replays = 0
 
     def _eager(self, batch):
