@@ -250,16 +250,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
   }
 }
 
-// split-K second pass: C = sum_z slab[z] (z ascending, fixed order) (+ bias) (+ C) (+ act)
+// split-K second pass: C = sum_z slab[z] (+ bias) (+ C) (+ act), in a FIXED order: 8 lanes per output element take the
+// slabs z = l, l+8, ... in ascending order (each 32-thread group reads 32 consecutive elements of a slab: coalesced),
+// then the 8 partial sums are added in lane order.  Deterministic; 8x the parallelism of one thread per element
+// (the output is small -- e.g. 64 x 320 -- and there are up to 256 slabs).
+constexpr int kRedLanes = 8;
 __global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits,
                                                                 float *__restrict__ C, const float *__restrict__ bias,
                                                                 int64_t M, int64_t N, int64_t ldc, int accumulate,
                                                                 int act) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * N) return;
-  const int64_t m = i / N, n = i % N;
+  __shared__ float part[kRedLanes][32];
+  const int e = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
+  const size_t mn = (size_t)M * (size_t)N;
   float v = 0.f;
-  for (int z = 0; z < splits; ++z) v = v + slabs[(size_t)z * (size_t)M * (size_t)N + i];
+  if (i < (int64_t)mn)
+    for (int z = l; z < splits; z += kRedLanes) v = v + slabs[(size_t)z * mn + i];
+  part[l][e] = v;
+  __syncthreads();
+  if (l != 0 || i >= (int64_t)mn) return;
+#pragma unroll
+  for (int k = 1; k < kRedLanes; ++k) v = v + part[k][e];
+  const int64_t m = i / N, n = i % N;
   if (bias) v = v + bias[n];
   if (accumulate) v = C[m * ldc + n] + v;
   if (act == 1) v = v > 0.f ? v : v * 0.01f;
@@ -392,7 +404,7 @@ extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const 
                        transB, accumulate, act, p.k_per_split, slabs);
   int rc = check_launch("gemm_f32_kernel");
   if (rc || p.splits == 1) return rc;
-  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, st, slabs,
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs,
                      p.splits, C, bias, M, N, ldc, accumulate, act);
   return check_launch("gemm_reduce_slabs_kernel");
 }
