@@ -142,6 +142,7 @@ class _BPR(torch.autograd.Function):
         ctx.save_for_backward(tab_u, tab_i, users, pos, neg, coef)
         ctx.reg_weight, ctx.item_offset = reg_weight, item_offset
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient tensor for `out` on every backward
         return loss, out
 
     @staticmethod

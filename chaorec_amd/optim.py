@@ -96,6 +96,7 @@ class GraphedTrainStep:
         graph (device-side sampling from a device counter), and the step is then called with no arguments."""
         self.model, self.optimizer, self.batch_fn = model, optimizer, batch_fn
         self.loss_fn = loss_fn or model.loss
+        self._seed = None
         dev = next(model.parameters()).device
         self.static = [b.to(dev).clone() for b in example_batch] if example_batch is not None else None
         self.shapes = [tuple(b.shape) for b in self.static] if self.static is not None else None
@@ -144,7 +145,9 @@ class GraphedTrainStep:
             batch = self.batch_fn()
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fn(*batch)
-        loss.backward()
+        if self._seed is None or self._seed.shape != loss.shape or self._seed.device != loss.device:
+            self._seed = torch.ones_like(loss)          # d(loss)/d(loss), kept: autograd would fill a fresh one per step
+        loss.backward(self._seed)
         self.optimizer.step()
         return loss.detach()
 
