@@ -90,7 +90,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
-    if lib.chaorec_abi_version() != 1:
+    if lib.chaorec_abi_version() != 2:
         raise RuntimeError("libchaorec_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -3,18 +3,19 @@
 // Replaces gene_ranklist's torch.matmul + python mask loop + torch.topk
 // (Model/LightGCN.py:147-155, Model/FREEDOM.py:230-238, Model/MMGCN.py:220-230).
 //
-// precision 0 (this file): exact fp32 on the f32 MFMA pipe, v_mfma_f32_32x32x2_f32.
-//   One wave64 = 32 users x a stream of 32-item tiles.  Items are the MFMA A rows, users the
-//   B columns, so the 32x32 accumulator puts ONE user on each lane (column = lane & 31) with
-//   16 of the tile's items in its registers: selection needs no cross-lane traffic.
-//   The users' fragment (D/2 floats per lane) stays in registers for the whole stream; item
-//   fragments come straight from global/L2 (the item table is a few MB and shared by every
-//   wave), prefetched one tile ahead of the 32*D MFMA cycles that consume them.
-//   Selection: per-user threshold tau (current K-th best) in a register; a score that beats
-//   tau is appended to the user's 128-entry LDS candidate list with a slot computed from
-//   popcounts (no atomics); a list that could overflow is pruned back to K by a wave-wide
-//   register bitonic sort of 64-bit keys (score bits | inverted item index), which also
-//   yields the new tau.  Ties: the key orders equal scores by ascending item index.
+// Three routes to the same result -- the exact top-K of the fp32 scores defined by the k-ordered fmaf chain of
+// v_mfma_f32_32x32x2_f32 (oracle_score_dot), ties to the lowest index:
+//   precision 0  bf16-MFMA prefilter + exact fp32 re-score (score_prefilter.hpp) where it applies, else route 2
+//   precision 2  fp32 MFMA sweep with sampled thresholds: score_candidates_kernel + score_select_kernel (this file)
+//   precision 1  one unthresholded fp32 pass: score_topk_f32_kernel (this file; also the streamed-K kNN build)
+// Common geometry of the fp32 kernels: one wave64 = 32 users x a stream of 32-item tiles.  Items are the MFMA A
+// rows, users the B columns, so the 32x32 accumulator puts ONE user on each lane (column = lane & 31) with 16 of
+// the tile's items in its registers: selection needs no cross-lane traffic.  The users' fragment (D/2 floats per
+// lane) stays in registers for the whole stream; item fragments come straight from global/L2, prefetched one tile
+// ahead of the 32*D MFMA cycles that consume them.  score_topk_f32_kernel keeps a per-user threshold (current K-th
+// best) in a register; a score that beats it is appended to the lane's LDS candidate list; a list that could
+// overflow is pruned back to K by a wave-wide register bitonic sort of 64-bit keys (score bits | inverted item
+// index), which also yields the new threshold.  Ties: the key orders equal scores by ascending item index.
 #include "common.h"
 #include <limits.h>
 

@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/chaorec_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes table and header drifted"
-    assert _lib.load().chaorec_abi_version() == 1
+    assert _lib.load().chaorec_abi_version() == 2
     assert _lib.load().chaorec_spmm_rows_per_wave(64) == 4
     assert _lib.load().chaorec_spmm_rows_per_wave(128) == 2
     assert _lib.load().chaorec_score_topk_workspace_bytes(28940, 15207, 50, 64) > 0
