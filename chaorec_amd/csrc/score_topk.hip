@@ -857,7 +857,7 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
     }
   }
   // bf16 prefilter + exact re-score: D in {64, 128}, enough tiles for the sampler's statistics
-  p.prefilter = (D == 64 || D == 128) && K <= 64 && n_tiles >= 256;
+  p.prefilter = (D == 64 || D == 128) && K <= 64 && n_tiles >= 128;
   p.pf_ub = D == 64 ? CHAOREC_PF_UB64 : CHAOREC_PF_UB128;
   {
     const int64_t ublocks = (groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves);   // workgroups per split

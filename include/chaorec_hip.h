@@ -161,7 +161,7 @@ int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *his
  * D <= 128, C = 64 above), per chunk base b:
  *     for s in [0, C/2): acc = fmaf(u[b+s], i[b+s], acc); acc = fmaf(u[b+C/2+s], i[b+C/2+s], acc)
  * `precision` selects the route to it:
- *   0  fastest exact route.  D in {64, 128} and >= 8192 items: the [U, I] sweep runs on the bf16 MFMA pipe
+ *   0  fastest exact route.  D in {64, 128} and >= 4096 items: the [U, I] sweep runs on the bf16 MFMA pipe
  *      (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) as a PREFILTER with a proven per-item error bound
  *      |s~ - s| <= e_uj = 1.05 * 2^-8 * ||u|| * ||i_j||: with L a lower bound of the K-th best exact score (the K-th
  *      largest s~ - e over the candidates), every item with s~ + e >= L is re-scored with the exact fp32 chain and

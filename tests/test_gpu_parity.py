@@ -346,7 +346,7 @@ def test_score_topk_sampled_threshold_fallback(dev, oracle):
         assert np.array_equal(got_i.cpu().numpy(), want_i), precision
 
 
-# ---- bf16 prefilter + exact fp32 re-score (precision 0 at >= 8192 items, D in {64, 128}) -------------------
+# ---- bf16 prefilter + exact fp32 re-score (precision 0 at >= 4096 items, D in {64, 128}) -------------------
 def _check_all_precisions(dev, oracle, ue, ie, hist, mask, K, id_offset=0):
     from chaorec_amd import ops
     want_i, want_v = oracle.score_topk(ue, ie, hist, mask, K, id_offset)
