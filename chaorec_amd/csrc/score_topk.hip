@@ -875,12 +875,12 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   }
   // very long item ranges: every 8th tile still samples >= 64 k items per user, and the sampler streams the packed
   // table once per 32 users
-  p.pf_sample_stride = n_tiles > 16384 ? 8 : 4;
+  p.pf_sample_stride = n_tiles > 32768 ? 16 : (n_tiles > 16384 ? 8 : 4);
   // a sampler wave's share of the sample fits its 24-slot lists up to ~16 k items; longer ranges take the
   // streaming-top-r instantiation (32 slots, fewer and longer waves)
   p.pf_sample_long = n_tiles > 512;
   p.pf_sample_splits = p.pf_sample_long ? 3 : 4;
-  p.pf_sample_rank = p.pf_sample_long ? (p.pf_sample_stride == 8 ? 10 : 14) : 10;
+  p.pf_sample_rank = p.pf_sample_long ? (p.pf_sample_stride == 16 ? 7 : (p.pf_sample_stride == 8 ? 10 : 14)) : 10;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 64 * (size_t)(D / 16 + 1) * 16 : 0);

@@ -360,7 +360,8 @@ def _check_all_precisions(dev, oracle, ue, ie, hist, mask, K, id_offset=0):
 
 @pytest.mark.parametrize("U,I,D,K", [(150, 9000, 64, 50), (70, 8200, 128, 20), (33, 12000, 64, 64),
                                      (129, 8192, 64, 1), (300, 15207, 64, 50), (64, 150000, 64, 50),
-                                     (40, 560000, 64, 50)])     # > 16384 tiles: coarser sample, more sweep splits
+                                     (40, 560000, 64, 50),      # > 16384 tiles: coarser sample, more sweep splits
+                                     (16, 1100000, 64, 50)])    # > 32768 tiles: every 16th tile sampled
 def test_score_topk_prefilter_bit_exact_vs_oracle(dev, oracle, U, I, D, K):
     rng = np.random.default_rng(U + I + D)
     ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
