@@ -253,13 +253,22 @@ __device__ __forceinline__ void sample_prune(float *lst, int lane, int &cnt, flo
 // over the user's two lanes); the user's threshold is the mean of the sample splits' estimates.
 // CAP / PRUNE: short item ranges (a wave's sample fits the list) run without the streaming-top-r code -- it doubles
 // the kernel's size and costs more than it saves there; long ranges need it (see sample_prune).
-template <int D, int CAP, bool PRUNE>
-__global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P) {
-  __shared__ float lst[CAP * 64];  // [slot][lane]: conflict-free for lane-local walks
-  __shared__ float park[16 * 64];
-  const int lane = threadIdx.x;
+// WG waves per workgroup (one user block each, same tiles, loosely in step through a barrier every 4 tiles): for
+// item tables beyond L2 the waves of a workgroup then find each other's fragment loads in the CU's L1 instead of
+// each streaming the table from HBM / Infinity Cache.  WG = 1 for tables that sit in L2 anyway.
+template <int D, int CAP, bool PRUNE, int WG>
+__global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefArgs P) {
+  __shared__ float lst_all[WG][CAP * 64];  // per wave [slot][lane]: conflict-free for lane-local walks
+  __shared__ float park_all[WG][16 * 64];
+  __shared__ int64_t rp_all[WG][33];
+  __shared__ int hs_all[WG][32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *lst = lst_all[wv], *park = park_all[wv];
+  int64_t *rp_s = rp_all[wv];
+  int *hs_s = hs_all[wv];
   const int ur = lane & 31, h = lane >> 5;
-  const int64_t u = (int64_t)blockIdx.x * 32 + ur;
+  const int64_t ublock = (int64_t)blockIdx.x * WG + wv;
+  const int64_t u = ublock * 32 + ur;
   const bool u_ok = u < P.n_users;
   const uint32_t n_items = (uint32_t)P.n_items;
   const int n_tiles = (int)((P.n_items + 31) / 32);
@@ -290,11 +299,9 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
   // masked one whenever mask_value does not matter, and any value is a valid threshold anyway (certification).
   // (counted by the whole wave over the block's contiguous CSR range: a per-lane walk of the own row is a chain of
   //  dependent loads as long as the heaviest user's history)
-  __shared__ int64_t rp_s[33];
-  __shared__ int hs_s[32];
   int h_s = 0;
   if (P.hist_rowptr) {
-    const int64_t ub = (int64_t)blockIdx.x * 32;
+    const int64_t ub = ublock * 32;
     if (lane < 33) rp_s[lane] = P.hist_rowptr[min(ub + lane, P.n_users)];
     if (lane < 32) hs_s[lane] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -389,7 +396,12 @@ __global__ __launch_bounds__(64) void score_sample_bf16_kernel(const PrefArgs P)
         if (PRUNE && __any(cnt > CAP - 16)) sample_prune<CAP>(lst, lane, cnt, tl, keep);
       }
     };
+    int since_sync = 0;
     while (t < n_tiles) {
+      if (WG > 1 && ++since_sync == 2) {   // (every 6 tiles: keeps the workgroup's waves within L1 reach of each other)
+        since_sync = 0;
+        __syncthreads();
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         if (t < n_tiles) {

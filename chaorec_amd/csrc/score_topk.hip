@@ -1046,16 +1046,17 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     rc = check_launch("pack_items_bf16_kernel");
     if (rc) return rc;
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);
+    const dim3 gs4((groups + 3) / 4, (unsigned)p.pf_sample_splits);
     const dim3 gw((unsigned)((groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves)), (unsigned)p.pf_splits);
     if (D == 64) {
-      if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true>), gs, dim3(64), 0, st, P);
-      else hipLaunchKernelGGL((score_sample_bf16_kernel<64, 24, false>), gs, dim3(64), 0, st, P);
+      if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true, 4>), gs4, dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((score_sample_bf16_kernel<64, 24, false, 1>), gs, dim3(64), 0, st, P);
       hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64 * kSweepWaves), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_kernel<64>, dim3((unsigned)n_users), dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_wide_kernel<64>, dim3(512), dim3(64), 0, st, P);
     } else {
-      if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true>), gs, dim3(64), 0, st, P);
-      else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false>), gs, dim3(64), 0, st, P);
+      if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true, 4>), gs4, dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false, 1>), gs, dim3(64), 0, st, P);
       hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_kernel<128>, dim3((unsigned)n_users), dim3(64), 0, st, P);
       hipLaunchKernelGGL(score_select_rescore_wide_kernel<128>, dim3(512), dim3(64), 0, st, P);
