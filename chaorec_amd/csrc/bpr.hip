@@ -123,13 +123,7 @@ __global__ __launch_bounds__(256) void bpr_bwd_kernel(
 // ---- sampler -------------------------------------------------------------------------------
 // Counter-based generator: splitmix64 finaliser over (seed, step, b, attempt).  Stateless, so a
 // draw does not depend on launch geometry or on how many draws other samples needed.
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
+// (mix64: common.h)
 __device__ __forceinline__ uint32_t sampler_draw(uint64_t seed, uint64_t step, uint32_t b,
                                                  uint32_t attempt, uint32_t num_item) {
   uint64_t h = mix64(seed ^ mix64(step ^ mix64(((uint64_t)b << 32) | attempt)));

@@ -42,6 +42,15 @@ __device__ __forceinline__ float4 add_rn4(float4 a, float4 b) {
   return make_float4(add_rn(a.x, b.x), add_rn(a.y, b.y), add_rn(a.z, b.z), add_rn(a.w, b.w));
 }
 
+// splitmix64 finaliser: the counter-based generator behind the negative sampler (bpr.hip) and the edge dropout
+// (graph_dropout.hip).  Stateless: a draw depends only on its counters, never on launch geometry.
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   // fixed butterfly order -> identical result on every lane and every run
 #pragma unroll

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
           if (bias) v = v + bv;
           if (accumulate) v = out[gm * ldo + gn] + v;
           if (act == 1) v = v > 0.f ? v : v * 0.01f;
+          if (act == 2) v = v > 0.f ? v : v * 0.2f;
         }
         out[gm * ldo + gn] = v;
       }
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float *__r
   if (bias) v = v + bias[n];
   if (accumulate) v = C[m * ldc + n] + v;
   if (act == 1) v = v > 0.f ? v : v * 0.01f;
+  if (act == 2) v = v > 0.f ? v : v * 0.2f;
   C[m * ldc + n] = v;
 }
 
@@ -383,7 +385,7 @@ extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const 
                                 int32_t act, void *workspace, size_t workspace_bytes, void *stream) {
   if (!A || !B || !C) return fail(CHAOREC_E_INVALID, "gemm: NULL argument");
   if (M < 0 || N < 0 || K < 0) return fail(CHAOREC_E_INVALID, "gemm: negative size");
-  if (act < 0 || act > 1) return fail(CHAOREC_E_INVALID, "gemm: act %d", act);
+  if (act < 0 || act > 2) return fail(CHAOREC_E_INVALID, "gemm: act %d", act);
   if (M == 0 || N == 0) return CHAOREC_OK;
   GemmPlan p = plan_gemm(M, N, K > 0 ? K : 1);
   if (K == 0) p.splits = 1;

@@ -180,3 +180,40 @@ def add_scaled_coo(a, wa, b, wb, n):
     idx = torch.cat([ia, ib], dim=1)
     val = torch.cat([wa * va, wb * vb])
     return coo_to_csr_coalesced(idx[0], idx[1], val, n, n, symmetric=False)
+
+
+class DropoutStructure(CSR):
+    """The CSR of D^-1/2 (A + I) D^-1/2 plus what the per-step edge dropout needs (ops.edge_dropout_norm): the
+    destination of every entry, the entry of the reversed edge, and a degree workspace.  `val` holds the
+    no-dropout normalisation; with_values() gives a view of the same structure over another value array (no
+    schedule: the SpMM schedule inlines values, and these change every step)."""
+
+    def __init__(self, csr, entry_row, transpose_entry, deg_ws=None):
+        super().__init__(csr.rowptr, csr.col, csr.val, csr.n_rows, csr.n_cols, symmetric=True)
+        self.entry_row, self.transpose_entry = entry_row, transpose_entry
+        self.deg_ws = deg_ws if deg_ws is not None else torch.zeros(csr.n_rows, dtype=torch.int32,
+                                                                    device=csr.rowptr.device)
+
+    def to(self, device):
+        return DropoutStructure(CSR.to(self, device), self.entry_row.to(device), self.transpose_entry.to(device),
+                                self.deg_ws.to(device))
+
+    def with_values(self, val):
+        v = CSR(self.rowptr, self.col, val, self.n_rows, self.n_cols)
+        v.schedule = lambda D: None
+        return v
+
+
+def ngcf_structure(edge_index, n_nodes):
+    """NGCFConv.forward's graph (Model/NGCF.py:49-58) for p = 0 -- the same D^-1/2 (A+I) D^-1/2 as BasicGCN -- and
+    the entry maps the dropout kernels need.  transpose_entry pairs the j-th copy of (r, c) with the j-th copy of
+    (c, r), so it is a bijection even when the edge list repeats an interaction."""
+    csr = basicgcn_csr(edge_index, n_nodes)
+    counts = csr.rowptr[1:] - csr.rowptr[:-1]
+    entry_row = torch.repeat_interleave(torch.arange(n_nodes, dtype=torch.int64), counts)
+    col = csr.col.to(torch.int64)
+    fwd = torch.argsort(entry_row * n_nodes + col, stable=True)
+    rev = torch.argsort(col * n_nodes + entry_row, stable=True)
+    tentry = torch.empty(col.numel(), dtype=torch.int64)
+    tentry[rev] = fwd
+    return DropoutStructure(csr, entry_row.to(torch.int32), tentry.to(torch.int32))

@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import FREEDOM, LightGCN, MMGCN
+from .Model import FREEDOM, LightGCN, MMGCN, NGCF
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
 from .optim import FusedAdam
@@ -33,13 +33,15 @@ def setup_logging(args):
 
 
 def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_feat, device):
-    """The three rows of the reference's constructor table (main.py:261-263, :269-270, :287-289)."""
+    """The rows of the reference's constructor table on the hot path (main.py:261-263, :267-270, :287-289)."""
     dim_E, aggr_mode = args.dim_E, args.aggr_mode
     table = {
         'MMGCN': lambda: MMGCN(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                                aggr_mode, 'False', True, device),
         'LightGCN': lambda: LightGCN(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight,
                                      args.n_layers, aggr_mode, device),
+        'NGCF': lambda: NGCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.dropout,
+                             args.n_layers, aggr_mode, device),
         'FREEDOM': lambda: FREEDOM(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E,
                                    args.feature_embed, args.reg_weight, args.dropout, args.n_layers, args.mm_layers,
                                    args.ii_topk, args.lambda_coeff, device),

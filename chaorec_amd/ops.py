@@ -342,3 +342,86 @@ class _SpMMAdd(torch.autograd.Function):
 
 def spmm_add(csr, x, z):
     return _SpMMAdd.apply(x, z, csr)
+
+
+# --------------------------------------------------------------------------------------------
+# per-step edge dropout (NGCF) and weighted edge sampling (FREEDOM)
+# --------------------------------------------------------------------------------------------
+def edge_dropout_norm(structure, p, seed, step=0, step_dev=None, salt=0, keep=None):
+    """Values of the dropped-and-renormalised graph and of its transpose over graph.DropoutStructure (one call per
+    NGCFConv.forward, Model/NGCF.py:38-58).  Returns (val, val_t), both fp32 [nnz] in the structure's entry order.
+    `keep` (uint8 [nnz], optional) replaces the generator with an externally drawn mask."""
+    _need_cuda(structure.col, step_dev, keep)
+    nnz = structure.nnz
+    dev = structure.col.device
+    val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    val_t = torch.empty(nnz, dtype=torch.float32, device=dev)
+    if keep is not None:
+        keep = keep.to(torch.uint8).contiguous()
+    rc = _lib.load().chaorec_edge_dropout_norm(_ptr(structure.entry_row), _ptr(structure.col),
+                                               _ptr(structure.transpose_entry), nnz, structure.n_rows, float(p),
+                                               int(seed) & (2**64 - 1), int(step), _ptr(step_dev), int(salt),
+                                               _ptr(keep), _ptr(structure.deg_ws), _ptr(val), _ptr(val_t), _stream())
+    _lib.check(rc, "chaorec_edge_dropout_norm")
+    return val, val_t
+
+
+class _SpMMValues(torch.autograd.Function):
+    """y = A x where A's values change every call (edge dropout) while its structure is fixed: forward with `val`,
+    backward with `val_t` (A^T in the same structure)."""
+
+    @staticmethod
+    def forward(ctx, x, structure, val, val_t):
+        ctx.structure, ctx.val_t = structure, val_t
+        return spmm_raw(structure.with_values(val), x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return spmm_raw(ctx.structure.with_values(ctx.val_t), gy.contiguous()), None, None, None
+
+
+def spmm_values(structure, val, val_t, x):
+    return _SpMMValues.apply(x, structure, val, val_t)
+
+
+class _NGCFCombine(torch.autograd.Function):
+    """leaky_relu_0.2(s W1^T + t W2^T): the dense half of NGCFConv (Model/NGCF.py:68-80) as two MFMA GEMM launches,
+    the second accumulating into the first's output with the activation in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, s, w1, t, w2):
+        y = gemm_raw(s, w1, transB=True)
+        gemm_raw(t, w2, transB=True, out=y, accumulate=True, act=2)
+        ctx.save_for_backward(s, w1, t, w2, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        s, w1, t, w2, y = ctx.saved_tensors
+        g = torch.where(y > 0, gy, gy * 0.2).contiguous()
+        gs = gemm_raw(g, w1) if ctx.needs_input_grad[0] else None
+        gw1 = gemm_raw(g, s, transA=True) if ctx.needs_input_grad[1] else None
+        gt = gemm_raw(g, w2) if ctx.needs_input_grad[2] else None
+        gw2 = gemm_raw(g, t, transA=True) if ctx.needs_input_grad[3] else None
+        return gs, gw1, gt, gw2
+
+
+def ngcf_combine(s, w1, t, w2):
+    return _NGCFCombine.apply(s, w1, t, w2)
+
+
+def weighted_sample_keep(weights, k, seed, step=0, step_dev=None, return_keys=False):
+    """uint8 [n] keep mask of a weighted sample without replacement of k of the n entries (FREEDOM's
+    torch.multinomial(edge_values, k), Model/FREEDOM.py:151, as a set; any n)."""
+    _need_cuda(weights, step_dev)
+    weights = _f32c(weights)
+    n = weights.numel()
+    lib = _lib.load()
+    nbytes = lib.chaorec_weighted_sample_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=weights.device)
+    keep = torch.empty(n, dtype=torch.uint8, device=weights.device)
+    keys = torch.empty(n, dtype=torch.int64, device=weights.device) if return_keys else None
+    rc = lib.chaorec_weighted_sample_keep(_ptr(weights), n, int(k), int(seed) & (2**64 - 1), int(step), _ptr(step_dev),
+                                          _ptr(ws), nbytes, _ptr(keep), _ptr(keys), _stream())
+    _lib.check(rc, "chaorec_weighted_sample_keep")
+    return (keep, keys) if return_keys else keep

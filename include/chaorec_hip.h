@@ -226,7 +226,8 @@ int chaorec_rank_metrics_f64(const int64_t *rank_idx, int64_t n_users, int64_t r
  *   forward  y = x W^T + b      : transA=0, transB=1 (W stored [N,K])
  *   grad x   = gy W             : transA=0, transB=0
  *   grad W   = gy^T x           : transA=1, transB=0
- * act: 0 none, 1 leaky_relu(0.01) applied to the result (F.leaky_relu default slope).
+ * act: 0 none, 1 leaky_relu(0.01) applied to the result (F.leaky_relu default slope), 2 leaky_relu(0.2)
+ *      (nn.LeakyReLU(0.2), Model/NGCF.py:32).
  * Few output tiles with a long reduction (weight gradients: K = number of graph nodes) are split along K into
  * slabs in `workspace` (size from chaorec_gemm_workspace_bytes) and summed in a fixed order by a second launch:
  * deterministic, equal to the unsplit chain to rounding. */
@@ -246,6 +247,48 @@ int chaorec_gemm_f32(const float *A, const float *B, float *C, const float *bias
 int chaorec_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                           int64_t n, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int32_t step, const int32_t *step_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Per-step edge dropout + symmetric renormalisation of a structure-static CSR (NGCF).
+ *
+ * Replaces: dropout_adj + add_self_loops + degree + deg^-1/2[row]*deg^-1/2[col] inside every NGCFConv.forward
+ *           (Model/NGCF.py:38-58), which rebuilds the edge list of the graph on every call.
+ *
+ * The graph is the destination-major CSR of the bidirectional train edges WITH one self loop per node (the
+ * structure of chaorec_spmm_csr_f32's operand, built once).  entry_row[k] = destination of entry k, col[k] = its
+ * source, transpose_entry[k] = the entry holding the reversed edge (a bijection; a self loop maps to itself).
+ *   keep_k = 1 for self loops (they are appended after the dropout), else u_k >= p with
+ *            u_k = 2^-24 * (mix64(seed ^ mix64(step' ^ mix64((salt << 48) ^ k))) >> 40), step' = step + *step_dev
+ *            (or keep_in[k] != 0 when keep_in is given: an externally drawn mask, used by the parity tests)
+ *   deg[n]  = number of kept entries whose SOURCE is n          (degree(row) on the kept list, int32 in deg_ws)
+ *   val[k]   = keep_k                  ? (1/sqrt(deg[col[k]])) * (1/sqrt(deg[entry_row[k]])) : 0
+ *   val_t[k] = keep_transpose_entry[k] ? the same product : 0      (the values of A^T in the same structure)
+ * p == 0 keeps everything.  deg_ws: n_nodes int32.  salt < 65536 separates the conv layers of one step.
+ * Not bit-comparable with the reference's mask (torch's generator); the keep law (independent, rate 1-p) is.
+ * ------------------------------------------------------------------------------------- */
+int chaorec_edge_dropout_norm(const int32_t *entry_row, const int32_t *col, const int32_t *transpose_entry,
+                              int64_t nnz, int64_t n_nodes, float p, uint64_t seed, uint64_t step,
+                              const int64_t *step_dev, uint32_t salt, const uint8_t *keep_in,
+                              int32_t *deg_ws, float *val, float *val_t, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weighted sampling WITHOUT replacement as a keep mask (FREEDOM's degree-sensitive pruning).
+ *
+ * Replaces: torch.multinomial(edge_values, k) (Model/FREEDOM.py:151), which is limited to 2^24 categories; the
+ *           reference only uses the drawn SET (the pruned graph is coalesced right after, :152-162).
+ *
+ * Exponential race: key_e = |log(u_e)| / w_e with u_e uniform in (0,1) from the counter generator
+ * (mix64(seed ^ mix64(step' ^ mix64((0x5A3B << 48) ^ e)))); the k smallest keys are kept -- the same law as k
+ * sequential draws without replacement with probabilities proportional to w.  The k-th smallest 64-bit key
+ * ((fp32 key bits << 32) | 32 fresh hash bits) is found by an exact radix select (6 passes, integer histograms),
+ * so the mask is a deterministic function of (weights, seed, step').  keep[e] = key_e <= that key: exactly k
+ * ones unless two entries share all 64 key bits.  w_e <= 0 is never kept (while k <= #positive weights).
+ * keys_out (optional, may be NULL): the n 64-bit keys, for the tests.
+ * ------------------------------------------------------------------------------------- */
+size_t chaorec_weighted_sample_workspace_bytes(void);
+int chaorec_weighted_sample_keep(const float *weights, int64_t n, int64_t k, uint64_t seed, uint64_t step,
+                                 const int64_t *step_dev, void *workspace, size_t workspace_bytes,
+                                 uint8_t *keep, uint64_t *keys_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -235,6 +235,7 @@ void oracle_gemm_f32(const float *A, const float *B, float *C, const float *bias
       if (bias) acc = acc + bias[n];
       if (accumulate) acc = C[m * ldc + n] + acc;
       if (act == 1) acc = acc > 0.0f ? acc : acc * 0.01f;
+      if (act == 2) acc = acc > 0.0f ? acc : acc * 0.2f;   /* nn.LeakyReLU(0.2), Model/NGCF.py:32 */
       C[m * ldc + n] = acc;
     }
   }

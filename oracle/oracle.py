@@ -261,6 +261,69 @@ def lightgcn_loss(x0, csr, n_layers, num_user, users, pos_local, neg_local, reg_
     return out, g
 
 
+def ngcf_forward(x0, w1s, w2s, train_edges, n_nodes, keep_masks=None):
+    """Model/NGCF.py:38-84 + :114-127, EDGE-WISE as the reference evaluates it: per conv call drop edges
+    (keep_masks[l], bool over the 2E bidirectional edges; None = no dropout), append self loops, recount degree(row),
+    m_e = norm_e * (W1 x[row_e] + W2 (x[row_e] * x[col_e])), scatter-add at col in edge order, leaky_relu(0.2);
+    result = x_0 + x_1 + ... (torch.sum over the stack).  fp32 throughout."""
+    src0, dst0 = bidirectional_edges(train_edges)
+    x = _c(x0, np.float32)
+    out = x.copy()
+    for l, (w1, w2) in enumerate(zip(w1s, w2s)):
+        src, dst = src0, dst0
+        if keep_masks is not None and len(keep_masks):
+            k = np.asarray(keep_masks[l], dtype=bool)
+            src, dst = src0[k], dst0[k]
+        src, dst = add_self_loops(src, dst, n_nodes)
+        norm = sym_norm_weights(src, dst, n_nodes)
+        xj, xi = x[src], x[dst]
+        msg = (norm[:, None] * (xj @ w1.T + (xj * xi) @ w2.T)).astype(np.float32)
+        agg = np.zeros_like(x)
+        np.add.at(agg, dst, msg)
+        x = np.where(agg > 0, agg, np.float32(0.2) * agg).astype(np.float32)
+        out = (out + x).astype(np.float32)
+    return out
+
+
+def mix64(z):
+    """splitmix64 finaliser on uint64 arrays (chaorec_amd/csrc/common.h:mix64)."""
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def edge_dropout_keep(nnz, p, seed, step, salt):
+    """The generator of chaorec_edge_dropout_norm (include/chaorec_hip.h): u_k = 2^-24 * (h_k >> 40), keep = u_k >= p.
+    Self loops are forced to 1 by the caller."""
+    k = np.arange(nnz, dtype=np.uint64)
+    h = mix64(np.uint64(seed) ^ mix64(np.uint64(step) ^ mix64((np.uint64(salt) << np.uint64(48)) ^ k)))
+    u = (h >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
+    return u >= np.float32(p)
+
+
+def edge_dropout_norm(entry_row, col, transpose_entry, n_nodes, keep):
+    """Values of the dropped + renormalised graph and of its transpose (chaorec_edge_dropout_norm), keep already
+    holding 1 at the self loops.  deg counts kept entries by SOURCE (= col of the destination-major CSR)."""
+    keep = np.asarray(keep, dtype=bool)
+    deg = np.bincount(np.asarray(col)[keep], minlength=n_nodes).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        dinv = (np.float32(1.0) / np.sqrt(deg)).astype(np.float32)
+    w = (dinv[col] * dinv[entry_row]).astype(np.float32)
+    zero = np.float32(0.0)
+    return np.where(keep, w, zero).astype(np.float32), np.where(keep[transpose_entry], w, zero).astype(np.float32)
+
+
+def race_uniform(n, seed, step):
+    """u_e and the low key bits of chaorec_weighted_sample_keep's exponential race."""
+    e = np.arange(n, dtype=np.uint64)
+    h = mix64(np.uint64(seed) ^ mix64(np.uint64(step) ^ mix64((np.uint64(0x5A3B) << np.uint64(48)) ^ e)))
+    u = ((h >> np.uint64(40)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    return u, (h & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
 def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50):
     """Model/LightGCN.py:137-162 -> int64 [U, topk] of GLOBAL item ids."""
     idx, val = score_topk(result[:num_user], result[num_user:num_user + num_item], hist,

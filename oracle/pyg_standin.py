@@ -13,6 +13,7 @@ propagate", and say so.  Published semantics restated here:
   * torch_scatter.scatter(reduce='sum') = zeros.scatter_add_(0, broadcast(index), src)
   * utils.degree(index, num_nodes, dtype) = zeros(N).scatter_add_(0, index, ones)
   * utils.add_self_loops(edge_index, num_nodes) appends arange(N) x2 AFTER the edges
+  * utils.dropout_adj(edge_index, p): mask = torch.rand(E) >= p; edge_index[:, mask]   (Model/NGCF.py:40)
 """
 import inspect
 import sys
@@ -66,6 +67,19 @@ def add_self_loops(edge_index, edge_attr=None, fill_value=None, num_nodes=None):
     return torch.cat([edge_index, loop], dim=1), edge_attr
 
 
+DROPOUT_LOG = []   # every keep mask dropout_adj drew, in call order (the golden generator stores them as inputs)
+
+
+def dropout_adj(edge_index, edge_attr=None, p=0.5, force_undirected=False, num_nodes=None, training=True):
+    """torch_geometric.utils.dropout_adj (2.1.0): keep each edge independently with probability 1 - p."""
+    assert not force_undirected and edge_attr is None
+    if not training or p == 0.0:
+        return edge_index, edge_attr
+    mask = torch.rand(edge_index.size(1), device=edge_index.device) >= p
+    DROPOUT_LOG.append(mask.clone())
+    return edge_index[:, mask], edge_attr
+
+
 def _unused(*a, **k):
     raise NotImplementedError("not on the hot path")
 
@@ -89,7 +103,7 @@ def install():
     utils.add_self_loops = add_self_loops
     utils.remove_self_loops = _unused
     utils.softmax = _unused
-    utils.dropout_adj = _unused
+    utils.dropout_adj = dropout_adj
     tg.nn = nn
     tg.utils = utils
     for name, mod in (("torch_geometric", tg), ("torch_geometric.nn", nn),

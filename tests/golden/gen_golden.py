@@ -35,6 +35,7 @@ warnings.filterwarnings("ignore")
 from Model.LightGCN import LightGCN  # noqa: E402
 from Model.FREEDOM import FREEDOM  # noqa: E402
 from Model.MMGCN import MMGCN  # noqa: E402
+from Model.NGCF import NGCF  # noqa: E402
 import metrics as ref_metrics  # noqa: E402,F401
 import utils as ref_utils  # noqa: E402
 import dataload as ref_dataload  # noqa: E402
@@ -289,8 +290,40 @@ def gen_mmgcn():
                         **{"p_" + k: v for k, v in state.items()}, **extra, **grads)
 
 
+def gen_ngcf():
+    """Reference NGCF (model code + restated propagate / dropout_adj): one loss + backward + ranking, without and
+    with edge dropout.  The keep masks dropout_adj drew are stored as inputs (bidirectional edge-list order)."""
+    U, I = 48, 40
+    e = small_graph(U, I, 3, 7, 8)
+    D, L = 16, 2
+    rng = np.random.default_rng(9)
+    b = rng.choice(len(e), 32, replace=False)
+    users = e[b, 0].astype(np.int64)
+    pos = e[b, 1].astype(np.int64)
+    neg = rng.integers(U, U + I, 32).astype(np.int64)
+    for dropout, tag in ((0.0, "nodrop"), (0.3, "drop")):
+        torch.manual_seed(0)
+        m = NGCF(U, I, e, uid(e), D, 1e-3, dropout, L, "add", DEV)
+        state = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+        del pyg_standin.DROPOUT_LOG[:]
+        torch.manual_seed(77)
+        loss = m.loss(torch.from_numpy(users), torch.from_numpy(pos), torch.from_numpy(neg))
+        loss.backward()
+        masks = np.stack([k.numpy() for k in pyg_standin.DROPOUT_LOG]) if dropout > 0 else np.zeros((0, 2 * len(e)), bool)
+        assert masks.shape[0] == (L if dropout > 0 else 0)
+        grads = {"g_" + k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+        NGCF.gene_ranklist.__defaults__ = (10,)
+        rank = m.gene_ranklist()
+        NGCF.gene_ranklist.__defaults__ = (50,)
+        np.savez_compressed(os.path.join(HERE, f"ngcf_small_{tag}.npz"), U=U, I=I, edges=e, D=D, L=L, reg=1e-3,
+                            dropout=dropout, users=users, pos=pos, neg=neg, keep_masks=masks,
+                            loss=np.float64(loss.item()), result=m.result.detach().numpy(), rank=rank.numpy(), topk=10,
+                            param_names=np.array([k for k, _ in m.named_parameters()]),
+                            **{"p_" + k: v for k, v in state.items()}, **grads)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lightgcn_tiny", "baby", "sampler", "freedom", "mmgcn"]
+    which = sys.argv[1:] or ["lightgcn_tiny", "baby", "sampler", "freedom", "mmgcn", "ngcf"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -244,3 +244,93 @@ def test_shared_gene_ranklist_helper(dev, oracle):
         got = ranking.gene_ranklist(torch.from_numpy(res).to(dev), U, I, hist, mask, 50)
         want, _ = oracle.gene_ranklist(res, U, I, oracle.user_hist_csr(e, U), mask, 50)
         assert got.dtype == torch.int64 and got.device.type == "cpu" and np.array_equal(got.numpy(), want)
+
+
+def _ngcf_from_golden(g, dev, dropout):
+    from chaorec_amd.Model import NGCF
+    from chaorec_amd import graph
+    U, I = int(g["U"]), int(g["I"])
+    m = NGCF(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), dropout,
+             int(g["L"]), "add", dev)
+    m.load_state_dict({str(n): torch.from_numpy(g["p_" + str(n)]) for n in g["param_names"]})
+    return m.to(dev)
+
+
+def _edge_masks_to_entries(edges, n_nodes, masks):
+    """keep masks over the 2E bidirectional edges (the reference's dropout_adj order) -> uint8 masks over the entries
+    of the destination-major CSR with self loops (stable sort by destination, loops appended last and always kept)."""
+    from chaorec_amd import graph
+    ei = graph.bidirectional_edge_index(edges)
+    dst = torch.cat([ei[1], torch.arange(n_nodes)])
+    order = torch.argsort(dst, stable=True)
+    out = []
+    for k in masks:
+        looped = torch.cat([torch.from_numpy(k.astype(np.uint8)), torch.ones(n_nodes, dtype=torch.uint8)])
+        out.append(looped[order].contiguous())
+    return out
+
+
+@pytest.mark.parametrize("tag", ["nodrop", "drop"])
+def test_ngcf_golden(dev, tag):
+    """NGCF on the kernels (SpMM + two GEMMs per layer) against the reference model evaluated edge-wise: same
+    representation, loss, gradients of every parameter and ranking, to fp32 re-association tolerance.  With dropout the
+    masks the reference drew are fed to chaorec_edge_dropout_norm (keep_in)."""
+    g = load_golden(f"ngcf_small_{tag}.npz")
+    U, I = int(g["U"]), int(g["I"])
+    m = _ngcf_from_golden(g, dev, float(g["dropout"]))
+    if tag == "drop":
+        m.forced_keep = [k.to(dev) for k in _edge_masks_to_entries(g["edges"], U + I, g["keep_masks"])]
+    loss = m.loss(torch.from_numpy(g["users"]), torch.from_numpy(g["pos"]), torch.from_numpy(g["neg"]))
+    loss.backward()
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 2e-6 * np.abs(g["result"]).max()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-6)
+    for n, p in m.named_parameters():
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-5 * (np.abs(ref).max() + 1e-12), n
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    sc = g["result"][:U] @ g["result"][U:].T
+    from chaorec_amd import graph
+    for u, items in graph.user_item_dict_from_edges(g["edges"]).items():
+        sc[u, np.asarray(items) - U] = 1e-6
+    ok, why = tie_aware_rank_equal(rank, np.take_along_axis(sc, rank - U, 1), g["rank"],
+                                   np.take_along_axis(sc, g["rank"] - U, 1), rtol=1e-4, atol=1e-7)
+    assert ok, why
+
+
+def test_ngcf_device_dropout_trains_under_graph_capture(dev):
+    """The default configuration (dropout 0.2, masks from the device generator): a fresh mask per forward, the
+    captured step equals the eager step on the same mask stream, and the loss goes down."""
+    from chaorec_amd.Model import NGCF
+    from chaorec_amd import graph
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    g = load_golden("ngcf_small_drop.npz")
+    U, I = int(g["U"]), int(g["I"])
+    batch = tuple(torch.from_numpy(g[k]).to(dev) for k in ("users", "pos", "neg"))
+
+    def make():
+        torch.manual_seed(3)
+        return NGCF(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), 16, 1e-3, 0.2, 2, "add", dev).to(dev)
+
+    a = make()
+    r1 = a.forward().detach().clone()
+    r2 = a.forward().detach().clone()
+    assert not torch.equal(r1, r2)                       # a new mask every call
+    b = make()
+    assert torch.equal(b.forward().detach(), r1)         # same seed, same call index -> same mask
+
+    eager, cap = make(), make()
+    oe, oc = FusedAdam(eager.parameters(), lr=1e-2), FusedAdam(cap.parameters(), lr=1e-2)
+    step = GraphedTrainStep(cap, oc, example_batch=batch)
+    eager._drop_calls.copy_(cap._drop_calls)             # the warm-up forwards advanced the captured model's counter
+    first = last = None
+    for it in range(30):
+        oe.zero_grad()
+        le = eager.loss(*batch)
+        le.backward()
+        oe.step()
+        lc = step(*batch)
+        assert float(lc.detach()) == pytest.approx(float(le.detach()), rel=1e-5), it
+        first = float(le.detach()) if first is None else first
+        last = float(le.detach())
+    assert last < first

@@ -720,3 +720,107 @@ def test_draw_batch_one_launch(dev, oracle, baby):
     exp = np.bincount(deg, weights=deg.astype(np.float64), minlength=deg.max() + 1) / deg.sum() * len(big)
     keep = exp > 50
     assert ((got[keep] - exp[keep]) ** 2 / exp[keep]).sum() < 3 * keep.sum()
+
+
+# ---- edge dropout + renormalisation, weighted edge sampling ---------------------------------------
+@pytest.mark.parametrize("p", [0.0, 0.2, 0.7])
+def test_edge_dropout_norm_bit_exact(dev, oracle, p):
+    from chaorec_amd import graph, ops
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E = 3000, 1700, 40000
+    edges = synthetic_interactions(U, I, E, seed=4)
+    s = graph.ngcf_structure(edges, U + I).to(dev)
+    er, col, te = (t.cpu().numpy() for t in (s.entry_row, s.col, s.transpose_entry))
+    step_dev = torch.tensor([5], dtype=torch.int64, device=dev)
+    val, val_t = ops.edge_dropout_norm(s, p, seed=1234, step=2, step_dev=step_dev, salt=3)
+    keep = oracle.edge_dropout_keep(s.nnz, p, 1234, 7, 3) | (er == col)
+    want, want_t = oracle.edge_dropout_norm(er, col, te, U + I, keep)
+    assert np.array_equal(val.cpu().numpy(), want)
+    assert np.array_equal(val_t.cpu().numpy(), want_t)
+    real = er != col
+    assert abs(keep[real].mean() - (1 - p)) < 0.01
+    if p == 0.0:       # no dropout: the static D^-1/2 (A+I) D^-1/2 of BasicGCN, to the ulp of pow(-0.5) vs 1/sqrt
+        assert np.allclose(want, s.val.cpu().numpy(), rtol=3e-7, atol=0)
+    # an externally drawn mask replaces the generator
+    ext = (np.random.default_rng(0).random(s.nnz) < 0.5)
+    v2, v2t = ops.edge_dropout_norm(s, p, seed=0, keep=torch.from_numpy(ext.astype(np.uint8)).to(dev))
+    w2, w2t = oracle.edge_dropout_norm(er, col, te, U + I, ext | (er == col))
+    assert np.array_equal(v2.cpu().numpy(), w2) and np.array_equal(v2t.cpu().numpy(), w2t)
+    # val_t really is the transpose: (A x) . y == x . (A^T y)
+    x = torch.randn(U + I, 64, device=dev, dtype=torch.float64).float()
+    y = torch.randn(U + I, 64, device=dev, dtype=torch.float64).float()
+    ax = ops.spmm_raw(s.with_values(val), x).double()
+    aty = ops.spmm_raw(s.with_values(val_t), y).double()
+    assert float((ax * y.double()).sum()) == pytest.approx(float((x.double() * aty).sum()), rel=1e-5)
+
+
+def test_spmm_values_matches_oracle_spmm(dev, oracle):
+    """The schedule-less SpMM route the per-step values take, against the ordered CPU SpMM."""
+    from chaorec_amd import graph, ops
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E = 900, 500, 9000
+    edges = synthetic_interactions(U, I, E, seed=6)
+    s = graph.ngcf_structure(edges, U + I).to(dev)
+    val, _ = ops.edge_dropout_norm(s, 0.3, seed=9)
+    x = np.random.default_rng(1).standard_normal((U + I, 64)).astype(np.float32)
+    want = oracle.spmm((s.rowptr.cpu().numpy(), s.col.cpu().numpy(), val.cpu().numpy()), x)
+    got = ops.spmm_raw(s.with_values(val), torch.from_numpy(x).to(dev))
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_gemm_leaky_02_accumulate_bit_exact(dev, oracle):
+    from chaorec_amd import ops
+    rng = np.random.default_rng(8)
+    A, B = rng.standard_normal((300, 64)).astype(np.float32), rng.standard_normal((64, 64)).astype(np.float32)
+    C = rng.standard_normal((300, 64)).astype(np.float32)
+    want = oracle.gemm(A, B, transB=True, C=C.copy(), act=2)
+    out = torch.from_numpy(C.copy()).to(dev)
+    ops.gemm_raw(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), transB=True, out=out, accumulate=True, act=2)
+    assert np.array_equal(out.cpu().numpy(), want) and (want < 0).any()
+
+
+@pytest.mark.parametrize("n,k", [(1000, 1), (1000, 1000), (50000, 40000), (3_000_000, 2_400_000)])
+def test_weighted_sample_keep_is_the_k_smallest_keys(dev, oracle, n, k):
+    from chaorec_amd import ops
+    rng = np.random.default_rng(n)
+    w = (rng.random(n) ** 2 + 1e-3).astype(np.float32)
+    w[::97] = 0.0                                            # never selected
+    if k == n:
+        w[:] = np.maximum(w, 1e-3)
+    wt = torch.from_numpy(w).to(dev)
+    keep, keys = ops.weighted_sample_keep(wt, k, seed=11, step=4, return_keys=True)
+    keep2 = ops.weighted_sample_keep(wt, k, seed=11, step_dev=torch.tensor([4], device=dev), step=0)
+    keep, keys = keep.cpu().numpy().astype(bool), keys.cpu().numpy().view(np.uint64)
+    assert np.array_equal(keep, keep2.cpu().numpy().astype(bool))          # deterministic, step == step_dev
+    assert keep.sum() == k
+    kth = np.partition(keys, k - 1)[k - 1]
+    assert np.array_equal(keep, keys <= kth)                                 # exactly the k smallest keys
+    assert not keep[w == 0].any()
+    # the keys are the exponential race of the header: |log u| / w in the high word, hash bits in the low word
+    u, low = oracle.race_uniform(n, 11, 4)
+    pos = w > 0
+    hi = (keys >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)[pos], low[pos])
+    assert np.allclose(hi[pos], np.abs(np.log(u[pos].astype(np.float64))) / w[pos], rtol=1e-5)
+    assert (keys[~pos] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    other = ops.weighted_sample_keep(wt, k, seed=12, step=4).cpu().numpy().astype(bool)
+    assert k == n or not np.array_equal(other, keep)
+
+
+def test_weighted_sample_inclusion_probabilities(dev):
+    """Sampling 2 of 4 weights without replacement: the pair frequencies over 3000 independent draws (one `step`
+    each) follow the sequential-draw law p(i then j) = w_i/W * w_j/(W - w_i), torch.multinomial's."""
+    from chaorec_amd import ops
+    w = np.array([1.0, 2.0, 3.0, 4.0], dtype=np.float32)
+    wt = torch.from_numpy(w).to(dev)
+    counts = np.zeros((4, 4))
+    T = 3000
+    for t in range(T):
+        k = ops.weighted_sample_keep(wt, 2, seed=5, step=t).cpu().numpy().astype(bool)
+        i, j = np.nonzero(k)[0]
+        counts[i, j] += 1
+    W = w.sum()
+    for i in range(4):
+        for j in range(i + 1, 4):
+            pij = w[i] / W * w[j] / (W - w[i]) + w[j] / W * w[i] / (W - w[j])
+            assert abs(counts[i, j] / T - pij) < 4 * np.sqrt(pij * (1 - pij) / T) + 1e-3, (i, j)

@@ -21,6 +21,10 @@ def test_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/chaorec_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes table and header drifted"
+    plain = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for name, args in re.findall(r"\b(chaorec_\w+)\s*\(([^;{]*?)\)\s*;", plain):
+        n_args = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        assert len(_lib.SIGNATURES[name][1]) == n_args, f"{name}: ctypes argtypes vs header"
     assert _lib.load().chaorec_abi_version() == 2
     assert _lib.load().chaorec_spmm_rows_per_wave(64) == 4
     assert _lib.load().chaorec_spmm_rows_per_wave(128) == 2
@@ -251,3 +255,29 @@ def test_lightgcn_tables_share_one_buffer_and_keep_their_names(baby):
     assert torch.equal(m._flat[:U], sd["user_embedding.weight"]) and torch.equal(m._flat[U:], sd["item_embedding.weight"])
     m = m.double()
     assert m._flat.dtype == torch.float64 and m.user_embedding.weight.data_ptr() == m._flat.data_ptr()
+
+
+def test_ngcf_structure_maps_and_parameter_surface():
+    """graph.ngcf_structure: entry_row / transpose_entry are consistent (the reversed edge, a bijection, self loops
+    fixed) also with a repeated interaction; the NGCF module registers the reference's parameters in its order."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import NGCF
+    g = load_golden("ngcf_small_drop.npz")
+    U, I = int(g["U"]), int(g["I"])
+    edges = np.concatenate([g["edges"], g["edges"][:3]])          # three duplicated interactions
+    s = graph.ngcf_structure(edges, U + I)
+    er, col, te = s.entry_row.numpy(), s.col.numpy(), s.transpose_entry.numpy()
+    assert s.nnz == 2 * len(edges) + U + I
+    assert np.array_equal(np.sort(te), np.arange(s.nnz))
+    assert np.array_equal(er[te], col) and np.array_equal(col[te], er)
+    loops = er == col
+    assert loops.sum() == U + I and np.array_equal(te[loops], np.nonzero(loops)[0])
+    assert np.array_equal(np.repeat(np.arange(U + I), np.diff(s.rowptr.numpy())), er)
+    torch.manual_seed(0)
+    m = NGCF(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), 1e-3, 0.3, int(g["L"]), "add",
+             torch.device("cpu"))
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():          # same seed, same creation order -> the reference's initial weights
+        assert np.array_equal(p.detach().numpy(), g["p_" + n]), n
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.forward()

@@ -128,3 +128,21 @@ def test_sampler_matches_reference_support(oracle):
         exp = 4000 / allowed.sum()
         chi2 = ((mine[u][allowed] - exp) ** 2 / exp).sum()
         assert chi2 < 30, (u, chi2)  # dof <= 4: p(chi2 > 30) ~ 5e-6
+
+
+@pytest.mark.parametrize("tag", ["nodrop", "drop"])
+def test_ngcf_oracle_vs_reference_golden(oracle, tag):
+    """The edge-wise NGCF restatement against the reference model's own output (tests/golden/gen_golden.py:gen_ngcf;
+    the dropout masks the reference drew are inputs of the fixture)."""
+    g = load_golden(f"ngcf_small_{tag}.npz")
+    U, I, L = int(g["U"]), int(g["I"]), int(g["L"])
+    x0 = np.concatenate([g["p_user_embedding.weight"], g["p_item_embedding.weight"]])
+    w1 = [g[f"p_conv_layers.{l}.W1.weight"] for l in range(L)]
+    w2 = [g[f"p_conv_layers.{l}.W2.weight"] for l in range(L)]
+    masks = g["keep_masks"] if tag == "drop" else None
+    out = oracle.ngcf_forward(x0, w1, w2, g["edges"], U + I, masks)
+    assert np.allclose(out, g["result"], rtol=1e-6, atol=1e-7)
+    terms, _ = oracle.bpr_fwd(out[:U], out[U:], g["users"], g["pos"] - U, g["neg"] - U, 0, float(g["reg"]))
+    assert float(terms[0]) == pytest.approx(float(g["loss"]), rel=2e-6)
+    if tag == "drop":
+        assert masks.shape == (L, 2 * len(g["edges"])) and 0.5 < masks.mean() < 0.9
