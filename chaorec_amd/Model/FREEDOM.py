@@ -8,7 +8,8 @@ tables, image_trs / text_trs Linears), `pre_epoch_processing()`, `forward(adj)`,
   Q4  gene_ranklist ranks the stale self.result of the last training forward (pruned graph).
 What changed underneath: every sparse product is the CSR SpMM kernel, the kNN graph is built by
 the scoring+top-K kernel (no [I, I] similarity matrix), the three BPR terms are the fused BPR
-kernel, the modality projections run on the f32 MFMA GEMM.
+kernel, the modality projections run on the f32 MFMA GEMM, the per-epoch pruning draws its weighted sample
+without replacement with the device sampler (chaorec_weighted_sample_keep) instead of torch.multinomial.
 """
 import torch
 import torch.nn.functional as F  # noqa: F401  (kept: reference module namespace)
@@ -46,6 +47,7 @@ class FREEDOM(nn.Module):
 
         self.edge_indices, self.edge_values = self.get_edge_info(self.edge_index_clone)
         self.edge_indices, self.edge_values = self.edge_indices.to(self.device), self.edge_values.to(self.device)
+        self._prune_seed, self._prune_calls = int(torch.initial_seed()) & (2**63 - 1), 0
 
         self.user_embedding = nn.Embedding(self.num_user, self.dim_E)
         self.item_embedding = nn.Embedding(self.num_item, self.dim_E)
@@ -131,8 +133,12 @@ class FREEDOM(nn.Module):
             self.masked_adj = self.norm_adj
             return
         degree_len = int(self.edge_values.size(0) * (1. - self.dropout))
-        degree_idx = torch.multinomial(self.edge_values, degree_len)
-        self._set_masked_adj(self.edge_indices[:, degree_idx])
+        # torch.multinomial(edge_values, degree_len) (:151) as a keep mask from the device sampler: the same law
+        # (weighted, without replacement), any edge count (multinomial stops at 2^24 categories), and a function of
+        # (torch seed, epoch) only.  The reference uses the drawn set, never its order (the graph is coalesced).
+        keep = ops.weighted_sample_keep(self.edge_values, degree_len, self._prune_seed, step=self._prune_calls)
+        self._prune_calls += 1
+        self._set_masked_adj(self.edge_indices[:, keep.bool()])
 
     def _set_masked_adj(self, keep_indices):
         keep_values = self._normalize_adj_m(keep_indices, torch.Size((self.num_user, self.num_item)))

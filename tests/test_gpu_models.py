@@ -109,6 +109,9 @@ def test_freedom_pre_epoch_statistics(dev):
     r, c = np.nonzero(ui)
     want = (1e-7 + du[r]).astype(np.float32) ** -0.5 * (1e-7 + di[c]).astype(np.float32) ** -0.5
     assert np.allclose(ui[r, c], want, rtol=1e-5)
+    m.pre_epoch_processing()                 # next epoch: another draw of the same size
+    B = _csr_dense(m.masked_adj)
+    assert (B != 0).sum() == 2 * keep and ((A != 0) != (B != 0)).any()
 
 
 def test_mmgcn_golden(dev):

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Step / epoch timing of the three models on dataset-shaped synthetic graphs (BASELINE configs 2-4 shapes)."""
+"""Step / epoch timing of the models on dataset-shaped synthetic graphs (BASELINE configs 2-4 shapes)."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chaorec_amd import graph, dataload
-from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN
+from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN, NGCF
 from chaorec_amd.optim import FusedAdam
 from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
 dev = torch.device("cuda:0")
@@ -18,6 +18,8 @@ for spec in which:
     t0 = time.time()
     if name == "LightGCN":
         m = LightGCN(U, I, edges, uid, 64, 1e-3, 3, "add", dev)
+    elif name == "NGCF":
+        m = NGCF(U, I, edges, uid, 64, 1e-3, 0.2, 3, "add", dev)
     elif name == "FREEDOM":
         m = FREEDOM(U, I, edges, uid, v_feat, t_feat, 64, 64, 1e-3, 0.1, 2, 1, 10, 0.8, dev)
     else:
