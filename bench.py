@@ -190,6 +190,13 @@ def main():
                   file=sys.stderr)
             graphed = None
         if sharded is not None:
+            # every rank must run the same launch mode, and must agree on it BEFORE anyone replays a graph that holds
+            # collectives (a replay on one rank against an eager collective on another would pair mismatched calls)
+            torch.cuda.synchronize()
+            ok = torch.tensor([1.0 if graphed is not None else 0.0], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                graphed = None
             if graphed is not None:
                 # first replays of a graph holding RCCL kernels, under a watchdog: a launch mode that cannot make
                 # progress must end the job with a message, not sit on the GPUs until an outer timeout
@@ -197,7 +204,7 @@ def main():
                 done = threading.Event()
 
                 def watchdog():
-                    if not done.wait(float(os.environ.get("CHAOREC_GRAPH_WATCHDOG_S", "180"))):
+                    if not done.wait(float(os.environ.get("CHAOREC_GRAPH_WATCHDOG_S", "120"))):
                         print(f"[bench rank {rank}] captured sharded step did not complete; rerun with "
                               f"CHAOREC_DIST_GRAPH=0", file=sys.stderr, flush=True)
                         os._exit(17)
@@ -207,11 +214,6 @@ def main():
                     graphed()
                 torch.cuda.synchronize()
                 done.set()
-            torch.cuda.synchronize()
-            ok = torch.tensor([1.0 if graphed is not None else 0.0], device=dev)
-            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-            if float(ok.item()) < 1.0:
-                graphed = None
 
     n_loss = [0]
 
@@ -392,10 +394,14 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(edges, U, I, D, L, B, reg, args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1 or force_sharded:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which would otherwise drain at exit, AFTER the result:
+        # flush it first so that the JSON object is the last line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
