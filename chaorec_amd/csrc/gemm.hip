@@ -17,10 +17,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // f32 MFMA consumes k = 2s (lanes 0-31) and 2s+1 (lanes 32-63): the per-element sum is the k-ascending fmaf
 // chain of oracle_gemm_f32 -- also across split-K slabs only up to the order of the final slab sum.
 constexpr int BK = 16, PAD = 4;
+// Short reductions (K of a 64-wide Linear) over many rows are latency-bound with 16-deep tiles: a workgroup would go
+// global -> registers -> LDS -> barrier four times for 2 us of MFMA work.  The <.., BKT = 64, NBUF = 1> form stages a
+// 64-deep tile per barrier pair (every load of the tile in flight at once, one LDS buffer: 49 KB for 128 x 64).
 
 // <BM, BN> in {(128,128): waves 2x2 of 64x64; (128,64): waves 4x1 of 32x64; (64,128): waves 2x2 of 32x64 -- the last
 // for outputs with <= 64 rows (weight gradients of 64-wide layers), where a 128-row tile would be half padding}
-template <int BM, int BN>
+template <int BM, int BN, int BKT = BK, int NBUF = 2>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
     const float *__restrict__ bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
@@ -28,8 +31,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     float *__restrict__ slabs) {
   constexpr int WM = (BM == 128 && BN == 128) ? 2 : 1;   // 32-row accumulator blocks per wave
   constexpr int WN = 2;                   // 32-col accumulator blocks per wave
-  __shared__ float As[2][BK][BM + PAD];
-  __shared__ float Bs[2][BK][BN + PAD];
+  constexpr int BK = BKT;                 // (shadows the default tile depth inside this kernel)
+  // k-rows of a deep tile are skewed by 4 floats per 16 rows (SK): the transposing stash below writes, per wave,
+  // 4 tile rows x 16 k-quads, and k-quads 16 rows apart would otherwise land in the same LDS banks
+  constexpr int SKW = BK > 16 ? 12 : 0;
+#define SK(k) (4 * (((k) >> 4) & 3))
+  constexpr int KQ = BK / 4;              // float4 per tile row along k
+  __shared__ float As[NBUF][BK][BM + PAD + SKW];
+  __shared__ float Bs[NBUF][BK][BN + PAD + SKW];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
       for (int p = 0; p < A_V; ++p) {
         const int v = t + p * 256;
         if (!transA) {
-          const int mm = v >> 2, k4 = (v & 3) * 4;
+          const int mm = v / KQ, k4 = (v % KQ) * 4;
           ra[p] = *reinterpret_cast<const float4 *>(A + (m0 + mm) * lda + k0 + k4);
         } else {
           const int kk = v / (BM / 4), m4 = (v % (BM / 4)) * 4;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
       const int v = t + p * 256;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!transA) {  // A[m][k]: vector along k
-        const int mm = v >> 2, k4 = (v & 3) * 4;
+        const int mm = v / KQ, k4 = (v % KQ) * 4;
         const int64_t gm = m0 + mm, gk = k0 + k4;
         if (gm < M) {
           const float *src = A + gm * lda + gk;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
       for (int p = 0; p < B_V; ++p) {
         const int v = t + p * 256;
         if (transB) {
-          const int nn = v >> 2, k4 = (v & 3) * 4;
+          const int nn = v / KQ, k4 = (v % KQ) * 4;
           rb[p] = *reinterpret_cast<const float4 *>(B + (n0 + nn) * ldb + k0 + k4);
         } else {
           const int kk = v / (BN / 4), n4 = (v % (BN / 4)) * 4;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
       const int v = t + p * 256;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (transB) {   // B stored [n][k]: vector along k
-        const int nn = v >> 2, k4 = (v & 3) * 4;
+        const int nn = v / KQ, k4 = (v % KQ) * 4;
         const int64_t gn = n0 + nn, gk = k0 + k4;
         if (gn < N) {
           const float *src = B + gn * ldb + gk;
@@ -161,28 +170,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     for (int p = 0; p < A_V; ++p) {
       const int v = t + p * 256;
       if (!transA) {
-        const int mm = v >> 2, k4 = (v & 3) * 4;
-        As[buf][k4 + 0][mm] = ra[p].x;
-        As[buf][k4 + 1][mm] = ra[p].y;
-        As[buf][k4 + 2][mm] = ra[p].z;
-        As[buf][k4 + 3][mm] = ra[p].w;
+        const int mm = v / KQ, k4 = (v % KQ) * 4;
+        float *d = &As[buf][k4][mm + SK(k4)];           // k4 .. k4+3 share a skew (k4 is a multiple of 4)
+        d[0 * (BM + PAD + SKW)] = ra[p].x;
+        d[1 * (BM + PAD + SKW)] = ra[p].y;
+        d[2 * (BM + PAD + SKW)] = ra[p].z;
+        d[3 * (BM + PAD + SKW)] = ra[p].w;
       } else {
         const int kk = v / (BM / 4), m4 = (v % (BM / 4)) * 4;
-        *reinterpret_cast<float4 *>(&As[buf][kk][m4]) = ra[p];
+        *reinterpret_cast<float4 *>(&As[buf][kk][m4 + SK(kk)]) = ra[p];
       }
     }
 #pragma unroll
     for (int p = 0; p < B_V; ++p) {
       const int v = t + p * 256;
       if (transB) {
-        const int nn = v >> 2, k4 = (v & 3) * 4;
-        Bs[buf][k4 + 0][nn] = rb[p].x;
-        Bs[buf][k4 + 1][nn] = rb[p].y;
-        Bs[buf][k4 + 2][nn] = rb[p].z;
-        Bs[buf][k4 + 3][nn] = rb[p].w;
+        const int nn = v / KQ, k4 = (v % KQ) * 4;
+        float *d = &Bs[buf][k4][nn + SK(k4)];
+        d[0 * (BN + PAD + SKW)] = rb[p].x;
+        d[1 * (BN + PAD + SKW)] = rb[p].y;
+        d[2 * (BN + PAD + SKW)] = rb[p].z;
+        d[3 * (BN + PAD + SKW)] = rb[p].w;
       } else {
         const int kk = v / (BN / 4), n4 = (v % (BN / 4)) * 4;
-        *reinterpret_cast<float4 *>(&Bs[buf][kk][n4]) = rb[p];
+        *reinterpret_cast<float4 *>(&Bs[buf][kk][n4 + SK(kk)]) = rb[p];
       }
     }
   };
@@ -206,9 +217,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) af[s][i] = As[buf][2 * s + h][wrow + 32 * i + r];
+      for (int i = 0; i < WM; ++i) af[s][i] = As[buf][2 * s + h][SK(2 * s) + wrow + 32 * i + r];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bf[s][j] = Bs[buf][2 * s + h][wcol + 32 * j + r];
+      for (int j = 0; j < WN; ++j) bf[s][j] = Bs[buf][2 * s + h][SK(2 * s) + wcol + 32 * j + r];
     }
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
@@ -218,9 +229,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
         for (int j = 0; j < WN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    if (NBUF == 2) {
+      if (more) stash(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    } else {
+      __syncthreads();          // every wave is done reading the single buffer
+      if (more) stash(0);
+      __syncthreads();
+    }
   }
 
   // epilogue: C/D layout col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -250,6 +267,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     }
   }
 }
+
+#undef SK
 
 // split-K second pass: C = sum_z slab[z] (+ bias) (+ C) (+ act), in a FIXED order: 8 lanes per output element take the
 // slabs z = l, l+8, ... in ascending order (each 32-thread group reads 32 consecutive elements of a slab: coalesced),
@@ -283,6 +302,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float *__r
 struct GemmPlan {
   int bm;
   int bn;
+  int bk;
   int splits;
   int64_t k_per_split;
 };
@@ -302,9 +322,12 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     if (s < 1) s = 1;
     p.splits = (int)s;
   }
+  // 64-wide outputs with a reduction of at most a few hundred (Linear 64->64 / 128->64 over all graph nodes, and the
+  // k-slices of their weight gradients): deep tiles, see the note at BK
+  p.bk = (p.bn == 64 && p.bm == 128 && (p.splits > 1 || K <= 512)) ? 64 : BK;
   int64_t per = (K + p.splits - 1) / p.splits;
-  per = (per + BK - 1) / BK * BK;
-  p.k_per_split = per < BK ? BK : per;
+  per = (per + p.bk - 1) / p.bk * p.bk;
+  p.k_per_split = per < p.bk ? p.bk : per;
   p.splits = (int)((K + p.k_per_split - 1) / p.k_per_split);
   if (p.splits < 1) p.splits = 1;
   return p;
@@ -395,7 +418,10 @@ extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const 
   hipStream_t st = (hipStream_t)stream;
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
   const dim3 grid((unsigned)((M + p.bm - 1) / p.bm), (unsigned)((N + p.bn - 1) / p.bn), (unsigned)p.splits);
-  if (p.bn == 64)
+  if (p.bn == 64 && p.bk == 64)
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 64, 1>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc,
+                       transA, transB, accumulate, act, p.k_per_split, slabs);
+  else if (p.bn == 64)
     hipLaunchKernelGGL((gemm_f32_kernel<128, 64>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
                        transB, accumulate, act, p.k_per_split, slabs);
   else if (p.bm == 64)

@@ -8,6 +8,8 @@ shapes = [  # (M, N, K, transA, transB)  -- C[M,N] = op(A) op(B)
     (60499, 256, 256, False, True), (60499, 64, 320, False, True), (60499, 64, 64, False, True),
     (60499, 256, 64, False, False), (256, 256, 60499, True, False), (64, 320, 60499, True, False),
     (11384, 64, 4096, False, True), (64, 4096, 11384, True, False), (14079, 256, 128, False, True),
+    # NGCF at sports size: forward / input-gradient / weight-gradient of a 64 -> 64 layer over all 47 k nodes
+    (47297, 64, 64, False, True), (47297, 64, 64, False, False), (64, 64, 47297, True, False), (47297, 64, 128, False, True),
 ]
 for M, N, K, tA, tB in shapes:
     A = torch.randn((K, M) if tA else (M, K), device=dev)
