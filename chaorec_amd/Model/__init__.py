@@ -2,3 +2,4 @@ from .LightGCN import LightGCN  # noqa: F401
 from .FREEDOM import FREEDOM  # noqa: F401
 from .MMGCN import MMGCN  # noqa: F401
 from .NGCF import NGCF  # noqa: F401
+from .MGCN import MGCN  # noqa: F401

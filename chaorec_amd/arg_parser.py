@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build_parser():
     parser = argparse.ArgumentParser(description="Run ChaoRec (MI355X hot path).")
-    parser.add_argument('--Model', nargs='?', default='LightGCN', help='Model name: LightGCN | MMGCN | FREEDOM')
+    parser.add_argument('--Model', nargs='?', default='LightGCN', help='Model name: LightGCN | MMGCN | FREEDOM | NGCF | MGCN')
     parser.add_argument('--data_path', nargs='?', default='baby', help='baby, clothing, sports, beauty, microlens, netfilx')
     parser.add_argument('--data_root', default='./Data', help='directory holding <data_path>/train.npy ...')
     parser.add_argument('--learning_rate', type=float, nargs='+', default=1e-3, help='Learning rates')
@@ -26,6 +26,8 @@ def build_parser():
     parser.add_argument('--dropout', type=float, default=0.2, help='Dropout.')
     parser.add_argument('--n_layers', type=int, default=2, help='conv_layers.')
     parser.add_argument('--mm_layers', type=int, default=2, help='the number of multimodal layer.')
+    parser.add_argument('--ssl_temp', type=float, default=0.9, help='temperature coefficient.')
+    parser.add_argument('--ssl_alpha', type=float, default=0.9, help='ssl coefficient.')
     parser.add_argument('--no_graph', action='store_true',
                         help='eager launches instead of one captured hipGraph replay per training batch')
     parser.add_argument('--ii_topk', type=int, default=10, help='the number of item-item graph topk.')

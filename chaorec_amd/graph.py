@@ -27,9 +27,13 @@ class CSR:
         return int(self.col.numel())
 
     def to(self, device):
-        t = self._t.to(device) if self._t is not None else None
-        return CSR(self.rowptr.to(device), self.col.to(device), self.val.to(device), self.n_rows,
-                   self.n_cols, self.symmetric, t)
+        out = CSR(self.rowptr.to(device), self.col.to(device), self.val.to(device), self.n_rows,
+                  self.n_cols, self.symmetric)
+        t = self._t
+        if t is not None:        # t() links a matrix and its transpose to each other: move the pair, keep the link
+            out._t = CSR(t.rowptr.to(device), t.col.to(device), t.val.to(device), t.n_rows, t.n_cols, t.symmetric)
+            out._t._t = out
+        return out
 
     def schedule(self, D):
         """The SpMM kernel's schedule for feature width D (int32 tensor on the graph's device, cached): row

@@ -80,6 +80,13 @@ def dropout_adj(edge_index, edge_attr=None, p=0.5, force_undirected=False, num_n
     return edge_index[:, mask], edge_attr
 
 
+def scatter_add(src, index, dim=0, out=None, dim_size=None):
+    """torch_scatter.scatter_add (2.0.9) for 1-D src along dim 0 (Model/MGCN.py:21-24)."""
+    assert dim == 0 and out is None and src.dim() == 1
+    n = int(index.max()) + 1 if dim_size is None else dim_size
+    return torch.zeros((n,), dtype=src.dtype, device=src.device).scatter_add_(0, index, src)
+
+
 def _unused(*a, **k):
     raise NotImplementedError("not on the hot path")
 
@@ -106,6 +113,11 @@ def install():
     utils.dropout_adj = dropout_adj
     tg.nn = nn
     tg.utils = utils
+    ts = types.ModuleType("torch_scatter")
+    ts._standin = True
+    ts.scatter_add = scatter_add
+    if "torch_scatter" not in sys.modules:
+        sys.modules["torch_scatter"] = ts
     for name, mod in (("torch_geometric", tg), ("torch_geometric.nn", nn),
                       ("torch_geometric.nn.conv", conv), ("torch_geometric.nn.inits", inits),
                       ("torch_geometric.utils", utils)):

@@ -36,6 +36,7 @@ from Model.LightGCN import LightGCN  # noqa: E402
 from Model.FREEDOM import FREEDOM  # noqa: E402
 from Model.MMGCN import MMGCN  # noqa: E402
 from Model.NGCF import NGCF  # noqa: E402
+from Model.MGCN import MGCN  # noqa: E402
 import metrics as ref_metrics  # noqa: E402,F401
 import utils as ref_utils  # noqa: E402
 import dataload as ref_dataload  # noqa: E402
@@ -322,8 +323,42 @@ def gen_ngcf():
                             **{"p_" + k: v for k, v in state.items()}, **grads)
 
 
+def gen_mgcn():
+    """Reference MGCN (a member of the torch.sparse.mm family; deterministic forward): construction,
+    one loss + backward, ranking.  torch_scatter.scatter_add is the restated one of oracle/pyg_standin.py."""
+    U, I = 48, 40
+    e = small_graph(U, I, 3, 7, 14)
+    D = 16
+    v_feat = seeded((I, 24), 31, 1.0)
+    t_feat = seeded((I, 12), 32, 1.0)
+    rng = np.random.default_rng(15)
+    b = rng.choice(len(e), 32, replace=False)
+    users = e[b, 0].astype(np.int64)
+    pos = e[b, 1].astype(np.int64)
+    neg = rng.integers(U, U + I, 32).astype(np.int64)
+    torch.manual_seed(0)
+    m = MGCN(U, I, e, uid(e), torch.from_numpy(v_feat), torch.from_numpy(t_feat), D, 1e-4, 2, "add", 0.2, 0.01, DEV)
+    state = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    loss = m.loss(torch.from_numpy(users), torch.from_numpy(pos), torch.from_numpy(neg))
+    loss.backward()
+    grads = {"g_" + k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+    MGCN.gene_ranklist.__defaults__ = (10,)
+    rank = m.gene_ranklist()
+    MGCN.gene_ranklist.__defaults__ = (50,)
+    coo = lambda t: (t.coalesce().indices().numpy(), t.coalesce().values().numpy())
+    (na_i, na_v), (r_i, r_v) = coo(m.norm_adj), coo(m.R)
+    (im_i, im_v), (tx_i, tx_v) = coo(m.image_original_adj), coo(m.text_original_adj)
+    np.savez_compressed(os.path.join(HERE, "mgcn_small.npz"), U=U, I=I, edges=e, D=D, reg=1e-4, ssl_temp=0.2,
+                        ssl_alpha=0.01, v_feat=v_feat, t_feat=t_feat, users=users, pos=pos, neg=neg,
+                        loss=np.float64(loss.item()), result=m.result.detach().numpy(), rank=rank.numpy(), topk=10,
+                        norm_adj_idx=na_i, norm_adj_val=na_v, R_idx=r_i, R_val=r_v, image_adj_idx=im_i,
+                        image_adj_val=im_v, text_adj_idx=tx_i, text_adj_val=tx_v,
+                        param_names=np.array([k for k, _ in m.named_parameters()]),
+                        **{"p_" + k: v for k, v in state.items()}, **grads)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lightgcn_tiny", "baby", "sampler", "freedom", "mmgcn", "ngcf"]
+    which = sys.argv[1:] or ["lightgcn_tiny", "baby", "sampler", "freedom", "mmgcn", "ngcf", "mgcn"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

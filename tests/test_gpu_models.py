@@ -337,3 +337,42 @@ def test_ngcf_device_dropout_trains_under_graph_capture(dev):
         first = float(le.detach()) if first is None else first
         last = float(le.detach())
     assert last < first
+
+
+def test_mgcn_golden(dev):
+    """MGCN (a member of the torch.sparse.mm family) against the reference model's own output: the
+    four graphs it builds, the representation, loss, the gradient of every parameter and the ranking."""
+    from chaorec_amd.Model import MGCN
+    from chaorec_amd import graph
+    g = load_golden("mgcn_small.npz")
+    U, I, N = int(g["U"]), int(g["I"]), int(g["U"]) + int(g["I"])
+    torch.manual_seed(0)
+    m = MGCN(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+             torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]), 2, "add", float(g["ssl_temp"]),
+             float(g["ssl_alpha"]), dev)
+    names = [str(n) for n in g["param_names"]]
+    assert [n for n, _ in m.named_parameters()] == names
+    for n, p in m.named_parameters():          # same seed, same creation order -> the reference's initial weights
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    m = m.to(dev)
+    assert np.array_equal(_csr_dense(m.norm_adj), _coo_dense(g["norm_adj_idx"], g["norm_adj_val"], (N, N)))
+    assert np.array_equal(_csr_dense(m.R), _coo_dense(g["R_idx"], g["R_val"], (U, I)))
+    for mine, tag in ((m.image_original_adj, "image"), (m.text_original_adj, "text")):
+        ref = _coo_dense(g[tag + "_adj_idx"], g[tag + "_adj_val"], (I, I))
+        got = _csr_dense(mine)
+        assert np.array_equal(got != 0, ref != 0) and np.allclose(got, ref, rtol=1e-5, atol=1e-7), tag
+    loss = m.loss(torch.from_numpy(g["users"]), torch.from_numpy(g["pos"]), torch.from_numpy(g["neg"]))
+    loss.backward()
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=5e-6)
+    for n, p in m.named_parameters():
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-12), n
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    sc = g["result"][:U] @ g["result"][U:].T
+    for u, items in graph.user_item_dict_from_edges(g["edges"]).items():
+        sc[u, np.asarray(items) - U] = 1e-6
+    ok, why = tie_aware_rank_equal(rank, np.take_along_axis(sc, rank - U, 1), g["rank"],
+                                   np.take_along_axis(sc, g["rank"] - U, 1), rtol=1e-4, atol=1e-7)
+    assert ok, why

@@ -281,3 +281,12 @@ def test_ngcf_structure_maps_and_parameter_surface():
         assert np.array_equal(p.detach().numpy(), g["p_" + n]), n
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.forward()
+
+
+def test_csr_to_keeps_the_transpose_link():
+    from chaorec_amd import graph
+    a = graph.coo_to_csr_coalesced(torch.tensor([0, 0, 2]), torch.tensor([1, 3, 0]), torch.tensor([1., 2., 3.]), 3, 4)
+    t = a.t()
+    assert t.t() is a and (t.n_rows, t.n_cols) == (4, 3)
+    b = a.to("cpu")                       # a matrix and its transpose reference each other: to() must not recurse
+    assert b.t().t() is b and torch.equal(b.t().col, t.col) and torch.equal(b.t().val, t.val)

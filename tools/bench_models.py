@@ -3,7 +3,7 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chaorec_amd import graph, dataload
-from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN, NGCF
+from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN, NGCF, MGCN
 from chaorec_amd.optim import FusedAdam
 from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
 dev = torch.device("cuda:0")
@@ -20,6 +20,8 @@ for spec in which:
         m = LightGCN(U, I, edges, uid, 64, 1e-3, 3, "add", dev)
     elif name == "NGCF":
         m = NGCF(U, I, edges, uid, 64, 1e-3, 0.2, 3, "add", dev)
+    elif name == "MGCN":
+        m = MGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, 2, "add", 0.2, 0.01, dev)
     elif name == "FREEDOM":
         m = FREEDOM(U, I, edges, uid, v_feat, t_feat, 64, 64, 1e-3, 0.1, 2, 1, 10, 0.8, dev)
     else:
