@@ -19,6 +19,8 @@ from .. import graph, ops, ranking
 
 
 class FREEDOM(nn.Module):
+    prunes_in_place = True     # pre_epoch_processing() rewrites masked_adj's arrays, it never re-allocates them
+
     def __init__(self, num_user, num_item, edge_index, user_item_dict, v_feat, t_feat, dim_E, dim_feat, reg_weight,
                  dropout, n_layers, mm_layers, ii_topk, mm_image_weight, device):
         super(FREEDOM, self).__init__()
@@ -146,8 +148,16 @@ class FREEDOM(nn.Module):
         keep_indices = keep_indices.clone()
         keep_indices[1] += self.num_user
         all_indices = torch.cat((keep_indices, torch.flip(keep_indices, [0])), 1)
-        self.masked_adj = graph.coo_to_csr_coalesced(all_indices[0], all_indices[1], all_values, self.n_nodes,
-                                                     self.n_nodes, symmetric=True).to(self.device)
+        new = graph.coo_to_csr_coalesced(all_indices[0], all_indices[1], all_values, self.n_nodes, self.n_nodes,
+                                         symmetric=True).to(self.device)
+        # every epoch keeps the same number of edges: rewrite the pruned graph in place, so that a captured training
+        # step (which holds the addresses of these arrays) trains on the new graph at its next replay
+        cur = self.masked_adj
+        if cur is None or cur is self.norm_adj:
+            self.masked_adj = new
+        elif not cur.update_from(new):
+            raise RuntimeError("FREEDOM: the pruned graph changed its entry count between epochs "
+                               f"({cur.nnz} -> {new.nnz}); a captured training step would keep the old one")
 
     # ---- hot path ---------------------------------------------------------------------------
     def forward(self, adj):

@@ -21,6 +21,7 @@ class CSR:
         self.symmetric = bool(symmetric)
         self._t = transpose
         self._orders = {}
+        self._order_dims = {}
 
     @property
     def nnz(self):
@@ -56,7 +57,22 @@ class CSR:
                                                  ctypes.c_void_p(out.data_ptr()), n)
             _lib.check(rc, "chaorec_spmm_build_schedule")
             self._orders[g] = out.to(self.rowptr.device)
+            self._order_dims[g] = int(D)
         return self._orders[g]
+
+    def update_from(self, other):
+        """Overwrite this graph IN PLACE with `other` (same shape and entry count) and refresh the SpMM schedules
+        already built for it: the device addresses stay the same, so a captured hipGraph that reads this CSR sees
+        the new graph on its next replay (FREEDOM re-prunes its adjacency every epoch).  False if the sizes differ."""
+        if (self.n_rows, self.n_cols, self.nnz) != (other.n_rows, other.n_cols, other.nnz) or self._t is not None:
+            return False
+        self.rowptr.copy_(other.rowptr)
+        self.col.copy_(other.col)
+        self.val.copy_(other.val)
+        self.symmetric = other.symmetric
+        for g, D in self._order_dims.items():
+            self._orders[g].copy_(other.schedule(D))
+        return True
 
     def t(self):
         """CSR of A^T (the backward operator).  A symmetric graph is its own transpose."""

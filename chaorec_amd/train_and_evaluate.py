@@ -50,11 +50,14 @@ def _log_metrics(title, metrics):
 def _capture_step(model, train_loader, optimizer, model_name):
     """The launch-bound inner loop (train_and_evaluate.py:43-48) as one hipGraph replay per batch: possible when the
     batches already live in HBM with a fixed shape, the optimizer's step counter is on the device and the graph
-    structure does not change between epochs (FREEDOM re-prunes its adjacency every epoch: eager)."""
+    graph arrays keep their addresses between epochs (FREEDOM re-prunes its adjacency every epoch IN PLACE, so its
+    step is captured once, after the first pre_epoch_processing())."""
     from .dataload import DeviceBatchSampler
     from .optim import FusedAdam, GraphedTrainStep
-    if model_name in PRE_EPOCH or not isinstance(train_loader, DeviceBatchSampler) or not isinstance(optimizer, FusedAdam):
+    if not isinstance(train_loader, DeviceBatchSampler) or not isinstance(optimizer, FusedAdam):
         return None
+    if model_name in PRE_EPOCH and not getattr(model, "prunes_in_place", False):
+        return None          # a graph that is re-allocated every epoch cannot sit behind captured addresses
     if len(train_loader) < 2:
         return None
     example = next(iter(train_loader))
@@ -64,7 +67,7 @@ def _capture_step(model, train_loader, optimizer, model_name):
 def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epochs, model_name="LightGCN",
                        topk=(5, 10, 20), patience=20, graph=True):
     model.train()
-    graphed = _capture_step(model, train_loader, optimizer, model_name) if graph else None
+    graphed, capture_pending = None, bool(graph)
     early_stopping = EarlyStopping(patience=patience, verbose=True)
     topk = [int(k) for k in topk]
     # evaluation stays on the device when the model can hand the rank list over in HBM
@@ -74,6 +77,8 @@ def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epoc
     for epoch in range(epochs):
         if model_name in PRE_EPOCH:
             model.pre_epoch_processing()
+        if capture_pending:
+            graphed, capture_pending = _capture_step(model, train_loader, optimizer, model_name), False
         loss = train(model, train_loader, optimizer, model_name, graphed)
         logging.info("Epoch {}, Loss: {:.5f}".format(epoch + 1, loss))
 

@@ -376,3 +376,36 @@ def test_mgcn_golden(dev):
     ok, why = tie_aware_rank_equal(rank, np.take_along_axis(sc, rank - U, 1), g["rank"],
                                    np.take_along_axis(sc, g["rank"] - U, 1), rtol=1e-4, atol=1e-7)
     assert ok, why
+
+
+def test_freedom_captured_step_follows_the_per_epoch_pruning(dev):
+    """pre_epoch_processing() rewrites the pruned graph IN PLACE (same addresses, refreshed SpMM schedule), so ONE
+    captured training step keeps training on the graph of the current epoch: per-step losses and final parameters
+    equal those of eager training on the same pruning stream."""
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    g = load_golden("freedom_small_drop.npz")
+    batch = tuple(torch.from_numpy(g[k]).to(dev) for k in ("users", "pos", "neg"))
+    eager, _, _ = _make_freedom(g, dev)
+    cap, _, _ = _make_freedom(g, dev)
+    oe, oc = FusedAdam(eager.parameters(), lr=1e-2), FusedAdam(cap.parameters(), lr=1e-2)
+    step, ptrs, graphs = None, None, []
+    for epoch in range(4):
+        eager.pre_epoch_processing()
+        cap.pre_epoch_processing()
+        assert torch.equal(eager.masked_adj.col, cap.masked_adj.col)
+        graphs.append(cap.masked_adj.col.clone())
+        if step is None:
+            step = GraphedTrainStep(cap, oc, example_batch=batch)
+            ptrs = (cap.masked_adj.rowptr.data_ptr(), cap.masked_adj.col.data_ptr(), cap.masked_adj.val.data_ptr())
+        assert ptrs == (cap.masked_adj.rowptr.data_ptr(), cap.masked_adj.col.data_ptr(), cap.masked_adj.val.data_ptr())
+        for it in range(3):
+            oe.zero_grad()
+            le = eager.loss(*batch)
+            le.backward()
+            oe.step()
+            lc = step(*batch)
+            assert float(lc.detach()) == pytest.approx(float(le.detach()), rel=1e-5), (epoch, it)
+    assert not torch.equal(graphs[0], graphs[1])          # the epochs really trained on different graphs
+    # (Adam turns rounding-level gradient differences of near-zero components into +-lr steps: loose bound)
+    for (n, a), (_, b) in zip(eager.named_parameters(), cap.named_parameters()):
+        assert float((a - b).abs().max()) < 0.03 * float(a.abs().max()) + 1e-3, n
