@@ -100,3 +100,56 @@ def test_main_entry_point_two_epochs(dev, model, tmp_path, monkeypatch):
         assert set(best[k]) == {"precision", "recall", "ndcg", "hit_rate", "map"}
         assert 0.0 <= best[k]["recall"] <= 1.0
     assert (tmp_path / "log" / f"{model}_baby.log").exists()
+
+
+def test_weighted_sample_beyond_the_multinomial_limit(dev):
+    """torch.multinomial stops at 2^24 categories (the reason FREEDOM's pruning cannot grow with the graph,
+    SURVEY 8(f).4); the device sampler keeps exactly k of 2^25 + 5 weighted edges, reproducibly, and favours heavy
+    edges as the sequential law does."""
+    from chaorec_amd import ops
+    n = (1 << 25) + 5
+    k = int(n * 0.8)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    w = torch.rand(n, device=dev, generator=g) + 0.05
+    with pytest.raises(RuntimeError):
+        torch.multinomial(w, k)
+    keep = ops.weighted_sample_keep(w, k, seed=3, step=1)
+    assert int(keep.sum()) == k
+    assert torch.equal(keep, ops.weighted_sample_keep(w, k, seed=3, step=1))
+    assert not torch.equal(keep, ops.weighted_sample_keep(w, k, seed=3, step=2))
+    kept, dropped = w[keep.bool()].mean().item(), w[~keep.bool()].mean().item()
+    assert kept > dropped + 0.1          # light edges are the ones that get pruned
+
+
+def test_ngcf_sports_size_step(dev):
+    """NGCF at the sports shape: the dropped-and-renormalised values stay a symmetric normalisation of the kept
+    graph (row sums of D^-1/2 (keep*A + I) D^-1/2 against its own degrees), a training step runs, ranking is valid."""
+    from chaorec_amd import graph, ops
+    from chaorec_amd.Model import NGCF
+    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+    U, I, E = DATASET_SHAPES["sports"]
+    edges = synthetic_interactions(U, I, E, seed=42)
+    torch.manual_seed(0)
+    m = NGCF(U, I, edges, graph.user_item_dict_from_edges(edges), 64, 1e-3, 0.2, 3, "add", dev).to(dev)
+    s = m.graph
+    val, val_t = ops.edge_dropout_norm(s, 0.2, seed=5, step=9)
+    er, col = s.entry_row.long(), s.col.long()
+    kept = val > 0
+    assert bool(kept[er == col].all())                                   # self loops always survive
+    frac = float(kept[er != col].float().mean())
+    assert abs(frac - 0.8) < 0.005
+    deg = torch.zeros(U + I, device=dev).index_add_(0, col[kept], torch.ones(int(kept.sum()), device=dev))
+    want = (deg[col] ** -0.5) * (deg[er] ** -0.5)
+    assert torch.allclose(val[kept], want[kept], rtol=1e-6)
+    # val_t is val read through the reversed-edge map
+    assert torch.equal(val_t, val[s.transpose_entry.long()])
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    b = torch.from_numpy(edges[:1024].astype(np.int64))
+    neg = torch.randint(U, U + I, (1024,))
+    loss = m.loss(b[:, 0], b[:, 1], neg)
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters())
+    rank = m.gene_ranklist(topk=20)
+    assert rank.shape == (U, 20) and int(rank.min()) >= U and int(rank.max()) < U + I
