@@ -11,7 +11,7 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libchaorec_hip.so")
-SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip", "metrics.hip", "graph_dropout.hip"]
+SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip", "metrics.hip", "graph_dropout.hip", "rowops.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
@@ -61,6 +61,9 @@ SIGNATURES = {
     "chaorec_edge_dropout_norm": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_float,
                                                  ctypes.c_uint64, ctypes.c_uint64, c_ptr, ctypes.c_uint32, c_ptr, c_ptr,
                                                  c_ptr, c_ptr, c_ptr]),
+    "chaorec_row_cosine_scale_fwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr]),
+    "chaorec_row_cosine_scale_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64,
+                                                        ctypes.c_int32, c_ptr]),
     "chaorec_weighted_sample_workspace_bytes": (ctypes.c_size_t, []),
     "chaorec_weighted_sample_keep": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
                                                     ctypes.c_uint64, c_ptr, c_ptr, ctypes.c_size_t, c_ptr, c_ptr,

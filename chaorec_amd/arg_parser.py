@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build_parser():
     parser = argparse.ArgumentParser(description="Run ChaoRec (MI355X hot path).")
-    parser.add_argument('--Model', nargs='?', default='LightGCN', help='Model name: LightGCN | MMGCN | FREEDOM | NGCF | MGCN')
+    parser.add_argument('--Model', nargs='?', default='LightGCN', help='Model name: LightGCN | MMGCN | FREEDOM | NGCF | MGCN | LayerGCN')
     parser.add_argument('--data_path', nargs='?', default='baby', help='baby, clothing, sports, beauty, microlens, netfilx')
     parser.add_argument('--data_root', default='./Data', help='directory holding <data_path>/train.npy ...')
     parser.add_argument('--learning_rate', type=float, nargs='+', default=1e-3, help='Learning rates')

@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import FREEDOM, LightGCN, MGCN, MMGCN, NGCF
+from .Model import FREEDOM, LayerGCN, LightGCN, MGCN, MMGCN, NGCF
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
 from .optim import FusedAdam
@@ -33,7 +33,7 @@ def setup_logging(args):
 
 
 def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_feat, device):
-    """The rows of the reference's constructor table on the hot path (main.py:261-263, :267-270, :287-289, :316-317)."""
+    """The rows of the reference's constructor table on the hot path (main.py:261-263, :267-270, :287-289, :316-317, :323-324)."""
     dim_E, aggr_mode = args.dim_E, args.aggr_mode
     table = {
         'MMGCN': lambda: MMGCN(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
@@ -45,6 +45,8 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
         'FREEDOM': lambda: FREEDOM(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E,
                                    args.feature_embed, args.reg_weight, args.dropout, args.n_layers, args.mm_layers,
                                    args.ii_topk, args.lambda_coeff, device),
+        'LayerGCN': lambda: LayerGCN(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight,
+                                     args.n_layers, args.dropout, device),
         'MGCN': lambda: MGCN(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                              args.n_layers, aggr_mode, args.ssl_temp, args.ssl_alpha, device),
     }

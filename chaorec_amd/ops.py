@@ -425,3 +425,35 @@ def weighted_sample_keep(weights, k, seed, step=0, step_dev=None, return_keys=Fa
                                           _ptr(ws), nbytes, _ptr(keep), _ptr(keys), _stream())
     _lib.check(rc, "chaorec_weighted_sample_keep")
     return (keep, keys) if return_keys else keep
+
+
+# --------------------------------------------------------------------------------------------
+# row-wise cosine re-weighting (LayerGCN)
+# --------------------------------------------------------------------------------------------
+class _RowCosineScale(torch.autograd.Function):
+    """out = cosine_similarity(y, e, dim=-1)[:, None] * y (Model/LayerGCN.py:125-127): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, y, e):
+        _need_cuda(y, e)
+        y, e = _f32c(y), _f32c(e)
+        out = torch.empty_like(y)
+        rc = _lib.load().chaorec_row_cosine_scale_fwd_f32(_ptr(y), _ptr(e), _ptr(out), None, y.shape[0], y.shape[1],
+                                                          _stream())
+        _lib.check(rc, "chaorec_row_cosine_scale_fwd_f32")
+        ctx.save_for_backward(y, e)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, e = ctx.saved_tensors
+        g = g.contiguous()
+        gy, ge = torch.empty_like(y), torch.empty_like(e)
+        rc = _lib.load().chaorec_row_cosine_scale_bwd_f32(_ptr(g), _ptr(y), _ptr(e), _ptr(gy), _ptr(ge), y.shape[0],
+                                                          y.shape[1], _stream())
+        _lib.check(rc, "chaorec_row_cosine_scale_bwd_f32")
+        return gy, ge
+
+
+def row_cosine_scale(y, e):
+    return _RowCosineScale.apply(y, e)

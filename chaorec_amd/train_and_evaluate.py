@@ -11,7 +11,7 @@ import torch
 from .utils import EarlyStopping, EvalLists, gene_metrics, gene_metrics_device
 
 MMGCN_STYLE = ("MMGCN", "GRCN")
-PRE_EPOCH = ("FREEDOM",)
+PRE_EPOCH = ("FREEDOM", "LayerGCN")     # reference train_and_evaluate.py:555
 
 
 def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):

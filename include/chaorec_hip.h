@@ -290,6 +290,23 @@ int chaorec_weighted_sample_keep(const float *weights, int64_t n, int64_t k, uin
                                  const int64_t *step_dev, void *workspace, size_t workspace_bytes,
                                  uint8_t *keep, uint64_t *keys_out, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Row-wise cosine re-weighting of a propagated layer (LayerGCN).
+ *
+ * Replaces: _weights = F.cosine_similarity(all_embeddings, ego_embeddings, dim=-1)
+ *           all_embeddings = torch.einsum('a,ab->ab', _weights, all_embeddings)       (Model/LayerGCN.py:125-127)
+ *           and their autograd backward -- ~12 + ~25 elementwise / reduction launches per layer in the reference.
+ *
+ * fwd:  w_r = <y_r, e_r> / (max(|y_r|, 1e-8) * max(|e_r|, 1e-8));  out_r = w_r * y_r;  w_out[r] = w_r (optional).
+ * bwd:  with a = max(|y|, eps), b = max(|e|, eps), s = <grad_out, y>:
+ *         grad_y = w grad_out + s (e/(a b) - [|y| > eps] w y / a^2),  grad_e = s (y/(a b) - [|e| > eps] w e / b^2)
+ * y, e, out, grads: fp32 [n_rows, D] row-major, D a multiple of 4 in [4, 1024].  One launch each, one pass over HBM.
+ * ------------------------------------------------------------------------------------- */
+int chaorec_row_cosine_scale_fwd_f32(const float *y, const float *e, float *out, float *w_out,
+                                     int64_t n_rows, int32_t D, void *stream);
+int chaorec_row_cosine_scale_bwd_f32(const float *grad_out, const float *y, const float *e, float *grad_y,
+                                     float *grad_e, int64_t n_rows, int32_t D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

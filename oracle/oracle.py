@@ -285,6 +285,16 @@ def ngcf_forward(x0, w1s, w2s, train_edges, n_nodes, keep_masks=None):
     return out
 
 
+def row_cosine_scale(y, e, eps=1e-8):
+    """Model/LayerGCN.py:125-127 in fp64: w = cosine_similarity(y, e, dim=-1) (each norm clamped at eps, torch's
+    definition), out = w[:, None] * y.  Returns (out, w)."""
+    y, e = np.asarray(y, np.float64), np.asarray(e, np.float64)
+    a = np.maximum(np.linalg.norm(y, axis=1), eps)
+    b = np.maximum(np.linalg.norm(e, axis=1), eps)
+    w = (y * e).sum(1) / (a * b)
+    return w[:, None] * y, w
+
+
 def mix64(z):
     """splitmix64 finaliser on uint64 arrays (chaorec_amd/csrc/common.h:mix64)."""
     z = np.asarray(z, dtype=np.uint64)

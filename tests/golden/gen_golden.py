@@ -37,6 +37,7 @@ from Model.FREEDOM import FREEDOM  # noqa: E402
 from Model.MMGCN import MMGCN  # noqa: E402
 from Model.NGCF import NGCF  # noqa: E402
 from Model.MGCN import MGCN  # noqa: E402
+from Model.LayerGCN import LayerGCN  # noqa: E402
 import metrics as ref_metrics  # noqa: E402,F401
 import utils as ref_utils  # noqa: E402
 import dataload as ref_dataload  # noqa: E402
@@ -357,8 +358,57 @@ def gen_mgcn():
                         **{"p_" + k: v for k, v in state.items()}, **grads)
 
 
+def gen_layergcn():
+    """Reference LayerGCN (torch.sparse.mm family; LightGCN propagate + cosine layer weights + FREEDOM-style pruning).
+    Its get_norm_adj_mat calls scipy's private dok_matrix._update (Model/LayerGCN.py:65), gone from the scipy
+    installed here: the generator restores it as "assign every (row, col) -> value of the dict" -- what the old
+    method did -- so this golden pins "reference model code + that one restated scipy method"."""
+    import scipy.sparse as sp
+    if not hasattr(sp.dok_matrix, "_update"):
+        def _update(self, data):
+            for (r, c), v in data.items():
+                self[r, c] = v
+        sp.dok_matrix._update = _update
+    U, I = 48, 40
+    e = small_graph(U, I, 3, 7, 21)
+    D, L = 16, 3
+    rng = np.random.default_rng(22)
+    b = rng.choice(len(e), 32, replace=False)
+    users = e[b, 0].astype(np.int64)
+    pos = e[b, 1].astype(np.int64)
+    neg = rng.integers(U, U + I, 32).astype(np.int64)
+    torch.manual_seed(0)
+    m = LayerGCN(U, I, e, uid(e), D, 1e-3, L, 0.2, DEV)
+    state = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    norm = m.norm_adj_matrix.coalesce()
+    out = dict(norm_idx=norm.indices().numpy(), norm_val=norm.values().numpy(),
+               edge_indices=m.edge_indices.numpy(), edge_values=m.edge_values.numpy())
+    import random as pyrandom
+    torch.manual_seed(5)
+    pyrandom.seed(5)
+    for ep in range(2):                      # epoch 0 prunes by multinomial, epoch 1 by random.sample (:101-105)
+        m.pre_epoch_processing()
+        raw = m.masked_adj
+        co = raw.coalesce()
+        out[f"masked_idx_raw{ep}"] = raw._indices().numpy().copy()
+        out[f"masked_idx{ep}"], out[f"masked_val{ep}"] = co.indices().numpy(), co.values().numpy()
+    loss = m.loss(torch.from_numpy(users), torch.from_numpy(pos), torch.from_numpy(neg))
+    loss.backward()
+    grads = {"g_" + k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+    LayerGCN.gene_ranklist.__defaults__ = (10,)
+    rank = m.gene_ranklist()
+    LayerGCN.gene_ranklist.__defaults__ = (50,)
+    m.forward_adj = m.norm_adj_matrix
+    ue, ie = m.forward()
+    np.savez_compressed(os.path.join(HERE, "layergcn_small.npz"), U=U, I=I, edges=e, D=D, L=L, reg=1e-3, dropout=0.2,
+                        users=users, pos=pos, neg=neg, loss=np.float64(loss.item()), rank=rank.numpy(), topk=10,
+                        eval_result=torch.cat([ue, ie]).detach().numpy(),
+                        param_names=np.array([k for k, _ in m.named_parameters()]),
+                        **{"p_" + k: v for k, v in state.items()}, **grads, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lightgcn_tiny", "baby", "sampler", "freedom", "mmgcn", "ngcf", "mgcn"]
+    which = sys.argv[1:] or ["lightgcn_tiny", "baby", "sampler", "freedom", "mmgcn", "ngcf", "mgcn", "layergcn"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

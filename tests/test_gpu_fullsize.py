@@ -86,7 +86,7 @@ def test_mmgcn_microlens_size_vs_torch(dev):
     assert rank.shape == (U, 50)
 
 
-@pytest.mark.parametrize("model", ["LightGCN", "FREEDOM", "MMGCN", "NGCF", "MGCN"])
+@pytest.mark.parametrize("model", ["LightGCN", "FREEDOM", "MMGCN", "NGCF", "MGCN", "LayerGCN"])
 def test_main_entry_point_two_epochs(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic: grid search, train, evaluate."""
     import logging

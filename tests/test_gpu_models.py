@@ -409,3 +409,51 @@ def test_freedom_captured_step_follows_the_per_epoch_pruning(dev):
     # (Adam turns rounding-level gradient differences of near-zero components into +-lr steps: loose bound)
     for (n, a), (_, b) in zip(eager.named_parameters(), cap.named_parameters()):
         assert float((a - b).abs().max()) < 0.03 * float(a.abs().max()) + 1e-3, n
+
+
+def test_layergcn_golden(dev):
+    """LayerGCN (torch.sparse.mm family) against the reference model's own output: same initial weights from the same
+    seed, the normalised graph bit for bit, both prunings (fed with the edges the reference drew), loss, gradients,
+    the evaluation forward on the unpruned graph and the ranking."""
+    from chaorec_amd.Model import LayerGCN
+    from chaorec_amd import graph
+    g = load_golden("layergcn_small.npz")
+    U, I, N = int(g["U"]), int(g["I"]), int(g["U"]) + int(g["I"])
+    torch.manual_seed(0)
+    m = LayerGCN(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]),
+                 int(g["L"]), float(g["dropout"]), dev)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    m = m.to(dev)
+    assert np.array_equal(_csr_dense(m.norm_adj_matrix), _coo_dense(g["norm_idx"], g["norm_val"], (N, N)))
+    assert np.array_equal(m.edge_indices.cpu().numpy(), g["edge_indices"])
+    assert np.array_equal(m.edge_values.cpu().numpy(), g["edge_values"])
+    for ep in range(2):
+        raw = g[f"masked_idx_raw{ep}"]
+        keep = torch.from_numpy(raw[:, :raw.shape[1] // 2].copy())
+        keep[1] -= U
+        m._set_masked_adj(keep.to(dev))
+        assert np.allclose(_csr_dense(m.masked_adj), _coo_dense(g[f"masked_idx{ep}"], g[f"masked_val{ep}"], (N, N)),
+                           rtol=1e-6, atol=1e-9), ep
+    loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-6)
+    for n, p in m.named_parameters():
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-5 * (np.abs(ref).max() + 1e-12), n
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    res = m.result.cpu().numpy()
+    assert np.abs(res - g["eval_result"]).max() <= 2e-6 * np.abs(g["eval_result"]).max()
+    sc = g["eval_result"][:U] @ g["eval_result"][U:].T
+    for u, items in graph.user_item_dict_from_edges(g["edges"]).items():
+        sc[u, np.asarray(items) - U] = 1e-6
+    ok, why = tie_aware_rank_equal(rank, np.take_along_axis(sc, rank - U, 1), g["rank"],
+                                   np.take_along_axis(sc, g["rank"] - U, 1), rtol=1e-4, atol=1e-7)
+    assert ok, why
+    # the public pruning: alternates degree-sensitive / uniform draws of the same size, in place
+    m.pre_epoch_processing()
+    a, ptr = m.masked_adj.col.clone(), m.masked_adj.col.data_ptr()
+    m.pre_epoch_processing()
+    assert m.masked_adj.col.data_ptr() == ptr and not torch.equal(a, m.masked_adj.col)
+    assert m.masked_adj.nnz == 2 * int(len(g["edges"]) * (1 - float(g["dropout"])))

@@ -824,3 +824,32 @@ def test_weighted_sample_inclusion_probabilities(dev):
         for j in range(i + 1, 4):
             pij = w[i] / W * w[j] / (W - w[i]) + w[j] / W * w[i] / (W - w[j])
             assert abs(counts[i, j] / T - pij) < 4 * np.sqrt(pij * (1 - pij) / T) + 1e-3, (i, j)
+
+
+@pytest.mark.parametrize("n,D", [(1, 4), (1000, 64), (777, 128), (300, 20), (65, 384), (40, 1024)])
+def test_row_cosine_scale_vs_oracle_and_torch_autograd(dev, oracle, n, D):
+    """chaorec_row_cosine_scale_fwd/bwd against the fp64 restatement and against torch's own
+    F.cosine_similarity + einsum autograd in fp64 (tolerance: fp32 rounding of 3 row reductions)."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(n + D)
+    y = rng.standard_normal((n, D)).astype(np.float32)
+    e = rng.standard_normal((n, D)).astype(np.float32)
+    if n > 10:
+        y[3] = 0.0            # |y| below eps: w = 0, and the clamp branch of the gradient
+        e[5] = 0.0
+        y[7] = e[7]           # w = 1
+    go = rng.standard_normal((n, D)).astype(np.float32)
+    ty = torch.from_numpy(y).to(dev).requires_grad_(True)
+    te = torch.from_numpy(e).to(dev).requires_grad_(True)
+    out = ops.row_cosine_scale(ty, te)
+    out.backward(torch.from_numpy(go).to(dev))
+    want, w = oracle.row_cosine_scale(y, e)
+    assert np.allclose(out.detach().cpu().numpy(), want, rtol=2e-6, atol=1e-6)
+    dy = torch.from_numpy(y).double().requires_grad_(True)
+    de = torch.from_numpy(e).double().requires_grad_(True)
+    ref = torch.einsum('a,ab->ab', torch.nn.functional.cosine_similarity(dy, de, dim=-1), dy)
+    ref.backward(torch.from_numpy(go).double())
+    assert np.allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-6)
+    for got, r in ((ty.grad, dy.grad), (te.grad, de.grad)):
+        scale = float(r.abs().max()) + 1e-12
+        assert float((got.cpu().double() - r).abs().max()) <= 5e-6 * scale

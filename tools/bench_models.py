@@ -3,7 +3,7 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chaorec_amd import graph, dataload
-from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN, NGCF, MGCN
+from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN, NGCF, MGCN, LayerGCN
 from chaorec_amd.optim import FusedAdam
 from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
 dev = torch.device("cuda:0")
@@ -20,6 +20,8 @@ for spec in which:
         m = LightGCN(U, I, edges, uid, 64, 1e-3, 3, "add", dev)
     elif name == "NGCF":
         m = NGCF(U, I, edges, uid, 64, 1e-3, 0.2, 3, "add", dev)
+    elif name == "LayerGCN":
+        m = LayerGCN(U, I, edges, uid, 64, 1e-3, 3, 0.1, dev)
     elif name == "MGCN":
         m = MGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, 2, "add", 0.2, 0.01, dev)
     elif name == "FREEDOM":
@@ -31,7 +33,7 @@ for spec in which:
     t_build = time.time() - t0
     opt = FusedAdam(m.parameters(), lr=1e-3)
     sampler = dataload.DeviceBatchSampler(U, I, uid, edges, 1024, dev, name)
-    if name == "FREEDOM":
+    if name in ("FREEDOM", "LayerGCN"):
         m.pre_epoch_processing()
     it = iter(sampler)
     batches = [next(it) for _ in range(12)]
