@@ -53,7 +53,31 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph step")
     p.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP Adam")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    p.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)   # child mode of probe_sharded_graph()
     return p.parse_args()
+
+
+def probe_sharded_graph(args, world):
+    """Can this node replay a hipGraph that holds RCCL collectives?  Asked in a CHILD job (one child per rank, its own
+    rendezvous port) before this process touches the GPU: a launch mode that hangs then costs a bounded wait and an
+    eager run instead of the whole measurement.  Returns True when the child captured the sharded step, replayed it
+    and ran a few timed steps.  CHAOREC_DIST_GRAPH=0/1 skips the probe."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29511")) + 17
+    env = dict(os.environ, MASTER_PORT=str(port), CHAOREC_DIST_GRAPH="1", CHAOREC_GRAPH_WATCHDOG_S="60",
+               TORCHELASTIC_USE_AGENT_STORE="False")     # the children rendezvous among themselves, not at the agent
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", "3", "--warmup", "1",
+           "--dataset", args.dataset, "--dim", str(args.dim), "--n-layers", str(args.n_layers), "--batch",
+           str(args.batch), "--no-cpu-baseline", "--no-trained-state", "--probe-graph"]
+    try:
+        rc = subprocess.run(cmd, env=env, timeout=float(os.environ.get("CHAOREC_PROBE_TIMEOUT_S", "300")),
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+    except subprocess.TimeoutExpired:
+        rc = -1
+    if rc != 0:
+        print(f"[bench rank {os.environ.get('RANK', '0')}] probe of the captured sharded step ended with {rc}: "
+              f"eager launches", file=sys.stderr, flush=True)
+    return rc == 0
 
 
 def spmm_model_bytes(nnz, n_rows, D):
@@ -116,13 +140,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # CHAOREC_FORCE_SHARDED=1: run the N>1 code path (sharded model, RCCL calls, graph capture of them) on one rank
+    force_sharded = world == 1 and os.environ.get("CHAOREC_FORCE_SHARDED", "0") == "1"
+    backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    probe_ok = None
+    if ((world > 1 or force_sharded) and backend == "nccl" and not args.probe_graph and not args.no_graph
+            and not args.torch_adam and os.environ.get("CHAOREC_DIST_GRAPH") is None):
+        probe_ok = probe_sharded_graph(args, world)        # before anything here initialises the GPU
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     local_rank %= torch.cuda.device_count()     # (lets a 1-GPU box exercise the N>1 code path with gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # CHAOREC_FORCE_SHARDED=1: run the N>1 code path (sharded model, RCCL calls, graph capture of them) on one rank
-    force_sharded = world == 1 and os.environ.get("CHAOREC_FORCE_SHARDED", "0") == "1"
-    backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
     if world > 1 or force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -179,6 +207,11 @@ def main():
     use_graph = not args.no_graph and not args.torch_adam
     if sharded is not None:
         use_graph = use_graph and backend == "nccl" and os.environ.get("CHAOREC_DIST_GRAPH", "1") == "1"
+        if probe_ok is not None:
+            # the launch mode must be the same on every rank BEFORE anyone starts capturing collectives
+            flag = torch.tensor([1.0 if (use_graph and probe_ok) else 0.0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            use_graph = float(flag.item()) > 0.0
     graphed = None
     if use_graph:
         try:
@@ -396,6 +429,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(edges, U, I, D, L, B, reg, args.cpu_seconds)
     if world > 1 or force_sharded:
         torch.distributed.destroy_process_group()
+    if args.probe_graph:
+        sys.exit(0 if graphed is not None else 3)
     if rank == 0:
         # RCCL writes its version banner through C stdio, which would otherwise drain at exit, AFTER the result:
         # flush it first so that the JSON object is the last line on stdout
