@@ -96,24 +96,45 @@ __global__ __launch_bounds__(256) void race_histogram_kernel(const float *__rest
     if (h_s[i]) atomicAdd(hist + i, h_s[i]);
 }
 
-// one block: walk the histogram from the smallest digit, find the bin the k-th smallest key falls into
+// one wave: find the bin the k-th smallest key falls into.  Lane l owns bins [32 l, 32 l + 32): lane totals, an
+// exclusive wave scan, then the owning lane walks its 32 bins.
 __global__ __launch_bounds__(64) void race_pick_kernel(int pass, uint64_t *__restrict__ state,
                                                        uint32_t *__restrict__ hist) {
-  if (threadIdx.x == 0) {
-    uint64_t want = state[1], prefix = pass == 0 ? 0 : state[0];
-    uint64_t run = 0;
-    int b = 0;
-    for (; b < kRaceBins - 1; ++b) {
-      if (run + hist[b] >= want) break;
-      run += hist[b];
+  constexpr int PER = kRaceBins / 64;
+  const int lane = threadIdx.x;
+  uint32_t mine[PER];
+  uint64_t tot = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    mine[j] = hist[lane * PER + j];
+    tot += mine[j];
+  }
+  uint64_t incl = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  const uint64_t excl = incl - tot;
+  const uint64_t want = state[1], prefix = pass == 0 ? 0 : state[0];
+  // the owner: the first lane whose inclusive count reaches `want` (the last lane if none does: bin 2047, as before)
+  const bool owner = (excl < want && incl >= want) || (lane == 63 && incl < want);
+  if (owner) {
+    uint64_t run = excl;
+    int j = 0;
+    for (; j < PER - 1; ++j) {
+      if (run + mine[j] >= want) break;
+      run += mine[j];
     }
+    const int b = lane * PER + j;
     const int shift = 64 - kRaceBits * (pass + 1);
     // last pass: only the top (64 - 55) = 9 bits of the digit are real key bits (the digit was shifted LEFT)
-    state[0] = shift >= 0 ? ((prefix << kRaceBits) | (uint64_t)b) : ((prefix << (kRaceBits + shift)) | ((uint64_t)b >> -shift));
+    state[0] = shift >= 0 ? ((prefix << kRaceBits) | (uint64_t)b)
+                          : ((prefix << (kRaceBits + shift)) | ((uint64_t)b >> -shift));
     state[1] = want - run;
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < kRaceBins; i += blockDim.x) hist[i] = 0;   // ready for the next pass
+#pragma unroll
+  for (int j = 0; j < PER; ++j) hist[lane * PER + j] = 0;   // ready for the next pass
 }
 
 __global__ __launch_bounds__(256) void race_keep_kernel(const float *__restrict__ w, int64_t n, uint64_t seed,
