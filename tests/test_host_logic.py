@@ -290,3 +290,14 @@ def test_csr_to_keeps_the_transpose_link():
     assert t.t() is a and (t.n_rows, t.n_cols) == (4, 3)
     b = a.to("cpu")                       # a matrix and its transpose reference each other: to() must not recurse
     assert b.t().t() is b and torch.equal(b.t().col, t.col) and torch.equal(b.t().val, t.val)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: with libchaorec_hip.so absent every op raises before doing anything."""
+    from chaorec_amd import _lib, ops
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libchaorec_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm_raw(torch.zeros(4, 4), torch.zeros(4, 4))
