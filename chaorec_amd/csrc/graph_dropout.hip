@@ -4,7 +4,7 @@
 //     (torch_geometric.utils.dropout_adj), appends the self loops, recounts degree(row) on what is left and
 //     normalises norm_e = deg^-1/2[row] * deg^-1/2[col].  The reference rebuilds edge lists for that; here the CSR
 //     structure (self loops included, built once) never changes and only its VALUE array is rewritten: a dropped
-//     entry gets 0, a kept one the renormalised weight.  Two launches: integer degree count, then the values of
+//     entry gets 0, a kept one the renormalised weight.  Two launches: integer degree count (one atomic per row segment of a wave), then the values of
 //     A and of A^T (same structure, entry k <-> transpose_entry[k]) for the backward pass.
 //   * FREEDOM (Model/FREEDOM.py:143-162): degree-sensitive pruning keeps a weighted sample WITHOUT replacement of
 //     the training edges (torch.multinomial, limited to 2^24 categories).  Here: exponential-race keys
@@ -29,15 +29,36 @@ __device__ __forceinline__ bool edge_kept(const int32_t *erow, const int32_t *co
   return edge_uniform(seed, step, salt, (uint64_t)k) >= p;   // dropout_adj: mask = rand(E) >= p
 }
 
+// degree(row, ...) counts SOURCES (edge_index[0]).  Entry k of the destination-major CSR has source col[k]; the
+// structure is symmetric, so the entries whose source is n are the reversed edges of row n's entries:
+//   deg[n] = #{k in row n : keep(transpose_entry[k])}
+// One thread per entry; the entries of a row are consecutive, so a wave first adds up each row segment it holds
+// (two ballots + a popcount) and issues ONE atomic per segment -- a popular item costs ~deg/64 atomics, not deg.
 __global__ __launch_bounds__(256) void edge_dropout_degree_kernel(
-    const int32_t *__restrict__ erow, const int32_t *__restrict__ col, const uint8_t *__restrict__ keep_in,
-    int64_t nnz, float p, uint64_t seed, uint64_t step, const int64_t *__restrict__ step_dev, uint64_t salt,
-    int32_t *__restrict__ deg) {
+    const int32_t *__restrict__ erow, const int32_t *__restrict__ col, const int32_t *__restrict__ tentry,
+    const uint8_t *__restrict__ keep_in, int64_t nnz, float p, uint64_t seed, uint64_t step,
+    const int64_t *__restrict__ step_dev, uint64_t salt, int32_t *__restrict__ deg) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nnz) return;
+  const int lane = threadIdx.x & 63;
   if (step_dev) step += (uint64_t)step_dev[0];
-  // degree(row, ...) counts SOURCES (edge_index[0]); entry k of the destination-major CSR has source col[k]
-  if (edge_kept(erow, col, keep_in, k, p, seed, step, salt)) atomicAdd(deg + col[k], 1);
+  const bool in = k < nnz;
+  const int row = in ? erow[k] : -1;
+  const bool kept = in && edge_kept(erow, col, keep_in, tentry[k], p, seed, step, salt);
+  const int prev = __shfl_up(row, 1, 64);
+  const bool head = in && (lane == 0 || prev != row);
+  const uint64_t kept_m = __ballot(kept), head_m = __ballot(head);
+  if (head) {
+    const uint64_t later = lane == 63 ? 0ull : (head_m >> (lane + 1));
+    const int end = later ? lane + 1 + __builtin_ctzll(later) : 64;             // next segment's first lane
+    const uint64_t seg = (end == 64 ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+    const int cnt = __popcll(kept_m & seg);
+    if (cnt) atomicAdd(deg + row, cnt);
+  }
+}
+
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t *__restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void edge_dropout_norm_kernel(
@@ -172,11 +193,13 @@ extern "C" int chaorec_edge_dropout_norm(const int32_t *entry_row, const int32_t
     return fail(CHAOREC_E_INVALID, "edge_dropout_norm: nnz=%lld n_nodes=%lld p=%g salt=%u", (long long)nnz,
                 (long long)n_nodes, (double)p, salt);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(deg_ws, 0, (size_t)n_nodes * sizeof(int32_t), st) != hipSuccess)
-    return fail(CHAOREC_E_LAUNCH, "edge_dropout_norm: memset failed");
-  if (nnz == 0) return CHAOREC_OK;
+  // (a kernel, not hipMemsetAsync: this call sits inside captured training steps, and a memset NODE of this size
+  // was observed not to take effect on replay -- the degrees then accumulate from step to step)
+  zero_i32_kernel<<<(unsigned)((n_nodes + 255) / 256), 256, 0, st>>>(deg_ws, n_nodes);
+  if (nnz == 0) return check_launch("edge_dropout_norm");
   const unsigned blocks = (unsigned)((nnz + 255) / 256);
-  edge_dropout_degree_kernel<<<blocks, 256, 0, st>>>(entry_row, col, keep_in, nnz, p, seed, step, step_dev, salt, deg_ws);
+  edge_dropout_degree_kernel<<<blocks, 256, 0, st>>>(entry_row, col, transpose_entry, keep_in, nnz, p, seed, step,
+                                                     step_dev, salt, deg_ws);
   edge_dropout_norm_kernel<<<blocks, 256, 0, st>>>(entry_row, col, transpose_entry, keep_in, nnz, p, seed, step,
                                                    step_dev, salt, deg_ws, val, val_t);
   return check_launch("edge_dropout_norm");

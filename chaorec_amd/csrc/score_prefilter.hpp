@@ -96,9 +96,13 @@ struct PrefArgs {
 // ---- pack ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_items_bf16_kernel(const float *__restrict__ item_emb,
                                                               uint4 *__restrict__ packed, int64_t n_items, int D,
-                                                              int64_t n_tiles, float *__restrict__ item_norm) {
+                                                              int64_t n_tiles, float *__restrict__ item_norm,
+                                                              uint4 *__restrict__ zero, int64_t zero_n) {
   // per tile Q = D/16 data fragments + ONE bound fragment: lane (r, h=0) holds k=0: 1.0, k=1: ||i_j|| (rounded up)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-element data fragment
+  // the per-call counters (scalars | tau_sum | fb_done) are cleared by this launch too: no memset in the call, so
+  // it can sit in a captured hipGraph (memset nodes were seen not to replay, see graph_dropout.hip)
+  for (int64_t z = i; z < zero_n; z += (int64_t)gridDim.x * blockDim.x) zero[z] = make_uint4(0u, 0u, 0u, 0u);
   const int Q = D / 16;
   if (i >= n_tiles * Q * 64) return;
   const int lane = (int)(i & 63);

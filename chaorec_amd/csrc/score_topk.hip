@@ -885,7 +885,7 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 64 * (size_t)(D / 16 + 1) * 16 : 0);
   p.off_pf_inorm = take(p.prefilter ? (size_t)n_tiles * 32 * 4 : 0);
-  // scalars | tau_sum | fb_done sit back to back: zeroed by ONE memset per call
+  // scalars | tau_sum | fb_done sit back to back: cleared together by the pack launch
   p.off_pf_scalars = take(p.prefilter ? 256 : 0);
   p.off_pf_tau = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fbdone = take(p.prefilter ? (size_t)n_users * 4 : 0);
@@ -976,6 +976,8 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
   if (precision != 0) p.prefilter = false;  // precision 2: fp32 sweep with sampled thresholds (the pre-bf16 path)
   if (p.total > workspace_bytes || (p.total && !workspace))
     return fail(CHAOREC_E_WORKSPACE, "score_topk: workspace %zu < %zu", workspace_bytes, p.total);
+  if (reinterpret_cast<uintptr_t>(workspace) & 255)
+    return fail(CHAOREC_E_INVALID, "score_topk: workspace must be 256-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   char *ws = (char *)workspace;
   const int64_t n_tiles = (n_items + 31) / 32;
@@ -1038,11 +1040,10 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.out_val = out_val;
     int *failf = (int *)(ws + p.off_fail);
     P.fail = failf;
-    if (hipMemsetAsync(ws + p.off_pf_scalars, 0, p.pf_zero_bytes, st) != hipSuccess)
-      return fail(CHAOREC_E_LAUNCH, "score_topk: memset");
     const int64_t nfrag = n_tiles * (D / 16) * 64;
     hipLaunchKernelGGL(pack_items_bf16_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, item_emb,
-                       (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.item_norm);
+                       (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.item_norm,
+                       (uint4 *)(ws + p.off_pf_scalars), (int64_t)(p.pf_zero_bytes / 16));
     rc = check_launch("pack_items_bf16_kernel");
     if (rc) return rc;
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);

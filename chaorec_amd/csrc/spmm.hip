@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     const float *__restrict__ val, const float *__restrict__ x, float *__restrict__ y,
     int64_t n_rows, int D4, float alpha, const float *__restrict__ z, float beta,
     float *acc, const float *__restrict__ acc_init, float acc_w,
-    const int32_t *__restrict__ sched, int64_t n_groups) {
+    const int32_t *__restrict__ sched, int64_t n_groups, int dyn_val) {
   constexpr int NG = kWave / LPR;   // lane groups = destination rows per wave
   constexpr int UNR = CHAOREC_SPMM_UNR;  // gathered rows in flight per group (short-row phase)
   constexpr int UNR2 = (kWave / NG) < 16 ? (kWave / NG) : 16;  // per group in the long-row phase
@@ -84,6 +84,14 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     for (int j = 0; j < kInline; ++j) {
       icol[j] = dword(4 + j);
       ival[j] = __int_as_float(dword(4 + kInline + j));
+    }
+    // CHAOREC_SPMM_DYNAMIC_VALUES: the schedule was built for this STRUCTURE but the values changed since (per-step
+    // edge dropout): take the first entries' values from val[] -- the address comes from the descriptor, so the
+    // loads travel together with the x gathers instead of adding a hop
+    if (dyn_val) {
+#pragma unroll
+      for (int j = 0; j < kInline; ++j)
+        if (j < deg) ival[j] = val[e0 + j];
     }
     n_inl = kInline;
   } else {
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
 template <int LPR, int CPL>
 static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                        float *y, int64_t n_rows, int D4, float alpha, const float *z, float beta,
-                       float *acc, const float *acc_init, float acc_w, const int32_t *sched,
+                       float *acc, const float *acc_init, float acc_w, const int32_t *sched, int dyn_val,
                        hipStream_t st) {
   constexpr int RPW = kWave / LPR;
   const int64_t waves = (n_rows + RPW - 1) / RPW;
@@ -378,7 +386,7 @@ static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *v
   if (blocks > 0x7fffffffLL) return fail(CHAOREC_E_INVALID, "spmm: grid too large");
   hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL>), dim3((unsigned)blocks), dim3(256), 0, st,
                      rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
-                     waves);
+                     waves, dyn_val);
   return check_launch("spmm_csr_ordered_kernel");
 }
 
@@ -401,12 +409,13 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
   if (!rowptr || !x || (!y && !acc)) return fail(CHAOREC_E_INVALID, "spmm: NULL rowptr/x or no output");
   if (n_rows < 0 || n_cols < 0) return fail(CHAOREC_E_INVALID, "spmm: negative size");
   if (D < 4 || D > 1024 || (D & 3)) return fail(CHAOREC_E_INVALID, "spmm: D=%d must be a multiple of 4 in [4,1024]", D);
-  if (mode != 0) return fail(CHAOREC_E_INVALID, "spmm: unknown mode %d", mode);
+  if (mode != 0 && mode != CHAOREC_SPMM_DYNAMIC_VALUES) return fail(CHAOREC_E_INVALID, "spmm: unknown mode %d", mode);
+  const int dyn_val = (mode & CHAOREC_SPMM_DYNAMIC_VALUES) && schedule;
   if (acc_init && !acc) return fail(CHAOREC_E_INVALID, "spmm: acc_init without acc");
   if (n_rows == 0) return CHAOREC_OK;
   hipStream_t st = (hipStream_t)stream;
   const int D4 = D / 4;
-#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, st
+#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, dyn_val, st
   if (D4 <= 1) return launch_spmm<1, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 2) return launch_spmm<2, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 4) return launch_spmm<4, 1>(CHAOREC_SPMM_ARGS);

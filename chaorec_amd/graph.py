@@ -205,8 +205,9 @@ def add_scaled_coo(a, wa, b, wb, n):
 class DropoutStructure(CSR):
     """The CSR of D^-1/2 (A + I) D^-1/2 plus what the per-step edge dropout needs (ops.edge_dropout_norm): the
     destination of every entry, the entry of the reversed edge, and a degree workspace.  `val` holds the
-    no-dropout normalisation; with_values() gives a view of the same structure over another value array (no
-    schedule: the SpMM schedule inlines values, and these change every step)."""
+    no-dropout normalisation; with_values() gives a view of the same structure over another value array that shares
+    this graph's SpMM schedule (built once; the kernel is told to take every value from the array,
+    CHAOREC_SPMM_DYNAMIC_VALUES, because the schedule's inlined values are the static ones)."""
 
     def __init__(self, csr, entry_row, transpose_entry, deg_ws=None):
         super().__init__(csr.rowptr, csr.col, csr.val, csr.n_rows, csr.n_cols, symmetric=True)
@@ -220,7 +221,8 @@ class DropoutStructure(CSR):
 
     def with_values(self, val):
         v = CSR(self.rowptr, self.col, val, self.n_rows, self.n_cols)
-        v.schedule = lambda D: None
+        v.schedule = self.schedule          # same structure, same descriptors
+        v.dynamic_values = True
         return v
 
 

@@ -51,9 +51,10 @@ def spmm_raw(csr, x, y=None, alpha=1.0, z=None, beta=0.0, acc=None, acc_init=Non
         y = torch.empty((csr.n_rows, D), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     order = csr.schedule(D)
+    mode = 1 if getattr(csr, "dynamic_values", False) else 0     # CHAOREC_SPMM_DYNAMIC_VALUES
     rc = lib.chaorec_spmm_csr_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x),
                                   _ptr(y if want_y else None), csr.n_rows, csr.n_cols, D, alpha,
-                                  _ptr(z), beta, _ptr(acc), _ptr(acc_init), acc_w, _ptr(order), 0, _stream())
+                                  _ptr(z), beta, _ptr(acc), _ptr(acc_init), acc_w, _ptr(order), mode, _stream())
     _lib.check(rc, "chaorec_spmm_csr_f32")
     return y
 

@@ -63,8 +63,11 @@ const char *chaorec_last_error(void);
  *   workgroup) and carries a 64-B descriptor per row {row, degree, first entry, first 6 (col,val) pairs} so the
  *   kernel's dependent-load chain is descriptor -> x instead of order -> rowptr -> (col,val) -> x.  It changes
  *   scheduling and latency only, never results.
- * mode: 0 = ordered (bit-reproducible, reference order).
+ * mode: 0 = ordered (bit-reproducible, reference order).  CHAOREC_SPMM_DYNAMIC_VALUES (1): same, but the schedule
+ *   was built for this structure under OTHER values (the value array is rewritten every step, e.g. edge dropout):
+ *   the kernel then ignores the values stored in the schedule and reads all of them from val[].
  * ------------------------------------------------------------------------------------- */
+#define CHAOREC_SPMM_DYNAMIC_VALUES 1
 int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                          const float *x, float *y, int64_t n_rows, int64_t n_cols, int32_t D,
                          float alpha, const float *z, float beta,
@@ -174,6 +177,8 @@ int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *his
  * D in {8, 16, 32, 64, 128} (users' fragment register-resident) or a multiple of 64 above 128
  * (streamed; the kNN build over modality features);  1 <= K <= 64;  n_items >= K.
  * hist_rowptr may be NULL (no mask).  hist_col ascending inside a row.
+ * workspace: chaorec_score_topk_workspace_bytes() bytes, 256-byte aligned; nothing in it survives the call.  The
+ * call issues kernels only (no memset / memcpy nodes), so it may be captured in a hipGraph.
  * ------------------------------------------------------------------------------------- */
 size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K, int32_t D);
 

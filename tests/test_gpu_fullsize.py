@@ -153,3 +153,38 @@ def test_ngcf_sports_size_step(dev):
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters())
     rank = m.gene_ranklist(topk=20)
     assert rank.shape == (U, 20) and int(rank.min()) >= U and int(rank.max()) < U + I
+
+
+def test_ngcf_captured_step_at_sports_size_equals_eager(dev):
+    """Regression: the degree workspace of chaorec_edge_dropout_norm used to be cleared with hipMemsetAsync; inside a
+    captured step that memset node did not take effect at this size, the degrees accumulated from replay to replay
+    and the captured model trained on an ever fainter graph (the 88-node golden graph did not show it).  Captured and
+    eager training on the same mask / batch streams must stay together, and the degrees must stay degrees."""
+    from chaorec_amd import graph, dataload
+    from chaorec_amd.Model import NGCF
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+    U, I, E = DATASET_SHAPES["sports"]
+    edges = synthetic_interactions(U, I, E, seed=42)
+    uid = graph.user_item_dict_from_edges(edges)
+
+    def make():
+        torch.manual_seed(0)
+        mm = NGCF(U, I, edges, uid, 64, 1e-3, 0.2, 3, "add", dev).to(dev)
+        return mm, FusedAdam(mm.parameters(), lr=1e-3)
+
+    sampler = dataload.DeviceBatchSampler(U, I, uid, edges, 1024, dev, "NGCF")
+    batches = [tuple(t.clone() for t in b) for _, b in zip(range(40), sampler)]
+    eager, oe = make()
+    cap, oc = make()
+    step = GraphedTrainStep(cap, oc, example_batch=batches[0])
+    eager._drop_calls.copy_(cap._drop_calls)
+    true_max = int(np.bincount(np.concatenate([edges[:, 0], edges[:, 1]])).max()) + 1
+    for it, b in enumerate(batches):
+        oe.zero_grad()
+        le = eager.loss(*b)
+        le.backward()
+        oe.step()
+        lc = step(*b)
+        assert float(lc.detach()) == pytest.approx(float(le.detach()), rel=2e-4), it
+        assert 1 <= int(cap.graph.deg_ws.min()) and int(cap.graph.deg_ws.max()) <= true_max, it
