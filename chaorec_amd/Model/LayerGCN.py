@@ -133,9 +133,9 @@ class LayerGCN(nn.Module):
 
     def regularization_loss(self, users, pos_items, neg_items):
         """Model/LayerGCN.py:147-155: on the EGO tables (LightGCN regularises the propagated ones)."""
-        return self.reg_weight * (torch.mean(self.user_embeddings[users] ** 2)
-                                  + torch.mean(self.item_embeddings[pos_items] ** 2)
-                                  + torch.mean(self.item_embeddings[neg_items] ** 2))
+        return self.reg_weight * (ops.mean_all(self.user_embeddings[users] ** 2)
+                                  + ops.mean_all(self.item_embeddings[pos_items] ** 2)
+                                  + ops.mean_all(self.item_embeddings[neg_items] ** 2))
 
     def loss(self, users, pos_items, neg_items):
         """Model/LayerGCN.py:157-169."""

@@ -173,7 +173,7 @@ class MGCN(nn.Module):
         view1, view2 = F.normalize(view1, dim=1), F.normalize(view2, dim=1)
         pos_score = torch.exp((view1 * view2).sum(dim=-1) / self.ssl_temp)
         ttl_score = torch.exp(ops.linear(view1, view2) / self.ssl_temp).sum(dim=1)
-        return torch.mean(-torch.log(pos_score / ttl_score))
+        return ops.mean_all(-torch.log(pos_score / ttl_score))
 
     def loss(self, users, pos_items, neg_items):
         """Model/MGCN.py:303-320."""

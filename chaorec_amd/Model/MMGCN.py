@@ -124,8 +124,9 @@ class MMGCN(torch.nn.Module):
         loss = ops.bpr_loss(out, None, users, pos, neg, ops.VARIANT_LOG_SIGMOID, 0.0, item_offset=0)[0]
         with torch.no_grad():  # regulariser over tensors no optimizer owns (Q2): a reported constant
             ut, it = user_tensor.reshape(-1), item_tensor.reshape(-1)
-            reg_embedding_loss = (self.id_embedding[ut] ** 2 + self.id_embedding[it] ** 2).mean() + (
-                self.v_gcn.preference ** 2).mean()
+            # (ops.mean_all, not .mean(): torch's multi-block reductions do not survive hipGraph replay here)
+            reg_embedding_loss = ops.mean_all(self.id_embedding[ut] ** 2 + self.id_embedding[it] ** 2) + \
+                ops.mean_all(self.v_gcn.preference ** 2)
         return loss + self.reg_weight * reg_embedding_loss
 
     def gene_ranklist(self, step=200, topk=50, to_cpu=True):

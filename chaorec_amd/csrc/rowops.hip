@@ -146,9 +146,109 @@ static int dispatch_row_cosine(const float *g, const float *y, const float *e, f
 #undef CHAOREC_RC_ARGS
 }
 
+// ---- deterministic reductions without semaphores or memset nodes ------------------------------------------------
+// torch's multi-block reductions (x.sum(0) over many rows, .mean() over millions of elements) clear a semaphore buffer
+// with cudaMemsetAsync; inside a captured hipGraph on this stack that memset node does not replay, and from the second
+// replay on the reduction returns stale or garbage values.  These two-pass kernels need neither: pass 1
+// writes one partial per (row chunk, column) / per block, pass 2 adds the partials in a fixed order.
+constexpr int kRedChunkRows = 512;     // rows per pass-1 block of the column sum
+constexpr int kRedMaxBlocks = 1024;    // pass-1 blocks of the scalar sum
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, int64_t M, int64_t N,
+                                                             int64_t ldx, float *__restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
+  const int64_t r0 = (int64_t)blockIdx.y * kRedChunkRows, r1 = min(M, r0 + kRedChunkRows);
+  float v = 0.f;
+  if (col < N)
+    for (int64_t r = r0 + q; r < r1; r += 4) v += x[r * ldx + col];
+  red[q][c] = v;
+  __syncthreads();
+  if (q == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, int64_t chunks, int64_t N,
+                                                           float *__restrict__ out) {
+  const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float v = 0.f;
+  for (int64_t k = 0; k < chunks; ++k) v += part[k * N + col];
+  out[col] = v;
+}
+
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float *__restrict__ x, int64_t n,
+                                                          float *__restrict__ part) {
+  __shared__ float red[256];
+  float v = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v += x[i];
+  red[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sum_final_kernel(const float *__restrict__ part, int blocks, float scale,
+                                                        float *__restrict__ out) {
+  __shared__ float red[256];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < blocks; i += 256) v += part[i];
+  red[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
 }  // namespace chaorec
 
 using namespace chaorec;
+
+extern "C" size_t chaorec_reduce_workspace_bytes(int64_t M, int64_t N) {
+  const int64_t chunks = (M + kRedChunkRows - 1) / kRedChunkRows;
+  const size_t col = (size_t)(chunks > 0 ? chunks : 1) * (size_t)(N > 0 ? N : 1) * sizeof(float);
+  const size_t sc = (size_t)kRedMaxBlocks * sizeof(float);
+  return col > sc ? col : sc;
+}
+
+extern "C" int chaorec_colsum_f32(const float *x, int64_t M, int64_t N, int64_t ldx, float *out, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  if (!x || !out || !workspace) return fail(CHAOREC_E_INVALID, "colsum: NULL argument");
+  if (M < 0 || N <= 0 || ldx < N) return fail(CHAOREC_E_INVALID, "colsum: M=%lld N=%lld ldx=%lld", (long long)M, (long long)N, (long long)ldx);
+  if (workspace_bytes < chaorec_reduce_workspace_bytes(M, N))
+    return fail(CHAOREC_E_WORKSPACE, "colsum: workspace %zu < %zu", workspace_bytes, chaorec_reduce_workspace_bytes(M, N));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t chunks = (M + kRedChunkRows - 1) / kRedChunkRows;
+  if (chunks > 65535) return fail(CHAOREC_E_INVALID, "colsum: M=%lld too large", (long long)M);
+  float *part = (float *)workspace;
+  if (chunks > 0)
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, st, x, M, N,
+                       ldx, part);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, part, chunks, N, out);
+  return check_launch("colsum");
+}
+
+extern "C" int chaorec_sum_f32(const float *x, int64_t n, float scale, float *out, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+  if (!x || !out || !workspace) return fail(CHAOREC_E_INVALID, "sum: NULL argument");
+  if (n < 0) return fail(CHAOREC_E_INVALID, "sum: n=%lld", (long long)n);
+  if (workspace_bytes < (size_t)kRedMaxBlocks * sizeof(float)) return fail(CHAOREC_E_WORKSPACE, "sum: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((n + 4095) / 4096);
+  if (blocks < 1) blocks = 1;
+  if (blocks > kRedMaxBlocks) blocks = kRedMaxBlocks;
+  float *part = (float *)workspace;
+  hipLaunchKernelGGL(sum_partial_kernel, dim3(blocks), dim3(256), 0, st, x, n, part);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, part, blocks, scale, out);
+  return check_launch("sum");
+}
 
 extern "C" int chaorec_row_cosine_scale_fwd_f32(const float *y, const float *e, float *out, float *w_out,
                                                 int64_t n_rows, int32_t D, void *stream) {

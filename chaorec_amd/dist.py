@@ -85,6 +85,12 @@ class _Pending:
             self.work.wait()
 
 
+def _mean_all(x):
+    """Scalar mean that survives hipGraph replay on the GPU (ops.mean_all); the gloo/CPU tests of the exchange logic
+    run the same expression through torch."""
+    return ops.mean_all(x) if x.is_cuda else x.mean()
+
+
 def _all_reduce_async(t, group):
     if dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES):
         return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
@@ -357,8 +363,10 @@ class ShardedMMGCN(nn.Module):
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         with torch.no_grad():  # the reported regulariser constant (Q2), this rank's share of it
             ut, it = user_tensor.reshape(-1).to(self.device), item_tensor.reshape(-1).to(self.device)
-            reg = (self.id_embedding[ut] ** 2 + self.id_embedding[it] ** 2).mean() / world + (
-                self.v_gcn.preference ** 2).sum() / (self.shard.num_user_global * self.v_gcn.preference.shape[1])
+            mean = _mean_all                # (not .mean(): multi-block torch reductions break under hipGraph replay)
+            pref = self.v_gcn.preference
+            reg = mean(self.id_embedding[ut] ** 2 + self.id_embedding[it] ** 2) / world + \
+                mean(pref ** 2) * (pref.shape[0] / self.shard.num_user_global)
         return loss / world + self.reg_weight * reg     # sum over ranks = the single-process loss
 
     def sync_grads(self):

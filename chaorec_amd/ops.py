@@ -306,7 +306,7 @@ class _Linear(torch.autograd.Function):
             gy = torch.where(y > 0, gy, gy * 0.01)
         gx = gemm_raw(gy, weight) if ctx.needs_input_grad[0] else None
         gw = gemm_raw(gy, x, transA=True) if ctx.needs_input_grad[1] else None
-        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[2] else None     # (not gy.sum(0): see col_sum)
         return gx, gw, gb, None
 
 
@@ -458,3 +458,47 @@ class _RowCosineScale(torch.autograd.Function):
 
 def row_cosine_scale(y, e):
     return _RowCosineScale.apply(y, e)
+
+
+# --------------------------------------------------------------------------------------------
+# reductions that survive hipGraph replay
+# --------------------------------------------------------------------------------------------
+def col_sum(x):
+    """x.sum(0) for fp32 [M, N], deterministic, in two launches.  torch's own multi-block reductions clear a semaphore
+    buffer with a memset, and a memset node inside a captured hipGraph does not replay on this stack:
+    inside captured training steps every large reduction goes through here or mean_all()."""
+    _need_cuda(x)
+    x = _f32c(x)
+    M, N = x.shape
+    lib = _lib.load()
+    nbytes = lib.chaorec_reduce_workspace_bytes(M, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    rc = lib.chaorec_colsum_f32(_ptr(x), M, N, N, _ptr(out), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "chaorec_colsum_f32")
+    return out
+
+
+class _MeanAll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        xc = _f32c(x)
+        n = xc.numel()
+        lib = _lib.load()
+        nbytes = lib.chaorec_reduce_workspace_bytes(n, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        rc = lib.chaorec_sum_f32(_ptr(xc), n, 1.0 / max(n, 1), _ptr(out), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, "chaorec_sum_f32")
+        ctx.shape, ctx.n = x.shape, n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.n).expand(ctx.shape)
+
+
+def mean_all(x):
+    """x.mean() over all elements (differentiable), safe inside captured steps (see col_sum)."""
+    return _MeanAll.apply(x)

@@ -312,6 +312,24 @@ int chaorec_row_cosine_scale_fwd_f32(const float *y, const float *e, float *out,
 int chaorec_row_cosine_scale_bwd_f32(const float *grad_out, const float *y, const float *e, float *grad_y,
                                      float *grad_e, int64_t n_rows, int32_t D, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Deterministic two-pass reductions (fixed order, no atomics, no semaphores, no memset nodes).
+ *
+ * Replaces: the bias gradient of every nn.Linear (grad_out.sum(0), autograd of Model/MMGCN.py:97-131,
+ *           Model/FREEDOM.py:209,212, Model/MGCN.py gates) and the scalar means of the regularisers
+ *           (Model/MMGCN.py:198-199, Model/LayerGCN.py:147-155, Model/MGCN.py:301) INSIDE captured training steps:
+ *           torch's multi-block reductions zero a semaphore buffer with a memset, and a memset node of a captured
+ *           hipGraph does not replay on this stack (stale / garbage sums from the second replay on).
+ *
+ * colsum: out[c] = sum_r x[r*ldx + c]  (x fp32 [M, N] row-major).   sum: out[0] = scale * sum_i x[i].
+ * workspace: chaorec_reduce_workspace_bytes(M, N) bytes (use M = n, N = 1 for the scalar sum).
+ * ------------------------------------------------------------------------------------- */
+size_t chaorec_reduce_workspace_bytes(int64_t M, int64_t N);
+int chaorec_colsum_f32(const float *x, int64_t M, int64_t N, int64_t ldx, float *out, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int chaorec_sum_f32(const float *x, int64_t n, float scale, float *out, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

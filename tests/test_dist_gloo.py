@@ -164,6 +164,7 @@ def _cpu_standins():
     ops.spmm = lambda csr, x: _Spmm.apply(x, csr)
     ops.spmm_raw = _oracle_spmm
     ops.bpr_loss = bpr_loss
+    ops.mean_all = lambda x: x.mean()
 
 
 def _mmgcn_problem():
@@ -221,7 +222,7 @@ def test_sharded_mmgcn_matches_single_process():
         mp.spawn(_mmgcn_worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
         r = [dict(np.load(os.path.join(tmp, f"mm{k}.npz"))) for k in range(world)]
     from chaorec_amd import ops
-    saved = (ops.linear, ops.spmm, ops.spmm_raw, ops.bpr_loss)
+    saved = (ops.linear, ops.spmm, ops.spmm_raw, ops.bpr_loss, ops.mean_all)
     try:
         _cpu_standins()
         U, I, edges, v_feat, t_feat = _mmgcn_problem()
@@ -245,4 +246,4 @@ def test_sharded_mmgcn_matches_single_process():
             assert np.allclose(r[0]["g_" + n], g, rtol=2e-3, atol=1e-7 + 1e-4 * np.abs(g).max()), n
             assert np.array_equal(r[0]["g_" + n], r[1]["g_" + n]), n       # identical update on every rank
     finally:
-        ops.linear, ops.spmm, ops.spmm_raw, ops.bpr_loss = saved
+        ops.linear, ops.spmm, ops.spmm_raw, ops.bpr_loss, ops.mean_all = saved

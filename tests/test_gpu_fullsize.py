@@ -188,3 +188,54 @@ def test_ngcf_captured_step_at_sports_size_equals_eager(dev):
         lc = step(*b)
         assert float(lc.detach()) == pytest.approx(float(le.detach()), rel=2e-4), it
         assert 1 <= int(cap.graph.deg_ws.min()) and int(cap.graph.deg_ws.max()) <= true_max, it
+
+
+@pytest.mark.parametrize("name,ds", [("LightGCN", "sports"), ("LayerGCN", "sports"), ("FREEDOM", "clothing"),
+                                     ("MGCN", "baby"), ("MMGCN", "baby")])
+def test_captured_training_equals_eager_at_dataset_size(dev, name, ds, monkeypatch):
+    """The step the benchmark times is the CAPTURED one: at dataset size, over 40 different batches, it must produce
+    the losses of the eager step (same kernels, same batches).  (A captured-only failure at this size is exactly how
+    the memset-node hazard of DESIGN 3.5 showed up.)"""
+    from chaorec_amd import graph, dataload
+    from chaorec_amd import Model
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+    monkeypatch.setitem(dataload.SYNTHETIC_FEATURE_DIMS, "default", (96, 64))
+    monkeypatch.setitem(dataload.SYNTHETIC_FEATURE_DIMS, ds, (96, 64))
+    U, I, E = DATASET_SHAPES[ds]
+    edges = synthetic_interactions(U, I, E, seed=42)
+    uid = graph.user_item_dict_from_edges(edges)
+    v_feat, t_feat = dataload.synthetic_features(I, ds)
+
+    def make():
+        torch.manual_seed(0)
+        if name == "LightGCN":
+            m = Model.LightGCN(U, I, edges, uid, 64, 1e-3, 3, "add", dev)
+        elif name == "LayerGCN":
+            m = Model.LayerGCN(U, I, edges, uid, 64, 1e-3, 3, 0.1, dev)
+        elif name == "FREEDOM":
+            m = Model.FREEDOM(U, I, edges, uid, v_feat, t_feat, 64, 64, 1e-3, 0.1, 2, 1, 10, 0.8, dev)
+        elif name == "MGCN":
+            m = Model.MGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, 2, "add", 0.2, 0.01, dev)
+        else:
+            m = Model.MMGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, "add", "False", True, dev)
+        m = m.to(dev)
+        if hasattr(m, "pre_epoch_processing"):
+            m.pre_epoch_processing()
+        return m, FusedAdam(m.parameters(), lr=1e-3)
+
+    sampler = dataload.DeviceBatchSampler(U, I, uid, edges, 1024, dev, name)
+    batches = [tuple(t.clone() for t in b) for _, b in zip(range(40), sampler)]
+    eager, oe = make()
+    cap, oc = make()
+    if name == "MMGCN":          # preference / id_embedding are random non-parameters (Q2): share them
+        cap.v_gcn.preference, cap.t_gcn.preference = eager.v_gcn.preference.clone(), eager.t_gcn.preference.clone()
+        cap.id_embedding = eager.id_embedding.clone()
+    step = GraphedTrainStep(cap, oc, example_batch=batches[0])
+    for it, b in enumerate(batches):
+        oe.zero_grad()
+        le = eager.loss(*b)
+        le.backward()
+        oe.step()
+        lc = step(*b)
+        assert float(lc.detach()) == pytest.approx(float(le.detach()), rel=5e-4), (name, it)

@@ -853,3 +853,40 @@ def test_row_cosine_scale_vs_oracle_and_torch_autograd(dev, oracle, n, D):
     for got, r in ((ty.grad, dy.grad), (te.grad, de.grad)):
         scale = float(r.abs().max()) + 1e-12
         assert float((got.cpu().double() - r).abs().max()) <= 5e-6 * scale
+
+
+@pytest.mark.parametrize("M,N", [(1, 1), (20000, 64), (513, 320), (70000, 7), (3, 1000)])
+def test_col_sum_and_mean_all_deterministic_and_replay_safe(dev, M, N):
+    """chaorec_colsum_f32 / chaorec_sum_f32: equal to fp64 sums to fp32 rounding, bit-identical run to run, and --
+    the reason they exist -- still right on every replay of a captured graph when the input changes in between
+    (torch's own multi-block x.sum(0) / x.mean() go stale from the second replay on, checked here too as a canary)."""
+    from chaorec_amd import ops
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(M * 31 + N)
+    x = torch.randn(M, N, device=dev, generator=g0)
+    cs, ma = ops.col_sum(x), ops.mean_all(x)
+    assert torch.equal(cs, ops.col_sum(x)) and torch.equal(ma, ops.mean_all(x))
+    assert torch.allclose(cs.double(), x.double().sum(0), rtol=1e-5, atol=1e-4 * max(1.0, M ** 0.5))
+    assert float(ma) == pytest.approx(float(x.double().mean()), abs=1e-5)
+    xr = x.clone().requires_grad_(True)
+    ops.mean_all(xr * xr).backward()
+    assert torch.allclose(xr.grad, 2 * x / x.numel(), rtol=1e-6, atol=1e-12)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            ops.col_sum(x), ops.mean_all(x)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        c_out, m_out, t_out = ops.col_sum(x), ops.mean_all(x), x.sum(0)
+    torch_stale = False
+    for r in range(3):
+        x.copy_(torch.randn(M, N, device=dev, generator=g0) * (r + 2))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c_out, ops.col_sum(x)) and torch.equal(m_out, ops.mean_all(x)), r
+        torch_stale |= not torch.allclose(t_out, x.sum(0), rtol=1e-4, atol=1e-3)
+    if M >= 20000:
+        # not an assertion on torch: if this starts passing the workaround may be dropped (DESIGN 3.5)
+        print("torch x.sum(0) stale under replay:", torch_stale)
