@@ -168,6 +168,48 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
   if (q == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
+// float4 form (N and ldx multiples of 4, 16-byte aligned base): 16 column quads x 16 row lanes per block, four
+// independent accumulators per thread so that the row loads overlap
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float4 *__restrict__ x4, int64_t M, int64_t N4,
+                                                              int64_t ld4, float4 *__restrict__ part4) {
+  __shared__ float4 red[16][16];
+  const int cq = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int64_t col = (int64_t)blockIdx.x * 16 + cq;
+  const int64_t r0 = (int64_t)blockIdx.y * kRedChunkRows, r1 = min(M, r0 + kRedChunkRows);
+  float4 a[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < N4) {
+    int64_t r = r0 + q;
+    for (; r + 48 < r1; r += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = x4[(r + 16 * u) * ld4 + col];
+        a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+      }
+    }
+    for (; r < r1; r += 16) {
+      const float4 v = x4[r * ld4 + col];
+      a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+    }
+  }
+  float4 t;
+  t.x = (a[0].x + a[1].x) + (a[2].x + a[3].x);
+  t.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+  t.z = (a[0].z + a[1].z) + (a[2].z + a[3].z);
+  t.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+  red[q][cq] = t;
+  __syncthreads();
+  if (q == 0 && col < N4) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 o = red[k][cq];
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    part4[(int64_t)blockIdx.y * N4 + col] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, int64_t chunks, int64_t N,
                                                            float *__restrict__ out) {
   const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,7 +270,12 @@ extern "C" int chaorec_colsum_f32(const float *x, int64_t M, int64_t N, int64_t 
   const int64_t chunks = (M + kRedChunkRows - 1) / kRedChunkRows;
   if (chunks > 65535) return fail(CHAOREC_E_INVALID, "colsum: M=%lld too large", (long long)M);
   float *part = (float *)workspace;
-  if (chunks > 0)
+  const bool vec = (N % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(part) & 15) == 0);
+  if (chunks > 0 && vec)
+    hipLaunchKernelGGL(colsum_partial4_kernel, dim3((unsigned)((N / 4 + 15) / 16), (unsigned)chunks), dim3(256), 0, st,
+                       (const float4 *)x, M, N / 4, ldx / 4, (float4 *)part);
+  else if (chunks > 0)
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, st, x, M, N,
                        ldx, part);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, part, chunks, N, out);
