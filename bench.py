@@ -80,6 +80,33 @@ def probe_sharded_graph(args, world):
     return rc == 0
 
 
+def captured_all_reduce_is_exact(dev, world, rank):
+    """Probe-mode check: an all-reduce captured in a hipGraph must return the sum of what the ranks hold AT REPLAY
+    TIME, on every replay (a graph node that only acts on the first replay -- as memset nodes do on this stack,
+    DESIGN 3.5 -- would time perfectly and train on stale sums)."""
+    import torch.distributed as dist
+    t = torch.zeros(1 << 20, device=dev)                 # 4 MB, the size of the item partials at sports scale
+    src = torch.zeros_like(t)
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        t.copy_(src)
+        dist.all_reduce(t)                               # eager first: communicator set-up happens outside capture
+    cur.wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        t.copy_(src)
+        dist.all_reduce(t)
+    ok = True
+    for r in range(3):
+        src.fill_(float((rank + 1) * (r + 1)))
+        g.replay()
+        torch.cuda.synchronize()
+        ok = ok and bool((t == float((r + 1) * world * (world + 1) // 2)).all())
+    return ok
+
+
 def spmm_model_bytes(nnz, n_rows, D):
     """SURVEY 8(d): no-reuse CSR model, fp32: per nonzero a D-float source row + 4 B col + 4 B val;
     per output row a D-float store + 8 B row pointer."""
@@ -161,6 +188,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    if args.probe_graph and not captured_all_reduce_is_exact(dev, world, rank):
+        print(f"[bench probe rank {rank}] a captured all-reduce returned stale sums on replay", file=sys.stderr, flush=True)
+        sys.exit(4)
 
     from chaorec_amd import _lib, graph, ops
     from chaorec_amd.Model import LightGCN
