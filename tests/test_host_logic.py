@@ -301,3 +301,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm_raw(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_csr_update_from_rewrites_in_place_and_refreshes_the_schedule():
+    """FREEDOM / LayerGCN re-prune their graph every epoch into the SAME arrays (a captured step holds their
+    addresses): data pointers stay, contents and the cached SpMM schedule become those of the new graph."""
+    from chaorec_amd import graph
+    rng = np.random.default_rng(0)
+
+    def rand_graph(seed):
+        r = np.random.default_rng(seed)
+        rows = torch.from_numpy(r.integers(0, 50, 400))
+        cols = torch.from_numpy(r.integers(0, 50, 400))
+        key = torch.unique(rows * 50 + cols)[:300]
+        return graph.coo_to_csr_coalesced(key // 50, key % 50, torch.from_numpy(r.random(300).astype(np.float32)), 50, 50)
+
+    a, b = rand_graph(1), rand_graph(2)
+    assert a.nnz == b.nnz == 300
+    sched_a = a.schedule(64)
+    ptrs = (a.rowptr.data_ptr(), a.col.data_ptr(), a.val.data_ptr(), sched_a.data_ptr())
+    before = sched_a.clone()
+    assert a.update_from(b)
+    assert ptrs == (a.rowptr.data_ptr(), a.col.data_ptr(), a.val.data_ptr(), a.schedule(64).data_ptr())
+    assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.col, b.col) and torch.equal(a.val, b.val)
+    assert torch.equal(a.schedule(64), b.schedule(64)) and not torch.equal(a.schedule(64), before)
+    c = graph.coo_to_csr_coalesced(torch.tensor([0, 1]), torch.tensor([1, 0]), torch.tensor([1., 1.]), 50, 50)
+    assert not a.update_from(c)          # different entry count: the caller must not keep a captured step on it
