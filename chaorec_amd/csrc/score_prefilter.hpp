@@ -58,6 +58,7 @@ __device__ __forceinline__ uint4 bf16_pack8(const float4 a, const float4 b) {
   return make_uint4(bf16_pack2(a.x, a.y), bf16_pack2(a.z, a.w), bf16_pack2(b.x, b.y), bf16_pack2(b.z, b.w));
 }
 
+constexpr int kPfFbGroupCap = 512;   // queued users the grouped f32 fallback takes (16 groups of 32)
 constexpr float kBf16ErrCoef = 1.05f / 256.0f;
 constexpr int kPfCap = 64;        // keys per (split, user, half) list of the sweep
 constexpr int kPfMaxRescore = 128;
@@ -91,6 +92,7 @@ struct PrefArgs {
   int *fb_list;                 // [U]
   int *fb_done;                 // [U] slices finished per queued user (zeroed per call)
   uint64_t *fb_partial;         // [U][kExSlices][kMaxK] per-slice best keys
+  int fb_skip;                  // queue entries below this index were ranked by the grouped f32 sweep
 };
 
 // ---- pack ----------------------------------------------------------------------------------------------------
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
   const int K = P.K;
   const int n_fb = *P.fb_cnt;
   const int64_t per_slice = (P.n_items + kExSlices - 1) / kExSlices;
-  for (int w = blockIdx.x; w < n_fb * kExSlices; w += gridDim.x) {
+  for (int w = blockIdx.x + P.fb_skip * kExSlices; w < n_fb * kExSlices; w += gridDim.x) {
     const int qi = w / kExSlices, slice = w % kExSlices;
     const int64_t u = P.fb_list[qi];
     const float *urow = P.user_emb + (size_t)u * D;

@@ -194,6 +194,10 @@ struct ScoreArgs {
   float *tau;                  // kModeSample: out; kModeMain: in (may be NULL)
   int *certify;                // kModeMain, splits == 1: out per-user "threshold was too high" flags
   const int *fail;             // kModeFallback: per-user flags
+  // compact user set (the prefilter route's exact fallback at large item counts): row u of the launch is user
+  // user_map[u] of the tables, and only the first min(*n_users_dev, n_users) rows exist.  NULL = identity / n_users.
+  const int *user_map;
+  const int *n_users_dev;
 };
 
 // D > 0: K-dim known at compile time, the users' fragment lives in registers for the whole stream.
@@ -211,8 +215,11 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
   const int lane = threadIdx.x;
   const int ur = lane & 31;
   const int h = lane >> 5;
-  const int64_t u = (int64_t)blockIdx.x * 32 + ur;
-  const bool u_ok = u < A.n_users;
+  const int64_t n_users_eff = A.n_users_dev ? min((int64_t)*A.n_users_dev, A.n_users) : A.n_users;
+  if ((int64_t)blockIdx.x * 32 >= n_users_eff) return;       // (only a compact launch has empty groups)
+  const int64_t uc = (int64_t)blockIdx.x * 32 + ur;          // row of this launch
+  const bool u_ok = uc < n_users_eff;
+  const int64_t u = (A.user_map && u_ok) ? (int64_t)A.user_map[uc] : uc;   // row of the tables
   const int K = A.K;
   const uint32_t n_items = (uint32_t)A.n_items;
   const int n_tiles = (int)((A.n_items + 31) / 32);
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int64_t ut = (int64_t)blockIdx.x * 32 + base + b;
-      if (ut >= A.n_users) continue;
+      if (ut >= n_users_eff) continue;
       const uint64_t kth = shfl_u64(e0[b], K - 1);
       const float kth_val = (tot[b] >= K) ? ord_to_f32((uint32_t)(kth >> 32)) : -INFINITY;
       if (A.mode == kModeSample) {
@@ -446,8 +453,9 @@ __global__ __launch_bounds__(64) void score_topk_f32_kernel(const ScoreArgs A) {
           A.partial[((size_t)split * A.n_users + ut) * K + lane] = e0[b];
         } else {
           const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0[b] & 0xFFFFFFFFull);
-          A.out_idx[(size_t)ut * K + lane] = (int64_t)item + A.id_offset;
-          A.out_val[(size_t)ut * K + lane] = ord_to_f32((uint32_t)(e0[b] >> 32));
+          const size_t uo = A.user_map ? (size_t)A.user_map[ut] : (size_t)ut;
+          A.out_idx[uo * K + lane] = (int64_t)item + A.id_offset;
+          A.out_val[uo * K + lane] = ord_to_f32((uint32_t)(e0[b] >> 32));
         }
       }
     }
@@ -464,10 +472,13 @@ __global__ __launch_bounds__(64) void score_topk_merge_kernel(const uint64_t *__
                                                               float *__restrict__ out_val,
                                                               const float *__restrict__ tau,
                                                               int *__restrict__ fail,
-                                                              const int *__restrict__ only_if) {
+                                                              const int *__restrict__ only_if,
+                                                              const int *__restrict__ user_map,
+                                                              const int *__restrict__ n_users_dev) {
   const int lane = threadIdx.x;
   const int64_t u = blockIdx.x;
   if (only_if && only_if[u] == 0) return;
+  if (n_users_dev && u >= *n_users_dev) return;
   uint64_t e0 = 0ull;
   for (int s = 0; s < splits; ++s) {
     uint64_t e1 = lane < K ? partial[((size_t)s * n_users + u) * K + lane] : 0ull;
@@ -483,8 +494,9 @@ __global__ __launch_bounds__(64) void score_topk_merge_kernel(const uint64_t *__
   }
   if (lane < K) {
     const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
-    out_idx[(size_t)u * K + lane] = (int64_t)item + id_offset;
-    out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
+    const size_t uo = user_map ? (size_t)user_map[u] : (size_t)u;
+    out_idx[uo * K + lane] = (int64_t)item + id_offset;
+    out_val[uo * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
   }
 }
 
@@ -791,6 +803,9 @@ struct ScorePlan {
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
   bool pf_sample_long;
   size_t off_pf_heavy, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
+  bool pf_group_fb;            // large item ranges: the first kPfFbGroupCap queued users share f32 MFMA sweeps
+  int pf_group_fb_splits;
+  size_t off_pf_fbgroup;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_margin, off_pf_cand, off_pf_cnt;
   size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
 };
@@ -893,6 +908,12 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.off_pf_heavy = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fb = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fbpart = take(p.prefilter ? (size_t)n_users * kExSlices * kMaxK * 8 : 0);
+  // The per-user exact route streams the whole item table once per queued user (1 GB per user at 2 M x 128): past
+  // 128 k items the queued users are instead swept 32 at a time on the f32 MFMA pipe (the route-1 kernel over a
+  // compact user set), the item range cut into enough splits to fill the chip with 1..16 user groups
+  p.pf_group_fb = p.prefilter && n_items >= 131072;
+  p.pf_group_fb_splits = (int)std::min<int64_t>(256, std::max<int64_t>(1, n_tiles / 64));
+  p.off_pf_fbgroup = take(p.pf_group_fb ? (size_t)p.pf_group_fb_splits * kPfFbGroupCap * (size_t)K * 8 : 0);
   p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_margin = take(p.prefilter ? (size_t)n_users * 4 : 0);
   // (sized for the most splits any device plan uses, so that the CPU-side query and the device plan agree)
@@ -1006,6 +1027,8 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
   a.tau = nullptr;
   a.certify = nullptr;
   a.fail = nullptr;
+  a.user_map = nullptr;
+  a.n_users_dev = nullptr;
 
   int rc;
   if (p.prefilter) {
@@ -1065,7 +1088,27 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     rc = check_launch("score prefilter kernels");
     if (rc) return rc;
     // uncertified users (list overflow, fewer than K above the threshold, band wider than the re-score slots) were
-    // queued on the device: exact fp32 scores of all items for each of them, one block per user
+    // queued on the device.  Large item ranges: the first kPfFbGroupCap of them as a compact user set through the
+    // unthresholded f32 MFMA sweep (32 users share each pass over the items), results written to their own rows.
+    P.fb_skip = 0;
+    if (p.pf_group_fb) {
+      ScoreArgs f = a;
+      f.n_users = kPfFbGroupCap;
+      f.user_map = P.fb_list;
+      f.n_users_dev = P.fb_cnt;
+      f.splits = p.pf_group_fb_splits;
+      f.tiles_per_split = (n_tiles + f.splits - 1) / f.splits;
+      f.partial = (uint64_t *)(ws + p.off_pf_fbgroup);
+      rc = dispatch_score(D, f, dim3(kPfFbGroupCap / 32, (unsigned)f.splits), st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(score_topk_merge_kernel, dim3(kPfFbGroupCap), dim3(64), 0, st, f.partial,
+                         (int64_t)kPfFbGroupCap, K, f.splits, id_offset, out_idx, out_val, (const float *)nullptr,
+                         (int *)nullptr, (const int *)nullptr, (const int *)P.fb_list, (const int *)P.fb_cnt);
+      rc = check_launch("score_topk_merge_kernel (grouped fallback)");
+      if (rc) return rc;
+      P.fb_skip = kPfFbGroupCap;
+    }
+    // ... and exact fp32 scores of all items for each remaining one, one block per (user, item slice)
     if (D == 64) hipLaunchKernelGGL(score_exact_user_kernel<64>, dim3(512), dim3(kExThreads), 0, st, P);
     else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(512), dim3(kExThreads), 0, st, P);
     return check_launch("score_exact_user_kernel");
@@ -1146,7 +1189,7 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     if (p.splits > 1) {
       hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, a.partial, n_users, K,
                          p.splits, id_offset, out_idx, out_val, (const float *)nullptr, (int *)nullptr,
-                         (const int *)failf);
+                         (const int *)failf, (const int *)nullptr, (const int *)nullptr);
       rc = check_launch("score_topk_merge_kernel");
     }
     return rc;
@@ -1156,7 +1199,7 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
   if (p.splits > 1) {
     hipLaunchKernelGGL(score_topk_merge_kernel, dim3((unsigned)n_users), dim3(64), 0, st, a.partial, n_users,
                        K, p.splits, id_offset, out_idx, out_val, (const float *)nullptr, (int *)nullptr,
-                       (const int *)nullptr);
+                       (const int *)nullptr, (const int *)nullptr, (const int *)nullptr);
     rc = check_launch("score_topk_merge_kernel");
     if (rc) return rc;
   }

@@ -890,3 +890,32 @@ def test_col_sum_and_mean_all_deterministic_and_replay_safe(dev, M, N):
     if M >= 20000:
         # not an assertion on torch: if this starts passing the workaround may be dropped
         print("torch x.sum(0) stale under replay:", torch_stale)
+
+
+@pytest.mark.parametrize("U,D,kind", [(40, 64, "ties"), (600, 64, "ties"), (70, 128, "hot_range")])
+def test_score_topk_grouped_fallback_on_long_item_ranges(dev, oracle, U, D, kind):
+    """Past 128 k items the users the prefilter cannot certify are ranked 32 at a time by the f32 MFMA sweep over a
+    COMPACT user set (device-side queue -> user_map), the overflow of that set (> 512 users) by the per-user exact
+    kernel.  Inputs that push every user (ties) or a strided subset (hot item range) into the queue must still give
+    the exact top-K, written to the right rows."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(U + D)
+    I, K = 140000, 50
+    ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
+    if kind == "ties":
+        ie[:] = ie[0]                       # every score of a user is the same number: lists overflow for everybody
+    else:
+        ie *= 0.05
+        ie[40000:40000 + 3 * 32] = np.abs(rng.standard_normal((96, D))).astype(np.float32) * 3
+        ue[::3] = np.abs(ue[::3])           # a third of the users see a hot, unsampled range: overflow
+    hist = _hist_random(U, I, 30, seed=U)
+    want_i, want_v = oracle.score_topk(ue, ie, hist, 1e-6, K, U)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    st = {}
+    got_i, got_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), dh, 1e-6, K, id_offset=U,
+                                  stats=st)
+    assert np.array_equal(got_v.cpu().numpy(), want_v)
+    assert np.array_equal(got_i.cpu().numpy(), want_i)
+    if kind == "ties":
+        assert st["fallback_users"] == U, st            # all of them went through the queue (U = 600: both routes)
