@@ -195,6 +195,7 @@ def main():
 
     from chaorec_amd import _lib, graph, ops
     from chaorec_amd.Model import LightGCN
+    _lib.ensure_built()
     from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
     _lib.load()
 

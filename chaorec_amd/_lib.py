@@ -91,6 +91,15 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def ensure_built():
+    """Entry points that own a whole run (bench.py, smoke(), the test session) call this first: compile the library
+    if the file is not there (a fresh checkout; hipcc cross-compiles without a GPU).  load() itself never builds and
+    never falls back: a missing library is an error for every op."""
+    if not os.path.exists(LIB_PATH):
+        build(verbose=True)
+    return LIB_PATH
+
+
 def load():
     global _lib
     if _lib is not None:

@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _hip_library():
+    """A fresh checkout has no libchaorec_hip.so (it is a build product): compile it once per session when hipcc is
+    there.  Nothing here falls back to anything: without the library the GPU tests fail in _lib.load()."""
+    import shutil
+    from chaorec_amd import _lib
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        _lib.ensure_built()
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
