@@ -464,10 +464,16 @@ def main():
     if args.probe_graph:
         sys.exit(0 if graphed is not None else 3)
     if rank == 0:
-        # RCCL writes its version banner through C stdio, which would otherwise drain at exit, AFTER the result:
-        # flush it first so that the JSON object is the last line on stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
+        if world > 1 or force_sharded:
+            # RCCL writes its version banner through C stdio, which would otherwise drain at exit, AFTER the result:
+            # flush C stdout first so that the JSON object is the last line (stdout only -- an fflush(NULL) from here
+            # hung under rocprofv3, which keeps streams of its own)
+            import ctypes
+            libc = ctypes.CDLL(None)
+            try:
+                libc.fflush(ctypes.c_void_p.in_dll(libc, "stdout"))
+            except (ValueError, OSError):
+                pass
         print(json.dumps(out), flush=True)
 
 

@@ -33,7 +33,7 @@ def run(tag, name, extra):
           ["--", "python3", os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--no-cpu-baseline",
            "--no-graph", "--no-trained-state"]
     env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not line:
         sys.stderr.write(r.stdout[-2000:] + r.stderr[-2000:])
