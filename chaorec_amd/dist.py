@@ -115,13 +115,21 @@ class _ShardedLayerMean(torch.autograd.Function):
         fu = torch.empty_like(xu) if n_layers else xu * w
         fi = xi * w
         cu, ci = xu, xi
+        # Layer l+1's item partial B_g^T x_u only needs this rank's user rows of layer l, not the all-reduce of layer
+        # l's partial: the wait for an all-reduce is therefore deferred until the user-row SpMM that consumes its result,
+        # ONE LAYER LATER -- each exchange travels under two SpMMs (and next to the following exchange) instead of one
+        pend = None                                     # all-reduce in flight for `ci`
         for l in range(n_layers):
             pi = spmm_fn(shard.iu, cu)
-            pending = _all_reduce_async(pi, group)       # item partials travel while the user rows are computed
+            pend_pi = _all_reduce_async(pi, group)
+            if pend is not None:
+                pend.wait()
+                fi.add_(ci, alpha=w)                    # the previous layer's item rows join the layer mean
             yu = spmm_fn(shard.ui, ci, acc=fu, acc_init=xu if l == 0 else None, acc_w=w)
-            pending.wait()
-            fi.add_(pi, alpha=w)
-            cu, ci = yu, pi
+            cu, ci, pend = yu, pi, pend_pi
+        if pend is not None:
+            pend.wait()
+            fi.add_(ci, alpha=w)
         ctx.shard, ctx.n_layers, ctx.w, ctx.spmm_fn, ctx.group = shard, n_layers, w, spmm_fn, group
         return fu, fi
 
@@ -131,14 +139,20 @@ class _ShardedLayerMean(torch.autograd.Function):
         # folded into the per-layer all-reduce:  g_i <- allreduce(B_g^T g_u + w * Gi_partial)
         shard, L, w, spmm_fn, group = ctx.shard, ctx.n_layers, ctx.w, ctx.spmm_fn, ctx.group
         Gu, Gi = Gu.contiguous(), Gi.contiguous()
-        Gi_full = _all_reduce(Gi.clone(), group)       # layer-L seed needs the full item gradient
-        gu, gi = Gu * w, Gi_full.mul_(w)
-        for _ in range(L):
+        Gi_full = Gi.clone()                            # layer-L seed needs the full item gradient
+        pend = _all_reduce_async(Gi_full, group)
+        gu, gi = Gu * w, Gi_full
+        for it in range(L):                             # same deferral as in forward
             pi = spmm_fn(shard.iu, gu, z=Gi, beta=w)
-            pending = _all_reduce_async(pi, group)
+            pend_pi = _all_reduce_async(pi, group)
+            pend.wait()
+            if it == 0:
+                gi = Gi_full.mul_(w)
             nu = spmm_fn(shard.ui, gi, z=Gu, beta=w)
-            pending.wait()
-            gu, gi = nu, pi
+            gu, gi, pend = nu, pi, pend_pi
+        pend.wait()
+        if L == 0:
+            gi = Gi_full.mul_(w)
         return gu, gi, None, None, None, None
 
 
