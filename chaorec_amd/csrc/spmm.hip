@@ -452,12 +452,37 @@ extern "C" int chaorec_spmm_build_schedule(const int64_t *rowptr, const int32_t 
   if (out_len < need) return fail(CHAOREC_E_WORKSPACE, "build_schedule: out_len %lld < %lld", (long long)out_len, (long long)need);
   const int64_t groups = (n_rows + g - 1) / g;
   const int64_t nb = (groups + 3) / 4;
+  // Which rows share a wave.  A wave's g lane groups finish together with its LONGEST row, so rows are grouped by
+  // degree, not by index (a descriptor carries its row id: any row can sit in any slot):
+  //   * rows above LONG_T (walked cooperatively by the whole block, one after the other) are dealt one per group,
+  //     longest first, each with the g-1 SHORTEST rows as company -- never two long rows behind each other in a block
+  //     unless there are more long rows than blocks;
+  //   * all other rows, sorted by degree, fill the remaining groups g at a time: equal trip counts inside a wave.
+  std::vector<int64_t> rows_sorted(n_rows);
+  for (int64_t r = 0; r < n_rows; ++r) rows_sorted[r] = r;
+  std::stable_sort(rows_sorted.begin(), rows_sorted.end(), [&](int64_t a, int64_t b) {
+    return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b];
+  });
+  int64_t n_long = 0;
+  if (g > 1)
+    while (n_long < n_rows && rowptr[rows_sorted[n_long] + 1] - rowptr[rows_sorted[n_long]] > CHAOREC_SPMM_LONG_T) ++n_long;
+  if (n_long > groups) n_long = groups;       // (more long rows than waves: the surplus is grouped like the rest)
+  std::vector<int64_t> slot_row((size_t)groups * g, -1);
+  {
+    int64_t lo = n_long, hi = n_rows - 1;     // unassigned rows: rows_sorted[lo .. hi], longest at lo
+    for (int64_t gi = 0; gi < n_long; ++gi) {
+      slot_row[(size_t)gi * g] = rows_sorted[gi];
+      for (int s2 = 1; s2 < g && hi >= lo; ++s2) slot_row[(size_t)gi * g + s2] = rows_sorted[hi--];
+    }
+    for (int64_t gi = n_long; gi < groups; ++gi)
+      for (int s2 = 0; s2 < g && lo <= hi; ++s2) slot_row[(size_t)gi * g + s2] = rows_sorted[lo++];
+  }
   std::vector<int64_t> heavy(groups, 0), order(groups);
   for (int64_t gi = 0; gi < groups; ++gi) {
     order[gi] = gi;
-    for (int s = 0; s < g; ++s) {
-      const int64_t r = gi * g + s;
-      if (r < n_rows) heavy[gi] = std::max(heavy[gi], rowptr[r + 1] - rowptr[r]);
+    for (int s2 = 0; s2 < g; ++s2) {
+      const int64_t r = slot_row[(size_t)gi * g + s2];
+      if (r >= 0) heavy[gi] = std::max(heavy[gi], rowptr[r + 1] - rowptr[r]);
     }
   }
   std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return heavy[a] > heavy[b]; });
@@ -473,7 +498,7 @@ extern "C" int chaorec_spmm_build_schedule(const int64_t *rowptr, const int32_t 
     for (int j = 0; j < 4; ++j) {
       for (int s = 0; s < g; ++s) {
         int32_t *d = out + (((size_t)(4 * b + j)) * g + s) * kDescDwords;
-        const int64_t r = grp[j] >= 0 ? grp[j] * g + s : -1;
+        const int64_t r = grp[j] >= 0 ? slot_row[(size_t)grp[j] * g + s] : -1;
         if (r < 0 || r >= n_rows) {
           d[0] = -1;
           d[1] = any_long ? (int32_t)0x80000000u : 0;
