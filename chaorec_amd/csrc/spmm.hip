@@ -487,12 +487,30 @@ extern "C" int chaorec_spmm_build_schedule(const int64_t *rowptr, const int32_t 
   }
   std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return heavy[a] > heavy[b]; });
   std::memset(out, 0, (size_t)need * sizeof(int32_t));
+  // Which groups share a workgroup (its LDS and wave slots are released when the LAST of its 4 waves ends):
+  //   * a group with a long row gets its own workgroup, together with the three LIGHTEST groups left -- their waves
+  //     are done early and then help walking the long row (the cooperative phase uses all 4 waves);
+  //   * the other workgroups take 4 consecutive groups of the degree-sorted list: waves of one block end together.
+  // Workgroups are numbered heavy first (the dispatcher hands them out in order).
+  int64_t n_long_groups = 0;
+  if (g > 1)
+    while (n_long_groups < groups && heavy[order[n_long_groups]] > CHAOREC_SPMM_LONG_T) ++n_long_groups;
+  if (n_long_groups > nb) n_long_groups = nb;
+  std::vector<int64_t> block_group((size_t)nb * 4, -1);
+  {
+    int64_t lo = n_long_groups, hi = groups - 1;
+    for (int64_t b = 0; b < n_long_groups; ++b) {
+      block_group[(size_t)b * 4] = order[b];
+      for (int j = 1; j < 4 && hi >= lo; ++j) block_group[(size_t)b * 4 + j] = order[hi--];
+    }
+    for (int64_t b = n_long_groups; b < nb; ++b)
+      for (int j = 0; j < 4 && lo <= hi; ++j) block_group[(size_t)b * 4 + j] = order[lo++];
+  }
   for (int64_t b = 0; b < nb; ++b) {
     bool any_long = false;
     int64_t grp[4];
     for (int j = 0; j < 4; ++j) {
-      const int64_t k = (int64_t)j * nb + b;   // slot 4*b + j  <-  sorted[j*nb + b]
-      grp[j] = k < groups ? order[k] : -1;
+      grp[j] = block_group[(size_t)b * 4 + j];
       if (grp[j] >= 0 && g > 1 && heavy[grp[j]] > CHAOREC_SPMM_LONG_T) any_long = true;
     }
     for (int j = 0; j < 4; ++j) {
