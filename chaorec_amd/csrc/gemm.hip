@@ -21,8 +21,9 @@ constexpr int BK = 16, PAD = 4;
 // global -> registers -> LDS -> barrier four times for 2 us of MFMA work.  The <.., BKT = 64, NBUF = 1> form stages a
 // 64-deep tile per barrier pair (every load of the tile in flight at once, one LDS buffer: 49 KB for 128 x 64).
 
-// <BM, BN> in {(128,128): waves 2x2 of 64x64; (128,64): waves 4x1 of 32x64; (64,128): waves 2x2 of 32x64 -- the last
-// for outputs with <= 64 rows (weight gradients of 64-wide layers), where a 128-row tile would be half padding}
+// <BM, BN> in {(128,128): waves 2x2 of 64x64; (128,64): waves 4x1 of 32x64; (64,128): waves 2x2 of 32x64; (64,64):
+// waves 2x2 of 32x32 -- the 64-row tiles for outputs with <= 64 rows (weight gradients of 64-wide layers), where a
+// 128-row tile would be half padding}
 template <int BM, int BN, int BKT = BK, int NBUF = 2>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
     int64_t ldc, int transA, int transB, int accumulate, int act, int64_t k_per_split,
     float *__restrict__ slabs) {
   constexpr int WM = (BM == 128 && BN == 128) ? 2 : 1;   // 32-row accumulator blocks per wave
-  constexpr int WN = 2;                   // 32-col accumulator blocks per wave
+  constexpr int WN = (BM == 64 && BN == 64) ? 1 : 2;     // 32-col accumulator blocks per wave
   constexpr int BK = BKT;                 // (shadows the default tile depth inside this kernel)
   // k-rows of a deep tile are skewed by 4 floats per 16 rows (SK): the transposing stash below writes, per wave,
   // 4 tile rows x 16 k-quads, and k-quads 16 rows apart would otherwise land in the same LDS banks
@@ -42,8 +43,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int wrow = BN == 64 ? wave * 32 : (wave >> 1) * (BM / 2);
-  const int wcol = BN == 64 ? 0 : (wave & 1) * 64;
+  // waves: (128,64) 4x1 of 32x64; (64,64) 2x2 of 32x32; (128,128) 2x2 of 64x64; (64,128) 2x2 of 32x64
+  const int wrow = (BM == 128 && BN == 64) ? wave * 32 : (wave >> 1) * (BM / 2);
+  const int wcol = (BM == 128 && BN == 64) ? 0 : (wave & 1) * (BN / 2);
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int64_t n0 = (int64_t)blockIdx.y * BN;
   const int64_t kb = (int64_t)blockIdx.z * k_per_split;
@@ -310,7 +312,7 @@ struct GemmPlan {
 static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   GemmPlan p;
   p.bn = N <= 64 ? 64 : 128;
-  p.bm = (M <= 64 && p.bn == 128) ? 64 : 128;
+  p.bm = M <= 64 ? 64 : 128;      // (64-row outputs -- weight gradients of 64-wide layers -- would be half padding)
   const int64_t tiles = ((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn);
   p.splits = 1;
   // few output tiles and a long reduction (weight gradients: K = number of graph nodes): split K so that the
@@ -324,7 +326,7 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   }
   // 64-wide outputs with a reduction of at most a few hundred (Linear 64->64 / 128->64 over all graph nodes, and the
   // k-slices of their weight gradients): deep tiles, see the note at BK
-  p.bk = (p.bn == 64 && p.bm == 128 && (p.splits > 1 || K <= 512)) ? 64 : BK;
+  p.bk = (p.bn == 64 && (p.splits > 1 || K <= 512)) ? 64 : BK;
   int64_t per = (K + p.splits - 1) / p.splits;
   per = (per + p.bk - 1) / p.bk * p.bk;
   p.k_per_split = per < p.bk ? p.bk : per;
@@ -418,7 +420,13 @@ extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const 
   hipStream_t st = (hipStream_t)stream;
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
   const dim3 grid((unsigned)((M + p.bm - 1) / p.bm), (unsigned)((N + p.bn - 1) / p.bn), (unsigned)p.splits);
-  if (p.bn == 64 && p.bk == 64)
+  if (p.bn == 64 && p.bm == 64 && p.bk == 64)
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 64, 1>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc,
+                       transA, transB, accumulate, act, p.k_per_split, slabs);
+  else if (p.bn == 64 && p.bm == 64)
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, transA,
+                       transB, accumulate, act, p.k_per_split, slabs);
+  else if (p.bn == 64 && p.bk == 64)
     hipLaunchKernelGGL((gemm_f32_kernel<128, 64, 64, 1>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc,
                        transA, transB, accumulate, act, p.k_per_split, slabs);
   else if (p.bn == 64)
