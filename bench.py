@@ -236,6 +236,16 @@ def main():
     # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph.  The sharded step holds
     # RCCL all-reduces; they are captured with it when the backend is RCCL (CHAOREC_DIST_GRAPH=0 keeps it eager).
     # Every rank must run the same launch mode: if the capture fails anywhere, all ranks fall back to eager.
+    # the unsharded model draws its batch INSIDE the fused BPR forward (one launch less per step)
+    fused_draw = hasattr(model, "loss_drawn")
+
+    def bump():
+        batch_counter.add_(1)
+        return ()
+
+    def drawn_loss():
+        return model.loss_drawn(edges_dev, B, 42 + rank, 0, step_dev=batch_counter)
+
     use_graph = not args.no_graph and not args.torch_adam
     if sharded is not None:
         use_graph = use_graph and backend == "nccl" and os.environ.get("CHAOREC_DIST_GRAPH", "1") == "1"
@@ -247,7 +257,8 @@ def main():
     graphed = None
     if use_graph:
         try:
-            graphed = GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local)
+            graphed = (GraphedTrainStep(model, opt, batch_fn=bump, loss_fn=drawn_loss) if fused_draw else
+                       GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local))
         except Exception as exc:      # noqa: BLE001 -- any capture failure means "launch eagerly", never a wrong result
             if sharded is None:
                 raise
@@ -287,9 +298,11 @@ def main():
         if graphed is not None and not force_eager:
             loss = graphed()          # sampling + loss + backward + Adam: one hipGraph replay, no inputs
         else:
-            users, pos, neg = draw(i)
             opt.zero_grad(set_to_none=True)
-            loss = model.loss_local(users, pos, neg)
+            if fused_draw:
+                loss = model.loss_drawn(edges_dev, B, 42 + rank, 1_000_000 + i)
+            else:
+                loss = model.loss_local(*draw(i))
             loss.backward()
             opt.step()
             loss = loss.detach()

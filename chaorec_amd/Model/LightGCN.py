@@ -105,6 +105,16 @@ class LightGCN(nn.Module):
         without the id shift and the host->device copies."""
         return self._fused(users, pos_items, neg_items, self.forward())[0]
 
+    def loss_drawn(self, edges, B, seed, step, step_dev=None):
+        """loss_local() with the batch drawn inside the fused BPR forward (ops.bpr_loss_drawn): `edges` is the int64
+        [E, 2] training list on the device (global item ids); the ids follow ops.draw_batch for the same
+        (seed, step, step_dev).  Keeps self.batch = (users, pos, neg) for callers that want to look."""
+        out, users, pos, neg = ops.bpr_loss_drawn(self.forward(), None, edges, self.hist, B, self.num_user,
+                                                  self.num_item, seed, step, ops.VARIANT_LOG_SIGMOID_EPS,
+                                                  self.reg_weight, item_offset=self.num_user, step_dev=step_dev)
+        self.batch = (users, pos, neg)
+        return out[0]
+
     def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/LightGCN.py:137-162 -> LongTensor [U, topk] of GLOBAL item ids on the CPU.
         Uses the stale self.result of the last training forward, as the reference does."""

@@ -16,17 +16,14 @@ namespace chaorec {
 
 __device__ __forceinline__ float sigmoidf_acc(float d) { return 1.0f / (1.0f + expf(-d)); }
 
-__global__ __launch_bounds__(256) void bpr_fwd_terms_kernel(
-    const float *__restrict__ tab_u, const float *__restrict__ tab_i,
-    const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
-    const int64_t *__restrict__ neg, int B, int D, int variant, float *__restrict__ coef,
-    float *__restrict__ ws) {
+// the wave of triple b: three row gathers, five wave butterflies, lane 0 writes the term / coefficient / L2 parts
+__device__ __forceinline__ void bpr_terms_wave(const float *__restrict__ tab_u, const float *__restrict__ tab_i,
+                                               int64_t iu, int64_t ip, int64_t in, int b, int B, int D, int variant,
+                                               float *__restrict__ coef, float *__restrict__ ws) {
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (b >= B) return;
-  const float *pu = tab_u + (size_t)users[b] * D;
-  const float *pp = tab_i + (size_t)pos[b] * D;
-  const float *pn = tab_i + (size_t)neg[b] * D;
+  const float *pu = tab_u + (size_t)iu * D;
+  const float *pp = tab_i + (size_t)ip * D;
+  const float *pn = tab_i + (size_t)in * D;
   float sp = 0.f, sn = 0.f, ru = 0.f, rp = 0.f, rn = 0.f;
   for (int k = lane; k < D; k += 64) {
     const float u = pu[k], p = pp[k], n = pn[k];
@@ -64,6 +61,47 @@ __global__ __launch_bounds__(256) void bpr_fwd_terms_kernel(
     ws[2 * B + b] = rp;
     ws[3 * B + b] = rn;
   }
+}
+
+__global__ __launch_bounds__(256) void bpr_fwd_terms_kernel(
+    const float *__restrict__ tab_u, const float *__restrict__ tab_i,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
+    const int64_t *__restrict__ neg, int B, int D, int variant, float *__restrict__ coef,
+    float *__restrict__ ws) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  bpr_terms_wave(tab_u, tab_i, users[b], pos[b], neg[b], b, B, D, variant, coef, ws);
+}
+
+// draw_triple is defined below (sampler section)
+__device__ __forceinline__ void draw_triple(const int64_t *__restrict__, int64_t, const int64_t *__restrict__,
+                                            const int32_t *__restrict__, int64_t, uint32_t, uint64_t, uint64_t,
+                                            uint32_t, int64_t &, int64_t &, int64_t &);
+
+// The same forward with the batch drawn IN the launch: lane 0 of triple b's wave picks the training edge and rejects
+// negatives against the user's history, the wave shares the three ids by shuffle, gathers and reduces.  The ids are
+// written out for the backward launch.  One launch less per step than draw_batch + bpr_fwd_terms.
+__global__ __launch_bounds__(256) void bpr_fwd_terms_drawn_kernel(
+    const float *__restrict__ tab_u, const float *__restrict__ tab_i, const int64_t *__restrict__ edges,
+    int64_t n_edges, const int64_t *__restrict__ hist_rowptr, const int32_t *__restrict__ hist_col, int64_t num_user,
+    uint32_t num_item, uint64_t seed, uint64_t step, const int64_t *__restrict__ step_dev,
+    int64_t *__restrict__ out_users, int64_t *__restrict__ out_pos, int64_t *__restrict__ out_neg, int B, int D,
+    int variant, float *__restrict__ coef, float *__restrict__ ws) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  if (step_dev) step += (uint64_t)step_dev[0];
+  int64_t u = 0, p = 0, n = 0;
+  if (lane == 0) {
+    draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n);
+    out_users[b] = u;
+    out_pos[b] = p;
+    out_neg[b] = n;
+  }
+  u = __shfl(u, 0, 64);
+  p = __shfl(p, 0, 64);
+  n = __shfl(n, 0, 64);
+  bpr_terms_wave(tab_u, tab_i, u, p, n, b, B, D, variant, coef, ws);
 }
 
 // One block, fixed order: thread t sums elements t, t+256, ... then a fixed LDS tree.
@@ -156,6 +194,33 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
   out_neg[b] = (int64_t)cand + id_offset;
 }
 
+// sample b of batch `step`: a training edge picked uniformly (user, positive as LOCAL item id) and one negative the
+// user has not interacted with (rejection against the ascending history row, bounded)
+__device__ __forceinline__ void draw_triple(const int64_t *__restrict__ edges, int64_t n_edges,
+                                            const int64_t *__restrict__ hist_rowptr,
+                                            const int32_t *__restrict__ hist_col, int64_t num_user, uint32_t num_item,
+                                            uint64_t seed, uint64_t step, uint32_t b, int64_t &u, int64_t &p,
+                                            int64_t &n) {
+  const uint64_t hsel = mix64(seed ^ mix64(step ^ mix64(0xED6E5ull ^ ((uint64_t)b << 32))));
+  // 64x64 -> high 64 multiply-shift onto [0, n_edges)
+  const uint64_t idx = (uint64_t)(((unsigned __int128)hsel * (unsigned __int128)(uint64_t)n_edges) >> 64);
+  u = edges[2 * idx];
+  p = edges[2 * idx + 1] - num_user;
+  const int64_t h0 = hist_rowptr[u], h1 = hist_rowptr[u + 1];
+  uint32_t cand = 0;
+  for (uint32_t attempt = 0;; ++attempt) {
+    cand = sampler_draw(seed, step, b, attempt, num_item);
+    int64_t lo = h0, hi = h1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint32_t)hist_col[mid] < cand) lo = mid + 1; else hi = mid;
+    }
+    const bool seen = (lo < h1) && ((uint32_t)hist_col[lo] == cand);
+    if (!seen || attempt >= 4096u) break;
+  }
+  n = (int64_t)cand;
+}
+
 // One launch per batch: pick B training edges uniformly (counter-based, with replacement across batches),
 // gather (user, positive) and draw one negative each -- the DataLoader(shuffle) + TrainingDataset.__getitem__
 // pair of main.py:194-195 / dataload.py:74-79 for a streaming trainer.  Outputs LOCAL ids (item - num_user),
@@ -168,25 +233,11 @@ __global__ __launch_bounds__(256) void draw_batch_kernel(
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   if (step_dev) step += (uint64_t)step_dev[0];
-  const uint64_t hsel = mix64(seed ^ mix64(step ^ mix64(0xED6E5ull ^ ((uint64_t)b << 32))));
-  // 64x64 -> high 64 multiply-shift onto [0, n_edges)
-  const uint64_t idx = (uint64_t)(((unsigned __int128)hsel * (unsigned __int128)(uint64_t)n_edges) >> 64);
-  const int64_t u = edges[2 * idx];
+  int64_t u, p, n;
+  draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n);
   out_users[b] = u;
-  out_pos[b] = edges[2 * idx + 1] - num_user;
-  const int64_t h0 = hist_rowptr[u], h1 = hist_rowptr[u + 1];
-  uint32_t cand = 0;
-  for (uint32_t attempt = 0;; ++attempt) {
-    cand = sampler_draw(seed, step, (uint32_t)b, attempt, num_item);
-    int64_t lo = h0, hi = h1;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if ((uint32_t)hist_col[mid] < cand) lo = mid + 1; else hi = mid;
-    }
-    const bool seen = (lo < h1) && ((uint32_t)hist_col[lo] == cand);
-    if (!seen || attempt >= 4096u) break;
-  }
-  out_neg[b] = (int64_t)cand;
+  out_pos[b] = p;
+  out_neg[b] = n;
 }
 
 }  // namespace chaorec
@@ -221,6 +272,27 @@ extern "C" int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i, const
   if (rc) return rc;
   hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight,
                      out_loss, out_total);
+  return check_launch("bpr_fwd_finalize_kernel");
+}
+
+extern "C" int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
+                                         const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
+                                         int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
+                                         int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
+                                         int64_t *out_pos, int64_t *out_neg, float *out_loss, float *out_total,
+                                         float *coef, float *workspace, void *stream) {
+  if (!tab_u || !tab_i || !edges || !hist_rowptr || !out_users || !out_pos || !out_neg || !out_loss || !coef || !workspace)
+    return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: NULL argument");
+  if (B <= 0 || D <= 0 || n_edges <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: bad sizes");
+  if (variant < 0 || variant > 2) return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: variant %d", variant);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bpr_fwd_terms_drawn_kernel, dim3((B + 3) / 4), dim3(256), 0, st, tab_u, tab_i, edges, n_edges,
+                     hist_rowptr, hist_col, num_user, (uint32_t)num_item, seed, step, step_dev, out_users, out_pos,
+                     out_neg, B, D, variant, coef, workspace);
+  int rc = check_launch("bpr_fwd_terms_drawn_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight, out_loss,
+                     out_total);
   return check_launch("bpr_fwd_finalize_kernel");
 }
 

@@ -178,6 +178,55 @@ class _LossParts:
         return self.parts.detach()
 
 
+class _BPRDrawn(torch.autograd.Function):
+    """_BPR with the batch drawn inside the forward launch (chaorec_bpr_fwd_drawn_f32): the (user, positive, negative)
+    ids of ops.draw_batch(edges, hist, B, num_user, num_item, seed, step, step_dev) are produced by the kernel, used
+    right away and kept for the backward.  -> (loss, parts, users, pos, neg)."""
+
+    @staticmethod
+    def forward(ctx, tab_u, tab_i, edges, hist_rowptr, hist_col, B, num_user, num_item, seed, step, step_dev, variant,
+                reg_weight, item_offset):
+        _need_cuda(tab_u, tab_i, edges, hist_rowptr, hist_col, step_dev)
+        tab_u = _f32c(tab_u)
+        D = tab_u.shape[1]
+        if tab_i is None:
+            pi = ctypes.c_void_p(tab_u.data_ptr() + item_offset * D * 4)
+        else:
+            tab_i = _f32c(tab_i)
+            pi = _ptr(tab_i)
+        dev = tab_u.device
+        users = torch.empty(B, dtype=torch.int64, device=dev)
+        pos, neg = torch.empty_like(users), torch.empty_like(users)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        coef = torch.empty(B, dtype=torch.float32, device=dev)
+        ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
+        rc = _lib.load().chaorec_bpr_fwd_drawn_f32(_ptr(tab_u), pi, _ptr(edges), edges.shape[0], _ptr(hist_rowptr),
+                                                   _ptr(hist_col), num_user, num_item, int(seed) & (2**64 - 1),
+                                                   int(step), _ptr(step_dev), B, D, variant, reg_weight, _ptr(users),
+                                                   _ptr(pos), _ptr(neg), _ptr(out), _ptr(loss), _ptr(coef), _ptr(ws),
+                                                   _stream())
+        _lib.check(rc, "chaorec_bpr_fwd_drawn_f32")
+        ctx.save_for_backward(tab_u, tab_i, users, pos, neg, coef)
+        ctx.reg_weight, ctx.item_offset = reg_weight, item_offset
+        ctx.mark_non_differentiable(out, users, pos, neg)
+        ctx.set_materialize_grads(False)
+        return loss, out, users, pos, neg
+
+    @staticmethod
+    def backward(ctx, g_loss, *_unused):
+        return _BPR.backward(ctx, g_loss, None)[:2] + (None,) * 12
+
+
+def bpr_loss_drawn(tab_u, tab_i, edges, hist, B, num_user, num_item, seed, step, variant, reg_weight=0.0,
+                   item_offset=0, step_dev=None):
+    """Fused batch draw + BPR(+L2): ([total, bpr, reg], users, pos, neg); differentiate [0][0]."""
+    loss, parts, users, pos, neg = _BPRDrawn.apply(tab_u, tab_i, edges, hist[0], hist[1], int(B), int(num_user),
+                                                   int(num_item), seed, step, step_dev, int(variant),
+                                                   float(reg_weight), int(item_offset))
+    return _LossParts(loss, parts), users, pos, neg
+
+
 def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset=0):
     """Fused BPR(+L2) over a batch of LOCAL row ids -> [total, bpr, reg]; differentiate [0]."""
     loss, parts = _BPR.apply(tab_u, tab_i, users, pos, neg, int(variant), float(reg_weight), int(item_offset))

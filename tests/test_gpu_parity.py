@@ -919,3 +919,39 @@ def test_score_topk_grouped_fallback_on_long_item_ranges(dev, oracle, U, D, kind
     assert np.array_equal(got_i.cpu().numpy(), want_i)
     if kind == "ties":
         assert st["fallback_users"] == U, st            # all of them went through the queue (U = 600: both routes)
+
+
+@pytest.mark.parametrize("variant,joined", [(0, True), (1, False), (2, True)])
+def test_bpr_fused_draw_equals_draw_then_bpr(dev, variant, joined):
+    """chaorec_bpr_fwd_drawn_f32 (batch drawn inside the forward launch) against chaorec_draw_batch followed by
+    chaorec_bpr_fwd_f32 for the same (seed, step, step_dev): identical ids, bit-identical loss parts and gradients."""
+    from chaorec_amd import graph, ops
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D, B = 3000, 1700, 30000, 64, 1024
+    edges = synthetic_interactions(U, I, E, seed=3)
+    hist = tuple(t.to(dev) for t in graph.user_hist_csr_from_edges(edges, U))
+    ed = torch.from_numpy(edges.astype(np.int64)).to(dev)
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(variant)
+    tab = (torch.randn(U + I, D, device=dev, generator=g0) * 0.3)
+    step_dev = torch.tensor([7], dtype=torch.int64, device=dev)
+
+    def run(fused):
+        t = tab.clone().requires_grad_(True)
+        tu, ti, off = (t, None, U) if joined else (t[:U], t[U:], 0)
+        if fused:
+            out, users, pos, neg = ops.bpr_loss_drawn(tu, ti, ed, hist, B, U, I, 99, 5, variant, 1e-3, item_offset=off,
+                                                      step_dev=step_dev)
+        else:
+            users, pos, neg = ops.draw_batch(ed, hist, B, U, I, 99, 5, step_dev=step_dev)
+            out = ops.bpr_loss(tu, ti, users, pos, neg, variant, 1e-3, item_offset=off)
+        out[0].backward()
+        return users, pos, neg, out.detach().clone(), t.grad.clone()
+
+    a, b = run(True), run(False)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[3], b[3])
+    # (the backward scatters with fp32 atomics: equal up to the order of duplicate rows inside the batch)
+    assert torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-9)
+    assert int(a[1].min()) >= 0 and int(a[1].max()) < I and int(a[2].max()) < I
