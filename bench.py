@@ -239,12 +239,11 @@ def main():
     # the unsharded model draws its batch INSIDE the fused BPR forward (one launch less per step)
     fused_draw = hasattr(model, "loss_drawn")
 
-    def bump():
-        batch_counter.add_(1)
+    def no_batch():
         return ()
 
-    def drawn_loss():
-        return model.loss_drawn(edges_dev, B, 42 + rank, 0, step_dev=batch_counter)
+    def drawn_loss():          # (the fused launch also advances the device batch counter)
+        return model.loss_drawn(edges_dev, B, 42 + rank, 0, step_dev=batch_counter, advance=True)
 
     use_graph = not args.no_graph and not args.torch_adam
     if sharded is not None:
@@ -257,7 +256,7 @@ def main():
     graphed = None
     if use_graph:
         try:
-            graphed = (GraphedTrainStep(model, opt, batch_fn=bump, loss_fn=drawn_loss) if fused_draw else
+            graphed = (GraphedTrainStep(model, opt, batch_fn=no_batch, loss_fn=drawn_loss) if fused_draw else
                        GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local))
         except Exception as exc:      # noqa: BLE001 -- any capture failure means "launch eagerly", never a wrong result
             if sharded is None:

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void bpr_fwd_terms_drawn_kernel(
 __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__restrict__ ws, int B,
                                                                int D, float reg_weight,
                                                                float *__restrict__ out_loss,
-                                                               float *__restrict__ out_total) {
+                                                               float *__restrict__ out_total,
+                                                               int64_t *__restrict__ advance) {
   __shared__ float red[4][256];
   const int t = threadIdx.x;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -135,6 +136,8 @@ __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__re
     out_loss[1] = bpr;
     out_loss[2] = reg;
     if (out_total) out_total[0] = bpr + reg;
+    // every wave of the terms launch has read the batch counter by now: move it on for the next step
+    if (advance) advance[0] += 1;
   }
 }
 
@@ -271,7 +274,7 @@ extern "C" int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i, const
   int rc = check_launch("bpr_fwd_terms_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight,
-                     out_loss, out_total);
+                     out_loss, out_total, (int64_t *)nullptr);
   return check_launch("bpr_fwd_finalize_kernel");
 }
 
@@ -280,7 +283,7 @@ extern "C" int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i,
                                          int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
                                          int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
                                          int64_t *out_pos, int64_t *out_neg, float *out_loss, float *out_total,
-                                         float *coef, float *workspace, void *stream) {
+                                         float *coef, float *workspace, int64_t *advance, void *stream) {
   if (!tab_u || !tab_i || !edges || !hist_rowptr || !out_users || !out_pos || !out_neg || !out_loss || !coef || !workspace)
     return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: NULL argument");
   if (B <= 0 || D <= 0 || n_edges <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: bad sizes");
@@ -292,7 +295,7 @@ extern "C" int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i,
   int rc = check_launch("bpr_fwd_terms_drawn_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight, out_loss,
-                     out_total);
+                     out_total, advance);
   return check_launch("bpr_fwd_finalize_kernel");
 }
 

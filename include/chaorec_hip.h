@@ -151,13 +151,15 @@ int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *his
  * sample b's wave draws (user, positive, negative) exactly as chaorec_draw_batch does for (seed, step + *step_dev, b),
  * the wave shares the ids by shuffle, gathers the three rows and reduces.  out_users / out_pos / out_neg receive the
  * ids (LOCAL item ids; the backward launch chaorec_bpr_bwd_f32 takes them).  Everything else as chaorec_bpr_fwd_f32;
- * results are bit-identical to the two-call form. */
+ * results are bit-identical to the two-call form.  advance (optional, may be step_dev itself): a device counter that
+ * the single-block finalize launch increments by one after the draw, so a captured step needs no separate
+ * counter kernel. */
 int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
                               const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
                               int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
                               int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
                               int64_t *out_pos, int64_t *out_neg, float *out_loss, float *out_total,
-                              float *coef, float *workspace, void *stream);
+                              float *coef, float *workspace, int64_t *advance, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * R: all-items scoring + history mask + top-K, never materialising the [U, I] matrix.

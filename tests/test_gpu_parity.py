@@ -955,3 +955,8 @@ def test_bpr_fused_draw_equals_draw_then_bpr(dev, variant, joined):
     # (the backward scatters with fp32 atomics: equal up to the order of duplicate rows inside the batch)
     assert torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-9)
     assert int(a[1].min()) >= 0 and int(a[1].max()) < I and int(a[2].max()) < I
+    # advance=True moves the device counter on AFTER the draw: same ids as step_dev = 7, counter 8 afterwards
+    ctr = torch.tensor([7], dtype=torch.int64, device=dev)
+    _, u2, p2, n2 = ops.bpr_loss_drawn(tab, None, ed, hist, B, U, I, 99, 5, variant, 1e-3, item_offset=U, step_dev=ctr,
+                                       advance=True)
+    assert int(ctr) == 8 and torch.equal(u2, a[0]) and torch.equal(p2, a[1]) and torch.equal(n2, a[2])
