@@ -243,7 +243,9 @@ def main():
         return ()
 
     def drawn_loss():          # (the fused launch also advances the device batch counter)
-        return model.loss_drawn(edges_dev, B, 42 + rank, 0, step_dev=batch_counter, advance=True)
+        loss = model.loss_drawn(edges_dev, B, 42 + rank, 0, step_dev=batch_counter, advance=True)
+        loss_sum.add_(loss.detach())      # per-batch loss bookkeeping inside the captured step: replays run back to back
+        return loss
 
     use_graph = not args.no_graph and not args.torch_adam
     if sharded is not None:
@@ -291,11 +293,17 @@ def main():
                 done.set()
 
     n_loss = [0]
+    in_graph_sum = graphed is not None and fused_draw
+    if in_graph_sum:
+        loss_sum.zero_()              # (the capture's warm-up steps ran drawn_loss() too)
 
     def step(i, force_eager=False):
         n_loss[0] += 1
         if graphed is not None and not force_eager:
-            loss = graphed()          # sampling + loss + backward + Adam: one hipGraph replay, no inputs
+            graphed()                 # sampling + loss + backward + Adam: one hipGraph replay, no inputs
+            if in_graph_sum:
+                return
+            loss = graphed.static_loss
         else:
             opt.zero_grad(set_to_none=True)
             if fused_draw:
