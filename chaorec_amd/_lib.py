@@ -117,7 +117,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
-    if lib.chaorec_abi_version() != 2:
+    if lib.chaorec_abi_version() != 3:
         raise RuntimeError("libchaorec_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 2   /* 2: gemm workspace, score stats, rank metrics */
+#define CHAOREC_ABI_VERSION 3   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+                                  row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
+                                  SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
