@@ -105,14 +105,14 @@ class LightGCN(nn.Module):
         without the id shift and the host->device copies."""
         return self._fused(users, pos_items, neg_items, self.forward())[0]
 
-    def loss_drawn(self, edges, B, seed, step, step_dev=None, advance=False):
+    def loss_drawn(self, edges, B, seed, step, step_dev=None, advance=False, perm=None, perm_pos=None):
         """loss_local() with the batch drawn inside the fused BPR forward (ops.bpr_loss_drawn): `edges` is the int64
         [E, 2] training list on the device (global item ids); the ids follow ops.draw_batch for the same
         (seed, step, step_dev).  Keeps self.batch = (users, pos, neg) for callers that want to look."""
         out, users, pos, neg = ops.bpr_loss_drawn(self.forward(), None, edges, self.hist, B, self.num_user,
                                                   self.num_item, seed, step, ops.VARIANT_LOG_SIGMOID_EPS,
                                                   self.reg_weight, item_offset=self.num_user, step_dev=step_dev,
-                                                  advance=advance)
+                                                  advance=advance, perm=perm, perm_pos=perm_pos)
         self.batch = (users, pos, neg)
         return out[0]
 

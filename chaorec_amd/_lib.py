@@ -67,7 +67,7 @@ SIGNATURES = {
     "chaorec_bpr_fwd_drawn_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr, c_ptr,
-                                                 c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+                                                 c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_reduce_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64]),
     "chaorec_colsum_f32": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_ptr, c_ptr,
                                           ctypes.c_size_t, c_ptr]),

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void bpr_fwd_terms_kernel(
 // draw_triple is defined below (sampler section)
 __device__ __forceinline__ void draw_triple(const int64_t *__restrict__, int64_t, const int64_t *__restrict__,
                                             const int32_t *__restrict__, int64_t, uint32_t, uint64_t, uint64_t,
-                                            uint32_t, int64_t &, int64_t &, int64_t &);
+                                            uint32_t, int64_t &, int64_t &, int64_t &, const int64_t *__restrict__,
+                                            int64_t);
 
 // The same forward with the batch drawn IN the launch: lane 0 of triple b's wave picks the training edge and rejects
 // negatives against the user's history, the wave shares the three ids by shuffle, gathers and reduces.  The ids are
@@ -86,14 +87,16 @@ __global__ __launch_bounds__(256) void bpr_fwd_terms_drawn_kernel(
     int64_t n_edges, const int64_t *__restrict__ hist_rowptr, const int32_t *__restrict__ hist_col, int64_t num_user,
     uint32_t num_item, uint64_t seed, uint64_t step, const int64_t *__restrict__ step_dev,
     int64_t *__restrict__ out_users, int64_t *__restrict__ out_pos, int64_t *__restrict__ out_neg, int B, int D,
-    int variant, float *__restrict__ coef, float *__restrict__ ws) {
+    int variant, float *__restrict__ coef, float *__restrict__ ws, const int64_t *__restrict__ perm,
+    const int64_t *__restrict__ perm_pos) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= B) return;
   if (step_dev) step += (uint64_t)step_dev[0];
   int64_t u = 0, p = 0, n = 0;
   if (lane == 0) {
-    draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n);
+    draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n, perm,
+                perm ? perm_pos[0] : 0);
     out_users[b] = u;
     out_pos[b] = p;
     out_neg[b] = n;
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__re
                                                                int D, float reg_weight,
                                                                float *__restrict__ out_loss,
                                                                float *__restrict__ out_total,
-                                                               int64_t *__restrict__ advance) {
+                                                               int64_t *__restrict__ advance,
+                                                               int64_t *__restrict__ advance_pos) {
   __shared__ float red[4][256];
   const int t = threadIdx.x;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__re
     if (out_total) out_total[0] = bpr + reg;
     // every wave of the terms launch has read the batch counter by now: move it on for the next step
     if (advance) advance[0] += 1;
+    if (advance_pos) advance_pos[0] += B;       // the epoch permutation's read position
   }
 }
 
@@ -203,10 +208,16 @@ __device__ __forceinline__ void draw_triple(const int64_t *__restrict__ edges, i
                                             const int64_t *__restrict__ hist_rowptr,
                                             const int32_t *__restrict__ hist_col, int64_t num_user, uint32_t num_item,
                                             uint64_t seed, uint64_t step, uint32_t b, int64_t &u, int64_t &p,
-                                            int64_t &n) {
-  const uint64_t hsel = mix64(seed ^ mix64(step ^ mix64(0xED6E5ull ^ ((uint64_t)b << 32))));
-  // 64x64 -> high 64 multiply-shift onto [0, n_edges)
-  const uint64_t idx = (uint64_t)(((unsigned __int128)hsel * (unsigned __int128)(uint64_t)n_edges) >> 64);
+                                            int64_t &n, const int64_t *__restrict__ perm,
+                                            int64_t perm_pos) {
+  uint64_t idx;
+  if (perm) {
+    idx = (uint64_t)perm[perm_pos + b];              // epoch permutation (DataLoader(shuffle=True)): every edge once
+  } else {
+    const uint64_t hsel = mix64(seed ^ mix64(step ^ mix64(0xED6E5ull ^ ((uint64_t)b << 32))));
+    // 64x64 -> high 64 multiply-shift onto [0, n_edges)
+    idx = (uint64_t)(((unsigned __int128)hsel * (unsigned __int128)(uint64_t)n_edges) >> 64);
+  }
   u = edges[2 * idx];
   p = edges[2 * idx + 1] - num_user;
   const int64_t h0 = hist_rowptr[u], h1 = hist_rowptr[u + 1];
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(256) void draw_batch_kernel(
   if (b >= B) return;
   if (step_dev) step += (uint64_t)step_dev[0];
   int64_t u, p, n;
-  draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n);
+  draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n, nullptr, 0);
   out_users[b] = u;
   out_pos[b] = p;
   out_neg[b] = n;
@@ -274,7 +285,7 @@ extern "C" int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i, const
   int rc = check_launch("bpr_fwd_terms_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight,
-                     out_loss, out_total, (int64_t *)nullptr);
+                     out_loss, out_total, (int64_t *)nullptr, (int64_t *)nullptr);
   return check_launch("bpr_fwd_finalize_kernel");
 }
 
@@ -283,19 +294,21 @@ extern "C" int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i,
                                          int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
                                          int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
                                          int64_t *out_pos, int64_t *out_neg, float *out_loss, float *out_total,
-                                         float *coef, float *workspace, int64_t *advance, void *stream) {
+                                         float *coef, float *workspace, int64_t *advance, const int64_t *perm,
+                                         int64_t *perm_pos, void *stream) {
   if (!tab_u || !tab_i || !edges || !hist_rowptr || !out_users || !out_pos || !out_neg || !out_loss || !coef || !workspace)
     return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: NULL argument");
+  if (perm && !perm_pos) return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: perm without perm_pos");
   if (B <= 0 || D <= 0 || n_edges <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: bad sizes");
   if (variant < 0 || variant > 2) return fail(CHAOREC_E_INVALID, "bpr_fwd_drawn: variant %d", variant);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bpr_fwd_terms_drawn_kernel, dim3((B + 3) / 4), dim3(256), 0, st, tab_u, tab_i, edges, n_edges,
                      hist_rowptr, hist_col, num_user, (uint32_t)num_item, seed, step, step_dev, out_users, out_pos,
-                     out_neg, B, D, variant, coef, workspace);
+                     out_neg, B, D, variant, coef, workspace, perm, (const int64_t *)perm_pos);
   int rc = check_launch("bpr_fwd_terms_drawn_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight, out_loss,
-                     out_total, advance);
+                     out_total, advance, (perm && advance) ? perm_pos : (int64_t *)nullptr);
   return check_launch("bpr_fwd_finalize_kernel");
 }
 

@@ -117,6 +117,25 @@ class DeviceBatchSampler:
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
         self.global_step = 0
+        # in-launch mode (models with loss_drawn): the epoch permutation, its read position and the global batch
+        # counter live in HBM at fixed addresses; the fused BPR forward draws from them and moves them on
+        self.perm = self.perm_pos = self.step_dev = None
+
+    def begin_epoch(self):
+        """In-launch mode: a fresh permutation of the edge list (the same one __iter__ would draw), read position 0.
+        The batches the fused forward then draws are exactly those __iter__ yields for this epoch."""
+        E = self.edges.shape[0]
+        if self.perm is None:
+            self.perm = torch.empty(E, dtype=torch.int64, device=self.device)
+            self.perm_pos = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self.step_dev = torch.full((1,), self.global_step, dtype=torch.int64, device=self.device)
+        self.perm.copy_(torch.randperm(E, device=self.device, generator=self.gen))
+        self.perm_pos.zero_()
+
+    def drawn_loss_fn(self, model):
+        """loss of the next full batch, drawn inside the fused BPR forward (capturable, no arguments)."""
+        return lambda: model.loss_drawn(self.edges, self.batch_size, self.seed, 0, step_dev=self.step_dev,
+                                        advance=True, perm=self.perm, perm_pos=self.perm_pos)
 
     def __len__(self):
         return (self.edges.shape[0] + self.batch_size - 1) // self.batch_size

@@ -185,8 +185,8 @@ class _BPRDrawn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tab_u, tab_i, edges, hist_rowptr, hist_col, B, num_user, num_item, seed, step, step_dev, variant,
-                reg_weight, item_offset, advance):
-        _need_cuda(tab_u, tab_i, edges, hist_rowptr, hist_col, step_dev)
+                reg_weight, item_offset, advance, perm, perm_pos):
+        _need_cuda(tab_u, tab_i, edges, hist_rowptr, hist_col, step_dev, perm, perm_pos)
         tab_u = _f32c(tab_u)
         D = tab_u.shape[1]
         if tab_i is None:
@@ -205,7 +205,8 @@ class _BPRDrawn(torch.autograd.Function):
                                                    _ptr(hist_col), num_user, num_item, int(seed) & (2**64 - 1),
                                                    int(step), _ptr(step_dev), B, D, variant, reg_weight, _ptr(users),
                                                    _ptr(pos), _ptr(neg), _ptr(out), _ptr(loss), _ptr(coef), _ptr(ws),
-                                                   _ptr(step_dev if advance else None), _stream())
+                                                   _ptr(step_dev if advance else None), _ptr(perm), _ptr(perm_pos),
+                                                   _stream())
         _lib.check(rc, "chaorec_bpr_fwd_drawn_f32")
         ctx.save_for_backward(tab_u, tab_i, users, pos, neg, coef)
         ctx.reg_weight, ctx.item_offset = reg_weight, item_offset
@@ -215,16 +216,18 @@ class _BPRDrawn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *_unused):
-        return _BPR.backward(ctx, g_loss, None)[:2] + (None,) * 13
+        return _BPR.backward(ctx, g_loss, None)[:2] + (None,) * 15
 
 
 def bpr_loss_drawn(tab_u, tab_i, edges, hist, B, num_user, num_item, seed, step, variant, reg_weight=0.0,
-                   item_offset=0, step_dev=None, advance=False):
+                   item_offset=0, step_dev=None, advance=False, perm=None, perm_pos=None):
     """Fused batch draw + BPR(+L2): ([total, bpr, reg], users, pos, neg); differentiate [0][0].  advance=True: the
-    launch also moves the device counter `step_dev` on by one (after the draw), for captured steps."""
+    launch also moves the device counter `step_dev` on by one (after the draw), for captured steps.  perm / perm_pos
+    (int64 device tensors): take the edges from an epoch permutation at position *perm_pos (advanced by B too)."""
     loss, parts, users, pos, neg = _BPRDrawn.apply(tab_u, tab_i, edges, hist[0], hist[1], int(B), int(num_user),
                                                    int(num_item), seed, step, step_dev, int(variant),
-                                                   float(reg_weight), int(item_offset), bool(advance and step_dev is not None))
+                                                   float(reg_weight), int(item_offset),
+                                                   bool(advance and step_dev is not None), perm, perm_pos)
     return _LossParts(loss, parts), users, pos, neg
 
 

@@ -14,9 +14,34 @@ MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM", "LayerGCN")     # reference train_and_evaluate.py:555
 
 
+def _train_epoch_in_launch(model, loader, optimizer, graphed):
+    """One epoch with the batches drawn INSIDE the fused BPR forward (models with loss_drawn): the loader only lays
+    down the epoch's permutation; every full batch is one argument-less graph replay, the short last batch (the
+    reference's DataLoader keeps it, drop_last=False) one eager step on the same counters."""
+    loader.begin_epoch()
+    E, B = loader.edges.shape[0], loader.batch_size
+    sum_loss = None
+    for _ in range(E // B):
+        d = graphed()
+        sum_loss = d.clone() if sum_loss is None else sum_loss.add_(d)
+    tail = E - (E // B) * B
+    if tail:
+        optimizer.zero_grad()
+        loss = model.loss_drawn(loader.edges, tail, loader.seed, 0, step_dev=loader.step_dev, advance=True,
+                                perm=loader.perm, perm_pos=loader.perm_pos)
+        loss.backward()
+        optimizer.step()
+        d = loss.detach()
+        sum_loss = d.clone() if sum_loss is None else sum_loss.add_(d)
+    loader.global_step += len(loader)
+    return float(sum_loss.item()) if sum_loss is not None else 0.0
+
+
 def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):
     """One epoch.  `graphed` (optim.GraphedTrainStep) replays the captured step for full-size batches."""
     model.train()
+    if graphed is not None and getattr(graphed, "draws_in_launch", False):
+        return _train_epoch_in_launch(model, train_loader, optimizer, graphed)
     sum_loss = None
     for batch in train_loader:
         if graphed is not None:
@@ -60,6 +85,12 @@ def _capture_step(model, train_loader, optimizer, model_name):
         return None          # a graph that is re-allocated every epoch cannot sit behind captured addresses
     if len(train_loader) < 2:
         return None
+    if hasattr(model, "loss_drawn") and model_name not in MMGCN_STYLE and model_name not in PRE_EPOCH:
+        # the batch is drawn by the fused BPR forward itself: a replay takes no inputs at all
+        train_loader.begin_epoch()
+        g = GraphedTrainStep(model, optimizer, batch_fn=lambda: (), loss_fn=train_loader.drawn_loss_fn(model))
+        g.draws_in_launch = True
+        return g
     example = next(iter(train_loader))
     return GraphedTrainStep(model, optimizer, example_batch=example)
 

@@ -155,13 +155,16 @@ int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *his
  * ids (LOCAL item ids; the backward launch chaorec_bpr_bwd_f32 takes them).  Everything else as chaorec_bpr_fwd_f32;
  * results are bit-identical to the two-call form.  advance (optional, may be step_dev itself): a device counter that
  * the single-block finalize launch increments by one after the draw, so a captured step needs no separate
- * counter kernel. */
+ * counter kernel.  perm / perm_pos (optional): draw the training edges from an epoch permutation instead -- sample b
+ * takes edge perm[*perm_pos + b] (DataLoader(shuffle=True): every edge once per epoch; negatives as above); with
+ * `advance` set, *perm_pos moves on by B in the finalize launch. */
 int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
                               const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
                               int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
                               int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
                               int64_t *out_pos, int64_t *out_neg, float *out_loss, float *out_total,
-                              float *coef, float *workspace, int64_t *advance, void *stream);
+                              float *coef, float *workspace, int64_t *advance, const int64_t *perm,
+                              int64_t *perm_pos, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * R: all-items scoring + history mask + top-K, never materialising the [U, I] matrix.

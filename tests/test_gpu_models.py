@@ -457,3 +457,47 @@ def test_layergcn_golden(dev):
     m.pre_epoch_processing()
     assert m.masked_adj.col.data_ptr() == ptr and not torch.equal(a, m.masked_adj.col)
     assert m.masked_adj.nnz == 2 * int(len(g["edges"]) * (1 - float(g["dropout"])))
+
+
+def test_in_launch_batches_equal_the_samplers(dev):
+    """The training loop's in-launch mode (LightGCN: the fused BPR forward draws from the epoch permutation) sees
+    exactly the batches DeviceBatchSampler.__iter__ yields for the same seed: same users, positives, negatives, in the
+    same order, including the short last batch; and one epoch of it equals one epoch over the sampler's tensors."""
+    from chaorec_amd import graph, dataload
+    from chaorec_amd import train_and_evaluate as tae
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B = 1500, 900, 10300, 1024            # 10 full batches + a tail of 60
+    edges = synthetic_interactions(U, I, E, seed=5)
+    uid = graph.user_item_dict_from_edges(edges)
+
+    def make():
+        torch.manual_seed(1)
+        m = LightGCN(U, I, edges, uid, 64, 1e-3, 2, "add", dev).to(dev)
+        return m, FusedAdam(m.parameters(), lr=1e-3), dataload.DeviceBatchSampler(U, I, uid, edges, B, dev, "LightGCN", 7)
+
+    ma, oa, la = make()
+    want = [tuple(t.clone() for t in b) for b in la]                      # epoch 0 as tensors
+    mb, ob, lb = make()
+    lb.begin_epoch()
+    got = []
+    for k in range(len(lb)):
+        nb = min(B, E - k * B)
+        mb.loss_drawn(lb.edges, nb, lb.seed, 0, step_dev=lb.step_dev, advance=True, perm=lb.perm, perm_pos=lb.perm_pos)
+        got.append(tuple(t.clone() for t in mb.batch))
+    for k, (w, g_) in enumerate(zip(want, got)):
+        assert torch.equal(w[0], g_[0]) and torch.equal(w[1] - U, g_[1]) and torch.equal(w[2] - U, g_[2]), k
+    # a whole epoch through train(): captured in-launch steps vs eager steps over the sampler's batches
+    mc, oc, lc = make()
+    md, od, ld = make()
+    graphed = tae._capture_step(md, ld, od, "LightGCN")
+    assert getattr(graphed, "draws_in_launch", False)
+    ld.gen.manual_seed(7)                                                  # (the capture drew a permutation of its own)
+    ld.global_step = 0
+    ld.step_dev.zero_()
+    loss_c = tae.train(mc, lc, oc, "LightGCN", None)
+    loss_d = tae.train(md, ld, od, "LightGCN", graphed)
+    assert loss_d == pytest.approx(loss_c, rel=1e-5)
+    for (n, a), (_, b2) in zip(mc.named_parameters(), md.named_parameters()):
+        assert torch.allclose(a, b2, rtol=1e-4, atol=1e-6), n
