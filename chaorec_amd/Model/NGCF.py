@@ -120,6 +120,15 @@ class NGCF(nn.Module):
     def loss_local(self, users, pos_items, neg_items):
         return self._fused(users, pos_items, neg_items, self.forward())[0]
 
+    def loss_drawn(self, edges, B, seed, step, step_dev=None, advance=False, perm=None, perm_pos=None):
+        """loss_local() with the batch drawn inside the fused BPR forward (see LightGCN.loss_drawn)."""
+        out, users, pos, neg = ops.bpr_loss_drawn(self.forward(), None, edges, self.hist, B, self.num_user,
+                                                  self.num_item, seed, step, ops.VARIANT_LOG_SIGMOID_EPS,
+                                                  self.reg_weight, item_offset=self.num_user, step_dev=step_dev,
+                                                  advance=advance, perm=perm, perm_pos=perm_pos)
+        self.batch = (users, pos, neg)
+        return out[0]
+
     def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/NGCF.py:170-195 (mask value 1e-6)."""
         return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu)
