@@ -33,13 +33,40 @@ def synthetic_features(num_item, dataset, seed=0):
     return torch.randn(num_item, dv, generator=g), torch.randn(num_item, dt, generator=g)
 
 
+FIXTURE_DIR = os.environ.get("CHAOREC_DATA_DIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                              "tests", "golden"))
+
+
+def packed_interactions(dataset, fixture_dir=None):
+    """The reference's Data/<dataset>/{train,val,test}.npy as shipped with this repository: one
+    <dataset>_interactions.npz (train int32 [E,2] with GLOBAL item ids; val/test rows [user, pos...] flattened with
+    offsets), written by tests/golden/gen_golden.py / gen_fullsize.py from the reference's files.  None if absent."""
+    path = os.path.join(fixture_dir or FIXTURE_DIR, f"{dataset}_interactions.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path, allow_pickle=False)
+    vf, vo, tf, to = g["val_flat"], g["val_off"], g["test_flat"], g["test_off"]
+    return dict(num_user=int(g["U"]), num_item=int(g["I"]), train=g["train"],
+                val=[vf[vo[i]:vo[i + 1]].tolist() for i in range(len(vo) - 1)],
+                test=[tf[to[i]:to[i + 1]].tolist() for i in range(len(to) - 1)])
+
+
 def data_load(dataset, has_v=True, has_t=True, data_root='./Data', synthetic=False):
-    """-> train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat (dataload.py:21-58)."""
+    """-> train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat (dataload.py:21-58).
+    Interactions come from <data_root>/<dataset>/*.npy (the reference's layout) or, failing that, from the packed copy
+    of the same files shipped under tests/golden/ (packed_interactions)."""
     num_user, num_item = DATASET_SIZES[dataset]
     dir_str = os.path.join(data_root, dataset)
-    if synthetic or not os.path.exists(os.path.join(dir_str, 'train.npy')):
+    packed = None
+    if not synthetic and not os.path.exists(os.path.join(dir_str, 'train.npy')):
+        packed = packed_interactions(dataset)
+    if packed is not None:
+        train_data, val_data, test_data = packed["train"], packed["val"], packed["test"]
+        user_item_dict = graph.user_item_dict_from_edges(train_data)
+    elif synthetic or not os.path.exists(os.path.join(dir_str, 'train.npy')):
         if not synthetic:
-            raise FileNotFoundError(f"{dir_str}/train.npy not found (pass --synthetic for a generated graph)")
+            raise FileNotFoundError(f"{dir_str}/train.npy not found and no packed copy under {FIXTURE_DIR} "
+                                    f"(pass --synthetic for a generated graph)")
         _, _, E = DATASET_SHAPES[dataset]
         train_data = synthetic_interactions(num_user, num_item, E, seed=42)
         val_data = synthetic_eval_lists(num_user, num_item, train_data, 1, seed=7)

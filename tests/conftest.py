@@ -35,13 +35,23 @@ def oracle():
     return o
 
 
+_INTERACTIONS = {}
+
+
+def load_interactions(name):
+    """The reference's Data/<name>/{train,val,test}.npy as packed by tests/golden/gen_golden.py / gen_fullsize.py."""
+    if name not in _INTERACTIONS:
+        g = load_golden(f"{name}_interactions.npz")
+        vf, vo, tf, to = g["val_flat"], g["val_off"], g["test_flat"], g["test_off"]   # NpzFile re-reads on every access
+        val = [vf[vo[i]:vo[i + 1]].tolist() for i in range(len(vo) - 1)]
+        test = [tf[to[i]:to[i + 1]].tolist() for i in range(len(to) - 1)]
+        _INTERACTIONS[name] = dict(U=int(g["U"]), I=int(g["I"]), train=g["train"], val=val, test=test)
+    return _INTERACTIONS[name]
+
+
 @pytest.fixture(scope="session")
 def baby():
-    g = load_golden("baby_interactions.npz")
-    vf, vo, tf, to = g["val_flat"], g["val_off"], g["test_flat"], g["test_off"]   # NpzFile re-reads on every access
-    val = [vf[vo[i]:vo[i + 1]].tolist() for i in range(len(vo) - 1)]
-    test = [tf[to[i]:to[i + 1]].tolist() for i in range(len(to) - 1)]
-    return dict(U=int(g["U"]), I=int(g["I"]), train=g["train"], val=val, test=test)
+    return load_interactions("baby")
 
 
 def tie_aware_rank_equal(idx_a, val_a, idx_b, val_b, rtol=0.0, atol=0.0):

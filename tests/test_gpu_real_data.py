@@ -1,0 +1,224 @@
+"""BASELINE.json configs[1..3] on the REAL interaction files against outputs of the reference's own classes
+(tests/golden/gen_fullsize.py), through the product classes and the C-ABI kernels, plus the training-trajectory
+golden of SURVEY 8(a) row L.  Weights / synthetic features are functions of a torch CPU seed: the tests first check
+stored sample rows of them, then compare what the reference computed from them."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_interactions, tie_aware_rank_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from chaorec_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _device_metrics(model, d, g, rank_dev):
+    from chaorec_amd.utils import EvalLists, gene_metrics_device
+    k_list = [int(k) for k in g["k_list"]]
+    out = {}
+    for split in ("val", "test"):
+        m = gene_metrics_device(EvalLists(d[split], model.device), rank_dev, k_list)
+        out[split] = np.array([[m[k][n] for n in g["metric_names"]] for k in k_list])
+    return out
+
+
+def _check_rank_and_metrics(model, d, g, mask, rtol=2e-5, atol=1e-9):
+    U = d["U"]
+    rank_dev = model.gene_ranklist(to_cpu=False)
+    rank = rank_dev.cpu().numpy()
+    assert rank.shape == (U, 50) and rank.min() >= U and rank.max() < U + d["I"]
+    urows = g["urows"]
+    res = model.result.detach().cpu().numpy().astype(np.float64)
+    mine = rank[urows]
+    # values of my list in the masked score row (fp64 restatement of the same row: tie groups are what matters)
+    hist = {}
+    for u, i in d["train"].tolist():
+        hist.setdefault(u, set()).add(i)
+
+    def vals(idx):
+        v = np.einsum("ud,ukd->uk", res[:U][urows], res[idx])
+        for r, u in enumerate(urows):
+            h = hist.get(int(u), ())
+            v[r, [k for k in range(idx.shape[1]) if int(idx[r, k]) in h]] = mask
+        return v
+
+    ok, why = tie_aware_rank_equal(mine, vals(mine), g["rank_rows"].astype(np.int64), vals(g["rank_rows"].astype(np.int64)),
+                                   rtol=rtol, atol=atol)
+    assert ok, why
+    got = _device_metrics(model, d, g, rank_dev)
+    # north_star: within 1e-4 on Recall / NDCG (all five metrics, all three cut-offs, both splits)
+    assert np.abs(got["val"] - g["val_metrics"]).max() < 1e-4
+    assert np.abs(got["test"] - g["test_metrics"]).max() < 1e-4
+
+
+def test_lightgcn_sports_real_graph_vs_reference(dev):
+    """configs[1]: LightGCN on Data/sports, dim 64, 3 layers, batch 1024."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import LightGCN
+    g = load_golden("lightgcn_sports.npz")
+    d = load_interactions("sports")
+    U, I, D, L = d["U"], d["I"], int(g["D"]), int(g["L"])
+    torch.manual_seed(int(g["init_seed"]))
+    m = LightGCN(U, I, d["train"], graph.user_item_dict_from_edges(d["train"]), D, float(g["reg"]), L, "add", dev).to(dev)
+    rows = g["rows"]
+    x0 = torch.cat((m.user_embedding.weight, m.item_embedding.weight), 0).detach().cpu().numpy()
+    assert np.array_equal(x0[rows], g["x0_rows"])                      # same seed => same weights
+    loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    loss.backward()
+    res = m.result.detach().cpu().numpy()
+    assert np.array_equal(res[rows], g["result_rows"])                 # ordered SpMM == scatter_add_, bit for bit
+    assert res.astype(np.float64).sum() == pytest.approx(float(g["result_sum"]), rel=1e-9)
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-6)
+    grad = torch.cat((m.user_embedding.weight.grad, m.item_embedding.weight.grad), 0).cpu().numpy()
+    assert np.allclose(grad[rows], g["g_rows"], rtol=2e-4, atol=1e-10)
+    assert np.abs(grad.astype(np.float64)).sum() == pytest.approx(float(g["g_abs_sum"]), rel=1e-4)
+    _check_rank_and_metrics(m, d, g, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["baby", "sports"])
+@pytest.mark.parametrize("captured", [True, False])
+def test_training_trajectory_vs_reference(dev, name, captured):
+    """Row L: T reference training iterations (zero_grad, loss, backward, Adam lr 1e-3) on fixed batches, then the
+    evaluation on the stale result, replayed through GraphedTrainStep + FusedAdam (captured hipGraph) or eagerly."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    g = load_golden(f"lightgcn_trajectory_{name}.npz")
+    d = load_interactions(name)
+    U, I, D, L, T = d["U"], d["I"], int(g["D"]), int(g["L"]), int(g["T"])
+    torch.manual_seed(int(g["init_seed"]))
+    m = LightGCN(U, I, d["train"], graph.user_item_dict_from_edges(d["train"]), D, float(g["reg"]), L, "add", dev).to(dev)
+    opt = FusedAdam([{"params": m.parameters(), "lr": float(g["lr"])}])
+    batches = [tuple(torch.from_numpy(g["batches"][t, k].astype(np.int64)).to(dev) for k in range(3)) for t in range(T)]
+    step = GraphedTrainStep(m, opt, example_batch=batches[0]) if captured else None
+    for t, b in enumerate(batches):
+        if captured:
+            loss = step(*b)
+        else:
+            opt.zero_grad()
+            loss = m.loss(*b)
+            loss.backward()
+            opt.step()
+        assert float(loss.detach()) == pytest.approx(float(g["losses"][t]), rel=5e-6), t
+    if captured:
+        assert step.replays == T
+    rows = g["rows"]
+    w = torch.cat((m.user_embedding.weight, m.item_embedding.weight), 0).detach().cpu().numpy()
+    # (an entry whose gradient is ~1e-8 sits on the knee of Adam's g / (sqrt(v) + 1e-8): a 1e-4 relative difference
+    #  in g moves it visibly; everything else agrees to the last digits)
+    assert np.allclose(w[rows], g["weight_rows"], rtol=0, atol=2e-5)
+    assert np.abs(w[rows] - g["weight_rows"]).mean() < 2e-7
+    assert np.allclose(m.result.detach().cpu().numpy()[rows], g["result_rows"], rtol=0, atol=1e-5)
+    _check_rank_and_metrics(m, d, g, 1e-6, rtol=1e-4, atol=1e-8)
+
+
+def test_freedom_clothing_real_graph_vs_reference(dev):
+    """configs[2]: FREEDOM on Data/clothing, 4096-d visual / 384-d textual features (synthetic), the
+    reference's own kept-edge draw as the pruning input."""
+    from chaorec_amd import dataload, graph
+    from chaorec_amd.Model import FREEDOM
+    g = load_golden("freedom_clothing.npz")
+    d = load_interactions("clothing")
+    U, I, D = d["U"], d["I"], int(g["D"])
+    v_feat, t_feat = dataload.synthetic_features(I, "clothing", seed=int(g["feat_seed"]))
+    assert v_feat.shape == (I, int(g["dv"])) and t_feat.shape == (I, int(g["dt"]))
+    assert float(v_feat.double().sum()) == pytest.approx(float(g["v_feat_sum"]), rel=1e-12)
+    assert float(t_feat.double().sum()) == pytest.approx(float(g["t_feat_sum"]), rel=1e-12)
+    torch.manual_seed(int(g["init_seed"]))
+    m = FREEDOM(U, I, d["train"], graph.user_item_dict_from_edges(d["train"]), v_feat, t_feat, D, D, float(g["reg"]),
+                float(g["dropout"]), int(g["L"]), int(g["mm_layers"]), int(g["knn"]), float(g["w"]), dev).to(dev)
+    rows = g["rows"]
+    x0 = torch.cat((m.user_embedding.weight, m.item_embedding.weight), 0).detach().cpu().numpy()
+    assert np.array_equal(x0[rows], g["x0_rows"])
+    assert np.array_equal(m.image_trs.weight.detach().cpu().numpy()[:4, :64], g["image_trs_w_rows"])
+    assert float(m.text_trs.weight.double().sum()) == pytest.approx(float(g["text_trs_w_sum"]), rel=1e-9)
+    assert float(m.edge_values.double().sum()) == pytest.approx(float(g["edge_values_sum"]), rel=1e-9)
+    # item-item kNN graph (P10): same neighbours, same weights on 256 stored rows; same size and mass overall
+    mm = m.mm_adj
+    assert mm.nnz == int(g["mm_nnz"])
+    assert float(mm.val.double().sum()) == pytest.approx(float(g["mm_val_sum"]), rel=1e-6)
+    rp, col, val = mm.rowptr.cpu().numpy(), mm.col.cpu().numpy(), mm.val.cpu().numpy()
+    ref_idx, ref_val = g["mm_idx"], g["mm_val"]
+    for r in g["mm_rows"]:
+        sel = ref_idx[0] == r
+        assert np.array_equal(col[rp[r]:rp[r + 1]], ref_idx[1][sel]), r
+        assert np.allclose(val[rp[r]:rp[r + 1]], ref_val[sel], rtol=1e-6), r
+    # pruning (P11) with the reference's kept set
+    keep = np.unpackbits(g["keep_bits"])[:len(d["train"])].astype(bool)
+    m._set_masked_adj(m.edge_indices[:, torch.from_numpy(keep).to(m.edge_indices.device)])
+    assert m.masked_adj.nnz == int(g["masked_nnz"])
+    assert float(m.masked_adj.val.double().sum()) == pytest.approx(float(g["masked_val_sum"]), rel=1e-6)
+    loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    loss.backward()
+    res = m.result.detach().cpu().numpy()
+    assert np.allclose(res[rows], g["result_rows"], rtol=1e-5, atol=1e-7)
+    assert res.astype(np.float64).sum() == pytest.approx(float(g["result_sum"]), rel=1e-6)
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    grad = torch.cat((m.user_embedding.weight.grad, m.item_embedding.weight.grad), 0).cpu().numpy()
+    assert np.allclose(grad[rows], g["g_rows"], rtol=2e-4, atol=1e-10)
+    assert np.abs(grad.astype(np.float64)).sum() == pytest.approx(float(g["g_abs_sum"]), rel=1e-4)
+    cols_v = np.arange(0, int(g["dv"]), 16)
+    gw = m.image_trs.weight.grad.cpu().numpy()
+    scale = float(np.abs(g["g_image_trs_w_cols"]).max())
+    assert np.abs(gw[:, cols_v] - g["g_image_trs_w_cols"]).max() <= 2e-4 * scale
+    assert np.abs(gw.astype(np.float64)).sum() == pytest.approx(float(g["g_image_trs_w_abs_sum"]), rel=1e-4)
+    gt = m.text_trs.weight.grad.cpu().numpy()
+    assert np.abs(gt - g["g_text_trs_w"]).max() <= 2e-4 * float(np.abs(g["g_text_trs_w"]).max())
+    # (the trs biases get +c for the positive and -c for the negative row of every sample: analytically zero)
+    for name, p in (("g_image_trs_b", m.image_trs.bias), ("g_text_trs_b", m.text_trs.bias)):
+        assert np.abs(p.grad.cpu().numpy() - g[name]).max() <= 1e-7, name
+    pos16 = (g["pos"] - U)[:16]
+    assert np.allclose(m.image_embedding.weight.grad.cpu().numpy()[pos16][:, cols_v], g["g_image_emb_rows"],
+                       rtol=2e-4, atol=1e-10)
+    assert np.allclose(m.text_embedding.weight.grad.cpu().numpy()[pos16], g["g_text_emb_rows"], rtol=2e-4, atol=1e-10)
+    assert float(m.image_embedding.weight.grad.double().abs().sum()) == pytest.approx(float(g["g_image_emb_abs_sum"]), rel=1e-4)
+    _check_rank_and_metrics(m, d, g, 1e-6, rtol=1e-4, atol=1e-8)
+
+
+def test_mmgcn_microlens_real_graph_vs_reference(dev):
+    """configs[3], single-GPU half: MMGCN on Data/microlens, 128-d visual / 768-d textual synthetic features."""
+    from chaorec_amd import dataload, graph
+    from chaorec_amd.Model import MMGCN
+    g = load_golden("mmgcn_microlens.npz")
+    d = load_interactions("microlens")
+    U, I = d["U"], d["I"]
+    v_feat, t_feat = dataload.synthetic_features(I, "microlens", seed=int(g["feat_seed"]))
+    assert v_feat.shape == (I, int(g["dv"])) and t_feat.shape == (I, int(g["dt"]))
+    torch.manual_seed(int(g["init_seed"]))
+    m = MMGCN(U, I, d["train"], graph.user_item_dict_from_edges(d["train"]), v_feat, t_feat, int(g["dim_x"]),
+              float(g["reg"]), "add", "False", True, dev).to(dev)
+    names = [str(n) for n in g["param_names"]]
+    assert [n for n, _ in m.named_parameters()] == names and len(names) == 50       # Q2
+    # the constructor's random state (parameters AND the non-parameter tables of Q2) equals the reference's
+    rows, prows = g["rows"], g["prows"]
+    assert np.array_equal(m.v_gcn.preference.cpu().numpy()[prows], g["v_pref_rows"])
+    assert np.array_equal(m.t_gcn.preference.cpu().numpy()[prows], g["t_pref_rows"])
+    assert np.array_equal(m.id_embedding.cpu().numpy()[rows], g["id_rows"])
+    for n, p in m.named_parameters():
+        assert float(p.double().sum()) == pytest.approx(float(g["psum_" + n]), rel=1e-9, abs=1e-12), n
+    loss = m.loss(torch.from_numpy(g["user_tensor"]), torch.from_numpy(g["item_tensor"]))
+    loss.backward()
+    res = m.result.detach().cpu().numpy()
+    scale = float(np.abs(g["result_rows"]).max())
+    assert np.abs(res[rows] - g["result_rows"]).max() <= 2e-4 * scale
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-5)
+    worst = 0.0
+    for n, p in m.named_parameters():
+        ref = g["g_" + n]
+        mine = p.grad.cpu().numpy()
+        mine_part = mine if ref.shape == mine.shape else mine[:ref.shape[0]]
+        s = float(np.abs(ref).max()) + 1e-30
+        err = float(np.abs(mine_part - ref).max()) / s
+        worst = max(worst, err)
+        assert err <= 1e-3, (n, err)
+        assert np.abs(mine.astype(np.float64)).sum() == pytest.approx(float(g["gsum_" + n]), rel=1e-3), n
+    print(f"MMGCN/microlens: worst gradient error relative to the tensor's max {worst:.2e}")
+    _check_rank_and_metrics(m, d, g, 1e-5, rtol=1e-3, atol=1e-7)
