@@ -230,6 +230,13 @@ def gen_freedom_clothing():
     mm = m.mm_adj.coalesce()
     mm_rows = np.sort(np.random.default_rng(13).choice(I, 256, replace=False))
     sel = np.isin(mm.indices()[0].numpy(), mm_rows)
+    # the whole item-item graph: every row has ii_topk neighbours per modality (self included) and every degree is
+    # ii_topk, so an entry takes one of three values (image only / text only / both): columns + a code per entry
+    mm_r, mm_c, mm_v = mm.indices()[0].numpy(), mm.indices()[1].numpy(), mm.values().numpy()
+    levels = np.unique(mm_v)
+    assert len(levels) == 3 and I < 32768, levels
+    mm_counts = np.bincount(mm_r, minlength=I)
+    assert mm_counts.max() < 256 and np.all(np.diff(mm_r) >= 0)
     masked = m.masked_adj.coalesce()
     rng = np.random.default_rng(14)
     rows = np.sort(rng.choice(U + I, 512, replace=False))
@@ -247,6 +254,8 @@ def gen_freedom_clothing():
         v_feat_sum=np.float64(v_feat.double().sum().item()), t_feat_sum=np.float64(t_feat.double().sum().item()),
         mm_rows=mm_rows, mm_idx=mm.indices().numpy()[:, sel].astype(np.int32), mm_val=mm.values().numpy()[sel],
         mm_nnz=np.int64(mm.values().numel()), mm_val_sum=np.float64(mm.values().double().sum().item()),
+        mm_counts=mm_counts.astype(np.uint8), mm_cols=mm_c.astype(np.int16), mm_levels=levels,
+        mm_code=np.searchsorted(levels, mm_v).astype(np.uint8),
         masked_nnz=np.int64(masked.values().numel()), masked_val_sum=np.float64(masked.values().double().sum().item()),
         edge_values_sum=np.float64(m.edge_values.double().sum().item()),
         result_rows=sample_rows(m.result, rows), result_sum=np.float64(m.result.double().sum().item()),

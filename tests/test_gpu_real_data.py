@@ -141,16 +141,46 @@ def test_freedom_clothing_real_graph_vs_reference(dev):
     assert np.array_equal(m.image_trs.weight.detach().cpu().numpy()[:4, :64], g["image_trs_w_rows"])
     assert float(m.text_trs.weight.double().sum()) == pytest.approx(float(g["text_trs_w_sum"]), rel=1e-9)
     assert float(m.edge_values.double().sum()) == pytest.approx(float(g["edge_values_sum"]), rel=1e-9)
-    # item-item kNN graph (P10): same neighbours, same weights on 256 stored rows; same size and mass overall
+    # item-item kNN graph (P10).  A 4096-term fp32 dot product has ~1e-7 of summation-order noise and the 10th / 11th
+    # neighbour of an item are ~1e-3 apart in cosine on average: a handful of the 11 384 items have a 10th neighbour
+    # that depends on the BLAS blocking (expected ~3).  Every differing row must be such a near-tie (checked in
+    # fp64); the values of the stored sample rows must agree; then the REFERENCE's graph is installed, so that
+    # everything downstream is compared on identical inputs (as with the kept-edge set of the pruning below).
     mm = m.mm_adj
-    assert mm.nnz == int(g["mm_nnz"])
-    assert float(mm.val.double().sum()) == pytest.approx(float(g["mm_val_sum"]), rel=1e-6)
-    rp, col, val = mm.rowptr.cpu().numpy(), mm.col.cpu().numpy(), mm.val.cpu().numpy()
+    rp, col, val = mm.rowptr.cpu().numpy(), mm.col.cpu().numpy().astype(np.int64), mm.val.cpu().numpy()
+    ref_rp = np.zeros(I + 1, np.int64)
+    np.cumsum(g["mm_counts"].astype(np.int64), out=ref_rp[1:])
+    ref_col = g["mm_cols"].astype(np.int64)
+    ref_val_all = g["mm_levels"][g["mm_code"]]
+    differ = [r for r in range(I) if not np.array_equal(col[rp[r]:rp[r + 1]], ref_col[ref_rp[r]:ref_rp[r + 1]])]
+    assert len(differ) <= 24, len(differ)
+    feats = [torch.nn.functional.normalize(f.double().to(dev), dim=-1) for f in (v_feat, t_feat)]
+    k = int(g["knn"])
+    for r in differ:
+        mine, ref = set(col[rp[r]:rp[r + 1]].tolist()), set(ref_col[ref_rp[r]:ref_rp[r + 1]].tolist())
+        for c in mine ^ ref:
+            gaps = []
+            for f in feats:
+                sim = f @ f[r]
+                kth = torch.topk(sim, k + 1).values
+                gaps.append(min(abs(float(sim[c] - kth[k - 1])), abs(float(sim[c] - kth[k]))))
+            assert min(gaps) < 2e-6, (r, c, gaps)          # c sits on the k-th / (k+1)-th boundary of a modality
+    same = np.setdiff1d(g["mm_rows"], differ)
     ref_idx, ref_val = g["mm_idx"], g["mm_val"]
-    for r in g["mm_rows"]:
+    for r in same:
         sel = ref_idx[0] == r
         assert np.array_equal(col[rp[r]:rp[r + 1]], ref_idx[1][sel]), r
         assert np.allclose(val[rp[r]:rp[r + 1]], ref_val[sel], rtol=1e-6), r
+    ok_rows = np.ones(I, bool)
+    ok_rows[differ] = False
+    ent_ok = np.repeat(ok_rows, rp[1:] - rp[:-1])
+    ref_ent_ok = np.repeat(ok_rows, ref_rp[1:] - ref_rp[:-1])
+    assert np.allclose(val[ent_ok], ref_val_all[ref_ent_ok], rtol=1e-6)
+    print(f"FREEDOM/clothing kNN graph: {len(differ)} of {I} rows differ from the reference's, all at fp32 near-ties")
+    m.mm_adj = graph.CSR(torch.from_numpy(ref_rp), torch.from_numpy(ref_col.astype(np.int32)),
+                         torch.from_numpy(ref_val_all.astype(np.float32)), I, I).to(dev)
+    assert m.mm_adj.nnz == int(g["mm_nnz"])
+    assert float(m.mm_adj.val.double().sum()) == pytest.approx(float(g["mm_val_sum"]), rel=1e-6)
     # pruning (P11) with the reference's kept set
     keep = np.unpackbits(g["keep_bits"])[:len(d["train"])].astype(bool)
     m._set_masked_adj(m.edge_indices[:, torch.from_numpy(keep).to(m.edge_indices.device)])
