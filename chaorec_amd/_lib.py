@@ -16,6 +16,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
+ABI_VERSION = 4
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -27,6 +28,18 @@ SIGNATURES = {
     "chaorec_spmm_csr_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr, c_ptr,
                                             ctypes.c_float, c_ptr, ctypes.c_int32, c_ptr]),
+    "chaorec_spmm_csr_adam_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
+                                                 ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr,
+                                                 ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                 ctypes.c_int32, c_ptr]),
+    "chaorec_bpr_fwd_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64,
+                                               ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr,
+                                               c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                               c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "chaorec_bpr_finalize_f32": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr,
+                                                c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr,
+                                                c_ptr]),
     "chaorec_spmm_rows_per_wave": (ctypes.c_int, [ctypes.c_int32]),
     "chaorec_spmm_schedule_len": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32]),
     "chaorec_spmm_build_schedule": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr,
@@ -80,17 +93,37 @@ SIGNATURES = {
 
 
 def build(force=False, verbose=False):
-    """Cross-compile the HIP kernels for gfx950 into csrc/libchaorec_hip.so (no GPU needed)."""
+    """Cross-compile the HIP kernels for gfx950 into csrc/libchaorec_hip.so (no GPU needed): one object per source
+    file (compiled in parallel, re-compiled only when the file or a header changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".h", ".hpp"))]
-    deps += [os.path.join(os.path.dirname(_CSRC), "..", "include", "chaorec_hip.h"), os.path.abspath(__file__)]
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    hdrs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".h", ".hpp"))]
+    hdrs += [os.path.join(os.path.dirname(_CSRC), "..", "include", "chaorec_hip.h"), os.path.abspath(__file__)]
+    extra = os.environ.get("CHAOREC_EXTRA_HIPCC_FLAGS", "").split()
+    if not force and not extra and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + hdrs):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("CHAOREC_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB_PATH] + srcs
+    objdir = os.path.join(_CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if (not force and not extra and os.path.exists(obj)
+                and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
+            return obj
+        cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB_PATH
 
@@ -117,7 +150,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
-    if lib.chaorec_abi_version() != 3:
+    if lib.chaorec_abi_version() != ABI_VERSION:
         raise RuntimeError("libchaorec_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -17,9 +17,9 @@ namespace chaorec {
 __device__ __forceinline__ float sigmoidf_acc(float d) { return 1.0f / (1.0f + expf(-d)); }
 
 // the wave of triple b: three row gathers, five wave butterflies, lane 0 writes the term / coefficient / L2 parts
-__device__ __forceinline__ void bpr_terms_wave(const float *__restrict__ tab_u, const float *__restrict__ tab_i,
-                                               int64_t iu, int64_t ip, int64_t in, int b, int B, int D, int variant,
-                                               float *__restrict__ coef, float *__restrict__ ws) {
+__device__ __forceinline__ float bpr_terms_wave(const float *__restrict__ tab_u, const float *__restrict__ tab_i,
+                                                int64_t iu, int64_t ip, int64_t in, int b, int B, int D, int variant,
+                                                float *__restrict__ coef, float *__restrict__ ws) {
   const int lane = threadIdx.x & 63;
   const float *pu = tab_u + (size_t)iu * D;
   const float *pp = tab_i + (size_t)ip * D;
@@ -38,10 +38,11 @@ __device__ __forceinline__ void bpr_terms_wave(const float *__restrict__ tab_u, 
   ru = wave_sum(ru);
   rp = wave_sum(rp);
   rn = wave_sum(rn);
+  float c = 0.f;
   if (lane == 0) {
     const float d = sp - sn;
     const float invB = 1.0f / (float)B;
-    float term, c;
+    float term;
     if (variant == CHAOREC_BPR_LOG_SIGMOID_EPS) {
       const float s = sigmoidf_acc(d);
       term = logf(s + 1e-5f);
@@ -61,6 +62,7 @@ __device__ __forceinline__ void bpr_terms_wave(const float *__restrict__ tab_u, 
     ws[2 * B + b] = rp;
     ws[3 * B + b] = rn;
   }
+  return __shfl(c, 0, 64);
 }
 
 __global__ __launch_bounds__(256) void bpr_fwd_terms_kernel(
@@ -107,13 +109,62 @@ __global__ __launch_bounds__(256) void bpr_fwd_terms_drawn_kernel(
   bpr_terms_wave(tab_u, tab_i, u, p, n, b, B, D, variant, coef, ws);
 }
 
+// Forward terms AND the backward's row updates in one launch, for a loss that is differentiated with d(loss) = 1
+// (a plain loss.backward()): the coefficient of sample b depends on its own score difference only, never on the
+// batch total, so the wave that just reduced the triple adds its three gradient rows right away -- the same
+// 256-B atomic row adds, the same values as bpr_bwd_kernel with grad_out = 1.  g_u / g_i must be zero where no
+// sample lands (the caller keeps such a buffer: see chaorec_spmm_csr_adam_f32's clear_z).
+__global__ __launch_bounds__(256) void bpr_fwd_bwd_drawn_kernel(
+    const float *__restrict__ tab_u, const float *__restrict__ tab_i, const int64_t *__restrict__ edges,
+    int64_t n_edges, const int64_t *__restrict__ hist_rowptr, const int32_t *__restrict__ hist_col, int64_t num_user,
+    uint32_t num_item, uint64_t seed, uint64_t step, const int64_t *__restrict__ step_dev,
+    const int64_t *__restrict__ in_users, const int64_t *__restrict__ in_pos, const int64_t *__restrict__ in_neg,
+    int64_t *__restrict__ out_users, int64_t *__restrict__ out_pos, int64_t *__restrict__ out_neg, int B, int D,
+    int variant, float reg_weight, float *__restrict__ coef, float *__restrict__ ws, const int64_t *__restrict__ perm,
+    const int64_t *__restrict__ perm_pos, float *g_u, float *g_i) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int64_t u = 0, p = 0, n = 0;
+  if (edges) {
+    if (step_dev) step += (uint64_t)step_dev[0];
+    if (lane == 0) {
+      draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n, perm,
+                  perm ? perm_pos[0] : 0);
+      out_users[b] = u;
+      out_pos[b] = p;
+      out_neg[b] = n;
+    }
+    u = __shfl(u, 0, 64);
+    p = __shfl(p, 0, 64);
+    n = __shfl(n, 0, 64);
+  } else {
+    u = in_users[b];
+    p = in_pos[b];
+    n = in_neg[b];
+  }
+  const float c = bpr_terms_wave(tab_u, tab_i, u, p, n, b, B, D, variant, coef, ws) * 1.0f;
+  const float r2 = 1.0f * 2.0f * reg_weight / ((float)B * (float)D);
+  const size_t ou = (size_t)u * D, op = (size_t)p * D, on = (size_t)n * D;
+  for (int k = lane; k < D; k += 64) {
+    const float uu = tab_u[ou + k], pp = tab_i[op + k], nn = tab_i[on + k];
+    atomicAdd(g_u + ou + k, c * (pp - nn) + r2 * uu);
+    atomicAdd(g_i + op + k, c * uu + r2 * pp);
+    atomicAdd(g_i + on + k, -c * uu + r2 * nn);
+  }
+}
+
 // One block, fixed order: thread t sums elements t, t+256, ... then a fixed LDS tree.
 __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__restrict__ ws, int B,
                                                                int D, float reg_weight,
                                                                float *__restrict__ out_loss,
                                                                float *__restrict__ out_total,
                                                                int64_t *__restrict__ advance,
-                                                               int64_t *__restrict__ advance_pos) {
+                                                               int64_t *__restrict__ advance_pos,
+                                                               float *__restrict__ loss_accum = nullptr,
+                                                               int32_t *__restrict__ adam_step = nullptr,
+                                                               float beta1 = 0.f, float beta2 = 0.f,
+                                                               float *__restrict__ adam_bc = nullptr) {
   __shared__ float red[4][256];
   const int t = threadIdx.x;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -143,6 +194,12 @@ __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__re
     // every wave of the terms launch has read the batch counter by now: move it on for the next step
     if (advance) advance[0] += 1;
     if (advance_pos) advance_pos[0] += B;       // the epoch permutation's read position
+    if (loss_accum) loss_accum[0] += bpr + reg;  // per-epoch loss bookkeeping (train_and_evaluate.py:48 without the sync)
+    if (adam_step) {                             // the optimizer's step count and this step's bias corrections
+      const int st = adam_step[0] + 1;
+      adam_step[0] = st;
+      adam_bias_corrections(st, beta1, beta2, adam_bc[0], adam_bc[1]);
+    }
   }
 }
 
@@ -212,7 +269,10 @@ __device__ __forceinline__ void draw_triple(const int64_t *__restrict__ edges, i
                                             int64_t perm_pos) {
   uint64_t idx;
   if (perm) {
-    idx = (uint64_t)perm[perm_pos + b];              // epoch permutation (DataLoader(shuffle=True)): every edge once
+    // epoch permutation (DataLoader(shuffle=True)): every edge once.  A read position past the end (a caller that
+    // draws more batches than the epoch holds) is clamped, never dereferenced.
+    const int64_t q = perm_pos + (int64_t)b;
+    idx = (uint64_t)perm[q < n_edges ? (q < 0 ? 0 : q) : n_edges - 1];
   } else {
     const uint64_t hsel = mix64(seed ^ mix64(step ^ mix64(0xED6E5ull ^ ((uint64_t)b << 32))));
     // 64x64 -> high 64 multiply-shift onto [0, n_edges)
@@ -309,6 +369,42 @@ extern "C" int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i,
   if (rc) return rc;
   hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, B, D, reg_weight, out_loss,
                      out_total, advance, (perm && advance) ? perm_pos : (int64_t *)nullptr);
+  return check_launch("bpr_fwd_finalize_kernel");
+}
+
+extern "C" int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
+                                       const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
+                                       int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
+                                       const int64_t *in_users, const int64_t *in_pos, const int64_t *in_neg,
+                                       int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
+                                       int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
+                                       const int64_t *perm, const int64_t *perm_pos, float *g_u, float *g_i,
+                                       void *stream) {
+  if (!tab_u || !tab_i || !coef || !workspace || !g_u || !g_i) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: NULL argument");
+  if (edges) {
+    if (!hist_rowptr || !out_users || !out_pos || !out_neg) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: NULL draw argument");
+    if (n_edges <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: bad sizes");
+    if (perm && !perm_pos) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: perm without perm_pos");
+  } else if (!in_users || !in_pos || !in_neg) {
+    return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: neither an edge list to draw from nor a batch");
+  }
+  if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: B=%d D=%d", B, D);
+  if (variant < 0 || variant > 2) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: variant %d", variant);
+  hipLaunchKernelGGL(bpr_fwd_bwd_drawn_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u, tab_i, edges,
+                     n_edges, hist_rowptr, hist_col, num_user, (uint32_t)num_item, seed, step, step_dev, in_users, in_pos,
+                     in_neg, out_users, out_pos, out_neg, B, D, variant, reg_weight, coef, workspace, perm, perm_pos, g_u,
+                     g_i);
+  return check_launch("bpr_fwd_bwd_drawn_kernel");
+}
+
+extern "C" int chaorec_bpr_finalize_f32(const float *workspace, int32_t B, int32_t D, float reg_weight, float *out_loss,
+                                        float *out_total, float *loss_accum, int64_t *advance, int64_t *perm_pos,
+                                        int32_t *adam_step, float beta1, float beta2, float *adam_bc, void *stream) {
+  if (!workspace || !out_loss) return fail(CHAOREC_E_INVALID, "bpr_finalize: NULL argument");
+  if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_finalize: B=%d D=%d", B, D);
+  if (adam_step && !adam_bc) return fail(CHAOREC_E_INVALID, "bpr_finalize: adam_step without adam_bc");
+  hipLaunchKernelGGL(bpr_fwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, B, D, reg_weight,
+                     out_loss, out_total, advance, perm_pos, loss_accum, adam_step, beta1, beta2, adam_bc);
   return check_launch("bpr_fwd_finalize_kernel");
 }
 

@@ -51,6 +51,26 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+// torch._single_tensor_adam on one element (main.py:397 defaults): exp_avg.lerp_(grad, 1-b1);
+// exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom.
+// Shared by adam_step_kernel and the SpMM kernel's Adam epilogue: same expression, same rounding.
+struct AdamConsts {
+  float lr, b1, b2, eps, wd;
+};
+__device__ __forceinline__ void adam_update(float &pi, float gi, float &mi, float &vi, const AdamConsts &c, float bc1,
+                                            float bc2_sqrt) {
+  if (c.wd != 0.f) gi = gi + c.wd * pi;
+  mi = mi + (gi - mi) * (1.0f - c.b1);
+  vi = vi * c.b2 + (1.0f - c.b2) * gi * gi;
+  const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
+  pi = pi - (c.lr / bc1) * (mi / denom);
+}
+// bias corrections in double, as torch does with python floats
+__device__ __forceinline__ void adam_bias_corrections(int step, float b1, float b2, float &bc1, float &bc2_sqrt) {
+  bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   // fixed butterfly order -> identical result on every lane and every run
 #pragma unroll

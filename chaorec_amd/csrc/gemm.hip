@@ -346,19 +346,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p,
   __shared__ float bc[2];
   if (threadIdx.x == 0) {
     const int step = step_dev ? step_dev[0] : step_host;
-    bc[0] = (float)(1.0 - pow((double)b1, (double)step));
-    bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    adam_bias_corrections(step, b1, b2, bc[0], bc[1]);
   }
   __syncthreads();
   const float bc1 = bc[0], bc2_sqrt = bc[1];
-  // torch._single_tensor_adam: exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-  auto upd = [&](float &pi, float gi, float &mi, float &vi) {
-    if (wd != 0.f) gi = gi + wd * pi;
-    mi = mi + (gi - mi) * (1.0f - b1);
-    vi = vi * b2 + (1.0f - b2) * gi * gi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    pi = pi - (lr / bc1) * (mi / denom);
-  };
+  const AdamConsts ac{lr, b1, b2, eps, wd};
+  auto upd = [&](float &pi, float gi, float &mi, float &vi) { adam_update(pi, gi, mi, vi, ac, bc1, bc2_sqrt); };
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (vec4) {   // 16-B accesses: the update streams 7 arrays, it is pure bandwidth

@@ -36,13 +36,26 @@ constexpr int kDescDwords = 16;  // 64-B descriptor: row, deg|flag, e0 lo/hi, 6 
 #define CHAOREC_SPMM_MINW 1
 #endif
 
-template <int LPR, int CPL>
+// Adam epilogue (ADAM instantiations): the row this group just produced is the GRADIENT of row r of a parameter
+// table -- the last backward propagate of a LightGCN step, g_0 = A^T g_1 + w G -- and the optimizer update of that
+// row (torch.optim.Adam, main.py:397) is applied right here: one launch and one pass over the gradient less per
+// step.  `bc` holds the step's two bias corrections (device memory: the step counter lives there too).  clear_z:
+// rows of z that were non-zero are zeroed after use (z = the batch gradient G, kept all-zero between steps
+// instead of being zero-filled every step; only legal when this launch does not GATHER from z).
+struct AdamEpi {
+  float *p, *m, *v;
+  const float *bc;
+  AdamConsts c;
+  int clear_z;
+};
+
+template <int LPR, int CPL, bool ADAM>
 __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, float *__restrict__ y,
-    int64_t n_rows, int D4, float alpha, const float *__restrict__ z, float beta,
+    int64_t n_rows, int D4, float alpha, const float *z, float beta,
     float *acc, const float *__restrict__ acc_init, float acc_w,
-    const int32_t *__restrict__ sched, int64_t n_groups, int dyn_val) {
+    const int32_t *__restrict__ sched, int64_t n_groups, int dyn_val, const AdamEpi ae) {
   constexpr int NG = kWave / LPR;   // lane groups = destination rows per wave
   constexpr int UNR = CHAOREC_SPMM_UNR;  // gathered rows in flight per group (short-row phase)
   constexpr int UNR2 = (kWave / NG) < 16 ? (kWave / NG) : 16;  // per group in the long-row phase
@@ -121,6 +134,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   const float4 *init4 = reinterpret_cast<const float4 *>(acc_init);
   float4 *acc4 = reinterpret_cast<float4 *>(acc);
   float4 zpre[CPL], apre[CPL];
+  float4 ppre[ADAM ? CPL : 1], mpre[ADAM ? CPL : 1], vpre[ADAM ? CPL : 1];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
     const int chunk = li + q * LPR;
@@ -130,6 +144,11 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
       const size_t o = (size_t)r * (size_t)D4 + chunk;
       if (z) zpre[q] = z4[o];
       if (acc) apre[q] = acc_init ? init4[o] : acc4[o];
+      if constexpr (ADAM) {
+        ppre[q] = reinterpret_cast<const float4 *>(ae.p)[o];
+        mpre[q] = reinterpret_cast<const float4 *>(ae.m)[o];
+        vpre[q] = reinterpret_cast<const float4 *>(ae.v)[o];
+      }
     }
   }
 
@@ -372,6 +391,19 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
       const float4 a0 = acc_init ? mul_rn4(acc_w, apre[q]) : apre[q];
       acc4[o] = add_rn4(a0, mul_rn4(acc_w, s));
     }
+    if constexpr (ADAM) {
+      const float bc1 = ae.bc[0], bc2_sqrt = ae.bc[1];
+      float4 pp = ppre[q], mm = mpre[q], vv = vpre[q];
+      adam_update(pp.x, s.x, mm.x, vv.x, ae.c, bc1, bc2_sqrt);
+      adam_update(pp.y, s.y, mm.y, vv.y, ae.c, bc1, bc2_sqrt);
+      adam_update(pp.z, s.z, mm.z, vv.z, ae.c, bc1, bc2_sqrt);
+      adam_update(pp.w, s.w, mm.w, vv.w, ae.c, bc1, bc2_sqrt);
+      reinterpret_cast<float4 *>(ae.m)[o] = mm;
+      reinterpret_cast<float4 *>(ae.v)[o] = vv;
+      reinterpret_cast<float4 *>(ae.p)[o] = pp;
+      if (ae.clear_z && z && (zpre[q].x != 0.f || zpre[q].y != 0.f || zpre[q].z != 0.f || zpre[q].w != 0.f))
+        reinterpret_cast<float4 *>(const_cast<float *>(z))[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -379,14 +411,24 @@ template <int LPR, int CPL>
 static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                        float *y, int64_t n_rows, int D4, float alpha, const float *z, float beta,
                        float *acc, const float *acc_init, float acc_w, const int32_t *sched, int dyn_val,
-                       hipStream_t st) {
+                       hipStream_t st, const AdamEpi *adam = nullptr) {
   constexpr int RPW = kWave / LPR;
   const int64_t waves = (n_rows + RPW - 1) / RPW;
   const int64_t blocks = (waves + 3) / 4;     // the schedule has exactly 4 * blocks wave slots
   if (blocks > 0x7fffffffLL) return fail(CHAOREC_E_INVALID, "spmm: grid too large");
-  hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL>), dim3((unsigned)blocks), dim3(256), 0, st,
-                     rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
-                     waves, dyn_val);
+  if (adam) {
+    if constexpr (CPL == 1) {
+      hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, true>), dim3((unsigned)blocks), dim3(256), 0, st,
+                         rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
+                         waves, dyn_val, *adam);
+    } else {
+      return fail(CHAOREC_E_INVALID, "spmm+adam: D > 256 not built");
+    }
+  } else {
+    hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, false>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
+                       waves, dyn_val, AdamEpi{});
+  }
   return check_launch("spmm_csr_ordered_kernel");
 }
 
@@ -401,12 +443,11 @@ static int rows_per_wave(int D) {
 
 using namespace chaorec;
 
-extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
-                                    const float *x, float *y, int64_t n_rows, int64_t n_cols,
-                                    int32_t D, float alpha, const float *z, float beta, float *acc,
-                                    const float *acc_init, float acc_w, const int32_t *schedule,
-                                    int32_t mode, void *stream) {
-  if (!rowptr || !x || (!y && !acc)) return fail(CHAOREC_E_INVALID, "spmm: NULL rowptr/x or no output");
+static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const float *x, float *y,
+                         int64_t n_rows, int64_t n_cols, int32_t D, float alpha, const float *z, float beta,
+                         float *acc, const float *acc_init, float acc_w, const int32_t *schedule, int32_t mode,
+                         void *stream, const AdamEpi *adam) {
+  if (!rowptr || !x || (!y && !acc && !adam)) return fail(CHAOREC_E_INVALID, "spmm: NULL rowptr/x or no output");
   if (n_rows < 0 || n_cols < 0) return fail(CHAOREC_E_INVALID, "spmm: negative size");
   if (D < 4 || D > 1024 || (D & 3)) return fail(CHAOREC_E_INVALID, "spmm: D=%d must be a multiple of 4 in [4,1024]", D);
   if (mode != 0 && mode != CHAOREC_SPMM_DYNAMIC_VALUES) return fail(CHAOREC_E_INVALID, "spmm: unknown mode %d", mode);
@@ -415,7 +456,7 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
   if (n_rows == 0) return CHAOREC_OK;
   hipStream_t st = (hipStream_t)stream;
   const int D4 = D / 4;
-#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, dyn_val, st
+#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, dyn_val, st, adam
   if (D4 <= 1) return launch_spmm<1, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 2) return launch_spmm<2, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 4) return launch_spmm<4, 1>(CHAOREC_SPMM_ARGS);
@@ -427,6 +468,35 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
   if (D4 <= 192) return launch_spmm<64, 3>(CHAOREC_SPMM_ARGS);
   return launch_spmm<64, 4>(CHAOREC_SPMM_ARGS);
 #undef CHAOREC_SPMM_ARGS
+}
+
+extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
+                                    const float *x, float *y, int64_t n_rows, int64_t n_cols,
+                                    int32_t D, float alpha, const float *z, float beta, float *acc,
+                                    const float *acc_init, float acc_w, const int32_t *schedule,
+                                    int32_t mode, void *stream) {
+  return spmm_dispatch(rowptr, col, val, x, y, n_rows, n_cols, D, alpha, z, beta, acc, acc_init, acc_w, schedule, mode,
+                       stream, nullptr);
+}
+
+extern "C" int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
+                                         float *grad_out, int64_t n_rows, int64_t n_cols, int32_t D, float alpha,
+                                         float *z, float beta, const int32_t *schedule, int32_t mode, float *param,
+                                         float *exp_avg, float *exp_avg_sq, const float *bias_corr, float lr,
+                                         float beta1, float beta2, float eps, float weight_decay, int32_t clear_z,
+                                         void *stream) {
+  if (!param || !exp_avg || !exp_avg_sq || !bias_corr) return fail(CHAOREC_E_INVALID, "spmm+adam: NULL argument");
+  if (D > 256) return fail(CHAOREC_E_INVALID, "spmm+adam: D=%d > 256 not built", D);
+  if (clear_z && (const float *)z == x) return fail(CHAOREC_E_INVALID, "spmm+adam: clear_z while gathering from z");
+  AdamEpi ae;
+  ae.p = param;
+  ae.m = exp_avg;
+  ae.v = exp_avg_sq;
+  ae.bc = bias_corr;
+  ae.c = AdamConsts{lr, beta1, beta2, eps, weight_decay};
+  ae.clear_z = clear_z ? 1 : 0;
+  return spmm_dispatch(rowptr, col, val, x, grad_out, n_rows, n_cols, D, alpha, z, beta, nullptr, nullptr, 0.f, schedule,
+                       mode, stream, &ae);
 }
 
 extern "C" int chaorec_spmm_rows_per_wave(int32_t D) { return rows_per_wave(D); }

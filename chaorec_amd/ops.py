@@ -59,6 +59,27 @@ def spmm_raw(csr, x, y=None, alpha=1.0, z=None, beta=0.0, acc=None, acc_init=Non
     return y
 
 
+def spmm_adam_raw(csr, x, param, exp_avg, exp_avg_sq, bias_corr, lr, betas, eps, weight_decay, alpha=1.0, z=None,
+                  beta=0.0, clear_z=False, grad_out=None):
+    """g = alpha * (A x) [+ beta z] and the Adam update of `param` with that gradient, row by row, in ONE launch
+    (chaorec_spmm_csr_adam_f32): the last backward propagate of a LightGCN step with optimizer.step() in its epilogue.
+    `bias_corr`: device float[2] written by bpr_finalize().  clear_z: zero the non-zero rows of z after use."""
+    _need_cuda(csr.rowptr, x, z, param, exp_avg, exp_avg_sq, bias_corr, grad_out)
+    x = _f32c(x)
+    D = x.shape[1]
+    if x.shape[0] != csr.n_cols or param.shape[0] != csr.n_rows or param.shape[1] != D:
+        raise ValueError("spmm_adam: shape mismatch")
+    for t in (param, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("spmm_adam: param / moments must be contiguous float32")
+    mode = 1 if getattr(csr, "dynamic_values", False) else 0
+    rc = _lib.load().chaorec_spmm_csr_adam_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x), _ptr(grad_out),
+                                               csr.n_rows, csr.n_cols, D, alpha, _ptr(z), beta, _ptr(csr.schedule(D)),
+                                               mode, _ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(bias_corr),
+                                               lr, betas[0], betas[1], eps, weight_decay, int(bool(clear_z)), _stream())
+    _lib.check(rc, "chaorec_spmm_csr_adam_f32")
+
+
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, csr):
@@ -235,6 +256,39 @@ def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset
     """Fused BPR(+L2) over a batch of LOCAL row ids -> [total, bpr, reg]; differentiate [0]."""
     loss, parts = _BPR.apply(tab_u, tab_i, users, pos, neg, int(variant), float(reg_weight), int(item_offset))
     return _LossParts(loss, parts)
+
+
+def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg_weight, coef, ws, ids, edges=None, hist=None, num_user=0,
+                num_item=0, seed=0, step=0, step_dev=None, perm=None, perm_pos=None):
+    """BPR(+L2) forward terms and backward row adds in one launch (chaorec_bpr_fwd_bwd_f32) over ONE [N, D] table
+    (items from row item_offset on) and its gradient buffer `grad` (same shape, zero where no sample lands).
+    edges given: the batch is drawn in the launch and written to ids = (users, pos, neg); else ids are the batch
+    (LOCAL item ids).  The loss comes from bpr_finalize(ws, ...)."""
+    _need_cuda(tab, grad, coef, ws, edges, step_dev, perm, perm_pos, *ids)
+    D = tab.shape[1]
+    off = item_offset * D * 4
+    ti, gi = ctypes.c_void_p(tab.data_ptr() + off), ctypes.c_void_p(grad.data_ptr() + off)
+    draw = edges is not None
+    rowptr, col = hist if hist is not None else (None, None)
+    rc = _lib.load().chaorec_bpr_fwd_bwd_f32(
+        _ptr(tab), ti, _ptr(edges), edges.shape[0] if draw else 0, _ptr(rowptr), _ptr(col), int(num_user), int(num_item),
+        int(seed) & (2**64 - 1), int(step), _ptr(step_dev), _ptr(None if draw else ids[0]), _ptr(None if draw else ids[1]),
+        _ptr(None if draw else ids[2]), int(B), D, int(variant), float(reg_weight), _ptr(ids[0] if draw else None),
+        _ptr(ids[1] if draw else None), _ptr(ids[2] if draw else None), _ptr(coef), _ptr(ws), _ptr(perm), _ptr(perm_pos),
+        _ptr(grad), gi, _stream())
+    _lib.check(rc, "chaorec_bpr_fwd_bwd_f32")
+
+
+def bpr_finalize(ws, B, D, reg_weight, out_loss, out_total=None, loss_accum=None, advance=None, perm_pos=None,
+                 adam_step=None, betas=(0.9, 0.999), adam_bc=None):
+    """Reduce a BPR forward's workspace to out_loss = [total, bpr, reg] and do the step's scalar bookkeeping
+    (chaorec_bpr_finalize_f32): loss_accum += total, advance += 1, perm_pos += B, adam_step += 1 with its bias
+    corrections into adam_bc."""
+    _need_cuda(ws, out_loss, out_total, loss_accum, advance, perm_pos, adam_step, adam_bc)
+    rc = _lib.load().chaorec_bpr_finalize_f32(_ptr(ws), int(B), int(D), float(reg_weight), _ptr(out_loss), _ptr(out_total),
+                                              _ptr(loss_accum), _ptr(advance), _ptr(perm_pos), _ptr(adam_step),
+                                              betas[0], betas[1], _ptr(adam_bc), _stream())
+    _lib.check(rc, "chaorec_bpr_finalize_f32")
 
 
 def sample_negatives(hist, users, num_item, seed, step, id_offset, step_dev=None):

@@ -33,35 +33,35 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step_dev = None
 
+    def _ensure_state(self, live):
+        """Moments for the parameters of `live` that have none yet.  Parameters that sit back to back in one buffer
+        (LightGCN's joined embedding tables) get their moments back to back too, so the whole run can be updated by
+        ONE launch."""
+        if live and self._step_dev is None:
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=live[0].device)
+        for p in live:
+            st = self.state[p]
+            if not st:
+                run = [q for q in live if not self.state[q] and q.dtype == p.dtype and q.is_contiguous()]
+                run = _adjacent_run(p, run)
+                total = sum(q.numel() for q in run)
+                flat_m = torch.zeros(total, dtype=p.dtype, device=p.device)
+                flat_v = torch.zeros(total, dtype=p.dtype, device=p.device)
+                o = 0
+                for q in run:
+                    self.state[q]["exp_avg"] = flat_m[o:o + q.numel()].view_as(q)
+                    self.state[q]["exp_avg_sq"] = flat_v[o:o + q.numel()].view_as(q)
+                    o += q.numel()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if self._step_dev is None:
-                    self._step_dev = torch.zeros(1, dtype=torch.int32, device=p.device)
-                break
+            self._ensure_state([p for p in group["params"] if p.grad is not None])
         if self._step_dev is not None:
             self._step_dev.add_(1)
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
-            for p in live:
-                st = self.state[p]
-                if not st:
-                    # parameters that sit back to back in one buffer (LightGCN's joined embedding tables) get their
-                    # moments back to back too, so the whole run can be updated by ONE launch
-                    run = [q for q in live if not self.state[q] and q.dtype == p.dtype and q.is_contiguous()]
-                    run = _adjacent_run(p, run)
-                    total = sum(q.numel() for q in run)
-                    flat_m = torch.zeros(total, dtype=p.dtype, device=p.device)
-                    flat_v = torch.zeros(total, dtype=p.dtype, device=p.device)
-                    o = 0
-                    for q in run:
-                        self.state[q]["exp_avg"] = flat_m[o:o + q.numel()].view_as(q)
-                        self.state[q]["exp_avg_sq"] = flat_v[o:o + q.numel()].view_as(q)
-                        o += q.numel()
             i = 0
             while i < len(live):
                 p = live[i]
@@ -166,4 +166,146 @@ class GraphedTrainStep:
         self.replays += 1
         if self._captured_result is not None:
             self.model.result = self._captured_result
+        return self.static_loss
+
+
+class FusedLightGCNStep:
+    """One LightGCN training iteration -- train_and_evaluate.py:43-48: zero_grad, model.loss() (Model/LightGCN.py:
+    123-135: L propagates + layer mean, BPR + L2), loss.backward(), Adam step -- as 2L + 2 kernel launches with no
+    autograd tape and no optimizer launch, captured in one hipGraph:
+
+        L x  SpMM (layer mean in the epilogue; the last one writes only the mean = model.result)
+        1 x  BPR forward + backward (batch drawn in the launch or given): gradient rows added into G
+        (side branch: the loss scalar, batch / permutation counters, Adam's step count and bias corrections)
+        L-1 x SpMM  g_l = A g_{l+1} + w G
+        1 x  SpMM  g_0 = A g_1 + w G with the Adam update of the embedding table in its epilogue
+
+    Same arithmetic, kernel for kernel, as LightGCN.loss_drawn()/loss_local() + backward() + FusedAdam.step(); what
+    is gone: the Adam launch and its pass over the gradient (chaorec_spmm_csr_adam_f32), the per-step zero fill of the
+    [N, D] batch-gradient buffer G (it is kept all-zero between steps: the last SpMM clears the rows it read),
+    the separate BPR backward launch, three counter launches and autograd's bookkeeping.  model.result is the
+    propagated table of THIS step's forward (the reference's stale-result quirk Q4 is kept).
+    The optimizer's state lives in the FusedAdam instance (same tensors, same step counter), so fused and unfused
+    steps can be mixed (the short last batch of an epoch runs through the ordinary path)."""
+
+    def __init__(self, model, optimizer, batch_size=1024, edges=None, seed=42, step_dev=None, perm=None, perm_pos=None,
+                 given_batch=False, loss_accum=None, capture=True):
+        if not isinstance(optimizer, FusedAdam) or len(optimizer.param_groups) != 1:
+            raise TypeError("FusedLightGCNStep needs a FusedAdam with one parameter group")
+        L = model.n_layers
+        if L < 1:
+            raise ValueError("FusedLightGCNStep: n_layers >= 1")
+        if not model.graph.symmetric:
+            raise ValueError("FusedLightGCNStep: the propagate graph must be its own transpose")
+        if (edges is None) == (not given_batch):
+            raise ValueError("FusedLightGCNStep: either edges (in-launch draw) or given_batch=True")
+        self.model, self.optimizer, self.B, self.L = model, optimizer, int(batch_size), L
+        self.edges, self.seed, self.step_dev, self.perm, self.perm_pos = edges, seed, step_dev, perm, perm_pos
+        group = optimizer.param_groups[0]
+        uw, iw = model.user_embedding.weight, model.item_embedding.weight
+        if [id(p) for p in group["params"]] != [id(uw), id(iw)]:
+            raise ValueError("FusedLightGCNStep: the optimizer must hold exactly the two embedding tables")
+        optimizer._ensure_state([uw, iw])
+        st_u, st_i = optimizer.state[uw], optimizer.state[iw]
+        flat = model._flat
+        N, D = flat.shape
+        esz = 4
+        if not (uw.data_ptr() == flat.data_ptr() and iw.data_ptr() == flat.data_ptr() + uw.numel() * esz
+                and st_i["exp_avg"].data_ptr() == st_u["exp_avg"].data_ptr() + uw.numel() * esz
+                and st_i["exp_avg_sq"].data_ptr() == st_u["exp_avg_sq"].data_ptr() + uw.numel() * esz):
+            raise ValueError("FusedLightGCNStep: embedding tables / moments are not one contiguous run")
+        dev = flat.device
+        self.N, self.D = N, D
+        self.m = torch.as_strided(st_u["exp_avg"], (N, D), (D, 1))
+        self.v = torch.as_strided(st_u["exp_avg_sq"], (N, D), (D, 1))
+        self.buf = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(2)]   # x_l, then g_l
+        self.final = torch.empty((N, D), dtype=torch.float32, device=dev)
+        self.G = torch.zeros((N, D), dtype=torch.float32, device=dev)       # all-zero between steps
+        self.ids = tuple(torch.zeros(self.B, dtype=torch.int64, device=dev) for _ in range(3))
+        self.coef = torch.empty(self.B, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(4 * self.B, dtype=torch.float32, device=dev)
+        self.out = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.static_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.bc = torch.ones(2, dtype=torch.float32, device=dev)
+        self.loss_accum = loss_accum
+        self.side = torch.cuda.Stream(device=dev)
+        self.replays = 0
+        self.graph = None
+        if capture:
+            # schedules, lazily built by the first SpMM call, must exist before capture
+            model.graph.schedule(D)
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream())
+            saved = self._save_state()
+            with torch.cuda.stream(s):
+                self._launch()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._restore_state(saved)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._launch()
+
+    def _counters(self):
+        return [t for t in (self.step_dev, self.perm_pos, self.loss_accum, self.optimizer._step_dev) if t is not None]
+
+    def _save_state(self):
+        return ([self.model._flat.clone(), self.m.clone(), self.v.clone()], [t.clone() for t in self._counters()])
+
+    def _restore_state(self, saved):
+        with torch.no_grad():
+            for dst, src in zip((self.model._flat, self.m, self.v), saved[0]):
+                dst.copy_(src)
+            for dst, src in zip(self._counters(), saved[1]):
+                dst.copy_(src)
+            self.G.zero_()
+
+    @torch.no_grad()
+    def _launch(self):
+        model, opt, L, B, D = self.model, self.optimizer, self.L, self.B, self.D
+        group = opt.param_groups[0]
+        csr, x0, w = model.graph, model._flat, 1.0 / (L + 1)
+        x = x0
+        for l in range(L):
+            last = l == L - 1
+            y = None if last else self.buf[l & 1]
+            ops.spmm_raw(csr, x, y=y, acc=self.final, acc_init=x0 if l == 0 else None, acc_w=w, want_y=not last)
+            x = y
+        draw = self.edges is not None
+        ops.bpr_fwd_bwd(self.final, model.num_user, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef,
+                        self.ws, self.ids, edges=self.edges, hist=model.hist if draw else None, num_user=model.num_user,
+                        num_item=model.num_item, seed=self.seed, step=0, step_dev=self.step_dev, perm=self.perm,
+                        perm_pos=self.perm_pos)
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):      # off the critical path: the backward does not need the loss value
+            ops.bpr_finalize(self.ws, B, D, model.reg_weight, self.out, out_total=self.static_loss,
+                             loss_accum=self.loss_accum, advance=self.step_dev if draw else None,
+                             perm_pos=self.perm_pos if (draw and self.perm is not None) else None,
+                             adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
+        g, alpha = self.G, w                    # g_{L-1} = w (A G) + w G, then g_l = A g_{l+1} + w G
+        for l in range(L - 1):
+            y = self.buf[l & 1]
+            ops.spmm_raw(csr, g, y=y, alpha=alpha, z=self.G, beta=w)
+            g, alpha = y, 1.0
+        cur.wait_stream(self.side)              # the Adam epilogue reads this step's bias corrections
+        ops.spmm_adam_raw(csr, g, x0, self.m, self.v, self.bc, group["lr"], group["betas"], group["eps"],
+                          group["weight_decay"], alpha=alpha, z=self.G, beta=w, clear_z=L >= 2)
+        if L < 2:
+            self.G.zero_()                      # (the single backward SpMM gathers from G: it cannot clear it)
+        model.result = self.final
+
+    def __call__(self, users=None, pos=None, neg=None):
+        """-> the step's loss (device scalar, rewritten by the next call).  users / pos / neg (GLOBAL item ids, the
+        reference's batch format) only in given_batch mode."""
+        if self.edges is None:
+            self.ids[0].copy_(users, non_blocking=True)
+            torch.sub(pos.to(self.ids[1].device), self.model.num_user, out=self.ids[1])
+            torch.sub(neg.to(self.ids[2].device), self.model.num_user, out=self.ids[2])
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch()
+        self.replays += 1
+        self.model.result = self.final
         return self.static_loss

@@ -26,9 +26,11 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 3   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 4   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
-                                  SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace */
+                                  SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
+                                  4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
+                                  stand-alone BPR finalize with loss / optimizer bookkeeping */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -75,6 +77,23 @@ int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float 
                          float alpha, const float *z, float beta,
                          float *acc, const float *acc_init, float acc_w,
                          const int32_t *schedule, int32_t mode, void *stream);
+
+/* The LAST backward propagate of a training step with the optimizer update in its epilogue
+ * (train_and_evaluate.py:46-47: loss.backward(); optimizer.step(), for a model whose parameter table IS the
+ * propagate's input: LightGCN, Model/LightGCN.py:76-95):
+ *     g[r]   = alpha * (A x)[r] + beta * z[r]         -- chaorec_spmm_csr_f32's arithmetic, e.g. g_0 = A^T g_1 + w G
+ *     Adam(param[r], g[r], exp_avg[r], exp_avg_sq[r]) -- chaorec_adam_step_f32's arithmetic, bit for bit
+ * in one launch: no separate optimizer launch and no second pass over the gradient (grad_out may be NULL).
+ * bias_corr: device float[2] = {1 - beta1^t, sqrt(1 - beta2^t)} of this step (chaorec_bpr_finalize_f32 writes it).
+ * clear_z != 0: every row of z that was non-zero is zeroed after it was read -- z is then the batch gradient buffer
+ * that chaorec_bpr_fwd_bwd_f32 adds into, kept all-zero between steps instead of being zero-filled every step
+ * (refused when x == z: another wave could still gather the row).  D <= 256. */
+int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
+                              float *grad_out, int64_t n_rows, int64_t n_cols, int32_t D, float alpha,
+                              float *z, float beta, const int32_t *schedule, int32_t mode, float *param,
+                              float *exp_avg, float *exp_avg_sq, const float *bias_corr, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int32_t clear_z,
+                              void *stream);
 
 /* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
 int chaorec_spmm_rows_per_wave(int32_t D);
@@ -165,6 +184,32 @@ int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i, const int6
                               int64_t *out_pos, int64_t *out_neg, float *out_loss, float *out_total,
                               float *coef, float *workspace, int64_t *advance, const int64_t *perm,
                               int64_t *perm_pos, void *stream);
+
+/* Forward terms AND backward row updates of the BPR(+L2) loss in ONE launch, for a loss differentiated with
+ * d(loss) = 1 (a plain loss.backward(), train_and_evaluate.py:46): sample b's coefficient depends on its own score
+ * difference only, so the wave that reduced the triple adds its three gradient rows at once (the arithmetic of
+ * chaorec_bpr_bwd_f32 with grad_out = 1).  The batch is drawn in the launch when `edges` != NULL (exactly as
+ * chaorec_bpr_fwd_drawn_f32; out_* receive the ids) or given by in_users / in_pos / in_neg (LOCAL item ids).
+ * g_u / g_i must be zero wherever no sample lands.  The loss itself comes from chaorec_bpr_finalize_f32 on the
+ * same workspace -- off the critical path of the backward propagates. */
+int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
+                            const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
+                            int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
+                            const int64_t *in_users, const int64_t *in_pos, const int64_t *in_neg,
+                            int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
+                            int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
+                            const int64_t *perm, const int64_t *perm_pos, float *g_u, float *g_i,
+                            void *stream);
+
+/* The single-block, fixed-order reduction of a BPR forward's workspace ([4, B]: terms, sum u^2, sum p^2, sum n^2)
+ * into out_loss[3] = {total, bpr, reg} (+ out_total[0] = total), and the step's scalar bookkeeping, all optional:
+ * loss_accum[0] += total (the per-epoch loss sum of train_and_evaluate.py:48 without its per-batch host sync);
+ * advance[0] += 1 and perm_pos[0] += B (batch counter / epoch-permutation position of the in-launch draw);
+ * adam_step[0] += 1 and adam_bc[2] = {1 - beta1^t, sqrt(1 - beta2^t)} for the new t (torch.optim.Adam's step count
+ * and bias corrections, consumed by chaorec_spmm_csr_adam_f32). */
+int chaorec_bpr_finalize_f32(const float *workspace, int32_t B, int32_t D, float reg_weight, float *out_loss,
+                             float *out_total, float *loss_accum, int64_t *advance, int64_t *perm_pos,
+                             int32_t *adam_step, float beta1, float beta2, float *adam_bc, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * R: all-items scoring + history mask + top-K, never materialising the [U, I] matrix.

@@ -84,13 +84,14 @@ def test_lightgcn_sports_real_graph_vs_reference(dev):
 
 
 @pytest.mark.parametrize("name", ["baby", "sports"])
-@pytest.mark.parametrize("captured", [True, False])
+@pytest.mark.parametrize("captured", [True, False, "fused"])
 def test_training_trajectory_vs_reference(dev, name, captured):
     """Row L: T reference training iterations (zero_grad, loss, backward, Adam lr 1e-3) on fixed batches, then the
-    evaluation on the stale result, replayed through GraphedTrainStep + FusedAdam (captured hipGraph) or eagerly."""
+    evaluation on the stale result, replayed through GraphedTrainStep + FusedAdam (captured hipGraph), eagerly, or
+    through FusedLightGCNStep (the 2L+2-launch step bench.py times)."""
     from chaorec_amd import graph
     from chaorec_amd.Model import LightGCN
-    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.optim import FusedAdam, FusedLightGCNStep, GraphedTrainStep
     g = load_golden(f"lightgcn_trajectory_{name}.npz")
     d = load_interactions(name)
     U, I, D, L, T = d["U"], d["I"], int(g["D"]), int(g["L"]), int(g["T"])
@@ -98,7 +99,10 @@ def test_training_trajectory_vs_reference(dev, name, captured):
     m = LightGCN(U, I, d["train"], graph.user_item_dict_from_edges(d["train"]), D, float(g["reg"]), L, "add", dev).to(dev)
     opt = FusedAdam([{"params": m.parameters(), "lr": float(g["lr"])}])
     batches = [tuple(torch.from_numpy(g["batches"][t, k].astype(np.int64)).to(dev) for k in range(3)) for t in range(T)]
-    step = GraphedTrainStep(m, opt, example_batch=batches[0]) if captured else None
+    if captured == "fused":
+        step = FusedLightGCNStep(m, opt, batch_size=len(batches[0][0]), given_batch=True)
+    else:
+        step = GraphedTrainStep(m, opt, example_batch=batches[0]) if captured else None
     for t, b in enumerate(batches):
         if captured:
             loss = step(*b)
