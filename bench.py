@@ -53,6 +53,11 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph step")
     p.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP Adam")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    p.add_argument("--unfused", action="store_true",
+                   help="N=1: the autograd step (loss_drawn -> backward -> FusedAdam) instead of FusedLightGCNStep")
+    p.add_argument("--synthetic", action="store_true", help="dataset-shaped synthetic graph instead of the real one")
+    p.add_argument("--no-hbm-regime", action="store_true", help="skip the config-5-shard sub-record (N=1)")
+    p.add_argument("--hbm-steps", type=int, default=10, help="timed steps of the config-5-shard sub-record")
     p.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)   # child mode of probe_sharded_graph()
     return p.parse_args()
 
@@ -114,61 +119,333 @@ def spmm_model_bytes(nnz, n_rows, D):
 
 
 def cpu_baseline(edges, U, I, D, L, B, reg, budget_s):
-    """The reference CPU path restated in plain torch (oracle/torch_ref.py), timed on this box's
-    host cores on a bounded number of steps."""
+    """The reference CPU path restated in plain torch (oracle/torch_ref.py), timed on this box's host cores on a
+    bounded number of steps.  Best of a small sweep over torch's intra-op thread count (the box has far more cores
+    than a 0.3 M-edge scatter can use: all of them is slower than a few)."""
     from oracle.torch_ref import TorchRefLightGCN
     from chaorec_amd.graph import user_item_dict_from_edges
-    torch.manual_seed(42)
+    ncpu = os.cpu_count() or 8
+    cands = sorted({t for t in (8, 16, 32, ncpu) if t <= ncpu} or {ncpu})
     uid = user_item_dict_from_edges(edges)
-    m = TorchRefLightGCN(U, I, edges, uid, D, reg, L)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     rng = np.random.default_rng(0)
     E = len(edges)
+    old_threads = torch.get_num_threads()
 
-    def batch():
-        b = rng.integers(0, E, B)
-        return (torch.from_numpy(edges[b, 0].astype(np.int64)), torch.from_numpy(edges[b, 1].astype(np.int64)),
-                torch.from_numpy(rng.integers(U, U + I, B)))
+    def run(threads, budget):
+        torch.set_num_threads(threads)
+        torch.manual_seed(42)
+        m = TorchRefLightGCN(U, I, edges, uid, D, reg, L)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
 
-    def step():
-        u, p, n = batch()
-        opt.zero_grad()
-        loss = m.loss(u, p, n)
-        loss.backward()
-        opt.step()
-        return loss.item()
+        def step():
+            b = rng.integers(0, E, B)
+            u, p = torch.from_numpy(edges[b, 0].astype(np.int64)), torch.from_numpy(edges[b, 1].astype(np.int64))
+            n = torch.from_numpy(rng.integers(U, U + I, B))
+            opt.zero_grad()
+            loss = m.loss(u, p, n)
+            loss.backward()
+            opt.step()
 
-    step()  # warm-up
-    t0 = time.perf_counter()
-    n_steps = 0
-    while n_steps < 3 or (time.perf_counter() - t0 < budget_s * 0.75 and n_steps < 200):
-        step()
-        n_steps += 1
-    dt = (time.perf_counter() - t0) / n_steps
+        step()  # warm-up
+        t0 = time.perf_counter()
+        n_steps = 0
+        while n_steps < 3 or (time.perf_counter() - t0 < budget and n_steps < 200):
+            step()
+            n_steps += 1
+        return (time.perf_counter() - t0) / n_steps, n_steps, m
+
+    share = budget_s * 0.6 / len(cands)
+    tried = {}
+    best = None
+    for t in cands:
+        dt, n_steps, m = run(t, share)
+        tried[t] = dt * 1e3
+        if best is None or dt < best[0]:
+            best = (dt, n_steps, t, m)
+    dt, n_steps, threads, m = best
+    torch.set_num_threads(threads)
     t1 = time.perf_counter()
     with torch.no_grad():
         m.gene_ranklist()
     t_rank = time.perf_counter() - t1
+    torch.set_num_threads(old_threads)
     e_dir = 2 * E
     return {
-        "value": 2 * L * e_dir / dt, "unit": "directed-edge messages/s", "cores": torch.get_num_threads(),
-        "kind": "port",
+        "value": 2 * L * e_dir / dt, "unit": "directed-edge messages/s", "cores": threads, "kind": "port",
         "sample": f"{n_steps} train steps of the same workload ({dt * 1e3:.1f} ms/step) + 1 gene_ranklist "
-                  f"({t_rank:.2f} s) with oracle/torch_ref.py (reference op sequence in plain torch, CPU)",
+                  f"({t_rank:.2f} s) with oracle/torch_ref.py (reference op sequence in plain torch, CPU); best of "
+                  f"torch threads {cands} on {ncpu} host cores",
         "ms_per_step": dt * 1e3, "users_scored_per_s": U / t_rank,
+        "ms_per_step_by_threads": {str(k): round(v, 1) for k, v in tried.items()},
     }
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    # CHAOREC_FORCE_SHARDED=1: run the N>1 code path (sharded model, RCCL calls, graph capture of them) on one rank
-    force_sharded = world == 1 and os.environ.get("CHAOREC_FORCE_SHARDED", "0") == "1"
+def load_graph(dataset, synthetic=False):
+    """-> (edges int32 [E,2] with global item ids, U, I, 'real' | 'synthetic').  The reference's Data/<dataset> files
+    travel with the repository as packed fixtures (tests/golden/<dataset>_interactions.npz); config5_shard (one GPU's
+    share of BASELINE configs[4]) is synthetic by definition."""
+    from chaorec_amd import dataload
+    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+    packed = None if synthetic else dataload.packed_interactions(dataset)
+    if packed is not None:
+        return packed["train"], packed["num_user"], packed["num_item"], "real"
+    U, I, E = DATASET_SHAPES[dataset]
+    return synthetic_interactions(U, I, E, seed=42), U, I, "synthetic"
+
+
+def time_spmm_calls(ops, calls, reps=20, passes=5):
+    """HIP events on the launch stream around back-to-back re-launches of recorded SpMM calls: (median pass average
+    in ms per launch, model bytes per launch, compulsory bytes per launch).  A single launch bracketed by events
+    from Python mostly times the host; a saturated queue times the kernel."""
+    pass_avg, tot_bytes, tot_comp, tot_launch = [], 0.0, 0.0, 0
+    for _ in range(passes):
+        pass_ms, pass_launch = 0.0, 0
+        for fn, csr, D in calls:
+            fn()                                     # warm
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            pass_ms += s.elapsed_time(e)
+            pass_launch += reps
+            tot_launch += reps
+            tot_bytes += reps * spmm_model_bytes(csr.nnz, csr.n_rows, D)
+            tot_comp += reps * (2 * csr.n_rows * 4 * D + csr.nnz * 8)
+        pass_avg.append(pass_ms / pass_launch)
+    return float(np.median(pass_avg)), tot_bytes / tot_launch, tot_comp / tot_launch
+
+
+def spmm_kernel_name(D, adam=False):
+    d4, lpr = D // 4, 1
+    while lpr < min(d4, 64):
+        lpr *= 2
+    return f"spmm_csr_ordered_kernel<{lpr},{max(1, (d4 + 63) // 64)},{'true' if adam else 'false'}>"
+
+
+def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps_rank=5, synthetic=False):
+    """One GPU, unsharded LightGCN: the timed training steps, the SpMM roofline, gene_ranklist.  -> dict."""
+    from chaorec_amd import ops
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, FusedLightGCNStep, GraphedTrainStep
+    L, B, reg = args.n_layers, args.batch, 1e-3
+    edges, U, I, data_kind = load_graph(dataset, synthetic)
+    E = len(edges)
+    e_dir = 2 * E
+    torch.manual_seed(42)
+    model = LightGCN(U, I, edges, None, D, reg, L, "add", dev).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else FusedAdam(model.parameters(), lr=1e-3)
+    edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
+    loss_sum = torch.zeros(1, device=dev)
+    batch_counter = torch.zeros(1, dtype=torch.int64, device=dev)   # device-resident: advances inside the graph
+    fused = not args.unfused and not args.torch_adam and L >= 1
+    n_loss = [0]
+    if fused:
+        # 2L+2 launches per step, no autograd, no optimizer launch (optim.FusedLightGCNStep); --no-graph launches the
+        # same kernels eagerly
+        stepper = FusedLightGCNStep(model, opt, batch_size=B, edges=edges_dev, seed=42, step_dev=batch_counter,
+                                    loss_accum=loss_sum, capture=not args.no_graph)
+        launch = ("captured hipGraph per step" if not args.no_graph else "eager launches") + ", fused step (2L+2 kernels)"
+
+        def step(i):
+            n_loss[0] += 1
+            stepper()
+    else:
+        acc0 = torch.zeros((), device=dev)
+
+        def drawn_loss():
+            loss = model.loss_drawn(edges_dev, B, 42, 0, step_dev=batch_counter, advance=True)
+            acc0.add_(loss.detach())
+            return loss
+
+        graphed = None
+        if not args.no_graph and not args.torch_adam:
+            graphed = GraphedTrainStep(model, opt, batch_fn=lambda: (), loss_fn=drawn_loss)
+            acc0.zero_()
+        launch = ("captured hipGraph per step" if graphed is not None else "eager launches") + ", autograd step"
+
+        def step(i):
+            n_loss[0] += 1
+            if graphed is not None:
+                graphed()
+                return
+            opt.zero_grad(set_to_none=True)
+            loss = drawn_loss()
+            loss.backward()
+            opt.step()
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    loss_sum.zero_()
+    n_loss[0] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms_per_step = dt / steps * 1e3
+    loss_mean = (float(loss_sum.item()) if fused else float(acc0.item())) / max(n_loss[0], 1)
+    msgs_per_step = 2 * L * e_dir
+
+    # --- SpMM roofline: the step's own SpMM calls (same graph, operands, epilogues), re-launched back to back ------
+    csr = model.graph
+    N = csr.n_rows
+    w = 1.0 / (L + 1)
+    x0 = model._flat.detach()
+    b0, b1, fin, G = (torch.empty_like(x0) for _ in range(4))
+    G.zero_()
+    plain = []
+    src = x0
+    for l in range(L):                               # forward: layer mean in the epilogue, the last one without y
+        last = l == L - 1
+        y = None if last else (b0 if l % 2 == 0 else b1)
+        plain.append((lambda src=src, y=y, l=l, last=last: ops.spmm_raw(csr, src, y=y, acc=fin,
+                                                                          acc_init=x0 if l == 0 else None, acc_w=w,
+                                                                          want_y=not last), csr, D))
+        src = y
+    g, alpha = G, w
+    for l in range(L - 1):                           # backward: g_l = A g_{l+1} + w G
+        y = b0 if l % 2 == 0 else b1
+        plain.append((lambda g=g, y=y, alpha=alpha: ops.spmm_raw(csr, g, y=y, alpha=alpha, z=G, beta=w), csr, D))
+        g, alpha = y, 1.0
+    avg_spmm_ms, model_bytes, compulsory = time_spmm_calls(ops, plain)
+    adam_ms = None
+    if fused and D <= 256:                           # the last backward propagate with the Adam epilogue, on copies
+        pc, mc, vc = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
+        bc = torch.tensor([0.1, 0.0316], device=dev)
+        adam_ms, _, _ = time_spmm_calls(ops, [(lambda: ops.spmm_adam_raw(csr, g, pc, mc, vc, bc, 1e-3, (0.9, 0.999), 1e-8,
+                                                                       0.0, alpha=alpha, z=G, beta=w, clear_z=L >= 2),
+                                               csr, D)])
+    del b0, b1, fin, G
+    achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
+    table_mb = N * D * 4 / 1e6
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"spmm_traffic_{dataset}_d{D}.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": spmm_kernel_name(D), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": model_bytes,
+                "avg_launch_us": avg_spmm_ms * 1e3, "compulsory_bytes_per_launch": compulsory,
+                "launches_per_step": 2 * L - (1 if adam_ms is not None else 0),
+                "note": ("embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is against "
+                         "the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)" % table_mb)
+                if table_mb < 256 else
+                ("embedding table %.0f MB, beyond the 256 MiB Infinity Cache: HBM-bound regime; `achieved` counts the "
+                 "no-reuse CSR model bytes, `traffic` (when present) the measured FETCH_SIZE+WRITE_SIZE bytes" % table_mb)}
+    if traffic:
+        roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
+    if adam_ms is not None:
+        adam_bytes = model_bytes + 6 * N * D * 4 - N * D * 4        # + p, m, v read and written, - the y store
+        roofline["adam_epilogue_launch"] = {"kernel": spmm_kernel_name(D, True), "avg_launch_us": adam_ms * 1e3,
+                                            "algorithmic_bytes": adam_bytes,
+                                            "achieved_GBps": adam_bytes / (adam_ms * 1e-3) / 1e9}
+
+    # --- full-rank evaluation ---------------------------------------------------------------------------------
+    def time_ranklist():
+        torch.cuda.synchronize()
+        model.gene_ranklist(to_cpu=False)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps_rank)]
+        st = {}
+        with torch.no_grad():
+            res = model.result.detach()
+            for s, e in ev:
+                s.record()
+                ops.score_topk(res[:U], res[U:U + I], model.hist, 1e-6, 50, id_offset=U)
+                e.record()
+            torch.cuda.synchronize()
+            ops.score_topk(res[:U], res[U:U + I], model.hist, 1e-6, 50, id_offset=U, stats=st)
+            # the reference contract: a LongTensor on the CPU (Model/LightGCN.py:162) -- wall time incl. the D2H copy
+            model.gene_ranklist()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                model.gene_ranklist()
+            host_ms = (time.perf_counter() - t1) / 3 * 1e3
+        return float(np.median([s.elapsed_time(e) for s, e in ev])), st, host_ms
+
+    steps_done = warmup + steps
+    early_ms, early_st, early_host_ms = time_ranklist()
+    score_ms, st, host_ms, state = early_ms, early_st, early_host_ms, f"after {steps_done} training steps"
+    extra = trained_steps - steps_done
+    if extra > 0 and extra * ms_per_step < 10_000:
+        for i in range(extra):
+            step(steps_done + i)
+        score_ms, st, host_ms = time_ranklist()
+        state = f"after {trained_steps} training steps ({extra} of them untimed, past the measured ones)"
+    tf = 2.0 * U * I * D / (score_ms * 1e-3) / 1e12
+    return dict(dataset=dataset, data=data_kind, U=U, I=I, E=E, e_dir=e_dir, D=D, L=L, B=B, ms_per_step=ms_per_step,
+                value=msgs_per_step / (dt / steps), msgs_per_step=msgs_per_step, loss_mean=loss_mean, launch=launch,
+                roofline=roofline, score_ms=score_ms, score_state=state, early_ms=early_ms, early_st=early_st,
+                score_st=st, score_tf=tf, host_rank_ms=host_ms, edges=edges, reg=reg, table_mb=table_mb)
+
+
+def scoring_roofline(r):
+    return {"bound": "mfma", "kernel": f"score_sweep_bf16_kernel<{r['D']},2> (+ pack, sample, select/re-score)",
+            "achieved": r["score_tf"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": r["score_tf"] / BF16_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": r["score_tf"] / F32_MFMA_PEAK_TFLOPS,
+            "prefilter": r["score_st"],
+            "note": "2*U*I*D over the whole gene_ranklist call.  The [U,I] sweep runs on the bf16 MFMA pipe "
+                    "(v_mfma_f32_32x32x16_bf16, 2.5 PF dense peak) as a prefilter with a proven error bound, the top-K "
+                    "is ranked on exact fp32 re-scores (bit-identical to the fp32 route); see DESIGN.md 3.3"}
+
+
+def main_single(args, dev):
+    from chaorec_amd import _lib
+    _lib.ensure_built()
+    _lib.load()
+    D = args.dim
+    r = measure_single_gpu(args, args.dataset, D, args.steps, args.warmup, dev,
+                           0 if args.no_trained_state else TRAINED_STEPS, synthetic=args.synthetic)
+    U, I = r["U"], r["I"]
+    out = {
+        "metric": f"GCN edges/sec + full-rank users-scored/sec, dim={D}",
+        "value": r["value"], "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
+        "users_scored_per_s": U / (r["score_ms"] * 1e-3),
+        "users_scored_per_s_incl_d2h": U / (r["host_rank_ms"] * 1e-3),
+        "users_scored_per_s_right_after_timed_steps": U / (r["early_ms"] * 1e-3),
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": r["data"],
+        "config": {"workload": f"LightGCN train step on the {'real' if r['data'] == 'real' else 'synthetic'} "
+                               f"{args.dataset} graph (U={U}, I={I}, E_dir={r['e_dir']}), dim={D}, n_layers={r['L']}, "
+                               f"batch={r['B']}; gene_ranklist top-50 over all users",
+                   "messages_per_step": r["msgs_per_step"], "gene_ranklist_ms": r["score_ms"],
+                   "gene_ranklist_ms_incl_d2h_wall": r["host_rank_ms"],
+                   "gene_ranklist_state": r["score_state"], "gene_ranklist_ms_right_after_timed_steps": r["early_ms"],
+                   "prefilter_right_after_timed_steps": r["early_st"], "launch": r["launch"],
+                   "optimizer": "torch.optim.Adam" if args.torch_adam else
+                   ("Adam in the last backward SpMM's epilogue (chaorec_spmm_csr_adam_f32)" if "fused" in r["launch"]
+                    else "FusedAdam (chaorec_adam_step_f32)"),
+                   "parallelism": "single GPU"},
+        "roofline": r["roofline"], "roofline_scoring": scoring_roofline(r), "loss_mean": r["loss_mean"],
+    }
+    edges, reg = r["edges"], r["reg"]
+    # --- the HBM-bound regime in the same run: one GPU's share of BASELINE configs[4] -----------------------------
+    if not args.no_hbm_regime and args.dataset != "config5_shard":
+        del r
+        torch.cuda.empty_cache()
+        h = measure_single_gpu(args, "config5_shard", 128, args.hbm_steps, 3, dev, 0, reps_rank=3)
+        out["hbm_regime"] = {
+            "workload": f"one GPU's share of BASELINE configs[4]: synthetic bipartite graph U={h['U']}, I={h['I']}, "
+                        f"E_dir={h['e_dir']}, dim=128, n_layers={h['L']}, batch={h['B']} (embedding table "
+                        f"{h['table_mb']:.0f} MB = {h['table_mb'] / 268.4:.1f}x the Infinity Cache)",
+            "data": h["data"], "steps": args.hbm_steps, "ms_per_step": h["ms_per_step"], "value": h["value"],
+            "unit": "directed-edge messages/s", "roofline": h["roofline"],
+            "gene_ranklist_ms": h["score_ms"], "users_scored_per_s": h["U"] / (h["score_ms"] * 1e-3),
+            "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"],
+        }
+        del h
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(edges, U, I, D, args.n_layers, args.batch, reg, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+
+
+def main_sharded(args, world, rank, local_rank, force_sharded):
     backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
     probe_ok = None
     if ((world > 1 or force_sharded) and backend == "nccl" and not args.probe_graph and not args.no_graph
@@ -500,6 +777,24 @@ def main():
             except (ValueError, OSError):
                 pass
         print(json.dumps(out), flush=True)
+
+
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # CHAOREC_FORCE_SHARDED=1: run the N>1 code path (sharded model, RCCL calls, graph capture of them) on one rank
+    force_sharded = world == 1 and os.environ.get("CHAOREC_FORCE_SHARDED", "0") == "1"
+    if world == 1 and not force_sharded:
+        assert torch.cuda.is_available(), "bench.py needs the MI355X"
+        torch.cuda.set_device(0)
+        return main_single(args, torch.device("cuda", 0))
+    return main_sharded(args, world, rank, local_rank, force_sharded)
 
 
 if __name__ == "__main__":

@@ -47,7 +47,10 @@ class LightGCN(nn.Module):
         # that read it, the kernels use the CSR below
         self.edge_index = graph.bidirectional_edge_index(edge_index)
         self.graph = graph.lightgcn_csr(edge_index, num_user + num_item).to(device)
-        rowptr, col = graph.user_hist_csr(user_item_dict, num_user)
+        # (user_item_dict=None: the history is derived from the edge list, vectorised -- graphs with millions of
+        #  users, where a python dict of lists is the slowest thing in the constructor)
+        rowptr, col = (graph.user_hist_csr(user_item_dict, num_user) if user_item_dict is not None
+                       else graph.user_hist_csr_from_edges(edge_index, num_user))
         self.hist = (rowptr.to(device), col.to(device))
 
         self.user_embedding = nn.Embedding(num_user, dim_E)

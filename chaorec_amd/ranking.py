@@ -15,6 +15,16 @@ def history_csr(user_item_dict, num_user, device):
     return rowptr.to(device), col.to(device)
 
 
+def _to_host(idx):
+    """[U, K] int64 rank list -> CPU LongTensor through page-locked memory (torch's caching host allocator hands the
+    same pages out again call after call; a pageable .cpu() copy of sports' 11.6 MB list costs several times the
+    ranking itself)."""
+    buf = torch.empty(idx.shape, dtype=idx.dtype, pin_memory=True)
+    buf.copy_(idx, non_blocking=True)
+    torch.cuda.current_stream(idx.device).synchronize()
+    return buf
+
+
 def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to_cpu=True):
     """result [N, D] (users first) on the GPU -> LongTensor [num_user, topk] of GLOBAL item ids on the CPU (the
     reference's contract); to_cpu=False keeps it in HBM for utils.gene_metrics_device."""
@@ -22,4 +32,4 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
         result = result.detach()
         idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                 id_offset=num_user)
-    return idx.cpu() if to_cpu else idx
+    return _to_host(idx) if to_cpu else idx
