@@ -55,6 +55,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     p.add_argument("--unfused", action="store_true",
                    help="N=1: the autograd step (loss_drawn -> backward -> FusedAdam) instead of FusedLightGCNStep")
+    p.add_argument("--steps-per-replay", type=int, default=10,
+                   help="training steps captured back to back in one hipGraph (N=1 fused step)")
     p.add_argument("--synthetic", action="store_true", help="dataset-shaped synthetic graph instead of the real one")
     p.add_argument("--no-hbm-regime", action="store_true", help="skip the config-5-shard sub-record (N=1)")
     p.add_argument("--hbm-steps", type=int, default=10, help="timed steps of the config-5-shard sub-record")
@@ -245,12 +247,13 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         # 2L+2 launches per step, no autograd, no optimizer launch (optim.FusedLightGCNStep); --no-graph launches the
         # same kernels eagerly
         stepper = FusedLightGCNStep(model, opt, batch_size=B, edges=edges_dev, seed=42, step_dev=batch_counter,
-                                    loss_accum=loss_sum, capture=not args.no_graph)
-        launch = ("captured hipGraph per step" if not args.no_graph else "eager launches") + ", fused step (2L+2 kernels)"
+                                    loss_accum=loss_sum, capture=not args.no_graph, steps_per_replay=args.steps_per_replay)
+        launch = ((f"captured hipGraph, {stepper.steps_per_replay} steps per replay" if not args.no_graph
+                   else "eager launches") + ", fused step (2L+2 kernels)")
 
-        def step(i):
-            n_loss[0] += 1
-            stepper()
+        def run_steps(n):          # whole replays of steps_per_replay steps, single-step replays for the remainder
+            n_loss[0] += n
+            stepper.run(n)
     else:
         acc0 = torch.zeros((), device=dev)
 
@@ -265,25 +268,26 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             acc0.zero_()
         launch = ("captured hipGraph per step" if graphed is not None else "eager launches") + ", autograd step"
 
-        def step(i):
-            n_loss[0] += 1
-            if graphed is not None:
-                graphed()
-                return
-            opt.zero_grad(set_to_none=True)
-            loss = drawn_loss()
-            loss.backward()
-            opt.step()
+        def run_steps(n):
+            for _ in range(n):
+                n_loss[0] += 1
+                if graphed is not None:
+                    graphed()
+                    continue
+                opt.zero_grad(set_to_none=True)
+                loss = drawn_loss()
+                loss.backward()
+                opt.step()
 
-    for i in range(warmup):
-        step(i)
+    run_steps(warmup)
     torch.cuda.synchronize()
     loss_sum.zero_()
+    if not fused:
+        acc0.zero_()
     n_loss[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        step(warmup + i)
+    run_steps(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms_per_step = dt / steps * 1e3
@@ -297,21 +301,28 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     x0 = model._flat.detach()
     b0, b1, fin, G = (torch.empty_like(x0) for _ in range(4))
     G.zero_()
-    plain = []
-    src = x0
-    for l in range(L):                               # forward: layer mean in the epilogue, the last one without y
-        last = l == L - 1
-        y = None if last else (b0 if l % 2 == 0 else b1)
-        plain.append((lambda src=src, y=y, l=l, last=last: ops.spmm_raw(csr, src, y=y, acc=fin,
-                                                                          acc_init=x0 if l == 0 else None, acc_w=w,
-                                                                          want_y=not last), csr, D))
+    plain, src = [], x0
+    use_mean = L <= ops.mean_terms_limit(D)
+    xs = [x0]
+    for l in range(L - 1 if use_mean else L):        # forward propagates (ops.forward_layers)
+        y = b0 if l % 2 == 0 else b1
+        if use_mean:
+            plain.append((lambda src=src, y=y: ops.spmm_raw(csr, src, y=y), csr, D))
+        else:
+            last = l == L - 1
+            plain.append((lambda src=src, y=y, l=l, last=last: ops.spmm_raw(
+                csr, src, y=None if last else y, acc=fin, acc_init=x0 if l == 0 else None, acc_w=w, want_y=not last), csr, D))
         src = y
+        xs.append(y)
     g, alpha = G, w
     for l in range(L - 1):                           # backward: g_l = A g_{l+1} + w G
         y = b0 if l % 2 == 0 else b1
         plain.append((lambda g=g, y=y, alpha=alpha: ops.spmm_raw(csr, g, y=y, alpha=alpha, z=G, beta=w), csr, D))
         g, alpha = y, 1.0
     avg_spmm_ms, model_bytes, compulsory = time_spmm_calls(ops, plain)
+    mean_ms = None
+    if use_mean:                                     # the last forward propagate with the whole layer mean in its epilogue
+        mean_ms, _, _ = time_spmm_calls(ops, [(lambda: ops.spmm_mean_raw(csr, xs[-1], xs, w, fin), csr, D)])
     adam_ms = None
     if fused and D <= 256:                           # the last backward propagate with the Adam epilogue, on copies
         pc, mc, vc = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
@@ -332,7 +343,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     roofline = {"bound": "hbm", "kernel": spmm_kernel_name(D), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": model_bytes,
                 "avg_launch_us": avg_spmm_ms * 1e3, "compulsory_bytes_per_launch": compulsory,
-                "launches_per_step": 2 * L - (1 if adam_ms is not None else 0),
+                "launches_per_step": len(plain),
                 "note": ("embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is against "
                          "the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)" % table_mb)
                 if table_mb < 256 else
@@ -340,6 +351,11 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                  "no-reuse CSR model bytes, `traffic` (when present) the measured FETCH_SIZE+WRITE_SIZE bytes" % table_mb)}
     if traffic:
         roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
+    if mean_ms is not None:
+        mean_bytes = model_bytes + (L - 1) * N * D * 4               # + the earlier layers' rows (x_L itself is not stored)
+        roofline["layer_mean_launch"] = {"kernel": spmm_kernel_name(D) + " (chaorec_spmm_csr_mean_f32)",
+                                         "avg_launch_us": mean_ms * 1e3, "algorithmic_bytes": mean_bytes,
+                                         "achieved_GBps": mean_bytes / (mean_ms * 1e-3) / 1e9}
     if adam_ms is not None:
         adam_bytes = model_bytes + 6 * N * D * 4 - N * D * 4        # + p, m, v read and written, - the y store
         roofline["adam_epilogue_launch"] = {"kernel": spmm_kernel_name(D, True), "avg_launch_us": adam_ms * 1e3,
@@ -374,8 +390,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     score_ms, st, host_ms, state = early_ms, early_st, early_host_ms, f"after {steps_done} training steps"
     extra = trained_steps - steps_done
     if extra > 0 and extra * ms_per_step < 10_000:
-        for i in range(extra):
-            step(steps_done + i)
+        run_steps(extra)
         score_ms, st, host_ms = time_ranklist()
         state = f"after {trained_steps} training steps ({extra} of them untimed, past the measured ones)"
     tf = 2.0 * U * I * D / (score_ms * 1e-3) / 1e12

@@ -28,6 +28,9 @@ SIGNATURES = {
     "chaorec_spmm_csr_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr, c_ptr,
                                             ctypes.c_float, c_ptr, ctypes.c_int32, c_ptr]),
+    "chaorec_spmm_csr_mean_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
+                                                 ctypes.c_int32, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_float, c_ptr,
+                                                 ctypes.c_int32, c_ptr]),
     "chaorec_spmm_csr_adam_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr,
                                                  ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float,
@@ -36,7 +39,8 @@ SIGNATURES = {
     "chaorec_bpr_fwd_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64,
                                                ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr,
                                                c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
-                                               c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+                                               c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                               ctypes.c_float, ctypes.c_float, c_ptr, c_ptr]),
     "chaorec_bpr_finalize_f32": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr,
                                                 c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr,
                                                 c_ptr]),

@@ -121,9 +121,17 @@ __global__ __launch_bounds__(256) void bpr_fwd_bwd_drawn_kernel(
     const int64_t *__restrict__ in_users, const int64_t *__restrict__ in_pos, const int64_t *__restrict__ in_neg,
     int64_t *__restrict__ out_users, int64_t *__restrict__ out_pos, int64_t *__restrict__ out_neg, int B, int D,
     int variant, float reg_weight, float *__restrict__ coef, float *__restrict__ ws, const int64_t *__restrict__ perm,
-    const int64_t *__restrict__ perm_pos, float *g_u, float *g_i) {
+    const int64_t *__restrict__ perm_pos, float *g_u, float *g_i, int32_t *__restrict__ adam_step, float beta1,
+    float beta2, float *__restrict__ adam_bc) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // the optimizer's step count and this step's bias corrections (two double pow()s on one otherwise idle thread,
+  // under the other lanes' draw + gathers): nothing else in this launch reads them, the Adam epilogue comes later
+  if (adam_step && blockIdx.x == 0 && threadIdx.x == blockDim.x - 1) {
+    const int st = adam_step[0] + 1;
+    adam_step[0] = st;
+    adam_bias_corrections(st, beta1, beta2, adam_bc[0], adam_bc[1]);
+  }
   if (b >= B) return;
   int64_t u = 0, p = 0, n = 0;
   if (edges) {
@@ -379,8 +387,9 @@ extern "C" int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, c
                                        int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
                                        int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
                                        const int64_t *perm, const int64_t *perm_pos, float *g_u, float *g_i,
-                                       void *stream) {
+                                       int32_t *adam_step, float beta1, float beta2, float *adam_bc, void *stream) {
   if (!tab_u || !tab_i || !coef || !workspace || !g_u || !g_i) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: NULL argument");
+  if (adam_step && !adam_bc) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: adam_step without adam_bc");
   if (edges) {
     if (!hist_rowptr || !out_users || !out_pos || !out_neg) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: NULL draw argument");
     if (n_edges <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: bad sizes");
@@ -393,7 +402,7 @@ extern "C" int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, c
   hipLaunchKernelGGL(bpr_fwd_bwd_drawn_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u, tab_i, edges,
                      n_edges, hist_rowptr, hist_col, num_user, (uint32_t)num_item, seed, step, step_dev, in_users, in_pos,
                      in_neg, out_users, out_pos, out_neg, B, D, variant, reg_weight, coef, workspace, perm, perm_pos, g_u,
-                     g_i);
+                     g_i, adam_step, beta1, beta2, adam_bc);
   return check_launch("bpr_fwd_bwd_drawn_kernel");
 }
 

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     const float *__restrict__ val, const float *__restrict__ x, float *__restrict__ y,
     int64_t n_rows, int D4, float alpha, const float *z, float beta,
     float *acc, const float *__restrict__ acc_init, float acc_w,
-    const int32_t *__restrict__ sched, int64_t n_groups, int dyn_val, const AdamEpi ae) {
+    const int32_t *__restrict__ sched, int64_t n_groups, int dyn_val, const AdamEpi ae,
+    const float *__restrict__ mean_t1, const float *__restrict__ mean_t2) {
   constexpr int NG = kWave / LPR;   // lane groups = destination rows per wave
   constexpr int UNR = CHAOREC_SPMM_UNR;  // gathered rows in flight per group (short-row phase)
   constexpr int UNR2 = (kWave / NG) < 16 ? (kWave / NG) : 16;  // per group in the long-row phase
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   const float4 *init4 = reinterpret_cast<const float4 *>(acc_init);
   float4 *acc4 = reinterpret_cast<float4 *>(acc);
   float4 zpre[CPL], apre[CPL];
+  float4 tpre[(LPR <= 16 && !ADAM) ? CPL : 1];
   float4 ppre[ADAM ? CPL : 1], mpre[ADAM ? CPL : 1], vpre[ADAM ? CPL : 1];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
@@ -144,6 +146,12 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
       const size_t o = (size_t)r * (size_t)D4 + chunk;
       if (z) zpre[q] = z4[o];
       if (acc) apre[q] = acc_init ? init4[o] : acc4[o];
+      // whole layer mean in ONE epilogue (the last forward propagate): the earlier layers' rows ride in the slots of
+      // the unused z operand and (narrow rows only: register budget) one extra slot
+      if (mean_t1) zpre[q] = reinterpret_cast<const float4 *>(mean_t1)[o];
+      if constexpr (LPR <= 16 && !ADAM) {
+        if (mean_t2) tpre[q] = reinterpret_cast<const float4 *>(mean_t2)[o];
+      }
       if constexpr (ADAM) {
         ppre[q] = reinterpret_cast<const float4 *>(ae.p)[o];
         mpre[q] = reinterpret_cast<const float4 *>(ae.m)[o];
@@ -388,7 +396,11 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     if (z) s = add_rn4(s, mul_rn4(beta, zpre[q]));
     if (y) y4[o] = s;
     if (acc) {
-      const float4 a0 = acc_init ? mul_rn4(acc_w, apre[q]) : apre[q];
+      float4 a0 = acc_init ? mul_rn4(acc_w, apre[q]) : apre[q];
+      if (mean_t1) a0 = add_rn4(a0, mul_rn4(acc_w, zpre[q]));
+      if constexpr (LPR <= 16 && !ADAM) {
+        if (mean_t2) a0 = add_rn4(a0, mul_rn4(acc_w, tpre[q]));
+      }
       acc4[o] = add_rn4(a0, mul_rn4(acc_w, s));
     }
     if constexpr (ADAM) {
@@ -411,23 +423,25 @@ template <int LPR, int CPL>
 static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                        float *y, int64_t n_rows, int D4, float alpha, const float *z, float beta,
                        float *acc, const float *acc_init, float acc_w, const int32_t *sched, int dyn_val,
-                       hipStream_t st, const AdamEpi *adam = nullptr) {
+                       hipStream_t st, const AdamEpi *adam = nullptr, const float *mean_t1 = nullptr,
+                       const float *mean_t2 = nullptr) {
   constexpr int RPW = kWave / LPR;
   const int64_t waves = (n_rows + RPW - 1) / RPW;
   const int64_t blocks = (waves + 3) / 4;     // the schedule has exactly 4 * blocks wave slots
   if (blocks > 0x7fffffffLL) return fail(CHAOREC_E_INVALID, "spmm: grid too large");
+  if (mean_t2 && LPR > 16) return fail(CHAOREC_E_INVALID, "spmm: three mean terms need D <= 64");
   if (adam) {
     if constexpr (CPL == 1) {
       hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, true>), dim3((unsigned)blocks), dim3(256), 0, st,
                          rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
-                         waves, dyn_val, *adam);
+                         waves, dyn_val, *adam, (const float *)nullptr, (const float *)nullptr);
     } else {
       return fail(CHAOREC_E_INVALID, "spmm+adam: D > 256 not built");
     }
   } else {
     hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, false>), dim3((unsigned)blocks), dim3(256), 0, st,
                        rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
-                       waves, dyn_val, AdamEpi{});
+                       waves, dyn_val, AdamEpi{}, mean_t1, mean_t2);
   }
   return check_launch("spmm_csr_ordered_kernel");
 }
@@ -446,7 +460,8 @@ using namespace chaorec;
 static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float *val, const float *x, float *y,
                          int64_t n_rows, int64_t n_cols, int32_t D, float alpha, const float *z, float beta,
                          float *acc, const float *acc_init, float acc_w, const int32_t *schedule, int32_t mode,
-                         void *stream, const AdamEpi *adam) {
+                         void *stream, const AdamEpi *adam, const float *mean_t1 = nullptr,
+                         const float *mean_t2 = nullptr) {
   if (!rowptr || !x || (!y && !acc && !adam)) return fail(CHAOREC_E_INVALID, "spmm: NULL rowptr/x or no output");
   if (n_rows < 0 || n_cols < 0) return fail(CHAOREC_E_INVALID, "spmm: negative size");
   if (D < 4 || D > 1024 || (D & 3)) return fail(CHAOREC_E_INVALID, "spmm: D=%d must be a multiple of 4 in [4,1024]", D);
@@ -456,7 +471,7 @@ static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float 
   if (n_rows == 0) return CHAOREC_OK;
   hipStream_t st = (hipStream_t)stream;
   const int D4 = D / 4;
-#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, dyn_val, st, adam
+#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, dyn_val, st, adam, mean_t1, mean_t2
   if (D4 <= 1) return launch_spmm<1, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 2) return launch_spmm<2, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 4) return launch_spmm<4, 1>(CHAOREC_SPMM_ARGS);
@@ -477,6 +492,18 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
                                     int32_t mode, void *stream) {
   return spmm_dispatch(rowptr, col, val, x, y, n_rows, n_cols, D, alpha, z, beta, acc, acc_init, acc_w, schedule, mode,
                        stream, nullptr);
+}
+
+extern "C" int chaorec_spmm_csr_mean_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
+                                         float *y, int64_t n_rows, int64_t n_cols, int32_t D, float *mean_out,
+                                         const float *const *terms, int32_t n_terms, float w, const int32_t *schedule,
+                                         int32_t mode, void *stream) {
+  if (!mean_out || !terms || n_terms < 1 || n_terms > 3 || !terms[0]) return fail(CHAOREC_E_INVALID, "spmm_mean: bad terms");
+  for (int k = 0; k < n_terms; ++k)
+    if (!terms[k]) return fail(CHAOREC_E_INVALID, "spmm_mean: NULL term %d", k);
+  if (n_terms == 3 && D > 64) return fail(CHAOREC_E_INVALID, "spmm_mean: three terms need D <= 64 (D=%d)", D);
+  return spmm_dispatch(rowptr, col, val, x, y, n_rows, n_cols, D, 1.0f, nullptr, 0.f, mean_out, terms[0], w, schedule, mode,
+                       stream, nullptr, n_terms > 1 ? terms[1] : nullptr, n_terms > 2 ? terms[2] : nullptr);
 }
 
 extern "C" int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,

@@ -59,6 +59,28 @@ def spmm_raw(csr, x, y=None, alpha=1.0, z=None, beta=0.0, acc=None, acc_init=Non
     return y
 
 
+def spmm_mean_raw(csr, x, terms, w, mean_out, y=None):
+    """mean_out = w * terms[0] + w * terms[1] + ... + w * (A x), accumulated in that order (LightGCN's layer mean in the
+    last forward propagate's epilogue, chaorec_spmm_csr_mean_f32); y (optional) receives A x."""
+    _need_cuda(csr.rowptr, x, mean_out, y, *terms)
+    x = _f32c(x)
+    D = x.shape[1]
+    if x.shape[0] != csr.n_cols:
+        raise ValueError(f"spmm_mean: x has {x.shape[0]} rows, graph has {csr.n_cols} columns")
+    ptrs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    mode = 1 if getattr(csr, "dynamic_values", False) else 0
+    rc = _lib.load().chaorec_spmm_csr_mean_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x), _ptr(y), csr.n_rows,
+                                               csr.n_cols, D, _ptr(mean_out), ctypes.cast(ptrs, ctypes.c_void_p),
+                                               len(terms), w, _ptr(csr.schedule(D)), mode, _stream())
+    _lib.check(rc, "chaorec_spmm_csr_mean_f32")
+    return mean_out
+
+
+def mean_terms_limit(D):
+    """How many earlier-layer tables the last forward propagate can fold into its epilogue for feature width D."""
+    return 3 if D <= 64 else 2
+
+
 def spmm_adam_raw(csr, x, param, exp_avg, exp_avg_sq, bias_corr, lr, betas, eps, weight_decay, alpha=1.0, z=None,
                   beta=0.0, clear_z=False, grad_out=None):
     """g = alpha * (A x) [+ beta z] and the Adam update of `param` with that gradient, row by row, in ONE launch
@@ -108,11 +130,7 @@ class _LayerMeanPropagate(torch.autograd.Function):
         final = torch.empty_like(x0)
         if n_layers == 0:
             final.copy_(x0)
-        x = x0
-        for l in range(n_layers):
-            y = torch.empty_like(x0)
-            spmm_raw(csr, x, y=y, acc=final, acc_init=x0 if l == 0 else None, acc_w=w)
-            x = y
+        forward_layers(csr, x0, n_layers, final, [torch.empty_like(x0) for _ in range(max(n_layers - 1, 0))])
         ctx.csr, ctx.n_layers, ctx.w = csr, n_layers, w
         return final
 
@@ -127,6 +145,29 @@ class _LayerMeanPropagate(torch.autograd.Function):
         for _ in range(L - 1):
             g = spmm_raw(At, g, z=G, beta=w)
         return g, None, None
+
+
+def forward_layers(csr, x0, n_layers, final, bufs):
+    """LightGCN.forward's L propagates into `final` (the layer mean, bit-identical to the reference's accumulation).
+    Few layers: x_1 .. x_{L-1} are plain SpMMs into `bufs` and the whole mean is formed in the LAST propagate's epilogue
+    (one read of every earlier layer, one write of the mean); more layers than the kernel has operand slots: the
+    per-layer acc epilogue (read-modify-write of the mean in every layer).  x_L itself is never written."""
+    L = n_layers
+    if L == 0:
+        return
+    w = 1.0 / (L + 1)
+    if L <= mean_terms_limit(x0.shape[1]):
+        xs = [x0]
+        for l in range(L - 1):
+            xs.append(spmm_raw(csr, xs[-1], y=bufs[l]))
+        spmm_mean_raw(csr, xs[-1], xs, w, final)
+        return
+    x = x0
+    for l in range(L):
+        last = l == L - 1
+        y = None if last else bufs[l]
+        spmm_raw(csr, x, y=y, acc=final, acc_init=x0 if l == 0 else None, acc_w=w, want_y=not last)
+        x = y
 
 
 def layer_mean_propagate(x0, csr, n_layers):
@@ -259,12 +300,14 @@ def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset
 
 
 def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg_weight, coef, ws, ids, edges=None, hist=None, num_user=0,
-                num_item=0, seed=0, step=0, step_dev=None, perm=None, perm_pos=None):
+                num_item=0, seed=0, step=0, step_dev=None, perm=None, perm_pos=None, adam_step=None, betas=(0.9, 0.999),
+                adam_bc=None):
     """BPR(+L2) forward terms and backward row adds in one launch (chaorec_bpr_fwd_bwd_f32) over ONE [N, D] table
     (items from row item_offset on) and its gradient buffer `grad` (same shape, zero where no sample lands).
     edges given: the batch is drawn in the launch and written to ids = (users, pos, neg); else ids are the batch
-    (LOCAL item ids).  The loss comes from bpr_finalize(ws, ...)."""
-    _need_cuda(tab, grad, coef, ws, edges, step_dev, perm, perm_pos, *ids)
+    (LOCAL item ids).  The loss comes from bpr_finalize(ws, ...).  adam_step / adam_bc: Adam's step counter is moved on
+    and the new step's bias corrections are written by this launch."""
+    _need_cuda(tab, grad, coef, ws, edges, step_dev, perm, perm_pos, adam_step, adam_bc, *ids)
     D = tab.shape[1]
     off = item_offset * D * 4
     ti, gi = ctypes.c_void_p(tab.data_ptr() + off), ctypes.c_void_p(grad.data_ptr() + off)
@@ -275,7 +318,7 @@ def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg_weight, coef, ws, ids, e
         int(seed) & (2**64 - 1), int(step), _ptr(step_dev), _ptr(None if draw else ids[0]), _ptr(None if draw else ids[1]),
         _ptr(None if draw else ids[2]), int(B), D, int(variant), float(reg_weight), _ptr(ids[0] if draw else None),
         _ptr(ids[1] if draw else None), _ptr(ids[2] if draw else None), _ptr(coef), _ptr(ws), _ptr(perm), _ptr(perm_pos),
-        _ptr(grad), gi, _stream())
+        _ptr(grad), gi, _ptr(adam_step), betas[0], betas[1], _ptr(adam_bc), _stream())
     _lib.check(rc, "chaorec_bpr_fwd_bwd_f32")
 
 

@@ -175,21 +175,25 @@ class FusedLightGCNStep:
     autograd tape and no optimizer launch, captured in one hipGraph:
 
         L x  SpMM (layer mean in the epilogue; the last one writes only the mean = model.result)
-        1 x  BPR forward + backward (batch drawn in the launch or given): gradient rows added into G
-        (side branch: the loss scalar, batch / permutation counters, Adam's step count and bias corrections)
+        1 x  BPR forward + backward (batch drawn in the launch or given): gradient rows added into G; one idle
+             thread moves Adam's step count on and computes the step's bias corrections
+        1 x  the loss scalar (single-block fixed-order reduction) + batch / permutation counters + loss bookkeeping
         L-1 x SpMM  g_l = A g_{l+1} + w G
         1 x  SpMM  g_0 = A g_1 + w G with the Adam update of the embedding table in its epilogue
 
     Same arithmetic, kernel for kernel, as LightGCN.loss_drawn()/loss_local() + backward() + FusedAdam.step(); what
     is gone: the Adam launch and its pass over the gradient (chaorec_spmm_csr_adam_f32), the per-step zero fill of the
     [N, D] batch-gradient buffer G (it is kept all-zero between steps: the last SpMM clears the rows it read),
-    the separate BPR backward launch, three counter launches and autograd's bookkeeping.  model.result is the
+    the separate BPR backward launch, three counter launches and autograd's bookkeeping.  `steps_per_replay` steps
+    are captured back to back in ONE hipGraph: consecutive replays of a graph are ~5 us apart on the device, kernels
+    inside one follow each other without a gap.  (The loss reduction stays in line: a forked capture branch for it
+    cost ~15 us of cross-queue fork/join on this stack and did not overlap.)  model.result is the
     propagated table of THIS step's forward (the reference's stale-result quirk Q4 is kept).
     The optimizer's state lives in the FusedAdam instance (same tensors, same step counter), so fused and unfused
     steps can be mixed (the short last batch of an epoch runs through the ordinary path)."""
 
     def __init__(self, model, optimizer, batch_size=1024, edges=None, seed=42, step_dev=None, perm=None, perm_pos=None,
-                 given_batch=False, loss_accum=None, capture=True):
+                 given_batch=False, loss_accum=None, capture=True, steps_per_replay=1):
         if not isinstance(optimizer, FusedAdam) or len(optimizer.param_groups) != 1:
             raise TypeError("FusedLightGCNStep needs a FusedAdam with one parameter group")
         L = model.n_layers
@@ -218,7 +222,8 @@ class FusedLightGCNStep:
         self.N, self.D = N, D
         self.m = torch.as_strided(st_u["exp_avg"], (N, D), (D, 1))
         self.v = torch.as_strided(st_u["exp_avg_sq"], (N, D), (D, 1))
-        self.buf = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(2)]   # x_l, then g_l
+        self.fbuf = [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(max(L - 1, 0))]   # x_1 .. x_{L-1}
+        self.buf = (self.fbuf + [torch.empty((N, D), dtype=torch.float32, device=dev) for _ in range(2)])[:2]   # g_l
         self.final = torch.empty((N, D), dtype=torch.float32, device=dev)
         self.G = torch.zeros((N, D), dtype=torch.float32, device=dev)       # all-zero between steps
         self.ids = tuple(torch.zeros(self.B, dtype=torch.int64, device=dev) for _ in range(3))
@@ -228,9 +233,9 @@ class FusedLightGCNStep:
         self.static_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.bc = torch.ones(2, dtype=torch.float32, device=dev)
         self.loss_accum = loss_accum
-        self.side = torch.cuda.Stream(device=dev)
+        self.steps_per_replay = int(steps_per_replay) if (capture and edges is not None) else 1
         self.replays = 0
-        self.graph = None
+        self.graph = self.graph1 = None
         if capture:
             # schedules, lazily built by the first SpMM call, must exist before capture
             model.graph.schedule(D)
@@ -242,9 +247,15 @@ class FusedLightGCNStep:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._restore_state(saved)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            self.graph1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph1):
                 self._launch()
+            self.graph = self.graph1
+            if self.steps_per_replay > 1:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    for _ in range(self.steps_per_replay):
+                        self._launch()
 
     def _counters(self):
         return [t for t in (self.step_dev, self.perm_pos, self.loss_accum, self.optimizer._step_dev) if t is not None]
@@ -265,47 +276,47 @@ class FusedLightGCNStep:
         model, opt, L, B, D = self.model, self.optimizer, self.L, self.B, self.D
         group = opt.param_groups[0]
         csr, x0, w = model.graph, model._flat, 1.0 / (L + 1)
-        x = x0
-        for l in range(L):
-            last = l == L - 1
-            y = None if last else self.buf[l & 1]
-            ops.spmm_raw(csr, x, y=y, acc=self.final, acc_init=x0 if l == 0 else None, acc_w=w, want_y=not last)
-            x = y
+        ops.forward_layers(csr, x0, L, self.final, self.fbuf)
         draw = self.edges is not None
         ops.bpr_fwd_bwd(self.final, model.num_user, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef,
                         self.ws, self.ids, edges=self.edges, hist=model.hist if draw else None, num_user=model.num_user,
                         num_item=model.num_item, seed=self.seed, step=0, step_dev=self.step_dev, perm=self.perm,
-                        perm_pos=self.perm_pos)
-        cur = torch.cuda.current_stream()
-        self.side.wait_stream(cur)
-        with torch.cuda.stream(self.side):      # off the critical path: the backward does not need the loss value
-            ops.bpr_finalize(self.ws, B, D, model.reg_weight, self.out, out_total=self.static_loss,
-                             loss_accum=self.loss_accum, advance=self.step_dev if draw else None,
-                             perm_pos=self.perm_pos if (draw and self.perm is not None) else None,
-                             adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
+                        perm_pos=self.perm_pos, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
+        ops.bpr_finalize(self.ws, B, D, model.reg_weight, self.out, out_total=self.static_loss,
+                         loss_accum=self.loss_accum, advance=self.step_dev if draw else None,
+                         perm_pos=self.perm_pos if (draw and self.perm is not None) else None)
         g, alpha = self.G, w                    # g_{L-1} = w (A G) + w G, then g_l = A g_{l+1} + w G
         for l in range(L - 1):
             y = self.buf[l & 1]
             ops.spmm_raw(csr, g, y=y, alpha=alpha, z=self.G, beta=w)
             g, alpha = y, 1.0
-        cur.wait_stream(self.side)              # the Adam epilogue reads this step's bias corrections
         ops.spmm_adam_raw(csr, g, x0, self.m, self.v, self.bc, group["lr"], group["betas"], group["eps"],
                           group["weight_decay"], alpha=alpha, z=self.G, beta=w, clear_z=L >= 2)
         if L < 2:
             self.G.zero_()                      # (the single backward SpMM gathers from G: it cannot clear it)
         model.result = self.final
 
-    def __call__(self, users=None, pos=None, neg=None):
-        """-> the step's loss (device scalar, rewritten by the next call).  users / pos / neg (GLOBAL item ids, the
-        reference's batch format) only in given_batch mode."""
+    def __call__(self, users=None, pos=None, neg=None, single=False):
+        """One replay = `steps_per_replay` training steps (single=True: exactly one, whatever the replay size) -> the
+        LAST step's loss (device scalar, rewritten by the next call; per-step sums go to loss_accum).  users / pos / neg
+        (GLOBAL item ids, the reference's batch format) only in given_batch mode."""
         if self.edges is None:
             self.ids[0].copy_(users, non_blocking=True)
             torch.sub(pos.to(self.ids[1].device), self.model.num_user, out=self.ids[1])
             torch.sub(neg.to(self.ids[2].device), self.model.num_user, out=self.ids[2])
         if self.graph is not None:
-            self.graph.replay()
+            (self.graph1 if single else self.graph).replay()
         else:
             self._launch()
         self.replays += 1
         self.model.result = self.final
+        return self.static_loss
+
+    def run(self, n_steps):
+        """n_steps training steps: whole replays first, single-step replays for the remainder."""
+        k = self.steps_per_replay
+        for _ in range(n_steps // k):
+            self()
+        for _ in range(n_steps % k):
+            self(single=True)
         return self.static_loss

@@ -78,6 +78,17 @@ int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float 
                          float *acc, const float *acc_init, float acc_w,
                          const int32_t *schedule, int32_t mode, void *stream);
 
+/* The LAST forward propagate of LightGCN.forward with the WHOLE layer mean in its epilogue (Model/LightGCN.py:86-93):
+ *     s = (A x)[r];  a = w * terms[0][r];  a = a + w * terms[k][r] (k = 1 .. n_terms-1, in order);  mean_out[r] = a + w * s
+ * -- the reference's accumulation order (final = 0 + w x_0 + w x_1 + ... + w x_L), every step rounded, so the result is
+ * bit-identical to chaorec_spmm_csr_f32's per-layer acc epilogue; what it saves is that epilogue's read-modify-write of
+ * the [N, D] mean in every earlier layer (terms = the earlier layers' outputs x_0 .. x_{L-1}, host array of DEVICE
+ * pointers, n_terms <= 3, and <= 2 for D > 64: register budget).  y may be NULL (x_L itself is not needed). */
+int chaorec_spmm_csr_mean_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
+                              float *y, int64_t n_rows, int64_t n_cols, int32_t D, float *mean_out,
+                              const float *const *terms, int32_t n_terms, float w, const int32_t *schedule,
+                              int32_t mode, void *stream);
+
 /* The LAST backward propagate of a training step with the optimizer update in its epilogue
  * (train_and_evaluate.py:46-47: loss.backward(); optimizer.step(), for a model whose parameter table IS the
  * propagate's input: LightGCN, Model/LightGCN.py:76-95):
@@ -191,7 +202,9 @@ int chaorec_bpr_fwd_drawn_f32(const float *tab_u, const float *tab_i, const int6
  * chaorec_bpr_bwd_f32 with grad_out = 1).  The batch is drawn in the launch when `edges` != NULL (exactly as
  * chaorec_bpr_fwd_drawn_f32; out_* receive the ids) or given by in_users / in_pos / in_neg (LOCAL item ids).
  * g_u / g_i must be zero wherever no sample lands.  The loss itself comes from chaorec_bpr_finalize_f32 on the
- * same workspace -- off the critical path of the backward propagates. */
+ * same workspace.  adam_step / adam_bc (optional): torch.optim.Adam's step count is incremented and the new step's
+ * bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} are written here, by one otherwise idle thread (consumed later in
+ * the step by chaorec_spmm_csr_adam_f32). */
 int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
                             const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
                             int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
@@ -199,7 +212,7 @@ int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, const int64_
                             int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
                             int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
                             const int64_t *perm, const int64_t *perm_pos, float *g_u, float *g_i,
-                            void *stream);
+                            int32_t *adam_step, float beta1, float beta2, float *adam_bc, void *stream);
 
 /* The single-block, fixed-order reduction of a BPR forward's workspace ([4, B]: terms, sum u^2, sum p^2, sum n^2)
  * into out_loss[3] = {total, bpr, reg} (+ out_total[0] = total), and the step's scalar bookkeeping, all optional:

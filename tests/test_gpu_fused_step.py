@@ -97,3 +97,46 @@ def test_fused_step_epoch_permutation_and_rank(dev):
     assert int(pos_f) == int(pos_r) == (len(edges) // 1024) * 1024
     ra, rb = fus.gene_ranklist(), ref.gene_ranklist()
     assert float((ra != rb).float().mean()) < 2e-3          # atomics-order noise can flip a near-tie, nothing more
+
+
+@pytest.mark.parametrize("D,L", [(64, 3), (64, 2), (64, 1), (128, 2), (128, 3), (64, 5), (8, 3)])
+def test_layer_mean_in_last_epilogue_is_bit_identical(dev, D, L):
+    """ops.forward_layers: the whole layer mean formed in the LAST propagate's epilogue (few layers) must equal the
+    per-layer acc epilogue bit for bit (both restate the reference's final += w * x_l order)."""
+    from chaorec_amd import graph, ops
+    d = load_interactions("baby")
+    N = d["U"] + d["I"]
+    csr = graph.lightgcn_csr(d["train"], N).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(D * 10 + L)
+    x0 = torch.randn(N, D, device=dev, generator=g) * 0.1
+    w = 1.0 / (L + 1)
+    want = torch.empty_like(x0)
+    x = x0
+    for l in range(L):
+        y = torch.empty_like(x0)
+        ops.spmm_raw(csr, x, y=y, acc=want, acc_init=x0 if l == 0 else None, acc_w=w)
+        x = y
+    got = torch.full_like(x0, float("nan"))
+    ops.forward_layers(csr, x0, L, got, [torch.empty_like(x0) for _ in range(L - 1)])
+    assert torch.equal(got, want)
+    assert torch.equal(ops.layer_mean_propagate(x0, csr, L), want)
+
+
+def test_multi_step_replay_equals_single_steps(dev):
+    from chaorec_amd.optim import FusedLightGCNStep
+    d = load_interactions("baby")
+    U, I, edges = d["U"], d["I"], d["train"]
+    (a, oa), (b, ob) = _pair(dev, U, I, edges, 64, 3)
+    edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
+    ca, cb = (torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2))
+    la, lb = (torch.zeros(1, dtype=torch.float32, device=dev) for _ in range(2))
+    sa = FusedLightGCNStep(a, oa, batch_size=1024, edges=edges_dev, seed=9, step_dev=ca, loss_accum=la, steps_per_replay=1)
+    sb = FusedLightGCNStep(b, ob, batch_size=1024, edges=edges_dev, seed=9, step_dev=cb, loss_accum=lb, steps_per_replay=4)
+    sa.run(11)
+    sb.run(11)                      # 2 replays of 4 + 3 single steps
+    assert int(ca) == int(cb) == 11 and int(oa._step_dev) == int(ob._step_dev) == 11
+    assert float(la) == pytest.approx(float(lb), rel=1e-5)
+    wa = torch.cat((a.user_embedding.weight, a.item_embedding.weight)).detach()
+    wb = torch.cat((b.user_embedding.weight, b.item_embedding.weight)).detach()
+    assert float((wa - wb).abs().max()) <= 2e-5 and float((wa - wb).abs().mean()) <= 1e-8
