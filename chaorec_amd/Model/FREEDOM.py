@@ -207,6 +207,7 @@ class FREEDOM(nn.Module):
 
     def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/FREEDOM.py:219-244 (mask value 1e-6, stale self.result)."""
-        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu)
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu,
+                                      state=ranking.state_of(self))
 
     full_sort_predict = gene_ranklist

@@ -156,6 +156,7 @@ class LayerGCN(nn.Module):
         with torch.no_grad():
             u, i = self.forward()
             self.result = torch.cat([u, i], 0)
-        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu)
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu,
+                                      state=ranking.state_of(self))
 
     full_sort_predict = gene_ranklist

@@ -122,7 +122,8 @@ class LightGCN(nn.Module):
     def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/LightGCN.py:137-162 -> LongTensor [U, topk] of GLOBAL item ids on the CPU.
         Uses the stale self.result of the last training forward, as the reference does."""
-        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu)
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu,
+                                      state=ranking.state_of(self))
 
     # north_star names full_sort_predict(); the reference method is gene_ranklist (SURVEY fact 3)
     full_sort_predict = gene_ranklist

@@ -132,6 +132,7 @@ class MMGCN(torch.nn.Module):
     def gene_ranklist(self, step=200, topk=50, to_cpu=True):
         """Model/MMGCN.py:204-244: mask value 1e-5.  The reference batches 200 users to bound its [200, I]
         score matrix; the fused kernel has no such matrix, `step` is accepted and ignored."""
-        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-5, topk, to_cpu=to_cpu)
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-5, topk, to_cpu=to_cpu,
+                                      state=ranking.state_of(self))
 
     full_sort_predict = gene_ranklist

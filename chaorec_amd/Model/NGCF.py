@@ -131,6 +131,7 @@ class NGCF(nn.Module):
 
     def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/NGCF.py:170-195 (mask value 1e-6)."""
-        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu)
+        return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu,
+                                      state=ranking.state_of(self))
 
     full_sort_predict = gene_ranklist

@@ -2,37 +2,42 @@
 //
 // The exact fp32 sweep costs 32*D MFMA cycles per 32x32 tile (v_mfma_f32_32x32x2_f32); the bf16 pipe does the same
 // tile in 2*D cycles (v_mfma_f32_32x32x16_bf16).  So the [U, I] sweep runs in bf16 and only decides WHICH items can
-// be in a user's top-K; the handful that can are re-scored in exact fp32 (the same k-ascending fmaf chain as the
-// f32 MFMA kernel / oracle_score_dot) and ranked on those values.  The result is bit-identical to the fp32 path:
+// be in a user's top-K; those are re-scored in exact fp32 (the same k-ascending fmaf chain as the f32 MFMA kernel /
+// oracle_score_dot) and ranked on those values.  The result is bit-identical to the fp32 path:
 //
 //   |s~(u,j) - s(u,j)| <= e_uj := c * ||u||_2 * ||i_j||_2,   c = 1.05 * 2^-8
 //     (two RNE bf16 roundings, 2^-9 relative each, + fp32 accumulation; Cauchy-Schwarz on sum_d |u_d||i_d|, PER ITEM:
 //      a table with a few outsized item norms does not widen the band of every other item).
-//   With e~_uj >= e_uj (bf16-rounded-up factors) let v_j = s~_j + e~_uj and w_j = s~_j - e~_uj, so w_j <= s_j <= v_j.
-//   The sweep keeps C = { j : v_j > T_u }.  If C holds >= K items, L = the K-th largest w_j over C is a lower bound
-//   of the K-th best TRUE score.  If L > T_u, every item outside C has s_j <= v_j <= T_u < L and every item of C
-//   with v_j < L has s_j < L: K items beat them strictly, none is in the top-K whatever the tie order.  So
-//   R = { j in C : v_j >= L } holds the whole exact top-K.  T_u comes from the sampler, which ranks w_j.
-//   Both v and w come out of the MFMA: the item side of an extra k-step carries (1, ||i_j||), the user side
-//   (T_u, -c||u||) in the sweep -- the accumulator is T_u - v_j, a hit is its sign bit -- and (0, -c||u||) in the
-//   sampler -- the accumulator is w_j.
-//   Masked (history) items carry mask_value exactly in both domains (error 0).
+//   With e~_uj >= e_uj (bf16-rounded-up factors) v_j = s~_j + e~_uj is an upper bound of the exact score s_j.
+//   The sweep keeps C = { j : v_j > T_u }: every item with s_j > T_u is in C.  The selection computes the EXACT score
+//   of every member of C (history members carry mask_value instead) and takes the top-K of those.  If the K-th best
+//   of them is > T_u, every item outside C has s_j <= v_j <= T_u < K-th best: it is strictly beaten by K items, so it
+//   is not in the top-K whatever the tie order.  T_u may be ANY value: a good one keeps C small, a bad one fails the
+//   certification and the user is retried / handed to the exact route; it never changes the result.
+//   The threshold rides on the MFMA: the item side of an extra k-step carries (1, ||i_j||), the user side
+//   (T_u, -c||u||) in the sweep -- with the users' fragments negated the accumulator is T_u - v_j, a hit is its sign
+//   bit -- and (0, -c||u||) in the sampler (accumulator = the lower bound w_j = s~_j - e~_uj).
 //
-// Pipeline (all on one stream, no host round trip):
-//   pack      items -> bf16 MFMA A-fragments (one coalesced 1 KiB wave load per k-step), max item norm
-//   sample    per user a threshold tau0 from every 4th tile, RAW scores (the rank is shifted by the number of
-//             history items in the sample): lane-local top-4 of the first 8 tiles gives a loose tau1, scores above
-//             it go to a 24-entry per-lane LDS list, a bisection pooled over the user's two lanes finds a value
-//             with >= r sample scores above it; mean over 4 sample splits (4 waves per user block)
-//   sweep     one wave = UB x 32 users (fragments in registers, stored negated), tiles interleaved over the
-//             splits; a 5th k-step adds the bf16 threshold, so a hit is the accumulator's sign bit; hits
-//             s~ > theta_u = bf16_floor(tau0 - 2 m_u) are appended to the lane's own global list as raw
-//             (item, score bits) pairs -- unmasked: the history is reconciled by the selection
-//   select    one wave per user: history members leave the candidates and the whole history returns with
-//             mask_value; a_K by ballot/popcount radix select; certification (>= K keys, a_K - 2 m_u > theta_u,
-//             no list overflow, |R| <= 128); exact fp32 re-score of R; one register bitonic sort; top-K out.
-//             Users with more than 512 keys are queued on the device for a 1024-slot instantiation; uncertified
-//             users are flagged and re-run by the exact fp32 sweep (score_topk_f32_kernel, kModeFallback).
+// Where T_u comes from:
+//   hint     the caller's per-user thresholds from the PREVIOUS call on (nearly) the same tables -- the exact score
+//            of rank hint_rank (> K) then.  One training epoch moves the scores little: ~1.7 K candidates per user
+//            instead of ~3.5 K, and no sampling pass at all.  (chaorec_score_topk_hinted_f32)
+//   sample   per user a threshold from every 4th tile (4 sample splits): the first call, and the RETRY pass for the
+//            users whose hint failed (scores moved too much: fewer than K above T_u, or more than the selection holds).
+//
+// Pipeline (all on one stream, no host round trip; every pass after the first works on a device-side queue):
+//   pack      items -> bf16 MFMA A-fragments (one coalesced 1 KiB wave load per k-step) + the bound fragment
+//   pass A    (hint given)  sweep(T = hint) -> select: certified users are done, the others are queued
+//   pass B    sample -> sweep(T = sample) -> select over the queue (all users when there is no hint)
+//   tail      users pass B could not certify: exact fp32 scores of all items, per user (or grouped f32 MFMA sweeps for
+//             very long item ranges)
+//   sweep     one wave = UB x 32 users (fragments in registers, negated), tiles interleaved over the splits, item
+//             fragments staged once per workgroup through LDS.  Per tile and user block: 16 v_alignbit collect the
+//             sign bits; a lane with a hit appends ONE 32-bit entry (tile sequence number << 16 | hit bits) to its own
+//             list -- no scores are stored, no LDS parking, no drain loop.
+//   select    one wave per user: entries -> item ids (popcount / prefix sums), history members dropped, exact fp32
+//             score per candidate (one candidate per lane, user row by scalar loads), register bitonic sort,
+//             certification, top-K out, next call's hint out.
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -60,13 +65,14 @@ __device__ __forceinline__ uint4 bf16_pack8(const float4 a, const float4 b) {
 
 constexpr int kPfFbGroupCap = 512;   // queued users the grouped f32 fallback takes (16 groups of 32)
 constexpr float kBf16ErrCoef = 1.05f / 256.0f;
-constexpr int kPfCap = 64;        // keys per (split, user, half) list of the sweep
-constexpr int kPfMaxRescore = 128;
+constexpr int kPfCap = 64;           // 32-bit entries per (split, user, half) list of the sweep
+constexpr int kPfMaxCand = 512;      // candidates per user the selection holds (8 per lane)
+constexpr int kPfMaxSplits = 16;
 
 struct PrefArgs {
   const float *user_emb;
   const float *item_emb;
-  const uint4 *packed;          // [n_tiles][D/16][64] bf16x8 fragments
+  const uint4 *packed;          // [n_tiles][D/16 + 1][64] bf16x8 fragments
   int64_t n_users, n_items;
   const int64_t *hist_rowptr;
   const int32_t *hist_col;
@@ -75,10 +81,10 @@ struct PrefArgs {
   int64_t id_offset;
   float *item_norm;             // [n_tiles * 32] ||i_j||_2 rounded UP to a bf16 value (0 for padding rows)
   float *tau_sum;               // [U] sampled threshold: mean over the sample splits (atomicAdd of est / splits)
-  float *theta;                 // [U] sweep threshold (written by sweep split 0)
-  float *margin;                // [U] c * ||u||_2 rounded UP to a bf16 value: e~_uj = margin[u] * item_norm[j]
-  uint64_t *cand;               // [splits][U][2][kPfCap] raw entries: low word item, high word score bits
+  float *theta;                 // [U] the threshold the sweep used (written by sweep split 0)
+  uint32_t *cand;               // [splits][U][2][kPfCap] entries: (tile sequence number << 16) | hit bits
   int *cand_cnt;                // [splits][U][2]
+  int *n_cand;                  // [U] candidates the selection expanded (statistics)
   int splits;                   // sweep splits (tiles interleaved)
   int sample_stride;            // every sample_stride-th tile is sampled ...
   int sample_splits;            // ... dealt round-robin to this many sampler waves per user block
@@ -86,8 +92,14 @@ struct PrefArgs {
   int64_t *out_idx;
   float *out_val;
   int *fail;
-  int *heavy_cnt;               // users queued for the 1024-slot selection
-  int *heavy_list;              // [U]
+  // compact passes: row i of the launch is user user_map[i], only the first *n_active rows exist (NULL = identity / all)
+  const int *user_map;
+  const int *n_active;
+  const float *hint_in;         // [U] thresholds carried from the previous call (pass A), else NULL: tau_sum
+  float *hint_out;              // [U] thresholds for the next call, or NULL
+  int hint_rank;                // the rank (> K, <= 128) whose exact score becomes the next threshold
+  int *retry_cnt;               // users pass A could not certify -> pass B (NULL: uncertified users go to the exact route)
+  int *retry_list;              // [U]
   int *fb_cnt;                  // users queued for the exact per-user route
   int *fb_list;                 // [U]
   int *fb_done;                 // [U] slices finished per queued user (zeroed per call)
@@ -274,8 +286,11 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
   int *hs_s = hs_all[wv];
   const int ur = lane & 31, h = lane >> 5;
   const int64_t ublock = (int64_t)blockIdx.x * WG + wv;
-  const int64_t u = ublock * 32 + ur;
-  const bool u_ok = u < P.n_users;
+  const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
+  if ((int64_t)blockIdx.x * WG * 32 >= n_act) return;    // (only a compact pass has empty workgroups)
+  const int64_t uc = ublock * 32 + ur;                    // row of this launch
+  const bool u_ok = uc < n_act;
+  const int64_t u = (P.user_map && u_ok) ? (int64_t)P.user_map[uc] : uc;   // row of the tables
   const uint32_t n_items = (uint32_t)P.n_items;
   const int n_tiles = (int)((P.n_items + 31) / 32);
   const int split = blockIdx.y;
@@ -306,7 +321,16 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
   // (counted by the whole wave over the block's contiguous CSR range: a per-lane walk of the own row is a chain of
   //  dependent loads as long as the heaviest user's history)
   int h_s = 0;
-  if (P.hist_rowptr) {
+  if (P.hist_rowptr && P.user_map) {
+    // compact pass: the block's users are scattered over the CSR; every lane walks its own user's row (both lanes of
+    // a user do the same walk: the pass is small, simplicity over speed)
+    if (u_ok) {
+      for (int64_t e = P.hist_rowptr[u]; e < P.hist_rowptr[u + 1]; ++e) {
+        const int tt = (int)((uint32_t)P.hist_col[e] >> 5);
+        if (tt >= t_first && (tt - t_first) % step == 0) ++h_s;
+      }
+    }
+  } else if (P.hist_rowptr) {
     const int64_t ub = ublock * 32;
     if (lane < 33) rp_s[lane] = P.hist_rowptr[min(ub + lane, P.n_users)];
     if (lane < 32) hs_s[lane] = 0;
@@ -449,20 +473,15 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
 }
 
 // ---- sweep ---------------------------------------------------------------------------------------------------
-// No history handling here: an interacted item is swept like any other (its raw score may or may not pass the
-// threshold); the selection drops every history member from the candidates and adds the user's whole history
-// back with mask_value, which is exactly the masked score row restricted to what can matter.
+// No history handling here: an interacted item is swept like any other; the selection drops history members from the
+// candidates and ranks the user's history with mask_value where that can matter.
 //
-// The loop body has to stay small: with the hit handling unrolled per accumulator register (16 x UB x 2 copies of
-// compare / branch / key / store) the loop was ~45 KB of ISA and the waves starved on instruction fetch.  Here a
-// tile's 16 compares become one bit mask per lane (v_sub + v_alignbit each), the scores are parked in a 4 KiB LDS
-// scratch ([reg][lane]) and ONE drain loop per user block stores the hits: every iteration is one store
-// instruction for all lanes that still hold a hit.
 // The threshold compare rides on the MFMA: the users' fragments are stored NEGATED and an extra k-step multiplies the
 // items' (1, ||i_j||) with the users' (T_u, -c||u||) (bf16, T_u rounded toward -inf, the norms rounded up), so the
-// accumulator holds T_u - v_j, v_j = s~_j + e~_uj the upper bound of the score, and a hit is its sign bit (1 VALU op
-// per score instead of a subtract and a shift-in).  The list keeps v_j = T_u - acc; the extra rounding (2^-23
-// relative) is inside kBf16ErrCoef.
+// accumulator holds T_u - v_j, v_j = s~_j + e~_uj the upper bound of the score, and a hit is its SIGN BIT: one
+// v_alignbit per accumulator register builds the lane's 16-bit hit mask.  A lane with a hit appends one 32-bit entry
+// (this split's tile sequence number << 16 | mask) to its own global list; the exact scores are computed by the
+// selection, so nothing else leaves the sweep: ~24 VALU instructions per tile and user block next to 5 MFMAs.
 __device__ __forceinline__ float bf16_floor(float x) {  // largest bf16-representable value <= x
   const uint32_t b = __float_as_uint(x);
   uint32_t t = b & 0xFFFF0000u;
@@ -480,25 +499,26 @@ constexpr int kSweepStage = 2;
 template <int D, int UB>
 __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(const PrefArgs P) {
   constexpr int FR = D / 16 + 1;                       // fragments (1 KiB each) per tile
-  __shared__ float4 park_all[kSweepWaves][4 * 64];     // per wave: [quad][lane], registers 4*quad .. 4*quad+3
   __shared__ uint4 stage[2][kSweepStage][FR * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float4 *park = park_all[wv];
   const int ur = lane & 31, h = lane >> 5;
+  const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
+  if ((int64_t)blockIdx.x * kSweepWaves * UB * 32 >= n_act) return;   // (only a compact pass has empty workgroups)
   const int64_t ublock0 = ((int64_t)blockIdx.x * kSweepWaves + wv) * UB;
   const uint32_t n_items = (uint32_t)P.n_items;
   const int n_tiles = (int)((P.n_items + 31) / 32);
   const int split = blockIdx.y;
   const int splits = P.splits;
+  const float *thr_src = P.hint_in ? P.hint_in : P.tau_sum;
 
   bf16x8 bu[UB][D / 16], bth[UB];
-  float theta[UB];
   int cnt[UB];
-  uint2 *mine[UB];
+  uint32_t *mine[UB];
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
-    const int64_t u = (ublock0 + b) * 32 + ur;
-    const bool ok = u < P.n_users;
+    const int64_t uc = (ublock0 + b) * 32 + ur;
+    const bool ok = uc < n_act;
+    const int64_t u = (P.user_map && ok) ? (int64_t)P.user_map[uc] : uc;
     float n2;
     load_user_frags<D>(bu[b], n2, P.user_emb, u, ok, h);
 #pragma unroll
@@ -515,22 +535,19 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
     const float cu = bf16_ceil_pos(kBf16ErrCoef * sqrtf(n2) + 1e-30f);   // e~_uj = cu * item_norm[j]
     float th = INFINITY;  // padding users never qualify
     if (ok) {
-      th = bf16_floor(P.tau_sum[u]);     // T_u: the sampler's estimate already lives in the lower-bound (w) domain
-      if (split == 0 && h == 0) {
-        P.theta[u] = th;
-        P.margin[u] = cu;
-      }
+      th = thr_src[u];
+      th = (th == th) ? bf16_floor(th) : -INFINITY;    // (a NaN threshold = none: every item is a candidate, the user fails over)
+      if (split == 0 && h == 0) P.theta[u] = th;
     }
-    theta[b] = th;
     // user side of the bound k-step: (T_u, -c||u||) against the items' (1, ||i_j||)
     Frag16 ft;
     ft.u = make_uint4(h == 0 ? ((__float_as_uint(th) >> 16) | (((__float_as_uint(cu) >> 16) | 0x8000u) << 16)) : 0u, 0u, 0u, 0u);
     bth[b] = ft.v;
     cnt[b] = 0;
-    mine[b] = reinterpret_cast<uint2 *>(P.cand) + (((size_t)split * P.n_users + (ok ? u : 0)) * 2 + h) * kPfCap;
+    mine[b] = P.cand + (((size_t)split * P.n_users + (ok ? u : 0)) * 2 + h) * kPfCap;
   }
 
-  auto consume = [&](const uint4 (&a)[D / 16 + 1], int t) __attribute__((always_inline)) {
+  auto consume = [&](const uint4 (&a)[D / 16 + 1], int t, int seq) __attribute__((always_inline)) {
     const uint32_t j0 = (uint32_t)t * 32u;
     // all UB accumulation chains first, k-step major: UB independent MFMAs between two dependent ones
     f32x16 accs[UB];
@@ -562,36 +579,14 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
           if (j0 + off >= n_items) acc[reg] = INFINITY;   // rows past the table never qualify
         }
       }
-      // bit (15 - reg) <=> s~ > theta~: the accumulator's sign bit
+      // bit (15 - reg) <=> v_j > T_u: the accumulator's sign bit
       uint32_t qbits = 0;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(acc[reg]), 31);
-      if (__any(qbits != 0)) {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-          park[q4 * 64 + lane] = make_float4(acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]);
-        __builtin_amdgcn_wave_barrier();
-        const float *pk = reinterpret_cast<const float *>(park);
-        do {
-          // up to two hits per lane and round, both LDS reads in flight together; raw (item, score bits) entries:
-          // the order-preserving key is built by the selection, 64 keys per instruction.  Past kPfCap entries are
-          // counted, not stored: the selection sees the overflow and flags the user.
-          const bool h1 = qbits != 0;
-          const int bit1 = h1 ? 31 - __clz(qbits) : 0;
-          const uint32_t q1 = h1 ? (qbits & ~(1u << bit1)) : 0u;
-          const bool h2 = q1 != 0;
-          const int bit2 = h2 ? 31 - __clz(q1) : 0;
-          qbits = h2 ? (q1 & ~(1u << bit2)) : 0u;
-          const int r1 = 15 - bit1, r2 = 15 - bit2;
-          const float v1 = pk[((r1 >> 2) * 64 + lane) * 4 + (r1 & 3)];
-          const float v2 = pk[((r2 >> 2) * 64 + lane) * 4 + (r2 & 3)];
-          if (h1 && cnt[b] < kPfCap)
-            mine[b][cnt[b]] = make_uint2(j0 + (r1 & 3) + 8 * (r1 >> 2) + 4 * h, __float_as_uint(theta[b] - v1));
-          if (h2 && cnt[b] + 1 < kPfCap)
-            mine[b][cnt[b] + 1] = make_uint2(j0 + (r2 & 3) + 8 * (r2 >> 2) + 4 * h, __float_as_uint(theta[b] - v2));
-          cnt[b] += (h1 ? 1 : 0) + (h2 ? 1 : 0);
-        } while (__any(qbits != 0));
-        __builtin_amdgcn_wave_barrier();
+      if (qbits) {
+        // past kPfCap entries are counted, not stored: the selection sees the overflow and flags the user
+        if (cnt[b] < kPfCap) mine[b][cnt[b]] = ((uint32_t)seq << 16) | qbits;
+        ++cnt[b];
       }
     }
   };
@@ -630,12 +625,13 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
     if (s0 + 1 < n_stages) fetch(s0 + 1);
 #pragma unroll
     for (int i = 0; i < kSweepStage; ++i) {
-      const int t = split + (kSweepStage * s0 + i) * splits;
+      const int seq = kSweepStage * s0 + i;
+      const int t = split + seq * splits;
       if (t < n_tiles) {                                          // block-uniform
         uint4 a[FR];
 #pragma unroll
         for (int q = 0; q < FR; ++q) a[q] = stage[buf][i][q * 64 + lane];
-        consume(a, t);
+        consume(a, t, seq);
       }
     }
     if (s0 + 1 < n_stages) stash(buf ^ 1);
@@ -643,8 +639,11 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   }
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
-    const int64_t u = (ublock0 + b) * 32 + ur;
-    if (u < P.n_users) P.cand_cnt[((size_t)split * P.n_users + u) * 2 + h] = cnt[b];
+    const int64_t uc = (ublock0 + b) * 32 + ur;
+    if (uc < n_act) {
+      const int64_t u = P.user_map ? (int64_t)P.user_map[uc] : uc;
+      P.cand_cnt[((size_t)split * P.n_users + u) * 2 + h] = cnt[b];
+    }
   }
 }
 
@@ -670,19 +669,37 @@ __device__ __forceinline__ float exact_score(const float *__restrict__ urow, con
   return acc;
 }
 
-// A value with at least K keys at or above it: the K-th largest score key truncated to its top BITS bits (a coarser
-// grid only widens the re-score band by 2^-(BITS-9) relative; the count condition is what the proof needs).
-template <int NR, int NRmax, int BITS>
-__device__ __forceinline__ uint32_t kth_largest_ord(const uint64_t (&k)[NRmax], int K) {
-  uint32_t prefix = 0;
-  for (int bit = 31; bit >= 32 - BITS; --bit) {
-    const uint32_t candv = prefix | (1u << bit);
+// The `rank`-th largest 64-bit key (keys unique, 0 = none; at least `rank` non-zero keys): bitwise search with wave
+// ballots and scalar popcounts, 32 steps on the score word, up to 32 more on the index word when a tie straddles the rank.
+template <int NR>
+__device__ __forceinline__ uint64_t kth_largest_key(const uint64_t (&k)[NR], int rank) {
+  uint32_t T = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t candv = T | (1u << bit);
     int c = 0;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) c += __popcll(__ballot((uint32_t)(k[r] >> 32) >= candv && k[r] != 0ull));
-    if (c >= K) prefix = candv;
+    for (int r = 0; r < NR; ++r) c += __popcll(__ballot(k[r] != 0ull && (uint32_t)(k[r] >> 32) >= candv));
+    if (c >= rank) T = candv;
   }
-  return prefix;
+  int gt = 0, eq = 0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    gt += __popcll(__ballot(k[r] != 0ull && (uint32_t)(k[r] >> 32) > T));
+    eq += __popcll(__ballot(k[r] != 0ull && (uint32_t)(k[r] >> 32) == T));
+  }
+  const int need = rank - gt;      // >= 1
+  uint32_t L = 0;
+  if (eq > need) {
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t candv = L | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        c += __popcll(__ballot(k[r] != 0ull && (uint32_t)(k[r] >> 32) == T && (uint32_t)k[r] >= candv));
+      if (c >= need) L = candv;
+    }
+  }
+  return ((uint64_t)T << 32) | (uint64_t)L;
 }
 
 // Wave-wide descending bitonic sort of 64 keys, one per lane.
@@ -700,18 +717,26 @@ __device__ __forceinline__ void sort64_desc(uint64_t &e, int lane) {
   }
 }
 
-constexpr int kPfHistLds = 1024;
+constexpr int kPfHistLds = 1024;            // longest history the exact per-user route keeps in LDS
+constexpr int kPfSelHist = 256;             // ... and the selection (longer histories are searched in global memory)
+constexpr int kPfSelNR = kPfMaxCand / 64;   // keys per lane on the many-candidates path
 
-// NRmax = 8 keys per lane (512 per user) runs at 8 waves per SIMD; the rare user with more (a long history on top of
-// the candidates) is flagged 3 and picked up by a second launch with NRmax = 16 (`second` = only flagged users).
-template <int D, int NRmax>
-__device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int64_t u, int *incl_s, uint32_t *keep_item,
-                                                    uint32_t *hist_s) {
+// reason codes (non-zero = not certified): 1 a sweep list overflowed, 2 fewer than K candidates, 3 more candidates
+// than the selection holds, 4 the K-th best exact score does not clear the sweep threshold
+//
+// LDS of one selection wave (4 KiB + 1 KiB): words [0, 64) the lists' prefix sums, words [64, 64 + 512) the candidate
+// item ids; on the many-candidates path the same block is overwritten IN PLACE by the 64-bit keys (key i = words 2i,
+// 2i+1; rounds run from the last to the first, so a round never overwrites an id that is still to be read).
+template <int D>
+__device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, uint32_t *lds, uint32_t *hist_s,
+                                            float *urow_s) {
   const int lane = threadIdx.x;
   const int K = P.K;
-  const int n_lists = 2 * P.splits;  // <= 64
+  const int n_lists = 2 * P.splits;  // <= 32
+  int *incl_s = reinterpret_cast<int *>(lds);
+  uint32_t *cand_s = lds + 64;
+  uint64_t *key_s = reinterpret_cast<uint64_t *>(lds);
 
-  // list lengths: lane l owns list l = (split, half)
   int c = 0;
   if (lane < n_lists) c = P.cand_cnt[((size_t)(lane >> 1) * P.n_users + u) * 2 + (lane & 1)];
   int64_t hb = 0, he = 0;
@@ -720,36 +745,29 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
     he = P.hist_rowptr[u + 1];
   }
   const int deg = (int)(he - hb);
-  const float cu = P.margin[u], theta = P.theta[u];   // e~_uj = cu * item_norm[j];  theta = T_u
+  const bool hist_lds = deg <= kPfSelHist;
+  const float theta = P.theta[u];
   const bool overflow = __any(c > kPfCap);
   int incl = c;
   for (int o = 1; o < 64; o <<= 1) {
     const int v = __shfl_up(incl, o, 64);
     if (lane >= o) incl += v;
   }
-  const int total = __shfl(incl, 63, 64);
-  // reason codes (nonzero = re-run on the fp32 route): 1 list overflow, 2 fewer than K candidates, 3 more than 64*NRmax,
-  // 4 L does not clear the sweep threshold, 5 more than 128 items whose upper bound reaches L
-  // (the user's history is copied to LDS for the membership tests; it joins the candidates only when mask_value can
-  //  reach the top-K, see below)
-  int why = overflow ? 1 : (total + deg < K ? 2 : ((total > 64 * NRmax || deg > kPfHistLds) ? 3 : 0));
-  uint64_t e0 = 0ull, e1 = 0ull;
+  const int total = __shfl(incl, 63, 64);          // entries (each holds >= 1 candidate)
+  int why = overflow ? 1 : (total > kPfMaxCand ? 3 : 0);
+  int n_cand = 0;
   if (why == 0) {
     incl_s[lane] = incl;
-    for (int i = lane; i < deg; i += 64) hist_s[i] = (uint32_t)P.hist_col[hb + i];
+    if (hist_lds)
+      for (int i = lane; i < deg; i += 64) hist_s[i] = (uint32_t)P.hist_col[hb + i];
+    // the user's row through LDS (broadcast reads in the score chain): 64 / 128 scalar registers held across the
+    // whole selection made the compiler spill
+    for (int i = lane; i < D; i += 64) urow_s[i] = P.user_emb[(size_t)u * D + i];
     __builtin_amdgcn_wave_barrier();
-    // every candidate key straight into registers: entry e of the user's concatenated lists sits in list
-    // l = first list with incl[l] > e (lane-local binary search in LDS), all loads in flight together
-    const uint2 *cand2 = reinterpret_cast<const uint2 *>(P.cand);
-    // key = (ord(w_j) << 32) | ~item with w_j = v_j - 2 e~_uj the lower bound of the score; vv = the stored upper bound
-    uint64_t k[NRmax];
-    float vv[NRmax];
-#pragma unroll
-    for (int r = 0; r < NRmax; ++r) {
-      k[r] = 0ull;
-      vv[r] = -INFINITY;
-      if (64 * r >= total) continue;   // wave-uniform: cost follows the actual key count
-      const int e = lane + 64 * r;
+    // entries -> item ids, in list order: entry e sits in list l = first list with incl[l] > e
+    for (int base = 0; base < total; base += 64) {
+      const int e = base + lane;
+      uint32_t bits = 0, j0 = 0;
       if (e < total) {
         int lo = 0, hi = 63;
 #pragma unroll
@@ -758,95 +776,145 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
           if (incl_s[mid] > e) hi = mid; else lo = mid + 1;
         }
         const int pos = e - (lo ? incl_s[lo - 1] : 0);
-        const uint2 raw = cand2[(((size_t)(lo >> 1) * P.n_users + u) * 2 + (lo & 1)) * kPfCap + pos];
-        vv[r] = __uint_as_float(raw.y);
-        k[r] = make_key(vv[r] - 2.0f * (cu * P.item_norm[raw.x]), raw.x);
-        // the sweep ran unmasked: a history member leaves the candidates here
-        int l2 = 0, h2 = deg;
-        while (l2 < h2) {
-          const int mid = (l2 + h2) >> 1;
-          if (hist_s[mid] < raw.x) l2 = mid + 1; else h2 = mid;
-        }
-        if (l2 < deg && hist_s[l2] == raw.x) k[r] = 0ull;
+        const uint32_t raw = P.cand[(((size_t)(lo >> 1) * P.n_users + u) * 2 + (lo & 1)) * kPfCap + pos];
+        bits = raw & 0xFFFFu;
+        j0 = ((uint32_t)(lo >> 1) + (raw >> 16) * (uint32_t)P.splits) * 32u + 4u * (uint32_t)(lo & 1);
       }
+      int pc = __popc(bits), ex = pc;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(ex, o, 64);
+        if (lane >= o) ex += v;
+      }
+      const int tot = __shfl(ex, 63, 64);
+      int slot = n_cand + ex - pc;
+      while (bits) {
+        const int bit = 31 - __clz(bits);
+        bits &= ~(1u << bit);
+        const int reg = 15 - bit;
+        if (slot < kPfMaxCand) cand_s[slot] = j0 + (uint32_t)((reg & 3) + 8 * (reg >> 2));
+        ++slot;
+      }
+      n_cand += tot;
     }
-    // L: a value that the lower bounds w of at least K entries of the masked row reach.  First over the unmasked
-    // candidates alone: the history's entries (all equal to mask_value, error 0) can only raise the row's K-th best,
-    // so this is a valid, possibly low, L.  Only if mask_value itself reaches L (the reference's 1e-6 / 1e-5 does when
-    // every real score is tiny or negative: quirk Q7) does the history join the keys, and L is taken again.
-    int total2 = total;
-    auto kth = [&](int n_keys) -> uint32_t {
-      if (n_keys <= 128) return kth_largest_ord<2, NRmax, 20>(k, K);
-      if (n_keys <= 256) return kth_largest_ord<4, NRmax, 20>(k, K);
-      if (n_keys <= 512 || NRmax <= 8) return kth_largest_ord<8, NRmax, 20>(k, K);
-      return kth_largest_ord<NRmax, NRmax, 20>(k, K);
+    if (n_cand > kPfMaxCand) why = 3;
+  }
+  uint64_t e0 = 0ull, e1 = 0ull;
+  int n_keys = 0;
+  if (why == 0) {
+    __builtin_amdgcn_wave_barrier();
+    const float *urow = urow_s;
+    auto in_hist = [&](uint32_t item) -> bool {
+      int lo = 0, hi = deg;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t hv = hist_lds ? hist_s[mid] : (uint32_t)P.hist_col[hb + mid];
+        if (hv < item) lo = mid + 1; else hi = mid;
+      }
+      return lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
     };
-    int valid = 0;
-#pragma unroll
-    for (int r = 0; r < NRmax; ++r) valid += __popcll(__ballot(k[r] != 0ull));
-    uint32_t T = valid >= K ? kth(total) : 0u;
-    const bool hist_matters = deg > 0 && (valid < K || P.mask_value >= ord_to_f32(T));
-    if (hist_matters) {   // wave-uniform
-      if (total + deg > 64 * NRmax) {
+    // exact score of candidate idx as a sortable key; a history member leaves the candidates here (the sweep ran
+    // unmasked) -- the history comes back below, with mask_value, only when that can matter
+    auto score_key = [&](int idx) -> uint64_t {
+      if (idx >= n_cand) return 0ull;
+      const uint32_t item = cand_s[idx];
+      if (in_hist(item)) return 0ull;
+      return make_key(exact_score<D>(urow, P.item_emb + (size_t)item * D), item);
+    };
+    const uint32_t mord = f32_to_ord(P.mask_value);
+    int valid, above;
+    bool small = n_cand <= 128;   // wave-uniform
+    if (small) {
+      e0 = score_key(lane);
+      if (n_cand > 64) e1 = score_key(lane + 64);
+      valid = __popcll(__ballot(e0 != 0ull)) + __popcll(__ballot(e1 != 0ull));
+      above = __popcll(__ballot(e0 != 0ull && (uint32_t)(e0 >> 32) > mord)) +
+              __popcll(__ballot(e1 != 0ull && (uint32_t)(e1 >> 32) > mord));
+    } else {
+      // many candidates: keys replace the ids in LDS, last round first (see the layout note above)
+      valid = above = 0;
+      for (int r = (n_cand - 1) >> 6; r >= 0; --r) {
+        const uint64_t k = score_key(lane + 64 * r);
+        __builtin_amdgcn_wave_barrier();
+        key_s[lane + 64 * r] = k;
+        valid += __popcll(__ballot(k != 0ull));
+        above += __popcll(__ballot(k != 0ull && (uint32_t)(k >> 32) > mord));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    n_keys = valid;
+    int n_slots = n_cand;         // key slots in use
+    // The masked row restricted to what can matter = the candidates + the user's history at mask_value.  The history
+    // only joins when mask_value can reach the top-K (the reference's 1e-6 / 1e-5 does when the real scores are tiny
+    // or negative: quirk Q7), i.e. when fewer than K candidates beat it.
+    if (deg > 0 && above < K) {   // wave-uniform
+      if (n_cand + deg > kPfMaxCand) {
         why = 3;
       } else {
-#pragma unroll
-        for (int r = 0; r < NRmax; ++r) {
-          const int e = lane + 64 * r;
-          if (e >= total && e < total + deg) {
-            k[r] = make_key(P.mask_value, hist_s[e - total]);
-            vv[r] = P.mask_value;
-          }
+        if (small) {              // move the keys to LDS first (slots lane, lane + 64)
+          key_s[lane] = e0;
+          key_s[lane + 64] = e1;
+          n_slots = n_cand > 64 ? 128 : 64;
         }
-        total2 = total + deg;
-        valid += deg;
-        T = valid >= K ? kth(total2) : 0u;
+        for (int i = lane; i < deg; i += 64)
+          key_s[n_slots + i] = make_key(P.mask_value, hist_lds ? hist_s[i] : (uint32_t)P.hist_col[hb + i]);
+        __builtin_amdgcn_wave_barrier();
+        n_slots += deg;
+        n_keys = valid + deg;
+        if (n_slots <= 128) {
+          e0 = lane < n_slots ? key_s[lane] : 0ull;
+          e1 = lane + 64 < n_slots ? key_s[lane + 64] : 0ull;
+          small = true;
+        } else {
+          small = false;
+        }
       }
     }
-    if (why == 0 && valid < K) why = 2;
-    const float cutoff = ord_to_f32(T);   // L (20-bit grid: at or below the exact K-th largest w)
-    if (why == 0 && !(cutoff > theta)) why = 4;  // L <= T_u: an item the sweep rejected (v <= T_u) could reach L
-    // survivors: approximate score >= cutoff
-    int base2 = 0;
-#pragma unroll
-    for (int r = 0; r < NRmax; ++r) {
-      if (64 * r >= total2) continue;
-      const bool keep = k[r] != 0ull && vv[r] >= cutoff;   // upper bound reaches L
-      const unsigned long long mk = __ballot(keep);
-      const int pos = base2 + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
-      if (keep && pos < kPfMaxRescore) keep_item[pos] = 0xFFFFFFFFu - (uint32_t)(k[r] & 0xFFFFFFFFull);
-      base2 += __popcll(mk);
-    }
-    if (base2 > kPfMaxRescore && why == 0) why = 5;
-    __builtin_amdgcn_wave_barrier();
+    if (why == 0 && n_keys < K) why = 2;
     if (why == 0) {
-      const float *urow = P.user_emb + (size_t)u * D;
-      auto rescore = [&](int idx) -> uint64_t {
-        if (idx >= base2) return 0ull;
-        const uint32_t item = keep_item[idx];
-        int lo = 0, hi = deg;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (hist_s[mid] < item) lo = mid + 1; else hi = mid;
-        }
-        const bool masked = lo < deg && hist_s[lo] == item;
-        const float s = masked ? P.mask_value : exact_score<D>(urow, P.item_emb + (size_t)item * D);
-        return make_key(s, item);
-      };
-      e0 = rescore(lane);
-      if (base2 > 64) {
-        e1 = rescore(lane + 64);
-        sort128_desc(e0, e1, lane);
+      const int want = min(max(P.hint_rank, K), min(n_keys, 128));   // ranks kept: the top-K and the next call's threshold
+      if (small) {
+        if (n_slots <= 64) sort64_desc(e0, lane);
+        else sort128_desc(e0, e1, lane);
       } else {
-        sort64_desc(e0, lane);
+        // keys >= the want-th largest (exactly `want` of them: keys are unique), compacted through LDS, one sort
+        uint64_t k[kPfSelNR];
+#pragma unroll
+        for (int r = 0; r < kPfSelNR; ++r) k[r] = (lane + 64 * r < n_slots) ? key_s[lane + 64 * r] : 0ull;
+        const uint64_t thr = kth_largest_key<kPfSelNR>(k, want);
+        __builtin_amdgcn_wave_barrier();
+        int base = 0;
+#pragma unroll
+        for (int r = 0; r < kPfSelNR; ++r) {
+          const bool w = k[r] != 0ull && k[r] >= thr;
+          const unsigned long long m = __ballot(w);
+          if (w) key_s[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = k[r];
+          base += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        e0 = lane < base ? key_s[lane] : 0ull;
+        e1 = lane + 64 < base ? key_s[lane + 64] : 0ull;
+        sort128_desc(e0, e1, lane);
+      }
+      // certification: the K-th best exact score must clear the threshold the sweep used
+      const uint64_t kth = shfl_u64(e0, K - 1);
+      if (kth == 0ull || !(ord_to_f32((uint32_t)(kth >> 32)) > theta)) why = 4;
+      if (why == 0 && P.hint_out) {
+        // next call's threshold: one float below the exact score of rank `want` (>= K): equal scores stay candidates
+        const int r1 = want - 1;
+        const uint64_t hk = r1 < 64 ? shfl_u64(e0, r1) : shfl_u64(e1, r1 - 64);
+        if (lane == 0) P.hint_out[u] = nextafterf(ord_to_f32((uint32_t)(hk >> 32)), -INFINITY);
       }
     }
   }
+  __builtin_amdgcn_wave_barrier();
   if (lane == 0) {
     P.fail[u] = why;
-    // more keys than this instantiation holds: queue the user for the wide one instead of the fp32 route
-    if (why == 3 && NRmax <= 8 && deg <= kPfHistLds) P.heavy_list[atomicAdd(P.heavy_cnt, 1)] = (int)u;
-    else if (why != 0) P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;   // not certifiable: exact per-user route
+    P.n_cand[u] = n_cand;
+    if (why != 0) {
+      // not certifiable from this threshold: retry with a sampled one (pass A) or take the exact per-user route
+      if (P.retry_cnt) P.retry_list[atomicAdd(P.retry_cnt, 1)] = (int)u;
+      else P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;
+    }
   }
   if (why == 0 && lane < K) {
     const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
@@ -855,25 +923,16 @@ __device__ __forceinline__ void select_rescore_user(const PrefArgs &P, const int
   }
 }
 
-// One wave per user, 512 key slots, 8 waves per SIMD.
+// One wave per user (a fixed grid walking the rows of the pass), 7 waves per SIMD (5.5 KiB of LDS each).
 template <int D>
-__global__ __launch_bounds__(64, 8) void score_select_rescore_kernel(const PrefArgs P) {
-  __shared__ int incl_s[64];
-  __shared__ uint32_t keep_item[kPfMaxRescore];
-  __shared__ uint32_t hist_s[kPfHistLds];
-  select_rescore_user<D, 8>(P, (int64_t)blockIdx.x, incl_s, keep_item, hist_s);
-}
-
-// The users the narrow pass queued (a long history on top of the candidates): 1024 key slots, a fixed small grid
-// walking the device-side queue -- no host round trip, no launch of one idle wave per user.
-template <int D>
-__global__ __launch_bounds__(64, 4) void score_select_rescore_wide_kernel(const PrefArgs P) {
-  __shared__ int incl_s[64];
-  __shared__ uint32_t keep_item[kPfMaxRescore];
-  __shared__ uint32_t hist_s[kPfHistLds];
-  const int n = *P.heavy_cnt;
-  for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    select_rescore_user<D, 16>(P, (int64_t)P.heavy_list[i], incl_s, keep_item, hist_s);
+__global__ __launch_bounds__(64, 7) void score_select_kernel_pf(const PrefArgs P) {
+  __shared__ uint64_t lds64[kPfMaxCand];               // 4 KiB: prefix sums + candidate ids, or the 64-bit keys
+  __shared__ uint32_t hist_s[kPfSelHist];
+  __shared__ float4 urow_s[D / 4];
+  const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
+  for (int64_t i = blockIdx.x; i < n_act; i += gridDim.x) {
+    const int64_t u = P.user_map ? (int64_t)P.user_map[i] : i;
+    select_user<D>(P, u, reinterpret_cast<uint32_t *>(lds64), hist_s, reinterpret_cast<float *>(urow_s));
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -1029,30 +1088,28 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
         P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;
         P.out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e >> 32));
       }
+      // (a user that needed the exact route keeps a threshold that lets everything through next time: K-th best, one below)
+      if (P.hint_out && lane == K - 1) P.hint_out[u] = nextafterf(ord_to_f32((uint32_t)(e >> 32)), -INFINITY);
     }
   }
 }
 
 // ---- statistics of the last prefilter call (monitoring / tuning) ------------------------------------------------
-// out[0] users sent to the fp32 fallback, out[1] candidate keys in total, out[2] longest list, out[3] users,
-// out[4..8] fallback users by reason code 1..5 (score_select_rescore_kernel)
+// out[0] users sent to the exact route, out[1] candidates in total, out[2] longest sweep list (entries), out[3] users,
+// out[4..8] uncertified users of the LAST selection pass by reason code 1..5 (select_user)
 __global__ __launch_bounds__(256) void score_prefilter_stats_kernel(const int *__restrict__ fail,
-                                                                    const int *__restrict__ cand_cnt, int64_t n_users,
+                                                                    const int *__restrict__ cand_cnt,
+                                                                    const int *__restrict__ n_cand, int64_t n_users,
                                                                     int splits, unsigned long long *__restrict__ out) {
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_users) return;
-  unsigned long long tot = 0;
   int mx = 0;
-  for (int l = 0; l < 2 * splits; ++l) {
-    const int c = cand_cnt[((size_t)(l >> 1) * n_users + u) * 2 + (l & 1)];
-    tot += (unsigned long long)c;
-    mx = max(mx, c);
-  }
+  for (int l = 0; l < 2 * splits; ++l) mx = max(mx, cand_cnt[((size_t)(l >> 1) * n_users + u) * 2 + (l & 1)]);
   if (fail[u]) {
     atomicAdd(out + 0, 1ull);
     atomicAdd(out + 3 + min(fail[u], 5), 1ull);
   }
-  atomicAdd(out + 1, tot);
+  atomicAdd(out + 1, (unsigned long long)n_cand[u]);
   atomicMax(out + 2, (unsigned long long)mx);
   atomicAdd(out + 3, 1ull);
 }

@@ -802,11 +802,11 @@ struct ScorePlan {
   bool prefilter;
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
   bool pf_sample_long;
-  size_t off_pf_heavy, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
+  size_t off_pf_retry, off_pf_ncand, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
   bool pf_group_fb;            // large item ranges: the first kPfFbGroupCap queued users share f32 MFMA sweeps
   int pf_group_fb_splits;
   size_t off_pf_fbgroup;
-  size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_margin, off_pf_cand, off_pf_cnt;
+  size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_cand, off_pf_cnt;
   size_t off_packed, off_tau, off_tau1, off_fail, off_partial, off_cand, off_cnt, total;
 };
 
@@ -872,7 +872,7 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
     }
   }
   // bf16 prefilter + exact re-score: D in {64, 128}, enough tiles for the sampler's statistics
-  p.prefilter = (D == 64 || D == 128) && K <= 64 && n_tiles >= 128;
+  p.prefilter = (D == 64 || D == 128) && K <= 64 && n_tiles >= 128 && n_tiles <= (int64_t)65535 * kPfMaxSplits;
   p.pf_ub = D == 64 ? CHAOREC_PF_UB64 : CHAOREC_PF_UB128;
   {
     const int64_t ublocks = (groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves);   // workgroups per split
@@ -880,10 +880,11 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
     // round costs a whole wave time
     int64_t sp = sweep_wave_slots(D) / ublocks;
     // ~200 candidates per user (~300 with the coarser sample of very long item ranges) over 2 * splits lists of
-    // kPfCap = 64: keep the lists short
+    // kPfCap = 64 entries: keep the lists short
     const int64_t sp_min = n_tiles > 16384 ? 10 : 6;
     if (sp < sp_min) sp = sp_min;
-    if (sp > 16) sp = 16;
+    if (sp > kPfMaxSplits) sp = kPfMaxSplits;
+    while (sp < kPfMaxSplits && (n_tiles + sp - 1) / sp > 65535) ++sp;   // (an entry holds a 16-bit tile sequence number)
     if (sp > n_tiles / 16) sp = n_tiles / 16;
     if (sp < 1) sp = 1;
     p.pf_splits = (int)sp;
@@ -905,7 +906,8 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.off_pf_tau = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fbdone = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.pf_zero_bytes = o - p.off_pf_scalars;
-  p.off_pf_heavy = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_retry = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_ncand = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fb = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fbpart = take(p.prefilter ? (size_t)n_users * kExSlices * kMaxK * 8 : 0);
   // The per-user exact route streams the whole item table once per queued user (1 GB per user at 2 M x 128): past
@@ -915,10 +917,9 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.pf_group_fb_splits = (int)std::min<int64_t>(256, std::max<int64_t>(1, n_tiles / 64));
   p.off_pf_fbgroup = take(p.pf_group_fb ? (size_t)p.pf_group_fb_splits * kPfFbGroupCap * (size_t)K * 8 : 0);
   p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
-  p.off_pf_margin = take(p.prefilter ? (size_t)n_users * 4 : 0);
   // (sized for the most splits any device plan uses, so that the CPU-side query and the device plan agree)
-  p.off_pf_cand = take(p.prefilter ? (size_t)16 * (size_t)n_users * 2 * kPfCap * 8 : 0);
-  p.off_pf_cnt = take(p.prefilter ? (size_t)16 * (size_t)n_users * 2 * 4 : 0);
+  p.off_pf_cand = take(p.prefilter ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * kPfCap * 4 : 0);
+  p.off_pf_cnt = take(p.prefilter ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * 4 : 0);
   p.off_packed = take(p.pack ? (size_t)n_tiles * 32 * (size_t)D * 4 : 0);
   p.off_tau = take(p.sample ? (size_t)n_users * 4 : 0);
   p.off_tau1 = take(p.sample ? (size_t)n_users * 4 : 0);
@@ -956,6 +957,13 @@ static int dispatch_score(int D, const ScoreArgs &a, dim3 grid, hipStream_t st) 
 
 using namespace chaorec;
 
+extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_emb, int64_t n_users,
+                                      int64_t n_items, int32_t D, const int64_t *hist_rowptr,
+                                      const int32_t *hist_col, float mask_value, int32_t K,
+                                      int64_t id_offset, int64_t *out_idx, float *out_val,
+                                      void *workspace, size_t workspace_bytes, int32_t precision,
+                                      void *stream);
+
 extern "C" size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_items, int32_t K, int32_t D) {
   if (n_users <= 0 || n_items <= 0 || K <= 0 || D <= 0) return 0;
   return plan_score(n_users, n_items, K, D).total;
@@ -971,17 +979,17 @@ extern "C" int chaorec_score_topk_stats(const void *workspace, int64_t n_users, 
   if (!p.prefilter) return CHAOREC_OK;   // all zeros: the call did not take the prefilter route
   const char *ws = (const char *)workspace;
   hipLaunchKernelGGL(score_prefilter_stats_kernel, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, st,
-                     (const int *)(ws + p.off_fail), (const int *)(ws + p.off_pf_cnt), n_users, p.pf_splits,
-                     (unsigned long long *)out9);
+                     (const int *)(ws + p.off_fail), (const int *)(ws + p.off_pf_cnt), (const int *)(ws + p.off_pf_ncand),
+                     n_users, p.pf_splits, (unsigned long long *)out9);
   return check_launch("score_prefilter_stats_kernel");
 }
 
-extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_emb, int64_t n_users,
-                                      int64_t n_items, int32_t D, const int64_t *hist_rowptr,
-                                      const int32_t *hist_col, float mask_value, int32_t K,
-                                      int64_t id_offset, int64_t *out_idx, float *out_val,
-                                      void *workspace, size_t workspace_bytes, int32_t precision,
-                                      void *stream) {
+static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t n_users,
+                           int64_t n_items, int32_t D, const int64_t *hist_rowptr,
+                           const int32_t *hist_col, float mask_value, int32_t K,
+                           int64_t id_offset, int64_t *out_idx, float *out_val,
+                           void *workspace, size_t workspace_bytes, int32_t precision,
+                           const float *hint_in, float *hint_out, int32_t hint_rank, void *stream) {
   if (!user_emb || !item_emb || !out_idx || !out_val) return fail(CHAOREC_E_INVALID, "score_topk: NULL argument");
   if (n_users < 0 || n_items <= 0) return fail(CHAOREC_E_INVALID, "score_topk: bad sizes");
   if (K < 1 || K > kMaxK) return fail(CHAOREC_E_INVALID, "score_topk: K=%d must be in [1,%d]", K, kMaxK);
@@ -1044,16 +1052,16 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.K = K;
     P.id_offset = id_offset;
     P.item_norm = (float *)(ws + p.off_pf_inorm);
-    P.heavy_cnt = (int *)(ws + p.off_pf_scalars + 64);
-    P.heavy_list = (int *)(ws + p.off_pf_heavy);
+    P.retry_cnt = nullptr;
+    P.retry_list = (int *)(ws + p.off_pf_retry);
+    P.n_cand = (int *)(ws + p.off_pf_ncand);
     P.fb_cnt = (int *)(ws + p.off_pf_scalars + 128);
     P.fb_list = (int *)(ws + p.off_pf_fb);
     P.fb_done = (int *)(ws + p.off_pf_fbdone);
     P.fb_partial = (uint64_t *)(ws + p.off_pf_fbpart);
     P.tau_sum = (float *)(ws + p.off_pf_tau);
     P.theta = (float *)(ws + p.off_pf_theta);
-    P.margin = (float *)(ws + p.off_pf_margin);
-    P.cand = (uint64_t *)(ws + p.off_pf_cand);
+    P.cand = (uint32_t *)(ws + p.off_pf_cand);
     P.cand_cnt = (int *)(ws + p.off_pf_cnt);
     P.splits = p.pf_splits;
     P.sample_stride = p.pf_sample_stride;
@@ -1061,8 +1069,14 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     P.sample_rank = p.pf_sample_rank;
     P.out_idx = out_idx;
     P.out_val = out_val;
+    P.user_map = nullptr;
+    P.n_active = nullptr;
+    P.hint_in = nullptr;
+    P.hint_out = hint_out;
+    P.hint_rank = hint_rank > K ? (hint_rank > 128 ? 128 : hint_rank) : K;
     int *failf = (int *)(ws + p.off_fail);
     P.fail = failf;
+    int *retry_cnt = (int *)(ws + p.off_pf_scalars + 64);
     const int64_t nfrag = n_tiles * (D / 16) * 64;
     hipLaunchKernelGGL(pack_items_bf16_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, item_emb,
                        (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.item_norm,
@@ -1072,19 +1086,38 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);
     const dim3 gs4((groups + 3) / 4, (unsigned)p.pf_sample_splits);
     const dim3 gw((unsigned)((groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves)), (unsigned)p.pf_splits);
-    if (D == 64) {
-      if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true, 4>), gs4, dim3(256), 0, st, P);
-      else hipLaunchKernelGGL((score_sample_bf16_kernel<64, 24, false, 1>), gs, dim3(64), 0, st, P);
-      hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64 * kSweepWaves), 0, st, P);
-      hipLaunchKernelGGL(score_select_rescore_kernel<64>, dim3((unsigned)n_users), dim3(64), 0, st, P);
-      hipLaunchKernelGGL(score_select_rescore_wide_kernel<64>, dim3(512), dim3(64), 0, st, P);
-    } else {
-      if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true, 4>), gs4, dim3(256), 0, st, P);
-      else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false, 1>), gs, dim3(64), 0, st, P);
-      hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, P);
-      hipLaunchKernelGGL(score_select_rescore_kernel<128>, dim3((unsigned)n_users), dim3(64), 0, st, P);
-      hipLaunchKernelGGL(score_select_rescore_wide_kernel<128>, dim3(512), dim3(64), 0, st, P);
+    const unsigned sel_all = (unsigned)n_users;
+    const unsigned sel_queue = (unsigned)std::min<int64_t>(n_users, 8192);    // a pass over a device-side queue
+    auto sweep = [&](const PrefArgs &A) {
+      if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64 * kSweepWaves), 0, st, A);
+      else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, A);
+    };
+    auto select = [&](const PrefArgs &A, unsigned grid) {
+      if (D == 64) hipLaunchKernelGGL(score_select_kernel_pf<64>, dim3(grid), dim3(64), 0, st, A);
+      else hipLaunchKernelGGL(score_select_kernel_pf<128>, dim3(grid), dim3(64), 0, st, A);
+    };
+    auto sample = [&](const PrefArgs &A) {
+      if (D == 64) {
+        if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true, 4>), gs4, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((score_sample_bf16_kernel<64, 24, false, 1>), gs, dim3(64), 0, st, A);
+      } else {
+        if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true, 4>), gs4, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false, 1>), gs, dim3(64), 0, st, A);
+      }
+    };
+    PrefArgs B = P;              // pass B: sampled thresholds; over the users pass A queued, or over everybody
+    if (hint_in) {
+      PrefArgs A = P;            // pass A: the carried thresholds
+      A.hint_in = hint_in;
+      A.retry_cnt = retry_cnt;
+      sweep(A);
+      select(A, sel_all);
+      B.user_map = P.retry_list;
+      B.n_active = retry_cnt;
     }
+    sample(B);
+    sweep(B);
+    select(B, hint_in ? sel_queue : sel_all);
     rc = check_launch("score prefilter kernels");
     if (rc) return rc;
     // uncertified users (list overflow, fewer than K above the threshold, band wider than the re-score slots) were
@@ -1204,4 +1237,24 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
     if (rc) return rc;
   }
   return CHAOREC_OK;
+}
+
+extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_emb, int64_t n_users,
+                                      int64_t n_items, int32_t D, const int64_t *hist_rowptr,
+                                      const int32_t *hist_col, float mask_value, int32_t K,
+                                      int64_t id_offset, int64_t *out_idx, float *out_val,
+                                      void *workspace, size_t workspace_bytes, int32_t precision,
+                                      void *stream) {
+  return score_topk_impl(user_emb, item_emb, n_users, n_items, D, hist_rowptr, hist_col, mask_value, K, id_offset, out_idx,
+                         out_val, workspace, workspace_bytes, precision, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int chaorec_score_topk_hinted_f32(const float *user_emb, const float *item_emb, int64_t n_users,
+                                             int64_t n_items, int32_t D, const int64_t *hist_rowptr,
+                                             const int32_t *hist_col, float mask_value, int32_t K,
+                                             int64_t id_offset, int64_t *out_idx, float *out_val,
+                                             void *workspace, size_t workspace_bytes, const float *hint_in,
+                                             float *hint_out, int32_t hint_rank, void *stream) {
+  return score_topk_impl(user_emb, item_emb, n_users, n_items, D, hist_rowptr, hist_col, mask_value, K, id_offset, out_idx,
+                         out_val, workspace, workspace_bytes, 0, hint_in, hint_out, hint_rank, stream);
 }

@@ -364,10 +364,13 @@ def draw_batch(edges, hist, B, num_user, num_item, seed, step, step_dev=None):
 # --------------------------------------------------------------------------------------------
 # scoring + top-K
 # --------------------------------------------------------------------------------------------
-def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0, stats=None):
+def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0, stats=None, hint=None,
+               hint_valid=False, hint_rank=80):
     """Top-K of user_emb @ item_emb.T with history masking, without the [U,I] matrix.
     Returns (idx int64 [U,K] = item + id_offset, val fp32 [U,K]).  `stats`: a dict to fill with the prefilter
-    route's counters (chaorec_score_topk_stats; costs a device sync)."""
+    route's counters (chaorec_score_topk_stats; costs a device sync).
+    hint (optional, float32 [U] on the device): per-user thresholds carried between calls
+    (chaorec_score_topk_hinted_f32): written by every call, read when hint_valid.  Never changes the result."""
     _need_cuda(user_emb, item_emb)
     user_emb, item_emb = _f32c(user_emb), _f32c(item_emb)
     U, D = user_emb.shape
@@ -380,10 +383,19 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
     rowptr, col = hist if hist is not None else (None, None)
     _need_cuda(rowptr, col)
-    rc = lib.chaorec_score_topk_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
-                                    mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
-                                    precision, _stream())
-    _lib.check(rc, "chaorec_score_topk_f32")
+    if hint is not None and precision == 0:
+        _need_cuda(hint)
+        if hint.dtype != torch.float32 or hint.numel() != U or not hint.is_contiguous():
+            raise TypeError("score_topk: hint must be a contiguous float32 [n_users] tensor")
+        rc = lib.chaorec_score_topk_hinted_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
+                                               mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
+                                               _ptr(hint if hint_valid else None), _ptr(hint), int(hint_rank), _stream())
+        _lib.check(rc, "chaorec_score_topk_hinted_f32")
+    else:
+        rc = lib.chaorec_score_topk_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
+                                        mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
+                                        precision, _stream())
+        _lib.check(rc, "chaorec_score_topk_f32")
     if stats is not None:
         out9 = torch.zeros(9, dtype=torch.int64, device=dev)
         _lib.check(lib.chaorec_score_topk_stats(_ptr(ws), U, I, K, D, _ptr(out9), _stream()), "chaorec_score_topk_stats")

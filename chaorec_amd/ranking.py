@@ -25,11 +25,41 @@ def _to_host(idx):
     return buf
 
 
-def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to_cpu=True):
+class RankState:
+    """What one model's evaluations carry from call to call: the per-user candidate thresholds of
+    chaorec_score_topk_hinted_f32 (each gene_ranklist() leaves, per user, the exact score of rank ~1.6 K for the next
+    one: one epoch of training moves the scores little, so the next call needs no sampling pass and re-scores about
+    half the candidates).  The thresholds never change a result; stale ones only cost a retry."""
+
+    def __init__(self):
+        self.hint, self.valid = None, False
+
+    def buffer(self, num_user, device):
+        if self.hint is None or self.hint.numel() != num_user or self.hint.device != device:
+            self.hint, self.valid = torch.empty(num_user, dtype=torch.float32, device=device), False
+        return self.hint
+
+
+def state_of(model):
+    """The RankState of `model` (created on first use; kept out of state_dict / parameters)."""
+    st = model.__dict__.get("_rank_state")
+    if st is None:
+        st = model.__dict__["_rank_state"] = RankState()
+    return st
+
+
+def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to_cpu=True, state=None):
     """result [N, D] (users first) on the GPU -> LongTensor [num_user, topk] of GLOBAL item ids on the CPU (the
     reference's contract); to_cpu=False keeps it in HBM for utils.gene_metrics_device."""
     with torch.no_grad():
         result = result.detach()
-        idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
-                                id_offset=num_user)
+        if state is not None:
+            hint = state.buffer(num_user, result.device)
+            idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
+                                    id_offset=num_user, hint=hint, hint_valid=state.valid,
+                                    hint_rank=max(topk + 14, (topk * 8 + 4) // 5))
+            state.valid = True
+        else:
+            idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
+                                    id_offset=num_user)
     return _to_host(idx) if to_cpu else idx

@@ -30,7 +30,8 @@ extern "C" {
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
-                                  stand-alone BPR finalize with loss / optimizer bookkeeping */
+                                  stand-alone BPR finalize with loss / optimizer bookkeeping, layer mean in the last
+                                  forward SpMM, scoring with carried thresholds */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -244,10 +245,12 @@ int chaorec_bpr_finalize_f32(const float *workspace, int32_t B, int32_t D, float
  * `precision` selects the route to it:
  *   0  fastest exact route.  D in {64, 128} and >= 4096 items: the [U, I] sweep runs on the bf16 MFMA pipe
  *      (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate) as a PREFILTER with a proven per-item error bound
- *      |s~ - s| <= e_uj = 1.05 * 2^-8 * ||u|| * ||i_j||: with L a lower bound of the K-th best exact score (the K-th
- *      largest s~ - e over the candidates), every item with s~ + e >= L is re-scored with the exact fp32 chain and
- *      the top-K is ranked on those values; a user the bound cannot certify (list overflow, too few candidates, more
- *      than 128 items to re-score) gets all its scores computed exactly.  Otherwise: route 2.
+ *      |s~ - s| <= e_uj = 1.05 * 2^-8 * ||u|| * ||i_j||: every item whose upper bound s~ + e exceeds a per-user
+ *      threshold T_u becomes a candidate, every candidate is re-scored with the exact fp32 chain and the top-K is
+ *      ranked on those values; the answer is certified when the K-th best exact score is > T_u (anything outside
+ *      the candidates is then strictly beaten by K items).  T_u is estimated from a sample of the items; a user that
+ *      cannot be certified (list overflow, too few / too many candidates) gets all its scores computed exactly.
+ *      Otherwise: route 2.
  *   1  one unthresholded fp32 MFMA pass (A/B runs and tests).
  *   2  fp32 MFMA sweep with a sampled per-user threshold: tau0 = 32nd best score over every s-th 32-item tile,
  *      the full pass keeps only scores above it, a certification step counts them and any user with fewer
@@ -268,11 +271,30 @@ int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
                            void *workspace, size_t workspace_bytes,
                            int32_t precision, void *stream);
 
-/* Monitoring: what the prefilter route of the LAST chaorec_score_topk_f32 call on this workspace did (same sizes).
- * out9 (device, 9 x uint64): [0] users re-run on the fp32 route, [1] candidate keys kept by the bf16 sweep in
- * total, [2] longest per-lane list, [3] users, [4..8] re-run users by reason (list overflow, fewer than K
- * candidates, more than the key slots, lower bound L not above the sweep threshold, more than 128 items to re-score).
- * All zeros if that call did not take the prefilter route. */
+/* chaorec_score_topk_f32 (route 0) with the per-user thresholds CARRIED from one call to the next: an evaluation
+ * loop ranks the same users once per epoch (train_and_evaluate.py:655-659) and one epoch moves the scores little.
+ *   hint_out (optional, [n_users] float, device): receives, per user, one float below the exact score of rank
+ *            hint_rank (K < hint_rank <= 128; 80 is a good value for K = 50) -- the next call's threshold.
+ *   hint_in  (optional): such an array from the previous call (may alias hint_out).  Pass A sweeps with T_u = hint_in
+ *            (no sampling pass, about half the candidates of a sampled threshold); users it cannot certify -- scores
+ *            moved too much since -- are queued on the device and retried with a sampled threshold (pass B), then, if
+ *            need be, ranked exactly.  hint_in == NULL: pass B for everybody (= chaorec_score_topk_f32).
+ * A threshold never changes the result, only the work: the output is bit-identical to chaorec_score_topk_f32's
+ * whatever the hints hold (NaN / inf / stale values included).  Needs the prefilter route (D in {64,128}, >= 4096
+ * items, K <= 64); otherwise the hints are ignored and hint_out is left untouched. */
+int chaorec_score_topk_hinted_f32(const float *user_emb, const float *item_emb,
+                                  int64_t n_users, int64_t n_items, int32_t D,
+                                  const int64_t *hist_rowptr, const int32_t *hist_col,
+                                  float mask_value, int32_t K, int64_t id_offset,
+                                  int64_t *out_idx, float *out_val,
+                                  void *workspace, size_t workspace_bytes,
+                                  const float *hint_in, float *hint_out, int32_t hint_rank, void *stream);
+
+/* Monitoring: what the prefilter route of the LAST scoring call on this workspace did (same sizes).
+ * out9 (device, 9 x uint64): [0] users handed to the exact route, [1] candidates re-scored in total, [2] longest
+ * per-lane sweep list (entries), [3] users, [4..8] users the last selection pass could not certify, by reason (list
+ * overflow, fewer than K candidates, more candidates than the selection holds, K-th best not above the sweep
+ * threshold, unused).  All zeros if that call did not take the prefilter route. */
 int chaorec_score_topk_stats(const void *workspace, int64_t n_users, int64_t n_items, int32_t K, int32_t D,
                              uint64_t *out9, void *stream);
 

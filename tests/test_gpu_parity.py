@@ -356,6 +356,23 @@ def _check_all_precisions(dev, oracle, ue, ie, hist, mask, K, id_offset=0):
         got_i, got_v = ops.score_topk(tu, ti, dh, mask, K, id_offset=id_offset, precision=precision)
         assert np.array_equal(got_v.cpu().numpy(), want_v), precision     # exact fp32 values, not bf16 ones
         assert np.array_equal(got_i.cpu().numpy(), want_i), precision
+    # thresholds carried between calls (chaorec_score_topk_hinted_f32) never change the result, whatever they hold:
+    # the previous call's own hints, and hints built to fail in every way (too high, too low, NaN, garbage)
+    U = ue.shape[0]
+    hint = torch.empty(U, dtype=torch.float32, device=dev)
+    rng = np.random.default_rng(U)
+    garbage = torch.from_numpy((rng.standard_normal(U) * 3).astype(np.float32)).to(dev)
+    checks = [("first", None), ("carried", "keep"), ("+inf", torch.full_like(hint, float("inf"))),
+              ("-inf", torch.full_like(hint, float("-inf"))), ("nan", torch.full_like(hint, float("nan"))),
+              ("garbage", garbage), ("huge", torch.full_like(hint, 3e38)), ("zero", torch.zeros_like(hint)),
+              ("carried again", "keep")]
+    for name, h in checks:
+        valid = h is not None
+        if valid and not isinstance(h, str):
+            hint.copy_(h)
+        got_i, got_v = ops.score_topk(tu, ti, dh, mask, K, id_offset=id_offset, hint=hint, hint_valid=valid)
+        assert np.array_equal(got_v.cpu().numpy(), want_v), name
+        assert np.array_equal(got_i.cpu().numpy(), want_i), name
 
 
 @pytest.mark.parametrize("U,I,D,K", [(150, 9000, 64, 50), (70, 8200, 128, 20), (33, 12000, 64, 64),
@@ -416,6 +433,37 @@ def test_score_topk_prefilter_adversarial(dev, oracle):
     # (g) negative scores everywhere with the positive mask value (Q7) and no history at all
     _check_all_precisions(dev, oracle, np.abs(base_u), -np.abs(base_i), hist, 1e-6, K)
     _check_all_precisions(dev, oracle, base_u, base_i, None, 0.0, K)
+
+
+def test_score_topk_carried_thresholds_cut_the_work(dev, oracle):
+    """Second call on slightly moved tables with the first call's hints: no user needs the retry pass or the exact
+    route, about K * 1.6 + a band of candidates per user instead of the sampled threshold's several K; a call on
+    tables that moved A LOT is still exact (retry pass)."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(5)
+    U, I, D, K = 2000, 15207, 64, 50
+    ue = (rng.standard_normal((U, D)) * 0.3).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * 0.3).astype(np.float32)
+    hist = _hist_random(U, I, 30, seed=2)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    tu, ti = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
+    hint = torch.empty(U, dtype=torch.float32, device=dev)
+    st0, st1, st2 = {}, {}, {}
+    ops.score_topk(tu, ti, dh, 1e-6, K, id_offset=U, hint=hint, hint_valid=False, stats=st0)
+    ue2 = (ue + rng.standard_normal((U, D)).astype(np.float32) * 0.003).astype(np.float32)     # "one epoch later"
+    ie2 = (ie + rng.standard_normal((I, D)).astype(np.float32) * 0.003).astype(np.float32)
+    want_i, want_v = oracle.score_topk(ue2, ie2, hist, 1e-6, K, U)
+    gi, gv = ops.score_topk(torch.from_numpy(ue2).to(dev), torch.from_numpy(ie2).to(dev), dh, 1e-6, K, id_offset=U,
+                            hint=hint, hint_valid=True, stats=st1)
+    assert np.array_equal(gi.cpu().numpy(), want_i) and np.array_equal(gv.cpu().numpy(), want_v)
+    assert st1["fallback_users"] == 0, st1
+    assert st1["candidates"] / U < 0.75 * st0["candidates"] / U and st1["candidates"] / U < 3 * K, (st0, st1)
+    ue3 = (ue * 0.3 + rng.standard_normal((U, D)).astype(np.float32) * 0.2).astype(np.float32)   # a different model
+    want_i, want_v = oracle.score_topk(ue3, ie2, hist, 1e-6, K, U)
+    gi, gv = ops.score_topk(torch.from_numpy(ue3).to(dev), torch.from_numpy(ie2).to(dev), dh, 1e-6, K, id_offset=U,
+                            hint=hint, hint_valid=True, stats=st2)
+    assert np.array_equal(gi.cpu().numpy(), want_i) and np.array_equal(gv.cpu().numpy(), want_v)
+    print("candidates per user: sampled", st0["candidates"] / U, "carried", st1["candidates"] / U, "stale", st2)
 
 
 def test_score_topk_single_pass_equals_sampled(dev):
