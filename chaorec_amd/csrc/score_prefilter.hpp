@@ -66,7 +66,8 @@ __device__ __forceinline__ uint4 bf16_pack8(const float4 a, const float4 b) {
 constexpr int kPfFbGroupCap = 512;   // queued users the grouped f32 fallback takes (16 groups of 32)
 constexpr float kBf16ErrCoef = 1.05f / 256.0f;
 constexpr int kPfCap = 64;           // 32-bit entries per (split, user, half) list of the sweep
-constexpr int kPfMaxCand = 512;      // candidates per user the selection holds (8 per lane)
+constexpr int kPfMaxCand = 512;      // candidates per user the selection holds (8 per lane) ...
+constexpr int kPfMaxCandWide = 1024; // ... and its second instantiation for the few users with more (long item ranges)
 constexpr int kPfMaxSplits = 16;
 
 struct PrefArgs {
@@ -100,6 +101,8 @@ struct PrefArgs {
   int hint_rank;                // the rank (> K, <= 128) whose exact score becomes the next threshold
   int *retry_cnt;               // users pass A could not certify -> pass B (NULL: uncertified users go to the exact route)
   int *retry_list;              // [U]
+  int *wide_cnt;                // users with more candidates than the narrow selection holds -> the wide one
+  int *wide_list;               // [U]
   int *fb_cnt;                  // users queued for the exact per-user route
   int *fb_list;                 // [U]
   int *fb_done;                 // [U] slices finished per queued user (zeroed per call)
@@ -719,7 +722,6 @@ __device__ __forceinline__ void sort64_desc(uint64_t &e, int lane) {
 
 constexpr int kPfHistLds = 1024;            // longest history the exact per-user route keeps in LDS
 constexpr int kPfSelHist = 256;             // ... and the selection (longer histories are searched in global memory)
-constexpr int kPfSelNR = kPfMaxCand / 64;   // keys per lane on the many-candidates path
 
 // reason codes (non-zero = not certified): 1 a sweep list overflowed, 2 fewer than K candidates, 3 more candidates
 // than the selection holds, 4 the K-th best exact score does not clear the sweep threshold
@@ -727,9 +729,10 @@ constexpr int kPfSelNR = kPfMaxCand / 64;   // keys per lane on the many-candida
 // LDS of one selection wave (4 KiB + 1 KiB): words [0, 64) the lists' prefix sums, words [64, 64 + 512) the candidate
 // item ids; on the many-candidates path the same block is overwritten IN PLACE by the 64-bit keys (key i = words 2i,
 // 2i+1; rounds run from the last to the first, so a round never overwrites an id that is still to be read).
-template <int D>
+template <int D, int MAXC>
 __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, uint32_t *lds, uint32_t *hist_s,
                                             float *urow_s) {
+  constexpr int kPfSelNR = MAXC / 64;   // keys per lane on the many-candidates path
   const int lane = threadIdx.x;
   const int K = P.K;
   const int n_lists = 2 * P.splits;  // <= 32
@@ -754,7 +757,7 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
     if (lane >= o) incl += v;
   }
   const int total = __shfl(incl, 63, 64);          // entries (each holds >= 1 candidate)
-  int why = overflow ? 1 : (total > kPfMaxCand ? 3 : 0);
+  int why = overflow ? 1 : (total > MAXC ? 3 : 0);
   int n_cand = 0;
   if (why == 0) {
     incl_s[lane] = incl;
@@ -791,12 +794,12 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
         const int bit = 31 - __clz(bits);
         bits &= ~(1u << bit);
         const int reg = 15 - bit;
-        if (slot < kPfMaxCand) cand_s[slot] = j0 + (uint32_t)((reg & 3) + 8 * (reg >> 2));
+        if (slot < MAXC) cand_s[slot] = j0 + (uint32_t)((reg & 3) + 8 * (reg >> 2));
         ++slot;
       }
       n_cand += tot;
     }
-    if (n_cand > kPfMaxCand) why = 3;
+    if (n_cand > MAXC) why = 3;
   }
   uint64_t e0 = 0ull, e1 = 0ull;
   int n_keys = 0;
@@ -847,7 +850,7 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
     // only joins when mask_value can reach the top-K (the reference's 1e-6 / 1e-5 does when the real scores are tiny
     // or negative: quirk Q7), i.e. when fewer than K candidates beat it.
     if (deg > 0 && above < K) {   // wave-uniform
-      if (n_cand + deg > kPfMaxCand) {
+      if (n_cand + deg > MAXC) {
         why = 3;
       } else {
         if (small) {              // move the keys to LDS first (slots lane, lane + 64)
@@ -911,8 +914,11 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
     P.fail[u] = why;
     P.n_cand[u] = n_cand;
     if (why != 0) {
-      // not certifiable from this threshold: retry with a sampled one (pass A) or take the exact per-user route
+      // not certifiable from this threshold: retry with a sampled one (pass A); more candidates than this
+      // instantiation holds (but no list overflow): the wide one; else the exact per-user route
       if (P.retry_cnt) P.retry_list[atomicAdd(P.retry_cnt, 1)] = (int)u;
+      else if (why == 3 && MAXC < kPfMaxCandWide && P.wide_cnt && n_cand + deg <= kPfMaxCandWide && total <= kPfMaxCandWide)
+        P.wide_list[atomicAdd(P.wide_cnt, 1)] = (int)u;
       else P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;
     }
   }
@@ -924,15 +930,15 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
 }
 
 // One wave per user (a fixed grid walking the rows of the pass), 7 waves per SIMD (5.5 KiB of LDS each).
-template <int D>
-__global__ __launch_bounds__(64, 7) void score_select_kernel_pf(const PrefArgs P) {
-  __shared__ uint64_t lds64[kPfMaxCand];               // 4 KiB: prefix sums + candidate ids, or the 64-bit keys
+template <int D, int MAXC>
+__global__ __launch_bounds__(64, MAXC <= 512 ? 7 : 4) void score_select_kernel_pf(const PrefArgs P) {
+  __shared__ uint64_t lds64[MAXC];                     // prefix sums + candidate ids, or the 64-bit keys
   __shared__ uint32_t hist_s[kPfSelHist];
   __shared__ float4 urow_s[D / 4];
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
   for (int64_t i = blockIdx.x; i < n_act; i += gridDim.x) {
     const int64_t u = P.user_map ? (int64_t)P.user_map[i] : i;
-    select_user<D>(P, u, reinterpret_cast<uint32_t *>(lds64), hist_s, reinterpret_cast<float *>(urow_s));
+    select_user<D, MAXC>(P, u, reinterpret_cast<uint32_t *>(lds64), hist_s, reinterpret_cast<float *>(urow_s));
     __builtin_amdgcn_wave_barrier();
   }
 }

@@ -802,7 +802,7 @@ struct ScorePlan {
   bool prefilter;
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
   bool pf_sample_long;
-  size_t off_pf_retry, off_pf_ncand, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
+  size_t off_pf_retry, off_pf_wide, off_pf_ncand, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
   bool pf_group_fb;            // large item ranges: the first kPfFbGroupCap queued users share f32 MFMA sweeps
   int pf_group_fb_splits;
   size_t off_pf_fbgroup;
@@ -907,6 +907,7 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.off_pf_fbdone = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.pf_zero_bytes = o - p.off_pf_scalars;
   p.off_pf_retry = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  p.off_pf_wide = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_ncand = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fb = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fbpart = take(p.prefilter ? (size_t)n_users * kExSlices * kMaxK * 8 : 0);
@@ -1054,6 +1055,8 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.item_norm = (float *)(ws + p.off_pf_inorm);
     P.retry_cnt = nullptr;
     P.retry_list = (int *)(ws + p.off_pf_retry);
+    P.wide_cnt = nullptr;
+    P.wide_list = (int *)(ws + p.off_pf_wide);
     P.n_cand = (int *)(ws + p.off_pf_ncand);
     P.fb_cnt = (int *)(ws + p.off_pf_scalars + 128);
     P.fb_list = (int *)(ws + p.off_pf_fb);
@@ -1093,8 +1096,8 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, A);
     };
     auto select = [&](const PrefArgs &A, unsigned grid) {
-      if (D == 64) hipLaunchKernelGGL(score_select_kernel_pf<64>, dim3(grid), dim3(64), 0, st, A);
-      else hipLaunchKernelGGL(score_select_kernel_pf<128>, dim3(grid), dim3(64), 0, st, A);
+      if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
+      else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
     };
     auto sample = [&](const PrefArgs &A) {
       if (D == 64) {
@@ -1115,9 +1118,17 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       B.user_map = P.retry_list;
       B.n_active = retry_cnt;
     }
+    int *wide_cnt = (int *)(ws + p.off_pf_scalars + 192);
+    B.wide_cnt = wide_cnt;
     sample(B);
     sweep(B);
     select(B, hint_in ? sel_queue : sel_all);
+    // the few users with more candidates than the narrow selection holds (coarse samples of very long item ranges)
+    PrefArgs W = P;
+    W.user_map = P.wide_list;
+    W.n_active = wide_cnt;
+    if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
+    else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
     rc = check_launch("score prefilter kernels");
     if (rc) return rc;
     // uncertified users (list overflow, fewer than K above the threshold, band wider than the re-score slots) were
