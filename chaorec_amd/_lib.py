@@ -65,7 +65,7 @@ SIGNATURES = {
     "chaorec_score_topk_hinted_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                      c_ptr, c_ptr, ctypes.c_float, ctypes.c_int32, ctypes.c_int64,
                                                      c_ptr, c_ptr, c_ptr, ctypes.c_size_t, c_ptr, c_ptr,
-                                                     ctypes.c_int32, c_ptr]),
+                                                     ctypes.c_int32, ctypes.c_int32, c_ptr, c_ptr]),
     "chaorec_score_topk_stats": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                 c_ptr, c_ptr]),
     "chaorec_rank_metrics_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32]),

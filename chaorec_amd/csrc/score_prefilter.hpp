@@ -96,6 +96,7 @@ struct PrefArgs {
   // compact passes: row i of the launch is user user_map[i], only the first *n_active rows exist (NULL = identity / all)
   const int *user_map;
   const int *n_active;
+  int min_active;               // a compact pass with at most this many rows does nothing (the exact route takes them)
   const float *hint_in;         // [U] thresholds carried from the previous call (pass A), else NULL: tau_sum
   float *hint_out;              // [U] thresholds for the next call, or NULL
   int hint_rank;                // the rank (> K, <= 128) whose exact score becomes the next threshold
@@ -103,6 +104,9 @@ struct PrefArgs {
   int *retry_list;              // [U]
   int *wide_cnt;                // users with more candidates than the narrow selection holds -> the wide one
   int *wide_list;               // [U]
+  int small_retry;              // exact route: also take the pass-A queue when it holds at most this many users
+  const int *retry_list_cnt;    // (the queue's length for that; retry_cnt itself is NULL outside pass A)
+  int *counters_out;            // [4] (optional) retry / exact-route / wide queue lengths of this call, for the caller
   int *fb_cnt;                  // users queued for the exact per-user route
   int *fb_list;                 // [U]
   int *fb_done;                 // [U] slices finished per queued user (zeroed per call)
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
   const int ur = lane & 31, h = lane >> 5;
   const int64_t ublock = (int64_t)blockIdx.x * WG + wv;
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
-  if ((int64_t)blockIdx.x * WG * 32 >= n_act) return;    // (only a compact pass has empty workgroups)
+  if ((int64_t)blockIdx.x * WG * 32 >= n_act || n_act <= P.min_active) return;    // (only a compact pass has empty workgroups)
   const int64_t uc = ublock * 32 + ur;                    // row of this launch
   const bool u_ok = uc < n_act;
   const int64_t u = (P.user_map && u_ok) ? (int64_t)P.user_map[uc] : uc;   // row of the tables
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ur = lane & 31, h = lane >> 5;
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
-  if ((int64_t)blockIdx.x * kSweepWaves * UB * 32 >= n_act) return;   // (only a compact pass has empty workgroups)
+  if ((int64_t)blockIdx.x * kSweepWaves * UB * 32 >= n_act || n_act <= P.min_active) return;   // (only a compact pass has empty workgroups)
   const int64_t ublock0 = ((int64_t)blockIdx.x * kSweepWaves + wv) * UB;
   const uint32_t n_items = (uint32_t)P.n_items;
   const int n_tiles = (int)((P.n_items + 31) / 32);
@@ -721,24 +725,51 @@ __device__ __forceinline__ void sort64_desc(uint64_t &e, int lane) {
 }
 
 constexpr int kPfHistLds = 1024;            // longest history the exact per-user route keeps in LDS
-constexpr int kPfSelHist = 256;             // ... and the selection (longer histories are searched in global memory)
+constexpr int kPfSelHist = 128;             // ... and the selection (longer histories are searched in global memory)
+
+// exact fp32 score from LDS copies of both rows: the same chain as exact_score()
+template <int D>
+__device__ __forceinline__ float exact_score_lds(const float *urow, const float *irow) {
+  float acc = 0.f;
+  const float4 *i0 = reinterpret_cast<const float4 *>(irow), *i1 = reinterpret_cast<const float4 *>(irow + D / 2);
+  const float4 *u0 = reinterpret_cast<const float4 *>(urow), *u1 = reinterpret_cast<const float4 *>(urow + D / 2);
+#pragma unroll
+  for (int q = 0; q < D / 8; ++q) {
+    const float4 a = i0[q], b = i1[q], x = u0[q], y = u1[q];
+    acc = __fmaf_rn(x.x, a.x, acc);
+    acc = __fmaf_rn(y.x, b.x, acc);
+    acc = __fmaf_rn(x.y, a.y, acc);
+    acc = __fmaf_rn(y.y, b.y, acc);
+    acc = __fmaf_rn(x.z, a.z, acc);
+    acc = __fmaf_rn(y.z, b.z, acc);
+    acc = __fmaf_rn(x.w, a.w, acc);
+    acc = __fmaf_rn(y.w, b.w, acc);
+  }
+  return acc;
+}
 
 // reason codes (non-zero = not certified): 1 a sweep list overflowed, 2 fewer than K candidates, 3 more candidates
 // than the selection holds, 4 the K-th best exact score does not clear the sweep threshold
 //
-// LDS of one selection wave (4 KiB + 1 KiB): words [0, 64) the lists' prefix sums, words [64, 64 + 512) the candidate
-// item ids; on the many-candidates path the same block is overwritten IN PLACE by the 64-bit keys (key i = words 2i,
-// 2i+1; rounds run from the last to the first, so a round never overwrites an id that is still to be read).
+// The exact re-score is where the selection's time goes: a candidate's chain is sequential, so one lane has to see the
+// whole item row -- but a lane that LOADS its own row issues D/4 16-byte requests into two cache lines that 27 other
+// waves of the CU keep evicting (measured: ~60 us per round of 64 candidates over sports' 28 940 users).  So the rows
+// are fetched COOPERATIVELY -- D/4 lanes per row, whole 128-B lines, 1024 / D rows per load instruction -- parked in an
+// LDS tile ([ROWS][D + 4] floats: the +4 skews the banks) and each of the first ROWS lanes then walks one row of the
+// tile.  Only ROWS of the 64 lanes run the chain; it is the memory system, not the FMAs, that this kernel waits for.
+template <int D>
+struct SelLds {
+  static constexpr int ROWS = 1024 / D;            // item rows per tile (16 at D = 64, 8 at D = 128)
+  static constexpr int STRIDE = D + 4;
+};
+
 template <int D, int MAXC>
-__device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, uint32_t *lds, uint32_t *hist_s,
-                                            float *urow_s) {
-  constexpr int kPfSelNR = MAXC / 64;   // keys per lane on the many-candidates path
+__device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, int *incl_s, uint32_t *cand_s,
+                                            uint32_t *hist_s, float *urow_s, float *tile_s) {
+  constexpr int ROWS = SelLds<D>::ROWS, STRIDE = SelLds<D>::STRIDE, LPRW = D / 4;   // lanes per row
   const int lane = threadIdx.x;
   const int K = P.K;
   const int n_lists = 2 * P.splits;  // <= 32
-  int *incl_s = reinterpret_cast<int *>(lds);
-  uint32_t *cand_s = lds + 64;
-  uint64_t *key_s = reinterpret_cast<uint64_t *>(lds);
 
   int c = 0;
   if (lane < n_lists) c = P.cand_cnt[((size_t)(lane >> 1) * P.n_users + u) * 2 + (lane & 1)];
@@ -763,8 +794,6 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
     incl_s[lane] = incl;
     if (hist_lds)
       for (int i = lane; i < deg; i += 64) hist_s[i] = (uint32_t)P.hist_col[hb + i];
-    // the user's row through LDS (broadcast reads in the score chain): 64 / 128 scalar registers held across the
-    // whole selection made the compiler spill
     for (int i = lane; i < D; i += 64) urow_s[i] = P.user_emb[(size_t)u * D + i];
     __builtin_amdgcn_wave_barrier();
     // entries -> item ids, in list order: entry e sits in list l = first list with incl[l] > e
@@ -805,7 +834,6 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
   int n_keys = 0;
   if (why == 0) {
     __builtin_amdgcn_wave_barrier();
-    const float *urow = urow_s;
     auto in_hist = [&](uint32_t item) -> bool {
       int lo = 0, hi = deg;
       while (lo < hi) {
@@ -815,89 +843,80 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
       }
       return lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
     };
-    // exact score of candidate idx as a sortable key; a history member leaves the candidates here (the sweep ran
-    // unmasked) -- the history comes back below, with mask_value, only when that can matter
-    auto score_key = [&](int idx) -> uint64_t {
-      if (idx >= n_cand) return 0ull;
-      const uint32_t item = cand_s[idx];
-      if (in_hist(item)) return 0ull;
-      return make_key(exact_score<D>(urow, P.item_emb + (size_t)item * D), item);
-    };
     const uint32_t mord = f32_to_ord(P.mask_value);
-    int valid, above;
-    bool small = n_cand <= 128;   // wave-uniform
-    if (small) {
-      e0 = score_key(lane);
-      if (n_cand > 64) e1 = score_key(lane + 64);
-      valid = __popcll(__ballot(e0 != 0ull)) + __popcll(__ballot(e1 != 0ull));
-      above = __popcll(__ballot(e0 != 0ull && (uint32_t)(e0 >> 32) > mord)) +
-              __popcll(__ballot(e1 != 0ull && (uint32_t)(e1 >> 32) > mord));
-    } else {
-      // many candidates: keys replace the ids in LDS, last round first (see the layout note above)
-      valid = above = 0;
-      for (int r = (n_cand - 1) >> 6; r >= 0; --r) {
-        const uint64_t k = score_key(lane + 64 * r);
-        __builtin_amdgcn_wave_barrier();
-        key_s[lane + 64 * r] = k;
-        valid += __popcll(__ballot(k != 0ull));
-        above += __popcll(__ballot(k != 0ull && (uint32_t)(k >> 32) > mord));
+    // Exact scores, ROWS candidates per tile.  The keys of tile t land in lanes [ROWS * (t % (64 / ROWS)), + ROWS) of
+    // the current 64-key block `cur`; full blocks go to e0, e1, and from the third one on they are merged into the
+    // running best 128 (two register sorts per block: only users with more than 128 candidates pay that).
+    uint64_t cur = 0ull;
+    int blocks = 0, valid = 0, above = 0;
+    bool sorted = false;
+    auto push_block = [&]() __attribute__((always_inline)) {
+      valid += __popcll(__ballot(cur != 0ull));
+      above += __popcll(__ballot(cur != 0ull && (uint32_t)(cur >> 32) > mord));
+      if (blocks == 0) {
+        e0 = cur;
+      } else if (blocks == 1) {
+        e1 = cur;
+      } else {
+        if (!sorted) {
+          sort128_desc(e0, e1, lane);
+          sorted = true;
+        }
+        sort128_desc(e1, cur, lane);      // the better half of (ranks 64..127, the new block) -> e1
+        sort128_desc(e0, e1, lane);
+      }
+      ++blocks;
+      cur = 0ull;
+    };
+    for (int base = 0; base < n_cand; base += ROWS) {
+      // cooperative fetch: instruction j brings rows j * (64 / LPRW) + lane / LPRW of the tile
+      float4 v[ROWS * LPRW / 64];
+#pragma unroll
+      for (int j = 0; j < ROWS * LPRW / 64; ++j) {
+        const int r = j * (64 / LPRW) + lane / LPRW;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + r < n_cand)
+          v[j] = reinterpret_cast<const float4 *>(P.item_emb + (size_t)cand_s[base + r] * D)[lane % LPRW];
+      }
+      uint32_t item = 0;
+      bool masked = true;
+      if (lane < ROWS && base + lane < n_cand) {
+        item = cand_s[base + lane];
+        masked = in_hist(item);          // (a history member leaves the candidates: the sweep ran unmasked)
+      }
+#pragma unroll
+      for (int j = 0; j < ROWS * LPRW / 64; ++j) {
+        const int r = j * (64 / LPRW) + lane / LPRW;
+        *reinterpret_cast<float4 *>(tile_s + r * STRIDE + 4 * (lane % LPRW)) = v[j];
       }
       __builtin_amdgcn_wave_barrier();
+      uint64_t key = 0ull;
+      if (!masked) key = make_key(exact_score_lds<D>(urow_s, tile_s + lane * STRIDE), item);
+      __builtin_amdgcn_wave_barrier();
+      const int sub = (base / ROWS) % (64 / ROWS);
+      const uint64_t moved = shfl_u64(key, lane & (ROWS - 1));
+      if ((lane / ROWS) == sub) cur = moved;
+      if (sub == 64 / ROWS - 1 || base + ROWS >= n_cand) push_block();
     }
     n_keys = valid;
-    int n_slots = n_cand;         // key slots in use
     // The masked row restricted to what can matter = the candidates + the user's history at mask_value.  The history
     // only joins when mask_value can reach the top-K (the reference's 1e-6 / 1e-5 does when the real scores are tiny
     // or negative: quirk Q7), i.e. when fewer than K candidates beat it.
     if (deg > 0 && above < K) {   // wave-uniform
-      if (n_cand + deg > MAXC) {
-        why = 3;
-      } else {
-        if (small) {              // move the keys to LDS first (slots lane, lane + 64)
-          key_s[lane] = e0;
-          key_s[lane + 64] = e1;
-          n_slots = n_cand > 64 ? 128 : 64;
-        }
-        for (int i = lane; i < deg; i += 64)
-          key_s[n_slots + i] = make_key(P.mask_value, hist_lds ? hist_s[i] : (uint32_t)P.hist_col[hb + i]);
-        __builtin_amdgcn_wave_barrier();
-        n_slots += deg;
-        n_keys = valid + deg;
-        if (n_slots <= 128) {
-          e0 = lane < n_slots ? key_s[lane] : 0ull;
-          e1 = lane + 64 < n_slots ? key_s[lane + 64] : 0ull;
-          small = true;
-        } else {
-          small = false;
-        }
+      for (int i0 = 0; i0 < deg; i0 += 64) {
+        const int i = i0 + lane;
+        cur = i < deg ? make_key(P.mask_value, hist_lds ? hist_s[i] : (uint32_t)P.hist_col[hb + i]) : 0ull;
+        push_block();
       }
+      n_keys = valid;
     }
-    if (why == 0 && n_keys < K) why = 2;
+    if (n_keys < K) why = 2;
     if (why == 0) {
-      const int want = min(max(P.hint_rank, K), min(n_keys, 128));   // ranks kept: the top-K and the next call's threshold
-      if (small) {
-        if (n_slots <= 64) sort64_desc(e0, lane);
+      if (!sorted) {
+        if (blocks <= 1) sort64_desc(e0, lane);
         else sort128_desc(e0, e1, lane);
-      } else {
-        // keys >= the want-th largest (exactly `want` of them: keys are unique), compacted through LDS, one sort
-        uint64_t k[kPfSelNR];
-#pragma unroll
-        for (int r = 0; r < kPfSelNR; ++r) k[r] = (lane + 64 * r < n_slots) ? key_s[lane + 64 * r] : 0ull;
-        const uint64_t thr = kth_largest_key<kPfSelNR>(k, want);
-        __builtin_amdgcn_wave_barrier();
-        int base = 0;
-#pragma unroll
-        for (int r = 0; r < kPfSelNR; ++r) {
-          const bool w = k[r] != 0ull && k[r] >= thr;
-          const unsigned long long m = __ballot(w);
-          if (w) key_s[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = k[r];
-          base += __popcll(m);
-        }
-        __builtin_amdgcn_wave_barrier();
-        e0 = lane < base ? key_s[lane] : 0ull;
-        e1 = lane + 64 < base ? key_s[lane + 64] : 0ull;
-        sort128_desc(e0, e1, lane);
       }
+      const int want = min(max(P.hint_rank, K), min(n_keys, 128));   // the rank whose score is the next call's threshold
       // certification: the K-th best exact score must clear the threshold the sweep used
       const uint64_t kth = shfl_u64(e0, K - 1);
       if (kth == 0ull || !(ord_to_f32((uint32_t)(kth >> 32)) > theta)) why = 4;
@@ -917,7 +936,7 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
       // not certifiable from this threshold: retry with a sampled one (pass A); more candidates than this
       // instantiation holds (but no list overflow): the wide one; else the exact per-user route
       if (P.retry_cnt) P.retry_list[atomicAdd(P.retry_cnt, 1)] = (int)u;
-      else if (why == 3 && MAXC < kPfMaxCandWide && P.wide_cnt && n_cand + deg <= kPfMaxCandWide && total <= kPfMaxCandWide)
+      else if (why == 3 && MAXC < kPfMaxCandWide && P.wide_cnt && n_cand <= kPfMaxCandWide && total <= kPfMaxCandWide)
         P.wide_list[atomicAdd(P.wide_cnt, 1)] = (int)u;
       else P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;
     }
@@ -929,16 +948,20 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
   }
 }
 
-// One wave per user (a fixed grid walking the rows of the pass), 7 waves per SIMD (5.5 KiB of LDS each).
+// One wave per user (a fixed grid walking the rows of the pass).  LDS per wave at D = 64: 256 B prefix sums + 2 KiB
+// candidate ids + 512 B history + 256 B user row + 4.25 KiB row tile = 7.25 KiB -> 5 waves per SIMD.
 template <int D, int MAXC>
-__global__ __launch_bounds__(64, MAXC <= 512 ? 7 : 4) void score_select_kernel_pf(const PrefArgs P) {
-  __shared__ uint64_t lds64[MAXC];                     // prefix sums + candidate ids, or the 64-bit keys
+__global__ __launch_bounds__(64, MAXC <= 512 ? 5 : 4) void score_select_kernel_pf(const PrefArgs P) {
+  __shared__ int incl_s[64];
+  __shared__ uint32_t cand_s[MAXC];
   __shared__ uint32_t hist_s[kPfSelHist];
   __shared__ float4 urow_s[D / 4];
+  __shared__ float4 tile_s[SelLds<D>::ROWS * SelLds<D>::STRIDE / 4];
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
+  if (n_act <= P.min_active) return;
   for (int64_t i = blockIdx.x; i < n_act; i += gridDim.x) {
     const int64_t u = P.user_map ? (int64_t)P.user_map[i] : i;
-    select_user<D, MAXC>(P, u, reinterpret_cast<uint32_t *>(lds64), hist_s, reinterpret_cast<float *>(urow_s));
+    select_user<D, MAXC>(P, u, incl_s, cand_s, hist_s, reinterpret_cast<float *>(urow_s), reinterpret_cast<float *>(tile_s));
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -1027,10 +1050,20 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = P.K;
   const int n_fb = *P.fb_cnt;
+  // the queue: fb_list[fb_skip .. n_fb), then -- when pass A left only a handful of users uncertified and no retry pass
+  // ran for them -- that retry queue as well (queue positions n_fb ..)
+  int n_rt = P.retry_list ? *(P.retry_list_cnt) : 0;
+  if (n_rt > P.small_retry) n_rt = 0;
+  if (P.counters_out && blockIdx.x == 0 && tid == 0) {
+    P.counters_out[0] = P.retry_list ? *(P.retry_list_cnt) : 0;
+    P.counters_out[1] = n_fb;
+    P.counters_out[2] = P.wide_cnt ? *P.wide_cnt : 0;
+    P.counters_out[3] = n_rt;
+  }
   const int64_t per_slice = (P.n_items + kExSlices - 1) / kExSlices;
-  for (int w = blockIdx.x + P.fb_skip * kExSlices; w < n_fb * kExSlices; w += gridDim.x) {
+  for (int w = blockIdx.x + P.fb_skip * kExSlices; w < (n_fb + n_rt) * kExSlices; w += gridDim.x) {
     const int qi = w / kExSlices, slice = w % kExSlices;
-    const int64_t u = P.fb_list[qi];
+    const int64_t u = qi < n_fb ? P.fb_list[qi] : P.retry_list[qi - n_fb];
     const float *urow = P.user_emb + (size_t)u * D;
     int64_t hb = 0, he = 0;
     if (P.hist_rowptr) {

@@ -990,7 +990,8 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
                            const int32_t *hist_col, float mask_value, int32_t K,
                            int64_t id_offset, int64_t *out_idx, float *out_val,
                            void *workspace, size_t workspace_bytes, int32_t precision,
-                           const float *hint_in, float *hint_out, int32_t hint_rank, void *stream) {
+                           const float *hint_in, float *hint_out, int32_t hint_rank, int32_t flags,
+                           int32_t *counters_out, void *stream) {
   if (!user_emb || !item_emb || !out_idx || !out_val) return fail(CHAOREC_E_INVALID, "score_topk: NULL argument");
   if (n_users < 0 || n_items <= 0) return fail(CHAOREC_E_INVALID, "score_topk: bad sizes");
   if (K < 1 || K > kMaxK) return fail(CHAOREC_E_INVALID, "score_topk: K=%d must be in [1,%d]", K, kMaxK);
@@ -1074,6 +1075,10 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.out_val = out_val;
     P.user_map = nullptr;
     P.n_active = nullptr;
+    P.min_active = 0;
+    P.small_retry = -1;
+    P.retry_list_cnt = (const int *)(ws + p.off_pf_scalars + 64);
+    P.counters_out = counters_out;
     P.hint_in = nullptr;
     P.hint_out = hint_out;
     P.hint_rank = hint_rank > K ? (hint_rank > 128 ? 128 : hint_rank) : K;
@@ -1108,27 +1113,40 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
         else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false, 1>), gs, dim3(64), 0, st, A);
       }
     };
-    PrefArgs B = P;              // pass B: sampled thresholds; over the users pass A queued, or over everybody
+    // Pass A (carried thresholds) certifies nearly everybody in steady state.  What is left goes to pass B (sampled
+    // thresholds over the device-side queue) -- unless it is a handful: then the exact per-user route is cheaper than
+    // three more launches whose critical path is a whole item sweep by one wave, and pass B returns at once.  With
+    // CHAOREC_SCORE_LIGHT the caller (who has seen the previous call's queue lengths) asks for no pass B at all.
+    const bool light = hint_in && (flags & CHAOREC_SCORE_LIGHT) && !p.pf_group_fb;
+    const int small_queue = p.pf_group_fb ? -1 : 64;   // (very long item ranges: the per-user exact route streams the table per user)
+    int *wide_cnt = (int *)(ws + p.off_pf_scalars + 192);
     if (hint_in) {
       PrefArgs A = P;            // pass A: the carried thresholds
       A.hint_in = hint_in;
       A.retry_cnt = retry_cnt;
       sweep(A);
       select(A, sel_all);
-      B.user_map = P.retry_list;
-      B.n_active = retry_cnt;
+      P.small_retry = light ? INT_MAX : small_queue;
     }
-    int *wide_cnt = (int *)(ws + p.off_pf_scalars + 192);
-    B.wide_cnt = wide_cnt;
-    sample(B);
-    sweep(B);
-    select(B, hint_in ? sel_queue : sel_all);
-    // the few users with more candidates than the narrow selection holds (coarse samples of very long item ranges)
-    PrefArgs W = P;
-    W.user_map = P.wide_list;
-    W.n_active = wide_cnt;
-    if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
-    else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
+    if (!light) {
+      PrefArgs B = P;            // pass B: sampled thresholds; over the users pass A queued, or over everybody
+      if (hint_in) {
+        B.user_map = P.retry_list;
+        B.n_active = retry_cnt;
+        B.min_active = small_queue;
+      }
+      B.wide_cnt = wide_cnt;
+      sample(B);
+      sweep(B);
+      select(B, hint_in ? sel_queue : sel_all);
+      // the few users with more candidates than the narrow selection holds (coarse samples of very long item ranges)
+      PrefArgs W = P;
+      W.user_map = P.wide_list;
+      W.n_active = wide_cnt;
+      if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
+      else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
+      P.wide_cnt = wide_cnt;     // (for the counters the exact-route launch reports)
+    }
     rc = check_launch("score prefilter kernels");
     if (rc) return rc;
     // uncertified users (list overflow, fewer than K above the threshold, band wider than the re-score slots) were
@@ -1257,7 +1275,7 @@ extern "C" int chaorec_score_topk_f32(const float *user_emb, const float *item_e
                                       void *workspace, size_t workspace_bytes, int32_t precision,
                                       void *stream) {
   return score_topk_impl(user_emb, item_emb, n_users, n_items, D, hist_rowptr, hist_col, mask_value, K, id_offset, out_idx,
-                         out_val, workspace, workspace_bytes, precision, nullptr, nullptr, 0, stream);
+                         out_val, workspace, workspace_bytes, precision, nullptr, nullptr, 0, 0, nullptr, stream);
 }
 
 extern "C" int chaorec_score_topk_hinted_f32(const float *user_emb, const float *item_emb, int64_t n_users,
@@ -1265,7 +1283,8 @@ extern "C" int chaorec_score_topk_hinted_f32(const float *user_emb, const float 
                                              const int32_t *hist_col, float mask_value, int32_t K,
                                              int64_t id_offset, int64_t *out_idx, float *out_val,
                                              void *workspace, size_t workspace_bytes, const float *hint_in,
-                                             float *hint_out, int32_t hint_rank, void *stream) {
+                                             float *hint_out, int32_t hint_rank, int32_t flags,
+                                             int32_t *counters_out, void *stream) {
   return score_topk_impl(user_emb, item_emb, n_users, n_items, D, hist_rowptr, hist_col, mask_value, K, id_offset, out_idx,
-                         out_val, workspace, workspace_bytes, 0, hint_in, hint_out, hint_rank, stream);
+                         out_val, workspace, workspace_bytes, 0, hint_in, hint_out, hint_rank, flags, counters_out, stream);
 }

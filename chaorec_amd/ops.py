@@ -364,13 +364,18 @@ def draw_batch(edges, hist, B, num_user, num_item, seed, step, step_dev=None):
 # --------------------------------------------------------------------------------------------
 # scoring + top-K
 # --------------------------------------------------------------------------------------------
+SCORE_LIGHT = 1      # CHAOREC_SCORE_LIGHT
+
+
 def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0, stats=None, hint=None,
-               hint_valid=False, hint_rank=80):
+               hint_valid=False, hint_rank=80, light=False, counters=None):
     """Top-K of user_emb @ item_emb.T with history masking, without the [U,I] matrix.
     Returns (idx int64 [U,K] = item + id_offset, val fp32 [U,K]).  `stats`: a dict to fill with the prefilter
     route's counters (chaorec_score_topk_stats; costs a device sync).
     hint (optional, float32 [U] on the device): per-user thresholds carried between calls
-    (chaorec_score_topk_hinted_f32): written by every call, read when hint_valid.  Never changes the result."""
+    (chaorec_score_topk_hinted_f32): written by every call, read when hint_valid.  Never changes the result.
+    light: no retry pass (the caller saw a short retry queue last time); counters: int32 [4] device tensor receiving
+    this call's queue lengths."""
     _need_cuda(user_emb, item_emb)
     user_emb, item_emb = _f32c(user_emb), _f32c(item_emb)
     U, D = user_emb.shape
@@ -389,7 +394,8 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
             raise TypeError("score_topk: hint must be a contiguous float32 [n_users] tensor")
         rc = lib.chaorec_score_topk_hinted_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
                                                mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
-                                               _ptr(hint if hint_valid else None), _ptr(hint), int(hint_rank), _stream())
+                                               _ptr(hint if hint_valid else None), _ptr(hint), int(hint_rank),
+                                               SCORE_LIGHT if (light and hint_valid) else 0, _ptr(counters), _stream())
         _lib.check(rc, "chaorec_score_topk_hinted_f32")
     else:
         rc = lib.chaorec_score_topk_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),

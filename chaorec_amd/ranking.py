@@ -31,13 +31,33 @@ class RankState:
     one: one epoch of training moves the scores little, so the next call needs no sampling pass and re-scores about
     half the candidates).  The thresholds never change a result; stale ones only cost a retry."""
 
+    LIGHT_BELOW = 64     # a call whose predecessor queued at most this many users for the retry pass runs without one
+
     def __init__(self):
         self.hint, self.valid = None, False
+        self.counters = self.counters_host = None
+        self.copied = None          # event: the previous call's counters have reached the host
 
     def buffer(self, num_user, device):
         if self.hint is None or self.hint.numel() != num_user or self.hint.device != device:
             self.hint, self.valid = torch.empty(num_user, dtype=torch.float32, device=device), False
+            self.counters = torch.zeros(4, dtype=torch.int32, device=device)
+            self.counters_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self.copied = None
         return self.hint
+
+    def light(self):
+        """No retry pass this time?  Yes when the previous call's queue lengths are on the host already (they were
+        copied asynchronously: no sync here) and that call queued only a handful of users."""
+        if not self.valid or self.copied is None or not self.copied.query():
+            return False
+        return int(self.counters_host[0]) <= self.LIGHT_BELOW
+
+    def after_call(self):
+        self.counters_host.copy_(self.counters, non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+        self.valid = True
 
 
 def state_of(model):
@@ -57,8 +77,9 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
             hint = state.buffer(num_user, result.device)
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                     id_offset=num_user, hint=hint, hint_valid=state.valid,
-                                    hint_rank=max(topk + 14, (topk * 8 + 4) // 5))
-            state.valid = True
+                                    hint_rank=max(topk + 14, (topk * 8 + 4) // 5), light=state.light(),
+                                    counters=state.counters)
+            state.after_call()
         else:
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                     id_offset=num_user)

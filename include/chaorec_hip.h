@@ -279,16 +279,24 @@ int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
  *            (no sampling pass, about half the candidates of a sampled threshold); users it cannot certify -- scores
  *            moved too much since -- are queued on the device and retried with a sampled threshold (pass B), then, if
  *            need be, ranked exactly.  hint_in == NULL: pass B for everybody (= chaorec_score_topk_f32).
+ *            A queue of at most 64 users skips pass B and is ranked exactly, per user, at once.
+ *   flags    CHAOREC_SCORE_LIGHT: launch no pass B at all (three launches and their one-wave critical path less) -- for
+ *            a caller that saw a short queue last time; whatever pass A leaves is ranked exactly per user, which is slow
+ *            only if that expectation was wrong.
+ *   counters_out (optional, device int32[4]): {users pass A queued, users ranked by the exact route, users of the wide
+ *            selection, queued users taken by the exact route} of THIS call -- what a caller bases the next call's flags on.
  * A threshold never changes the result, only the work: the output is bit-identical to chaorec_score_topk_f32's
  * whatever the hints hold (NaN / inf / stale values included).  Needs the prefilter route (D in {64,128}, >= 4096
- * items, K <= 64); otherwise the hints are ignored and hint_out is left untouched. */
+ * items, K <= 64); otherwise the hints are ignored and hint_out / counters_out are left untouched. */
+#define CHAOREC_SCORE_LIGHT 1
 int chaorec_score_topk_hinted_f32(const float *user_emb, const float *item_emb,
                                   int64_t n_users, int64_t n_items, int32_t D,
                                   const int64_t *hist_rowptr, const int32_t *hist_col,
                                   float mask_value, int32_t K, int64_t id_offset,
                                   int64_t *out_idx, float *out_val,
                                   void *workspace, size_t workspace_bytes,
-                                  const float *hint_in, float *hint_out, int32_t hint_rank, void *stream);
+                                  const float *hint_in, float *hint_out, int32_t hint_rank, int32_t flags,
+                                  int32_t *counters_out, void *stream);
 
 /* Monitoring: what the prefilter route of the LAST scoring call on this workspace did (same sizes).
  * out9 (device, 9 x uint64): [0] users handed to the exact route, [1] candidates re-scored in total, [2] longest

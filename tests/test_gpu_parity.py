@@ -365,14 +365,20 @@ def _check_all_precisions(dev, oracle, ue, ie, hist, mask, K, id_offset=0):
     checks = [("first", None), ("carried", "keep"), ("+inf", torch.full_like(hint, float("inf"))),
               ("-inf", torch.full_like(hint, float("-inf"))), ("nan", torch.full_like(hint, float("nan"))),
               ("garbage", garbage), ("huge", torch.full_like(hint, 3e38)), ("zero", torch.zeros_like(hint)),
-              ("carried again", "keep")]
+              ("carried again", "keep"), ("light carried", "keep"), ("light garbage", garbage), ("light after garbage", "keep")]
+    counters = torch.zeros(4, dtype=torch.int32, device=dev)
     for name, h in checks:
         valid = h is not None
         if valid and not isinstance(h, str):
             hint.copy_(h)
-        got_i, got_v = ops.score_topk(tu, ti, dh, mask, K, id_offset=id_offset, hint=hint, hint_valid=valid)
+        got_i, got_v = ops.score_topk(tu, ti, dh, mask, K, id_offset=id_offset, hint=hint, hint_valid=valid,
+                                      light=name.startswith("light"), counters=counters)
         assert np.array_equal(got_v.cpu().numpy(), want_v), name
         assert np.array_equal(got_i.cpu().numpy(), want_i), name
+        c = counters.tolist()
+        assert 0 <= c[0] <= U and 0 <= c[1] <= U and c[3] <= c[0], (name, c)
+        if name.startswith("light"):
+            assert c[3] == c[0], (name, c)        # no retry pass: everything pass A queued went to the exact route
 
 
 @pytest.mark.parametrize("U,I,D,K", [(150, 9000, 64, 50), (70, 8200, 128, 20), (33, 12000, 64, 64),

@@ -1,0 +1,71 @@
+"""gene_ranklist on a trained LightGCN/sports model, three ways: cold (sampled thresholds), carried thresholds on the SAME
+tables, carried thresholds from one epoch (155 steps) earlier.  Prints event timings; run under
+`rocprofv3 --kernel-trace --stats` for the per-kernel split."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from chaorec_amd import dataload, ops  # noqa: E402
+from chaorec_amd.Model import LightGCN  # noqa: E402
+from chaorec_amd.optim import FusedAdam, FusedLightGCNStep  # noqa: E402
+
+
+def timed(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for s, e in ev:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    return float(np.median([s.elapsed_time(e) for s, e in ev]))
+
+
+def main():
+    dev = torch.device("cuda:0")
+    train_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    d = dataload.packed_interactions("sports")
+    U, I, edges = d["num_user"], d["num_item"], d["train"]
+    torch.manual_seed(42)
+    m = LightGCN(U, I, edges, None, 64, 1e-3, 3, "add", dev).to(dev)
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    step = FusedLightGCNStep(m, opt, batch_size=1024, edges=edges_dev, seed=42, step_dev=cnt, steps_per_replay=5)
+    step.run(train_steps)
+    res = m.result.detach().clone()
+    ue, ie = res[:U], res[U:U + I]
+    hint = torch.empty(U, dtype=torch.float32, device=dev)
+    st = {}
+    cold = timed(lambda: ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U))
+    ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, stats=st)
+    print(f"cold                      {cold * 1e3:7.1f} us  cand/user {st['candidates'] / U:6.1f}  exact-route users {st['fallback_users']}")
+    ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=False)
+    same = timed(lambda: ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True))
+    ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, stats=st)
+    print(f"carried, same tables      {same * 1e3:7.1f} us  cand/user {st['candidates'] / U:6.1f}  exact-route users {st['fallback_users']}")
+    # one epoch apart: hints from the tables before 155 more steps
+    ts = []
+    for ep in range(4):
+        step.run(155)
+        res = m.result.detach()
+        ue, ie = res[:U], res[U:U + I]
+        h2 = hint.clone()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True)
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=h2, hint_valid=True, stats=st)
+        print(f"carried, one epoch apart  {ts[-1] * 1e3:7.1f} us  cand/user {st['candidates'] / U:6.1f}  exact-route users {st['fallback_users']}")
+
+
+if __name__ == "__main__":
+    main()
