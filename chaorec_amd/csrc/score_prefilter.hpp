@@ -501,7 +501,10 @@ __device__ __forceinline__ float bf16_floor(float x) {  // largest bf16-represen
 // from there by all its waves -- with one wave per workgroup the sweep streamed the whole packed item table once per
 // 64 users (1.1 GB per sports sweep, 11 TB at 1.25 M users x 2 M items).
 constexpr int kSweepWaves = 4;
-constexpr int kSweepStage = 2;
+#ifndef CHAOREC_SWEEP_STAGE
+#define CHAOREC_SWEEP_STAGE 2
+#endif
+constexpr int kSweepStage = CHAOREC_SWEEP_STAGE;
 
 template <int D, int UB>
 __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(const PrefArgs P) {
@@ -727,46 +730,28 @@ __device__ __forceinline__ void sort64_desc(uint64_t &e, int lane) {
 constexpr int kPfHistLds = 1024;            // longest history the exact per-user route keeps in LDS
 constexpr int kPfSelHist = 128;             // ... and the selection (longer histories are searched in global memory)
 
-// exact fp32 score from LDS copies of both rows: the same chain as exact_score()
-template <int D>
-__device__ __forceinline__ float exact_score_lds(const float *urow, const float *irow) {
-  float acc = 0.f;
-  const float4 *i0 = reinterpret_cast<const float4 *>(irow), *i1 = reinterpret_cast<const float4 *>(irow + D / 2);
-  const float4 *u0 = reinterpret_cast<const float4 *>(urow), *u1 = reinterpret_cast<const float4 *>(urow + D / 2);
-#pragma unroll
-  for (int q = 0; q < D / 8; ++q) {
-    const float4 a = i0[q], b = i1[q], x = u0[q], y = u1[q];
-    acc = __fmaf_rn(x.x, a.x, acc);
-    acc = __fmaf_rn(y.x, b.x, acc);
-    acc = __fmaf_rn(x.y, a.y, acc);
-    acc = __fmaf_rn(y.y, b.y, acc);
-    acc = __fmaf_rn(x.z, a.z, acc);
-    acc = __fmaf_rn(y.z, b.z, acc);
-    acc = __fmaf_rn(x.w, a.w, acc);
-    acc = __fmaf_rn(y.w, b.w, acc);
-  }
-  return acc;
-}
-
 // reason codes (non-zero = not certified): 1 a sweep list overflowed, 2 fewer than K candidates, 3 more candidates
 // than the selection holds, 4 the K-th best exact score does not clear the sweep threshold
 //
-// The exact re-score is where the selection's time goes: a candidate's chain is sequential, so one lane has to see the
-// whole item row -- but a lane that LOADS its own row issues D/4 16-byte requests into two cache lines that 27 other
-// waves of the CU keep evicting (measured: ~60 us per round of 64 candidates over sports' 28 940 users).  So the rows
-// are fetched COOPERATIVELY -- D/4 lanes per row, whole 128-B lines, 1024 / D rows per load instruction -- parked in an
-// LDS tile ([ROWS][D + 4] floats: the +4 skews the banks) and each of the first ROWS lanes then walks one row of the
-// tile.  Only ROWS of the 64 lanes run the chain; it is the memory system, not the FMAs, that this kernel waits for.
+// The exact re-score is where the selection's time goes, and what it costs is ADDRESSES, not bytes or flops: a lane
+// that loads its own candidate's row puts 64 different cache lines into every load instruction, and the CU's address
+// path retires about one line per clock -- measured ~90 us per round of 64 candidates over sports' 28 940 users,
+// whatever the register budget.  So the rows are fetched in whole 128-B lines: G = D/8 lanes per candidate (64 / G
+// candidates per load instruction), lane l of a group holding floats [4l, 4l+4) and [D/2 + 4l, D/2 + 4l + 4) of the
+// row -- exactly the operands of chain steps 8l .. 8l+7 (the chain alternates between the two halves of the row).
+// The chain itself stays sequential: the accumulator walks through the group's lanes, one DPP move per 8 fmas, every
+// lane executing every segment (the result of the lane whose turn it is is kept).  ~11 VALU instructions per
+// candidate instead of ~1, no LDS traffic, and an order of magnitude fewer addresses.
+// (Tried: lane-per-candidate loads with the whole row in flight -- address-bound, as said; rows through an LDS tile
+//  walked by 16 lanes -- LDS-bound.)
 template <int D>
-struct SelLds {
-  static constexpr int ROWS = 1024 / D;            // item rows per tile (16 at D = 64, 8 at D = 128)
-  static constexpr int STRIDE = D + 4;
-};
+__device__ __forceinline__ float dpp_prev_lane(float v) {   // lane i <- lane i - 1 (within its row of 16 lanes)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+}
 
 template <int D, int MAXC>
 __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, int *incl_s, uint32_t *cand_s,
-                                            uint32_t *hist_s, float *urow_s, float *tile_s) {
-  constexpr int ROWS = SelLds<D>::ROWS, STRIDE = SelLds<D>::STRIDE, LPRW = D / 4;   // lanes per row
+                                            uint32_t *hist_s, float *urow_s) {
   const int lane = threadIdx.x;
   const int K = P.K;
   const int n_lists = 2 * P.splits;  // <= 32
@@ -830,8 +815,12 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
     }
     if (n_cand > MAXC) why = 3;
   }
-  uint64_t e0 = 0ull, e1 = 0ull;
-  int n_keys = 0;
+#if defined(CHAOREC_SEL_EXP) && CHAOREC_SEL_EXP == 5
+  if (lane == 0) P.n_cand[u] = n_cand;            // (experiment: expansion only)
+  return;
+#endif
+  uint64_t e0 = 0ull;
+  bool written_by_rank = false;
   if (why == 0) {
     __builtin_amdgcn_wave_barrier();
     auto in_hist = [&](uint32_t item) -> bool {
@@ -844,89 +833,179 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
       return lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
     };
     const uint32_t mord = f32_to_ord(P.mask_value);
-    // Exact scores, ROWS candidates per tile.  The keys of tile t land in lanes [ROWS * (t % (64 / ROWS)), + ROWS) of
-    // the current 64-key block `cur`; full blocks go to e0, e1, and from the third one on they are merged into the
-    // running best 128 (two register sorts per block: only users with more than 128 candidates pay that).
-    uint64_t cur = 0ull;
-    int blocks = 0, valid = 0, above = 0;
-    bool sorted = false;
-    auto push_block = [&]() __attribute__((always_inline)) {
+    constexpr int NR = MAXC / 64;          // key registers per lane
+    constexpr int G = 4;                   // lanes per candidate
+    constexpr int CPI = 64 / G;            // candidates per chain pass
+    constexpr int SEG = D / (2 * G);       // floats of each half of the row per lane (8 at D = 64, 16 at D = 128)
+    const int l = lane % G, g = lane / G;
+    // this lane's operands of the user's row, for the whole selection
+    float ua[SEG], ub[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+      ua[i] = urow_s[SEG * l + i];
+      ub[i] = urow_s[D / 2 + SEG * l + i];
+    }
+    uint64_t k[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) k[r] = 0ull;
+    int valid = 0, above = 0, blocks = 0;
+    auto load_rows = [&](float (&a)[SEG], float (&b)[SEG], int c) __attribute__((always_inline)) {
+      const float *row = P.item_emb + (size_t)cand_s[c] * D;
+#pragma unroll
+      for (int i = 0; i < SEG; i += 4) {
+        const float4 x = reinterpret_cast<const float4 *>(row + SEG * l)[i / 4];
+        const float4 y = reinterpret_cast<const float4 *>(row + D / 2 + SEG * l)[i / 4];
+        a[i] = x.x, a[i + 1] = x.y, a[i + 2] = x.z, a[i + 3] = x.w;
+        b[i] = y.x, b[i + 1] = y.y, b[i + 2] = y.z, b[i + 3] = y.w;
+      }
+    };
+    for (int base = 0; base < n_cand; base += 64) {
+      float sc = 0.f;                      // lane j: exact score of candidate base + j
+      float a[SEG], b[SEG];
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] = b[i] = 0.f;
+      if (base + g < n_cand) load_rows(a, b, base + g);
+      for (int it = 0; it < G; ++it) {     // pass `it`: candidates base + it * CPI + g
+        if (base + it * CPI >= n_cand) break;                      // wave-uniform
+        float ca[SEG], cb[SEG];
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) ca[i] = a[i], cb[i] = b[i];
+        const int cn = base + (it + 1) * CPI + g;                  // next pass's rows fly under this pass's chain
+        if (it + 1 < G && cn < n_cand) load_rows(a, b, cn);
+        float acc = 0.f;
+#pragma unroll
+        for (int seg = 0; seg < G; ++seg) {
+          float t = acc;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            t = __fmaf_rn(ua[i], ca[i], t);
+            t = __fmaf_rn(ub[i], cb[i], t);
+          }
+          if (l == seg) acc = t;
+          if (seg + 1 < G) {
+            const float nx = dpp_prev_lane<D>(acc);
+            if (l == seg + 1) acc = nx;
+          }
+        }
+        // the group's last lane holds the score of candidate base + it * CPI + g: route it to lane it * CPI + g
+        const float moved = __shfl(acc, (lane % CPI) * G + G - 1, 64);
+        if (lane / CPI == it) sc = moved;
+      }
+      const int idx = base + lane;
+      uint64_t cur = 0ull;
+      if (idx < n_cand) {
+        const uint32_t item = cand_s[idx];
+        // (a history member leaves the candidates: the sweep ran unmasked)
+        if (!in_hist(item)) cur = make_key(sc, item);
+      }
       valid += __popcll(__ballot(cur != 0ull));
       above += __popcll(__ballot(cur != 0ull && (uint32_t)(cur >> 32) > mord));
-      if (blocks == 0) {
-        e0 = cur;
-      } else if (blocks == 1) {
-        e1 = cur;
-      } else {
-        if (!sorted) {
-          sort128_desc(e0, e1, lane);
-          sorted = true;
-        }
-        sort128_desc(e1, cur, lane);      // the better half of (ranks 64..127, the new block) -> e1
-        sort128_desc(e0, e1, lane);
-      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        if (r == blocks) k[r] = cur;       // (blocks is wave-uniform)
       ++blocks;
-      cur = 0ull;
-    };
-    for (int base = 0; base < n_cand; base += ROWS) {
-      // cooperative fetch: instruction j brings rows j * (64 / LPRW) + lane / LPRW of the tile
-      float4 v[ROWS * LPRW / 64];
-#pragma unroll
-      for (int j = 0; j < ROWS * LPRW / 64; ++j) {
-        const int r = j * (64 / LPRW) + lane / LPRW;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (base + r < n_cand)
-          v[j] = reinterpret_cast<const float4 *>(P.item_emb + (size_t)cand_s[base + r] * D)[lane % LPRW];
-      }
-      uint32_t item = 0;
-      bool masked = true;
-      if (lane < ROWS && base + lane < n_cand) {
-        item = cand_s[base + lane];
-        masked = in_hist(item);          // (a history member leaves the candidates: the sweep ran unmasked)
-      }
-#pragma unroll
-      for (int j = 0; j < ROWS * LPRW / 64; ++j) {
-        const int r = j * (64 / LPRW) + lane / LPRW;
-        *reinterpret_cast<float4 *>(tile_s + r * STRIDE + 4 * (lane % LPRW)) = v[j];
-      }
-      __builtin_amdgcn_wave_barrier();
-      uint64_t key = 0ull;
-      if (!masked) key = make_key(exact_score_lds<D>(urow_s, tile_s + lane * STRIDE), item);
-      __builtin_amdgcn_wave_barrier();
-      const int sub = (base / ROWS) % (64 / ROWS);
-      const uint64_t moved = shfl_u64(key, lane & (ROWS - 1));
-      if ((lane / ROWS) == sub) cur = moved;
-      if (sub == 64 / ROWS - 1 || base + ROWS >= n_cand) push_block();
     }
-    n_keys = valid;
+#if defined(CHAOREC_SEL_EXP) && CHAOREC_SEL_EXP == 6
+    if (lane == 0) P.n_cand[u] = n_cand + (int)(k[0] >> 60) + (int)(k[1] >> 60);   // (experiment: expansion + scores, no ranking)
+    return;
+#endif
+    int n_keys = valid;
     // The masked row restricted to what can matter = the candidates + the user's history at mask_value.  The history
     // only joins when mask_value can reach the top-K (the reference's 1e-6 / 1e-5 does when the real scores are tiny
     // or negative: quirk Q7), i.e. when fewer than K candidates beat it.
     if (deg > 0 && above < K) {   // wave-uniform
-      for (int i0 = 0; i0 < deg; i0 += 64) {
-        const int i = i0 + lane;
-        cur = i < deg ? make_key(P.mask_value, hist_lds ? hist_s[i] : (uint32_t)P.hist_col[hb + i]) : 0ull;
-        push_block();
+      if (blocks * 64 + deg > MAXC) {
+        why = 3;
+      } else {
+        for (int i0 = 0; i0 < deg; i0 += 64) {
+          const int i = i0 + lane;
+          const uint64_t cur = i < deg ? make_key(P.mask_value, hist_lds ? hist_s[i] : (uint32_t)P.hist_col[hb + i]) : 0ull;
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            if (r == blocks) k[r] = cur;
+          ++blocks;
+        }
+        n_keys = valid + deg;
       }
-      n_keys = valid;
     }
-    if (n_keys < K) why = 2;
-    if (why == 0) {
-      if (!sorted) {
-        if (blocks <= 1) sort64_desc(e0, lane);
-        else sort128_desc(e0, e1, lane);
+    if (why == 0 && n_keys < K) why = 2;
+    bool wrote = false;
+    if (why == 0 && blocks <= 2) {
+      // Up to 128 keys (the steady state with carried thresholds): rank every key by COUNTING the keys above it --
+      // key j is broadcast from its lane (v_readlane), every lane compares it with its own two.  O(n^2) compares, but
+      // no dependent chain at all: a bitonic sort is 21..28 dependent cross-lane stages and a bitwise order-statistic
+      // search 32..64 dependent scalar steps, and it is their LATENCY this kernel was spending its time on.
+      const uint64_t k0 = k[0], k1 = NR > 1 ? k[1] : 0ull;
+      const int n0 = blocks >= 1 ? 64 : 0, n1 = blocks >= 2 ? 64 : 0;
+      uint32_t r0 = 0, r1 = 0;
+      auto lane_key = [&](uint64_t v, int j) -> uint64_t {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), j);
+        return ((uint64_t)hi << 32) | lo;
+      };
+      for (int j = 0; j < n0; ++j) {
+        const uint64_t kj = lane_key(k0, j);
+        r0 += kj > k0 ? 1u : 0u;
+        r1 += kj > k1 ? 1u : 0u;
       }
-      const int want = min(max(P.hint_rank, K), min(n_keys, 128));   // the rank whose score is the next call's threshold
+      for (int j = 0; j < n1; ++j) {
+        const uint64_t kj = lane_key(k1, j);
+        r0 += kj > k0 ? 1u : 0u;
+        r1 += kj > k1 ? 1u : 0u;
+      }
+      auto key_of_rank = [&](int rank) -> uint64_t {     // (exists: rank < n_keys; keys are unique)
+        const unsigned long long m0 = __ballot(k0 != 0ull && r0 == (uint32_t)rank);
+        if (m0) return lane_key(k0, __builtin_ctzll(m0));
+        const unsigned long long m1 = __ballot(k1 != 0ull && r1 == (uint32_t)rank);
+        return m1 ? lane_key(k1, __builtin_ctzll(m1)) : 0ull;
+      };
       // certification: the K-th best exact score must clear the threshold the sweep used
-      const uint64_t kth = shfl_u64(e0, K - 1);
+      const uint64_t kth = key_of_rank(K - 1);
       if (kth == 0ull || !(ord_to_f32((uint32_t)(kth >> 32)) > theta)) why = 4;
+      if (why == 0) {
+        if (k0 != 0ull && r0 < (uint32_t)K) {
+          P.out_idx[(size_t)u * K + r0] = (int64_t)(0xFFFFFFFFu - (uint32_t)(k0 & 0xFFFFFFFFull)) + P.id_offset;
+          P.out_val[(size_t)u * K + r0] = ord_to_f32((uint32_t)(k0 >> 32));
+        }
+        if (k1 != 0ull && r1 < (uint32_t)K) {
+          P.out_idx[(size_t)u * K + r1] = (int64_t)(0xFFFFFFFFu - (uint32_t)(k1 & 0xFFFFFFFFull)) + P.id_offset;
+          P.out_val[(size_t)u * K + r1] = ord_to_f32((uint32_t)(k1 >> 32));
+        }
+        wrote = true;
+        if (P.hint_out) {
+          // next call's threshold: one float below the exact score of rank `want` (>= K): equal scores stay candidates
+          const uint64_t hk = key_of_rank(min(max(P.hint_rank, K), n_keys) - 1);
+          if (lane == 0) P.hint_out[u] = nextafterf(ord_to_f32((uint32_t)(hk >> 32)), -INFINITY);
+        }
+      }
+    } else if (why == 0) {
+      // many keys: the K best keys (keys are unique: exactly K of them are >= the K-th largest), compacted into one register
+      // through LDS and ordered by one 64-lane sort; the next call's threshold is the exact score of rank `want`
+      const uint64_t thr = (blocks <= 4 && NR >= 4) ? kth_largest_key<(NR >= 4 ? 4 : NR)>(
+                                                           reinterpret_cast<const uint64_t (&)[(NR >= 4 ? 4 : NR)]>(k[0]), K)
+                                                     : kth_largest_key<NR>(k, K);
+      uint64_t *stage = reinterpret_cast<uint64_t *>(cand_s);      // (the candidate ids are all consumed)
+      __builtin_amdgcn_wave_barrier();
+      int base = 0;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const bool w = r < blocks && k[r] != 0ull && k[r] >= thr;
+        const unsigned long long m = __ballot(w);
+        if (w) stage[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = k[r];
+        base += __popcll(m);
+      }
+      __builtin_amdgcn_wave_barrier();
+      e0 = lane < base ? stage[lane] : 0ull;
+      sort64_desc(e0, lane);
+      if (!(ord_to_f32((uint32_t)(thr >> 32)) > theta)) why = 4;
       if (why == 0 && P.hint_out) {
-        // next call's threshold: one float below the exact score of rank `want` (>= K): equal scores stay candidates
-        const int r1 = want - 1;
-        const uint64_t hk = r1 < 64 ? shfl_u64(e0, r1) : shfl_u64(e1, r1 - 64);
+        const int want = min(max(P.hint_rank, K), n_keys);
+        const uint64_t hk = want == K ? thr : kth_largest_key<NR>(k, want);
         if (lane == 0) P.hint_out[u] = nextafterf(ord_to_f32((uint32_t)(hk >> 32)), -INFINITY);
       }
     }
+    if (wrote) e0 = 0ull;      // (the counting path stored its rows itself)
+    written_by_rank = wrote;
   }
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) {
@@ -941,27 +1020,28 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
       else P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;
     }
   }
-  if (why == 0 && lane < K) {
+  if (why == 0 && !written_by_rank && lane < K) {
     const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
     P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;
     P.out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
   }
 }
 
-// One wave per user (a fixed grid walking the rows of the pass).  LDS per wave at D = 64: 256 B prefix sums + 2 KiB
-// candidate ids + 512 B history + 256 B user row + 4.25 KiB row tile = 7.25 KiB -> 5 waves per SIMD.
+// One wave per user (a fixed grid walking the rows of the pass).
+#ifndef CHAOREC_SEL_WAVES
+#define CHAOREC_SEL_WAVES 5
+#endif
 template <int D, int MAXC>
-__global__ __launch_bounds__(64, MAXC <= 512 ? 5 : 4) void score_select_kernel_pf(const PrefArgs P) {
+__global__ __launch_bounds__(64, MAXC <= 512 ? CHAOREC_SEL_WAVES : 3) void score_select_kernel_pf(const PrefArgs P) {
   __shared__ int incl_s[64];
   __shared__ uint32_t cand_s[MAXC];
   __shared__ uint32_t hist_s[kPfSelHist];
   __shared__ float4 urow_s[D / 4];
-  __shared__ float4 tile_s[SelLds<D>::ROWS * SelLds<D>::STRIDE / 4];
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
   if (n_act <= P.min_active) return;
   for (int64_t i = blockIdx.x; i < n_act; i += gridDim.x) {
     const int64_t u = P.user_map ? (int64_t)P.user_map[i] : i;
-    select_user<D, MAXC>(P, u, incl_s, cand_s, hist_s, reinterpret_cast<float *>(urow_s), reinterpret_cast<float *>(tile_s));
+    select_user<D, MAXC>(P, u, incl_s, cand_s, hist_s, reinterpret_cast<float *>(urow_s));
     __builtin_amdgcn_wave_barrier();
   }
 }

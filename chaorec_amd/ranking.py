@@ -27,11 +27,11 @@ def _to_host(idx):
 
 class RankState:
     """What one model's evaluations carry from call to call: the per-user candidate thresholds of
-    chaorec_score_topk_hinted_f32 (each gene_ranklist() leaves, per user, the exact score of rank ~1.6 K for the next
+    chaorec_score_topk_hinted_f32 (each gene_ranklist() leaves, per user, the exact score of rank 2 K for the next
     one: one epoch of training moves the scores little, so the next call needs no sampling pass and re-scores about
     half the candidates).  The thresholds never change a result; stale ones only cost a retry."""
 
-    LIGHT_BELOW = 64     # a call whose predecessor queued at most this many users for the retry pass runs without one
+    LIGHT_BELOW = 256    # a call whose predecessor queued at most this many users for the retry pass runs without one
 
     def __init__(self):
         self.hint, self.valid = None, False
@@ -77,7 +77,7 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
             hint = state.buffer(num_user, result.device)
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                     id_offset=num_user, hint=hint, hint_valid=state.valid,
-                                    hint_rank=max(topk + 14, (topk * 8 + 4) // 5), light=state.light(),
+                                    hint_rank=min(2 * topk, 128), light=state.light(),
                                     counters=state.counters)
             state.after_call()
         else:

@@ -377,7 +377,7 @@ def _check_all_precisions(dev, oracle, ue, ie, hist, mask, K, id_offset=0):
         assert np.array_equal(got_i.cpu().numpy(), want_i), name
         c = counters.tolist()
         assert 0 <= c[0] <= U and 0 <= c[1] <= U and c[3] <= c[0], (name, c)
-        if name.startswith("light"):
+        if name.startswith("light") and ie.shape[0] < 131072:     # (very long item ranges keep their retry pass)
             assert c[3] == c[0], (name, c)        # no retry pass: everything pass A queued went to the exact route
 
 

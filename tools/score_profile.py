@@ -42,6 +42,12 @@ def main():
     ue, ie = res[:U], res[U:U + I]
     hint = torch.empty(U, dtype=torch.float32, device=dev)
     st = {}
+    if os.environ.get("ONLY_CARRIED"):
+        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=False)
+        for _ in range(8):
+            ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, light=True)
+        torch.cuda.synchronize()
+        return
     cold = timed(lambda: ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U))
     ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, stats=st)
     print(f"cold                      {cold * 1e3:7.1f} us  cand/user {st['candidates'] / U:6.1f}  exact-route users {st['fallback_users']}")
@@ -50,21 +56,23 @@ def main():
     ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, stats=st)
     print(f"carried, same tables      {same * 1e3:7.1f} us  cand/user {st['candidates'] / U:6.1f}  exact-route users {st['fallback_users']}")
     # one epoch apart: hints from the tables before 155 more steps
-    ts = []
-    for ep in range(4):
-        step.run(155)
-        res = m.result.detach()
-        ue, ie = res[:U], res[U:U + I]
-        h2 = hint.clone()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        s.record()
-        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True)
-        e.record()
-        torch.cuda.synchronize()
-        ts.append(s.elapsed_time(e))
-        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=h2, hint_valid=True, stats=st)
-        print(f"carried, one epoch apart  {ts[-1] * 1e3:7.1f} us  cand/user {st['candidates'] / U:6.1f}  exact-route users {st['fallback_users']}")
+    for rank in [int(x) for x in os.environ.get("HINT_RANKS", "80").split(",")]:
+        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=False, hint_rank=rank)
+        counters = torch.zeros(4, dtype=torch.int32, device=dev)
+        for ep in range(int(os.environ.get('EPOCHS', '4'))):
+            step.run(155)
+            res = m.result.detach()
+            ue, ie = res[:U], res[U:U + I]
+            light = ep > 0 and int(counters[0]) <= 256
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s.record()
+            ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, hint_rank=rank, light=light,
+                           counters=counters)
+            e.record()
+            torch.cuda.synchronize()
+            print(f"carried (rank {rank}), one epoch apart, light={int(light)}  {s.elapsed_time(e) * 1e3:7.1f} us  "
+                  f"queues [retry, exact, wide, retry->exact] {counters.tolist()}")
 
 
 if __name__ == "__main__":
