@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
 #define CHAOREC_SEL_WAVES 5
 #endif
 template <int D, int MAXC>
-__global__ __launch_bounds__(64, MAXC <= 512 ? CHAOREC_SEL_WAVES : 3) void score_select_kernel_pf(const PrefArgs P) {
+__global__ __launch_bounds__(64, D > 64 ? 3 : (MAXC <= 512 ? CHAOREC_SEL_WAVES : 3)) void score_select_kernel_pf(const PrefArgs P) {
   __shared__ int incl_s[64];
   __shared__ uint32_t cand_s[MAXC];
   __shared__ uint32_t hist_s[kPfSelHist];
