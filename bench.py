@@ -75,7 +75,7 @@ def probe_sharded_graph(args, world):
                TORCHELASTIC_USE_AGENT_STORE="False")     # the children rendezvous among themselves, not at the agent
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", "3", "--warmup", "1",
            "--dataset", args.dataset, "--dim", str(args.dim), "--n-layers", str(args.n_layers), "--batch",
-           str(args.batch), "--no-cpu-baseline", "--no-trained-state", "--probe-graph"]
+           str(args.batch), "--no-cpu-baseline", "--no-trained-state", "--probe-graph"] + (["--synthetic"] if args.synthetic else [])
     try:
         rc = subprocess.run(cmd, env=env, timeout=float(os.environ.get("CHAOREC_PROBE_TIMEOUT_S", "300")),
                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
@@ -518,147 +518,103 @@ def main_single(args, dev):
 
 
 def main_sharded(args, world, rank, local_rank, force_sharded):
+    """N > 1 (weak scaling): rank g owns one copy of the dataset's users over the shared item set, the item partials
+    of every layer are summed over RCCL (chaorec_amd/dist.py; CHAOREC_DIST_EXCHANGE picks the collective)."""
     backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
     probe_ok = None
-    if ((world > 1 or force_sharded) and backend == "nccl" and not args.probe_graph and not args.no_graph
-            and not args.torch_adam and os.environ.get("CHAOREC_DIST_GRAPH") is None):
+    if (backend == "nccl" and not args.probe_graph and not args.no_graph and not args.torch_adam
+            and os.environ.get("CHAOREC_DIST_GRAPH") is None):
         probe_ok = probe_sharded_graph(args, world)        # before anything here initialises the GPU
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     local_rank %= torch.cuda.device_count()     # (lets a 1-GPU box exercise the N>1 code path with gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or force_sharded:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
 
     if args.probe_graph and not captured_all_reduce_is_exact(dev, world, rank):
         print(f"[bench probe rank {rank}] a captured all-reduce returned stale sums on replay", file=sys.stderr, flush=True)
         sys.exit(4)
 
-    from chaorec_amd import _lib, graph, ops
-    from chaorec_amd.Model import LightGCN
+    from chaorec_amd import _lib, ops
+    from chaorec_amd import dist as cdist
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
     _lib.ensure_built()
-    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
     _lib.load()
-
-    U1, I, E1 = DATASET_SHAPES[args.dataset]
     D, L, B, reg = args.dim, args.n_layers, args.batch, 1e-3
-
-    if world == 1 and not force_sharded:
-        U = U1
-        edges = synthetic_interactions(U1, I, E1, seed=42)
-        torch.manual_seed(42)
-        model = LightGCN(U, I, edges, graph.user_item_dict_from_edges(edges), D, reg, L, "add", dev).to(dev)
-        sharded = None
-    else:
-        from chaorec_amd import dist as cdist
-        sharded = cdist.build_weak_scaling_job(U1, I, E1, world, rank, D, L, reg, dev, seed=42)
-        model, edges, U = sharded.model, sharded.local_edges, sharded.num_user_local
-
+    job = cdist.build_weak_scaling_job(args.dataset, world, rank, D, L, reg, dev, seed=42, synthetic=args.synthetic)
+    model, edges, U, I, U1 = job["model"], job["local_edges"], job["num_user_local"], job["I"], job["U1"]
     E = len(edges)
     e_dir = 2 * E
-    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
     opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else FusedAdam(model.parameters(), lr=1e-3)
     edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(42 + rank)
     loss_sum = torch.zeros((), device=dev)
-
     batch_counter = torch.zeros(1, dtype=torch.int64, device=dev)   # device-resident: advances inside the graph
 
     def draw(i=None):
-        """One batch in ONE launch (chaorec_draw_batch): B training edges picked uniformly (DataLoader(shuffle=True)
-        stand-in) + one sampled negative each, LOCAL item ids.  i=None: graph-capturable form, the batch index
-        comes from the device counter."""
+        """One batch in ONE launch (chaorec_draw_batch): B training edges of this rank picked uniformly + one sampled
+        negative each, LOCAL item ids.  i=None: graph-capturable form, the batch index comes from the device counter."""
         if i is None:
             batch_counter.add_(1)
             return ops.draw_batch(edges_dev, model.hist, B, model.num_user, I, 42 + rank, 0, step_dev=batch_counter)
         return ops.draw_batch(edges_dev, model.hist, B, model.num_user, I, 42 + rank, 1_000_000 + i)
 
-    # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph.  The sharded step holds
-    # RCCL all-reduces; they are captured with it when the backend is RCCL (CHAOREC_DIST_GRAPH=0 keeps it eager).
-    # Every rank must run the same launch mode: if the capture fails anywhere, all ranks fall back to eager.
-    # the unsharded model draws its batch INSIDE the fused BPR forward (one launch less per step)
-    fused_draw = hasattr(model, "loss_drawn")
-
-    def no_batch():
-        return ()
-
-    def drawn_loss():          # (the fused launch also advances the device batch counter)
-        loss = model.loss_drawn(edges_dev, B, 42 + rank, 0, step_dev=batch_counter, advance=True)
-        loss_sum.add_(loss.detach())      # per-batch loss bookkeeping inside the captured step: replays run back to back
-        return loss
-
-    use_graph = not args.no_graph and not args.torch_adam
-    if sharded is not None:
-        use_graph = use_graph and backend == "nccl" and os.environ.get("CHAOREC_DIST_GRAPH", "1") == "1"
-        if probe_ok is not None:
-            # the launch mode must be the same on every rank BEFORE anyone starts capturing collectives
-            flag = torch.tensor([1.0 if (use_graph and probe_ok) else 0.0], device=dev)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-            use_graph = float(flag.item()) > 0.0
+    # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph, RCCL calls included
+    # (CHAOREC_DIST_GRAPH=0 keeps it eager).  Every rank must run the same launch mode.
+    use_graph = (not args.no_graph and not args.torch_adam and backend == "nccl"
+                 and os.environ.get("CHAOREC_DIST_GRAPH", "1") == "1")
+    if probe_ok is not None:
+        flag = torch.tensor([1.0 if (use_graph and probe_ok) else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_graph = float(flag.item()) > 0.0
     graphed = None
     if use_graph:
         try:
-            graphed = (GraphedTrainStep(model, opt, batch_fn=no_batch, loss_fn=drawn_loss) if fused_draw else
-                       GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local))
+            graphed = GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local)
         except Exception as exc:      # noqa: BLE001 -- any capture failure means "launch eagerly", never a wrong result
-            if sharded is None:
-                raise
             print(f"[bench rank {rank}] hipGraph capture of the sharded step failed ({exc!r}); eager launches",
                   file=sys.stderr)
             graphed = None
-        if sharded is not None:
-            # every rank must run the same launch mode, and must agree on it BEFORE anyone replays a graph that holds
-            # collectives (a replay on one rank against an eager collective on another would pair mismatched calls)
+        torch.cuda.synchronize()
+        ok = torch.tensor([1.0 if graphed is not None else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            graphed = None
+        if graphed is not None:
+            # first replays of a graph holding RCCL kernels, under a watchdog: a launch mode that cannot make progress
+            # must end the job with a message, not sit on the GPUs until an outer timeout
+            import threading
+            done = threading.Event()
+
+            def watchdog():
+                if not done.wait(float(os.environ.get("CHAOREC_GRAPH_WATCHDOG_S", "120"))):
+                    print(f"[bench rank {rank}] captured sharded step did not complete; rerun with "
+                          f"CHAOREC_DIST_GRAPH=0", file=sys.stderr, flush=True)
+                    os._exit(17)
+
+            threading.Thread(target=watchdog, daemon=True).start()
+            for _ in range(2):
+                graphed()
             torch.cuda.synchronize()
-            ok = torch.tensor([1.0 if graphed is not None else 0.0], device=dev)
-            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-            if float(ok.item()) < 1.0:
-                graphed = None
-            if graphed is not None:
-                # first replays of a graph holding RCCL kernels, under a watchdog: a launch mode that cannot make
-                # progress must end the job with a message, not sit on the GPUs until an outer timeout
-                import threading
-                done = threading.Event()
-
-                def watchdog():
-                    if not done.wait(float(os.environ.get("CHAOREC_GRAPH_WATCHDOG_S", "120"))):
-                        print(f"[bench rank {rank}] captured sharded step did not complete; rerun with "
-                              f"CHAOREC_DIST_GRAPH=0", file=sys.stderr, flush=True)
-                        os._exit(17)
-
-                threading.Thread(target=watchdog, daemon=True).start()
-                for _ in range(2):
-                    graphed()
-                torch.cuda.synchronize()
-                done.set()
+            done.set()
 
     n_loss = [0]
-    in_graph_sum = graphed is not None and fused_draw
-    if in_graph_sum:
-        loss_sum.zero_()              # (the capture's warm-up steps ran drawn_loss() too)
 
     def step(i, force_eager=False):
         n_loss[0] += 1
         if graphed is not None and not force_eager:
             graphed()                 # sampling + loss + backward + Adam: one hipGraph replay, no inputs
-            if in_graph_sum:
-                return
             loss = graphed.static_loss
         else:
             opt.zero_grad(set_to_none=True)
-            if fused_draw:
-                loss = model.loss_drawn(edges_dev, B, 42 + rank, 1_000_000 + i)
-            else:
-                loss = model.loss_local(*draw(i))
+            loss = model.loss_local(*draw(i))
             loss.backward()
             opt.step()
             loss = loss.detach()
@@ -666,8 +622,7 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -678,22 +633,17 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
         step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    e_dir_all = e_dir
-    if world > 1:
-        t = torch.tensor([float(e_dir)], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t)
-        e_dir_all = int(t.item())
+    t = torch.tensor([float(e_dir), float(U)], device=dev, dtype=torch.float64)
+    dist.all_reduce(t)
+    e_dir_all, n_scored = int(t[0].item()), float(t[1].item())
     msgs_per_step_all = 2 * L * e_dir_all
     value = msgs_per_step_all / (dt / args.steps)
 
-    # --- SpMM roofline: HIP events on the launch stream around back-to-back re-launches of the step's own
-    # SpMM calls (same graph, operands and epilogues as the timed step: 3 forward + 3 backward launches).
-    # A single launch bracketed by events from Python mostly times the host; a saturated queue times the kernel.
+    # --- SpMM roofline: the step's own SpMM calls (the shard's two block products per layer), re-launched back to back
     calls = []
     orig = ops.spmm_raw
 
@@ -706,151 +656,73 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
     step(args.warmup + args.steps, force_eager=True)
     ops.spmm_raw = orig
     torch.cuda.synchronize()
-    # five passes over the step's SpMM calls, 20 back-to-back launches each; the figure is the MEDIAN pass average (one
-    # pass that collides with something else on the box -- a previous process winding down -- must not set the number)
-    reps, pass_avg, tot_bytes, tot_comp, tot_launch = 20, [], 0.0, 0.0, 0
-    for _ in range(5):
-        pass_ms, pass_launch = 0.0, 0
-        for csr, x, a, k in calls:
-            k = dict(k)
-            if k.get("acc") is not None:
-                k["acc"] = k["acc"].clone()          # keep the model state out of the measurement
-            orig(csr, x, *a, **k)                    # warm
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(reps):
-                orig(csr, x, *a, **k)
-            e.record()
-            torch.cuda.synchronize()
-            pass_ms += s.elapsed_time(e)
-            pass_launch += reps
-            tot_launch += reps
-            tot_bytes += reps * spmm_model_bytes(csr.nnz, csr.n_rows, x.shape[1])
-            tot_comp += reps * (2 * csr.n_rows * 4 * x.shape[1] + csr.nnz * 8)
-        pass_avg.append(pass_ms / pass_launch)
-    avg_spmm_ms = float(np.median(pass_avg))
-    model_bytes = tot_bytes / tot_launch
-    compulsory = tot_comp / tot_launch
-    n_rows = model.graph.n_rows
+    timed = []
+    for csr, x, a, k in calls:
+        k = dict(k)
+        for name in ("acc", "y"):
+            if k.get(name) is not None:
+                k[name] = k[name].clone()            # keep the model state out of the measurement
+        timed.append((lambda csr=csr, x=x, a=a, k=k: orig(csr, x, *a, **k), csr, x.shape[1]))
+    avg_spmm_ms, model_bytes, compulsory = time_spmm_calls(ops, timed)
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "spmm_traffic.json")
-    # (measured on the N=1 sports / D=64 kernel over the full graph; not the shard blocks, not other shapes)
-    if os.path.exists(tpath) and sharded is None and args.dataset == "sports" and D == 64:
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    d4 = D // 4
-    lpr = 1
-    while lpr < min(d4, 64):
-        lpr *= 2
-    table_mb = n_rows * D * 4 / 1e6
-    roofline = {"bound": "hbm", "kernel": f"spmm_csr_ordered_kernel<{lpr},{max(1, (d4 + 63) // 64)}>", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": model_bytes, "avg_launch_us": avg_spmm_ms * 1e3,
-                "compulsory_bytes_per_launch": compulsory,
-                "note": ("embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is against "
-                         "the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)" % table_mb)
-                if table_mb < 256 else
-                ("embedding table %.0f MB, beyond the 256 MiB Infinity Cache: HBM-bound regime; `achieved` counts the "
-                 "no-reuse CSR model bytes, the DRAM traffic is lower by the cache reuse of hot rows" % table_mb)}
+    roofline = {"bound": "hbm", "kernel": spmm_kernel_name(D), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": model_bytes,
+                "avg_launch_us": avg_spmm_ms * 1e3, "compulsory_bytes_per_launch": compulsory,
+                "launches_per_step": len(calls),
+                "note": "rank 0's shard blocks (user x item and item x user rows of the normalised graph)"}
 
-    # --- full-rank evaluation: users scored per second ---------------------------------------------
-    def time_ranklist():
+    # --- full-rank evaluation: every rank ranks its own users against the replicated item table, no exchange --------
+    torch.cuda.synchronize()
+    model.gene_ranklist()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    st = {}
+    with torch.no_grad():
+        ru, ri = model.result_u.detach(), model.result_i.detach()
+        for s_, e_ in ev:
+            s_.record()
+            ops.score_topk(ru, ri, model.hist, 1e-6, 50, id_offset=model.shard.num_user_global)
+            e_.record()
         torch.cuda.synchronize()
-        model.gene_ranklist()
-        torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-        st = {}
-        with torch.no_grad():
-            res = model.result.detach()
-            for s, e in ev:
-                s.record()
-                ops.score_topk(res[:model.num_user], res[model.num_user:model.num_user + I], model.hist, 1e-6, 50,
-                               id_offset=model.num_user)
-                e.record()
-            torch.cuda.synchronize()
-            ops.score_topk(res[:model.num_user], res[model.num_user:model.num_user + I], model.hist, 1e-6, 50,
-                           id_offset=model.num_user, stats=st)
-        ms = float(np.median([s.elapsed_time(e) for s, e in ev]))
-        if world > 1:
-            t = torch.tensor([ms], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            ms = float(t.item())
-        return ms, st
-
-    n_scored = U
-    if world > 1:
-        t = torch.tensor([float(U)], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t)
-        n_scored = float(t.item())
-    # (1) on the embeddings the timed steps left behind; (2) after training on to TRAINED_STEPS steps in total,
-    # untimed: a few hundred steps from the xavier initialisation the propagated tables still have a handful of
-    # items with outsized norms, which widens the prefilter's error band for some users (they take the exact
-    # per-user route); a trained table does not.  Both are reported; (2) is skipped when it would take > ~10 s.
-    steps_done = args.warmup + args.steps + 1
-    early_ms, early_st = time_ranklist()
-    score_ms, st, state = early_ms, early_st, f"after {steps_done} training steps"
-    extra = TRAINED_STEPS - steps_done
-    if extra > 0 and extra * ms_per_step < 10_000 and not args.no_trained_state:
-        for i in range(extra):
-            step(steps_done + i)
-        score_ms, st = time_ranklist()
-        state = f"after {TRAINED_STEPS} training steps ({extra} of them untimed, past the measured ones)"
-    users_per_s = n_scored / (score_ms * 1e-3)
-    score_flops = 2.0 * U * I * D
-    tf = score_flops / (score_ms * 1e-3) / 1e12
-    roofline_scoring = {"bound": "mfma", "kernel": f"score_sweep_bf16_kernel<{D},2> (+ sample, select/re-score)",
-                        "achieved": tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf / BF16_MFMA_PEAK_TFLOPS,
-                        "frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS,
-                        "prefilter": st,
-                        "note": "2*U*I*D over the whole gene_ranklist call.  The [U,I] sweep runs on the bf16 MFMA pipe "
-                                "(v_mfma_f32_32x32x16_bf16, 2.5 PF dense peak) as a prefilter with a proven error "
-                                "bound, the top-K is ranked on exact fp32 re-scores (bit-identical to the fp32 route, "
-                                "157 TF peak); the call is bound by per-score selection work (VALU), not by MFMA "
-                                "issue -- see DESIGN.md"}
-
+        ops.score_topk(ru, ri, model.hist, 1e-6, 50, id_offset=model.shard.num_user_global, stats=st)
+    score_ms = float(np.median([s_.elapsed_time(e_) for s_, e_ in ev]))
+    t = torch.tensor([score_ms], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    score_ms = float(t.item())
+    tf = 2.0 * n_scored * I * D / (score_ms * 1e-3) / 1e12
+    r = dict(D=D, score_tf=tf, score_st=st)
     out = {
         "metric": f"GCN edges/sec + full-rank users-scored/sec, dim={D}",
         "value": value, "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
-        "users_scored_per_s": users_per_s,
-        "users_scored_per_s_right_after_timed_steps": n_scored / (early_ms * 1e-3),
+        "users_scored_per_s": n_scored / (score_ms * 1e-3),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"LightGCN train step on {args.dataset}-shaped synthetic graph "
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": job["data"],
+        "config": {"workload": f"LightGCN train step, {args.dataset} graph replicated by user rows: rank g owns the {U1} "
+                               f"users of the {job['data']} graph as users g*{U1}.. over the same {I} items "
                                f"(U={U1}x{world}, I={I}, E_dir={e_dir_all}), dim={D}, n_layers={L}, batch={B}x{world}; "
-                               f"gene_ranklist top-50 over all users",
+                               f"gene_ranklist top-50 over all users (cold thresholds)",
                    "messages_per_step": msgs_per_step_all, "gene_ranklist_ms": score_ms,
-                   "gene_ranklist_state": state, "gene_ranklist_ms_right_after_timed_steps": early_ms,
-                   "prefilter_right_after_timed_steps": early_st,
                    "launch": "captured hipGraph per step" if graphed is not None else "eager launches",
                    "optimizer": "torch.optim.Adam" if args.torch_adam else "FusedAdam (chaorec_adam_step_f32)",
-                   "parallelism": "single GPU" if world == 1 else f"user-row shards x{world}, item all-reduce per layer"},
-        "roofline": roofline, "roofline_scoring": roofline_scoring,
+                   "parallelism": f"user-row shards x{world}; item partials summed per layer by "
+                                  f"{cdist.exchange_mode()} over {backend}"},
+        "roofline": roofline, "roofline_scoring": scoring_roofline(r),
         "loss_mean": float(loss_sum.item()) / max(n_loss[0], 1),
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(edges, U, I, D, L, B, reg, args.cpu_seconds)
-    if world > 1 or force_sharded:
-        torch.distributed.destroy_process_group()
+    dist.destroy_process_group()
     if args.probe_graph:
         sys.exit(0 if graphed is not None else 3)
     if rank == 0:
-        if world > 1 or force_sharded:
-            # RCCL writes its version banner through C stdio, which would otherwise drain at exit, AFTER the result:
-            # flush C stdout first so that the JSON object is the last line (stdout only -- an fflush(NULL) from here
-            # hung under rocprofv3, which keeps streams of its own)
-            import ctypes
-            libc = ctypes.CDLL(None)
-            try:
-                libc.fflush(ctypes.c_void_p.in_dll(libc, "stdout"))
-            except (ValueError, OSError):
-                pass
+        # RCCL writes its version banner through C stdio, which would otherwise drain at exit, AFTER the result: flush C
+        # stdout first so that the JSON object is the last line (stdout only -- an fflush(NULL) from here hung under
+        # rocprofv3, which keeps streams of its own)
+        import ctypes
+        libc = ctypes.CDLL(None)
+        try:
+            libc.fflush(ctypes.c_void_p.in_dll(libc, "stdout"))
+        except (ValueError, OSError):
+            pass
         print(json.dumps(out), flush=True)
-
-
 
 
 def main():

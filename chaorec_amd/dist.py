@@ -40,49 +40,123 @@ class UserShard:
     """Rank-local graph blocks: `ui` rows = local users / cols = items, `iu` rows = items / cols = local users."""
 
     def __init__(self, edges, num_user, num_item, world, rank, device, self_loops=False):
-        """self_loops: BasicGCN's D^-1/2 (A + I) D^-1/2 (BasicGCN.py:37-46): degrees count the loop, the loop's own
-        weight 1/(d+1) is kept as the diagonals `diag_u` (local users) / `diag_i` (items)."""
+        """From the WHOLE edge list (every rank holds it: small graphs, tests).  self_loops: BasicGCN's
+        D^-1/2 (A + I) D^-1/2 (BasicGCN.py:37-46): degrees count the loop, the loop's own weight 1/(d+1) is kept as the
+        diagonals `diag_u` (local users) / `diag_i` (items)."""
         e = np.asarray(edges, dtype=np.int64)
         u, i = e[:, 0], e[:, 1] - num_user
-        deg_u = np.bincount(u, minlength=num_user) + (1 if self_loops else 0)
-        deg_i = np.bincount(i, minlength=num_item) + (1 if self_loops else 0)
-        self.bounds = partition_users_by_nnz(deg_u - (1 if self_loops else 0), world)
+        bounds = partition_users_by_nnz(np.bincount(u, minlength=num_user), world)
+        sel = (u >= bounds[rank]) & (u < bounds[rank + 1])
+        deg_i = np.bincount(i, minlength=num_item)
+        self._build(u[sel], i[sel], deg_i, bounds, num_user, num_item, world, rank, device, self_loops)
+
+    @classmethod
+    def from_local(cls, local_edges, bounds, num_item, world, rank, device, group=None, self_loops=False):
+        """Per-rank construction: `local_edges` [E_g, 2] holds ONLY this rank's users -- GLOBAL user ids
+        in [bounds[rank], bounds[rank+1]), item ids as item + num_user_global -- so no rank ever generates, loads or
+        sorts the whole graph.  The one global quantity the normalisation needs, the item degrees, is an all-reduce
+        of the ranks' local counts ([I] int64: 16 MB at 2 M items)."""
+        self = cls.__new__(cls)
+        num_user = int(bounds[-1])
+        e = np.asarray(local_edges, dtype=np.int64)
+        u, i = e[:, 0], e[:, 1] - num_user
+        if len(u) and (u.min() < bounds[rank] or u.max() >= bounds[rank + 1]):
+            raise ValueError("from_local: an edge of a user this rank does not own")
+        deg_i = torch.from_numpy(np.bincount(i, minlength=num_item).astype(np.int64))
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            backend = dist.get_backend(group)
+            t = deg_i.to(device) if backend == "nccl" else deg_i
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            deg_i = t.cpu()
+        self._build(u, i, deg_i.numpy(), list(bounds), num_user, num_item, world, rank, device, self_loops)
+        return self
+
+    def _build(self, u, il, deg_i, bounds, num_user, num_item, world, rank, device, self_loops):
+        self.bounds = [int(b) for b in bounds]
         self.u0, self.u1 = self.bounds[rank], self.bounds[rank + 1]
         self.num_user_global, self.num_item, self.world, self.rank = num_user, num_item, world, rank
-        sel = (u >= self.u0) & (u < self.u1)
-        ul, il = u[sel] - self.u0, i[sel]
+        n_local = self.u1 - self.u0
+        ul = u - self.u0
+        loop = 1 if self_loops else 0
+        deg_u = np.bincount(ul, minlength=n_local) + loop            # this rank's users only: all their edges are here
+        deg_i = np.asarray(deg_i) + loop
         # same fp32 normalisation as graph.lightgcn_csr, with GLOBAL degrees
         dis_u = torch.from_numpy(deg_u.astype(np.float32)).pow(-0.5)
         dis_i = torch.from_numpy(deg_i.astype(np.float32)).pow(-0.5)
-        w = dis_u[torch.from_numpy(u[sel])] * dis_i[torch.from_numpy(il)]
-        n_local = self.u1 - self.u0
+        w = dis_u[torch.from_numpy(ul)] * dis_i[torch.from_numpy(il)]
         self.ui = graph.coo_to_csr(ul, il, w, n_local, num_item).to(device)        # y_u = B_g x_i
         self.iu = graph.coo_to_csr(il, ul, w, num_item, n_local).to(device)        # p_i = B_g^T x_u
         self.ui._t, self.iu._t = self.iu, self.ui
         self.local_edges = np.stack([ul, il + n_local], 1).astype(np.int32)        # shard-local id convention
         self.num_user_local = n_local
+        self.nnz = int(len(ul))
         self.diag_u = self.diag_i = None
         if self_loops:
-            self.diag_u = (dis_u[self.u0:self.u1] * dis_u[self.u0:self.u1]).view(-1, 1).to(device)
+            self.diag_u = (dis_u * dis_u).view(-1, 1).to(device)
             self.diag_i = (dis_i * dis_i).view(-1, 1).to(device)
 
 
+# CHAOREC_FORCE_COLLECTIVES=1: issue the exchanges on a 1-rank group too, so that a 1-GPU box exercises the
+# RCCL launch (and hipGraph capture of it) that the N>1 job uses
+import os as _os
+_FORCE_COLLECTIVES = _os.environ.get("CHAOREC_FORCE_COLLECTIVES", "0") == "1"
+
+# How the ranks' [I, D] item partials are summed (SURVEY 8(e) "Collective choice"; CHAOREC_DIST_EXCHANGE):
+#   allreduce  one all-reduce (RCCL picks ring / tree: a ring is bound by ONE xGMI link, 2 * 7/8 * bytes / 153 GB/s)
+#   rs_ag      reduce-scatter + all-gather of 1/world row blocks (RCCL's own algorithms for each half)
+#   direct     the reduce-scatter as ONE all-to-all -- every rank sends block j straight to rank j, all 7 links at
+#              once, and sums the 8 blocks it receives itself -- then the all-gather: 2 * bytes / 8 / 153 GB/s per
+#              half on a fully connected xGMI node (1.7 ms instead of 11.7 ms for config 5's 1.02 GB)
+# Same sums up to fp32 association.  No multi-GPU node was available to time them against each other (DESIGN 6).
+EXCHANGE_MODES = ("allreduce", "rs_ag", "direct")
+
+
+def exchange_mode():
+    m = _os.environ.get("CHAOREC_DIST_EXCHANGE", "allreduce")
+    if m not in EXCHANGE_MODES:
+        raise ValueError(f"CHAOREC_DIST_EXCHANGE={m}: one of {EXCHANGE_MODES}")
+    return m
+
+
+def _active(group):
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES)
+
+
+def padded_rows(n_rows, group=None):
+    """Rows of an exchange buffer: a multiple of the world size, so that it splits into equal row blocks."""
+    w = dist.get_world_size(group) if dist.is_initialized() else 1
+    return (n_rows + w - 1) // w * w
+
+
+def exchange_buffer(n_rows, D, like, group=None):
+    """-> (padded [rows_pad, D] buffer, its [n_rows, D] view).  The pad rows take part in the sums and are never read."""
+    buf = torch.empty((padded_rows(n_rows, group), D), dtype=like.dtype, device=like.device)
+    if buf.shape[0] > n_rows:
+        buf[n_rows:].zero_()
+    return buf, buf[:n_rows]
+
+
 def _all_reduce(t, group):
-    if dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES):
+    if _active(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
 class _Pending:
-    """Handle of an all-reduce issued with async_op=True (RCCL runs it on its own stream, so the SpMM launched
-    next on the compute stream overlaps it; wait() makes the compute stream depend on the result)."""
+    """Handle of an exchange in flight (RCCL runs it on its own stream, so the SpMM launched next on the compute
+    stream overlaps it; wait() makes the compute stream depend on the result).  `then` runs the second half of a
+    two-step exchange once the first has arrived."""
 
-    def __init__(self, work):
-        self.work = work
+    def __init__(self, work, then=None):
+        self.work, self.then = work, then
 
     def wait(self):
         if self.work is not None:
             self.work.wait()
+            self.work = None
+        if self.then is not None:
+            nxt, self.then = self.then, None
+            nxt().wait()
 
 
 def _mean_all(x):
@@ -91,16 +165,35 @@ def _mean_all(x):
     return ops.mean_all(x) if x.is_cuda else x.mean()
 
 
+def _sum_exchange_async(buf, group):
+    """Sum `buf` ([rows_pad, D], rows_pad a multiple of the world size) over the ranks, in place, asynchronously."""
+    if not _active(group):
+        return _Pending(None)
+    mode = exchange_mode()
+    if mode == "allreduce" or buf.shape[0] % dist.get_world_size(group):
+        return _Pending(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rows = buf.shape[0] // world
+    mine = buf[rank * rows:(rank + 1) * rows]
+    if mode == "rs_ag":
+        chunk = torch.empty_like(mine)
+        rs = dist.reduce_scatter_tensor(chunk, buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return _Pending(rs, lambda: _Pending(dist.all_gather_into_tensor(buf, chunk, group=group, async_op=True)))
+    recv = torch.empty_like(buf)                       # block j of `recv` = rank j's partial of MY row block
+    a2a = dist.all_to_all_single(recv, buf, group=group, async_op=True)
+
+    def gather():
+        chunk = recv.view(world, rows, -1).sum(0)
+        return _Pending(dist.all_gather_into_tensor(buf, chunk, group=group, async_op=True))
+
+    return _Pending(a2a, gather)
+
+
 def _all_reduce_async(t, group):
-    if dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES):
+    """Whole-tensor all-reduce (small / unpadded tensors)."""
+    if _active(group):
         return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
     return _Pending(None)
-
-
-# CHAOREC_FORCE_COLLECTIVES=1: issue the all-reduces on a 1-rank group too, so that a 1-GPU box exercises the
-# RCCL launch (and hipGraph capture of it) that the N>1 job uses
-import os as _os
-_FORCE_COLLECTIVES = _os.environ.get("CHAOREC_FORCE_COLLECTIVES", "0") == "1"
 
 
 class _ShardedLayerMean(torch.autograd.Function):
@@ -118,10 +211,12 @@ class _ShardedLayerMean(torch.autograd.Function):
         # Layer l+1's item partial B_g^T x_u only needs this rank's user rows of layer l, not the all-reduce of layer
         # l's partial: the wait for an all-reduce is therefore deferred until the user-row SpMM that consumes its result,
         # ONE LAYER LATER -- each exchange travels under two SpMMs (and next to the following exchange) instead of one
-        pend = None                                     # all-reduce in flight for `ci`
+        pend = None                                     # exchange in flight for `ci`
+        I, D = xi.shape
         for l in range(n_layers):
-            pi = spmm_fn(shard.iu, cu)
-            pend_pi = _all_reduce_async(pi, group)
+            pbuf, pi = exchange_buffer(I, D, xi, group)
+            spmm_fn(shard.iu, cu, y=pi)
+            pend_pi = _sum_exchange_async(pbuf, group)
             if pend is not None:
                 pend.wait()
                 fi.add_(ci, alpha=w)                    # the previous layer's item rows join the layer mean
@@ -139,12 +234,15 @@ class _ShardedLayerMean(torch.autograd.Function):
         # folded into the per-layer all-reduce:  g_i <- allreduce(B_g^T g_u + w * Gi_partial)
         shard, L, w, spmm_fn, group = ctx.shard, ctx.n_layers, ctx.w, ctx.spmm_fn, ctx.group
         Gu, Gi = Gu.contiguous(), Gi.contiguous()
-        Gi_full = Gi.clone()                            # layer-L seed needs the full item gradient
-        pend = _all_reduce_async(Gi_full, group)
+        I, D = Gi.shape
+        gbuf, Gi_full = exchange_buffer(I, D, Gi, group)  # layer-L seed needs the full item gradient
+        Gi_full.copy_(Gi)
+        pend = _sum_exchange_async(gbuf, group)
         gu, gi = Gu * w, Gi_full
         for it in range(L):                             # same deferral as in forward
-            pi = spmm_fn(shard.iu, gu, z=Gi, beta=w)
-            pend_pi = _all_reduce_async(pi, group)
+            pbuf, pi = exchange_buffer(I, D, Gi, group)
+            spmm_fn(shard.iu, gu, y=pi, z=Gi, beta=w)
+            pend_pi = _sum_exchange_async(pbuf, group)
             pend.wait()
             if it == 0:
                 gi = Gi_full.mul_(w)
@@ -166,36 +264,50 @@ class ShardedLightGCN(nn.Module):
     gradient leaves backward already summed over ranks, so every rank applies the same Adam update."""
 
     def __init__(self, shard, user_item_dict_local, dim_E, reg_weight, n_layers, device, seed=42, spmm_fn=None,
-                 bpr_fn=None, group=None):
+                 bpr_fn=None, group=None, global_init=True):
         super().__init__()
         self.shard, self.device, self.group = shard, device, group
         self.num_user, self.num_item = shard.num_user_local, shard.num_item
         self.reg_weight, self.n_layers, self.dim_embedding = reg_weight, n_layers, dim_E
         self.user_item_dict = user_item_dict_local
         self.spmm_fn, self.bpr_fn = spmm_fn, bpr_fn
-        # one global initialisation, sliced: identical to the single-GPU model under the same seed
-        g = torch.Generator().manual_seed(seed)
         bound_u = (6.0 / (shard.num_user_global + dim_E)) ** 0.5     # nn.init.xavier_uniform_ bounds
         bound_i = (6.0 / (shard.num_item + dim_E)) ** 0.5
-        full_u = (torch.rand(shard.num_user_global, dim_E, generator=g) * 2 - 1) * bound_u
+        if global_init:
+            # one global initialisation, sliced: identical to the single-GPU model under the same seed
+            g = torch.Generator().manual_seed(seed)
+            full_u = (torch.rand(shard.num_user_global, dim_E, generator=g) * 2 - 1) * bound_u
+            mine_u = full_u[shard.u0:shard.u1].clone()
+        else:
+            # per-rank: the item table from the shared seed (replicated), this rank's user rows from its own stream --
+            # no rank materialises the [U_global, D] table (5 GB at config 5)
+            g = torch.Generator().manual_seed(seed)
+            gu = torch.Generator().manual_seed(seed * 1_000_003 + 1 + shard.rank)
+            mine_u = (torch.rand(self.num_user, dim_E, generator=gu) * 2 - 1) * bound_u
         full_i = (torch.rand(shard.num_item, dim_E, generator=g) * 2 - 1) * bound_i
-        self.user_embedding = nn.Embedding.from_pretrained(full_u[shard.u0:shard.u1].clone(), freeze=False)
+        self.user_embedding = nn.Embedding.from_pretrained(mine_u, freeze=False)
         self.item_embedding = nn.Embedding.from_pretrained(full_i, freeze=False)
-        rowptr, col = graph.user_hist_csr(user_item_dict_local, self.num_user)
+        rowptr, col = (graph.user_hist_csr(user_item_dict_local, self.num_user) if user_item_dict_local is not None
+                       else graph.user_hist_csr_from_edges(shard.local_edges, self.num_user))
         self.hist = (rowptr.to(device), col.to(device))
         self.graph = shard.ui
-        self.result_u = self.result_i = None
+        self.result_u = self.result_i = self._result_cat = None
 
     def forward(self):
         fu, fi = sharded_layer_mean_propagate(self.user_embedding.weight, self.item_embedding.weight, self.shard,
                                               self.n_layers, self.spmm_fn, self.group)
-        self.result_u, self.result_i = fu, fi
+        self.result_u, self.result_i, self._result_cat = fu, fi, None
         return fu, fi
 
     @property
     def result(self):
-        """[U_g + I, D] in the reference's row convention (users then items), built on demand."""
-        return None if self.result_u is None else torch.cat((self.result_u, self.result_i), 0)
+        """[U_g + I, D] in the reference's row convention (users then items): concatenated on the first access
+        after a forward, then kept."""
+        if self.result_u is None:
+            return None
+        if self._result_cat is None:
+            self._result_cat = torch.cat((self.result_u, self.result_i), 0)
+        return self._result_cat
 
     def loss(self, users, pos_items, neg_items):
         pos_items = pos_items - self.num_user
@@ -241,27 +353,27 @@ def gather_ranklists(idx_local, shard, group=None):
     return torch.cat([o[:s] for o, s in zip(out, sizes)], 0).cpu()
 
 
-class WeakScalingJob:
-    pass
-
-
-def build_weak_scaling_job(U1, I, E1, world, rank, D, L, reg, device, seed=42):
-    """bench.py at N GPUs: one synthetic graph with N x U1 users over the same I items (every rank generates it
-    from the same seed), sharded by user rows; per-rank work stays that of the N=1 configuration."""
-    from .synthetic import synthetic_interactions
+def build_weak_scaling_job(dataset, world, rank, D, L, reg, device, seed=42, group=None, synthetic=False):
+    """bench.py at N GPUs (weak scaling): rank g owns ONE copy of the dataset's users -- global user id g * U1 + u has
+    the interactions of user u of the real graph (Data/<dataset>/train.npy, packed in the repository) -- over the
+    same I items, so per-rank work stays that of the N=1 configuration and an item's degree is N x its real degree.
+    Every rank builds only its own shard (UserShard.from_local); the item degrees come from one all-reduce.
+    -> dict(model, local_edges, num_user_local, shard, data)."""
+    from . import dataload
+    from .synthetic import DATASET_SHAPES, synthetic_interactions
+    packed = None if synthetic else dataload.packed_interactions(dataset)
+    if packed is not None:
+        U1, I, edges1, kind = packed["num_user"], packed["num_item"], np.asarray(packed["train"], dtype=np.int64), "real"
+    else:
+        U1, I, E1 = DATASET_SHAPES[dataset]
+        edges1, kind = synthetic_interactions(U1, I, E1, seed=seed).astype(np.int64), "synthetic"
     U = U1 * world
-    edges = synthetic_interactions(U, I, E1 * world, seed=seed)
-    shard = UserShard(edges, U, I, world, rank, device)
-    uid_local = graph.user_item_dict_from_edges(shard.local_edges)
-    for u in range(shard.num_user_local):
-        uid_local.setdefault(u, [])
-    job = WeakScalingJob()
-    job.model = ShardedLightGCN(shard, uid_local, D, reg, L, device, seed=seed).to(device)
-    job.local_edges = shard.local_edges
-    job.num_user_local = shard.num_user_local
-    job.shard = shard
-    job.local_user_ids = lambda users: users
-    return job
+    mine = np.stack([edges1[:, 0] + rank * U1, edges1[:, 1] - U1 + U], 1)      # global user ids, items as item + U_global
+    bounds = [k * U1 for k in range(world + 1)]
+    shard = UserShard.from_local(mine, bounds, I, world, rank, device, group=group)
+    model = ShardedLightGCN(shard, None, D, reg, L, device, seed=seed, group=group, global_init=False).to(device)
+    return dict(model=model, local_edges=shard.local_edges, num_user_local=shard.num_user_local, shard=shard, data=kind,
+                U1=U1, I=I)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -278,8 +390,9 @@ class _ShardedPropagate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xu, xi, shard, spmm_fn, group):
         xu, xi = xu.contiguous(), xi.contiguous()
-        pi = spmm_fn(shard.iu, xu)
-        pending = _all_reduce_async(pi, group)          # item partials travel while the user rows are computed
+        pbuf, pi = exchange_buffer(xi.shape[0], xu.shape[1], xu, group)
+        spmm_fn(shard.iu, xu, y=pi)
+        pending = _sum_exchange_async(pbuf, group)      # item partials travel while the user rows are computed
         yu = spmm_fn(shard.ui, xi)
         if shard.diag_u is not None:
             yu.addcmul_(xu, shard.diag_u)
@@ -293,8 +406,9 @@ class _ShardedPropagate(torch.autograd.Function):
     def backward(ctx, Gyu, Gyi):
         shard, spmm_fn, group = ctx.shard, ctx.spmm_fn, ctx.group
         Gyu, Gyi = Gyu.contiguous(), Gyi.contiguous()
-        tot = Gyi.clone()
-        pending = _all_reduce_async(tot, group)
+        tbuf, tot = exchange_buffer(Gyi.shape[0], Gyi.shape[1], Gyi, group)
+        tot.copy_(Gyi)
+        pending = _sum_exchange_async(tbuf, group)
         gxi = spmm_fn(shard.iu, Gyu)                    # partial: this rank's users only
         if shard.diag_i is not None:
             gxi.addcmul_(Gyi, shard.diag_i)
@@ -317,10 +431,48 @@ class ShardedGraph:
         return torch.cat((yu, yi), 0)
 
 
+class GradBucket:
+    """The replicated parameters' gradients as views of ONE persistent flat buffer: autograd accumulates into the
+    views in place, the rank sum is one all-reduce of the buffer -- no per-step concatenation or copy-back
+    (optimizers must not drop the gradients: zero() instead of zero_grad(set_to_none=True))."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def attached(self):
+        o = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + o * self.flat.element_size():
+                return False
+            o += p.numel()
+        return True
+
+    def zero(self):
+        if not self.attached():            # someone ran zero_grad(set_to_none=True): hook the views up again
+            o = 0
+            for p in self.params:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+        self.flat.zero_()
+
+    def all_reduce(self, group=None):
+        if not self.attached():
+            raise RuntimeError("GradBucket: a gradient no longer lives in the bucket (zero_grad(set_to_none=True)?)")
+        _all_reduce(self.flat, group)
+
+
 def allreduce_grads(params, group=None):
-    """Sum the ranks' partial gradients of the replicated parameters: one flat bucket, one all-reduce."""
+    """Sum the ranks' partial gradients of the replicated parameters (one flat bucket, one all-reduce) for callers
+    without a GradBucket: concatenates and copies back."""
     ps = [p for p in params if p.grad is not None]
-    if not ps or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE_COLLECTIVES):
+    if not ps or not _active(group):
         return
     flat = torch.cat([p.grad.reshape(-1) for p in ps])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
@@ -361,6 +513,7 @@ class ShardedMMGCN(nn.Module):
         rowptr, col = graph.user_hist_csr(graph.user_item_dict_from_edges(shard.local_edges), self.num_user)
         self.hist = (rowptr.to(device), col.to(device))
         self.result = None
+        self._bucket = None
 
     def forward(self):
         rep = (self.v_gcn(self.v_feat, self.id_embedding) + self.t_gcn(self.t_feat, self.id_embedding)) / 2
@@ -383,8 +536,17 @@ class ShardedMMGCN(nn.Module):
                 mean(pref ** 2) * (pref.shape[0] / self.shard.num_user_global)
         return loss / world + self.reg_weight * reg     # sum over ranks = the single-process loss
 
+    def zero_grad(self, set_to_none=False):
+        """Gradients live in one persistent flat bucket (GradBucket): they are zeroed in place, never dropped."""
+        if self._bucket is None:
+            self._bucket = GradBucket(list(self.parameters()))
+        self._bucket.zero()
+
     def sync_grads(self):
-        allreduce_grads(self.parameters(), self.group)
+        if self._bucket is not None and self._bucket.attached():
+            self._bucket.all_reduce(self.group)
+        else:
+            allreduce_grads(self.parameters(), self.group)
 
     def gene_ranklist(self, topk=50, gather=False):
         with torch.no_grad():

@@ -15,17 +15,20 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _oracle_spmm(csr, x, alpha=1.0, z=None, beta=0.0, acc=None, acc_init=None, acc_w=0.0):
+def _oracle_spmm(csr, x, y=None, alpha=1.0, z=None, beta=0.0, acc=None, acc_init=None, acc_w=0.0):
     """ops.spmm_raw's keyword contract (include/chaorec_hip.h, chaorec_spmm_csr_f32) on the CPU oracle."""
     from oracle import oracle
     s = torch.from_numpy(oracle.spmm((csr.rowptr.numpy(), csr.col.numpy(), csr.val.numpy()), x.detach().numpy()))
     if acc is not None:
         a0 = acc_w * acc_init if acc_init is not None else acc
         acc.copy_(a0 + acc_w * s)
-    y = alpha * s
+    out = alpha * s
     if z is not None:
-        y = y + beta * z
-    return y
+        out = out + beta * z
+    if y is not None:
+        y.copy_(out)
+        return y
+    return out
 
 
 class _OracleBPR(torch.autograd.Function):
@@ -126,6 +129,102 @@ def test_sharded_lightgcn_matches_single_process_oracle(oracle):
     assert np.array_equal(r[0]["gi"], r[1]["gi"])                              # identical item update on every rank
 
 
+def _worker4(rank, world, port, tmp, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CHAOREC_DIST_EXCHANGE"] = mode
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from chaorec_amd import dist as cdist
+    U, I, D, L, B = 900, 301, 16, 3, 64          # (301 items: not a multiple of the world size -> padded exchange rows)
+    edges = _heavy_tailed_graph(U, I)
+    # per-rank construction: this rank sees ONLY its own users' edges
+    deg = np.bincount(edges[:, 0], minlength=U)
+    bounds = cdist.partition_users_by_nnz(deg, world)
+    mine = edges[(edges[:, 0] >= bounds[rank]) & (edges[:, 0] < bounds[rank + 1])]
+    shard = cdist.UserShard.from_local(mine, bounds, I, world, rank, torch.device("cpu"))
+    whole = cdist.UserShard(edges, U, I, world, rank, torch.device("cpu"))            # the all-edges constructor
+    assert shard.bounds == whole.bounds and torch.equal(shard.ui.val, whole.ui.val) and torch.equal(shard.iu.col, whole.iu.col)
+    m = cdist.ShardedLightGCN(shard, None, D, 1e-3, L, torch.device("cpu"), seed=9, spmm_fn=_oracle_spmm, bpr_fn=_bpr)
+    rng = np.random.default_rng(100 + rank)
+    sel = rng.choice(len(shard.local_edges), B, replace=False)
+    users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64))
+    pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64))
+    neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + I, B))
+    loss = m.loss(users, pos, neg)
+    loss.backward()
+    assert m.result is m.result                       # concatenated once per forward, then kept
+    # gather_ranklists: every rank contributes [U_g, K] rows, rank order = user order
+    K = 7
+    mine_rank = (torch.arange(shard.num_user_local).view(-1, 1) + shard.u0) * 100 + torch.arange(K).view(1, -1)
+    gathered = cdist.gather_ranklists(mine_rank, shard)
+    want = (torch.arange(U).view(-1, 1)) * 100 + torch.arange(K).view(1, -1)
+    assert torch.equal(gathered, want)
+    # GradBucket: gradients live in one flat buffer, one all-reduce sums them on every rank
+    lin = torch.nn.Linear(5, 3)
+    bucket = cdist.GradBucket(list(lin.parameters()))
+    bucket.zero()
+    lin(torch.full((2, 5), float(rank + 1))).sum().backward()
+    assert bucket.attached()
+    local = bucket.flat.clone()
+    bucket.all_reduce()
+    tot = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(tot, local)
+    assert torch.allclose(bucket.flat, sum(tot)) and lin.weight.grad.data_ptr() == bucket.flat.data_ptr()
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), u0=shard.u0, u1=shard.u1, bounds=np.array(shard.bounds),
+             fu=m.result_u.detach().numpy(), fi=m.result_i.detach().numpy(), loss=float(loss),
+             gu=m.user_embedding.weight.grad.numpy(), gi=m.item_embedding.weight.grad.numpy(),
+             xu=m.user_embedding.weight.detach().numpy(), xi=m.item_embedding.weight.detach().numpy(),
+             users=users.numpy() + shard.u0, pos=pos.numpy() - shard.num_user_local,
+             neg=neg.numpy() - shard.num_user_local, nnz=shard.nnz)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _heavy_tailed_graph(U, I, seed=3):
+    """Users with Zipf-like degrees (a few users hold a large share of the edges: the case shard-by-count gets wrong)."""
+    rng = np.random.default_rng(seed)
+    deg = np.minimum(3 + (rng.pareto(1.1, U) * 2).astype(np.int64), I // 2)
+    deg[:5] = I // 2                                   # five users at the front as heavy as 150 median users
+    rows = []
+    for u in range(U):
+        for i in rng.choice(I, int(deg[u]), replace=False):
+            rows.append((u, int(i) + U))
+    return np.array(rows, dtype=np.int32)
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag", "direct"])
+def test_world4_exchange_modes_per_rank_shards(oracle, mode):
+    """SURVEY 8(e) at world size 4: shards built per rank from local edges only, balanced by nnz on a heavy-tailed
+    graph; the per-layer item exchange as all-reduce, reduce-scatter + all-gather, and direct all-to-all + all-gather;
+    rank-list gather; flat gradient bucket.  Every mode reproduces the single-process oracle."""
+    world = 4
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker4, args=(world, _free_port(), tmp, mode), nprocs=world, join=True)
+        r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
+    U, I, D, L = 900, 301, 16, 3
+    edges = _heavy_tailed_graph(U, I)
+    nnz = np.array([int(x["nnz"]) for x in r])
+    assert nnz.sum() == len(edges) and nnz.max() <= 1.25 * nnz.mean(), nnz            # balanced by edges ...
+    sizes = np.array([int(x["u1"] - x["u0"]) for x in r])
+    assert sizes.min() < 0.5 * sizes.max(), sizes                                     # ... not by user count
+    x0 = np.concatenate([x["xu"] for x in r] + [r[0]["xi"]], 0)
+    csr = oracle.lightgcn_csr(edges, U + I)
+    final, _ = oracle.lightgcn_forward(x0, csr, L)
+    assert np.allclose(np.concatenate([x["fu"] for x in r], 0), final[:U], rtol=1e-5, atol=1e-7)
+    g_tot = np.zeros((U + I, D))
+    for k in range(world):
+        assert np.allclose(r[k]["fi"], final[U:], rtol=1e-5, atol=1e-7)
+        out, g = oracle.lightgcn_loss(x0, csr, L, U, r[k]["users"], r[k]["pos"], r[k]["neg"], 1e-3)
+        g_tot += g / world
+        assert r[k]["loss"] == pytest.approx(out[0] / world, rel=1e-5)
+    assert np.allclose(np.concatenate([x["gu"] for x in r], 0), g_tot[:U], rtol=2e-4, atol=1e-9)
+    for k in range(world):
+        assert np.allclose(r[k]["gi"], g_tot[U:], rtol=2e-4, atol=1e-9)
+        assert np.array_equal(r[k]["gi"], r[0]["gi"])                                 # identical item update on every rank
+
+
 def test_partition_users_by_nnz():
     from chaorec_amd.dist import partition_users_by_nnz
     deg = np.array([1000] + [1] * 999)
@@ -207,7 +306,16 @@ def _mmgcn_worker(rank, world, port, tmp):
     ut, it = _mmgcn_batch(shard.local_edges, shard.num_user_local, I, rank)
     loss = m.loss(ut, it)
     loss.backward()
+    first = {n: p.grad.clone() for n, p in m.named_parameters()}
     m.sync_grads()
+    # the same step again through the persistent gradient bucket (zero_grad keeps the views, sync is ONE all-reduce)
+    m.zero_grad()
+    assert m._bucket is not None and m._bucket.attached()
+    m.loss(ut, it).backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, first[n], rtol=1e-6, atol=1e-9), n
+    m.sync_grads()
+    assert m._bucket.attached()
     np.savez(os.path.join(tmp, f"mm{rank}.npz"), u0=shard.u0, u1=shard.u1, loss=float(loss), ut=ut.numpy(), it=it.numpy(),
              res=m.result.detach().numpy(), **{"g_" + n: p.grad.numpy() for n, p in m.named_parameters()})
     dist.barrier()
