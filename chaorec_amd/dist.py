@@ -183,7 +183,9 @@ def _sum_exchange_async(buf, group):
     a2a = dist.all_to_all_single(recv, buf, group=group, async_op=True)
 
     def gather():
-        chunk = recv.view(world, rows, -1).sum(0)
+        # (the two-pass column sum of the kernels library on the GPU: fixed order, no memset node under capture)
+        blocks = recv.view(world, -1)
+        chunk = (ops.col_sum(blocks) if recv.is_cuda else blocks.sum(0)).view(rows, -1)
         return _Pending(dist.all_gather_into_tensor(buf, chunk, group=group, async_op=True))
 
     return _Pending(a2a, gather)
