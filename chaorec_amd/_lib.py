@@ -11,7 +11,8 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libchaorec_hip.so")
-SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip", "metrics.hip", "graph_dropout.hip", "rowops.hip"]
+SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip", "gemm_bf16x3.hip", "metrics.hip", "graph_dropout.hip",
+           "rowops.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
@@ -76,6 +77,10 @@ SIGNATURES = {
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_ptr,
                                         ctypes.c_size_t, c_ptr]),
+    "chaorec_gemm_nt_bf16x3_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    "chaorec_gemm_nt_bf16x3": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, c_ptr,
+                                              ctypes.c_size_t, c_ptr]),
     "chaorec_adam_step_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_float,
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                              ctypes.c_int32, c_ptr, c_ptr]),

@@ -1,0 +1,246 @@
+// C[M,N] = A[M,K] . B[N,K]^T (+ bias, + leaky-relu) on the bf16 MFMA pipe at fp32-grade accuracy.
+//
+// Replaces the FORWARD of the modality projections and of every other nn.Linear on the path (y = x W^T + b:
+// Model/FREEDOM.py:59-60,209,212 image_trs / text_trs over the 4096- / 384-wide feature tables;
+// Model/MMGCN.py:40,97,102-131; BasicGCN.py:40) -- north_star's "modality-feature projection (v_feat/t_feat x W) on
+// MFMA bf16".
+//
+// A plain bf16 GEMM has 8 significand bits per operand; the reference computes these products in fp32.  So every
+// fp32 operand is split EXACTLY into three bf16 planes, x = h + m + l (h = rne_bf16(x), m = rne_bf16(x - h),
+// l = x - h - m: 8 + 8 + 8 bits cover fp32's 24), and the product a.b is accumulated from six of the nine plane
+// products on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; a bf16 x bf16 product is exact in fp32):
+//     ah.bh + ah.bm + am.bh + ah.bl + al.bh + am.bm          (dropped: am.bl, al.bm, al.bl <= 3 * 2^-24 |a||b|)
+// -> |error| <= ~4e-7 * sum_k |a_k||b_k| including the fp32 accumulation order: the accuracy class of an fp32 GEMM (it
+// is NOT bit-identical to oracle_gemm_f32's k-ascending chain; chaorec_gemm_f32 stays for that).  Six bf16 MFMAs do
+// a 32x32x16 block in 192 cycles; the f32 MFMA (v_mfma_f32_32x32x2_f32) needs 512: 2.7x the matrix rate, which turns
+// the skinny projections (N = 64: 32 flop per byte of A) from MFMA-bound into HBM-bound.
+//
+// Tile: 128 x 64 x 32 per workgroup, 4 waves, wave w owns rows [32w, 32w + 32) x 64 columns (2 accumulators).
+// Global -> registers (float4 along k, both operands are k-contiguous in memory: no transposition anywhere) -> split
+// -> LDS as three bf16 planes per operand ([plane][row][32 k + 8 pad] : a lane's MFMA fragment, 8 consecutive k of
+// one row, is one 16-B LDS read) -> MFMA.  The next k-tile is fetched while the current one is multiplied.
+// K is cut into slabs over blockIdx.z when the output has few tiles (the same fixed-order slab sum as
+// chaorec_gemm_f32: gemm_reduce_slabs_kernel).
+#include "common.h"
+
+namespace chaorec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XBM = 128, XBN = 64, XBK = 32, XPAD = 8;   // (row stride 40 bf16 = 80 B: 16-B aligned, banks skewed)
+
+union Frag8 {
+  uint4 u;
+  bf16x8 v;
+};
+
+__device__ __forceinline__ uint32_t rne_bf16_bits(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+
+// x = h + m + l exactly (finite x): three bf16 bit patterns
+__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = rne_bf16_bits(x);
+  const float r1 = x - __uint_as_float(h << 16);
+  m = rne_bf16_bits(r1);
+  const float r2 = r1 - __uint_as_float(m << 16);
+  l = __float_as_uint(r2) >> 16;          // (r2 has at most 8 significant bits left: exact)
+}
+
+// four consecutive k of one row -> 8 B per plane
+__device__ __forceinline__ void split3x4(const float4 x, uint2 &h, uint2 &m, uint2 &l) {
+  uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+  split3(x.x, h0, m0, l0);
+  split3(x.y, h1, m1, l1);
+  split3(x.z, h2, m2, l2);
+  split3(x.w, h3, m3, l3);
+  h = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+  m = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+  l = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
+
+extern __global__ void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits, float *__restrict__ C,
+                                                const float *__restrict__ bias, int64_t M, int64_t N, int64_t ldc,
+                                                int accumulate, int act);
+
+__global__ __launch_bounds__(256) void gemm_nt_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                             float *__restrict__ C, const float *__restrict__ bias,
+                                                             int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                                                             int64_t ldc, int act, int64_t k_per_split,
+                                                             float *__restrict__ slabs) {
+  __shared__ uint16_t As[3][XBM][XBK + XPAD];
+  __shared__ uint16_t Bs[3][XBN][XBK + XPAD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * XBM, n0 = (int64_t)blockIdx.y * XBN;
+  const int64_t kb = (int64_t)blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+  // this thread's float4s of a k-tile: A 128 x 32 = 1024 float4 (4 per thread), B 64 x 32 = 512 (2 per thread)
+  float4 ra[4], rb[2];
+  const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  auto load4 = [&](const float *base, int64_t ld, int64_t row, int64_t n_rows, int64_t k, bool vec) -> float4 {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < n_rows && k < ke) {
+      const float *src = base + row * ld + k;
+      if (vec && k + 3 < ke) {
+        x = *reinterpret_cast<const float4 *>(src);
+      } else {
+        x.x = src[0];
+        if (k + 1 < ke) x.y = src[1];
+        if (k + 2 < ke) x.z = src[2];
+        if (k + 3 < ke) x.w = src[3];
+      }
+    }
+    return x;
+  };
+  auto fetch = [&](int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int v = t + p * 256;                  // float4 index: row = v / 8, k4 = (v % 8) * 4
+      ra[p] = load4(A, lda, m0 + (v >> 3), M, k0 + ((v & 7) << 2), a_vec);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int v = t + p * 256;
+      rb[p] = load4(B, ldb, n0 + (v >> 3), N, k0 + ((v & 7) << 2), b_vec);
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int v = t + p * 256;
+      uint2 hh, mm, ll;
+      split3x4(ra[p], hh, mm, ll);
+      const int row = v >> 3, k4 = (v & 7) << 2;
+      *reinterpret_cast<uint2 *>(&As[0][row][k4]) = hh;
+      *reinterpret_cast<uint2 *>(&As[1][row][k4]) = mm;
+      *reinterpret_cast<uint2 *>(&As[2][row][k4]) = ll;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int v = t + p * 256;
+      uint2 hh, mm, ll;
+      split3x4(rb[p], hh, mm, ll);
+      const int row = v >> 3, k4 = (v & 7) << 2;
+      *reinterpret_cast<uint2 *>(&Bs[0][row][k4]) = hh;
+      *reinterpret_cast<uint2 *>(&Bs[1][row][k4]) = mm;
+      *reinterpret_cast<uint2 *>(&Bs[2][row][k4]) = ll;
+    }
+  };
+
+  if (kb < ke) fetch(kb);
+  for (int64_t k0 = kb; k0 < ke; k0 += XBK) {
+    __syncthreads();                              // the previous tile's fragment reads are done
+    stash();
+    __syncthreads();
+    if (k0 + XBK < ke) fetch(k0 + XBK);           // next tile's loads fly under this tile's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < XBK; ks += 16) {
+      Frag8 a[3], b[2][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        a[pl].u = *reinterpret_cast<const uint4 *>(&As[pl][wave * 32 + r][ks + 8 * h]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][j * 32 + r][ks + 8 * h]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // smallest products first (0 = h, 1 = m, 2 = l)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[j][1].v, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, b[j][0].v, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][2].v, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[j][0].v, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][1].v, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][0].v, acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // C[m][n]: accumulator register q of lane (r, h) is row 32*wave + (q & 3) + 8 * (q >> 2) + 4h, column 32 j + r
+  const bool to_slab = slabs != nullptr;
+  float *dst = to_slab ? slabs + (size_t)blockIdx.z * (size_t)M * (size_t)N : C;
+  const int64_t ldd = to_slab ? N : ldc;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = n0 + j * 32 + r;
+    if (n >= N) continue;
+    const float bv = (!to_slab && bias) ? bias[n] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t m = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (m >= M) continue;
+      float v = acc[j][q];
+      if (!to_slab) {
+        v = v + bv;
+        if (act == 1) v = v > 0.f ? v : v * 0.01f;
+        if (act == 2) v = v > 0.f ? v : v * 0.2f;
+      }
+      dst[m * ldd + n] = v;
+    }
+  }
+}
+
+struct XPlan {
+  int splits;
+  int64_t k_per_split;
+};
+
+static XPlan plan_x(int64_t M, int64_t N, int64_t K) {
+  XPlan p;
+  const int64_t tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
+  int64_t s = 1;
+  if (tiles < 512 && K >= 512) {                 // few output tiles, long reduction: fill the chip by cutting K
+    s = (1024 + tiles - 1) / tiles;
+    if (s > K / 256) s = K / 256;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+  }
+  int64_t per = (K + s - 1) / s;
+  per = (per + XBK - 1) / XBK * XBK;
+  p.k_per_split = per;
+  p.splits = (int)((K + per - 1) / per);
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+}  // namespace chaorec
+
+using namespace chaorec;
+
+extern "C" size_t chaorec_gemm_nt_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const XPlan p = plan_x(M, N, K);
+  return p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, const float *bias, int64_t M, int64_t N,
+                                      int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t act, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+  if (!A || !B || !C) return fail(CHAOREC_E_INVALID, "gemm_nt_bf16x3: NULL argument");
+  if (M < 0 || N < 0 || K <= 0) return fail(CHAOREC_E_INVALID, "gemm_nt_bf16x3: bad size");
+  if (act < 0 || act > 2) return fail(CHAOREC_E_INVALID, "gemm_nt_bf16x3: act %d", act);
+  if (M == 0 || N == 0) return CHAOREC_OK;
+  const XPlan p = plan_x(M, N, K);
+  const size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace))
+    return fail(CHAOREC_E_WORKSPACE, "gemm_nt_bf16x3: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
+  const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
+  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
+                     p.k_per_split, slabs);
+  int rc = check_launch("gemm_nt_bf16x3_kernel");
+  if (rc || p.splits == 1) return rc;
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
+                     bias, M, N, ldc, 0, act);
+  return check_launch("gemm_reduce_slabs_kernel");
+}

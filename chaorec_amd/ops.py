@@ -456,12 +456,43 @@ def gemm_raw(A, B, transA=False, transB=False, bias=None, out=None, accumulate=F
     return out
 
 
+def gemm_nt_bf16x3(x, weight, bias=None, act=0, out=None):
+    """y = act(x W^T + b) on the bf16 MFMA pipe with every fp32 operand split into three bf16 planes (fp32-grade
+    accuracy, chaorec_gemm_nt_bf16x3): the forward of nn.Linear."""
+    _need_cuda(x, weight, bias, out)
+    x, weight = _f32c(x), _f32c(weight)
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"gemm_nt_bf16x3: inner dims {K} vs {weight.shape[1]}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.chaorec_gemm_nt_bf16x3_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    rc = lib.chaorec_gemm_nt_bf16x3(_ptr(x), _ptr(weight), _ptr(out), _ptr(bias), M, N, K, x.shape[1], weight.shape[1],
+                                    out.shape[1], act, _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "chaorec_gemm_nt_bf16x3")
+    return out
+
+
+# which pipe nn.Linear's FORWARD runs on: "bf16x3" (split-bf16 MFMA, fp32-grade accuracy, 2.7x the f32 matrix rate) or
+# "f32" (the exact k-ascending fmaf chain of chaorec_gemm_f32).  The backward GEMMs (k-major operands) stay on f32.
+import os as _os
+LINEAR_FORWARD = _os.environ.get("CHAOREC_LINEAR_FORWARD", "bf16x3")
+
+
 class _Linear(torch.autograd.Function):
-    """y = act(x W^T + b) (nn.Linear [+ F.leaky_relu]) on the f32 MFMA pipe."""
+    """y = act(x W^T + b) (nn.Linear [+ F.leaky_relu]): forward on the bf16 MFMA pipe (three bf16 planes per fp32
+    operand) where the reduction is long enough to pay for the split, else -- and the whole backward -- on the f32
+    MFMA pipe."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
-        y = gemm_raw(x, weight, transB=True, bias=bias, act=act)
+        if LINEAR_FORWARD == "bf16x3" and x.shape[1] >= 64 and x.shape[0] >= 256:
+            y = gemm_nt_bf16x3(x, weight, bias=bias, act=act)
+        else:
+            y = gemm_raw(x, weight, transB=True, bias=bias, act=act)
         ctx.save_for_backward(x, weight, y if act else None)
         ctx.has_bias, ctx.act = bias is not None, act
         return y
@@ -471,7 +502,7 @@ class _Linear(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         gy = gy.contiguous()
         if ctx.act:
-            gy = torch.where(y > 0, gy, gy * 0.01)
+            gy = torch.where(y > 0, gy, gy * (0.01 if ctx.act == 1 else 0.2))
         gx = gemm_raw(gy, weight) if ctx.needs_input_grad[0] else None
         gw = gemm_raw(gy, x, transA=True) if ctx.needs_input_grad[1] else None
         gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[2] else None     # (not gy.sum(0): see col_sum)

@@ -31,7 +31,7 @@ extern "C" {
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
                                   stand-alone BPR finalize with loss / optimizer bookkeeping, layer mean in the last
-                                  forward SpMM, scoring with carried thresholds */
+                                  forward SpMM, scoring with carried thresholds, split-bf16 NT GEMM */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -349,6 +349,23 @@ int chaorec_gemm_f32(const float *A, const float *B, float *C, const float *bias
                      int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                      int32_t transA, int32_t transB, int32_t accumulate, int32_t act,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * y = x W^T (+ bias, + leaky-relu) on the bf16 MFMA pipe at fp32-grade accuracy: the FORWARD of the modality
+ * projections image_trs / text_trs over the [I, 4096] / [I, 384] feature tables (Model/FREEDOM.py:59-60,209,212) and
+ * of MMGCN's Linears (Model/MMGCN.py:40,97,102-131; BasicGCN.py:40).
+ *   C[M,N] = A[M,K] . B[N,K]^T, both operands k-contiguous (torch's nn.Linear layout), fp32 in / fp32 out.
+ * Every operand is split exactly into three bf16 planes (8+8+8 significand bits) and six of the nine plane products
+ * are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: |C - exact| <= ~4e-7 * sum_k |a||b| (an fp32 GEMM's accuracy
+ * class; NOT bit-identical to chaorec_gemm_f32 / oracle_gemm_f32, whose k-ascending fmaf chain stays available), at
+ * 2.7x the f32 MFMA rate -- the skinny N = 64 projections become HBM-bound (A is read once).
+ * act: 0 none, 1 leaky_relu(0.01), 2 leaky_relu(0.2).  workspace: chaorec_gemm_nt_bf16x3_workspace_bytes(M,N,K)
+ * (K-slabs of outputs with few tiles, summed in a fixed order).
+ * ------------------------------------------------------------------------------------- */
+size_t chaorec_gemm_nt_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, const float *bias, int64_t M, int64_t N,
+                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t act, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused Adam step over one flat fp32 parameter (torch.optim.Adam defaults, main.py:397):

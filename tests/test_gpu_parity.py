@@ -1014,3 +1014,50 @@ def test_bpr_fused_draw_equals_draw_then_bpr(dev, variant, joined):
     _, u2, p2, n2 = ops.bpr_loss_drawn(tab, None, ed, hist, B, U, I, 99, 5, variant, 1e-3, item_offset=U, step_dev=ctr,
                                        advance=True)
     assert int(ctr) == 8 and torch.equal(u2, a[0]) and torch.equal(p2, a[1]) and torch.equal(n2, a[2])
+
+
+@pytest.mark.parametrize("M,N,K,act,bias", [(11384, 64, 4096, 0, True), (1000, 64, 384, 1, True), (777, 100, 320, 2, False),
+                                            (300, 256, 128, 0, True), (4097, 64, 70, 0, False), (128, 64, 8192, 0, True)])
+def test_gemm_nt_bf16x3_fp32_grade(dev, M, N, K, act, bias):
+    """The split-bf16 projection GEMM (three bf16 planes per fp32 operand, six MFMA products): error against an fp64
+    product bounded by 1e-6 * sum_k |a||b| per element (stated tolerance; an fp32 chain's own bound is K * 6e-8 of
+    that), and at least as close to it as the exact-chain f32 kernel is on the long reductions."""
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(M + N + K)
+    x = torch.randn(M, K, device=dev, generator=g) * torch.exp(torch.randn(M, 1, device=dev, generator=g))
+    w = torch.randn(N, K, device=dev, generator=g) * 0.05
+    b = torch.randn(N, device=dev, generator=g) if bias else None
+    got = ops.gemm_nt_bf16x3(x, w, bias=b, act=act)
+    ref = x.double() @ w.double().t()
+    mass = x.double().abs() @ w.double().abs().t()
+    if b is not None:
+        ref = ref + b.double()
+        mass = mass + b.double().abs()
+    slope = {0: 1.0, 1: 0.01, 2: 0.2}[act]
+    ref_act = torch.where(ref > 0, ref, ref * slope) if act else ref
+    err = (got.double() - ref_act).abs()
+    assert bool((err <= 1e-6 * mass + 1e-30).all()), float((err / (mass + 1e-30)).max())
+    f32 = ops.gemm_raw(x, w, transB=True, bias=b, act=act)
+    assert float(err.mean()) <= 1.5 * float((f32.double() - ref_act).abs().mean()) + 1e-12
+    # deterministic
+    assert torch.equal(got, ops.gemm_nt_bf16x3(x, w, bias=b, act=act))
+
+
+def test_linear_forward_pipes_agree(dev):
+    """ops.linear on either pipe: same autograd contract, outputs equal to fp32 rounding, identical backward kernels."""
+    from chaorec_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(3000, 384, device=dev, requires_grad=True)
+    lin = torch.nn.Linear(384, 64).to(dev)
+    outs = {}
+    for pipe in ("bf16x3", "f32"):
+        ops.LINEAR_FORWARD = pipe
+        x.grad = None
+        lin.zero_grad()
+        y = ops.linear(x, lin.weight, lin.bias, act=1)
+        y.square().sum().backward()
+        outs[pipe] = (y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    ops.LINEAR_FORWARD = "bf16x3"
+    for a, b in zip(outs["bf16x3"], outs["f32"]):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()))

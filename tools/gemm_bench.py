@@ -25,3 +25,21 @@ for M, N, K, tA, tB in shapes:
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 10
     print(f"M={M:6d} N={N:5d} K={K:6d} tA={int(tA)} tB={int(tB)}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TF/s")
+
+print("-- split-bf16 NT (chaorec_gemm_nt_bf16x3) vs f32 MFMA on the forward shapes")
+for M, N, K in [(11384, 64, 4096), (11384, 64, 384), (14079, 256, 128), (60499, 256, 256), (60499, 64, 320), (60499, 768, 768),
+                (47297, 64, 64)]:
+    A = torch.randn((M, K), device=dev)
+    B = torch.randn((N, K), device=dev)
+    for name, fn in (("f32   ", lambda: ops.gemm_raw(A, B, transB=True)), ("bf16x3", lambda: ops.gemm_nt_bf16x3(A, B))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / 10
+        print(f"{name} M={M:6d} N={N:5d} K={K:6d}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:7.1f} TF/s  A-stream {M*K*4/ms/1e9:7.2f} TB/s")
