@@ -156,8 +156,11 @@ class FREEDOM(nn.Module):
         if cur is None or cur is self.norm_adj:
             self.masked_adj = new
         elif not cur.update_from(new):
-            raise RuntimeError("FREEDOM: the pruned graph changed its entry count between epochs "
-                               f"({cur.nnz} -> {new.nnz}); a captured training step would keep the old one")
+            # another entry count (a train.npy with repeated interactions coalesces to fewer entries; a key tie in the
+            # race select): the arrays cannot be rewritten in place.  Without a captured step nothing holds their
+            # addresses: rebind.  With one, the caller has to re-capture (train_and_evaluate does: graph_stale).
+            self.masked_adj = new
+            self.graph_stale = True
 
     # ---- hot path ---------------------------------------------------------------------------
     def forward(self, adj):

@@ -108,8 +108,11 @@ class LayerGCN(nn.Module):
         if cur is None or cur is self.norm_adj_matrix:
             self.masked_adj = new
         elif not cur.update_from(new):
-            raise RuntimeError("LayerGCN: the pruned graph changed its entry count between epochs "
-                               f"({cur.nnz} -> {new.nnz}); a captured training step would keep the old one")
+            # another entry count (a train.npy with repeated interactions coalesces to fewer entries; a key tie in the
+            # race select): the arrays cannot be rewritten in place.  Without a captured step nothing holds their
+            # addresses: rebind.  With one, the caller has to re-capture (train_and_evaluate does: graph_stale).
+            self.masked_adj = new
+            self.graph_stale = True
 
     def get_ego_embeddings(self):
         return torch.cat([self.user_embeddings, self.item_embeddings], 0)

@@ -21,9 +21,15 @@ def _train_epoch_in_launch(model, loader, optimizer, graphed):
     loader.begin_epoch()
     E, B = loader.edges.shape[0], loader.batch_size
     sum_loss = None
-    for _ in range(E // B):
-        d = graphed()
-        sum_loss = d.clone() if sum_loss is None else sum_loss.add_(d)
+    if getattr(graphed, "fused", False):
+        # optim.FusedLightGCNStep: several steps per replay, the per-batch losses summed on the device by the step itself
+        graphed.loss_accum.zero_()
+        graphed.run(E // B)
+        sum_loss = graphed.loss_accum[0].clone()
+    else:
+        for _ in range(E // B):
+            d = graphed()
+            sum_loss = d.clone() if sum_loss is None else sum_loss.add_(d)
     tail = E - (E // B) * B
     if tail:
         optimizer.zero_grad()
@@ -86,9 +92,31 @@ def _capture_step(model, train_loader, optimizer, model_name):
     if len(train_loader) < 2:
         return None
     if hasattr(model, "loss_drawn") and model_name not in MMGCN_STYLE and model_name not in PRE_EPOCH:
-        # the batch is drawn by the fused BPR forward itself: a replay takes no inputs at all
+        # the batch is drawn by the fused BPR forward itself: a replay takes no inputs at all.  The capture's warm-up
+        # steps draw full batches from the epoch permutation: the edge list must hold them (the kernel clamps a read
+        # past the end, but those would not be the sampler's batches), and the loader's counters / generator are put
+        # back afterwards so that a captured run draws exactly what an eager one draws.
+        E, B = train_loader.edges.shape[0], train_loader.batch_size
+        if E < 4 * B:
+            return None
+        gen_state = train_loader.gen.get_state()
         train_loader.begin_epoch()
-        g = GraphedTrainStep(model, optimizer, batch_fn=lambda: (), loss_fn=train_loader.drawn_loss_fn(model))
+        saved = [t.clone() for t in (train_loader.step_dev, train_loader.perm_pos, train_loader.perm)]
+        from .Model import LightGCN
+        if type(model) is LightGCN and model.n_layers >= 1 and len(optimizer.param_groups) == 1:
+            from .optim import FusedLightGCNStep
+            acc = torch.zeros(1, dtype=torch.float32, device=train_loader.edges.device)
+            k = next((c for c in (11, 10, 8, 7, 5, 4, 3, 2) if (E // B) % c == 0), 1)
+            g = FusedLightGCNStep(model, optimizer, batch_size=B, edges=train_loader.edges, seed=train_loader.seed,
+                                  step_dev=train_loader.step_dev, perm=train_loader.perm, perm_pos=train_loader.perm_pos,
+                                  loss_accum=acc, steps_per_replay=k)
+            g.fused = True
+        else:
+            g = GraphedTrainStep(model, optimizer, batch_fn=lambda: (), loss_fn=train_loader.drawn_loss_fn(model))
+        with torch.no_grad():
+            for dst, src in zip((train_loader.step_dev, train_loader.perm_pos, train_loader.perm), saved):
+                dst.copy_(src)
+        train_loader.gen.set_state(gen_state)
         g.draws_in_launch = True
         return g
     example = next(iter(train_loader))
@@ -102,12 +130,17 @@ def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epoc
     early_stopping = EarlyStopping(patience=patience, verbose=True)
     topk = [int(k) for k in topk]
     # evaluation stays on the device when the model can hand the rank list over in HBM
-    on_device = getattr(model, "device", None) is not None and torch.device(model.device).type == "cuda" and max(topk) <= 64
+    # (gene_ranklist returns 50 columns, as the reference's does: larger cut-offs take the host path, which truncates)
+    on_device = getattr(model, "device", None) is not None and torch.device(model.device).type == "cuda" and max(topk) <= 50
     if on_device:
         val_data, test_data = EvalLists(val_data, model.device), EvalLists(test_data, model.device)
     for epoch in range(epochs):
         if model_name in PRE_EPOCH:
             model.pre_epoch_processing()
+            if getattr(model, "graph_stale", False):     # the pruned graph was re-allocated: a captured step holds dead addresses
+                model.graph_stale = False
+                if graphed is not None:
+                    graphed, capture_pending = None, bool(graph)
         if capture_pending:
             graphed, capture_pending = _capture_step(model, train_loader, optimizer, model_name), False
         loss = train(model, train_loader, optimizer, model_name, graphed)

@@ -57,8 +57,8 @@ def gene_metrics(val_data, rank_list, k_list):
     """val_data: sequence of [user, pos...]; rank_list: [U, >=max(k)] global item ids (tensor or array).
     -> {k: {'precision','recall','ndcg','hit_rate','map'}} averaged over len(val_data)."""
     k_list = [int(k) for k in k_list]
-    kmax = max(k_list)
     rank = rank_list.cpu().numpy() if isinstance(rank_list, torch.Tensor) else np.asarray(rank_list)
+    kmax = min(max(k_list), rank.shape[1])          # (ranked_items[:k] of a shorter list is the whole list: utils.py:124)
     n = len(val_data)
     users = np.fromiter((int(d[0]) for d in val_data), dtype=np.int64, count=n)
     lens = np.fromiter((len(d) - 1 for d in val_data), dtype=np.int64, count=n)
@@ -77,23 +77,24 @@ def gene_metrics(val_data, rank_list, k_list):
     dup_sorted[:, 1:] = ts[:, 1:] == ts[:, :-1]
     np.put_along_axis(first, srt, ~dup_sorted, 1)
     hit_set = hit & first
-    disc = 1.0 / np.log(np.arange(kmax) + 2.0)
+    disc = 1.0 / np.log(np.arange(max(k_list)) + 2.0)
     names = ("precision", "recall", "ndcg", "hit_rate", "map")
     out = {k: dict.fromkeys(names, 0.0) for k in k_list}
     has = lens > 0
     safe_len = np.maximum(lens, 1).astype(np.float64)
     idcg_prefix = np.concatenate([[0.0], np.cumsum(disc)])
-    for k in k_list:
+    for k_asked in k_list:
+        k = min(k_asked, kmax)
         inter = hit_set[:, :k].sum(1).astype(np.float64)
-        out[k]["precision"] = float((inter / k).sum() / n)
-        out[k]["recall"] = float(np.where(has, inter / safe_len, 0.0).sum() / n)
+        out[k_asked]["precision"] = float((inter / k_asked).sum() / n)
+        out[k_asked]["recall"] = float(np.where(has, inter / safe_len, 0.0).sum() / n)
         dcg = (hit[:, :k] * disc[:k]).sum(1)                            # `item in test_list` per position
-        idcg = idcg_prefix[np.minimum(lens, k)]
-        out[k]["ndcg"] = float(np.where(has, dcg / np.where(has, idcg, 1.0), 0.0).sum() / n)
-        out[k]["hit_rate"] = float((inter > 0).sum() / n)
+        idcg = idcg_prefix[np.minimum(lens, k_asked)]                   # (metrics.py:34: min(len(test), k) with the k asked for)
+        out[k_asked]["ndcg"] = float(np.where(has, dcg / np.where(has, idcg, 1.0), 0.0).sum() / n)
+        out[k_asked]["hit_rate"] = float((inter > 0).sum() / n)
         cum = np.cumsum(hit[:, :k], 1)
         ap = (hit[:, :k] * cum / np.arange(1, k + 1)).sum(1)
-        out[k]["map"] = float(np.where(has, ap / safe_len, 0.0).sum() / n)
+        out[k_asked]["map"] = float(np.where(has, ap / safe_len, 0.0).sum() / n)
     return out
 
 
