@@ -400,7 +400,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, hint_rank=hint_rank,
                                counters=counters)
                 queues = counters.tolist()
-                light = queues[0] <= 256                     # (ranking.RankState.LIGHT_BELOW)
+                light = queues[0] <= 16                      # (ranking.RankState.LIGHT_BELOW)
 
                 def steady():
                     hint.copy_(old)
@@ -433,13 +433,11 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         state = (f"after {trained_steps} training steps ({extra + epoch_steps} of them untimed, past the measured ones); steady "
                  f"= thresholds carried from the evaluation {epoch_steps} steps (one epoch) earlier")
     else:
-        # (an epoch of the config-5 shard is 24 k steps: its steady state is measured with thresholds carried over 10
-        #  steps only, and says so)
-        if epoch_steps * ms_per_step > 5_000:
-            epoch_steps = 10
-        rk = time_ranklist(True)
-        state = (f"after {steps_done} training steps; steady = thresholds carried from the evaluation {epoch_steps} steps "
-                 f"earlier")
+        # (no trained state within the run's budget -- an epoch of the config-5 shard is 24 k steps --: the cold call
+        #  only; thresholds carried across the first steps of training are stale by construction, ranking.RankState
+        #  backs off from them)
+        rk = time_ranklist(False)
+        state = f"after {steps_done} training steps; cold thresholds"
     score_ms = rk.get("steady_ms", rk["cold_ms"])
     early_ms, early_st = early["cold_ms"], early["cold_st"]
     st, host_ms = rk.get("steady_st", rk["cold_st"]), rk["host_ms"]

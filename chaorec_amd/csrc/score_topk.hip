@@ -1118,7 +1118,7 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     // three more launches whose critical path is a whole item sweep by one wave, and pass B returns at once.  With
     // CHAOREC_SCORE_LIGHT the caller (who has seen the previous call's queue lengths) asks for no pass B at all.
     const bool light = hint_in && (flags & CHAOREC_SCORE_LIGHT) && !p.pf_group_fb;
-    const int small_queue = p.pf_group_fb ? -1 : 256;   // (very long item ranges: the per-user exact route streams the table per user)
+    const int small_queue = p.pf_group_fb ? -1 : 16;        // (the exact route costs ~6 us per user, a retry pass ~120 us)   // (very long item ranges: the per-user exact route streams the table per user)
     int *wide_cnt = (int *)(ws + p.off_pf_scalars + 192);
     if (hint_in) {
       PrefArgs A = P;            // pass A: the carried thresholds

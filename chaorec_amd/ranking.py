@@ -53,11 +53,33 @@ class RankState:
             return False
         return int(self.counters_host[0]) <= self.LIGHT_BELOW
 
-    def after_call(self):
+    def use_hints(self, num_user):
+        """Carried thresholds pay off when the tables moved little since the last call.  Early in training they move a
+        lot -- every user fails pass A, which then only costs time (a full sweep + selection before the retry pass).
+        The previous call's queue length tells: after a call that queued more than STALE_SHARE of the users the next
+        calls run without hints, 1, 2, 4 ... up to 16 of them, until a hinted call succeeds again."""
+        if not self.valid:
+            return False
+        if self.copied is not None and self.copied.query() and self.last_hinted:
+            if int(self.counters_host[0]) > self.STALE_SHARE * num_user:
+                self.backoff = min(max(2 * self.backoff, 1), 16)
+                self.cooldown = self.backoff
+            else:
+                self.backoff = 0
+            self.last_hinted = False
+        if self.cooldown > 0:
+            self.cooldown -= 1
+            return False
+        return True
+
+    last_hinted = False
+
+    def after_call(self, hinted):
         self.counters_host.copy_(self.counters, non_blocking=True)
         self.copied = torch.cuda.Event()
         self.copied.record()
         self.valid = True
+        self.last_hinted = bool(hinted)
 
 
 def state_of(model):
@@ -75,11 +97,12 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
         result = result.detach()
         if state is not None:
             hint = state.buffer(num_user, result.device)
+            hinted = state.use_hints(num_user)
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
-                                    id_offset=num_user, hint=hint, hint_valid=state.valid,
-                                    hint_rank=min(2 * topk, 128), light=state.light(),
+                                    id_offset=num_user, hint=hint, hint_valid=hinted,
+                                    hint_rank=min(2 * topk, 128), light=hinted and state.light(),
                                     counters=state.counters)
-            state.after_call()
+            state.after_call(hinted)
         else:
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                     id_offset=num_user)

@@ -279,7 +279,7 @@ int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
  *            (no sampling pass, about half the candidates of a sampled threshold); users it cannot certify -- scores
  *            moved too much since -- are queued on the device and retried with a sampled threshold (pass B), then, if
  *            need be, ranked exactly.  hint_in == NULL: pass B for everybody (= chaorec_score_topk_f32).
- *            A queue of at most 256 users skips pass B and is ranked exactly, per user, at once.
+ *            A queue of at most 16 users skips pass B and is ranked exactly, per user, at once.
  *   flags    CHAOREC_SCORE_LIGHT: launch no pass B at all (three launches and their one-wave critical path less) -- for
  *            a caller that saw a short queue last time; whatever pass A leaves is ranked exactly per user, which is slow
  *            only if that expectation was wrong.
