@@ -896,7 +896,10 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   // streaming-top-r instantiation (32 slots, fewer and longer waves)
   p.pf_sample_long = n_tiles > 512;
   p.pf_sample_splits = p.pf_sample_long ? 3 : 4;
-  p.pf_sample_rank = p.pf_sample_long ? (p.pf_sample_stride == 16 ? 7 : (p.pf_sample_stride == 8 ? 10 : 14)) : 10;
+  #ifndef CHAOREC_PF_RANK
+#define CHAOREC_PF_RANK 8
+#endif
+  p.pf_sample_rank = p.pf_sample_long ? (p.pf_sample_stride == 16 ? 7 : (p.pf_sample_stride == 8 ? 10 : 14)) : CHAOREC_PF_RANK;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 64 * (size_t)(D / 16 + 1) * 16 : 0);
