@@ -31,12 +31,14 @@ class RankState:
     one: one epoch of training moves the scores little, so the next call needs no sampling pass and re-scores about
     half the candidates).  The thresholds never change a result; stale ones only cost a retry."""
 
-    LIGHT_BELOW = 256    # a call whose predecessor queued at most this many users for the retry pass runs without one
+    LIGHT_BELOW = 16     # a call whose predecessor queued at most this many users for the retry pass runs without one
+    STALE_SHARE = 0.1    # ... and one whose predecessor queued more than this share of the users runs WITHOUT hints
 
     def __init__(self):
         self.hint, self.valid = None, False
         self.counters = self.counters_host = None
         self.copied = None          # event: the previous call's counters have reached the host
+        self.cooldown = self.backoff = 0
 
     def buffer(self, num_user, device):
         if self.hint is None or self.hint.numel() != num_user or self.hint.device != device:
@@ -49,9 +51,7 @@ class RankState:
     def light(self):
         """No retry pass this time?  Yes when the previous call's queue lengths are on the host already (they were
         copied asynchronously: no sync here) and that call queued only a handful of users."""
-        if not self.valid or self.copied is None or not self.copied.query():
-            return False
-        return int(self.counters_host[0]) <= self.LIGHT_BELOW
+        return self.prev_queue is not None and self.prev_queue <= self.LIGHT_BELOW
 
     def use_hints(self, num_user):
         """Carried thresholds pay off when the tables moved little since the last call.  Early in training they move a
@@ -60,19 +60,22 @@ class RankState:
         calls run without hints, 1, 2, 4 ... up to 16 of them, until a hinted call succeeds again."""
         if not self.valid:
             return False
+        self.prev_queue = None                      # the previous call's pass-A queue, if it had a pass A and we know it
         if self.copied is not None and self.copied.query() and self.last_hinted:
-            if int(self.counters_host[0]) > self.STALE_SHARE * num_user:
+            self.prev_queue = int(self.counters_host[0])
+            if self.prev_queue > self.STALE_SHARE * num_user:
                 self.backoff = min(max(2 * self.backoff, 1), 16)
                 self.cooldown = self.backoff
             else:
                 self.backoff = 0
-            self.last_hinted = False
+        self.last_hinted = False
         if self.cooldown > 0:
             self.cooldown -= 1
             return False
         return True
 
     last_hinted = False
+    prev_queue = None
 
     def after_call(self, hinted):
         self.counters_host.copy_(self.counters, non_blocking=True)

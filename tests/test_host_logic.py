@@ -327,3 +327,35 @@ def test_csr_update_from_rewrites_in_place_and_refreshes_the_schedule():
     assert torch.equal(a.schedule(64), b.schedule(64)) and not torch.equal(a.schedule(64), before)
     c = graph.coo_to_csr_coalesced(torch.tensor([0, 1]), torch.tensor([1, 0]), torch.tensor([1., 1.]), 50, 50)
     assert not a.update_from(c)          # different entry count: the caller must not keep a captured step on it
+
+
+def test_rank_state_backs_off_from_stale_thresholds():
+    """ranking.RankState: a hinted call that queued most users for the retry pass is followed by 1, 2, 4 ... calls
+    without hints; a successful hinted call resets the back-off; light mode only after a short queue."""
+    import torch
+    from chaorec_amd import ranking
+
+    class _Done:
+        def query(self):
+            return True
+
+    st = ranking.RankState()
+    st.hint, st.valid = torch.zeros(4), True
+    st.counters_host = torch.zeros(4, dtype=torch.int32)
+    U = 1000
+
+    def call(queued):
+        hinted = st.use_hints(U)
+        light = hinted and st.light()
+        st.counters_host[0] = queued if hinted else 0          # what the call's counters would report
+        st.copied, st.last_hinted = _Done(), hinted
+        return hinted, light
+
+    assert call(900) == (True, False)             # first hinted call (no previous counters on the host): fails massively
+    assert call(0)[0] is False                    # back-off 1
+    assert call(900)[0] is True                   # tries again, fails again
+    assert [call(0)[0] for _ in range(2)] == [False, False]          # back-off 2
+    assert call(5) == (True, False)               # succeeds (queue of 5): back-off reset; light not yet (previous call was cold)
+    assert call(3) == (True, True)                # short queue last time: no retry pass
+    assert call(400)[0] is True                   # 40 % queued: stale again
+    assert call(0)[0] is False
