@@ -390,7 +390,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, stats=st)
             out["cold_st"] = st
             if with_steady:
-                hint_rank = 125                              # (ranking.gene_ranklist: 2.5 K)
+                hint_rank = 100                              # (ranking.gene_ranklist: 2 K)
                 old = torch.empty(U, dtype=torch.float32, device=dev)
                 ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=False, hint_rank=hint_rank)
                 run_steps(epoch_steps)                       # one epoch of training between the two evaluations

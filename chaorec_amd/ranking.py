@@ -27,7 +27,7 @@ def _to_host(idx):
 
 class RankState:
     """What one model's evaluations carry from call to call: the per-user candidate thresholds of
-    chaorec_score_topk_hinted_f32 (each gene_ranklist() leaves, per user, the exact score of rank 2.5 K for the next
+    chaorec_score_topk_hinted_f32 (each gene_ranklist() leaves, per user, the exact score of rank 2 K for the next
     one: one epoch of training moves the scores little, so the next call needs no sampling pass and re-scores about
     half the candidates).  The thresholds never change a result; stale ones only cost a retry."""
 
@@ -103,7 +103,7 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
             hinted = state.use_hints(num_user)
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                     id_offset=num_user, hint=hint, hint_valid=hinted,
-                                    hint_rank=min((5 * topk + 1) // 2, 128), light=hinted and state.light(),
+                                    hint_rank=min(2 * topk, 128), light=hinted and state.light(),
                                     counters=state.counters)
             state.after_call(hinted)
         else:
