@@ -407,8 +407,7 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
         _lib.check(lib.chaorec_score_topk_stats(_ptr(ws), U, I, K, D, _ptr(out9), _stream()), "chaorec_score_topk_stats")
         v = out9.tolist()
         stats.update(fallback_users=v[0], candidates=v[1], longest_list=v[2], prefilter_users=v[3],
-                     fallback_reasons=dict(overflow=v[4], too_few=v[5], too_many=v[6], band_below_threshold=v[7],
-                                           band_too_wide=v[8]))
+                     fallback_reasons=dict(overflow=v[4], too_few=v[5], too_many=v[6], kth_not_above_threshold=v[7]))
     return idx, val
 
 
