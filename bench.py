@@ -450,7 +450,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
 
 
 def scoring_roofline(r):
-    return {"bound": "mfma", "kernel": f"score_sweep_bf16_kernel<{r['D']},2> (+ pack, sample, select/re-score)",
+    return {"bound": "mfma", "kernel": f"score_sweep_bf16_kernel<{r['D']},{3 if r['D'] <= 64 else 2}> (+ pack, sample, select/re-score)",
             "achieved": r["score_tf"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": r["score_tf"] / BF16_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": r["score_tf"] / F32_MFMA_PEAK_TFLOPS,
             "prefilter": r["score_st"],

@@ -736,12 +736,12 @@ constexpr int kPfSelHist = 128;             // ... and the selection (longer his
 // The exact re-score is where the selection's time goes, and what it costs is ADDRESSES, not bytes or flops: a lane
 // that loads its own candidate's row puts 64 different cache lines into every load instruction, and the CU's address
 // path retires about one line per clock -- measured ~90 us per round of 64 candidates over sports' 28 940 users,
-// whatever the register budget.  So the rows are fetched in whole 128-B lines: G = D/8 lanes per candidate (64 / G
-// candidates per load instruction), lane l of a group holding floats [4l, 4l+4) and [D/2 + 4l, D/2 + 4l + 4) of the
-// row -- exactly the operands of chain steps 8l .. 8l+7 (the chain alternates between the two halves of the row).
-// The chain itself stays sequential: the accumulator walks through the group's lanes, one DPP move per 8 fmas, every
-// lane executing every segment (the result of the lane whose turn it is is kept).  ~11 VALU instructions per
-// candidate instead of ~1, no LDS traffic, and an order of magnitude fewer addresses.
+// whatever the register budget.  So a row is fetched by G = 4 lanes per candidate (16 candidates per load
+// instruction), lane l of a group holding floats [S l, S l + S) and [D/2 + S l, D/2 + S l + S) of the row, S = D/8
+// -- exactly the operands of chain steps 2 S l .. 2 S l + 2 S - 1 (the chain alternates between the two halves of the
+// row).  The chain itself stays sequential: the accumulator walks through the group's lanes, one DPP move per 2 S
+// fmas, every lane executing every segment (the result of the lane whose turn it is is kept).  G x the fmas of a
+// lane-per-candidate chain, no LDS traffic, and 4 x fewer, line-sized addresses.
 // (Tried: lane-per-candidate loads with the whole row in flight -- address-bound, as said; rows through an LDS tile
 //  walked by 16 lanes -- LDS-bound.)
 template <int D>
