@@ -974,8 +974,21 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
         wrote = true;
         if (P.hint_out) {
           // next call's threshold: one float below the exact score of rank `want` (>= K): equal scores stay candidates
-          const uint64_t hk = key_of_rank(min(max(P.hint_rank, K), n_keys) - 1);
-          if (lane == 0) P.hint_out[u] = nextafterf(ord_to_f32((uint32_t)(hk >> 32)), -INFINITY);
+          const int want = max(P.hint_rank, K);
+          const uint64_t hk = key_of_rank(min(want, n_keys) - 1);
+          float t = nextafterf(ord_to_f32((uint32_t)(hk >> 32)), -INFINITY);
+          if (n_keys < want) {
+            // Fewer candidates than the rank the threshold is taken at: the user's scores sank below the carried
+            // threshold since it was set.  The lowest candidate is then (about) that same threshold again, and a user
+            // that keeps sinking ends on the exact route (48 us for the call, however few users take it).  Take the
+            // threshold where rank `want` would be if the scores went on falling as they do between rank K and the
+            // last candidate.  Any value is legal.
+            const float s_k = ord_to_f32((uint32_t)(kth >> 32)), s_last = ord_to_f32((uint32_t)(hk >> 32));
+            const float s_top = ord_to_f32((uint32_t)(key_of_rank(0) >> 32));
+            const float slope = n_keys > K ? (s_k - s_last) / (float)(n_keys - K) : (s_top - s_k) / (float)max(K - 1, 1);
+            t -= slope * (float)(want - n_keys);
+          }
+          if (lane == 0) P.hint_out[u] = t;
         }
       }
     } else if (why == 0) {
@@ -1178,7 +1191,7 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
           key[j] = make_key(sv, item);
         }
       }
-      bk = wave_select_topk<kExPer>(key, bk, K, stage[wave]);
+      bk = wave_select_topk<kExPer>(key, bk, kMaxK, stage[wave]);   // (the 64 best: the next call's threshold wants more than K)
     }
     // block merge: the NW wave lists -> wave 0 (NW keys per lane)
     stage[wave][lane] = bk;
@@ -1189,7 +1202,7 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
 #pragma unroll
       for (int j = 0; j < NW; ++j) mk[j] = stage[j][lane];
       __builtin_amdgcn_wave_barrier();
-      const uint64_t bb = wave_select_topk<NW>(mk, 0ull, K, stage[0]);
+      const uint64_t bb = wave_select_topk<NW>(mk, 0ull, kMaxK, stage[0]);
       part[slice * kMaxK + lane] = bb;   // kMaxK == 64
       __threadfence();
       if (lane == 0) last = atomicAdd(P.fb_done + qi, 1) == kExSlices - 1 ? 1 : 0;
@@ -1200,15 +1213,28 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
       uint64_t mk[kExSlices];
 #pragma unroll
       for (int j = 0; j < kExSlices; ++j) mk[j] = __builtin_nontemporal_load(part + j * kMaxK + lane);
-      uint64_t e = wave_select_topk<kExSlices>(mk, 0ull, K, stage[0]);
+      uint64_t e = wave_select_topk<kExSlices>(mk, 0ull, kMaxK, stage[0]);
       sort64_desc(e, lane);
       if (lane < K) {
         const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull);
         P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;
         P.out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e >> 32));
       }
-      // (a user that needed the exact route keeps a threshold that lets everything through next time: K-th best, one below)
-      if (P.hint_out && lane == K - 1) P.hint_out[u] = nextafterf(ord_to_f32((uint32_t)(e >> 32)), -INFINITY);
+      // A user on this route had a threshold that cut too close: its next one is taken well below what a certified
+      // user gets (the score of rank 2 K): the scores of ranks 32 and 64 extrapolated as far again below rank 64 --
+      // about rank 100 on a level score curve, lower where the curve is steep.  (With "one float below the K-th best"
+      // these users failed again at the next call, whichever way their scores moved, and the queue grew from call to
+      // call.)  Any value is legal.
+      if (P.hint_out) {
+        const uint32_t o31 = (uint32_t)__shfl((int)(uint32_t)(e >> 32), 31, 64), o63 = (uint32_t)__shfl((int)(uint32_t)(e >> 32), 63, 64);
+        const uint64_t ek = shfl_u64(e, K - 1);
+        float t = nextafterf(ord_to_f32((uint32_t)(ek >> 32)), -INFINITY);
+        if (shfl_u64(e, 63) != 0ull) {
+          const float s31 = ord_to_f32(o31), s63 = ord_to_f32(o63);
+          t = fminf(t, s63 - (s31 - s63));
+        }
+        if (lane == 0) P.hint_out[u] = t;
+      }
     }
   }
 }

@@ -48,6 +48,23 @@ def main():
             ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, light=True)
         torch.cuda.synchronize()
         return
+    if os.environ.get("EPOCH_APART"):
+        # bench.py's steady state: thresholds of rank 100 from the tables one epoch (155 steps) earlier, light mode
+        old = torch.empty(U, dtype=torch.float32, device=dev)
+        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=False, hint_rank=100)
+        step.run(155)
+        res = m.result.detach().clone()
+        ue, ie = res[:U], res[U:U + I]
+        counters = torch.zeros(4, dtype=torch.int32, device=dev)
+
+        def steady():
+            hint.copy_(old)
+            ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True,
+                           hint_rank=int(os.environ.get("TIMED_HINT_RANK", "100")), light=True, counters=counters)
+        t = timed(steady, 8)
+        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, hint_rank=100, light=True, stats=st)
+        print(f"epoch apart, light        {t * 1e3:7.1f} us  cand/user {st['candidates'] / U:6.1f}  queues {counters.tolist()}")
+        return
     cold = timed(lambda: ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U))
     ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, stats=st)
     print(f"cold                      {cold * 1e3:7.1f} us  cand/user {st['candidates'] / U:6.1f}  exact-route users {st['fallback_users']}")
@@ -71,8 +88,11 @@ def main():
                            counters=counters)
             e.record()
             torch.cuda.synchronize()
+            st2 = {}
+            keep = hint.clone()
+            ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=keep, hint_valid=True, hint_rank=rank, light=light, stats=st2)
             print(f"carried (rank {rank}), one epoch apart, light={int(light)}  {s.elapsed_time(e) * 1e3:7.1f} us  "
-                  f"queues [retry, exact, wide, retry->exact] {counters.tolist()}")
+                  f"queues [retry, exact, wide, retry->exact] {counters.tolist()}  (same tables again: cand/user {st2['candidates'] / U:6.1f})")
 
 
 if __name__ == "__main__":

@@ -14,6 +14,11 @@ for v in variants:
     subprocess.check_call([sys.executable, "-c", "from chaorec_amd import _lib; _lib.build(force=True)"], cwd=ROOT, env=env)
     out = "/tmp/selvar"
     shutil.rmtree(out, ignore_errors=True)
+    if os.environ.get("EPOCH_APART"):       # bench.py's steady state only: the timeline of the last calls
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_timeline.py"), "1500", "EPOCH_APART"], cwd=ROOT, env=env,
+                           capture_output=True, text=True)
+        print(f"== {v or 'baseline'}\n" + "\n".join(r.stdout.splitlines()[-6:]), flush=True)
+        continue
     subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable,
                     os.path.join(ROOT, "tools", "score_profile.py"), "1500"], cwd="/tmp", env=env, capture_output=True)
     rows = list(csv.DictReader(open(glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0])))
