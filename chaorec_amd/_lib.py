@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -102,6 +102,8 @@ SIGNATURES = {
     "chaorec_weighted_sample_keep": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
                                                     ctypes.c_uint64, c_ptr, c_ptr, ctypes.c_size_t, c_ptr, c_ptr,
                                                     c_ptr]),
+    "chaorec_weighted_sample_keys": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, c_ptr,
+                                                    c_ptr, c_ptr]),
 }
 
 

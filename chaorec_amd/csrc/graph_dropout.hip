@@ -80,13 +80,15 @@ __global__ __launch_bounds__(256) void edge_dropout_norm_kernel(
 // ---- weighted sampling without replacement ----------------------------------------------------------------
 // 64-bit key of entry e: high 32 bits = fp32 bits of -log(u)/w (positive -> unsigned order == float order), low 32
 // bits = fresh hash bits that order entries whose fp32 keys coincide.  w <= 0 -> never selected.
-__device__ __forceinline__ uint64_t race_key(const float *__restrict__ w, int64_t e, uint64_t seed, uint64_t step) {
+__device__ __forceinline__ uint64_t race_key_of(float we, int64_t e, uint64_t seed, uint64_t step) {
   const uint64_t h = mix64(seed ^ mix64(step ^ mix64(0x5A3Bull << 48 ^ (uint64_t)e)));
-  const float we = w[e];
   if (!(we > 0.f)) return ~0ull;
   const float u = ((float)(uint32_t)(h >> 40) + 0.5f) * 5.9604644775390625e-08f;   // (0,1): log finite
   const float key = fabsf(logf(u)) / we;          // >= +0: unsigned order of the bits == float order
   return ((uint64_t)__float_as_uint(key) << 32) | (uint32_t)h;
+}
+__device__ __forceinline__ uint64_t race_key(const float *__restrict__ w, int64_t e, uint64_t seed, uint64_t step) {
+  return race_key_of(w[e], e, seed, step);
 }
 
 constexpr int kRaceBits = 11, kRaceBins = 1 << kRaceBits, kRacePasses = 6;   // 6 x 11 >= 64
@@ -171,6 +173,17 @@ __global__ __launch_bounds__(256) void race_keep_kernel(const float *__restrict_
   }
 }
 
+// keys only, entry j numbered ids[j] (a rank's share of an edge list keeps the numbers of the whole list: the keys,
+// and with them the kept set, do not depend on how the edges are spread over the ranks)
+__global__ __launch_bounds__(256) void race_keys_kernel(const float *__restrict__ w, const int64_t *__restrict__ ids,
+                                                        int64_t n, uint64_t seed, uint64_t step,
+                                                        const int64_t *__restrict__ step_dev,
+                                                        uint64_t *__restrict__ keys_out) {
+  if (step_dev) step += (uint64_t)step_dev[0];
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+    keys_out[j] = race_key_of(w[j], ids ? ids[j] : j, seed, step);
+}
+
 __global__ void race_init_kernel(uint64_t *state, uint32_t *hist, int64_t k) {
   for (int i = threadIdx.x; i < kRaceBins; i += blockDim.x) hist[i] = 0;
   if (threadIdx.x == 0) {
@@ -228,4 +241,14 @@ extern "C" int chaorec_weighted_sample_keep(const float *weights, int64_t n, int
   }
   race_keep_kernel<<<blocks, 256, 0, st>>>(weights, n, seed, step, step_dev, state, keep, keys_out);
   return check_launch("weighted_sample_keep");
+}
+
+extern "C" int chaorec_weighted_sample_keys(const float *weights, const int64_t *ids, int64_t n, uint64_t seed,
+                                            uint64_t step, const int64_t *step_dev, uint64_t *keys_out, void *stream) {
+  if (!weights || !keys_out) return fail(CHAOREC_E_INVALID, "weighted_sample_keys: null pointer");
+  if (n < 0) return fail(CHAOREC_E_INVALID, "weighted_sample_keys: n=%lld", (long long)n);
+  if (n == 0) return CHAOREC_OK;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  race_keys_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(weights, ids, n, seed, step, step_dev, keys_out);
+  return check_launch("weighted_sample_keys");
 }

@@ -558,3 +558,169 @@ class ShardedMMGCN(nn.Module):
         if gather and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             return gather_ranklists(idx, self.shard, self.group)
         return idx.cpu()
+
+
+# ---------------------------------------------------------------------------------------------------- FREEDOM
+class _SumGradAcrossRanks(torch.autograd.Function):
+    """Identity whose gradient is summed over the ranks: a replicated tensor feeding a rank-local branch of the loss."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        if _active(ctx.group):
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+def global_kth_smallest(keys, k, group=None):
+    """The k-th smallest (1-based) of the ranks' int64 keys taken together, keys >= 0 (entries < 0 never count): a radix
+    select, 4 digits of 16 bits, one all-reduce of a 65 536-bin histogram per digit -- no rank sees another's keys."""
+    keys = keys[keys >= 0]
+    prefix, want = 0, int(k)
+    for shift in (48, 32, 16, 0):
+        digit = (keys >> shift) & 0xFFFF
+        hist = torch.bincount(digit, minlength=65536)
+        if _active(group):
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+        csum = torch.cumsum(hist, 0)
+        d = int(torch.searchsorted(csum, torch.tensor([want], device=csum.device, dtype=csum.dtype))[0])
+        if d >= 65536:
+            raise ValueError("global_kth_smallest: k exceeds the number of keys")
+        want -= int(csum[d - 1]) if d > 0 else 0
+        prefix |= d << shift
+        keys = keys[digit == d]
+    return prefix
+
+
+class ShardedFREEDOM(nn.Module):
+    """FREEDOM (Model/FREEDOM.py) on one user shard, built from a single-process chaorec_amd FREEDOM (or any object
+    with its attributes) so that every rank starts from the same weights.  Users are sharded by rows like LightGCN's;
+    everything on the item side -- item embeddings, the modality tables and their transforms, the item-item kNN graph
+    mm_adj and its SpMM -- is replicated: the item-item propagation runs on every rank (no exchange), and the partial
+    gradients of the replicated parameters are summed (item rows inside the backward, the rest in one flat bucket:
+    sync_grads()).  Ids are shard-local: users [0, U_g), items [0, I) as in FREEDOM.loss after its own offset.
+
+    The per-epoch degree-sensitive pruning (Model/FREEDOM.py:143-162) keeps the k edges with the smallest race keys of
+    the WHOLE edge list: every rank computes the keys of its own edges numbered as in the whole list
+    (chaorec_weighted_sample_keys), the k-th smallest key over all ranks comes from global_kth_smallest, and the kept
+    set is exactly the single-process one for the same seed.  The pruned shard is rebuilt per rank from its kept edges
+    (item degrees of the pruned graph by one all-reduce: UserShard.from_local)."""
+
+    def __init__(self, full, bounds, world, rank, device, group=None, spmm_fn=None, mm_spmm_fn=None, bpr_fn=None,
+                 linear_fn=None, keys_fn=None, prune_seed=None):
+        super().__init__()
+        import copy
+        self.device, self.group, self.world, self.rank = device, group, world, rank
+        self.bounds = [int(b) for b in bounds]
+        self.u0, self.u1 = self.bounds[rank], self.bounds[rank + 1]
+        self.num_user, self.num_item = self.u1 - self.u0, full.num_item
+        self.num_user_global = full.num_user
+        self.n_layers, self.mm_layers = full.n_layers, full.mm_layers
+        self.reg_weight, self.dropout = full.reg_weight, full.dropout
+        self.user_embedding = nn.Embedding(self.num_user, full.user_embedding.weight.shape[1])
+        with torch.no_grad():
+            self.user_embedding.weight.copy_(full.user_embedding.weight[self.u0:self.u1])
+        self.item_embedding = copy.deepcopy(full.item_embedding)
+        self.text_embedding, self.image_embedding = copy.deepcopy(full.text_embedding), copy.deepcopy(full.image_embedding)
+        self.text_trs, self.image_trs = copy.deepcopy(full.text_trs), copy.deepcopy(full.image_trs)
+        self.mm_adj = full.mm_adj.to(device)
+        self.to(device)
+        # this rank's share of the edge list, with the edges' numbers in the whole list
+        ei = full.edge_indices.cpu()
+        mine = ((ei[0] >= self.u0) & (ei[0] < self.u1)).nonzero().flatten()
+        self.edge_ids = mine.to(device)
+        self.local_edges = np.stack([ei[0][mine].numpy(), ei[1][mine].numpy() + self.num_user_global], 1).astype(np.int64)
+        self.edge_values = full.edge_values.detach().cpu()[mine].to(device)
+        self.n_edges_global = int(ei.shape[1])
+        self._spmm_fn = spmm_fn or ops.spmm_raw
+        self._mm_spmm = mm_spmm_fn or ops.spmm
+        self._bpr = bpr_fn or ops.bpr_loss
+        self._linear = linear_fn or ops.linear
+        self._keys_fn = keys_fn or ops.weighted_sample_keys
+        self._prune_seed = int(prune_seed if prune_seed is not None else getattr(full, "_prune_seed", 0))
+        self._prune_calls = 0
+        rowptr, col = graph.user_hist_csr(graph.user_item_dict_from_edges(
+            np.stack([self.local_edges[:, 0] - self.u0, self.local_edges[:, 1] - self.num_user_global + self.num_user], 1)),
+            self.num_user)
+        self.hist = (rowptr.to(device), col.to(device))
+        self.shard = None            # the (pruned) graph of this epoch
+        self.result = None
+        self._bucket = None
+        if self.dropout <= .0:
+            self._set_shard(self.local_edges, scale=0.5)
+
+    def _set_shard(self, kept_local_edges, scale=1.0):
+        sh = UserShard.from_local(kept_local_edges, self.bounds, self.num_item, self.world, self.rank, self.device,
+                                  group=self.group)
+        if scale != 1.0:
+            # dropout == 0 trains on get_norm_adj_mat's graph: degrees counted over the bidirectional list (Q6), i.e.
+            # (2 d_u)^-1/2 (2 d_i)^-1/2 = half of the values of the pruned graphs' normalisation
+            sh.ui.val.mul_(scale)
+            sh.iu.val.mul_(scale)
+        self.shard = sh
+
+    def pre_epoch_processing(self):
+        """Model/FREEDOM.py:143-162 on the sharded edge list."""
+        if self.dropout <= .0:
+            return
+        k = int(self.n_edges_global * (1. - self.dropout))
+        keys = self._keys_fn(self.edge_values, self.edge_ids, self._prune_seed, self._prune_calls)
+        self._prune_calls += 1
+        kth = global_kth_smallest(keys, k, self.group)
+        keep = ((keys >= 0) & (keys <= kth)).cpu().numpy()
+        self._set_shard(self.local_edges[keep])
+
+    def forward(self):
+        xu, xi = self.user_embedding.weight, self.item_embedding.weight
+        fu, fi = sharded_layer_mean_propagate(xu, xi, self.shard, self.n_layers, self._spmm_fn, self.group)
+        h = _SumGradAcrossRanks.apply(xi, self.group)      # the item-item branch: replicated compute, summed gradient
+        for _ in range(self.mm_layers):
+            h = self._mm_spmm(self.mm_adj, h)
+        ig = fi + h
+        self.result = torch.cat((fu, ig), 0)
+        return fu, ig
+
+    def loss(self, users, pos_items, neg_items):
+        """Model/FREEDOM.py:194-217 on this rank's triples (local user ids, item ids in [0, I)); the global loss is the
+        mean over ranks."""
+        users, pos, neg = users.to(self.device), pos_items.to(self.device), neg_items.to(self.device)
+        ua, ia = self.forward()
+        V = ops.VARIANT_LOGSIGMOID
+        total = self._bpr(ua, ia, users, pos, neg, V, 0.0)[0]
+        tf = self._linear(self.text_embedding.weight, self.text_trs.weight, self.text_trs.bias)
+        vf = self._linear(self.image_embedding.weight, self.image_trs.weight, self.image_trs.bias)
+        total = total + self.reg_weight * (self._bpr(ua, tf, users, pos, neg, V, 0.0)[0] +
+                                           self._bpr(ua, vf, users, pos, neg, V, 0.0)[0])
+        return total / self.world
+
+    def replicated_parameters(self):
+        """Parameters every rank holds whose gradients are PARTIAL after backward (item_embedding's is already summed)."""
+        return [p for m in (self.text_embedding, self.image_embedding, self.text_trs, self.image_trs) for p in m.parameters()]
+
+    def zero_grad(self, set_to_none=False):
+        if self._bucket is None:
+            self._bucket = GradBucket(self.replicated_parameters())
+        self._bucket.zero()
+        for p in (self.user_embedding.weight, self.item_embedding.weight):
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def sync_grads(self):
+        if self._bucket is not None and self._bucket.attached():
+            self._bucket.all_reduce(self.group)
+        else:
+            allreduce_grads(self.replicated_parameters(), self.group)
+
+    def gene_ranklist(self, topk=50, gather=False):
+        with torch.no_grad():
+            r = self.result.detach()
+            idx, _ = ops.score_topk(r[:self.num_user], r[self.num_user:], self.hist, 1e-6, topk,
+                                    id_offset=self.num_user_global)
+        if gather and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return gather_ranklists(idx, self, self.group)
+        return idx.cpu()

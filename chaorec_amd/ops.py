@@ -626,6 +626,24 @@ def weighted_sample_keep(weights, k, seed, step=0, step_dev=None, return_keys=Fa
     return (keep, keys) if return_keys else keep
 
 
+def weighted_sample_keys(weights, ids=None, seed=0, step=0, step_dev=None):
+    """int64 [n] race keys of chaorec_weighted_sample_keep alone, entry j numbered ids[j] (its number in the whole
+    edge list; None: j): one rank's share of a sharded pruning (dist.ShardedFREEDOM).  Non-negative as int64 for
+    positive weights; entries with weight <= 0 get -1 (all 64 bits set: never among the k smallest of the unsigned order)."""
+    _need_cuda(weights, ids, step_dev)
+    weights = _f32c(weights)
+    n = weights.numel()
+    if ids is not None:
+        ids = ids.to(torch.int64).contiguous()
+        if ids.numel() != n:
+            raise ValueError("weighted_sample_keys: ids and weights differ in length")
+    keys = torch.empty(n, dtype=torch.int64, device=weights.device)
+    rc = _lib.load().chaorec_weighted_sample_keys(_ptr(weights), _ptr(ids), n, int(seed) & (2**64 - 1), int(step),
+                                                  _ptr(step_dev), _ptr(keys), _stream())
+    _lib.check(rc, "chaorec_weighted_sample_keys")
+    return keys
+
+
 # --------------------------------------------------------------------------------------------
 # row-wise cosine re-weighting (LayerGCN)
 # --------------------------------------------------------------------------------------------

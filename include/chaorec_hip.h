@@ -26,12 +26,13 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 4   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 5   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
                                   stand-alone BPR finalize with loss / optimizer bookkeeping, layer mean in the last
-                                  forward SpMM, scoring with carried thresholds, split-bf16 NT GEMM */
+                                  forward SpMM, scoring with carried thresholds, split-bf16 NT GEMM;
+                                  5: weighted_sample_keys (sharded edge pruning) */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -419,6 +420,13 @@ size_t chaorec_weighted_sample_workspace_bytes(void);
 int chaorec_weighted_sample_keep(const float *weights, int64_t n, int64_t k, uint64_t seed, uint64_t step,
                                  const int64_t *step_dev, void *workspace, size_t workspace_bytes,
                                  uint8_t *keep, uint64_t *keys_out, void *stream);
+
+/* The keys of that race alone, entry j numbered ids[j] (NULL: j): what a RANK of a user-sharded job computes for its
+ * own share of the edge list (chaorec_amd/dist.py:ShardedFREEDOM.pre_epoch_processing) -- with the edges' numbers in
+ * the whole list the keys, hence the kept set { key <= the k-th smallest key of ALL ranks }, do not depend on the
+ * sharding; the k-th smallest key over the ranks is found by a radix select over all-reduced histograms. */
+int chaorec_weighted_sample_keys(const float *weights, const int64_t *ids, int64_t n, uint64_t seed, uint64_t step,
+                                 const int64_t *step_dev, uint64_t *keys_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row-wise cosine re-weighting of a propagated layer (LayerGCN).

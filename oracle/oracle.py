@@ -334,6 +334,19 @@ def race_uniform(n, seed, step):
     return u, (h & np.uint64(0xFFFFFFFF)).astype(np.uint32)
 
 
+def race_keys(weights, seed, step, ids=None):
+    """uint64 keys of chaorec_weighted_sample_keep / _keys (chaorec_amd/csrc/graph_dropout.hip:race_key_of): high word
+    = fp32 bits of |log u| / w, low word = hash bits; entry j numbered ids[j] (None: j); w <= 0 -> all ones."""
+    w = np.asarray(weights, dtype=np.float32)
+    e = (np.arange(len(w)) if ids is None else np.asarray(ids)).astype(np.uint64)
+    h = mix64(np.uint64(seed) ^ mix64(np.uint64(step) ^ mix64((np.uint64(0x5A3B) << np.uint64(48)) ^ e)))
+    u = ((h >> np.uint64(40)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        key = (np.abs(np.log(u)).astype(np.float32) / w).astype(np.float32)
+    out = (key.view(np.uint32).astype(np.uint64) << np.uint64(32)) | (h & np.uint64(0xFFFFFFFF))
+    return np.where(w > 0, out, np.uint64(0xFFFFFFFFFFFFFFFF))
+
+
 def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50):
     """Model/LightGCN.py:137-162 -> int64 [U, topk] of GLOBAL item ids."""
     idx, val = score_topk(result[:num_user], result[num_user:num_user + num_item], hist,

@@ -355,3 +355,144 @@ def test_sharded_mmgcn_matches_single_process():
             assert np.array_equal(r[0]["g_" + n], r[1]["g_" + n]), n       # identical update on every rank
     finally:
         ops.linear, ops.spmm, ops.spmm_raw, ops.bpr_loss, ops.mean_all = saved
+
+
+# ---------------------------------------------------------------------------------------------------- FREEDOM
+def _freedom_full(dropout=0.2):
+    """Everything dist.ShardedFREEDOM reads from a single-process FREEDOM, without its constructor (the kNN build is a
+    GPU kernel): same seed -> same object on every rank and in the checking process."""
+    import types
+    from chaorec_amd import graph
+    from chaorec_amd.Model.FREEDOM import FREEDOM
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D = 260, 90, 1300, 16
+    edges = synthetic_interactions(U, I, E, seed=12)
+    torch.manual_seed(31)
+    ns = types.SimpleNamespace(num_user=U, num_item=I, n_layers=2, mm_layers=1, reg_weight=1e-3, dropout=dropout,
+                               _prune_seed=77)
+    ns.user_embedding, ns.item_embedding = torch.nn.Embedding(U, D), torch.nn.Embedding(I, D)
+    torch.nn.init.xavier_uniform_(ns.user_embedding.weight)
+    torch.nn.init.xavier_uniform_(ns.item_embedding.weight)
+    ns.text_embedding = torch.nn.Embedding.from_pretrained(torch.randn(I, 12), freeze=False)
+    ns.image_embedding = torch.nn.Embedding.from_pretrained(torch.randn(I, 20), freeze=False)
+    ns.text_trs, ns.image_trs = torch.nn.Linear(12, D), torch.nn.Linear(20, D)
+    g = torch.Generator().manual_seed(5)
+    rows = torch.arange(I).repeat_interleave(4)
+    cols = torch.randint(0, I, (4 * I,), generator=g)
+    ns.mm_adj = graph.coo_to_csr_coalesced(rows, cols, torch.full((4 * I,), 0.25), I, I)
+    e = torch.from_numpy(np.asarray(edges, dtype=np.int64))
+    ns.edge_indices = torch.stack([e[:, 0], e[:, 1] - U])
+    ns.edge_values = FREEDOM._normalize_adj_m(None, ns.edge_indices, torch.Size((U, I)))
+    return ns, edges
+
+
+def _freedom_standins(oracle_mod):
+    import torch.nn.functional as F
+    from chaorec_amd import ops
+
+    class _Spmm(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, csr):
+            ctx.csr = csr
+            return _oracle_spmm(csr, x)
+
+        @staticmethod
+        def backward(ctx, g):
+            return _oracle_spmm(ctx.csr.t(), g.contiguous()), None
+
+    def bpr(tab_u, tab_i, users, pos, neg, variant, reg):
+        assert variant == ops.VARIANT_LOGSIGMOID and reg == 0.0
+        s = (tab_u[users] * tab_i[pos]).sum(1) - (tab_u[users] * tab_i[neg]).sum(1)
+        return (-torch.mean(F.logsigmoid(s)),)
+
+    def keys(w, ids, seed, step):
+        return torch.from_numpy(oracle_mod.race_keys(w.numpy(), seed, step, ids.numpy()).view(np.int64))
+
+    return dict(spmm_fn=_oracle_spmm, mm_spmm_fn=lambda csr, x: _Spmm.apply(x, csr), bpr_fn=bpr, linear_fn=F.linear, keys_fn=keys)
+
+
+def _freedom_batch(m, rank, B=40):
+    rng = np.random.default_rng(300 + rank)
+    sel = rng.choice(len(m.local_edges), B, replace=False)
+    users = torch.from_numpy(m.local_edges[sel, 0] - m.u0)
+    pos = torch.from_numpy(m.local_edges[sel, 1] - m.num_user_global)
+    neg = torch.from_numpy(rng.integers(0, m.num_item, B))
+    return users, pos, neg
+
+
+def _freedom_worker(rank, world, port, tmp, dropout):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from chaorec_amd import dist as cdist
+    from oracle import oracle as oracle_mod
+    full, edges = _freedom_full(dropout)
+    bounds = cdist.partition_users_by_nnz(np.bincount(edges[:, 0], minlength=full.num_user), world)
+    m = cdist.ShardedFREEDOM(full, bounds, world, rank, torch.device("cpu"), **_freedom_standins(oracle_mod))
+    m.pre_epoch_processing()
+    m.pre_epoch_processing()                               # the second epoch's draw (step 1)
+    users, pos, neg = _freedom_batch(m, rank)
+    m.zero_grad()
+    loss = m.loss(users, pos, neg)
+    loss.backward()
+    m.sync_grads()
+    kept = np.stack([m.shard.local_edges[:, 0] + m.u0, m.shard.local_edges[:, 1] - m.num_user], 1)
+    np.savez(os.path.join(tmp, f"fr{rank}.npz"), u0=m.u0, u1=m.u1, loss=float(loss), users=users.numpy() + m.u0,
+             pos=pos.numpy(), neg=neg.numpy(), res=m.result.detach().numpy(), kept=kept,
+             **{"g_" + n: p.grad.numpy() for n, p in m.named_parameters()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dropout", [0.2, 0.0])
+def test_sharded_freedom_matches_single_process(oracle, dropout):
+    """BASELINE north_star "FREEDOM-style": FREEDOM sharded by user rows (2 gloo ranks, CPU stand-ins for the kernels):
+    the per-epoch pruning keeps exactly the single-process edge set (race keys numbered over the whole edge list, k-th
+    smallest key by a distributed radix select), representations, loss, and every gradient -- user rows, the item rows
+    summed inside the backward, the modality tables and transforms after sync_grads() -- equal the plain-torch
+    restatement of Model/FREEDOM.py:164-217 on the whole graph."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model.FREEDOM import FREEDOM
+    from oracle.torch_ref import freedom_reference_loss
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_freedom_worker, args=(world, _free_port(), tmp, dropout), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(tmp, f"fr{k}.npz"))) for k in range(world)]
+    full, edges = _freedom_full(dropout)
+    U, I = full.num_user, full.num_item
+    # single process: the second epoch's kept set (step 1) and its normalised, symmetrised graph (Model/FREEDOM.py:143-162)
+    if dropout > 0:
+        k = int(full.edge_values.numel() * (1 - dropout))
+        keys = oracle.race_keys(full.edge_values.numpy(), 77, 1)
+        keep = keys <= np.partition(keys, k - 1)[k - 1]
+        assert keep.sum() == k
+        ki = full.edge_indices[:, torch.from_numpy(keep)]
+        kept_ranks = np.concatenate([x["kept"] for x in r], 0)
+        assert {(int(a), int(b)) for a, b in kept_ranks} == {(int(a), int(b)) for a, b in ki.t().numpy()}
+        vals = FREEDOM._normalize_adj_m(None, ki, torch.Size((U, I)))
+    else:
+        ki = full.edge_indices
+        vals = 0.5 * FREEDOM._normalize_adj_m(None, ki, torch.Size((U, I)))     # (get_norm_adj_mat's doubled degrees, Q6)
+    rows = torch.cat((ki[0], ki[1] + U))
+    cols = torch.cat((ki[1] + U, ki[0]))
+    full.masked_adj = graph.coo_to_csr_coalesced(rows, cols, torch.cat((vals, vals)), U + I, U + I, symmetric=True)
+    users = torch.from_numpy(np.concatenate([x["users"] for x in r]))
+    pos = torch.from_numpy(np.concatenate([x["pos"] for x in r])) + U
+    neg = torch.from_numpy(np.concatenate([x["neg"] for x in r])) + U
+    ref_loss, ref_res = freedom_reference_loss(full, users, pos, neg)
+    ref_loss.backward()
+    assert sum(x["loss"] for x in r) == pytest.approx(float(ref_loss.detach()), rel=1e-5)
+    res_u = np.concatenate([x["res"][:x["u1"] - x["u0"]] for x in r], 0)
+    assert np.allclose(res_u, ref_res[:U].detach().numpy(), rtol=1e-5, atol=1e-7)
+    for x in r:
+        assert np.allclose(x["res"][x["u1"] - x["u0"]:], ref_res[U:].detach().numpy(), rtol=1e-5, atol=1e-7)
+    gu = np.concatenate([x["g_user_embedding.weight"] for x in r], 0)
+    assert np.allclose(gu, full.user_embedding.weight.grad.numpy(), rtol=2e-4, atol=1e-9)
+    for name, mod in (("item_embedding", full.item_embedding), ("text_embedding", full.text_embedding),
+                      ("image_embedding", full.image_embedding), ("text_trs", full.text_trs), ("image_trs", full.image_trs)):
+        for pn, p in mod.named_parameters():
+            for x in r:
+                got = x[f"g_{name}.{pn}"]
+                assert np.allclose(got, p.grad.numpy(), rtol=2e-4, atol=1e-8), (name, pn)

@@ -501,3 +501,41 @@ def test_in_launch_batches_equal_the_samplers(dev):
     assert loss_d == pytest.approx(loss_c, rel=1e-5)
     for (n, a), (_, b2) in zip(mc.named_parameters(), md.named_parameters()):
         assert torch.allclose(a, b2, rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.parametrize("tag", ["drop", "nodrop"])
+def test_sharded_freedom_one_rank_equals_freedom(dev, tag):
+    """dist.ShardedFREEDOM on ONE rank through the HIP kernels (sharded propagate blocks, keys-only sampler entry + the
+    radix select over the histograms, item-item branch with the summed-gradient identity) against the single-process
+    FREEDOM on the same weights: the same pruned edge set, representation, loss and gradients."""
+    from chaorec_amd import dist as cdist, ops
+    g = load_golden(f"freedom_small_{tag}.npz")
+    m, U, I = _make_freedom(g, dev)
+    sh = cdist.ShardedFREEDOM(m, [0, U], 1, 0, dev)
+    m.pre_epoch_processing()
+    sh.pre_epoch_processing()
+    if m.dropout > 0:
+        # the keys-only entry numbers entries by `ids`: a shuffled share of the list gets the whole list's keys
+        w = m.edge_values
+        _, keys = ops.weighted_sample_keep(w, 5, seed=3, step=2, return_keys=True)
+        perm = torch.randperm(w.numel(), device=dev)
+        assert torch.equal(ops.weighted_sample_keys(w[perm], perm, seed=3, step=2), keys[perm])
+        assert torch.equal(ops.weighted_sample_keys(w, None, seed=3, step=2), keys)
+        # k-th smallest by histograms == by sorting
+        k = int(w.numel() * 0.7)
+        assert cdist.global_kth_smallest(keys, k) == int(torch.sort(keys[keys >= 0]).values[k - 1])
+        assert sh.shard.nnz * 2 == m.masked_adj.nnz
+    batch = tuple(torch.from_numpy(g[k]).to(dev) for k in ("users", "pos", "neg"))
+    loss = m.loss(*batch)
+    loss.backward()
+    sh.zero_grad()
+    ls = sh.loss(batch[0], batch[1] - U, batch[2] - U)
+    ls.backward()
+    sh.sync_grads()
+    assert float(ls.detach()) == pytest.approx(float(loss.detach()), rel=1e-5)
+    assert torch.allclose(sh.result, m.result, rtol=1e-5, atol=1e-7)
+    for n, p in m.named_parameters():
+        q = dict(sh.named_parameters())[n]
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((q.grad - p.grad).abs().max()) <= 2e-4 * scale + 1e-9, n
+    assert torch.equal(sh.gene_ranklist(topk=10), m.gene_ranklist(topk=10))
