@@ -364,9 +364,9 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
 
     # --- full-rank evaluation ---------------------------------------------------------------------------------
     # Two states of the same call.  COLD: no thresholds carried (the first evaluation of a run): sampled thresholds.
-    # STEADY: the evaluation loop's state (train_and_evaluate.py:655-659 ranks once per epoch): per-user thresholds
-    # carried from the evaluation one epoch (E // B steps) EARLIER, light mode as ranking.RankState decides it from the
-    # previous call's queue lengths.  Every timed repetition starts from the same epoch-old thresholds (a copy is put
+    # STEADY: the evaluation loop's state (train_and_evaluate.py:655-659 ranks once per epoch) from its third evaluation
+    # on: per-user thresholds left by the evaluation one epoch (E // B steps) EARLIER, which itself ran on carried
+    # thresholds; light mode as ranking.RankState decides it from the previous call's queue lengths.  Every timed repetition starts from the same epoch-old thresholds (a copy is put
     # back first; its 116 KB device copy is inside the timed region).
     epoch_steps = max(E // B, 1)
 
@@ -392,15 +392,18 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             if with_steady:
                 hint_rank = 100                              # (ranking.gene_ranklist: 2 K)
                 old = torch.empty(U, dtype=torch.float32, device=dev)
+                counters = torch.zeros(4, dtype=torch.int32, device=dev)
                 ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=False, hint_rank=hint_rank)
-                run_steps(epoch_steps)                       # one epoch of training between the two evaluations
+                run_steps(epoch_steps)                       # one epoch of training between two evaluations
+                res = model.result.detach()
+                ops.score_topk(res[:U], res[U:U + I], model.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=True,
+                               hint_rank=hint_rank, counters=counters)   # `old` now: thresholds left by a CARRIED evaluation
+                queues_prev = counters.tolist()
+                run_steps(epoch_steps)
                 res = model.result.detach()
                 ue, ie = res[:U], res[U:U + I]
-                hint, counters = old.clone(), torch.zeros(4, dtype=torch.int32, device=dev)
-                ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, hint_rank=hint_rank,
-                               counters=counters)
-                queues = counters.tolist()
-                light = queues[0] <= 16                      # (ranking.RankState.LIGHT_BELOW)
+                hint = old.clone()
+                light = queues_prev[0] <= 16                 # (ranking.RankState.LIGHT_BELOW, the previous call's queue)
 
                 def steady():
                     hint.copy_(old)
@@ -426,12 +429,12 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
 
     steps_done = warmup + steps
     early = time_ranklist(False)
-    extra = trained_steps - steps_done - epoch_steps
-    if extra > 0 and (extra + epoch_steps) * ms_per_step < 10_000:
+    extra = trained_steps - steps_done - 2 * epoch_steps
+    if extra > 0 and (extra + 2 * epoch_steps) * ms_per_step < 10_000:
         run_steps(extra)
         rk = time_ranklist(True)
-        state = (f"after {trained_steps} training steps ({extra + epoch_steps} of them untimed, past the measured ones); steady "
-                 f"= thresholds carried from the evaluation {epoch_steps} steps (one epoch) earlier")
+        state = (f"after {trained_steps} training steps ({extra + 2 * epoch_steps} of them untimed, past the measured ones); "
+                 f"steady = thresholds carried from the (carried-threshold) evaluation {epoch_steps} steps (one epoch) earlier")
     else:
         # (no trained state within the run's budget -- an epoch of the config-5 shard is 24 k steps --: the cold call
         #  only; thresholds carried across the first steps of training are stale by construction, ranking.RankState

@@ -679,6 +679,63 @@ __device__ __forceinline__ float exact_score(const float *__restrict__ urow, con
   return acc;
 }
 
+// Exact scores of 64 CONSECUTIVE items [i0, i0 + 64) of one user, lane j -> item i0 + j (items >= n_items: garbage,
+// rows clamped into the table), fetched by the wave together: 4 lanes per row, 64 consecutive bytes per instruction
+// and group -- whole sectors, 16 rows per instruction.  With a lane per row every load instruction asks for 64
+// different sectors and uses 16 bytes of each; a 1024-thread block of the exact route then spends ~35 us waiting for
+// its 2048 rows, the rest of its work ~10.  Lane l of a group holds floats [16 t + 4 l, 16 t + 4 l + 4) of both row
+// halves (ua, ub: the user's), the operands of chain steps 32 t + 8 l .. + 7; the accumulator walks round the
+// group's lanes D/32 times in the k-ascending order of the f32 MFMA kernel, every lane running every segment.
+__device__ __forceinline__ float dpp_quad_rot(float v) {   // lane i <- lane (i - 1) % 4 of its quad
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93 /* quad_perm:[3,0,1,2] */, 0xF, 0xF, false));
+}
+template <int D>
+__device__ __forceinline__ float exact_scores_64(const float *__restrict__ item_emb, int64_t i0, int64_t n_items,
+                                                 const float (&ua)[D / 8], const float (&ub)[D / 8], int lane) {
+  constexpr int G = 4, CPI = 16, SEG = D / 8;
+  const int l = lane % G, g = lane / G;
+  auto load_rows = [&](float (&a)[SEG], float (&b)[SEG], int pass) __attribute__((always_inline)) {
+    const int64_t item = min(i0 + pass * CPI + g, n_items - 1);
+    const float *row = item_emb + (size_t)item * D + 4 * l;
+#pragma unroll
+    for (int i = 0; i < SEG; i += 4) {
+      const float4 x = reinterpret_cast<const float4 *>(row + 4 * i)[0];
+      const float4 y = reinterpret_cast<const float4 *>(row + D / 2 + 4 * i)[0];
+      a[i] = x.x, a[i + 1] = x.y, a[i + 2] = x.z, a[i + 3] = x.w;
+      b[i] = y.x, b[i + 1] = y.y, b[i + 2] = y.z, b[i + 3] = y.w;
+    }
+  };
+  float sc = 0.f;
+  float a[SEG], b[SEG];
+  load_rows(a, b, 0);
+#pragma unroll
+  for (int it = 0; it < G; ++it) {     // pass `it`: items i0 + it * 16 + g
+    float ca[SEG], cb[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) ca[i] = a[i], cb[i] = b[i];
+    if (it + 1 < G) load_rows(a, b, it + 1);
+    float acc = 0.f;
+#pragma unroll
+    for (int seg = 0; seg < SEG; ++seg) {
+      float t = acc;
+#pragma unroll
+      for (int i = 4 * (seg / G); i < 4 * (seg / G) + 4; ++i) {
+        t = __fmaf_rn(ua[i], ca[i], t);
+        t = __fmaf_rn(ub[i], cb[i], t);
+      }
+      if (l == seg % G) acc = t;
+      if (seg + 1 < SEG) {
+        const float nx = dpp_quad_rot(acc);
+        if (l == (seg + 1) % G) acc = nx;
+      }
+    }
+    // the group's last lane holds the score of item i0 + it * 16 + g: route it to lane it * 16 + g
+    const float moved = __shfl(acc, (lane % CPI) * G + G - 1, 64);
+    if (lane / CPI == it) sc = moved;
+  }
+  return sc;
+}
+
 // The `rank`-th largest 64-bit key (keys unique, 0 = none; at least `rank` non-zero keys): bitwise search with wave
 // ballots and scalar popcounts, 32 steps on the score word, up to 32 more on the index word when a tie straddles the rank.
 template <int NR>
@@ -1171,24 +1228,34 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
     __syncthreads();
     // this block's contiguous slice of the items, kExThreads * kExPer per round; every wave keeps its own K best
     const int64_t i_begin = (int64_t)slice * per_slice, i_end = min(P.n_items, i_begin + per_slice);
+    // this lane's pieces of the user's row (exact_scores_64)
+    float ua[D / 8], ub[D / 8];
+#pragma unroll
+    for (int i = 0; i < D / 8; ++i) {
+      ua[i] = urow[16 * (i / 4) + 4 * (lane & 3) + (i & 3)];
+      ub[i] = urow[D / 2 + 16 * (i / 4) + 4 * (lane & 3) + (i & 3)];
+    }
     uint64_t bk = 0ull;
     for (int64_t c0 = i_begin; c0 < i_end; c0 += (int64_t)kExThreads * kExPer) {
       uint64_t key[kExPer];
 #pragma unroll
       for (int j = 0; j < kExPer; ++j) {
-        const int64_t it = c0 + tid + (int64_t)kExThreads * j;
+        const int64_t it0 = c0 + 64 * wave + (int64_t)kExThreads * j;      // the wave's 64 consecutive items
+        const int64_t it = it0 + lane;
         key[j] = 0ull;
-        if (it < i_end) {
-          const uint32_t item = (uint32_t)it;
-          int lo = 0, hi = deg;
-          while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const uint32_t hv = hist_lds ? hist_s[mid] : (uint32_t)P.hist_col[hb + mid];
-            if (hv < item) lo = mid + 1; else hi = mid;
+        if (it0 < i_end) {                                                 // wave-uniform
+          const float sx = exact_scores_64<D>(P.item_emb, it0, P.n_items, ua, ub, lane);
+          if (it < i_end) {
+            const uint32_t item = (uint32_t)it;
+            int lo = 0, hi = deg;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              const uint32_t hv = hist_lds ? hist_s[mid] : (uint32_t)P.hist_col[hb + mid];
+              if (hv < item) lo = mid + 1; else hi = mid;
+            }
+            const bool masked = lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
+            key[j] = make_key(masked ? P.mask_value : sx, item);
           }
-          const bool masked = lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
-          const float sv = masked ? P.mask_value : exact_score<D>(urow, P.item_emb + (size_t)item * D);
-          key[j] = make_key(sv, item);
         }
       }
       bk = wave_select_topk<kExPer>(key, bk, kMaxK, stage[wave]);   // (the 64 best: the next call's threshold wants more than K)
