@@ -1191,6 +1191,20 @@ __device__ __forceinline__ uint64_t wave_select_topk(const uint64_t (&key)[NK], 
   return out;
 }
 
+// a: 64 keys in descending order, b: 64 keys in descending order (one per lane, 0 = none) -> the 64 largest of
+// both, descending: b reversed against a gives a bitonic sequence of the lane-wise maxima, six merge stages order it.
+__device__ __forceinline__ uint64_t merge_top64(uint64_t a, uint64_t b, int lane) {
+  const uint64_t r = shfl_u64(b, 63 - lane);
+  uint64_t m = a > r ? a : r;
+#pragma unroll
+  for (int j = 32; j > 0; j >>= 1) {
+    const uint64_t p = shfl_xor_u64(m, j);
+    const uint64_t mx = m > p ? m : p, mn = m > p ? p : m;
+    m = (lane & j) == 0 ? mx : mn;
+  }
+  return m;
+}
+
 template <int D>
 __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const PrefArgs P) {
   constexpr int NW = kExThreads / 64;
@@ -1260,28 +1274,32 @@ __global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const Pref
       }
       bk = wave_select_topk<kExPer>(key, bk, kMaxK, stage[wave]);   // (the 64 best: the next call's threshold wants more than K)
     }
-    // block merge: the NW wave lists -> wave 0 (NW keys per lane)
+    // block merge: every wave orders its 64 best, then a tree of pairwise merges through LDS (log2 NW levels of one
+    // reverse + six stages each).  One wave picking the 64 best of all NW lists by a bitwise search (32 steps x NW + 1
+    // ballots) was 20 of the route's 48 us.
+    sort64_desc(bk, lane);
     stage[wave][lane] = bk;
     __syncthreads();
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+      uint64_t mine = 0ull;
+      if (wave < half) mine = merge_top64(stage[wave][lane], stage[wave + half][lane], lane);
+      __syncthreads();
+      if (wave < half) stage[wave][lane] = mine;
+      __syncthreads();
+    }
     uint64_t *part = P.fb_partial + (size_t)qi * kExSlices * kMaxK;
     if (wave == 0) {
-      uint64_t mk[NW];
-#pragma unroll
-      for (int j = 0; j < NW; ++j) mk[j] = stage[j][lane];
-      __builtin_amdgcn_wave_barrier();
-      const uint64_t bb = wave_select_topk<NW>(mk, 0ull, kMaxK, stage[0]);
-      part[slice * kMaxK + lane] = bb;   // kMaxK == 64
+      part[slice * kMaxK + lane] = stage[0][lane];   // kMaxK == 64; descending
       __threadfence();
       if (lane == 0) last = atomicAdd(P.fb_done + qi, 1) == kExSlices - 1 ? 1 : 0;
     }
     __syncthreads();
     if (last && wave == 0) {   // the last slice to arrive merges the user's kExSlices lists
       __threadfence();
-      uint64_t mk[kExSlices];
+      uint64_t e = __builtin_nontemporal_load(part + lane);      // the slices' lists are in descending order
 #pragma unroll
-      for (int j = 0; j < kExSlices; ++j) mk[j] = __builtin_nontemporal_load(part + j * kMaxK + lane);
-      uint64_t e = wave_select_topk<kExSlices>(mk, 0ull, kMaxK, stage[0]);
-      sort64_desc(e, lane);
+      for (int j = 1; j < kExSlices; ++j) e = merge_top64(e, __builtin_nontemporal_load(part + j * kMaxK + lane), lane);
       if (lane < K) {
         const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull);
         P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;
