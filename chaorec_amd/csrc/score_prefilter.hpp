@@ -787,34 +787,224 @@ __device__ __forceinline__ void sort64_desc(uint64_t &e, int lane) {
 constexpr int kPfHistLds = 1024;            // longest history the exact per-user route keeps in LDS
 constexpr int kPfSelHist = 128;             // ... and the selection (longer histories are searched in global memory)
 
-// reason codes (non-zero = not certified): 1 a sweep list overflowed, 2 fewer than K candidates, 3 more candidates
-// than the selection holds, 4 the K-th best exact score does not clear the sweep threshold
-//
-// The exact re-score is where the selection's time goes, and what it costs is ADDRESSES, not bytes or flops: a lane
-// that loads its own candidate's row puts 64 different cache lines into every load instruction, and the CU's address
-// path retires about one line per clock -- measured ~90 us per round of 64 candidates over sports' 28 940 users,
-// whatever the register budget.  So a row is fetched by G = 4 lanes per candidate (16 candidates per load
-// instruction), lane l of a group holding floats [S l, S l + S) and [D/2 + S l, D/2 + S l + S) of the row, S = D/8
-// -- exactly the operands of chain steps 2 S l .. 2 S l + 2 S - 1 (the chain alternates between the two halves of the
-// row).  The chain itself stays sequential: the accumulator walks through the group's lanes, one DPP move per 2 S
-// fmas, every lane executing every segment (the result of the lane whose turn it is is kept).  G x the fmas of a
-// lane-per-candidate chain, no LDS traffic, and 4 x fewer, line-sized addresses.
-// (Tried: lane-per-candidate loads with the whole row in flight -- address-bound, as said; rows through an LDS tile
-//  walked by 16 lanes -- LDS-bound.)
-template <int D>
+// The selection is bound by instruction issue (profiles/r02_c_score_pmc.txt: its VALU pipes are busy for the whole
+// kernel), so everything below is written for few instructions per user:
+//  * prefix sums and owner look-ups are DPP scans (6 instructions), not shuffles through LDS or binary searches;
+//  * the exact re-score fetches rows by 4 lanes per candidate and keeps the next rows in flight under the chain;
+//  * the ranking is a bitonic network with the per-stage lane masks as scalar constants: compare, two selects.
+
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ int dpp_or0(int v) {   // lanes without a source (or outside ROW_MASK) read 0
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, BOUND);
+}
+// inclusive scans over the 64 lanes: shifts by 1, 2, 4, 8 inside the rows of 16, then lane 15 of row 0 / 2 into
+// row 1 / 3 and lane 31 into rows 2 and 3
+__device__ __forceinline__ int wave_scan_add(int x) {
+  x += dpp_or0<0x111, 0xF, true>(x);
+  x += dpp_or0<0x112, 0xF, true>(x);
+  x += dpp_or0<0x114, 0xF, true>(x);
+  x += dpp_or0<0x118, 0xF, true>(x);
+  x += dpp_or0<0x142, 0xA, false>(x);
+  x += dpp_or0<0x143, 0xC, false>(x);
+  return x;
+}
+__device__ __forceinline__ int wave_scan_max(int x) {   // x >= 0
+  x = max(x, dpp_or0<0x111, 0xF, true>(x));
+  x = max(x, dpp_or0<0x112, 0xF, true>(x));
+  x = max(x, dpp_or0<0x114, 0xF, true>(x));
+  x = max(x, dpp_or0<0x118, 0xF, true>(x));
+  x = max(x, dpp_or0<0x142, 0xA, false>(x));
+  x = max(x, dpp_or0<0x143, 0xC, false>(x));
+  return x;
+}
 __device__ __forceinline__ float dpp_prev_lane(float v) {   // lane i <- lane i - 1 (within its row of 16 lanes)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
 }
 
+// ---- bitonic networks over one key per lane, lane masks as scalar constants ---------------------------------------
+__device__ __forceinline__ uint32_t lane_select(uint32_t a, uint32_t b, uint64_t m) {   // bit of the lane set in m ? b : a
+  uint32_t r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+  return r;
+}
+__device__ __forceinline__ uint64_t lane_select64(uint64_t a, uint64_t b, uint64_t m) {
+  return ((uint64_t)lane_select((uint32_t)(a >> 32), (uint32_t)(b >> 32), m) << 32) | lane_select((uint32_t)a, (uint32_t)b, m);
+}
+struct PermAddr {   // byte addresses of ds_bpermute: lane ^ 1, 2, 4, 8, 16, 32 and 63 - lane
+  int x0, x1, x2, x3, x4, x5, rev;
+  template <int I>
+  __device__ __forceinline__ int x() const {
+    if constexpr (I == 0) return x0;
+    else if constexpr (I == 1) return x1;
+    else if constexpr (I == 2) return x2;
+    else if constexpr (I == 3) return x3;
+    else if constexpr (I == 4) return x4;
+    else return x5;
+  }
+};
+__device__ __forceinline__ PermAddr perm_addr(int lane) {
+  PermAddr a;
+  a.x0 = (lane ^ 1) << 2, a.x1 = (lane ^ 2) << 2, a.x2 = (lane ^ 4) << 2, a.x3 = (lane ^ 8) << 2;
+  a.x4 = (lane ^ 16) << 2, a.x5 = (lane ^ 32) << 2, a.rev = (63 - lane) << 2;
+  return a;
+}
+__device__ __forceinline__ uint64_t permute64(uint64_t v, int addr) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// lanes of `keepmax` keep the larger of (e, p), the others the smaller: one compare, one scalar xnor, two selects
+__device__ __forceinline__ void compare_exchange(uint64_t &e, uint64_t p, uint64_t keepmax) {
+  const uint64_t gt = __ballot(p > e);
+  e = lane_select64(e, p, ~(gt ^ keepmax));
+}
+constexpr uint64_t keepmax_mask(int k, int j, bool all_desc) {   // stage (k, j) of a descending bitonic sort
+  uint64_t m = 0;
+  for (int lane = 0; lane < 64; ++lane) {
+    const bool lower = (lane & j) == 0, desc = all_desc || (lane & k) == 0;
+    if (lower == desc) m |= 1ull << lane;
+  }
+  return m;
+}
+template <int LOGJ>
+__device__ __forceinline__ void merge_stages(uint64_t &e, const PermAddr &pa) {   // bitonic -> descending, strides 2^LOGJ .. 1
+  compare_exchange(e, permute64(e, pa.template x<LOGJ>()), keepmax_mask(64, 1 << LOGJ, true));
+  if constexpr (LOGJ > 0) merge_stages<LOGJ - 1>(e, pa);
+}
+template <int LOGK, int LOGJ>
+__device__ __forceinline__ void sort_stages(uint64_t &e, const PermAddr &pa) {
+  compare_exchange(e, permute64(e, pa.template x<LOGJ>()), keepmax_mask(1 << LOGK, 1 << LOGJ, LOGK == 6));
+  if constexpr (LOGJ > 0) sort_stages<LOGK, LOGJ - 1>(e, pa);
+  else if constexpr (LOGK < 6) sort_stages<LOGK + 1, LOGK>(e, pa);
+}
+__device__ __forceinline__ void sort64_keys(uint64_t &e, const PermAddr &pa) { sort_stages<1, 0>(e, pa); }   // descending
+// two descending registers -> the 128 keys in descending order over (e0, e1)
+__device__ __forceinline__ void merge128_keys(uint64_t &e0, uint64_t &e1, const PermAddr &pa) {
+  const uint64_t r = permute64(e1, pa.rev);
+  const uint64_t gt = __ballot(r > e0);
+  const uint64_t hi = lane_select64(e0, r, gt), lo = lane_select64(r, e0, gt);
+  e0 = hi;
+  e1 = lo;
+  merge_stages<5>(e0, pa);
+  merge_stages<5>(e1, pa);
+}
+// 64 more keys (any order) into the descending top-128 (e0, e1); what falls out of the 128 is dropped
+__device__ __forceinline__ void merge_block_keys(uint64_t &e0, uint64_t &e1, uint64_t b, const PermAddr &pa) {
+  sort64_keys(b, pa);
+  const uint64_t r = permute64(b, pa.rev);
+  e1 = lane_select64(e1, r, __ballot(r > e1));   // descending vs ascending: the lane-wise maxima are the 64 largest, bitonic
+  merge_stages<5>(e1, pa);
+  merge128_keys(e0, e1, pa);
+}
+
+// 64 more keys (0 = none) into the descending top-128 (e0, e1); `blocks` = how many were taken before
+__device__ __forceinline__ void take_block_keys(uint64_t &e0, uint64_t &e1, int &blocks, uint64_t cur, const PermAddr &pa) {
+  if (blocks == 0) {
+    sort64_keys(cur, pa);
+    e0 = cur;
+  } else if (blocks == 1) {
+    sort64_keys(cur, pa);
+    uint64_t a = e0, b = cur;
+    merge128_keys(a, b, pa);
+    e0 = a, e1 = b;
+  } else {
+    uint64_t a = e0, b = e1;
+    merge_block_keys(a, b, cur, pa);
+    e0 = a, e1 = b;
+  }
+  ++blocks;
+}
+__device__ __forceinline__ uint64_t key_of_rank(uint64_t e0, uint64_t e1, int rank) {   // rank < 128, wave-uniform
+  const uint32_t lo0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e0, rank & 63);
+  const uint32_t hi0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e0 >> 32), rank & 63);
+  const uint32_t lo1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e1, rank & 63);
+  const uint32_t hi1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e1 >> 32), rank & 63);
+  return rank < 64 ? (((uint64_t)hi0 << 32) | lo0) : (((uint64_t)hi1 << 32) | lo1);
+}
+
+// Exact scores of the 64 candidates cand_s[base .. base + 64) (lane j -> candidate base + j; beyond n_cand: 0).
+// What the re-score costs is ADDRESSES as much as flops: a lane that loads its own candidate's row puts 64 different
+// cache lines into every load instruction, and the CU's address path retires about one line per clock.  So a row is
+// fetched by G = 4 lanes per candidate (16 candidates per load instruction), lane l of a group holding floats
+// [S l, S l + S) and [D/2 + S l, D/2 + S l + S) of the row, S = D/8 -- the operands of chain steps 2 S l .. 2 S l + 2 S - 1
+// (the chain of the f32 MFMA kernel alternates between the two halves of the row; ua, ub: the user's).  The chain stays
+// sequential: the accumulator walks through the group's lanes, one DPP move per 2 S fmas, every lane executing every
+// segment (the result of the lane whose turn it is is kept); the next 16 candidates' rows fly under it.
+// (Tried, each bit-exact: a pipeline in which every lane's fma is a useful one, 4 lanes per row and 8 lanes per row
+//  with whole-line fetches, 2 to 12 row pieces in flight per lane: 112 and 170 us for this stage against 44 us.)
+template <int D>
+__device__ __forceinline__ float chain_block(const float *__restrict__ item_emb, const uint32_t *cand_s, int base, int n_cand,
+                                             const float (&ua)[D / 8], const float (&ub)[D / 8], int lane) {
+  constexpr int G = 4, CPI = 64 / G, SEG = D / (2 * G);
+  const int l = lane % G, g = lane / G;
+  auto load_rows = [&](float (&a)[SEG], float (&b)[SEG], int c) __attribute__((always_inline)) {
+    const float *row = item_emb + (size_t)cand_s[c] * D;
+#pragma unroll
+    for (int i = 0; i < SEG; i += 4) {
+      const float4 x = reinterpret_cast<const float4 *>(row + SEG * l)[i / 4];
+      const float4 y = reinterpret_cast<const float4 *>(row + D / 2 + SEG * l)[i / 4];
+      a[i] = x.x, a[i + 1] = x.y, a[i + 2] = x.z, a[i + 3] = x.w;
+      b[i] = y.x, b[i + 1] = y.y, b[i + 2] = y.z, b[i + 3] = y.w;
+    }
+  };
+  float sc = 0.f;
+  float a[SEG], b[SEG];
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) a[i] = b[i] = 0.f;
+  if (base + g < n_cand) load_rows(a, b, base + g);
+  for (int it = 0; it < G; ++it) {     // pass `it`: candidates base + it * CPI + g
+    if (base + it * CPI >= n_cand) break;                      // wave-uniform
+    float ca[SEG], cb[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) ca[i] = a[i], cb[i] = b[i];
+    const int cn = base + (it + 1) * CPI + g;                  // next pass's rows fly under this pass's chain
+    if (it + 1 < G && cn < n_cand) load_rows(a, b, cn);
+    float acc = 0.f;
+#pragma unroll
+    for (int seg = 0; seg < G; ++seg) {
+      float t = acc;
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        t = __fmaf_rn(ua[i], ca[i], t);
+        t = __fmaf_rn(ub[i], cb[i], t);
+      }
+      if (l == seg) acc = t;
+      if (seg + 1 < G) {
+        const float nx = dpp_prev_lane(acc);
+        if (l == seg + 1) acc = nx;
+      }
+    }
+    // the group's last lane holds the score of candidate base + it * CPI + g: route it to lane it * CPI + g
+    const float moved = __shfl(acc, (lane % CPI) * G + G - 1, 64);
+    if (lane / CPI == it) sc = moved;
+  }
+  return sc;
+}
+
+// reason codes (non-zero = not certified): 1 a sweep list overflowed, 2 fewer than K candidates, 3 more candidates
+// than the selection holds, 4 the K-th best exact score does not clear the sweep threshold
 template <int D, int MAXC>
-__device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, int *incl_s, uint32_t *cand_s,
-                                            uint32_t *hist_s, float *urow_s) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, int lane, int2 *meta_s, uint32_t *cand_s,
+                                            uint32_t *hist_s, float *score_s) {
   const int K = P.K;
   const int n_lists = 2 * P.splits;  // <= 32
+  const PermAddr pa = perm_addr(lane);
 
+  // this lane's list of the sweep: (split lane / 2, half lane & 1)
+  const int listidx = (int)(((int64_t)(lane >> 1) * P.n_users + u) * 2 + (lane & 1));
   int c = 0;
-  if (lane < n_lists) c = P.cand_cnt[((size_t)(lane >> 1) * P.n_users + u) * 2 + (lane & 1)];
+  if (lane < n_lists) c = P.cand_cnt[listidx];
+  // this lane's segments of the user's row (chain_block)
+  float ua[D / 8], ub[D / 8];
+  {
+    const float *urow = P.user_emb + (size_t)u * D + (D / 8) * (lane & 3);
+#pragma unroll
+    for (int i = 0; i < D / 8; i += 4) {
+      const float4 x = reinterpret_cast<const float4 *>(urow)[i / 4], y = reinterpret_cast<const float4 *>(urow + D / 2)[i / 4];
+      ua[i] = x.x, ua[i + 1] = x.y, ua[i + 2] = x.z, ua[i + 3] = x.w;
+      ub[i] = y.x, ub[i + 1] = y.y, ub[i + 2] = y.z, ub[i + 3] = y.w;
+    }
+  }
   int64_t hb = 0, he = 0;
   if (P.hist_rowptr) {
     hb = P.hist_rowptr[u];
@@ -824,62 +1014,65 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
   const bool hist_lds = deg <= kPfSelHist;
   const float theta = P.theta[u];
   const bool overflow = __any(c > kPfCap);
-  int incl = c;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  const int total = __shfl(incl, 63, 64);          // entries (each holds >= 1 candidate)
+  const int incl = wave_scan_add(c);
+  const int total = __builtin_amdgcn_readlane(incl, 63);   // entries (each holds >= 1 candidate)
   int why = overflow ? 1 : (total > MAXC ? 3 : 0);
   int n_cand = 0;
   if (why == 0) {
-    incl_s[lane] = incl;
-    if (hist_lds)
+    // entry e of the concatenated lists belongs to the last list that starts at or before it: the lists mark their
+    // first entry with their number + 1, a running maximum over the entries spreads it
+    int *owner_s = reinterpret_cast<int *>(score_s);
+#pragma unroll 1
+    for (int i = lane; i < total; i += 64) owner_s[i] = 0;
+    meta_s[lane] = make_int2(incl - c, listidx);
+    if (hist_lds) {
+#pragma unroll 1
       for (int i = lane; i < deg; i += 64) hist_s[i] = (uint32_t)P.hist_col[hb + i];
-    for (int i = lane; i < D; i += 64) urow_s[i] = P.user_emb[(size_t)u * D + i];
+    }
     __builtin_amdgcn_wave_barrier();
-    // entries -> item ids, in list order: entry e sits in list l = first list with incl[l] > e
+    if (c > 0) owner_s[incl - c] = lane + 1;
+    __builtin_amdgcn_wave_barrier();
+    int owner_carry = 0;
+#pragma unroll 1
     for (int base = 0; base < total; base += 64) {
       const int e = base + lane;
+      int own = e < total ? owner_s[e] : 0;
+      own = max(wave_scan_max(own), owner_carry);
+      owner_carry = __builtin_amdgcn_readlane(own, 63);
       uint32_t bits = 0, j0 = 0;
       if (e < total) {
-        int lo = 0, hi = 63;
-#pragma unroll
-        for (int st = 0; st < 6; ++st) {
-          const int mid = (lo + hi) >> 1;
-          if (incl_s[mid] > e) hi = mid; else lo = mid + 1;
-        }
-        const int pos = e - (lo ? incl_s[lo - 1] : 0);
-        const uint32_t raw = P.cand[(((size_t)(lo >> 1) * P.n_users + u) * 2 + (lo & 1)) * kPfCap + pos];
+        const int list = own - 1;
+        const int2 m = meta_s[list];
+        const uint32_t raw = P.cand[(size_t)m.y * kPfCap + (e - m.x)];
         bits = raw & 0xFFFFu;
-        j0 = ((uint32_t)(lo >> 1) + (raw >> 16) * (uint32_t)P.splits) * 32u + 4u * (uint32_t)(lo & 1);
+        j0 = ((uint32_t)(list >> 1) + (raw >> 16) * (uint32_t)P.splits) * 32u + 4u * (uint32_t)(list & 1);
       }
-      int pc = __popc(bits), ex = pc;
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(ex, o, 64);
-        if (lane >= o) ex += v;
-      }
-      const int tot = __shfl(ex, 63, 64);
+      const int pc = __popc(bits);
+      const int ex = wave_scan_add(pc);
       int slot = n_cand + ex - pc;
-      while (bits) {
-        const int bit = 31 - __clz(bits);
-        bits &= ~(1u << bit);
-        const int reg = 15 - bit;
-        if (slot < MAXC) cand_s[slot] = j0 + (uint32_t)((reg & 3) + 8 * (reg >> 2));
-        ++slot;
+#pragma unroll 1
+      while (__any(bits != 0u)) {
+        if (bits) {
+          const int bit = 31 - __clz(bits);
+          bits &= ~(1u << bit);
+          const int reg = 15 - bit;
+          if (slot < MAXC) cand_s[slot] = j0 + (uint32_t)((reg & 3) + 8 * (reg >> 2));
+          ++slot;
+        }
       }
-      n_cand += tot;
+      n_cand += __builtin_amdgcn_readlane(ex, 63);
     }
     if (n_cand > MAXC) why = 3;
+    __builtin_amdgcn_wave_barrier();
   }
 #if defined(CHAOREC_SEL_EXP) && CHAOREC_SEL_EXP == 5
-  if (lane == 0) P.n_cand[u] = n_cand;            // (experiment: expansion only)
-  return;
+  if (P.hint_rank >= 1000) {
+    if (lane == 0) P.n_cand[u] = n_cand;            // (experiment: expansion only)
+    return;
+  }
 #endif
-  uint64_t e0 = 0ull;
-  bool written_by_rank = false;
+  uint64_t e0 = 0ull, e1 = 0ull;      // the 128 best keys, descending over (e0, e1)
   if (why == 0) {
-    __builtin_amdgcn_wave_barrier();
     auto in_hist = [&](uint32_t item) -> bool {
       int lo = 0, hi = deg;
       while (lo < hi) {
@@ -890,194 +1083,64 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
       return lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
     };
     const uint32_t mord = f32_to_ord(P.mask_value);
-    constexpr int NR = MAXC / 64;          // key registers per lane
-    constexpr int G = 4;                   // lanes per candidate
-    constexpr int CPI = 64 / G;            // candidates per chain pass
-    constexpr int SEG = D / (2 * G);       // floats of each half of the row per lane (8 at D = 64, 16 at D = 128)
-    const int l = lane % G, g = lane / G;
-    // this lane's operands of the user's row, for the whole selection
-    float ua[SEG], ub[SEG];
-#pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-      ua[i] = urow_s[SEG * l + i];
-      ub[i] = urow_s[D / 2 + SEG * l + i];
-    }
-    uint64_t k[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) k[r] = 0ull;
     int valid = 0, above = 0, blocks = 0;
-    auto load_rows = [&](float (&a)[SEG], float (&b)[SEG], int c) __attribute__((always_inline)) {
-      const float *row = P.item_emb + (size_t)cand_s[c] * D;
-#pragma unroll
-      for (int i = 0; i < SEG; i += 4) {
-        const float4 x = reinterpret_cast<const float4 *>(row + SEG * l)[i / 4];
-        const float4 y = reinterpret_cast<const float4 *>(row + D / 2 + SEG * l)[i / 4];
-        a[i] = x.x, a[i + 1] = x.y, a[i + 2] = x.z, a[i + 3] = x.w;
-        b[i] = y.x, b[i + 1] = y.y, b[i + 2] = y.z, b[i + 3] = y.w;
-      }
-    };
+#pragma unroll 1
     for (int base = 0; base < n_cand; base += 64) {
-      float sc = 0.f;                      // lane j: exact score of candidate base + j
-      float a[SEG], b[SEG];
-#pragma unroll
-      for (int i = 0; i < SEG; ++i) a[i] = b[i] = 0.f;
-      if (base + g < n_cand) load_rows(a, b, base + g);
-      for (int it = 0; it < G; ++it) {     // pass `it`: candidates base + it * CPI + g
-        if (base + it * CPI >= n_cand) break;                      // wave-uniform
-        float ca[SEG], cb[SEG];
-#pragma unroll
-        for (int i = 0; i < SEG; ++i) ca[i] = a[i], cb[i] = b[i];
-        const int cn = base + (it + 1) * CPI + g;                  // next pass's rows fly under this pass's chain
-        if (it + 1 < G && cn < n_cand) load_rows(a, b, cn);
-        float acc = 0.f;
-#pragma unroll
-        for (int seg = 0; seg < G; ++seg) {
-          float t = acc;
-#pragma unroll
-          for (int i = 0; i < SEG; ++i) {
-            t = __fmaf_rn(ua[i], ca[i], t);
-            t = __fmaf_rn(ub[i], cb[i], t);
-          }
-          if (l == seg) acc = t;
-          if (seg + 1 < G) {
-            const float nx = dpp_prev_lane<D>(acc);
-            if (l == seg + 1) acc = nx;
-          }
-        }
-        // the group's last lane holds the score of candidate base + it * CPI + g: route it to lane it * CPI + g
-        const float moved = __shfl(acc, (lane % CPI) * G + G - 1, 64);
-        if (lane / CPI == it) sc = moved;
-      }
+      const float sc = chain_block<D>(P.item_emb, cand_s, base, n_cand, ua, ub, lane);
       const int idx = base + lane;
       uint64_t cur = 0ull;
       if (idx < n_cand) {
         const uint32_t item = cand_s[idx];
         // (a history member leaves the candidates: the sweep ran unmasked)
-        if (!in_hist(item)) cur = make_key(sc, item);
+        if (deg == 0 || !in_hist(item)) cur = make_key(sc, item);
       }
       valid += __popcll(__ballot(cur != 0ull));
       above += __popcll(__ballot(cur != 0ull && (uint32_t)(cur >> 32) > mord));
-#pragma unroll
-      for (int r = 0; r < NR; ++r)
-        if (r == blocks) k[r] = cur;       // (blocks is wave-uniform)
-      ++blocks;
+      take_block_keys(e0, e1, blocks, cur, pa);
     }
 #if defined(CHAOREC_SEL_EXP) && CHAOREC_SEL_EXP == 6
-    if (lane == 0) P.n_cand[u] = n_cand + (int)(k[0] >> 60) + (int)(k[1] >> 60);   // (experiment: expansion + scores, no ranking)
-    return;
+    if (P.hint_rank >= 1000) {
+      if (lane == 0) P.n_cand[u] = n_cand + (int)(e0 >> 60) + (int)(e1 >> 60);   // (experiment: no history keys, no output)
+      return;
+    }
 #endif
     int n_keys = valid;
     // The masked row restricted to what can matter = the candidates + the user's history at mask_value.  The history
     // only joins when mask_value can reach the top-K (the reference's 1e-6 / 1e-5 does when the real scores are tiny
     // or negative: quirk Q7), i.e. when fewer than K candidates beat it.
     if (deg > 0 && above < K) {   // wave-uniform
-      if (blocks * 64 + deg > MAXC) {
-        why = 3;
-      } else {
-        for (int i0 = 0; i0 < deg; i0 += 64) {
-          const int i = i0 + lane;
-          const uint64_t cur = i < deg ? make_key(P.mask_value, hist_lds ? hist_s[i] : (uint32_t)P.hist_col[hb + i]) : 0ull;
-#pragma unroll
-          for (int r = 0; r < NR; ++r)
-            if (r == blocks) k[r] = cur;
-          ++blocks;
-        }
-        n_keys = valid + deg;
+#pragma unroll 1
+      for (int i0 = 0; i0 < deg; i0 += 64) {
+        const int i = i0 + lane;
+        take_block_keys(e0, e1, blocks, i < deg ? make_key(P.mask_value, hist_lds ? hist_s[i] : (uint32_t)P.hist_col[hb + i]) : 0ull, pa);
       }
+      n_keys = valid + deg;
     }
-    if (why == 0 && n_keys < K) why = 2;
-    bool wrote = false;
-    if (why == 0 && blocks <= 2) {
-      // Up to 128 keys (the steady state with carried thresholds): rank every key by COUNTING the keys above it --
-      // key j is broadcast from its lane (v_readlane), every lane compares it with its own two.  O(n^2) compares, but
-      // no dependent chain at all: a bitonic sort is 21..28 dependent cross-lane stages and a bitwise order-statistic
-      // search 32..64 dependent scalar steps, and it is their LATENCY this kernel was spending its time on.
-      const uint64_t k0 = k[0], k1 = NR > 1 ? k[1] : 0ull;
-      const int n0 = blocks >= 1 ? 64 : 0, n1 = blocks >= 2 ? 64 : 0;
-      uint32_t r0 = 0, r1 = 0;
-      auto lane_key = [&](uint64_t v, int j) -> uint64_t {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), j);
-        return ((uint64_t)hi << 32) | lo;
-      };
-      for (int j = 0; j < n0; ++j) {
-        const uint64_t kj = lane_key(k0, j);
-        r0 += kj > k0 ? 1u : 0u;
-        r1 += kj > k1 ? 1u : 0u;
-      }
-      for (int j = 0; j < n1; ++j) {
-        const uint64_t kj = lane_key(k1, j);
-        r0 += kj > k0 ? 1u : 0u;
-        r1 += kj > k1 ? 1u : 0u;
-      }
-      auto key_of_rank = [&](int rank) -> uint64_t {     // (exists: rank < n_keys; keys are unique)
-        const unsigned long long m0 = __ballot(k0 != 0ull && r0 == (uint32_t)rank);
-        if (m0) return lane_key(k0, __builtin_ctzll(m0));
-        const unsigned long long m1 = __ballot(k1 != 0ull && r1 == (uint32_t)rank);
-        return m1 ? lane_key(k1, __builtin_ctzll(m1)) : 0ull;
-      };
+    if (n_keys < K) why = 2;
+    if (why == 0) {
       // certification: the K-th best exact score must clear the threshold the sweep used
-      const uint64_t kth = key_of_rank(K - 1);
+      const uint64_t kth = key_of_rank(e0, e1, K - 1);   // K <= 64
       if (kth == 0ull || !(ord_to_f32((uint32_t)(kth >> 32)) > theta)) why = 4;
-      if (why == 0) {
-        if (k0 != 0ull && r0 < (uint32_t)K) {
-          P.out_idx[(size_t)u * K + r0] = (int64_t)(0xFFFFFFFFu - (uint32_t)(k0 & 0xFFFFFFFFull)) + P.id_offset;
-          P.out_val[(size_t)u * K + r0] = ord_to_f32((uint32_t)(k0 >> 32));
-        }
-        if (k1 != 0ull && r1 < (uint32_t)K) {
-          P.out_idx[(size_t)u * K + r1] = (int64_t)(0xFFFFFFFFu - (uint32_t)(k1 & 0xFFFFFFFFull)) + P.id_offset;
-          P.out_val[(size_t)u * K + r1] = ord_to_f32((uint32_t)(k1 >> 32));
-        }
-        wrote = true;
-        if (P.hint_out) {
-          // next call's threshold: one float below the exact score of rank `want` (>= K): equal scores stay candidates
-          const int want = max(P.hint_rank, K);
-          const uint64_t hk = key_of_rank(min(want, n_keys) - 1);
-          float t = nextafterf(ord_to_f32((uint32_t)(hk >> 32)), -INFINITY);
-          if (n_keys < want) {
-            // Fewer candidates than the rank the threshold is taken at: the user's scores sank below the carried
-            // threshold since it was set.  The lowest candidate is then (about) that same threshold again, and a user
-            // that keeps sinking ends on the exact route (48 us for the call, however few users take it).  Take the
-            // threshold where rank `want` would be if the scores went on falling as they do between rank K and the
-            // last candidate.  Any value is legal.
-            const float s_k = ord_to_f32((uint32_t)(kth >> 32)), s_last = ord_to_f32((uint32_t)(hk >> 32));
-            const float s_top = ord_to_f32((uint32_t)(key_of_rank(0) >> 32));
-            const float slope = n_keys > K ? (s_k - s_last) / (float)(n_keys - K) : (s_top - s_k) / (float)max(K - 1, 1);
-            t -= slope * (float)(want - n_keys);
-          }
-          if (lane == 0) P.hint_out[u] = t;
-        }
-      }
-    } else if (why == 0) {
-      // many keys: the K best keys (keys are unique: exactly K of them are >= the K-th largest), compacted into one register
-      // through LDS and ordered by one 64-lane sort; the next call's threshold is the exact score of rank `want`
-      const uint64_t thr = (blocks <= 4 && NR >= 4) ? kth_largest_key<(NR >= 4 ? 4 : NR)>(
-                                                           reinterpret_cast<const uint64_t (&)[(NR >= 4 ? 4 : NR)]>(k[0]), K)
-                                                     : kth_largest_key<NR>(k, K);
-      uint64_t *stage = reinterpret_cast<uint64_t *>(cand_s);      // (the candidate ids are all consumed)
-      __builtin_amdgcn_wave_barrier();
-      int base = 0;
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const bool w = r < blocks && k[r] != 0ull && k[r] >= thr;
-        const unsigned long long m = __ballot(w);
-        if (w) stage[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = k[r];
-        base += __popcll(m);
-      }
-      __builtin_amdgcn_wave_barrier();
-      e0 = lane < base ? stage[lane] : 0ull;
-      sort64_desc(e0, lane);
-      if (!(ord_to_f32((uint32_t)(thr >> 32)) > theta)) why = 4;
       if (why == 0 && P.hint_out) {
-        const int want = min(max(P.hint_rank, K), n_keys);
-        const uint64_t hk = want == K ? thr : kth_largest_key<NR>(k, want);
-        if (lane == 0) P.hint_out[u] = nextafterf(ord_to_f32((uint32_t)(hk >> 32)), -INFINITY);
+        // next call's threshold: one float below the exact score of rank `want` (>= K): equal scores stay candidates
+        const int want = min(max(P.hint_rank, K), 128);
+        const uint64_t hk = key_of_rank(e0, e1, min(want, n_keys) - 1);
+        float t = nextafterf(ord_to_f32((uint32_t)(hk >> 32)), -INFINITY);
+        if (n_keys < want) {
+          // Fewer candidates than the rank the threshold is taken at: the user's scores sank below the carried
+          // threshold since it was set.  The lowest candidate is then (about) that same threshold again, and a user
+          // that keeps sinking ends on the exact route (30 us for the call, however few users take it).  Take the
+          // threshold where rank `want` would be if the scores went on falling as they do between rank K and the
+          // last candidate.  Any value is legal.
+          const float s_k = ord_to_f32((uint32_t)(kth >> 32)), s_last = ord_to_f32((uint32_t)(hk >> 32));
+          const float s_top = ord_to_f32((uint32_t)(key_of_rank(e0, e1, 0) >> 32));
+          const float slope = n_keys > K ? (s_k - s_last) / (float)(n_keys - K) : (s_top - s_k) / (float)max(K - 1, 1);
+          t -= slope * (float)(want - n_keys);
+        }
+        if (lane == 0) P.hint_out[u] = t;
       }
     }
-    if (wrote) e0 = 0ull;      // (the counting path stored its rows itself)
-    written_by_rank = wrote;
   }
-  __builtin_amdgcn_wave_barrier();
   if (lane == 0) {
     P.fail[u] = why;
     P.n_cand[u] = n_cand;
@@ -1090,7 +1153,7 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
       else P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;
     }
   }
-  if (why == 0 && !written_by_rank && lane < K) {
+  if (why == 0 && lane < K) {
     const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
     P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;
     P.out_val[(size_t)u * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
@@ -1099,19 +1162,22 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
 
 // One wave per user (a fixed grid walking the rows of the pass).
 #ifndef CHAOREC_SEL_WAVES
-#define CHAOREC_SEL_WAVES 5
+#define CHAOREC_SEL_WAVES 4
 #endif
 template <int D, int MAXC>
 __global__ __launch_bounds__(64, D > 64 ? 3 : (MAXC <= 512 ? CHAOREC_SEL_WAVES : 3)) void score_select_kernel_pf(const PrefArgs P) {
-  __shared__ int incl_s[64];
+  __shared__ int2 meta_s[64];
   __shared__ uint32_t cand_s[MAXC];
   __shared__ uint32_t hist_s[kPfSelHist];
-  __shared__ float4 urow_s[D / 4];
+  __shared__ float score_s[MAXC];
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
   if (n_act <= P.min_active) return;
+#pragma unroll 1
   for (int64_t i = blockIdx.x; i < n_act; i += gridDim.x) {
     const int64_t u = P.user_map ? (int64_t)P.user_map[i] : i;
-    select_user<D, MAXC>(P, u, incl_s, cand_s, hist_s, reinterpret_cast<float *>(urow_s));
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));       // (keeps the lane-dependent constants of the networks out of the loop preheader)
+    select_user<D, MAXC>(P, u, lane, meta_s, cand_s, hist_s, score_s);
     __builtin_amdgcn_wave_barrier();
   }
 }

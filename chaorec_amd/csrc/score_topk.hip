@@ -1085,6 +1085,9 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.hint_in = nullptr;
     P.hint_out = hint_out;
     P.hint_rank = hint_rank > K ? (hint_rank > 128 ? 128 : hint_rank) : K;
+#ifdef CHAOREC_SEL_EXP
+    if (hint_rank >= 1000) P.hint_rank = hint_rank;      // (experiment builds: the run-time switch of tools/sel_variants.py)
+#endif
     int *failf = (int *)(ws + p.off_fail);
     P.fail = failf;
     int *retry_cnt = (int *)(ws + p.off_pf_scalars + 64);

@@ -1,12 +1,13 @@
 """VALU / SALU / VMEM instruction counts of the selection kernel by phase: builds with the stage-cut experiment macros
-(CHAOREC_SEL_EXP = 5 expansion only, 8 + exact scores, 6 + keys, none = whole kernel) under rocprofv3 --pmc."""
+(CHAOREC_SEL_EXP = 5 expansion only, 6 + exact scores and keys, 9 = whole kernel; the cuts act on calls with
+hint_rank >= 1000, so the earlier calls of the script leave valid thresholds) under rocprofv3 --pmc."""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 extra = sys.argv[1] if len(sys.argv) > 1 else ""
-for v in ["-DCHAOREC_SEL_EXP=5", "-DCHAOREC_SEL_EXP=8", "-DCHAOREC_SEL_EXP=6", "-DCHAOREC_SEL_EXP=9"]:
+for v in ["-DCHAOREC_SEL_EXP=5", "-DCHAOREC_SEL_EXP=6", "-DCHAOREC_SEL_EXP=9"]:
     env = dict(os.environ, CHAOREC_EXTRA_HIPCC_FLAGS=(v + " " + extra).strip(), TMPDIR="/tmp", EPOCH_APART="1", LAST_N="4",
                PMC_PASSES="0,2", TIMED_HINT_RANK="1100" if v else "100")
     subprocess.check_call([sys.executable, "-c", "from chaorec_amd import _lib; _lib.build(force=True)"], cwd=ROOT, env=env,
