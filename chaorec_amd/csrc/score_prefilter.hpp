@@ -582,13 +582,8 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
 #pragma unroll
     for (int b = 0; b < UB; ++b) {
       f32x16 &acc = accs[b];
-      if (j0 + 32u > n_items) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int off = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          if (j0 + off >= n_items) acc[reg] = INFINITY;   // rows past the table never qualify
-        }
-      }
+      // (rows past the table are zero vectors with a zero norm: they qualify when T_u < 0; the selection drops them --
+      //  masking them here cost 20 instructions per tile and user block for 31 rows of the whole table)
       // bit (15 - reg) <=> v_j > T_u: the accumulator's sign bit
       uint32_t qbits = 0;
 #pragma unroll
@@ -1046,6 +1041,11 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
         const uint32_t raw = P.cand[(size_t)m.y * kPfCap + (e - m.x)];
         bits = raw & 0xFFFFu;
         j0 = ((uint32_t)(list >> 1) + (raw >> 16) * (uint32_t)P.splits) * 32u + 4u * (uint32_t)(list & 1);
+      }
+      if (__any(bits != 0u && j0 + 32u > (uint32_t)P.n_items)) {   // the table's last tile (a scalar branch: rarely taken):
+#pragma unroll 1
+        for (int reg = 0; reg < 16; ++reg)                          // the sweep does not mask the rows past the table's end
+          if (j0 + (uint32_t)((reg & 3) + 8 * (reg >> 2)) >= (uint32_t)P.n_items) bits &= ~(1u << (15 - reg));
       }
       const int pc = __popc(bits);
       const int ex = wave_scan_add(pc);
