@@ -10,6 +10,7 @@ PASSES = [
     ["SQ_INST_CYCLES_VMEM_RD", "SQ_VMEM_TA_ADDR_FIFO_FULL", "SQ_VMEM_TA_CMD_FIFO_FULL", "SQ_INST_LEVEL_VMEM"],
     ["TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TA_TOTAL_WAVEFRONTS_sum"],
     ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_EA0_RDREQ_sum"],
+    ["GRBM_GUI_ACTIVE", "GRBM_COUNT", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"],
 ]
 sep = sys.argv.index("--")
 filt, cmd = sys.argv[1:sep], sys.argv[sep + 1:]
