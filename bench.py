@@ -249,7 +249,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         stepper = FusedLightGCNStep(model, opt, batch_size=B, edges=edges_dev, seed=42, step_dev=batch_counter,
                                     loss_accum=loss_sum, capture=not args.no_graph, steps_per_replay=args.steps_per_replay)
         launch = ((f"captured hipGraph, {stepper.steps_per_replay} steps per replay" if not args.no_graph
-                   else "eager launches") + ", fused step (2L+2 kernels)")
+                   else "eager launches") + ", fused step (2L+1 kernels per step + one loss-bookkeeping launch per replay)")
 
         def run_steps(n):          # whole replays of steps_per_replay steps, single-step replays for the remainder
             n_loss[0] += n

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_bwd_drawn_kernel(
     int64_t *__restrict__ out_users, int64_t *__restrict__ out_pos, int64_t *__restrict__ out_neg, int B, int D,
     int variant, float reg_weight, float *__restrict__ coef, float *__restrict__ ws, const int64_t *__restrict__ perm,
     const int64_t *__restrict__ perm_pos, float *g_u, float *g_i, int32_t *__restrict__ adam_step, float beta1,
-    float beta2, float *__restrict__ adam_bc) {
+    float beta2, float *__restrict__ adam_bc, int64_t pos_offset) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   // the optimizer's step count and this step's bias corrections (two double pow()s on one otherwise idle thread,
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_bwd_drawn_kernel(
     if (step_dev) step += (uint64_t)step_dev[0];
     if (lane == 0) {
       draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n, perm,
-                  perm ? perm_pos[0] : 0);
+                  perm ? perm_pos[0] + pos_offset : 0);
       out_users[b] = u;
       out_pos[b] = p;
       out_neg[b] = n;
@@ -208,6 +208,57 @@ __global__ __launch_bounds__(256) void bpr_fwd_finalize_kernel(const float *__re
       adam_step[0] = st;
       adam_bias_corrections(st, beta1, beta2, adam_bc[0], adam_bc[1]);
     }
+  }
+}
+
+// The same reduction for n_steps consecutive steps' workspaces in ONE launch (a replay of k captured steps runs its
+// loss bookkeeping once: nothing later in a step reads what the finalize writes, only the NEXT step's batch draw does,
+// and that reads `advance` / `advance_pos` plus a per-launch offset).  Step by step, in order: the same sums, the same
+// sequence of additions into loss_accum as n_steps single launches.
+__global__ __launch_bounds__(256) void bpr_fwd_finalize_steps_kernel(const float *__restrict__ ws, int64_t ws_stride,
+                                                                     int n_steps, int B, int D, float reg_weight,
+                                                                     float *__restrict__ out_loss,
+                                                                     float *__restrict__ out_total,
+                                                                     int64_t *__restrict__ advance,
+                                                                     int64_t *__restrict__ advance_pos,
+                                                                     float *__restrict__ loss_accum) {
+  __shared__ float red[4][256];
+  const int t = threadIdx.x;
+  for (int st = 0; st < n_steps; ++st) {
+    const float *w = ws + (size_t)st * ws_stride;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < B; i += 256) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] += w[q * B + i];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[q][t] = a[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[q][t] += red[q][t + s];
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const float bpr = -red[0][0] / (float)B;
+      const float denom = (float)B * (float)D;
+      float reg = 0.f;
+      if (reg_weight != 0.f) reg = reg_weight * (red[1][0] / denom + red[2][0] / denom + red[3][0] / denom);
+      if (st == n_steps - 1) {
+        out_loss[0] = bpr + reg;
+        out_loss[1] = bpr;
+        out_loss[2] = reg;
+        if (out_total) out_total[0] = bpr + reg;
+      }
+      if (loss_accum) loss_accum[0] += bpr + reg;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (advance) advance[0] += n_steps;
+    if (advance_pos) advance_pos[0] += (int64_t)n_steps * B;
   }
 }
 
@@ -388,7 +439,23 @@ extern "C" int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, c
                                        int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
                                        const int64_t *perm, const int64_t *perm_pos, float *g_u, float *g_i,
                                        int32_t *adam_step, float beta1, float beta2, float *adam_bc, void *stream) {
+  return chaorec_bpr_fwd_bwd_at_f32(tab_u, tab_i, edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step,
+                                    step_dev, in_users, in_pos, in_neg, B, D, variant, reg_weight, out_users, out_pos,
+                                    out_neg, coef, workspace, perm, perm_pos, 0, g_u, g_i, adam_step, beta1, beta2, adam_bc,
+                                    stream);
+}
+
+extern "C" int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
+                                          const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
+                                          int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
+                                          const int64_t *in_users, const int64_t *in_pos, const int64_t *in_neg,
+                                          int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
+                                          int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
+                                          const int64_t *perm, const int64_t *perm_pos, int64_t pos_offset, float *g_u,
+                                          float *g_i, int32_t *adam_step, float beta1, float beta2, float *adam_bc,
+                                          void *stream) {
   if (!tab_u || !tab_i || !coef || !workspace || !g_u || !g_i) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: NULL argument");
+  if (pos_offset < 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: pos_offset %lld", (long long)pos_offset);
   if (adam_step && !adam_bc) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: adam_step without adam_bc");
   if (edges) {
     if (!hist_rowptr || !out_users || !out_pos || !out_neg) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: NULL draw argument");
@@ -402,8 +469,19 @@ extern "C" int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, c
   hipLaunchKernelGGL(bpr_fwd_bwd_drawn_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u, tab_i, edges,
                      n_edges, hist_rowptr, hist_col, num_user, (uint32_t)num_item, seed, step, step_dev, in_users, in_pos,
                      in_neg, out_users, out_pos, out_neg, B, D, variant, reg_weight, coef, workspace, perm, perm_pos, g_u,
-                     g_i, adam_step, beta1, beta2, adam_bc);
+                     g_i, adam_step, beta1, beta2, adam_bc, pos_offset);
   return check_launch("bpr_fwd_bwd_drawn_kernel");
+}
+
+extern "C" int chaorec_bpr_finalize_steps_f32(const float *workspace, int64_t ws_stride, int32_t n_steps, int32_t B,
+                                              int32_t D, float reg_weight, float *out_loss, float *out_total,
+                                              float *loss_accum, int64_t *advance, int64_t *perm_pos, void *stream) {
+  if (!workspace || !out_loss) return fail(CHAOREC_E_INVALID, "bpr_finalize_steps: NULL argument");
+  if (B <= 0 || D <= 0 || n_steps < 1 || ws_stride < 4 * (int64_t)B)
+    return fail(CHAOREC_E_INVALID, "bpr_finalize_steps: B=%d D=%d n_steps=%d ws_stride=%lld", B, D, n_steps, (long long)ws_stride);
+  hipLaunchKernelGGL(bpr_fwd_finalize_steps_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, ws_stride,
+                     n_steps, B, D, reg_weight, out_loss, out_total, advance, perm_pos, loss_accum);
+  return check_launch("bpr_fwd_finalize_steps_kernel");
 }
 
 extern "C" int chaorec_bpr_finalize_f32(const float *workspace, int32_t B, int32_t D, float reg_weight, float *out_loss,

@@ -301,25 +301,26 @@ def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset
 
 def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg_weight, coef, ws, ids, edges=None, hist=None, num_user=0,
                 num_item=0, seed=0, step=0, step_dev=None, perm=None, perm_pos=None, adam_step=None, betas=(0.9, 0.999),
-                adam_bc=None):
+                adam_bc=None, pos_offset=0):
     """BPR(+L2) forward terms and backward row adds in one launch (chaorec_bpr_fwd_bwd_f32) over ONE [N, D] table
     (items from row item_offset on) and its gradient buffer `grad` (same shape, zero where no sample lands).
     edges given: the batch is drawn in the launch and written to ids = (users, pos, neg); else ids are the batch
     (LOCAL item ids).  The loss comes from bpr_finalize(ws, ...).  adam_step / adam_bc: Adam's step counter is moved on
-    and the new step's bias corrections are written by this launch."""
+    and the new step's bias corrections are written by this launch.  pos_offset: added to *perm_pos (step j of a
+    replay whose finalize runs once, after its last step: step = j, pos_offset = j * B)."""
     _need_cuda(tab, grad, coef, ws, edges, step_dev, perm, perm_pos, adam_step, adam_bc, *ids)
     D = tab.shape[1]
     off = item_offset * D * 4
     ti, gi = ctypes.c_void_p(tab.data_ptr() + off), ctypes.c_void_p(grad.data_ptr() + off)
     draw = edges is not None
     rowptr, col = hist if hist is not None else (None, None)
-    rc = _lib.load().chaorec_bpr_fwd_bwd_f32(
+    rc = _lib.load().chaorec_bpr_fwd_bwd_at_f32(
         _ptr(tab), ti, _ptr(edges), edges.shape[0] if draw else 0, _ptr(rowptr), _ptr(col), int(num_user), int(num_item),
         int(seed) & (2**64 - 1), int(step), _ptr(step_dev), _ptr(None if draw else ids[0]), _ptr(None if draw else ids[1]),
         _ptr(None if draw else ids[2]), int(B), D, int(variant), float(reg_weight), _ptr(ids[0] if draw else None),
         _ptr(ids[1] if draw else None), _ptr(ids[2] if draw else None), _ptr(coef), _ptr(ws), _ptr(perm), _ptr(perm_pos),
-        _ptr(grad), gi, _ptr(adam_step), betas[0], betas[1], _ptr(adam_bc), _stream())
-    _lib.check(rc, "chaorec_bpr_fwd_bwd_f32")
+        int(pos_offset), _ptr(grad), gi, _ptr(adam_step), betas[0], betas[1], _ptr(adam_bc), _stream())
+    _lib.check(rc, "chaorec_bpr_fwd_bwd_at_f32")
 
 
 def bpr_finalize(ws, B, D, reg_weight, out_loss, out_total=None, loss_accum=None, advance=None, perm_pos=None,
@@ -332,6 +333,17 @@ def bpr_finalize(ws, B, D, reg_weight, out_loss, out_total=None, loss_accum=None
                                               _ptr(loss_accum), _ptr(advance), _ptr(perm_pos), _ptr(adam_step),
                                               betas[0], betas[1], _ptr(adam_bc), _stream())
     _lib.check(rc, "chaorec_bpr_finalize_f32")
+
+
+def bpr_finalize_steps(ws, n_steps, B, D, reg_weight, out_loss, out_total=None, loss_accum=None, advance=None, perm_pos=None):
+    """bpr_finalize for the n_steps workspaces ws[j] (ws: [n_steps, >= 4 B]) of a replay in ONE launch
+    (chaorec_bpr_finalize_steps_f32): the same sums and additions into loss_accum, in step order; out_loss / out_total of
+    the last step; advance += n_steps, perm_pos += n_steps * B."""
+    _need_cuda(ws, out_loss, out_total, loss_accum, advance, perm_pos)
+    rc = _lib.load().chaorec_bpr_finalize_steps_f32(_ptr(ws), int(ws.stride(0)), int(n_steps), int(B), int(D), float(reg_weight),
+                                                    _ptr(out_loss), _ptr(out_total), _ptr(loss_accum), _ptr(advance),
+                                                    _ptr(perm_pos), _stream())
+    _lib.check(rc, "chaorec_bpr_finalize_steps_f32")
 
 
 def sample_negatives(hist, users, num_item, seed, step, id_offset, step_dev=None):

@@ -171,7 +171,7 @@ class GraphedTrainStep:
 
 class FusedLightGCNStep:
     """One LightGCN training iteration -- train_and_evaluate.py:43-48: zero_grad, model.loss() (Model/LightGCN.py:
-    123-135: L propagates + layer mean, BPR + L2), loss.backward(), Adam step -- as 2L + 2 kernel launches with no
+    123-135: L propagates + layer mean, BPR + L2), loss.backward(), Adam step -- as 2L + 2 kernel launches (2L + 1 + 1/k in a k-step replay) with no
     autograd tape and no optimizer launch, captured in one hipGraph:
 
         L x  SpMM (layer mean in the epilogue; the last one writes only the mean = model.result)
@@ -229,6 +229,7 @@ class FusedLightGCNStep:
         self.ids = tuple(torch.zeros(self.B, dtype=torch.int64, device=dev) for _ in range(3))
         self.coef = torch.empty(self.B, dtype=torch.float32, device=dev)
         self.ws = torch.empty(4 * self.B, dtype=torch.float32, device=dev)
+        self.ws_steps = None                # [steps_per_replay, 4 B]: one workspace per step of a multi-step replay
         self.out = torch.zeros(3, dtype=torch.float32, device=dev)
         self.static_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.bc = torch.ones(2, dtype=torch.float32, device=dev)
@@ -252,10 +253,15 @@ class FusedLightGCNStep:
                 self._launch()
             self.graph = self.graph1
             if self.steps_per_replay > 1:
+                # k steps per replay: the loss bookkeeping (reduction of the per-sample terms, epoch loss, batch counter
+                # and permutation cursor) runs ONCE, after the last step -- nothing inside a step reads it, only the next
+                # step's batch draw does, and that takes its position as cursor + j B with j fixed per captured launch
+                k = self.steps_per_replay
+                self.ws_steps = torch.empty((k, 4 * self.B), dtype=torch.float32, device=dev)
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
-                    for _ in range(self.steps_per_replay):
-                        self._launch()
+                    for j in range(k):
+                        self._launch(j, k)
 
     def _counters(self):
         return [t for t in (self.step_dev, self.perm_pos, self.loss_accum, self.optimizer._step_dev) if t is not None]
@@ -272,19 +278,25 @@ class FusedLightGCNStep:
             self.G.zero_()
 
     @torch.no_grad()
-    def _launch(self):
+    def _launch(self, j=0, k=1):
+        """Step j of a k-step replay (k = 1: a step with its own finalize launch)."""
         model, opt, L, B, D = self.model, self.optimizer, self.L, self.B, self.D
         group = opt.param_groups[0]
         csr, x0, w = model.graph, model._flat, 1.0 / (L + 1)
         ops.forward_layers(csr, x0, L, self.final, self.fbuf)
         draw = self.edges is not None
+        ws = self.ws if k == 1 else self.ws_steps[j]
         ops.bpr_fwd_bwd(self.final, model.num_user, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef,
-                        self.ws, self.ids, edges=self.edges, hist=model.hist if draw else None, num_user=model.num_user,
-                        num_item=model.num_item, seed=self.seed, step=0, step_dev=self.step_dev, perm=self.perm,
-                        perm_pos=self.perm_pos, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
-        ops.bpr_finalize(self.ws, B, D, model.reg_weight, self.out, out_total=self.static_loss,
-                         loss_accum=self.loss_accum, advance=self.step_dev if draw else None,
-                         perm_pos=self.perm_pos if (draw and self.perm is not None) else None)
+                        ws, self.ids, edges=self.edges, hist=model.hist if draw else None, num_user=model.num_user,
+                        num_item=model.num_item, seed=self.seed, step=j, step_dev=self.step_dev, perm=self.perm,
+                        perm_pos=self.perm_pos, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc,
+                        pos_offset=j * B)
+        book = dict(out_total=self.static_loss, loss_accum=self.loss_accum, advance=self.step_dev if draw else None,
+                    perm_pos=self.perm_pos if (draw and self.perm is not None) else None)
+        if k == 1:
+            ops.bpr_finalize(ws, B, D, model.reg_weight, self.out, **book)
+        elif j == k - 1:
+            ops.bpr_finalize_steps(self.ws_steps, k, B, D, model.reg_weight, self.out, **book)
         g, alpha = self.G, w                    # g_{L-1} = w (A G) + w G, then g_l = A g_{l+1} + w G
         for l in range(L - 1):
             y = self.buf[l & 1]

@@ -26,13 +26,14 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 5   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 6   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
                                   stand-alone BPR finalize with loss / optimizer bookkeeping, layer mean in the last
                                   forward SpMM, scoring with carried thresholds, split-bf16 NT GEMM;
-                                  5: weighted_sample_keys (sharded edge pruning) */
+                                  5: weighted_sample_keys (sharded edge pruning);
+                                  6: BPR batch at an offset + one finalize for k captured steps */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -225,6 +226,25 @@ int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, const int64_
 int chaorec_bpr_finalize_f32(const float *workspace, int32_t B, int32_t D, float reg_weight, float *out_loss,
                              float *out_total, float *loss_accum, int64_t *advance, int64_t *perm_pos,
                              int32_t *adam_step, float beta1, float beta2, float *adam_bc, void *stream);
+
+/* The two above for a replay of k captured steps that runs its loss bookkeeping ONCE (chaorec_amd/optim.py:
+ * FusedLightGCNStep, steps_per_replay > 1): step j of the replay draws its batch with step = j and
+ * pos_offset = j * B (read position *perm_pos + pos_offset of the epoch permutation) into its own workspace
+ * workspace + j * ws_stride, and ONE chaorec_bpr_finalize_steps_f32 after the last step reduces the k workspaces in
+ * order -- the same sums and the same sequence of additions into loss_accum as k single launches -- writes the LAST
+ * step's out_loss / out_total and moves *advance on by k and *perm_pos by k * B. */
+int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
+                               const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
+                               int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
+                               const int64_t *in_users, const int64_t *in_pos, const int64_t *in_neg,
+                               int32_t B, int32_t D, int32_t variant, float reg_weight, int64_t *out_users,
+                               int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
+                               const int64_t *perm, const int64_t *perm_pos, int64_t pos_offset, float *g_u,
+                               float *g_i, int32_t *adam_step, float beta1, float beta2, float *adam_bc,
+                               void *stream);
+int chaorec_bpr_finalize_steps_f32(const float *workspace, int64_t ws_stride, int32_t n_steps, int32_t B,
+                                   int32_t D, float reg_weight, float *out_loss, float *out_total,
+                                   float *loss_accum, int64_t *advance, int64_t *perm_pos, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * R: all-items scoring + history mask + top-K, never materialising the [U, I] matrix.
