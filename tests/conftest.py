@@ -81,3 +81,13 @@ def tie_aware_rank_equal(idx_a, val_a, idx_b, val_b, rtol=0.0, atol=0.0):
                 break
             s = e
     return bad == 0, f"{bad} rows differ outside tie groups"
+
+
+@pytest.fixture(autouse=True)
+def _seed_everything():
+    """Every test starts from the same torch / numpy generator state (CPU and GPU): inputs drawn without an explicit
+    generator are the same from run to run, so a tolerance that holds once holds at the round-end run too."""
+    import torch
+    torch.manual_seed(20260203)
+    np.random.seed(20260203)
+    yield
