@@ -123,13 +123,14 @@ def build(force=False, verbose=False):
     hdrs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".h", ".hpp"))]
     hdrs += [os.path.join(os.path.dirname(_CSRC), "..", "include", "chaorec_hip.h"), os.path.abspath(__file__)]
     extra = os.environ.get("CHAOREC_EXTRA_HIPCC_FLAGS", "").split()
-    if not force and not extra and os.path.exists(LIB_PATH) and all(
+    drop = os.environ.get("CHAOREC_DROP_HIPCC_FLAGS", "").split()       # (experiments: e.g. "-mllvm -amdgpu-mfma-vgpr-form")
+    if not force and not extra and not drop and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + hdrs):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     objdir = os.path.join(_CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared" and f not in drop] + extra
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
