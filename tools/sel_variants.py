@@ -1,5 +1,6 @@
 """Rebuild libchaorec_hip.so with experiment macros and report the duration of the selection kernel in the cold and
-the carried-threshold call (rocprofv3 kernel trace of tools/score_profile.py) per variant."""
+the carried-threshold call (compare variants only within ONE run of this script: the kernels' times depend on the
+training state, TRAIN_STEPS, default 3000 in the EPOCH_APART mode) (rocprofv3 kernel trace of tools/score_profile.py) per variant."""
 import csv
 import glob
 import os
@@ -15,7 +16,7 @@ for v in variants:
     out = "/tmp/selvar"
     shutil.rmtree(out, ignore_errors=True)
     if os.environ.get("EPOCH_APART"):       # bench.py's steady state only: the timeline of the last calls
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_timeline.py"), "1500", "EPOCH_APART"], cwd=ROOT, env=env,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "score_timeline.py"), os.environ.get("TRAIN_STEPS", "3000"), "EPOCH_APART"], cwd=ROOT, env=env,
                            capture_output=True, text=True)
         print(f"== {v or 'baseline'}\n" + "\n".join(r.stdout.splitlines()[-6:]), flush=True)
         continue
