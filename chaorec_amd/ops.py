@@ -380,20 +380,28 @@ SCORE_LIGHT = 1      # CHAOREC_SCORE_LIGHT
 
 
 def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0, stats=None, hint=None,
-               hint_valid=False, hint_rank=80, light=False, counters=None):
+               hint_valid=False, hint_rank=80, light=False, counters=None, idx_out=None):
     """Top-K of user_emb @ item_emb.T with history masking, without the [U,I] matrix.
     Returns (idx int64 [U,K] = item + id_offset, val fp32 [U,K]).  `stats`: a dict to fill with the prefilter
     route's counters (chaorec_score_topk_stats; costs a device sync).
     hint (optional, float32 [U] on the device): per-user thresholds carried between calls
     (chaorec_score_topk_hinted_f32): written by every call, read when hint_valid.  Never changes the result.
     light: no retry pass (the caller saw a short retry queue last time); counters: int32 [4] device tensor receiving
-    this call's queue lengths."""
+    this call's queue lengths.  idx_out: an int64 [U, K] tensor to write the indices to -- a PINNED host tensor is allowed
+    (page-locked memory is mapped into the device's address space: the selection then writes the rank list straight over
+    PCIe while it runs, instead of a device buffer that is copied afterwards; sync the stream before reading it)."""
     _need_cuda(user_emb, item_emb)
     user_emb, item_emb = _f32c(user_emb), _f32c(item_emb)
     U, D = user_emb.shape
     I = item_emb.shape[0]
     dev = user_emb.device
-    idx = torch.empty((U, K), dtype=torch.int64, device=dev)
+    if idx_out is not None:
+        if idx_out.dtype != torch.int64 or tuple(idx_out.shape) != (U, K) or not idx_out.is_contiguous() or \
+                not (idx_out.is_cuda or idx_out.is_pinned()):
+            raise TypeError("score_topk: idx_out must be a contiguous int64 [n_users, K] device or pinned host tensor")
+        idx = idx_out
+    else:
+        idx = torch.empty((U, K), dtype=torch.int64, device=dev)
     val = torch.empty((U, K), dtype=torch.float32, device=dev)
     lib = _lib.load()
     nbytes = lib.chaorec_score_topk_workspace_bytes(U, I, K, D)

@@ -93,9 +93,15 @@ def state_of(model):
     return st
 
 
+ZERO_COPY = True     # to_cpu: the selection writes the rank list into pinned host memory itself (no D2H copy afterwards)
+
+
 def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to_cpu=True, state=None):
     """result [N, D] (users first) on the GPU -> LongTensor [num_user, topk] of GLOBAL item ids on the CPU (the
     reference's contract); to_cpu=False keeps it in HBM for utils.gene_metrics_device."""
+    host = None
+    if to_cpu and ZERO_COPY:
+        host = torch.empty((num_user, topk), dtype=torch.int64, pin_memory=True)
     with torch.no_grad():
         result = result.detach()
         if state is not None:
@@ -104,9 +110,12 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                     id_offset=num_user, hint=hint, hint_valid=hinted,
                                     hint_rank=min(2 * topk, 128), light=hinted and state.light(),
-                                    counters=state.counters)
+                                    counters=state.counters, idx_out=host)
             state.after_call(hinted)
         else:
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
-                                    id_offset=num_user)
+                                    id_offset=num_user, idx_out=host)
+    if host is not None:
+        torch.cuda.current_stream(result.device).synchronize()
+        return host
     return _to_host(idx) if to_cpu else idx
