@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
     for (int b = 0; b < UB; ++b) {
       f32x16 &acc = accs[b];
       // (rows past the table are zero vectors with a zero norm: they qualify when T_u < 0; the selection drops them --
-      //  masking them here cost 20 instructions per tile and user block for 31 rows of the whole table)
+      //  masking them here put 42 more instructions into every tile's block for 31 rows of the whole table)
       // bit (15 - reg) <=> v_j > T_u: the accumulator's sign bit
       uint32_t qbits = 0;
 #pragma unroll
