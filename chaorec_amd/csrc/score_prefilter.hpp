@@ -983,6 +983,9 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
                                             uint32_t *hist_s, float *score_s) {
   const int K = P.K;
   const int n_lists = 2 * P.splits;  // <= 32
+#if defined(CHAOREC_SEL_EXP) && CHAOREC_SEL_EXP == 4
+  if (P.hint_rank >= 1000) return;     // (experiment: the launch alone)
+#endif
   const PermAddr pa = perm_addr(lane);
 
   // this lane's list of the sweep: (split lane / 2, half lane & 1)
