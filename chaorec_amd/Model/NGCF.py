@@ -49,7 +49,7 @@ class NGCFConv(nn.Module):
             s = ops.spmm_values(structure, val, val_t, x)
         else:
             s = ops.spmm(structure, x)
-        return ops.ngcf_combine(s, self.W1.weight, s * x, self.W2.weight)
+        return ops.ngcf_layer(s, x, self.W1.weight, self.W2.weight)
 
 
 class NGCF(nn.Module):

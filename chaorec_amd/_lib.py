@@ -112,6 +112,8 @@ SIGNATURES = {
                                                     c_ptr]),
     "chaorec_weighted_sample_keys": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint64, c_ptr,
                                                     c_ptr, c_ptr]),
+    "chaorec_leaky_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_float, c_ptr, ctypes.c_int64, c_ptr]),
+    "chaorec_mul_pair_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
 }
 
 

@@ -249,6 +249,29 @@ __global__ __launch_bounds__(256) void sum_final_kernel(const float *__restrict_
   if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// ---- NGCF's elementwise backward (Model/NGCF.py:60-84 restated as out = leaky_0.2(s W1^T + (s * x) W2^T)) --------------
+// g = leaky_relu'(y) * gy  (one launch instead of compare + multiply + where)
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const float4 *__restrict__ y, const float4 *__restrict__ gy,
+                                                        float slope, float4 *__restrict__ g, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = y[i], b = gy[i];
+    g[i] = make_float4(a.x > 0.f ? b.x : b.x * slope, a.y > 0.f ? b.y : b.y * slope, a.z > 0.f ? b.z : b.z * slope,
+                       a.w > 0.f ? b.w : b.w * slope);
+  }
+}
+// the product t = s * x backwards, and the sum with s's other gradient:  gs += gt * x;  gx = gt * s
+// (separately rounded product and sum: what torch's mul + add give)
+__global__ __launch_bounds__(256) void mul_pair_bwd_kernel(const float4 *__restrict__ gt, const float4 *__restrict__ s,
+                                                           const float4 *__restrict__ x, float4 *__restrict__ gs,
+                                                           float4 *__restrict__ gx, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 t = gt[i], a = s[i], b = x[i], c = gs[i];
+    gs[i] = make_float4(__fadd_rn(c.x, __fmul_rn(t.x, b.x)), __fadd_rn(c.y, __fmul_rn(t.y, b.y)),
+                        __fadd_rn(c.z, __fmul_rn(t.z, b.z)), __fadd_rn(c.w, __fmul_rn(t.w, b.w)));
+    gx[i] = make_float4(t.x * a.x, t.y * a.y, t.z * a.z, t.w * a.w);
+  }
+}
+
 }  // namespace chaorec
 
 using namespace chaorec;
@@ -313,4 +336,28 @@ extern "C" int chaorec_row_cosine_scale_bwd_f32(const float *grad_out, const flo
     return fail(CHAOREC_E_INVALID, "row_cosine_scale_bwd: n_rows=%lld D=%d (D: multiple of 4 in [4,1024])", (long long)n_rows, D);
   if (n_rows == 0) return CHAOREC_OK;
   return dispatch_row_cosine(grad_out, y, e, grad_y, grad_e, nullptr, n_rows, D, (hipStream_t)stream);
+}
+
+extern "C" int chaorec_leaky_bwd_f32(const float *y, const float *grad_out, float slope, float *grad_in, int64_t n,
+                                     void *stream) {
+  if (!y || !grad_out || !grad_in) return fail(CHAOREC_E_INVALID, "leaky_bwd: null pointer");
+  if (n < 0 || n % 4) return fail(CHAOREC_E_INVALID, "leaky_bwd: n=%lld must be a non-negative multiple of 4", (long long)n);
+  if (n == 0) return CHAOREC_OK;
+  const int64_t n4 = n / 4;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 4096);
+  leaky_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4 *)y, (const float4 *)grad_out, slope,
+                                                           (float4 *)grad_in, n4);
+  return check_launch("leaky_bwd");
+}
+
+extern "C" int chaorec_mul_pair_bwd_f32(const float *grad_t, const float *s, const float *x, float *grad_s, float *grad_x,
+                                        int64_t n, void *stream) {
+  if (!grad_t || !s || !x || !grad_s || !grad_x) return fail(CHAOREC_E_INVALID, "mul_pair_bwd: null pointer");
+  if (n < 0 || n % 4) return fail(CHAOREC_E_INVALID, "mul_pair_bwd: n=%lld must be a non-negative multiple of 4", (long long)n);
+  if (n == 0) return CHAOREC_OK;
+  const int64_t n4 = n / 4;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 4096);
+  mul_pair_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4 *)grad_t, (const float4 *)s, (const float4 *)x,
+                                                              (float4 *)grad_s, (float4 *)grad_x, n4);
+  return check_launch("mul_pair_bwd");
 }

@@ -603,30 +603,41 @@ def spmm_values(structure, val, val_t, x):
     return _SpMMValues.apply(x, structure, val, val_t)
 
 
-class _NGCFCombine(torch.autograd.Function):
-    """leaky_relu_0.2(s W1^T + t W2^T): the dense half of NGCFConv (Model/NGCF.py:68-80) as two MFMA GEMM launches,
-    the second accumulating into the first's output with the activation in its epilogue."""
+class _NGCFLayer(torch.autograd.Function):
+    """leaky_relu_0.2(s W1^T + (s * x) W2^T): the dense half of NGCFConv (Model/NGCF.py:68-84) as two MFMA GEMM launches
+    (the second accumulating into the first's output with the activation in its epilogue) after one product launch;
+    backward: the activation's mask in one launch (chaorec_leaky_bwd_f32), four GEMMs, and the product's backward plus
+    the sum into s's other gradient in one launch (chaorec_mul_pair_bwd_f32)."""
 
     @staticmethod
-    def forward(ctx, s, w1, t, w2):
+    def forward(ctx, s, x, w1, w2):
+        t = s * x
         y = gemm_raw(s, w1, transB=True)
         gemm_raw(t, w2, transB=True, out=y, accumulate=True, act=2)
-        ctx.save_for_backward(s, w1, t, w2, y)
+        ctx.save_for_backward(s, x, w1, t, w2, y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        s, w1, t, w2, y = ctx.saved_tensors
-        g = torch.where(y > 0, gy, gy * 0.2).contiguous()
-        gs = gemm_raw(g, w1) if ctx.needs_input_grad[0] else None
-        gw1 = gemm_raw(g, s, transA=True) if ctx.needs_input_grad[1] else None
-        gt = gemm_raw(g, w2) if ctx.needs_input_grad[2] else None
+        s, x, w1, t, w2, y = ctx.saved_tensors
+        lib = _lib.load()
+        gy = gy.contiguous()
+        g = torch.empty_like(gy)
+        _lib.check(lib.chaorec_leaky_bwd_f32(_ptr(y), _ptr(gy), 0.2, _ptr(g), g.numel(), _stream()), "chaorec_leaky_bwd_f32")
+        gs = gemm_raw(g, w1)
+        gt = gemm_raw(g, w2)
+        gx = torch.empty_like(x)
+        _lib.check(lib.chaorec_mul_pair_bwd_f32(_ptr(gt), _ptr(s), _ptr(x), _ptr(gs), _ptr(gx), gs.numel(), _stream()),
+                   "chaorec_mul_pair_bwd_f32")
+        gw1 = gemm_raw(g, s, transA=True) if ctx.needs_input_grad[2] else None
         gw2 = gemm_raw(g, t, transA=True) if ctx.needs_input_grad[3] else None
-        return gs, gw1, gt, gw2
+        return gs, gx, gw1, gw2
 
 
-def ngcf_combine(s, w1, t, w2):
-    return _NGCFCombine.apply(s, w1, t, w2)
+def ngcf_layer(s, x, w1, w2):
+    """leaky_relu_0.2(s W1^T + (s * x) W2^T) for [N, D] tables with D a multiple of 4."""
+    _need_cuda(s, x, w1, w2)
+    return _NGCFLayer.apply(_f32c(s), _f32c(x), w1, w2)
 
 
 def weighted_sample_keep(weights, k, seed, step=0, step_dev=None, return_keys=False):

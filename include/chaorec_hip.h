@@ -33,7 +33,7 @@ extern "C" {
                                   stand-alone BPR finalize with loss / optimizer bookkeeping, layer mean in the last
                                   forward SpMM, scoring with carried thresholds, split-bf16 NT GEMM;
                                   5: weighted_sample_keys (sharded edge pruning);
-                                  6: BPR batch at an offset + one finalize for k captured steps */
+                                  6: BPR batch at an offset + one finalize for k captured steps, NGCF elementwise backward */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -464,6 +464,15 @@ int chaorec_row_cosine_scale_fwd_f32(const float *y, const float *e, float *out,
                                      int64_t n_rows, int32_t D, void *stream);
 int chaorec_row_cosine_scale_bwd_f32(const float *grad_out, const float *y, const float *e, float *grad_y,
                                      float *grad_e, int64_t n_rows, int32_t D, void *stream);
+
+/* NGCF's elementwise backward, one launch each (n a multiple of 4; 16-B aligned pointers).
+ * Replaces: torch.where(y > 0, g, 0.2 g) (three launches: the backward of nn.LeakyReLU(0.2), Model/NGCF.py:32,80-84) and
+ *           the backward of x_j * x_i (Model/NGCF.py:78: two multiplies and the add into the aggregate's other gradient).
+ *   chaorec_leaky_bwd_f32:     grad_in = y > 0 ? grad_out : slope * grad_out
+ *   chaorec_mul_pair_bwd_f32:  grad_s += grad_t * x (separately rounded product and sum);  grad_x = grad_t * s */
+int chaorec_leaky_bwd_f32(const float *y, const float *grad_out, float slope, float *grad_in, int64_t n, void *stream);
+int chaorec_mul_pair_bwd_f32(const float *grad_t, const float *s, const float *x, float *grad_s, float *grad_x,
+                             int64_t n, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Deterministic two-pass reductions (fixed order, no atomics, no semaphores, no memset nodes).
