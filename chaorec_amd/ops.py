@@ -503,8 +503,8 @@ LINEAR_FORWARD = _os.environ.get("CHAOREC_LINEAR_FORWARD", "bf16x3")
 
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) (nn.Linear [+ F.leaky_relu]): forward on the bf16 MFMA pipe (three bf16 planes per fp32
-    operand) where the reduction is long enough to pay for the split, else -- and the whole backward -- on the f32
-    MFMA pipe."""
+    operand) where the reduction is long enough to pay for the split -- the input gradient likewise --, else and
+    for the weight gradient (a TN product over all rows) on the f32 MFMA pipe."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
@@ -521,8 +521,22 @@ class _Linear(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         gy = gy.contiguous()
         if ctx.act:
-            gy = torch.where(y > 0, gy, gy * (0.01 if ctx.act == 1 else 0.2))
-        gx = gemm_raw(gy, weight) if ctx.needs_input_grad[0] else None
+            slope = 0.01 if ctx.act == 1 else 0.2
+            if gy.numel() % 4 == 0:                  # the activation's mask in one launch
+                g = torch.empty_like(gy)
+                _lib.check(_lib.load().chaorec_leaky_bwd_f32(_ptr(y), _ptr(gy), slope, _ptr(g), g.numel(), _stream()),
+                           "chaorec_leaky_bwd_f32")
+                gy = g
+            else:
+                gy = torch.where(y > 0, gy, gy * slope)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # input gradient g W: as g (W^T)^T on the bf16 MFMA pipe where the forward went there too (W is small:
+            # its transpose is one short copy)
+            if LINEAR_FORWARD == "bf16x3" and weight.shape[0] >= 64 and gy.shape[0] >= 256:
+                gx = gemm_nt_bf16x3(gy, weight.t().contiguous())
+            else:
+                gx = gemm_raw(gy, weight)
         gw = gemm_raw(gy, x, transA=True) if ctx.needs_input_grad[1] else None
         gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[2] else None     # (not gy.sum(0): see col_sum)
         return gx, gw, gb, None
