@@ -1061,3 +1061,27 @@ def test_linear_forward_pipes_agree(dev):
     ops.LINEAR_FORWARD = "bf16x3"
     for a, b in zip(outs["bf16x3"], outs["f32"]):
         assert torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()))
+
+
+def test_ngcf_elementwise_backward_kernels_equal_torch(dev):
+    """chaorec_leaky_bwd_f32 / chaorec_mul_pair_bwd_f32 against the torch expressions they replace, bit for bit
+    (separately rounded product and sum), through ops.ngcf_layer's autograd and directly on the Linear's slope too."""
+    from chaorec_amd import ops
+    N, D = 4099, 64
+    s = torch.randn(N, D, device=dev, requires_grad=True)
+    x = torch.randn(N, D, device=dev, requires_grad=True)
+    w1 = (torch.randn(D, D, device=dev) * 0.1).requires_grad_()
+    w2 = (torch.randn(D, D, device=dev) * 0.1).requires_grad_()
+    gy = torch.randn(N, D, device=dev)
+    y = ops.ngcf_layer(s, x, w1, w2)
+    y.backward(gy)
+    # the same chain with torch's elementwise ops around the same GEMM launches
+    g = torch.where(y.detach() > 0, gy, gy * 0.2)
+    gs_ref = ops.gemm_raw(g, w1.detach()) + ops.gemm_raw(g, w2.detach()) * x.detach()
+    gx_ref = ops.gemm_raw(g, w2.detach()) * s.detach()
+    assert torch.equal(s.grad, gs_ref) and torch.equal(x.grad, gx_ref)
+    assert torch.equal(w1.grad, ops.gemm_raw(g, s.detach(), transA=True))
+    assert torch.equal(w2.grad, ops.gemm_raw(g, (s * x).detach(), transA=True))
+    # forward value: leaky_relu_0.2 of the two products (fp32 association of the accumulate epilogue: tolerance)
+    ref = torch.nn.functional.leaky_relu(s.detach() @ w1.detach().t() + (s * x).detach() @ w2.detach().t(), 0.2)
+    assert torch.allclose(y.detach(), ref, rtol=1e-4, atol=1e-5)
