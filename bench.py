@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+STEADY_EVALS = 6                     # carried-threshold evaluations (one per epoch) before the timed one
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md matrix-core table
 TRAINED_STEPS = 5000            # ~32 epochs of the sports-sized graph: embeddings in a trained state
 F32_MFMA_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_32x32x2_f32 dense peak
@@ -228,7 +229,7 @@ def spmm_kernel_name(D, adam=False):
 
 def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps_rank=5, synthetic=False):
     """One GPU, unsharded LightGCN: the timed training steps, the SpMM roofline, gene_ranklist.  -> dict."""
-    from chaorec_amd import ops
+    from chaorec_amd import ops, ranking
     from chaorec_amd.Model import LightGCN
     from chaorec_amd.optim import FusedAdam, FusedLightGCNStep, GraphedTrainStep
     L, B, reg = args.n_layers, args.batch, 1e-3
@@ -364,9 +365,10 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
 
     # --- full-rank evaluation ---------------------------------------------------------------------------------
     # Two states of the same call.  COLD: no thresholds carried (the first evaluation of a run): sampled thresholds.
-    # STEADY: the evaluation loop's state (train_and_evaluate.py:655-659 ranks once per epoch) from its third evaluation
-    # on: per-user thresholds left by the evaluation one epoch (E // B steps) EARLIER, which itself ran on carried
-    # thresholds; light mode as ranking.RankState decides it from the previous call's queue lengths.  Every timed repetition starts from the same epoch-old thresholds (a copy is put
+    # STEADY: the evaluation loop's state (train_and_evaluate.py:655-659 ranks once per epoch) a few epochs into a run
+    # (evaluation STEADY_EVALS + 2): per-user thresholds left by the evaluation one epoch (E // B steps) EARLIER, which
+    # itself ran on carried thresholds -- the users whose thresholds failed in the first carried evaluations have been
+    # given wider ones by then; light mode as ranking.RankState decides it from the previous call's queue lengths.  Every timed repetition starts from the same epoch-old thresholds (a copy is put
     # back first; its 116 KB device copy is inside the timed region).
     epoch_steps = max(E // B, 1)
 
@@ -390,14 +392,15 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, stats=st)
             out["cold_st"] = st
             if with_steady:
-                hint_rank = 100                              # (ranking.gene_ranklist: 2 K)
+                hint_rank = ranking.hint_rank_for(50)        # (what ranking.gene_ranklist passes: 2.2 K)
                 old = torch.empty(U, dtype=torch.float32, device=dev)
                 counters = torch.zeros(4, dtype=torch.int32, device=dev)
                 ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=False, hint_rank=hint_rank)
-                run_steps(epoch_steps)                       # one epoch of training between two evaluations
-                res = model.result.detach()
-                ops.score_topk(res[:U], res[U:U + I], model.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=True,
-                               hint_rank=hint_rank, counters=counters)   # `old` now: thresholds left by a CARRIED evaluation
+                for _ in range(STEADY_EVALS):                # epochs of training, each followed by its evaluation
+                    run_steps(epoch_steps)
+                    res = model.result.detach()
+                    ops.score_topk(res[:U], res[U:U + I], model.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=True,
+                                   hint_rank=hint_rank, counters=counters)   # `old`: thresholds left by a CARRIED evaluation
                 queues_prev = counters.tolist()
                 run_steps(epoch_steps)
                 res = model.result.detach()
@@ -429,12 +432,13 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
 
     steps_done = warmup + steps
     early = time_ranklist(False)
-    extra = trained_steps - steps_done - 2 * epoch_steps
-    if extra > 0 and (extra + 2 * epoch_steps) * ms_per_step < 10_000:
+    extra = trained_steps - steps_done - (STEADY_EVALS + 1) * epoch_steps
+    if extra > 0 and (extra + (STEADY_EVALS + 1) * epoch_steps) * ms_per_step < 10_000:
         run_steps(extra)
         rk = time_ranklist(True)
-        state = (f"after {trained_steps} training steps ({extra + 2 * epoch_steps} of them untimed, past the measured ones); "
-                 f"steady = thresholds carried from the (carried-threshold) evaluation {epoch_steps} steps (one epoch) earlier")
+        state = (f"after {trained_steps} training steps ({extra + (STEADY_EVALS + 1) * epoch_steps} of them untimed, past the measured "
+                 f"ones); steady = evaluation number {STEADY_EVALS + 2} of a run that evaluates once per epoch ({epoch_steps} steps): "
+                 f"thresholds carried from the evaluation one epoch earlier")
     else:
         # (no trained state within the run's budget -- an epoch of the config-5 shard is 24 k steps --: the cold call
         #  only; thresholds carried across the first steps of training are stale by construction, ranking.RankState

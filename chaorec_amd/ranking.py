@@ -27,7 +27,7 @@ def _to_host(idx):
 
 class RankState:
     """What one model's evaluations carry from call to call: the per-user candidate thresholds of
-    chaorec_score_topk_hinted_f32 (each gene_ranklist() leaves, per user, the exact score of rank 2 K for the next
+    chaorec_score_topk_hinted_f32 (each gene_ranklist() leaves, per user, the exact score of rank 2.2 K for the next
     one: one epoch of training moves the scores little, so the next call needs no sampling pass and re-scores about
     half the candidates).  The thresholds never change a result; stale ones only cost a retry."""
 
@@ -85,6 +85,14 @@ class RankState:
         self.last_hinted = bool(hinted)
 
 
+def hint_rank_for(topk):
+    """The rank whose exact score becomes the next call's threshold: 2.2 K.  At 2 K a handful of sports' 28 940 users
+    (0-5 per epoch) drop below K candidates one epoch later and take the exact route, which costs the call 23 us
+    however few they are; at 2.2 K that queue is empty in most epochs, for 11 % more candidates (tools/score_profile.py
+    with HINT_RANKS)."""
+    return min(int(2.2 * topk), 128)
+
+
 def state_of(model):
     """The RankState of `model` (created on first use; kept out of state_dict / parameters)."""
     st = model.__dict__.get("_rank_state")
@@ -109,7 +117,7 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
             hinted = state.use_hints(num_user)
             idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
                                     id_offset=num_user, hint=hint, hint_valid=hinted,
-                                    hint_rank=min(2 * topk, 128), light=hinted and state.light(),
+                                    hint_rank=hint_rank_for(topk), light=hinted and state.light(),
                                     counters=state.counters, idx_out=host)
             state.after_call(hinted)
         else:
