@@ -60,6 +60,11 @@ class FREEDOM(nn.Module):
         self.text_embedding = nn.Embedding.from_pretrained(self.t_feat, freeze=False)
         self.image_trs = nn.Linear(self.v_feat.shape[1], self.dim_feat)
         self.text_trs = nn.Linear(self.t_feat.shape[1], self.dim_feat)
+        # the feature tables are read only through ops.linear_rows (the batch rows of their projection): an optimizer
+        # that knows how (optim.FusedAdam) may update them without ever forming their dense [I, K] gradient
+        self.image_embedding.weight._chaorec_rows_only = True
+        self.text_embedding.weight._chaorec_rows_only = True
+        self._batch_idx = None
 
         rowptr, col = graph.user_hist_csr(user_item_dict, num_user)
         self.hist = (rowptr.to(device), col.to(device))
@@ -197,15 +202,20 @@ class FREEDOM(nn.Module):
         ua_embeddings, ia_embeddings = self.forward(self.masked_adj)
         batch_mf_loss = ops.bpr_loss(ua_embeddings, ia_embeddings, users, pos_items, neg_items,
                                      ops.VARIANT_LOGSIGMOID, 0.0)[0]
+        # Model/FREEDOM.py:208-213 project the WHOLE feature table and read the batch rows of the result; a row of a
+        # Linear depends on that row alone, so only the rows of the batch are projected (ops.linear_rows)
         mf_v_loss, mf_t_loss = 0.0, 0.0
+        B = users.shape[0]
+        rows = torch.cat((pos_items, neg_items), 0)
+        if self._batch_idx is None or self._batch_idx.shape[0] != B or self._batch_idx.device != users.device:
+            self._batch_idx = torch.arange(B, device=users.device)
+        idx = self._batch_idx
         if self.t_feat is not None:
-            text_feats = ops.linear(self.text_embedding.weight, self.text_trs.weight, self.text_trs.bias)
-            mf_t_loss = ops.bpr_loss(ua_embeddings, text_feats, users, pos_items, neg_items,
-                                     ops.VARIANT_LOGSIGMOID, 0.0)[0]
+            text_rows = ops.linear_rows(self.text_embedding.weight, rows, self.text_trs.weight, self.text_trs.bias)
+            mf_t_loss = ops.bpr_loss(ua_embeddings, text_rows, users, idx, idx + B, ops.VARIANT_LOGSIGMOID, 0.0)[0]
         if self.v_feat is not None:
-            image_feats = ops.linear(self.image_embedding.weight, self.image_trs.weight, self.image_trs.bias)
-            mf_v_loss = ops.bpr_loss(ua_embeddings, image_feats, users, pos_items, neg_items,
-                                     ops.VARIANT_LOGSIGMOID, 0.0)[0]
+            image_rows = ops.linear_rows(self.image_embedding.weight, rows, self.image_trs.weight, self.image_trs.bias)
+            mf_v_loss = ops.bpr_loss(ua_embeddings, image_rows, users, idx, idx + B, ops.VARIANT_LOGSIGMOID, 0.0)[0]
         return batch_mf_loss + self.reg_weight * (mf_t_loss + mf_v_loss)
 
     def gene_ranklist(self, topk=50, to_cpu=True):

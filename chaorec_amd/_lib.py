@@ -12,12 +12,12 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libchaorec_hip.so")
 SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip", "gemm_bf16x3.hip", "metrics.hip", "graph_dropout.hip",
-           "rowops.hip"]
+           "rowops.hip", "feature_adam.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -114,6 +114,14 @@ SIGNATURES = {
                                                     c_ptr, c_ptr]),
     "chaorec_leaky_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_float, c_ptr, ctypes.c_int64, c_ptr]),
     "chaorec_mul_pair_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
+    "chaorec_adam_lowrank_strips": (ctypes.c_int32, [ctypes.c_int32]),
+    "chaorec_adam_bias_table": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_float, ctypes.c_float, c_ptr]),
+    "chaorec_adam_lowrank_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_float, ctypes.c_int32, c_ptr, ctypes.c_int32,
+                                                c_ptr, c_ptr, ctypes.c_int32, c_ptr, c_ptr, ctypes.c_int32,
+                                                ctypes.c_int32, c_ptr]),
+    "chaorec_unique_rows": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 
 

@@ -317,9 +317,12 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   p.splits = 1;
   // few output tiles and a long reduction (weight gradients: K = number of graph nodes): split K so that the
   // chip is filled, partial sums go to slabs and are added in a fixed order
-  if (tiles < 128 && K >= 4096) {
+  // (from K = 2048 on: the weight gradient of a projection over the 2 B gathered rows of a batch, ops.linear_rows,
+  // is [64, 4096] from a reduction of 2048 -- 32 tiles on 256 CUs without the split)
+  if (tiles < 128 && K >= 2048) {
     int64_t s = (1024 + tiles - 1) / tiles;     // ~4 workgroups per CU
-    if (s > K / 256) s = K / 256;               // at least 16 k-tiles per workgroup
+    const int64_t min_k = K >= 4096 ? 256 : 128;
+    if (s > K / min_k) s = K / min_k;           // at least 16 (8 below K = 4096) k-tiles per workgroup
     if (s > 256) s = 256;
     if (s < 1) s = 1;
     p.splits = (int)s;

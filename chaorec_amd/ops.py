@@ -559,6 +559,118 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999
     _lib.check(rc, "chaorec_adam_step_f32")
 
 
+def adam_bias_table(n_steps, betas, device):
+    """float [n_steps, 2]: (1 - beta1^s, sqrt(1 - beta2^s)) per step s (entry 0 unused), computed by the device with the
+    same double-precision expression every Adam launch uses for its own step."""
+    t = torch.empty((int(n_steps), 2), dtype=torch.float32, device=device)
+    _lib.check(_lib.load().chaorec_adam_bias_table(_ptr(t), int(n_steps), betas[0], betas[1], _stream()),
+               "chaorec_adam_bias_table")
+    return t
+
+
+def unique_rows(rows, claim, stamp_dev, out_list, out_count):
+    """out_list[0 .. out_count[0]) = the distinct ids in `rows` (int64, duplicates allowed), any order; `claim` int32
+    [n_rows] and `stamp_dev` int32 [1]: scratch the launches keep between them (zero-initialised once)."""
+    _need_cuda(rows, claim, stamp_dev, out_list, out_count)
+    rows = rows.to(torch.int64).contiguous()
+    if out_list.numel() < rows.numel():
+        raise ValueError("unique_rows: the list must hold as many ids as `rows`")
+    _lib.check(_lib.load().chaorec_unique_rows(_ptr(rows), rows.numel(), _ptr(claim), _ptr(stamp_dev), _ptr(out_list),
+                                               _ptr(out_count), _stream()), "chaorec_unique_rows")
+
+
+def adam_lowrank_strips(K):
+    return int(_lib.load().chaorec_adam_lowrank_strips(int(K)))
+
+
+def adam_lowrank(param, gy, weight, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 step_dev=None, mode=0, last=None, bc_table=None, rowlist=None, rows_given=True):
+    """Adam on a feature table [n, K] whose gradient is gy [n, R] @ weight [R, K], never materialised
+    (chaorec_adam_lowrank_f32).  mode 0: every row, every step; 1: only the rows with a non-zero gy row, after they
+    caught up on the zero-gradient steps they sat out (`last` int32 [strips, n]); 2: flush -- every row catches up;
+    3: the rows flagged by a non-zero row of `gy` catch up (before a forward reads them).
+    rowlist (modes 1, 3): (list int32 [cap], count int32 [1]); rows_given: filled by unique_rows -- visit exactly these
+    rows; else scratch (cap >= n) the launch fills with the rows whose gy (flag) row is non-zero."""
+    _need_cuda(param, exp_avg, exp_avg_sq, step_dev, last, bc_table)
+    if rowlist is None and mode in (1, 3):               # scratch for the launch's own row scan
+        rowlist = (torch.empty(param.shape[0], dtype=torch.int32, device=param.device),
+                   torch.empty(1, dtype=torch.int32, device=param.device))
+        rows_given = False
+    rl, rc_, cap = (rowlist[0], rowlist[1], rowlist[0].numel()) if rowlist is not None else (None, None, 0)
+    _need_cuda(rl, rc_)
+    n, K = param.shape
+    R = 1
+    if mode <= 1:
+        _need_cuda(gy, weight)
+        gy, weight = _f32c(gy), _f32c(weight)
+        if tuple(gy.shape) != (n, weight.shape[0]) or weight.shape[1] != K:
+            raise ValueError(f"adam_lowrank: param {tuple(param.shape)} gy {tuple(gy.shape)} weight {tuple(weight.shape)}")
+        R = weight.shape[0]
+    elif mode == 3 and gy is not None:
+        _need_cuda(gy)
+        gy = _f32c(gy)                                   # row flags [n, R]
+        if gy.dim() != 2 or gy.shape[0] != n:
+            raise ValueError(f"adam_lowrank: flags {tuple(gy.shape)} for a table of {n} rows")
+        R = gy.shape[1]
+    if not (param.is_contiguous() and exp_avg.is_contiguous() and exp_avg_sq.is_contiguous()):
+        raise ValueError("adam_lowrank: contiguous tables")
+    rc = _lib.load().chaorec_adam_lowrank_f32(_ptr(param), _ptr(gy if mode != 2 else None),
+                                              _ptr(weight if mode <= 1 else None), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                              n, K, R, lr, betas[0], betas[1], eps, weight_decay, int(step),
+                                              _ptr(step_dev), int(mode), _ptr(last), _ptr(bc_table),
+                                              0 if bc_table is None else bc_table.shape[0], _ptr(rl), _ptr(rc_), cap,
+                                              int(bool(rows_given)), _stream())
+    _lib.check(rc, "chaorec_adam_lowrank_f32")
+
+
+class _LinearRows(torch.autograd.Function):
+    """y = (x W^T + b)[rows], computed on the gathered rows only (a row of a Linear depends on that row alone).
+    Model/FREEDOM.py:209-213 projects the whole trainable feature table every step and then reads the 2 B rows of the
+    batch: 2 B x K instead of I x K of reads, and a gradient  gy W  that is non-zero in those rows only.  When the
+    optimizer has claimed x (optim.FusedAdam, chaorec_adam_lowrank_f32) the [I, K] gradient is never formed: the
+    optimizer receives gy (scattered to [I, R]) and W instead; otherwise x.grad is the usual dense tensor."""
+
+    @staticmethod
+    def forward(ctx, x, rows, weight, bias):
+        sink = getattr(x, "_chaorec_lowrank_sink", None)
+        ctx.row_token = None
+        if sink is not None and sink.lazy_rows and sink.accepts(x):
+            ctx.row_token = sink.catch_up(x, rows)       # lazily updated table: these rows must be current first
+        xg = x.index_select(0, rows)
+        if LINEAR_FORWARD == "bf16x3" and xg.shape[1] >= 64 and xg.shape[0] >= 256:
+            y = gemm_nt_bf16x3(xg, weight, bias=bias)
+        else:
+            y = gemm_raw(xg, weight, transB=True, bias=bias)
+        ctx.save_for_backward(xg, rows, weight)
+        ctx.x_param, ctx.has_bias = x, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xg, rows, weight = ctx.saved_tensors
+        x = ctx.x_param
+        gy = gy.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gy_full = torch.zeros((x.shape[0], gy.shape[1]), dtype=gy.dtype, device=gy.device)
+            gy_full.index_add_(0, rows, gy)              # an item can sit in the batch more than once
+            sink = getattr(x, "_chaorec_lowrank_sink", None)
+            if sink is not None and sink.accepts(x):
+                sink.submit(x, gy_full, weight, ctx.row_token)
+            elif LINEAR_FORWARD == "bf16x3" and weight.shape[0] >= 64 and gy_full.shape[0] >= 256:
+                gx = gemm_nt_bf16x3(gy_full, weight.t().contiguous())
+            else:
+                gx = gemm_raw(gy_full, weight)
+        gw = gemm_raw(gy, xg, transA=True) if ctx.needs_input_grad[2] else None
+        gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return gx, None, gw, gb
+
+
+def linear_rows(x, rows, weight, bias=None):
+    """== linear(x, weight, bias)[rows]"""
+    return _LinearRows.apply(x, rows, weight, bias)
+
+
 class _SpMMAdd(torch.autograd.Function):
     """y = A x + z in one launch (FREEDOM's `i_g_embeddings + h`, Model/FREEDOM.py:168,181)."""
 

@@ -7,6 +7,8 @@ GraphedTrainStep: captures zero_grad -> model.loss -> backward -> optimizer.step
 torch.cuda.CUDAGraph: every chaorec kernel is enqueued on the capturing stream) and replays it per batch from
 static input buffers: the launch-bound inner loop of train_and_evaluate.py:43-48 without per-kernel host cost.
 """
+import os
+
 import torch
 
 from . import ops
@@ -28,10 +30,103 @@ def _adjacent_run(first, candidates):
     return run or [first]
 
 
+BIAS_TABLE_STEPS = 1 << 16
+
+
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam (main.py:397) as one launch per parameter run, step count on the device.
+
+    Feature tables that a model marks `_chaorec_rows_only` (read only through ops.linear_rows: FREEDOM's trainable image
+    / text features, Model/FREEDOM.py:59-60, 209-213) are claimed: their [I, K] gradient is never materialised, the
+    update comes from chaorec_adam_lowrank_f32 (gy [I, R] and the projection weight instead).  `lazy_rows=True` (env
+    CHAOREC_LAZY_ADAM=1) additionally defers the zero-gradient updates of rows outside the batch until the row is next
+    in a batch -- replayed then operation for operation, so after flush() the tables are bit-identical to the eager
+    ones; between flushes rows outside the recent batches are stale (state_dict() flushes)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lazy_rows=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step_dev = None
+        self.lazy_rows = (os.environ.get("CHAOREC_LAZY_ADAM", "0") == "1") if lazy_rows is None else bool(lazy_rows)
+        self._pending = {}      # claimed parameter -> [gy_full, projection weight] of the backward that just ran
+        self._claimed = {}      # id(parameter) -> its group
+        self._bc_table = None
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "_chaorec_rows_only", False) and p.dim() == 2 and p.shape[1] % 4 == 0 \
+                        and p.dtype == torch.float32 and p.is_contiguous():
+                    p._chaorec_lowrank_sink = self
+                    self._claimed[id(p)] = group
+
+    # -- the sink side of ops.linear_rows' backward -------------------------------------------------------------
+    def accepts(self, p):
+        return id(p) in self._claimed and p.is_cuda
+
+    def submit(self, p, gy_full, weight, row_token=None):
+        if weight.shape[0] > 64:
+            raise ValueError("FusedAdam: a claimed feature table needs a projection of at most 64 outputs")
+        cur = self._pending.get(p)
+        if cur is None:
+            self._pending[p] = [gy_full, weight, row_token]
+        else:
+            if cur[1] is not weight:
+                raise ValueError("FusedAdam: one claimed feature table, two different projections")
+            cur[0] = cur[0] + gy_full            # gradient accumulation over several backward() calls
+            cur[2] = None                        # (more than one batch: the step scans gy for the rows instead)
+
+    def zero_grad(self, set_to_none=True):
+        self._pending.clear()
+        super().zero_grad(set_to_none=set_to_none)
+
+    def _lowrank_state(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        if self.lazy_rows and "last" not in st:
+            strips = ops.adam_lowrank_strips(p.shape[1])
+            st["last"] = self._step_dev.to(torch.int32).expand(strips * p.shape[0]).contiguous().view(strips, p.shape[0])
+            st["claim"] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)   # chaorec_unique_rows' scratch
+            st["stamp"] = torch.zeros(1, dtype=torch.int32, device=p.device)
+            st["rowcount"] = torch.zeros(1, dtype=torch.int32, device=p.device)
+            st["list_gen"] = 0
+            if self._bc_table is None:
+                self._bc_table = ops.adam_bias_table(BIAS_TABLE_STEPS, self.param_groups[0]["betas"], p.device)
+        return st
+
+    @torch.no_grad()
+    def catch_up(self, p, rows):
+        """Lazy rows: replay the zero-gradient steps the given rows of a claimed table sat out."""
+        st = self.state.get(p)
+        if not st or "last" not in st:
+            return
+        group = self._claimed[id(p)]
+        # the distinct rows of the batch, listed once: this catch-up and the step's update visit exactly them
+        rl = st.get("rowlist")
+        if rl is None or rl.numel() < rows.numel():
+            rl = st["rowlist"] = torch.zeros(rows.numel(), dtype=torch.int32, device=p.device)
+        ops.unique_rows(rows, st["claim"], st["stamp"], rl, st["rowcount"])
+        st["list_gen"] += 1
+        ops.adam_lowrank(p.data, None, None, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
+                         group["eps"], group["weight_decay"], step_dev=self._step_dev, mode=3, last=st["last"],
+                         bc_table=self._bc_table, rowlist=(rl, st["rowcount"]))
+        return st["list_gen"]
+
+    @torch.no_grad()
+    def flush(self):
+        """Bring every lazily updated row up to the current step (no-op without lazy_rows)."""
+        if not self.lazy_rows or self._step_dev is None:
+            return
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if id(p) in self._claimed and st and "last" in st:
+                    ops.adam_lowrank(p.data, None, None, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
+                                     group["eps"], group["weight_decay"], step_dev=self._step_dev, mode=2,
+                                     last=st["last"], bc_table=self._bc_table)
+
+    def state_dict(self):
+        self.flush()
+        return super().state_dict()
 
     def _ensure_state(self, live):
         """Moments for the parameters of `live` that have none yet.  Parameters that sit back to back in one buffer
@@ -58,8 +153,25 @@ class FusedAdam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             self._ensure_state([p for p in group["params"] if p.grad is not None])
+        if self._pending and self._step_dev is None:
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=next(iter(self._pending)).device)
+        for p in self._pending:
+            self._lowrank_state(p)
         if self._step_dev is not None:
             self._step_dev.add_(1)
+        # claimed feature tables first: their update reads the projection weight of THIS step, which the loop below
+        # updates
+        for p, (gy_full, weight, row_token) in self._pending.items():
+            group, st = self._claimed[id(p)], self.state[p]
+            # the row list of this batch's catch-up serves the update too (the gradient is zero in every other row) --
+            # unless another forward has re-listed since: then the update finds its rows by scanning gy
+            rl = None
+            if self.lazy_rows and row_token is not None and row_token == st.get("list_gen"):
+                rl = (st["rowlist"], st["rowcount"])
+            ops.adam_lowrank(p.data, gy_full, weight, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
+                             group["eps"], group["weight_decay"], step_dev=self._step_dev,
+                             mode=1 if self.lazy_rows else 0, last=st.get("last"), bc_table=self._bc_table, rowlist=rl)
+        self._pending.clear()
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
             i = 0
@@ -126,7 +238,10 @@ class GraphedTrainStep:
                 for k, v in optimizer.state.get(p, {}).items():
                     if torch.is_tensor(v):                 # in place: the captured graph holds these addresses
                         old = had_state.get(id(p), {}).get(k)
-                        v.copy_(old) if old is not None else v.zero_()
+                        if old is None and k == "last" and saved_step is not None:
+                            v.copy_(saved_step.expand_as(v))       # (lazy rows: "current for the step count so far")
+                        else:
+                            v.copy_(old) if old is not None else v.zero_()
             if getattr(optimizer, "_step_dev", None) is not None:
                 optimizer._step_dev.copy_(saved_step) if saved_step is not None else optimizer._step_dev.zero_()
         self.graph = torch.cuda.CUDAGraph()

@@ -159,6 +159,8 @@ def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epoc
             print("Early stopping")
             break
 
+    if hasattr(optimizer, "flush"):
+        optimizer.flush()          # lazily updated feature rows (optim.FusedAdam lazy_rows): current before anyone reads them
     best_metrics = early_stopping.best_metrics
     _log_metrics('Best Test Metrics:', best_metrics)
     return best_metrics

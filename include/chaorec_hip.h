@@ -26,14 +26,15 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 6   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 7   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
                                   stand-alone BPR finalize with loss / optimizer bookkeeping, layer mean in the last
                                   forward SpMM, scoring with carried thresholds, split-bf16 NT GEMM;
                                   5: weighted_sample_keys (sharded edge pruning);
-                                  6: BPR batch at an offset + one finalize for k captured steps, NGCF elementwise backward */
+                                  6: BPR batch at an offset + one finalize for k captured steps, NGCF elementwise backward;
+                                  7: Adam over a feature table with a low-rank, row-sparse gradient (dense / lazy / flush) */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -398,6 +399,50 @@ int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, const float
 int chaorec_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                           int64_t n, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int32_t step, const int32_t *step_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Adam over a trainable feature table whose gradient is  G = gy W  (rank R <= 64, non-zero in the few rows of the batch).
+ *
+ * Replaces: the dense [n_rows, K] gradient of nn.Embedding.from_pretrained(feat, freeze=False).weight behind
+ *           trs(feat.weight)[pos | neg] (Model/FREEDOM.py:59-60, 209-213: autograd materialises gy W, 186 MB at
+ *           clothing size) + torch.optim.Adam streaming it (main.py:397).
+ *
+ * param, exp_avg, exp_avg_sq [n_rows, K] (K % 4 == 0, 16-byte aligned); gy [n_rows, R] = gradient with respect to the
+ * projection's output (zero rows for items outside the batch); W [R, K] = the projection's weight (nn.Linear layout).
+ *   g[n, c] = fmaf chain over r ascending of gy[n, r] * W[r, c], starting from +0; a row whose gy row is all zero takes
+ *   g = +0; then chaorec_adam_step_f32's arithmetic with t = *step_dev (or `step`).
+ * mode 0 (dense): every row is updated: the tables always equal what chaorec_adam_step_f32 on the dense gradient gives.
+ * mode 1 (lazy):  only rows with a non-zero gy row are read or written; such a row first replays the zero-gradient
+ *                 steps it sat out (last[strip, row] + 1 .. t - 1: same operations, order and bias corrections), then
+ *                 takes step t.  `last`: int32 [chaorec_adam_lowrank_strips(K), n_rows], initialised to the step count at
+ *                 which lazy updating starts.
+ * mode 2 (flush): every row catches up to step t inclusive with zero gradients and no new step (gy, W unused): after
+ *                 it the three tables are bit-identical to mode 0's.  Readers of `param` must flush first, or
+ * mode 3 (catch up): the same for the rows with a non-zero row in `gy` only (gy is then a flag array [n_rows, R], W
+ *                 unused): the rows of a batch, before its forward gathers them.
+ * bc_table (optional, float[2 * bc_len] from chaorec_adam_bias_table): (1 - beta1^s, sqrt(1 - beta2^s)) per step s,
+ * spares the replay two double-precision pow() per missed step; steps >= bc_len are computed in the launch.
+ * rowlist / rowcount / rowcap (modes 1 and 3): these modes walk a list of distinct rows (int32 ids in device memory,
+ * *rowcount <= rowcap of them).  rows_given != 0: the caller filled it (chaorec_unique_rows over the batch's item ids)
+ * and the launch visits exactly these rows -- a listed row whose gy row is zero takes the step with g = +0 (mode 1),
+ * which is what mode 0 does to it; mode 3 then needs no flag array (gy may be NULL).  rows_given == 0: the launch
+ * fills the list itself with the rows whose gy (or flag) row is non-zero (rowcap >= n_rows).
+ *
+ * chaorec_unique_rows: list[0 .. *count) = the distinct values of rows[0 .. n) (item ids of a batch, duplicates
+ * allowed), order unspecified.  claim: int32 [n_rows] scratch and stamp_dev: int32 [1], both zero-initialised once and
+ * then left to the launches: each one takes the stamp *stamp_dev + 1, marks the rows it lists with it and stores it
+ * back, so nothing is cleared between launches (also not between replays of a captured hipGraph).  One workgroup:
+ * meant for batches of a few thousand ids.
+ * ------------------------------------------------------------------------------------- */
+int32_t chaorec_adam_lowrank_strips(int32_t K);
+int chaorec_adam_bias_table(float *table, int32_t n_steps, float beta1, float beta2, void *stream);
+int chaorec_unique_rows(const int64_t *rows, int64_t n, int32_t *claim, int32_t *stamp_dev, int32_t *list,
+                        int32_t *count, void *stream);
+int chaorec_adam_lowrank_f32(float *param, const float *gy, const float *W, float *exp_avg, float *exp_avg_sq,
+                             int64_t n_rows, int32_t K, int32_t R, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int32_t step, const int32_t *step_dev, int32_t mode, int32_t *last,
+                             const float *bc_table, int32_t bc_len, int32_t *rowlist, int32_t *rowcount,
+                             int32_t rowcap, int32_t rows_given, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Per-step edge dropout + symmetric renormalisation of a structure-static CSR (NGCF).

@@ -51,8 +51,22 @@ for spec in which:
     torch.cuda.synchronize()
     ms = (time.time() - t0) / 10 * 1e3
     t0 = time.time(); m.gene_ranklist(); torch.cuda.synchronize(); t_rank = time.time() - t0
+    if getattr(opt, "_claimed", None):
+        print(f"          feature tables claimed by FusedAdam (no dense [I,K] gradient), lazy_rows={opt.lazy_rows}")
     print(f"{name:9s} {ds:10s} feat=({v_feat.shape[1]},{t_feat.shape[1]}) build {t_build:6.2f} s  step {ms:8.2f} ms  "
           f"epoch({len(sampler)} batches) {ms * len(sampler) / 1e3:6.2f} s  gene_ranklist {t_rank * 1e3:7.2f} ms")
+    # the captured step on its own (what train_and_evaluate replays per batch): zero_grad + loss + backward + Adam
+    from chaorec_amd.optim import GraphedTrainStep
+    if name != "LightGCN":
+        gstep = GraphedTrainStep(m, opt, example_batch=batches[0])
+        for b in batches[:3]:
+            gstep(*b)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for i in range(100):
+            gstep(*batches[i % len(batches)])
+        torch.cuda.synchronize()
+        print(f"          captured step (hipGraph replay, batch copied in): {(time.time() - t0) / 100 * 1e3:7.3f} ms")
     # the real loop of train_and_evaluate.train_and_evaluate: one epoch incl. evaluation and device metrics
     from chaorec_amd import train_and_evaluate as tae
     from chaorec_amd.synthetic import synthetic_eval_lists
