@@ -207,15 +207,16 @@ class FREEDOM(nn.Module):
         mf_v_loss, mf_t_loss = 0.0, 0.0
         B = users.shape[0]
         rows = torch.cat((pos_items, neg_items), 0)
-        if self._batch_idx is None or self._batch_idx.shape[0] != B or self._batch_idx.device != users.device:
-            self._batch_idx = torch.arange(B, device=users.device)
-        idx = self._batch_idx
+        if self._batch_idx is None or self._batch_idx[0].shape[0] != B or self._batch_idx[0].device != users.device:
+            idx = torch.arange(B, device=users.device)
+            self._batch_idx = (idx, idx + B)
+        idx, idx_neg = self._batch_idx
         if self.t_feat is not None:
             text_rows = ops.linear_rows(self.text_embedding.weight, rows, self.text_trs.weight, self.text_trs.bias)
-            mf_t_loss = ops.bpr_loss(ua_embeddings, text_rows, users, idx, idx + B, ops.VARIANT_LOGSIGMOID, 0.0)[0]
+            mf_t_loss = ops.bpr_loss(ua_embeddings, text_rows, users, idx, idx_neg, ops.VARIANT_LOGSIGMOID, 0.0)[0]
         if self.v_feat is not None:
             image_rows = ops.linear_rows(self.image_embedding.weight, rows, self.image_trs.weight, self.image_trs.bias)
-            mf_v_loss = ops.bpr_loss(ua_embeddings, image_rows, users, idx, idx + B, ops.VARIANT_LOGSIGMOID, 0.0)[0]
+            mf_v_loss = ops.bpr_loss(ua_embeddings, image_rows, users, idx, idx_neg, ops.VARIANT_LOGSIGMOID, 0.0)[0]
         return batch_mf_loss + self.reg_weight * (mf_t_loss + mf_v_loss)
 
     def gene_ranklist(self, topk=50, to_cpu=True):

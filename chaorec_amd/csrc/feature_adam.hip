@@ -349,11 +349,15 @@ extern "C" int chaorec_adam_lowrank_f32(float *param, const float *gy, const flo
   const int strips = (K + kStripCols - 1) / kStripCols;
   if (mode == 0) {
     // streaming: 16 waves per workgroup (two workgroups per CU hold their 64 KB strips of W: 32 waves per CU keep enough
-    // 16-byte loads in flight), ~8 workgroups per CU over the whole grid, non-temporal accesses (every byte is touched
+    // 16-byte loads in flight), up to ~8 workgroups per CU over the whole grid, non-temporal accesses (every byte is touched
     // once): 246 -> 224 us at [11384, 4096] against 4-wave workgroups with plain loads
     constexpr int kWavesDense = 16;
     const int rows_per_pass = kWavesDense * kUnr;
-    const int64_t chunks0 = (2048 + strips - 1) / strips;
+    // (~0.5 MB of table traffic per workgroup, so that the 64 KB strip of W it stages first stays a small part of it;
+    // 4-wave workgroups were slower for the narrow [I, 384] text table too: 45 vs 35 us)
+    int64_t wgs = (6 * n_rows * (int64_t)K * 4) >> 19;
+    wgs = wgs < 256 ? 256 : (wgs > 2048 ? 2048 : wgs);
+    const int64_t chunks0 = (wgs + strips - 1) / strips;
     int64_t rows_per_wg = (n_rows + chunks0 - 1) / chunks0;
     rows_per_wg = (rows_per_wg + rows_per_pass - 1) / rows_per_pass * rows_per_pass;
     const int64_t chunks = (n_rows + rows_per_wg - 1) / rows_per_wg;
