@@ -612,7 +612,7 @@ class ShardedFREEDOM(nn.Module):
     (item degrees of the pruned graph by one all-reduce: UserShard.from_local)."""
 
     def __init__(self, full, bounds, world, rank, device, group=None, spmm_fn=None, mm_spmm_fn=None, bpr_fn=None,
-                 linear_fn=None, keys_fn=None, prune_seed=None):
+                 linear_rows_fn=None, keys_fn=None, prune_seed=None):
         super().__init__()
         import copy
         self.device, self.group, self.world, self.rank = device, group, world, rank
@@ -640,7 +640,13 @@ class ShardedFREEDOM(nn.Module):
         self._spmm_fn = spmm_fn or ops.spmm_raw
         self._mm_spmm = mm_spmm_fn or ops.spmm
         self._bpr = bpr_fn or ops.bpr_loss
-        self._linear = linear_fn or ops.linear
+        self._linear_rows = linear_rows_fn or ops.linear_rows
+        # the modality tables are read only through the batch rows of their projection (FREEDOM.loss): an optimizer that
+        # claims them (optim.FusedAdam) gets gy [I, R] + W instead of the dense [I, K] gradient -- and the ranks then sum
+        # THAT in sync_grads(): 2 x I x 64 floats per step over xGMI instead of I x (4096 + 384)
+        self.image_embedding.weight._chaorec_rows_only = True
+        self.text_embedding.weight._chaorec_rows_only = True
+        self._batch_idx = None
         self._keys_fn = keys_fn or ops.weighted_sample_keys
         self._prune_seed = int(prune_seed if prune_seed is not None else getattr(full, "_prune_seed", 0))
         self._prune_calls = 0
@@ -692,15 +698,33 @@ class ShardedFREEDOM(nn.Module):
         ua, ia = self.forward()
         V = ops.VARIANT_LOGSIGMOID
         total = self._bpr(ua, ia, users, pos, neg, V, 0.0)[0]
-        tf = self._linear(self.text_embedding.weight, self.text_trs.weight, self.text_trs.bias)
-        vf = self._linear(self.image_embedding.weight, self.image_trs.weight, self.image_trs.bias)
-        total = total + self.reg_weight * (self._bpr(ua, tf, users, pos, neg, V, 0.0)[0] +
-                                           self._bpr(ua, vf, users, pos, neg, V, 0.0)[0])
+        B = users.shape[0]
+        rows = torch.cat((pos, neg), 0)
+        if self._batch_idx is None or self._batch_idx[0].shape[0] != B or self._batch_idx[0].device != users.device:
+            idx = torch.arange(B, device=users.device)
+            self._batch_idx = (idx, idx + B)
+        idx, idx_neg = self._batch_idx
+        tf = self._linear_rows(self.text_embedding.weight, rows, self.text_trs.weight, self.text_trs.bias)
+        vf = self._linear_rows(self.image_embedding.weight, rows, self.image_trs.weight, self.image_trs.bias)
+        total = total + self.reg_weight * (self._bpr(ua, tf, users, idx, idx_neg, V, 0.0)[0] +
+                                           self._bpr(ua, vf, users, idx, idx_neg, V, 0.0)[0])
         return total / self.world
 
+    def _claimed_tables(self):
+        """The modality tables an optimizer has claimed (their gradient travels as gy [I, R], see __init__)."""
+        out = []
+        for p in (self.text_embedding.weight, self.image_embedding.weight):
+            sink = getattr(p, "_chaorec_lowrank_sink", None)
+            if sink is not None and sink.accepts(p):
+                out.append((p, sink))
+        return out
+
     def replicated_parameters(self):
-        """Parameters every rank holds whose gradients are PARTIAL after backward (item_embedding's is already summed)."""
-        return [p for m in (self.text_embedding, self.image_embedding, self.text_trs, self.image_trs) for p in m.parameters()]
+        """Parameters every rank holds whose DENSE gradients are partial after backward (item_embedding's is already
+        summed; a claimed modality table has no dense gradient)."""
+        claimed = {id(p) for p, _ in self._claimed_tables()}
+        return [p for m in (self.text_embedding, self.image_embedding, self.text_trs, self.image_trs)
+                for p in m.parameters() if id(p) not in claimed]
 
     def zero_grad(self, set_to_none=False):
         if self._bucket is None:
@@ -715,6 +739,10 @@ class ShardedFREEDOM(nn.Module):
             self._bucket.all_reduce(self.group)
         else:
             allreduce_grads(self.replicated_parameters(), self.group)
+        # claimed modality tables: the ranks' batches touch different rows -- sum the [I, R] row gradients (the update
+        # g = gy W is linear in gy), and let the optimizer find the touched rows in the sum, not in this rank's batch
+        for p, sink in self._claimed_tables():
+            sink.reduce_pending(p, lambda t: _all_reduce(t, self.group))
 
     def gene_ranklist(self, topk=50, gather=False):
         with torch.no_grad():

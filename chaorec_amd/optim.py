@@ -73,6 +73,14 @@ class FusedAdam(torch.optim.Optimizer):
             cur[0] = cur[0] + gy_full            # gradient accumulation over several backward() calls
             cur[2] = None                        # (more than one batch: the step scans gy for the rows instead)
 
+    def reduce_pending(self, p, reduce_fn):
+        """Multi-process training (dist.ShardedFREEDOM.sync_grads): sum the ranks' gy of a claimed table in place; the
+        rows to update are then the union of the ranks' batches, not this rank's list."""
+        cur = self._pending.get(p)
+        if cur is not None:
+            reduce_fn(cur[0])
+            cur[2] = None
+
     def zero_grad(self, set_to_none=True):
         self._pending.clear()
         super().zero_grad(set_to_none=set_to_none)

@@ -408,7 +408,60 @@ def _freedom_standins(oracle_mod):
     def keys(w, ids, seed, step):
         return torch.from_numpy(oracle_mod.race_keys(w.numpy(), seed, step, ids.numpy()).view(np.int64))
 
-    return dict(spmm_fn=_oracle_spmm, mm_spmm_fn=lambda csr, x: _Spmm.apply(x, csr), bpr_fn=bpr, linear_fn=F.linear, keys_fn=keys)
+    class _LinearRows(torch.autograd.Function):
+        """ops.linear_rows' contract on the CPU: (x W^T + b)[rows]; a claimed table's gradient leaves as gy [I, R] + W
+        through the sink (optim.FusedAdam's protocol), an unclaimed one's as the dense tensor."""
+        @staticmethod
+        def forward(ctx, x, rows, weight, bias):
+            xg = x.index_select(0, rows)
+            ctx.save_for_backward(xg, rows, weight)
+            ctx.x_param = x
+            return F.linear(xg, weight, bias)
+
+        @staticmethod
+        def backward(ctx, gy):
+            xg, rows, weight = ctx.saved_tensors
+            x = ctx.x_param
+            gy_full = torch.zeros((x.shape[0], gy.shape[1]), dtype=gy.dtype).index_add_(0, rows, gy)
+            sink = getattr(x, "_chaorec_lowrank_sink", None)
+            gx = None
+            if sink is not None and sink.accepts(x):
+                sink.submit(x, gy_full, weight, None)
+            else:
+                gx = gy_full @ weight
+            return gx, None, gy.t() @ xg, gy.sum(0)
+
+    return dict(spmm_fn=_oracle_spmm, mm_spmm_fn=lambda csr, x: _Spmm.apply(x, csr), bpr_fn=bpr,
+                linear_rows_fn=_LinearRows.apply, keys_fn=keys)
+
+
+class _CpuRowSink:
+    """The optimizer side of the claimed-table protocol (optim.FusedAdam: accepts / submit / reduce_pending), in torch:
+    after the ranks' sum, the dense gradient a claimed table WOULD have had is gy_full @ W."""
+    lazy_rows = False
+
+    def __init__(self, params):
+        self._pending = {}
+        self.ids = {id(p) for p in params}
+        for p in params:
+            p._chaorec_lowrank_sink = self
+
+    def accepts(self, p):
+        return id(p) in self.ids
+
+    def submit(self, p, gy_full, weight, token=None):
+        assert p not in self._pending
+        self._pending[p] = [gy_full, weight, token]
+
+    def reduce_pending(self, p, reduce_fn):
+        cur = self._pending.get(p)
+        if cur is not None:
+            reduce_fn(cur[0])
+            cur[2] = None
+
+    def dense_gradient(self, p):
+        gy_full, weight, _ = self._pending[p]
+        return (gy_full @ weight).detach()
 
 
 def _freedom_batch(m, rank, B=40):
@@ -420,7 +473,7 @@ def _freedom_batch(m, rank, B=40):
     return users, pos, neg
 
 
-def _freedom_worker(rank, world, port, tmp, dropout):
+def _freedom_worker(rank, world, port, tmp, dropout, claimed=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -431,6 +484,8 @@ def _freedom_worker(rank, world, port, tmp, dropout):
     full, edges = _freedom_full(dropout)
     bounds = cdist.partition_users_by_nnz(np.bincount(edges[:, 0], minlength=full.num_user), world)
     m = cdist.ShardedFREEDOM(full, bounds, world, rank, torch.device("cpu"), **_freedom_standins(oracle_mod))
+    tables = [m.text_embedding.weight, m.image_embedding.weight]
+    sink = _CpuRowSink(tables) if claimed else None
     m.pre_epoch_processing()
     m.pre_epoch_processing()                               # the second epoch's draw (step 1)
     users, pos, neg = _freedom_batch(m, rank)
@@ -438,27 +493,36 @@ def _freedom_worker(rank, world, port, tmp, dropout):
     loss = m.loss(users, pos, neg)
     loss.backward()
     m.sync_grads()
+    if claimed:
+        # no dense gradient was formed or exchanged for the tables: what travelled is gy [I, R]
+        assert all(p.grad is None for p in tables) and not any(p is t for p in m.replicated_parameters() for t in tables)
+        grads = {n: (sink.dense_gradient(p) if any(p is t for t in tables) else p.grad).numpy()
+                 for n, p in m.named_parameters()}
+    else:
+        grads = {n: p.grad.numpy() for n, p in m.named_parameters()}
     kept = np.stack([m.shard.local_edges[:, 0] + m.u0, m.shard.local_edges[:, 1] - m.num_user], 1)
     np.savez(os.path.join(tmp, f"fr{rank}.npz"), u0=m.u0, u1=m.u1, loss=float(loss), users=users.numpy() + m.u0,
              pos=pos.numpy(), neg=neg.numpy(), res=m.result.detach().numpy(), kept=kept,
-             **{"g_" + n: p.grad.numpy() for n, p in m.named_parameters()})
+             **{"g_" + n: v for n, v in grads.items()})
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dropout", [0.2, 0.0])
-def test_sharded_freedom_matches_single_process(oracle, dropout):
+@pytest.mark.parametrize("dropout,claimed", [(0.2, False), (0.0, False), (0.2, True)])
+def test_sharded_freedom_matches_single_process(oracle, dropout, claimed):
     """BASELINE north_star "FREEDOM-style": FREEDOM sharded by user rows (2 gloo ranks, CPU stand-ins for the kernels):
     the per-epoch pruning keeps exactly the single-process edge set (race keys numbered over the whole edge list, k-th
     smallest key by a distributed radix select), representations, loss, and every gradient -- user rows, the item rows
     summed inside the backward, the modality tables and transforms after sync_grads() -- equal the plain-torch
-    restatement of Model/FREEDOM.py:164-217 on the whole graph."""
+    restatement of Model/FREEDOM.py:164-217 on the whole graph.  `claimed`: the modality tables' gradients travel as
+    gy [I, R] (an optimizer claimed them, chaorec_adam_lowrank_f32's protocol): their sum over the ranks, times W, is the
+    same dense gradient -- at I x 64 instead of I x K floats per table on the wire."""
     from chaorec_amd import graph
     from chaorec_amd.Model.FREEDOM import FREEDOM
     from oracle.torch_ref import freedom_reference_loss
     world = 2
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_freedom_worker, args=(world, _free_port(), tmp, dropout), nprocs=world, join=True)
+        mp.spawn(_freedom_worker, args=(world, _free_port(), tmp, dropout, claimed), nprocs=world, join=True)
         r = [dict(np.load(os.path.join(tmp, f"fr{k}.npz"))) for k in range(world)]
     full, edges = _freedom_full(dropout)
     U, I = full.num_user, full.num_item

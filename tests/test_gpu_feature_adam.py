@@ -220,3 +220,30 @@ def test_freedom_claimed_step_captured_equals_eager(dev):
             res.append({k: v.detach().clone() for k, v in m.named_parameters()})
         for k in res[0]:
             assert torch.allclose(res[0][k], res[1][k], rtol=0, atol=1e-7), (lazy, k)
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_sharded_freedom_trains_like_freedom_with_claimed_tables(dev, lazy):
+    """dist.ShardedFREEDOM (one rank) + FusedAdam: the claimed tables' gy goes through sync_grads()' reduction hook, after
+    which the update finds its rows by scanning the summed gy (lazy: mode 1 without a list) -- same parameters as the
+    single-process FREEDOM + FusedAdam after six steps."""
+    from chaorec_amd import dist as cdist
+    from chaorec_amd.optim import FusedAdam
+    m, g, U, I = _freedom(dev, True)
+    sh = cdist.ShardedFREEDOM(m, [0, U], 1, 0, dev)
+    opt_m, opt_s = FusedAdam(m.parameters(), lr=1e-3), FusedAdam(sh.parameters(), lr=1e-3, lazy_rows=lazy)
+    assert len(opt_s._claimed) == 2
+    batches = _batches(g, U, I, 6, dev)
+    _train(m, opt_m, batches)
+    for b in batches:
+        sh.zero_grad()
+        loss = sh.loss(b[0], b[1] - U, b[2] - U)
+        loss.backward()
+        assert sh.image_embedding.weight.grad is None
+        assert not any(p is sh.image_embedding.weight for p in sh.replicated_parameters())
+        sh.sync_grads()
+        opt_s.step()
+    opt_s.flush()
+    ref = dict(m.named_parameters())
+    for n, p in sh.named_parameters():
+        assert torch.allclose(p, ref[n], rtol=0, atol=2e-6), n
