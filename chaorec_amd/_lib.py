@@ -121,6 +121,10 @@ SIGNATURES = {
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_int32, c_ptr, ctypes.c_int32,
                                                 c_ptr, c_ptr, ctypes.c_int32, c_ptr, c_ptr, ctypes.c_int32,
                                                 ctypes.c_int32, c_ptr]),
+    "chaorec_gemm_tn_bf16x3_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    "chaorec_gemm_tn_bf16x3": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_ptr, ctypes.c_size_t,
+                                              c_ptr]),
     "chaorec_unique_rows": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 

@@ -1,4 +1,5 @@
-// C[M,N] = A[M,K] . B[N,K]^T (+ bias, + leaky-relu) on the bf16 MFMA pipe at fp32-grade accuracy.
+// C[M,N] = A[M,K] . B[N,K]^T (+ bias, + leaky-relu), and C[M,N] = A[K,M]^T . B[K,N], on the bf16 MFMA pipe at fp32-grade
+// accuracy.
 //
 // Replaces the FORWARD of the modality projections and of every other nn.Linear on the path (y = x W^T + b:
 // Model/FREEDOM.py:59-60,209,212 image_trs / text_trs over the 4096- / 384-wide feature tables;
@@ -65,7 +66,13 @@ extern __global__ void gemm_reduce_slabs_kernel(const float *__restrict__ slabs,
                                                 const float *__restrict__ bias, int64_t M, int64_t N, int64_t ldc,
                                                 int accumulate, int act);
 
-__global__ __launch_bounds__(256) void gemm_nt_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
+// TN = false: A [M, K], B [N, K] (k contiguous in both: the forward and, through W^T, the input gradient of a Linear).
+// TN = true:  A [K, M], B [K, N] (the reduction runs over the ROWS of both operands: the weight gradient
+//             dW = gy^T x, Model/MMGCN.py's Linears over all graph nodes).  A thread then fetches a 4 (m) x 4 (k)
+//             block of A -- four float4 along m, one per k -- and a 4 (n) x 2 (k) block of B, transposes them in
+//             registers (a choice of components, no instructions) and writes the same k-major bf16 planes to LDS.
+template <bool TN>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                              float *__restrict__ C, const float *__restrict__ bias,
                                                              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                                              int64_t ldc, int act, int64_t k_per_split,
@@ -102,7 +109,32 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16x3_kernel(const float *__rest
     }
     return x;
   };
+  // TN: float4 along the m / n dimension of row k (zero past the matrix or past this slab's k range)
+  auto load4t = [&](const float *base, int64_t ld, int64_t k, int64_t col, int64_t n_cols, bool vec) -> float4 {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < ke && col < n_cols) {
+      const float *src = base + k * ld + col;
+      if (vec && col + 3 < n_cols) {
+        x = *reinterpret_cast<const float4 *>(src);
+      } else {
+        x.x = src[0];
+        if (col + 1 < n_cols) x.y = src[1];
+        if (col + 2 < n_cols) x.z = src[2];
+        if (col + 3 < n_cols) x.w = src[3];
+      }
+    }
+    return x;
+  };
+  const int a_mq = t & 31, a_kq = t >> 5;         // TN: A block = rows 4 a_mq .. +3, k 4 a_kq .. +3
+  const int b_nq = t & 15, b_kp = t >> 4;         // TN: B block = rows 4 b_nq .. +3, k 2 b_kp, 2 b_kp + 1
   auto fetch = [&](int64_t k0) __attribute__((always_inline)) {
+    if constexpr (TN) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ra[j] = load4t(A, lda, k0 + 4 * a_kq + j, m0 + 4 * a_mq, M, a_vec);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rb[j] = load4t(B, ldb, k0 + 2 * b_kp + j, n0 + 4 * b_nq, N, b_vec);
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int v = t + p * 256;                  // float4 index: row = v / 8, k4 = (v % 8) * 4
@@ -115,6 +147,31 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16x3_kernel(const float *__rest
     }
   };
   auto stash = [&]() __attribute__((always_inline)) {
+    if constexpr (TN) {
+      const float ax[4][4] = {{ra[0].x, ra[1].x, ra[2].x, ra[3].x}, {ra[0].y, ra[1].y, ra[2].y, ra[3].y},
+                              {ra[0].z, ra[1].z, ra[2].z, ra[3].z}, {ra[0].w, ra[1].w, ra[2].w, ra[3].w}};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint2 hh, mm, ll;
+        split3x4(make_float4(ax[i][0], ax[i][1], ax[i][2], ax[i][3]), hh, mm, ll);
+        // (tile row 4 mq + i is kept at LDS row 32 i + mq: a wave's 32 m-quads then write 32 consecutive LDS rows --
+        // with the natural order they are 4 rows = 320 B apart and land in two banks)
+        *reinterpret_cast<uint2 *>(&As[0][32 * i + a_mq][4 * a_kq]) = hh;
+        *reinterpret_cast<uint2 *>(&As[1][32 * i + a_mq][4 * a_kq]) = mm;
+        *reinterpret_cast<uint2 *>(&As[2][32 * i + a_mq][4 * a_kq]) = ll;
+      }
+      const float bx[4][2] = {{rb[0].x, rb[1].x}, {rb[0].y, rb[1].y}, {rb[0].z, rb[1].z}, {rb[0].w, rb[1].w}};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t h0, h1, m0_, m1, l0, l1;
+        split3(bx[i][0], h0, m0_, l0);
+        split3(bx[i][1], h1, m1, l1);
+        *reinterpret_cast<uint32_t *>(&Bs[0][16 * i + b_nq][2 * b_kp]) = h0 | (h1 << 16);
+        *reinterpret_cast<uint32_t *>(&Bs[1][16 * i + b_nq][2 * b_kp]) = m0_ | (m1 << 16);
+        *reinterpret_cast<uint32_t *>(&Bs[2][16 * i + b_nq][2 * b_kp]) = l0 | (l1 << 16);
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int v = t + p * 256;
@@ -148,9 +205,14 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16x3_kernel(const float *__rest
       Frag8 a[3], b[2][3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
-        a[pl].u = *reinterpret_cast<const uint4 *>(&As[pl][wave * 32 + r][ks + 8 * h]);
+        // LDS row of tile row (32 wave + r) resp. (32 j + r): the identity, or the TN stash's permutation
+        const int arow = TN ? (r & 3) * 32 + wave * 8 + (r >> 2) : wave * 32 + r;
+        a[pl].u = *reinterpret_cast<const uint4 *>(&As[pl][arow][ks + 8 * h]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][j * 32 + r][ks + 8 * h]);
+        for (int j = 0; j < 2; ++j) {
+          const int brow = TN ? (r & 3) * 16 + j * 8 + (r >> 2) : j * 32 + r;
+          b[j][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][brow][ks + 8 * h]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -212,9 +274,56 @@ static XPlan plan_x(int64_t M, int64_t N, int64_t K) {
   return p;
 }
 
+// weight gradients: outputs of a few tiles, reductions over all graph nodes -- up to 256 slabs of at least 128 k
+static XPlan plan_x_tn(int64_t M, int64_t N, int64_t K) {
+  XPlan p;
+  const int64_t tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
+  int64_t s = 1;
+  if (tiles < 512 && K >= 512) {
+    s = (1024 + tiles - 1) / tiles;
+    if (s > K / 128) s = K / 128;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+  }
+  int64_t per = (K + s - 1) / s;
+  per = (per + XBK - 1) / XBK * XBK;
+  p.k_per_split = per;
+  p.splits = (int)((K + per - 1) / per);
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
 }  // namespace chaorec
 
 using namespace chaorec;
+
+extern "C" size_t chaorec_gemm_tn_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const XPlan p = plan_x_tn(M, N, K);
+  return p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, int64_t M, int64_t N, int64_t K,
+                                      int64_t lda, int64_t ldb, int64_t ldc, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+  if (!A || !B || !C) return fail(CHAOREC_E_INVALID, "gemm_tn_bf16x3: NULL argument");
+  if (M < 0 || N < 0 || K <= 0 || lda < M || ldb < N || ldc < N) return fail(CHAOREC_E_INVALID, "gemm_tn_bf16x3: bad size");
+  if (M == 0 || N == 0) return CHAOREC_OK;
+  const XPlan p = plan_x_tn(M, N, K);
+  const size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace))
+    return fail(CHAOREC_E_WORKSPACE, "gemm_tn_bf16x3: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
+  const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
+  hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K, lda, ldb,
+                     ldc, 0, p.k_per_split, slabs);
+  int rc = check_launch("gemm_bf16x3_kernel<TN>");
+  if (rc || p.splits == 1) return rc;
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
+                     (const float *)nullptr, M, N, ldc, 0, 0);
+  return check_launch("gemm_reduce_slabs_kernel");
+}
 
 extern "C" size_t chaorec_gemm_nt_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -236,9 +345,9 @@ extern "C" int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, 
   hipStream_t st = (hipStream_t)stream;
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
-  hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
+  hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
                      p.k_per_split, slabs);
-  int rc = check_launch("gemm_nt_bf16x3_kernel");
+  int rc = check_launch("gemm_bf16x3_kernel<NT>");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
                      bias, M, N, ldc, 0, act);

@@ -495,16 +495,36 @@ def gemm_nt_bf16x3(x, weight, bias=None, act=0, out=None):
     return out
 
 
+def gemm_tn_bf16x3(gy, x, out=None):
+    """gy^T x  ([rows, M]^T [rows, N] -> [M, N]) on the bf16 MFMA pipe, three bf16 planes per fp32 operand
+    (chaorec_gemm_tn_bf16x3): the weight gradient of nn.Linear."""
+    _need_cuda(gy, x, out)
+    gy, x = _f32c(gy), _f32c(x)
+    K, M = gy.shape
+    N = x.shape[1]
+    if x.shape[0] != K:
+        raise ValueError(f"gemm_tn_bf16x3: row counts {K} vs {x.shape[0]}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.chaorec_gemm_tn_bf16x3_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    rc = lib.chaorec_gemm_tn_bf16x3(_ptr(gy), _ptr(x), _ptr(out), M, N, K, gy.shape[1], x.shape[1], out.shape[1],
+                                    _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "chaorec_gemm_tn_bf16x3")
+    return out
+
+
 # which pipe nn.Linear's FORWARD runs on: "bf16x3" (split-bf16 MFMA, fp32-grade accuracy, 2.7x the f32 matrix rate) or
-# "f32" (the exact k-ascending fmaf chain of chaorec_gemm_f32).  The backward GEMMs (k-major operands) stay on f32.
+# "f32" (the exact k-ascending fmaf chain of chaorec_gemm_f32); the backward GEMMs follow it.
 import os as _os
 LINEAR_FORWARD = _os.environ.get("CHAOREC_LINEAR_FORWARD", "bf16x3")
 
 
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) (nn.Linear [+ F.leaky_relu]): forward on the bf16 MFMA pipe (three bf16 planes per fp32
-    operand) where the reduction is long enough to pay for the split -- the input gradient likewise --, else and
-    for the weight gradient (a TN product over all rows) on the f32 MFMA pipe."""
+    operand) where the reduction is long enough to pay for the split -- the input gradient and the weight gradient
+    (a TN product over all rows) likewise --, else on the f32 MFMA pipe."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
@@ -537,7 +557,15 @@ class _Linear(torch.autograd.Function):
                 gx = gemm_nt_bf16x3(gy, weight.t().contiguous())
             else:
                 gx = gemm_raw(gy, weight)
-        gw = gemm_raw(gy, x, transA=True) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            # weight gradient gy^T x: a reduction over all rows -- the same split-bf16 pipe where its 128-row tile is
+            # not half padding (out >= 128: 768^2 over 60 k rows 994 -> 744 us, 256^2 128 -> 94 us; the 64-wide layers'
+            # gradients are faster on the f32 kernel's 64-row tile)
+            if LINEAR_FORWARD == "bf16x3" and gy.shape[0] >= 4096 and gy.shape[1] >= 128 and x.shape[1] >= 64:
+                gw = gemm_tn_bf16x3(gy, x)
+            else:
+                gw = gemm_raw(gy, x, transA=True)
         gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[2] else None     # (not gy.sum(0): see col_sum)
         return gx, gw, gb, None
 

@@ -34,7 +34,8 @@ extern "C" {
                                   forward SpMM, scoring with carried thresholds, split-bf16 NT GEMM;
                                   5: weighted_sample_keys (sharded edge pruning);
                                   6: BPR batch at an offset + one finalize for k captured steps, NGCF elementwise backward;
-                                  7: Adam over a feature table with a low-rank, row-sparse gradient (dense / lazy / flush) */
+                                  7: Adam over a feature table with a low-rank, row-sparse gradient (dense / lazy / flush), split-bf16 TN GEMM
+                                     (weight gradients) */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -388,6 +389,14 @@ size_t chaorec_gemm_nt_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, const float *bias, int64_t M, int64_t N,
                            int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t act, void *workspace,
                            size_t workspace_bytes, void *stream);
+
+/* The weight gradient of those Linears on the same pipe:  C[M, N] = A[K, M]^T B[K, N]  (A = the gradient of the layer's
+ * output, B = its input, K = the rows both run over -- every graph node for Model/MMGCN.py:97-131's layers), same
+ * three-plane split, same accuracy class, slabs along K summed in a fixed order (deterministic).  Replaces
+ * autograd's  grad_output.t() @ input  (an fp32 GEMM).  lda >= M, ldb >= N, ldc >= N. */
+size_t chaorec_gemm_tn_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                           int64_t ldb, int64_t ldc, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused Adam step over one flat fp32 parameter (torch.optim.Adam defaults, main.py:397):

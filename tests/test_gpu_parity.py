@@ -1044,6 +1044,27 @@ def test_gemm_nt_bf16x3_fp32_grade(dev, M, N, K, act, bias):
     assert torch.equal(got, ops.gemm_nt_bf16x3(x, w, bias=b, act=act))
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 64, 47001), (64, 768, 9000), (768, 768, 5000), (70, 130, 4099), (33, 61, 1234),
+                                   (256, 128, 640), (128, 4096, 2048)])
+def test_gemm_tn_bf16x3_fp32_grade(dev, M, N, K):
+    """The split-bf16 weight-gradient GEMM gy^T x (reduction over the rows of both operands, slabs along K): error
+    against an fp64 product bounded by 1e-6 * sum_k |a||b| per element, on average no worse than 1.5x the f32 kernel's,
+    bit-identical run to run; ragged sizes take the scalar fetch path."""
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(M + N + K)
+    gy = torch.randn(K, M, device=dev, generator=g) * torch.exp(torch.randn(K, 1, device=dev, generator=g))
+    x = torch.randn(K, N, device=dev, generator=g) * 0.05
+    got = ops.gemm_tn_bf16x3(gy, x)
+    ref = gy.double().t() @ x.double()
+    mass = gy.double().abs().t() @ x.double().abs()
+    err = (got.double() - ref).abs()
+    assert bool((err <= 1e-6 * mass + 1e-30).all()), float((err / (mass + 1e-30)).max())
+    f32 = ops.gemm_raw(gy, x, transA=True)
+    assert float(err.mean()) <= 1.5 * float((f32.double() - ref).abs().mean()) + 1e-12
+    assert torch.equal(got, ops.gemm_tn_bf16x3(gy, x))
+
+
 def test_linear_forward_pipes_agree(dev):
     """ops.linear on either pipe: same autograd contract, outputs equal to fp32 rounding, identical backward kernels."""
     from chaorec_amd import ops
