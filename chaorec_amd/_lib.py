@@ -125,6 +125,10 @@ SIGNATURES = {
     "chaorec_gemm_tn_bf16x3": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_ptr, ctypes.c_size_t,
                                               c_ptr]),
+    "chaorec_adam_multi_max": (ctypes.c_int32, []),
+    "chaorec_adam_multi_f32": (ctypes.c_int, [ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float,
+                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                              ctypes.c_int32, c_ptr, c_ptr]),
     "chaorec_unique_rows": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 

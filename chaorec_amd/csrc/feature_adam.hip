@@ -295,9 +295,100 @@ __global__ __launch_bounds__(WAVES * 64) void adam_lowrank_rows_kernel(LowrankAr
   }
 }
 
+// ---- many small parameters, one launch -------------------------------------------------------------------------
+// A model like MMGCN has ~50 parameter tensors of a few thousand elements: one Adam launch each is 50 x ~4.5 us of launch
+// latency per step.  The tensors' pointers travel BY VALUE in the kernel argument (no device-side table to keep in sync,
+// and a captured hipGraph bakes them in like any other argument); block b finds its tensor by the prefix of block counts.
+constexpr int kMultiMax = 48;
+constexpr int kMultiBlockElems = 4096;     // elements per block: 256 threads x 4 x float4
+
+struct AdamMultiArgs {
+  float *p[kMultiMax];
+  const float *g[kMultiMax];
+  float *m[kMultiMax];
+  float *v[kMultiMax];
+  int32_t n[kMultiMax];
+  int32_t first_block[kMultiMax + 1];
+  int count;
+  AdamConsts ac;
+  int step_host;
+  const int32_t *step_dev;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamMultiArgs a) {
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const int step = a.step_dev ? a.step_dev[0] : a.step_host;
+    adam_bias_corrections(step, a.ac.b1, a.ac.b2, bc[0], bc[1]);
+  }
+  int t = 0;                                          // largest t with first_block[t] <= blockIdx.x
+#pragma unroll 1
+  for (int hi = a.count; hi - t > 1;) {
+    const int mid = (t + hi) >> 1;
+    if ((int)blockIdx.x >= a.first_block[mid]) t = mid; else hi = mid;
+  }
+  __syncthreads();
+  const float bc1 = bc[0], bc2s = bc[1];
+  float *__restrict__ p = a.p[t];
+  const float *__restrict__ g = a.g[t];
+  float *__restrict__ m = a.m[t];
+  float *__restrict__ v = a.v[t];
+  const int n = a.n[t];
+  const int e0 = ((int)blockIdx.x - a.first_block[t]) * kMultiBlockElems;
+  const int e1 = e0 + kMultiBlockElems < n ? e0 + kMultiBlockElems : n;
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  if (vec) {
+    const int q1 = e0 + ((e1 - e0) & ~3);
+    for (int i = e0 + 4 * (int)threadIdx.x; i < q1; i += 1024) {
+      float4 pp = *reinterpret_cast<float4 *>(p + i), mm = *reinterpret_cast<float4 *>(m + i);
+      float4 vv = *reinterpret_cast<float4 *>(v + i);
+      const float4 gg = *reinterpret_cast<const float4 *>(g + i);
+      adam4(pp, gg, mm, vv, a.ac, bc1, bc2s);
+      *reinterpret_cast<float4 *>(m + i) = mm;
+      *reinterpret_cast<float4 *>(v + i) = vv;
+      *reinterpret_cast<float4 *>(p + i) = pp;
+    }
+    for (int i = q1 + (int)threadIdx.x; i < e1; i += 256) adam_update(p[i], g[i], m[i], v[i], a.ac, bc1, bc2s);
+  } else {
+    for (int i = e0 + (int)threadIdx.x; i < e1; i += 256) adam_update(p[i], g[i], m[i], v[i], a.ac, bc1, bc2s);
+  }
+}
+
 }  // namespace chaorec
 
 using namespace chaorec;
+
+extern "C" int32_t chaorec_adam_multi_max(void) { return kMultiMax; }
+
+extern "C" int chaorec_adam_multi_f32(int32_t count, float *const *param, const float *const *grad, float *const *exp_avg,
+                                      float *const *exp_avg_sq, const int64_t *numel, float lr, float beta1, float beta2,
+                                      float eps, float weight_decay, int32_t step, const int32_t *step_dev, void *stream) {
+  if (count < 0 || count > kMultiMax) return fail(CHAOREC_E_INVALID, "adam_multi: count=%d (0..%d)", count, kMultiMax);
+  if (count == 0) return CHAOREC_OK;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !numel) return fail(CHAOREC_E_INVALID, "adam_multi: NULL argument");
+  if (!step_dev && step < 1) return fail(CHAOREC_E_INVALID, "adam_multi: step=%d", step);
+  AdamMultiArgs a;
+  int blocks = 0, k = 0;
+  for (int i = 0; i < count; ++i) {
+    if (numel[i] == 0) continue;
+    if (!param[i] || !grad[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0 || numel[i] > (int64_t)1 << 30)
+      return fail(CHAOREC_E_INVALID, "adam_multi: tensor %d: NULL pointer or numel=%lld", i, (long long)numel[i]);
+    a.p[k] = param[i]; a.g[k] = grad[i]; a.m[k] = exp_avg[i]; a.v[k] = exp_avg_sq[i];
+    a.n[k] = (int32_t)numel[i];
+    a.first_block[k] = blocks;
+    blocks += (int)((numel[i] + kMultiBlockElems - 1) / kMultiBlockElems);
+    ++k;
+  }
+  if (k == 0) return CHAOREC_OK;
+  for (int i = k; i <= kMultiMax; ++i) a.first_block[i] = blocks;
+  for (int i = k; i < kMultiMax; ++i) { a.p[i] = nullptr; a.g[i] = nullptr; a.m[i] = nullptr; a.v[i] = nullptr; a.n[i] = 0; }
+  a.count = k;
+  a.ac = AdamConsts{lr, beta1, beta2, eps, weight_decay};
+  a.step_host = step;
+  a.step_dev = step_dev;
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("adam_multi_kernel");
+}
 
 extern "C" int chaorec_adam_bias_table(float *table, int32_t n_steps, float beta1, float beta2, void *stream) {
   if (!table || n_steps < 1) return fail(CHAOREC_E_INVALID, "adam_bias_table: table=%p n_steps=%d", (void *)table, n_steps);

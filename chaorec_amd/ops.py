@@ -699,6 +699,28 @@ def linear_rows(x, rows, weight, bias=None):
     return _LinearRows.apply(x, rows, weight, bias)
 
 
+def adam_multi(tensors, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step_dev=None):
+    """One Adam launch over several small tensors: `tensors` = [(param, grad, exp_avg, exp_avg_sq, numel)], at most
+    adam_multi_max() of them (chaorec_adam_multi_f32; same arithmetic as adam_step)."""
+    n = len(tensors)
+    if n == 0:
+        return
+    arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+    for t in tensors:
+        _need_cuda(t[0], t[1], t[2], t[3])
+    numel = (ctypes.c_int64 * n)(*[int(t[4]) for t in tensors])
+    rc = _lib.load().chaorec_adam_multi_f32(n, arr([t[0].data_ptr() for t in tensors]),
+                                            arr([t[1].data_ptr() for t in tensors]),
+                                            arr([t[2].data_ptr() for t in tensors]),
+                                            arr([t[3].data_ptr() for t in tensors]), numel, lr, betas[0], betas[1], eps,
+                                            weight_decay, int(step), _ptr(step_dev), _stream())
+    _lib.check(rc, "chaorec_adam_multi_f32")
+
+
+def adam_multi_max():
+    return int(_lib.load().chaorec_adam_multi_max())
+
+
 class _SpMMAdd(torch.autograd.Function):
     """y = A x + z in one launch (FREEDOM's `i_g_embeddings + h`, Model/FREEDOM.py:168,181)."""
 

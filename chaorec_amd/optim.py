@@ -31,6 +31,7 @@ def _adjacent_run(first, candidates):
 
 
 BIAS_TABLE_STEPS = 1 << 16
+MULTI_TENSOR_BELOW = 1 << 20      # parameter runs with fewer elements share one Adam launch (chaorec_adam_multi_f32)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -182,6 +183,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._pending.clear()
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
+            small = []
             i = 0
             while i < len(live):
                 p = live[i]
@@ -200,9 +202,23 @@ class FusedAdam(torch.optim.Optimizer):
                         break
                     n += q.numel()
                     j += 1
-                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
-                              group["eps"], group["weight_decay"], step_dev=self._step_dev, numel=n)
+                if n >= MULTI_TENSOR_BELOW or p.dtype != torch.float32:
+                    ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
+                                  group["eps"], group["weight_decay"], step_dev=self._step_dev, numel=n)
+                else:
+                    small.append((p.data, g, st["exp_avg"], st["exp_avg_sq"], n))
                 i = j
+            # the small tensors of the group (biases, 64 x 64 weights ...): one launch per 48 of them instead of one each
+            cap = ops.adam_multi_max() if small else 0
+            for k in range(0, len(small), cap or 1):
+                chunk = small[k:k + cap]
+                if len(chunk) == 1:
+                    t = chunk[0]
+                    ops.adam_step(t[0], t[1], t[2], t[3], 0, group["lr"], group["betas"], group["eps"],
+                                  group["weight_decay"], step_dev=self._step_dev, numel=t[4])
+                else:
+                    ops.adam_multi(chunk, 0, group["lr"], group["betas"], group["eps"], group["weight_decay"],
+                                   step_dev=self._step_dev)
         return loss
 
 

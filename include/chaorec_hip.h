@@ -35,7 +35,7 @@ extern "C" {
                                   5: weighted_sample_keys (sharded edge pruning);
                                   6: BPR batch at an offset + one finalize for k captured steps, NGCF elementwise backward;
                                   7: Adam over a feature table with a low-rank, row-sparse gradient (dense / lazy / flush), split-bf16 TN GEMM
-                                     (weight gradients) */
+                                     (weight gradients), multi-tensor Adam */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -408,6 +408,14 @@ int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, int64_t M, 
 int chaorec_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                           int64_t n, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int32_t step, const int32_t *step_dev, void *stream);
+
+/* The same update for up to chaorec_adam_multi_max() parameter tensors in ONE launch (host arrays of `count` device
+ * pointers and element counts; the pointers travel in the kernel argument): a model with ~50 small tensors
+ * (Model/MMGCN.py) otherwise pays one launch latency per tensor and step.  Same arithmetic, bit for bit. */
+int32_t chaorec_adam_multi_max(void);
+int chaorec_adam_multi_f32(int32_t count, float *const *param, const float *const *grad, float *const *exp_avg,
+                           float *const *exp_avg_sq, const int64_t *numel, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int32_t step, const int32_t *step_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Adam over a trainable feature table whose gradient is  G = gy W  (rank R <= 64, non-zero in the few rows of the batch).

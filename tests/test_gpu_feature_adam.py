@@ -247,3 +247,47 @@ def test_sharded_freedom_trains_like_freedom_with_claimed_tables(dev, lazy):
     ref = dict(m.named_parameters())
     for n, p in sh.named_parameters():
         assert torch.allclose(p, ref[n], rtol=0, atol=2e-6), n
+
+
+def test_adam_multi_equals_one_launch_per_tensor(dev):
+    """chaorec_adam_multi_f32 (one launch, pointers in the kernel argument) == chaorec_adam_step_f32 per tensor, bit for
+    bit: sizes below / at / above a block, a size that is no multiple of 4, views at 4-byte (not 16-byte) alignment, an
+    empty tensor; and FusedAdam, which batches its small tensors through it, == torch.optim.Adam to rounding."""
+    from chaorec_amd import ops
+    from chaorec_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    sizes = [1, 3, 64, 4096, 4097, 8192 + 5, 100_003, 0, 64 * 64, 12]
+    flat = torch.randn(sum(sizes) + 16, device=dev)
+    tensors, ref, o = [], [], 1                        # offset 1: every view is only 4-byte aligned
+    for n in sizes:
+        p = flat[o:o + n]
+        o += n
+        g = torch.randn(n, device=dev) * 0.1
+        m, v = torch.rand(n, device=dev) * 0.01, torch.rand(n, device=dev) * 0.001
+        tensors.append((p, g, m, v, n))
+        ref.append((p.clone(), g, m.clone(), v.clone(), n))
+    aligned = [(torch.randn(n, device=dev), torch.randn(n, device=dev), torch.zeros(n, device=dev),
+                torch.zeros(n, device=dev), n) for n in (7, 640, 5000)]
+    ref += [(p.clone(), g, m.clone(), v.clone(), n) for p, g, m, v, n in aligned]
+    tensors += aligned
+    assert len(tensors) <= ops.adam_multi_max()
+    for step in (1, 2, 7):
+        ops.adam_multi(tensors, step, weight_decay=1e-3)
+        for p, g, m, v, n in ref:
+            if n:
+                ops.adam_step(p, g, m, v, step, weight_decay=1e-3)
+    for a, b in zip(tensors, ref):
+        for x, y in ((a[0], b[0]), (a[2], b[2]), (a[3], b[3])):
+            assert torch.equal(x, y)
+    # through the optimizer: 60 small parameters (two launches) against torch.optim.Adam
+    ps = [torch.nn.Parameter(torch.randn(n, device=dev)) for n in [33, 64, 4096, 5000] * 15]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fa, ta = FusedAdam(ps, lr=1e-2), torch.optim.Adam(qs, lr=1e-2)
+    for _ in range(3):
+        for p, q in zip(ps, qs):
+            p.grad = torch.randn_like(p) * 0.1
+            q.grad = p.grad.clone()
+        fa.step()
+        ta.step()
+    for p, q in zip(ps, qs):
+        assert torch.allclose(p, q, rtol=0, atol=1e-6)
