@@ -62,8 +62,8 @@ class FREEDOM(nn.Module):
         self.text_trs = nn.Linear(self.t_feat.shape[1], self.dim_feat)
         # the feature tables are read only through ops.linear_rows (the batch rows of their projection): an optimizer
         # that knows how (optim.FusedAdam) may update them without ever forming their dense [I, K] gradient
-        self.image_embedding.weight._chaorec_rows_only = True
-        self.text_embedding.weight._chaorec_rows_only = True
+        self.image_embedding.weight._chaorec_projected_only = True
+        self.text_embedding.weight._chaorec_projected_only = True
         self._batch_idx = None
 
         rowptr, col = graph.user_hist_csr(user_item_dict, num_user)

@@ -81,6 +81,10 @@ class MGCN(nn.Module):
         self.image_original_adj = _sym_normalised_knn(self.image_embedding.weight.detach(), self.knn_k, device)
         self.text_embedding = nn.Embedding.from_pretrained(t_feat, freeze=False)
         self.text_original_adj = _sym_normalised_knn(self.text_embedding.weight.detach(), self.knn_k, device)
+        # the trainable feature tables are read only through their projections (ops.linear below): optim.FusedAdam may
+        # apply their rank-64 gradient gy W without materialising it (chaorec_adam_lowrank_f32)
+        self.image_embedding.weight._chaorec_projected_only = True
+        self.text_embedding.weight._chaorec_projected_only = True
 
         self.image_trs = nn.Linear(v_feat.shape[1], self.dim_E)
         self.text_trs = nn.Linear(t_feat.shape[1], self.dim_E)

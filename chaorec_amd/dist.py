@@ -644,8 +644,8 @@ class ShardedFREEDOM(nn.Module):
         # the modality tables are read only through the batch rows of their projection (FREEDOM.loss): an optimizer that
         # claims them (optim.FusedAdam) gets gy [I, R] + W instead of the dense [I, K] gradient -- and the ranks then sum
         # THAT in sync_grads(): 2 x I x 64 floats per step over xGMI instead of I x (4096 + 384)
-        self.image_embedding.weight._chaorec_rows_only = True
-        self.text_embedding.weight._chaorec_rows_only = True
+        self.image_embedding.weight._chaorec_projected_only = True
+        self.text_embedding.weight._chaorec_projected_only = True
         self._batch_idx = None
         self._keys_fn = keys_fn or ops.weighted_sample_keys
         self._prune_seed = int(prune_seed if prune_seed is not None else getattr(full, "_prune_seed", 0))

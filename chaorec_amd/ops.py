@@ -534,6 +534,8 @@ class _Linear(torch.autograd.Function):
             y = gemm_raw(x, weight, transB=True, bias=bias, act=act)
         ctx.save_for_backward(x, weight, y if act else None)
         ctx.has_bias, ctx.act = bias is not None, act
+        # a trainable table an optimizer has claimed (optim.FusedAdam): its gradient gy W leaves as (gy, W), see backward
+        ctx.x_param = x if getattr(x, "_chaorec_lowrank_sink", None) is not None else None
         return y
 
     @staticmethod
@@ -550,7 +552,12 @@ class _Linear(torch.autograd.Function):
             else:
                 gy = torch.where(y > 0, gy, gy * slope)
         gx = None
-        if ctx.needs_input_grad[0]:
+        xp = ctx.x_param
+        if ctx.needs_input_grad[0] and xp is not None and weight.shape[0] <= 64 and xp._chaorec_lowrank_sink.accepts(xp):
+            # the input is a claimed feature table (Model/MGCN.py:80-83: trainable [I, 4096] features projected as a
+            # whole): its dense gradient gy W is never formed, the optimizer applies it row by row (adam_lowrank)
+            xp._chaorec_lowrank_sink.submit(xp, gy, weight, None)
+        elif ctx.needs_input_grad[0]:
             # input gradient g W: as g (W^T)^T on the bf16 MFMA pipe where the forward went there too (W is small:
             # its transpose is one short copy)
             if LINEAR_FORWARD == "bf16x3" and weight.shape[0] >= 64 and gy.shape[0] >= 256:

@@ -37,7 +37,7 @@ MULTI_TENSOR_BELOW = 1 << 20      # parameter runs with fewer elements share one
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam (main.py:397) as one launch per parameter run, step count on the device.
 
-    Feature tables that a model marks `_chaorec_rows_only` (read only through ops.linear_rows: FREEDOM's trainable image
+    Feature tables that a model marks `_chaorec_projected_only` (read only through ops.linear_rows: FREEDOM's trainable image
     / text features, Model/FREEDOM.py:59-60, 209-213) are claimed: their [I, K] gradient is never materialised, the
     update comes from chaorec_adam_lowrank_f32 (gy [I, R] and the projection weight instead).  `lazy_rows=True` (env
     CHAOREC_LAZY_ADAM=1) additionally defers the zero-gradient updates of rows outside the batch until the row is next
@@ -53,7 +53,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._bc_table = None
         for group in self.param_groups:
             for p in group["params"]:
-                if getattr(p, "_chaorec_rows_only", False) and p.dim() == 2 and p.shape[1] % 4 == 0 \
+                if getattr(p, "_chaorec_projected_only", False) and p.dim() == 2 and p.shape[1] % 4 == 0 \
                         and p.dtype == torch.float32 and p.is_contiguous():
                     p._chaorec_lowrank_sink = self
                     self._claimed[id(p)] = group

@@ -143,7 +143,7 @@ def _freedom(dev, claim):
     g = load_golden("freedom_small_nodrop.npz")
     m, U, I = _make_freedom(g, dev)
     if not claim:
-        del m.image_embedding.weight._chaorec_rows_only, m.text_embedding.weight._chaorec_rows_only
+        del m.image_embedding.weight._chaorec_projected_only, m.text_embedding.weight._chaorec_projected_only
     m.pre_epoch_processing()
     return m, g, U, I
 
@@ -291,3 +291,34 @@ def test_adam_multi_equals_one_launch_per_tensor(dev):
         ta.step()
     for p, q in zip(ps, qs):
         assert torch.allclose(p, q, rtol=0, atol=1e-6)
+
+
+def test_mgcn_training_with_claimed_feature_tables(dev):
+    """MGCN projects its trainable feature tables as a WHOLE (ops.linear over every item row, Model/MGCN.py:80-83, 125-
+    126): gy is dense, the gradient gy W still has rank 64.  Five FusedAdam steps with the tables claimed (no [I, K]
+    gradient, no input-gradient GEMM) against five with the dense gradients: same parameters to rounding."""
+    from chaorec_amd.Model import MGCN
+    from chaorec_amd import graph
+    from chaorec_amd.optim import FusedAdam
+    g = load_golden("mgcn_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    rng = np.random.default_rng(9)
+    B = int(g["users"].shape[0])
+    batches = [(torch.from_numpy(rng.integers(0, U, B)), torch.from_numpy(rng.integers(U, U + I, B)),
+                torch.from_numpy(rng.integers(U, U + I, B))) for _ in range(5)]
+    out = {}
+    for claim in (False, True):
+        torch.manual_seed(0)
+        m = MGCN(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+                 torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]), 2, "add", float(g["ssl_temp"]),
+                 float(g["ssl_alpha"]), dev).to(dev)
+        if not claim:
+            del m.image_embedding.weight._chaorec_projected_only, m.text_embedding.weight._chaorec_projected_only
+        opt = FusedAdam(m.parameters(), lr=1e-3)
+        assert len(opt._claimed) == (2 if claim else 0)
+        _train(m, opt, batches)
+        assert (m.image_embedding.weight.grad is None) == claim
+        out[claim] = {k: v.detach().clone() for k, v in m.named_parameters()}
+    for k in out[True]:
+        assert torch.allclose(out[True][k], out[False][k], rtol=0, atol=2e-6), k
+    assert not torch.equal(out[True]["image_embedding.weight"].cpu(), torch.from_numpy(g["v_feat"]))
