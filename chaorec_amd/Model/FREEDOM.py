@@ -64,7 +64,7 @@ class FREEDOM(nn.Module):
         # that knows how (optim.FusedAdam) may update them without ever forming their dense [I, K] gradient
         self.image_embedding.weight._chaorec_projected_only = True
         self.text_embedding.weight._chaorec_projected_only = True
-        self._batch_idx = None
+        self._batch_idx = self._loss_w = None
 
         rowptr, col = graph.user_hist_csr(user_item_dict, num_user)
         self.hist = (rowptr.to(device), col.to(device))
@@ -200,24 +200,28 @@ class FREEDOM(nn.Module):
         users, pos_items, neg_items = users.to(self.device), pos_items.to(self.device), neg_items.to(self.device)
 
         ua_embeddings, ia_embeddings = self.forward(self.masked_adj)
-        batch_mf_loss = ops.bpr_loss(ua_embeddings, ia_embeddings, users, pos_items, neg_items,
-                                     ops.VARIANT_LOGSIGMOID, 0.0)[0]
         # Model/FREEDOM.py:208-213 project the WHOLE feature table and read the batch rows of the result; a row of a
-        # Linear depends on that row alone, so only the rows of the batch are projected (ops.linear_rows)
-        mf_v_loss, mf_t_loss = 0.0, 0.0
+        # Linear depends on that row alone, so only the rows of the batch are projected (ops.linear_rows).  The three
+        # BPR terms -- total = mf + reg_weight * (text + image), :203-215 -- share the user table and the batch's users:
+        # one autograd node (ops.bpr_loss_multi)
         B = users.shape[0]
         rows = torch.cat((pos_items, neg_items), 0)
         if self._batch_idx is None or self._batch_idx[0].shape[0] != B or self._batch_idx[0].device != users.device:
             idx = torch.arange(B, device=users.device)
             self._batch_idx = (idx, idx + B)
         idx, idx_neg = self._batch_idx
+        terms, weights = [(ia_embeddings, pos_items, neg_items)], [1.0]
         if self.t_feat is not None:
             text_rows = ops.linear_rows(self.text_embedding.weight, rows, self.text_trs.weight, self.text_trs.bias)
-            mf_t_loss = ops.bpr_loss(ua_embeddings, text_rows, users, idx, idx_neg, ops.VARIANT_LOGSIGMOID, 0.0)[0]
+            terms.append((text_rows, idx, idx_neg))
+            weights.append(self.reg_weight)
         if self.v_feat is not None:
             image_rows = ops.linear_rows(self.image_embedding.weight, rows, self.image_trs.weight, self.image_trs.bias)
-            mf_v_loss = ops.bpr_loss(ua_embeddings, image_rows, users, idx, idx_neg, ops.VARIANT_LOGSIGMOID, 0.0)[0]
-        return batch_mf_loss + self.reg_weight * (mf_t_loss + mf_v_loss)
+            terms.append((image_rows, idx, idx_neg))
+            weights.append(self.reg_weight)
+        if self._loss_w is None or self._loss_w.device != users.device or self._loss_w.numel() != len(weights):
+            self._loss_w = torch.tensor(weights, dtype=torch.float32, device=users.device)
+        return ops.bpr_loss_multi(ua_embeddings, users, ops.VARIANT_LOGSIGMOID, terms, self._loss_w)
 
     def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/FREEDOM.py:219-244 (mask value 1e-6, stale self.result)."""

@@ -227,6 +227,64 @@ class _BPR(torch.autograd.Function):
         return g_u, g_i, None, None, None, None, None, None
 
 
+class _BPRMulti(torch.autograd.Function):
+    """sum_k w_k * BPR(tab_u[users], tab_i_k[pos_k], tab_i_k[neg_k]) for several item tables that share the user table and
+    the batch's users (Model/FREEDOM.py:203-215: the id-embedding loss + reg_weight * (text loss + image loss)) as ONE
+    autograd node: one gradient buffer for the user table that the T backward launches add into (instead of T zero-filled
+    buffers and T - 1 additions by autograd), the weighted sum and its backward as two small launches."""
+
+    @staticmethod
+    def forward(ctx, tab_u, users, variant, wvec, *flat):
+        T = len(flat) // 3
+        _need_cuda(tab_u, users, wvec, *flat)
+        tab_u = _f32c(tab_u)
+        users = users.to(torch.int64).contiguous()
+        B, D, dev = users.numel(), tab_u.shape[1], tab_u.device
+        tabs = [_f32c(flat[3 * k]) for k in range(T)]
+        ids = [(flat[3 * k + 1].to(torch.int64).contiguous(), flat[3 * k + 2].to(torch.int64).contiguous()) for k in range(T)]
+        totals = torch.empty(T, dtype=torch.float32, device=dev)
+        outs = torch.empty((T, 3), dtype=torch.float32, device=dev)
+        coef = torch.empty((T, B), dtype=torch.float32, device=dev)
+        ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        for k in range(T):
+            rc = lib.chaorec_bpr_fwd_f32(_ptr(tab_u), _ptr(tabs[k]), _ptr(users), _ptr(ids[k][0]), _ptr(ids[k][1]), B, D,
+                                         variant, 0.0, ctypes.c_void_p(outs.data_ptr() + 12 * k),
+                                         ctypes.c_void_p(totals.data_ptr() + 4 * k),
+                                         ctypes.c_void_p(coef.data_ptr() + 4 * B * k), _ptr(ws), _stream())
+            _lib.check(rc, "chaorec_bpr_fwd_f32")
+        ctx.save_for_backward(tab_u, users, coef, wvec, *tabs, *[t for pn in ids for t in pn])
+        ctx.T = T
+        return (totals * wvec).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        T = ctx.T
+        tab_u, users, coef, wvec = ctx.saved_tensors[:4]
+        tabs = ctx.saved_tensors[4:4 + T]
+        ids = ctx.saved_tensors[4 + T:]
+        B, D = users.numel(), tab_u.shape[1]
+        gvec = (g * wvec).contiguous()                   # d total / d loss_k, on the device
+        g_u = torch.zeros_like(tab_u)
+        lib = _lib.load()
+        grads = []
+        for k in range(T):
+            g_i = torch.zeros_like(tabs[k])
+            rc = lib.chaorec_bpr_bwd_f32(_ptr(tab_u), _ptr(tabs[k]), _ptr(users), _ptr(ids[2 * k]), _ptr(ids[2 * k + 1]), B,
+                                         D, ctypes.c_void_p(coef.data_ptr() + 4 * B * k), 0.0,
+                                         ctypes.c_void_p(gvec.data_ptr() + 4 * k), _ptr(g_u), _ptr(g_i), _stream())
+            _lib.check(rc, "chaorec_bpr_bwd_f32")
+            grads += [g_i, None, None]
+        return (g_u, None, None, None, *grads)
+
+
+def bpr_loss_multi(tab_u, users, variant, terms, wvec):
+    """sum_k wvec[k] * bpr_loss(tab_u, terms[k] = (tab_i, pos, neg), users)[0] with reg_weight 0 (see _BPRMulti); wvec: a
+    float32 device tensor with one weight per term."""
+    flat = [t for term in terms for t in term]
+    return _BPRMulti.apply(tab_u, users, int(variant), wvec, *flat)
+
+
 class _LossParts:
     """What bpr_loss returns: indexable like the old [total, bpr, reg] tensor; [0] is the differentiable total."""
 
