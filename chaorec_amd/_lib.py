@@ -129,7 +129,7 @@ SIGNATURES = {
     "chaorec_adam_multi_f32": (ctypes.c_int, [ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                               ctypes.c_int32, c_ptr, c_ptr]),
-    "chaorec_unique_rows": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "chaorec_unique_rows": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 
 

@@ -49,7 +49,7 @@ struct LowrankArgs {
 
 // The distinct values of rows[0..n) in arbitrary order, and how many: one workgroup.  claim[row] remembers the stamp of
 // the launch that listed the row last and every launch takes a new stamp, so nothing is cleared between launches.
-__global__ __launch_bounds__(1024) void unique_rows_kernel(const int64_t *__restrict__ rows, int64_t n,
+__global__ __launch_bounds__(1024) void unique_rows_kernel(const int64_t *__restrict__ rows, int64_t n, int64_t n_rows,
                                                            int32_t *__restrict__ claim, int32_t *stamp_dev,
                                                            int32_t *__restrict__ list, int32_t *__restrict__ count) {
   __shared__ int n_s;
@@ -57,8 +57,9 @@ __global__ __launch_bounds__(1024) void unique_rows_kernel(const int64_t *__rest
   if (threadIdx.x == 0) n_s = 0;
   __syncthreads();
   for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
-    const int row = (int)rows[j];
-    if (atomicExch(&claim[row], stamp) != stamp) list[atomicAdd(&n_s, 1)] = row;
+    const int64_t row = rows[j];
+    if (row < 0 || row >= n_rows) continue;          // (an id outside the table is not listed: nothing is touched for it)
+    if (atomicExch(&claim[row], stamp) != stamp) list[atomicAdd(&n_s, 1)] = (int)row;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -236,6 +237,10 @@ __global__ __launch_bounds__(WAVES * 64) void adam_lowrank_rows_kernel(LowrankAr
     valid[u] = j0 + u < n_visit;
     const int64_t j = valid[u] ? j0 + u : n_visit - 1;
     rows[u] = a.rowlist ? (int64_t)a.rowlist[j] : j;
+    if (rows[u] < 0 || rows[u] >= a.n_rows) {            // (a list entry outside the table: skipped, never dereferenced)
+      valid[u] = false;
+      rows[u] = 0;
+    }
   }
   float gyl[RPW];
   int lst[RPW];
@@ -397,11 +402,11 @@ extern "C" int chaorec_adam_bias_table(float *table, int32_t n_steps, float beta
   return check_launch("adam_bias_table");
 }
 
-extern "C" int chaorec_unique_rows(const int64_t *rows, int64_t n, int32_t *claim, int32_t *stamp_dev, int32_t *list,
-                                   int32_t *count, void *stream) {
-  if (!rows || !claim || !stamp_dev || !list || !count || n < 0)
-    return fail(CHAOREC_E_INVALID, "unique_rows: null pointer / n=%lld", (long long)n);
-  unique_rows_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rows, n, claim, stamp_dev, list, count);
+extern "C" int chaorec_unique_rows(const int64_t *rows, int64_t n, int64_t n_rows, int32_t *claim, int32_t *stamp_dev,
+                                   int32_t *list, int32_t *count, void *stream) {
+  if (!rows || !claim || !stamp_dev || !list || !count || n < 0 || n_rows < 0 || n_rows > INT32_MAX)
+    return fail(CHAOREC_E_INVALID, "unique_rows: null pointer / n=%lld n_rows=%lld", (long long)n, (long long)n_rows);
+  unique_rows_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rows, n, n_rows, claim, stamp_dev, list, count);
   return check_launch("unique_rows_kernel");
 }
 

@@ -668,8 +668,8 @@ def unique_rows(rows, claim, stamp_dev, out_list, out_count):
     rows = rows.to(torch.int64).contiguous()
     if out_list.numel() < rows.numel():
         raise ValueError("unique_rows: the list must hold as many ids as `rows`")
-    _lib.check(_lib.load().chaorec_unique_rows(_ptr(rows), rows.numel(), _ptr(claim), _ptr(stamp_dev), _ptr(out_list),
-                                               _ptr(out_count), _stream()), "chaorec_unique_rows")
+    _lib.check(_lib.load().chaorec_unique_rows(_ptr(rows), rows.numel(), claim.numel(), _ptr(claim), _ptr(stamp_dev),
+                                               _ptr(out_list), _ptr(out_count), _stream()), "chaorec_unique_rows")
 
 
 def adam_lowrank_strips(K):

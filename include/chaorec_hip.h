@@ -446,15 +446,15 @@ int chaorec_adam_multi_f32(int32_t count, float *const *param, const float *cons
  * fills the list itself with the rows whose gy (or flag) row is non-zero (rowcap >= n_rows).
  *
  * chaorec_unique_rows: list[0 .. *count) = the distinct values of rows[0 .. n) (item ids of a batch, duplicates
- * allowed), order unspecified.  claim: int32 [n_rows] scratch and stamp_dev: int32 [1], both zero-initialised once and
+ * allowed; ids outside [0, n_rows) are dropped), order unspecified.  claim: int32 [n_rows] scratch and stamp_dev: int32 [1], both zero-initialised once and
  * then left to the launches: each one takes the stamp *stamp_dev + 1, marks the rows it lists with it and stores it
  * back, so nothing is cleared between launches (also not between replays of a captured hipGraph).  One workgroup:
  * meant for batches of a few thousand ids.
  * ------------------------------------------------------------------------------------- */
 int32_t chaorec_adam_lowrank_strips(int32_t K);
 int chaorec_adam_bias_table(float *table, int32_t n_steps, float beta1, float beta2, void *stream);
-int chaorec_unique_rows(const int64_t *rows, int64_t n, int32_t *claim, int32_t *stamp_dev, int32_t *list,
-                        int32_t *count, void *stream);
+int chaorec_unique_rows(const int64_t *rows, int64_t n, int64_t n_rows, int32_t *claim, int32_t *stamp_dev,
+                        int32_t *list, int32_t *count, void *stream);
 int chaorec_adam_lowrank_f32(float *param, const float *gy, const float *W, float *exp_avg, float *exp_avg_sq,
                              int64_t n_rows, int32_t K, int32_t R, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int32_t step, const int32_t *step_dev, int32_t mode, int32_t *last,

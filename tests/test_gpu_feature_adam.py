@@ -112,6 +112,10 @@ def test_adam_lowrank_row_list_path_equals_dense(dev):
     for step in range(1, 13):
         batch = rng.integers(0, n, cap)                       # duplicates on purpose
         batch[:5] = batch[5:10]
+        if step == 3:                                         # ids outside the table are dropped, not dereferenced
+            bad = torch.from_numpy(np.concatenate([batch[:10], [n, n + 7, -1]])).to(dev)
+            ops.unique_rows(bad, claim, stamp, rowlist, rowcount)
+            assert int(rowcount[0]) == np.unique(batch[:10]).size
         gy = np.zeros((n, R), np.float32)
         hot = np.unique(batch)[3:]                            # three listed rows get a zero gradient row
         gy[hot] = (rng.standard_normal((hot.size, R)) * 0.05).astype(np.float32)
