@@ -313,6 +313,11 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   GemmPlan p;
   p.bn = N <= 64 ? 64 : 128;
   p.bm = M <= 64 ? 64 : 128;      // (64-row outputs -- weight gradients of 64-wide layers -- would be half padding)
+  // tall 64-wide products with a short reduction (Linear 64 -> 64 over all graph nodes): one k-tile per workgroup, so
+  // a workgroup's life is one load -> MFMA -> store chain; 128-row tiles give 1.3 workgroups per CU at 44 k rows (two
+  // rounds of that chain), 64-row tiles 2.7, all resident at once: 18.3 -> 14.2 us (no gain once 64-row tiles exceed
+  // three per CU as well: 60 k rows)
+  if (p.bn == 64 && K <= 512 && M > 64 && (M + 63) / 64 <= 768) p.bm = 64;
   const int64_t tiles = ((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn);
   p.splits = 1;
   // few output tiles and a long reduction (weight gradients: K = number of graph nodes): split K so that the
