@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import FREEDOM, LayerGCN, LightGCN, MGCN, MMGCN, NGCF
+from .Model import BPRMF, FREEDOM, LayerGCN, LightGCN, MGCN, MMGCN, NGCF, VBPR
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
 from .optim import FusedAdam
@@ -49,6 +49,9 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
                                      args.n_layers, args.dropout, device),
         'MGCN': lambda: MGCN(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                              args.n_layers, aggr_mode, args.ssl_temp, args.ssl_alpha, device),
+        'BPR': lambda: BPRMF(num_user, num_item, user_item_dict, dim_E, args.reg_weight, device),
+        'VBPR': lambda: VBPR(num_user, num_item, user_item_dict, v_feat, dim_E, args.feature_embed, args.reg_weight,
+                             device),
     }
     if args.Model not in table:
         raise SystemExit(f"--Model {args.Model}: only {sorted(table)} are on the MI355X hot path")
@@ -67,7 +70,7 @@ def main(argv=None):
     if device.type != "cuda":
         raise SystemExit("chaorec_amd runs on the MI355X only: no GPU visible")
     config = load_yaml_config(args.Model)
-    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN")
+    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR")
     train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat = dataload.data_load(
         args.data_path, has_v=needs_feat, has_t=needs_feat, data_root=args.data_root, synthetic=args.synthetic)
     if args.host_sampler:

@@ -112,6 +112,12 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
         host = torch.empty((num_user, topk), dtype=torch.int64, pin_memory=True)
     with torch.no_grad():
         result = result.detach()
+        D = result.shape[1]
+        if D not in (8, 16, 32, 64, 128) and not (D > 128 and D % 64 == 0):
+            # a width the scoring kernels do not tile (VBPR with a 16-wide id embedding: 80): zero columns up to the next
+            # one that they do -- a dot product's k-ascending chain only gains +0 * 0 terms, the scores keep their bits
+            wide = next(w for w in (8, 16, 32, 64, 128) if w >= D) if D < 128 else (D + 63) // 64 * 64
+            result = torch.cat((result, result.new_zeros(result.shape[0], wide - D)), 1)
         if state is not None:
             hint = state.buffer(num_user, result.device)
             hinted = state.use_hints(num_user)

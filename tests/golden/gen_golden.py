@@ -38,6 +38,8 @@ from Model.MMGCN import MMGCN  # noqa: E402
 from Model.NGCF import NGCF  # noqa: E402
 from Model.MGCN import MGCN  # noqa: E402
 from Model.LayerGCN import LayerGCN  # noqa: E402
+from Model.BPR import BPRMF  # noqa: E402
+from Model.VBPR import VBPR  # noqa: E402
 import metrics as ref_metrics  # noqa: E402,F401
 import utils as ref_utils  # noqa: E402
 import dataload as ref_dataload  # noqa: E402
@@ -407,8 +409,48 @@ def gen_layergcn():
                         **{"p_" + k: v for k, v in state.items()}, **grads, **out)
 
 
+def gen_bpr_family():
+    """Reference BPRMF and VBPR (models that are the BPR kernel + the shared ranking): initial state, one
+    loss + backward, ranking; for BPRMF the item bias is given non-zero values first (it is initialised to zero, which
+    would hide it from the loss)."""
+    U, I = 48, 40
+    e = small_graph(U, I, 3, 7, 21)
+    rng = np.random.default_rng(22)
+    b = rng.choice(len(e), 32, replace=False)
+    users, pos = e[b, 0].astype(np.int64), e[b, 1].astype(np.int64)
+    neg = rng.integers(U, U + I, 32).astype(np.int64)
+    batch = tuple(torch.from_numpy(x) for x in (users, pos, neg))
+    # BPRMF
+    torch.manual_seed(0)
+    m = BPRMF(U, I, uid(e), 16, 1e-3, DEV)
+    with torch.no_grad():
+        m.item_bias.weight.copy_(torch.from_numpy(seeded((I, 1), 23, 0.3)))
+    state = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    loss = m.loss(*batch)
+    loss.backward()
+    grads = {"g_" + k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+    rank = m.gene_ranklist(topk=10)
+    np.savez_compressed(os.path.join(HERE, "bprmf_small.npz"), U=U, I=I, edges=e, D=16, reg=1e-3, users=users, pos=pos,
+                        neg=neg, loss=np.float64(loss.item()), rank=rank.numpy(), topk=10,
+                        param_names=np.array([k for k, _ in m.named_parameters()]),
+                        **{"p_" + k: v for k, v in state.items()}, **grads)
+    # VBPR
+    v_feat = seeded((I, 24), 24, 1.0)
+    torch.manual_seed(0)
+    m = VBPR(U, I, uid(e), torch.from_numpy(v_feat), 16, 64, 1e-3, DEV)
+    state = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    loss = m.loss(*batch)
+    loss.backward()
+    grads = {"g_" + k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+    rank = m.gene_ranklist(topk=10)
+    np.savez_compressed(os.path.join(HERE, "vbpr_small.npz"), U=U, I=I, edges=e, D=16, reg=1e-3, users=users, pos=pos,
+                        neg=neg, v_feat=v_feat, loss=np.float64(loss.item()), result=m.result.detach().numpy(),
+                        rank=rank.numpy(), topk=10, param_names=np.array([k for k, _ in m.named_parameters()]),
+                        **{"p_" + k: v for k, v in state.items()}, **grads)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["lightgcn_tiny", "baby", "sampler", "freedom", "mmgcn", "ngcf", "mgcn", "layergcn"]
+    which = sys.argv[1:] or ["lightgcn_tiny", "baby", "sampler", "freedom", "mmgcn", "ngcf", "mgcn", "layergcn", "bpr_family"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -250,7 +250,7 @@ def test_ngcf_captured_step_at_sports_size_equals_eager(dev):
 
 
 @pytest.mark.parametrize("name,ds", [("LightGCN", "sports"), ("LayerGCN", "sports"), ("FREEDOM", "clothing"),
-                                     ("MGCN", "baby"), ("MMGCN", "baby")])
+                                     ("MGCN", "baby"), ("MMGCN", "baby"), ("BPR", "sports"), ("VBPR", "baby")])
 def test_captured_training_equals_eager_at_dataset_size(dev, name, ds, monkeypatch):
     """The step the benchmark times is the CAPTURED one: at dataset size, over 40 different batches, it must produce
     the losses of the eager step (same kernels, same batches).  (A captured-only failure at this size is exactly how
@@ -276,6 +276,10 @@ def test_captured_training_equals_eager_at_dataset_size(dev, name, ds, monkeypat
             m = Model.FREEDOM(U, I, edges, uid, v_feat, t_feat, 64, 64, 1e-3, 0.1, 2, 1, 10, 0.8, dev)
         elif name == "MGCN":
             m = Model.MGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, 2, "add", 0.2, 0.01, dev)
+        elif name == "BPR":
+            m = Model.BPRMF(U, I, uid, 64, 1e-3, dev)
+        elif name == "VBPR":
+            m = Model.VBPR(U, I, uid, v_feat, 64, 64, 1e-3, dev)
         else:
             m = Model.MMGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, "add", "False", True, dev)
         m = m.to(dev)

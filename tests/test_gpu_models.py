@@ -539,3 +539,88 @@ def test_sharded_freedom_one_rank_equals_freedom(dev, tag):
         scale = float(p.grad.abs().max()) + 1e-12
         assert float((q.grad - p.grad).abs().max()) <= 2e-4 * scale + 1e-9, n
     assert torch.equal(sh.gene_ranklist(topk=10), m.gene_ranklist(topk=10))
+
+
+def _rank_check(m, g, U, result_u, result_i):
+    from chaorec_amd import graph
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    sc = result_u @ result_i.T
+    for u, items in graph.user_item_dict_from_edges(g["edges"]).items():
+        sc[u, np.asarray(items) - U] = 1e-6
+    ok, why = tie_aware_rank_equal(rank, np.take_along_axis(sc, rank - U, 1), g["rank"],
+                                   np.take_along_axis(sc, g["rank"] - U, 1), rtol=1e-4, atol=1e-7)
+    assert ok, why
+
+
+def test_bprmf_golden(dev):
+    """BPRMF against the reference class: loss with the item bias and the reference's own regulariser
+    (negative rows un-squared), every gradient -- the bias's through the padded table column --, and the ranking
+    (which ignores the bias, as the reference's does)."""
+    from chaorec_amd.Model import BPRMF
+    from chaorec_amd import graph
+    g = load_golden("bprmf_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    m = BPRMF(U, I, graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), dev)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.from_numpy(g["p_" + n]))
+    m = m.to(dev)
+    batch = tuple(torch.from_numpy(g[k]) for k in ("users", "pos", "neg"))
+    loss = m.loss(*batch)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-6)
+    for n, p in m.named_parameters():
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-5 * (np.abs(ref).max() + 1e-12), n
+    pos_s, neg_s = m.forward(batch[0], batch[1] - U, batch[2] - U)
+    assert pos_s.shape == neg_s.shape == (len(g["users"]),)
+    _rank_check(m, g, U, g["p_user_embedding.weight"], g["p_item_embedding.weight"])
+
+
+def test_vbpr_golden(dev):
+    """VBPR against the reference class: the joined representation, loss, every gradient (the trainable
+    visual feature table included: dense here, no optimizer has claimed it) and the ranking; then three FusedAdam steps
+    with the feature table claimed against three with its dense gradient."""
+    from chaorec_amd.Model import VBPR
+    from chaorec_amd import graph
+    from chaorec_amd.optim import FusedAdam
+    g = load_golden("vbpr_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+
+    def make():
+        m = VBPR(U, I, graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), int(g["D"]), 64,
+                 float(g["reg"]), dev)
+        assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                p.copy_(torch.from_numpy(g["p_" + n]))
+        return m.to(dev)
+
+    m = make()
+    batch = tuple(torch.from_numpy(g[k]) for k in ("users", "pos", "neg"))
+    loss = m.loss(*batch)
+    loss.backward()
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=5e-6)
+    for n, p in m.named_parameters():
+        ref = g["g_" + n]
+        # (+1e-8: the projection's bias gradient is a sum of +c u and -c u terms that cancel to ~1e-5 -- what is left
+        # is the rounding of either implementation)
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-8, n
+    _rank_check(m, g, U, g["result"][:U], g["result"][U:])
+    out = {}
+    for claim in (False, True):
+        m = make()
+        if not claim:
+            del m.v_feat.weight._chaorec_projected_only
+        opt = FusedAdam(m.parameters(), lr=1e-3)
+        assert len(opt._claimed) == int(claim)
+        for _ in range(3):
+            opt.zero_grad()
+            m.loss(*batch).backward()
+            opt.step()
+        out[claim] = {k: v.detach().clone() for k, v in m.named_parameters()}
+    for k in out[True]:
+        assert torch.allclose(out[True][k], out[False][k], rtol=0, atol=2e-6), k

@@ -3,7 +3,7 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chaorec_amd import graph, dataload
-from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN, NGCF, MGCN, LayerGCN
+from chaorec_amd.Model import LightGCN, FREEDOM, MMGCN, NGCF, MGCN, LayerGCN, BPRMF, VBPR
 from chaorec_amd.optim import FusedAdam
 from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
 dev = torch.device("cuda:0")
@@ -24,6 +24,10 @@ for spec in which:
         m = LayerGCN(U, I, edges, uid, 64, 1e-3, 3, 0.1, dev)
     elif name == "MGCN":
         m = MGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, 2, "add", 0.2, 0.01, dev)
+    elif name == "BPR":
+        m = BPRMF(U, I, uid, 64, 1e-3, dev)
+    elif name == "VBPR":
+        m = VBPR(U, I, uid, v_feat, 64, 64, 1e-3, dev)
     elif name == "FREEDOM":
         m = FREEDOM(U, I, edges, uid, v_feat, t_feat, 64, 64, 1e-3, 0.1, 2, 1, 10, 0.8, dev)
     else:
