@@ -145,13 +145,18 @@ def test_mmgcn_microlens_size_vs_torch(dev):
     assert rank.shape == (U, 50)
 
 
-@pytest.mark.parametrize("model", ["LightGCN", "FREEDOM", "MMGCN", "NGCF", "MGCN", "LayerGCN"])
+@pytest.mark.parametrize("model", ["LightGCN", "FREEDOM", "MMGCN", "NGCF", "MGCN", "LayerGCN", "BPR", "VBPR", "FREEDOM-lazy"])
 def test_main_entry_point_two_epochs(dev, model, tmp_path, monkeypatch):
-    """python -m chaorec_amd.main --Model X --data_path baby --synthetic: grid search, train, evaluate."""
+    """python -m chaorec_amd.main --Model X --data_path baby --synthetic: grid search, train, evaluate.
+    (FREEDOM-lazy: the same with CHAOREC_LAZY_ADAM=1 -- lazily updated feature rows through the per-epoch re-pruning, the
+    captured step and the flush at the end of training.)"""
     import logging
     from chaorec_amd import main as cmain, dataload
     monkeypatch.chdir(tmp_path)
     monkeypatch.setitem(dataload.SYNTHETIC_FEATURE_DIMS, "default", (96, 64))
+    if model.endswith("-lazy"):
+        model = model[:-5]
+        monkeypatch.setenv("CHAOREC_LAZY_ADAM", "1")
     logging.getLogger().handlers.clear()
     best = cmain.main(["--Model", model, "--data_path", "baby", "--synthetic", "--num_epoch", "2"])
     assert set(best.keys()) == {5, 10, 20}
