@@ -404,7 +404,7 @@ extern "C" int chaorec_adam_bias_table(float *table, int32_t n_steps, float beta
 
 extern "C" int chaorec_unique_rows(const int64_t *rows, int64_t n, int64_t n_rows, int32_t *claim, int32_t *stamp_dev,
                                    int32_t *list, int32_t *count, void *stream) {
-  if (!rows || !claim || !stamp_dev || !list || !count || n < 0 || n_rows < 0 || n_rows > INT32_MAX)
+  if ((!rows && n > 0) || !claim || !stamp_dev || !list || !count || n < 0 || n_rows < 0 || n_rows > INT32_MAX)
     return fail(CHAOREC_E_INVALID, "unique_rows: null pointer / n=%lld n_rows=%lld", (long long)n, (long long)n_rows);
   unique_rows_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(rows, n, n_rows, claim, stamp_dev, list, count);
   return check_launch("unique_rows_kernel");
@@ -418,6 +418,7 @@ extern "C" int chaorec_adam_lowrank_f32(float *param, const float *gy, const flo
                                         int32_t mode, int32_t *last, const float *bc_table, int32_t bc_len,
                                         int32_t *rowlist, int32_t *rowcount, int32_t rowcap, int32_t rows_given,
                                         void *stream) {
+  if (n_rows == 0) return CHAOREC_OK;                      // (an empty table has no storage to point at)
   if (!param || !exp_avg || !exp_avg_sq) return fail(CHAOREC_E_INVALID, "adam_lowrank: null table pointer");
   if (mode < 0 || mode > 3) return fail(CHAOREC_E_INVALID, "adam_lowrank: mode=%d", mode);
   if (mode != 0 && !last) return fail(CHAOREC_E_INVALID, "adam_lowrank: mode %d needs `last`", mode);

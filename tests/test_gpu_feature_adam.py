@@ -326,3 +326,38 @@ def test_mgcn_training_with_claimed_feature_tables(dev):
     for k in out[True]:
         assert torch.allclose(out[True][k], out[False][k], rtol=0, atol=2e-6), k
     assert not torch.equal(out[True]["image_embedding.weight"].cpu(), torch.from_numpy(g["v_feat"]))
+
+
+def test_feature_adam_edge_cases(dev):
+    """Empty and minimal inputs, and the argument checks of the new entry points: an empty table and an empty batch are
+    no-ops; K = 4 / R = 1 is the smallest table the kernels take; bad shapes fail loudly instead of launching."""
+    from chaorec_amd import ops, _lib
+    lib = _lib.load()
+    z = torch.zeros(0, 8, device=dev)
+    ops.adam_lowrank(z, torch.zeros(0, 2, device=dev), torch.zeros(2, 8, device=dev), z.clone(), z.clone(), 1)   # no rows
+    ops.adam_multi([], 1)
+    claim, stamp = torch.zeros(5, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    lst, cnt = torch.zeros(4, dtype=torch.int32, device=dev), torch.full((1,), 7, dtype=torch.int32, device=dev)
+    ops.unique_rows(torch.zeros(0, dtype=torch.int64, device=dev), claim, stamp, lst, cnt)
+    assert int(cnt[0]) == 0 and int(stamp[0]) == 1
+    # smallest table: K = 4, R = 1
+    p, m, v = torch.ones(3, 4, device=dev), torch.zeros(3, 4, device=dev), torch.zeros(3, 4, device=dev)
+    gy, W = torch.tensor([[1.0], [0.0], [-2.0]], device=dev), torch.tensor([[0.5, -1.0, 0.0, 2.0]], device=dev)
+    q, mq, vq = p.clone(), m.clone(), v.clone()
+    ops.adam_lowrank(p, gy, W, m, v, 1)
+    ops.adam_step(q, gy @ W, mq, vq, 1)
+    assert torch.equal(p, q) and torch.equal(m, mq) and torch.equal(v, vq)
+    assert torch.equal(p[1], torch.ones(4, device=dev))                      # zero gradient, zero moments: untouched
+    # argument checks
+    for bad in (dict(K=6), dict(R=65), dict(mode=4)):
+        rc = lib.chaorec_adam_lowrank_f32(p.data_ptr(), gy.data_ptr(), W.data_ptr(), m.data_ptr(), v.data_ptr(), 3,
+                                          bad.get("K", 4), bad.get("R", 1), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None,
+                                          bad.get("mode", 0), None, None, 0, None, None, 0, 0, None)
+        assert rc != 0, bad
+    rc = lib.chaorec_adam_lowrank_f32(p.data_ptr(), gy.data_ptr(), W.data_ptr(), m.data_ptr(), v.data_ptr(), 3, 4, 1, 1e-3,
+                                      0.9, 0.999, 1e-8, 0.0, 1, None, 1, None, None, 0, None, None, 0, 0, None)
+    assert rc != 0                                                            # lazy mode without `last`
+    with pytest.raises(ValueError):
+        ops.adam_lowrank(p, gy, torch.zeros(1, 8, device=dev), m, v, 1)       # W's width is not the table's
+    with pytest.raises(RuntimeError):
+        ops.adam_lowrank(torch.ones(3, 4), gy.cpu(), W.cpu(), torch.zeros(3, 4), torch.zeros(3, 4), 1)   # no CPU path
