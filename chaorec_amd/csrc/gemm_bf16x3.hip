@@ -29,7 +29,9 @@ namespace chaorec {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int XBM = 128, XBN = 64, XBK = 32, XPAD = 8;   // (row stride 40 bf16 = 80 B: 16-B aligned, banks skewed)
+constexpr int XBM = 128, XBK = 32, XPAD = 8;   // (row stride 40 bf16 = 80 B: 16-B aligned, banks skewed)
+// N tile: 64 (the skinny projections, N = 64: one tile covers the output's width) or 128 (wide outputs: every staged and
+// split A element then feeds twice the MFMAs -- the three-plane split is VALU work of the same order as the MFMA time)
 
 union Frag8 {
   uint4 u;
@@ -71,7 +73,7 @@ extern __global__ void gemm_reduce_slabs_kernel(const float *__restrict__ slabs,
 //             dW = gy^T x, Model/MMGCN.py's Linears over all graph nodes).  A thread then fetches a 4 (m) x 4 (k)
 //             block of A -- four float4 along m, one per k -- and a 4 (n) x 2 (k) block of B, transposes them in
 //             registers (a choice of components, no instructions) and writes the same k-major bf16 planes to LDS.
-template <bool TN>
+template <bool TN, int XBN>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                              float *__restrict__ C, const float *__restrict__ bias,
                                                              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
@@ -84,14 +86,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
   const int64_t m0 = (int64_t)blockIdx.x * XBM, n0 = (int64_t)blockIdx.y * XBN;
   const int64_t kb = (int64_t)blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
 
-  f32x16 acc[2];
+  constexpr int NJ = XBN / 32;      // accumulators per wave (32 x 32 each)
+  constexpr int NB = XBN / 32;      // B float4 per thread per k-tile (NT) / B blocks per thread (TN)
+  f32x16 acc[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 
   // this thread's float4s of a k-tile: A 128 x 32 = 1024 float4 (4 per thread), B 64 x 32 = 512 (2 per thread)
-  float4 ra[4], rb[2];
+  float4 ra[4], rb[NB];
   const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   auto load4 = [&](const float *base, int64_t ld, int64_t row, int64_t n_rows, int64_t k, bool vec) -> float4 {
@@ -132,7 +136,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) ra[j] = load4t(A, lda, k0 + 4 * a_kq + j, m0 + 4 * a_mq, M, a_vec);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) rb[j] = load4t(B, ldb, k0 + 2 * b_kp + j, n0 + 4 * b_nq, N, b_vec);
+      for (int bb = 0; bb < NB / 2; ++bb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          rb[2 * bb + j] = load4t(B, ldb, k0 + 2 * b_kp + j, n0 + 4 * (b_nq + 16 * bb), N, b_vec);
       return;
     }
 #pragma unroll
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
       ra[p] = load4(A, lda, m0 + (v >> 3), M, k0 + ((v & 7) << 2), a_vec);
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NB; ++p) {
       const int v = t + p * 256;
       rb[p] = load4(B, ldb, n0 + (v >> 3), N, k0 + ((v & 7) << 2), b_vec);
     }
@@ -160,15 +167,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
         *reinterpret_cast<uint2 *>(&As[1][32 * i + a_mq][4 * a_kq]) = mm;
         *reinterpret_cast<uint2 *>(&As[2][32 * i + a_mq][4 * a_kq]) = ll;
       }
-      const float bx[4][2] = {{rb[0].x, rb[1].x}, {rb[0].y, rb[1].y}, {rb[0].z, rb[1].z}, {rb[0].w, rb[1].w}};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t h0, h1, m0_, m1, l0, l1;
-        split3(bx[i][0], h0, m0_, l0);
-        split3(bx[i][1], h1, m1, l1);
-        *reinterpret_cast<uint32_t *>(&Bs[0][16 * i + b_nq][2 * b_kp]) = h0 | (h1 << 16);
-        *reinterpret_cast<uint32_t *>(&Bs[1][16 * i + b_nq][2 * b_kp]) = m0_ | (m1 << 16);
-        *reinterpret_cast<uint32_t *>(&Bs[2][16 * i + b_nq][2 * b_kp]) = l0 | (l1 << 16);
+      for (int bb = 0; bb < NB / 2; ++bb) {
+        const float4 r0 = rb[2 * bb], r1 = rb[2 * bb + 1];
+        const float bx[4][2] = {{r0.x, r1.x}, {r0.y, r1.y}, {r0.z, r1.z}, {r0.w, r1.w}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint32_t h0, h1, m0_, m1, l0, l1;
+          split3(bx[i][0], h0, m0_, l0);
+          split3(bx[i][1], h1, m1, l1);
+          // tile row 4 (nq + 16 bb) + i of a 64-row half is kept at LDS row 64 bb + 16 i + nq (see the A tile)
+          *reinterpret_cast<uint32_t *>(&Bs[0][64 * bb + 16 * i + b_nq][2 * b_kp]) = h0 | (h1 << 16);
+          *reinterpret_cast<uint32_t *>(&Bs[1][64 * bb + 16 * i + b_nq][2 * b_kp]) = m0_ | (m1 << 16);
+          *reinterpret_cast<uint32_t *>(&Bs[2][64 * bb + 16 * i + b_nq][2 * b_kp]) = l0 | (l1 << 16);
+        }
       }
       return;
     }
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
       *reinterpret_cast<uint2 *>(&As[2][row][k4]) = ll;
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NB; ++p) {
       const int v = t + p * 256;
       uint2 hh, mm, ll;
       split3x4(rb[p], hh, mm, ll);
@@ -202,20 +214,21 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
     if (k0 + XBK < ke) fetch(k0 + XBK);           // next tile's loads fly under this tile's MFMAs
 #pragma unroll
     for (int ks = 0; ks < XBK; ks += 16) {
-      Frag8 a[3], b[2][3];
+      Frag8 a[3], b[NJ][3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
         // LDS row of tile row (32 wave + r) resp. (32 j + r): the identity, or the TN stash's permutation
         const int arow = TN ? (r & 3) * 32 + wave * 8 + (r >> 2) : wave * 32 + r;
         a[pl].u = *reinterpret_cast<const uint4 *>(&As[pl][arow][ks + 8 * h]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int brow = TN ? (r & 3) * 16 + j * 8 + (r >> 2) : j * 32 + r;
+        for (int j = 0; j < NJ; ++j) {
+          // (TN: tile row 32 j + r lies in the 64-row half j / 2, at 64 (j / 2) + 16 (r & 3) + 8 (j & 1) + (r >> 2))
+          const int brow = TN ? 64 * (j >> 1) + (r & 3) * 16 + (j & 1) * 8 + (r >> 2) : j * 32 + r;
           b[j][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][brow][ks + 8 * h]);
         }
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         // smallest products first (0 = h, 1 = m, 2 = l)
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[j][1].v, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, b[j][0].v, acc[j], 0, 0, 0);
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
   float *dst = to_slab ? slabs + (size_t)blockIdx.z * (size_t)M * (size_t)N : C;
   const int64_t ldd = to_slab ? N : ldc;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int64_t n = n0 + j * 32 + r;
     if (n >= N) continue;
     const float bv = (!to_slab && bias) ? bias[n] : 0.f;
@@ -256,8 +269,12 @@ struct XPlan {
   int64_t k_per_split;
 };
 
+// the N tile: 128 once the output is at least two 64-wide tiles wide
+static int pick_bn(int64_t N) { return N >= 128 ? 128 : 64; }
+
 static XPlan plan_x(int64_t M, int64_t N, int64_t K) {
   XPlan p;
+  const int XBN = pick_bn(N);
   const int64_t tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
   int64_t s = 1;
   if (tiles < 512 && K >= 512) {                 // few output tiles, long reduction: fill the chip by cutting K
@@ -277,6 +294,7 @@ static XPlan plan_x(int64_t M, int64_t N, int64_t K) {
 // weight gradients: outputs of a few tiles, reductions over all graph nodes -- up to 256 slabs of at least 128 k
 static XPlan plan_x_tn(int64_t M, int64_t N, int64_t K) {
   XPlan p;
+  const int XBN = pick_bn(N);
   const int64_t tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
   int64_t s = 1;
   if (tiles < 512 && K >= 512) {
@@ -315,9 +333,14 @@ extern "C" int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, 
     return fail(CHAOREC_E_WORKSPACE, "gemm_tn_bf16x3: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
+  const int XBN = pick_bn(N);
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
-  hipLaunchKernelGGL(gemm_bf16x3_kernel<true>, grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K, lda, ldb,
-                     ldc, 0, p.k_per_split, slabs);
+  if (XBN == 128)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, 128>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K,
+                       lda, ldb, ldc, 0, p.k_per_split, slabs);
+  else
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, 64>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K, lda,
+                       ldb, ldc, 0, p.k_per_split, slabs);
   int rc = check_launch("gemm_bf16x3_kernel<TN>");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
@@ -344,9 +367,14 @@ extern "C" int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, 
     return fail(CHAOREC_E_WORKSPACE, "gemm_nt_bf16x3: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
+  const int XBN = pick_bn(N);
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
-  hipLaunchKernelGGL(gemm_bf16x3_kernel<false>, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
-                     p.k_per_split, slabs);
+  if (XBN == 128)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, 128>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
+                       p.k_per_split, slabs);
+  else
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, 64>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
+                       p.k_per_split, slabs);
   int rc = check_launch("gemm_bf16x3_kernel<NT>");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
