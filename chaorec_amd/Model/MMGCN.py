@@ -31,6 +31,7 @@ class GCN(torch.nn.Module):
         self.concate = concate
         self.has_id = has_id
         self.device = device
+        self._const_key, self._const = None, None
 
         if self.dim_latent:
             self.preference = nn.init.xavier_normal_(torch.rand((self.num_user, self.dim_latent))).to(self.device)
@@ -66,12 +67,54 @@ class GCN(torch.nn.Module):
             return ops.linear(torch.cat((h, u_hat), dim=1), g.weight, g.bias, act=1)
         return F.leaky_relu(ops.linear(h, g.weight, g.bias) + u_hat)
 
+    def _constant_input(self, features):
+        """Without the latent MLP (the textual branch: Model/MMGCN.py:176-180 builds it with dim_latent=None) the first
+        layer's input  x = normalize([preference; features])  depends on no trainable tensor -- `preference` is a plain
+        tensor in the reference (Q2) and the features are data.  x, and with it A x of the first convolution, are then the
+        same in every step: computed once, keyed on the tensors' storage and version counters.
+        -> (x, [A x | A 1 | 0-pad]) or None."""
+        if self.dim_latent or self.preference.requires_grad or features.requires_grad or \
+                not isinstance(self.edge_index, graph.CSR):
+            return None
+        key = (self.preference.data_ptr(), self.preference._version, features.data_ptr(), features._version,
+               id(self.edge_index))
+        if self._const_key != key:
+            with torch.no_grad():
+                x = F.normalize(torch.cat((self.preference, features), dim=0))
+                ax = ops.spmm_raw(self.edge_index, x)
+                ones = torch.ones((x.shape[0], 4), dtype=x.dtype, device=x.device)
+                rowsum = ops.spmm_raw(self.edge_index, ones)[:, :1]
+                pad = (-(x.shape[1] + 1)) % 4
+                self._const = (x, torch.cat((ax, rowsum, x.new_zeros(x.shape[0], pad)), dim=1).contiguous(), pad)
+            self._const_key = key
+        return self._const
+
+    def _layer1_constant(self, x, ax_aug, pad, id_embedding):
+        """_layer(1, ...) for a constant input: BasicGCN's  A (x W^T + 1 b^T) = (A x) W^T + (A 1) b^T  as ONE product of the
+        cached [A x | A 1] with [W | b] -- no 768-wide SpMM forward, none backward (the weight gradient is a product with
+        the same cached operand).  Same arithmetic up to the association of the sums."""
+        conv, lin, g = self.conv_embed_1, self.linear_layer1, self.g_layer1
+        w_aug = torch.cat((conv.lin.weight, conv.lin.bias[:, None], conv.lin.weight.new_zeros(conv.lin.weight.shape[0], pad)), 1)
+        h = ops.linear(ax_aug, w_aug, None, act=1)                                   # equation 1 (+ leaky_relu)
+        u_hat = ops.linear(x, lin.weight, lin.bias, act=1)                           # equation 5
+        if self.has_id:
+            u_hat = u_hat + id_embedding
+        if self.concate:
+            return ops.linear(torch.cat((h, u_hat), dim=1), g.weight, g.bias, act=1)
+        return F.leaky_relu(ops.linear(h, g.weight, g.bias) + u_hat)
+
     def forward(self, features, id_embedding):
         """Model/MMGCN.py:96-143."""
-        temp_features = ops.linear(features, self.MLP.weight, self.MLP.bias) if self.dim_latent else features
-        x = torch.cat((self.preference, temp_features), dim=0)
-        x = F.normalize(x)
-        for k in (1, 2, 3, 4):
+        const = self._constant_input(features)
+        if const is not None:
+            x = self._layer1_constant(const[0], const[1], const[2], id_embedding)
+            first = 2
+        else:
+            temp_features = ops.linear(features, self.MLP.weight, self.MLP.bias) if self.dim_latent else features
+            x = torch.cat((self.preference, temp_features), dim=0)
+            x = F.normalize(x)
+            first = 1
+        for k in range(first, 5):
             x = self._layer(k, x, id_embedding)
         return x
 
