@@ -193,7 +193,7 @@ def test_freedom_training_with_claimed_feature_tables(dev):
     # (two runs are not bit-comparable: the BPR backward and the scatter of gy add with float atomics; the bitwise
     # lazy == dense statement is test_adam_lowrank_lazy_then_flush_equals_dense's)
     for k in out["claimed"][1]:
-        assert torch.allclose(out["claimed"][1][k], out["lazy"][1][k], rtol=0, atol=1e-7), k
+        assert torch.allclose(out["claimed"][1][k], out["lazy"][1][k], rtol=0, atol=5e-7), k
         for n in out["claimed"][2][k]:
             assert torch.allclose(out["claimed"][2][k][n], out["lazy"][2][k][n], rtol=1e-4, atol=1e-9), (k, n)
         assert torch.allclose(out["claimed"][1][k], out["dense_grad"][1][k], rtol=0, atol=2e-6), k
@@ -223,7 +223,7 @@ def test_freedom_claimed_step_captured_equals_eager(dev):
             torch.cuda.synchronize()
             res.append({k: v.detach().clone() for k, v in m.named_parameters()})
         for k in res[0]:
-            assert torch.allclose(res[0][k], res[1][k], rtol=0, atol=1e-7), (lazy, k)
+            assert torch.allclose(res[0][k], res[1][k], rtol=0, atol=5e-7), (lazy, k)
 
 
 @pytest.mark.parametrize("lazy", [False, True])
