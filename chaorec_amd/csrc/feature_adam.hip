@@ -17,12 +17,14 @@
 //   MODE 2 (flush)  every row catches up to the current step (no gradient): what a reader of the table needs first.
 //   MODE 3 (catch up) the same for the rows with a non-zero row in `gy` (here a flag array): the rows of the next batch,
 //                   before the forward gathers them.
-// Modes 1 and 3 can be given the list of distinct rows to visit (chaorec_unique_rows over the batch's item ids): the
-// launch then touches those rows only instead of scanning gy for them -- scanning is 16 strips x I short dependent
-// loads, which costs more than the update itself.
+// Modes 1 and 3 walk a LIST of distinct rows (adam_lowrank_rows_kernel): the caller's (chaorec_unique_rows over the batch's
+// item ids), or one the launch builds from the non-zero rows of gy (rows_from_gy_kernel) -- scanning gy inside the update
+// kernel was 16 strips x I short dependent loads, more than the update itself.
 //
-// Layout: a workgroup owns a strip of 256 columns (one float4 per lane) and a chunk of rows, its four waves take groups
-// of rows round-robin, all loads of a group in flight together.  HBM-bound in MODE 0 (24 B per element), latency/issue-bound in MODE 1.
+// Layout: a workgroup owns a strip of 256 columns (one float4 per lane) and a chunk of rows (MODE 0: 16 waves take groups
+// of four rows round-robin; modes 1-3: a few rows per wave), all loads of a group in flight together.  MODE 0 is HBM-bound
+// (24 B per element); the lazy modes are bound by Adam's arithmetic (two IEEE divisions and a square root per element and
+// replayed step) and by their short dependent chains.  Also here: chaorec_adam_multi_f32 (many small tensors, one launch).
 #include "common.h"
 
 namespace chaorec {
