@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MIN_TIMED_S = 0.05                   # the timed region is repeated in blocks of --steps until this much was timed
 STEADY_EVALS = 6                     # carried-threshold evaluations (one per epoch) before the timed one
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md matrix-core table
 TRAINED_STEPS = 5000            # ~32 epochs of the sports-sized graph: embeddings in a trained state
@@ -188,12 +189,19 @@ def load_graph(dataset, synthetic=False):
     travel with the repository as packed fixtures (tests/golden/<dataset>_interactions.npz); config5_shard (one GPU's
     share of BASELINE configs[4]) is synthetic by definition."""
     from chaorec_amd import dataload
-    from chaorec_amd.synthetic import DATASET_SHAPES, synthetic_interactions
+    from chaorec_amd.synthetic import DATASET_SHAPES, DEVICE_BUILT, synthetic_interactions, synthetic_interactions_torch
     packed = None if synthetic else dataload.packed_interactions(dataset)
     if packed is not None:
         return packed["train"], packed["num_user"], packed["num_item"], "real"
     U, I, E = DATASET_SHAPES[dataset]
+    if dataset in DEVICE_BUILT:      # BASELINE configs[4] whole: generated and laid out on the GPU (an int32 [E, 2] CUDA tensor)
+        return synthetic_interactions_torch(U, I, E, seed=42, device="cuda"), U, I, "synthetic"
     return synthetic_interactions(U, I, E, seed=42), U, I, "synthetic"
+
+
+def spmm_source_hash():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "chaorec_amd", "csrc", "spmm.hip"), "rb").read()).hexdigest()
 
 
 def time_spmm_calls(ops, calls, reps=20, passes=5):
@@ -233,22 +241,35 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     from chaorec_amd.Model import LightGCN
     from chaorec_amd.optim import FusedAdam, FusedLightGCNStep, GraphedTrainStep
     L, B, reg = args.n_layers, args.batch, 1e-3
+    t_build = time.perf_counter()
     edges, U, I, data_kind = load_graph(dataset, synthetic)
+    torch.cuda.synchronize()
+    build_s = {"edge_list_s": time.perf_counter() - t_build}
     E = len(edges)
     e_dir = 2 * E
     torch.manual_seed(42)
+    t_build = time.perf_counter()
     model = LightGCN(U, I, edges, None, D, reg, L, "add", dev).to(dev)
+    torch.cuda.synchronize()
+    build_s["model_csr_history_tables_s"] = time.perf_counter() - t_build
+    t_build = time.perf_counter()
+    model.graph.schedule(D)                     # (the SpMM row descriptors, built on the host from a copy of the CSR)
+    torch.cuda.synchronize()
+    build_s["spmm_schedule_s"] = time.perf_counter() - t_build
     opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else FusedAdam(model.parameters(), lr=1e-3)
-    edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
+    edges_dev = edges.to(torch.int64) if torch.is_tensor(edges) else torch.from_numpy(edges.astype(np.int64)).to(dev)
+    if torch.is_tensor(edges):
+        edges = None                            # (the int32 device copy is not needed any more; no CPU baseline at this size)
     loss_sum = torch.zeros(1, device=dev)
     batch_counter = torch.zeros(1, dtype=torch.int64, device=dev)   # device-resident: advances inside the graph
     fused = not args.unfused and not args.torch_adam and L >= 1
+    spr = 1 if E > 50_000_000 else args.steps_per_replay     # (a config-5 step is ~0.25 s: nothing to gain from k-step replays)
     n_loss = [0]
     if fused:
         # 2L+2 launches per step, no autograd, no optimizer launch (optim.FusedLightGCNStep); --no-graph launches the
         # same kernels eagerly
         stepper = FusedLightGCNStep(model, opt, batch_size=B, edges=edges_dev, seed=42, step_dev=batch_counter,
-                                    loss_accum=loss_sum, capture=not args.no_graph, steps_per_replay=args.steps_per_replay)
+                                    loss_accum=loss_sum, capture=not args.no_graph, steps_per_replay=spr)
         launch = ((f"captured hipGraph, {stepper.steps_per_replay} steps per replay" if not args.no_graph
                    else "eager launches") + ", fused step (2L+1 kernels per step + one loss-bookkeeping launch per replay)")
 
@@ -286,11 +307,19 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     if not fused:
         acc0.zero_()
     n_loss[0] = 0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # The timed region is a block of EXACTLY `steps` steps between two synchronisations.  A block of the driver's 20
+    # sports steps is 2.5 ms (two graph replays): too short to quote alone, so the block is repeated until >= 50 ms
+    # have been timed and the MEDIAN block is the one reported; every block's ms/step is in `ms_per_step_blocks`.
+    blocks = []
+    while True:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+        if sum(blocks) >= MIN_TIMED_S or len(blocks) >= 64:
+            break
+    dt = float(np.median(blocks))
     ms_per_step = dt / steps * 1e3
     loss_mean = (float(loss_sum.item()) if fused else float(acc0.item())) / max(n_loss[0], 1)
     msgs_per_step = 2 * L * e_dir
@@ -336,13 +365,22 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     table_mb = N * D * 4 / 1e6
     traffic = None
     tpath = os.path.join(ROOT, "profiles", f"spmm_traffic_{dataset}_d{D}.json")
+    traffic_note = "no PMC file for this workload under profiles/"
     if os.path.exists(tpath):
+        # PMC traffic is collected by separate rocprofv3 --pmc passes (tools/collect_profiles.py), not in this run: it
+        # is only quoted when the file was measured on the spmm.hip this run was built from
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("spmm_hip_sha256") == spmm_source_hash():
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_note = "from " + os.path.relpath(tpath, ROOT) + " (same spmm.hip)"
+            else:
+                traffic_note = os.path.relpath(tpath, ROOT) + " was measured on a different spmm.hip: dropped"
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": spmm_kernel_name(D), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": model_bytes,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                "algorithmic_bytes_per_launch": model_bytes,
                 "avg_launch_us": avg_spmm_ms * 1e3, "compulsory_bytes_per_launch": compulsory,
                 "launches_per_step": len(plain),
                 "note": ("embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is against "
@@ -423,14 +461,20 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 out["steady_st"] = st2
             # the reference contract: a LongTensor on the CPU (Model/LightGCN.py:162) -- wall time incl. the D2H copy,
             # through the model's own gene_ranklist (carried thresholds, as the evaluation loop calls it)
-            model.gene_ranklist()
-            t1 = time.perf_counter()
-            for _ in range(3):
+            out["host_ms"] = None
+            if not heavy:
                 model.gene_ranklist()
-            out["host_ms"] = (time.perf_counter() - t1) / 3 * 1e3
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    model.gene_ranklist()
+                out["host_ms"] = (time.perf_counter() - t1) / 3 * 1e3
         return out
 
-    steps_done = warmup + steps
+    steps_done = warmup + steps * len(blocks)
+    # (BASELINE configs[4] whole is 5 PFLOP per ranking call -- seconds: one timed call, and no 4 GB rank list on the host)
+    heavy = 2.0 * U * I * D > 1e15
+    if heavy:
+        reps_rank = 1
     early = time_ranklist(False)
     extra = trained_steps - steps_done - (STEADY_EVALS + 1) * epoch_steps
     if extra > 0 and (extra + (STEADY_EVALS + 1) * epoch_steps) * ms_per_step < 10_000:
@@ -443,7 +487,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         # (no trained state within the run's budget -- an epoch of the config-5 shard is 24 k steps --: the cold call
         #  only; thresholds carried across the first steps of training are stale by construction, ranking.RankState
         #  backs off from them)
-        rk = time_ranklist(False)
+        rk = early if heavy else time_ranklist(False)
         state = f"after {steps_done} training steps; cold thresholds"
     score_ms = rk.get("steady_ms", rk["cold_ms"])
     early_ms, early_st = early["cold_ms"], early["cold_st"]
@@ -453,7 +497,8 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 value=msgs_per_step / (dt / steps), msgs_per_step=msgs_per_step, loss_mean=loss_mean, launch=launch,
                 roofline=roofline, score_ms=score_ms, score_state=state, early_ms=early_ms, early_st=early_st,
                 cold_ms=rk["cold_ms"], cold_st=rk["cold_st"], steady="steady_ms" in rk,
-                score_st=st, score_tf=tf, host_rank_ms=host_ms, edges=edges, reg=reg, table_mb=table_mb)
+                score_st=st, score_tf=tf, host_rank_ms=host_ms, edges=edges, reg=reg, table_mb=table_mb,
+                build_s=build_s, blocks_ms_per_step=[b / steps * 1e3 for b in blocks])
 
 
 def scoring_roofline(r):
@@ -479,9 +524,13 @@ def main_single(args, dev):
         "value": r["value"], "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
         "users_scored_per_s": U / (r["score_ms"] * 1e-3),
         "users_scored_per_s_cold": U / (r["cold_ms"] * 1e-3),
-        "users_scored_per_s_incl_d2h": U / (r["host_rank_ms"] * 1e-3),
+        "users_scored_per_s_incl_d2h": U / (r["host_rank_ms"] * 1e-3) if r["host_rank_ms"] else None,
         "users_scored_per_s_right_after_timed_steps": U / (r["early_ms"] * 1e-3),
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+        "timed_blocks": {"blocks_of_steps": len(r["blocks_ms_per_step"]), "ms_per_step_min": min(r["blocks_ms_per_step"]),
+                         "ms_per_step_median": r["ms_per_step"], "ms_per_step_max": max(r["blocks_ms_per_step"]),
+                         "note": f"the --steps block repeated until >= {MIN_TIMED_S * 1e3:.0f} ms were timed; value and "
+                                 "ms_per_step are the median block"},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": r["data"],
         "config": {"workload": f"LightGCN train step on the {'real' if r['data'] == 'real' else 'synthetic'} "
                                f"{args.dataset} graph (U={U}, I={I}, E_dir={r['e_dir']}), dim={D}, n_layers={r['L']}, "
@@ -496,12 +545,12 @@ def main_single(args, dev):
                    "optimizer": "torch.optim.Adam" if args.torch_adam else
                    ("Adam in the last backward SpMM's epilogue (chaorec_spmm_csr_adam_f32)" if "fused" in r["launch"]
                     else "FusedAdam (chaorec_adam_step_f32)"),
-                   "parallelism": "single GPU"},
+                   "parallelism": "single GPU", "host_build_seconds": r["build_s"]},
         "roofline": r["roofline"], "roofline_scoring": scoring_roofline(r), "loss_mean": r["loss_mean"],
     }
     edges, reg = r["edges"], r["reg"]
     # --- the HBM-bound regime in the same run: one GPU's share of BASELINE configs[4] -----------------------------
-    if not args.no_hbm_regime and args.dataset != "config5_shard":
+    if not args.no_hbm_regime and args.dataset not in ("config5_shard", "config5"):
         del r
         torch.cuda.empty_cache()
         h = measure_single_gpu(args, "config5_shard", 128, args.hbm_steps, 3, dev, 0, reps_rank=3)
@@ -517,7 +566,7 @@ def main_single(args, dev):
             "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"],
         }
         del h
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and edges is not None:
         out["cpu_baseline"] = cpu_baseline(edges, U, I, D, args.n_layers, args.batch, reg, args.cpu_seconds)
     print(json.dumps(out), flush=True)
 

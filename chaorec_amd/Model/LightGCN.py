@@ -45,7 +45,10 @@ class LightGCN(nn.Module):
         self.n_layers = n_layers
         # reference keeps the raw bidirectional edge list (Model/LightGCN.py:63-64); kept for callers
         # that read it, the kernels use the CSR below
-        self.edge_index = graph.bidirectional_edge_index(edge_index)
+        # (an edge list handed over as a CUDA tensor -- config 5: 2e8 interactions generated on the device -- is laid
+        #  out there; the raw [2, 2E] int64 copy, 6.4 GB at that size and read by nothing here, is not made)
+        on_device = torch.is_tensor(edge_index) and edge_index.is_cuda
+        self.edge_index = None if on_device else graph.bidirectional_edge_index(edge_index)
         self.graph = graph.lightgcn_csr(edge_index, num_user + num_item).to(device)
         # (user_item_dict=None: the history is derived from the edge list, vectorised -- graphs with millions of
         #  users, where a python dict of lists is the slowest thing in the constructor)

@@ -6,6 +6,7 @@ libchaorec_hip.so and returns immediately.  There is no CPU implementation: a CP
 missing library raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -453,6 +454,42 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     U, D = user_emb.shape
     I = item_emb.shape[0]
     dev = user_emb.device
+    lib = _lib.load()
+    limit = int(os.environ.get("CHAOREC_SCORE_WS_LIMIT", str(24 << 30)))
+    if U > 4096 and lib.chaorec_score_topk_workspace_bytes(U, I, K, D) > limit:
+        # The workspace is per user (candidate lists of every sweep split, the exact route's partial lists: ~20 KB per
+        # user): BASELINE configs[4] at 1e7 users would ask for > 200 GB.  The users are independent, so the call is
+        # cut into user ranges whose workspace fits `limit`; every range re-packs the item table (a few ms at 2 M x 128).
+        per = max(4096, (U * limit // lib.chaorec_score_topk_workspace_bytes(U, I, K, D)) // 4096 * 4096)
+        while per > 4096 and lib.chaorec_score_topk_workspace_bytes(per, I, K, D) > limit:
+            per -= 4096
+        idx = idx_out if idx_out is not None else torch.empty((U, K), dtype=torch.int64, device=dev)
+        val = torch.empty((U, K), dtype=torch.float32, device=dev)
+        tot = torch.zeros(4, dtype=torch.int32, device=dev) if counters is not None else None
+        agg = {}
+        for u0 in range(0, U, per):
+            u1 = min(U, u0 + per)
+            sub = {} if stats is not None else None
+            _, v = score_topk(user_emb[u0:u1], item_emb, None if hist is None else (hist[0][u0:u1 + 1], hist[1]), mask_value,
+                              K, id_offset=id_offset, precision=precision, stats=sub,
+                              hint=None if hint is None else hint[u0:u1], hint_valid=hint_valid, hint_rank=hint_rank,
+                              light=light, counters=counters, idx_out=idx[u0:u1])
+            val[u0:u1] = v
+            if tot is not None:
+                tot += counters
+            if sub is not None:
+                for k_, v_ in sub.items():
+                    if isinstance(v_, dict):
+                        d_ = agg.setdefault(k_, {})
+                        for kk, vv in v_.items():
+                            d_[kk] = d_.get(kk, 0) + vv
+                    else:
+                        agg[k_] = max(agg.get(k_, 0), v_) if k_ == "longest_list" else agg.get(k_, 0) + v_
+        if tot is not None:
+            counters.copy_(tot)
+        if stats is not None:
+            stats.update(agg, user_chunks=(U + per - 1) // per)
+        return idx, val
     if idx_out is not None:
         if idx_out.dtype != torch.int64 or tuple(idx_out.shape) != (U, K) or not idx_out.is_contiguous() or \
                 not (idx_out.is_cuda or idx_out.is_pinned()):
@@ -461,7 +498,6 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     else:
         idx = torch.empty((U, K), dtype=torch.int64, device=dev)
     val = torch.empty((U, K), dtype=torch.float32, device=dev)
-    lib = _lib.load()
     nbytes = lib.chaorec_score_topk_workspace_bytes(U, I, K, D)
     ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
     rowptr, col = hist if hist is not None else (None, None)
@@ -614,7 +650,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0] and xp is not None and weight.shape[0] <= 64 and xp._chaorec_lowrank_sink.accepts(xp):
             # the input is a claimed feature table (Model/MGCN.py:80-83: trainable [I, 4096] features projected as a
             # whole): its dense gradient gy W is never formed, the optimizer applies it row by row (adam_lowrank)
-            xp._chaorec_lowrank_sink.submit(xp, gy, weight, None)
+            xp._chaorec_lowrank_sink.submit(xp, gy, weight, None, dense_reader=True)
         elif ctx.needs_input_grad[0]:
             # input gradient g W: as g (W^T)^T on the bf16 MFMA pipe where the forward went there too (W is small:
             # its transpose is one short copy)

@@ -50,6 +50,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.lazy_rows = (os.environ.get("CHAOREC_LAZY_ADAM", "0") == "1") if lazy_rows is None else bool(lazy_rows)
         self._pending = {}      # claimed parameter -> [gy_full, projection weight] of the backward that just ran
         self._claimed = {}      # id(parameter) -> its group
+        self._dense_read = set()  # id(claimed parameter) read as a whole by ops.linear: never updated lazily (submit())
         self._bc_table = None
         for group in self.param_groups:
             for p in group["params"]:
@@ -62,9 +63,15 @@ class FusedAdam(torch.optim.Optimizer):
     def accepts(self, p):
         return id(p) in self._claimed and p.is_cuda
 
-    def submit(self, p, gy_full, weight, row_token=None):
+    def submit(self, p, gy_full, weight, row_token=None, dense_reader=False):
+        """dense_reader: the submission comes from ops.linear -- a forward that reads EVERY row of the table (VBPR's v_feat,
+        MGCN's image / text tables).  Such a table cannot be updated lazily: its forward has no catch-up, so rows outside
+        the batch would be read stale (and ranked stale by gene_ranklist).  It is brought up to date once and from then on
+        takes the dense update (mode 0), whatever `lazy_rows` says."""
         if weight.shape[0] > 64:
             raise ValueError("FusedAdam: a claimed feature table needs a projection of at most 64 outputs")
+        if dense_reader and id(p) not in self._dense_read:
+            self._make_dense(p)
         cur = self._pending.get(p)
         if cur is None:
             self._pending[p] = [gy_full, weight, row_token]
@@ -82,6 +89,18 @@ class FusedAdam(torch.optim.Optimizer):
             reduce_fn(cur[0])
             cur[2] = None
 
+    @torch.no_grad()
+    def _make_dense(self, p):
+        self._dense_read.add(id(p))
+        st = self.state.get(p)
+        if st and "last" in st:          # rows deferred so far: replay them now, then drop the lazy bookkeeping
+            group = self._claimed[id(p)]
+            ops.adam_lowrank(p.data, None, None, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
+                             group["eps"], group["weight_decay"], step_dev=self._step_dev, mode=2, last=st["last"],
+                             bc_table=self._bc_table)
+            for k in ("last", "claim", "stamp", "rowcount", "rowlist", "list_gen"):
+                st.pop(k, None)
+
     def zero_grad(self, set_to_none=True):
         self._pending.clear()
         super().zero_grad(set_to_none=set_to_none)
@@ -91,7 +110,7 @@ class FusedAdam(torch.optim.Optimizer):
         if "exp_avg" not in st:
             st["exp_avg"] = torch.zeros_like(p)
             st["exp_avg_sq"] = torch.zeros_like(p)
-        if self.lazy_rows and "last" not in st:
+        if self.lazy_rows and "last" not in st and id(p) not in self._dense_read:
             strips = ops.adam_lowrank_strips(p.shape[1])
             st["last"] = self._step_dev.to(torch.int32).expand(strips * p.shape[0]).contiguous().view(strips, p.shape[0])
             st["claim"] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)   # chaorec_unique_rows' scratch
@@ -175,11 +194,12 @@ class FusedAdam(torch.optim.Optimizer):
             # the row list of this batch's catch-up serves the update too (the gradient is zero in every other row) --
             # unless another forward has re-listed since: then the update finds its rows by scanning gy
             rl = None
-            if self.lazy_rows and row_token is not None and row_token == st.get("list_gen"):
+            lazy = self.lazy_rows and "last" in st       # (a table ops.linear reads as a whole has no "last": dense update)
+            if lazy and row_token is not None and row_token == st.get("list_gen"):
                 rl = (st["rowlist"], st["rowcount"])
             ops.adam_lowrank(p.data, gy_full, weight, st["exp_avg"], st["exp_avg_sq"], 0, group["lr"], group["betas"],
                              group["eps"], group["weight_decay"], step_dev=self._step_dev,
-                             mode=1 if self.lazy_rows else 0, last=st.get("last"), bc_table=self._bc_table, rowlist=rl)
+                             mode=1 if lazy else 0, last=st.get("last") if lazy else None, bc_table=self._bc_table, rowlist=rl)
         self._pending.clear()
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]

@@ -624,3 +624,18 @@ def test_vbpr_golden(dev):
         out[claim] = {k: v.detach().clone() for k, v in m.named_parameters()}
     for k in out[True]:
         assert torch.allclose(out[True][k], out[False][k], rtol=0, atol=2e-6), k
+    # lazy rows must not apply to a table whose forward reads EVERY row (ops.linear): rows outside the batch would be
+    # projected and ranked stale.  FusedAdam(lazy_rows=True) has to train this model exactly like lazy_rows=False.
+    lazy_out = {}
+    for lazy in (False, True):
+        m = make()
+        opt = FusedAdam(m.parameters(), lr=1e-3, lazy_rows=lazy)
+        for _ in range(4):
+            opt.zero_grad()
+            m.loss(*batch).backward()
+            opt.step()
+        lazy_out[lazy] = ({k: v.detach().clone() for k, v in m.named_parameters()}, m.result.detach().clone())
+        assert "last" not in opt.state[m.v_feat.weight]
+    for k in lazy_out[True][0]:       # (atomics order in the BPR backward: last-bit noise between any two runs)
+        assert torch.allclose(lazy_out[True][0][k], lazy_out[False][0][k], rtol=0, atol=2e-6), k
+    assert torch.allclose(lazy_out[True][1], lazy_out[False][1], rtol=0, atol=2e-6)

@@ -181,6 +181,7 @@ def test_freedom_clothing_real_graph_vs_reference(dev):
     ref_ent_ok = np.repeat(ok_rows, ref_rp[1:] - ref_rp[:-1])
     assert np.allclose(val[ent_ok], ref_val_all[ref_ent_ok], rtol=1e-6)
     print(f"FREEDOM/clothing kNN graph: {len(differ)} of {I} rows differ from the reference's, all at fp32 near-ties")
+    product_mm_adj = m.mm_adj
     m.mm_adj = graph.CSR(torch.from_numpy(ref_rp), torch.from_numpy(ref_col.astype(np.int32)),
                          torch.from_numpy(ref_val_all.astype(np.float32)), I, I).to(dev)
     assert m.mm_adj.nnz == int(g["mm_nnz"])
@@ -215,10 +216,35 @@ def test_freedom_clothing_real_graph_vs_reference(dev):
     assert np.allclose(m.text_embedding.weight.grad.cpu().numpy()[pos16], g["g_text_emb_rows"], rtol=2e-4, atol=1e-10)
     assert float(m.image_embedding.weight.grad.double().abs().sum()) == pytest.approx(float(g["g_image_emb_abs_sum"]), rel=1e-4)
     _check_rank_and_metrics(m, d, g, 1e-6, rtol=1e-4, atol=1e-8)
+    # End to end on the PRODUCT-built kNN graph (the <= 24 near-tie rows differ from the reference's): the same forward
+    # and evaluation; north_star's bound is on the metrics -- Recall / NDCG (all five, @10/20/50, val and test) within
+    # 1e-4 of the reference's numbers.
+    m.mm_adj = product_mm_adj
+    m.zero_grad()
+    m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    res2 = m.result.detach().cpu().numpy()
+    assert np.abs(res2[rows] - g["result_rows"]).max() <= 1e-4 * np.abs(g["result_rows"]).max()
+    got = _device_metrics(m, d, g, m.gene_ranklist(to_cpu=False))
+    assert np.abs(got["val"] - g["val_metrics"]).max() < 1e-4
+    assert np.abs(got["test"] - g["test_metrics"]).max() < 1e-4
 
 
-def test_mmgcn_microlens_real_graph_vs_reference(dev):
-    """configs[3], single-GPU half: MMGCN on Data/microlens, 128-d visual / 768-d textual synthetic features."""
+@pytest.mark.parametrize("pipe", ["f32", "bf16x3"])
+def test_mmgcn_microlens_real_graph_vs_reference(dev, pipe):
+    """configs[3], single-GPU half: MMGCN on Data/microlens, 128-d visual / 768-d textual synthetic features.  Run on both
+    Linear pipes (ops.LINEAR_FORWARD): the exact k-ascending fp32 chain (`f32`) keeps the small golden's 3e-4 bound; the
+    split-bf16 pipe (fp32-grade products in another association) is allowed 2e-3 on single entries but must agree with the
+    reference on all but a small share of every gradient tensor."""
+    from chaorec_amd import ops
+    old_pipe = ops.LINEAR_FORWARD
+    ops.LINEAR_FORWARD = pipe
+    try:
+        _mmgcn_microlens(dev, pipe)
+    finally:
+        ops.LINEAR_FORWARD = old_pipe
+
+
+def _mmgcn_microlens(dev, pipe):
     from chaorec_amd import dataload, graph
     from chaorec_amd.Model import MMGCN
     g = load_golden("mmgcn_microlens.npz")
@@ -244,17 +270,27 @@ def test_mmgcn_microlens_real_graph_vs_reference(dev):
     scale = float(np.abs(g["result_rows"]).max())
     assert np.abs(res[rows] - g["result_rows"]).max() <= 2e-4 * scale
     assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=2e-5)
-    worst = 0.0
+    worst, worst_share = 0.0, 0.0
+    tight, loose = 3e-4, 2e-3
     for n, p in m.named_parameters():
         ref = g["g_" + n]
         mine = p.grad.cpu().numpy()
         mine_part = mine if ref.shape == mine.shape else mine[:ref.shape[0]]
         s = float(np.abs(ref).max()) + 1e-30
-        err = float(np.abs(mine_part - ref).max()) / s
-        worst = max(worst, err)
+        rel = np.abs(mine_part - ref) / s
+        err = float(rel.max())
+        share = float((rel > tight).mean())         # entries outside the exact pipe's bound
+        worst, worst_share = max(worst, err), max(worst_share, share)
         # (fp32 sums in another order than the reference's BLAS: a pre-activation within rounding of zero takes the other
         #  leaky-relu branch, and the [60 499, d] reductions of the weight gradients see that as ~1e-3 of their largest entry)
-        assert err <= 2e-3, (n, err)
+        if pipe == "f32":
+            assert err <= tight, (n, err)
+        else:
+            assert err <= loose and share <= 0.02, (n, err, share)
         assert np.abs(mine.astype(np.float64)).sum() == pytest.approx(float(g["gsum_" + n]), rel=1e-3), n
-    print(f"MMGCN/microlens: worst gradient error relative to the tensor's max {worst:.2e}")
-    _check_rank_and_metrics(m, d, g, 1e-5, rtol=1e-3, atol=1e-7)
+    print(f"MMGCN/microlens [{pipe}]: worst gradient error relative to the tensor's max {worst:.2e}; largest share of a "
+          f"tensor's sampled entries beyond {tight:.0e}: {worst_share:.4f}")
+    if pipe == "f32":
+        _check_rank_and_metrics(m, d, g, 1e-5, rtol=2e-4, atol=1e-7)
+    else:
+        _check_rank_and_metrics(m, d, g, 1e-5, rtol=1e-3, atol=1e-7)

@@ -16,6 +16,7 @@ rocprofv3 is started with the program directly after `--` (python3 bench.py ...)
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -28,6 +29,8 @@ WORKLOADS = {
     "sports": ("sports", 64, ["--steps", "60", "--warmup", "5", "--no-hbm-regime"], 1.478),
     "config5": ("config5_shard", 128, ["--dataset", "config5_shard", "--dim", "128", "--steps", "6", "--warmup", "2",
                                        "--no-hbm-regime"], 1.61),
+    "config5_full": ("config5", 128, ["--dataset", "config5", "--dim", "128", "--steps", "3", "--warmup", "1",
+                                      "--no-hbm-regime"], 1.61),
 }
 
 
@@ -96,6 +99,7 @@ def main():
                           "profiles/r01_c_spmm_hbm_scale.json); WRITE_SIZE exact; separate --pmc passes, eager launches",
             "hbm_bytes_per_launch": (fetch_kb * factor + write_kb) * 1024.0,
             "kernel_avg_us_rocprofv3": avg[0] / 1e3 if avg else None,
+            "spmm_hip_sha256": hashlib.sha256(open(os.path.join(ROOT, "chaorec_amd", "csrc", "spmm.hip"), "rb").read()).hexdigest(),
             "note": "L2 fabric-side requests: Infinity-Cache hits are included (at the cache-resident sports size this is "
                     "L2-miss traffic, not DRAM traffic); mean over the plain SpMM launches of the step (forward "
                     "propagates without the layer-mean epilogue and backward propagates without the Adam epilogue)",
