@@ -603,6 +603,11 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
     _lib.ensure_built()
     _lib.load()
     D, L, B, reg = args.dim, args.n_layers, args.batch, 1e-3
+    # the sharded step: "fused" (dist.FusedShardedLightGCNStep: joined-graph propagates, Adam in the last propagate's
+    # epilogue, no autograd) or "autograd" (round 2's path: loss_local -> backward -> FusedAdam under GraphedTrainStep)
+    step_kind = os.environ.get("CHAOREC_DIST_STEP", "fused")
+    if args.torch_adam or L < 1:
+        step_kind = "autograd"
     job = cdist.build_weak_scaling_job(args.dataset, world, rank, D, L, reg, dev, seed=42, synthetic=args.synthetic)
     model, edges, U, I, U1 = job["model"], job["local_edges"], job["num_user_local"], job["I"], job["U1"]
     E = len(edges)
@@ -629,7 +634,28 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         use_graph = float(flag.item()) > 0.0
     graphed = None
-    if use_graph:
+    fused = None
+    fused_loss = torch.zeros(1, device=dev)     # sum of this rank's batch losses, accumulated inside the step
+    if step_kind == "fused":
+        def make_fused(capture):
+            return cdist.FusedShardedLightGCNStep(model, opt, batch_size=B, edges=edges_dev, seed=42 + rank,
+                                                  step_dev=batch_counter, capture=capture, loss_accum=fused_loss)
+        if use_graph:
+            try:
+                fused = make_fused(True)
+            except Exception as exc:      # noqa: BLE001
+                print(f"[bench rank {rank}] hipGraph capture of the fused sharded step failed ({exc!r}); eager launches",
+                      file=sys.stderr)
+                fused = None
+            ok = torch.tensor([1.0 if fused is not None else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                fused = None
+        if fused is None:
+            use_graph = False
+            fused = make_fused(False)
+        graphed = fused if use_graph else None          # (what the launch-mode fields below report)
+    elif use_graph:
         try:
             graphed = GraphedTrainStep(model, opt, batch_fn=draw, loss_fn=model.loss_local)
         except Exception as exc:      # noqa: BLE001 -- any capture failure means "launch eagerly", never a wrong result
@@ -663,6 +689,12 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
 
     def step(i, force_eager=False):
         n_loss[0] += 1
+        if fused is not None:
+            if force_eager:           # (the SpMM-recording pass: the same launches, issued eagerly)
+                fused._launch()
+            else:
+                fused()
+            return
         if graphed is not None and not force_eager:
             graphed()                 # sampling + loss + backward + Adam: one hipGraph replay, no inputs
             loss = graphed.static_loss
@@ -756,12 +788,16 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                                f"(U={U1}x{world}, I={I}, E_dir={e_dir_all}), dim={D}, n_layers={L}, batch={B}x{world}; "
                                f"gene_ranklist top-50 over all users (cold thresholds)",
                    "messages_per_step": msgs_per_step_all, "gene_ranklist_ms": score_ms,
-                   "launch": "captured hipGraph per step" if graphed is not None else "eager launches",
-                   "optimizer": "torch.optim.Adam" if args.torch_adam else "FusedAdam (chaorec_adam_step_f32)",
+                   "launch": ("captured hipGraph per step" if graphed is not None else "eager launches") +
+                             (", fused sharded step (dist.FusedShardedLightGCNStep: 2L+5 launches, 2L+1 exchanges)"
+                              if fused is not None else ", autograd step"),
+                   "optimizer": "torch.optim.Adam" if args.torch_adam else
+                   ("Adam in the last user-row SpMM's epilogue + one fused launch on the replicated item rows"
+                    if fused is not None else "FusedAdam (chaorec_adam_step_f32)"),
                    "parallelism": f"user-row shards x{world}; item partials summed per layer by "
                                   f"{cdist.exchange_mode()} over {backend}"},
         "roofline": roofline, "roofline_scoring": scoring_roofline(r),
-        "loss_mean": float(loss_sum.item()) / max(n_loss[0], 1),
+        "loss_mean": (float(fused_loss.item()) / world if fused is not None else float(loss_sum.item())) / max(n_loss[0], 1),
     }
     dist.destroy_process_group()
     if args.probe_graph:

@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -114,6 +114,7 @@ SIGNATURES = {
                                                     c_ptr, c_ptr]),
     "chaorec_leaky_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_float, c_ptr, ctypes.c_int64, c_ptr]),
     "chaorec_mul_pair_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
+    "chaorec_rows_mean_f32": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_int64, c_ptr]),
     "chaorec_adam_lowrank_strips": (ctypes.c_int32, [ctypes.c_int32]),
     "chaorec_adam_bias_table": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_float, ctypes.c_float, c_ptr]),
     "chaorec_adam_lowrank_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,

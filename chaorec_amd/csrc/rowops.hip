@@ -357,6 +357,39 @@ extern "C" int chaorec_row_cosine_scale_bwd_f32(const float *grad_out, const flo
   return dispatch_row_cosine(grad_out, y, e, grad_y, grad_e, nullptr, n_rows, D, (hipStream_t)stream);
 }
 
+// out = w t_0 + w t_1 + ... + w t_{k-1}, accumulated in that order with separately rounded products and sums: the
+// association of LightGCN's layer mean (Model/LightGCN.py:86-93: final = 0 + w x_0 + w x_1 + ...), i.e. of
+// chaorec_spmm_csr_mean_f32's epilogue.  Pointers by value in the kernel argument (capturable like any argument).
+struct MeanTerms {
+  const float4 *t[8];
+  int n;
+};
+__global__ __launch_bounds__(256) void rows_mean_kernel(const MeanTerms T, float w, float4 *__restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = mul_rn4(w, T.t[0][i]);
+    for (int k = 1; k < T.n; ++k) {
+      const float4 v = mul_rn4(w, T.t[k][i]);
+      a = make_float4(add_rn(a.x, v.x), add_rn(a.y, v.y), add_rn(a.z, v.z), add_rn(a.w, v.w));
+    }
+    out[i] = a;
+  }
+}
+
+extern "C" int chaorec_rows_mean_f32(const float *const *terms, int32_t n_terms, float w, float *out, int64_t n,
+                                     void *stream) {
+  if (!terms || !out) return fail(CHAOREC_E_INVALID, "rows_mean: null pointer");
+  if (n_terms < 1 || n_terms > 8) return fail(CHAOREC_E_INVALID, "rows_mean: n_terms=%d must be in [1, 8]", n_terms);
+  if (n < 0 || n % 4) return fail(CHAOREC_E_INVALID, "rows_mean: n=%lld must be a non-negative multiple of 4", (long long)n);
+  if (n == 0) return CHAOREC_OK;
+  MeanTerms T;
+  T.n = n_terms;
+  for (int k = 0; k < 8; ++k) T.t[k] = (const float4 *)(k < n_terms ? terms[k] : terms[0]);
+  const int64_t n4 = n / 4;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, 4096);
+  rows_mean_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(T, w, (float4 *)out, n4);
+  return check_launch("rows_mean");
+}
+
 extern "C" int chaorec_leaky_bwd_f32(const float *y, const float *grad_out, float slope, float *grad_in, int64_t n,
                                      void *stream) {
   if (!y || !grad_out || !grad_in) return fail(CHAOREC_E_INVALID, "leaky_bwd: null pointer");

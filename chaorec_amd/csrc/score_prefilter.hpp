@@ -63,6 +63,11 @@ __device__ __forceinline__ uint4 bf16_pack8(const float4 a, const float4 b) {
   return make_uint4(bf16_pack2(a.x, a.y), bf16_pack2(a.z, a.w), bf16_pack2(b.x, b.y), bf16_pack2(b.z, b.w));
 }
 
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ int dpp_or0(int v) {   // lanes without a source (or outside ROW_MASK) read 0
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, BOUND);
+}
+
 constexpr int kPfFbGroupCap = 512;   // queued users the grouped f32 fallback takes (16 groups of 32)
 constexpr float kBf16ErrCoef = 1.05f / 256.0f;
 constexpr int kPfCap = 64;           // 32-bit entries per (split, user, half) list of the sweep
@@ -112,6 +117,10 @@ struct PrefArgs {
   int *fb_done;                 // [U] slices finished per queued user (zeroed per call)
   uint64_t *fb_partial;         // [U][kExSlices][kMaxK] per-slice best keys
   int fb_skip;                  // queue entries below this index were ranked by the grouped f32 sweep
+  // block-joint selection (score_blocksel.hpp): the sweep writes per-user-block union bitmaps instead of per-lane lists
+  uint32_t *bitmap;             // [user block][split][chunk][64] raw hit words (one per tile), or NULL
+  int bm_chunks;                // chunks of 64 tiles per split
+  int key_cap;                  // keys per user the selection's LDS lists hold
 };
 
 // ---- pack ----------------------------------------------------------------------------------------------------
@@ -506,10 +515,13 @@ constexpr int kSweepWaves = 4;
 #endif
 constexpr int kSweepStage = CHAOREC_SWEEP_STAGE;
 
-template <int D, int UB>
+template <int D, int UB, bool BM>
 __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(const PrefArgs P) {
   constexpr int FR = D / 16 + 1;                       // fragments (1 KiB each) per tile
   __shared__ uint4 stage[2][kSweepStage][FR * 64];
+  // BM: the union of the block's hit masks per tile, 64 tiles at a time: [wave][user block][tile sequence % 64] words of
+  // (half 1 mask << 16 | half 0 mask) -- the input of the block-joint selection (score_blocksel.hpp)
+  __shared__ uint16_t bm_s[BM ? kSweepWaves : 1][BM ? UB : 1][BM ? 128 : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ur = lane & 31, h = lane >> 5;
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
@@ -588,6 +600,18 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
       uint32_t qbits = 0;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(acc[reg]), 31);
+      if constexpr (BM) {
+        // OR over the 32 lanes of each half: prefix-OR inside the rows of 16 (row_shr 1, 2, 4, 8), then lane 15 of rows
+        // 0 / 2 into rows 1 / 3: lanes 31 and 63 hold their half's union and store it (one 2-byte LDS store, no list)
+        int x = (int)qbits;
+        x |= dpp_or0<0x111, 0xF, true>(x);
+        x |= dpp_or0<0x112, 0xF, true>(x);
+        x |= dpp_or0<0x114, 0xF, true>(x);
+        x |= dpp_or0<0x118, 0xF, true>(x);
+        x |= dpp_or0<0x142, 0xA, false>(x);
+        if (ur == 31) bm_s[wv][b][2 * (seq & 63) + h] = (uint16_t)x;
+        continue;
+      }
       if (qbits) {
         // past kPfCap entries are counted, not stored: the selection sees the overflow and flags the user
         if (cnt[b] < kPfCap) mine[b][cnt[b]] = ((uint32_t)seq << 16) | qbits;
@@ -620,6 +644,24 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   };
   const int n_mine = split < n_tiles ? (n_tiles - split + splits - 1) / splits : 0;   // tiles of this split
   const int n_stages = (n_mine + kSweepStage - 1) / kSweepStage;
+  // BM: a wave's own LDS words (its LDS operations execute in order: no barrier between its stores and its reads)
+  auto bm_clear = [&]() __attribute__((always_inline)) {
+    if constexpr (BM) {
+#pragma unroll
+      for (int b = 0; b < UB; ++b) reinterpret_cast<uint32_t *>(bm_s[wv][b])[lane] = 0u;
+    }
+  };
+  auto bm_flush = [&](int chunk) __attribute__((always_inline)) {
+    if constexpr (BM) {
+#pragma unroll
+      for (int b = 0; b < UB; ++b) {
+        if ((ublock0 + b) * 32 < n_act)      // wave-uniform; the bitmap's rows are this launch's user blocks
+          P.bitmap[(((size_t)(ublock0 + b) * splits + split) * P.bm_chunks + chunk) * 64 + lane] =
+              reinterpret_cast<const uint32_t *>(bm_s[wv][b])[lane];
+      }
+    }
+  };
+  bm_clear();
   if (n_stages > 0) {
     fetch(0);
     stash(0);
@@ -638,9 +680,23 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
         for (int q = 0; q < FR; ++q) a[q] = stage[buf][i][q * 64 + lane];
         consume(a, t, seq);
       }
+      if (BM && (seq & 63) == 63) {
+        bm_flush(seq >> 6);
+        bm_clear();
+      }
     }
     if (s0 + 1 < n_stages) stash(buf ^ 1);
     __syncthreads();
+  }
+  if constexpr (BM) {
+    // the last, partly filled chunk -- and every chunk after it that another split has and this one does not: the
+    // selection reads bm_chunks chunks of every split
+    const int done = (kSweepStage * n_stages) >> 6;               // chunks flushed inside the loop
+    for (int c = done; c < P.bm_chunks; ++c) {
+      bm_flush(c);
+      bm_clear();
+    }
+    return;
   }
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
@@ -788,10 +844,6 @@ constexpr int kPfSelHist = 128;             // ... and the selection (longer his
 //  * the exact re-score fetches rows by 4 lanes per candidate and keeps the next rows in flight under the chain;
 //  * the ranking is a bitonic network with the per-stage lane masks as scalar constants: compare, two selects.
 
-template <int CTRL, int ROW_MASK, bool BOUND>
-__device__ __forceinline__ int dpp_or0(int v) {   // lanes without a source (or outside ROW_MASK) read 0
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, BOUND);
-}
 // inclusive scans over the 64 lanes: shifts by 1, 2, 4, 8 inside the rows of 16, then lane 15 of row 0 / 2 into
 // row 1 / 3 and lane 31 into rows 2 and 3
 __device__ __forceinline__ int wave_scan_add(int x) {
@@ -1403,7 +1455,11 @@ __global__ __launch_bounds__(256) void score_prefilter_stats_kernel(const int *_
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_users) return;
   int mx = 0;
-  for (int l = 0; l < 2 * splits; ++l) mx = max(mx, cand_cnt[((size_t)(l >> 1) * n_users + u) * 2 + (l & 1)]);
+  if (cand_cnt) {
+    for (int l = 0; l < 2 * splits; ++l) mx = max(mx, cand_cnt[((size_t)(l >> 1) * n_users + u) * 2 + (l & 1)]);
+  } else {
+    mx = n_cand[u];          // block-joint selection: no per-lane lists; the longest key list instead
+  }
   if (fail[u]) {
     atomicAdd(out + 0, 1ull);
     atomicAdd(out + 3 + min(fail[u], 5), 1ull);

@@ -789,6 +789,7 @@ __global__ __launch_bounds__(64) void score_select_kernel(const uint64_t *__rest
 }
 
 #include "score_prefilter.hpp"
+#include "score_blocksel.hpp"
 
 // ---- launch plan -----------------------------------------------------------------------------
 struct ScorePlan {
@@ -804,6 +805,8 @@ struct ScorePlan {
   bool pf_sample_long;
   size_t off_pf_retry, off_pf_wide, off_pf_ncand, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
   bool pf_group_fb;            // large item ranges: the first kPfFbGroupCap queued users share f32 MFMA sweeps
+  bool pf_block;               // block-joint selection: union bitmaps + f32 MFMA re-score (score_blocksel.hpp)
+  size_t off_pf_bitmap;
   int pf_group_fb_splits;
   size_t off_pf_fbgroup;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_cand, off_pf_cnt;
@@ -826,8 +829,8 @@ static int sweep_wave_slots(int D) {
   hipError_t e = hipGetDevice(&dev);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e == hipSuccess) {
-    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>, 64 * kSweepWaves, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>, 64 * kSweepWaves, 0);
+    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, true>, 64 * kSweepWaves, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, true>, 64 * kSweepWaves, 0);
   }
   if (e != hipSuccess || per_cu <= 0 || cus <= 0) {
     (void)hipGetLastError();
@@ -921,9 +924,20 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.pf_group_fb_splits = (int)std::min<int64_t>(256, std::max<int64_t>(1, n_tiles / 64));
   p.off_pf_fbgroup = take(p.pf_group_fb ? (size_t)p.pf_group_fb_splits * kPfFbGroupCap * (size_t)K * 8 : 0);
   p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  // Block-joint selection where the exact route is the per-user one (item ranges below 128 k): the sweep's output is a
+  // union bitmap per user block -- n_tiles / 8 bytes per user instead of 8 KB of list slots
+#ifndef CHAOREC_PF_BLOCK
+#define CHAOREC_PF_BLOCK 1
+#endif
+  p.pf_block = p.prefilter && !p.pf_group_fb && CHAOREC_PF_BLOCK;
+  {
+    const int64_t per_wg = (int64_t)p.pf_ub * kSweepWaves;
+    const int64_t ublocks_pad = (groups + per_wg - 1) / per_wg * per_wg;      // the sweep's grid covers whole workgroups
+    p.off_pf_bitmap = take(p.pf_block ? (size_t)ublocks_pad * (size_t)bs_words_per_block_max(n_tiles) * 4 : 0);
+  }
   // (sized for the most splits any device plan uses, so that the CPU-side query and the device plan agree)
-  p.off_pf_cand = take(p.prefilter ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * kPfCap * 4 : 0);
-  p.off_pf_cnt = take(p.prefilter ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * 4 : 0);
+  p.off_pf_cand = take(p.prefilter && !p.pf_block ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * kPfCap * 4 : 0);
+  p.off_pf_cnt = take(p.prefilter && !p.pf_block ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * 4 : 0);
   p.off_packed = take(p.pack ? (size_t)n_tiles * 32 * (size_t)D * 4 : 0);
   p.off_tau = take(p.sample ? (size_t)n_users * 4 : 0);
   p.off_tau1 = take(p.sample ? (size_t)n_users * 4 : 0);
@@ -983,8 +997,8 @@ extern "C" int chaorec_score_topk_stats(const void *workspace, int64_t n_users, 
   if (!p.prefilter) return CHAOREC_OK;   // all zeros: the call did not take the prefilter route
   const char *ws = (const char *)workspace;
   hipLaunchKernelGGL(score_prefilter_stats_kernel, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, st,
-                     (const int *)(ws + p.off_fail), (const int *)(ws + p.off_pf_cnt), (const int *)(ws + p.off_pf_ncand),
-                     n_users, p.pf_splits, (unsigned long long *)out9);
+                     (const int *)(ws + p.off_fail), p.pf_block ? (const int *)nullptr : (const int *)(ws + p.off_pf_cnt),
+                     (const int *)(ws + p.off_pf_ncand), n_users, p.pf_splits, (unsigned long long *)out9);
   return check_launch("score_prefilter_stats_kernel");
 }
 
@@ -1071,6 +1085,9 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.cand = (uint32_t *)(ws + p.off_pf_cand);
     P.cand_cnt = (int *)(ws + p.off_pf_cnt);
     P.splits = p.pf_splits;
+    P.bitmap = p.pf_block ? (uint32_t *)(ws + p.off_pf_bitmap) : nullptr;
+    P.bm_chunks = bs_chunks(n_tiles, p.pf_splits);
+    P.key_cap = 0;
     P.sample_stride = p.pf_sample_stride;
     P.sample_splits = p.pf_sample_splits;
     P.sample_rank = p.pf_sample_rank;
@@ -1103,10 +1120,38 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     const unsigned sel_all = (unsigned)n_users;
     const unsigned sel_queue = (unsigned)std::min<int64_t>(n_users, 8192);    // a pass over a device-side queue
     auto sweep = [&](const PrefArgs &A) {
-      if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64 * kSweepWaves), 0, st, A);
-      else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, A);
+      if (p.pf_block) {
+        if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, true>), gw, dim3(64 * kSweepWaves), 0, st, A);
+        else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, true>), gw, dim3(64 * kSweepWaves), 0, st, A);
+      } else {
+        if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, false>), gw, dim3(64 * kSweepWaves), 0, st, A);
+        else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, false>), gw, dim3(64 * kSweepWaves), 0, st, A);
+      }
+    };
+    // block-joint selection: `cap` keys per user in LDS (32 x cap x 8 B per workgroup + 12.5 KB of lists); a pass over
+    // everybody launches one workgroup per user block, a pass over a device-side queue a fixed grid
+    static bool bs_attr_set[2] = {false, false};
+    auto select_block = [&](PrefArgs A, bool all_rows, int cap) {
+      A.key_cap = cap;
+      const size_t dyn = (size_t)32 * cap * sizeof(uint64_t);
+      bool &done = bs_attr_set[D == 64 ? 0 : 1];
+      if (!done) {       // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
+        const int most = (int)((size_t)32 * kBsCapCold * sizeof(uint64_t));
+        if (D == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_select_block_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_select_block_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
+        done = true;
+      }
+      const unsigned grid = all_rows ? groups : (unsigned)std::min<int64_t>(groups, 512);
+      if (D == 64) hipLaunchKernelGGL((score_select_block_kernel<64>), dim3(grid), dim3(64 * kBsWaves), dyn, st, A);
+      else hipLaunchKernelGGL((score_select_block_kernel<128>), dim3(grid), dim3(64 * kBsWaves), dyn, st, A);
     };
     auto select = [&](const PrefArgs &A, unsigned grid) {
+      if (p.pf_block) {
+        // carried thresholds keep ~2.2 K keys per user: the short lists (2 workgroups per CU); sampled thresholds are
+        // looser (cold calls, the retry pass): the long ones
+        select_block(A, grid == sel_all, A.hint_in ? kBsCapSteady : kBsCapCold);
+        return;
+      }
       if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
       else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
     };
@@ -1145,12 +1190,15 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       sample(B);
       sweep(B);
       select(B, hint_in ? sel_queue : sel_all);
-      // the few users with more candidates than the narrow selection holds (coarse samples of very long item ranges)
-      PrefArgs W = P;
-      W.user_map = P.wide_list;
-      W.n_active = wide_cnt;
-      if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
-      else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
+      // the few users with more candidates than the narrow selection holds (coarse samples of very long item ranges;
+      // the block-joint selection has no wide form: its overflowing users go to the exact route)
+      if (!p.pf_block) {
+        PrefArgs W = P;
+        W.user_map = P.wide_list;
+        W.n_active = wide_cnt;
+        if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
+        else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
+      }
       P.wide_cnt = wide_cnt;     // (for the counters the exact-route launch reports)
     }
     rc = check_launch("score prefilter kernels");

@@ -96,6 +96,20 @@ class UserShard:
             self.diag_i = (dis_i * dis_i).view(-1, 1).to(device)
 
 
+def joined_shard_csr(shard):
+    """The rank's blocks as ONE symmetric graph over its own joined table [local users; items]: rows 0 .. U_g-1 are
+    B_g's rows (columns shifted by U_g), rows U_g .. are B_g^T's.  One SpMM launch over it computes a layer's user rows
+    (complete) and the rank's partial of the item rows -- the launch count of the unsharded step."""
+    if getattr(shard, "_joined", None) is None:
+        ui, iu = shard.ui, shard.iu
+        U = shard.num_user_local
+        rowptr = torch.cat([ui.rowptr, iu.rowptr[1:] + ui.nnz])
+        col = torch.cat([ui.col + U, iu.col])
+        val = torch.cat([ui.val, iu.val])
+        shard._joined = graph.CSR(rowptr, col, val, U + shard.num_item, U + shard.num_item, symmetric=True)
+    return shard._joined
+
+
 # CHAOREC_FORCE_COLLECTIVES=1: issue the exchanges on a 1-rank group too, so that a 1-GPU box exercises the
 # RCCL launch (and hipGraph capture of it) that the N>1 job uses
 import os as _os
@@ -353,6 +367,191 @@ def gather_ranklists(idx_local, shard, group=None):
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
     return torch.cat([o[:s] for o, s in zip(out, sizes)], 0).cpu()
+
+
+class _HipStepKernels:
+    """The launches FusedShardedLightGCNStep is made of, on the MI355X.  tests/test_dist_gloo.py injects an oracle-backed
+    stand-in with the same methods (the product has no CPU kernels)."""
+    spmm = staticmethod(lambda *a, **k: ops.spmm_raw(*a, **k))       # (looked up per call: bench.py records the step's SpMMs)
+    spmm_mean = staticmethod(ops.spmm_mean_raw)
+    spmm_adam = staticmethod(ops.spmm_adam_raw)
+    rows_mean = staticmethod(ops.rows_mean)
+    adam_step = staticmethod(ops.adam_step)
+    bpr_fwd_bwd = staticmethod(ops.bpr_fwd_bwd)
+    bpr_finalize = staticmethod(ops.bpr_finalize)
+    mean_terms_limit = staticmethod(ops.mean_terms_limit)
+
+
+class FusedShardedLightGCNStep:
+    """optim.FusedLightGCNStep for a user-row shard: one training iteration of Model/LightGCN.py:76-135 +
+    train_and_evaluate.py:43-48 on rank g's users as a fixed launch sequence -- no autograd tape, no optimizer launch for
+    the user rows, Adam for them in the last backward propagate's epilogue:
+
+        L x   SpMM over the rank's JOINED graph [[0, B_g], [B_g^T, 0]] (user rows complete, item rows = this rank's
+              partial) + the exchange that sums the item rows over the ranks, in place
+        1 x   layer mean of the item rows (chaorec_rows_mean_f32; the user rows' mean rides in the last SpMM's epilogue)
+        1 x   BPR forward + backward on the rank's batch (its users only), gradient rows into G; 1 x the loss scalar
+        1 x   copy of G + exchange of its item rows: the seed of the backward needs the item gradient of ALL ranks
+        L-1 x SpMM  g_l = A_g g_{l+1} + (w / world) G   (the epilogue adds this rank's PARTIAL item gradient: the
+              exchange sums it with the others') + exchange
+        last: SpMM over B_g^T (item rows) -> exchange, travelling under the SpMM over B_g (user rows) with the Adam
+              epilogue; then one fused Adam launch on the replicated item rows (the same update on every rank)
+
+    2 L + 5 launches + 2 L + 1 exchanges (the autograd path: 4 L SpMMs, ~3 L elementwise launches, the four-kernel BPR,
+    two Adam launches).  The global loss is the mean over the ranks' batch losses, so every gradient carries 1 / world:
+    folded into the epilogue factors.  Item rows end identical on every rank (same sums, same Adam arithmetic)."""
+
+    def __init__(self, model, optimizer, batch_size=1024, edges=None, seed=42, step_dev=None, given_batch=False,
+                 loss_accum=None, capture=True, kernels=None, group=None):
+        from .optim import FusedAdam
+        if not isinstance(optimizer, FusedAdam) or len(optimizer.param_groups) != 1:
+            raise TypeError("FusedShardedLightGCNStep needs a FusedAdam with one parameter group")
+        if model.n_layers < 1:
+            raise ValueError("FusedShardedLightGCNStep: n_layers >= 1")
+        if (edges is None) == (not given_batch):
+            raise ValueError("FusedShardedLightGCNStep: either edges (in-launch draw) or given_batch=True")
+        self.model, self.optimizer, self.B, self.L = model, optimizer, int(batch_size), model.n_layers
+        self.K = kernels or _HipStepKernels
+        self.group = group if group is not None else model.group
+        self.edges, self.seed, self.step_dev, self.loss_accum = edges, seed, step_dev, loss_accum
+        shard = model.shard
+        U, I = shard.num_user_local, shard.num_item
+        uw, iw = model.user_embedding.weight, model.item_embedding.weight
+        if [id(p) for p in optimizer.param_groups[0]["params"]] != [id(uw), id(iw)]:
+            raise ValueError("FusedShardedLightGCNStep: the optimizer must hold exactly the two embedding tables")
+        D = uw.shape[1]
+        dev = uw.device
+        self.U, self.I, self.N, self.D = U, I, U + I, D
+        self.N_pad = U + padded_rows(I, self.group)
+        # the two tables as views of ONE [U + I_pad, D] buffer (same Parameters): the joined graph's operand
+        flat = torch.zeros((self.N_pad, D), dtype=torch.float32, device=dev)
+        flat[:U].copy_(uw.data)
+        flat[U:U + I].copy_(iw.data)
+        uw.data, iw.data = flat[:U], flat[U:U + I]
+        self.flat = flat
+        optimizer._ensure_state([uw, iw])
+        st_u, st_i = optimizer.state[uw], optimizer.state[iw]
+        if st_i["exp_avg"].data_ptr() != st_u["exp_avg"].data_ptr() + uw.numel() * 4 or \
+                st_i["exp_avg_sq"].data_ptr() != st_u["exp_avg_sq"].data_ptr() + uw.numel() * 4:
+            raise ValueError("FusedShardedLightGCNStep: the Adam moments of the two tables are not adjacent")
+        self.m = torch.as_strided(st_u["exp_avg"], (self.N, D), (D, 1))
+        self.v = torch.as_strided(st_u["exp_avg_sq"], (self.N, D), (D, 1))
+        new = lambda: torch.zeros((self.N_pad, D), dtype=torch.float32, device=dev)       # (pad rows stay zero)
+        self.ybuf = [new() for _ in range(max(self.L, 1))]          # x_1 .. x_L, then the backward's g buffers
+        self.final, self.G, self.S = new(), new(), new()
+        self.csr = joined_shard_csr(shard)
+        self.ids = tuple(torch.zeros(self.B, dtype=torch.int64, device=dev) for _ in range(3))
+        self.coef = torch.empty(self.B, dtype=torch.float32, device=dev)
+        self.ws = torch.empty(4 * self.B, dtype=torch.float32, device=dev)
+        self.out = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.static_loss = torch.zeros((), dtype=torch.float32, device=dev)    # this rank's batch loss (global = mean over ranks)
+        self.bc = torch.ones(2, dtype=torch.float32, device=dev)
+        self.use_mean = self.L <= self.K.mean_terms_limit(D)
+        self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        self.replays = 0
+        self.graph = None
+        if capture:
+            for c in (self.csr, shard.ui, shard.iu):
+                c.schedule(D)                   # lazily built by the first SpMM: must exist before capture
+            saved = self._save_state()
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._launch()                  # eager first: communicators are set up outside capture
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._restore_state(saved)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._launch()
+            saved = self._save_state()
+            self.graph.replay()
+            torch.cuda.synchronize()
+            self._restore_state(saved)
+
+    def _counters(self):
+        return [t for t in (self.step_dev, self.loss_accum, self.optimizer._step_dev) if t is not None]
+
+    def _save_state(self):
+        return ([self.flat.clone(), self.m.clone(), self.v.clone()], [t.clone() for t in self._counters()])
+
+    def _restore_state(self, saved):
+        with torch.no_grad():
+            for dst, src in zip((self.flat, self.m, self.v), saved[0]):
+                dst.copy_(src)
+            for dst, src in zip(self._counters(), saved[1]):
+                dst.copy_(src)
+            self.G.zero_()
+
+    def _exchange(self, buf):
+        """Sum the item rows of a joined buffer over the ranks, in place; -> a handle to wait on."""
+        return _sum_exchange_async(buf[self.U:], self.group)
+
+    @torch.no_grad()
+    def _launch(self):
+        K, model, opt, L, B, D = self.K, self.model, self.optimizer, self.L, self.B, self.D
+        U, I, N = self.U, self.I, self.N
+        group = opt.param_groups[0]
+        shard, csr, w = model.shard, self.csr, 1.0 / (L + 1)
+        xs = [self.flat]
+        for l in range(L):
+            y = self.ybuf[l]
+            if l == L - 1 and self.use_mean:        # the user rows' layer mean in this launch's epilogue
+                K.spmm_mean(csr, xs[-1][:N], [t[:N] for t in xs], w, self.final[:N], y=y[:N])
+            else:
+                K.spmm(csr, xs[-1][:N], y=y[:N])
+            self._exchange(y).wait()
+            xs.append(y)
+        # the item rows' propagated values arrived with the exchanges, after the launches that could have averaged them
+        lo = U if self.use_mean else 0
+        K.rows_mean([t[lo:N] for t in xs], w, self.final[lo:N])
+        draw = self.edges is not None
+        K.bpr_fwd_bwd(self.final, U, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef, self.ws, self.ids,
+                      edges=self.edges, hist=model.hist if draw else None, num_user=U, num_item=I, seed=self.seed, step=0,
+                      step_dev=self.step_dev, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
+        K.bpr_finalize(self.ws, B, D, model.reg_weight, self.out, out_total=self.static_loss, loss_accum=self.loss_accum,
+                       advance=self.step_dev if draw else None)
+        # backward.  S = [G_u; sum over ranks of G_i]: what the first propagate gathers from; its epilogue (and every
+        # later one) adds this rank's PARTIAL item gradient G_i, which the exchange then sums with the others'.
+        c = w / self.world
+        self.S.copy_(self.G)
+        self._exchange(self.S).wait()
+        g, alpha = self.S, c
+        for l in range(L - 1):
+            y = self.ybuf[l & 1]
+            K.spmm(csr, g[:N], y=y[:N], alpha=alpha, z=self.G[:N], beta=c)
+            self._exchange(y).wait()
+            g, alpha = y, 1.0
+        Y = self.ybuf[min(L - 1, 2)]
+        K.spmm(shard.iu, g[:U], y=Y[U:N], alpha=alpha, z=self.G[U:N], beta=c)
+        pend = self._exchange(Y)                    # travels under the user rows' launch
+        K.spmm_adam(shard.ui, g[U:N], self.flat[:U], self.m[:U], self.v[:U], self.bc, group["lr"], group["betas"],
+                    group["eps"], group["weight_decay"], alpha=alpha, z=self.G[:U], beta=c, clear_z=True)
+        pend.wait()
+        K.adam_step(self.flat[U:N], Y[U:N], self.m[U:N], self.v[U:N], 0, group["lr"], group["betas"], group["eps"],
+                    group["weight_decay"], step_dev=opt._step_dev)
+        self.G[U:N].zero_()
+        model.result_u, model.result_i, model._result_cat = self.final[:U], self.final[U:N], None
+
+    def __call__(self, users=None, pos=None, neg=None):
+        """One training step -> this rank's batch loss (device scalar; the global loss is the mean over ranks).
+        users / pos / neg (shard-local ids, items as item + U_g) only in given_batch mode."""
+        if self.edges is None:
+            self.ids[0].copy_(users, non_blocking=True)
+            torch.sub(pos.to(self.ids[1].device), self.U, out=self.ids[1])
+            torch.sub(neg.to(self.ids[2].device), self.U, out=self.ids[2])
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch()
+        self.replays += 1
+        self.model.result_u, self.model.result_i, self.model._result_cat = self.final[:self.U], self.final[self.U:self.N], None
+        return self.static_loss
+
+    def run(self, n_steps):
+        for _ in range(n_steps):
+            self()
+        return self.static_loss
 
 
 def build_weak_scaling_job(dataset, world, rank, D, L, reg, device, seed=42, group=None, synthetic=False):

@@ -77,6 +77,20 @@ def spmm_mean_raw(csr, x, terms, w, mean_out, y=None):
     return mean_out
 
 
+def rows_mean(terms, w, out):
+    """out = w * terms[0] + w * terms[1] + ... in that order (chaorec_rows_mean_f32): the layer mean of rows whose
+    propagated values arrive after the SpMM launches (the replicated item rows of a user shard)."""
+    _need_cuda(out, *terms)
+    n = out.numel()
+    for t in terms:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise TypeError("rows_mean: contiguous float32 terms of out's size")
+    ptrs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    _lib.check(_lib.load().chaorec_rows_mean_f32(ctypes.cast(ptrs, ctypes.c_void_p), len(terms), float(w), _ptr(out), n,
+                                                 _stream()), "chaorec_rows_mean_f32")
+    return out
+
+
 def mean_terms_limit(D):
     """How many earlier-layer tables the last forward propagate can fold into its epilogue for feature width D."""
     return 3 if D <= 64 else 2

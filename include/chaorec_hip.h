@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 7   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 8   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -35,7 +35,9 @@ extern "C" {
                                   5: weighted_sample_keys (sharded edge pruning);
                                   6: BPR batch at an offset + one finalize for k captured steps, NGCF elementwise backward;
                                   7: Adam over a feature table with a low-rank, row-sparse gradient (dense / lazy / flush), split-bf16 TN GEMM
-                                     (weight gradients), multi-tensor Adam */
+                                     (weight gradients), multi-tensor Adam;
+                                  8: rows_mean (layer mean of exchanged rows: fused sharded LightGCN step); the prefilter's
+                                     selection is block-joint (union bitmaps + f32 MFMA re-score) below 128 k items */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -535,6 +537,13 @@ int chaorec_row_cosine_scale_bwd_f32(const float *grad_out, const float *y, cons
 int chaorec_leaky_bwd_f32(const float *y, const float *grad_out, float slope, float *grad_in, int64_t n, void *stream);
 int chaorec_mul_pair_bwd_f32(const float *grad_t, const float *s, const float *x, float *grad_s, float *grad_x,
                              int64_t n, void *stream);
+
+/* out = w * terms[0] + w * terms[1] + ... + w * terms[n_terms-1] over n floats, accumulated in that order (products and
+ * sums rounded separately): LightGCN's layer mean (Model/LightGCN.py:86-93) for rows whose propagated values arrive
+ * AFTER the propagate launches -- the replicated item rows of a user-row shard, summed over the ranks by the per-layer
+ * exchange (chaorec_amd/dist.py).  Same association as chaorec_spmm_csr_mean_f32's epilogue.  terms: HOST array of
+ * n_terms (<= 8) device pointers; n a multiple of 4. */
+int chaorec_rows_mean_f32(const float *const *terms, int32_t n_terms, float w, float *out, int64_t n, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Deterministic two-pass reductions (fixed order, no atomics, no semaphores, no memset nodes).

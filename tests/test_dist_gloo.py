@@ -225,6 +225,147 @@ def test_world4_exchange_modes_per_rank_shards(oracle, mode):
         assert np.array_equal(r[k]["gi"], r[0]["gi"])                                 # identical item update on every rank
 
 
+class _OracleStepKernels:
+    """dist._HipStepKernels' contract on the CPU (oracle SpMM / BPR, torch Adam arithmetic): the stand-in the fused
+    sharded step runs on in the gloo tests."""
+    spmm = staticmethod(_oracle_spmm)
+
+    @staticmethod
+    def mean_terms_limit(D):
+        return 3
+
+    @staticmethod
+    def spmm_mean(csr, x, terms, w, mean_out, y=None):
+        s = _oracle_spmm(csr, x)
+        if y is not None:
+            y.copy_(s)
+        a = w * terms[0]
+        for t in terms[1:]:
+            a = a + w * t
+        mean_out.copy_(a + w * s)
+
+    @staticmethod
+    def rows_mean(terms, w, out):
+        a = w * terms[0]
+        for t in terms[1:]:
+            a = a + w * t
+        out.copy_(a)
+
+    @staticmethod
+    def _adam(p, g, m, v, bc1, bc2s, lr, betas, eps, wd):
+        if wd:
+            g = g + wd * p
+        m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+        v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)
+
+    @classmethod
+    def spmm_adam(cls, csr, x, p, m, v, bc, lr, betas, eps, wd, alpha=1.0, z=None, beta=0.0, clear_z=False):
+        g = _oracle_spmm(csr, x, alpha=alpha, z=z, beta=beta)
+        cls._adam(p, g, m, v, float(bc[0]), float(bc[1]), lr, betas, eps, wd)
+        if clear_z:
+            z.zero_()
+
+    @classmethod
+    def adam_step(cls, p, g, m, v, step, lr, betas, eps, wd, step_dev=None):
+        t = int(step_dev) if step_dev is not None else step
+        cls._adam(p, g, m, v, 1 - betas[0] ** t, (1 - betas[1] ** t) ** 0.5, lr, betas, eps, wd)
+
+    @staticmethod
+    def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg, coef, ws, ids, edges=None, hist=None, num_user=0, num_item=0,
+                    seed=0, step=0, step_dev=None, adam_step=None, betas=(0.9, 0.999), adam_bc=None):
+        from oracle import oracle
+        assert edges is None
+        U, I = item_offset, num_item
+        tu, ti = tab[:U].numpy(), tab[U:U + I].numpy()
+        u, p, n = (t.numpy() for t in ids)
+        out, cf = oracle.bpr_fwd(tu, ti, u, p, n, variant, reg)
+        gu, gi = oracle.bpr_bwd(tu, ti, u, p, n, cf, reg, 1.0)
+        grad[:U] += torch.from_numpy(gu).float()
+        grad[U:U + I] += torch.from_numpy(gi).float()
+        ws[:3] = torch.tensor(out, dtype=torch.float32)
+        adam_step += 1
+        t = int(adam_step)
+        adam_bc[0], adam_bc[1] = 1 - betas[0] ** t, (1 - betas[1] ** t) ** 0.5
+
+    @staticmethod
+    def bpr_finalize(ws, B, D, reg, out, out_total=None, loss_accum=None, advance=None):
+        out.copy_(ws[:3])
+        if out_total is not None:
+            out_total.copy_(ws[0])
+        if loss_accum is not None:
+            loss_accum += ws[0]
+
+
+def _worker_fused(rank, world, port, tmp, mode, L):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CHAOREC_DIST_EXCHANGE"] = mode
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from chaorec_amd import dist as cdist
+    from chaorec_amd.optim import FusedAdam
+    U, I, D, B, T = 500, 203, 16, 48, 3           # (203 items: padded exchange rows at every world size used here)
+    edges = _heavy_tailed_graph(U, I)
+    deg = np.bincount(edges[:, 0], minlength=U)
+    bounds = cdist.partition_users_by_nnz(deg, world)
+    mine = edges[(edges[:, 0] >= bounds[rank]) & (edges[:, 0] < bounds[rank + 1])]
+    shard = cdist.UserShard.from_local(mine, bounds, I, world, rank, torch.device("cpu"))
+    m = cdist.ShardedLightGCN(shard, None, D, 1e-3, L, torch.device("cpu"), seed=9)
+    x0u, x0i = m.user_embedding.weight.detach().clone().numpy(), m.item_embedding.weight.detach().clone().numpy()
+    opt = FusedAdam(m.parameters(), lr=1e-2)
+    step = cdist.FusedShardedLightGCNStep(m, opt, batch_size=B, given_batch=True, capture=False, kernels=_OracleStepKernels)
+    assert step.N_pad % world == (shard.num_user_local % world)          # item rows padded to a multiple of the world size
+    rng = np.random.default_rng(100 + rank)
+    batches, losses = [], []
+    for t in range(T):
+        sel = rng.choice(len(shard.local_edges), B, replace=False)
+        users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64))
+        pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64))
+        neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + I, B))
+        losses.append(float(step(users, pos, neg)))
+        batches.append(np.stack([users.numpy() + shard.u0, pos.numpy() - shard.num_user_local,
+                                 neg.numpy() - shard.num_user_local]))
+    assert float(step.G.abs().max()) == 0.0                               # the gradient buffer is all-zero between steps
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), x0u=x0u, x0i=x0i, xu=m.user_embedding.weight.detach().numpy(),
+             xi=m.item_embedding.weight.detach().numpy(), fu=m.result_u.numpy(), fi=m.result_i.numpy(),
+             batches=np.stack(batches), losses=np.array(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,L", [(2, "allreduce", 3), (2, "direct", 1), (4, "rs_ag", 2)])
+def test_fused_sharded_step_trains_like_the_single_process_oracle(oracle, world, mode, L):
+    """dist.FusedShardedLightGCNStep (joined-graph propagates, in-place item exchanges, Adam in the last propagate /
+    one fused launch for the replicated item rows) over T optimizer steps against the oracle on the WHOLE graph: the global
+    loss is the mean of the ranks' batch losses, torch.optim.Adam's arithmetic on its gradient."""
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_fused, args=(world, _free_port(), tmp, mode, L), nprocs=world, join=True)
+        r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
+    U, I, D, T = 500, 203, 16, 3
+    edges = _heavy_tailed_graph(U, I)
+    csr = oracle.lightgcn_csr(edges, U + I)
+    x = np.concatenate([x_["x0u"] for x_ in r] + [r[0]["x0i"]], 0).astype(np.float64)
+    m, v = np.zeros_like(x), np.zeros_like(x)
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    for t in range(T):
+        g_tot = np.zeros_like(x)
+        for k in range(world):
+            bu, bp, bn = r[k]["batches"][t]
+            out, g = oracle.lightgcn_loss(x.astype(np.float32), csr, L, U, bu, bp, bn, 1e-3)
+            g_tot += g / world
+            assert r[k]["losses"][t] == pytest.approx(out[0], rel=2e-5), (t, k)
+        m = b1 * m + (1 - b1) * g_tot
+        v = b2 * v + (1 - b2) * g_tot * g_tot
+        x = x - lr * (m / (1 - b1 ** (t + 1))) / (np.sqrt(v) / np.sqrt(1 - b2 ** (t + 1)) + eps)
+    xu = np.concatenate([x_["xu"] for x_ in r], 0)
+    assert np.allclose(xu, x[:U], rtol=0, atol=2e-5)
+    for k in range(world):
+        assert np.allclose(r[k]["xi"], x[U:], rtol=0, atol=2e-5)
+        assert np.array_equal(r[k]["xi"], r[0]["xi"])                      # identical item update on every rank
+
+
 def test_partition_users_by_nnz():
     from chaorec_amd.dist import partition_users_by_nnz
     deg = np.array([1000] + [1] * 999)

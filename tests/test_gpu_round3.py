@@ -85,3 +85,55 @@ def test_score_topk_in_user_chunks_equals_one_piece(dev, hinted):
             os.environ["CHAOREC_SCORE_WS_LIMIT"] = old
     assert st["user_chunks"] >= 3 and st["prefilter_users"] == U
     assert torch.equal(got_i, want_i) and torch.equal(got_v, want_v)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+@pytest.mark.parametrize("capture", [False, True])
+def test_fused_sharded_step_one_rank_equals_the_unsharded_fused_step(dev, L, capture):
+    """dist.FusedShardedLightGCNStep on a single shard that holds every user == optim.FusedLightGCNStep: the joined
+    shard graph is the whole graph, the exchanges are no-ops, and the item rows (layer mean by chaorec_rows_mean_f32,
+    Adam by one fused launch) must come out like the rows the unsharded step updates in its SpMM epilogues."""
+    from chaorec_amd import dist as cdist, graph
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, FusedLightGCNStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, D, B, T = 3000, 1200, 20000, 64, 256, 4
+    edges = synthetic_interactions(U, I, E, seed=2)
+    torch.manual_seed(3)
+    ref = LightGCN(U, I, edges, None, D, 1e-3, L, "add", dev).to(dev)
+    shard = cdist.UserShard(edges, U, I, 1, 0, dev)
+    m = cdist.ShardedLightGCN(shard, None, D, 1e-3, L, dev, seed=1).to(dev)
+    with torch.no_grad():
+        m.user_embedding.weight.copy_(ref.user_embedding.weight)
+        m.item_embedding.weight.copy_(ref.item_embedding.weight)
+    # the joined shard graph IS the unsharded normalised graph
+    j = cdist.joined_shard_csr(shard)
+    assert torch.equal(j.rowptr, ref.graph.rowptr) and torch.equal(j.col, ref.graph.col) and torch.equal(j.val, ref.graph.val)
+    s_ref = FusedLightGCNStep(ref, FusedAdam(ref.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=False)
+    s_sh = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True,
+                                          capture=capture)
+    rng = np.random.default_rng(5)
+    for t in range(T):
+        sel = rng.choice(E, B, replace=False)
+        users = torch.from_numpy(edges[sel, 0].astype(np.int64)).to(dev)
+        pos = torch.from_numpy(edges[sel, 1].astype(np.int64)).to(dev)
+        neg = torch.from_numpy(rng.integers(U, U + I, B)).to(dev)
+        l0, l1 = float(s_ref(users, pos, neg)), float(s_sh(users, pos, neg))
+        assert l1 == pytest.approx(l0, rel=1e-6), t
+    assert float(s_sh.G.abs().max()) == 0.0
+    # (the BPR backward's float atomics: last-bit noise between any two runs, ten-fold by lr 1e-2 / eps-sized moments)
+    assert torch.allclose(m.user_embedding.weight, ref.user_embedding.weight, rtol=0, atol=5e-6)
+    assert torch.allclose(m.item_embedding.weight, ref.item_embedding.weight, rtol=0, atol=5e-6)
+    assert torch.allclose(m.result_u, ref.result[:U], rtol=0, atol=5e-6) and torch.allclose(m.result_i, ref.result[U:], rtol=0, atol=5e-6)
+
+
+def test_rows_mean_matches_the_layer_mean_association(dev):
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev).manual_seed(4)
+    terms = [torch.randn(5000, 64, generator=g, device=dev) for _ in range(4)]
+    w = 0.25
+    out = ops.rows_mean(terms, w, torch.empty_like(terms[0]))
+    a = np.float32(w) * terms[0].cpu().numpy()
+    for t in terms[1:]:
+        a = a + np.float32(w) * t.cpu().numpy()
+    assert np.array_equal(out.cpu().numpy(), a)
