@@ -795,7 +795,7 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                    ("Adam in the last user-row SpMM's epilogue + one fused launch on the replicated item rows"
                     if fused is not None else "FusedAdam (chaorec_adam_step_f32)"),
                    "parallelism": f"user-row shards x{world}; item partials summed per layer by "
-                                  f"{cdist.exchange_mode()} over {backend}"},
+                                  f"{cdist.exchange_mode_used()} over {backend}"},
         "roofline": roofline, "roofline_scoring": scoring_roofline(r),
         "loss_mean": (float(fused_loss.item()) / world if fused is not None else float(loss_sum.item())) / max(n_loss[0], 1),
     }

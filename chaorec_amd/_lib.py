@@ -134,6 +134,26 @@ SIGNATURES = {
 }
 
 
+def _experiment_flags():
+    """(extra, dropped) hipcc flags of an experiment build (tools/*_variants.py): CHAOREC_EXTRA_HIPCC_FLAGS /
+    CHAOREC_DROP_HIPCC_FLAGS (e.g. "-mllvm -amdgpu-mfma-vgpr-form")."""
+    return (os.environ.get("CHAOREC_EXTRA_HIPCC_FLAGS", "").split(), os.environ.get("CHAOREC_DROP_HIPCC_FLAGS", "").split())
+
+
+def _experiment_tag():
+    extra, drop = _experiment_flags()
+    if not extra and not drop:
+        return ""
+    import hashlib
+    return hashlib.sha1((" ".join(extra) + "|" + " ".join(drop)).encode()).hexdigest()[:10]
+
+
+def current_lib_path():
+    """The product library -- or, only while an experiment's flags are in the environment, that experiment's own file."""
+    tag = _experiment_tag()
+    return os.path.join(_CSRC, "exp", f"libchaorec_hip_{tag}.so") if tag else LIB_PATH
+
+
 def build(force=False, verbose=False):
     """Cross-compile the HIP kernels for gfx950 into csrc/libchaorec_hip.so (no GPU needed): one object per source
     file (compiled in parallel, re-compiled only when the file or a header changed), then one link."""
@@ -141,19 +161,22 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".h", ".hpp"))]
     hdrs += [os.path.join(os.path.dirname(_CSRC), "..", "include", "chaorec_hip.h"), os.path.abspath(__file__)]
-    extra = os.environ.get("CHAOREC_EXTRA_HIPCC_FLAGS", "").split()
-    drop = os.environ.get("CHAOREC_DROP_HIPCC_FLAGS", "").split()       # (experiments: e.g. "-mllvm -amdgpu-mfma-vgpr-form")
-    if not force and not extra and not drop and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + hdrs):
-        return LIB_PATH
+    extra, drop = _experiment_flags()
+    lib_path = current_lib_path()
+    if not force and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in srcs + hdrs):
+        return lib_path
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    objdir = os.path.join(_CSRC, "build")
+    # an experiment build (extra / dropped compiler flags) has its own objects and its own library: it can never
+    # replace, or be mistaken for, the product build
+    tag = _experiment_tag()
+    objdir = os.path.join(_CSRC, "build" + (("_exp_" + tag) if tag else ""))
     os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
     cflags = [f for f in HIPCC_FLAGS if f != "-shared" and f not in drop] + extra
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if (not force and not extra and os.path.exists(obj)
+        if (not force and os.path.exists(obj)
                 and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
             return obj
         cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
@@ -164,31 +187,36 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 def ensure_built():
     """Entry points that own a whole run (bench.py, smoke(), the test session) call this first: compile the library
     if the file is not there (a fresh checkout; hipcc cross-compiles without a GPU).  load() itself never builds and
     never falls back: a missing library is an error for every op."""
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(current_lib_path()):
         build(verbose=True)
-    return LIB_PATH
+    return current_lib_path()
 
 
 def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    lib_path = current_lib_path()
+    if not os.path.exists(lib_path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or chaorec_amd._lib.build()).  chaorec_amd has no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    # torch first: it brings its own HIP runtime (libamdhip64 of its ROCm build); a process in which THIS library pulled
+    # in the system's copy before torch was imported ended with "no ROCm-capable device is detected" at the first launch
+    # (python __graft_entry__.py smoke: build() loads the library, smoke() then imported torch)
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(lib_path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library drift
         fn.restype = res

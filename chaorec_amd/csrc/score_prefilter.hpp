@@ -120,7 +120,8 @@ struct PrefArgs {
   // block-joint selection (score_blocksel.hpp): the sweep writes per-user-block union bitmaps instead of per-lane lists
   uint32_t *bitmap;             // [user block][split][chunk][64] raw hit words (one per tile), or NULL
   int bm_chunks;                // chunks of 64 tiles per split
-  int key_cap;                  // keys per user the selection's LDS lists hold
+  int key_cap;                  // keys per user the selection's lists hold
+  uint64_t *keys;               // [launch row][key_cap] keys above the user's threshold
 };
 
 // ---- pack ----------------------------------------------------------------------------------------------------

@@ -806,7 +806,7 @@ struct ScorePlan {
   size_t off_pf_retry, off_pf_wide, off_pf_ncand, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
   bool pf_group_fb;            // large item ranges: the first kPfFbGroupCap queued users share f32 MFMA sweeps
   bool pf_block;               // block-joint selection: union bitmaps + f32 MFMA re-score (score_blocksel.hpp)
-  size_t off_pf_bitmap;
+  size_t off_pf_bitmap, off_pf_keys;
   int pf_group_fb_splits;
   size_t off_pf_fbgroup;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_cand, off_pf_cnt;
@@ -924,16 +924,19 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.pf_group_fb_splits = (int)std::min<int64_t>(256, std::max<int64_t>(1, n_tiles / 64));
   p.off_pf_fbgroup = take(p.pf_group_fb ? (size_t)p.pf_group_fb_splits * kPfFbGroupCap * (size_t)K * 8 : 0);
   p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
-  // Block-joint selection where the exact route is the per-user one (item ranges below 128 k): the sweep's output is a
-  // union bitmap per user block -- n_tiles / 8 bytes per user instead of 8 KB of list slots
+  // Block-joint selection (score_blocksel.hpp; item ranges below 128 k): the sweep's output is a union bitmap per user
+  // block, the re-score runs on the f32 MFMA pipe.  Bit-exact (the scoring tests pass on it: profiles/r03_d_*), but
+  // MEASURED SLOWER than the per-user selection at sports size -- 125-139 us against 80 us (stage cuts in DESIGN 3.3) --
+  // so it is an experiment build (-DCHAOREC_PF_BLOCK=1, tools/bs_variants.py), not the product path.
 #ifndef CHAOREC_PF_BLOCK
-#define CHAOREC_PF_BLOCK 1
+#define CHAOREC_PF_BLOCK 0
 #endif
   p.pf_block = p.prefilter && !p.pf_group_fb && CHAOREC_PF_BLOCK;
   {
     const int64_t per_wg = (int64_t)p.pf_ub * kSweepWaves;
     const int64_t ublocks_pad = (groups + per_wg - 1) / per_wg * per_wg;      // the sweep's grid covers whole workgroups
     p.off_pf_bitmap = take(p.pf_block ? (size_t)ublocks_pad * (size_t)bs_words_per_block_max(n_tiles) * 4 : 0);
+    p.off_pf_keys = take(p.pf_block ? (size_t)groups * 32 * (size_t)kBsCap * 8 : 0);
   }
   // (sized for the most splits any device plan uses, so that the CPU-side query and the device plan agree)
   p.off_pf_cand = take(p.prefilter && !p.pf_block ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * kPfCap * 4 : 0);
@@ -1087,7 +1090,8 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.splits = p.pf_splits;
     P.bitmap = p.pf_block ? (uint32_t *)(ws + p.off_pf_bitmap) : nullptr;
     P.bm_chunks = bs_chunks(n_tiles, p.pf_splits);
-    P.key_cap = 0;
+    P.key_cap = kBsCap;
+    P.keys = p.pf_block ? (uint64_t *)(ws + p.off_pf_keys) : nullptr;
     P.sample_stride = p.pf_sample_stride;
     P.sample_splits = p.pf_sample_splits;
     P.sample_rank = p.pf_sample_rank;
@@ -1102,8 +1106,8 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.hint_in = nullptr;
     P.hint_out = hint_out;
     P.hint_rank = hint_rank > K ? (hint_rank > 128 ? 128 : hint_rank) : K;
-#ifdef CHAOREC_SEL_EXP
-    if (hint_rank >= 1000) P.hint_rank = hint_rank;      // (experiment builds: the run-time switch of tools/sel_variants.py)
+#if defined(CHAOREC_SEL_EXP) || defined(CHAOREC_BS_EXP)
+    if (hint_rank >= 1000) P.hint_rank = hint_rank;      // (experiment builds: the run-time switch of tools/sel_variants.py / bs_variants.py)
 #endif
     int *failf = (int *)(ws + p.off_fail);
     P.fail = failf;
@@ -1128,28 +1132,16 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
         else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, false>), gw, dim3(64 * kSweepWaves), 0, st, A);
       }
     };
-    // block-joint selection: `cap` keys per user in LDS (32 x cap x 8 B per workgroup + 12.5 KB of lists); a pass over
-    // everybody launches one workgroup per user block, a pass over a device-side queue a fixed grid
-    static bool bs_attr_set[2] = {false, false};
-    auto select_block = [&](PrefArgs A, bool all_rows, int cap) {
-      A.key_cap = cap;
-      const size_t dyn = (size_t)32 * cap * sizeof(uint64_t);
-      bool &done = bs_attr_set[D == 64 ? 0 : 1];
-      if (!done) {       // (dynamic LDS beyond 64 KB has to be asked for once per kernel)
-        const int most = (int)((size_t)32 * kBsCapCold * sizeof(uint64_t));
-        if (D == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_select_block_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&score_select_block_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, most);
-        done = true;
-      }
-      const unsigned grid = all_rows ? groups : (unsigned)std::min<int64_t>(groups, 512);
-      if (D == 64) hipLaunchKernelGGL((score_select_block_kernel<64>), dim3(grid), dim3(64 * kBsWaves), dyn, st, A);
-      else hipLaunchKernelGGL((score_select_block_kernel<128>), dim3(grid), dim3(64 * kBsWaves), dyn, st, A);
+    // block-joint selection: a pass over everybody launches one workgroup per user block, a pass over a device-side
+    // queue a fixed grid
+    auto select_block = [&](const PrefArgs &A, bool all_rows) {
+      const unsigned grid = all_rows ? groups : (unsigned)std::min<int64_t>(groups, 1024);
+      if (D == 64) hipLaunchKernelGGL((score_select_block_kernel<64>), dim3(grid), dim3(64 * kBsWaves), 0, st, A);
+      else hipLaunchKernelGGL((score_select_block_kernel<128>), dim3(grid), dim3(64 * kBsWaves), 0, st, A);
     };
     auto select = [&](const PrefArgs &A, unsigned grid) {
       if (p.pf_block) {
-        // carried thresholds keep ~2.2 K keys per user: the short lists (2 workgroups per CU); sampled thresholds are
-        // looser (cold calls, the retry pass): the long ones
-        select_block(A, grid == sel_all, A.hint_in ? kBsCapSteady : kBsCapCold);
+        select_block(A, grid == sel_all);
         return;
       }
       if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);

@@ -123,6 +123,7 @@ _FORCE_COLLECTIVES = _os.environ.get("CHAOREC_FORCE_COLLECTIVES", "0") == "1"
 #              half on a fully connected xGMI node (1.7 ms instead of 11.7 ms for config 5's 1.02 GB)
 # Same sums up to fp32 association.  No multi-GPU node was available to time them against each other.
 EXCHANGE_MODES = ("allreduce", "rs_ag", "direct")
+DIRECT_FELL_BACK = False       # set when a captured step replaced `direct` by `rs_ag` (see _sum_exchange_async)
 
 
 def exchange_mode():
@@ -130,6 +131,12 @@ def exchange_mode():
     if m not in EXCHANGE_MODES:
         raise ValueError(f"CHAOREC_DIST_EXCHANGE={m}: one of {EXCHANGE_MODES}")
     return m
+
+
+def exchange_mode_used():
+    """What the bench line reports: the mode asked for, and what captured steps ran instead where that differs."""
+    m = exchange_mode()
+    return m + (" (captured steps: rs_ag -- RCCL's all-to-all is not capturable on this stack)" if DIRECT_FELL_BACK else "")
 
 
 def _active(group):
@@ -184,6 +191,14 @@ def _sum_exchange_async(buf, group):
     if not _active(group):
         return _Pending(None)
     mode = exchange_mode()
+    if mode == "direct" and buf.is_cuda and torch.cuda.is_current_stream_capturing():
+        # RCCL's all-to-all cannot be captured on this stack (ROCm 7.2 / RCCL of torch 2.10: a captured
+        # all_to_all_single hangs or segfaults even alone in a graph, tools/direct_capture_repro.py,
+        # profiles/r03_a_all_to_all_capture_repro.log; reduce-scatter and all-gather capture fine): a captured step that
+        # asked for `direct` gets the same two-phase exchange through RCCL's reduce-scatter instead
+        global DIRECT_FELL_BACK
+        DIRECT_FELL_BACK = True
+        mode = "rs_ag"
     if mode == "allreduce" or buf.shape[0] % dist.get_world_size(group):
         return _Pending(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
     world, rank = dist.get_world_size(group), dist.get_rank(group)

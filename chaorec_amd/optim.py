@@ -247,11 +247,14 @@ class GraphedTrainStep:
     replayed from one captured hipGraph.  Batch tensors must keep their shapes (the last, short batch of an
     epoch falls back to the eager path).  Returns the (device) loss of the step."""
 
-    def __init__(self, model, optimizer, example_batch=None, warmup=3, batch_fn=None, loss_fn=None):
+    def __init__(self, model, optimizer, example_batch=None, warmup=3, batch_fn=None, loss_fn=None, after_backward=None):
         """`batch_fn` (optional): a capturable callable returning the batch tensors; it is captured INSIDE the
-        graph (device-side sampling from a device counter), and the step is then called with no arguments."""
+        graph (device-side sampling from a device counter), and the step is then called with no arguments.
+        `after_backward` (optional): called between loss.backward() and optimizer.step() -- a sharded model's
+        sync_grads() (the all-reduce of the replicated parameters' partial gradients), captured with the rest."""
         self.model, self.optimizer, self.batch_fn = model, optimizer, batch_fn
         self.loss_fn = loss_fn or model.loss
+        self.after_backward = after_backward
         self._seed = None
         dev = next(model.parameters()).device
         self.static = [b.to(dev).clone() for b in example_batch] if example_batch is not None else None
@@ -307,6 +310,8 @@ class GraphedTrainStep:
         if self._seed is None or self._seed.shape != loss.shape or self._seed.device != loss.device:
             self._seed = torch.ones_like(loss)          # d(loss)/d(loss), kept: autograd would fill a fresh one per step
         loss.backward(self._seed)
+        if self.after_backward is not None:
+            self.after_backward()
         self.optimizer.step()
         return loss.detach()
 
