@@ -73,17 +73,19 @@ class GCN(torch.nn.Module):
         tensor in the reference (Q2) and the features are data.  x, and with it A x of the first convolution, are then the
         same in every step: computed once, keyed on the tensors' storage and version counters.
         -> (x, [A x | A 1 | 0-pad]) or None."""
+        is_op = hasattr(self.edge_index, "propagate")      # dist.ShardedGraph: rows = [local users; items], A x needs ONE exchange, once
         if self.dim_latent or self.preference.requires_grad or features.requires_grad or \
-                not isinstance(self.edge_index, graph.CSR):
+                not (isinstance(self.edge_index, graph.CSR) or is_op):
             return None
         key = (self.preference.data_ptr(), self.preference._version, features.data_ptr(), features._version,
                id(self.edge_index))
         if self._const_key != key:
             with torch.no_grad():
                 x = F.normalize(torch.cat((self.preference, features), dim=0))
-                ax = ops.spmm_raw(self.edge_index, x)
+                apply_a = self.edge_index.propagate if is_op else (lambda t: ops.spmm_raw(self.edge_index, t))
+                ax = apply_a(x)
                 ones = torch.ones((x.shape[0], 4), dtype=x.dtype, device=x.device)
-                rowsum = ops.spmm_raw(self.edge_index, ones)[:, :1]
+                rowsum = apply_a(ones)[:, :1]
                 pad = (-(x.shape[1] + 1)) % 4
                 self._const = (x, torch.cat((ax, rowsum, x.new_zeros(x.shape[0], pad)), dim=1).contiguous(), pad)
             self._const_key = key

@@ -56,12 +56,18 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // Shared by adam_step_kernel and the SpMM kernel's Adam epilogue: same expression, same rounding.
 struct AdamConsts {
   float lr, b1, b2, eps, wd;
+  float omb1, omb2;     // 1 - beta, taken in DOUBLE on the host and then rounded, as torch does with its python floats:
+                        // (float)(1.0 - 0.999) = 0.001f, whereas 1.0f - 0.999f = 0.00099998713f (1.3e-5 off in every
+                        // exp_avg_sq increment)
 };
+__host__ __device__ inline AdamConsts make_adam_consts(float lr, float b1, float b2, float eps, float wd) {
+  return AdamConsts{lr, b1, b2, eps, wd, (float)(1.0 - (double)b1), (float)(1.0 - (double)b2)};
+}
 __device__ __forceinline__ void adam_update(float &pi, float gi, float &mi, float &vi, const AdamConsts &c, float bc1,
                                             float bc2_sqrt) {
   if (c.wd != 0.f) gi = gi + c.wd * pi;
-  mi = mi + (gi - mi) * (1.0f - c.b1);
-  vi = vi * c.b2 + (1.0f - c.b2) * gi * gi;
+  mi = mi + (gi - mi) * c.omb1;
+  vi = vi * c.b2 + c.omb2 * gi * gi;
   const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
   pi = pi - (c.lr / bc1) * (mi / denom);
 }

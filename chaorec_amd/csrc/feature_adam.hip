@@ -390,7 +390,7 @@ extern "C" int chaorec_adam_multi_f32(int32_t count, float *const *param, const 
   for (int i = k; i <= kMultiMax; ++i) a.first_block[i] = blocks;
   for (int i = k; i < kMultiMax; ++i) { a.p[i] = nullptr; a.g[i] = nullptr; a.m[i] = nullptr; a.v[i] = nullptr; a.n[i] = 0; }
   a.count = k;
-  a.ac = AdamConsts{lr, beta1, beta2, eps, weight_decay};
+  a.ac = make_adam_consts(lr, beta1, beta2, eps, weight_decay);
   a.step_host = step;
   a.step_dev = step_dev;
   hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -440,7 +440,7 @@ extern "C" int chaorec_adam_lowrank_f32(float *param, const float *gy, const flo
   LowrankArgs a;
   a.p = param; a.m = exp_avg; a.v = exp_avg_sq; a.gy = gy; a.W = W;
   a.n_rows = n_rows; a.K = K; a.R = R;
-  a.ac = AdamConsts{lr, beta1, beta2, eps, weight_decay};
+  a.ac = make_adam_consts(lr, beta1, beta2, eps, weight_decay);
   a.step_host = step; a.step_dev = step_dev;
   a.last = last; a.bc_table = (const float2 *)bc_table; a.bc_len = bc_table ? bc_len : 0;
   a.rowlist = (mode == 1 || mode == 3) ? rowlist : nullptr; a.rowcount = rowcount;

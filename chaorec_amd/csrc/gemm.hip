@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float *__restrict__ p,
   }
   __syncthreads();
   const float bc1 = bc[0], bc2_sqrt = bc[1];
-  const AdamConsts ac{lr, b1, b2, eps, wd};
+  const AdamConsts ac = make_adam_consts(lr, b1, b2, eps, wd);
   auto upd = [&](float &pi, float gi, float &mi, float &vi) { adam_update(pi, gi, mi, vi, ac, bc1, bc2_sqrt); };
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -520,7 +520,7 @@ extern "C" int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *c
   ae.m = exp_avg;
   ae.v = exp_avg_sq;
   ae.bc = bias_corr;
-  ae.c = AdamConsts{lr, beta1, beta2, eps, weight_decay};
+  ae.c = make_adam_consts(lr, beta1, beta2, eps, weight_decay);
   ae.clear_z = clear_z ? 1 : 0;
   return spmm_dispatch(rowptr, col, val, x, grad_out, n_rows, n_cols, D, alpha, z, beta, nullptr, nullptr, 0.f, schedule,
                        mode, stream, &ae);

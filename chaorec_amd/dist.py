@@ -360,12 +360,13 @@ class ShardedLightGCN(nn.Module):
 
     def gene_ranklist(self, topk=50, gather=False):
         """Rank this shard's users against the replicated item table; ids are GLOBAL (item + U_global)."""
-        with torch.no_grad():
-            idx, _ = ops.score_topk(self.result_u.detach(), self.result_i.detach(), self.hist, 1e-6, topk,
-                                    id_offset=self.shard.num_user_global)
-        if gather and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            return gather_ranklists(idx, self.shard, self.group)
-        return idx.cpu()
+        from . import ranking
+        want_gather = gather and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        # (the shared evaluation path: carried thresholds from call to call, the list written straight to pinned memory)
+        idx = ranking.gene_ranklist(self.result_u, self.num_user, self.num_item, self.hist, 1e-6, topk,
+                                    to_cpu=not want_gather, state=ranking.state_of(self),
+                                    id_offset=self.shard.num_user_global, items=self.result_i)
+        return gather_ranklists(idx, self.shard, self.group) if want_gather else idx
 
     def local_user_ids(self, users):
         return users
@@ -765,13 +766,11 @@ class ShardedMMGCN(nn.Module):
             allreduce_grads(self.parameters(), self.group)
 
     def gene_ranklist(self, topk=50, gather=False):
-        with torch.no_grad():
-            r = self.result.detach()
-            idx, _ = ops.score_topk(r[:self.num_user], r[self.num_user:], self.hist, 1e-5, topk,
-                                    id_offset=self.shard.num_user_global)
-        if gather and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            return gather_ranklists(idx, self.shard, self.group)
-        return idx.cpu()
+        from . import ranking
+        want_gather = gather and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        idx = ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-5, topk, to_cpu=not want_gather,
+                                    state=ranking.state_of(self), id_offset=self.shard.num_user_global)
+        return gather_ranklists(idx, self.shard, self.group) if want_gather else idx
 
 
 # ---------------------------------------------------------------------------------------------------- FREEDOM
@@ -959,10 +958,8 @@ class ShardedFREEDOM(nn.Module):
             sink.reduce_pending(p, lambda t: _all_reduce(t, self.group))
 
     def gene_ranklist(self, topk=50, gather=False):
-        with torch.no_grad():
-            r = self.result.detach()
-            idx, _ = ops.score_topk(r[:self.num_user], r[self.num_user:], self.hist, 1e-6, topk,
-                                    id_offset=self.num_user_global)
-        if gather and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            return gather_ranklists(idx, self, self.group)
-        return idx.cpu()
+        from . import ranking
+        want_gather = gather and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        idx = ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=not want_gather,
+                                    state=ranking.state_of(self), id_offset=self.num_user_global)
+        return gather_ranklists(idx, self, self.group) if want_gather else idx

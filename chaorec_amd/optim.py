@@ -153,8 +153,23 @@ class FusedAdam(torch.optim.Optimizer):
                                      last=st["last"], bc_table=self._bc_table)
 
     def state_dict(self):
+        """torch.optim.Adam keeps a `step` per parameter; here the count is one device scalar for the whole optimizer:
+        saved as a top-level `chaorec_step` entry and restored by load_state_dict (the per-row `last` stamps of lazy
+        rows are only meaningful next to it)."""
         self.flush()
-        return super().state_dict()
+        sd = super().state_dict()
+        sd["chaorec_step"] = int(self._step_dev.item()) if self._step_dev is not None else 0
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        step = int(state_dict.pop("chaorec_step", 0))
+        super().load_state_dict(state_dict)
+        params = [p for g in self.param_groups for p in g["params"]]
+        if params:
+            if self._step_dev is None:
+                self._step_dev = torch.zeros(1, dtype=torch.int32, device=params[0].device)
+            self._step_dev.fill_(step)
 
     def _ensure_state(self, live):
         """Moments for the parameters of `live` that have none yet.  Parameters that sit back to back in one buffer
@@ -316,6 +331,12 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self, *batch):
+        if getattr(self.model, "graph_stale", False):
+            # FREEDOM / LayerGCN re-allocated their pruned graph (another entry count than the one captured): the hipGraph
+            # still holds the old arrays' addresses -- replaying it would train on freed memory.  The training loop
+            # (train_and_evaluate) clears the flag and captures again; any other holder of a captured step must too.
+            raise RuntimeError("GraphedTrainStep: the model rebound its graph after this step was captured "
+                               "(model.graph_stale): capture a new step")
         if self.batch_fn is not None:
             self.graph.replay()
             self.replays += 1

@@ -104,9 +104,15 @@ def state_of(model):
 ZERO_COPY = True     # to_cpu: the selection writes the rank list into pinned host memory itself (no D2H copy afterwards)
 
 
-def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to_cpu=True, state=None):
+def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to_cpu=True, state=None, id_offset=None,
+                  items=None):
     """result [N, D] (users first) on the GPU -> LongTensor [num_user, topk] of GLOBAL item ids on the CPU (the
-    reference's contract); to_cpu=False keeps it in HBM for utils.gene_metrics_device."""
+    reference's contract); to_cpu=False keeps it in HBM for utils.gene_metrics_device.
+    id_offset (default num_user): what is added to an item's row number -- a user shard ranks its own users against the
+    replicated items and reports item + num_user_GLOBAL.  items: the item table where it is not part of `result`."""
+    if items is not None and result.shape[1] not in (8, 16, 32, 64, 128) and not (result.shape[1] > 128 and result.shape[1] % 64 == 0):
+        result, items = torch.cat((result[:num_user].detach(), items.detach()), 0), None     # (odd width: padded below)
+    id_offset = num_user if id_offset is None else int(id_offset)
     host = None
     if to_cpu and ZERO_COPY:
         host = torch.empty((num_user, topk), dtype=torch.int64, pin_memory=True)
@@ -121,14 +127,17 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
         if state is not None:
             hint = state.buffer(num_user, result.device)
             hinted = state.use_hints(num_user)
-            idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
-                                    id_offset=num_user, hint=hint, hint_valid=hinted,
+        ue = result[:num_user]
+        ie = items.detach() if items is not None else result[num_user:num_user + num_item]
+        if state is not None:
+            hint = state.buffer(num_user, result.device)
+            hinted = state.use_hints(num_user)
+            idx, _ = ops.score_topk(ue, ie, hist, mask_value, topk, id_offset=id_offset, hint=hint, hint_valid=hinted,
                                     hint_rank=hint_rank_for(topk), light=hinted and state.light(),
                                     counters=state.counters, idx_out=host)
             state.after_call(hinted)
         else:
-            idx, _ = ops.score_topk(result[:num_user], result[num_user:num_user + num_item], hist, mask_value, topk,
-                                    id_offset=num_user, idx_out=host)
+            idx, _ = ops.score_topk(ue, ie, hist, mask_value, topk, id_offset=id_offset, idx_out=host)
     if host is not None:
         torch.cuda.current_stream(result.device).synchronize()
         return host

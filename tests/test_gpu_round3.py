@@ -137,3 +137,42 @@ def test_rows_mean_matches_the_layer_mean_association(dev):
     for t in terms[1:]:
         a = a + np.float32(w) * t.cpu().numpy()
     assert np.array_equal(out.cpu().numpy(), a)
+
+
+def test_captured_step_refuses_a_stale_graph_and_optimizer_step_survives_state_dict(dev):
+    """ADVICE (round 2): a captured step whose model re-allocated its graph must fail loudly, not replay dead addresses;
+    FusedAdam's device step counter travels in state_dict (bias corrections and lazy-row stamps depend on it)."""
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E = 1500, 700, 9000
+    edges = synthetic_interactions(U, I, E, seed=4)
+    torch.manual_seed(0)
+    m = LightGCN(U, I, edges, None, 64, 1e-3, 2, "add", dev).to(dev)
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    rng = np.random.default_rng(0)
+    sel = rng.choice(E, 128, replace=False)
+    batch = (torch.from_numpy(edges[sel, 0].astype(np.int64)), torch.from_numpy(edges[sel, 1].astype(np.int64)),
+             torch.from_numpy(rng.integers(U, U + I, 128)))
+    step = GraphedTrainStep(m, opt, example_batch=batch)
+    for _ in range(3):
+        step(*batch)
+    m.graph_stale = True
+    with pytest.raises(RuntimeError, match="graph_stale"):
+        step(*batch)
+    m.graph_stale = False
+    sd = opt.state_dict()
+    assert sd["chaorec_step"] == 3
+    opt2 = FusedAdam(m.parameters(), lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert int(opt2._step_dev.item()) == 3
+    w0 = m.user_embedding.weight.detach().clone()
+    for o in (opt, opt2):                                   # the same fourth step from either optimizer
+        with torch.no_grad():
+            m.user_embedding.weight.copy_(w0)
+        o.zero_grad()
+        m.loss(*batch).backward()
+        o.step()
+        if o is opt:
+            w_a = m.user_embedding.weight.detach().clone()
+    assert torch.allclose(m.user_embedding.weight, w_a, rtol=0, atol=1e-6)
