@@ -166,10 +166,10 @@ def test_captured_step_refuses_a_stale_graph_and_optimizer_step_survives_state_d
     opt2 = FusedAdam(m.parameters(), lr=1e-3)
     opt2.load_state_dict(sd)
     assert int(opt2._step_dev.item()) == 3
-    w0 = m.user_embedding.weight.detach().clone()
+    w0 = m._flat.detach().clone()
     for o in (opt, opt2):                                   # the same fourth step from either optimizer
         with torch.no_grad():
-            m.user_embedding.weight.copy_(w0)
+            m._flat.copy_(w0)
         o.zero_grad()
         m.loss(*batch).backward()
         o.step()
