@@ -62,6 +62,8 @@ def parse():
     p.add_argument("--synthetic", action="store_true", help="dataset-shaped synthetic graph instead of the real one")
     p.add_argument("--no-hbm-regime", action="store_true", help="skip the config-5-shard sub-record (N=1)")
     p.add_argument("--hbm-steps", type=int, default=10, help="timed steps of the config-5-shard sub-record")
+    p.add_argument("--no-full-config5", action="store_true",
+                   help="skip the sub-record of BASELINE configs[4] WHOLE on this GPU (10 M x 2 M, 4e8 directed edges: ~40 s)")
     p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MMGCN", "FREEDOM"],
                    help="LightGCN: the headline workload.  MMGCN (BASELINE configs[3], microlens) / FREEDOM (configs[2], "
                         "clothing): the model's captured train step + gene_ranklist, user-sharded at --gpus N > 1")
@@ -569,6 +571,21 @@ def main_single(args, dev):
             "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"],
         }
         del h
+        torch.cuda.empty_cache()
+        if not args.no_full_config5 and torch.cuda.get_device_properties(dev).total_memory > 200 * (1 << 30):
+            # ... and the whole of configs[4] on this one GPU: the N = 1 anchor of that config's scaling curve
+            f = measure_single_gpu(args, "config5", 128, 3, 1, dev, 0, reps_rank=1)
+            out["config5_whole_on_one_gpu"] = {
+                "workload": f"BASELINE configs[4] whole: synthetic bipartite graph U={f['U']}, I={f['I']}, E_dir={f['e_dir']}, "
+                            f"dim=128, n_layers={f['L']}, batch={f['B']} (embedding table {f['table_mb']:.0f} MB; generated "
+                            f"and laid out on the device)",
+                "data": f["data"], "steps": 3, "ms_per_step": f["ms_per_step"], "value": f["value"],
+                "unit": "directed-edge messages/s", "roofline": f["roofline"], "host_build_seconds": f["build_s"],
+                "gene_ranklist_ms_cold": f["cold_ms"], "users_scored_per_s_cold": f["U"] / (f["cold_ms"] * 1e-3),
+                "roofline_scoring": scoring_roofline(f), "loss_mean": f["loss_mean"],
+            }
+            del f
+            torch.cuda.empty_cache()
     if not args.no_cpu_baseline and edges is not None:
         out["cpu_baseline"] = cpu_baseline(edges, U, I, D, args.n_layers, args.batch, reg, args.cpu_seconds)
     print(json.dumps(out), flush=True)
@@ -642,7 +659,8 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
     if step_kind == "fused":
         def make_fused(capture):
             return cdist.FusedShardedLightGCNStep(model, opt, batch_size=B, edges=edges_dev, seed=42 + rank,
-                                                  step_dev=batch_counter, capture=capture, loss_accum=fused_loss)
+                                                  step_dev=batch_counter, capture=capture, loss_accum=fused_loss,
+                                                  steps_per_replay=args.steps_per_replay)
         if use_graph:
             try:
                 fused = make_fused(True)
@@ -696,7 +714,7 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
             if force_eager:           # (the SpMM-recording pass: the same launches, issued eagerly)
                 fused._launch()
             else:
-                fused()
+                fused(single=True)
             return
         if graphed is not None and not force_eager:
             graphed()                 # sampling + loss + backward + Adam: one hipGraph replay, no inputs
@@ -714,12 +732,18 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
         dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first, n):
+        if fused is not None:         # whole k-step replays, single-step replays for the remainder
+            n_loss[0] += n
+            fused.run(n)
+            return
+        for i in range(n):
+            step(first + i)
+
+    run_steps(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run_steps(args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -792,8 +816,8 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                                f"gene_ranklist top-50 over all users (cold thresholds)",
                    "messages_per_step": msgs_per_step_all, "gene_ranklist_ms": score_ms,
                    "launch": ("captured hipGraph per step" if graphed is not None else "eager launches") +
-                             (", fused sharded step (dist.FusedShardedLightGCNStep: 2L+5 launches, 2L+1 exchanges)"
-                              if fused is not None else ", autograd step"),
+                             (f", fused sharded step (dist.FusedShardedLightGCNStep: 2L+5 launches, 2L+1 exchanges; {fused.steps_per_replay} "
+                              f"steps per replay)" if fused is not None else ", autograd step"),
                    "optimizer": "torch.optim.Adam" if args.torch_adam else
                    ("Adam in the last user-row SpMM's epilogue + one fused launch on the replicated item rows"
                     if fused is not None else "FusedAdam (chaorec_adam_step_f32)"),

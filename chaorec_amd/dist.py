@@ -418,7 +418,7 @@ class FusedShardedLightGCNStep:
     folded into the epilogue factors.  Item rows end identical on every rank (same sums, same Adam arithmetic)."""
 
     def __init__(self, model, optimizer, batch_size=1024, edges=None, seed=42, step_dev=None, given_batch=False,
-                 loss_accum=None, capture=True, kernels=None, group=None):
+                 loss_accum=None, capture=True, kernels=None, group=None, steps_per_replay=1):
         from .optim import FusedAdam
         if not isinstance(optimizer, FusedAdam) or len(optimizer.param_groups) != 1:
             raise TypeError("FusedShardedLightGCNStep needs a FusedAdam with one parameter group")
@@ -465,7 +465,10 @@ class FusedShardedLightGCNStep:
         self.use_mean = self.L <= self.K.mean_terms_limit(D)
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         self.replays = 0
-        self.graph = None
+        self.graph = self.graph1 = None
+        # k steps per hipGraph (in-launch batches only): a replay boundary costs ~5.5 us on this stack, the launches inside
+        # a graph follow each other without a gap
+        self.steps_per_replay = int(steps_per_replay) if (capture and edges is not None) else 1
         if capture:
             for c in (self.csr, shard.ui, shard.iu):
                 c.schedule(D)                   # lazily built by the first SpMM: must exist before capture
@@ -477,11 +480,18 @@ class FusedShardedLightGCNStep:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._restore_state(saved)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            self.graph1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph1):
                 self._launch()
+            self.graph = self.graph1
+            if self.steps_per_replay > 1:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    for _ in range(self.steps_per_replay):
+                        self._launch()
             saved = self._save_state()
-            self.graph.replay()
+            for gph in {id(self.graph1): self.graph1, id(self.graph): self.graph}.values():
+                gph.replay()
             torch.cuda.synchronize()
             self._restore_state(saved)
 
@@ -549,15 +559,16 @@ class FusedShardedLightGCNStep:
         self.G[U:N].zero_()
         model.result_u, model.result_i, model._result_cat = self.final[:U], self.final[U:N], None
 
-    def __call__(self, users=None, pos=None, neg=None):
-        """One training step -> this rank's batch loss (device scalar; the global loss is the mean over ranks).
-        users / pos / neg (shard-local ids, items as item + U_g) only in given_batch mode."""
+    def __call__(self, users=None, pos=None, neg=None, single=False):
+        """One replay = `steps_per_replay` training steps (single=True: exactly one) -> this rank's last batch loss
+        (device scalar; the global loss is the mean over ranks).  users / pos / neg (shard-local ids, items as
+        item + U_g) only in given_batch mode."""
         if self.edges is None:
             self.ids[0].copy_(users, non_blocking=True)
             torch.sub(pos.to(self.ids[1].device), self.U, out=self.ids[1])
             torch.sub(neg.to(self.ids[2].device), self.U, out=self.ids[2])
         if self.graph is not None:
-            self.graph.replay()
+            (self.graph1 if single else self.graph).replay()
         else:
             self._launch()
         self.replays += 1
@@ -565,8 +576,12 @@ class FusedShardedLightGCNStep:
         return self.static_loss
 
     def run(self, n_steps):
-        for _ in range(n_steps):
+        """n_steps training steps: whole replays first, single-step replays for the remainder."""
+        k = self.steps_per_replay
+        for _ in range(n_steps // k):
             self()
+        for _ in range(n_steps % k):
+            self(single=True)
         return self.static_loss
 
 
