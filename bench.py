@@ -67,6 +67,9 @@ def parse():
     p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MMGCN", "FREEDOM"],
                    help="LightGCN: the headline workload.  MMGCN (BASELINE configs[3], microlens) / FREEDOM (configs[2], "
                         "clothing): the model's captured train step + gene_ranklist, user-sharded at --gpus N > 1")
+    p.add_argument("--spmm-only", action="store_true",
+                   help="N=1: stop after the timed steps and the SpMM roofline (no ranking): the command of the --pmc passes "
+                        "at config 5, where a counter-collecting run of the 5 PFLOP ranking takes tens of minutes")
     p.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)   # child mode of probe_sharded_graph()
     return p.parse_args()
 
@@ -406,6 +409,11 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                                             "algorithmic_bytes": adam_bytes,
                                             "achieved_GBps": adam_bytes / (adam_ms * 1e-3) / 1e9}
 
+    if getattr(args, "spmm_only", False):
+        return dict(spmm_only=True, dataset=dataset, data=data_kind, U=U, I=I, E=E, e_dir=e_dir, D=D, L=L, B=B,
+                    ms_per_step=ms_per_step, value=msgs_per_step / (dt / steps), msgs_per_step=msgs_per_step,
+                    loss_mean=loss_mean, launch=launch, roofline=roofline, build_s=build_s)
+
     # --- full-rank evaluation ---------------------------------------------------------------------------------
     # Two states of the same call.  COLD: no thresholds carried (the first evaluation of a run): sampled thresholds.
     # STEADY: the evaluation loop's state (train_and_evaluate.py:655-659 ranks once per epoch) a few epochs into a run
@@ -524,6 +532,15 @@ def main_single(args, dev):
     r = measure_single_gpu(args, args.dataset, D, args.steps, args.warmup, dev,
                            0 if args.no_trained_state else TRAINED_STEPS, synthetic=args.synthetic)
     U, I = r["U"], r["I"]
+    if r.get("spmm_only"):
+        print(json.dumps({"metric": f"GCN edges/sec, dim={D} (--spmm-only: no ranking)", "value": r["value"],
+                          "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "dtype": "f32",
+                          "data": r["data"], "config": {"workload": f"LightGCN train step on the {r['data']} {args.dataset} "
+                                                                    f"graph (U={U}, I={I}, E_dir={r['e_dir']}), dim={D}",
+                                                        "launch": r["launch"], "host_build_seconds": r["build_s"]},
+                          "roofline": r["roofline"], "loss_mean": r["loss_mean"]}), flush=True)
+        return
     out = {
         "metric": f"GCN edges/sec + full-rank users-scored/sec, dim={D}",
         "value": r["value"], "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",

@@ -16,6 +16,7 @@ import torch.nn.functional as F  # noqa: F401  (kept: reference module namespace
 from torch import nn
 
 from .. import graph, ops, ranking
+from .LightGCN import _JoinTables
 
 
 class FREEDOM(nn.Module):
@@ -56,6 +57,9 @@ class FREEDOM(nn.Module):
         nn.init.xavier_uniform_(self.user_embedding.weight)
         nn.init.xavier_uniform_(self.item_embedding.weight)
 
+        self._flat = None
+        self._join_tables()
+
         self.image_embedding = nn.Embedding.from_pretrained(self.v_feat, freeze=False)
         self.text_embedding = nn.Embedding.from_pretrained(self.t_feat, freeze=False)
         self.image_trs = nn.Linear(self.v_feat.shape[1], self.dim_feat)
@@ -82,6 +86,33 @@ class FREEDOM(nn.Module):
             # Model/FREEDOM.py:69: mm_adj = w * image_adj + (1 - w) * text_adj (sparse add = union of entries)
             self.mm_adj = graph.add_scaled_coo(image_adj, self.mm_image_weight, text_adj, 1.0 - self.mm_image_weight,
                                                self.num_item).to(self.device)
+
+    # ---- the two id-embedding tables as views of ONE [N, D] buffer (as in Model/LightGCN.py here) -----------------------
+    def _join_tables(self):
+        """torch.cat((user_embedding.weight, item_embedding.weight)) (Model/FREEDOM.py:165) without the per-step copy
+        and without the gradient split in the backward: same Parameters, same state_dict, one Adam launch for both."""
+        uw, iw = self.user_embedding.weight, self.item_embedding.weight
+        flat = torch.cat((uw.data, iw.data), 0)
+        uw.data, iw.data = flat[:self.num_user], flat[self.num_user:]
+        self._flat = flat
+
+    def _apply(self, fn, *args, **kwargs):     # .to(device) / .float() / ... replace the Parameters' storage
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_flat", None) is not None:
+            self._join_tables()
+        return out
+
+    @property
+    def result(self):
+        """[N, D] users then items (read by gene_ranklist, stale as in the reference): concatenated on the first access
+        after a forward -- once per epoch, not once per training step."""
+        if self._result_cat is None and self._result_parts is not None:
+            self._result_cat = torch.cat(self._result_parts, dim=0)
+        return self._result_cat
+
+    @result.setter
+    def result(self, value):
+        self._result_cat, self._result_parts = value, None
 
     # ---- graph construction (host, once) -------------------------------------------------
     def get_norm_adj_mat(self, edge_index):
@@ -170,10 +201,12 @@ class FREEDOM(nn.Module):
     # ---- hot path ---------------------------------------------------------------------------
     def forward(self, adj):
         """Model/FREEDOM.py:164-183."""
-        ego_embeddings = torch.cat((self.user_embedding.weight, self.item_embedding.weight), dim=0)
+        uw, iw = self.user_embedding.weight, self.item_embedding.weight
+        if uw.data_ptr() != self._flat.data_ptr() or iw.data_ptr() != self._flat[self.num_user:].data_ptr():
+            self._join_tables()                # someone re-assigned a weight's storage (e.g. weight.data = ...)
+        ego_embeddings = _JoinTables.apply(uw, iw, self._flat)
         all_embeddings = ops.layer_mean_propagate(ego_embeddings, adj, self.n_layers)
-        u_g_embeddings = all_embeddings[:self.num_user]
-        i_g_embeddings = all_embeddings[self.num_user:]
+        u_g_embeddings, i_g_embeddings = ops.split_rows(all_embeddings, self.num_user)
         h = self.item_embedding.weight
         if self.mm_layers == 0:
             i_g_embeddings = i_g_embeddings + h
@@ -182,7 +215,7 @@ class FREEDOM(nn.Module):
                 h = ops.spmm(self.mm_adj, h)
             else:  # last item-item layer fused with `i_g_embeddings + h`
                 i_g_embeddings = ops.spmm_add(self.mm_adj, h, i_g_embeddings)
-        self.result = torch.cat((u_g_embeddings, i_g_embeddings), dim=0)
+        self._result_parts, self._result_cat = (u_g_embeddings.detach(), i_g_embeddings.detach()), None
         return u_g_embeddings, i_g_embeddings
 
     def bpr_loss(self, users, pos_items, neg_items):

@@ -280,17 +280,47 @@ class _BPRMulti(torch.autograd.Function):
         ids = ctx.saved_tensors[4 + T:]
         B, D = users.numel(), tab_u.shape[1]
         gvec = (g * wvec).contiguous()                   # d total / d loss_k, on the device
-        g_u = torch.zeros_like(tab_u)
+        # ONE zero fill for the T + 1 gradient buffers (views of it), not one launch each
+        sizes = [tab_u.numel()] + [t.numel() for t in tabs]
+        flat = torch.zeros(sum(sizes), dtype=tab_u.dtype, device=tab_u.device)
+        offs = [0]
+        for n_ in sizes:
+            offs.append(offs[-1] + n_)
+        g_u = flat[:sizes[0]].view_as(tab_u)
         lib = _lib.load()
         grads = []
         for k in range(T):
-            g_i = torch.zeros_like(tabs[k])
+            g_i = flat[offs[k + 1]:offs[k + 2]].view_as(tabs[k])
             rc = lib.chaorec_bpr_bwd_f32(_ptr(tab_u), _ptr(tabs[k]), _ptr(users), _ptr(ids[2 * k]), _ptr(ids[2 * k + 1]), B,
                                          D, ctypes.c_void_p(coef.data_ptr() + 4 * B * k), 0.0,
                                          ctypes.c_void_p(gvec.data_ptr() + 4 * k), _ptr(g_u), _ptr(g_i), _stream())
             _lib.check(rc, "chaorec_bpr_bwd_f32")
             grads += [g_i, None, None]
         return (g_u, None, None, None, *grads)
+
+
+class _SplitRows(torch.autograd.Function):
+    """(x[:n], x[n:]) of a [N, D] table whose two halves feed different branches (FREEDOM: the propagated user rows go
+    to the loss, the item rows through the item-item graph first).  Plain slicing costs the backward two zero-filled
+    [N, D] buffers, two slice copies and an add; here it is one concatenation of the two incoming gradients."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.rows = n, x.shape[0]
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        if g_a is None or g_b is None:               # (a half that does not reach the loss: its gradient is zero)
+            other = g_a if g_a is not None else g_b
+            rows = ctx.n if g_a is None else ctx.rows - ctx.n
+            zero = other.new_zeros((rows, other.shape[1]))
+            g_a, g_b = (zero, g_b) if g_a is None else (g_a, zero)
+        return torch.cat((g_a, g_b), 0), None
+
+
+def split_rows(x, n):
+    return _SplitRows.apply(x, n)
 
 
 def bpr_loss_multi(tab_u, users, variant, terms, wvec):

@@ -163,8 +163,9 @@ def test_captured_step_refuses_a_stale_graph_and_optimizer_step_survives_state_d
     m.graph_stale = False
     sd = opt.state_dict()
     assert sd["chaorec_step"] == 3
+    import copy
     opt2 = FusedAdam(m.parameters(), lr=1e-3)
-    opt2.load_state_dict(sd)
+    opt2.load_state_dict(copy.deepcopy(sd))       # (as from a file: torch's load_state_dict keeps tensors that already fit)
     assert int(opt2._step_dev.item()) == 3
     w0 = m._flat.detach().clone()
     for o in (opt, opt2):                                   # the same fourth step from either optimizer

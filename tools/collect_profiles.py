@@ -32,6 +32,9 @@ WORKLOADS = {
     "config5_full": ("config5", 128, ["--dataset", "config5", "--dim", "128", "--steps", "3", "--warmup", "1",
                                       "--no-hbm-regime"], 1.61),
 }
+# extra bench arguments of the --pmc passes (counter collection serialises every dispatch: config 5's ranking, 5 PFLOP per
+# call, does not finish in a quarter of an hour under it -- the SpMM counters do not need it)
+PMC_EXTRA = {"config5_full": ["--spmm-only"]}
 
 
 def run(tag, wl, name, extra, graph):
@@ -39,7 +42,7 @@ def run(tag, wl, name, extra, graph):
     shutil.rmtree(out, ignore_errors=True)
     cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", name] + extra + \
           ["--", "python3", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-trained-state"] + \
-          WORKLOADS[wl][2] + ([] if graph else ["--no-graph"])
+          WORKLOADS[wl][2] + ([] if graph else ["--no-graph"]) + (PMC_EXTRA.get(wl, []) if "--pmc" in extra else [])
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -70,11 +73,17 @@ def main():
     os.makedirs(prof, exist_ok=True)
     for wl in which:
         dataset, D, _, factor = WORKLOADS[wl]
-        out, line = run(tag, wl, "stats", ["--stats"], graph=True)
-        f = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)[0]
-        shutil.copy(f, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
+        kept = os.path.join(ROOT, "profiles", f"{tag}_{wl}_kernel_stats.csv")
+        if os.environ.get("CHAOREC_REUSE_STATS") == "1" and os.path.exists(kept):
+            # (re-run of the --pmc passes only: the kernel-stats pass of this tag is already under profiles/)
+            f = kept
+            line = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{wl}_bench_line_under_rocprof.json")))
+        else:
+            out, line = run(tag, wl, "stats", ["--stats"], graph=True)
+            f = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)[0]
+            shutil.copy(f, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
+            json.dump(line, open(os.path.join(prof, f"{tag}_{wl}_bench_line_under_rocprof.json"), "w"), indent=1)
         stats = {r["Name"]: r for r in csv.DictReader(open(f))}
-        json.dump(line, open(os.path.join(prof, f"{tag}_{wl}_bench_line_under_rocprof.json"), "w"), indent=1)
         means = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out, _ = run(tag, wl, counter, ["--pmc", counter], graph=False)
