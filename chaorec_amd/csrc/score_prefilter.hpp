@@ -1246,6 +1246,10 @@ __global__ __launch_bounds__(64, D > 64 ? 3 : (MAXC <= 512 ? CHAOREC_SEL_WAVES :
 // lists and sorts the final K.  Cost is per user, independent of how many users need it (a 32-user group of the
 // fp32 MFMA sweep costs ~0.5 ms of latency).
 constexpr int kExThreads = 1024;
+// D = 128 keeps twice the row pieces per lane: at 1024 threads (128 VGPRs) the kernel spilled 18 registers; 512-thread
+// blocks get 256
+template <int D>
+constexpr int ex_threads() { return D <= 64 ? kExThreads : kExThreads / 2; }
 constexpr int kExPer = 2;                         // keys per lane and round
 constexpr int kExSlices = 8;                      // blocks per user: one CU's vector-memory path cannot stream the
                                                   // item table (a thread per row = 64 cache lines per load) fast enough
@@ -1328,7 +1332,8 @@ __device__ __forceinline__ uint64_t merge_top64(uint64_t a, uint64_t b, int lane
 }
 
 template <int D>
-__global__ __launch_bounds__(kExThreads) void score_exact_user_kernel(const PrefArgs P) {
+__global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const PrefArgs P) {
+  constexpr int kExThreads = ex_threads<D>();      // (shadows the namespace constant: this instantiation's block size)
   constexpr int NW = kExThreads / 64;
   __shared__ uint64_t stage[NW][64];         // per-wave staging / the waves' lists for the block merge
   __shared__ uint32_t hist_s[kPfHistLds];

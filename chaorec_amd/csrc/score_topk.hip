@@ -1217,8 +1217,8 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       P.fb_skip = kPfFbGroupCap;
     }
     // ... and exact fp32 scores of all items for each remaining one, one block per (user, item slice)
-    if (D == 64) hipLaunchKernelGGL(score_exact_user_kernel<64>, dim3(512), dim3(kExThreads), 0, st, P);
-    else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(512), dim3(kExThreads), 0, st, P);
+    if (D == 64) hipLaunchKernelGGL(score_exact_user_kernel<64>, dim3(512), dim3(ex_threads<64>()), 0, st, P);
+    else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(1024), dim3(ex_threads<128>()), 0, st, P);
     return check_launch("score_exact_user_kernel");
   }
   if (p.pack) {
