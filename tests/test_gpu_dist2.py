@@ -1,0 +1,121 @@
+"""Two ranks on ONE GPU (gloo for the collectives, the HIP kernels for the compute): dist.FusedShardedLightGCNStep at
+world size 2 on real kernels -- joined shard graphs over different user ranges, padded exchange buffers, the 1 / world
+factors in the SpMM epilogues, Adam in the user-row epilogue and the fused launch on the replicated item rows -- against
+optim.FusedLightGCNStep on the whole graph in the parent process.  (RCCL itself needs one GPU per rank: the driver's
+multi-GPU run is the first place it meets this code; what is checked here is everything around the collective.)"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+U, I, E, D, B, T = 2400, 901, 16000, 64, 192, 3
+
+
+def _problem():
+    from chaorec_amd.synthetic import synthetic_interactions
+    edges = synthetic_interactions(U, I, E, seed=6)
+    g = torch.Generator().manual_seed(8)
+    x0 = (torch.rand(U + I, D, generator=g) * 2 - 1) * 0.05
+    rng = np.random.default_rng(2)
+    batches = []
+    for t in range(T):
+        per_rank = []
+        for r in range(2):
+            sel = rng.choice(E, B, replace=False)
+            per_rank.append((edges[sel, 0].astype(np.int64), edges[sel, 1].astype(np.int64), rng.integers(U, U + I, B)))
+        batches.append(per_rank)
+    return edges, x0, batches
+
+
+def _worker(rank, world, port, tmp, L):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chaorec_amd import dist as cdist
+    from chaorec_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    edges, x0, batches = _problem()
+    deg = np.bincount(edges[:, 0], minlength=U)
+    bounds = cdist.partition_users_by_nnz(deg, world)
+    mine = edges[(edges[:, 0] >= bounds[rank]) & (edges[:, 0] < bounds[rank + 1])]
+    shard = cdist.UserShard.from_local(mine, bounds, I, world, rank, dev)
+    m = cdist.ShardedLightGCN(shard, None, D, 1e-3, L, dev, seed=1).to(dev)
+    with torch.no_grad():
+        m.user_embedding.weight.copy_(x0[shard.u0:shard.u1])
+        m.item_embedding.weight.copy_(x0[U:])
+    step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=False)
+    losses = []
+    for t in range(T):
+        # this rank's batch: the triples of BOTH ranks' draws whose user it owns would change the batch size; instead
+        # every rank gets its own B triples of users it owns (re-drawn from its local edges with the problem's seed)
+        rng = np.random.default_rng(100 * t + rank)
+        sel = rng.choice(len(shard.local_edges), B, replace=False)
+        users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64)).to(dev)
+        pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64)).to(dev)
+        neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + I, B)).to(dev)
+        losses.append(float(step(users, pos, neg)))
+    torch.cuda.synchronize()
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), u0=shard.u0, u1=shard.u1, xu=m.user_embedding.weight.detach().cpu().numpy(),
+             xi=m.item_embedding.weight.detach().cpu().numpy(), fu=m.result_u.cpu().numpy(), fi=m.result_i.cpu().numpy(),
+             losses=np.array(losses), n_local_edges=len(shard.local_edges))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("L", [1, 3])
+def test_fused_sharded_step_world2_on_the_kernels(oracle, L):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(world, _free_port(), tmp, L), nprocs=world, join=True)
+        r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
+    # the whole-graph reference: the oracle's loss gradient of the mean over the ranks' batches + Adam, in fp64
+    from chaorec_amd import dist as cdist
+    edges, x0, _ = _problem()
+    csr = oracle.lightgcn_csr(edges, U + I)
+    x = x0.numpy().astype(np.float64)
+    m, v = np.zeros_like(x), np.zeros_like(x)
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    bounds = cdist.partition_users_by_nnz(np.bincount(edges[:, 0], minlength=U), world)
+    for t in range(T):
+        g_tot = np.zeros_like(x)
+        for k in range(world):
+            mine = edges[(edges[:, 0] >= bounds[k]) & (edges[:, 0] < bounds[k + 1])]
+            rng = np.random.default_rng(100 * t + k)
+            sel = rng.choice(len(mine), B, replace=False)
+            n_loc = bounds[k + 1] - bounds[k]
+            bu = mine[sel, 0].astype(np.int64)
+            bp = mine[sel, 1].astype(np.int64) - U
+            bn = rng.integers(n_loc, n_loc + I, B) - n_loc
+            out, g = oracle.lightgcn_loss(x.astype(np.float32), csr, L, U, bu, bp, bn, 1e-3)
+            g_tot += g / world
+            assert r[k]["losses"][t] == pytest.approx(out[0], rel=2e-5), (t, k)
+        m = b1 * m + (1 - b1) * g_tot
+        v = b2 * v + (1 - b2) * g_tot * g_tot
+        x = x - lr * (m / (1 - b1 ** (t + 1))) / (np.sqrt(v) / np.sqrt(1 - b2 ** (t + 1)) + eps)
+    xu = np.concatenate([x_["xu"] for x_ in r], 0)
+    assert np.allclose(xu, x[:U], rtol=0, atol=3e-5)
+    for k in range(world):
+        assert np.allclose(r[k]["xi"], x[U:], rtol=0, atol=3e-5)
+    assert np.array_equal(r[0]["xi"], r[1]["xi"])                      # identical item update on every rank
