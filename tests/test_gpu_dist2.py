@@ -119,3 +119,83 @@ def test_fused_sharded_step_world2_on_the_kernels(oracle, L):
     for k in range(world):
         assert np.allclose(r[k]["xi"], x[U:], rtol=0, atol=3e-5)
     assert np.array_equal(r[0]["xi"], r[1]["xi"])                      # identical item update on every rank
+
+
+# ---------------------------------------------------------------------------------------------------- MMGCN (configs[3])
+def _mmgcn_problem():
+    from chaorec_amd.synthetic import synthetic_interactions
+    Um, Im, Em = 2000, 700, 12000
+    edges = synthetic_interactions(Um, Im, Em, seed=8)
+    g = torch.Generator().manual_seed(1)
+    return Um, Im, edges, torch.randn(Im, 128, generator=g), torch.randn(Im, 256, generator=g)
+
+
+def _mmgcn_full(dev):
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MMGCN
+    Um, Im, edges, v_feat, t_feat = _mmgcn_problem()
+    torch.manual_seed(77)
+    return MMGCN(Um, Im, edges, graph.user_item_dict_from_edges(edges), v_feat, t_feat, 64, 1e-4, "add", "False", True, dev).to(dev)
+
+
+def _mmgcn_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chaorec_amd import dist as cdist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    Um, Im, edges, _, _ = _mmgcn_problem()
+    full = _mmgcn_full(dev)
+    shard = cdist.UserShard(edges, Um, Im, world, rank, dev, self_loops=True)
+    m = cdist.ShardedMMGCN(full, shard, dev)
+    rng = np.random.default_rng(200 + rank)
+    sel = rng.choice(len(shard.local_edges), 256, replace=False)
+    u = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64))
+    pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64))
+    neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + Im, 256))
+    ut, it = torch.stack((u, u), 1), torch.stack((pos, neg), 1)
+    m.zero_grad()
+    loss = m.loss(ut, it)
+    loss.backward()
+    m.sync_grads()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(tmp, f"mm{rank}.npz"), u0=shard.u0, u1=shard.u1, loss=float(loss), ut=ut.numpy(), it=it.numpy(),
+             res=m.result.detach().cpu().numpy(), **{"g_" + n: p.grad.cpu().numpy() for n, p in m.named_parameters()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mmgcn_world2_on_the_kernels():
+    """BASELINE configs[3]'s sharding on the real kernels: two ranks (one GPU, gloo) against the single-process MMGCN on
+    the whole graph -- representation, loss, the summed gradient of every Linear, identical on both ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_mmgcn_worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(tmp, f"mm{k}.npz"))) for k in range(world)]
+    dev = torch.device("cuda:0")
+    Um = _mmgcn_problem()[0]
+    full = _mmgcn_full(dev)
+    uts, its = [], []
+    for k in range(world):
+        n_local = int(r[k]["u1"] - r[k]["u0"])
+        uts.append(torch.from_numpy(r[k]["ut"] + int(r[k]["u0"])))
+        its.append(torch.from_numpy(r[k]["it"] - n_local + Um))
+    loss = full.loss(torch.cat(uts), torch.cat(its))
+    loss.backward()
+    assert sum(float(x["loss"]) for x in r) == pytest.approx(float(loss.detach()), rel=2e-5)
+    ref = full.result.detach().cpu().numpy()
+    scale = np.abs(ref).max()
+    for k in range(world):
+        u0, u1 = int(r[k]["u0"]), int(r[k]["u1"])
+        assert np.abs(r[k]["res"][:u1 - u0] - ref[u0:u1]).max() <= 3e-4 * scale
+        assert np.abs(r[k]["res"][u1 - u0:] - ref[Um:]).max() <= 3e-4 * scale
+    for n, p in full.named_parameters():
+        g = p.grad.cpu().numpy()
+        assert np.abs(r[0]["g_" + n] - g).max() <= 2e-3 * (np.abs(g).max() + 1e-12), n
+        assert np.array_equal(r[0]["g_" + n], r[1]["g_" + n]), n       # identical update on every rank
