@@ -199,3 +199,92 @@ def test_sharded_mmgcn_world2_on_the_kernels():
         g = p.grad.cpu().numpy()
         assert np.abs(r[0]["g_" + n] - g).max() <= 2e-3 * (np.abs(g).max() + 1e-12), n
         assert np.array_equal(r[0]["g_" + n], r[1]["g_" + n]), n       # identical update on every rank
+
+
+# ---------------------------------------------------------------------------------------------------- FREEDOM (configs[2])
+def _freedom_full(dev):
+    """The small reference golden's FREEDOM (dropout 0.2: the per-epoch pruning is on) with its stored weights."""
+    from conftest import load_golden
+    from chaorec_amd.Model import FREEDOM
+    from chaorec_amd import graph
+    g = load_golden("freedom_small_drop.npz")
+    Uf, If = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = FREEDOM(Uf, If, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+                torch.from_numpy(g["t_feat"]), int(g["D"]), int(g["D"]), float(g["reg"]), float(g["dropout"]),
+                int(g["L"]), int(g["mm_layers"]), int(g["knn"]), float(g["w"]), dev)
+    with torch.no_grad():
+        m.user_embedding.weight.copy_(torch.from_numpy(g["x0"][:Uf]))
+        m.item_embedding.weight.copy_(torch.from_numpy(g["x0"][Uf:]))
+    return m.to(dev), Uf, If, g["edges"]
+
+
+def _freedom_batch(n_edges_local, rank, B=64):
+    return np.random.default_rng(300 + rank).choice(n_edges_local, B, replace=False), np.random.default_rng(400 + rank)
+
+
+def _freedom_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chaorec_amd import dist as cdist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    full, Uf, If, edges = _freedom_full(dev)
+    bounds = cdist.partition_users_by_nnz(np.bincount(edges[:, 0], minlength=Uf), world)
+    sh = cdist.ShardedFREEDOM(full, bounds, world, rank, dev)
+    sh.pre_epoch_processing()
+    loc = sh.local_edges                                   # [global user, item + U_global] of this rank's users
+    sel, rng = _freedom_batch(len(loc), rank)
+    users = torch.from_numpy(loc[sel, 0] - sh.u0).to(dev)
+    pos = torch.from_numpy(loc[sel, 1] - Uf).to(dev)
+    neg = torch.from_numpy(rng.integers(0, If, len(sel))).to(dev)
+    sh.zero_grad()
+    loss = sh.loss(users, pos, neg)
+    loss.backward()
+    sh.sync_grads()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(tmp, f"fr{rank}.npz"), u0=sh.u0, u1=sh.u1, loss=float(loss), users=(users + sh.u0).cpu().numpy(),
+             pos=pos.cpu().numpy(), neg=neg.cpu().numpy(), res=sh.result.detach().cpu().numpy(), kept=sh.shard.nnz,
+             **{"g_" + n: p.grad.cpu().numpy() for n, p in sh.named_parameters() if p.grad is not None})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_freedom_world2_on_the_kernels():
+    """BASELINE configs[2]'s sharding on the real kernels: two ranks (one GPU, gloo) with the DISTRIBUTED per-epoch pruning
+    (keys of the own edges, k-th smallest over all ranks by all-reduced histograms) against the single-process FREEDOM: the
+    same number of kept edges, representation, loss, gradients of the id embeddings and of the modality transforms."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_freedom_worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
+        r = [dict(np.load(os.path.join(tmp, f"fr{k}.npz"))) for k in range(world)]
+    dev = torch.device("cuda:0")
+    full, Uf, If, _ = _freedom_full(dev)
+    full.pre_epoch_processing()
+    assert sum(int(x["kept"]) for x in r) * 2 == full.masked_adj.nnz           # the same pruned edge count
+    users = torch.from_numpy(np.concatenate([x["users"] for x in r]))
+    pos = torch.from_numpy(np.concatenate([x["pos"] for x in r]) + Uf)
+    neg = torch.from_numpy(np.concatenate([x["neg"] for x in r]) + Uf)
+    loss = full.loss(users, pos, neg)
+    loss.backward()
+    assert sum(float(x["loss"]) for x in r) == pytest.approx(float(loss.detach()), rel=1e-5)
+    ref = full.result.detach().cpu().numpy()
+    for k in range(world):
+        u0, u1 = int(r[k]["u0"]), int(r[k]["u1"])
+        assert np.allclose(r[k]["res"][:u1 - u0], ref[u0:u1], rtol=1e-5, atol=1e-7)
+        assert np.allclose(r[k]["res"][u1 - u0:], ref[Uf:], rtol=1e-5, atol=1e-7)
+    named = dict(full.named_parameters())
+    gu = np.concatenate([x["g_user_embedding.weight"] for x in r], 0)
+    ref_gu = named["user_embedding.weight"].grad.cpu().numpy()
+    assert np.abs(gu - ref_gu).max() <= 2e-4 * np.abs(ref_gu).max() + 1e-9
+    for n in ("item_embedding.weight", "image_trs.weight", "text_trs.weight", "image_trs.bias", "text_trs.bias"):
+        g = named[n].grad.cpu().numpy()
+        assert np.abs(r[0]["g_" + n] - g).max() <= 2e-4 * np.abs(g).max() + 1e-9, n
+        assert np.allclose(r[0]["g_" + n], r[1]["g_" + n], rtol=0, atol=1e-12 + 1e-6 * np.abs(g).max()), n
