@@ -104,15 +104,16 @@ class FREEDOM(nn.Module):
 
     @property
     def result(self):
-        """[N, D] users then items (read by gene_ranklist, stale as in the reference): concatenated on the first access
-        after a forward -- once per epoch, not once per training step."""
-        if self._result_cat is None and self._result_parts is not None:
-            self._result_cat = torch.cat(self._result_parts, dim=0)
-        return self._result_cat
+        """[N, D] users then items (read by gene_ranklist, stale as in the reference): concatenated when it is READ -- once
+        per evaluation, not once per training step.  Never cached: under a captured step the two halves are the hipGraph's
+        static output buffers, rewritten by every replay without this Python code running again."""
+        if self._result_parts is not None:
+            return torch.cat(self._result_parts, dim=0)
+        return self._result_set
 
     @result.setter
     def result(self, value):
-        self._result_cat, self._result_parts = value, None
+        self._result_set, self._result_parts = value, None
 
     # ---- graph construction (host, once) -------------------------------------------------
     def get_norm_adj_mat(self, edge_index):
@@ -215,7 +216,7 @@ class FREEDOM(nn.Module):
                 h = ops.spmm(self.mm_adj, h)
             else:  # last item-item layer fused with `i_g_embeddings + h`
                 i_g_embeddings = ops.spmm_add(self.mm_adj, h, i_g_embeddings)
-        self._result_parts, self._result_cat = (u_g_embeddings.detach(), i_g_embeddings.detach()), None
+        self._result_parts = (u_g_embeddings.detach(), i_g_embeddings.detach())
         return u_g_embeddings, i_g_embeddings
 
     def bpr_loss(self, users, pos_items, neg_items):

@@ -332,13 +332,11 @@ class ShardedLightGCN(nn.Module):
 
     @property
     def result(self):
-        """[U_g + I, D] in the reference's row convention (users then items): concatenated on the first access
-        after a forward, then kept."""
+        """[U_g + I, D] in the reference's row convention (users then items): concatenated when it is read.  Not cached:
+        under a captured step the two halves are static buffers that every replay rewrites without any Python running."""
         if self.result_u is None:
             return None
-        if self._result_cat is None:
-            self._result_cat = torch.cat((self.result_u, self.result_i), 0)
-        return self._result_cat
+        return torch.cat((self.result_u, self.result_i), 0)
 
     def loss(self, users, pos_items, neg_items):
         pos_items = pos_items - self.num_user
@@ -517,6 +515,11 @@ class FusedShardedLightGCNStep:
     def _launch(self):
         K, model, opt, L, B, D = self.K, self.model, self.optimizer, self.L, self.B, self.D
         U, I, N = self.U, self.I, self.N
+        if model.user_embedding.weight.data_ptr() != self.flat.data_ptr() or \
+                model.item_embedding.weight.data_ptr() != self.flat[U:].data_ptr():
+            # (model.to(...) / weight.data = ... after this step was built: it would train a buffer nobody reads)
+            raise RuntimeError("FusedShardedLightGCNStep: the model's embedding tables were re-allocated after the step was "
+                               "built; build a new step")
         group = opt.param_groups[0]
         shard, csr, w = model.shard, self.csr, 1.0 / (L + 1)
         xs = [self.flat]

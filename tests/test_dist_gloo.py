@@ -154,7 +154,7 @@ def _worker4(rank, world, port, tmp, mode):
     neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + I, B))
     loss = m.loss(users, pos, neg)
     loss.backward()
-    assert m.result is m.result                       # concatenated once per forward, then kept
+    assert torch.equal(m.result[:shard.num_user_local], m.result_u) and torch.equal(m.result[shard.num_user_local:], m.result_i)
     # gather_ranklists: every rank contributes [U_g, K] rows, rank order = user order
     K = 7
     mine_rank = (torch.arange(shard.num_user_local).view(-1, 1) + shard.u0) * 100 + torch.arange(K).view(1, -1)

@@ -177,3 +177,35 @@ def test_captured_step_refuses_a_stale_graph_and_optimizer_step_survives_state_d
         if o is opt:
             w_a = m.user_embedding.weight.detach().clone()
     assert torch.allclose(m.user_embedding.weight, w_a, rtol=0, atol=1e-6)
+
+
+def test_freedom_result_is_fresh_under_a_captured_step(dev):
+    """FREEDOM.result is concatenated lazily from the forward's two halves; under GraphedTrainStep those halves are the
+    hipGraph's static buffers and no Python runs per replay -- the concatenation must therefore never be cached (a cached
+    one would make every evaluation after the first rank the tables of the first)."""
+    from conftest import load_golden
+    from chaorec_amd import graph
+    from chaorec_amd.Model import FREEDOM
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    g = load_golden("freedom_small_nodrop.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = FREEDOM(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+                torch.from_numpy(g["t_feat"]), int(g["D"]), int(g["D"]), float(g["reg"]), float(g["dropout"]),
+                int(g["L"]), int(g["mm_layers"]), int(g["knn"]), float(g["w"]), dev).to(dev)
+    m.pre_epoch_processing()
+    opt = FusedAdam(m.parameters(), lr=1e-2)
+    batch = tuple(torch.from_numpy(g[k]) for k in ("users", "pos", "neg"))
+    step = GraphedTrainStep(m, opt, example_batch=batch)
+    step(*batch)
+    r1 = m.result.clone()
+    for _ in range(5):
+        step(*batch)
+    r2 = m.result
+    assert not torch.equal(r1, r2)                      # five Adam steps at lr 1e-2 moved the tables
+    # what an eager forward at the weights BEFORE the last update gives is what the last replay left (stale-result quirk):
+    # check against a forward at the current weights up to one step's movement, and exactly against the parts
+    assert torch.equal(r2[:U], m._result_parts[0]) and torch.equal(r2[U:], m._result_parts[1])
+    with torch.no_grad():
+        fu, fi = m.forward(m.masked_adj)
+    assert float((torch.cat((fu, fi), 0) - r2).abs().max()) < 0.05
