@@ -118,29 +118,20 @@ class FREEDOM(nn.Module):
     # ---- graph construction (host, once) -------------------------------------------------
     def get_norm_adj_mat(self, edge_index):
         """Model/FREEDOM.py:73-83 (Q6: bincount over cat(row, col) of the bidirectional list)."""
-        row, col = edge_index.long()
-        deg = torch.bincount(torch.cat([row, col]))
-        deg_inv_sqrt = deg.pow(-0.5)
-        norm = deg_inv_sqrt[row] * deg_inv_sqrt[col]
-        # torch.sparse.mm(adj, x): out[row] += v * x[col]; entries coalesced (column-ascending per row)
-        return graph.coo_to_csr_coalesced(row, col, norm, self.n_nodes, self.n_nodes, symmetric=True)
+        dst, src = edge_index.long()
+        # (Q6: the degree is counted over BOTH endpoint columns of the already bidirectional list -- every node twice)
+        inv = torch.bincount(torch.cat([dst, src])).pow(-0.5)
+        # torch.sparse.mm(adj, x): out[dst] += v * x[src]; entries coalesced (column-ascending per row)
+        return graph.coo_to_csr_coalesced(dst, src, inv[dst] * inv[src], self.n_nodes, self.n_nodes, symmetric=True)
 
     def _normalize_adj_m(self, indices, adj_size):
-        """Model/FREEDOM.py:85-99: 1e-7 + degree, ^-1/2, product per edge (fp32)."""
-        ones = torch.ones_like(indices[0])
-        row_sum = 1e-7 + torch.zeros(adj_size[0], dtype=ones.dtype, device=indices.device).scatter_add_(0, indices[0], ones)
-        col_sum = 1e-7 + torch.zeros(adj_size[1], dtype=ones.dtype, device=indices.device).scatter_add_(0, indices[1], ones)
-        r_inv_sqrt = torch.pow(row_sum, -0.5)
-        c_inv_sqrt = torch.pow(col_sum, -0.5)
-        return r_inv_sqrt[indices[0]] * c_inv_sqrt[indices[1]]
+        """Model/FREEDOM.py:85-99 (kept for callers of the reference's name): graph.inv_sqrt_degree_edge_weights."""
+        return graph.inv_sqrt_degree_edge_weights(indices[0], indices[1], adj_size[0], adj_size[1])
 
     def get_edge_info(self, edge_index):
-        """Model/FREEDOM.py:101-108."""
-        rows, cols = edge_index
-        cols = cols - self.num_user
-        edges = torch.stack([rows, cols]).type(torch.LongTensor)
-        values = self._normalize_adj_m(edges, torch.Size((self.num_user, self.num_item)))
-        return edges, values
+        """Model/FREEDOM.py:101-108 -> (interactions [2, E] with LOCAL item ids, their normalised weights [E])."""
+        pairs = torch.stack((edge_index[0], edge_index[1] - self.num_user)).long().cpu()
+        return pairs, graph.inv_sqrt_degree_edge_weights(pairs[0], pairs[1], self.num_user, self.num_item)
 
     def get_knn_adj_mat(self, mm_embeddings):
         """Model/FREEDOM.py:111-126: cosine kNN (self included) -> D^-1/2 A D^-1/2 with row-sum degrees.
@@ -159,34 +150,27 @@ class FREEDOM(nn.Module):
 
     def compute_normalized_laplacian(self, indices, adj_size):
         """Model/FREEDOM.py:128-138 -> (indices [2, nnz], values [nnz]) on the host."""
-        ones = torch.ones_like(indices[0])
-        row_sum = 1e-7 + torch.zeros(adj_size[0], dtype=ones.dtype).scatter_add_(0, indices[0], ones)
-        r_inv_sqrt = torch.pow(row_sum, -0.5)
-        values = r_inv_sqrt[indices[0]] * r_inv_sqrt[indices[1]]
-        return indices, values
+        return indices, graph.out_degree_normalised_weights(indices[0], indices[1], adj_size[0])
 
     # ---- per-epoch pruning ----------------------------------------------------------------
     def pre_epoch_processing(self):
-        """Model/FREEDOM.py:143-162: degree-sensitive edge pruning, re-normalised and symmetrised."""
+        """Model/FREEDOM.py:143-162: every epoch trains on a degree-sensitive sample of (1 - dropout) E interactions,
+        re-normalised on the sample and symmetrised."""
         if self.dropout <= .0:
             self.masked_adj = self.norm_adj
             return
-        degree_len = int(self.edge_values.size(0) * (1. - self.dropout))
-        # torch.multinomial(edge_values, degree_len) (:151) as a keep mask from the device sampler: the same law
-        # (weighted, without replacement), any edge count (multinomial stops at 2^24 categories), and a function of
-        # (torch seed, epoch) only.  The reference uses the drawn set, never its order (the graph is coalesced).
-        keep = ops.weighted_sample_keep(self.edge_values, degree_len, self._prune_seed, step=self._prune_calls)
+        n_keep = int(self.edge_values.size(0) * (1. - self.dropout))
+        # torch.multinomial(edge_values, n_keep) (:151) as a keep mask from the device sampler: the same law (weighted,
+        # without replacement), any edge count (multinomial stops at 2^24 categories), and a function of (torch seed,
+        # epoch) only.  The reference uses the drawn set, never its order (the graph is coalesced).
+        mask = ops.weighted_sample_keep(self.edge_values, n_keep, self._prune_seed, step=self._prune_calls)
         self._prune_calls += 1
-        self._set_masked_adj(self.edge_indices[:, keep.bool()])
+        self._set_masked_adj(self.edge_indices[:, mask.bool()])
 
-    def _set_masked_adj(self, keep_indices):
-        keep_values = self._normalize_adj_m(keep_indices, torch.Size((self.num_user, self.num_item)))
-        all_values = torch.cat((keep_values, keep_values))
-        keep_indices = keep_indices.clone()
-        keep_indices[1] += self.num_user
-        all_indices = torch.cat((keep_indices, torch.flip(keep_indices, [0])), 1)
-        new = graph.coo_to_csr_coalesced(all_indices[0], all_indices[1], all_values, self.n_nodes, self.n_nodes,
-                                         symmetric=True).to(self.device)
+    def _set_masked_adj(self, kept):
+        """The pruned propagation graph of the interactions `kept` [2, E'] (users, LOCAL item ids)."""
+        w = graph.inv_sqrt_degree_edge_weights(kept[0], kept[1], self.num_user, self.num_item)
+        new = graph.symmetric_bipartite_csr(kept[0], kept[1], w, self.num_user, self.num_item).to(self.device)
         # every epoch keeps the same number of edges: rewrite the pruned graph in place, so that a captured training
         # step (which holds the addresses of these arrays) trains on the new graph at its next replay
         cur = self.masked_adj

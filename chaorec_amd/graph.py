@@ -243,6 +243,33 @@ def add_scaled_coo(a, wa, b, wb, n):
     return coo_to_csr_coalesced(idx[0], idx[1], val, n, n, symmetric=False)
 
 
+def inv_sqrt_degree_edge_weights(src, dst, n_src, n_dst, eps=1e-7):
+    """Weight of every edge (src_e, dst_e) of a bipartite list: (deg(src_e) + eps)^-1/2 * (deg(dst_e) + eps)^-1/2, degrees
+    counted on THIS list (FREEDOM normalises its full interaction list once and every epoch's pruned list again:
+    Model/FREEDOM.py:85-99).  Integer counts, then + eps (which makes them fp32), then the power, then one product per
+    edge -- the order in which the reference's sparse row / column sums round, so the values are bit-identical."""
+    inv_s = (torch.bincount(src, minlength=n_src) + eps).pow(-0.5)
+    inv_d = (torch.bincount(dst, minlength=n_dst) + eps).pow(-0.5)
+    return inv_s[src] * inv_d[dst]
+
+
+def out_degree_normalised_weights(rows, cols, n, eps=1e-7):
+    """Weight of every entry (r, c) of an n x n adjacency normalised by its ROW sums on both sides:
+    (rowsum(r) + eps)^-1/2 * (rowsum(c) + eps)^-1/2 (the kNN item graph, Model/FREEDOM.py:128-138: every row has exactly
+    k entries, so this is 1/k up to eps)."""
+    inv = (torch.bincount(rows, minlength=n) + eps).pow(-0.5)
+    return inv[rows] * inv[cols]
+
+
+def symmetric_bipartite_csr(users, items, weights, num_user, num_item):
+    """CSR of [[0, W], [W^T, 0]] over users then items for the weighted interactions (users_e, items_e, weights_e):
+    entries coalesced per row in ascending column order (what torch.sparse.mm works on).  On the inputs' device."""
+    n = num_user + num_item
+    shifted = items + num_user
+    return coo_to_csr_coalesced(torch.cat((users, shifted)), torch.cat((shifted, users)), torch.cat((weights, weights)),
+                                n, n, symmetric=True)
+
+
 class DropoutStructure(CSR):
     """The CSR of D^-1/2 (A + I) D^-1/2 plus what the per-step edge dropout needs (ops.edge_dropout_norm): the
     destination of every entry, the entry of the reversed edge, and a degree workspace.  `val` holds the
