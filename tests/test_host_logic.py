@@ -359,3 +359,53 @@ def test_rank_state_backs_off_from_stale_thresholds():
     assert call(3) == (True, True)                # short queue last time: no retry pass
     assert call(400)[0] is True                   # 40 % queued: stale again
     assert call(0)[0] is False
+
+
+def test_torch_generator_and_tensor_graph_builders_on_cpu():
+    """Round 3 (config 5 whole): the torch edge generator's contract and the tensor forms of the graph builders, run here
+    on CPU tensors (on the GPU box the same functions take CUDA tensors: tests/test_gpu_round3.py)."""
+    import numpy as np
+    import torch
+    from chaorec_amd import graph
+    from chaorec_amd.synthetic import synthetic_interactions, synthetic_interactions_torch
+    U, I, E = 20000, 5000, 300000
+    e = synthetic_interactions_torch(U, I, E, seed=3, chunk_users=7000)
+    assert e.dtype == torch.int32 and abs(len(e) - E) <= 0.003 * E
+    u, i = e[:, 0].long(), e[:, 1].long() - U
+    assert bool((u[1:] >= u[:-1]).all()) and int(i.min()) >= 0 and int(i.max()) < I
+    assert (u * I + i).unique().numel() == len(e)                 # unique interactions
+    deg = torch.bincount(u, minlength=U)
+    assert int(deg.min()) >= 3 and int(deg.max()) <= 256
+    assert torch.equal(e, synthetic_interactions_torch(U, I, E, seed=3, chunk_users=7000))   # deterministic per seed / device
+    # tensor-input builders == numpy-input builders, bit for bit
+    en = synthetic_interactions(3000, 900, 20000, seed=3)
+    a, b = graph.lightgcn_csr(en, 3900), graph._lightgcn_csr_device(torch.from_numpy(en), 3900)
+    for k in ("rowptr", "col", "val"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    h0, h1 = graph.user_hist_csr_from_edges(en, 3000), graph.user_hist_csr_from_edges(torch.from_numpy(en), 3000)
+    assert torch.equal(h0[0], h1[0]) and torch.equal(h0[1], h1[1])
+
+
+def test_freedom_edge_weights_follow_the_reference_formulas():
+    """graph.inv_sqrt_degree_edge_weights / out_degree_normalised_weights / symmetric_bipartite_csr against the sparse-tensor
+    expressions of Model/FREEDOM.py:85-99, 128-138, 154-162 (restated with torch.sparse here), bit for bit."""
+    import torch
+    from chaorec_amd import graph
+    g = torch.Generator().manual_seed(0)
+    nu, ni, E = 40, 23, 300
+    idx = torch.stack((torch.randint(0, nu, (E,), generator=g), torch.randint(0, ni, (E,), generator=g)))
+    adj = torch.sparse_coo_tensor(idx, torch.ones_like(idx[0]), (nu, ni))
+    r = torch.pow(1e-7 + torch.sparse.sum(adj, -1).to_dense(), -0.5)
+    c = torch.pow(1e-7 + torch.sparse.sum(adj.t(), -1).to_dense(), -0.5)
+    want = r[idx[0]] * c[idx[1]]
+    got = graph.inv_sqrt_degree_edge_weights(idx[0], idx[1], nu, ni)
+    assert torch.equal(got, want)
+    kn = torch.stack((torch.arange(ni).repeat_interleave(4), torch.randint(0, ni, (4 * ni,), generator=g)))
+    a2 = torch.sparse_coo_tensor(kn, torch.ones_like(kn[0]), (ni, ni))
+    rs = torch.pow(1e-7 + torch.sparse.sum(a2, -1).to_dense(), -0.5)
+    assert torch.equal(graph.out_degree_normalised_weights(kn[0], kn[1], ni), rs[kn[0]] * rs[kn[1]])
+    csr = graph.symmetric_bipartite_csr(idx[0], idx[1], got, nu, ni)
+    full = torch.sparse_coo_tensor(torch.cat((torch.stack((idx[0], idx[1] + nu)), torch.stack((idx[1] + nu, idx[0]))), 1),
+                                   torch.cat((got, got)), (nu + ni, nu + ni)).coalesce()
+    rows = torch.repeat_interleave(torch.arange(nu + ni), csr.rowptr[1:] - csr.rowptr[:-1])
+    assert torch.equal(torch.stack((rows, csr.col.long())), full.indices()) and torch.allclose(csr.val, full.values(), rtol=1e-6, atol=0)
