@@ -654,13 +654,79 @@ class _ShardedPropagate(torch.autograd.Function):
         return gxu, gxi, None, None, None
 
 
+def joined_loop_csr(shard):
+    """joined_shard_csr(shard) plus the self-loop weight of every LOCAL USER row on its diagonal (BasicGCN's
+    D^-1/2 (A + I) D^-1/2, BasicGCN.py:37-46; the loop entry last in its row, as the reference appends it).  The item
+    rows' loop term is NOT in the matrix: every rank would add it to its partial -- it is added once, after the exchange."""
+    if getattr(shard, "_joined_loop", None) is None:
+        base = joined_shard_csr(shard)
+        U, N = shard.num_user_local, shard.num_user_local + shard.num_item
+        dev = base.col.device
+        counts = base.rowptr[1:] - base.rowptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(N, device=dev), counts)
+        loop_rows = torch.arange(U, device=dev)
+        # stable sort by row of (entries..., loops): a row's loop lands behind its entries
+        all_rows = torch.cat((rows, loop_rows))
+        order = torch.argsort(all_rows, stable=True)
+        col = torch.cat((base.col, loop_rows.to(torch.int32)))[order].contiguous()
+        val = torch.cat((base.val, shard.diag_u.view(-1).to(base.val.dtype)))[order].contiguous()
+        rowptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(all_rows, minlength=N), 0, out=rowptr[1:])
+        # symmetric up to the missing item-row loops: A^T = A on what is stored
+        shard._joined_loop = graph.CSR(rowptr, col, val, N, N, symmetric=True)
+    return shard._joined_loop
+
+
+class _ShardedPropagateJoined(torch.autograd.Function):
+    """_ShardedPropagate on the rank's JOINED table [local users; items] -- one SpMM launch per direction instead of two
+    block launches, two diagonal updates and a concatenation:
+        forward   y = A_g x  (user rows complete incl. their loop term; item rows = this rank's partial) -> exchange of
+                  the item rows in place -> + d_i x_i once
+        backward  S = [G_u; sum over ranks of G_i]  ->  g = A_g S  (user rows: B_g G_i_total + d_u G_u; item rows: B_g^T G_u,
+                  PARTIAL as the convention demands) -> item rows += d_i G_i(partial)"""
+
+    @staticmethod
+    def forward(ctx, x, shard, spmm_fn, group):
+        x = x.contiguous()
+        U, N, D = shard.num_user_local, x.shape[0], x.shape[1]
+        csr = joined_loop_csr(shard)
+        buf = torch.empty((U + padded_rows(N - U, group), D), dtype=x.dtype, device=x.device)
+        if buf.shape[0] > N:
+            buf[N:].zero_()
+        spmm_fn(csr, x, y=buf[:N])
+        _sum_exchange_async(buf[U:], group).wait()
+        y = buf[:N]
+        y[U:].addcmul_(x[U:], shard.diag_i)
+        ctx.shard, ctx.spmm_fn, ctx.group = shard, spmm_fn, group
+        return y
+
+    @staticmethod
+    def backward(ctx, G):
+        shard, spmm_fn, group = ctx.shard, ctx.spmm_fn, ctx.group
+        G = G.contiguous()
+        U, N, D = shard.num_user_local, G.shape[0], G.shape[1]
+        S = torch.empty((U + padded_rows(N - U, group), D), dtype=G.dtype, device=G.device)
+        if S.shape[0] > N:
+            S[N:].zero_()
+        S[:N].copy_(G)
+        _sum_exchange_async(S[U:], group).wait()
+        g = spmm_fn(joined_loop_csr(shard), S[:N])
+        g[U:].addcmul_(G[U:], shard.diag_i)
+        return g, None, None, None
+
+
 class ShardedGraph:
-    """The graph operator BasicGCN.forward accepts in place of an edge_index: x = [local users; all items] rows."""
+    """The graph operator BasicGCN.forward accepts in place of an edge_index: x = [local users; all items] rows.
+    CHAOREC_DIST_PROPAGATE=blocks restores the two-block form (_ShardedPropagate: the item exchange travels under the
+    user-row SpMM there; one launch more per direction, a concatenation and two diagonal updates)."""
 
     def __init__(self, shard, spmm_fn=None, group=None):
         self.shard, self.spmm_fn, self.group = shard, spmm_fn, group
+        self.joined = shard.diag_u is not None and _os.environ.get("CHAOREC_DIST_PROPAGATE", "joined") == "joined"
 
     def propagate(self, x):
+        if self.joined:
+            return _ShardedPropagateJoined.apply(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group)
         n = self.shard.num_user_local
         yu, yi = _ShardedPropagate.apply(x[:n], x[n:], self.shard, self.spmm_fn or ops.spmm_raw, self.group)
         return torch.cat((yu, yi), 0)
@@ -877,7 +943,7 @@ class ShardedFREEDOM(nn.Module):
         # THAT in sync_grads(): 2 x I x 64 floats per step over xGMI instead of I x (4096 + 384)
         self.image_embedding.weight._chaorec_projected_only = True
         self.text_embedding.weight._chaorec_projected_only = True
-        self._batch_idx = None
+        self._batch_idx = self._loss_w = None
         self._keys_fn = keys_fn or ops.weighted_sample_keys
         self._prune_seed = int(prune_seed if prune_seed is not None else getattr(full, "_prune_seed", 0))
         self._prune_calls = 0
@@ -919,8 +985,19 @@ class ShardedFREEDOM(nn.Module):
         for _ in range(self.mm_layers):
             h = self._mm_spmm(self.mm_adj, h)
         ig = fi + h
-        self.result = torch.cat((fu, ig), 0)
+        self._result_parts = (fu.detach(), ig.detach())
         return fu, ig
+
+    @property
+    def result(self):
+        """[U_g + I, D]: concatenated when read (never cached: under a captured step the halves are static buffers)."""
+        if self._result_parts is not None:
+            return torch.cat(self._result_parts, 0)
+        return None
+
+    @result.setter
+    def result(self, value):
+        self._result_parts = None if value is None else (value[:self.num_user], value[self.num_user:])
 
     def loss(self, users, pos_items, neg_items):
         """Model/FREEDOM.py:194-217 on this rank's triples (local user ids, item ids in [0, I)); the global loss is the
@@ -928,7 +1005,6 @@ class ShardedFREEDOM(nn.Module):
         users, pos, neg = users.to(self.device), pos_items.to(self.device), neg_items.to(self.device)
         ua, ia = self.forward()
         V = ops.VARIANT_LOGSIGMOID
-        total = self._bpr(ua, ia, users, pos, neg, V, 0.0)[0]
         B = users.shape[0]
         rows = torch.cat((pos, neg), 0)
         if self._batch_idx is None or self._batch_idx[0].shape[0] != B or self._batch_idx[0].device != users.device:
@@ -937,8 +1013,15 @@ class ShardedFREEDOM(nn.Module):
         idx, idx_neg = self._batch_idx
         tf = self._linear_rows(self.text_embedding.weight, rows, self.text_trs.weight, self.text_trs.bias)
         vf = self._linear_rows(self.image_embedding.weight, rows, self.image_trs.weight, self.image_trs.bias)
-        total = total + self.reg_weight * (self._bpr(ua, tf, users, idx, idx_neg, V, 0.0)[0] +
-                                           self._bpr(ua, vf, users, idx, idx_neg, V, 0.0)[0])
+        if self._bpr is ops.bpr_loss and ua.is_cuda:
+            # the three terms share the user table and the batch's users: ONE autograd node, as in Model/FREEDOM.py here
+            if self._loss_w is None or self._loss_w.device != users.device:
+                self._loss_w = torch.tensor([1.0, self.reg_weight, self.reg_weight], dtype=torch.float32, device=users.device)
+            total = ops.bpr_loss_multi(ua, users, V, [(ia, pos, neg), (tf, idx, idx_neg), (vf, idx, idx_neg)], self._loss_w)
+        else:
+            total = self._bpr(ua, ia, users, pos, neg, V, 0.0)[0]
+            total = total + self.reg_weight * (self._bpr(ua, tf, users, idx, idx_neg, V, 0.0)[0] +
+                                               self._bpr(ua, vf, users, idx, idx_neg, V, 0.0)[0])
         return total / self.world
 
     def _claimed_tables(self):
