@@ -81,12 +81,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("L", [1, 3])
-def test_fused_sharded_step_world2_on_the_kernels(oracle, L):
+@pytest.mark.parametrize("L,world", [(1, 2), (3, 2), (2, 4)])
+def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
-    world = 2
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(world, _free_port(), tmp, L), nprocs=world, join=True)
         r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
@@ -118,7 +117,7 @@ def test_fused_sharded_step_world2_on_the_kernels(oracle, L):
     assert np.allclose(xu, x[:U], rtol=0, atol=3e-5)
     for k in range(world):
         assert np.allclose(r[k]["xi"], x[U:], rtol=0, atol=3e-5)
-    assert np.array_equal(r[0]["xi"], r[1]["xi"])                      # identical item update on every rank
+        assert np.array_equal(r[0]["xi"], r[k]["xi"])                  # identical item update on every rank
 
 
 # ---------------------------------------------------------------------------------------------------- MMGCN (configs[3])
