@@ -624,10 +624,10 @@ def test_vbpr_golden(dev):
         out[claim] = {k: v.detach().clone() for k, v in m.named_parameters()}
     # (item_linear.bias: its gradient is analytically zero -- +c and -c per sample -- so what arrives is the rounding of
     #  the backward's float atomics, and Adam turns a gradient of pure noise into steps of +-lr: two RUNS of the same code
-    #  differ there by up to 3 lr after three steps.  The bias shifts every item's visual part alike; it cancels in
+    #  differ there by up to 2 x 3 lr after three steps (each run walks its own way).  The bias shifts every item's visual part alike; it cancels in
     #  pos - neg and reaches the other parameters only through the 1e-3-weighted regulariser.)
     def same(a, b, k):
-        return torch.allclose(a[k], b[k], rtol=0, atol=3.2e-3 if k == "item_linear.bias" else 2e-6)
+        return torch.allclose(a[k], b[k], rtol=0, atol=7e-3 if k == "item_linear.bias" else 2e-6)   # (2 x 3 steps x lr + margin)
     for k in out[True]:
         assert same(out[True], out[False], k), k
     # lazy rows must not apply to a table whose forward reads EVERY row (ops.linear): rows outside the batch would be
@@ -644,7 +644,7 @@ def test_vbpr_golden(dev):
         assert "last" not in opt.state[m.v_feat.weight]
     for k in lazy_out[True][0]:       # (atomics order in the BPR backward: last-bit noise between any two runs)
         assert torch.allclose(lazy_out[True][0][k], lazy_out[False][0][k], rtol=0,
-                              atol=4.2e-3 if k == "item_linear.bias" else 2e-6), k
+                              atol=9e-3 if k == "item_linear.bias" else 2e-6), k      # (2 x 4 steps x lr + margin)
     ra, rb = lazy_out[True][1], lazy_out[False][1]
     E = ra.shape[1] - 64                  # (the visual part of the item rows carries the bias: compare it up to that shift)
     assert torch.allclose(ra[:, :E], rb[:, :E], rtol=0, atol=2e-6) and torch.allclose(ra[:U], rb[:U], rtol=0, atol=2e-6)
