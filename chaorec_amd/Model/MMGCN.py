@@ -57,8 +57,16 @@ class GCN(torch.nn.Module):
             setattr(self, f"linear_layer{k}", lin)
             setattr(self, f"g_layer{k}", g)
 
+    def _fused(self, x):
+        """The layer as ONE autograd node (ops.mmgcn_layer): the concat branch over a CSR in HBM, row widths the float4
+        kernels take.  Sharded graphs (an operator with .propagate) and the other branches keep the composition."""
+        return (ops.MMGCN_LAYER == "fused" and self.concate and isinstance(self.edge_index, graph.CSR) and x.is_cuda
+                and x.shape[1] % 4 == 0 and self.dim_id % 4 == 0)
+
     def _layer(self, k, x, id_embedding):
         conv, lin, g = (getattr(self, f"conv_embed_{k}"), getattr(self, f"linear_layer{k}"), getattr(self, f"g_layer{k}"))
+        if self._fused(x):
+            return ops.mmgcn_layer(x, id_embedding if self.has_id else None, conv.lin, lin, g, self.edge_index)
         h = F.leaky_relu(conv(x, self.edge_index))                                   # equation 1
         u_hat = ops.linear(x, lin.weight, lin.bias, act=1)                           # equation 5
         if self.has_id:
@@ -96,6 +104,9 @@ class GCN(torch.nn.Module):
         cached [A x | A 1] with [W | b] -- no 768-wide SpMM forward, none backward (the weight gradient is a product with
         the same cached operand).  Same arithmetic up to the association of the sums."""
         conv, lin, g = self.conv_embed_1, self.linear_layer1, self.g_layer1
+        if self._fused(x) and isinstance(self.edge_index, graph.CSR):
+            return ops.mmgcn_layer(x, id_embedding if self.has_id else None, conv.lin, lin, g, self.edge_index,
+                                   ax_aug=ax_aug, pad=pad)
         w_aug = torch.cat((conv.lin.weight, conv.lin.bias[:, None], conv.lin.weight.new_zeros(conv.lin.weight.shape[0], pad)), 1)
         h = ops.linear(ax_aug, w_aug, None, act=1)                                   # equation 1 (+ leaky_relu)
         u_hat = ops.linear(x, lin.weight, lin.bias, act=1)                           # equation 5
@@ -113,8 +124,11 @@ class GCN(torch.nn.Module):
             first = 2
         else:
             temp_features = ops.linear(features, self.MLP.weight, self.MLP.bias) if self.dim_latent else features
-            x = torch.cat((self.preference, temp_features), dim=0)
-            x = F.normalize(x)
+            if temp_features.is_cuda and temp_features.shape[1] % 4 == 0 and ops.MMGCN_LAYER == "fused":
+                x = ops.normalize_rows(self.preference, temp_features)             # cat + F.normalize, one launch
+            else:
+                x = torch.cat((self.preference, temp_features), dim=0)
+                x = F.normalize(x)
             first = 1
         for k in range(first, 5):
             x = self._layer(k, x, id_embedding)

@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -126,6 +126,18 @@ SIGNATURES = {
     "chaorec_gemm_tn_bf16x3": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_ptr, ctypes.c_size_t,
                                               c_ptr]),
+    "chaorec_gemm_nn_bf16x3_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    "chaorec_gemm_nn_bf16x3": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, c_ptr,
+                                              ctypes.c_size_t, c_ptr]),
+    "chaorec_leaky_cat_add_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
+                                                 ctypes.c_int32, ctypes.c_float, c_ptr]),
+    "chaorec_leaky_split_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64,
+                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_ptr]),
+    "chaorec_normalize_rows_fwd_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                                      ctypes.c_float, c_ptr, c_ptr, c_ptr]),
+    "chaorec_normalize_rows_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
+                                                      ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr]),
     "chaorec_adam_multi_max": (ctypes.c_int32, []),
     "chaorec_adam_multi_f32": (ctypes.c_int, [ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,

@@ -68,17 +68,20 @@ extern __global__ void gemm_reduce_slabs_kernel(const float *__restrict__ slabs,
                                                 const float *__restrict__ bias, int64_t M, int64_t N, int64_t ldc,
                                                 int accumulate, int act);
 
-// TN = false: A [M, K], B [N, K] (k contiguous in both: the forward and, through W^T, the input gradient of a Linear).
-// TN = true:  A [K, M], B [K, N] (the reduction runs over the ROWS of both operands: the weight gradient
+// NT (TA = TB = false): A [M, K], B [N, K] (k contiguous in both: the forward and, through W^T, the input gradient of a Linear).
+// TN (TA = TB = true): A [K, M], B [K, N] (the reduction runs over the ROWS of both operands: the weight gradient
 //             dW = gy^T x, Model/MMGCN.py's Linears over all graph nodes).  A thread then fetches a 4 (m) x 4 (k)
 //             block of A -- four float4 along m, one per k -- and a 4 (n) x 2 (k) block of B, transposes them in
 //             registers (a choice of components, no instructions) and writes the same k-major bf16 planes to LDS.
-template <bool TN, int XBN>
+// TA / TB: the operand is k-MAJOR in memory (A [K, M] / B [K, N]).  (false, false) = NT, (true, true) = TN, (false, true)
+// = NN: C = A[M,K] . B[K,N] -- a Linear's input gradient gy . W with W as it lies in memory (W^T as a small copy in
+// front of every such product was ~20 launches of 4.6 us per MMGCN step).
+template <bool TA, bool TB, int XBN>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                              float *__restrict__ C, const float *__restrict__ bias,
                                                              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                                              int64_t ldc, int act, int64_t k_per_split,
-                                                             float *__restrict__ slabs) {
+                                                             float *__restrict__ slabs, int accumulate) {
   __shared__ uint16_t As[3][XBM][XBK + XPAD];
   __shared__ uint16_t Bs[3][XBN][XBK + XPAD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -132,29 +135,32 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
   const int a_mq = t & 31, a_kq = t >> 5;         // TN: A block = rows 4 a_mq .. +3, k 4 a_kq .. +3
   const int b_nq = t & 15, b_kp = t >> 4;         // TN: B block = rows 4 b_nq .. +3, k 2 b_kp, 2 b_kp + 1
   auto fetch = [&](int64_t k0) __attribute__((always_inline)) {
-    if constexpr (TN) {
+    if constexpr (TA) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) ra[j] = load4t(A, lda, k0 + 4 * a_kq + j, m0 + 4 * a_mq, M, a_vec);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int v = t + p * 256;                  // float4 index: row = v / 8, k4 = (v % 8) * 4
+        ra[p] = load4(A, lda, m0 + (v >> 3), M, k0 + ((v & 7) << 2), a_vec);
+      }
+    }
+    if constexpr (TB) {
 #pragma unroll
       for (int bb = 0; bb < NB / 2; ++bb)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           rb[2 * bb + j] = load4t(B, ldb, k0 + 2 * b_kp + j, n0 + 4 * (b_nq + 16 * bb), N, b_vec);
-      return;
-    }
+    } else {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int v = t + p * 256;                  // float4 index: row = v / 8, k4 = (v % 8) * 4
-      ra[p] = load4(A, lda, m0 + (v >> 3), M, k0 + ((v & 7) << 2), a_vec);
-    }
-#pragma unroll
-    for (int p = 0; p < NB; ++p) {
-      const int v = t + p * 256;
-      rb[p] = load4(B, ldb, n0 + (v >> 3), N, k0 + ((v & 7) << 2), b_vec);
+      for (int p = 0; p < NB; ++p) {
+        const int v = t + p * 256;
+        rb[p] = load4(B, ldb, n0 + (v >> 3), N, k0 + ((v & 7) << 2), b_vec);
+      }
     }
   };
   auto stash = [&]() __attribute__((always_inline)) {
-    if constexpr (TN) {
+    if constexpr (TA) {
       const float ax[4][4] = {{ra[0].x, ra[1].x, ra[2].x, ra[3].x}, {ra[0].y, ra[1].y, ra[2].y, ra[3].y},
                               {ra[0].z, ra[1].z, ra[2].z, ra[3].z}, {ra[0].w, ra[1].w, ra[2].w, ra[3].w}};
 #pragma unroll
@@ -167,6 +173,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
         *reinterpret_cast<uint2 *>(&As[1][32 * i + a_mq][4 * a_kq]) = mm;
         *reinterpret_cast<uint2 *>(&As[2][32 * i + a_mq][4 * a_kq]) = ll;
       }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int v = t + p * 256;
+        uint2 hh, mm, ll;
+        split3x4(ra[p], hh, mm, ll);
+        const int row = v >> 3, k4 = (v & 7) << 2;
+        *reinterpret_cast<uint2 *>(&As[0][row][k4]) = hh;
+        *reinterpret_cast<uint2 *>(&As[1][row][k4]) = mm;
+        *reinterpret_cast<uint2 *>(&As[2][row][k4]) = ll;
+      }
+    }
+    if constexpr (TB) {
 #pragma unroll
       for (int bb = 0; bb < NB / 2; ++bb) {
         const float4 r0 = rb[2 * bb], r1 = rb[2 * bb + 1];
@@ -182,27 +201,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
           *reinterpret_cast<uint32_t *>(&Bs[2][64 * bb + 16 * i + b_nq][2 * b_kp]) = l0 | (l1 << 16);
         }
       }
-      return;
-    }
+    } else {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int v = t + p * 256;
-      uint2 hh, mm, ll;
-      split3x4(ra[p], hh, mm, ll);
-      const int row = v >> 3, k4 = (v & 7) << 2;
-      *reinterpret_cast<uint2 *>(&As[0][row][k4]) = hh;
-      *reinterpret_cast<uint2 *>(&As[1][row][k4]) = mm;
-      *reinterpret_cast<uint2 *>(&As[2][row][k4]) = ll;
-    }
-#pragma unroll
-    for (int p = 0; p < NB; ++p) {
-      const int v = t + p * 256;
-      uint2 hh, mm, ll;
-      split3x4(rb[p], hh, mm, ll);
-      const int row = v >> 3, k4 = (v & 7) << 2;
-      *reinterpret_cast<uint2 *>(&Bs[0][row][k4]) = hh;
-      *reinterpret_cast<uint2 *>(&Bs[1][row][k4]) = mm;
-      *reinterpret_cast<uint2 *>(&Bs[2][row][k4]) = ll;
+      for (int p = 0; p < NB; ++p) {
+        const int v = t + p * 256;
+        uint2 hh, mm, ll;
+        split3x4(rb[p], hh, mm, ll);
+        const int row = v >> 3, k4 = (v & 7) << 2;
+        *reinterpret_cast<uint2 *>(&Bs[0][row][k4]) = hh;
+        *reinterpret_cast<uint2 *>(&Bs[1][row][k4]) = mm;
+        *reinterpret_cast<uint2 *>(&Bs[2][row][k4]) = ll;
+      }
     }
   };
 
@@ -218,12 +227,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
         // LDS row of tile row (32 wave + r) resp. (32 j + r): the identity, or the TN stash's permutation
-        const int arow = TN ? (r & 3) * 32 + wave * 8 + (r >> 2) : wave * 32 + r;
+        const int arow = TA ? (r & 3) * 32 + wave * 8 + (r >> 2) : wave * 32 + r;
         a[pl].u = *reinterpret_cast<const uint4 *>(&As[pl][arow][ks + 8 * h]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           // (TN: tile row 32 j + r lies in the 64-row half j / 2, at 64 (j / 2) + 16 (r & 3) + 8 (j & 1) + (r >> 2))
-          const int brow = TN ? 64 * (j >> 1) + (r & 3) * 16 + (j & 1) * 8 + (r >> 2) : j * 32 + r;
+          const int brow = TB ? 64 * (j >> 1) + (r & 3) * 16 + (j & 1) * 8 + (r >> 2) : j * 32 + r;
           b[j][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][brow][ks + 8 * h]);
         }
       }
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
       float v = acc[j][q];
       if (!to_slab) {
         v = v + bv;
+        if (accumulate) v = dst[m * ldd + n] + v;
         if (act == 1) v = v > 0.f ? v : v * 0.01f;
         if (act == 2) v = v > 0.f ? v : v * 0.2f;
       }
@@ -336,11 +346,11 @@ extern "C" int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, 
   const int XBN = pick_bn(N);
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
   if (XBN == 128)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, 128>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K,
-                       lda, ldb, ldc, 0, p.k_per_split, slabs);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 128>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K,
+                       lda, ldb, ldc, 0, p.k_per_split, slabs, 0);
   else
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, 64>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K, lda,
-                       ldb, ldc, 0, p.k_per_split, slabs);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 64>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K, lda,
+                       ldb, ldc, 0, p.k_per_split, slabs, 0);
   int rc = check_launch("gemm_bf16x3_kernel<TN>");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
@@ -370,14 +380,46 @@ extern "C" int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, 
   const int XBN = pick_bn(N);
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
   if (XBN == 128)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, 128>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
-                       p.k_per_split, slabs);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 128>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
+                       p.k_per_split, slabs, 0);
   else
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, 64>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
-                       p.k_per_split, slabs);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 64>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
+                       p.k_per_split, slabs, 0);
   int rc = check_launch("gemm_bf16x3_kernel<NT>");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
                      bias, M, N, ldc, 0, act);
+  return check_launch("gemm_reduce_slabs_kernel");
+}
+
+extern "C" size_t chaorec_gemm_nn_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  return chaorec_gemm_nt_bf16x3_workspace_bytes(M, N, K);
+}
+
+// C[M,N] = A[M,K] . B[K,N]  (B k-major: a Linear's weight [out = K, in = N] as it lies in memory)
+extern "C" int chaorec_gemm_nn_bf16x3(const float *A, const float *B, float *C, int64_t M, int64_t N, int64_t K,
+                                      int64_t lda, int64_t ldb, int64_t ldc, int32_t accumulate, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+  if (!A || !B || !C) return fail(CHAOREC_E_INVALID, "gemm_nn_bf16x3: NULL argument");
+  if (M < 0 || N < 0 || K <= 0 || lda < K || ldb < N || ldc < N) return fail(CHAOREC_E_INVALID, "gemm_nn_bf16x3: bad size");
+  if (M == 0 || N == 0) return CHAOREC_OK;
+  const XPlan p = plan_x(M, N, K);
+  const size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace))
+    return fail(CHAOREC_E_WORKSPACE, "gemm_nn_bf16x3: workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
+  const int XBN = pick_bn(N);
+  const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
+  if (XBN == 128)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 128>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N,
+                       K, lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0);
+  else
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 64>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K,
+                       lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0);
+  int rc = check_launch("gemm_bf16x3_kernel<NN>");
+  if (rc || p.splits == 1) return rc;
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
+                     (const float *)nullptr, M, N, ldc, accumulate ? 1 : 0, 0);
   return check_launch("gemm_reduce_slabs_kernel");
 }

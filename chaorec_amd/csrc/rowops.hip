@@ -276,6 +276,111 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float4 *__restrict
                        a.w > 0.f ? b.w : b.w * slope);
   }
 }
+// ---- MMGCN's layer tail (Model/MMGCN.py:102-131: h = leaky_relu(conv(x)); u = leaky_relu(linear(x)) + id_embedding;
+// x' = leaky_relu(g_layer(cat(h, u)))) --------------------------------------------------------------------------------
+// out[r] = [leaky(s[r]) | u[r] + id[r]]: the activation of the propagated half, the id residual of the other half and the
+// concatenation in ONE pass (torch: leaky_relu + add + cat = 3 launches, 10 row passes instead of 5).  id may be NULL.
+__global__ __launch_bounds__(256) void leaky_cat_add_kernel(const float4 *__restrict__ s, const float4 *__restrict__ u,
+                                                            const float4 *__restrict__ id, float4 *__restrict__ out,
+                                                            int64_t n_rows, int d1q, int d2q, float slope) {
+  const int tq = d1q + d2q;
+  const int64_t total = n_rows * tq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / tq;
+    const int c = (int)(i - r * tq);
+    float4 v;
+    if (c < d1q) {
+      const float4 a = s[r * d1q + c];
+      v = make_float4(a.x > 0.f ? a.x : a.x * slope, a.y > 0.f ? a.y : a.y * slope, a.z > 0.f ? a.z : a.z * slope,
+                      a.w > 0.f ? a.w : a.w * slope);
+    } else {
+      v = u[r * d2q + (c - d1q)];
+      if (id) {
+        const float4 b = id[r * d2q + (c - d1q)];
+        v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+      }
+    }
+    out[i] = v;
+  }
+}
+// backwards: the gradient of the concatenation [N, D1 + D2] -> gs = g[:, :D1] * leaky'(h) (h = the stored first half of
+// the concatenation: leaky(s) > 0 <=> s > 0), gu = g[:, D1:] * leaky'(uy) (uy = the activated Linear output the residual
+// was added to), both contiguous (torch: two strided copies + two activation backwards).  gid (optional) = g[:, D1:].
+__global__ __launch_bounds__(256) void leaky_split_bwd_kernel(const float4 *__restrict__ g, const float4 *__restrict__ cat,
+                                                              const float4 *__restrict__ uy, float4 *__restrict__ gs,
+                                                              float4 *__restrict__ gu, float4 *__restrict__ gid,
+                                                              int64_t n_rows, int d1q, int d2q, float slope) {
+  const int tq = d1q + d2q;
+  const int64_t total = n_rows * tq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / tq;
+    const int c = (int)(i - r * tq);
+    const float4 b = g[i];
+    if (c < d1q) {
+      const float4 a = cat[i];
+      gs[r * d1q + c] = make_float4(a.x > 0.f ? b.x : b.x * slope, a.y > 0.f ? b.y : b.y * slope,
+                                    a.z > 0.f ? b.z : b.z * slope, a.w > 0.f ? b.w : b.w * slope);
+    } else {
+      const int64_t j = r * d2q + (c - d1q);
+      const float4 a = uy[j];
+      gu[j] = make_float4(a.x > 0.f ? b.x : b.x * slope, a.y > 0.f ? b.y : b.y * slope, a.z > 0.f ? b.z : b.z * slope,
+                          a.w > 0.f ? b.w : b.w * slope);
+      if (gid) gid[j] = b;
+    }
+  }
+}
+
+// ---- F.normalize(cat(a, b), p=2, dim=1) (Model/MMGCN.py:99-100: x = F.normalize(cat(preference, features))) ---------
+// One wave per row: y = x / max(|x|, eps), the row norm kept for the backward.  Rows [0, na) come from `a`, the rest from
+// `b` (the concatenation is never materialised).  torch: cat + norm + clamp + expand + div = 4 launches forward and 8
+// backward over [N, 256]; here one each.
+__global__ __launch_bounds__(256) void normalize_rows_fwd_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b,
+                                                                 int64_t na, int64_t n_rows, int dq, float eps,
+                                                                 float4 *__restrict__ y, float *__restrict__ norm) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_rows; r += (int64_t)gridDim.x * 4) {
+    const float4 *src = r < na ? a + r * dq : b + (r - na) * dq;
+    float ss = 0.f;
+    for (int c = lane; c < dq; c += 64) {
+      const float4 v = src[c];
+      ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float nr = sqrtf(ss), d = fmaxf(nr, eps);
+    for (int c = lane; c < dq; c += 64) {
+      const float4 v = src[c];
+      y[r * dq + c] = make_float4(v.x / d, v.y / d, v.z / d, v.w / d);
+    }
+    if (lane == 0) norm[r] = nr;
+  }
+}
+// gx = (gy - y <gy, y>) / |x|  where |x| >= eps (the clamp passes the gradient there), gy / eps below it; rows < r_skip
+// are not written (the caller does not need the gradient of `a`: MMGCN's preference is no Parameter, Q2)
+__global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float4 *__restrict__ gy, const float4 *__restrict__ y,
+                                                                 const float *__restrict__ norm, int64_t r_skip,
+                                                                 int64_t n_rows, int dq, float eps,
+                                                                 float4 *__restrict__ gx) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = r_skip + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_rows; r += (int64_t)gridDim.x * 4) {
+    const float nr = norm[r];
+    float dot = 0.f;
+    if (nr >= eps) {
+      for (int c = lane; c < dq; c += 64) {
+        const float4 g = gy[r * dq + c], v = y[r * dq + c];
+        dot += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    }
+    const float d = fmaxf(nr, eps);
+    for (int c = lane; c < dq; c += 64) {
+      const float4 g = gy[r * dq + c], v = y[r * dq + c];
+      gx[r * dq + c] = make_float4((g.x - v.x * dot) / d, (g.y - v.y * dot) / d, (g.z - v.z * dot) / d, (g.w - v.w * dot) / d);
+    }
+  }
+}
+
 // the product t = s * x backwards, and the sum with s's other gradient:  gs += gt * x;  gx = gt * s
 // (separately rounded product and sum: what torch's mul + add give)
 __global__ __launch_bounds__(256) void mul_pair_bwd_kernel(const float4 *__restrict__ gt, const float4 *__restrict__ s,
@@ -412,4 +517,56 @@ extern "C" int chaorec_mul_pair_bwd_f32(const float *grad_t, const float *s, con
   mul_pair_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4 *)grad_t, (const float4 *)s, (const float4 *)x,
                                                               (float4 *)grad_s, (float4 *)grad_x, n4);
   return check_launch("mul_pair_bwd");
+}
+
+extern "C" int chaorec_leaky_cat_add_f32(const float *s, const float *u, const float *id, float *out, int64_t n_rows,
+                                         int32_t d1, int32_t d2, float slope, void *stream) {
+  if (!s || !u || !out) return fail(CHAOREC_E_INVALID, "leaky_cat_add: null pointer");
+  if (n_rows < 0 || d1 < 4 || d2 < 4 || (d1 & 3) || (d2 & 3))
+    return fail(CHAOREC_E_INVALID, "leaky_cat_add: n_rows=%lld d1=%d d2=%d (multiples of 4)", (long long)n_rows, d1, d2);
+  if (n_rows == 0) return CHAOREC_OK;
+  const int64_t total = n_rows * ((d1 + d2) / 4);
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+  leaky_cat_add_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4 *)s, (const float4 *)u, (const float4 *)id,
+                                                               (float4 *)out, n_rows, d1 / 4, d2 / 4, slope);
+  return check_launch("leaky_cat_add");
+}
+
+extern "C" int chaorec_leaky_split_bwd_f32(const float *grad_cat, const float *cat, const float *uy, float *grad_s,
+                                           float *grad_u, float *grad_id, int64_t n_rows, int32_t d1, int32_t d2,
+                                           float slope, void *stream) {
+  if (!grad_cat || !cat || !uy || !grad_s || !grad_u) return fail(CHAOREC_E_INVALID, "leaky_split_bwd: null pointer");
+  if (n_rows < 0 || d1 < 4 || d2 < 4 || (d1 & 3) || (d2 & 3))
+    return fail(CHAOREC_E_INVALID, "leaky_split_bwd: n_rows=%lld d1=%d d2=%d (multiples of 4)", (long long)n_rows, d1, d2);
+  if (n_rows == 0) return CHAOREC_OK;
+  const int64_t total = n_rows * ((d1 + d2) / 4);
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+  leaky_split_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4 *)grad_cat, (const float4 *)cat,
+                                                                 (const float4 *)uy, (float4 *)grad_s, (float4 *)grad_u,
+                                                                 (float4 *)grad_id, n_rows, d1 / 4, d2 / 4, slope);
+  return check_launch("leaky_split_bwd");
+}
+
+extern "C" int chaorec_normalize_rows_fwd_f32(const float *a, const float *b, int64_t rows_a, int64_t n_rows, int32_t D,
+                                              float eps, float *y, float *norm, void *stream) {
+  if (!a || !y || !norm || (rows_a < n_rows && !b)) return fail(CHAOREC_E_INVALID, "normalize_rows_fwd: null pointer");
+  if (n_rows < 0 || rows_a < 0 || rows_a > n_rows || D < 4 || (D & 3))
+    return fail(CHAOREC_E_INVALID, "normalize_rows_fwd: rows_a=%lld n_rows=%lld D=%d", (long long)rows_a, (long long)n_rows, D);
+  if (n_rows == 0) return CHAOREC_OK;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n_rows + 3) / 4, 16384);
+  normalize_rows_fwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4 *)a, (const float4 *)b, rows_a, n_rows,
+                                                                    D / 4, eps, (float4 *)y, norm);
+  return check_launch("normalize_rows_fwd");
+}
+
+extern "C" int chaorec_normalize_rows_bwd_f32(const float *grad_y, const float *y, const float *norm, int64_t skip_rows,
+                                              int64_t n_rows, int32_t D, float eps, float *grad_x, void *stream) {
+  if (!grad_y || !y || !norm || !grad_x) return fail(CHAOREC_E_INVALID, "normalize_rows_bwd: null pointer");
+  if (n_rows < 0 || skip_rows < 0 || skip_rows > n_rows || D < 4 || (D & 3))
+    return fail(CHAOREC_E_INVALID, "normalize_rows_bwd: skip=%lld n_rows=%lld D=%d", (long long)skip_rows, (long long)n_rows, D);
+  if (n_rows == skip_rows) return CHAOREC_OK;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n_rows - skip_rows + 3) / 4, 16384);
+  normalize_rows_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const float4 *)grad_y, (const float4 *)y, norm, skip_rows,
+                                                                    n_rows, D / 4, eps, (float4 *)grad_x);
+  return check_launch("normalize_rows_bwd");
 }

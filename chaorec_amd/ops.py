@@ -38,6 +38,16 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _f32rows(t):
+    """A 2-D fp32 operand the GEMM kernels can read or write in place: unit column stride, any row stride (a column
+    slice of a wider buffer travels as (pointer, ld) -- no copy); anything else is made contiguous."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
 # --------------------------------------------------------------------------------------------
 # SpMM
 # --------------------------------------------------------------------------------------------
@@ -603,11 +613,13 @@ def gemm_raw(A, B, transA=False, transB=False, bias=None, out=None, accumulate=F
         raise ValueError(f"gemm: inner dims {K} vs {Kb}")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError("gemm: `out` must be fp32 [M, N] with unit column stride")
     lib = _lib.load()
     nbytes = lib.chaorec_gemm_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device) if nbytes else None
     rc = lib.chaorec_gemm_f32(_ptr(A), _ptr(B), _ptr(out), _ptr(bias), M, N, K, A.shape[1], B.shape[1],
-                              out.shape[1], int(transA), int(transB), int(accumulate), act, _ptr(ws), nbytes,
+                              out.stride(0), int(transA), int(transB), int(accumulate), act, _ptr(ws), nbytes,
                               _stream())
     _lib.check(rc, "chaorec_gemm_f32")
     return out
@@ -615,20 +627,22 @@ def gemm_raw(A, B, transA=False, transB=False, bias=None, out=None, accumulate=F
 
 def gemm_nt_bf16x3(x, weight, bias=None, act=0, out=None):
     """y = act(x W^T + b) on the bf16 MFMA pipe with every fp32 operand split into three bf16 planes (fp32-grade
-    accuracy, chaorec_gemm_nt_bf16x3): the forward of nn.Linear."""
+    accuracy, chaorec_gemm_nt_bf16x3): the forward of nn.Linear.  x and `out` may be column slices of wider buffers."""
     _need_cuda(x, weight, bias, out)
-    x, weight = _f32c(x), _f32c(weight)
+    x, weight = _f32rows(x), _f32rows(weight)
     M, K = x.shape
     N = weight.shape[0]
     if weight.shape[1] != K:
         raise ValueError(f"gemm_nt_bf16x3: inner dims {K} vs {weight.shape[1]}")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError("gemm_nt_bf16x3: `out` must be fp32 [M, N] with unit column stride")
     lib = _lib.load()
     nbytes = lib.chaorec_gemm_nt_bf16x3_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    rc = lib.chaorec_gemm_nt_bf16x3(_ptr(x), _ptr(weight), _ptr(out), _ptr(bias), M, N, K, x.shape[1], weight.shape[1],
-                                    out.shape[1], act, _ptr(ws), nbytes, _stream())
+    rc = lib.chaorec_gemm_nt_bf16x3(_ptr(x), _ptr(weight), _ptr(out), _ptr(bias), M, N, K, x.stride(0), weight.stride(0),
+                                    out.stride(0), act, _ptr(ws), nbytes, _stream())
     _lib.check(rc, "chaorec_gemm_nt_bf16x3")
     return out
 
@@ -637,7 +651,7 @@ def gemm_tn_bf16x3(gy, x, out=None):
     """gy^T x  ([rows, M]^T [rows, N] -> [M, N]) on the bf16 MFMA pipe, three bf16 planes per fp32 operand
     (chaorec_gemm_tn_bf16x3): the weight gradient of nn.Linear."""
     _need_cuda(gy, x, out)
-    gy, x = _f32c(gy), _f32c(x)
+    gy, x = _f32rows(gy), _f32rows(x)
     K, M = gy.shape
     N = x.shape[1]
     if x.shape[0] != K:
@@ -647,9 +661,33 @@ def gemm_tn_bf16x3(gy, x, out=None):
     lib = _lib.load()
     nbytes = lib.chaorec_gemm_tn_bf16x3_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    rc = lib.chaorec_gemm_tn_bf16x3(_ptr(gy), _ptr(x), _ptr(out), M, N, K, gy.shape[1], x.shape[1], out.shape[1],
+    rc = lib.chaorec_gemm_tn_bf16x3(_ptr(gy), _ptr(x), _ptr(out), M, N, K, gy.stride(0), x.stride(0), out.stride(0),
                                     _ptr(ws), nbytes, _stream())
     _lib.check(rc, "chaorec_gemm_tn_bf16x3")
+    return out
+
+
+def gemm_nn_bf16x3(gy, weight, out=None, accumulate=False):
+    """gy W  ([M, K] [K, N] -> [M, N], W = an nn.Linear weight [out, in] as it lies in memory) on the bf16 MFMA pipe,
+    three bf16 planes per fp32 operand (chaorec_gemm_nn_bf16x3): the input gradient of nn.Linear."""
+    _need_cuda(gy, weight, out)
+    gy, weight = _f32rows(gy), _f32rows(weight)
+    M, K = gy.shape
+    N = weight.shape[1]
+    if weight.shape[0] != K:
+        raise ValueError(f"gemm_nn_bf16x3: inner dims {K} vs {weight.shape[0]}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=gy.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError("gemm_nn_bf16x3: `out` must be fp32 [M, N] with unit column stride")
+    lib = _lib.load()
+    nbytes = lib.chaorec_gemm_nn_bf16x3_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=gy.device) if nbytes else None
+    if accumulate and out is None:
+        raise ValueError("gemm_nn_bf16x3: accumulate needs `out`")
+    rc = lib.chaorec_gemm_nn_bf16x3(_ptr(gy), _ptr(weight), _ptr(out), M, N, K, gy.stride(0), weight.stride(0),
+                                    out.stride(0), int(bool(accumulate)), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "chaorec_gemm_nn_bf16x3")
     return out
 
 
@@ -659,17 +697,54 @@ import os as _os
 LINEAR_FORWARD = _os.environ.get("CHAOREC_LINEAR_FORWARD", "bf16x3")
 
 
+def _linear_fwd_raw(x, weight, bias, act, out=None):
+    """act(x W^T + b): the bf16 MFMA pipe (three bf16 planes per fp32 operand) where the reduction is long enough to pay
+    for the split, else the f32 MFMA pipe.  `out` may be a column slice of a wider buffer."""
+    if LINEAR_FORWARD == "bf16x3" and x.shape[1] >= 64 and x.shape[0] >= 256:
+        return gemm_nt_bf16x3(x, weight, bias=bias, act=act, out=out)
+    return gemm_raw(x, weight, transB=True, bias=bias, act=act, out=out)
+
+
+def _leaky_bwd_raw(y, gy, act):
+    """gy * leaky_relu'(y) for act 1 (slope 0.01) / 2 (slope 0.2), one launch."""
+    slope = 0.01 if act == 1 else 0.2
+    if gy.numel() % 4 == 0:
+        gy = gy.contiguous()
+        g = torch.empty_like(gy)
+        _lib.check(_lib.load().chaorec_leaky_bwd_f32(_ptr(y), _ptr(gy), slope, _ptr(g), g.numel(), _stream()),
+                   "chaorec_leaky_bwd_f32")
+        return g
+    return torch.where(y > 0, gy, gy * slope)
+
+
+def _linear_gx_raw(gy, weight, out=None, accumulate=False):
+    """The input gradient gy W (W read as it lies: NN product) on the pipe the forward used; `accumulate`: out += gy W."""
+    if LINEAR_FORWARD == "bf16x3" and weight.shape[0] >= 64 and gy.shape[0] >= 256:
+        return gemm_nn_bf16x3(gy, weight, out=out, accumulate=accumulate)
+    return gemm_raw(gy, weight, out=out, accumulate=accumulate)
+
+
+def _linear_gw_raw(gy, x):
+    """The weight gradient gy^T x: a reduction over all rows -- the split-bf16 pipe where its 128-row tile is not half
+    padding (out >= 128: 768^2 over 60 k rows 994 -> 744 us, 256^2 128 -> 94 us; the 64-wide layers' gradients are faster
+    on the f32 kernel's 64-row tile)."""
+    if LINEAR_FORWARD == "bf16x3" and gy.shape[0] >= 4096 and gy.shape[1] >= 128 and x.shape[1] >= 64:
+        return gemm_tn_bf16x3(gy, x)
+    if LINEAR_FORWARD == "bf16x3" and gy.shape[0] >= 4096 and gy.shape[1] <= 64 and x.shape[1] >= 128:
+        # a 64-row gradient of a wide layer: with the operands swapped the WIDE dimension fills the 128-row tiles
+        # (x^T gy, then one small transpose): [64, 320] over 60 k rows 70 -> 51 us, [64, 832] 108 -> 86 us
+        return gemm_tn_bf16x3(x, gy).t().contiguous()
+    return gemm_raw(gy, x, transA=True)
+
+
 class _Linear(torch.autograd.Function):
-    """y = act(x W^T + b) (nn.Linear [+ F.leaky_relu]): forward on the bf16 MFMA pipe (three bf16 planes per fp32
-    operand) where the reduction is long enough to pay for the split -- the input gradient and the weight gradient
-    (a TN product over all rows) likewise --, else on the f32 MFMA pipe."""
+    """y = act(x W^T + b) (nn.Linear [+ F.leaky_relu]): forward, input gradient and weight gradient (a TN product over all
+    rows) on the bf16 MFMA pipe (three bf16 planes per fp32 operand) where the reduction is long enough to pay for the
+    split, else on the f32 MFMA pipe."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
-        if LINEAR_FORWARD == "bf16x3" and x.shape[1] >= 64 and x.shape[0] >= 256:
-            y = gemm_nt_bf16x3(x, weight, bias=bias, act=act)
-        else:
-            y = gemm_raw(x, weight, transB=True, bias=bias, act=act)
+        y = _linear_fwd_raw(x, weight, bias, act)
         ctx.save_for_backward(x, weight, y if act else None)
         ctx.has_bias, ctx.act = bias is not None, act
         # a trainable table an optimizer has claimed (optim.FusedAdam): its gradient gy W leaves as (gy, W), see backward
@@ -679,16 +754,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
-        gy = gy.contiguous()
-        if ctx.act:
-            slope = 0.01 if ctx.act == 1 else 0.2
-            if gy.numel() % 4 == 0:                  # the activation's mask in one launch
-                g = torch.empty_like(gy)
-                _lib.check(_lib.load().chaorec_leaky_bwd_f32(_ptr(y), _ptr(gy), slope, _ptr(g), g.numel(), _stream()),
-                           "chaorec_leaky_bwd_f32")
-                gy = g
-            else:
-                gy = torch.where(y > 0, gy, gy * slope)
+        gy = _leaky_bwd_raw(y, gy, ctx.act) if ctx.act else gy.contiguous()
         gx = None
         xp = ctx.x_param
         if ctx.needs_input_grad[0] and xp is not None and weight.shape[0] <= 64 and xp._chaorec_lowrank_sink.accepts(xp):
@@ -696,31 +762,146 @@ class _Linear(torch.autograd.Function):
             # whole): its dense gradient gy W is never formed, the optimizer applies it row by row (adam_lowrank)
             xp._chaorec_lowrank_sink.submit(xp, gy, weight, None, dense_reader=True)
         elif ctx.needs_input_grad[0]:
-            # input gradient g W: as g (W^T)^T on the bf16 MFMA pipe where the forward went there too (W is small:
-            # its transpose is one short copy)
-            if LINEAR_FORWARD == "bf16x3" and weight.shape[0] >= 64 and gy.shape[0] >= 256:
-                gx = gemm_nt_bf16x3(gy, weight.t().contiguous())
-            else:
-                gx = gemm_raw(gy, weight)
-        gw = None
-        if ctx.needs_input_grad[1]:
-            # weight gradient gy^T x: a reduction over all rows -- the same split-bf16 pipe where its 128-row tile is
-            # not half padding (out >= 128: 768^2 over 60 k rows 994 -> 744 us, 256^2 128 -> 94 us; the 64-wide layers'
-            # gradients are faster on the f32 kernel's 64-row tile)
-            if LINEAR_FORWARD == "bf16x3" and gy.shape[0] >= 4096 and gy.shape[1] >= 128 and x.shape[1] >= 64:
-                gw = gemm_tn_bf16x3(gy, x)
-            elif LINEAR_FORWARD == "bf16x3" and gy.shape[0] >= 4096 and gy.shape[1] <= 64 and x.shape[1] >= 128:
-                # a 64-row gradient of a wide layer: with the operands swapped the WIDE dimension fills the 128-row
-                # tiles (x^T gy, then one small transpose): [64, 320] over 60 k rows 70 -> 51 us, [64, 832] 108 -> 86 us
-                gw = gemm_tn_bf16x3(x, gy).t().contiguous()
-            else:
-                gw = gemm_raw(gy, x, transA=True)
+            gx = _linear_gx_raw(gy, weight)
+        gw = _linear_gw_raw(gy, x) if ctx.needs_input_grad[1] else None
         gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[2] else None     # (not gy.sum(0): see col_sum)
         return gx, gw, gb, None
 
 
 def linear(x, weight, bias=None, act=0):
     return _Linear.apply(x, weight, bias, act)
+
+
+# --------------------------------------------------------------------------------------------
+# MMGCN: one layer as one autograd node, F.normalize over a row concatenation
+# --------------------------------------------------------------------------------------------
+def leaky_cat_add(s, u, id_rows=None, out=None, slope=0.01):
+    """[leaky_relu(s) | u + id_rows] in one pass (chaorec_leaky_cat_add_f32)."""
+    _need_cuda(s, u, id_rows, out)
+    s, u = _f32c(s), _f32c(u)
+    id_rows = _f32c(id_rows) if id_rows is not None else None
+    n, d1, d2 = s.shape[0], s.shape[1], u.shape[1]
+    if out is None:
+        out = torch.empty((n, d1 + d2), dtype=torch.float32, device=s.device)
+    _lib.check(_lib.load().chaorec_leaky_cat_add_f32(_ptr(s), _ptr(u), _ptr(id_rows), _ptr(out), n, d1, d2, slope, _stream()),
+               "chaorec_leaky_cat_add_f32")
+    return out
+
+
+def leaky_split_bwd(gcat, cat, uy, d1, want_gid=False, slope=0.01):
+    """-> (gcat[:, :d1] * leaky'(cat[:, :d1]), gcat[:, d1:] * leaky'(uy), gcat[:, d1:] or None), all contiguous, one pass
+    (chaorec_leaky_split_bwd_f32)."""
+    _need_cuda(gcat, cat, uy)
+    gcat, cat, uy = _f32c(gcat), _f32c(cat), _f32c(uy)
+    n, d2 = gcat.shape[0], gcat.shape[1] - d1
+    gs = torch.empty((n, d1), dtype=torch.float32, device=gcat.device)
+    gu = torch.empty((n, d2), dtype=torch.float32, device=gcat.device)
+    gid = torch.empty((n, d2), dtype=torch.float32, device=gcat.device) if want_gid else None
+    _lib.check(_lib.load().chaorec_leaky_split_bwd_f32(_ptr(gcat), _ptr(cat), _ptr(uy), _ptr(gs), _ptr(gu), _ptr(gid), n, d1,
+                                                       d2, slope, _stream()), "chaorec_leaky_split_bwd_f32")
+    return gs, gu, gid
+
+
+# "fused" (one autograd node per MMGCN layer, below) or "unfused" (the composition of linear / spmm / torch ops it
+# replaces; the two are bit-identical -- tests/test_gpu_models.py)
+MMGCN_LAYER = _os.environ.get("CHAOREC_MMGCN_LAYER", "fused")
+
+
+class _MMGCNLayer(torch.autograd.Function):
+    """One MMGCN layer, concat branch (Model/MMGCN.py:102-131):
+        h = leaky_relu(A (x Wc^T + bc));  u = leaky_relu(x Wl^T + bl) + id;  out = leaky_relu([h | u] Wg^T + bg)
+    as one autograd node: 5 launches forward (GEMM, SpMM, GEMM, tail, GEMM), and backward the concatenation's gradient is
+    split, masked and made contiguous by one launch, x's two gradient flows meet in a GEMM epilogue.  The composition of
+    ops.linear / ops.spmm / F.leaky_relu / + / torch.cat it replaces spent 7 torch launches per layer and direction on
+    the same data (DESIGN 8: the at::native share of the MMGCN step).  Same kernels, same arithmetic: bit-identical.
+    `ax_aug` = the cached [A x | A 1 | 0] of a constant input (GCN._constant_input): then h = leaky_relu(ax_aug [Wc | bc |
+    0]^T) is written by the GEMM straight into the concatenation's left columns and there is no SpMM either way."""
+
+    @staticmethod
+    def forward(ctx, x, id_rows, Wc, bc, Wl, bl, Wg, bg, csr, ax_aug, pad):
+        n, d1, d2 = x.shape[0], Wc.shape[0], Wl.shape[0]
+        uy = _linear_fwd_raw(x, Wl, bl, 1)
+        if ax_aug is None:
+            s = spmm_raw(csr, _linear_fwd_raw(x, Wc, bc, 0))
+            cat = leaky_cat_add(s, uy, id_rows)
+        else:
+            cat = torch.empty((n, d1 + d2), dtype=torch.float32, device=x.device)
+            w_aug = torch.cat((Wc, bc[:, None], Wc.new_zeros(d1, pad)), 1)
+            _linear_fwd_raw(ax_aug, w_aug, None, 1, out=cat[:, :d1])
+            right = cat[:, d1:]
+            if id_rows is not None:
+                torch.add(uy, id_rows, out=right)
+            else:
+                right.copy_(uy)
+        out = _linear_fwd_raw(cat, Wg, bg, 1)
+        ctx.save_for_backward(x, Wc, Wl, Wg, cat, uy, out, ax_aug)
+        ctx.csr, ctx.d1, ctx.has_id = csr, d1, id_rows is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, Wc, Wl, Wg, cat, uy, out, ax_aug = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        d1 = ctx.d1
+        g1 = _leaky_bwd_raw(out, gout, 1)
+        gWg = _linear_gw_raw(g1, cat) if need[6] else None
+        gbg = col_sum(g1) if need[7] else None
+        gcat = _linear_gx_raw(g1, Wg)
+        gs, gu, gid = leaky_split_bwd(gcat, cat, uy, d1, want_gid=ctx.has_id and need[1])
+        gWl = _linear_gw_raw(gu, x) if need[4] else None
+        gbl = col_sum(gu) if need[5] else None
+        gx = _linear_gx_raw(gu, Wl) if need[0] else None
+        if ax_aug is None:
+            gc = spmm_raw(ctx.csr.t(), gs)
+            gWc = _linear_gw_raw(gc, x) if need[2] else None
+            gbc = col_sum(gc) if need[3] else None
+            if need[0]:
+                gx = _linear_gx_raw(gc, Wc, out=gx, accumulate=True)
+        else:
+            gWc = gbc = None
+            if need[2] or need[3]:
+                gw_aug = _linear_gw_raw(gs, ax_aug)
+                k = Wc.shape[1]
+                gWc, gbc = gw_aug[:, :k].contiguous(), gw_aug[:, k].contiguous()
+        return gx, gid, gWc, gbc, gWl, gbl, gWg, gbg, None, None, None
+
+
+def mmgcn_layer(x, id_rows, conv_lin, lin, g_lin, csr, ax_aug=None, pad=0):
+    return _MMGCNLayer.apply(x, id_rows, conv_lin.weight, conv_lin.bias, lin.weight, lin.bias, g_lin.weight, g_lin.bias, csr,
+                             ax_aug, pad)
+
+
+class _NormalizeRows(torch.autograd.Function):
+    """F.normalize(torch.cat((a, b), dim=0)) (Model/MMGCN.py:99-100) in one launch each way, the concatenation never
+    materialised; the gradient of `a` is only computed when asked for (MMGCN's preference is no Parameter, Q2)."""
+
+    @staticmethod
+    def forward(ctx, a, b, eps):
+        a = _f32c(a)
+        b = _f32c(b) if b is not None else None
+        na, nb, D = a.shape[0], (b.shape[0] if b is not None else 0), a.shape[1]
+        y = torch.empty((na + nb, D), dtype=torch.float32, device=a.device)
+        norm = torch.empty(na + nb, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().chaorec_normalize_rows_fwd_f32(_ptr(a), _ptr(b), na, na + nb, D, eps, _ptr(y), _ptr(norm),
+                                                              _stream()), "chaorec_normalize_rows_fwd_f32")
+        ctx.save_for_backward(y, norm)
+        ctx.na, ctx.eps = na, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, norm = ctx.saved_tensors
+        gy = gy.contiguous()
+        skip = 0 if ctx.needs_input_grad[0] else ctx.na
+        gx = torch.empty_like(y)
+        _lib.check(_lib.load().chaorec_normalize_rows_bwd_f32(_ptr(gy), _ptr(y), _ptr(norm), skip, y.shape[0], y.shape[1],
+                                                              ctx.eps, _ptr(gx), _stream()), "chaorec_normalize_rows_bwd_f32")
+        return (gx[:ctx.na] if ctx.needs_input_grad[0] else None), (gx[ctx.na:] if ctx.needs_input_grad[1] else None), None
+
+
+def normalize_rows(a, b=None, eps=1e-12):
+    """== F.normalize(torch.cat((a, b), dim=0)) (or F.normalize(a)); D a multiple of 4."""
+    return _NormalizeRows.apply(a, b, eps)
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
@@ -835,7 +1016,7 @@ class _LinearRows(torch.autograd.Function):
             if sink is not None and sink.accepts(x):
                 sink.submit(x, gy_full, weight, ctx.row_token)
             elif LINEAR_FORWARD == "bf16x3" and weight.shape[0] >= 64 and gy_full.shape[0] >= 256:
-                gx = gemm_nt_bf16x3(gy_full, weight.t().contiguous())
+                gx = gemm_nn_bf16x3(gy_full, weight)
             else:
                 gx = gemm_raw(gy_full, weight)
         gw = gemm_raw(gy, xg, transA=True) if ctx.needs_input_grad[2] else None

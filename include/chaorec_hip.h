@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 8   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 9   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -36,8 +36,9 @@ extern "C" {
                                   6: BPR batch at an offset + one finalize for k captured steps, NGCF elementwise backward;
                                   7: Adam over a feature table with a low-rank, row-sparse gradient (dense / lazy / flush), split-bf16 TN GEMM
                                      (weight gradients), multi-tensor Adam;
-                                  8: rows_mean (layer mean of exchanged rows: fused sharded LightGCN step); the prefilter's
-                                     selection is block-joint (union bitmaps + f32 MFMA re-score) below 128 k items */
+                                  8: rows_mean (layer mean of exchanged rows: fused sharded LightGCN step);
+                                  9: split-bf16 NN GEMM (input gradients, accumulate epilogue), MMGCN's layer tail
+                                     (leaky_cat_add / leaky_split_bwd), normalize_rows */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -400,6 +401,15 @@ size_t chaorec_gemm_tn_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, int64_t M, int64_t N, int64_t K, int64_t lda,
                            int64_t ldb, int64_t ldc, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The INPUT gradient of those Linears,  C[M, N] = A[M, K] . B[K, N]  with B = the layer's weight [out = K, in = N] as it
+ * lies in memory (autograd's  grad_output @ weight, Model/MMGCN.py:97-131's layers backwards): same pipe, same split,
+ * same accuracy class.  lda >= K, ldb >= N, ldc >= N.  accumulate != 0: C += A B (a node's second gradient flow added in
+ * the epilogue instead of by a separate launch; a + b is commutative, so the bits are those of the separate add). */
+size_t chaorec_gemm_nn_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int chaorec_gemm_nn_bf16x3(const float *A, const float *B, float *C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                           int64_t ldb, int64_t ldc, int32_t accumulate, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Fused Adam step over one flat fp32 parameter (torch.optim.Adam defaults, main.py:397):
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
@@ -562,6 +572,28 @@ int chaorec_colsum_f32(const float *x, int64_t M, int64_t N, int64_t ldx, float 
                        size_t workspace_bytes, void *stream);
 int chaorec_sum_f32(const float *x, int64_t n, float scale, float *out, void *workspace, size_t workspace_bytes,
                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MMGCN's layer tail in one pass each way (Model/MMGCN.py:102-131, per layer:
+ *   h = F.leaky_relu(conv(x));  x_hat = F.leaky_relu(linear(x)) + id_embedding;  cat((h, x_hat), dim=1) ):
+ *   out[r] = [ leaky_relu(s[r]) | u[r] + id[r] ]       s [n, d1], u / id [n, d2] (id may be NULL), out [n, d1 + d2]
+ * and backwards from the concatenation's gradient:
+ *   grad_s = g[:, :d1] * leaky'(cat[:, :d1]),  grad_u = g[:, d1:] * leaky'(uy),  grad_id (optional) = g[:, d1:]
+ * (uy = the activated Linear output u; cat = the forward's output).  d1, d2 multiples of 4, everything contiguous.
+ * ------------------------------------------------------------------------------------- */
+int chaorec_leaky_cat_add_f32(const float *s, const float *u, const float *id, float *out, int64_t n_rows, int32_t d1,
+                              int32_t d2, float slope, void *stream);
+int chaorec_leaky_split_bwd_f32(const float *grad_cat, const float *cat, const float *uy, float *grad_s, float *grad_u,
+                                float *grad_id, int64_t n_rows, int32_t d1, int32_t d2, float slope, void *stream);
+
+/* F.normalize(torch.cat((a, b), dim=0), p=2, dim=1, eps) (Model/MMGCN.py:99-100) without the concatenation: rows
+ * [0, rows_a) are read from a, rows [rows_a, n_rows) from b (b may be NULL when rows_a == n_rows); y [n_rows, D],
+ * norm [n_rows] = |x_r| for the backward:  grad_x = (grad_y - y <grad_y, y>) / |x|  where |x| >= eps, grad_y / eps below;
+ * rows < skip_rows of grad_x are left unwritten (the caller does not need them).  D a multiple of 4. */
+int chaorec_normalize_rows_fwd_f32(const float *a, const float *b, int64_t rows_a, int64_t n_rows, int32_t D, float eps,
+                                   float *y, float *norm, void *stream);
+int chaorec_normalize_rows_bwd_f32(const float *grad_y, const float *y, const float *norm, int64_t skip_rows,
+                                   int64_t n_rows, int32_t D, float eps, float *grad_x, void *stream);
 
 #ifdef __cplusplus
 }

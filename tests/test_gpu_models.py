@@ -114,6 +114,75 @@ def test_freedom_pre_epoch_statistics(dev):
     assert (B != 0).sum() == 2 * keep and ((A != 0) != (B != 0)).any()
 
 
+def test_mmgcn_fused_layer_is_the_composition_bit_for_bit(dev, monkeypatch):
+    """ops.mmgcn_layer (one autograd node per layer, CHAOREC_MMGCN_LAYER=fused) against the composition of ops.linear /
+    ops.spmm / F.leaky_relu / + / torch.cat it replaces: same GEMM and SpMM kernels, same elementwise arithmetic -> loss,
+    representation and every gradient (parameters and id_embedding) bit-identical.  With ops.normalize_rows in place of
+    cat + F.normalize as well (a row's squares summed in another order) everything agrees to 2e-5 relative."""
+    from chaorec_amd.Model import MMGCN
+    from chaorec_amd import graph, ops
+    g = load_golden("mmgcn_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    names = [str(n) for n in g["param_names"]]
+
+    def run(mode, torch_normalize=False):
+        monkeypatch.setattr(ops, "MMGCN_LAYER", mode)
+        if torch_normalize:
+            monkeypatch.setattr(ops, "normalize_rows", lambda a, b: torch.nn.functional.normalize(torch.cat((a, b), dim=0)))
+        torch.manual_seed(0)
+        m = MMGCN(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+                  torch.from_numpy(g["t_feat"]), int(g["dim_x"]), float(g["reg"]), "add", "False", True, dev)
+        m.load_state_dict({n: torch.from_numpy(g["p_" + n]) for n in names})
+        m = m.to(dev)
+        m.v_gcn.preference = torch.from_numpy(g["v_pref"]).to(dev)
+        m.t_gcn.preference = torch.from_numpy(g["t_pref"]).to(dev)
+        m.id_embedding = torch.from_numpy(g["id_embedding"]).to(dev).requires_grad_(True)   # (exercises grad_id too)
+        loss = m.loss(torch.from_numpy(g["user_tensor"]), torch.from_numpy(g["item_tensor"]))
+        loss.backward()
+        monkeypatch.undo()
+        return m.result.detach(), loss.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}, m.id_embedding.grad.clone()
+
+    ru, lu, gu, idu = run("unfused")
+    rf, lf, gf, idf = run("fused", torch_normalize=True)
+    assert torch.equal(rf, ru) and torch.equal(lf, lu) and torch.equal(idf, idu)
+    for n in names:
+        assert torch.equal(gf[n], gu[n]), n
+    rn, ln, gn, idn = run("fused")
+    for n in names:
+        scale = float(gu[n].abs().max()) + 1e-30
+        assert float((gn[n] - gu[n]).abs().max()) <= 2e-5 * scale, n
+    assert float((ln - lu).abs()) <= 2e-6 * float(lu.abs())
+    assert float((idn - idu).abs().max()) <= 2e-5 * float(idu.abs().max())
+    assert torch.allclose(rn, ru, rtol=2e-5, atol=1e-7)
+
+
+def test_normalize_rows_is_f_normalize(dev):
+    from chaorec_amd import ops
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    a = torch.randn(1000, 256, device=dev, generator=gen)
+    b = (torch.randn(777, 256, device=dev, generator=gen) * 3).requires_grad_(True)
+    a[3] = 0                                     # |x| < eps: y = x / eps = 0, gradient gy / eps
+    a[4] = 1e-14
+    a = a.requires_grad_(True)
+    w = torch.randn(1777, 256, device=dev, generator=gen)
+    y = ops.normalize_rows(a, b)
+    ref = torch.nn.functional.normalize(torch.cat((a.detach(), b.detach())).double())
+    assert torch.allclose(y.double(), ref, rtol=0, atol=2e-7)
+    (y * w).sum().backward()
+    a64, b64 = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    (torch.nn.functional.normalize(torch.cat((a64, b64))) * w.double()).sum().backward()
+    for got, want in ((a.grad, a64.grad), (b.grad, b64.grad)):
+        err, scale = (got.double() - want).abs().amax(1), want.abs().amax(1)      # per row: the |x| < eps rows are 1e12 x
+        assert bool((err <= 1e-5 * scale + 1e-30).all()), float((err / (scale + 1e-30)).max())
+    # the gradient of `a` is skipped when nobody asks for it
+    a2, b2 = a.detach(), b.detach().clone().requires_grad_(True)
+    (ops.normalize_rows(a2, b2) * w).sum().backward()
+    assert torch.equal(b2.grad, b.grad)
+    # single-source form
+    assert torch.equal(ops.normalize_rows(a.detach()), y[:1000].detach())
+
+
 def test_mmgcn_golden(dev):
     from chaorec_amd.Model import MMGCN
     from chaorec_amd import graph

@@ -1065,6 +1065,34 @@ def test_gemm_tn_bf16x3_fp32_grade(dev, M, N, K):
     assert torch.equal(got, ops.gemm_tn_bf16x3(gy, x))
 
 
+@pytest.mark.parametrize("M,N,K", [(47001, 64, 64), (9000, 320, 64), (5000, 768, 768), (4099, 130, 70), (1234, 61, 33),
+                                   (640, 128, 256), (300, 4096, 64)])
+def test_gemm_nn_bf16x3_fp32_grade(dev, M, N, K):
+    """The split-bf16 input-gradient GEMM gy W (W [K = out, N = in] as nn.Linear stores it, no transposed copy): error
+    against an fp64 product bounded by 1e-6 * sum_k |a||b| per element, on average no worse than 1.5x the f32 kernel's,
+    bit-identical run to run; also reading / writing column slices of wider buffers in place."""
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(M + N + K)
+    gy = torch.randn(M, K, device=dev, generator=g) * torch.exp(torch.randn(M, 1, device=dev, generator=g))
+    w = torch.randn(K, N, device=dev, generator=g) * 0.05
+    got = ops.gemm_nn_bf16x3(gy, w)
+    ref = gy.double() @ w.double()
+    mass = gy.double().abs() @ w.double().abs()
+    err = (got.double() - ref).abs()
+    assert bool((err <= 1e-6 * mass + 1e-30).all()), float((err / (mass + 1e-30)).max())
+    f32 = ops.gemm_raw(gy, w)
+    assert float(err.mean()) <= 1.5 * float((f32.double() - ref).abs().mean()) + 1e-12
+    assert torch.equal(got, ops.gemm_nn_bf16x3(gy, w))
+    if K % 4 == 0 and N % 4 == 0:
+        wide_in = torch.full((M, K + 8), float("nan"), device=dev)
+        wide_in[:, 4:4 + K] = gy
+        wide_out = torch.full((M, N + 12), -7.0, device=dev)
+        ops.gemm_nn_bf16x3(wide_in[:, 4:4 + K], w, out=wide_out[:, 8:8 + N])
+        assert torch.equal(wide_out[:, 8:8 + N], got)
+        assert bool((wide_out[:, :8] == -7.0).all()) and bool((wide_out[:, 8 + N:] == -7.0).all())
+
+
 def test_linear_forward_pipes_agree(dev):
     """ops.linear on either pipe: same autograd contract, outputs equal to fp32 rounding, identical backward kernels."""
     from chaorec_amd import ops
