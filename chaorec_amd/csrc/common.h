@@ -93,4 +93,13 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
+// lanes per output element of gemm_reduce_slabs_kernel (block = 32 elements x lanes): many slabs of a SMALL output (a
+// 64 x 64 weight gradient over 256 slabs) want 32 lanes -- the launch is a latency chain of splits / lanes loads --, a large
+// output with few slabs (768 x 772 over 25) has parallelism enough and would only idle the extra lanes
+inline int reduce_lanes(int splits, int64_t mn) {
+  int lanes = 8;
+  while (lanes < 32 && splits >= 8 * lanes && mn * lanes <= (int64_t)1 << 20) lanes *= 2;
+  return lanes;
+}
+
 }  // namespace chaorec

@@ -272,27 +272,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 
 #undef SK
 
-// split-K second pass: C = sum_z slab[z] (+ bias) (+ C) (+ act), in a FIXED order: 8 lanes per output element take the
-// slabs z = l, l+8, ... in ascending order (each 32-thread group reads 32 consecutive elements of a slab: coalesced),
-// then the 8 partial sums are added in lane order.  Deterministic; 8x the parallelism of one thread per element
-// (the output is small -- e.g. 64 x 320 -- and there are up to 256 slabs).
-constexpr int kRedLanes = 8;
-__global__ __launch_bounds__(256) void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits,
-                                                                float *__restrict__ C, const float *__restrict__ bias,
-                                                                int64_t M, int64_t N, int64_t ldc, int accumulate,
-                                                                int act) {
+// split-K second pass: C = sum_z slab[z] (+ bias) (+ C) (+ act), in a FIXED order: kRedLanes lanes per output element take
+// the slabs z = l, l + kRedLanes, ... in ascending order (each 32-thread group reads 32 consecutive elements of a slab:
+// coalesced), then the partial sums are added in lane order.  Deterministic.  The output is small -- e.g. 64 x 64 -- and
+// there are up to 256 slabs: with 8 lanes per element a lane walked 32 dependent-issue loads and the launch took 12 us, 27
+// times per MMGCN step; 32 lanes (1024-thread blocks) walk 8.
+constexpr int kRedLanes = 32;   // at most; the launch picks blockDim = 32 * lanes (reduce_lanes)
+__global__ __launch_bounds__(32 * kRedLanes) void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits,
+                                                                          float *__restrict__ C, const float *__restrict__ bias,
+                                                                          int64_t M, int64_t N, int64_t ldc, int accumulate,
+                                                                          int act) {
   __shared__ float part[kRedLanes][32];
+  const int lanes = blockDim.x >> 5;
   const int e = threadIdx.x & 31, l = threadIdx.x >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + e;
   const size_t mn = (size_t)M * (size_t)N;
   float v = 0.f;
-  if (i < (int64_t)mn)
-    for (int z = l; z < splits; z += kRedLanes) v = v + slabs[(size_t)z * mn + i];
+  if (i < (int64_t)mn) {
+    int z = l;
+    float v1 = 0.f;
+    for (; z + lanes < splits; z += 2 * lanes) {     // two loads in flight per lane
+      const float a = slabs[(size_t)z * mn + i], b = slabs[(size_t)(z + lanes) * mn + i];
+      v = v + a;
+      v1 = v1 + b;
+    }
+    if (z < splits) v = v + slabs[(size_t)z * mn + i];
+    v = v + v1;
+  }
   part[l][e] = v;
   __syncthreads();
   if (l != 0 || i >= (int64_t)mn) return;
-#pragma unroll
-  for (int k = 1; k < kRedLanes; ++k) v = v + part[k][e];
+  for (int k = 1; k < lanes; ++k) v = v + part[k][e];
   const int64_t m = i / N, n = i % N;
   if (bias) v = v + bias[n];
   if (accumulate) v = C[m * ldc + n] + v;
@@ -441,7 +451,7 @@ extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const 
                        transB, accumulate, act, p.k_per_split, slabs);
   int rc = check_launch("gemm_f32_kernel");
   if (rc || p.splits == 1) return rc;
-  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs,
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st, slabs,
                      p.splits, C, bias, M, N, ldc, accumulate, act);
   return check_launch("gemm_reduce_slabs_kernel");
 }

@@ -287,7 +287,9 @@ static XPlan plan_x(int64_t M, int64_t N, int64_t K) {
   const int XBN = pick_bn(N);
   const int64_t tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
   int64_t s = 1;
-  if (tiles < 512 && K >= 512) {                 // few output tiles, long reduction: fill the chip by cutting K
+  // few output tiles, long reduction: fill the chip by cutting K.  (Not at 400+ tiles: [60499, 768] x [768, 64] has 473 --
+  // all resident at once --, and three slabs of 15.5 MB each cost a 55 us second pass on top of their own writes.)
+  if (tiles < 400 && K >= 512) {
     s = (1024 + tiles - 1) / tiles;
     if (s > K / 256) s = K / 256;
     if (s > 64) s = 64;
@@ -353,7 +355,7 @@ extern "C" int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, 
                        ldb, ldc, 0, p.k_per_split, slabs, 0);
   int rc = check_launch("gemm_bf16x3_kernel<TN>");
   if (rc || p.splits == 1) return rc;
-  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st, slabs, p.splits, C,
                      (const float *)nullptr, M, N, ldc, 0, 0);
   return check_launch("gemm_reduce_slabs_kernel");
 }
@@ -387,7 +389,7 @@ extern "C" int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, 
                        p.k_per_split, slabs, 0);
   int rc = check_launch("gemm_bf16x3_kernel<NT>");
   if (rc || p.splits == 1) return rc;
-  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st, slabs, p.splits, C,
                      bias, M, N, ldc, 0, act);
   return check_launch("gemm_reduce_slabs_kernel");
 }
@@ -419,7 +421,7 @@ extern "C" int chaorec_gemm_nn_bf16x3(const float *A, const float *B, float *C, 
                        lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0);
   int rc = check_launch("gemm_bf16x3_kernel<NN>");
   if (rc || p.splits == 1) return rc;
-  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(256), 0, st, slabs, p.splits, C,
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st, slabs, p.splits, C,
                      (const float *)nullptr, M, N, ldc, accumulate ? 1 : 0, 0);
   return check_launch("gemm_reduce_slabs_kernel");
 }

@@ -212,28 +212,34 @@ __global__ __launch_bounds__(256) void colsum_partial4_kernel(const float4 *__re
   }
 }
 
-// pass 2: 64 columns per block, the chunks of a column over four waves (each with four independent accumulators, so the
-// loads of a wave are in flight together: one thread walking 118 chunk rows of a 60 k-row sum alone took 27 us), combined
-// in a fixed order
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, int64_t chunks, int64_t N,
-                                                           float *__restrict__ out) {
-  __shared__ float red[4][64];
+// pass 2: 64 columns per block, the chunks of a column over kFinalWaves waves (each with four independent accumulators, so
+// the loads of a wave are in flight together: one thread walking 118 chunk rows of a 60 k-row sum alone took 27 us, four
+// waves 9.5 us -- 24 times per MMGCN step), combined in a fixed order
+constexpr int kFinalWaves = 16;
+__global__ __launch_bounds__(64 * kFinalWaves) void colsum_final_kernel(const float *__restrict__ part, int64_t chunks,
+                                                                        int64_t N, float *__restrict__ out) {
+  __shared__ float red[kFinalWaves][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t col = (int64_t)blockIdx.x * 64 + tx;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (col < N) {
     int64_t k = ty;
-    for (; k + 12 < chunks; k += 16) {
+    for (; k + 3 * kFinalWaves < chunks; k += 4 * kFinalWaves) {
       a0 += part[k * N + col];
-      a1 += part[(k + 4) * N + col];
-      a2 += part[(k + 8) * N + col];
-      a3 += part[(k + 12) * N + col];
+      a1 += part[(k + kFinalWaves) * N + col];
+      a2 += part[(k + 2 * kFinalWaves) * N + col];
+      a3 += part[(k + 3 * kFinalWaves) * N + col];
     }
-    for (; k < chunks; k += 4) a0 += part[k * N + col];
+    for (; k < chunks; k += kFinalWaves) a0 += part[k * N + col];
   }
   red[ty][tx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (ty == 0 && col < N) out[col] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (ty == 0 && col < N) {
+    float v = red[0][tx];
+#pragma unroll
+    for (int w = 1; w < kFinalWaves; ++w) v += red[w][tx];
+    out[col] = v;
+  }
 }
 
 __global__ __launch_bounds__(256) void sum_partial_kernel(const float *__restrict__ x, int64_t n,
@@ -425,7 +431,7 @@ extern "C" int chaorec_colsum_f32(const float *x, int64_t M, int64_t N, int64_t 
   else if (chunks > 0)
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, st, x, M, N,
                        ldx, part, cr);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, part, chunks, N, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64 * kFinalWaves), 0, st, part, chunks, N, out);
   return check_launch("colsum");
 }
 
