@@ -58,9 +58,10 @@ class GCN(torch.nn.Module):
             setattr(self, f"g_layer{k}", g)
 
     def _fused(self, x):
-        """The layer as ONE autograd node (ops.mmgcn_layer): the concat branch over a CSR in HBM, row widths the float4
-        kernels take.  Sharded graphs (an operator with .propagate) and the other branches keep the composition."""
-        return (ops.MMGCN_LAYER == "fused" and self.concate and isinstance(self.edge_index, graph.CSR) and x.is_cuda
+        """The layer as ONE autograd node (ops.mmgcn_layer): the concat branch over a CSR in HBM or a sharded graph in its
+        joined form, row widths the float4 kernels take.  Everything else keeps the composition."""
+        on_graph = isinstance(self.edge_index, graph.CSR) or getattr(self.edge_index, "joined", False)   # (dist.ShardedGraph)
+        return (ops.MMGCN_LAYER == "fused" and self.concate and on_graph and x.is_cuda
                 and x.shape[1] % 4 == 0 and self.dim_id % 4 == 0)
 
     def _layer(self, k, x, id_embedding):
@@ -104,7 +105,7 @@ class GCN(torch.nn.Module):
         cached [A x | A 1] with [W | b] -- no 768-wide SpMM forward, none backward (the weight gradient is a product with
         the same cached operand).  Same arithmetic up to the association of the sums."""
         conv, lin, g = self.conv_embed_1, self.linear_layer1, self.g_layer1
-        if self._fused(x) and isinstance(self.edge_index, graph.CSR):
+        if self._fused(x):
             return ops.mmgcn_layer(x, id_embedding if self.has_id else None, conv.lin, lin, g, self.edge_index,
                                    ax_aug=ax_aug, pad=pad)
         w_aug = torch.cat((conv.lin.weight, conv.lin.bias[:, None], conv.lin.weight.new_zeros(conv.lin.weight.shape[0], pad)), 1)

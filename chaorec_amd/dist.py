@@ -687,32 +687,40 @@ class _ShardedPropagateJoined(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, shard, spmm_fn, group):
-        x = x.contiguous()
-        U, N, D = shard.num_user_local, x.shape[0], x.shape[1]
-        csr = joined_loop_csr(shard)
-        buf = torch.empty((U + padded_rows(N - U, group), D), dtype=x.dtype, device=x.device)
-        if buf.shape[0] > N:
-            buf[N:].zero_()
-        spmm_fn(csr, x, y=buf[:N])
-        _sum_exchange_async(buf[U:], group).wait()
-        y = buf[:N]
-        y[U:].addcmul_(x[U:], shard.diag_i)
         ctx.shard, ctx.spmm_fn, ctx.group = shard, spmm_fn, group
-        return y
+        return propagate_joined_fwd(x, shard, spmm_fn, group)
 
     @staticmethod
     def backward(ctx, G):
-        shard, spmm_fn, group = ctx.shard, ctx.spmm_fn, ctx.group
-        G = G.contiguous()
-        U, N, D = shard.num_user_local, G.shape[0], G.shape[1]
-        S = torch.empty((U + padded_rows(N - U, group), D), dtype=G.dtype, device=G.device)
-        if S.shape[0] > N:
-            S[N:].zero_()
-        S[:N].copy_(G)
-        _sum_exchange_async(S[U:], group).wait()
-        g = spmm_fn(joined_loop_csr(shard), S[:N])
-        g[U:].addcmul_(G[U:], shard.diag_i)
-        return g, None, None, None
+        return propagate_joined_bwd(G, ctx.shard, ctx.spmm_fn, ctx.group), None, None, None
+
+
+def propagate_joined_fwd(x, shard, spmm_fn, group):
+    """_ShardedPropagateJoined's forward as a plain function (also called by ops.mmgcn_layer's node)."""
+    x = x.contiguous()
+    U, N, D = shard.num_user_local, x.shape[0], x.shape[1]
+    csr = joined_loop_csr(shard)
+    buf = torch.empty((U + padded_rows(N - U, group), D), dtype=x.dtype, device=x.device)
+    if buf.shape[0] > N:
+        buf[N:].zero_()
+    spmm_fn(csr, x, y=buf[:N])
+    _sum_exchange_async(buf[U:], group).wait()
+    y = buf[:N]
+    y[U:].addcmul_(x[U:], shard.diag_i)
+    return y
+
+
+def propagate_joined_bwd(G, shard, spmm_fn, group):
+    G = G.contiguous()
+    U, N, D = shard.num_user_local, G.shape[0], G.shape[1]
+    S = torch.empty((U + padded_rows(N - U, group), D), dtype=G.dtype, device=G.device)
+    if S.shape[0] > N:
+        S[N:].zero_()
+    S[:N].copy_(G)
+    _sum_exchange_async(S[U:], group).wait()
+    g = spmm_fn(joined_loop_csr(shard), S[:N])
+    g[U:].addcmul_(G[U:], shard.diag_i)
+    return g
 
 
 class ShardedGraph:
@@ -723,6 +731,13 @@ class ShardedGraph:
     def __init__(self, shard, spmm_fn=None, group=None):
         self.shard, self.spmm_fn, self.group = shard, spmm_fn, group
         self.joined = shard.diag_u is not None and _os.environ.get("CHAOREC_DIST_PROPAGATE", "joined") == "joined"
+
+    def propagate_raw(self, x):
+        """A x without an autograd node (joined form only): for nodes that own their backward (ops.mmgcn_layer)."""
+        return propagate_joined_fwd(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group)
+
+    def propagate_t_raw(self, g):
+        return propagate_joined_bwd(g, self.shard, self.spmm_fn or ops.spmm_raw, self.group)
 
     def propagate(self, x):
         if self.joined:

@@ -814,7 +814,8 @@ class _MMGCNLayer(torch.autograd.Function):
     split, masked and made contiguous by one launch, x's two gradient flows meet in a GEMM epilogue.  The composition of
     ops.linear / ops.spmm / F.leaky_relu / + / torch.cat it replaces spent 7 torch launches per layer and direction on
     the same data (DESIGN 8: the at::native share of the MMGCN step).  Same kernels, same arithmetic: bit-identical.
-    `ax_aug` = the cached [A x | A 1 | 0] of a constant input (GCN._constant_input): then h = leaky_relu(ax_aug [Wc | bc |
+    `csr`: a graph.CSR, or a sharded graph operator with propagate_raw / propagate_t_raw (dist.ShardedGraph, joined form:
+    the item rows' exchange happens inside).  `ax_aug` = the cached [A x | A 1 | 0] of a constant input (GCN._constant_input): then h = leaky_relu(ax_aug [Wc | bc |
     0]^T) is written by the GEMM straight into the concatenation's left columns and there is no SpMM either way."""
 
     @staticmethod
@@ -822,7 +823,8 @@ class _MMGCNLayer(torch.autograd.Function):
         n, d1, d2 = x.shape[0], Wc.shape[0], Wl.shape[0]
         uy = _linear_fwd_raw(x, Wl, bl, 1)
         if ax_aug is None:
-            s = spmm_raw(csr, _linear_fwd_raw(x, Wc, bc, 0))
+            c = _linear_fwd_raw(x, Wc, bc, 0)
+            s = csr.propagate_raw(c) if hasattr(csr, "propagate_raw") else spmm_raw(csr, c)
             cat = leaky_cat_add(s, uy, id_rows)
         else:
             cat = torch.empty((n, d1 + d2), dtype=torch.float32, device=x.device)
@@ -852,7 +854,7 @@ class _MMGCNLayer(torch.autograd.Function):
         gbl = col_sum(gu) if need[5] else None
         gx = _linear_gx_raw(gu, Wl) if need[0] else None
         if ax_aug is None:
-            gc = spmm_raw(ctx.csr.t(), gs)
+            gc = ctx.csr.propagate_t_raw(gs) if hasattr(ctx.csr, "propagate_t_raw") else spmm_raw(ctx.csr.t(), gs)
             gWc = _linear_gw_raw(gc, x) if need[2] else None
             gbc = col_sum(gc) if need[3] else None
             if need[0]:
