@@ -1364,9 +1364,13 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
     const int deg = (int)(he - hb);
     const bool hist_lds = deg <= kPfHistLds;
     __syncthreads();
-    if (hist_lds)
-      for (int i = tid; i < deg; i += kExThreads) hist_s[i] = (uint32_t)P.hist_col[hb + i];
-    __syncthreads();
+    // (the history is only needed for the mask AFTER a round's scores: its loads -- two dependent round trips behind the
+    //  user's id -- travel under the item rows' instead of in front of them)
+    constexpr int HR = kPfHistLds / kExThreads;     // history entries per thread
+    uint32_t hreg[HR];
+#pragma unroll
+    for (int q = 0; q < HR; ++q) hreg[q] = (hist_lds && tid + q * kExThreads < deg) ? (uint32_t)P.hist_col[hb + tid + q * kExThreads] : 0u;
+    bool hist_ready = false;
     // this block's contiguous slice of the items, kExThreads * kExPer per round; every wave keeps its own K best
     const int64_t i_begin = (int64_t)slice * per_slice, i_end = min(P.n_items, i_begin + per_slice);
     // this lane's pieces of the user's row (exact_scores_64)
@@ -1379,16 +1383,37 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
     uint64_t bk = 0ull;
     for (int64_t c0 = i_begin; c0 < i_end; c0 += (int64_t)kExThreads * kExPer) {
       uint64_t key[kExPer];
+      float sxs[kExPer];
 #pragma unroll
       for (int j = 0; j < kExPer; ++j) {
         const int64_t it0 = c0 + 64 * wave + (int64_t)kExThreads * j;      // the wave's 64 consecutive items
+        sxs[j] = 0.f;
+#if defined(CHAOREC_EX_EXP) && CHAOREC_EX_EXP == 5   // experiment: no scores
+        sxs[j] = ua[0] * (float)it0;
+#else
+        if (it0 < i_end) sxs[j] = exact_scores_64<D>(P.item_emb, it0, P.n_items, ua, ub, lane);   // wave-uniform
+#endif
+      }
+      if (!hist_ready) {          // block-uniform: every thread's first round
+#pragma unroll
+        for (int q = 0; q < HR; ++q)
+          if (tid + q * kExThreads < deg) hist_s[tid + q * kExThreads] = hreg[q];
+        __syncthreads();
+        hist_ready = true;
+      }
+#pragma unroll
+      for (int j = 0; j < kExPer; ++j) {
+        const int64_t it0 = c0 + 64 * wave + (int64_t)kExThreads * j;
         const int64_t it = it0 + lane;
         key[j] = 0ull;
-        if (it0 < i_end) {                                                 // wave-uniform
-          const float sx = exact_scores_64<D>(P.item_emb, it0, P.n_items, ua, ub, lane);
+        if (it0 < i_end) {
+          const float sx = sxs[j];
           if (it < i_end) {
             const uint32_t item = (uint32_t)it;
             int lo = 0, hi = deg;
+#if defined(CHAOREC_EX_EXP) && CHAOREC_EX_EXP == 4   // experiment: no history search
+            hi = 0;
+#endif
             while (lo < hi) {
               const int mid = (lo + hi) >> 1;
               const uint32_t hv = hist_lds ? hist_s[mid] : (uint32_t)P.hist_col[hb + mid];
@@ -1399,8 +1424,16 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
           }
         }
       }
+#if defined(CHAOREC_EX_EXP) && (CHAOREC_EX_EXP == 1 || CHAOREC_EX_EXP >= 4)   // experiment: scores only (wrong result)
+      bk = key[0] ^ key[1];
+      continue;
+#endif
       bk = wave_select_topk<kExPer>(key, bk, kMaxK, stage[wave]);   // (the 64 best: the next call's threshold wants more than K)
     }
+#if defined(CHAOREC_EX_EXP) && (CHAOREC_EX_EXP == 1 || CHAOREC_EX_EXP == 2 || CHAOREC_EX_EXP >= 4)   // experiment: no block merge
+    if (bk == 1ull) P.fb_partial[0] = bk;
+    continue;
+#endif
     // block merge: every wave orders its 64 best, then a tree of pairwise merges through LDS (log2 NW levels of one
     // reverse + six stages each).  One wave picking the 64 best of all NW lists by a bitwise search (32 steps x NW + 1
     // ballots) was 20 of the route's 48 us.
@@ -1416,6 +1449,10 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
       __syncthreads();
     }
     uint64_t *part = P.fb_partial + (size_t)qi * kExSlices * kMaxK;
+#if defined(CHAOREC_EX_EXP) && CHAOREC_EX_EXP == 3   // experiment: no slice merge
+    if (wave == 0) part[slice * kMaxK + lane] = stage[0][lane];
+    continue;
+#endif
     if (wave == 0) {
       part[slice * kMaxK + lane] = stage[0][lane];   // kMaxK == 64; descending
       __threadfence();
@@ -1424,9 +1461,12 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
     __syncthreads();
     if (last && wave == 0) {   // the last slice to arrive merges the user's kExSlices lists
       __threadfence();
-      uint64_t e = __builtin_nontemporal_load(part + lane);      // the slices' lists are in descending order
+      uint64_t sl[kExSlices];                                    // the slices' lists are in descending order; all loads
+#pragma unroll                                                   // in flight together, not one round trip per merge
+      for (int j = 0; j < kExSlices; ++j) sl[j] = __builtin_nontemporal_load(part + j * kMaxK + lane);
+      uint64_t e = sl[0];
 #pragma unroll
-      for (int j = 1; j < kExSlices; ++j) e = merge_top64(e, __builtin_nontemporal_load(part + j * kMaxK + lane), lane);
+      for (int j = 1; j < kExSlices; ++j) e = merge_top64(e, sl[j], lane);
       if (lane < K) {
         const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull);
         P.out_idx[(size_t)u * K + lane] = (int64_t)item + P.id_offset;

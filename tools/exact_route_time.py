@@ -1,6 +1,10 @@
 """Cost of the exact per-user route against the number of users on it: LightGCN/sports, carried thresholds on the same
 tables, the first n users' thresholds set to +inf (no candidates -> they fail pass A and, in light mode, take the
-exact route).  Whole-call event times; the difference to n = 0 is the route's cost."""
+exact route).  Whole-call event times; the difference to n = 0 is the route's cost.
+Stage cuts (experiment builds, wrong results): CHAOREC_EXTRA_HIPCC_FLAGS=-DCHAOREC_EX_EXP=k with k = 1 scores only,
+2 + per-wave selection, 3 + block merge (no slice merge), 4 scores without the history search, 5 history search without
+scores.  Round 3, one user: scores 22 of the route's 30-35 us (a chain of dependent gathers: id -> row pointer -> rows,
+then 8 passes of 16 rows per wave), block merge 6.7, slice merge 6.4."""
 import os
 import sys
 
