@@ -130,6 +130,10 @@ SIGNATURES = {
     "chaorec_gemm_nn_bf16x3": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, c_ptr,
                                               ctypes.c_size_t, c_ptr]),
+    "chaorec_bpr_multi_fwd_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_int32,
+                                                 ctypes.c_int32, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "chaorec_bpr_multi_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_int32,
+                                                 ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_leaky_cat_add_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.c_float, c_ptr]),
     "chaorec_leaky_split_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64,

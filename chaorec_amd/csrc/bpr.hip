@@ -282,6 +282,80 @@ __global__ __launch_bounds__(256) void bpr_bwd_kernel(
   }
 }
 
+// ---- several BPR terms over one user table (Model/FREEDOM.py:203-215: mf_loss + reg_weight * (mf_t_loss + mf_v_loss)) ----
+// T item tables (the propagated id embeddings, the projected text rows, the projected image rows), each with its own
+// positive / negative row ids, share the user table and the batch's users.  One launch for all T * B triples, one
+// finalize that also forms  sum_k w_k * loss_k, one backward launch: 4 launches per step where T calls of
+// chaorec_bpr_fwd_f32 / chaorec_bpr_bwd_f32 plus the weighted sum in torch took 13.
+constexpr int kBprMaxTerms = 4;
+struct BprMultiArgs {
+  const float *tab_i[kBprMaxTerms];
+  const int64_t *pos[kBprMaxTerms];
+  const int64_t *neg[kBprMaxTerms];
+  float *g_i[kBprMaxTerms];
+  int T;
+};
+
+__global__ __launch_bounds__(256) void bpr_multi_fwd_terms_kernel(const float *__restrict__ tab_u,
+                                                                  const int64_t *__restrict__ users, const BprMultiArgs A,
+                                                                  int B, int D, int variant, float *__restrict__ coef,
+                                                                  float *__restrict__ ws) {
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int k = w / B, b = w - k * B;
+  if (k >= A.T) return;
+  bpr_terms_wave(tab_u, A.tab_i[k], users[b], A.pos[k][b], A.neg[k][b], b, B, D, variant, coef + (size_t)k * B,
+                 ws + (size_t)k * 4 * B);
+}
+
+// one block; term by term the reduction of bpr_fwd_finalize_kernel (thread t sums elements t, t + 256, ... then a fixed LDS
+// tree), then total = ((w_0 l_0 + w_1 l_1) + w_2 l_2) + ...
+__global__ __launch_bounds__(256) void bpr_multi_finalize_kernel(const float *__restrict__ ws, int T, int B,
+                                                                 const float *__restrict__ wvec,
+                                                                 float *__restrict__ losses, float *__restrict__ out_total) {
+  __shared__ float red[256];
+  const int t = threadIdx.x;
+  float total = 0.f;
+  for (int k = 0; k < T; ++k) {
+    const float *w = ws + (size_t)k * 4 * B;
+    float a = 0.f;
+    for (int i = t; i < B; i += 256) a += w[i];
+    red[t] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) red[t] += red[t + s];
+      __syncthreads();
+    }
+    if (t == 0) {
+      const float l = -red[0] / (float)B;
+      losses[k] = l;
+      total = k == 0 ? l * wvec[0] : total + l * wvec[k];
+    }
+    __syncthreads();
+  }
+  if (t == 0) out_total[0] = total;
+}
+
+__global__ __launch_bounds__(256) void bpr_multi_bwd_kernel(const float *__restrict__ tab_u, const int64_t *__restrict__ users,
+                                                            const BprMultiArgs A, int B, int D, const float *__restrict__ coef,
+                                                            const float *__restrict__ wvec, const float *__restrict__ grad_out,
+                                                            float *g_u) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int k = w / B, b = w - k * B;
+  if (k >= A.T) return;
+  const float go = (grad_out ? grad_out[0] : 1.0f) * wvec[k];
+  const float c = coef[(size_t)k * B + b] * go;
+  const float *tab_i = A.tab_i[k];
+  float *g_i = A.g_i[k];
+  const size_t ou = (size_t)users[b] * D, op = (size_t)A.pos[k][b] * D, on = (size_t)A.neg[k][b] * D;
+  for (int q = lane; q < D; q += 64) {
+    const float u = tab_u[ou + q], p = tab_i[op + q], n = tab_i[on + q];
+    atomicAdd(g_u + ou + q, c * (p - n));
+    atomicAdd(g_i + op + q, c * u);
+    atomicAdd(g_i + on + q, -c * u);
+  }
+}
+
 // ---- sampler -------------------------------------------------------------------------------
 // Counter-based generator: splitmix64 finaliser over (seed, step, b, attempt).  Stateless, so a
 // draw does not depend on launch geometry or on how many draws other samples needed.
@@ -505,6 +579,53 @@ extern "C" int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i, const
   hipLaunchKernelGGL(bpr_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u,
                      tab_i, users, pos, neg, B, D, coef, reg_weight, grad_out, g_u, g_i);
   return check_launch("bpr_bwd_kernel");
+}
+
+static int fill_multi(BprMultiArgs &A, int32_t T, const float *const *tabs, const int64_t *const *pos,
+                      const int64_t *const *neg, float *const *g_i, const char *who) {
+  if (T < 1 || T > kBprMaxTerms) return fail(CHAOREC_E_INVALID, "%s: T=%d must be in [1, %d]", who, T, kBprMaxTerms);
+  if (!tabs || !pos || !neg) return fail(CHAOREC_E_INVALID, "%s: NULL argument", who);
+  A.T = T;
+  for (int k = 0; k < kBprMaxTerms; ++k) {
+    const int j = k < T ? k : 0;
+    if (!tabs[j] || !pos[j] || !neg[j] || (g_i && !g_i[j])) return fail(CHAOREC_E_INVALID, "%s: NULL term %d", who, j);
+    A.tab_i[k] = tabs[j], A.pos[k] = pos[j], A.neg[k] = neg[j], A.g_i[k] = g_i ? g_i[j] : nullptr;
+  }
+  return CHAOREC_OK;
+}
+
+extern "C" int chaorec_bpr_multi_fwd_f32(const float *tab_u, const int64_t *users, int32_t T, const float *const *tabs,
+                                         const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
+                                         int32_t variant, const float *wvec, float *losses, float *out_total, float *coef,
+                                         float *workspace, void *stream) {
+  if (!tab_u || !users || !wvec || !losses || !out_total || !coef || !workspace)
+    return fail(CHAOREC_E_INVALID, "bpr_multi_fwd: NULL argument");
+  if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_multi_fwd: B=%d D=%d", B, D);
+  if (variant < 0 || variant > 2) return fail(CHAOREC_E_INVALID, "bpr_multi_fwd: variant %d", variant);
+  BprMultiArgs A;
+  int rc = fill_multi(A, T, tabs, pos, neg, nullptr, "bpr_multi_fwd");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bpr_multi_fwd_terms_kernel, dim3((T * B + 3) / 4), dim3(256), 0, st, tab_u, users, A, B, D, variant,
+                     coef, workspace);
+  rc = check_launch("bpr_multi_fwd_terms_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bpr_multi_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, T, B, wvec, losses, out_total);
+  return check_launch("bpr_multi_finalize_kernel");
+}
+
+extern "C" int chaorec_bpr_multi_bwd_f32(const float *tab_u, const int64_t *users, int32_t T, const float *const *tabs,
+                                         const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
+                                         const float *coef, const float *wvec, const float *grad_out, float *g_u,
+                                         float *const *g_i, void *stream) {
+  if (!tab_u || !users || !wvec || !coef || !g_u || !g_i) return fail(CHAOREC_E_INVALID, "bpr_multi_bwd: NULL argument");
+  if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_multi_bwd: B=%d D=%d", B, D);
+  BprMultiArgs A;
+  int rc = fill_multi(A, T, tabs, pos, neg, g_i, "bpr_multi_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bpr_multi_bwd_kernel, dim3((T * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u, users, A, B, D,
+                     coef, wvec, grad_out, g_u);
+  return check_launch("bpr_multi_bwd_kernel");
 }
 
 extern "C" int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col,

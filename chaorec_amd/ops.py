@@ -252,11 +252,15 @@ class _BPR(torch.autograd.Function):
         return g_u, g_i, None, None, None, None, None, None
 
 
+BPR_MULTI_MAX = 4 if os.environ.get("CHAOREC_BPR_MULTI", "1") == "1" else 0     # chaorec_bpr_multi_*_f32's term limit
+
+
 class _BPRMulti(torch.autograd.Function):
     """sum_k w_k * BPR(tab_u[users], tab_i_k[pos_k], tab_i_k[neg_k]) for several item tables that share the user table and
     the batch's users (Model/FREEDOM.py:203-215: the id-embedding loss + reg_weight * (text loss + image loss)) as ONE
     autograd node: one gradient buffer for the user table that the T backward launches add into (instead of T zero-filled
-    buffers and T - 1 additions by autograd), the weighted sum and its backward as two small launches."""
+    buffers and T - 1 additions by autograd); up to four terms run as ONE forward launch, one finalize that also forms the
+    weighted sum, and one backward launch (chaorec_bpr_multi_*_f32: 4 launches per step instead of 13)."""
 
     @staticmethod
     def forward(ctx, tab_u, users, variant, wvec, *flat):
@@ -272,6 +276,17 @@ class _BPRMulti(torch.autograd.Function):
         coef = torch.empty((T, B), dtype=torch.float32, device=dev)
         ws = torch.empty(4 * B, dtype=torch.float32, device=dev)
         lib = _lib.load()
+        ctx.T = T
+        if T <= BPR_MULTI_MAX:       # all terms in one launch (+ one finalize that also forms the weighted sum)
+            ws = torch.empty(4 * B * T, dtype=torch.float32, device=dev)
+            total = torch.empty((), dtype=torch.float32, device=dev)
+            arr = lambda ts: (ctypes.c_void_p * T)(*[t.data_ptr() for t in ts])
+            rc = lib.chaorec_bpr_multi_fwd_f32(_ptr(tab_u), _ptr(users), T, arr(tabs), arr([p for p, _ in ids]),
+                                               arr([n for _, n in ids]), B, D, variant, _ptr(wvec), _ptr(totals), _ptr(total),
+                                               _ptr(coef), _ptr(ws), _stream())
+            _lib.check(rc, "chaorec_bpr_multi_fwd_f32")
+            ctx.save_for_backward(tab_u, users, coef, wvec, *tabs, *[t for pn in ids for t in pn])
+            return total
         for k in range(T):
             rc = lib.chaorec_bpr_fwd_f32(_ptr(tab_u), _ptr(tabs[k]), _ptr(users), _ptr(ids[k][0]), _ptr(ids[k][1]), B, D,
                                          variant, 0.0, ctypes.c_void_p(outs.data_ptr() + 12 * k),
@@ -279,7 +294,6 @@ class _BPRMulti(torch.autograd.Function):
                                          ctypes.c_void_p(coef.data_ptr() + 4 * B * k), _ptr(ws), _stream())
             _lib.check(rc, "chaorec_bpr_fwd_f32")
         ctx.save_for_backward(tab_u, users, coef, wvec, *tabs, *[t for pn in ids for t in pn])
-        ctx.T = T
         return (totals * wvec).sum()
 
     @staticmethod
@@ -289,7 +303,6 @@ class _BPRMulti(torch.autograd.Function):
         tabs = ctx.saved_tensors[4:4 + T]
         ids = ctx.saved_tensors[4 + T:]
         B, D = users.numel(), tab_u.shape[1]
-        gvec = (g * wvec).contiguous()                   # d total / d loss_k, on the device
         # ONE zero fill for the T + 1 gradient buffers (views of it), not one launch each
         sizes = [tab_u.numel()] + [t.numel() for t in tabs]
         flat = torch.zeros(sum(sizes), dtype=tab_u.dtype, device=tab_u.device)
@@ -299,6 +312,17 @@ class _BPRMulti(torch.autograd.Function):
         g_u = flat[:sizes[0]].view_as(tab_u)
         lib = _lib.load()
         grads = []
+        if T <= BPR_MULTI_MAX:
+            g_is = [flat[offs[k + 1]:offs[k + 2]].view_as(tabs[k]) for k in range(T)]
+            arr = lambda ts: (ctypes.c_void_p * T)(*[t.data_ptr() for t in ts])
+            g = g.contiguous()
+            rc = lib.chaorec_bpr_multi_bwd_f32(_ptr(tab_u), _ptr(users), T, arr(tabs), arr(ids[0::2]), arr(ids[1::2]), B, D,
+                                               _ptr(coef), _ptr(wvec), _ptr(g), _ptr(g_u), arr(g_is), _stream())
+            _lib.check(rc, "chaorec_bpr_multi_bwd_f32")
+            for g_i in g_is:
+                grads += [g_i, None, None]
+            return (g_u, None, None, None, *grads)
+        gvec = (g * wvec).contiguous()                   # d total / d loss_k, on the device
         for k in range(T):
             g_i = flat[offs[k + 1]:offs[k + 2]].view_as(tabs[k])
             rc = lib.chaorec_bpr_bwd_f32(_ptr(tab_u), _ptr(tabs[k]), _ptr(users), _ptr(ids[2 * k]), _ptr(ids[2 * k + 1]), B,

@@ -38,7 +38,7 @@ extern "C" {
                                      (weight gradients), multi-tensor Adam;
                                   8: rows_mean (layer mean of exchanged rows: fused sharded LightGCN step);
                                   9: split-bf16 NN GEMM (input gradients, accumulate epilogue), MMGCN's layer tail
-                                     (leaky_cat_add / leaky_split_bwd), normalize_rows */
+                                     (leaky_cat_add / leaky_split_bwd), normalize_rows, multi-term BPR */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -572,6 +572,24 @@ int chaorec_colsum_f32(const float *x, int64_t M, int64_t N, int64_t ldx, float 
                        size_t workspace_bytes, void *stream);
 int chaorec_sum_f32(const float *x, int64_t n, float scale, float *out, void *workspace, size_t workspace_bytes,
                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Several BPR terms over ONE user table and one batch of users (Model/FREEDOM.py:203-215:
+ *   mf_loss + reg_weight * (mf_t_loss + mf_v_loss), each -mean(logsigmoid(s+ - s-)) over its own item table):
+ *   losses[k] = BPR(tab_u[users], tabs[k][pos[k]], tabs[k][neg[k]]),  out_total = sum_k wvec[k] * losses[k]
+ * T <= 4 terms; tabs / pos / neg / g_i: HOST arrays of T device pointers (copied into the kernel argument).
+ * coef [T, B] and workspace [T, 4 B] floats are kept for the backward, which adds
+ *   grad_out * wvec[k] * d losses[k]  into g_u (shared) and g_i[k] (atomic row adds; the buffers must be zero where no
+ * sample lands).  wvec, grad_out: device pointers (grad_out may be NULL = 1).  Two launches forward, one backward.
+ * ------------------------------------------------------------------------------------- */
+int chaorec_bpr_multi_fwd_f32(const float *tab_u, const int64_t *users, int32_t T, const float *const *tabs,
+                              const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
+                              int32_t variant, const float *wvec, float *losses, float *out_total, float *coef,
+                              float *workspace, void *stream);
+int chaorec_bpr_multi_bwd_f32(const float *tab_u, const int64_t *users, int32_t T, const float *const *tabs,
+                              const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
+                              const float *coef, const float *wvec, const float *grad_out, float *g_u,
+                              float *const *g_i, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * MMGCN's layer tail in one pass each way (Model/MMGCN.py:102-131, per layer:

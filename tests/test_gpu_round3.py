@@ -209,3 +209,39 @@ def test_freedom_result_is_fresh_under_a_captured_step(dev):
     with torch.no_grad():
         fu, fi = m.forward(m.masked_adj)
     assert float((torch.cat((fu, fi), 0) - r2).abs().max()) < 0.05
+
+
+def test_bpr_multi_one_launch_equals_term_by_term(dev, monkeypatch):
+    """chaorec_bpr_multi_{fwd,bwd}_f32 (all of FREEDOM's three BPR terms in one launch each way, the weighted sum in the
+    finalize) against T calls of chaorec_bpr_fwd_f32 / chaorec_bpr_bwd_f32 and the weighted sum in torch: per-term losses
+    bit-identical, total to one rounding, gradients to the atomics' order."""
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    U, I, B, D = 3000, 2000, 1024, 64
+    tab_u = torch.randn(U, D, device=dev, generator=g) * 0.1
+    users = torch.randint(0, U, (B,), device=dev, generator=g)
+    wvec = torch.tensor([1.0, 1e-3, 1e-3], device=dev)
+
+    def run(limit):
+        monkeypatch.setattr(ops, "BPR_MULTI_MAX", limit)
+        tu = tab_u.clone().requires_grad_(True)
+        gg = torch.Generator(device=dev)
+        gg.manual_seed(12)
+        terms, leaves = [], []
+        for k, rows in enumerate((I, 2 * B, 2 * B)):
+            t = (torch.randn(rows, D, device=dev, generator=gg) * 0.1).requires_grad_(True)
+            leaves.append(t)
+            terms.append((t, torch.randint(0, rows, (B,), device=dev, generator=gg), torch.randint(0, rows, (B,), device=dev, generator=gg)))
+        loss = ops.bpr_loss_multi(tu, users, ops.VARIANT_LOGSIGMOID, terms, wvec)
+        (loss * 1.5).backward()
+        return loss.detach(), tu.grad, [t.grad for t in leaves]
+
+    l1, gu1, gi1 = run(4)
+    l0, gu0, gi0 = run(0)
+    assert float((l1 - l0).abs()) <= 2e-7 * float(l0.abs())
+    assert torch.allclose(gu1, gu0, rtol=0, atol=2e-7 * float(gu0.abs().max()))
+    for a, b in zip(gi1, gi0):
+        assert torch.allclose(a, b, rtol=0, atol=2e-7 * float(b.abs().max()) + 1e-12)
+    # deterministic forward
+    assert torch.equal(run(4)[0], l1)
