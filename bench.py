@@ -929,10 +929,13 @@ def main_model(args, world, rank, local_rank, force_sharded):
 
     def draw():
         counter.add_(1)
-        u, pos, neg = ops.draw_batch(edges_dev, hist, B, U_g, I, 42 + rank, 0, step_dev=counter)       # LOCAL item ids
+        # item ids as the reference's dataset hands them over (dataload.py:74-88): GLOBAL (item + num_user), added in the draw
+        # launch; the sharded FREEDOM takes local ones
+        glob = name == "MMGCN" or not sharded
+        u, pos, neg = ops.draw_batch(edges_dev, hist, B, U_g, I, 42 + rank, 0, step_dev=counter, item_offset=U_g if glob else 0)
         if name == "MMGCN":                     # Model/MMGCN.py:188-202: [B, 2] user / item tensors indexing the joined table
-            return torch.stack((u, u), 1), torch.stack((pos + U_g, neg + U_g), 1)
-        return (u, pos, neg) if sharded else (u, pos + U_g, neg + U_g)                # (FREEDOM.loss shifts global ids itself)
+            return torch.stack((u, u), 1), torch.stack((pos, neg), 1)
+        return u, pos, neg                      # (FREEDOM.loss shifts global ids itself)
 
     sync = model.sync_grads if sharded else None
     # exchange bytes of one step on this rank, and the step's SpMM work: one eager step with the calls counted

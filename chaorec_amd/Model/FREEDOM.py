@@ -213,9 +213,13 @@ class FREEDOM(nn.Module):
 
     def loss(self, users, pos_items, neg_items):
         """Model/FREEDOM.py:194-217."""
-        pos_items = pos_items - self.num_user
-        neg_items = neg_items - self.num_user
         users, pos_items, neg_items = users.to(self.device), pos_items.to(self.device), neg_items.to(self.device)
+        if pos_items.is_cuda and pos_items.dim() == 1 and pos_items.numel() == neg_items.numel():
+            pos_items, neg_items, rows = ops.shift_cat(pos_items, neg_items, self.num_user)   # :195-196 + the batch's row list
+        else:
+            pos_items = pos_items - self.num_user
+            neg_items = neg_items - self.num_user
+            rows = torch.cat((pos_items, neg_items), 0)
 
         ua_embeddings, ia_embeddings = self.forward(self.masked_adj)
         # Model/FREEDOM.py:208-213 project the WHOLE feature table and read the batch rows of the result; a row of a
@@ -223,7 +227,6 @@ class FREEDOM(nn.Module):
         # BPR terms -- total = mf + reg_weight * (text + image), :203-215 -- share the user table and the batch's users:
         # one autograd node (ops.bpr_loss_multi)
         B = users.shape[0]
-        rows = torch.cat((pos_items, neg_items), 0)
         if self._batch_idx is None or self._batch_idx[0].shape[0] != B or self._batch_idx[0].device != users.device:
             idx = torch.arange(B, device=users.device)
             self._batch_idx = (idx, idx + B)

@@ -436,15 +436,24 @@ __global__ __launch_bounds__(256) void draw_batch_kernel(
     const int64_t *__restrict__ edges, int64_t n_edges, const int64_t *__restrict__ hist_rowptr,
     const int32_t *__restrict__ hist_col, int B, int64_t num_user, uint32_t num_item, uint64_t seed, uint64_t step,
     const int64_t *__restrict__ step_dev, int64_t *__restrict__ out_users, int64_t *__restrict__ out_pos,
-    int64_t *__restrict__ out_neg) {
+    int64_t *__restrict__ out_neg, int64_t item_offset) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   if (step_dev) step += (uint64_t)step_dev[0];
   int64_t u, p, n;
   draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n, nullptr, 0);
   out_users[b] = u;
-  out_pos[b] = p;
-  out_neg[b] = n;
+  out_pos[b] = p + item_offset;      // (item_offset = num_user: the GLOBAL ids dataload.py:74-79 hands to Model.loss())
+  out_neg[b] = n + item_offset;
+}
+
+// rows = [pos - offset ; neg - offset]: Model.loss()'s first lines (Model/FREEDOM.py:195-196: pos_items - self.num_user,
+// neg_items - self.num_user) and the row list of the batch's 2 B items in one launch instead of three
+__global__ __launch_bounds__(256) void shift_cat_kernel(const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+                                                        int64_t offset, int B, int64_t *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= 2 * B) return;
+  out[b] = (b < B ? pos[b] : neg[b - B]) - offset;
 }
 
 }  // namespace chaorec
@@ -454,14 +463,23 @@ using namespace chaorec;
 extern "C" int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *hist_rowptr,
                                   const int32_t *hist_col, int32_t B, int64_t num_user, int32_t num_item,
                                   uint64_t seed, uint64_t step, const int64_t *step_dev, int64_t *out_users,
-                                  int64_t *out_pos, int64_t *out_neg, void *stream) {
+                                  int64_t *out_pos, int64_t *out_neg, int64_t item_offset, void *stream) {
   if (!edges || !hist_rowptr || !out_users || !out_pos || !out_neg)
     return fail(CHAOREC_E_INVALID, "draw_batch: NULL argument");
   if (B <= 0 || n_edges <= 0 || num_item <= 0) return fail(CHAOREC_E_INVALID, "draw_batch: bad sizes");
   hipLaunchKernelGGL(draw_batch_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, edges, n_edges,
                      hist_rowptr, hist_col, B, num_user, (uint32_t)num_item, seed, step, step_dev, out_users,
-                     out_pos, out_neg);
+                     out_pos, out_neg, item_offset);
   return check_launch("draw_batch_kernel");
+}
+
+extern "C" int chaorec_shift_cat_i64(const int64_t *pos, const int64_t *neg, int64_t offset, int32_t B, int64_t *out,
+                                     void *stream) {
+  if (!pos || !neg || !out) return fail(CHAOREC_E_INVALID, "shift_cat: NULL argument");
+  if (B <= 0) return fail(CHAOREC_E_INVALID, "shift_cat: B=%d", B);
+  hipLaunchKernelGGL(shift_cat_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, neg, offset, B,
+                     out);
+  return check_launch("shift_cat_kernel");
 }
 
 extern "C" int chaorec_bpr_fwd_f32(const float *tab_u, const float *tab_i, const int64_t *users,

@@ -496,8 +496,9 @@ def sample_negatives(hist, users, num_item, seed, step, id_offset, step_dev=None
     return out
 
 
-def draw_batch(edges, hist, B, num_user, num_item, seed, step, step_dev=None):
-    """(users, pos_local, neg_local) for one batch in ONE launch: uniform edge pick + gather + negative draw."""
+def draw_batch(edges, hist, B, num_user, num_item, seed, step, step_dev=None, item_offset=0):
+    """(users, pos_local + item_offset, neg_local + item_offset) for one batch in ONE launch: uniform edge pick + gather +
+    negative draw (item_offset = num_user: the global ids Model.loss() takes)."""
     rowptr, col = hist
     _need_cuda(edges, rowptr, col, step_dev)
     if edges.dtype != torch.int64 or not edges.is_contiguous():
@@ -505,9 +506,20 @@ def draw_batch(edges, hist, B, num_user, num_item, seed, step, step_dev=None):
     out = torch.empty((3, B), dtype=torch.int64, device=edges.device)
     rc = _lib.load().chaorec_draw_batch(_ptr(edges), edges.shape[0], _ptr(rowptr), _ptr(col), B, num_user, num_item,
                                         seed, step, _ptr(step_dev), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
-                                        _stream())
+                                        int(item_offset), _stream())
     _lib.check(rc, "chaorec_draw_batch")
     return out[0], out[1], out[2]
+
+
+def shift_cat(pos, neg, offset):
+    """(pos - offset, neg - offset, cat of the two) in one launch: the two halves are views of the row list."""
+    _need_cuda(pos, neg)
+    pos, neg = pos.to(torch.int64).contiguous(), neg.to(torch.int64).contiguous()
+    B = pos.numel()
+    rows = torch.empty(2 * B, dtype=torch.int64, device=pos.device)
+    _lib.check(_lib.load().chaorec_shift_cat_i64(_ptr(pos), _ptr(neg), int(offset), B, _ptr(rows), _stream()),
+               "chaorec_shift_cat_i64")
+    return rows[:B], rows[B:], rows
 
 
 # --------------------------------------------------------------------------------------------

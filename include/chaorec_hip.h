@@ -180,11 +180,16 @@ int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col
 /* One launch per training batch for a streaming trainer: B edges picked uniformly from `edges` ([n_edges, 2]
  * int64, GLOBAL item ids, device), their (user, positive) gathered and one negative drawn for each by the rule
  * above (same draw stream as chaorec_sample_negatives).  Replaces DataLoader(shuffle=True) +
- * TrainingDataset.__getitem__ (main.py:194-195, dataload.py:74-106).  Outputs LOCAL item ids. */
+ * TrainingDataset.__getitem__ (main.py:194-195, dataload.py:74-106).  Outputs LOCAL item ids + item_offset (ABI 9:
+ * item_offset = num_user gives the GLOBAL ids the reference's dataset hands to Model.loss()). */
 int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *hist_rowptr,
                        const int32_t *hist_col, int32_t B, int64_t num_user, int32_t num_item,
                        uint64_t seed, uint64_t step, const int64_t *step_dev, int64_t *out_users,
-                       int64_t *out_pos, int64_t *out_neg, void *stream);
+                       int64_t *out_pos, int64_t *out_neg, int64_t item_offset, void *stream);
+
+/* out[0:B] = pos - offset, out[B:2B] = neg - offset: Model.loss()'s id shift (Model/FREEDOM.py:195-196) and the row list of
+ * the batch's 2 B items in one launch (ABI 9). */
+int chaorec_shift_cat_i64(const int64_t *pos, const int64_t *neg, int64_t offset, int32_t B, int64_t *out, void *stream);
 
 /* The fused form the training loop uses (north_star: "fused BPR negative-sample + gather + pairwise-logsigmoid +
  * L2-reg kernel using wavefront shuffles"): chaorec_draw_batch + chaorec_bpr_fwd_f32 in ONE forward launch -- lane 0 of
