@@ -12,7 +12,7 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libchaorec_hip.so")
 SOURCES = ["spmm.hip", "bpr.hip", "score_topk.hip", "gemm.hip", "gemm_bf16x3.hip", "metrics.hip", "graph_dropout.hip",
-           "rowops.hip", "feature_adam.hip"]
+           "rowops.hip", "feature_adam.hip", "exchange.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
@@ -66,6 +66,8 @@ SIGNATURES = {
     "chaorec_draw_batch": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int64,
                                           ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr, c_ptr,
                                           ctypes.c_int64, c_ptr]),
+    "chaorec_exchange_pull_sum_f32": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, c_ptr, c_ptr]),
+    "chaorec_exchange_pull_gather_f32": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int64, c_ptr, c_ptr]),
     "chaorec_shift_cat_i64": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr, c_ptr]),
     "chaorec_score_topk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                             ctypes.c_int32]),

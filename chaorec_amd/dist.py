@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import graph, ops
+from . import _lib, graph, ops
 
 
 def partition_users_by_nnz(user_deg, world):
@@ -122,8 +122,9 @@ _FORCE_COLLECTIVES = _os.environ.get("CHAOREC_FORCE_COLLECTIVES", "0") == "1"
 #              once, and sums the 8 blocks it receives itself -- then the all-gather: 2 * bytes / 8 / 153 GB/s per
 #              half on a fully connected xGMI node (1.7 ms instead of 11.7 ms for config 5's 1.02 GB)
 # Same sums up to fp32 association.  No multi-GPU node was available to time them against each other.
-EXCHANGE_MODES = ("allreduce", "rs_ag", "direct")
+EXCHANGE_MODES = ("allreduce", "rs_ag", "direct", "p2p")
 DIRECT_FELL_BACK = False       # set when a captured step replaced `direct` by `rs_ag` (see _sum_exchange_async)
+DIRECT_WENT_P2P = False        # set when a captured step ran `direct` as the hand-written peer-to-peer exchange instead
 
 
 def exchange_mode():
@@ -136,6 +137,9 @@ def exchange_mode():
 def exchange_mode_used():
     """What the bench line reports: the mode asked for, and what captured steps ran instead where that differs."""
     m = exchange_mode()
+    if DIRECT_WENT_P2P:
+        return m + " (captured steps: p2p -- RCCL's all-to-all is not capturable on this stack; the same direct pattern as " \
+                   "pull kernels over IPC-mapped peer buffers)"
     return m + (" (captured steps: rs_ag -- RCCL's all-to-all is not capturable on this stack)" if DIRECT_FELL_BACK else "")
 
 
@@ -186,6 +190,96 @@ def _mean_all(x):
     return ops.mean_all(x) if x.is_cuda else x.mean()
 
 
+class P2PExchange:
+    """The `direct` exchange pattern (every row block crosses one xGMI link once: reduce-scatter by pull, all-gather by pull)
+    written by hand over IPC-mapped peer buffers -- plain kernel launches (csrc/exchange.hip), so a captured step can contain
+    it, which RCCL's all-to-all cannot on this stack.  Per buffer size every rank owns two "mailboxes" that all its peers map
+    once (torch's storage sharing = hipIpcGetMemHandle / hipIpcOpenMemHandle; set-up is a collective on the host and cannot
+    happen inside a capture): P for its partial, R (one row block) for the block it reduces.  One exchange: P <- partial;
+    barrier; R = sum of the ranks' P rows of my block, rank order; barrier; every rank's R into the caller's buffer.  Two
+    barriers per exchange are enough for any sequence of exchanges (csrc/exchange.hip).  The barrier is a one-element
+    all-reduce on the stream with RCCL (a kernel boundary on every rank); with gloo (the ranks-on-one-GPU tests) a stream
+    synchronisation + host barrier, eager only.
+    Never run across xGMI: the boxes of this build have one GPU; opt-in."""
+
+    _by_group = {}
+
+    @classmethod
+    def of(cls, group):
+        key = id(group) if group is not None else 0
+        if key not in cls._by_group:
+            cls._by_group[key] = cls(group)
+        return cls._by_group[key]
+
+    def __init__(self, group):
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.rccl = dist.get_backend(group) == "nccl"
+        self.boxes = {}          # numel -> dict(P, R: this rank's mailboxes; keep: the peers' mapped tensors; pP, pR: pointer arrays)
+        self.flag = None
+
+    def ready(self, numel):
+        return numel in self.boxes
+
+    def setup(self, numel, device):
+        """Collective, host-synchronous: allocate this rank's mailboxes for buffers of `numel` floats and map every peer's."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("P2PExchange.setup inside a hipGraph capture (run one eager step first)")
+        import ctypes
+        block = numel // self.world
+        mail = [torch.zeros(numel, dtype=torch.float32, device=device), torch.zeros(block, dtype=torch.float32, device=device)]
+        mine = [(m.untyped_storage()._share_cuda_(), m.storage_offset()) for m in mail]
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        keep, ptrs = [], []
+        for k, n in enumerate((numel, block)):
+            row = []
+            for r in range(self.world):
+                if r == self.rank:
+                    row.append(mail[k])
+                    continue
+                handle, off = everyone[r][k]
+                st = torch.UntypedStorage._new_shared_cuda(*handle)
+                row.append(torch.empty(0, dtype=torch.float32, device=device).set_(st, off, (n,)))
+            keep.append(row)
+            ptrs.append((ctypes.c_void_p * self.world)(*[t.data_ptr() for t in row]))
+        if self.flag is None:
+            self.flag = torch.zeros(1, dtype=torch.float32, device=device)
+        self.boxes[numel] = dict(P=mail[0], R=mail[1], keep=keep, pP=ptrs[0], pR=ptrs[1])
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+
+    def _barrier(self):
+        if self.rccl:
+            dist.all_reduce(self.flag, group=self.group)        # on the stream; capturable
+        else:
+            torch.cuda.current_stream().synchronize()
+            dist.barrier(group=self.group)
+
+    def exchange(self, buf):
+        """buf [rows_pad, D] fp32 on the GPU, rows_pad a multiple of the world size: summed over the ranks in place."""
+        numel = buf.numel()
+        if not self.ready(numel):
+            self.setup(numel, buf.device)
+        box = self.boxes[numel]
+        block = numel // self.world
+        lib = _lib.load()
+        stream = ops._stream()
+        box["P"].copy_(buf.reshape(-1))
+        self._barrier()
+        _lib.check(lib.chaorec_exchange_pull_sum_f32(box["pP"], self.world, self.rank * block, block, ops._ptr(box["R"]),
+                                                     stream), "chaorec_exchange_pull_sum_f32")
+        self._barrier()
+        _lib.check(lib.chaorec_exchange_pull_gather_f32(box["pR"], self.world, block, ops._ptr(buf), stream),
+                   "chaorec_exchange_pull_gather_f32")
+
+
+def _p2p_usable(buf, group):
+    return buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous() and \
+        (buf.numel() // dist.get_world_size(group)) % 4 == 0 and buf.shape[0] % dist.get_world_size(group) == 0 and \
+        dist.get_world_size(group) <= 16
+
+
 def _sum_exchange_async(buf, group):
     """Sum `buf` ([rows_pad, D], rows_pad a multiple of the world size) over the ranks, in place, asynchronously."""
     if not _active(group):
@@ -194,11 +288,27 @@ def _sum_exchange_async(buf, group):
     if mode == "direct" and buf.is_cuda and torch.cuda.is_current_stream_capturing():
         # RCCL's all-to-all cannot be captured on this stack (ROCm 7.2 / RCCL of torch 2.10: a captured
         # all_to_all_single hangs or segfaults even alone in a graph, tools/direct_capture_repro.py,
-        # profiles/r03_a_all_to_all_capture_repro.log; reduce-scatter and all-gather capture fine): a captured step that
-        # asked for `direct` gets the same two-phase exchange through RCCL's reduce-scatter instead
-        global DIRECT_FELL_BACK
-        DIRECT_FELL_BACK = True
-        mode = "rs_ag"
+        # profiles/r03_a_all_to_all_capture_repro.log; reduce-scatter and all-gather capture fine).  A captured step that
+        # asked for `direct` gets the same pattern from the hand-written peer-to-peer exchange when its mailboxes exist
+        # (an eager step ran first and CHAOREC_DIST_DIRECT_CAPTURE=p2p), else the two-phase exchange through RCCL's
+        # reduce-scatter
+        global DIRECT_FELL_BACK, DIRECT_WENT_P2P
+        if _os.environ.get("CHAOREC_DIST_DIRECT_CAPTURE", "rs_ag") == "p2p" and _p2p_usable(buf, group) and \
+                P2PExchange.of(group).ready(buf.numel()):
+            DIRECT_WENT_P2P = True
+            mode = "p2p"
+        else:
+            DIRECT_FELL_BACK = True
+            mode = "rs_ag"
+    elif mode == "direct" and buf.is_cuda and _os.environ.get("CHAOREC_DIST_DIRECT_CAPTURE", "rs_ag") == "p2p" and \
+            _p2p_usable(buf, group) and not P2PExchange.of(group).ready(buf.numel()):
+        P2PExchange.of(group).setup(buf.numel(), buf.device)       # (eager call: the mailboxes a later capture will use)
+    if mode == "p2p":
+        if not _p2p_usable(buf, group):
+            mode = "allreduce"
+        else:
+            P2PExchange.of(group).exchange(buf)
+            return _Pending(None)
     if mode == "allreduce" or buf.shape[0] % dist.get_world_size(group):
         return _Pending(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
     world, rank = dist.get_world_size(group), dist.get_rank(group)

@@ -38,7 +38,8 @@ extern "C" {
                                      (weight gradients), multi-tensor Adam;
                                   8: rows_mean (layer mean of exchanged rows: fused sharded LightGCN step);
                                   9: split-bf16 NN GEMM (input gradients, accumulate epilogue), MMGCN's layer tail
-                                     (leaky_cat_add / leaky_split_bwd), normalize_rows, multi-term BPR */
+                                     (leaky_cat_add / leaky_split_bwd), normalize_rows, multi-term BPR, draw_batch item_offset, shift_cat,
+                                     peer-to-peer exchange kernels */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -577,6 +578,21 @@ int chaorec_colsum_f32(const float *x, int64_t M, int64_t N, int64_t ldx, float 
                        size_t workspace_bytes, void *stream);
 int chaorec_sum_f32(const float *x, int64_t n, float scale, float *out, void *workspace, size_t workspace_bytes,
                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Peer-to-peer exchange of a sharded layer's item partial (the "direct" reduce-scatter + all-gather in which
+ * every row block crosses one xGMI link once), as two plain kernels over IPC-mapped peer buffers ("mailboxes"):
+ *   pull_sum:    out[0:n] = sum over r = 0..world-1, in that order, of peers[r][offset : offset + n]
+ *   pull_gather: out[r * block : (r + 1) * block] = peers[r][0 : block]   for every r
+ * peers: HOST array of `world` (<= 16) device pointers -- this rank's own mailbox at its own index, the others mapped from
+ * the peers' processes (hipIpcOpenMemHandle): the partial mailboxes (whole buffer) for pull_sum, the result mailboxes (one
+ * block) for pull_gather.  The caller orders the phases across the ranks (a barrier between mailbox write, pull_sum and
+ * pull_gather; chaorec_amd/dist.py: a one-element all-reduce on the stream).  offset, n, block in floats, multiples of 4.
+ * Plain launches: capturable in a hipGraph (ABI 9).
+ * ------------------------------------------------------------------------------------- */
+int chaorec_exchange_pull_sum_f32(const void *const *peers, int32_t world, int64_t offset, int64_t n, float *out,
+                                  void *stream);
+int chaorec_exchange_pull_gather_f32(const void *const *peers, int32_t world, int64_t block, float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Several BPR terms over ONE user table and one batch of users (Model/FREEDOM.py:203-215:

@@ -34,9 +34,10 @@ def _problem():
     return edges, x0, batches
 
 
-def _worker(rank, world, port, tmp, L):
+def _worker(rank, world, port, tmp, L, exchange="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CHAOREC_DIST_EXCHANGE"] = exchange
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -81,13 +82,119 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("L,world", [(1, 2), (3, 2), (2, 4)])
-def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world):
+def _p2p_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CHAOREC_DIST_EXCHANGE"] = "p2p"
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chaorec_amd import dist as cdist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    ok = True
+    for rows, D, reps in ((world * 300, 64, 5), (world * 7, 128, 3), (world * 300, 64, 2)):
+        for rep in range(reps):
+            g = torch.Generator().manual_seed(1000 * rows + 10 * rep + rank)
+            mine = torch.randn(rows, D, generator=g)
+            want = mine.clone()
+            dist.all_reduce(want)                                   # gloo, on the host: the reference sum
+            # the p2p sum adds the ranks in rank order: bit-identical to a rank-ordered host sum
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            ordered = parts[0].clone()
+            for q in parts[1:]:
+                ordered += q
+            buf = mine.to(dev)
+            cdist._sum_exchange_async(buf, None).wait()
+            torch.cuda.synchronize()
+            got = buf.cpu()
+            ok = ok and torch.equal(got, ordered) and torch.allclose(got, want, rtol=0, atol=1e-5)
+    px = cdist.P2PExchange.of(None)
+    np.savez(os.path.join(tmp, f"p2p{rank}.npz"), ok=ok, boxes=len(px.boxes), got=got.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rccl_worker(rank, world, port, tmp, exchange, direct_capture):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CHAOREC_DIST_EXCHANGE"] = exchange
+    os.environ["CHAOREC_DIST_DIRECT_CAPTURE"] = direct_capture
+    os.environ["CHAOREC_FORCE_COLLECTIVES"] = "1"          # a 1-rank group still issues every exchange
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from chaorec_amd import dist as cdist
+    from chaorec_amd.optim import FusedAdam
+    edges, x0, _ = _problem()
+    bounds = [0, U]
+    shard = cdist.UserShard.from_local(edges, bounds, I, world, rank, dev)
+    m = cdist.ShardedLightGCN(shard, None, D, 1e-3, 3, dev, seed=1).to(dev)
+    with torch.no_grad():
+        m.user_embedding.weight.copy_(x0[:U])
+        m.item_embedding.weight.copy_(x0[U:])
+    step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=True)
+    losses = []
+    for t in range(T):
+        rng = np.random.default_rng(100 * t)
+        sel = rng.choice(len(shard.local_edges), B, replace=False)
+        users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64)).to(dev)
+        pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64)).to(dev)
+        neg = torch.from_numpy(rng.integers(U, U + I, B)).to(dev)
+        losses.append(float(step(users, pos, neg)))
+    torch.cuda.synchronize()
+    np.savez(os.path.join(tmp, f"rccl_{exchange}_{direct_capture}.npz"), xu=m.user_embedding.weight.detach().cpu().numpy(),
+             xi=m.item_embedding.weight.detach().cpu().numpy(), losses=np.array(losses), used=cdist.exchange_mode_used())
+    dist.destroy_process_group()
+
+
+def test_captured_exchanges_on_a_one_rank_rccl_group():
+    """The fused sharded step CAPTURED in a hipGraph with its exchanges really issued through RCCL (1-rank group,
+    CHAOREC_FORCE_COLLECTIVES=1): all-reduce, the hand-written peer-to-peer exchange (barriers = one-element RCCL
+    all-reduces inside the graph), and `direct` run as p2p under capture -- three Adam steps, the same tables."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for exchange, dc in (("allreduce", "rs_ag"), ("p2p", "rs_ag"), ("direct", "p2p"), ("direct", "rs_ag")):
+            mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, exchange, dc), nprocs=1, join=True)
+            out[(exchange, dc)] = dict(np.load(os.path.join(tmp, f"rccl_{exchange}_{dc}.npz")))
+    ref = out[("allreduce", "rs_ag")]
+    for key, r in out.items():       # (two runs differ by the order of the BPR backward's atomic row adds: ~1e-7)
+        assert np.allclose(r["xu"], ref["xu"], rtol=0, atol=2e-6) and np.allclose(r["xi"], ref["xi"], rtol=0, atol=2e-6), key
+        assert np.allclose(r["losses"], ref["losses"], rtol=1e-6), key
+    assert "p2p" in str(out[("direct", "p2p")]["used"]) and "rs_ag" in str(out[("direct", "rs_ag")]["used"])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_exchange_sums_like_an_all_reduce(world):
+    """dist.P2PExchange (CHAOREC_DIST_EXCHANGE=p2p): IPC-mapped mailboxes + chaorec_exchange_pull_{sum,gather}_f32 between
+    `world` processes sharing one GPU -- repeated exchanges on the same mailboxes, several sizes: the rank-ordered sum bit for
+    bit, identical on every rank."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, _free_port(), tmp, L), nprocs=world, join=True)
+        mp.spawn(_p2p_worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
+        r = [np.load(os.path.join(tmp, f"p2p{k}.npz")) for k in range(world)]
+    assert all(bool(x["ok"]) for x in r)
+    assert all(int(x["boxes"]) == 2 for x in r)            # two buffer sizes -> two pairs of mailboxes, set up once each
+    for k in range(1, world):
+        assert np.array_equal(r[0]["got"], r[k]["got"])
+
+
+@pytest.mark.parametrize("L,world,exchange", [(1, 2, "allreduce"), (3, 2, "allreduce"), (2, 4, "allreduce"), (3, 2, "p2p"),
+                                              (2, 4, "p2p")])
+def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world, exchange):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(world, _free_port(), tmp, L, exchange), nprocs=world, join=True)
         r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
     # the whole-graph reference: the oracle's loss gradient of the mean over the ranks' batches + Adam, in fp64
     from chaorec_amd import dist as cdist
