@@ -515,6 +515,19 @@ constexpr int kSweepWaves = 4;
 #define CHAOREC_SWEEP_STAGE 2
 #endif
 constexpr int kSweepStage = CHAOREC_SWEEP_STAGE;
+#ifndef CHAOREC_SWEEP_PARK
+#define CHAOREC_SWEEP_PARK 8
+#endif
+#ifndef CHAOREC_SWEEP_PIPE
+#define CHAOREC_SWEEP_PIPE 0
+#endif
+constexpr bool kSweepPipe = CHAOREC_SWEEP_PIPE != 0;
+#ifndef CHAOREC_SWEEP_BFREE
+#define CHAOREC_SWEEP_BFREE 0
+#endif
+constexpr bool kSweepBranchFree = CHAOREC_SWEEP_BFREE != 0;
+constexpr int kSweepPark = CHAOREC_SWEEP_PARK;    // list entries per lane and user block parked in LDS (0: store each at once)
+static_assert(kSweepPark % 4 == 0 && kSweepPark <= kPfCap, "whole 16-byte stores inside a list");
 
 template <int D, int UB, bool BM>
 __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(const PrefArgs P) {
@@ -523,6 +536,11 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   // BM: the union of the block's hit masks per tile, 64 tiles at a time: [wave][user block][tile sequence % 64] words of
   // (half 1 mask << 16 | half 0 mask) -- the input of the block-joint selection (score_blocksel.hpp)
   __shared__ uint16_t bm_s[BM ? kSweepWaves : 1][BM ? UB : 1][BM ? 128 : 1];
+  // A lane's first kSweepPark list entries wait here ([entry][lane]: conflict-free) and leave as 16-byte stores after the
+  // sweep.  Every entry used to be its own 4-byte store into its own cache line -- 2.9 M separate L2 write requests per
+  // sports sweep (~100 entries per user): 14 of the kernel's 77 us (stage cut: hits counted but never stored).  A list
+  // gets ~5 entries per split: now one or two requests instead of five.
+  __shared__ uint32_t park_s[BM ? 1 : kSweepWaves][BM ? 1 : UB][BM ? 1 : kSweepPark + 1][BM ? 1 : 64];   // (+1: the pipelined form's dump row)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ur = lane & 31, h = lane >> 5;
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
@@ -599,8 +617,12 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
       //  masking them here put 42 more instructions into every tile's block for 31 rows of the whole table)
       // bit (15 - reg) <=> v_j > T_u: the accumulator's sign bit
       uint32_t qbits = 0;
+#if defined(CHAOREC_SWEEP_EXP) && CHAOREC_SWEEP_EXP == 2   // experiment (wrong result): one register's sign instead of sixteen
+      qbits = __float_as_uint(acc[0] + acc[7]) >> 31;
+#else
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(acc[reg]), 31);
+#endif
       if constexpr (BM) {
         // OR over the 32 lanes of each half: prefix-OR inside the rows of 16 (row_shr 1, 2, 4, 8), then lane 15 of rows
         // 0 / 2 into rows 1 / 3: lanes 31 and 63 hold their half's union and store it (one 2-byte LDS store, no list)
@@ -613,10 +635,97 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
         if (ur == 31) bm_s[wv][b][2 * (seq & 63) + h] = (uint16_t)x;
         continue;
       }
+#if defined(CHAOREC_SWEEP_EXP) && CHAOREC_SWEEP_EXP == 1   // experiment (wrong result): hits counted, never stored
+      cnt[b] += qbits != 0u;
+      continue;
+#endif
+      if constexpr (!BM && kSweepPark > 0 && kSweepBranchFree) {
+        // branch-free append: an entry without hits (or past the parked part of its list) goes to the dump row; only a
+        // list longer than kSweepPark entries in one split -- rare -- takes a branch
+        const bool hit = qbits != 0u;
+        const bool parked = hit && cnt[b] < kSweepPark;
+        const uint32_t entry = ((uint32_t)seq << 16) | qbits;
+        park_s[wv][b][parked ? cnt[b] : kSweepPark][lane] = entry;
+        if (__builtin_expect(__any(hit && !parked), 0)) {
+          if (hit && !parked && cnt[b] < kPfCap) mine[b][cnt[b]] = entry;
+        }
+        cnt[b] += hit ? 1 : 0;
+        continue;
+      }
       if (qbits) {
         // past kPfCap entries are counted, not stored: the selection sees the overflow and flags the user
-        if (cnt[b] < kPfCap) mine[b][cnt[b]] = ((uint32_t)seq << 16) | qbits;
+        const uint32_t entry = ((uint32_t)seq << 16) | qbits;
+        if constexpr (!BM && kSweepPark > 0) {
+          if (cnt[b] < kSweepPark) park_s[wv][b][cnt[b]][lane] = entry;
+          else if (cnt[b] < kPfCap) mine[b][cnt[b]] = entry;
+        } else {
+          if (cnt[b] < kPfCap) mine[b][cnt[b]] = entry;
+        }
         ++cnt[b];
+      }
+    }
+  };
+
+  // The pipelined form of `consume` for a whole stage (CHAOREC_SWEEP_PIPE, !BM): the waves of a SIMD run the same code in
+  // step (a barrier every stage), so with "all MFMAs of a tile, then its sign bits and list stores" the matrix pipe and the
+  // VALU take turns instead of running side by side -- 5 MFMAs (160 cycles) cost 400 per tile and user block.  Here a
+  // stage is ONE basic block: the MFMA chains of all its tiles, the sign-bit collection of tile i free to be scheduled
+  // between the MFMAs of tile i + 1, and a branch-free list append (an entry without hits goes to a dump row of the
+  // parking array); only the rare list overflow (more than kSweepPark entries in one split) branches.
+  auto consume_stage = [&](int buf, int s0) __attribute__((always_inline)) {
+    f32x16 accs[kSweepStage][UB];
+    uint32_t qb[kSweepStage][UB];
+#pragma unroll
+    for (int i = 0; i < kSweepStage; ++i) {
+      uint4 a[FR];
+#pragma unroll
+      for (int q = 0; q < FR; ++q) a[q] = stage[buf][i][q * 64 + lane];
+#pragma unroll
+      for (int b = 0; b < UB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[i][b][r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < D / 16; ++q) {
+        Frag16 f;
+        f.u = a[q];
+#pragma unroll
+        for (int b = 0; b < UB; ++b) accs[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v, bu[b][q], accs[i][b], 0, 0, 0);
+      }
+      Frag16 fa;
+      fa.u = a[D / 16];
+#pragma unroll
+      for (int b = 0; b < UB; ++b) accs[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bth[b], accs[i][b], 0, 0, 0);
+    }
+    bool spill = false;
+#pragma unroll
+    for (int i = 0; i < kSweepStage; ++i) {
+      const int seq = kSweepStage * s0 + i;
+      const bool live = split + seq * splits < n_tiles;      // block-uniform (a slot past the end holds a repeated tile)
+#pragma unroll
+      for (int b = 0; b < UB; ++b) {
+        uint32_t q = 0;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) q = __builtin_amdgcn_alignbit(q, __float_as_uint(accs[i][b][reg]), 31);
+        q = live ? q : 0u;
+        qb[i][b] = q;
+        const bool hit = q != 0u;
+        const bool parked = hit && cnt[b] < kSweepPark;
+        park_s[wv][b][parked ? cnt[b] : kSweepPark][lane] = ((uint32_t)seq << 16) | q;
+        spill |= hit && !parked;
+        cnt[b] += hit ? 1 : 0;
+      }
+    }
+    if (__builtin_expect(__any(spill), 0)) {                // some list is past its parked entries: redo the stage's appends
+#pragma unroll                                               // for those lanes in order (cnt already counts them)
+      for (int b = 0; b < UB; ++b) {
+        int c = cnt[b];
+#pragma unroll
+        for (int i = kSweepStage - 1; i >= 0; --i) {
+          if (qb[i][b]) {
+            --c;
+            if (c >= kSweepPark && c < kPfCap) mine[b][c] = ((uint32_t)(kSweepStage * s0 + i) << 16) | qb[i][b];
+          }
+        }
       }
     }
   };
@@ -671,6 +780,12 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   for (int s0 = 0; s0 < n_stages; ++s0) {
     const int buf = s0 & 1;
     if (s0 + 1 < n_stages) fetch(s0 + 1);
+    if constexpr (!BM && kSweepPipe && kSweepPark > 0) {
+      consume_stage(buf, s0);
+      if (s0 + 1 < n_stages) stash(buf ^ 1);
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < kSweepStage; ++i) {
       const int seq = kSweepStage * s0 + i;
@@ -701,6 +816,19 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   }
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
+    if constexpr (kSweepPark > 0) {
+      // the parked entries: a lane reads back its own column (its wave's LDS operations are ordered: no barrier) and
+      // writes four entries per store; slots past the count receive stale words the selection never reads
+#pragma unroll
+      for (int c0 = 0; c0 < kSweepPark; c0 += 4) {
+        if (c0 < cnt[b]) {
+          uint4 q;
+          q.x = park_s[wv][b][c0][lane], q.y = park_s[wv][b][c0 + 1][lane];
+          q.z = park_s[wv][b][c0 + 2][lane], q.w = park_s[wv][b][c0 + 3][lane];
+          *reinterpret_cast<uint4 *>(mine[b] + c0) = q;
+        }
+      }
+    }
     const int64_t uc = (ublock0 + b) * 32 + ur;
     if (uc < n_act) {
       const int64_t u = P.user_map ? (int64_t)P.user_map[uc] : uc;
