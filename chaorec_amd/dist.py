@@ -200,6 +200,7 @@ class P2PExchange:
     barriers per exchange are enough for any sequence of exchanges (csrc/exchange.hip).  The barrier is a one-element
     all-reduce on the stream with RCCL (a kernel boundary on every rank); with gloo (the ranks-on-one-GPU tests) a stream
     synchronisation + host barrier, eager only.
+    Needs every rank to see all the node's GPUs under the same indices (torchrun's default: LOCAL_RANK picks the device).
     Never run across xGMI: the boxes of this build have one GPU; opt-in."""
 
     _by_group = {}
@@ -239,8 +240,13 @@ class P2PExchange:
                     row.append(mail[k])
                     continue
                 handle, off = everyone[r][k]
-                st = torch.UntypedStorage._new_shared_cuda(*handle)
-                row.append(torch.empty(0, dtype=torch.float32, device=device).set_(st, off, (n,)))
+                st = torch.UntypedStorage._new_shared_cuda(*handle)      # opened on the OWNER's device index
+                t = torch.empty(0, dtype=torch.float32, device=st.device).set_(st, off, (n,))
+                if t.device != torch.device(device):
+                    # the pull kernels run on this rank's device and read the peer's memory through the mapping: peer
+                    # access must be on (torch switches it on in its device-to-device copy path)
+                    torch.empty(1, dtype=torch.float32, device=device).copy_(t[:1])
+                row.append(t)
             keep.append(row)
             ptrs.append((ctypes.c_void_p * self.world)(*[t.data_ptr() for t in row]))
         if self.flag is None:
