@@ -1108,10 +1108,15 @@ __device__ __forceinline__ uint64_t key_of_rank(uint64_t e0, uint64_t e1, int ra
 // segment (the result of the lane whose turn it is is kept); the next 16 candidates' rows fly under it.
 // (Tried, each bit-exact: a pipeline in which every lane's fma is a useful one, 4 lanes per row and 8 lanes per row
 //  with whole-line fetches, 2 to 12 row pieces in flight per lane: 112 and 170 us for this stage against 44 us.)
+#ifndef CHAOREC_SEL_G
+#define CHAOREC_SEL_G 4
+#endif
+constexpr int kSelG = CHAOREC_SEL_G;      // lanes per candidate row in the selection's re-score (2: half the chain instructions
+                                          // per candidate, twice the row registers)
 template <int D>
 __device__ __forceinline__ float chain_block(const float *__restrict__ item_emb, const uint32_t *cand_s, int base, int n_cand,
-                                             const float (&ua)[D / 8], const float (&ub)[D / 8], int lane) {
-  constexpr int G = 4, CPI = 64 / G, SEG = D / (2 * G);
+                                             const float (&ua)[D / (2 * kSelG)], const float (&ub)[D / (2 * kSelG)], int lane) {
+  constexpr int G = kSelG, CPI = 64 / G, SEG = D / (2 * G);
   const int l = lane % G, g = lane / G;
   auto load_rows = [&](float (&a)[SEG], float (&b)[SEG], int c) __attribute__((always_inline)) {
     const float *row = item_emb + (size_t)cand_s[c] * D;
@@ -1174,11 +1179,11 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
   int c = 0;
   if (lane < n_lists) c = P.cand_cnt[listidx];
   // this lane's segments of the user's row (chain_block)
-  float ua[D / 8], ub[D / 8];
+  float ua[D / (2 * kSelG)], ub[D / (2 * kSelG)];
   {
-    const float *urow = P.user_emb + (size_t)u * D + (D / 8) * (lane & 3);
+    const float *urow = P.user_emb + (size_t)u * D + (D / (2 * kSelG)) * (lane % kSelG);
 #pragma unroll
-    for (int i = 0; i < D / 8; i += 4) {
+    for (int i = 0; i < D / (2 * kSelG); i += 4) {
       const float4 x = reinterpret_cast<const float4 *>(urow)[i / 4], y = reinterpret_cast<const float4 *>(urow + D / 2)[i / 4];
       ua[i] = x.x, ua[i + 1] = x.y, ua[i + 2] = x.z, ua[i + 3] = x.w;
       ub[i] = y.x, ub[i + 1] = y.y, ub[i + 2] = y.z, ub[i + 3] = y.w;
