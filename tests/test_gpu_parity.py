@@ -765,6 +765,12 @@ def test_draw_batch_one_launch(dev, oracle, baby):
     assert all((int(a), int(b) + U) in train for a, b in zip(u[:500], p[:500]))    # picked pairs are training edges
     assert np.array_equal(n, oracle.sample_negatives(hist, u, I, seed=42, step=7, id_offset=0))
     assert len(np.unique(u)) > B // 4                                               # spread over the edge list
+    # global item ids straight from the launch (item_offset = num_user), and Model.loss()'s shift back + row list in one
+    ug, pg, ng = ops.draw_batch(edges, dh, B, U, I, 42, 2, step_dev=counter, item_offset=U)
+    assert np.array_equal(ug.cpu().numpy(), u) and np.array_equal(pg.cpu().numpy(), p + U) and np.array_equal(ng.cpu().numpy(), n + U)
+    pl, nl, rows = ops.shift_cat(pg, ng, U)
+    assert np.array_equal(pl.cpu().numpy(), p) and np.array_equal(nl.cpu().numpy(), n)
+    assert np.array_equal(rows.cpu().numpy(), np.concatenate([p, n])) and rows.data_ptr() == pl.data_ptr()
     u2, _, _ = ops.draw_batch(edges, dh, B, U, I, 42, 8)
     assert (u2.cpu().numpy() != u).mean() > 0.9
     # uniform over edges: users appear in proportion to their degree (chi-square on degree buckets)
