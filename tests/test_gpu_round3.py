@@ -240,8 +240,8 @@ def test_bpr_multi_one_launch_equals_term_by_term(dev, monkeypatch):
     l1, gu1, gi1 = run(4)
     l0, gu0, gi0 = run(0)
     assert float((l1 - l0).abs()) <= 2e-7 * float(l0.abs())
-    assert torch.allclose(gu1, gu0, rtol=0, atol=2e-7 * float(gu0.abs().max()))
+    assert torch.allclose(gu1, gu0, rtol=0, atol=1e-6 * float(gu0.abs().max()))          # (a few ulp of the largest addend)
     for a, b in zip(gi1, gi0):
-        assert torch.allclose(a, b, rtol=0, atol=2e-7 * float(b.abs().max()) + 1e-12)
+        assert torch.allclose(a, b, rtol=0, atol=1e-6 * float(b.abs().max()) + 1e-12)
     # deterministic forward
     assert torch.equal(run(4)[0], l1)
