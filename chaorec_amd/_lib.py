@@ -137,6 +137,11 @@ SIGNATURES = {
                                                  ctypes.c_int32, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_bpr_multi_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_int32,
                                                  ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "chaorec_gemm_nt_bf16x3_dual": (ctypes.c_int, [c_ptr] * 7 + [ctypes.c_int64] * 9 + [ctypes.c_int32, ctypes.c_int32, c_ptr]),
+    "chaorec_gemm_nn_bf16x3_dual_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    "chaorec_gemm_nn_bf16x3_dual": (ctypes.c_int, [c_ptr] * 5 + [ctypes.c_int64] * 9 + [c_ptr, ctypes.c_size_t, c_ptr]),
+    "chaorec_gemm_tn_bf16x3_dual_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    "chaorec_gemm_tn_bf16x3_dual": (ctypes.c_int, [c_ptr] * 5 + [ctypes.c_int64] * 9 + [c_ptr, ctypes.c_size_t, c_ptr]),
     "chaorec_leaky_cat_add_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.c_float, c_ptr]),
     "chaorec_leaky_split_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64,

@@ -281,7 +281,8 @@ constexpr int kRedLanes = 32;   // at most; the launch picks blockDim = 32 * lan
 __global__ __launch_bounds__(32 * kRedLanes) void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits,
                                                                           float *__restrict__ C, const float *__restrict__ bias,
                                                                           int64_t M, int64_t N, int64_t ldc, int accumulate,
-                                                                          int act) {
+                                                                          int act, float *__restrict__ C2, int64_t ldc2,
+                                                                          int64_t row_split) {   // rows m >= row_split -> C2
   __shared__ float part[kRedLanes][32];
   const int lanes = blockDim.x >> 5;
   const int e = threadIdx.x & 31, l = threadIdx.x >> 5;
@@ -305,10 +306,11 @@ __global__ __launch_bounds__(32 * kRedLanes) void gemm_reduce_slabs_kernel(const
   for (int k = 1; k < lanes; ++k) v = v + part[k][e];
   const int64_t m = i / N, n = i % N;
   if (bias) v = v + bias[n];
-  if (accumulate) v = C[m * ldc + n] + v;
+  float *out = m >= row_split ? C2 + (m - row_split) * ldc2 + n : C + m * ldc + n;
+  if (accumulate) v = *out + v;
   if (act == 1) v = v > 0.f ? v : v * 0.01f;
   if (act == 2) v = v > 0.f ? v : v * 0.2f;
-  C[m * ldc + n] = v;
+  *out = v;
 }
 
 struct GemmPlan {
@@ -452,7 +454,7 @@ extern "C" int chaorec_gemm_f32(const float *A, const float *B, float *C, const 
   int rc = check_launch("gemm_f32_kernel");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st, slabs,
-                     p.splits, C, bias, M, N, ldc, accumulate, act);
+                     p.splits, C, bias, M, N, ldc, accumulate, act, (float *)nullptr, (int64_t)0, (int64_t)INT64_MAX);
   return check_launch("gemm_reduce_slabs_kernel");
 }
 

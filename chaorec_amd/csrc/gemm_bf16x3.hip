@@ -70,7 +70,36 @@ __device__ __forceinline__ void split3x4(const float4 x, uint2 &h, uint2 &m, uin
 
 extern __global__ void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits, float *__restrict__ C,
                                                 const float *__restrict__ bias, int64_t M, int64_t N, int64_t ldc,
-                                                int accumulate, int act);
+                                                int accumulate, int act, float *__restrict__ C2, int64_t ldc2,
+                                                int64_t row_split);
+
+// Optional SECOND segments of the operands: a virtual concatenation without the copy, so that the two Linears MMGCN applies
+// to the same x (Model/MMGCN.py:102-131: conv.lin and linear_layer) run as ONE product each way --
+//   forward   x [Wc; Wl]^T       B's memory rows n >= b_split come from B2; columns n >= c_split of the result go to C2
+//                                (with bias2 / act2)
+//   gx        [gc | gu] [Wc; Wl] A's memory columns k >= a_split come from A2, B's memory rows k >= b_split from B2
+//   dW        [gc | gu]^T x      A's memory columns m >= a_split come from A2; rows m >= c_split of the result go to C2
+// A is always split along its memory COLUMN index, B along its memory ROW index, C along columns (c_rows = 0) or rows.
+// Splits are multiples of 4 and the second pointers 16-byte aligned: a float4 never straddles a boundary.
+struct X3Seg {
+  const float *A2;
+  const float *B2;
+  float *C2;
+  const float *bias2;
+  int64_t lda2, ldb2, ldc2;
+  int64_t a_split, b_split, c_split;     // INT64_MAX: no second segment
+  int act2, c_rows;
+};
+constexpr int64_t kNoSplit = INT64_MAX;
+static X3Seg no_seg() {
+  X3Seg g;
+  g.A2 = g.B2 = g.bias2 = nullptr;
+  g.C2 = nullptr;
+  g.lda2 = g.ldb2 = g.ldc2 = 0;
+  g.a_split = g.b_split = g.c_split = kNoSplit;
+  g.act2 = g.c_rows = 0;
+  return g;
+}
 
 // NT (TA = TB = false): A [M, K], B [N, K] (k contiguous in both: the forward and, through W^T, the input gradient of a Linear).
 // TN (TA = TB = true): A [K, M], B [K, N] (the reduction runs over the ROWS of both operands: the weight gradient
@@ -80,12 +109,20 @@ extern __global__ void gemm_reduce_slabs_kernel(const float *__restrict__ slabs,
 // TA / TB: the operand is k-MAJOR in memory (A [K, M] / B [K, N]).  (false, false) = NT, (true, true) = TN, (false, true)
 // = NN: C = A[M,K] . B[K,N] -- a Linear's input gradient gy . W with W as it lies in memory (W^T as a small copy in
 // front of every such product was ~20 launches of 4.6 us per MMGCN step).
-template <bool TA, bool TB, int XBN>
+template <bool TA, bool TB, int XBN, bool SEG = false>   // SEG: the operands have second segments (X3Seg)
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                              float *__restrict__ C, const float *__restrict__ bias,
                                                              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                                              int64_t ldc, int act, int64_t k_per_split,
-                                                             float *__restrict__ slabs, int accumulate) {
+                                                             float *__restrict__ slabs, int accumulate, const X3Seg seg_in) {
+  // (without SEG every split is the constant "none": the segment selects fold away)
+  X3Seg seg = seg_in;
+  if constexpr (!SEG) {
+    seg.A2 = seg.B2 = seg.bias2 = nullptr;
+    seg.C2 = nullptr;
+    seg.a_split = seg.b_split = seg.c_split = kNoSplit;
+    seg.c_rows = 0;
+  }
   __shared__ uint16_t As[3][XBM][XBK + XPAD];
   __shared__ uint16_t Bs[3][XBN][XBK + XPAD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -103,12 +140,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
 
   // this thread's float4s of a k-tile: A 128 x 32 = 1024 float4 (4 per thread), B 64 x 32 = 512 (2 per thread)
   float4 ra[4], rb[NB];
-  const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  auto load4 = [&](const float *base, int64_t ld, int64_t row, int64_t n_rows, int64_t k, bool vec) -> float4 {
+  const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                     (!seg.A2 || (((seg.lda2 | seg.a_split) & 3) == 0 && (reinterpret_cast<uintptr_t>(seg.A2) & 15) == 0));
+  const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) &&
+                     (!seg.B2 || ((seg.ldb2 & 3) == 0 && (reinterpret_cast<uintptr_t>(seg.B2) & 15) == 0));
+  // (row, k): indices of the VIRTUAL operand; col_split: its memory columns (k) past the split live in base2;
+  // row_split: its memory rows past the split live in base2
+  auto load4 = [&](const float *base, int64_t ld, int64_t row, int64_t n_rows, int64_t k, bool vec, const float *base2,
+                   int64_t ld2, int64_t col_split, int64_t row_split) -> float4 {
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < n_rows && k < ke) {
       const float *src = base + row * ld + k;
+      if (k >= col_split) src = base2 + row * ld2 + (k - col_split);
+      if (row >= row_split) src = base2 + (row - row_split) * ld2 + k;
       if (vec && k + 3 < ke) {
         x = *reinterpret_cast<const float4 *>(src);
       } else {
@@ -121,10 +165,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
     return x;
   };
   // TN: float4 along the m / n dimension of row k (zero past the matrix or past this slab's k range)
-  auto load4t = [&](const float *base, int64_t ld, int64_t k, int64_t col, int64_t n_cols, bool vec) -> float4 {
+  auto load4t = [&](const float *base, int64_t ld, int64_t k, int64_t col, int64_t n_cols, bool vec, const float *base2,
+                    int64_t ld2, int64_t col_split, int64_t row_split) -> float4 {
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < ke && col < n_cols) {
       const float *src = base + k * ld + col;
+      if (col >= col_split) src = base2 + k * ld2 + (col - col_split);
+      if (k >= row_split) src = base2 + (k - row_split) * ld2 + col;
       if (vec && col + 3 < n_cols) {
         x = *reinterpret_cast<const float4 *>(src);
       } else {
@@ -141,12 +188,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
   auto fetch = [&](int64_t k0) __attribute__((always_inline)) {
     if constexpr (TA) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ra[j] = load4t(A, lda, k0 + 4 * a_kq + j, m0 + 4 * a_mq, M, a_vec);
+      for (int j = 0; j < 4; ++j)
+        ra[j] = load4t(A, lda, k0 + 4 * a_kq + j, m0 + 4 * a_mq, M, a_vec, seg.A2, seg.lda2, seg.a_split, kNoSplit);
     } else {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int v = t + p * 256;                  // float4 index: row = v / 8, k4 = (v % 8) * 4
-        ra[p] = load4(A, lda, m0 + (v >> 3), M, k0 + ((v & 7) << 2), a_vec);
+        ra[p] = load4(A, lda, m0 + (v >> 3), M, k0 + ((v & 7) << 2), a_vec, seg.A2, seg.lda2, seg.a_split, kNoSplit);
       }
     }
     if constexpr (TB) {
@@ -154,12 +202,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
       for (int bb = 0; bb < NB / 2; ++bb)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          rb[2 * bb + j] = load4t(B, ldb, k0 + 2 * b_kp + j, n0 + 4 * (b_nq + 16 * bb), N, b_vec);
+          rb[2 * bb + j] = load4t(B, ldb, k0 + 2 * b_kp + j, n0 + 4 * (b_nq + 16 * bb), N, b_vec, seg.B2, seg.ldb2, kNoSplit,
+                                  seg.b_split);
     } else {
 #pragma unroll
       for (int p = 0; p < NB; ++p) {
         const int v = t + p * 256;
-        rb[p] = load4(B, ldb, n0 + (v >> 3), N, k0 + ((v & 7) << 2), b_vec);
+        rb[p] = load4(B, ldb, n0 + (v >> 3), N, k0 + ((v & 7) << 2), b_vec, seg.B2, seg.ldb2, kNoSplit, seg.b_split);
       }
     }
   };
@@ -261,19 +310,25 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
   for (int j = 0; j < NJ; ++j) {
     const int64_t n = n0 + j * 32 + r;
     if (n >= N) continue;
-    const float bv = (!to_slab && bias) ? bias[n] : 0.f;
+    const bool col2 = !seg.c_rows && n >= seg.c_split;            // this column belongs to the second output
+    float bv = 0.f;
+    if (!to_slab) bv = col2 ? (seg.bias2 ? seg.bias2[n - seg.c_split] : 0.f) : (bias ? bias[n] : 0.f);
+    const int a_here = col2 ? seg.act2 : act;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int64_t m = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
       if (m >= M) continue;
       float v = acc[j][q];
+      float *out = dst + m * ldd + n;
       if (!to_slab) {
+        if (col2) out = seg.C2 + m * seg.ldc2 + (n - seg.c_split);
+        if (seg.c_rows && m >= seg.c_split) out = seg.C2 + (m - seg.c_split) * seg.ldc2 + n;
         v = v + bv;
-        if (accumulate) v = dst[m * ldd + n] + v;
-        if (act == 1) v = v > 0.f ? v : v * 0.01f;
-        if (act == 2) v = v > 0.f ? v : v * 0.2f;
+        if (accumulate) v = *out + v;
+        if (a_here == 1) v = v > 0.f ? v : v * 0.01f;
+        if (a_here == 2) v = v > 0.f ? v : v * 0.2f;
       }
-      dst[m * ldd + n] = v;
+      *out = v;
     }
   }
 }
@@ -353,14 +408,14 @@ extern "C" int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, 
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
   if (XBN == 128)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 128>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K,
-                       lda, ldb, ldc, 0, p.k_per_split, slabs, 0);
+                       lda, ldb, ldc, 0, p.k_per_split, slabs, 0, no_seg());
   else
     hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 64>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K, lda,
-                       ldb, ldc, 0, p.k_per_split, slabs, 0);
+                       ldb, ldc, 0, p.k_per_split, slabs, 0, no_seg());
   int rc = check_launch("gemm_bf16x3_kernel<TN>");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st, slabs, p.splits, C,
-                     (const float *)nullptr, M, N, ldc, 0, 0);
+                     (const float *)nullptr, M, N, ldc, 0, 0, (float *)nullptr, (int64_t)0, kNoSplit);
   return check_launch("gemm_reduce_slabs_kernel");
 }
 
@@ -387,14 +442,14 @@ extern "C" int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, 
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
   if (XBN == 128)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 128>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
-                       p.k_per_split, slabs, 0);
+                       p.k_per_split, slabs, 0, no_seg());
   else
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 64>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
-                       p.k_per_split, slabs, 0);
+                       p.k_per_split, slabs, 0, no_seg());
   int rc = check_launch("gemm_bf16x3_kernel<NT>");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st, slabs, p.splits, C,
-                     bias, M, N, ldc, 0, act);
+                     bias, M, N, ldc, 0, act, (float *)nullptr, (int64_t)0, kNoSplit);
   return check_launch("gemm_reduce_slabs_kernel");
 }
 
@@ -419,13 +474,119 @@ extern "C" int chaorec_gemm_nn_bf16x3(const float *A, const float *B, float *C, 
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
   if (XBN == 128)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 128>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N,
-                       K, lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0);
+                       K, lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0, no_seg());
   else
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 64>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K,
-                       lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0);
+                       lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0, no_seg());
   int rc = check_launch("gemm_bf16x3_kernel<NN>");
   if (rc || p.splits == 1) return rc;
   hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st, slabs, p.splits, C,
-                     (const float *)nullptr, M, N, ldc, accumulate ? 1 : 0, 0);
+                     (const float *)nullptr, M, N, ldc, accumulate ? 1 : 0, 0, (float *)nullptr, (int64_t)0, kNoSplit);
+  return check_launch("gemm_reduce_slabs_kernel");
+}
+
+// ---- the two Linears MMGCN applies to the same x as ONE product each way (X3Seg) ---------------------------------------
+static bool seg_ok(const void *p, int64_t ld, int64_t split) {
+  return p && (ld & 3) == 0 && (split & 3) == 0 && split > 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
+// [C1 | C2] = act1/act2(A [B1; B2]^T + [bias1 | bias2]):  B1 [N1, K], B2 [N2, K], C1 [M, N1], C2 [M, N2]
+extern "C" int chaorec_gemm_nt_bf16x3_dual(const float *A, const float *B1, const float *B2, float *C1, float *C2,
+                                           const float *bias1, const float *bias2, int64_t M, int64_t N1, int64_t N2,
+                                           int64_t K, int64_t lda, int64_t ldb1, int64_t ldb2, int64_t ldc1, int64_t ldc2,
+                                           int32_t act1, int32_t act2, void *stream) {
+  if (!A || !B1 || !C1 || !C2) return fail(CHAOREC_E_INVALID, "gemm_nt_bf16x3_dual: NULL argument");
+  if (M < 0 || N1 <= 0 || N2 <= 0 || K <= 0 || act1 < 0 || act1 > 2 || act2 < 0 || act2 > 2)
+    return fail(CHAOREC_E_INVALID, "gemm_nt_bf16x3_dual: bad size / act");
+  if (!seg_ok(B2, ldb2, N1)) return fail(CHAOREC_E_INVALID, "gemm_nt_bf16x3_dual: N1, ldb2 multiples of 4, B2 16-byte aligned");
+  if (M == 0) return CHAOREC_OK;
+  const int64_t N = N1 + N2;
+  const XPlan p = plan_x(M, N, K);
+  if (p.splits != 1) return fail(CHAOREC_E_INVALID, "gemm_nt_bf16x3_dual: this shape wants split-K (call the two products separately)");
+  X3Seg g = no_seg();
+  g.B2 = B2, g.ldb2 = ldb2, g.b_split = N1;
+  g.C2 = C2, g.ldc2 = ldc2, g.c_split = N1, g.bias2 = bias2, g.act2 = act2;
+  const int XBN = pick_bn(N);
+  const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (XBN == 128)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 128, true>), grid, dim3(256), 0, st, A, B1, C1, bias1, M, N, K, lda, ldb1,
+                       ldc1, act1, p.k_per_split, (float *)nullptr, 0, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 64, true>), grid, dim3(256), 0, st, A, B1, C1, bias1, M, N, K, lda, ldb1,
+                       ldc1, act1, p.k_per_split, (float *)nullptr, 0, g);
+  return check_launch("gemm_bf16x3_kernel<NT, dual>");
+}
+
+// C = [A1 | A2] [B1; B2]:  A1 [M, K1], A2 [M, K2], B1 [K1, N], B2 [K2, N]  (gx = gc Wc + gu Wl in one accumulation)
+extern "C" size_t chaorec_gemm_nn_bf16x3_dual_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  return chaorec_gemm_nt_bf16x3_workspace_bytes(M, N, K);
+}
+extern "C" int chaorec_gemm_nn_bf16x3_dual(const float *A1, const float *A2, const float *B1, const float *B2, float *C,
+                                           int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t lda1, int64_t lda2,
+                                           int64_t ldb1, int64_t ldb2, int64_t ldc, void *workspace, size_t workspace_bytes,
+                                           void *stream) {
+  if (!A1 || !B1 || !C) return fail(CHAOREC_E_INVALID, "gemm_nn_bf16x3_dual: NULL argument");
+  if (M < 0 || N <= 0 || K1 <= 0 || K2 <= 0) return fail(CHAOREC_E_INVALID, "gemm_nn_bf16x3_dual: bad size");
+  if (!seg_ok(A2, lda2, K1) || !seg_ok(B2, ldb2, K1))
+    return fail(CHAOREC_E_INVALID, "gemm_nn_bf16x3_dual: K1, lda2, ldb2 multiples of 4, A2 / B2 16-byte aligned");
+  if (M == 0) return CHAOREC_OK;
+  const int64_t K = K1 + K2;
+  const XPlan p = plan_x(M, N, K);
+  const size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace))
+    return fail(CHAOREC_E_WORKSPACE, "gemm_nn_bf16x3_dual: workspace %zu < %zu", workspace_bytes, need);
+  X3Seg g = no_seg();
+  g.A2 = A2, g.lda2 = lda2, g.a_split = K1;
+  g.B2 = B2, g.ldb2 = ldb2, g.b_split = K1;
+  float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
+  const int XBN = pick_bn(N);
+  const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (XBN == 128)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 128, true>), grid, dim3(256), 0, st, A1, B1, C, (const float *)nullptr, M, N,
+                       K, lda1, ldb1, ldc, 0, p.k_per_split, slabs, 0, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 64, true>), grid, dim3(256), 0, st, A1, B1, C, (const float *)nullptr, M, N,
+                       K, lda1, ldb1, ldc, 0, p.k_per_split, slabs, 0, g);
+  int rc = check_launch("gemm_bf16x3_kernel<NN, dual>");
+  if (rc || p.splits == 1) return rc;
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st,
+                     slabs, p.splits, C, (const float *)nullptr, M, N, ldc, 0, 0, (float *)nullptr, (int64_t)0, kNoSplit);
+  return check_launch("gemm_reduce_slabs_kernel");
+}
+
+// [C1; C2] = [A1 | A2]^T B:  A1 [K, M1], A2 [K, M2], B [K, N], C1 [M1, N], C2 [M2, N]  (both weight gradients of the pair)
+extern "C" size_t chaorec_gemm_tn_bf16x3_dual_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  return chaorec_gemm_tn_bf16x3_workspace_bytes(M, N, K);
+}
+extern "C" int chaorec_gemm_tn_bf16x3_dual(const float *A1, const float *A2, const float *B, float *C1, float *C2, int64_t M1,
+                                           int64_t M2, int64_t N, int64_t K, int64_t lda1, int64_t lda2, int64_t ldb,
+                                           int64_t ldc1, int64_t ldc2, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!A1 || !B || !C1 || !C2) return fail(CHAOREC_E_INVALID, "gemm_tn_bf16x3_dual: NULL argument");
+  if (M1 <= 0 || M2 <= 0 || N <= 0 || K <= 0) return fail(CHAOREC_E_INVALID, "gemm_tn_bf16x3_dual: bad size");
+  if (!seg_ok(A2, lda2, M1)) return fail(CHAOREC_E_INVALID, "gemm_tn_bf16x3_dual: M1, lda2 multiples of 4, A2 16-byte aligned");
+  const int64_t M = M1 + M2;
+  const XPlan p = plan_x_tn(M, N, K);
+  const size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (need > workspace_bytes || (need && !workspace))
+    return fail(CHAOREC_E_WORKSPACE, "gemm_tn_bf16x3_dual: workspace %zu < %zu", workspace_bytes, need);
+  X3Seg g = no_seg();
+  g.A2 = A2, g.lda2 = lda2, g.a_split = M1;
+  g.C2 = C2, g.ldc2 = ldc2, g.c_split = M1, g.c_rows = 1;
+  float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
+  const int XBN = pick_bn(N);
+  const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (XBN == 128)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 128, true>), grid, dim3(256), 0, st, A1, B, C1, (const float *)nullptr, M, N, K,
+                       lda1, ldb, ldc1, 0, p.k_per_split, slabs, 0, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 64, true>), grid, dim3(256), 0, st, A1, B, C1, (const float *)nullptr, M, N, K,
+                       lda1, ldb, ldc1, 0, p.k_per_split, slabs, 0, g);
+  int rc = check_launch("gemm_bf16x3_kernel<TN, dual>");
+  if (rc || p.splits == 1) return rc;
+  hipLaunchKernelGGL(gemm_reduce_slabs_kernel, dim3((unsigned)((M * N + 31) / 32)), dim3(32 * reduce_lanes(p.splits, M * N)), 0, st,
+                     slabs, p.splits, C1, (const float *)nullptr, M, N, ldc1, 0, 0, C2, ldc2, M1);
   return check_launch("gemm_reduce_slabs_kernel");
 }

@@ -727,6 +727,58 @@ def gemm_nn_bf16x3(gy, weight, out=None, accumulate=False):
     return out
 
 
+def _dual_ok(*ts):
+    """Operands the dual (two-segment) GEMMs take: fp32, unit column stride, row strides multiples of 4, 16-byte aligned."""
+    return all(t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and
+               t.data_ptr() % 16 == 0 for t in ts)
+
+
+def gemm_nt_bf16x3_dual(x, w1, w2, b1, b2, act1, act2):
+    """(act1(x w1^T + b1), act2(x w2^T + b2)) in ONE launch (chaorec_gemm_nt_bf16x3_dual): two Linears over the same input."""
+    _need_cuda(x, w1, w2, b1, b2)
+    x, w1, w2 = _f32rows(x), _f32rows(w1), _f32rows(w2)
+    M, K, N1, N2 = x.shape[0], x.shape[1], w1.shape[0], w2.shape[0]
+    y1 = torch.empty((M, N1), dtype=torch.float32, device=x.device)
+    y2 = torch.empty((M, N2), dtype=torch.float32, device=x.device)
+    rc = _lib.load().chaorec_gemm_nt_bf16x3_dual(_ptr(x), _ptr(w1), _ptr(w2), _ptr(y1), _ptr(y2), _ptr(b1), _ptr(b2), M, N1, N2, K,
+                                                 x.stride(0), w1.stride(0), w2.stride(0), N1, N2, act1, act2, _stream())
+    _lib.check(rc, "chaorec_gemm_nt_bf16x3_dual")
+    return y1, y2
+
+
+def gemm_nn_bf16x3_dual(g1, g2, w1, w2):
+    """g1 w1 + g2 w2 as ONE product [g1 | g2] [w1; w2] (chaorec_gemm_nn_bf16x3_dual): the input gradient of two Linears over the
+    same input."""
+    _need_cuda(g1, g2, w1, w2)
+    g1, g2, w1, w2 = _f32rows(g1), _f32rows(g2), _f32rows(w1), _f32rows(w2)
+    M, K1, K2, N = g1.shape[0], g1.shape[1], g2.shape[1], w1.shape[1]
+    out = torch.empty((M, N), dtype=torch.float32, device=g1.device)
+    lib = _lib.load()
+    nbytes = lib.chaorec_gemm_nn_bf16x3_dual_workspace_bytes(M, N, K1 + K2)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=g1.device) if nbytes else None
+    rc = lib.chaorec_gemm_nn_bf16x3_dual(_ptr(g1), _ptr(g2), _ptr(w1), _ptr(w2), _ptr(out), M, N, K1, K2, g1.stride(0), g2.stride(0),
+                                         w1.stride(0), w2.stride(0), N, _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "chaorec_gemm_nn_bf16x3_dual")
+    return out
+
+
+def gemm_tn_bf16x3_dual(g1, g2, x):
+    """(g1^T x, g2^T x) as ONE product [g1 | g2]^T x (chaorec_gemm_tn_bf16x3_dual): both weight gradients of two Linears over the
+    same input."""
+    _need_cuda(g1, g2, x)
+    g1, g2, x = _f32rows(g1), _f32rows(g2), _f32rows(x)
+    K, M1, M2, N = g1.shape[0], g1.shape[1], g2.shape[1], x.shape[1]
+    o1 = torch.empty((M1, N), dtype=torch.float32, device=x.device)
+    o2 = torch.empty((M2, N), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.chaorec_gemm_tn_bf16x3_dual_workspace_bytes(M1 + M2, N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    rc = lib.chaorec_gemm_tn_bf16x3_dual(_ptr(g1), _ptr(g2), _ptr(x), _ptr(o1), _ptr(o2), M1, M2, N, K, g1.stride(0), g2.stride(0),
+                                         x.stride(0), N, N, _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "chaorec_gemm_tn_bf16x3_dual")
+    return o1, o2
+
+
 # which pipe nn.Linear's FORWARD runs on: "bf16x3" (split-bf16 MFMA, fp32-grade accuracy, 2.7x the f32 matrix rate) or
 # "f32" (the exact k-ascending fmaf chain of chaorec_gemm_f32); the backward GEMMs follow it.
 import os as _os
@@ -841,6 +893,9 @@ def leaky_split_bwd(gcat, cat, uy, d1, want_gid=False, slope=0.01):
 # "fused" (one autograd node per MMGCN layer, below) or "unfused" (the composition of linear / spmm / torch ops it
 # replaces; the two are bit-identical -- tests/test_gpu_models.py)
 MMGCN_LAYER = _os.environ.get("CHAOREC_MMGCN_LAYER", "fused")
+# inside the fused layer: conv.lin and linear_layer (two Linears over the same x) as ONE product each way
+# (chaorec_gemm_{nt,nn,tn}_bf16x3_dual); 0 = two products each way, bit-identical to the composition
+MMGCN_DUAL = _os.environ.get("CHAOREC_MMGCN_DUAL", "1") == "1"
 
 
 class _MMGCNLayer(torch.autograd.Function):
@@ -849,7 +904,9 @@ class _MMGCNLayer(torch.autograd.Function):
     as one autograd node: 5 launches forward (GEMM, SpMM, GEMM, tail, GEMM), and backward the concatenation's gradient is
     split, masked and made contiguous by one launch, x's two gradient flows meet in a GEMM epilogue.  The composition of
     ops.linear / ops.spmm / F.leaky_relu / + / torch.cat it replaces spent 7 torch launches per layer and direction on
-    the same data (DESIGN 8: the at::native share of the MMGCN step).  Same kernels, same arithmetic: bit-identical.
+    the same data (DESIGN 8: the at::native share of the MMGCN step).  Same kernels, same arithmetic: bit-identical --
+    except that at full size the two Linears over x (conv.lin, linear_layer) run as ONE product each way (MMGCN_DUAL:
+    forward bit-identical, the two backward products with another association of the same sums).
     `csr`: a graph.CSR, or a sharded graph operator with propagate_raw / propagate_t_raw (dist.ShardedGraph, joined form:
     the item rows' exchange happens inside).  `ax_aug` = the cached [A x | A 1 | 0] of a constant input (GCN._constant_input): then h = leaky_relu(ax_aug [Wc | bc |
     0]^T) is written by the GEMM straight into the concatenation's left columns and there is no SpMM either way."""
@@ -857,9 +914,17 @@ class _MMGCNLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, id_rows, Wc, bc, Wl, bl, Wg, bg, csr, ax_aug, pad):
         n, d1, d2 = x.shape[0], Wc.shape[0], Wl.shape[0]
-        uy = _linear_fwd_raw(x, Wl, bl, 1)
+        # conv.lin and linear_layer read the same x: ONE product each way where the split-bf16 pipe serves the shape
+        dual = (MMGCN_DUAL and ax_aug is None and LINEAR_FORWARD == "bf16x3" and n >= 4096 and 64 <= x.shape[1] < 512
+                and d1 % 4 == 0 and d2 % 4 == 0 and _dual_ok(x, Wc, Wl))
+        ctx.dual = dual
+        if dual:
+            c, uy = gemm_nt_bf16x3_dual(x, Wc, Wl, bc, bl, 0, 1)
+        else:
+            uy = _linear_fwd_raw(x, Wl, bl, 1)
         if ax_aug is None:
-            c = _linear_fwd_raw(x, Wc, bc, 0)
+            if not dual:
+                c = _linear_fwd_raw(x, Wc, bc, 0)
             s = csr.propagate_raw(c) if hasattr(csr, "propagate_raw") else spmm_raw(csr, c)
             cat = leaky_cat_add(s, uy, id_rows)
         else:
@@ -886,8 +951,16 @@ class _MMGCNLayer(torch.autograd.Function):
         gbg = col_sum(g1) if need[7] else None
         gcat = _linear_gx_raw(g1, Wg)
         gs, gu, gid = leaky_split_bwd(gcat, cat, uy, d1, want_gid=ctx.has_id and need[1])
-        gWl = _linear_gw_raw(gu, x) if need[4] else None
         gbl = col_sum(gu) if need[5] else None
+        if ax_aug is None and ctx.dual:
+            gc = ctx.csr.propagate_t_raw(gs) if hasattr(ctx.csr, "propagate_t_raw") else spmm_raw(ctx.csr.t(), gs)
+            gbc = col_sum(gc) if need[3] else None
+            gWc = gWl = None
+            if need[2] or need[4]:
+                gWc, gWl = gemm_tn_bf16x3_dual(gc, gu, x)            # [gc | gu]^T x
+            gx = gemm_nn_bf16x3_dual(gc, gu, Wc, Wl) if need[0] else None      # [gc | gu] [Wc; Wl]
+            return gx, gid, gWc, gbc, gWl, gbl, gWg, gbg, None, None, None
+        gWl = _linear_gw_raw(gu, x) if need[4] else None
         gx = _linear_gx_raw(gu, Wl) if need[0] else None
         if ax_aug is None:
             gc = ctx.csr.propagate_t_raw(gs) if hasattr(ctx.csr, "propagate_t_raw") else spmm_raw(ctx.csr.t(), gs)

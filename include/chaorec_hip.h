@@ -416,6 +416,25 @@ int chaorec_gemm_nn_bf16x3(const float *A, const float *B, float *C, int64_t M, 
                            int64_t ldb, int64_t ldc, int32_t accumulate, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* The two Linears MMGCN applies to the same x -- conv.lin (BasicGCN.py:40) and linear_layer (Model/MMGCN.py:104-131) -- as ONE
+ * product each way, their operands concatenated virtually (second pointers, no copies), same pipe and accuracy class (ABI 9):
+ *   nt_dual  [C1 | C2] = act1/act2( A [B1; B2]^T + [bias1 | bias2] )      B1 [N1, K], B2 [N2, K]; C1 [M, N1], C2 [M, N2]
+ *   nn_dual  C = [A1 | A2] [B1; B2]                                      A1 [M, K1], A2 [M, K2]; B1 [K1, N], B2 [K2, N]
+ *   tn_dual  [C1; C2] = [A1 | A2]^T B                                    A1 [K, M1], A2 [K, M2]; B [K, N]; C1 [M1, N], C2 [M2, N]
+ * The split sizes (N1 / K1 / M1) and the second operands' leading dimensions are multiples of 4, the second pointers 16-byte
+ * aligned.  nt_dual serves shapes without split-K only (error otherwise: call the products separately). */
+int chaorec_gemm_nt_bf16x3_dual(const float *A, const float *B1, const float *B2, float *C1, float *C2, const float *bias1,
+                                const float *bias2, int64_t M, int64_t N1, int64_t N2, int64_t K, int64_t lda, int64_t ldb1,
+                                int64_t ldb2, int64_t ldc1, int64_t ldc2, int32_t act1, int32_t act2, void *stream);
+size_t chaorec_gemm_nn_bf16x3_dual_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int chaorec_gemm_nn_bf16x3_dual(const float *A1, const float *A2, const float *B1, const float *B2, float *C, int64_t M,
+                                int64_t N, int64_t K1, int64_t K2, int64_t lda1, int64_t lda2, int64_t ldb1, int64_t ldb2,
+                                int64_t ldc, void *workspace, size_t workspace_bytes, void *stream);
+size_t chaorec_gemm_tn_bf16x3_dual_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int chaorec_gemm_tn_bf16x3_dual(const float *A1, const float *A2, const float *B, float *C1, float *C2, int64_t M1, int64_t M2,
+                                int64_t N, int64_t K, int64_t lda1, int64_t lda2, int64_t ldb, int64_t ldc1, int64_t ldc2,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Fused Adam step over one flat fp32 parameter (torch.optim.Adam defaults, main.py:397):
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;

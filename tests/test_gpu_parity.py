@@ -1099,6 +1099,34 @@ def test_gemm_nn_bf16x3_fp32_grade(dev, M, N, K):
         assert bool((wide_out[:, :8] == -7.0).all()) and bool((wide_out[:, 8 + N:] == -7.0).all())
 
 
+@pytest.mark.parametrize("M,K,N1,N2", [(60499, 64, 64, 64), (5000, 256, 256, 64), (777, 128, 64, 128), (300, 64, 4, 60)])
+def test_gemm_bf16x3_dual_products(dev, M, K, N1, N2):
+    """The two-segment GEMMs (two Linears over the same input as ONE product each way): the forward is bit-identical to the two
+    separate products (the same k-ordered accumulation per output element); the input gradient [g1 | g2] [w1; w2] and the
+    weight gradients [g1 | g2]^T x are fp32-grade against fp64 (other associations than two products + an add)."""
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(M + K + N1)
+    x = torch.randn(M, K, device=dev, generator=g)
+    w1, w2 = torch.randn(N1, K, device=dev, generator=g) * 0.1, torch.randn(N2, K, device=dev, generator=g) * 0.1
+    b1, b2 = torch.randn(N1, device=dev, generator=g), torch.randn(N2, device=dev, generator=g)
+    y1, y2 = ops.gemm_nt_bf16x3_dual(x, w1, w2, b1, b2, 0, 1)
+    assert torch.equal(y1, ops.gemm_nt_bf16x3(x, w1, bias=b1, act=0)) and torch.equal(y2, ops.gemm_nt_bf16x3(x, w2, bias=b2, act=1))
+    g1, g2 = torch.randn(M, N1, device=dev, generator=g), torch.randn(M, N2, device=dev, generator=g)
+    gx = ops.gemm_nn_bf16x3_dual(g1, g2, w1, w2)
+    ref = g1.double() @ w1.double() + g2.double() @ w2.double()
+    mass = g1.double().abs() @ w1.double().abs() + g2.double().abs() @ w2.double().abs()
+    assert bool(((gx.double() - ref).abs() <= 1e-6 * mass + 1e-30).all())
+    d1, d2 = ops.gemm_tn_bf16x3_dual(g1, g2, x)
+    for got, gg in ((d1, g1), (d2, g2)):
+        ref = gg.double().t() @ x.double()
+        mass = gg.double().abs().t() @ x.double().abs()
+        assert bool(((got.double() - ref).abs() <= 1e-6 * mass + 1e-30).all())
+    assert torch.equal(gx, ops.gemm_nn_bf16x3_dual(g1, g2, w1, w2))              # deterministic
+    d1b, d2b = ops.gemm_tn_bf16x3_dual(g1, g2, x)
+    assert torch.equal(d1, d1b) and torch.equal(d2, d2b)
+
+
 def test_linear_forward_pipes_agree(dev):
     """ops.linear on either pipe: same autograd contract, outputs equal to fp32 rounding, identical backward kernels."""
     from chaorec_amd import ops
