@@ -245,3 +245,47 @@ def test_bpr_multi_one_launch_equals_term_by_term(dev, monkeypatch):
         assert torch.allclose(a, b, rtol=0, atol=1e-6 * float(b.abs().max()) + 1e-12)
     # deterministic forward
     assert torch.equal(run(4)[0], l1)
+
+
+def test_mmgcn_branches_on_two_streams_train_like_one_stream(dev, monkeypatch):
+    """CHAOREC_MMGCN_STREAMS (the visual branch on a side stream, forward and backward): six CAPTURED training steps at a size
+    that takes the split-bf16 pipe and the dual products -- every parameter equal to the one-stream run up to the order of
+    the BPR backward's atomic adds; repeated three times (a race between the streams would show as a large, varying error)."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MMGCN
+    import sys
+    mm = sys.modules["chaorec_amd.Model.MMGCN"]          # (the package re-exports the class under the module's name)
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B = 6000, 2500, 40000, 512
+    edges = synthetic_interactions(U, I, E, seed=3)
+    uid = graph.user_item_dict_from_edges(edges)
+    g = torch.Generator().manual_seed(4)
+    v_feat, t_feat = torch.randn(I, 128, generator=g), torch.randn(I, 256, generator=g)
+    rng = np.random.default_rng(9)
+    batches = []
+    for _ in range(6):
+        sel = rng.choice(E, B, replace=False)
+        u = torch.from_numpy(edges[sel, 0].astype(np.int64))
+        pos = torch.from_numpy(edges[sel, 1].astype(np.int64))
+        neg = torch.from_numpy(rng.integers(U, U + I, B))
+        batches.append((torch.stack((u, u), 1).to(dev), torch.stack((pos, neg), 1).to(dev)))
+
+    def run(streams):
+        monkeypatch.setattr(mm, "BRANCH_STREAMS", streams)
+        torch.manual_seed(21)
+        m = MMGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, "add", "False", True, dev).to(dev)
+        opt = FusedAdam(m.parameters(), lr=1e-3)
+        step = GraphedTrainStep(m, opt, example_batch=batches[0])
+        for b in batches:
+            step(*b)
+        torch.cuda.synchronize()
+        return {n: p.detach().clone() for n, p in m.named_parameters()}
+
+    ref = run(False)
+    for rep in range(3):
+        got = run(True)
+        for n in ref:
+            d = (got[n] - ref[n]).abs()
+            # (Adam turns a gradient that is all atomics-order noise into a full step: allow a handful of such elements)
+            assert float((d > 1e-5).float().mean()) <= 1e-3 and float(d.median()) <= 1e-6, (rep, n, float(d.max()))
