@@ -106,7 +106,8 @@ __global__ __launch_bounds__(WAVES * 64) void adam_lowrank_dense_kernel(LowrankA
   const bool col_ok = c0 < a.K;
   // step count and bias corrections of this step: one thread, handed over through the (not yet filled) strip buffer
   if (threadIdx.x == 0) {
-    const int step = a.step_dev ? a.step_dev[0] : a.step_host;
+    // (device counter + host offset: a launch issued BEFORE the optimizer advanced the counter passes offset 1)
+    const int step = a.step_dev ? a.step_dev[0] + a.step_host : a.step_host;
     adam_bias_corrections(step, a.ac.b1, a.ac.b2, w_s[0], w_s[1]);
   }
   __syncthreads();

@@ -30,6 +30,10 @@ def _adjacent_run(first, candidates):
     return run or [first]
 
 
+# GraphedTrainStep: claimed tables' updates on a side stream beside the rest of the backward (opt-in: FREEDOM's captured step
+# 0.496 -> 0.476 ms at best -- the table update fills every CU, so the backward's small launches queue behind its workgroups
+# -- and 0.56 / 1.26 ms with other stream priorities: not worth a default)
+EARLY_TABLES = os.environ.get("CHAOREC_EARLY_ADAM", "0") == "1"
 BIAS_TABLE_STEPS = 1 << 16
 MULTI_TENSOR_BELOW = 1 << 20      # parameter runs with fewer elements share one Adam launch (chaorec_adam_multi_f32)
 
@@ -52,6 +56,10 @@ class FusedAdam(torch.optim.Optimizer):
         self._claimed = {}      # id(parameter) -> its group
         self._dense_read = set()  # id(claimed parameter) read as a whole by ops.linear: never updated lazily (submit())
         self._bc_table = None
+        # early_tables: the dense updates of claimed tables are launched on a side stream by submit(), step() joins them.
+        # Only for loops with exactly one backward() per step() and no gradient exchange in between -- GraphedTrainStep
+        # switches it on for itself.
+        self._early, self._side, self.early_tables = set(), None, False
         for group in self.param_groups:
             for p in group["params"]:
                 if getattr(p, "_chaorec_projected_only", False) and p.dim() == 2 and p.shape[1] % 4 == 0 \
@@ -73,13 +81,38 @@ class FusedAdam(torch.optim.Optimizer):
         if dense_reader and id(p) not in self._dense_read:
             self._make_dense(p)
         cur = self._pending.get(p)
+        if cur is not None and p in self._early:
+            raise RuntimeError("FusedAdam.early_tables: a second backward() reached a claimed table before step() -- its "
+                               "update is already running (set early_tables = False for gradient accumulation)")
         if cur is None:
             self._pending[p] = [gy_full, weight, row_token]
+            if self.early_tables:
+                self._launch_early(p)
         else:
             if cur[1] is not weight:
                 raise ValueError("FusedAdam: one claimed feature table, two different projections")
             cur[0] = cur[0] + gy_full            # gradient accumulation over several backward() calls
             cur[2] = None                        # (more than one batch: the step scans gy for the rows instead)
+
+    def _launch_early(self, p):
+        """early_tables: the dense update of a claimed table starts the moment its gradient (gy, W) exists -- on a side
+        stream, beside the rest of the backward pass (FREEDOM: the 46.6 M-element image table's update is HBM-bound for
+        ~235 us while the propagate's backward is a chain of small launches).  Needs the moments and the step counter
+        (from the second step on) and the dense mode; step() joins the stream before it advances the counter."""
+        st = self.state.get(p)
+        if not p.is_cuda or self._step_dev is None or not st or "exp_avg" not in st or (self.lazy_rows and "last" in st):
+            return
+        gy_full, weight, _ = self._pending[p]
+        group = self._claimed[id(p)]
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=p.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side), torch.no_grad():
+            # (step offset 1: the device counter still holds the previous step's number)
+            ops.adam_lowrank(p.data, gy_full, weight, st["exp_avg"], st["exp_avg_sq"], 1, group["lr"], group["betas"],
+                             group["eps"], group["weight_decay"], step_dev=self._step_dev, mode=0)
+        self._early.add(p)
 
     def reduce_pending(self, p, reduce_fn):
         """Multi-process training (dist.ShardedFREEDOM.sync_grads): sum the ranks' gy of a claimed table in place; the
@@ -102,6 +135,9 @@ class FusedAdam(torch.optim.Optimizer):
                 st.pop(k, None)
 
     def zero_grad(self, set_to_none=True):
+        if self._early:          # (an update already running cannot be recalled: early_tables is for backward -> step loops)
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._early.clear()
         self._pending.clear()
         super().zero_grad(set_to_none=set_to_none)
 
@@ -200,11 +236,15 @@ class FusedAdam(torch.optim.Optimizer):
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=next(iter(self._pending)).device)
         for p in self._pending:
             self._lowrank_state(p)
+        if self._early:          # updates already running on the side stream read the counter and W: join before either moves
+            torch.cuda.current_stream().wait_stream(self._side)
         if self._step_dev is not None:
             self._step_dev.add_(1)
         # claimed feature tables first: their update reads the projection weight of THIS step, which the loop below
         # updates
         for p, (gy_full, weight, row_token) in self._pending.items():
+            if p in self._early:
+                continue
             group, st = self._claimed[id(p)], self.state[p]
             # the row list of this batch's catch-up serves the update too (the gradient is zero in every other row) --
             # unless another forward has re-listed since: then the update finds its rows by scanning gy
@@ -216,6 +256,7 @@ class FusedAdam(torch.optim.Optimizer):
                              group["eps"], group["weight_decay"], step_dev=self._step_dev,
                              mode=1 if lazy else 0, last=st.get("last") if lazy else None, bc_table=self._bc_table, rowlist=rl)
         self._pending.clear()
+        self._early.clear()
         for group in self.param_groups:
             live = [p for p in group["params"] if p.grad is not None]
             small = []
@@ -270,6 +311,8 @@ class GraphedTrainStep:
         self.model, self.optimizer, self.batch_fn = model, optimizer, batch_fn
         self.loss_fn = loss_fn or model.loss
         self.after_backward = after_backward
+        if isinstance(optimizer, FusedAdam) and after_backward is None and EARLY_TABLES:
+            optimizer.early_tables = True      # this step is exactly zero_grad -> loss -> backward -> step, nothing between
         self._seed = None
         dev = next(model.parameters()).device
         self.static = [b.to(dev).clone() for b in example_batch] if example_batch is not None else None

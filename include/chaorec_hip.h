@@ -482,6 +482,9 @@ int chaorec_adam_multi_f32(int32_t count, float *const *param, const float *cons
  * which is what mode 0 does to it; mode 3 then needs no flag array (gy may be NULL).  rows_given == 0: the launch
  * fills the list itself with the rows whose gy (or flag) row is non-zero (rowcap >= n_rows).
  *
+ * mode 0 with step_dev: the step used is *step_dev + step (ABI 9) -- a launch issued before the optimizer advanced its device
+ * counter (on a side stream, beside the rest of the backward pass) passes step = 1, every other caller 0.
+ *
  * chaorec_unique_rows: list[0 .. *count) = the distinct values of rows[0 .. n) (item ids of a batch, duplicates
  * allowed; ids outside [0, n_rows) are dropped), order unspecified.  claim: int32 [n_rows] scratch and stamp_dev: int32 [1], both zero-initialised once and
  * then left to the launches: each one takes the stamp *stamp_dev + 1, marks the rows it lists with it and stores it

@@ -289,3 +289,37 @@ def test_mmgcn_branches_on_two_streams_train_like_one_stream(dev, monkeypatch):
             d = (got[n] - ref[n]).abs()
             # (Adam turns a gradient that is all atomics-order noise into a full step: allow a handful of such elements)
             assert float((d > 1e-5).float().mean()) <= 1e-3 and float(d.median()) <= 1e-6, (rep, n, float(d.max()))
+
+
+def test_fused_adam_early_tables_equal_the_in_step_update(dev):
+    """FusedAdam.early_tables (a claimed table's dense update launched by submit() on a side stream, step offset 1, joined by
+    step() before the counter moves): four eager steps of a Linear over a claimed table, bit-identical to the in-step update."""
+    from chaorec_amd import ops
+    from chaorec_amd.optim import FusedAdam
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    t0 = torch.randn(3000, 256, device=dev, generator=g)
+    w0 = torch.randn(64, 256, device=dev, generator=g) * 0.05
+    rows = [torch.randperm(3000, device=dev, generator=g)[:512] for _ in range(4)]     # (distinct: index_add_ stays deterministic)
+    tgt = torch.randn(512, 64, device=dev, generator=g)
+
+    def run(early):
+        table = torch.nn.Parameter(t0.clone())
+        table._chaorec_projected_only = True
+        lin = torch.nn.Linear(256, 64, bias=True).to(dev)
+        with torch.no_grad():
+            lin.weight.copy_(w0)
+            lin.bias.zero_()
+        opt = FusedAdam([table, lin.weight, lin.bias], lr=1e-2)
+        opt.early_tables = early
+        for r in rows:
+            opt.zero_grad()
+            y = ops.linear_rows(table, r, lin.weight, lin.bias)
+            ((y - tgt) ** 2).mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return table.detach().clone(), lin.weight.detach().clone()
+
+    ta, wa = run(False)
+    tb, wb = run(True)
+    assert torch.equal(ta, tb) and torch.equal(wa, wb)
