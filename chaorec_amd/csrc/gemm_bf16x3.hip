@@ -29,6 +29,12 @@ namespace chaorec {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef CHAOREC_X3_WAVE2X2
+#define CHAOREC_X3_WAVE2X2 1
+#endif
+// 128-wide tiles: waves as 2 x 2 of 64 x 64 instead of 4 x 1 of 32 x 128 (12 LDS fragment reads per 24 MFMAs instead of 15:
+// 768 x 768 x 60 499 TN 683 -> 658 us, NT 552 -> 546 us; same bits)
+constexpr bool kWave2x2 = CHAOREC_X3_WAVE2X2 != 0;
 constexpr int XBM = 128, XBK = 32, XPAD = 8;   // (row stride 40 bf16 = 80 B: 16-B aligned, banks skewed)
 // N tile: 64 (the skinny projections, N = 64: one tile covers the output's width) or 128 (wide outputs: every staged and
 // split A element then feeds twice the MFMAs -- the three-plane split is VALU work of the same order as the MFMA time)
@@ -274,6 +280,37 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
     stash();
     __syncthreads();
     if (k0 + XBK < ke) fetch(k0 + XBK);           // next tile's loads fly under this tile's MFMAs
+    if constexpr (XBN == 128 && kWave2x2) {
+      // 2 x 2 waves of 64 x 64 (accumulator j = 2 i + jj: rows 64 (wave / 2) + 32 i, columns 64 (wave % 2) + 32 jj): two A
+      // and two B fragments per plane feed the four accumulators -- 12 LDS reads per 24 MFMAs instead of 15
+#pragma unroll
+      for (int ks = 0; ks < XBK; ks += 16) {
+        Frag8 a2[2][3], b2[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int R = 64 * (wave >> 1) + 32 * i + r, Rn = 64 * (wave & 1) + 32 * i + r;
+            const int arow = TA ? 32 * (R & 3) + (R >> 2) : R;
+            const int brow = TB ? 64 * (Rn >> 6) + 16 * (Rn & 3) + ((Rn & 63) >> 2) : Rn;
+            a2[i][pl].u = *reinterpret_cast<const uint4 *>(&As[pl][arow][ks + 8 * h]);
+            b2[i][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][brow][ks + 8 * h]);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * i + jj;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i][1].v, b2[jj][1].v, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i][2].v, b2[jj][0].v, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i][0].v, b2[jj][2].v, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i][1].v, b2[jj][0].v, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i][0].v, b2[jj][1].v, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i][0].v, b2[jj][0].v, acc[j], 0, 0, 0);
+          }
+      }
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < XBK; ks += 16) {
       Frag8 a[3], b[NJ][3];
@@ -306,9 +343,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
   const bool to_slab = slabs != nullptr;
   float *dst = to_slab ? slabs + (size_t)blockIdx.z * (size_t)M * (size_t)N : C;
   const int64_t ldd = to_slab ? N : ldc;
+  constexpr bool W22 = XBN == 128 && kWave2x2;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int64_t n = n0 + j * 32 + r;
+    const int64_t n = n0 + (W22 ? 64 * (wave & 1) + 32 * (j & 1) : j * 32) + r;
     if (n >= N) continue;
     const bool col2 = !seg.c_rows && n >= seg.c_split;            // this column belongs to the second output
     float bv = 0.f;
@@ -316,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
     const int a_here = col2 ? seg.act2 : act;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int64_t m = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      const int64_t m = m0 + (W22 ? 64 * (wave >> 1) + 32 * (j >> 1) : wave * 32) + (q & 3) + 8 * (q >> 2) + 4 * h;
       if (m >= M) continue;
       float v = acc[j][q];
       float *out = dst + m * ldd + n;
