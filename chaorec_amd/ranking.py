@@ -124,14 +124,11 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
             # one that they do -- a dot product's k-ascending chain only gains +0 * 0 terms, the scores keep their bits
             wide = next(w for w in (8, 16, 32, 64, 128) if w >= D) if D < 128 else (D + 63) // 64 * 64
             result = torch.cat((result, result.new_zeros(result.shape[0], wide - D)), 1)
-        if state is not None:
-            hint = state.buffer(num_user, result.device)
-            hinted = state.use_hints(num_user)
         ue = result[:num_user]
         ie = items.detach() if items is not None else result[num_user:num_user + num_item]
         if state is not None:
             hint = state.buffer(num_user, result.device)
-            hinted = state.use_hints(num_user)
+            hinted = state.use_hints(num_user)          # (once per call: it consumes the previous call's counters)
             idx, _ = ops.score_topk(ue, ie, hist, mask_value, topk, id_offset=id_offset, hint=hint, hint_valid=hinted,
                                     hint_rank=hint_rank_for(topk), light=hinted and state.light(),
                                     counters=state.counters, idx_out=host)

@@ -323,3 +323,30 @@ def test_fused_adam_early_tables_equal_the_in_step_update(dev):
     ta, wa = run(False)
     tb, wb = run(True)
     assert torch.equal(ta, tb) and torch.equal(wa, wb)
+
+
+def test_gene_ranklist_reaches_the_light_mode(dev, monkeypatch):
+    """ranking.gene_ranklist consumes the previous call's queue counters ONCE per call (RankState.use_hints): from the third
+    evaluation of unchanged tables on, the call carries thresholds AND runs without the retry pass (light), and the lists
+    stay identical."""
+    from chaorec_amd import ops, ranking
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    U, I, D = 3000, 5000, 64
+    res = torch.randn(U + I, D, device=dev, generator=g) * 0.1
+    hist = (torch.arange(U + 1, dtype=torch.int64, device=dev) * 0, torch.zeros(1, dtype=torch.int32, device=dev))
+    seen = []
+    real = ops.score_topk
+
+    def spy(*a, **k):
+        seen.append((bool(k.get("hint_valid")), bool(k.get("light"))))
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops, "score_topk", spy)
+    state = ranking.RankState()
+    lists = []
+    for _ in range(4):
+        lists.append(ranking.gene_ranklist(res, U, I, hist, 1e-6, 50, to_cpu=False, state=state).clone())
+        torch.cuda.synchronize()
+    assert seen[0] == (False, False) and seen[1][0] and seen[-1] == (True, True), seen
+    assert all(torch.equal(lists[0], x) for x in lists[1:])
