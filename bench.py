@@ -2,13 +2,14 @@
 """bench.py -- the hot path's headline numbers on MI355X.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W          # spawns its own N ranks (before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): LightGCN, Amazon-sports shape (U=28940, I=15207,
-E=158554 -> 317108 directed edges), dim=64, n_layers=3, batch 1024.  The reference's Data/
-does not exist on the GPU box, so the graph is synthetic with the same shape and degree profile
-(chaorec_amd/synthetic.py) and the embeddings are xavier-initialised under seed 42.
+Workload (BASELINE.json configs[1]): LightGCN on the REAL Amazon-sports interaction graph (U=28940, I=15207,
+E=158554 -> 317108 directed edges; the reference's Data/sports/train.npy travels with the repository as a packed
+fixture, tests/golden/sports_interactions.npz), dim=64, n_layers=3, batch 1024, embeddings xavier-initialised under
+seed 42 (random-init weights: there are no checkpoints).  --synthetic swaps in a seeded graph of the same shape.
 
 A "step" is one reference training iteration (train_and_evaluate.py:43-48): negative sampling,
 model.loss() = full-graph 3-layer propagate + BPR + L2, loss.backward(), Adam step.  `value` is
@@ -64,6 +65,8 @@ def parse():
     p.add_argument("--hbm-steps", type=int, default=10, help="timed steps of the config-5-shard sub-record")
     p.add_argument("--no-full-config5", action="store_true",
                    help="skip the sub-record of BASELINE configs[4] WHOLE on this GPU (10 M x 2 M, 4e8 directed edges: ~40 s)")
+    p.add_argument("--no-models", action="store_true", help="N > 1: skip the sharded MMGCN / FREEDOM sub-records")
+    p.add_argument("--full-steps", type=int, default=10, help="timed steps of the configs[4]-whole sub-record (N=1)")
     p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MMGCN", "FREEDOM"],
                    help="LightGCN: the headline workload.  MMGCN (BASELINE configs[3], microlens) / FREEDOM (configs[2], "
                         "clothing): the model's captured train step + gene_ranklist, user-sharded at --gpus N > 1")
@@ -71,30 +74,79 @@ def parse():
                    help="N=1: stop after the timed steps and the SpMM roofline (no ranking): the command of the --pmc passes "
                         "at config 5, where a counter-collecting run of the 5 PFLOP ranking takes tens of minutes")
     p.add_argument("--probe-graph", action="store_true", help=argparse.SUPPRESS)   # child mode of probe_sharded_graph()
+    p.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)   # child mode of the launcher's CPU test
     return p.parse_args()
 
 
-def probe_sharded_graph(args, world):
-    """Can this node replay a hipGraph that holds RCCL collectives?  Asked in a CHILD job (one child per rank, its own
-    rendezvous port) before this process touches the GPU: a launch mode that hangs then costs a bounded wait and an
-    eager run instead of the whole measurement.  Returns True when the child captured the sharded step, replayed it
-    and ran a few timed steps.  CHAOREC_DIST_GRAPH=0/1 skips the probe."""
+def probe_path():
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"chaorec_probe_{os.environ.get('MASTER_PORT', '29511')}.json")
+
+
+def probe_node(args, world, want_p2p):
+    """What can this node's launch stack do?  Asked in a CHILD job (one child per rank, its own rendezvous port) before
+    this process touches the GPU, so that a mode that hangs or faults costs a bounded wait, not the measurement:
+      stage `allreduce_replay`  an all-reduce captured in a hipGraph returns fresh sums on every replay
+      stage `p2p`               (want_p2p) the hand-written peer-to-peer exchange (csrc/exchange.hip: peer kernels'
+                                writes read through IPC mappings after a stream-ordered barrier) equals dist.all_reduce,
+                                eagerly and replayed, at the sizes this run will exchange -- its FIRST contact with
+                                real xGMI links happens here, in a process whose death costs nothing
+      stage `step_graph`        the fused sharded step captures, replays and trains a few steps
+    The child job's rank 0 rewrites a small JSON file after every stage; a stage that was entered and never finished
+    counts as failed.  -> dict(graph=bool, p2p=bool).  A child that died in the p2p stage (a fault in a pull kernel
+    cannot be caught in-process) is followed by a second child job with p2p vetoed, for the remaining stages.
+    CHAOREC_DIST_GRAPH=0/1 skips the probe."""
     import subprocess
     port = int(os.environ.get("MASTER_PORT", "29511")) + 17
-    env = dict(os.environ, MASTER_PORT=str(port), CHAOREC_DIST_GRAPH="1", CHAOREC_GRAPH_WATCHDOG_S="60",
-               TORCHELASTIC_USE_AGENT_STORE="False")     # the children rendezvous among themselves, not at the agent
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", "3", "--warmup", "1",
-           "--dataset", args.dataset, "--dim", str(args.dim), "--n-layers", str(args.n_layers), "--batch",
-           str(args.batch), "--no-cpu-baseline", "--no-trained-state", "--probe-graph"] + (["--synthetic"] if args.synthetic else [])
+    path = probe_path()
+    rank = os.environ.get("RANK", "0")
+
+    def run(veto_p2p):
+        if rank == "0" and os.path.exists(path):
+            os.remove(path)
+        env = dict(os.environ, MASTER_PORT=str(port + (5 if veto_p2p else 0)), CHAOREC_DIST_GRAPH="1",
+                   CHAOREC_GRAPH_WATCHDOG_S="60", CHAOREC_PROBE_FILE=path,
+                   TORCHELASTIC_USE_AGENT_STORE="False")     # the children rendezvous among themselves, not at the agent
+        if veto_p2p or not want_p2p:
+            env["CHAOREC_DIST_VETO"] = ",".join(filter(None, [env.get("CHAOREC_DIST_VETO", ""), "p2p"]))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", "3", "--warmup", "1",
+               "--dataset", args.dataset, "--dim", str(args.dim), "--n-layers", str(args.n_layers), "--batch",
+               str(args.batch), "--no-cpu-baseline", "--no-trained-state", "--probe-graph"] + \
+              (["--synthetic"] if args.synthetic else []) + (["--no-hbm-regime"] if args.no_hbm_regime else [])
+        try:
+            rc = subprocess.run(cmd, env=env, timeout=float(os.environ.get("CHAOREC_PROBE_TIMEOUT_S", "300")),
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+        except subprocess.TimeoutExpired:
+            rc = -1
+        time.sleep(1.0)                    # (every rank's child has ended or been ended: the file is final)
+        try:
+            st = json.load(open(path))
+        except Exception:      # noqa: BLE001
+            st = {}
+        return rc, st
+
+    rc, st = run(False)
+    res = dict(graph=bool(st.get("step_graph")), p2p=bool(st.get("p2p")) and want_p2p, first_rc=rc, stages=st)
+    if want_p2p and not st.get("p2p") and "step_graph" not in st:
+        rc2, st2 = run(True)               # the p2p stage took the child job down: the other stages without it
+        res.update(graph=bool(st2.get("step_graph")), second_rc=rc2, stages_second=st2)
+    if not res["graph"] or (want_p2p and not res["p2p"]):
+        print(f"[bench rank {rank}] node probe: {res}", file=sys.stderr, flush=True)
+    return res
+
+
+def probe_mark(stage, ok):
+    """Child side of probe_node(): rank 0 records a finished stage."""
+    path = os.environ.get("CHAOREC_PROBE_FILE")
+    if not path or os.environ.get("RANK", "0") != "0":
+        return
     try:
-        rc = subprocess.run(cmd, env=env, timeout=float(os.environ.get("CHAOREC_PROBE_TIMEOUT_S", "300")),
-                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
-    except subprocess.TimeoutExpired:
-        rc = -1
-    if rc != 0:
-        print(f"[bench rank {os.environ.get('RANK', '0')}] probe of the captured sharded step ended with {rc}: "
-              f"eager launches", file=sys.stderr, flush=True)
-    return rc == 0
+        st = json.load(open(path))
+    except Exception:      # noqa: BLE001
+        st = {}
+    st[stage] = bool(ok)
+    with open(path + ".tmp", "w") as f:
+        json.dump(st, f)
+    os.replace(path + ".tmp", path)
 
 
 def captured_all_reduce_is_exact(dev, world, rank):
@@ -132,12 +184,13 @@ def spmm_model_bytes(nnz, n_rows, D):
 
 def cpu_baseline(edges, U, I, D, L, B, reg, budget_s):
     """The reference CPU path restated in plain torch (oracle/torch_ref.py), timed on this box's host cores on a
-    bounded number of steps.  Best of a small sweep over torch's intra-op thread count (the box has far more cores
-    than a 0.3 M-edge scatter can use: all of them is slower than a few)."""
+    bounded number of steps.  Best of a small sweep over torch's intra-op thread count, capped at 64 (the box has far
+    more cores than a 0.3 M-edge scatter can use: all of them is slower than a few); `cores` = the thread count of the
+    best run, the one `value` is quoted from."""
     from oracle.torch_ref import TorchRefLightGCN
     from chaorec_amd.graph import user_item_dict_from_edges
     ncpu = os.cpu_count() or 8
-    cands = sorted({t for t in (8, 16, 32, ncpu) if t <= ncpu} or {ncpu})
+    cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} or {ncpu})   # (all 256 threads: 20 s per step, never the best)
     uid = user_item_dict_from_edges(edges)
     rng = np.random.default_rng(0)
     E = len(edges)
@@ -236,6 +289,60 @@ def time_spmm_calls(ops, calls, reps=20, passes=5):
     return float(np.median(pass_avg)), tot_bytes / tot_launch, tot_comp / tot_launch
 
 
+CHAIN_TIMING_NOTE = ("HIP events (on the launch stream) around replays of a hipGraph that holds the step's own SpMM launches "
+                     "IN THE STEP'S ORDER -- every launch gathers from what the previous one wrote, as in the step, and the "
+                     "kernel-to-kernel boundaries of the step are inside the figure: avg_launch_us = elapsed / launches.  "
+                     "(Relaunching ONE call back to back, the method of rounds 1-3, re-reads a source table the previous "
+                     "launch left in the caches and came out 3-6 % faster than the same kernel inside the step.)")
+
+
+def time_spmm_chain(calls, min_pass_ms=10.0, passes=5):
+    """calls: [(fn, csr, D)] in the step's order.  -> (ms per launch: median over `passes` of elapsed / launches, model
+    bytes per launch, compulsory bytes per launch).  The chain is captured once and replayed (no host between the
+    launches, like the step's own graph); if the capture fails the launches are issued eagerly, back to back."""
+    for fn, _, _ in calls:
+        fn()
+    torch.cuda.synchronize()
+    graph = None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for fn, _, _ in calls:
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for fn, _, _ in calls:
+                fn()
+    except Exception:      # noqa: BLE001
+        graph = None
+    torch.cuda.synchronize()
+
+    def once():
+        if graph is not None:
+            graph.replay()
+        else:
+            for fn, _, _ in calls:
+                fn()
+
+    def timed(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            once()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e)
+
+    once()
+    reps = max(1, min(200, int(min_pass_ms / max(timed(1), 1e-3)) + 1))
+    per_launch = [timed(reps) / (reps * len(calls)) for _ in range(passes)]
+    tot_bytes = sum(spmm_model_bytes(csr.nnz, csr.n_rows, D) for _, csr, D in calls) / len(calls)
+    tot_comp = sum(2 * csr.n_rows * 4 * D + csr.nnz * 8 for _, csr, D in calls) / len(calls)
+    return float(np.median(per_launch)), tot_bytes, tot_comp
+
+
 def spmm_kernel_name(D, adam=False):
     d4, lpr = D // 4, 1
     while lpr < min(d4, 64):
@@ -332,15 +439,15 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     loss_mean = (float(loss_sum.item()) if fused else float(acc0.item())) / max(n_loss[0], 1)
     msgs_per_step = 2 * L * e_dir
 
-    # --- SpMM roofline: the step's own SpMM calls (same graph, operands, epilogues), re-launched back to back ------
+    # --- SpMM roofline: the step's own SpMM launches (same graph, operands, epilogues) replayed IN THE STEP'S ORDER -----
     csr = model.graph
     N = csr.n_rows
     w = 1.0 / (L + 1)
     x0 = model._flat.detach()
     b0, b1, fin, G = (torch.empty_like(x0) for _ in range(4))
     G.zero_()
-    plain, src = [], x0
     use_mean = L <= ops.mean_terms_limit(D)
+    plain, whole, src = [], [], x0
     xs = [x0]
     for l in range(L - 1 if use_mean else L):        # forward propagates (ops.forward_layers)
         y = b0 if l % 2 == 0 else b1
@@ -352,23 +459,26 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 csr, src, y=None if last else y, acc=fin, acc_init=x0 if l == 0 else None, acc_w=w, want_y=not last), csr, D))
         src = y
         xs.append(y)
+    whole += plain
+    if use_mean:                                     # the last forward propagate with the whole layer mean in its epilogue
+        whole.append((lambda: ops.spmm_mean_raw(csr, xs[-1], xs, w, fin), csr, D))
+    n_fwd_plain = len(plain)
     g, alpha = G, w
     for l in range(L - 1):                           # backward: g_l = A g_{l+1} + w G
         y = b0 if l % 2 == 0 else b1
         plain.append((lambda g=g, y=y, alpha=alpha: ops.spmm_raw(csr, g, y=y, alpha=alpha, z=G, beta=w), csr, D))
         g, alpha = y, 1.0
-    avg_spmm_ms, model_bytes, compulsory = time_spmm_calls(ops, plain)
-    mean_ms = None
-    if use_mean:                                     # the last forward propagate with the whole layer mean in its epilogue
-        mean_ms, _, _ = time_spmm_calls(ops, [(lambda: ops.spmm_mean_raw(csr, xs[-1], xs, w, fin), csr, D)])
-    adam_ms = None
+    whole += plain[n_fwd_plain:]
     if fused and D <= 256:                           # the last backward propagate with the Adam epilogue, on copies
         pc, mc, vc = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
         bc = torch.tensor([0.1, 0.0316], device=dev)
-        adam_ms, _, _ = time_spmm_calls(ops, [(lambda: ops.spmm_adam_raw(csr, g, pc, mc, vc, bc, 1e-3, (0.9, 0.999), 1e-8,
-                                                                       0.0, alpha=alpha, z=G, beta=w, clear_z=L >= 2),
-                                               csr, D)])
-    del b0, b1, fin, G
+        whole.append((lambda: ops.spmm_adam_raw(csr, g, pc, mc, vc, bc, 1e-3, (0.9, 0.999), 1e-8, 0.0, alpha=alpha, z=G,
+                                                beta=w, clear_z=False), csr, D))
+    heavy_graph = csr.nnz > 50_000_000
+    avg_spmm_ms, model_bytes, compulsory = time_spmm_chain(plain, passes=3 if heavy_graph else 5)
+    whole_ms, _, _ = time_spmm_chain(whole, passes=3 if heavy_graph else 5)
+    whole_ms *= len(whole)                           # all SpMM-family launches of ONE step, boundaries included
+    del b0, b1, fin, G, plain, whole
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
     table_mb = N * D * 4 / 1e6
     traffic = None
@@ -390,7 +500,11 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": model_bytes,
                 "avg_launch_us": avg_spmm_ms * 1e3, "compulsory_bytes_per_launch": compulsory,
-                "launches_per_step": len(plain),
+                "launches_per_step": len(plain), "timing": CHAIN_TIMING_NOTE,
+                "spmm_launches_of_one_step": {"launches": len(whole), "us": whole_ms * 1e3,
+                                              "share_of_ms_per_step": whole_ms / ms_per_step,
+                                              "what": f"the step's {len(whole)} SpMM-family launches ({len(plain)} plain + layer-mean "
+                                                      f"epilogue + Adam epilogue) replayed in order as one hipGraph"},
                 "note": ("embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is against "
                          "the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)" % table_mb)
                 if table_mb < 256 else
@@ -398,29 +512,18 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                  "no-reuse CSR model bytes, `traffic` (when present) the measured FETCH_SIZE+WRITE_SIZE bytes" % table_mb)}
     if traffic:
         roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
-    if mean_ms is not None:
-        mean_bytes = model_bytes + (L - 1) * N * D * 4               # + the earlier layers' rows (x_L itself is not stored)
-        roofline["layer_mean_launch"] = {"kernel": spmm_kernel_name(D) + " (chaorec_spmm_csr_mean_f32)",
-                                         "avg_launch_us": mean_ms * 1e3, "algorithmic_bytes": mean_bytes,
-                                         "achieved_GBps": mean_bytes / (mean_ms * 1e-3) / 1e9}
-    if adam_ms is not None:
-        adam_bytes = model_bytes + 6 * N * D * 4 - N * D * 4        # + p, m, v read and written, - the y store
-        roofline["adam_epilogue_launch"] = {"kernel": spmm_kernel_name(D, True), "avg_launch_us": adam_ms * 1e3,
-                                            "algorithmic_bytes": adam_bytes,
-                                            "achieved_GBps": adam_bytes / (adam_ms * 1e-3) / 1e9}
-
     if getattr(args, "spmm_only", False):
         return dict(spmm_only=True, dataset=dataset, data=data_kind, U=U, I=I, E=E, e_dir=e_dir, D=D, L=L, B=B,
                     ms_per_step=ms_per_step, value=msgs_per_step / (dt / steps), msgs_per_step=msgs_per_step,
                     loss_mean=loss_mean, launch=launch, roofline=roofline, build_s=build_s)
 
     # --- full-rank evaluation ---------------------------------------------------------------------------------
-    # Two states of the same call.  COLD: no thresholds carried (the first evaluation of a run): sampled thresholds.
-    # STEADY: the evaluation loop's state (train_and_evaluate.py:655-659 ranks once per epoch) a few epochs into a run
-    # (evaluation STEADY_EVALS + 2): per-user thresholds left by the evaluation one epoch (E // B steps) EARLIER, which
-    # itself ran on carried thresholds -- the users whose thresholds failed in the first carried evaluations have been
-    # given wider ones by then; light mode as ranking.RankState decides it from the previous call's queue lengths.  Every timed repetition starts from the same epoch-old thresholds (a copy is put
-    # back first; its 116 KB device copy is inside the timed region).
+    # Two states of the same call.  COLD: no thresholds carried (the first evaluation of a run): sampled thresholds,
+    # timed on ops.score_topk.  STEADY: the evaluation loop itself (train_and_evaluate.py:655-659 ranks once per epoch)
+    # through the PRODUCT ENTRY, model.gene_ranklist(to_cpu=False) -- ranking.RankState decides hints / light mode /
+    # back-off exactly as it does in a training run, nothing of it is re-implemented here: STEADY_EVALS epochs of
+    # training each followed by its evaluation, then `reps_rank` more epochs whose evaluations are the timed calls
+    # (HIP events around the call; the median is reported, every call's time and queue lengths are in the line).
     epoch_steps = max(E // B, 1)
 
     def time_calls(fn, n):
@@ -443,34 +546,25 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, stats=st)
             out["cold_st"] = st
             if with_steady:
-                hint_rank = ranking.hint_rank_for(50)        # (what ranking.gene_ranklist passes: 2.2 K)
-                old = torch.empty(U, dtype=torch.float32, device=dev)
-                counters = torch.zeros(4, dtype=torch.int32, device=dev)
-                ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=False, hint_rank=hint_rank)
+                state = ranking.state_of(model)
+                model.gene_ranklist(to_cpu=False)            # the run's first evaluation: leaves thresholds behind
                 for _ in range(STEADY_EVALS):                # epochs of training, each followed by its evaluation
                     run_steps(epoch_steps)
-                    res = model.result.detach()
-                    ops.score_topk(res[:U], res[U:U + I], model.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=True,
-                                   hint_rank=hint_rank, counters=counters)   # `old`: thresholds left by a CARRIED evaluation
-                queues_prev = counters.tolist()
-                run_steps(epoch_steps)
-                res = model.result.detach()
-                ue, ie = res[:U], res[U:U + I]
-                hint = old.clone()
-                light = queues_prev[0] <= 16                 # (ranking.RankState.LIGHT_BELOW, the previous call's queue)
-
-                def steady():
-                    hint.copy_(old)
-                    ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True,
-                                   hint_rank=hint_rank, light=light, counters=counters)
-
-                out["steady_ms"] = time_calls(steady, reps_rank)
-                st2 = {}
-                hint.copy_(old)
-                ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True, hint_rank=hint_rank,
-                               light=light, counters=counters, stats=st2)
-                st2["queues_retry_exact_wide_retry2exact"] = counters.tolist()
-                st2["light"] = bool(light)
+                    model.gene_ranklist(to_cpu=False)
+                calls = []
+                for _ in range(max(reps_rank, 5)):
+                    run_steps(epoch_steps)                   # (queued ahead of the call: the events see the device time)
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    model.gene_ranklist(to_cpu=False)
+                    e.record()
+                    torch.cuda.synchronize()
+                    calls.append({"ms": s.elapsed_time(e), "hinted": bool(state.last_hinted),
+                                  "light": bool(state.last_light),
+                                  "queues_retry_exact_wide_retry2exact": state.counters.tolist()})
+                out["steady_ms"] = float(np.median([c["ms"] for c in calls]))
+                st2 = {"through": "model.gene_ranklist(to_cpu=False) (ranking.RankState decides hints / light mode)",
+                       "timed_calls": calls}
                 out["steady_st"] = st2
             # the reference contract: a LongTensor on the CPU (Model/LightGCN.py:162) -- wall time incl. the D2H copy,
             # through the model's own gene_ranklist (carried thresholds, as the evaluation loop calls it)
@@ -591,12 +685,12 @@ def main_single(args, dev):
         torch.cuda.empty_cache()
         if not args.no_full_config5 and torch.cuda.get_device_properties(dev).total_memory > 200 * (1 << 30):
             # ... and the whole of configs[4] on this one GPU: the N = 1 anchor of that config's scaling curve
-            f = measure_single_gpu(args, "config5", 128, 3, 1, dev, 0, reps_rank=1)
+            f = measure_single_gpu(args, "config5", 128, args.full_steps, 2, dev, 0, reps_rank=1)
             out["config5_whole_on_one_gpu"] = {
                 "workload": f"BASELINE configs[4] whole: synthetic bipartite graph U={f['U']}, I={f['I']}, E_dir={f['e_dir']}, "
                             f"dim=128, n_layers={f['L']}, batch={f['B']} (embedding table {f['table_mb']:.0f} MB; generated "
                             f"and laid out on the device)",
-                "data": f["data"], "steps": 3, "ms_per_step": f["ms_per_step"], "value": f["value"],
+                "data": f["data"], "steps": args.full_steps, "ms_per_step": f["ms_per_step"], "value": f["value"],
                 "unit": "directed-edge messages/s", "roofline": f["roofline"], "host_build_seconds": f["build_s"],
                 "gene_ranklist_ms_cold": f["cold_ms"], "users_scored_per_s_cold": f["U"] / (f["cold_ms"] * 1e-3),
                 "roofline_scoring": scoring_roofline(f), "loss_mean": f["loss_mean"],
@@ -608,51 +702,68 @@ def main_single(args, dev):
     print(json.dumps(out), flush=True)
 
 
-def main_sharded(args, world, rank, local_rank, force_sharded):
-    """N > 1 (weak scaling): rank g owns one copy of the dataset's users over the shared item set, the item partials
-    of every layer are summed over RCCL (chaorec_amd/dist.py; CHAOREC_DIST_EXCHANGE picks the collective)."""
-    backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
-    probe_ok = None
-    if (backend == "nccl" and not args.probe_graph and not args.no_graph and not args.torch_adam
-            and os.environ.get("CHAOREC_DIST_GRAPH") is None):
-        probe_ok = probe_sharded_graph(args, world)        # before anything here initialises the GPU
+def init_ranks(local_rank, sharded=True):
+    """This rank's device + the process group (RCCL = backend "nccl"; CHAOREC_DIST_BACKEND=gloo for ranks that share a
+    device).  -> (dev, backend)."""
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     local_rank %= torch.cuda.device_count()     # (lets a 1-GPU box exercise the N>1 code path with gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    if sharded:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    return dev, backend
+
+
+def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, backend, use_graph, probe_mode=False):
+    """One user-sharded LightGCN measurement (weak scaling: rank g owns one copy of the dataset's users over the shared
+    item set; dist.FusedShardedLightGCNStep, joined or split launches by item-table size): timed steps between
+    barriers (max over ranks), the SpMM roofline from the step's own launches, cold ranking of every rank's users.
+    -> dict (identical on every rank)."""
     import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
-    os.environ.setdefault("RANK", "0")
-    os.environ.setdefault("WORLD_SIZE", "1")
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=dev)
-    else:
-        dist.init_process_group(backend)
-
-    if args.probe_graph and not captured_all_reduce_is_exact(dev, world, rank):
-        print(f"[bench probe rank {rank}] a captured all-reduce returned stale sums on replay", file=sys.stderr, flush=True)
-        sys.exit(4)
-
-    from chaorec_amd import _lib, ops
+    from chaorec_amd import ops
     from chaorec_amd import dist as cdist
     from chaorec_amd.optim import FusedAdam, GraphedTrainStep
-    _lib.ensure_built()
-    _lib.load()
-    D, L, B, reg = args.dim, args.n_layers, args.batch, 1e-3
+    L, B, reg = args.n_layers, args.batch, 1e-3
     # the sharded step: "fused" (dist.FusedShardedLightGCNStep: joined-graph propagates, Adam in the last propagate's
     # epilogue, no autograd) or "autograd" (round 2's path: loss_local -> backward -> FusedAdam under GraphedTrainStep)
     step_kind = os.environ.get("CHAOREC_DIST_STEP", "fused")
     if args.torch_adam or L < 1:
         step_kind = "autograd"
-    job = cdist.build_weak_scaling_job(args.dataset, world, rank, D, L, reg, dev, seed=42, synthetic=args.synthetic)
+    t_build = time.perf_counter()
+    job = cdist.build_weak_scaling_job(dataset, world, rank, D, L, reg, dev, seed=42, synthetic=args.synthetic)
     model, edges, U, I, U1 = job["model"], job["local_edges"], job["num_user_local"], job["I"], job["U1"]
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t_build
     E = len(edges)
     e_dir = 2 * E
     opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else FusedAdam(model.parameters(), lr=1e-3)
     edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
     loss_sum = torch.zeros((), device=dev)
     batch_counter = torch.zeros(1, dtype=torch.int64, device=dev)   # device-resident: advances inside the graph
+
+    # --- first contact: before a step trusts an exchange mode on this node, the mode sums a random buffer of the step's
+    # own size and is compared with dist.all_reduce (eagerly and replayed from a hipGraph); large buffers also get the
+    # modes timed against each other and `auto` takes the fastest that passed (dist.calibrate_exchange)
+    item_bytes = cdist.padded_rows(I) * D * 4
+    calibration = None
+    if cdist._active(None):
+        big = item_bytes >= cdist.AUTO_BIG_BYTES
+        asked = cdist.exchange_mode()
+        cands = ("allreduce", "rs_ag", "p2p") if (asked == "auto" and big) else \
+            (() if asked in ("auto", "allreduce") else (asked if asked != "direct" else "rs_ag",))
+        if cands:
+            calibration = cdist.calibrate_exchange(I, D, dev, captured=use_graph and backend == "nccl", candidates=cands)
+            if probe_mode and "p2p" in cands:
+                probe_mark("p2p", calibration.get("p2p", {}).get("ok", False))
 
     def draw(i=None):
         """One batch in ONE launch (chaorec_draw_batch): B training edges of this rank picked uniformly + one sampled
@@ -662,22 +773,15 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
             return ops.draw_batch(edges_dev, model.hist, B, model.num_user, I, 42 + rank, 0, step_dev=batch_counter)
         return ops.draw_batch(edges_dev, model.hist, B, model.num_user, I, 42 + rank, 1_000_000 + i)
 
-    # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph, RCCL calls included
-    # (CHAOREC_DIST_GRAPH=0 keeps it eager).  Every rank must run the same launch mode.
-    use_graph = (not args.no_graph and not args.torch_adam and backend == "nccl"
-                 and os.environ.get("CHAOREC_DIST_GRAPH", "1") == "1")
-    if probe_ok is not None:
-        flag = torch.tensor([1.0 if (use_graph and probe_ok) else 0.0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        use_graph = float(flag.item()) > 0.0
     graphed = None
     fused = None
     fused_loss = torch.zeros(1, device=dev)     # sum of this rank's batch losses, accumulated inside the step
+    spr = 1 if E > 5_000_000 else args.steps_per_replay       # (a config-5-shard step is ~30 ms: nothing to gain from k-step replays)
     if step_kind == "fused":
         def make_fused(capture):
             return cdist.FusedShardedLightGCNStep(model, opt, batch_size=B, edges=edges_dev, seed=42 + rank,
                                                   step_dev=batch_counter, capture=capture, loss_accum=fused_loss,
-                                                  steps_per_replay=args.steps_per_replay)
+                                                  steps_per_replay=spr)
         if use_graph:
             try:
                 fused = make_fused(True)
@@ -757,23 +861,64 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
         for i in range(n):
             step(first + i)
 
-    run_steps(0, args.warmup)
+    run_steps(0, warmup)
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
+    run_steps(warmup, steps)
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
+    ms_per_step = dt / steps * 1e3
     t = torch.tensor([float(e_dir), float(U)], device=dev, dtype=torch.float64)
     dist.all_reduce(t)
     e_dir_all, n_scored = int(t[0].item()), float(t[1].item())
     msgs_per_step_all = 2 * L * e_dir_all
-    value = msgs_per_step_all / (dt / args.steps)
+    value = msgs_per_step_all / (dt / steps)
+    loss_mean = (float(fused_loss.item()) / world if fused is not None else float(loss_sum.item())) / max(n_loss[0], 1)
 
-    # --- SpMM roofline: the step's own SpMM calls (the shard's two block products per layer), re-launched back to back
+    if probe_mode:
+        return dict(graphed=graphed is not None)
+
+    # --- exposed communication: the same step with the exchanges switched off (every rank computes on its own partial
+    # sums: wrong numbers, same launches) -- what the exchanges cost the step beyond what the launches hide
+    exposed = None
+    if fused is not None and cdist._active(None) and not probe_mode:
+        saved = fused._save_state()
+        real_exchange = fused._exchange
+        fused._exchange = lambda buf: cdist._Pending(None)
+        try:
+            for _ in range(2):
+                fused._launch()
+            barrier()
+            t0 = time.perf_counter()
+            n_dry = max(3, min(steps, 10))
+            for _ in range(n_dry):
+                fused._launch()
+            barrier()
+            dry = (time.perf_counter() - t0) / n_dry * 1e3
+        finally:
+            fused._exchange = real_exchange
+            fused._restore_state(saved)
+        for _ in range(2):
+            fused._launch()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_dry):
+            fused._launch()
+        barrier()
+        wet = (time.perf_counter() - t0) / n_dry * 1e3
+        t = torch.tensor([dry, wet], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed = {"eager_ms_per_step_with_exchanges": float(t[1]), "eager_ms_per_step_without_exchanges": float(t[0]),
+                   "exposed_exchange_ms_per_step": float(t[1] - t[0]), "exchanges_per_step": 2 * L + 1,
+                   "bytes_per_exchange": item_bytes,
+                   "note": "both eager (same launches, the exchanges replaced by nothing in the second run): the difference "
+                           "is what the 2L+1 exchanges cost beyond what the SpMM launches hide"}
+        fused._restore_state(saved)
+
+    # --- SpMM roofline: the step's own SpMM calls, recorded in one eager step and replayed IN THE STEP'S ORDER
     calls = []
     orig = ops.spmm_raw
 
@@ -783,32 +928,29 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
         return out
 
     ops.spmm_raw = recording_spmm
-    step(args.warmup + args.steps, force_eager=True)
+    step(warmup + steps, force_eager=True)
     ops.spmm_raw = orig
     torch.cuda.synchronize()
     timed = []
     for csr, x, a, k in calls:
-        k = dict(k)
-        for name in ("acc", "y"):
-            if k.get(name) is not None:
-                k[name] = k[name].clone()            # keep the model state out of the measurement
         timed.append((lambda csr=csr, x=x, a=a, k=k: orig(csr, x, *a, **k), csr, x.shape[1]))
-    avg_spmm_ms, model_bytes, compulsory = time_spmm_calls(ops, timed)
+    avg_spmm_ms, model_bytes, compulsory = time_spmm_chain(timed)
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": spmm_kernel_name(D), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": model_bytes,
                 "avg_launch_us": avg_spmm_ms * 1e3, "compulsory_bytes_per_launch": compulsory,
-                "launches_per_step": len(calls),
-                "note": "rank 0's shard blocks (user x item and item x user rows of the normalised graph)"}
+                "launches_per_step": len(calls), "timing": CHAIN_TIMING_NOTE,
+                "note": "rank 0's shard: " + ("the two row blocks of every layer as separate launches (split step)"
+                                              if getattr(fused, "split", False) else
+                                              "one launch per layer over the rank's joined graph [[0, B_g], [B_g^T, 0]]")}
 
     # --- full-rank evaluation: every rank ranks its own users against the replicated item table, no exchange --------
     torch.cuda.synchronize()
-    model.gene_ranklist()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3 if E > 5_000_000 else 5)]
     st = {}
     with torch.no_grad():
         ru, ri = model.result_u.detach(), model.result_i.detach()
+        ops.score_topk(ru, ri, model.hist, 1e-6, 50, id_offset=model.shard.num_user_global)
         for s_, e_ in ev:
             s_.record()
             ops.score_topk(ru, ri, model.hist, 1e-6, 50, id_offset=model.shard.num_user_global)
@@ -820,70 +962,171 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     score_ms = float(t.item())
     tf = 2.0 * n_scored * I * D / (score_ms * 1e-3) / 1e12
-    r = dict(D=D, score_tf=tf, score_st=st)
+    launch = ("captured hipGraph per step" if graphed is not None else "eager launches") + \
+        (f", fused sharded step (dist.FusedShardedLightGCNStep, {'split' if fused.split else 'joined'} launches: "
+         f"{'4L+5' if fused.split else '2L+5'} launches, 2L+1 exchanges; {fused.steps_per_replay} steps per replay)"
+         if fused is not None else ", autograd step")
+    res = dict(dataset=dataset, data=job["data"], U1=U1, I=I, D=D, L=L, B=B, world=world, e_dir_all=e_dir_all,
+               ms_per_step=ms_per_step, value=value, msgs_per_step=msgs_per_step_all, loss_mean=loss_mean, launch=launch,
+               graphed=graphed is not None, fused=fused is not None, split=bool(getattr(fused, "split", False)),
+               roofline=roofline, score_ms=score_ms, score_tf=tf, score_st=st, n_scored=n_scored, build_s=build_s,
+               exchange=cdist.exchange_mode_used(), exchange_bytes=item_bytes, calibration=calibration, exposed=exposed,
+               table_mb=(U + I) * D * 4 / 1e6)
+    del fused, graphed, model, opt, job, edges_dev, calls, timed
+    torch.cuda.empty_cache()
+    return res
+
+
+def main_sharded(args, world, rank, local_rank, force_sharded):
+    """N > 1 (weak scaling): rank g owns one copy of the dataset's users over the shared item set, the item partials
+    of every layer are summed over RCCL (chaorec_amd/dist.py; CHAOREC_DIST_EXCHANGE picks the collective, `auto` by
+    size after a first-contact calibration on this node).  The line carries the same sub-records as the N = 1 line:
+    `hbm_regime` (config5_shard per rank, D = 128: at N = 8 that IS BASELINE configs[4]) and `models` (MMGCN/microlens
+    = configs[3], FREEDOM/clothing = configs[2], user-sharded)."""
+    backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    probe = None
+    want_p2p = backend == "nccl" and os.environ.get("CHAOREC_DIST_EXCHANGE", "auto") in ("auto", "p2p") \
+        and "p2p" not in os.environ.get("CHAOREC_DIST_VETO", "")
+    if (backend == "nccl" and not args.probe_graph and not args.no_graph and not args.torch_adam
+            and os.environ.get("CHAOREC_DIST_GRAPH") is None):
+        probe = probe_node(args, world, want_p2p)          # before anything here initialises the GPU
+        if want_p2p and not probe["p2p"]:
+            os.environ["CHAOREC_DIST_VETO"] = ",".join(filter(None, [os.environ.get("CHAOREC_DIST_VETO", ""), "p2p"]))
+    dev, backend = init_ranks(local_rank)
+    import torch.distributed as dist
+
+    from chaorec_amd import _lib
+    from chaorec_amd import dist as cdist
+    _lib.ensure_built()
+    _lib.load()
+    if args.probe_graph:
+        ok = captured_all_reduce_is_exact(dev, world, rank)
+        probe_mark("allreduce_replay", ok)
+        if not ok:
+            print(f"[bench probe rank {rank}] a captured all-reduce returned stale sums on replay", file=sys.stderr, flush=True)
+            sys.exit(4)
+        if "p2p" not in cdist._VETOED and not args.no_hbm_regime:
+            # the p2p exchange at the size of the hbm_regime sub-record (2 M items x 128: 1 GB), eager and replayed
+            from chaorec_amd.synthetic import DATASET_SHAPES
+            tbl = cdist.calibrate_exchange(DATASET_SHAPES["config5_shard"][1], 128, dev, captured=True, candidates=("p2p",))
+            probe_mark("p2p", tbl.get("p2p", {}).get("ok", False))
+
+    # the whole zero_grad -> loss -> backward -> Adam sequence as ONE captured hipGraph, RCCL calls included
+    # (CHAOREC_DIST_GRAPH=0 keeps it eager).  Every rank must run the same launch mode.
+    use_graph = (not args.no_graph and not args.torch_adam and backend == "nccl"
+                 and os.environ.get("CHAOREC_DIST_GRAPH", "1") == "1")
+    if probe is not None:
+        flag = torch.tensor([1.0 if (use_graph and probe["graph"]) else 0.0, 1.0 if "p2p" not in cdist._VETOED else 0.0],
+                            device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_graph = float(flag[0].item()) > 0.0
+        if float(flag[1].item()) == 0.0:
+            cdist.veto("p2p")
+
+    head = measure_sharded_lightgcn(args, args.dataset, args.dim, args.steps, args.warmup, world, rank, dev, backend,
+                                    use_graph, probe_mode=args.probe_graph)
+    if args.probe_graph:
+        probe_mark("step_graph", head["graphed"])
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if head["graphed"] else 3)
+    D, L, B, U1, I = head["D"], head["L"], head["B"], head["U1"], head["I"]
+    measured_rccl = bool(world > 1 and backend == "nccl" and int(os.environ.get("CHAOREC_BENCH_VISIBLE_GPUS", str(world))) >= world
+                         and torch.cuda.device_count() >= world)
     out = {
         "metric": f"GCN edges/sec + full-rank users-scored/sec, dim={D}",
-        "value": value, "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
-        "users_scored_per_s": n_scored / (score_ms * 1e-3),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": job["data"],
+        "value": head["value"], "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
+        "users_scored_per_s": head["n_scored"] / (head["score_ms"] * 1e-3),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": head["data"],
+        "multi_rank_rccl_measured": measured_rccl,
         "config": {"workload": f"LightGCN train step, {args.dataset} graph replicated by user rows: rank g owns the {U1} "
-                               f"users of the {job['data']} graph as users g*{U1}.. over the same {I} items "
-                               f"(U={U1}x{world}, I={I}, E_dir={e_dir_all}), dim={D}, n_layers={L}, batch={B}x{world}; "
+                               f"users of the {head['data']} graph as users g*{U1}.. over the same {I} items "
+                               f"(U={U1}x{world}, I={I}, E_dir={head['e_dir_all']}), dim={D}, n_layers={L}, batch={B}x{world}; "
                                f"gene_ranklist top-50 over all users (cold thresholds)",
-                   "messages_per_step": msgs_per_step_all, "gene_ranklist_ms": score_ms,
-                   "launch": ("captured hipGraph per step" if graphed is not None else "eager launches") +
-                             (f", fused sharded step (dist.FusedShardedLightGCNStep: 2L+5 launches, 2L+1 exchanges; {fused.steps_per_replay} "
-                              f"steps per replay)" if fused is not None else ", autograd step"),
+                   "messages_per_step": head["msgs_per_step"], "gene_ranklist_ms": head["score_ms"],
+                   "launch": head["launch"],
                    "optimizer": "torch.optim.Adam" if args.torch_adam else
                    ("Adam in the last user-row SpMM's epilogue + one fused launch on the replicated item rows"
-                    if fused is not None else "FusedAdam (chaorec_adam_step_f32)"),
-                   "parallelism": f"user-row shards x{world}; item partials summed per layer by "
-                                  f"{cdist.exchange_mode_used()} over {backend}"},
-        "roofline": roofline, "roofline_scoring": scoring_roofline(r),
-        "loss_mean": (float(fused_loss.item()) / world if fused is not None else float(loss_sum.item())) / max(n_loss[0], 1),
+                    if head["fused"] else "FusedAdam (chaorec_adam_step_f32)"),
+                   "parallelism": f"user-row shards x{world}; item partials ({head['exchange_bytes'] / 1e6:.1f} MB) summed per "
+                                  f"layer by {head['exchange']} over {backend}",
+                   "ranks_share_devices": torch.cuda.device_count() < world,
+                   "node_probe": probe, "exchange_calibration": head["calibration"],
+                   "exposed_communication": head["exposed"], "host_build_seconds": head["build_s"]},
+        "roofline": head["roofline"], "roofline_scoring": scoring_roofline(head),
+        "loss_mean": head["loss_mean"],
     }
-    dist.destroy_process_group()
-    if args.probe_graph:
-        sys.exit(0 if graphed is not None else 3)
-    if rank == 0:
-        # RCCL writes its version banner through C stdio, which would otherwise drain at exit, AFTER the result: flush C
-        # stdout first so that the JSON object is the last line (stdout only -- an fflush(NULL) from here hung under
-        # rocprofv3, which keeps streams of its own)
-        import ctypes
-        libc = ctypes.CDLL(None)
+
+    # Sub-records, under a watchdog: a collective that cannot make progress in a sub-record must not take the headline
+    # numbers (measured above) with it -- rank 0 then prints the line without the unfinished ones and the job ends.
+    import threading
+    finished = threading.Event()
+
+    def give_up():
+        if not finished.wait(float(os.environ.get("CHAOREC_SUBRECORD_TIMEOUT_S", "900"))):
+            if rank == 0:
+                out.setdefault("hbm_regime", {"error": "sub-records did not finish in time"})
+                flush_c_stdout()
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 0)
+
+    threading.Thread(target=give_up, daemon=True).start()
+
+    def all_ok(ok):
+        t = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item()) > 0.0
+
+    if not args.no_hbm_regime and args.dataset not in ("config5_shard", "config5"):
         try:
-            libc.fflush(ctypes.c_void_p.in_dll(libc, "stdout"))
-        except (ValueError, OSError):
-            pass
+            h = measure_sharded_lightgcn(args, "config5_shard", 128, args.hbm_steps, 3, world, rank, dev, backend, use_graph)
+            out["hbm_regime"] = {
+                "workload": f"BASELINE configs[4] at {world} rank(s): every rank owns one GPU's share of the synthetic "
+                            f"bipartite graph (U={h['U1']} per rank x {world}, I={h['I']}, E_dir={h['e_dir_all']}), dim=128, "
+                            f"n_layers={h['L']}, batch={h['B']}x{world} (per-rank table {h['table_mb']:.0f} MB; item partial "
+                            f"{h['exchange_bytes'] / 1e6:.0f} MB per exchange)" +
+                            (" -- at 8 ranks this IS configs[4]" if world == 8 else ""),
+                "data": h["data"], "steps": args.hbm_steps, "ms_per_step": h["ms_per_step"], "value": h["value"],
+                "unit": "directed-edge messages/s", "launch": h["launch"], "exchange": h["exchange"],
+                "exchange_calibration": h["calibration"], "exposed_communication": h["exposed"],
+                "roofline": h["roofline"], "gene_ranklist_ms_cold": h["score_ms"],
+                "users_scored_per_s_cold": h["n_scored"] / (h["score_ms"] * 1e-3),
+                "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"], "host_build_seconds": h["build_s"],
+            }
+            del h
+        except Exception as exc:      # noqa: BLE001
+            out["hbm_regime"] = {"error": repr(exc)[:300]}
+        torch.cuda.empty_cache()
+    if not args.no_models:
+        out["models"] = {}
+        for name in ("MMGCN", "FREEDOM"):
+            try:
+                out["models"][name] = measure_model(args, name, world, rank, dev, True, backend,
+                                                    steps=min(args.steps, 20), warmup=min(args.warmup, 5))
+            except Exception as exc:      # noqa: BLE001
+                out["models"][name] = {"error": repr(exc)[:300]}
+            torch.cuda.empty_cache()
+    finished.set()
+    dist.barrier()
+    dist.destroy_process_group()
+    cdist.P2PExchange.forget_all()
+    if rank == 0:
+        flush_c_stdout()
         print(json.dumps(out), flush=True)
 
 
-def main_model(args, world, rank, local_rank, force_sharded):
-    """--model MMGCN / FREEDOM: the model's train step (zero_grad -> loss -> backward -> [gradient exchange] -> FusedAdam,
+def measure_model(args, name, world, rank, dev, sharded, backend, steps=None, warmup=None, dataset=None):
+    """MMGCN / FREEDOM: the model's train step (zero_grad -> loss -> backward -> [gradient exchange] -> FusedAdam,
     one captured hipGraph, batch drawn on the device) and gene_ranklist on the REAL interaction graph of its BASELINE
-    config (microlens / clothing) with the seeded synthetic modality features.  N = 1: the single-process model class.
-    N > 1 (or CHAOREC_FORCE_SHARDED=1): dist.ShardedMMGCN / dist.ShardedFREEDOM, weak scaling -- rank g owns one copy of
-    the dataset's users over the shared item set, like the LightGCN path.  `value`: directed-edge messages per second
-    through the step's SpMM launches (sum of nnz over every propagate, forward and backward, all ranks)."""
-    name = args.model
-    dataset = args.dataset if args.dataset != "sports" else {"MMGCN": "microlens", "FREEDOM": "clothing"}[name]
-    sharded = world > 1 or force_sharded
-    backend = os.environ.get("CHAOREC_DIST_BACKEND", "nccl")
-    assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    config (microlens / clothing) with the seeded synthetic modality features.  Not sharded: the single-process model
+    class.  Sharded: dist.ShardedMMGCN / dist.ShardedFREEDOM, weak scaling -- rank g owns one copy of the dataset's
+    users over the shared item set, like the LightGCN path.  `value`: directed-edge messages per second through the
+    step's SpMM launches (sum of nnz over every propagate, forward and backward, all ranks).  -> the record (dict)."""
     import torch.distributed as dist
-    if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    dataset = dataset or {"MMGCN": "microlens", "FREEDOM": "clothing"}[name]
     from chaorec_amd import _lib, dataload, graph, ops
     from chaorec_amd import dist as cdist
     from chaorec_amd.Model import FREEDOM, MMGCN
@@ -940,13 +1183,6 @@ def main_model(args, world, rank, local_rank, force_sharded):
     sync = model.sync_grads if sharded else None
     # exchange bytes of one step on this rank, and the step's SpMM work: one eager step with the calls counted
     xbytes, nnz_step = [0], [0]
-    real = {k: getattr(dist, k) for k in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor", "all_to_all_single")}
-
-    def counting(fn_name, which):
-        def f(*a, **k):
-            xbytes[0] += a[which].numel() * a[which].element_size()
-            return real[fn_name](*a, **k)
-        return f
 
     spmm_orig = ops.spmm_raw
 
@@ -964,13 +1200,12 @@ def main_model(args, world, rank, local_rank, force_sharded):
         return loss.detach()
 
     eager_step()                                # warm-up: lazily built schedules, Adam state, communicators
-    dist.all_reduce, dist.reduce_scatter_tensor = counting("all_reduce", 0), counting("reduce_scatter_tensor", 1)
-    dist.all_gather_into_tensor, dist.all_to_all_single = counting("all_gather_into_tensor", 1), counting("all_to_all_single", 1)
     ops.spmm_raw = spmm_counting
+    before = dict(cdist.STATS)
     eager_step()
     ops.spmm_raw = spmm_orig
-    for k, v in real.items():
-        setattr(dist, k, v)
+    xbytes[0] = cdist.STATS["bytes"] - before["bytes"]
+    n_exchanges = cdist.STATS["exchanges"] - before["exchanges"]
     torch.cuda.synchronize()
     use_graph = not args.no_graph and (not sharded or (backend == "nccl" and os.environ.get("CHAOREC_DIST_GRAPH", "1") == "1"))
     graphed = None
@@ -992,17 +1227,22 @@ def main_model(args, world, rank, local_rank, force_sharded):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     blocks = []
     while True:
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         barrier()
         blocks.append(time.perf_counter() - t0)
-        if sum(blocks) >= MIN_TIMED_S or len(blocks) >= 64:
+        stop = sum(blocks) >= MIN_TIMED_S or len(blocks) >= 64
+        if sharded:                             # (the ranks leave the loop together: every block ends in a barrier)
+            flag = torch.tensor([1.0 if stop else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            stop = float(flag.item()) > 0.0
+        if stop:
             break
     dt = float(np.median(blocks))
     t = torch.tensor([dt, float(nnz_step[0]), float(U_g)], device=dev, dtype=torch.float64)
@@ -1022,11 +1262,11 @@ def main_model(args, world, rank, local_rank, force_sharded):
     rank_ms = (time.perf_counter() - t1) / 3 * 1e3
     out = {
         "metric": "GCN edges/sec + full-rank users-scored/sec, dim=64",
-        "value": nnz_all / (dt / args.steps), "unit": "directed-edge messages/s (every SpMM launch of the train step, fwd+bwd)",
+        "value": nnz_all / (dt / steps), "unit": "directed-edge messages/s (every SpMM launch of the train step, fwd+bwd)",
         "users_scored_per_s_incl_d2h": n_scored / (rank_ms * 1e-3),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "timed_blocks": {"blocks_of_steps": len(blocks), "ms_per_step_min": min(blocks) / args.steps * 1e3,
-                         "ms_per_step_max": max(blocks) / args.steps * 1e3},
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "timed_blocks": {"blocks_of_steps": len(blocks), "ms_per_step_min": min(blocks) / steps * 1e3,
+                         "ms_per_step_max": max(blocks) / steps * 1e3},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "real interactions, synthetic modality features, random-init weights",
         "config": {"workload": f"{name} train step on the real {dataset} graph" +
@@ -1034,14 +1274,29 @@ def main_model(args, world, rank, local_rank, force_sharded):
                                 if sharded else "") + f" (U={U1}x{world}, I={I}), features {tuple(v_feat.shape[1:])} / "
                                f"{tuple(t_feat.shape[1:])}, dim=64, batch={B}x{world}; gene_ranklist top-50 (to the CPU)",
                    "model_class": type(model).__name__, "spmm_nnz_per_step_all_ranks": nnz_all,
-                   "exchange_bytes_per_step_per_rank": xbytes[0], "gene_ranklist_ms_incl_d2h_wall": rank_ms,
+                   "exchange_bytes_per_step_per_rank": xbytes[0], "collectives_per_step": n_exchanges,
+                   "collectives_forced_on_one_rank": bool(sharded and world == 1 and cdist._FORCE_COLLECTIVES),
+                   "gene_ranklist_ms_incl_d2h_wall": rank_ms,
                    "launch": "captured hipGraph per step" if graphed is not None else "eager launches",
                    "parallelism": (f"user-row shards x{world}; exchanges by {cdist.exchange_mode_used()} over {backend}"
                                    if sharded else "single GPU"),
-                   "multi_rank_rccl_measured": bool(sharded and world > 1 and backend == "nccl"),
+                   "multi_rank_rccl_measured": bool(sharded and world > 1 and backend == "nccl"
+                                                    and torch.cuda.device_count() >= world),
                    "host_build_seconds": build_s},
     }
+    del model, opt, graphed, step
+    torch.cuda.empty_cache()
+    return out
+
+
+def main_model(args, world, rank, local_rank, force_sharded):
+    """--model MMGCN / FREEDOM as the headline of the line (measure_model)."""
+    sharded = world > 1 or force_sharded
+    dev, backend = init_ranks(local_rank, sharded)
+    dataset = args.dataset if args.dataset != "sports" else None
+    out = measure_model(args, args.model, world, rank, dev, sharded, backend, dataset=dataset)
     if sharded:
+        import torch.distributed as dist
         dist.destroy_process_group()
     if rank == 0:
         flush_c_stdout()
@@ -1059,13 +1314,123 @@ def flush_c_stdout():
         pass
 
 
+def visible_gpu_count():
+    """Devices this process could use, WITHOUT initialising the GPU runtime (the launcher must not touch it: it starts
+    children).  torch.cuda.device_count() is a device-file / NVML-style count on this image; any failure means 0."""
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:      # noqa: BLE001
+        return 0
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- one child process per GPU with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what torch.distributed.run would hand them -- BEFORE this
+    process makes any GPU call (a process that initialised the GPU must not exec another program; this one only counts
+    devices and waits).  Rank 0's stdout is relayed line by line (its last line is the JSON result), the other ranks'
+    stdout goes to stderr.  Any rank ending non-zero ends the job: the others are terminated BY PID and the launcher
+    exits with that code.  On a box with fewer devices than ranks the ranks share devices (LOCAL_RANK modulo the count)
+    and, unless CHAOREC_DIST_BACKEND says otherwise, exchange through gloo: RCCL wants one device per rank -- the line
+    then says `multi_rank_rccl_measured: false`."""
+    import signal
+    import subprocess
+    import threading
+    n = args.gpus
+    n_dev = visible_gpu_count()
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(os.environ.get("MASTER_PORT") or _free_port()), CHAOREC_BENCH_SELF_LAUNCHED="1",
+               CHAOREC_BENCH_VISIBLE_GPUS=str(n_dev))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL / shared CUDA tensors across processes
+    if n_dev < n and "CHAOREC_DIST_BACKEND" not in env:
+        env["CHAOREC_DIST_BACKEND"] = "gloo"
+        print(f"[bench launcher] {n} ranks on {n_dev} visible GPU(s): ranks share devices, exchanges over gloo "
+              f"(not an RCCL measurement)", file=sys.stderr, flush=True)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode(errors="replace"))
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    deadline = time.time() + float(os.environ.get("CHAOREC_BENCH_TIMEOUT_S", "3000"))
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 128 - bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                print("[bench launcher] timed out", file=sys.stderr, flush=True)
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:                       # (only ever the exact processes started above)
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        t.join(timeout=5)
+    if rc:
+        print(f"[bench launcher] a rank ended with {rc}", file=sys.stderr, flush=True)
+    return rc
+
+
+def launch_selftest(world, rank):
+    """Child mode of the launcher's CPU test (tests/test_host_logic.py): rendezvous over gloo, sum the ranks, rank 0
+    prints one JSON line.  CHAOREC_BENCH_SELFTEST_FAIL_RANK makes that rank exit 7 first (failure propagation)."""
+    import torch.distributed as dist
+    if os.environ.get("CHAOREC_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "sum": float(t.item()),
+                          "local_rank": int(os.environ["LOCAL_RANK"]),
+                          "self_launched": os.environ.get("CHAOREC_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_selftest:
+        return launch_selftest(world, rank)
     # CHAOREC_FORCE_SHARDED=1: run the N>1 code path (sharded model, RCCL calls, graph capture of them) on one rank
     force_sharded = world == 1 and os.environ.get("CHAOREC_FORCE_SHARDED", "0") == "1"
     if args.model != "LightGCN":

@@ -122,21 +122,64 @@ _FORCE_COLLECTIVES = _os.environ.get("CHAOREC_FORCE_COLLECTIVES", "0") == "1"
 #              once, and sums the 8 blocks it receives itself -- then the all-gather: 2 * bytes / 8 / 153 GB/s per
 #              half on a fully connected xGMI node (1.7 ms instead of 11.7 ms for config 5's 1.02 GB)
 # Same sums up to fp32 association.  No multi-GPU node was available to time them against each other.
-EXCHANGE_MODES = ("allreduce", "rs_ag", "direct", "p2p")
+EXCHANGE_MODES = ("auto", "allreduce", "rs_ag", "direct", "p2p")
 DIRECT_FELL_BACK = False       # set when a captured step replaced `direct` by `rs_ag` (see _sum_exchange_async)
 DIRECT_WENT_P2P = False        # set when a captured step ran `direct` as the hand-written peer-to-peer exchange instead
+# `auto` (the default) picks by buffer size: below AUTO_BIG_BYTES one RCCL all-reduce (launch-latency-bound: one launch);
+# from there on whatever calibrate_exchange() measured fastest among the modes that passed its first-contact check
+# on this node -- and RCCL's all-reduce when nobody calibrated (the conservative choice: the hand-written p2p exchange
+# has to prove itself against an all-reduce on the node it runs on before a step trusts it).
+AUTO_BIG_BYTES = int(_os.environ.get("CHAOREC_DIST_BIG_BYTES", str(64 << 20)))
+_AUTO_BIG_CHOICE = {}          # numel -> mode, filled by calibrate_exchange()
+_VETOED = set()                # modes that failed a first-contact check in this process (or were vetoed by the launcher)
+MODES_USED = set()             # what the exchanges of this process actually ran (bench line)
+CALIBRATION = {}               # numel -> the table calibrate_exchange() measured (bench line)
+_FORCED = [None]               # calibrate_exchange() runs one named mode at a time through the product path
+STATS = {"exchanges": 0, "bytes": 0}     # every buffer this process handed to a collective (host-side count, bench line)
+
+
+def _count(t):
+    STATS["exchanges"] += 1
+    STATS["bytes"] += t.numel() * t.element_size()
 
 
 def exchange_mode():
-    m = _os.environ.get("CHAOREC_DIST_EXCHANGE", "allreduce")
+    m = _os.environ.get("CHAOREC_DIST_EXCHANGE", "auto")
     if m not in EXCHANGE_MODES:
         raise ValueError(f"CHAOREC_DIST_EXCHANGE={m}: one of {EXCHANGE_MODES}")
     return m
 
 
+def veto(mode):
+    _VETOED.add(mode)
+    for k in [k for k, v in _AUTO_BIG_CHOICE.items() if v == mode]:
+        del _AUTO_BIG_CHOICE[k]
+
+
+for _m in _os.environ.get("CHAOREC_DIST_VETO", "").split(","):
+    if _m:
+        _VETOED.add(_m)
+
+
+def resolve_mode(buf):
+    """The exchange mode for THIS buffer: the mode asked for, `auto` resolved by size, vetoed modes replaced by rs_ag."""
+    m = _FORCED[0] or exchange_mode()
+    if m == "auto":
+        big = buf.numel() * buf.element_size() >= AUTO_BIG_BYTES
+        m = _AUTO_BIG_CHOICE.get(buf.numel(), "allreduce") if big else "allreduce"
+    if m in _VETOED:
+        m = "rs_ag" if "rs_ag" not in _VETOED else "allreduce"
+    return m
+
+
 def exchange_mode_used():
-    """What the bench line reports: the mode asked for, and what captured steps ran instead where that differs."""
+    """What the bench line reports: the mode asked for, what `auto` resolved to, and what captured steps ran instead
+    where that differs."""
     m = exchange_mode()
+    if m == "auto" or _VETOED:
+        m += " -> " + "/".join(sorted(MODES_USED) or ["(no exchange ran)"])
+        if _VETOED:
+            m += f" (failed their first-contact check here: {sorted(_VETOED)})"
     if DIRECT_WENT_P2P:
         return m + " (captured steps: p2p -- RCCL's all-to-all is not capturable on this stack; the same direct pattern as " \
                    "pull kernels over IPC-mapped peer buffers)"
@@ -163,6 +206,7 @@ def exchange_buffer(n_rows, D, like, group=None):
 
 def _all_reduce(t, group):
     if _active(group):
+        _count(t)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -182,6 +226,19 @@ class _Pending:
         if self.then is not None:
             nxt, self.then = self.then, None
             nxt().wait()
+
+
+class _PendingStream:
+    """Handle of an exchange made of plain launches on a side stream (the hand-written p2p exchange): wait() makes the
+    compute stream depend on everything the side stream was given so far."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.stream = None
 
 
 def _mean_all(x):
@@ -207,17 +264,37 @@ class P2PExchange:
 
     @classmethod
     def of(cls, group):
-        key = id(group) if group is not None else 0
-        if key not in cls._by_group:
-            cls._by_group[key] = cls(group)
-        return cls._by_group[key]
+        """The exchange of this process group.  Keyed on the group AND what it looks like now: after
+        destroy_process_group() + a new init (or a new group object re-using an id) the old instance -- old world size,
+        rank, mailboxes, peer pointers -- must not be handed out again."""
+        pg = group if group is not None else dist.group.WORLD
+        key = id(pg)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        inst = cls._by_group.get(key)
+        if inst is None or inst.pg is not pg or (inst.world, inst.rank) != (world, rank):
+            inst = cls._by_group[key] = cls(group)
+            inst.pg = pg                           # (a strong reference: the id cannot be re-used while this entry lives)
+        return inst
+
+    @classmethod
+    def forget_all(cls):
+        """Drop every cached exchange (call after dist.destroy_process_group())."""
+        cls._by_group.clear()
 
     def __init__(self, group):
         self.group = group
+        self.pg = None
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.rccl = dist.get_backend(group) == "nccl"
         self.boxes = {}          # numel -> dict(P, R: this rank's mailboxes; keep: the peers' mapped tensors; pP, pR: pointer arrays)
         self.flag = None
+        self._side = None
+
+    def side_stream(self, device):
+        """The stream the exchange's launches run on, so that the compute stream's next SpMM overlaps them."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def ready(self, numel):
         return numel in self.boxes
@@ -229,9 +306,16 @@ class P2PExchange:
         import ctypes
         block = numel // self.world
         mail = [torch.zeros(numel, dtype=torch.float32, device=device), torch.zeros(block, dtype=torch.float32, device=device)]
-        mine = [(m.untyped_storage()._share_cuda_(), m.storage_offset()) for m in mail]
+        # every rank must see all the node's GPUs under the same indices (torchrun's default): a handle is opened on the
+        # OWNER's device index -- with per-rank HIP_VISIBLE_DEVICES that index names another (or no) device here
+        n_vis = torch.cuda.device_count()
+        mine = [(m.untyped_storage()._share_cuda_(), m.storage_offset()) for m in mail] + [torch.device(device).index or 0, n_vis]
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=self.group)
+        for r, entry in enumerate(everyone):
+            if entry[2] >= n_vis or entry[3] != n_vis:
+                raise RuntimeError(f"P2PExchange: rank {r} lives on device index {entry[2]} of {entry[3]} visible devices, "
+                                   f"this rank sees {n_vis}: the ranks do not share one device numbering")
         keep, ptrs = [], []
         for k, n in enumerate((numel, block)):
             row = []
@@ -290,7 +374,8 @@ def _sum_exchange_async(buf, group):
     """Sum `buf` ([rows_pad, D], rows_pad a multiple of the world size) over the ranks, in place, asynchronously."""
     if not _active(group):
         return _Pending(None)
-    mode = exchange_mode()
+    _count(buf)
+    mode = resolve_mode(buf)
     if mode == "direct" and buf.is_cuda and torch.cuda.is_current_stream_capturing():
         # RCCL's all-to-all cannot be captured on this stack (ROCm 7.2 / RCCL of torch 2.10: a captured
         # all_to_all_single hangs or segfaults even alone in a graph, tools/direct_capture_repro.py,
@@ -313,8 +398,16 @@ def _sum_exchange_async(buf, group):
         if not _p2p_usable(buf, group):
             mode = "allreduce"
         else:
-            P2PExchange.of(group).exchange(buf)
-            return _Pending(None)
+            ex = P2PExchange.of(group)
+            if not ex.ready(buf.numel()):
+                ex.setup(buf.numel(), buf.device)          # (collective, eager only: raises inside a capture)
+            MODES_USED.add("p2p")
+            side = ex.side_stream(buf.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ex.exchange(buf)
+            return _PendingStream(side)
+    MODES_USED.add("allreduce" if (mode == "allreduce" or buf.shape[0] % dist.get_world_size(group)) else mode)
     if mode == "allreduce" or buf.shape[0] % dist.get_world_size(group):
         return _Pending(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -339,8 +432,135 @@ def _sum_exchange_async(buf, group):
 def _all_reduce_async(t, group):
     """Whole-tensor all-reduce (small / unpadded tensors)."""
     if _active(group):
+        _count(t)
         return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True))
     return _Pending(None)
+
+
+def calibrate_exchange(n_rows, D, device, group=None, captured=False, reps=3, candidates=("allreduce", "rs_ag", "p2p")):
+    """First contact + choice for exchange buffers of [n_rows (padded), D] floats on THIS node, before a step trusts them:
+    every candidate mode sums a seeded random buffer through the product path (_sum_exchange_async: eagerly, and --
+    captured=True -- from a replayed hipGraph on fresh contents, twice) and is compared with dist.all_reduce of the same
+    data; the result must also be the SAME BITS on every rank (the replicated item rows must not drift apart).  A mode
+    that raises or differs is vetoed for the rest of the process (resolve_mode then gives rs_ag / allreduce); among the
+    ones that passed, the fastest (max over ranks of the median of `reps` timed exchanges) becomes what `auto` picks
+    for buffers of this size.  Collective: every rank calls it with the same arguments.  -> the table (also kept in
+    CALIBRATION for the bench line).  What it covers that no 1-GPU test can: the p2p exchange's cross-device visibility
+    (peer kernels' writes read through an IPC mapping after a stream-ordered RCCL barrier)."""
+    if not _active(group):
+        return {}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rows = padded_rows(n_rows, group)
+    dev = torch.device(device)
+    on_gpu = dev.type == "cuda"
+    gen = torch.Generator(device=dev).manual_seed(977 + rank)
+
+    def fresh():
+        return torch.rand((rows, D), generator=gen, device=dev, dtype=torch.float32) - 0.5
+
+    def agreed(ok):
+        t = torch.tensor([1.0 if ok else 0.0], device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(t.item() > 0)
+
+    def same_on_all_ranks(t):
+        hi, lo = t.clone(), t.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        return bool(torch.equal(hi, lo))
+
+    def check(out, src):
+        ref = src.clone()
+        dist.all_reduce(ref, group=group)
+        same = same_on_all_ranks(out)               # (collective: never behind a rank-local condition)
+        return bool(torch.allclose(out, ref, rtol=0, atol=2e-6 * world)) and same
+
+    table = {}
+    for mode in candidates:
+        if mode in _VETOED:
+            table[mode] = {"ok": False, "why": "vetoed before calibration"}
+            continue
+        why, ms = None, None
+        _FORCED[0] = mode
+
+        def stage(fn):
+            """One stage on every rank, then ONE agreement on whether it worked everywhere: the ranks enter the next
+            stage together or not at all (a rank-local exception must not leave the others inside a collective alone)."""
+            nonlocal why
+            try:
+                good = fn()
+            except Exception as exc:      # noqa: BLE001 -- "this mode does not work here", never a wrong step
+                good, why = False, why or repr(exc)[:200]
+            return agreed(bool(good))
+
+        def eager():
+            nonlocal why
+            src = fresh()
+            out = src.clone()
+            _sum_exchange_async(out, group).wait()
+            if on_gpu:
+                torch.cuda.synchronize()
+            if not check(out, src):
+                why = "eager sum differs from all_reduce"
+                return False
+            return True
+
+        def replayed():
+            nonlocal why
+            static_src, static_out = fresh(), torch.empty((rows, D), device=dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out.copy_(static_src)
+                _sum_exchange_async(static_out, group).wait()
+            good = True
+            for _ in range(2):
+                static_src.copy_(fresh())
+                g.replay()
+                torch.cuda.synchronize()
+                if not check(static_out, static_src) and good:        # (check() is collective: run it both times)
+                    good, why = False, "captured sum differs from all_reduce on replay"
+            return good
+
+        def timed():
+            nonlocal ms
+            import time as _time
+            out = fresh()
+            times = []
+            for _ in range(reps):
+                if on_gpu:
+                    torch.cuda.synchronize()
+                dist.barrier(group=group)
+                t0 = _time.perf_counter()
+                _sum_exchange_async(out, group).wait()
+                if on_gpu:
+                    torch.cuda.synchronize()
+                times.append(_time.perf_counter() - t0)
+            t = torch.tensor([float(np.median(times))], dtype=torch.float64,
+                             device=dev if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            ms = float(t.item()) * 1e3
+            return True
+
+        try:
+            ok = stage(eager)
+            if ok and captured and on_gpu:
+                ok = stage(replayed)
+            if ok:
+                ok = stage(timed)
+        finally:
+            _FORCED[0] = None
+        if not ok:
+            veto(mode)
+        table[mode] = {"ok": ok, "ms": ms if ok else None}
+        if why:
+            table[mode]["why"] = why
+    good = {m: e["ms"] for m, e in table.items() if e["ok"] and e["ms"] is not None}
+    if good:
+        best = min(good, key=good.get)
+        _AUTO_BIG_CHOICE[rows * D] = best
+        table["chosen"] = best
+    CALIBRATION[rows * D] = dict(table, rows=rows, D=D, bytes=rows * D * 4, captured=bool(captured and on_gpu))
+    return table
 
 
 class _ShardedLayerMean(torch.autograd.Function):
@@ -512,6 +732,9 @@ class _HipStepKernels:
     mean_terms_limit = staticmethod(ops.mean_terms_limit)
 
 
+SPLIT_BYTES = int(_os.environ.get("CHAOREC_DIST_SPLIT_BYTES", str(64 << 20)))     # item partial size from which a step splits
+
+
 class FusedShardedLightGCNStep:
     """optim.FusedLightGCNStep for a user-row shard: one training iteration of Model/LightGCN.py:76-135 +
     train_and_evaluate.py:43-48 on rank g's users as a fixed launch sequence -- no autograd tape, no optimizer launch for
@@ -532,7 +755,9 @@ class FusedShardedLightGCNStep:
     folded into the epilogue factors.  Item rows end identical on every rank (same sums, same Adam arithmetic)."""
 
     def __init__(self, model, optimizer, batch_size=1024, edges=None, seed=42, step_dev=None, given_batch=False,
-                 loss_accum=None, capture=True, kernels=None, group=None, steps_per_replay=1):
+                 loss_accum=None, capture=True, kernels=None, group=None, steps_per_replay=1, split=None):
+        """split: None = by size (item partial I_pad * D * 4 >= SPLIT_BYTES, or CHAOREC_DIST_SPLIT=0/1), True / False =
+        the split / joined launch sequence (see _launch_split)."""
         from .optim import FusedAdam
         if not isinstance(optimizer, FusedAdam) or len(optimizer.param_groups) != 1:
             raise TypeError("FusedShardedLightGCNStep needs a FusedAdam with one parameter group")
@@ -578,6 +803,10 @@ class FusedShardedLightGCNStep:
         self.bc = torch.ones(2, dtype=torch.float32, device=dev)
         self.use_mean = self.L <= self.K.mean_terms_limit(D)
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if split is None:
+            env = _os.environ.get("CHAOREC_DIST_SPLIT", "")
+            split = (env == "1") if env in ("0", "1") else (self.N_pad - U) * D * 4 >= SPLIT_BYTES
+        self.split = bool(split)
         self.replays = 0
         self.graph = self.graph1 = None
         # k steps per hipGraph (in-launch batches only): a replay boundary costs ~5.5 us on this stack, the launches inside
@@ -586,28 +815,33 @@ class FusedShardedLightGCNStep:
         if capture:
             for c in (self.csr, shard.ui, shard.iu):
                 c.schedule(D)                   # lazily built by the first SpMM: must exist before capture
+            # whatever happens below (a capture that raises included), the model, the Adam moments and the step / loss
+            # counters leave this constructor as they entered it: a caller that falls back to capture=False then starts
+            # from the same state as the captured run would have
             saved = self._save_state()
-            s = torch.cuda.Stream(device=dev)
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                self._launch()                  # eager first: communicators are set up outside capture
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            self._restore_state(saved)
-            self.graph1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph1):
-                self._launch()
-            self.graph = self.graph1
-            if self.steps_per_replay > 1:
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    for _ in range(self.steps_per_replay):
-                        self._launch()
-            saved = self._save_state()
-            for gph in {id(self.graph1): self.graph1, id(self.graph): self.graph}.values():
-                gph.replay()
-            torch.cuda.synchronize()
-            self._restore_state(saved)
+            try:
+                s = torch.cuda.Stream(device=dev)
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._launch()                  # eager first: communicators are set up outside capture
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                self._restore_state(saved)
+                self.graph1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph1):
+                    self._launch()
+                self.graph = self.graph1
+                if self.steps_per_replay > 1:
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph):
+                        for _ in range(self.steps_per_replay):
+                            self._launch()
+                for gph in {id(self.graph1): self.graph1, id(self.graph): self.graph}.values():
+                    gph.replay()
+                torch.cuda.synchronize()
+            finally:
+                torch.cuda.synchronize()
+                self._restore_state(saved)
 
     def _counters(self):
         return [t for t in (self.step_dev, self.loss_accum, self.optimizer._step_dev) if t is not None]
@@ -636,6 +870,8 @@ class FusedShardedLightGCNStep:
             # (model.to(...) / weight.data = ... after this step was built: it would train a buffer nobody reads)
             raise RuntimeError("FusedShardedLightGCNStep: the model's embedding tables were re-allocated after the step was "
                                "built; build a new step")
+        if self.split:
+            return self._launch_split()
         group = opt.param_groups[0]
         shard, csr, w = model.shard, self.csr, 1.0 / (L + 1)
         xs = [self.flat]
@@ -674,6 +910,69 @@ class FusedShardedLightGCNStep:
                     group["eps"], group["weight_decay"], alpha=alpha, z=self.G[:U], beta=c, clear_z=True)
         pend.wait()
         K.adam_step(self.flat[U:N], Y[U:N], self.m[U:N], self.v[U:N], 0, group["lr"], group["betas"], group["eps"],
+                    group["weight_decay"], step_dev=opt._step_dev)
+        self.G[U:N].zero_()
+        model.result_u, model.result_i, model._result_cat = self.final[:U], self.final[U:N], None
+
+    @torch.no_grad()
+    def _launch_split(self):
+        """The same step with every joined launch cut into its two row blocks, so that EVERY exchange travels under
+        compute (large item tables: config 5's 1 GB item partial takes longer over xGMI than the SpMM that produced it).
+        Layer l + 1's item partial B_g^T x_u(l) needs only this rank's user rows of layer l -- not the exchanged item rows
+        of layer l -- so per layer:
+
+            SpMM over B_g^T (item partial of layer l+1)  ->  exchange l+1 starts
+            wait for exchange l                           (it travelled under the two launches issued since it started)
+            SpMM over B_g (user rows of layer l+1, gathers the now complete item rows of layer l)
+
+        and the backward mirrors it (the gradient seed's exchange travels under the first B_g^T launch).  2 launches per
+        layer and direction instead of 1 (4.4 us each: nothing against a millisecond exchange, too much at sports size --
+        hence by size).  Row for row the same sums in the same order as the joined launches: bit-identical results."""
+        K, model, opt, L, B, D = self.K, self.model, self.optimizer, self.L, self.B, self.D
+        U, I, N = self.U, self.I, self.N
+        group = opt.param_groups[0]
+        shard, w = model.shard, 1.0 / (L + 1)
+        ui, iu = shard.ui, shard.iu
+        xs, pend = [self.flat], None
+        for l in range(L):
+            x, y = xs[-1], self.ybuf[l]
+            K.spmm(iu, x[:U], y=y[U:N])
+            nxt = self._exchange(y)
+            if pend is not None:
+                pend.wait()                          # x's item rows are the sum over the ranks from here on
+            if l == L - 1 and self.use_mean:         # (x_L's user rows feed nothing but the mean: not stored)
+                K.spmm_mean(ui, x[U:N], [t[:U] for t in xs], w, self.final[:U])
+            else:
+                K.spmm(ui, x[U:N], y=y[:U])
+            pend = nxt
+            xs.append(y)
+        pend.wait()
+        lo = U if self.use_mean else 0
+        K.rows_mean([t[lo:N] for t in xs], w, self.final[lo:N])
+        draw = self.edges is not None
+        K.bpr_fwd_bwd(self.final, U, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef, self.ws, self.ids,
+                      edges=self.edges, hist=model.hist if draw else None, num_user=U, num_item=I, seed=self.seed, step=0,
+                      step_dev=self.step_dev, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
+        K.bpr_finalize(self.ws, B, D, model.reg_weight, self.out, out_total=self.static_loss, loss_accum=self.loss_accum,
+                       advance=self.step_dev if draw else None)
+        c = w / self.world
+        self.S.copy_(self.G)
+        pend = self._exchange(self.S)                # the seed's item rows: summed while the first B_g^T launch runs
+        g, alpha = self.S, c
+        for l in range(L):
+            last = l == L - 1
+            Y = self.ybuf[min(L - 1, 2)] if last else self.ybuf[l & 1]
+            K.spmm(iu, g[:U], y=Y[U:N], alpha=alpha, z=self.G[U:N], beta=c)
+            nxt = self._exchange(Y)
+            pend.wait()
+            if last:
+                K.spmm_adam(ui, g[U:N], self.flat[:U], self.m[:U], self.v[:U], self.bc, group["lr"], group["betas"],
+                            group["eps"], group["weight_decay"], alpha=alpha, z=self.G[:U], beta=c, clear_z=True)
+            else:
+                K.spmm(ui, g[U:N], y=Y[:U], alpha=alpha, z=self.G[:U], beta=c)
+            g, alpha, pend = Y, 1.0, nxt
+        pend.wait()
+        K.adam_step(self.flat[U:N], g[U:N], self.m[U:N], self.v[U:N], 0, group["lr"], group["betas"], group["eps"],
                     group["weight_decay"], step_dev=opt._step_dev)
         self.G[U:N].zero_()
         model.result_u, model.result_i, model._result_cat = self.final[:U], self.final[U:N], None
@@ -1001,6 +1300,7 @@ class _SumGradAcrossRanks(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous().clone()
         if _active(ctx.group):
+            _count(g)
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
         return g, None
 

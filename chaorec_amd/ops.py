@@ -845,14 +845,17 @@ class _Linear(torch.autograd.Function):
         gy = _leaky_bwd_raw(y, gy, ctx.act) if ctx.act else gy.contiguous()
         gx = None
         xp = ctx.x_param
+        # Everything that READS x first: with FusedAdam.early_tables a claimed table's in-place update starts on a side
+        # stream the moment submit() is called -- x IS that table here, and the weight gradient below reads all of it
+        # (submit() before _linear_gw_raw raced the update against this node's own read).
+        gw = _linear_gw_raw(gy, x) if ctx.needs_input_grad[1] else None
+        gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[2] else None     # (not gy.sum(0): see col_sum)
         if ctx.needs_input_grad[0] and xp is not None and weight.shape[0] <= 64 and xp._chaorec_lowrank_sink.accepts(xp):
             # the input is a claimed feature table (Model/MGCN.py:80-83: trainable [I, 4096] features projected as a
             # whole): its dense gradient gy W is never formed, the optimizer applies it row by row (adam_lowrank)
             xp._chaorec_lowrank_sink.submit(xp, gy, weight, None, dense_reader=True)
         elif ctx.needs_input_grad[0]:
             gx = _linear_gx_raw(gy, weight)
-        gw = _linear_gw_raw(gy, x) if ctx.needs_input_grad[1] else None
-        gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[2] else None     # (not gy.sum(0): see col_sum)
         return gx, gw, gb, None
 
 

@@ -75,14 +75,16 @@ class RankState:
         return True
 
     last_hinted = False
+    last_light = False       # (what the last call ran as: read by bench.py for its line, never by the product)
     prev_queue = None
 
-    def after_call(self, hinted):
+    def after_call(self, hinted, light=False):
         self.counters_host.copy_(self.counters, non_blocking=True)
         self.copied = torch.cuda.Event()
         self.copied.record()
         self.valid = True
         self.last_hinted = bool(hinted)
+        self.last_light = bool(light)
 
 
 def hint_rank_for(topk):
@@ -129,10 +131,10 @@ def gene_ranklist(result, num_user, num_item, hist, mask_value=1e-6, topk=50, to
         if state is not None:
             hint = state.buffer(num_user, result.device)
             hinted = state.use_hints(num_user)          # (once per call: it consumes the previous call's counters)
+            light = hinted and state.light()
             idx, _ = ops.score_topk(ue, ie, hist, mask_value, topk, id_offset=id_offset, hint=hint, hint_valid=hinted,
-                                    hint_rank=hint_rank_for(topk), light=hinted and state.light(),
-                                    counters=state.counters, idx_out=host)
-            state.after_call(hinted)
+                                    hint_rank=hint_rank_for(topk), light=light, counters=state.counters, idx_out=host)
+            state.after_call(hinted, light)
         else:
             idx, _ = ops.score_topk(ue, ie, hist, mask_value, topk, id_offset=id_offset, idx_out=host)
     if host is not None:

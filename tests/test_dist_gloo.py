@@ -297,7 +297,7 @@ class _OracleStepKernels:
             loss_accum += ws[0]
 
 
-def _worker_fused(rank, world, port, tmp, mode, L):
+def _worker_fused(rank, world, port, tmp, mode, L, split=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = mode
@@ -315,7 +315,9 @@ def _worker_fused(rank, world, port, tmp, mode, L):
     m = cdist.ShardedLightGCN(shard, None, D, 1e-3, L, torch.device("cpu"), seed=9)
     x0u, x0i = m.user_embedding.weight.detach().clone().numpy(), m.item_embedding.weight.detach().clone().numpy()
     opt = FusedAdam(m.parameters(), lr=1e-2)
-    step = cdist.FusedShardedLightGCNStep(m, opt, batch_size=B, given_batch=True, capture=False, kernels=_OracleStepKernels)
+    step = cdist.FusedShardedLightGCNStep(m, opt, batch_size=B, given_batch=True, capture=False, kernels=_OracleStepKernels,
+                                          split=split)
+    assert step.split == split
     assert step.N_pad % world == (shard.num_user_local % world)          # item rows padded to a multiple of the world size
     rng = np.random.default_rng(100 + rank)
     batches, losses = [], []
@@ -335,13 +337,16 @@ def _worker_fused(rank, world, port, tmp, mode, L):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,L", [(2, "allreduce", 3), (2, "direct", 1), (4, "rs_ag", 2)])
-def test_fused_sharded_step_trains_like_the_single_process_oracle(oracle, world, mode, L):
+@pytest.mark.parametrize("world,mode,L,split", [(2, "allreduce", 3, False), (2, "direct", 1, False), (4, "rs_ag", 2, False),
+                                                (2, "auto", 3, True), (4, "allreduce", 2, True), (2, "rs_ag", 1, True)])
+def test_fused_sharded_step_trains_like_the_single_process_oracle(oracle, world, mode, L, split):
     """dist.FusedShardedLightGCNStep (joined-graph propagates, in-place item exchanges, Adam in the last propagate /
     one fused launch for the replicated item rows) over T optimizer steps against the oracle on the WHOLE graph: the global
-    loss is the mean of the ranks' batch losses, torch.optim.Adam's arithmetic on its gradient."""
+    loss is the mean of the ranks' batch losses, torch.optim.Adam's arithmetic on its gradient.  split=True: the launch
+    sequence of large item tables (every joined launch as its two row blocks, every exchange in flight under the next
+    launches, dist.FusedShardedLightGCNStep._launch_split)."""
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker_fused, args=(world, _free_port(), tmp, mode, L), nprocs=world, join=True)
+        mp.spawn(_worker_fused, args=(world, _free_port(), tmp, mode, L, split), nprocs=world, join=True)
         r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
     U, I, D, T = 500, 203, 16, 3
     edges = _heavy_tailed_graph(U, I)
@@ -701,3 +706,43 @@ def test_sharded_freedom_matches_single_process(oracle, dropout, claimed):
             for x in r:
                 got = x[f"g_{name}.{pn}"]
                 assert np.allclose(got, p.grad.numpy(), rtol=2e-4, atol=1e-8), (name, pn)
+
+
+def _worker_calibrate(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("CHAOREC_DIST_EXCHANGE", None)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chaorec_amd import dist as cdist
+    cdist.AUTO_BIG_BYTES = 1024                        # (so that the test's small buffer counts as a large one)
+    table = cdist.calibrate_exchange(203, 16, "cpu", candidates=("allreduce", "rs_ag", "direct"))
+    assert all(table[m]["ok"] and table[m]["ms"] > 0 for m in ("allreduce", "rs_ag", "direct")), table
+    buf = torch.zeros((cdist.padded_rows(203), 16))
+    assert cdist.resolve_mode(buf) == table["chosen"]                    # `auto` now picks what was measured fastest
+    assert cdist.resolve_mode(torch.zeros((4, 16))) == "allreduce"       # small buffers: one all-reduce
+    # a mode whose sum is wrong is vetoed on EVERY rank, even when only one rank saw it differ
+    real = cdist._sum_exchange_async
+
+    def broken(b, group):
+        pend = real(b, group)
+        if cdist._FORCED[0] == "rs_ag" and rank == 1:
+            pend.wait()
+            b[0, 0] += 1.0
+            return cdist._Pending(None)
+        return pend
+
+    cdist._sum_exchange_async = broken
+    table = cdist.calibrate_exchange(203, 16, "cpu", candidates=("allreduce", "rs_ag"))
+    cdist._sum_exchange_async = real
+    assert table["allreduce"]["ok"] and not table["rs_ag"]["ok"] and table["chosen"] == "allreduce", table
+    os.environ["CHAOREC_DIST_EXCHANGE"] = "rs_ag"
+    assert cdist.resolve_mode(buf) == "allreduce" and "rs_ag" in cdist.exchange_mode_used()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_calibrate_exchange_checks_every_mode_against_all_reduce_and_vetoes_wrong_ones():
+    """dist.calibrate_exchange: the first-contact check bench.py runs before it trusts an exchange mode on a node."""
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_calibrate, args=(2, _free_port(), tmp), nprocs=2, join=True)

@@ -34,7 +34,7 @@ def _problem():
     return edges, x0, batches
 
 
-def _worker(rank, world, port, tmp, L, exchange="allreduce"):
+def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = exchange
@@ -54,7 +54,9 @@ def _worker(rank, world, port, tmp, L, exchange="allreduce"):
     with torch.no_grad():
         m.user_embedding.weight.copy_(x0[shard.u0:shard.u1])
         m.item_embedding.weight.copy_(x0[U:])
-    step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=False)
+    step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=False,
+                                          split=split)
+    assert step.split == split
     losses = []
     for t in range(T):
         # this rank's batch: the triples of BOTH ranks' draws whose user it owns would change the batch size; instead
@@ -116,7 +118,7 @@ def _p2p_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def _rccl_worker(rank, world, port, tmp, exchange, direct_capture):
+def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = exchange
@@ -136,7 +138,8 @@ def _rccl_worker(rank, world, port, tmp, exchange, direct_capture):
     with torch.no_grad():
         m.user_embedding.weight.copy_(x0[:U])
         m.item_embedding.weight.copy_(x0[U:])
-    step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=True)
+    step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=True,
+                                          split=split)
     losses = []
     for t in range(T):
         rng = np.random.default_rng(100 * t)
@@ -146,7 +149,7 @@ def _rccl_worker(rank, world, port, tmp, exchange, direct_capture):
         neg = torch.from_numpy(rng.integers(U, U + I, B)).to(dev)
         losses.append(float(step(users, pos, neg)))
     torch.cuda.synchronize()
-    np.savez(os.path.join(tmp, f"rccl_{exchange}_{direct_capture}.npz"), xu=m.user_embedding.weight.detach().cpu().numpy(),
+    np.savez(os.path.join(tmp, f"rccl_{exchange}_{direct_capture}_{int(split)}.npz"), xu=m.user_embedding.weight.detach().cpu().numpy(),
              xi=m.item_embedding.weight.detach().cpu().numpy(), losses=np.array(losses), used=cdist.exchange_mode_used())
     dist.destroy_process_group()
 
@@ -160,10 +163,14 @@ def test_captured_exchanges_on_a_one_rank_rccl_group():
     import torch.multiprocessing as mp
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for exchange, dc in (("allreduce", "rs_ag"), ("p2p", "rs_ag"), ("direct", "p2p"), ("direct", "rs_ag")):
-            mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, exchange, dc), nprocs=1, join=True)
-            out[(exchange, dc)] = dict(np.load(os.path.join(tmp, f"rccl_{exchange}_{dc}.npz")))
-    ref = out[("allreduce", "rs_ag")]
+        for exchange, dc, split in (("allreduce", "rs_ag", False), ("p2p", "rs_ag", False), ("direct", "p2p", False),
+                                    ("direct", "rs_ag", False), ("allreduce", "rs_ag", True), ("p2p", "rs_ag", True),
+                                    ("rs_ag", "rs_ag", True)):
+            # split=True: every exchange in flight under the next launches (RCCL's own stream / the p2p side stream, forked
+            # and joined inside the captured graph)
+            mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, exchange, dc, split), nprocs=1, join=True)
+            out[(exchange, dc, split)] = dict(np.load(os.path.join(tmp, f"rccl_{exchange}_{dc}_{int(split)}.npz")))
+    ref = out[("allreduce", "rs_ag", False)]
     for key, r in out.items():
         # two runs differ by the order of the BPR backward's atomic row adds (~1e-7 relative on a gradient); Adam turns a
         # gradient that is ALL rounding noise into a full step, so a handful of elements may differ by lr: count them
@@ -171,7 +178,7 @@ def test_captured_exchanges_on_a_one_rank_rccl_group():
             d = np.abs(r[name] - ref[name])
             assert (d > 2e-6).mean() <= 1e-4 and np.median(d) <= 1e-7, (key, name, float(d.max()))
         assert np.allclose(r["losses"], ref["losses"], rtol=1e-5), key
-    assert "p2p" in str(out[("direct", "p2p")]["used"]) and "rs_ag" in str(out[("direct", "rs_ag")]["used"])
+    assert "p2p" in str(out[("direct", "p2p", False)]["used"]) and "rs_ag" in str(out[("direct", "rs_ag", False)]["used"])
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -191,14 +198,17 @@ def test_p2p_exchange_sums_like_an_all_reduce(world):
         assert np.array_equal(r[0]["got"], r[k]["got"])
 
 
-@pytest.mark.parametrize("L,world,exchange", [(1, 2, "allreduce"), (3, 2, "allreduce"), (2, 4, "allreduce"), (3, 2, "p2p"),
-                                              (2, 4, "p2p")])
-def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world, exchange):
+@pytest.mark.parametrize("L,world,exchange,split", [(1, 2, "allreduce", False), (3, 2, "allreduce", False),
+                                                    (2, 4, "allreduce", False), (3, 2, "p2p", False), (2, 4, "p2p", False),
+                                                    (3, 2, "allreduce", True), (2, 4, "p2p", True), (1, 2, "p2p", True)])
+def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world, exchange, split):
+    """split=True: the launch sequence of large item tables (dist.FusedShardedLightGCNStep._launch_split) -- every joined
+    launch as its two row blocks, every exchange travelling under the launches that follow it."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, _free_port(), tmp, L, exchange), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), tmp, L, exchange, split), nprocs=world, join=True)
         r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
     # the whole-graph reference: the oracle's loss gradient of the mean over the ranks' batches + Adam, in fp64
     from chaorec_amd import dist as cdist
@@ -229,6 +239,93 @@ def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world, exchange):
     for k in range(world):
         assert np.allclose(r[k]["xi"], x[U:], rtol=0, atol=3e-5)
         assert np.array_equal(r[0]["xi"], r[k]["xi"])                  # identical item update on every rank
+
+
+def test_split_launches_equal_the_joined_launches_bit_for_bit():
+    """One process, no group: the split step's forward (row blocks of the joined graph as separate launches, the user
+    rows' mean in the B_g launch's epilogue) writes the same bits as the joined step's; after three Adam steps the tables
+    agree up to the BPR backward's atomic-add order."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from chaorec_amd import dist as cdist
+    from chaorec_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    edges, x0, _ = _problem()
+    out = {}
+    for split in (False, True):
+        shard = cdist.UserShard.from_local(edges, [0, U], I, 1, 0, dev)
+        m = cdist.ShardedLightGCN(shard, None, D, 1e-3, 3, dev, seed=1).to(dev)
+        with torch.no_grad():
+            m.user_embedding.weight.copy_(x0[:U])
+            m.item_embedding.weight.copy_(x0[U:])
+        step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True,
+                                              capture=False, split=split)
+        finals = []
+        for t in range(T):
+            rng = np.random.default_rng(100 * t)
+            sel = rng.choice(len(shard.local_edges), B, replace=False)
+            users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64)).to(dev)
+            pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64)).to(dev)
+            neg = torch.from_numpy(rng.integers(U, U + I, B)).to(dev)
+            step(users, pos, neg)
+            if t == 0:
+                finals.append(step.final[:U + I].clone())
+        out[split] = (finals[0].cpu(), m.user_embedding.weight.detach().cpu(), m.item_embedding.weight.detach().cpu())
+    assert torch.equal(out[False][0], out[True][0])                       # the first forward: same weights in, same bits out
+    for a, b in zip(out[False][1:], out[True][1:]):
+        d = (a - b).abs()
+        assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7
+
+
+def _calibrate_worker(rank, world, port, tmp, backend):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("CHAOREC_DIST_EXCHANGE", None)
+    os.environ["CHAOREC_FORCE_COLLECTIVES"] = "1"
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chaorec_amd import dist as cdist
+    cdist.AUTO_BIG_BYTES = 1 << 16
+    table = cdist.calibrate_exchange(1001, 64, dev, captured=backend == "nccl", candidates=("allreduce", "rs_ag", "p2p"))
+    buf = torch.zeros((cdist.padded_rows(1001), 64), device=dev)
+    chosen = cdist.resolve_mode(buf)
+    # the product path with `auto`: a buffer of the calibrated size goes through the chosen mode and sums correctly
+    g = torch.Generator(device=dev).manual_seed(5 + rank)
+    src = torch.rand(buf.shape, generator=g, device=dev)
+    want = src.clone()
+    dist.all_reduce(want)
+    got = src.clone()
+    cdist._sum_exchange_async(got, None).wait()
+    torch.cuda.synchronize()
+    import json
+    with open(os.path.join(tmp, f"cal{rank}.json"), "w") as f:
+        json.dump({"table": table, "chosen": chosen, "sum_ok": bool(torch.allclose(got, want, rtol=0, atol=1e-5)),
+                   "used": cdist.exchange_mode_used()}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_calibrate_exchange_on_the_gpu(world, backend):
+    """dist.calibrate_exchange on the real kernels: two ranks sharing one GPU (gloo collectives + the IPC pull kernels),
+    and a 1-rank RCCL group with the exchanges also replayed from a hipGraph (the p2p exchange on its side stream, its
+    barriers RCCL launches inside the graph).  Every mode passes; `auto` then resolves large buffers to the chosen one."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_calibrate_worker, args=(world, _free_port(), tmp, backend), nprocs=world, join=True)
+        r = [json.load(open(os.path.join(tmp, f"cal{k}.json"))) for k in range(world)]
+    for x in r:
+        assert all(x["table"][m]["ok"] for m in ("allreduce", "rs_ag", "p2p")), x["table"]
+        assert x["chosen"] == x["table"]["chosen"] == r[0]["chosen"] and x["sum_ok"], x
 
 
 # ---------------------------------------------------------------------------------------------------- MMGCN (configs[3])

@@ -409,3 +409,27 @@ def test_freedom_edge_weights_follow_the_reference_formulas():
                                    torch.cat((got, got)), (nu + ni, nu + ni)).coalesce()
     rows = torch.repeat_interleave(torch.arange(nu + ni), csr.rowptr[1:] - csr.rowptr[:-1])
     assert torch.equal(torch.stack((rows, csr.col.long())), full.indices()) and torch.allclose(csr.val, full.values(), rtol=1e-6, atol=0)
+
+
+def test_bench_launches_its_own_ranks_and_propagates_failures():
+    """`python bench.py --gpus N` without torchrun: the launcher starts N children with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* before any GPU call, relays rank 0's JSON line and exits with a failing rank's code.  The
+    children here run the launcher's self-test mode (a gloo all-reduce): no GPU in this container."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "3", "--launch-selftest"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"selftest": True, "n_gpus": 3, "sum": 6.0, "local_rank": 0, "self_launched": True}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-selftest"],
+                       env=dict(env, CHAOREC_BENCH_SELFTEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7 and "a rank ended with 7" in r.stderr
+    # without a GPU the real bench must fail loudly through the launcher too (no CPU path), not hang
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=dict(env, CHAOREC_DIST_GRAPH="0"), capture_output=True, text=True, timeout=300)
+    if not __import__("torch").cuda.is_available():
+        assert r.returncode != 0 and "needs the MI355X" in r.stderr
