@@ -164,7 +164,8 @@ def captured_all_reduce_is_exact(dev, world, rank):
         dist.all_reduce(t)                               # eager first: communicator set-up happens outside capture
     cur.wait_stream(side)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (RCCL's watchdog thread polls events meanwhile)
         t.copy_(src)
         dist.all_reduce(t)
     ok = True
@@ -311,8 +312,9 @@ def time_spmm_chain(calls, min_pass_ms=10.0, passes=5):
             for fn, _, _ in calls:
                 fn()
         torch.cuda.current_stream().wait_stream(side)
+        import torch.distributed as _td
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if _td.is_initialized() else "global"):
             for fn, _, _ in calls:
                 fn()
     except Exception:      # noqa: BLE001
@@ -478,6 +480,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     avg_spmm_ms, model_bytes, compulsory = time_spmm_chain(plain, passes=3 if heavy_graph else 5)
     whole_ms, _, _ = time_spmm_chain(whole, passes=3 if heavy_graph else 5)
     whole_ms *= len(whole)                           # all SpMM-family launches of ONE step, boundaries included
+    n_plain, n_whole = len(plain), len(whole)
     del b0, b1, fin, G, plain, whole
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
     table_mb = N * D * 4 / 1e6
@@ -500,10 +503,10 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": model_bytes,
                 "avg_launch_us": avg_spmm_ms * 1e3, "compulsory_bytes_per_launch": compulsory,
-                "launches_per_step": len(plain), "timing": CHAIN_TIMING_NOTE,
-                "spmm_launches_of_one_step": {"launches": len(whole), "us": whole_ms * 1e3,
+                "launches_per_step": n_plain, "timing": CHAIN_TIMING_NOTE,
+                "spmm_launches_of_one_step": {"launches": n_whole, "us": whole_ms * 1e3,
                                               "share_of_ms_per_step": whole_ms / ms_per_step,
-                                              "what": f"the step's {len(whole)} SpMM-family launches ({len(plain)} plain + layer-mean "
+                                              "what": f"the step's {n_whole} SpMM-family launches ({n_plain} plain + layer-mean "
                                                       f"epilogue + Adam epilogue) replayed in order as one hipGraph"},
                 "note": ("embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is against "
                          "the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)" % table_mb)

@@ -179,9 +179,9 @@ class FREEDOM(nn.Module):
         elif not cur.update_from(new):
             # another entry count (a train.npy with repeated interactions coalesces to fewer entries; a key tie in the
             # race select): the arrays cannot be rewritten in place.  Without a captured step nothing holds their
-            # addresses: rebind.  With one, the caller has to re-capture (train_and_evaluate does: graph_stale).
+            # addresses: rebind.  With one, the caller has to re-capture (train_and_evaluate does: graph_generation).
             self.masked_adj = new
-            self.graph_stale = True
+            self.graph_generation = getattr(self, "graph_generation", 0) + 1
 
     # ---- hot path ---------------------------------------------------------------------------
     def forward(self, adj):

@@ -110,9 +110,9 @@ class LayerGCN(nn.Module):
         elif not cur.update_from(new):
             # another entry count (a train.npy with repeated interactions coalesces to fewer entries; a key tie in the
             # race select): the arrays cannot be rewritten in place.  Without a captured step nothing holds their
-            # addresses: rebind.  With one, the caller has to re-capture (train_and_evaluate does: graph_stale).
+            # addresses: rebind.  With one, the caller has to re-capture (train_and_evaluate does: graph_generation).
             self.masked_adj = new
-            self.graph_stale = True
+            self.graph_generation = getattr(self, "graph_generation", 0) + 1
 
     def get_ego_embeddings(self):
         return torch.cat([self.user_embeddings, self.item_embeddings], 0)

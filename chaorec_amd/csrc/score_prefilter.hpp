@@ -117,11 +117,6 @@ struct PrefArgs {
   int *fb_done;                 // [U] slices finished per queued user (zeroed per call)
   uint64_t *fb_partial;         // [U][kExSlices][kMaxK] per-slice best keys
   int fb_skip;                  // queue entries below this index were ranked by the grouped f32 sweep
-  // block-joint selection (score_blocksel.hpp): the sweep writes per-user-block union bitmaps instead of per-lane lists
-  uint32_t *bitmap;             // [user block][split][chunk][64] raw hit words (one per tile), or NULL
-  int bm_chunks;                // chunks of 64 tiles per split
-  int key_cap;                  // keys per user the selection's lists hold
-  uint64_t *keys;               // [launch row][key_cap] keys above the user's threshold
 };
 
 // ---- pack ----------------------------------------------------------------------------------------------------
@@ -518,29 +513,18 @@ constexpr int kSweepStage = CHAOREC_SWEEP_STAGE;
 #ifndef CHAOREC_SWEEP_PARK
 #define CHAOREC_SWEEP_PARK 8
 #endif
-#ifndef CHAOREC_SWEEP_PIPE
-#define CHAOREC_SWEEP_PIPE 0
-#endif
-constexpr bool kSweepPipe = CHAOREC_SWEEP_PIPE != 0;
-#ifndef CHAOREC_SWEEP_BFREE
-#define CHAOREC_SWEEP_BFREE 0
-#endif
-constexpr bool kSweepBranchFree = CHAOREC_SWEEP_BFREE != 0;
 constexpr int kSweepPark = CHAOREC_SWEEP_PARK;    // list entries per lane and user block parked in LDS (0: store each at once)
 static_assert(kSweepPark % 4 == 0 && kSweepPark <= kPfCap, "whole 16-byte stores inside a list");
 
-template <int D, int UB, bool BM>
+template <int D, int UB>
 __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(const PrefArgs P) {
   constexpr int FR = D / 16 + 1;                       // fragments (1 KiB each) per tile
   __shared__ uint4 stage[2][kSweepStage][FR * 64];
-  // BM: the union of the block's hit masks per tile, 64 tiles at a time: [wave][user block][tile sequence % 64] words of
-  // (half 1 mask << 16 | half 0 mask) -- the input of the block-joint selection (score_blocksel.hpp)
-  __shared__ uint16_t bm_s[BM ? kSweepWaves : 1][BM ? UB : 1][BM ? 128 : 1];
   // A lane's first kSweepPark list entries wait here ([entry][lane]: conflict-free) and leave as 16-byte stores after the
   // sweep.  Every entry used to be its own 4-byte store into its own cache line -- 2.9 M separate L2 write requests per
   // sports sweep (~100 entries per user): 14 of the kernel's 77 us (stage cut: hits counted but never stored).  A list
   // gets ~5 entries per split: now one or two requests instead of five.
-  __shared__ uint32_t park_s[BM ? 1 : kSweepWaves][BM ? 1 : UB][BM ? 1 : kSweepPark + 1][BM ? 1 : 64];   // (+1: the pipelined form's dump row)
+  __shared__ uint32_t park_s[kSweepWaves][UB][kSweepPark > 0 ? kSweepPark : 1][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ur = lane & 31, h = lane >> 5;
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
@@ -617,115 +601,18 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
       //  masking them here put 42 more instructions into every tile's block for 31 rows of the whole table)
       // bit (15 - reg) <=> v_j > T_u: the accumulator's sign bit
       uint32_t qbits = 0;
-#if defined(CHAOREC_SWEEP_EXP) && CHAOREC_SWEEP_EXP == 2   // experiment (wrong result): one register's sign instead of sixteen
-      qbits = __float_as_uint(acc[0] + acc[7]) >> 31;
-#else
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(acc[reg]), 31);
-#endif
-      if constexpr (BM) {
-        // OR over the 32 lanes of each half: prefix-OR inside the rows of 16 (row_shr 1, 2, 4, 8), then lane 15 of rows
-        // 0 / 2 into rows 1 / 3: lanes 31 and 63 hold their half's union and store it (one 2-byte LDS store, no list)
-        int x = (int)qbits;
-        x |= dpp_or0<0x111, 0xF, true>(x);
-        x |= dpp_or0<0x112, 0xF, true>(x);
-        x |= dpp_or0<0x114, 0xF, true>(x);
-        x |= dpp_or0<0x118, 0xF, true>(x);
-        x |= dpp_or0<0x142, 0xA, false>(x);
-        if (ur == 31) bm_s[wv][b][2 * (seq & 63) + h] = (uint16_t)x;
-        continue;
-      }
-#if defined(CHAOREC_SWEEP_EXP) && CHAOREC_SWEEP_EXP == 1   // experiment (wrong result): hits counted, never stored
-      cnt[b] += qbits != 0u;
-      continue;
-#endif
-      if constexpr (!BM && kSweepPark > 0 && kSweepBranchFree) {
-        // branch-free append: an entry without hits (or past the parked part of its list) goes to the dump row; only a
-        // list longer than kSweepPark entries in one split -- rare -- takes a branch
-        const bool hit = qbits != 0u;
-        const bool parked = hit && cnt[b] < kSweepPark;
-        const uint32_t entry = ((uint32_t)seq << 16) | qbits;
-        park_s[wv][b][parked ? cnt[b] : kSweepPark][lane] = entry;
-        if (__builtin_expect(__any(hit && !parked), 0)) {
-          if (hit && !parked && cnt[b] < kPfCap) mine[b][cnt[b]] = entry;
-        }
-        cnt[b] += hit ? 1 : 0;
-        continue;
-      }
       if (qbits) {
         // past kPfCap entries are counted, not stored: the selection sees the overflow and flags the user
         const uint32_t entry = ((uint32_t)seq << 16) | qbits;
-        if constexpr (!BM && kSweepPark > 0) {
+        if constexpr (kSweepPark > 0) {
           if (cnt[b] < kSweepPark) park_s[wv][b][cnt[b]][lane] = entry;
           else if (cnt[b] < kPfCap) mine[b][cnt[b]] = entry;
         } else {
           if (cnt[b] < kPfCap) mine[b][cnt[b]] = entry;
         }
         ++cnt[b];
-      }
-    }
-  };
-
-  // The pipelined form of `consume` for a whole stage (CHAOREC_SWEEP_PIPE, !BM): the waves of a SIMD run the same code in
-  // step (a barrier every stage), so with "all MFMAs of a tile, then its sign bits and list stores" the matrix pipe and the
-  // VALU take turns instead of running side by side -- 5 MFMAs (160 cycles) cost 400 per tile and user block.  Here a
-  // stage is ONE basic block: the MFMA chains of all its tiles, the sign-bit collection of tile i free to be scheduled
-  // between the MFMAs of tile i + 1, and a branch-free list append (an entry without hits goes to a dump row of the
-  // parking array); only the rare list overflow (more than kSweepPark entries in one split) branches.
-  auto consume_stage = [&](int buf, int s0) __attribute__((always_inline)) {
-    f32x16 accs[kSweepStage][UB];
-    uint32_t qb[kSweepStage][UB];
-#pragma unroll
-    for (int i = 0; i < kSweepStage; ++i) {
-      uint4 a[FR];
-#pragma unroll
-      for (int q = 0; q < FR; ++q) a[q] = stage[buf][i][q * 64 + lane];
-#pragma unroll
-      for (int b = 0; b < UB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accs[i][b][r] = 0.f;
-#pragma unroll
-      for (int q = 0; q < D / 16; ++q) {
-        Frag16 f;
-        f.u = a[q];
-#pragma unroll
-        for (int b = 0; b < UB; ++b) accs[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v, bu[b][q], accs[i][b], 0, 0, 0);
-      }
-      Frag16 fa;
-      fa.u = a[D / 16];
-#pragma unroll
-      for (int b = 0; b < UB; ++b) accs[i][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bth[b], accs[i][b], 0, 0, 0);
-    }
-    bool spill = false;
-#pragma unroll
-    for (int i = 0; i < kSweepStage; ++i) {
-      const int seq = kSweepStage * s0 + i;
-      const bool live = split + seq * splits < n_tiles;      // block-uniform (a slot past the end holds a repeated tile)
-#pragma unroll
-      for (int b = 0; b < UB; ++b) {
-        uint32_t q = 0;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) q = __builtin_amdgcn_alignbit(q, __float_as_uint(accs[i][b][reg]), 31);
-        q = live ? q : 0u;
-        qb[i][b] = q;
-        const bool hit = q != 0u;
-        const bool parked = hit && cnt[b] < kSweepPark;
-        park_s[wv][b][parked ? cnt[b] : kSweepPark][lane] = ((uint32_t)seq << 16) | q;
-        spill |= hit && !parked;
-        cnt[b] += hit ? 1 : 0;
-      }
-    }
-    if (__builtin_expect(__any(spill), 0)) {                // some list is past its parked entries: redo the stage's appends
-#pragma unroll                                               // for those lanes in order (cnt already counts them)
-      for (int b = 0; b < UB; ++b) {
-        int c = cnt[b];
-#pragma unroll
-        for (int i = kSweepStage - 1; i >= 0; --i) {
-          if (qb[i][b]) {
-            --c;
-            if (c >= kSweepPark && c < kPfCap) mine[b][c] = ((uint32_t)(kSweepStage * s0 + i) << 16) | qb[i][b];
-          }
-        }
       }
     }
   };
@@ -754,24 +641,6 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   };
   const int n_mine = split < n_tiles ? (n_tiles - split + splits - 1) / splits : 0;   // tiles of this split
   const int n_stages = (n_mine + kSweepStage - 1) / kSweepStage;
-  // BM: a wave's own LDS words (its LDS operations execute in order: no barrier between its stores and its reads)
-  auto bm_clear = [&]() __attribute__((always_inline)) {
-    if constexpr (BM) {
-#pragma unroll
-      for (int b = 0; b < UB; ++b) reinterpret_cast<uint32_t *>(bm_s[wv][b])[lane] = 0u;
-    }
-  };
-  auto bm_flush = [&](int chunk) __attribute__((always_inline)) {
-    if constexpr (BM) {
-#pragma unroll
-      for (int b = 0; b < UB; ++b) {
-        if ((ublock0 + b) * 32 < n_act)      // wave-uniform; the bitmap's rows are this launch's user blocks
-          P.bitmap[(((size_t)(ublock0 + b) * splits + split) * P.bm_chunks + chunk) * 64 + lane] =
-              reinterpret_cast<const uint32_t *>(bm_s[wv][b])[lane];
-      }
-    }
-  };
-  bm_clear();
   if (n_stages > 0) {
     fetch(0);
     stash(0);
@@ -780,12 +649,6 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   for (int s0 = 0; s0 < n_stages; ++s0) {
     const int buf = s0 & 1;
     if (s0 + 1 < n_stages) fetch(s0 + 1);
-    if constexpr (!BM && kSweepPipe && kSweepPark > 0) {
-      consume_stage(buf, s0);
-      if (s0 + 1 < n_stages) stash(buf ^ 1);
-      __syncthreads();
-      continue;
-    }
 #pragma unroll
     for (int i = 0; i < kSweepStage; ++i) {
       const int seq = kSweepStage * s0 + i;
@@ -796,23 +659,9 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
         for (int q = 0; q < FR; ++q) a[q] = stage[buf][i][q * 64 + lane];
         consume(a, t, seq);
       }
-      if (BM && (seq & 63) == 63) {
-        bm_flush(seq >> 6);
-        bm_clear();
-      }
     }
     if (s0 + 1 < n_stages) stash(buf ^ 1);
     __syncthreads();
-  }
-  if constexpr (BM) {
-    // the last, partly filled chunk -- and every chunk after it that another split has and this one does not: the
-    // selection reads bm_chunks chunks of every split
-    const int done = (kSweepStage * n_stages) >> 6;               // chunks flushed inside the loop
-    for (int c = done; c < P.bm_chunks; ++c) {
-      bm_flush(c);
-      bm_clear();
-    }
-    return;
   }
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
@@ -1169,9 +1018,6 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
                                             uint32_t *hist_s, float *score_s) {
   const int K = P.K;
   const int n_lists = 2 * P.splits;  // <= 32
-#if defined(CHAOREC_SEL_EXP) && CHAOREC_SEL_EXP == 4
-  if (P.hint_rank >= 1000) return;     // (experiment: the launch alone)
-#endif
   const PermAddr pa = perm_addr(lane);
 
   // this lane's list of the sweep: (split lane / 2, half lane & 1)
@@ -1254,12 +1100,6 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
     if (n_cand > MAXC) why = 3;
     __builtin_amdgcn_wave_barrier();
   }
-#if defined(CHAOREC_SEL_EXP) && CHAOREC_SEL_EXP == 5
-  if (P.hint_rank >= 1000) {
-    if (lane == 0) P.n_cand[u] = n_cand;            // (experiment: expansion only)
-    return;
-  }
-#endif
   uint64_t e0 = 0ull, e1 = 0ull;      // the 128 best keys, descending over (e0, e1)
   if (why == 0) {
     auto in_hist = [&](uint32_t item) -> bool {
@@ -1287,12 +1127,6 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
       above += __popcll(__ballot(cur != 0ull && (uint32_t)(cur >> 32) > mord));
       take_block_keys(e0, e1, blocks, cur, pa);
     }
-#if defined(CHAOREC_SEL_EXP) && CHAOREC_SEL_EXP == 6
-    if (P.hint_rank >= 1000) {
-      if (lane == 0) P.n_cand[u] = n_cand + (int)(e0 >> 60) + (int)(e1 >> 60);   // (experiment: no history keys, no output)
-      return;
-    }
-#endif
     int n_keys = valid;
     // The masked row restricted to what can matter = the candidates + the user's history at mask_value.  The history
     // only joins when mask_value can reach the top-K (the reference's 1e-6 / 1e-5 does when the real scores are tiny
@@ -1521,11 +1355,7 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
       for (int j = 0; j < kExPer; ++j) {
         const int64_t it0 = c0 + 64 * wave + (int64_t)kExThreads * j;      // the wave's 64 consecutive items
         sxs[j] = 0.f;
-#if defined(CHAOREC_EX_EXP) && CHAOREC_EX_EXP == 5   // experiment: no scores
-        sxs[j] = ua[0] * (float)it0;
-#else
         if (it0 < i_end) sxs[j] = exact_scores_64<D>(P.item_emb, it0, P.n_items, ua, ub, lane);   // wave-uniform
-#endif
       }
       if (!hist_ready) {          // block-uniform: every thread's first round
 #pragma unroll
@@ -1544,9 +1374,6 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
           if (it < i_end) {
             const uint32_t item = (uint32_t)it;
             int lo = 0, hi = deg;
-#if defined(CHAOREC_EX_EXP) && CHAOREC_EX_EXP == 4   // experiment: no history search
-            hi = 0;
-#endif
             while (lo < hi) {
               const int mid = (lo + hi) >> 1;
               const uint32_t hv = hist_lds ? hist_s[mid] : (uint32_t)P.hist_col[hb + mid];
@@ -1557,16 +1384,8 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
           }
         }
       }
-#if defined(CHAOREC_EX_EXP) && (CHAOREC_EX_EXP == 1 || CHAOREC_EX_EXP >= 4)   // experiment: scores only (wrong result)
-      bk = key[0] ^ key[1];
-      continue;
-#endif
       bk = wave_select_topk<kExPer>(key, bk, kMaxK, stage[wave]);   // (the 64 best: the next call's threshold wants more than K)
     }
-#if defined(CHAOREC_EX_EXP) && (CHAOREC_EX_EXP == 1 || CHAOREC_EX_EXP == 2 || CHAOREC_EX_EXP >= 4)   // experiment: no block merge
-    if (bk == 1ull) P.fb_partial[0] = bk;
-    continue;
-#endif
     // block merge: every wave orders its 64 best, then a tree of pairwise merges through LDS (log2 NW levels of one
     // reverse + six stages each).  One wave picking the 64 best of all NW lists by a bitwise search (32 steps x NW + 1
     // ballots) was 20 of the route's 48 us.
@@ -1582,10 +1401,6 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
       __syncthreads();
     }
     uint64_t *part = P.fb_partial + (size_t)qi * kExSlices * kMaxK;
-#if defined(CHAOREC_EX_EXP) && CHAOREC_EX_EXP == 3   // experiment: no slice merge
-    if (wave == 0) part[slice * kMaxK + lane] = stage[0][lane];
-    continue;
-#endif
     if (wave == 0) {
       part[slice * kMaxK + lane] = stage[0][lane];   // kMaxK == 64; descending
       __threadfence();

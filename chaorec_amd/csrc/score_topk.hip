@@ -789,7 +789,6 @@ __global__ __launch_bounds__(64) void score_select_kernel(const uint64_t *__rest
 }
 
 #include "score_prefilter.hpp"
-#include "score_blocksel.hpp"
 
 // ---- launch plan -----------------------------------------------------------------------------
 struct ScorePlan {
@@ -805,8 +804,6 @@ struct ScorePlan {
   bool pf_sample_long;
   size_t off_pf_retry, off_pf_wide, off_pf_ncand, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
   bool pf_group_fb;            // large item ranges: the first kPfFbGroupCap queued users share f32 MFMA sweeps
-  bool pf_block;               // block-joint selection: union bitmaps + f32 MFMA re-score (score_blocksel.hpp)
-  size_t off_pf_bitmap, off_pf_keys;
   int pf_group_fb_splits;
   size_t off_pf_fbgroup;
   size_t off_pf_packed, off_pf_scalars, off_pf_tau, off_pf_theta, off_pf_cand, off_pf_cnt;
@@ -819,8 +816,8 @@ struct ScorePlan {
 #ifndef CHAOREC_PF_UB128
 #define CHAOREC_PF_UB128 2
 #endif
-// Wave slots of the sweep kernel on this device (waves per CU x CUs), queried once; without a device (the CPU-side
-// workspace query) the gfx950 defaults.
+// Workgroup slots of the sweep kernel THAT IS LAUNCHED on this device (workgroups per CU x CUs), queried once; without a
+// device (the CPU-side workspace query) the gfx950 defaults.
 static int sweep_wave_slots(int D) {
   static int cached[2] = {0, 0};
   int &c = cached[D == 64 ? 0 : 1];
@@ -829,8 +826,8 @@ static int sweep_wave_slots(int D) {
   hipError_t e = hipGetDevice(&dev);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e == hipSuccess) {
-    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, true>, 64 * kSweepWaves, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, true>, 64 * kSweepWaves, 0);
+    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>, 64 * kSweepWaves, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>, 64 * kSweepWaves, 0);
   }
   if (e != hipSuccess || per_cu <= 0 || cus <= 0) {
     (void)hipGetLastError();
@@ -924,23 +921,9 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.pf_group_fb_splits = (int)std::min<int64_t>(256, std::max<int64_t>(1, n_tiles / 64));
   p.off_pf_fbgroup = take(p.pf_group_fb ? (size_t)p.pf_group_fb_splits * kPfFbGroupCap * (size_t)K * 8 : 0);
   p.off_pf_theta = take(p.prefilter ? (size_t)n_users * 4 : 0);
-  // Block-joint selection (score_blocksel.hpp; item ranges below 128 k): the sweep's output is a union bitmap per user
-  // block, the re-score runs on the f32 MFMA pipe.  Bit-exact (the scoring tests pass on it: profiles/r03_d_*), but
-  // MEASURED SLOWER than the per-user selection at sports size -- 125-139 us against 80 us (stage cuts in DESIGN 3.3) --
-  // so it is an experiment build (-DCHAOREC_PF_BLOCK=1, tools/bs_variants.py), not the product path.
-#ifndef CHAOREC_PF_BLOCK
-#define CHAOREC_PF_BLOCK 0
-#endif
-  p.pf_block = p.prefilter && !p.pf_group_fb && CHAOREC_PF_BLOCK;
-  {
-    const int64_t per_wg = (int64_t)p.pf_ub * kSweepWaves;
-    const int64_t ublocks_pad = (groups + per_wg - 1) / per_wg * per_wg;      // the sweep's grid covers whole workgroups
-    p.off_pf_bitmap = take(p.pf_block ? (size_t)ublocks_pad * (size_t)bs_words_per_block_max(n_tiles) * 4 : 0);
-    p.off_pf_keys = take(p.pf_block ? (size_t)groups * 32 * (size_t)kBsCap * 8 : 0);
-  }
   // (sized for the most splits any device plan uses, so that the CPU-side query and the device plan agree)
-  p.off_pf_cand = take(p.prefilter && !p.pf_block ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * kPfCap * 4 : 0);
-  p.off_pf_cnt = take(p.prefilter && !p.pf_block ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * 4 : 0);
+  p.off_pf_cand = take(p.prefilter ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * kPfCap * 4 : 0);
+  p.off_pf_cnt = take(p.prefilter ? (size_t)kPfMaxSplits * (size_t)n_users * 2 * 4 : 0);
   p.off_packed = take(p.pack ? (size_t)n_tiles * 32 * (size_t)D * 4 : 0);
   p.off_tau = take(p.sample ? (size_t)n_users * 4 : 0);
   p.off_tau1 = take(p.sample ? (size_t)n_users * 4 : 0);
@@ -1000,7 +983,7 @@ extern "C" int chaorec_score_topk_stats(const void *workspace, int64_t n_users, 
   if (!p.prefilter) return CHAOREC_OK;   // all zeros: the call did not take the prefilter route
   const char *ws = (const char *)workspace;
   hipLaunchKernelGGL(score_prefilter_stats_kernel, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, st,
-                     (const int *)(ws + p.off_fail), p.pf_block ? (const int *)nullptr : (const int *)(ws + p.off_pf_cnt),
+                     (const int *)(ws + p.off_fail), (const int *)(ws + p.off_pf_cnt),
                      (const int *)(ws + p.off_pf_ncand), n_users, p.pf_splits, (unsigned long long *)out9);
   return check_launch("score_prefilter_stats_kernel");
 }
@@ -1088,10 +1071,6 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.cand = (uint32_t *)(ws + p.off_pf_cand);
     P.cand_cnt = (int *)(ws + p.off_pf_cnt);
     P.splits = p.pf_splits;
-    P.bitmap = p.pf_block ? (uint32_t *)(ws + p.off_pf_bitmap) : nullptr;
-    P.bm_chunks = bs_chunks(n_tiles, p.pf_splits);
-    P.key_cap = kBsCap;
-    P.keys = p.pf_block ? (uint64_t *)(ws + p.off_pf_keys) : nullptr;
     P.sample_stride = p.pf_sample_stride;
     P.sample_splits = p.pf_sample_splits;
     P.sample_rank = p.pf_sample_rank;
@@ -1106,9 +1085,6 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.hint_in = nullptr;
     P.hint_out = hint_out;
     P.hint_rank = hint_rank > K ? (hint_rank > 128 ? 128 : hint_rank) : K;
-#if defined(CHAOREC_SEL_EXP) || defined(CHAOREC_BS_EXP)
-    if (hint_rank >= 1000) P.hint_rank = hint_rank;      // (experiment builds: the run-time switch of tools/sel_variants.py / bs_variants.py)
-#endif
     int *failf = (int *)(ws + p.off_fail);
     P.fail = failf;
     int *retry_cnt = (int *)(ws + p.off_pf_scalars + 64);
@@ -1124,26 +1100,10 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     const unsigned sel_all = (unsigned)n_users;
     const unsigned sel_queue = (unsigned)std::min<int64_t>(n_users, 8192);    // a pass over a device-side queue
     auto sweep = [&](const PrefArgs &A) {
-      if (p.pf_block) {
-        if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, true>), gw, dim3(64 * kSweepWaves), 0, st, A);
-        else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, true>), gw, dim3(64 * kSweepWaves), 0, st, A);
-      } else {
-        if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, false>), gw, dim3(64 * kSweepWaves), 0, st, A);
-        else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, false>), gw, dim3(64 * kSweepWaves), 0, st, A);
-      }
-    };
-    // block-joint selection: a pass over everybody launches one workgroup per user block, a pass over a device-side
-    // queue a fixed grid
-    auto select_block = [&](const PrefArgs &A, bool all_rows) {
-      const unsigned grid = all_rows ? groups : (unsigned)std::min<int64_t>(groups, 1024);
-      if (D == 64) hipLaunchKernelGGL((score_select_block_kernel<64>), dim3(grid), dim3(64 * kBsWaves), 0, st, A);
-      else hipLaunchKernelGGL((score_select_block_kernel<128>), dim3(grid), dim3(64 * kBsWaves), 0, st, A);
+      if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64 * kSweepWaves), 0, st, A);
+      else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, A);
     };
     auto select = [&](const PrefArgs &A, unsigned grid) {
-      if (p.pf_block) {
-        select_block(A, grid == sel_all);
-        return;
-      }
       if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
       else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
     };
@@ -1182,9 +1142,8 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       sample(B);
       sweep(B);
       select(B, hint_in ? sel_queue : sel_all);
-      // the few users with more candidates than the narrow selection holds (coarse samples of very long item ranges;
-      // the block-joint selection has no wide form: its overflowing users go to the exact route)
-      if (!p.pf_block) {
+      // the few users with more candidates than the narrow selection holds (coarse samples of very long item ranges)
+      {
         PrefArgs W = P;
         W.user_map = P.wide_list;
         W.n_active = wide_cnt;

@@ -228,6 +228,15 @@ class _Pending:
             nxt().wait()
 
 
+def capture_mode():
+    """capture_error_mode for a hipGraph capture that holds collectives: "thread_local" while a process group exists --
+    RCCL's watchdog THREAD polls the events of earlier eager collectives (hipEventQuery), which a capture in the default
+    global mode forbids to every thread of the process: the poll then throws inside the watchdog and takes the process
+    down (seen on the first captured exchange that followed eager ones closely).  Thread-local mode only restricts the
+    capturing thread."""
+    return "thread_local" if dist.is_initialized() else "global"
+
+
 class _PendingStream:
     """Handle of an exchange made of plain launches on a side stream (the hand-written p2p exchange): wait() makes the
     compute stream depend on everything the side stream was given so far."""
@@ -509,7 +518,8 @@ def calibrate_exchange(n_rows, D, device, group=None, captured=False, reps=3, ca
             nonlocal why
             static_src, static_out = fresh(), torch.empty((rows, D), device=dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, capture_error_mode=capture_mode()):
                 static_out.copy_(static_src)
                 _sum_exchange_async(static_out, group).wait()
             good = True
@@ -828,12 +838,12 @@ class FusedShardedLightGCNStep:
                 torch.cuda.synchronize()
                 self._restore_state(saved)
                 self.graph1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph1):
+                with torch.cuda.graph(self.graph1, capture_error_mode=capture_mode()):
                     self._launch()
                 self.graph = self.graph1
                 if self.steps_per_replay > 1:
                     self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph):
+                    with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
                         for _ in range(self.steps_per_replay):
                             self._launch()
                 for gph in {id(self.graph1): self.graph1, id(self.graph): self.graph}.values():

@@ -351,13 +351,18 @@ class GraphedTrainStep:
                 optimizer._step_dev.copy_(saved_step) if saved_step is not None else optimizer._step_dev.zero_()
         self.graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # (a step that holds collectives -- after_backward = a sharded model's sync_grads -- is captured in thread-local
+        #  mode: RCCL's watchdog thread polls events while we capture, dist.capture_mode)
+        import torch.distributed as _td
+        mode = "thread_local" if (_td.is_available() and _td.is_initialized()) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.static_loss = self._eager(self.static)
         # the captured forward's output buffer: every replay rewrites it, and model.result must keep pointing at it
         # (an eager step in between -- the short last batch of an epoch -- rebinds model.result to its own tensor)
         plain_attr = not isinstance(getattr(type(model), "result", None), property)   # (a sharded model derives it)
         res = getattr(model, "result", None) if plain_attr else None
         self._captured_result = res if torch.is_tensor(res) else None
+        self._graph_generation = getattr(model, "graph_generation", 0)      # the graph arrays this capture holds
         self.replays = 0
 
     def _eager(self, batch):
@@ -374,12 +379,13 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self, *batch):
-        if getattr(self.model, "graph_stale", False):
-            # FREEDOM / LayerGCN re-allocated their pruned graph (another entry count than the one captured): the hipGraph
-            # still holds the old arrays' addresses -- replaying it would train on freed memory.  The training loop
-            # (train_and_evaluate) clears the flag and captures again; any other holder of a captured step must too.
+        if getattr(self.model, "graph_generation", 0) != self._graph_generation:
+            # FREEDOM / LayerGCN re-allocated their pruned graph AFTER this step was captured (another entry count than the
+            # one captured): the hipGraph still holds the old arrays' addresses -- replaying it would train on freed
+            # memory.  The training loop (train_and_evaluate) captures again; any other holder of a captured step must too.
+            # (A rebind BEFORE the capture is harmless: the generation is recorded when the capture ends -- ADVICE r3.)
             raise RuntimeError("GraphedTrainStep: the model rebound its graph after this step was captured "
-                               "(model.graph_stale): capture a new step")
+                               "(model.graph_generation moved): capture a new step")
         if self.batch_fn is not None:
             self.graph.replay()
             self.replays += 1

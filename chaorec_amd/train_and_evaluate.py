@@ -137,10 +137,8 @@ def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epoc
     for epoch in range(epochs):
         if model_name in PRE_EPOCH:
             model.pre_epoch_processing()
-            if getattr(model, "graph_stale", False):     # the pruned graph was re-allocated: a captured step holds dead addresses
-                model.graph_stale = False
-                if graphed is not None:
-                    graphed, capture_pending = None, bool(graph)
+            if graphed is not None and getattr(model, "graph_generation", 0) != getattr(graphed, "_graph_generation", 0):
+                graphed, capture_pending = None, bool(graph)     # the pruned graph was re-allocated: capture again
         if capture_pending:
             graphed, capture_pending = _capture_step(model, train_loader, optimizer, model_name), False
         loss = train(model, train_loader, optimizer, model_name, graphed)

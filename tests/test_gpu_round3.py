@@ -157,16 +157,18 @@ def test_captured_step_refuses_a_stale_graph_and_optimizer_step_survives_state_d
     step = GraphedTrainStep(m, opt, example_batch=batch)
     for _ in range(3):
         step(*batch)
-    m.graph_stale = True
-    with pytest.raises(RuntimeError, match="graph_stale"):
+    m.graph_generation = getattr(m, "graph_generation", 0) + 1          # what FREEDOM / LayerGCN do when they rebind their graph
+    with pytest.raises(RuntimeError, match="graph_generation"):
         step(*batch)
-    m.graph_stale = False
+    # a rebind BEFORE a capture is harmless (the old flag made the first replay of such a step raise)
+    step2 = GraphedTrainStep(m, opt, example_batch=batch)
+    step2(*batch)
     sd = opt.state_dict()
-    assert sd["chaorec_step"] == 3
+    assert sd["chaorec_step"] == 4
     import copy
     opt2 = FusedAdam(m.parameters(), lr=1e-3)
     opt2.load_state_dict(copy.deepcopy(sd))       # (as from a file: torch's load_state_dict keeps tensors that already fit)
-    assert int(opt2._step_dev.item()) == 3
+    assert int(opt2._step_dev.item()) == 4
     w0 = m._flat.detach().clone()
     for o in (opt, opt2):                                   # the same fourth step from either optimizer
         with torch.no_grad():
