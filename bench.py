@@ -446,8 +446,13 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     N = csr.n_rows
     w = 1.0 / (L + 1)
     x0 = model._flat.detach()
-    b0, b1, fin, G = (torch.empty_like(x0) for _ in range(4))
-    G.zero_()
+    if fused and L >= 3 and os.environ.get("CHAOREC_BENCH_CHAIN_BUFFERS", "step") == "step":
+        # the step's OWN layer / gradient buffers (between steps they hold nothing anyone reads; G is all-zero by the
+        # step's contract): the replayed launches then touch exactly the memory the step's launches touch
+        b0, b1, fin, G = stepper.fbuf[0], stepper.fbuf[1], stepper.final, stepper.G
+    else:
+        b0, b1, fin, G = (torch.empty_like(x0) for _ in range(4))
+        G.zero_()
     use_mean = L <= ops.mean_terms_limit(D)
     plain, whole, src = [], [], x0
     xs = [x0]

@@ -231,18 +231,20 @@ class FREEDOM(nn.Module):
             idx = torch.arange(B, device=users.device)
             self._batch_idx = (idx, idx + B)
         idx, idx_neg = self._batch_idx
-        terms, weights = [(ia_embeddings, pos_items, neg_items)], [1.0]
+        terms, weights, gathered = [(ia_embeddings, pos_items, neg_items)], [1.0], [None]
         if self.t_feat is not None:
             text_rows = ops.linear_rows(self.text_embedding.weight, rows, self.text_trs.weight, self.text_trs.bias)
             terms.append((text_rows, idx, idx_neg))
             weights.append(self.reg_weight)
+            gathered.append((rows, self.num_item))
         if self.v_feat is not None:
             image_rows = ops.linear_rows(self.image_embedding.weight, rows, self.image_trs.weight, self.image_trs.bias)
             terms.append((image_rows, idx, idx_neg))
             weights.append(self.reg_weight)
+            gathered.append((rows, self.num_item))
         if self._loss_w is None or self._loss_w.device != users.device or self._loss_w.numel() != len(weights):
             self._loss_w = torch.tensor(weights, dtype=torch.float32, device=users.device)
-        return ops.bpr_loss_multi(ua_embeddings, users, ops.VARIANT_LOGSIGMOID, terms, self._loss_w)
+        return ops.bpr_loss_multi(ua_embeddings, users, ops.VARIANT_LOGSIGMOID, terms, self._loss_w, gathered=gathered)
 
     def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/FREEDOM.py:219-244 (mask value 1e-6, stale self.result)."""

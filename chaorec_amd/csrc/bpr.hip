@@ -293,6 +293,12 @@ struct BprMultiArgs {
   const int64_t *pos[kBprMaxTerms];
   const int64_t *neg[kBprMaxTerms];
   float *g_i[kBprMaxTerms];
+  // backward only: term k's item table is a block of rows GATHERED from a longer table (FREEDOM's projected batch rows,
+  // ops.linear_rows): row r of it is row scatter_rows[k][r] there, and its gradient is ALSO added into
+  // scatter_out[k][scatter_rows[k][r]] -- the zero-filled [n_table_rows, D] buffer + index_add_ of the gathering node's
+  // backward, inside this launch.  NULL: no scatter.
+  const int64_t *scatter_rows[kBprMaxTerms];
+  float *scatter_out[kBprMaxTerms];
   int T;
 };
 
@@ -347,12 +353,21 @@ __global__ __launch_bounds__(256) void bpr_multi_bwd_kernel(const float *__restr
   const float c = coef[(size_t)k * B + b] * go;
   const float *tab_i = A.tab_i[k];
   float *g_i = A.g_i[k];
-  const size_t ou = (size_t)users[b] * D, op = (size_t)A.pos[k][b] * D, on = (size_t)A.neg[k][b] * D;
+  const int64_t pr = A.pos[k][b], nr = A.neg[k][b];
+  const size_t ou = (size_t)users[b] * D, op = (size_t)pr * D, on = (size_t)nr * D;
+  const int64_t *srows = A.scatter_rows[k];
+  float *sout = A.scatter_out[k];
+  size_t sp = 0, sn = 0;
+  if (srows) sp = (size_t)srows[pr] * D, sn = (size_t)srows[nr] * D;     // wave-uniform
   for (int q = lane; q < D; q += 64) {
     const float u = tab_u[ou + q], p = tab_i[op + q], n = tab_i[on + q];
     atomicAdd(g_u + ou + q, c * (p - n));
     atomicAdd(g_i + op + q, c * u);
     atomicAdd(g_i + on + q, -c * u);
+    if (srows) {
+      atomicAdd(sout + sp + q, c * u);
+      atomicAdd(sout + sn + q, -c * u);
+    }
   }
 }
 
@@ -608,6 +623,7 @@ static int fill_multi(BprMultiArgs &A, int32_t T, const float *const *tabs, cons
     const int j = k < T ? k : 0;
     if (!tabs[j] || !pos[j] || !neg[j] || (g_i && !g_i[j])) return fail(CHAOREC_E_INVALID, "%s: NULL term %d", who, j);
     A.tab_i[k] = tabs[j], A.pos[k] = pos[j], A.neg[k] = neg[j], A.g_i[k] = g_i ? g_i[j] : nullptr;
+    A.scatter_rows[k] = nullptr, A.scatter_out[k] = nullptr;
   }
   return CHAOREC_OK;
 }
@@ -635,12 +651,22 @@ extern "C" int chaorec_bpr_multi_fwd_f32(const float *tab_u, const int64_t *user
 extern "C" int chaorec_bpr_multi_bwd_f32(const float *tab_u, const int64_t *users, int32_t T, const float *const *tabs,
                                          const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
                                          const float *coef, const float *wvec, const float *grad_out, float *g_u,
-                                         float *const *g_i, void *stream) {
+                                         float *const *g_i, const int64_t *const *scatter_rows, float *const *scatter_out,
+                                         void *stream) {
   if (!tab_u || !users || !wvec || !coef || !g_u || !g_i) return fail(CHAOREC_E_INVALID, "bpr_multi_bwd: NULL argument");
   if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_multi_bwd: B=%d D=%d", B, D);
+  if ((scatter_rows == nullptr) != (scatter_out == nullptr))
+    return fail(CHAOREC_E_INVALID, "bpr_multi_bwd: scatter_rows and scatter_out come together");
   BprMultiArgs A;
   int rc = fill_multi(A, T, tabs, pos, neg, g_i, "bpr_multi_bwd");
   if (rc) return rc;
+  if (scatter_rows) {
+    for (int k = 0; k < T; ++k) {
+      if ((scatter_rows[k] == nullptr) != (scatter_out[k] == nullptr))
+        return fail(CHAOREC_E_INVALID, "bpr_multi_bwd: term %d has one of scatter_rows / scatter_out", k);
+      A.scatter_rows[k] = scatter_rows[k], A.scatter_out[k] = scatter_out[k];
+    }
+  }
   hipLaunchKernelGGL(bpr_multi_bwd_kernel, dim3((T * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u, users, A, B, D,
                      coef, wvec, grad_out, g_u);
   return check_launch("bpr_multi_bwd_kernel");

@@ -1257,7 +1257,28 @@ class ShardedMMGCN(nn.Module):
         self._bucket = None
 
     def forward(self):
-        rep = (self.v_gcn(self.v_feat, self.id_embedding) + self.t_gcn(self.t_feat, self.id_embedding)) / 2
+        import importlib
+        _mm = importlib.import_module(__package__ + ".Model.MMGCN")        # (the package re-exports the CLASS under this name)
+        streams = _os.environ.get("CHAOREC_DIST_MMGCN_STREAMS", "1") == "1" and _mm.BRANCH_STREAMS
+        if streams and self.id_embedding.is_cuda:
+            # The two modality branches are independent until the mean: the visual one on a side stream, like the
+            # single-process model (Model/MMGCN.py forward; autograd replays every node's backward on its forward's
+            # stream).  The branches' exchanges are then issued from two streams of ONE host thread: RCCL queues them on
+            # its own stream in host order -- the same order on every rank, the program is the same.  (Round 3 saw this
+            # "dump core" under capture: it was the capture's global error mode, which forbids the event polls of RCCL's
+            # watchdog thread; captures that hold collectives are thread-local now, dist.capture_mode.)
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=self.id_embedding.device)
+            self._side_stream.wait_stream(cur)
+            with torch.cuda.stream(self._side_stream):
+                v_rep = self.v_gcn(self.v_feat, self.id_embedding)
+            t_rep = self.t_gcn(self.t_feat, self.id_embedding)
+            cur.wait_stream(self._side_stream)
+        else:
+            v_rep = self.v_gcn(self.v_feat, self.id_embedding)
+            t_rep = self.t_gcn(self.t_feat, self.id_embedding)
+        rep = (v_rep + t_rep) / 2
         self.result = rep
         return rep
 
@@ -1458,7 +1479,8 @@ class ShardedFREEDOM(nn.Module):
             # the three terms share the user table and the batch's users: ONE autograd node, as in Model/FREEDOM.py here
             if self._loss_w is None or self._loss_w.device != users.device:
                 self._loss_w = torch.tensor([1.0, self.reg_weight, self.reg_weight], dtype=torch.float32, device=users.device)
-            total = ops.bpr_loss_multi(ua, users, V, [(ia, pos, neg), (tf, idx, idx_neg), (vf, idx, idx_neg)], self._loss_w)
+            total = ops.bpr_loss_multi(ua, users, V, [(ia, pos, neg), (tf, idx, idx_neg), (vf, idx, idx_neg)], self._loss_w,
+                                       gathered=[None, (rows, self.num_item), (rows, self.num_item)])
         else:
             total = self._bpr(ua, ia, users, pos, neg, V, 0.0)[0]
             total = total + self.reg_weight * (self._bpr(ua, tf, users, idx, idx_neg, V, 0.0)[0] +

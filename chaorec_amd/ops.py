@@ -263,9 +263,12 @@ class _BPRMulti(torch.autograd.Function):
     weighted sum, and one backward launch (chaorec_bpr_multi_*_f32: 4 launches per step instead of 13)."""
 
     @staticmethod
-    def forward(ctx, tab_u, users, variant, wvec, *flat):
+    def forward(ctx, tab_u, users, variant, wvec, gathered, *flat):
         T = len(flat) // 3
         _need_cuda(tab_u, users, wvec, *flat)
+        # gathered[k] = (rows, n_table_rows) or None: term k's table is a block of rows gathered from a longer table (the
+        # projected batch rows of linear_rows): its backward also scatters the gradient into a [n_table_rows, D] buffer
+        ctx.gathered = list(gathered) if gathered is not None else [None] * T
         tab_u = _f32c(tab_u)
         users = users.to(torch.int64).contiguous()
         B, D, dev = users.numel(), tab_u.shape[1], tab_u.device
@@ -303,8 +306,10 @@ class _BPRMulti(torch.autograd.Function):
         tabs = ctx.saved_tensors[4:4 + T]
         ids = ctx.saved_tensors[4 + T:]
         B, D = users.numel(), tab_u.shape[1]
-        # ONE zero fill for the T + 1 gradient buffers (views of it), not one launch each
-        sizes = [tab_u.numel()] + [t.numel() for t in tabs]
+        # ONE zero fill for the T + 1 gradient buffers (views of it) -- and for the scattered row gradients of gathered
+        # terms --, not one launch each
+        gathered = ctx.gathered if T <= BPR_MULTI_MAX else [None] * T
+        sizes = [tab_u.numel()] + [t.numel() for t in tabs] + [(gt[1] * D if gt is not None else 0) for gt in gathered]
         flat = torch.zeros(sum(sizes), dtype=tab_u.dtype, device=tab_u.device)
         offs = [0]
         for n_ in sizes:
@@ -316,12 +321,22 @@ class _BPRMulti(torch.autograd.Function):
             g_is = [flat[offs[k + 1]:offs[k + 2]].view_as(tabs[k]) for k in range(T)]
             arr = lambda ts: (ctypes.c_void_p * T)(*[t.data_ptr() for t in ts])
             g = g.contiguous()
+            srows, souts = None, None
+            _SCATTERED.clear()
+            if any(gt is not None for gt in gathered):
+                full = [flat[offs[T + 1 + k]:offs[T + 2 + k]].view(gathered[k][1], D) if gathered[k] is not None else None
+                        for k in range(T)]
+                parr = lambda ts: (ctypes.c_void_p * T)(*[(t.data_ptr() if t is not None else 0) for t in ts])
+                srows, souts = parr([gt[0] if gt is not None else None for gt in gathered]), parr(full)
+                for k in range(T):
+                    if full[k] is not None:      # handed to the gathering node's backward (ops._LinearRows) by address
+                        _SCATTERED[g_is[k].data_ptr()] = (full[k], gathered[k][0])
             rc = lib.chaorec_bpr_multi_bwd_f32(_ptr(tab_u), _ptr(users), T, arr(tabs), arr(ids[0::2]), arr(ids[1::2]), B, D,
-                                               _ptr(coef), _ptr(wvec), _ptr(g), _ptr(g_u), arr(g_is), _stream())
+                                               _ptr(coef), _ptr(wvec), _ptr(g), _ptr(g_u), arr(g_is), srows, souts, _stream())
             _lib.check(rc, "chaorec_bpr_multi_bwd_f32")
             for g_i in g_is:
                 grads += [g_i, None, None]
-            return (g_u, None, None, None, *grads)
+            return (g_u, None, None, None, None, *grads)
         gvec = (g * wvec).contiguous()                   # d total / d loss_k, on the device
         for k in range(T):
             g_i = flat[offs[k + 1]:offs[k + 2]].view_as(tabs[k])
@@ -330,7 +345,12 @@ class _BPRMulti(torch.autograd.Function):
                                          ctypes.c_void_p(gvec.data_ptr() + 4 * k), _ptr(g_u), _ptr(g_i), _stream())
             _lib.check(rc, "chaorec_bpr_bwd_f32")
             grads += [g_i, None, None]
-        return (g_u, None, None, None, *grads)
+        return (g_u, None, None, None, None, *grads)
+
+
+# gradient block of a gathered term (by address) -> (its rows scattered into [n_table_rows, D], the row list): written by
+# _BPRMulti.backward, consumed by the backward of the node that gathered the rows (_LinearRows)
+_SCATTERED = {}
 
 
 class _SplitRows(torch.autograd.Function):
@@ -350,6 +370,12 @@ class _SplitRows(torch.autograd.Function):
             rows = ctx.n if g_a is None else ctx.rows - ctx.n
             zero = other.new_zeros((rows, other.shape[1]))
             g_a, g_b = (zero, g_b) if g_a is None else (g_a, zero)
+        if (g_a.is_contiguous() and g_b.is_contiguous() and g_a.dtype == g_b.dtype and g_a.shape[1] == g_b.shape[1]
+                and g_a.untyped_storage().data_ptr() == g_b.untyped_storage().data_ptr()
+                and g_b.data_ptr() == g_a.data_ptr() + g_a.numel() * g_a.element_size()):
+            # the two gradients already lie back to back in one buffer (_BPRMulti.backward lays its gradient buffers out
+            # as [g_u | g_i0 | ...] for exactly this): the concatenation is a view
+            return torch.as_strided(g_a, (ctx.rows, g_a.shape[1]), (g_a.shape[1], 1)), None
         return torch.cat((g_a, g_b), 0), None
 
 
@@ -357,11 +383,13 @@ def split_rows(x, n):
     return _SplitRows.apply(x, n)
 
 
-def bpr_loss_multi(tab_u, users, variant, terms, wvec):
+def bpr_loss_multi(tab_u, users, variant, terms, wvec, gathered=None):
     """sum_k wvec[k] * bpr_loss(tab_u, terms[k] = (tab_i, pos, neg), users)[0] with reg_weight 0 (see _BPRMulti); wvec: a
-    float32 device tensor with one weight per term."""
+    float32 device tensor with one weight per term.  gathered (optional): per term None or (rows, n_table_rows) -- the
+    term's table is linear_rows(table, rows, ...): the backward then scatters that block's gradient into the
+    [n_table_rows, D] row gradient itself (one launch less per table and direction, one zero fill for everything)."""
     flat = [t for term in terms for t in term]
-    return _BPRMulti.apply(tab_u, users, int(variant), wvec, *flat)
+    return _BPRMulti.apply(tab_u, users, int(variant), wvec, gathered, *flat)
 
 
 class _LossParts:
@@ -1124,8 +1152,12 @@ class _LinearRows(torch.autograd.Function):
         gy = gy.contiguous()
         gx = None
         if ctx.needs_input_grad[0]:
-            gy_full = torch.zeros((x.shape[0], gy.shape[1]), dtype=gy.dtype, device=gy.device)
-            gy_full.index_add_(0, rows, gy)              # an item can sit in the batch more than once
+            pre = _SCATTERED.pop(gy.data_ptr(), None)
+            if pre is not None and tuple(pre[0].shape) == (x.shape[0], gy.shape[1]) and pre[1].data_ptr() == rows.data_ptr():
+                gy_full = pre[0]                         # (already scattered by the multi-term BPR backward's launch)
+            else:
+                gy_full = torch.zeros((x.shape[0], gy.shape[1]), dtype=gy.dtype, device=gy.device)
+                gy_full.index_add_(0, rows, gy)          # an item can sit in the batch more than once
             sink = getattr(x, "_chaorec_lowrank_sink", None)
             if sink is not None and sink.accepts(x):
                 sink.submit(x, gy_full, weight, ctx.row_token)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 9   /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 10  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -39,7 +39,8 @@ extern "C" {
                                   8: rows_mean (layer mean of exchanged rows: fused sharded LightGCN step);
                                   9: split-bf16 NN GEMM (input gradients, accumulate epilogue), MMGCN's layer tail
                                      (leaky_cat_add / leaky_split_bwd), normalize_rows, multi-term BPR, draw_batch item_offset, shift_cat,
-                                     peer-to-peer exchange kernels */
+                                     peer-to-peer exchange kernels;
+                                  10: multi-term BPR backward scatters the gradient of gathered row blocks itself */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -629,10 +630,16 @@ int chaorec_bpr_multi_fwd_f32(const float *tab_u, const int64_t *users, int32_t 
                               const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
                               int32_t variant, const float *wvec, float *losses, float *out_total, float *coef,
                               float *workspace, void *stream);
+/* scatter_rows / scatter_out (both NULL, or HOST arrays of T device pointers, entries NULL per term): term k's item table
+ * is a block of rows gathered from a longer table (Model/FREEDOM.py:208-213 reads the batch rows of the projected feature
+ * table: here only those rows are projected) -- row r of it is row scatter_rows[k][r] of that table, and the backward adds
+ * its gradient ALSO into scatter_out[k][scatter_rows[k][r], :] (zero where no sample lands): the [I, D] row gradient the
+ * feature table's optimizer takes, without a separate zero fill + index_add launch per table. */
 int chaorec_bpr_multi_bwd_f32(const float *tab_u, const int64_t *users, int32_t T, const float *const *tabs,
                               const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
                               const float *coef, const float *wvec, const float *grad_out, float *g_u,
-                              float *const *g_i, void *stream);
+                              float *const *g_i, const int64_t *const *scatter_rows, float *const *scatter_out,
+                              void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * MMGCN's layer tail in one pass each way (Model/MMGCN.py:102-131, per layer:

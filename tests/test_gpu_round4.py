@@ -97,3 +97,103 @@ def test_bench_self_launches_two_ranks_on_this_gpu(dev):
     for name in ("MMGCN", "FREEDOM"):
         m = line["models"][name]
         assert "error" not in m and m["ms_per_step"] > 0 and m["config"]["exchange_bytes_per_step_per_rank"] > 0, m
+
+
+def _sharded_mmgcn_streams_worker(rank, world, port, tmp, streams):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CHAOREC_FORCE_COLLECTIVES"] = "1"          # a 1-rank group still issues every exchange through RCCL
+    os.environ["CHAOREC_DIST_MMGCN_STREAMS"] = "1" if streams else "0"
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from chaorec_amd import dist as cdist, graph, ops
+    from chaorec_amd.Model import MMGCN
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B = 6000, 2500, 40000, 512
+    edges = synthetic_interactions(U, I, E, seed=3)
+    g = torch.Generator().manual_seed(4)
+    v_feat, t_feat = torch.randn(I, 128, generator=g), torch.randn(I, 256, generator=g)
+    torch.manual_seed(21)
+    full = MMGCN(U, I, edges, graph.user_item_dict_from_edges(edges), v_feat, t_feat, 64, 1e-4, "add", "False", True, dev).to(dev)
+    shard = cdist.UserShard(edges, U, I, world, rank, dev, self_loops=True)
+    m = cdist.ShardedMMGCN(full, shard, dev)
+    del full
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    edges_dev = torch.from_numpy(shard.local_edges.astype(np.int64)).to(dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def draw():
+        counter.add_(1)
+        u, pos, neg = ops.draw_batch(edges_dev, m.hist, B, U, I, 42, 0, step_dev=counter, item_offset=U)
+        return torch.stack((u, u), 1), torch.stack((pos, neg), 1)
+
+    before = dict(cdist.STATS)
+    step = GraphedTrainStep(m, opt, batch_fn=draw, after_backward=m.sync_grads)
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize()
+    out = {n: p.detach().cpu().numpy() for n, p in m.named_parameters()}
+    out["__exchanges"] = np.array(cdist.STATS["exchanges"] - before["exchanges"])
+    np.savez(os.path.join(tmp, f"mm_streams_{int(streams)}.npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_sharded_mmgcn_two_streams_captured_with_rccl(dev):
+    """dist.ShardedMMGCN with its two modality branches on two streams, the exchanges of both really issued
+    through RCCL (1-rank group, forced) and the whole step captured in one hipGraph: six replayed steps leave the same
+    parameters as the one-stream run, up to the order of the BPR backward's atomic adds."""
+    import tempfile
+    import torch.multiprocessing as mp
+    from test_gpu_dist2 import _free_port
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for streams in (False, True):
+            mp.spawn(_sharded_mmgcn_streams_worker, args=(1, _free_port(), tmp, streams), nprocs=1, join=True)
+            out[streams] = dict(np.load(os.path.join(tmp, f"mm_streams_{int(streams)}.npz")))
+    assert int(out[True]["__exchanges"]) > 0
+    for n, ref in out[False].items():
+        if n.startswith("__"):
+            continue
+        d = np.abs(out[True][n] - ref)
+        assert (d > 1e-5).mean() <= 1e-3 and np.median(d) <= 1e-6, (n, float(d.max()))
+
+
+def test_bpr_multi_backward_scatters_gathered_terms_itself(dev):
+    """ops.bpr_loss_multi(..., gathered=...) (FREEDOM.loss): the backward launch adds the gradient of a projected row block
+    also into its [I, D] row gradient, which ops.linear_rows' backward then takes instead of a zero fill + index_add_ of
+    its own; ops.split_rows' backward returns a view when its two gradients already lie back to back.  Same loss, same
+    gradients as the path without `gathered` (up to the order of the atomic adds), duplicated rows included."""
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    U, I, D, B, Kt = 900, 700, 64, 512, 256
+    x0 = torch.randn(U + I, D, device=dev, generator=g) * 0.1
+    table0 = torch.randn(I, Kt, device=dev, generator=g) * 0.1
+    w0, b0 = torch.randn(D, Kt, device=dev, generator=g) * 0.05, torch.randn(D, device=dev, generator=g) * 0.01
+    users = torch.randint(0, U, (B,), device=dev, generator=g)
+    pos = torch.randint(0, I, (B,), device=dev, generator=g)
+    neg = torch.randint(0, 40, (B,), device=dev, generator=g)          # few distinct negatives: rows repeat in the batch
+    rows = torch.cat((pos, neg))
+    idx = torch.arange(B, device=dev)
+    wvec = torch.tensor([1.0, 0.3], device=dev)
+
+    def run(gathered):
+        x = x0.clone().requires_grad_(True)
+        table, w, b = (t.clone().requires_grad_(True) for t in (table0, w0, b0))
+        xu, xi = ops.split_rows(x, U)
+        proj = ops.linear_rows(table, rows, w, b)
+        loss = ops.bpr_loss_multi(xu, users, ops.VARIANT_LOGSIGMOID, [(xi, pos, neg), (proj, idx, idx + B)], wvec,
+                                  gathered=[None, (rows, I)] if gathered else None)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach(), x.grad, table.grad, w.grad, b.grad
+
+    ref, got = run(False), run(True)
+    assert torch.equal(ref[0], got[0])
+    for a, c in zip(ref[1:], got[1:]):
+        assert torch.allclose(a, c, rtol=0, atol=2e-6 * float(a.abs().max()) + 1e-12)
+    assert float(got[2].abs().sum()) > 0 and not ops._SCATTERED                  # the hand-over was consumed
