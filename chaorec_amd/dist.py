@@ -204,10 +204,16 @@ def exchange_buffer(n_rows, D, like, group=None):
     return buf, buf[:n_rows]
 
 
-def _all_reduce(t, group):
+def _all_reduce(t, group, home=None):
     if _active(group):
-        _count(t)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        def run():
+            _count(t)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        hopped = _hop(run, home, t)
+        if hopped is not None:
+            hopped.wait()
+        else:
+            run()
     return t
 
 
@@ -379,10 +385,34 @@ def _p2p_usable(buf, group):
         dist.get_world_size(group) <= 16
 
 
-def _sum_exchange_async(buf, group):
+# One stream for every collective of a model whose compute runs on several streams (ShardedMMGCN's two modality
+# branches): RCCL calls issued from two capturing streams crash this stack (core dump inside the capture, with the
+# capture in thread-local mode too: profiles/r04_c_*), calls issued from ONE stream -- whatever streams produce and
+# consume the buffers -- do not.  With a `home` stream every exchange hops: home waits for the caller's stream, the
+# collective runs (and is waited for) on home, the caller's stream waits for home.
+def _hop(fn, home, *tensors):
+    """Run fn() (collectives, waited for) on `home` when it is a stream other than the current one -> a handle whose
+    wait() makes the caller's stream depend on the result; else None (the caller issues on its own stream)."""
+    if home is None or not tensors or not tensors[0].is_cuda:
+        return None
+    cur = torch.cuda.current_stream()
+    if cur == home:
+        return None
+    home.wait_stream(cur)
+    with torch.cuda.stream(home):
+        fn()
+    return _PendingStream(home)
+
+
+def _sum_exchange_async(buf, group, home=None):
     """Sum `buf` ([rows_pad, D], rows_pad a multiple of the world size) over the ranks, in place, asynchronously."""
     if not _active(group):
         return _Pending(None)
+    hopped = _hop(lambda: _sum_exchange_issue(buf, group).wait(), home, buf)
+    return hopped if hopped is not None else _sum_exchange_issue(buf, group)
+
+
+def _sum_exchange_issue(buf, group):
     _count(buf)
     mode = resolve_mode(buf)
     if mode == "direct" and buf.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -1111,17 +1141,18 @@ class _ShardedPropagateJoined(torch.autograd.Function):
                   PARTIAL as the convention demands) -> item rows += d_i G_i(partial)"""
 
     @staticmethod
-    def forward(ctx, x, shard, spmm_fn, group):
-        ctx.shard, ctx.spmm_fn, ctx.group = shard, spmm_fn, group
-        return propagate_joined_fwd(x, shard, spmm_fn, group)
+    def forward(ctx, x, shard, spmm_fn, group, home):
+        ctx.shard, ctx.spmm_fn, ctx.group, ctx.home = shard, spmm_fn, group, home
+        return propagate_joined_fwd(x, shard, spmm_fn, group, home)
 
     @staticmethod
     def backward(ctx, G):
-        return propagate_joined_bwd(G, ctx.shard, ctx.spmm_fn, ctx.group), None, None, None
+        return propagate_joined_bwd(G, ctx.shard, ctx.spmm_fn, ctx.group, ctx.home), None, None, None, None
 
 
-def propagate_joined_fwd(x, shard, spmm_fn, group):
-    """_ShardedPropagateJoined's forward as a plain function (also called by ops.mmgcn_layer's node)."""
+def propagate_joined_fwd(x, shard, spmm_fn, group, home=None):
+    """_ShardedPropagateJoined's forward as a plain function (also called by ops.mmgcn_layer's node).  home: the stream
+    the exchange is issued from when the caller's compute runs on several streams (_hop)."""
     x = x.contiguous()
     U, N, D = shard.num_user_local, x.shape[0], x.shape[1]
     csr = joined_loop_csr(shard)
@@ -1129,20 +1160,20 @@ def propagate_joined_fwd(x, shard, spmm_fn, group):
     if buf.shape[0] > N:
         buf[N:].zero_()
     spmm_fn(csr, x, y=buf[:N])
-    _sum_exchange_async(buf[U:], group).wait()
+    _sum_exchange_async(buf[U:], group, home).wait()
     y = buf[:N]
     y[U:].addcmul_(x[U:], shard.diag_i)
     return y
 
 
-def propagate_joined_bwd(G, shard, spmm_fn, group):
+def propagate_joined_bwd(G, shard, spmm_fn, group, home=None):
     G = G.contiguous()
     U, N, D = shard.num_user_local, G.shape[0], G.shape[1]
     S = torch.empty((U + padded_rows(N - U, group), D), dtype=G.dtype, device=G.device)
     if S.shape[0] > N:
         S[N:].zero_()
     S[:N].copy_(G)
-    _sum_exchange_async(S[U:], group).wait()
+    _sum_exchange_async(S[U:], group, home).wait()
     g = spmm_fn(joined_loop_csr(shard), S[:N])
     g[U:].addcmul_(G[U:], shard.diag_i)
     return g
@@ -1156,17 +1187,18 @@ class ShardedGraph:
     def __init__(self, shard, spmm_fn=None, group=None):
         self.shard, self.spmm_fn, self.group = shard, spmm_fn, group
         self.joined = shard.diag_u is not None and _os.environ.get("CHAOREC_DIST_PROPAGATE", "joined") == "joined"
+        self.home = None       # the stream every exchange of this graph is issued from (a model on several streams sets it)
 
     def propagate_raw(self, x):
         """A x without an autograd node (joined form only): for nodes that own their backward (ops.mmgcn_layer)."""
-        return propagate_joined_fwd(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group)
+        return propagate_joined_fwd(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.home)
 
     def propagate_t_raw(self, g):
-        return propagate_joined_bwd(g, self.shard, self.spmm_fn or ops.spmm_raw, self.group)
+        return propagate_joined_bwd(g, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.home)
 
     def propagate(self, x):
         if self.joined:
-            return _ShardedPropagateJoined.apply(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group)
+            return _ShardedPropagateJoined.apply(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.home)
         n = self.shard.num_user_local
         yu, yi = _ShardedPropagate.apply(x[:n], x[n:], self.shard, self.spmm_fn or ops.spmm_raw, self.group)
         return torch.cat((yu, yi), 0)
@@ -1203,10 +1235,10 @@ class GradBucket:
                 o += p.numel()
         self.flat.zero_()
 
-    def all_reduce(self, group=None):
+    def all_reduce(self, group=None, home=None):
         if not self.attached():
             raise RuntimeError("GradBucket: a gradient no longer lives in the bucket (zero_grad(set_to_none=True)?)")
-        _all_reduce(self.flat, group)
+        _all_reduce(self.flat, group, home)
 
 
 def allreduce_grads(params, group=None):
@@ -1236,7 +1268,7 @@ class ShardedMMGCN(nn.Module):
         self.num_user, self.num_item = shard.num_user_local, shard.num_item
         self.reg_weight = full.reg_weight
         U, u0, u1 = shard.num_user_global, shard.u0, shard.u1
-        op = ShardedGraph(shard, spmm_fn, group)
+        op = self._graph_op = ShardedGraph(shard, spmm_fn, group)
 
         def take(t):       # [U + I, d] or [U, d] global rows -> this shard's layout
             t = t.detach().cpu()
@@ -1259,23 +1291,26 @@ class ShardedMMGCN(nn.Module):
     def forward(self):
         import importlib
         _mm = importlib.import_module(__package__ + ".Model.MMGCN")        # (the package re-exports the CLASS under this name)
-        streams = _os.environ.get("CHAOREC_DIST_MMGCN_STREAMS", "1") == "1" and _mm.BRANCH_STREAMS
+        streams = _os.environ.get("CHAOREC_DIST_MMGCN_STREAMS", "1") == "1" and _mm.BRANCH_STREAMS and self._graph_op.joined
         if streams and self.id_embedding.is_cuda:
             # The two modality branches are independent until the mean: the visual one on a side stream, like the
             # single-process model (Model/MMGCN.py forward; autograd replays every node's backward on its forward's
-            # stream).  The branches' exchanges are then issued from two streams of ONE host thread: RCCL queues them on
-            # its own stream in host order -- the same order on every rank, the program is the same.  (Round 3 saw this
-            # "dump core" under capture: it was the capture's global error mode, which forbids the event polls of RCCL's
-            # watchdog thread; captures that hold collectives are thread-local now, dist.capture_mode.)
+            # stream).  Their exchanges -- and the gradient bucket's all-reduce -- are all issued from ONE third stream
+            # (exchange_home): RCCL sees a single caller stream; a branch waits for that stream when it needs a sum.
             cur = torch.cuda.current_stream()
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream(device=self.id_embedding.device)
+                self._comm_stream = torch.cuda.Stream(device=self.id_embedding.device)
+            self._graph_op.home = self._comm_stream     # (the backward's exchanges, run by autograd later, hop too)
+            self._comm_stream.wait_stream(cur)
             self._side_stream.wait_stream(cur)
             with torch.cuda.stream(self._side_stream):
                 v_rep = self.v_gcn(self.v_feat, self.id_embedding)
             t_rep = self.t_gcn(self.t_feat, self.id_embedding)
             cur.wait_stream(self._side_stream)
+            cur.wait_stream(self._comm_stream)
         else:
+            self._graph_op.home = None
             v_rep = self.v_gcn(self.v_feat, self.id_embedding)
             t_rep = self.t_gcn(self.t_feat, self.id_embedding)
         rep = (v_rep + t_rep) / 2
@@ -1306,7 +1341,7 @@ class ShardedMMGCN(nn.Module):
 
     def sync_grads(self):
         if self._bucket is not None and self._bucket.attached():
-            self._bucket.all_reduce(self.group)
+            self._bucket.all_reduce(self.group, self._graph_op.home)
         else:
             allreduce_grads(self.parameters(), self.group)
 

@@ -307,3 +307,20 @@ def ngcf_structure(edge_index, n_nodes):
     tentry = torch.empty(col.numel(), dtype=torch.int64)
     tentry[rev] = fwd
     return DropoutStructure(csr, entry_row.to(torch.int32), tentry.to(torch.int32))
+
+
+def binary_sym_norm_csr(users, items, num_user, num_item):
+    """The adjacency every `torch.sparse.mm` model of the reference builds with scipy (e.g. Model/SimGCL.py:64-112,
+    Model/NCL.py:97-137, Model/SelfCF.py:63-99): binary A over users then items (a repeated interaction counts once),
+    degree = distinct neighbours + 1e-7, D^-1/2 A D^-1/2 evaluated in fp64 and stored as fp32 -- vectorised (the
+    reference fills a dok matrix entry by entry).  users / items: int64 tensors, LOCAL item ids.  -> coalesced CSR."""
+    import numpy as np
+    U, I, N = num_user, num_item, num_user + num_item
+    key = torch.unique(users.long() * I + items.long())
+    u, i = torch.div(key, I, rounding_mode="floor"), key % I
+    deg = torch.zeros(N, dtype=torch.float64)
+    deg.index_add_(0, u, torch.ones(u.numel(), dtype=torch.float64))
+    deg.index_add_(0, U + i, torch.ones(i.numel(), dtype=torch.float64))
+    d = torch.from_numpy(np.power(deg.numpy() + 1e-7, -0.5))
+    val = ((d[u] * 1.0) * d[U + i]).to(torch.float32)
+    return coo_to_csr_coalesced(torch.cat([u, U + i]), torch.cat([U + i, u]), torch.cat([val, val]), N, N, symmetric=True)

@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import BPRMF, FREEDOM, LayerGCN, LightGCN, MGCN, MMGCN, NGCF, VBPR
+from .Model import BPRMF, FREEDOM, LayerGCN, LightGCN, MGCN, MMGCN, NCL, NGCF, SelfCF, SimGCL, VBPR
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
 from .optim import FusedAdam
@@ -52,6 +52,13 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
         'BPR': lambda: BPRMF(num_user, num_item, user_item_dict, dim_E, args.reg_weight, device),
         'VBPR': lambda: VBPR(num_user, num_item, user_item_dict, v_feat, dim_E, args.feature_embed, args.reg_weight,
                              device),
+        # three more members of the torch.sparse.mm family, through the adapter alone (main.py:305-306, :335-336, :344-345)
+        'NCL': lambda: NCL(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers, aggr_mode,
+                           args.ssl_temp, args.ssl_alpha, device),
+        'SimGCL': lambda: SimGCL(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
+                                 args.ssl_temp, args.ssl_alpha, device),
+        'SelfCF': lambda: SelfCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
+                                 args.dropout, device),
     }
     if args.Model not in table:
         raise SystemExit(f"--Model {args.Model}: only {sorted(table)} are on the MI355X hot path")

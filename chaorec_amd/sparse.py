@@ -8,6 +8,12 @@ into the embedding table every layer).
 The COO tensor is converted ONCE into the kernel's CSR (coalesced, cached on the tensor object) and every call
 is one chaorec_spmm_csr_f32 launch with autograd (backward = the transposed CSR, or the same one when the
 matrix is symmetric).
+
+`sparse_dropout(adj, rate)` is the family's per-step edge dropout helper (Model/SelfCF.py:101-112 and its copies:
+every stored entry kept with probability 1 - rate, the kept ones scaled by 1 / (1 - rate)).  The reference builds a
+new COO tensor per step; here the structure stays (one CSR, one SpMM schedule) and only the VALUE array changes --
+a dropped entry is a zero value, which adds +0 * x to its row's sum -- so `mm` of the result is the same kernel in
+its dynamic-values mode, forward over the masked values and backward over the masked values of the transpose.
 """
 import torch
 
@@ -33,10 +39,7 @@ def from_torch_sparse(adj, assume_symmetric=None):
     return csr
 
 
-def mm(adj, dense):
-    """torch.sparse.mm(adj, dense) on the HIP SpMM kernel; `adj` may be a torch sparse tensor or a graph.CSR."""
-    if isinstance(adj, graph.CSR):
-        return ops.spmm(adj, dense)
+def _cached_csr(adj):
     csr = getattr(adj, _CACHE_ATTR, None)
     if csr is None:
         csr = from_torch_sparse(adj)
@@ -44,4 +47,52 @@ def mm(adj, dense):
             setattr(adj, _CACHE_ATTR, csr)
         except AttributeError:
             pass
-    return ops.spmm(csr, dense)
+    return csr
+
+
+def mm(adj, dense):
+    """torch.sparse.mm(adj, dense) on the HIP SpMM kernel; `adj` may be a torch sparse tensor, a graph.CSR or the
+    result of sparse_dropout()."""
+    if isinstance(adj, DroppedAdj):
+        return ops.spmm_values(adj.structure, adj.val, adj.val_t, dense)
+    if isinstance(adj, graph.CSR):
+        return ops.spmm(adj, dense)
+    return ops.spmm(_cached_csr(adj), dense)
+
+
+class DroppedAdj:
+    """`sparse_dropout`'s result: the adjacency's fixed structure with this step's values (and its transpose's)."""
+
+    def __init__(self, structure, val, val_t):
+        self.structure, self.val, self.val_t = structure, val, val_t
+
+
+def _dropout_structure(csr):
+    """graph.DropoutStructure over an arbitrary square CSR (entry -> its row, entry -> the entry of the reversed pair;
+    entries without a stored reverse cannot be transposed in place and raise)."""
+    n = csr.n_rows
+    dev = csr.col.device
+    counts = csr.rowptr[1:] - csr.rowptr[:-1]
+    entry_row = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=dev), counts)
+    col = csr.col.to(torch.int64)
+    fwd = torch.argsort(entry_row * n + col, stable=True)
+    rev = torch.argsort(col * n + entry_row, stable=True)
+    if not torch.equal((entry_row * n + col)[fwd], (col * n + entry_row)[rev]):
+        raise ValueError("sparse_dropout: the adjacency's pattern is not symmetric")
+    tentry = torch.empty(col.numel(), dtype=torch.int64, device=dev)
+    tentry[rev] = fwd
+    return graph.DropoutStructure(csr, entry_row.to(torch.int32), tentry.to(torch.int32))
+
+
+def sparse_dropout(adj, rate, keep=None, generator=None):
+    """Model/SelfCF.py:101-112: keep each stored entry with probability 1 - rate (mask = floor(1 - rate + U[0,1))), scale
+    the kept ones by 1 / (1 - rate).  `adj`: a torch sparse tensor or a graph.CSR with a symmetric pattern; `keep`
+    (bool [nnz] in the CSR's entry order, optional) replaces the draw.  -> DroppedAdj for `mm`."""
+    csr = adj if isinstance(adj, graph.CSR) else _cached_csr(adj)
+    st = getattr(csr, "_dropout_structure", None)
+    if st is None:
+        st = csr._dropout_structure = _dropout_structure(csr)
+    if keep is None:
+        keep = torch.floor(1.0 - rate + torch.rand(csr.nnz, device=csr.val.device, generator=generator)).to(torch.bool)
+    val = torch.where(keep, csr.val * (1.0 / (1.0 - rate)), torch.zeros((), dtype=csr.val.dtype, device=csr.val.device))
+    return DroppedAdj(st, val, val[st.transpose_entry.long()])

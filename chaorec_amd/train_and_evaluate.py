@@ -12,6 +12,8 @@ from .utils import EarlyStopping, EvalLists, gene_metrics, gene_metrics_device
 
 MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM", "LayerGCN")     # reference train_and_evaluate.py:555
+E_STEP = ("NCL",)                       # reference train_and_evaluate.py:107-114
+NO_CAPTURE = ("NCL", "SimGCL", "SelfCF")    # host-side randomness / clustering inside the step: eager launches
 
 
 def _train_epoch_in_launch(model, loader, optimizer, graphed):
@@ -54,6 +56,8 @@ def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):
             d = graphed(*batch)
         else:
             optimizer.zero_grad()
+            if model_name in E_STEP:
+                model.e_step()               # NCL clusters its embeddings before EVERY batch (train_and_evaluate.py:107-114)
             loss = model.loss(*batch)
             loss.backward()
             optimizer.step()
@@ -86,6 +90,8 @@ def _capture_step(model, train_loader, optimizer, model_name):
     from .dataload import DeviceBatchSampler
     from .optim import FusedAdam, GraphedTrainStep
     if not isinstance(train_loader, DeviceBatchSampler) or not isinstance(optimizer, FusedAdam):
+        return None
+    if model_name in NO_CAPTURE:
         return None
     if model_name in PRE_EPOCH and not getattr(model, "prunes_in_place", False):
         return None          # a graph that is re-allocated every epoch cannot sit behind captured addresses

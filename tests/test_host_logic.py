@@ -433,3 +433,38 @@ def test_bench_launches_its_own_ranks_and_propagates_failures():
                        env=dict(env, CHAOREC_DIST_GRAPH="0"), capture_output=True, text=True, timeout=300)
     if not __import__("torch").cuda.is_available():
         assert r.returncode != 0 and "needs the MI355X" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["simgcl_small.npz", "ncl_small.npz", "selfcf_small.npz"])
+def test_sparse_family_models_start_from_the_reference_state(name):
+    """SimGCL / NCL / SelfCF (through the adapter alone): what needs no GPU -- the same seed gives the
+    reference class's parameter names and initial weights, and graph.binary_sym_norm_csr gives its scipy-built
+    D^-1/2 A D^-1/2 bit for bit (goldens of tests/golden/gen_sparse_family.py: the reference classes' own output)."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import NCL, SelfCF, SimGCL
+    g = load_golden(name)
+    U, I = int(g["U"]), int(g["I"])
+    uid = graph.user_item_dict_from_edges(g["edges"])
+    cpu = torch.device("cpu")
+    torch.manual_seed(0)
+    if name.startswith("simgcl"):
+        m = SimGCL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), float(g["ssl_temp"]), float(g["ssl_reg"]), cpu)
+        adj = m.sparse_norm_adj
+    elif name.startswith("ncl"):
+        m = NCL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), "add", float(g["ssl_temp"]), float(g["ssl_reg"]), cpu)
+        adj = m.norm_adj_mat
+    else:
+        m = SelfCF(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), float(g["dropout"]), cpu)
+        adj = m.online_encoder.sparse_norm_adj
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().numpy(), g["p_" + n]), n
+    dense = np.zeros((U + I, U + I), np.float32)
+    rp, col, val = adj.rowptr.numpy(), adj.col.numpy(), adj.val.numpy()
+    for r in range(U + I):
+        dense[r, col[rp[r]:rp[r + 1]]] = val[rp[r]:rp[r + 1]]
+    ref = np.zeros((U + I, U + I), np.float32)
+    ref[g["norm_idx"][0], g["norm_idx"][1]] = g["norm_val"]
+    assert np.array_equal(dense, ref)
+    with pytest.raises(RuntimeError, match="MI355X only"):          # no CPU compute path: the propagate raises
+        m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))

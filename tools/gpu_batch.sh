@@ -10,7 +10,7 @@ for part in "$@"; do
     tests)
       python -m pytest tests -x -q -m gpu > $out/${tag}_tests.log 2>&1; echo "tests rc=$?"; tail -3 $out/${tag}_tests.log ;;
     tests_new)
-      python -m pytest tests/test_gpu_round4.py tests/test_gpu_dist2.py -x -q -m gpu > $out/${tag}_tests_new.log 2>&1; echo "tests_new rc=$?"; tail -3 $out/${tag}_tests_new.log ;;
+      python -m pytest tests/test_gpu_round4.py tests/test_gpu_sparse_family.py tests/test_gpu_dist2.py -q -m gpu > $out/${tag}_tests_new.log 2>&1; echo "tests_new rc=$?"; tail -3 $out/${tag}_tests_new.log ;;
     bench)
       python bench.py --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?" ;;
     models)
@@ -27,6 +27,12 @@ for part in "$@"; do
       python3 tools/prof_stats.py $out/${tag}_prof_FREEDOM 14 ;;
     mmgcn_prof)
       (cd /tmp && CHAOREC_FORCE_SHARDED=1 CHAOREC_FORCE_COLLECTIVES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/${tag}_prof_MMGCN_sharded -o MMGCN -- python3 $GRAFT_REPO_ROOT/bench.py --model MMGCN --steps 50 --warmup 10 > $GRAFT_REPO_ROOT/$out/${tag}_prof_MMGCN_sharded.json 2> $GRAFT_REPO_ROOT/$out/${tag}_prof_MMGCN_sharded.err); echo "mmgcn_prof rc=$?" ;;
+    mmgcn_sharded)
+      CHAOREC_FORCE_SHARDED=1 CHAOREC_FORCE_COLLECTIVES=1 python bench.py --model MMGCN --steps 50 --warmup 10 > $out/${tag}_bench_MMGCN_sharded.json 2> $out/${tag}_bench_MMGCN_sharded.err; echo "MMGCN sharded (two streams) rc=$?"
+      CHAOREC_DIST_MMGCN_STREAMS=0 CHAOREC_FORCE_SHARDED=1 CHAOREC_FORCE_COLLECTIVES=1 python bench.py --model MMGCN --steps 50 --warmup 10 > $out/${tag}_bench_MMGCN_sharded_1stream.json 2> $out/${tag}_bench_MMGCN_sharded_1stream.err; echo "MMGCN sharded (one stream) rc=$?" ;;
+    overlap)
+      python tools/score_overlap_exp.py > $out/${tag}_score_overlap_ub3.txt 2>&1; echo "overlap ub3 rc=$?"; cat $out/${tag}_score_overlap_ub3.txt | tail -6
+      CHAOREC_EXTRA_HIPCC_FLAGS="-DCHAOREC_PF_UB64=2" python tools/score_overlap_exp.py > $out/${tag}_score_overlap_ub2.txt 2>&1; echo "overlap ub2 rc=$?"; cat $out/${tag}_score_overlap_ub2.txt | tail -6 ;;
     *) echo "unknown part $part" ;;
   esac
 done

@@ -9,7 +9,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from chaorec_amd import dataload, ops, ranking  # noqa: E402
+from chaorec_amd import _lib, dataload, ops, ranking  # noqa: E402
+
+_lib.ensure_built()          # (an experiment build -- CHAOREC_EXTRA_HIPCC_FLAGS -- compiles its own library on first use)
 from chaorec_amd.Model import LightGCN  # noqa: E402
 from chaorec_amd.optim import FusedAdam, FusedLightGCNStep  # noqa: E402
 
