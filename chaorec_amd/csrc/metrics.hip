@@ -34,15 +34,16 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const MetricArgs A) {
   __shared__ double red[4][kMetMaxNK * 5];
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double acc[kMetMaxNK * 5];
-#pragma unroll
-  for (int i = 0; i < kMetMaxNK * 5; ++i) acc[i] = 0.0;
-  if (row < A.n_rows) {
+  // (no per-thread array of the n_k * 5 values: indexed by a run-time cut-off number it lived in scratch memory, 336 B
+  //  per lane; every cut-off's five values go from registers straight into the wave reduction instead)
+  const bool valid = row < A.n_rows;
+  unsigned long long hit = 0ull, first = 0ull;   // bit p: ranked[p] in test_list / first occurrence of its id
+  int64_t len = 0;
+  if (valid) {
     const int64_t u = A.row_user[row];
     const int64_t pb = A.pos_rowptr[row], pe = A.pos_rowptr[row + 1];
-    const int64_t len = pe - pb;
+    len = pe - pb;
     const int64_t *top = A.rank_idx + u * A.rank_stride;
-    unsigned long long hit = 0ull, first = 0ull;   // bit p: ranked[p] in test_list / first occurrence of its id
     for (int p = 0; p < A.kmax; ++p) {
       const int64_t it = top[p];
       bool h = false;
@@ -52,9 +53,14 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const MetricArgs A) {
       if (h) hit |= 1ull << p;
       if (!dup) first |= 1ull << p;
     }
-    const double dlen = (double)len;
-    for (int ki = 0; ki < A.n_k; ++ki) {
-      const int k = A.k_list[ki];
+  }
+  const double dlen = (double)len;
+  // fixed-order block reduction: lanes by butterfly, waves in index order
+  const int n = A.n_k * 5;
+  for (int ki = 0; ki < A.n_k; ++ki) {
+    const int k = A.k_list[ki];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+    if (valid) {
       const unsigned long long km = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
       const double inter = (double)__popcll(hit & first & km);
       double dcg = 0.0, ap = 0.0;
@@ -67,19 +73,26 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const MetricArgs A) {
         }
       }
       const int64_t m = len < k ? len : k;
-      acc[ki * 5 + 0] = inter / (double)k;
-      acc[ki * 5 + 1] = len > 0 ? inter / dlen : 0.0;
-      acc[ki * 5 + 2] = len > 0 ? dcg / A.idcg[m] : 0.0;
-      acc[ki * 5 + 3] = inter > 0.0 ? 1.0 : 0.0;
-      acc[ki * 5 + 4] = len > 0 ? ap / dlen : 0.0;
+      v0 = inter / (double)k;
+      v1 = len > 0 ? inter / dlen : 0.0;
+      v2 = len > 0 ? dcg / A.idcg[m] : 0.0;
+      v3 = inter > 0.0 ? 1.0 : 0.0;
+      v4 = len > 0 ? ap / dlen : 0.0;
     }
-  }
-  // fixed-order block reduction: lanes by butterfly, waves in index order
-  const int n = A.n_k * 5;
-  for (int i = 0; i < n; ++i) {
-    double v = acc[i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) red[wave][i] = v;
+    for (int o = 32; o > 0; o >>= 1) {
+      v0 += __shfl_xor(v0, o, 64);
+      v1 += __shfl_xor(v1, o, 64);
+      v2 += __shfl_xor(v2, o, 64);
+      v3 += __shfl_xor(v3, o, 64);
+      v4 += __shfl_xor(v4, o, 64);
+    }
+    if (lane == 0) {
+      red[wave][ki * 5 + 0] = v0;
+      red[wave][ki * 5 + 1] = v1;
+      red[wave][ki * 5 + 2] = v2;
+      red[wave][ki * 5 + 3] = v3;
+      red[wave][ki * 5 + 4] = v4;
+    }
   }
   __syncthreads();
   if ((int)threadIdx.x < n)

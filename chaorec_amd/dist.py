@@ -204,16 +204,10 @@ def exchange_buffer(n_rows, D, like, group=None):
     return buf, buf[:n_rows]
 
 
-def _all_reduce(t, group, home=None):
+def _all_reduce(t, group):
     if _active(group):
-        def run():
-            _count(t)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        hopped = _hop(run, home, t)
-        if hopped is not None:
-            hopped.wait()
-        else:
-            run()
+        _count(t)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -385,34 +379,18 @@ def _p2p_usable(buf, group):
         dist.get_world_size(group) <= 16
 
 
-# One stream for every collective of a model whose compute runs on several streams (ShardedMMGCN's two modality
-# branches): RCCL calls issued from two capturing streams crash this stack (core dump inside the capture, with the
-# capture in thread-local mode too: profiles/r04_c_*), calls issued from ONE stream -- whatever streams produce and
-# consume the buffers -- do not.  With a `home` stream every exchange hops: home waits for the caller's stream, the
-# collective runs (and is waited for) on home, the caller's stream waits for home.
-def _hop(fn, home, *tensors):
-    """Run fn() (collectives, waited for) on `home` when it is a stream other than the current one -> a handle whose
-    wait() makes the caller's stream depend on the result; else None (the caller issues on its own stream)."""
-    if home is None or not tensors or not tensors[0].is_cuda:
-        return None
-    cur = torch.cuda.current_stream()
-    if cur == home:
-        return None
-    home.wait_stream(cur)
-    with torch.cuda.stream(home):
-        fn()
-    return _PendingStream(home)
-
-
-def _sum_exchange_async(buf, group, home=None):
-    """Sum `buf` ([rows_pad, D], rows_pad a multiple of the world size) over the ranks, in place, asynchronously."""
+def _sum_exchange_async(buf, group, sync=False):
+    """Sum `buf` ([rows_pad, D], rows_pad a multiple of the world size) over the ranks, in place; -> a handle to wait on.
+    sync=True: c10d's synchronous form (the CURRENT stream waits for the collective, nothing to wait on afterwards) -- what a
+    model whose compute runs on SEVERAL streams must use inside a captured step: on this stack (ROCm 7.2, RCCL 2.26 of torch
+    2.10) `async_op=True` collectives issued from a second capturing stream segfault in the capture, the synchronous form
+    from the same streams is fine, eagerly both are (tools/rccl_streams_repro.py, profiles/r04_f_rccl_streams_repro.txt)."""
     if not _active(group):
         return _Pending(None)
-    hopped = _hop(lambda: _sum_exchange_issue(buf, group).wait(), home, buf)
-    return hopped if hopped is not None else _sum_exchange_issue(buf, group)
+    return _sum_exchange_issue(buf, group, sync)
 
 
-def _sum_exchange_issue(buf, group):
+def _sum_exchange_issue(buf, group, sync=False):
     _count(buf)
     mode = resolve_mode(buf)
     if mode == "direct" and buf.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -441,29 +419,33 @@ def _sum_exchange_issue(buf, group):
             if not ex.ready(buf.numel()):
                 ex.setup(buf.numel(), buf.device)          # (collective, eager only: raises inside a capture)
             MODES_USED.add("p2p")
+            if sync:
+                ex.exchange(buf)                          # (on the caller's stream: nothing to wait on)
+                return _Pending(None)
             side = ex.side_stream(buf.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ex.exchange(buf)
             return _PendingStream(side)
     MODES_USED.add("allreduce" if (mode == "allreduce" or buf.shape[0] % dist.get_world_size(group)) else mode)
+    lazy = not sync                                    # (async_op=False returns no handle: _Pending(None) waits for nothing)
     if mode == "allreduce" or buf.shape[0] % dist.get_world_size(group):
-        return _Pending(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        return _Pending(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=lazy))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     rows = buf.shape[0] // world
     mine = buf[rank * rows:(rank + 1) * rows]
     if mode == "rs_ag":
         chunk = torch.empty_like(mine)
-        rs = dist.reduce_scatter_tensor(chunk, buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        return _Pending(rs, lambda: _Pending(dist.all_gather_into_tensor(buf, chunk, group=group, async_op=True)))
+        rs = dist.reduce_scatter_tensor(chunk, buf, op=dist.ReduceOp.SUM, group=group, async_op=lazy)
+        return _Pending(rs, lambda: _Pending(dist.all_gather_into_tensor(buf, chunk, group=group, async_op=lazy)))
     recv = torch.empty_like(buf)                       # block j of `recv` = rank j's partial of MY row block
-    a2a = dist.all_to_all_single(recv, buf, group=group, async_op=True)
+    a2a = dist.all_to_all_single(recv, buf, group=group, async_op=lazy)
 
     def gather():
         # (the two-pass column sum of the kernels library on the GPU: fixed order, no memset node under capture)
         blocks = recv.view(world, -1)
         chunk = (ops.col_sum(blocks) if recv.is_cuda else blocks.sum(0)).view(rows, -1)
-        return _Pending(dist.all_gather_into_tensor(buf, chunk, group=group, async_op=True))
+        return _Pending(dist.all_gather_into_tensor(buf, chunk, group=group, async_op=lazy))
 
     return _Pending(a2a, gather)
 
@@ -1141,18 +1123,18 @@ class _ShardedPropagateJoined(torch.autograd.Function):
                   PARTIAL as the convention demands) -> item rows += d_i G_i(partial)"""
 
     @staticmethod
-    def forward(ctx, x, shard, spmm_fn, group, home):
-        ctx.shard, ctx.spmm_fn, ctx.group, ctx.home = shard, spmm_fn, group, home
-        return propagate_joined_fwd(x, shard, spmm_fn, group, home)
+    def forward(ctx, x, shard, spmm_fn, group, sync):
+        ctx.shard, ctx.spmm_fn, ctx.group, ctx.sync = shard, spmm_fn, group, sync
+        return propagate_joined_fwd(x, shard, spmm_fn, group, sync)
 
     @staticmethod
     def backward(ctx, G):
-        return propagate_joined_bwd(G, ctx.shard, ctx.spmm_fn, ctx.group, ctx.home), None, None, None, None
+        return propagate_joined_bwd(G, ctx.shard, ctx.spmm_fn, ctx.group, ctx.sync), None, None, None, None
 
 
-def propagate_joined_fwd(x, shard, spmm_fn, group, home=None):
-    """_ShardedPropagateJoined's forward as a plain function (also called by ops.mmgcn_layer's node).  home: the stream
-    the exchange is issued from when the caller's compute runs on several streams (_hop)."""
+def propagate_joined_fwd(x, shard, spmm_fn, group, sync=False):
+    """_ShardedPropagateJoined's forward as a plain function (also called by ops.mmgcn_layer's node).  sync: the
+    synchronous collective form (_sum_exchange_async), for callers whose compute runs on several streams."""
     x = x.contiguous()
     U, N, D = shard.num_user_local, x.shape[0], x.shape[1]
     csr = joined_loop_csr(shard)
@@ -1160,20 +1142,20 @@ def propagate_joined_fwd(x, shard, spmm_fn, group, home=None):
     if buf.shape[0] > N:
         buf[N:].zero_()
     spmm_fn(csr, x, y=buf[:N])
-    _sum_exchange_async(buf[U:], group, home).wait()
+    _sum_exchange_async(buf[U:], group, sync).wait()
     y = buf[:N]
     y[U:].addcmul_(x[U:], shard.diag_i)
     return y
 
 
-def propagate_joined_bwd(G, shard, spmm_fn, group, home=None):
+def propagate_joined_bwd(G, shard, spmm_fn, group, sync=False):
     G = G.contiguous()
     U, N, D = shard.num_user_local, G.shape[0], G.shape[1]
     S = torch.empty((U + padded_rows(N - U, group), D), dtype=G.dtype, device=G.device)
     if S.shape[0] > N:
         S[N:].zero_()
     S[:N].copy_(G)
-    _sum_exchange_async(S[U:], group, home).wait()
+    _sum_exchange_async(S[U:], group, sync).wait()
     g = spmm_fn(joined_loop_csr(shard), S[:N])
     g[U:].addcmul_(G[U:], shard.diag_i)
     return g
@@ -1187,18 +1169,18 @@ class ShardedGraph:
     def __init__(self, shard, spmm_fn=None, group=None):
         self.shard, self.spmm_fn, self.group = shard, spmm_fn, group
         self.joined = shard.diag_u is not None and _os.environ.get("CHAOREC_DIST_PROPAGATE", "joined") == "joined"
-        self.home = None       # the stream every exchange of this graph is issued from (a model on several streams sets it)
+        self.sync = False      # synchronous collectives (a model whose compute runs on several streams sets it: _sum_exchange_async)
 
     def propagate_raw(self, x):
         """A x without an autograd node (joined form only): for nodes that own their backward (ops.mmgcn_layer)."""
-        return propagate_joined_fwd(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.home)
+        return propagate_joined_fwd(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.sync)
 
     def propagate_t_raw(self, g):
-        return propagate_joined_bwd(g, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.home)
+        return propagate_joined_bwd(g, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.sync)
 
     def propagate(self, x):
         if self.joined:
-            return _ShardedPropagateJoined.apply(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.home)
+            return _ShardedPropagateJoined.apply(x, self.shard, self.spmm_fn or ops.spmm_raw, self.group, self.sync)
         n = self.shard.num_user_local
         yu, yi = _ShardedPropagate.apply(x[:n], x[n:], self.shard, self.spmm_fn or ops.spmm_raw, self.group)
         return torch.cat((yu, yi), 0)
@@ -1235,10 +1217,10 @@ class GradBucket:
                 o += p.numel()
         self.flat.zero_()
 
-    def all_reduce(self, group=None, home=None):
+    def all_reduce(self, group=None):
         if not self.attached():
             raise RuntimeError("GradBucket: a gradient no longer lives in the bucket (zero_grad(set_to_none=True)?)")
-        _all_reduce(self.flat, group, home)
+        _all_reduce(self.flat, group)
 
 
 def allreduce_grads(params, group=None):
@@ -1254,6 +1236,13 @@ def allreduce_grads(params, group=None):
         n = p.grad.numel()
         p.grad.copy_(flat[o:o + n].view_as(p.grad))
         o += n
+
+
+# ShardedMMGCN's two modality branches on two streams (CHAOREC_DIST_MMGCN_STREAMS=0: one stream).  Round 3 had this "dump
+# core" under capture; tools/rccl_streams_repro.py (profiles/r04_f_rccl_streams_repro.txt) narrowed it down: `async_op=True`
+# collectives from a second capturing stream segfault, and so does every collective hopped onto a third "communication"
+# stream; the synchronous form issued by the branch's own stream captures and replays fine.
+SHARDED_MMGCN_STREAMS_DEFAULT = "1"
 
 
 class ShardedMMGCN(nn.Module):
@@ -1291,26 +1280,25 @@ class ShardedMMGCN(nn.Module):
     def forward(self):
         import importlib
         _mm = importlib.import_module(__package__ + ".Model.MMGCN")        # (the package re-exports the CLASS under this name)
-        streams = _os.environ.get("CHAOREC_DIST_MMGCN_STREAMS", "1") == "1" and _mm.BRANCH_STREAMS and self._graph_op.joined
+        streams = _os.environ.get("CHAOREC_DIST_MMGCN_STREAMS", SHARDED_MMGCN_STREAMS_DEFAULT) == "1" and _mm.BRANCH_STREAMS \
+            and self._graph_op.joined
         if streams and self.id_embedding.is_cuda:
             # The two modality branches are independent until the mean: the visual one on a side stream, like the
             # single-process model (Model/MMGCN.py forward; autograd replays every node's backward on its forward's
-            # stream).  Their exchanges -- and the gradient bucket's all-reduce -- are all issued from ONE third stream
-            # (exchange_home): RCCL sees a single caller stream; a branch waits for that stream when it needs a sum.
+            # stream).  Each branch issues its own exchanges from its own stream -- in c10d's SYNCHRONOUS form: that is what
+            # survives a capture from two streams on this stack (_sum_exchange_async).  RCCL queues the collectives on its
+            # own stream in host order, the same on every rank.
             cur = torch.cuda.current_stream()
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream(device=self.id_embedding.device)
-                self._comm_stream = torch.cuda.Stream(device=self.id_embedding.device)
-            self._graph_op.home = self._comm_stream     # (the backward's exchanges, run by autograd later, hop too)
-            self._comm_stream.wait_stream(cur)
+            self._graph_op.sync = True                   # (the backward's exchanges, run by autograd later, too)
             self._side_stream.wait_stream(cur)
             with torch.cuda.stream(self._side_stream):
                 v_rep = self.v_gcn(self.v_feat, self.id_embedding)
             t_rep = self.t_gcn(self.t_feat, self.id_embedding)
             cur.wait_stream(self._side_stream)
-            cur.wait_stream(self._comm_stream)
         else:
-            self._graph_op.home = None
+            self._graph_op.sync = False
             v_rep = self.v_gcn(self.v_feat, self.id_embedding)
             t_rep = self.t_gcn(self.t_feat, self.id_embedding)
         rep = (v_rep + t_rep) / 2
@@ -1341,7 +1329,7 @@ class ShardedMMGCN(nn.Module):
 
     def sync_grads(self):
         if self._bucket is not None and self._bucket.attached():
-            self._bucket.all_reduce(self.group, self._graph_op.home)
+            self._bucket.all_reduce(self.group)
         else:
             allreduce_grads(self.parameters(), self.group)
 

@@ -103,7 +103,7 @@ def _sharded_mmgcn_streams_worker(rank, world, port, tmp, streams):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_FORCE_COLLECTIVES"] = "1"          # a 1-rank group still issues every exchange through RCCL
-    os.environ["CHAOREC_DIST_MMGCN_STREAMS"] = "1" if streams else "0"
+    os.environ["CHAOREC_DIST_MMGCN_STREAMS"] = "1" if streams else "0"          # (opt-in: see dist.SHARDED_MMGCN_STREAMS_DEFAULT)
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     dev = torch.device("cuda:0")

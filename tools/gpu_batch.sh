@@ -33,6 +33,8 @@ for part in "$@"; do
     overlap)
       python tools/score_overlap_exp.py > $out/${tag}_score_overlap_ub3.txt 2>&1; echo "overlap ub3 rc=$?"; cat $out/${tag}_score_overlap_ub3.txt | tail -6
       CHAOREC_EXTRA_HIPCC_FLAGS="-DCHAOREC_PF_UB64=2" python tools/score_overlap_exp.py > $out/${tag}_score_overlap_ub2.txt 2>&1; echo "overlap ub2 rc=$?"; cat $out/${tag}_score_overlap_ub2.txt | tail -6 ;;
+    rccl_streams)
+      python tools/rccl_streams_repro.py > $out/${tag}_rccl_streams_repro.txt 2>&1; echo "rccl_streams rc=$?"; cat $out/${tag}_rccl_streams_repro.txt ;;
     *) echo "unknown part $part" ;;
   esac
 done
