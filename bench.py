@@ -489,7 +489,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     del b0, b1, fin, G, plain, whole
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
     table_mb = N * D * 4 / 1e6
-    traffic = None
+    traffic = kernel_only_us = None
     tpath = os.path.join(ROOT, "profiles", f"spmm_traffic_{dataset}_d{D}.json")
     traffic_note = "no PMC file for this workload under profiles/"
     if os.path.exists(tpath):
@@ -500,6 +500,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             if tj.get("spmm_hip_sha256") == spmm_source_hash():
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_note = "from " + os.path.relpath(tpath, ROOT) + " (same spmm.hip)"
+                kernel_only_us = tj.get("kernel_avg_us_rocprofv3")
             else:
                 traffic_note = os.path.relpath(tpath, ROOT) + " was measured on a different spmm.hip: dropped"
         except Exception:
@@ -520,6 +521,13 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                  "no-reuse CSR model bytes, `traffic` (when present) the measured FETCH_SIZE+WRITE_SIZE bytes" % table_mb)}
     if traffic:
         roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
+    if kernel_only_us:
+        # the same kernel's average duration in the rocprofv3 kernel trace of the same command (begin -> end of the kernel,
+        # no launch boundary), from the committed profile this run's spmm.hip was measured with -- NOT measured in this run
+        roofline["kernel_only_rocprofv3"] = {"avg_us": kernel_only_us,
+                                             "frac": model_bytes / (kernel_only_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                             "source": os.path.relpath(tpath, ROOT),
+                                             "launch_boundary_us": avg_spmm_ms * 1e3 - kernel_only_us}
     if getattr(args, "spmm_only", False):
         return dict(spmm_only=True, dataset=dataset, data=data_kind, U=U, I=I, E=E, e_dir=e_dir, D=D, L=L, B=B,
                     ms_per_step=ms_per_step, value=msgs_per_step / (dt / steps), msgs_per_step=msgs_per_step,
