@@ -806,11 +806,8 @@ class FusedShardedLightGCNStep:
         flat[U:U + I].copy_(iw.data)
         uw.data, iw.data = flat[:U], flat[U:U + I]
         self.flat = flat
-        optimizer._ensure_state([uw, iw])
+        optimizer.make_moments_adjacent([uw, iw])          # (existing moments are migrated into one buffer, not refused)
         st_u, st_i = optimizer.state[uw], optimizer.state[iw]
-        if st_i["exp_avg"].data_ptr() != st_u["exp_avg"].data_ptr() + uw.numel() * 4 or \
-                st_i["exp_avg_sq"].data_ptr() != st_u["exp_avg_sq"].data_ptr() + uw.numel() * 4:
-            raise ValueError("FusedShardedLightGCNStep: the Adam moments of the two tables are not adjacent")
         self.m = torch.as_strided(st_u["exp_avg"], (self.N, D), (D, 1))
         self.v = torch.as_strided(st_u["exp_avg_sq"], (self.N, D), (D, 1))
         new = lambda: torch.zeros((self.N_pad, D), dtype=torch.float32, device=dev)       # (pad rows stay zero)

@@ -228,6 +228,36 @@ class FusedAdam(torch.optim.Optimizer):
                     o += q.numel()
 
     @torch.no_grad()
+    def make_moments_adjacent(self, params):
+        """The Adam moments of `params` (tensors that sit back to back in one buffer) as views of ONE buffer each, in
+        that order -- what the fused steps need to update the joined table in a single epilogue.  Moments that exist
+        already (an optimizer that trained the tables separately, a loaded state_dict) are MIGRATED: copied into the
+        joint buffers and rebound, values unchanged (the fused steps used to raise on such an optimizer)."""
+        self._ensure_state(list(params))
+        ms, vs = [self.state[p]["exp_avg"] for p in params], [self.state[p]["exp_avg_sq"] for p in params]
+
+        def adjacent(ts):
+            end = ts[0].data_ptr()
+            for t in ts:
+                if t.data_ptr() != end or not t.is_contiguous():
+                    return False
+                end += t.numel() * t.element_size()
+            return True
+
+        if adjacent(ms) and adjacent(vs):
+            return
+        total = sum(p.numel() for p in params)
+        flat_m = torch.empty(total, dtype=params[0].dtype, device=params[0].device)
+        flat_v = torch.empty_like(flat_m)
+        o = 0
+        for p, m, v in zip(params, ms, vs):
+            n = p.numel()
+            flat_m[o:o + n].copy_(m.reshape(-1))
+            flat_v[o:o + n].copy_(v.reshape(-1))
+            self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"] = flat_m[o:o + n].view_as(p), flat_v[o:o + n].view_as(p)
+            o += n
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
@@ -443,7 +473,7 @@ class FusedLightGCNStep:
         uw, iw = model.user_embedding.weight, model.item_embedding.weight
         if [id(p) for p in group["params"]] != [id(uw), id(iw)]:
             raise ValueError("FusedLightGCNStep: the optimizer must hold exactly the two embedding tables")
-        optimizer._ensure_state([uw, iw])
+        optimizer.make_moments_adjacent([uw, iw])
         st_u, st_i = optimizer.state[uw], optimizer.state[iw]
         flat = model._flat
         N, D = flat.shape

@@ -197,3 +197,42 @@ def test_bpr_multi_backward_scatters_gathered_terms_itself(dev):
     for a, c in zip(ref[1:], got[1:]):
         assert torch.allclose(a, c, rtol=0, atol=2e-6 * float(a.abs().max()) + 1e-12)
     assert float(got[2].abs().sum()) > 0 and not ops._SCATTERED                  # the hand-over was consumed
+
+
+def test_fused_step_migrates_existing_adam_moments(dev):
+    """an optimizer that already holds moments in separate tensors (trained the tables before, or came out of
+    load_state_dict) used to be refused by the fused steps ("not adjacent").  FusedAdam.make_moments_adjacent copies them
+    into one buffer: a fused step built on such an optimizer continues exactly like one built on the untouched optimizer."""
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, FusedLightGCNStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B = 1500, 700, 9000, 128
+    edges = synthetic_interactions(U, I, E, seed=4)
+    rng = np.random.default_rng(0)
+    batches = []
+    for _ in range(4):
+        sel = rng.choice(E, B, replace=False)
+        batches.append((torch.from_numpy(edges[sel, 0].astype(np.int64)).to(dev), torch.from_numpy(edges[sel, 1].astype(np.int64)).to(dev),
+                        torch.from_numpy(rng.integers(U, U + I, B)).to(dev)))
+
+    def run(scatter_state):
+        torch.manual_seed(0)
+        m = LightGCN(U, I, edges, None, 64, 1e-3, 2, "add", dev).to(dev)
+        opt = FusedAdam(m.parameters(), lr=1e-2)
+        for b in batches[:2]:                          # two ordinary steps: the optimizer now has moments
+            opt.zero_grad()
+            m.loss(*b).backward()
+            opt.step()
+        if scatter_state:                              # ... and they no longer sit back to back (as after load_state_dict)
+            for p in m.parameters():
+                for k in ("exp_avg", "exp_avg_sq"):
+                    opt.state[p][k] = opt.state[p][k].clone()
+        step = FusedLightGCNStep(m, opt, batch_size=B, given_batch=True, capture=False)
+        for b in batches[2:]:
+            step(*b)
+        torch.cuda.synchronize()
+        return m._flat.detach().clone(), opt.state[m.user_embedding.weight]["exp_avg"].detach().clone()
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=0, atol=2e-6)
