@@ -236,3 +236,16 @@ def test_fused_step_migrates_existing_adam_moments(dev):
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert torch.allclose(x, y, rtol=0, atol=2e-6)
+
+
+def test_bench_sharded_path_with_rccl_on_one_rank(dev):
+    """The N > 1 code path of bench.py with RCCL itself (a 1-rank group, every exchange forced through it): the node probe
+    runs in a child job before the parent touches the GPU, the step is captured with its collectives, the line says what was
+    used."""
+    line = _run_bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--no-hbm-regime", "--no-models", "--no-cpu-baseline"],
+                      {"CHAOREC_FORCE_SHARDED": "1", "CHAOREC_FORCE_COLLECTIVES": "1"})
+    cfg = line["config"]
+    assert cfg["node_probe"]["graph"] is True and cfg["node_probe"]["stages"]["allreduce_replay"] is True
+    assert "captured hipGraph" in cfg["launch"] and "over nccl" in cfg["parallelism"]
+    assert line["multi_rank_rccl_measured"] is False and np.isfinite(line["loss_mean"])
+    assert cfg["exposed_communication"]["exchanges_per_step"] == 7
