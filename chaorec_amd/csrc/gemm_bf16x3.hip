@@ -51,10 +51,6 @@ __device__ __forceinline__ uint32_t rne_bf16_bits(float f) {
 
 // x = h + m + l exactly (finite x): three bf16 bit patterns
 __device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
-#ifdef CHAOREC_X3_EXP_NOSPLIT   // experiment (wrong numerics): what the kernels cost without the split's VALU work
-  h = m = l = __float_as_uint(x) >> 16;
-  return;
-#endif
   h = rne_bf16_bits(x);
   const float r1 = x - __uint_as_float(h << 16);
   m = rne_bf16_bits(r1);
