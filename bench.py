@@ -345,11 +345,13 @@ def time_spmm_chain(calls, min_pass_ms=10.0, passes=5):
     return float(np.median(per_launch)), tot_bytes, tot_comp
 
 
-def spmm_kernel_name(D, adam=False):
+def spmm_kernel_name(D, adam=False, rowsparse=False):
+    """<LPR, CPL, ADAM, SP> as rocprofv3 prints the instantiation."""
     d4, lpr = D // 4, 1
     while lpr < min(d4, 64):
         lpr *= 2
-    return f"spmm_csr_ordered_kernel<{lpr},{max(1, (d4 + 63) // 64)},{'true' if adam else 'false'}>"
+    return (f"spmm_csr_ordered_kernel<{lpr}, {max(1, (d4 + 63) // 64)}, {'true' if adam else 'false'}, "
+            f"{'true' if rowsparse else 'false'}>")
 
 
 def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps_rank=5, synthetic=False):
@@ -469,13 +471,25 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     whole += plain
     if use_mean:                                     # the last forward propagate with the whole layer mean in its epilogue
         whole.append((lambda: ops.spmm_mean_raw(csr, xs[-1], xs, w, fin), csr, D))
-    n_fwd_plain = len(plain)
+    # backward: g_l = A g_{l+1} + w G.  The fused step runs the first two of these launches in their ROW-SPARSE form (the batch
+    # gradient G has 3 B non-zero rows: optim.FusedLightGCNStep.sparse_bwd): they are replayed as the step issues them, over
+    # the G and the row bitmaps ONE real BPR launch leaves behind -- and they are not `plain` launches of the dense kernel
+    # (their model bytes are not the dense kernel's: the roofline below is the dense launches').
+    sparse_bwd = bool(fused and getattr(stepper, "sparse_bwd", False) and G is stepper.G)
+    if sparse_bwd:
+        ops.bpr_fwd_bwd(stepper.final, U, G, B, ops.VARIANT_LOG_SIGMOID_EPS, reg, stepper.coef, stepper.ws, stepper.ids,
+                        edges=edges_dev, hist=model.hist, num_user=U, num_item=I, seed=4242, step=7, row_bits=stepper.bits[0])
     g, alpha = G, w
-    for l in range(L - 1):                           # backward: g_l = A g_{l+1} + w G
+    for l in range(L - 1):
         y = b0 if l % 2 == 0 else b1
-        plain.append((lambda g=g, y=y, alpha=alpha: ops.spmm_raw(csr, g, y=y, alpha=alpha, z=G, beta=w), csr, D))
+        if sparse_bwd and l < 2:
+            whole.append((lambda g=g, y=y, alpha=alpha, l=l: ops.spmm_rowsparse_raw(
+                csr, g, y, alpha=alpha, z=G, beta=w, src_bits=stepper.bits[l], z_bits=stepper.bits[0],
+                out_bits=stepper.bits[1] if (l == 0 and L >= 3) else None), csr, D))
+        else:
+            plain.append((lambda g=g, y=y, alpha=alpha: ops.spmm_raw(csr, g, y=y, alpha=alpha, z=G, beta=w), csr, D))
+            whole.append(plain[-1])
         g, alpha = y, 1.0
-    whole += plain[n_fwd_plain:]
     if fused and D <= 256:                           # the last backward propagate with the Adam epilogue, on copies
         pc, mc, vc = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
         bc = torch.tensor([0.1, 0.0316], device=dev)
@@ -486,6 +500,13 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     whole_ms, _, _ = time_spmm_chain(whole, passes=3 if heavy_graph else 5)
     whole_ms *= len(whole)                           # all SpMM-family launches of ONE step, boundaries included
     n_plain, n_whole = len(plain), len(whole)
+    sparse_ms = None
+    if sparse_bwd:
+        sparse_calls = [c for c in whole if c not in plain][1 if use_mean else 0:][:min(L - 1, 2)]
+        sparse_ms, _, _ = time_spmm_chain(sparse_calls, passes=3 if heavy_graph else 5)
+        G.zero_()                                    # (the step's contract: all-zero between steps, bitmaps clear)
+        for b_ in stepper.bits:
+            b_.zero_()
     del b0, b1, fin, G, plain, whole
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
     table_mb = N * D * 4 / 1e6
@@ -512,13 +533,20 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 "launches_per_step": n_plain, "timing": CHAIN_TIMING_NOTE,
                 "spmm_launches_of_one_step": {"launches": n_whole, "us": whole_ms * 1e3,
                                               "share_of_ms_per_step": whole_ms / ms_per_step,
-                                              "what": f"the step's {n_whole} SpMM-family launches ({n_plain} plain + layer-mean "
-                                                      f"epilogue + Adam epilogue) replayed in order as one hipGraph"},
+                                              "what": f"the step's {n_whole} SpMM-family launches ({n_plain} dense plain"
+                                                      + (f" + {n_whole - n_plain - 2} row-sparse backward" if sparse_ms is not None else "")
+                                                      + " + layer-mean epilogue + Adam epilogue) replayed in order as one hipGraph"},
                 "note": ("embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is against "
                          "the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)" % table_mb)
                 if table_mb < 256 else
                 ("embedding table %.0f MB, beyond the 256 MiB Infinity Cache: HBM-bound regime; `achieved` counts the "
                  "no-reuse CSR model bytes, `traffic` (when present) the measured FETCH_SIZE+WRITE_SIZE bytes" % table_mb)}
+    if sparse_ms is not None:
+        roofline["rowsparse_backward_launches"] = {
+            "kernel": spmm_kernel_name(D, rowsparse=True), "per_step": min(L - 1, 2), "avg_launch_us": sparse_ms * 1e3,
+            "note": "the first two backward propagates gather from row-sparse operands (the batch gradient: 3 B non-zero rows; its "
+                    "1-hop image): rows whose bit in the operand's row bitmap is clear are not gathered -- the same sums bit for bit "
+                    "(chaorec_spmm_csr_rowsparse_f32); timed over the G and bitmaps one real BPR launch left"}
     if traffic:
         roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
     if kernel_only_us:

@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -36,7 +36,10 @@ SIGNATURES = {
                                                  ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr,
                                                  ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float,
                                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                                 ctypes.c_int32, c_ptr]),
+                                                 ctypes.c_int32, c_ptr, ctypes.c_int64, c_ptr, ctypes.c_int64, c_ptr]),
+    "chaorec_spmm_csr_rowsparse_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
+                                                      ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr,
+                                                      ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_bpr_fwd_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64,
                                                ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr,
                                                c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
@@ -46,7 +49,8 @@ SIGNATURES = {
                                                   ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr,
                                                   c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr,
-                                                  c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr, c_ptr]),
+                                                  c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr, c_ptr, ctypes.c_int64,
+                                                  c_ptr]),
     "chaorec_bpr_finalize_steps_f32": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                       ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                       c_ptr]),

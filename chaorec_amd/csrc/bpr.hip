@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_bwd_drawn_kernel(
     int64_t *__restrict__ out_users, int64_t *__restrict__ out_pos, int64_t *__restrict__ out_neg, int B, int D,
     int variant, float reg_weight, float *__restrict__ coef, float *__restrict__ ws, const int64_t *__restrict__ perm,
     const int64_t *__restrict__ perm_pos, float *g_u, float *g_i, int32_t *__restrict__ adam_step, float beta1,
-    float beta2, float *__restrict__ adam_bc, int64_t pos_offset) {
+    float beta2, float *__restrict__ adam_bc, int64_t pos_offset, uint32_t *row_bits, int64_t bits_item_offset) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   // the optimizer's step count and this step's bias corrections (two double pow()s on one otherwise idle thread,
@@ -159,6 +159,12 @@ __global__ __launch_bounds__(256) void bpr_fwd_bwd_drawn_kernel(
     atomicAdd(g_u + ou + k, c * (pp - nn) + r2 * uu);
     atomicAdd(g_i + op + k, c * uu + r2 * pp);
     atomicAdd(g_i + on + k, -c * uu + r2 * nn);
+  }
+  // the rows of the gradient buffer this sample touched, for the row-sparse backward propagates
+  // (chaorec_spmm_csr_rowsparse_f32): bit r of a bitmap over the joined table's rows, items from bits_item_offset on
+  if (row_bits && lane < 3) {
+    const int64_t r = lane == 0 ? u : bits_item_offset + (lane == 1 ? p : n);
+    atomicOr(row_bits + (r >> 5), 1u << (r & 31));
   }
 }
 
@@ -549,7 +555,7 @@ extern "C" int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, c
   return chaorec_bpr_fwd_bwd_at_f32(tab_u, tab_i, edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step,
                                     step_dev, in_users, in_pos, in_neg, B, D, variant, reg_weight, out_users, out_pos,
                                     out_neg, coef, workspace, perm, perm_pos, 0, g_u, g_i, adam_step, beta1, beta2, adam_bc,
-                                    stream);
+                                    nullptr, 0, stream);
 }
 
 extern "C" int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
@@ -560,7 +566,7 @@ extern "C" int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i
                                           int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
                                           const int64_t *perm, const int64_t *perm_pos, int64_t pos_offset, float *g_u,
                                           float *g_i, int32_t *adam_step, float beta1, float beta2, float *adam_bc,
-                                          void *stream) {
+                                          uint32_t *row_bits, int64_t bits_item_offset, void *stream) {
   if (!tab_u || !tab_i || !coef || !workspace || !g_u || !g_i) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: NULL argument");
   if (pos_offset < 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: pos_offset %lld", (long long)pos_offset);
   if (adam_step && !adam_bc) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: adam_step without adam_bc");
@@ -576,7 +582,7 @@ extern "C" int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i
   hipLaunchKernelGGL(bpr_fwd_bwd_drawn_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u, tab_i, edges,
                      n_edges, hist_rowptr, hist_col, num_user, (uint32_t)num_item, seed, step, step_dev, in_users, in_pos,
                      in_neg, out_users, out_pos, out_neg, B, D, variant, reg_weight, coef, workspace, perm, perm_pos, g_u,
-                     g_i, adam_step, beta1, beta2, adam_bc, pos_offset);
+                     g_i, adam_step, beta1, beta2, adam_bc, pos_offset, row_bits, bits_item_offset);
   return check_launch("bpr_fwd_bwd_drawn_kernel");
 }
 

@@ -49,14 +49,39 @@ struct AdamEpi {
   int clear_z;
 };
 
-template <int LPR, int CPL, bool ADAM>
+// Row-sparse operands (SP instantiations; the backward propagates of a BPR-trained model): the gradient a BPR batch leaves
+// in G has 3 B non-zero rows out of N, the first backward propagate's output is non-zero in their neighbours only -- most
+// gathers of those launches would fetch rows of exact zeros.  A bitmap per operand (bit r set = row r may be non-zero; a
+// superset is fine) gates the LOADS: a source row whose bit is clear is not gathered, a z row whose bit is clear is not
+// read.  The arithmetic is untouched: the skipped terms are val * (+0) = +0 added to the running sum (weights are
+// positive, cleared rows hold +0), so the result is bit-identical to the dense launch (up to the sign of an exact zero).
+// out_bits receives a superset of the output's non-zero rows (a row with any gathered source or a flagged z row; rows
+// walked by the cooperative long-row section are always flagged).  `clear`: bitmap words this launch zeroes as a side job
+// (the launch after the last reader of a bitmap cleans it for the next step; any instantiation).
+struct RowSparse {
+  const uint32_t *src_bits;
+  const uint32_t *z_bits;
+  uint32_t *out_bits;
+  uint32_t *clear[2];
+  int64_t n_clear[2];
+};
+__device__ __forceinline__ bool row_bit(const uint32_t *bits, int64_t r) { return (bits[r >> 5] >> (r & 31)) & 1u; }
+
+template <int LPR, int CPL, bool ADAM, bool SP = false>
 __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, float *__restrict__ y,
     int64_t n_rows, int D4, float alpha, const float *z, float beta,
     float *acc, const float *__restrict__ acc_init, float acc_w,
     const int32_t *__restrict__ sched, int64_t n_groups, int dyn_val, const AdamEpi ae,
-    const float *__restrict__ mean_t1, const float *__restrict__ mean_t2) {
+    const float *__restrict__ mean_t1, const float *__restrict__ mean_t2, const RowSparse sa) {
+  if (sa.clear[0] || sa.clear[1]) {        // (kernel-uniform; two short bitmaps: a few words per thread at most)
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+      if (sa.clear[w])
+        for (int64_t i = gt; i < sa.n_clear[w]; i += gs) sa.clear[w][i] = 0u;
+  }
   constexpr int NG = kWave / LPR;   // lane groups = destination rows per wave
   constexpr int UNR = CHAOREC_SPMM_UNR;  // gathered rows in flight per group (short-row phase)
   constexpr int UNR2 = (kWave / NG) < 16 ? (kWave / NG) : 16;  // per group in the long-row phase
@@ -134,6 +159,11 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   const float4 *z4 = reinterpret_cast<const float4 *>(z);
   const float4 *init4 = reinterpret_cast<const float4 *>(acc_init);
   float4 *acc4 = reinterpret_cast<float4 *>(acc);
+  bool zflag = true;            // SP: is this row of z worth reading?
+  bool any_src = !SP;           // SP: did this row gather anything (group-uniform)?
+  if constexpr (SP) {
+    if (z && sa.z_bits && row_ok) zflag = row_bit(sa.z_bits, r);
+  }
   float4 zpre[CPL], apre[CPL];
   float4 tpre[(LPR <= 16 && !ADAM) ? CPL : 1];
   float4 ppre[ADAM ? CPL : 1], mpre[ADAM ? CPL : 1], vpre[ADAM ? CPL : 1];
@@ -144,7 +174,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     apre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row_ok && chunk < D4) {
       const size_t o = (size_t)r * (size_t)D4 + chunk;
-      if (z) zpre[q] = z4[o];
+      if (z && zflag) zpre[q] = z4[o];
       if (acc) apre[q] = acc_init ? init4[o] : acc4[o];
       // whole layer mean in ONE epilogue (the last forward propagate): the earlier layers' rows ride in the slots of
       // the unused z operand and (narrow rows only: register budget) one extra slot
@@ -166,6 +196,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   const int64_t e0r = e0 + n_inl;
   int c_first = 0;
   float v_first = 0.f;
+  int b_first = 1;
   if (li < rest) {
     c_first = col[e0r + li];
     v_first = val[e0r + li];
@@ -173,33 +204,52 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   // first the entries that came with the descriptor (all in flight at once) ...
   if (sched) {
     float4 xin[kInline][CPL];
+    bool sflag[kInline];
+#pragma unroll
+    for (int j = 0; j < kInline; ++j) {
+      sflag[j] = j < deg1;
+      if constexpr (SP) {       // (the LPR lanes of a group ask for the same word: one request)
+        if (sa.src_bits && sflag[j]) sflag[j] = row_bit(sa.src_bits, icol[j]);
+        any_src = any_src || sflag[j];
+      }
+    }
+    if constexpr (SP) {         // the remainder's first block: its bits travel with the inline gathers
+      if (sa.src_bits && li < rest) b_first = row_bit(sa.src_bits, c_first) ? 1 : 0;
+    }
 #pragma unroll
     for (int j = 0; j < kInline; ++j) {
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         const int chunk = li + q * LPR;
         xin[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < deg1 && chunk < D4) xin[j][q] = x4[(size_t)icol[j] * (size_t)D4 + chunk];
+        if (sflag[j] && chunk < D4) xin[j][q] = x4[(size_t)icol[j] * (size_t)D4 + chunk];
       }
     }
 #pragma unroll
     for (int j = 0; j < kInline; ++j) {
-      if (j < deg1) {
+      if (sflag[j]) {
 #pragma unroll
         for (int q = 0; q < CPL; ++q) sum[q] = add_rn4(sum[q], mul_rn4(ival[j], xin[j][q]));
       }
     }
+  } else if constexpr (SP) {
+    if (sa.src_bits && li < rest) b_first = row_bit(sa.src_bits, c_first) ? 1 : 0;
   }
   // ... then the rest of the row from the CSR arrays, UNR source rows in flight
   for (int base = 0; base < dmax; base += LPR) {
     int c = c_first;
     float v = v_first;
+    int bt = b_first;
     if (base > 0) {
       c = 0;
       v = 0.f;
+      bt = 1;
       if (base + li < rest) {  // one coalesced (col,val) load per group, broadcast below
         c = col[e0r + base + li];
         v = val[e0r + base + li];
+        if constexpr (SP) {
+          if (sa.src_bits) bt = row_bit(sa.src_bits, c) ? 1 : 0;
+        }
       }
     }
     const int n = min(LPR, rest - base);
@@ -215,6 +265,11 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
         cj[u] = __shfl(c, src, 64);
         vj[u] = __shfl(v, src, 64);
         p[u] = (j + u) < n;
+        if constexpr (SP) {
+          const bool flagged = __shfl(bt, src, 64) != 0;      // (by every lane, before the && -- see the long-row section)
+          p[u] = p[u] && flagged;
+          any_src = any_src || p[u];
+        }
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -290,9 +345,13 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
       auto gather = [&](int k) {
         int c = 0;
         float v = 0.f;
+        int bt = 1;
         if (lane < HALF && k * HALF + lane < n) {
           c = col[le0 + k * HALF + lane];
           v = val[le0 + k * HALF + lane];
+          if constexpr (SP) {
+            if (sa.src_bits) bt = row_bit(sa.src_bits, c) ? 1 : 0;
+          }
         }
 #pragma unroll
         for (int u = 0; u < UH; ++u) {
@@ -300,7 +359,14 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
           const int cj = __shfl(c, idx, 64);
           vv[u] = __shfl(v, idx, 64);
           xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (k * HALF + idx < n && li < D4) xv[u] = x4[(size_t)cj * (size_t)D4 + li];
+          bool live = k * HALF + idx < n && li < D4;
+          if constexpr (SP) {
+            // (the shuffle FIRST, by every lane: `live && __shfl(..)` would leave the lanes that are not live out of it,
+            //  and they are other lanes' sources.  A skipped row parks v * (+0) = +0 in the tile.)
+            const bool flagged = __shfl(bt, idx, 64) != 0;
+            live = live && flagged;
+          }
+          if (live) xv[u] = x4[(size_t)cj * (size_t)D4 + li];
         }
       };
       if (wv < nchunks) gather(wv);
@@ -327,8 +393,12 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
       }
       __syncthreads();
     }
-    if (my_slot >= 0) sum[0] = long_sum[my_slot][li];
+    if (my_slot >= 0) {
+      sum[0] = long_sum[my_slot][li];
+      any_src = true;             // (a long row's gathers are not tracked: always flagged)
+    }
   } else if constexpr (NG > 1) {
+    any_src = true;               // (this path gathers without looking at the bitmap)
     unsigned long long lm = __ballot(is_long && li == 0);
     while (lm) {
       const int gl = (int)(__builtin_ctzll(lm) / LPR);
@@ -386,6 +456,9 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
   }
 
   if (!row_ok) return;
+  if constexpr (SP) {
+    if (sa.out_bits && li == 0 && (any_src || (z && zflag))) atomicOr(sa.out_bits + (r >> 5), 1u << (r & 31));
+  }
   float4 *y4 = reinterpret_cast<float4 *>(y);
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
@@ -424,7 +497,11 @@ static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *v
                        float *y, int64_t n_rows, int D4, float alpha, const float *z, float beta,
                        float *acc, const float *acc_init, float acc_w, const int32_t *sched, int dyn_val,
                        hipStream_t st, const AdamEpi *adam = nullptr, const float *mean_t1 = nullptr,
-                       const float *mean_t2 = nullptr) {
+                       const float *mean_t2 = nullptr, const RowSparse *rs = nullptr) {
+  RowSparse sa;
+  std::memset(&sa, 0, sizeof(sa));
+  if (rs) sa = *rs;
+  const bool sparse = sa.src_bits || sa.z_bits || sa.out_bits;
   constexpr int RPW = kWave / LPR;
   const int64_t waves = (n_rows + RPW - 1) / RPW;
   const int64_t blocks = (waves + 3) / 4;     // the schedule has exactly 4 * blocks wave slots
@@ -432,16 +509,25 @@ static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *v
   if (mean_t2 && LPR > 16) return fail(CHAOREC_E_INVALID, "spmm: three mean terms need D <= 64");
   if (adam) {
     if constexpr (CPL == 1) {
+      if (sparse) return fail(CHAOREC_E_INVALID, "spmm+adam: no row-sparse form (bitmaps can only be cleared here)");
       hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, true>), dim3((unsigned)blocks), dim3(256), 0, st,
                          rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
-                         waves, dyn_val, *adam, (const float *)nullptr, (const float *)nullptr);
+                         waves, dyn_val, *adam, (const float *)nullptr, (const float *)nullptr, sa);
     } else {
       return fail(CHAOREC_E_INVALID, "spmm+adam: D > 256 not built");
+    }
+  } else if (sparse) {
+    if constexpr (CPL == 1 && LPR >= 8) {      // (D = 32 .. 256: the widths the training steps use)
+      hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, false, true>), dim3((unsigned)blocks), dim3(256), 0, st,
+                         rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
+                         waves, dyn_val, AdamEpi{}, mean_t1, mean_t2, sa);
+    } else {
+      return fail(CHAOREC_E_INVALID, "spmm (row-sparse): built for 32 <= D <= 256");
     }
   } else {
     hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, false>), dim3((unsigned)blocks), dim3(256), 0, st,
                        rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
-                       waves, dyn_val, AdamEpi{}, mean_t1, mean_t2);
+                       waves, dyn_val, AdamEpi{}, mean_t1, mean_t2, sa);
   }
   return check_launch("spmm_csr_ordered_kernel");
 }
@@ -461,7 +547,7 @@ static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float 
                          int64_t n_rows, int64_t n_cols, int32_t D, float alpha, const float *z, float beta,
                          float *acc, const float *acc_init, float acc_w, const int32_t *schedule, int32_t mode,
                          void *stream, const AdamEpi *adam, const float *mean_t1 = nullptr,
-                         const float *mean_t2 = nullptr) {
+                         const float *mean_t2 = nullptr, const RowSparse *rs = nullptr) {
   if (!rowptr || !x || (!y && !acc && !adam)) return fail(CHAOREC_E_INVALID, "spmm: NULL rowptr/x or no output");
   if (n_rows < 0 || n_cols < 0) return fail(CHAOREC_E_INVALID, "spmm: negative size");
   if (D < 4 || D > 1024 || (D & 3)) return fail(CHAOREC_E_INVALID, "spmm: D=%d must be a multiple of 4 in [4,1024]", D);
@@ -471,7 +557,7 @@ static int spmm_dispatch(const int64_t *rowptr, const int32_t *col, const float 
   if (n_rows == 0) return CHAOREC_OK;
   hipStream_t st = (hipStream_t)stream;
   const int D4 = D / 4;
-#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, dyn_val, st, adam, mean_t1, mean_t2
+#define CHAOREC_SPMM_ARGS rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, schedule, dyn_val, st, adam, mean_t1, mean_t2, rs
   if (D4 <= 1) return launch_spmm<1, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 2) return launch_spmm<2, 1>(CHAOREC_SPMM_ARGS);
   if (D4 <= 4) return launch_spmm<4, 1>(CHAOREC_SPMM_ARGS);
@@ -494,6 +580,21 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
                        stream, nullptr);
 }
 
+extern "C" int chaorec_spmm_csr_rowsparse_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
+                                              float *y, int64_t n_rows, int64_t n_cols, int32_t D, float alpha, const float *z,
+                                              float beta, const int32_t *schedule, int32_t mode, const uint32_t *src_bits,
+                                              const uint32_t *z_bits, uint32_t *out_bits, void *stream) {
+  if (!y) return fail(CHAOREC_E_INVALID, "spmm (row-sparse): NULL y");
+  if (z_bits && !z) return fail(CHAOREC_E_INVALID, "spmm (row-sparse): z_bits without z");
+  RowSparse rs;
+  std::memset(&rs, 0, sizeof(rs));
+  rs.src_bits = src_bits;
+  rs.z_bits = z_bits;
+  rs.out_bits = out_bits;
+  return spmm_dispatch(rowptr, col, val, x, y, n_rows, n_cols, D, alpha, z, beta, nullptr, nullptr, 0.f, schedule, mode, stream,
+                       nullptr, nullptr, nullptr, &rs);
+}
+
 extern "C" int chaorec_spmm_csr_mean_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                                          float *y, int64_t n_rows, int64_t n_cols, int32_t D, float *mean_out,
                                          const float *const *terms, int32_t n_terms, float w, const int32_t *schedule,
@@ -511,8 +612,10 @@ extern "C" int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *c
                                          float *z, float beta, const int32_t *schedule, int32_t mode, float *param,
                                          float *exp_avg, float *exp_avg_sq, const float *bias_corr, float lr,
                                          float beta1, float beta2, float eps, float weight_decay, int32_t clear_z,
+                                         uint32_t *clear_bits_a, int64_t n_words_a, uint32_t *clear_bits_b, int64_t n_words_b,
                                          void *stream) {
   if (!param || !exp_avg || !exp_avg_sq || !bias_corr) return fail(CHAOREC_E_INVALID, "spmm+adam: NULL argument");
+  if (n_words_a < 0 || n_words_b < 0) return fail(CHAOREC_E_INVALID, "spmm+adam: negative bitmap length");
   if (D > 256) return fail(CHAOREC_E_INVALID, "spmm+adam: D=%d > 256 not built", D);
   if (clear_z && (const float *)z == x) return fail(CHAOREC_E_INVALID, "spmm+adam: clear_z while gathering from z");
   AdamEpi ae;
@@ -522,8 +625,12 @@ extern "C" int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *c
   ae.bc = bias_corr;
   ae.c = make_adam_consts(lr, beta1, beta2, eps, weight_decay);
   ae.clear_z = clear_z ? 1 : 0;
+  RowSparse rs;
+  std::memset(&rs, 0, sizeof(rs));
+  rs.clear[0] = clear_bits_a, rs.n_clear[0] = clear_bits_a ? n_words_a : 0;
+  rs.clear[1] = clear_bits_b, rs.n_clear[1] = clear_bits_b ? n_words_b : 0;
   return spmm_dispatch(rowptr, col, val, x, grad_out, n_rows, n_cols, D, alpha, z, beta, nullptr, nullptr, 0.f, schedule,
-                       mode, stream, &ae);
+                       mode, stream, &ae, nullptr, nullptr, &rs);
 }
 
 extern "C" int chaorec_spmm_rows_per_wave(int32_t D) { return rows_per_wave(D); }

@@ -106,8 +106,30 @@ def mean_terms_limit(D):
     return 3 if D <= 64 else 2
 
 
+def row_bitmap(n_rows, device):
+    """An all-clear bitmap over n_rows rows (uint32 words as int32 storage) for the row-sparse backward propagates."""
+    return torch.zeros((int(n_rows) + 31) // 32 + 1, dtype=torch.int32, device=device)
+
+
+def spmm_rowsparse_raw(csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None, out_bits=None):
+    """y = alpha * (A x) [+ beta z] for ROW-SPARSE operands (chaorec_spmm_csr_rowsparse_f32): rows of x whose bit in src_bits
+    is clear are not gathered, rows of z whose bit in z_bits is clear are not read (they hold exact zeros: the result is the
+    dense launch's, bit for bit); out_bits (all-clear on entry) receives a superset of y's non-zero rows."""
+    _need_cuda(csr.rowptr, x, y, z, src_bits, z_bits, out_bits)
+    x = _f32c(x)
+    D = x.shape[1]
+    if x.shape[0] != csr.n_cols or y.shape[0] != csr.n_rows:
+        raise ValueError("spmm_rowsparse: shape mismatch")
+    mode = 1 if getattr(csr, "dynamic_values", False) else 0
+    rc = _lib.load().chaorec_spmm_csr_rowsparse_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x), _ptr(y),
+                                                    csr.n_rows, csr.n_cols, D, alpha, _ptr(z), beta, _ptr(csr.schedule(D)),
+                                                    mode, _ptr(src_bits), _ptr(z_bits), _ptr(out_bits), _stream())
+    _lib.check(rc, "chaorec_spmm_csr_rowsparse_f32")
+    return y
+
+
 def spmm_adam_raw(csr, x, param, exp_avg, exp_avg_sq, bias_corr, lr, betas, eps, weight_decay, alpha=1.0, z=None,
-                  beta=0.0, clear_z=False, grad_out=None):
+                  beta=0.0, clear_z=False, grad_out=None, clear_bits=()):
     """g = alpha * (A x) [+ beta z] and the Adam update of `param` with that gradient, row by row, in ONE launch
     (chaorec_spmm_csr_adam_f32): the last backward propagate of a LightGCN step with optimizer.step() in its epilogue.
     `bias_corr`: device float[2] written by bpr_finalize().  clear_z: zero the non-zero rows of z after use."""
@@ -120,10 +142,14 @@ def spmm_adam_raw(csr, x, param, exp_avg, exp_avg_sq, bias_corr, lr, betas, eps,
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise TypeError("spmm_adam: param / moments must be contiguous float32")
     mode = 1 if getattr(csr, "dynamic_values", False) else 0
+    cb = (list(clear_bits) + [None, None])[:2]         # row bitmaps this (the step's last) launch zeroes as a side job
+    _need_cuda(*cb)
     rc = _lib.load().chaorec_spmm_csr_adam_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x), _ptr(grad_out),
                                                csr.n_rows, csr.n_cols, D, alpha, _ptr(z), beta, _ptr(csr.schedule(D)),
                                                mode, _ptr(param), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(bias_corr),
-                                               lr, betas[0], betas[1], eps, weight_decay, int(bool(clear_z)), _stream())
+                                               lr, betas[0], betas[1], eps, weight_decay, int(bool(clear_z)),
+                                               _ptr(cb[0]), cb[0].numel() if cb[0] is not None else 0,
+                                               _ptr(cb[1]), cb[1].numel() if cb[1] is not None else 0, _stream())
     _lib.check(rc, "chaorec_spmm_csr_adam_f32")
 
 
@@ -466,14 +492,15 @@ def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset
 
 def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg_weight, coef, ws, ids, edges=None, hist=None, num_user=0,
                 num_item=0, seed=0, step=0, step_dev=None, perm=None, perm_pos=None, adam_step=None, betas=(0.9, 0.999),
-                adam_bc=None, pos_offset=0):
+                adam_bc=None, pos_offset=0, row_bits=None):
     """BPR(+L2) forward terms and backward row adds in one launch (chaorec_bpr_fwd_bwd_f32) over ONE [N, D] table
     (items from row item_offset on) and its gradient buffer `grad` (same shape, zero where no sample lands).
     edges given: the batch is drawn in the launch and written to ids = (users, pos, neg); else ids are the batch
     (LOCAL item ids).  The loss comes from bpr_finalize(ws, ...).  adam_step / adam_bc: Adam's step counter is moved on
     and the new step's bias corrections are written by this launch.  pos_offset: added to *perm_pos (step j of a
-    replay whose finalize runs once, after its last step: step = j, pos_offset = j * B)."""
-    _need_cuda(tab, grad, coef, ws, edges, step_dev, perm, perm_pos, adam_step, adam_bc, *ids)
+    replay whose finalize runs once, after its last step: step = j, pos_offset = j * B).  row_bits (optional, ops.row_bitmap
+    over the table's rows): the rows of `grad` the launch touched are flagged for the row-sparse backward propagates."""
+    _need_cuda(tab, grad, coef, ws, edges, step_dev, perm, perm_pos, adam_step, adam_bc, row_bits, *ids)
     D = tab.shape[1]
     off = item_offset * D * 4
     ti, gi = ctypes.c_void_p(tab.data_ptr() + off), ctypes.c_void_p(grad.data_ptr() + off)
@@ -484,7 +511,8 @@ def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg_weight, coef, ws, ids, e
         int(seed) & (2**64 - 1), int(step), _ptr(step_dev), _ptr(None if draw else ids[0]), _ptr(None if draw else ids[1]),
         _ptr(None if draw else ids[2]), int(B), D, int(variant), float(reg_weight), _ptr(ids[0] if draw else None),
         _ptr(ids[1] if draw else None), _ptr(ids[2] if draw else None), _ptr(coef), _ptr(ws), _ptr(perm), _ptr(perm_pos),
-        int(pos_offset), _ptr(grad), gi, _ptr(adam_step), betas[0], betas[1], _ptr(adam_bc), _stream())
+        int(pos_offset), _ptr(grad), gi, _ptr(adam_step), betas[0], betas[1], _ptr(adam_bc), _ptr(row_bits), int(item_offset),
+        _stream())
     _lib.check(rc, "chaorec_bpr_fwd_bwd_at_f32")
 
 

@@ -498,6 +498,13 @@ class FusedLightGCNStep:
         self.static_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.bc = torch.ones(2, dtype=torch.float32, device=dev)
         self.loss_accum = loss_accum
+        # Row-sparse backward (CHAOREC_SPARSE_BACKWARD=0: off): the batch gradient G has 3 B non-zero rows, the first
+        # backward propagate's output is non-zero in their neighbours only -- the first two backward launches skip the
+        # gathers of rows whose bit is clear (same sums, bit for bit: ops.spmm_rowsparse_raw).  bits[0]: rows of G (set by
+        # the BPR launch), bits[1]: rows of the first backward propagate's output; the step's last launch clears both.
+        self.sparse_bwd = (L >= 2 and 32 <= D <= 256 and D % 4 == 0 and (D // 4) in (8, 16, 32, 64)
+                           and os.environ.get("CHAOREC_SPARSE_BACKWARD", "1") == "1")
+        self.bits = [ops.row_bitmap(N, dev), ops.row_bitmap(N, dev)] if self.sparse_bwd else None
         self.steps_per_replay = int(steps_per_replay) if (capture and edges is not None) else 1
         self.replays = 0
         self.graph = self.graph1 = None
@@ -547,6 +554,9 @@ class FusedLightGCNStep:
             for dst, src in zip(self._counters(), saved[1]):
                 dst.copy_(src)
             self.G.zero_()
+            if self.bits is not None:
+                for b in self.bits:
+                    b.zero_()
 
     @torch.no_grad()
     def _launch(self, j=0, k=1):
@@ -561,7 +571,7 @@ class FusedLightGCNStep:
                         ws, self.ids, edges=self.edges, hist=model.hist if draw else None, num_user=model.num_user,
                         num_item=model.num_item, seed=self.seed, step=j, step_dev=self.step_dev, perm=self.perm,
                         perm_pos=self.perm_pos, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc,
-                        pos_offset=j * B)
+                        pos_offset=j * B, row_bits=self.bits[0] if self.sparse_bwd else None)
         book = dict(out_total=self.static_loss, loss_accum=self.loss_accum, advance=self.step_dev if draw else None,
                     perm_pos=self.perm_pos if (draw and self.perm is not None) else None)
         if k == 1:
@@ -571,10 +581,16 @@ class FusedLightGCNStep:
         g, alpha = self.G, w                    # g_{L-1} = w (A G) + w G, then g_l = A g_{l+1} + w G
         for l in range(L - 1):
             y = self.buf[l & 1]
-            ops.spmm_raw(csr, g, y=y, alpha=alpha, z=self.G, beta=w)
+            if self.sparse_bwd and l < 2:
+                # g is G itself (l = 0: its rows are flagged in bits[0]) or the first propagate's output (bits[1])
+                ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=self.G, beta=w, src_bits=self.bits[l], z_bits=self.bits[0],
+                                       out_bits=self.bits[1] if (l == 0 and L >= 3) else None)
+            else:
+                ops.spmm_raw(csr, g, y=y, alpha=alpha, z=self.G, beta=w)
             g, alpha = y, 1.0
         ops.spmm_adam_raw(csr, g, x0, self.m, self.v, self.bc, group["lr"], group["betas"], group["eps"],
-                          group["weight_decay"], alpha=alpha, z=self.G, beta=w, clear_z=L >= 2)
+                          group["weight_decay"], alpha=alpha, z=self.G, beta=w, clear_z=L >= 2,
+                          clear_bits=self.bits if self.sparse_bwd else ())
         if L < 2:
             self.G.zero_()                      # (the single backward SpMM gathers from G: it cannot clear it)
         model.result = self.final

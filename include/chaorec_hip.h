@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 10  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 11  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -40,7 +40,9 @@ extern "C" {
                                   9: split-bf16 NN GEMM (input gradients, accumulate epilogue), MMGCN's layer tail
                                      (leaky_cat_add / leaky_split_bwd), normalize_rows, multi-term BPR, draw_batch item_offset, shift_cat,
                                      peer-to-peer exchange kernels;
-                                  10: multi-term BPR backward scatters the gradient of gathered row blocks itself */
+                                  10: multi-term BPR backward scatters the gradient of gathered row blocks itself;
+                                  11: row-sparse backward propagates (row bitmaps written by the BPR launch, read by
+                                      chaorec_spmm_csr_rowsparse_f32, cleared by chaorec_spmm_csr_adam_f32) */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -109,12 +111,28 @@ int chaorec_spmm_csr_mean_f32(const int64_t *rowptr, const int32_t *col, const f
  * clear_z != 0: every row of z that was non-zero is zeroed after it was read -- z is then the batch gradient buffer
  * that chaorec_bpr_fwd_bwd_f32 adds into, kept all-zero between steps instead of being zero-filled every step
  * (refused when x == z: another wave could still gather the row).  D <= 256. */
+/* clear_bits_a / _b (optional, n_words_* uint32 words each): row bitmaps of the row-sparse propagates below that this
+ * launch zeroes as a side job -- it is the step's last launch, every reader of the step's bitmaps is done. */
 int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                               float *grad_out, int64_t n_rows, int64_t n_cols, int32_t D, float alpha,
                               float *z, float beta, const int32_t *schedule, int32_t mode, float *param,
                               float *exp_avg, float *exp_avg_sq, const float *bias_corr, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int32_t clear_z,
+                              uint32_t *clear_bits_a, int64_t n_words_a, uint32_t *clear_bits_b, int64_t n_words_b,
                               void *stream);
+
+/* A backward propagate whose operands are ROW-SPARSE (train_and_evaluate.py:46 loss.backward() through
+ * Model/LightGCN.py:81-83 for a BPR batch): the batch gradient G has 3 B non-zero rows out of N, the first backward
+ * propagate's result is non-zero in their neighbours only.  Same arithmetic, entry order and result as
+ * chaorec_spmm_csr_f32's  y = alpha (A x) + beta z  (bit for bit, up to the sign of an exact zero); the bitmaps only gate
+ * LOADS: a source row whose bit in src_bits is clear is not gathered (its term is val * (+0)), a row of z whose bit in
+ * z_bits is clear is not read.  A set bit means "may be non-zero": supersets are fine.  out_bits (optional, all-zero on
+ * entry) receives such a superset for y.  Bitmaps: uint32 words, bit r & 31 of word r >> 5; any of the three may be NULL.
+ * 32 <= D <= 256. */
+int chaorec_spmm_csr_rowsparse_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
+                                   float *y, int64_t n_rows, int64_t n_cols, int32_t D, float alpha, const float *z,
+                                   float beta, const int32_t *schedule, int32_t mode, const uint32_t *src_bits,
+                                   const uint32_t *z_bits, uint32_t *out_bits, void *stream);
 
 /* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
 int chaorec_spmm_rows_per_wave(int32_t D);
@@ -253,7 +271,9 @@ int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i, const int
                                int64_t *out_pos, int64_t *out_neg, float *coef, float *workspace,
                                const int64_t *perm, const int64_t *perm_pos, int64_t pos_offset, float *g_u,
                                float *g_i, int32_t *adam_step, float beta1, float beta2, float *adam_bc,
-                               void *stream);
+                               uint32_t *row_bits, int64_t bits_item_offset, void *stream);
+/* (row_bits, optional: bit u, bit bits_item_offset + pos, bit bits_item_offset + neg of every sample are set -- the
+ *  rows of the gradient buffer the launch touched, for chaorec_spmm_csr_rowsparse_f32) */
 int chaorec_bpr_finalize_steps_f32(const float *workspace, int64_t ws_stride, int32_t n_steps, int32_t B,
                                    int32_t D, float reg_weight, float *out_loss, float *out_total,
                                    float *loss_accum, int64_t *advance, int64_t *perm_pos, void *stream);

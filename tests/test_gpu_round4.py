@@ -249,3 +249,104 @@ def test_bench_sharded_path_with_rccl_on_one_rank(dev):
     assert "captured hipGraph" in cfg["launch"] and "over nccl" in cfg["parallelism"]
     assert line["multi_rank_rccl_measured"] is False and np.isfinite(line["loss_mean"])
     assert cfg["exposed_communication"]["exchanges_per_step"] == 7
+
+
+def _bits_to_rows(bits, n):
+    w = bits.cpu().numpy().view(np.uint32)
+    return np.nonzero(np.unpackbits(w.view(np.uint8), bitorder="little")[:n])[0]
+
+
+@pytest.mark.parametrize("D", [32, 64, 128, 256])
+def test_rowsparse_spmm_equals_the_dense_launch_bit_for_bit(dev, D):
+    """chaorec_spmm_csr_rowsparse_f32: with the source's (and z's) non-zero rows flagged in bitmaps, the launch skips the
+    gathers of unflagged rows and gives the dense launch's bits; out_bits is a superset of the output's non-zero rows; the
+    chain source -> output -> next launch (the first two backward propagates of a training step) stays exact.  Heavy-tailed
+    graph: inline entries, the remainder loop and the cooperative long-row walk are all on the path."""
+    from chaorec_amd import graph, ops
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E = 3000, 900, 30000                              # (item degrees up to several hundred: long rows)
+    edges = synthetic_interactions(U, I, E, seed=11)
+    N = U + I
+    csr = graph.lightgcn_csr(edges, N).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(D)
+    rows = torch.randperm(N, device=dev, generator=gen)[:200]
+    G = torch.zeros(N, D, device=dev)
+    G[rows] = torch.randn(200, D, device=dev, generator=gen)
+    bits0 = ops.row_bitmap(N, dev)
+    w = bits0.cpu().numpy().view(np.uint32)
+    for r in rows.cpu().tolist():
+        w[r >> 5] |= np.uint32(1 << (r & 31))
+    bits0.copy_(torch.from_numpy(w.view(np.int32)))
+    dense1 = ops.spmm_raw(csr, G, alpha=0.25, z=G, beta=0.25)
+    bits1 = ops.row_bitmap(N, dev)
+    y1 = torch.full((N, D), 7.0, device=dev)                 # (stale contents: every row must be written)
+    ops.spmm_rowsparse_raw(csr, G, y1, alpha=0.25, z=G, beta=0.25, src_bits=bits0, z_bits=bits0, out_bits=bits1)
+    assert torch.equal(y1, dense1)
+    nz = torch.nonzero(dense1.abs().sum(1) > 0).flatten().cpu().numpy()
+    flagged = _bits_to_rows(bits1, N)
+    assert np.isin(nz, flagged).all()                        # a superset ...
+    assert len(flagged) < N or D < 64                        # ... and a real restriction (D = 32 takes the path that flags every row)
+    dense2 = ops.spmm_raw(csr, dense1, z=G, beta=0.25)
+    y2 = torch.full((N, D), -3.0, device=dev)
+    ops.spmm_rowsparse_raw(csr, y1, y2, z=G, beta=0.25, src_bits=bits1, z_bits=bits0)
+    assert torch.equal(y2, dense2)
+    # no bitmaps at all = the dense launch; src bitmap only / z bitmap only
+    y3 = torch.empty((N, D), device=dev)
+    ops.spmm_rowsparse_raw(csr, G, y3, alpha=0.25, z=G, beta=0.25, src_bits=bits0)
+    assert torch.equal(y3, dense1)
+    ops.spmm_rowsparse_raw(csr, G, y3, alpha=0.25, z=G, beta=0.25, z_bits=bits0)
+    assert torch.equal(y3, dense1)
+
+
+def test_fused_step_with_the_rowsparse_backward_trains_like_the_dense_one(dev, monkeypatch):
+    """optim.FusedLightGCNStep with the first two backward propagates in their row-sparse form (the BPR launch flags the
+    rows of the batch gradient, the Adam launch clears the bitmaps): the same batches give the same tables as the dense
+    backward up to the order of the BPR launch's atomic adds, eager and captured, and the bitmaps are clean after a step."""
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, FusedLightGCNStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B = 4000, 1500, 30000, 256
+    edges = synthetic_interactions(U, I, E, seed=5)
+    rng = np.random.default_rng(1)
+    batches = []
+    for _ in range(5):
+        sel = rng.choice(E, B, replace=False)
+        batches.append((torch.from_numpy(edges[sel, 0].astype(np.int64)).to(dev), torch.from_numpy(edges[sel, 1].astype(np.int64)).to(dev),
+                        torch.from_numpy(rng.integers(U, U + I, B)).to(dev)))
+
+    def run(sparse, capture):
+        monkeypatch.setenv("CHAOREC_SPARSE_BACKWARD", "1" if sparse else "0")
+        torch.manual_seed(0)
+        m = LightGCN(U, I, edges, None, 64, 1e-3, 3, "add", dev).to(dev)
+        step = FusedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=capture)
+        assert step.sparse_bwd == sparse
+        losses = [float(step(*b)) for b in batches]
+        torch.cuda.synchronize()
+        if sparse:
+            assert int(step.bits[0].abs().sum()) == 0 and int(step.bits[1].abs().sum()) == 0
+            assert float(step.G.abs().max()) == 0.0
+        return m._flat.detach().clone(), losses
+
+    ref, ref_losses = run(False, False)
+    for capture in (False, True):
+        got, losses = run(True, capture)
+        d = (got - ref).abs()
+        assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7, (capture, float(d.max()))
+        assert np.allclose(losses, ref_losses, rtol=1e-5)
+
+
+def test_bpr_launch_flags_exactly_the_rows_it_touched(dev):
+    from chaorec_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(2)
+    U, I, D, B = 700, 500, 64, 128
+    tab = torch.randn(U + I, D, device=dev, generator=gen) * 0.1
+    G = torch.zeros_like(tab)
+    ids = (torch.randint(0, U, (B,), device=dev, generator=gen), torch.randint(0, I, (B,), device=dev, generator=gen),
+           torch.randint(0, I, (B,), device=dev, generator=gen))
+    bits = ops.row_bitmap(U + I, dev)
+    ops.bpr_fwd_bwd(tab, U, G, B, ops.VARIANT_LOG_SIGMOID_EPS, 1e-3, torch.empty(B, device=dev), torch.empty(4 * B, device=dev), ids,
+                    row_bits=bits)
+    torch.cuda.synchronize()
+    want = np.unique(np.concatenate([ids[0].cpu().numpy(), U + ids[1].cpu().numpy(), U + ids[2].cpu().numpy()]))
+    assert np.array_equal(_bits_to_rows(bits, U + I), want)
+    assert np.array_equal(torch.nonzero(G.abs().sum(1) > 0).flatten().cpu().numpy(), want)

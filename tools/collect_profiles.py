@@ -94,12 +94,16 @@ def main():
                 w.writerow(["Kernel_Name", "Launches", f"{counter}_KB_mean"])
                 for k, (n, v) in sorted(m.items(), key=lambda kv: -kv[1][1] * kv[1][0]):
                     w.writerow([k, n, f"{v:.3f}"])
-        plain = [k for k in means["FETCH_SIZE"] if "spmm_csr_ordered_kernel" in k and "false" in k]
+        # the DENSE plain instantiation <LPR, CPL, ADAM = false, SP = false> (the row-sparse backward form is <.., false, true>)
+        def is_plain(name):
+            args = name.split("<")[1].split(">")[0].replace(" ", "").split(",") if "<" in name else []
+            return "spmm_csr_ordered_kernel" in name and args[2:3] == ["false"] and args[3:4] in ([], ["false"])
+        plain = [k for k in means["FETCH_SIZE"] if is_plain(k)]
         if not plain:
             raise SystemExit("SpMM kernel not in counter output: " + ", ".join(means["FETCH_SIZE"]))
         k = plain[0]
         fetch_kb, write_kb = means["FETCH_SIZE"][k][1], means["WRITE_SIZE"][k][1]
-        avg = [float(r["AverageNs"]) for n, r in stats.items() if "spmm_csr_ordered_kernel" in n and "false" in n]
+        avg = [float(r["AverageNs"]) for n, r in stats.items() if is_plain(n)]
         traffic = {
             "kernel": k.split("(")[0], "workload": line["config"]["workload"],
             "launches_averaged": means["FETCH_SIZE"][k][0],
