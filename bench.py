@@ -483,9 +483,11 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     for l in range(L - 1):
         y = b0 if l % 2 == 0 else b1
         if sparse_bwd and l < 2:
-            whole.append((lambda g=g, y=y, alpha=alpha, l=l: ops.spmm_rowsparse_raw(
-                csr, g, y, alpha=alpha, z=G, beta=w, src_bits=stepper.bits[l], z_bits=stepper.bits[0],
-                out_bits=stepper.bits[1] if (l == 0 and L >= 3) else None), csr, D))
+            next_sparse = (l + 1 < L - 1) and (l + 1 < 2)
+            whole.append((lambda g=g, y=y, alpha=alpha, l=l, ns=next_sparse: (
+                ops.expand_row_bits(csr, stepper.bits[l], stepper.bits[l + 1]),
+                ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=G, beta=w, src_bits=stepper.bits[l], z_bits=stepper.bits[0],
+                                       row_bits=stepper.bits[l + 1], write_zeros=not ns)), csr, D))
         else:
             plain.append((lambda g=g, y=y, alpha=alpha: ops.spmm_raw(csr, g, y=y, alpha=alpha, z=G, beta=w), csr, D))
             whole.append(plain[-1])
@@ -505,8 +507,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         sparse_calls = [c for c in whole if c not in plain][1 if use_mean else 0:][:min(L - 1, 2)]
         sparse_ms, _, _ = time_spmm_chain(sparse_calls, passes=3 if heavy_graph else 5)
         G.zero_()                                    # (the step's contract: all-zero between steps, bitmaps clear)
-        for b_ in stepper.bits:
-            b_.zero_()
+        stepper._bits_all.zero_()
     del b0, b1, fin, G, plain, whole
     achieved = model_bytes / (avg_spmm_ms * 1e-3) / 1e9
     table_mb = N * D * 4 / 1e6
@@ -544,9 +545,10 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     if sparse_ms is not None:
         roofline["rowsparse_backward_launches"] = {
             "kernel": spmm_kernel_name(D, rowsparse=True), "per_step": min(L - 1, 2), "avg_launch_us": sparse_ms * 1e3,
-            "note": "the first two backward propagates gather from row-sparse operands (the batch gradient: 3 B non-zero rows; its "
-                    "1-hop image): rows whose bit in the operand's row bitmap is clear are not gathered -- the same sums bit for bit "
-                    "(chaorec_spmm_csr_rowsparse_f32); timed over the G and bitmaps one real BPR launch left"}
+            "note": "the first two backward propagates work on row-sparse operands (the batch gradient: 3 B non-zero rows; its 1-hop "
+                    "image): output rows outside the frontier walk no entries, inside it only flagged source rows are gathered -- "
+                    "the same sums bit for bit (chaorec_expand_row_bits + chaorec_spmm_csr_rowsparse_f32; avg_launch_us = one "
+                    "such pair); timed over the G and bitmaps one real BPR launch left"}
     if traffic:
         roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
     if kernel_only_us:

@@ -62,6 +62,12 @@ struct RowSparse {
   const uint32_t *src_bits;
   const uint32_t *z_bits;
   uint32_t *out_bits;
+  // row_bits: which OUTPUT rows can be non-zero at all (a superset: the 1-hop image of the source's rows, computed by
+  // chaorec_expand_row_bits from the few flagged rows instead of by scanning every entry).  A row whose bit is clear -- and
+  // whose z row is not flagged -- does nothing: no entry scan, no gathers; it stores zeros when write_zeros is set (the
+  // next launch reads y densely) and nothing at all otherwise (the next launch gathers from flagged rows only).
+  const uint32_t *row_bits;
+  int write_zeros;
   uint32_t *clear[2];
   int64_t n_clear[2];
 };
@@ -143,6 +149,13 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     }
   }
   const bool row_ok = r >= 0;
+  bool active = true;           // SP: can this output row be non-zero?
+  if constexpr (SP) {
+    if (sa.row_bits && row_ok) {
+      active = row_bit(sa.row_bits, r) || (z && sa.z_bits && row_bit(sa.z_bits, r));
+      if (!active) deg = 0;     // (no entries to walk: the row's sum is the empty sum)
+    }
+  }
   const bool is_long = (NG > 1) && deg > LONG_T;
   const int deg1 = is_long ? 0 : deg;
   const int rest = max(deg1 - n_inl, 0);            // entries still to be fetched from the CSR arrays
@@ -467,7 +480,11 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     const size_t o = (size_t)r * (size_t)D4 + chunk;
     float4 s = mul_rn4(alpha, sum[q]);
     if (z) s = add_rn4(s, mul_rn4(beta, zpre[q]));
-    if (y) y4[o] = s;
+    if constexpr (SP) {
+      if (y && (active || sa.write_zeros)) y4[o] = s;       // (an inactive row: s = +0)
+    } else {
+      if (y) y4[o] = s;
+    }
     if (acc) {
       float4 a0 = acc_init ? mul_rn4(acc_w, apre[q]) : apre[q];
       if (mean_t1) a0 = add_rn4(a0, mul_rn4(acc_w, zpre[q]));
@@ -501,7 +518,7 @@ static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *v
   RowSparse sa;
   std::memset(&sa, 0, sizeof(sa));
   if (rs) sa = *rs;
-  const bool sparse = sa.src_bits || sa.z_bits || sa.out_bits;
+  const bool sparse = sa.src_bits || sa.z_bits || sa.out_bits || sa.row_bits;
   constexpr int RPW = kWave / LPR;
   const int64_t waves = (n_rows + RPW - 1) / RPW;
   const int64_t blocks = (waves + 3) / 4;     // the schedule has exactly 4 * blocks wave slots
@@ -583,14 +600,18 @@ extern "C" int chaorec_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, c
 extern "C" int chaorec_spmm_csr_rowsparse_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                                               float *y, int64_t n_rows, int64_t n_cols, int32_t D, float alpha, const float *z,
                                               float beta, const int32_t *schedule, int32_t mode, const uint32_t *src_bits,
-                                              const uint32_t *z_bits, uint32_t *out_bits, void *stream) {
+                                              const uint32_t *z_bits, uint32_t *out_bits, const uint32_t *row_bits,
+                                              int32_t write_zeros, void *stream) {
   if (!y) return fail(CHAOREC_E_INVALID, "spmm (row-sparse): NULL y");
   if (z_bits && !z) return fail(CHAOREC_E_INVALID, "spmm (row-sparse): z_bits without z");
+  if (row_bits && z && !z_bits) return fail(CHAOREC_E_INVALID, "spmm (row-sparse): row_bits with an unflagged z");
   RowSparse rs;
   std::memset(&rs, 0, sizeof(rs));
   rs.src_bits = src_bits;
   rs.z_bits = z_bits;
   rs.out_bits = out_bits;
+  rs.row_bits = row_bits;
+  rs.write_zeros = write_zeros ? 1 : 0;
   return spmm_dispatch(rowptr, col, val, x, y, n_rows, n_cols, D, alpha, z, beta, nullptr, nullptr, 0.f, schedule, mode, stream,
                        nullptr, nullptr, nullptr, &rs);
 }
@@ -631,6 +652,47 @@ extern "C" int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *c
   rs.clear[1] = clear_bits_b, rs.n_clear[1] = clear_bits_b ? n_words_b : 0;
   return spmm_dispatch(rowptr, col, val, x, grad_out, n_rows, n_cols, D, alpha, z, beta, nullptr, nullptr, 0.f, schedule,
                        mode, stream, &ae, nullptr, nullptr, &rs);
+}
+
+namespace chaorec {
+// bits_out |= bits_in | { c : A[r, c] != 0 for some r flagged in bits_in }: the rows a propagate over a SYMMETRIC graph can
+// make non-zero when its source is non-zero in the flagged rows only (a frontier expansion: work ~ the flagged rows'
+// entries, not the graph's).  One wave per pair of bitmap words; a flagged row's entries are walked by the whole wave.
+__global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                              int64_t n_rows, const uint32_t *__restrict__ bits_in,
+                                                              uint32_t *bits_out, int64_t n_words) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  for (int k = 0; k < 2; ++k) {
+    const int64_t wi = 2 * wave + k;
+    if (wi >= n_words) return;
+    uint32_t word = bits_in[wi];          // wave-uniform
+    if (word == 0u) continue;
+    if (lane == 0) atomicOr(bits_out + wi, word);
+    while (word) {
+      const int b = __builtin_ctz(word);
+      word &= word - 1;
+      const int64_t r = wi * 32 + b;
+      if (r >= n_rows) break;
+      const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
+      for (int64_t e = e0 + lane; e < e1; e += 64) {
+        const int c = col[e];
+        atomicOr(bits_out + (c >> 5), 1u << (c & 31));
+      }
+    }
+  }
+}
+}  // namespace chaorec
+
+extern "C" int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col, int64_t n_rows, const uint32_t *bits_in,
+                                       uint32_t *bits_out, void *stream) {
+  if (!rowptr || !col || !bits_in || !bits_out) return fail(CHAOREC_E_INVALID, "expand_row_bits: NULL argument");
+  if (n_rows <= 0) return fail(CHAOREC_E_INVALID, "expand_row_bits: n_rows=%lld", (long long)n_rows);
+  const int64_t n_words = (n_rows + 31) / 32;
+  const int64_t waves = (n_words + 1) / 2;
+  hipLaunchKernelGGL(expand_row_bits_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, col,
+                     n_rows, bits_in, bits_out, n_words);
+  return check_launch("expand_row_bits_kernel");
 }
 
 extern "C" int chaorec_spmm_rows_per_wave(int32_t D) { return rows_per_wave(D); }

@@ -111,11 +111,25 @@ def row_bitmap(n_rows, device):
     return torch.zeros((int(n_rows) + 31) // 32 + 1, dtype=torch.int32, device=device)
 
 
-def spmm_rowsparse_raw(csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None, out_bits=None):
+def expand_row_bits(csr, bits_in, bits_out):
+    """bits_out |= bits_in | {columns of the rows flagged in bits_in} (chaorec_expand_row_bits; symmetric graphs): the rows the
+    next propagate can make non-zero.  Work ~ the flagged rows' entries."""
+    _need_cuda(csr.rowptr, bits_in, bits_out)
+    if not csr.symmetric:
+        raise ValueError("expand_row_bits: the graph must be its own transpose")
+    _lib.check(_lib.load().chaorec_expand_row_bits(_ptr(csr.rowptr), _ptr(csr.col), csr.n_rows, _ptr(bits_in), _ptr(bits_out),
+                                                   _stream()), "chaorec_expand_row_bits")
+    return bits_out
+
+
+def spmm_rowsparse_raw(csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None, out_bits=None, row_bits=None,
+                       write_zeros=True):
     """y = alpha * (A x) [+ beta z] for ROW-SPARSE operands (chaorec_spmm_csr_rowsparse_f32): rows of x whose bit in src_bits
     is clear are not gathered, rows of z whose bit in z_bits is clear are not read (they hold exact zeros: the result is the
-    dense launch's, bit for bit); out_bits (all-clear on entry) receives a superset of y's non-zero rows."""
-    _need_cuda(csr.rowptr, x, y, z, src_bits, z_bits, out_bits)
+    dense launch's, bit for bit); out_bits (all-clear on entry) receives a superset of y's non-zero rows.  row_bits: a
+    superset of the rows of y that can be non-zero (expand_row_bits of src_bits): the others walk no entries and store zeros
+    (write_zeros) or nothing (write_zeros=False: only when every later reader of y gathers flagged rows only)."""
+    _need_cuda(csr.rowptr, x, y, z, src_bits, z_bits, out_bits, row_bits)
     x = _f32c(x)
     D = x.shape[1]
     if x.shape[0] != csr.n_cols or y.shape[0] != csr.n_rows:
@@ -123,7 +137,8 @@ def spmm_rowsparse_raw(csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_
     mode = 1 if getattr(csr, "dynamic_values", False) else 0
     rc = _lib.load().chaorec_spmm_csr_rowsparse_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x), _ptr(y),
                                                     csr.n_rows, csr.n_cols, D, alpha, _ptr(z), beta, _ptr(csr.schedule(D)),
-                                                    mode, _ptr(src_bits), _ptr(z_bits), _ptr(out_bits), _stream())
+                                                    mode, _ptr(src_bits), _ptr(z_bits), _ptr(out_bits), _ptr(row_bits),
+                                                    int(bool(write_zeros)), _stream())
     _lib.check(rc, "chaorec_spmm_csr_rowsparse_f32")
     return y
 

@@ -498,13 +498,22 @@ class FusedLightGCNStep:
         self.static_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.bc = torch.ones(2, dtype=torch.float32, device=dev)
         self.loss_accum = loss_accum
-        # Row-sparse backward (CHAOREC_SPARSE_BACKWARD=0: off): the batch gradient G has 3 B non-zero rows, the first
-        # backward propagate's output is non-zero in their neighbours only -- the first two backward launches skip the
-        # gathers of rows whose bit is clear (same sums, bit for bit: ops.spmm_rowsparse_raw).  bits[0]: rows of G (set by
-        # the BPR launch), bits[1]: rows of the first backward propagate's output; the step's last launch clears both.
-        self.sparse_bwd = (L >= 2 and 32 <= D <= 256 and D % 4 == 0 and (D // 4) in (8, 16, 32, 64)
-                           and os.environ.get("CHAOREC_SPARSE_BACKWARD", "1") == "1")
-        self.bits = [ops.row_bitmap(N, dev), ops.row_bitmap(N, dev)] if self.sparse_bwd else None
+        # Row-sparse backward.  The batch gradient G has 3 B non-zero rows R0 out of N; g_{L-1} = w (A G) + w G is non-zero in
+        # N1 = R0 + nbr(R0) only, g_{L-2} in N2 = nbr(N1).  The first two backward launches therefore run in their
+        # row-sparse form (ops.spmm_rowsparse_raw: same sums, bit for bit): output rows outside the frontier walk no entries,
+        # inside it only flagged source rows are gathered.  bits[0] = R0 (set by the BPR launch), bits[1] = N1, bits[2] = N2
+        # (ops.expand_row_bits: work ~ the frontier's entries); the step's last launch clears all three.  It pays where the
+        # frontier is a small part of the graph -- BASELINE configs[4]: 12 M rows, N1 ~ 2 % of them -- and costs two small
+        # launches where it is not (sports: N2 is the whole graph), hence by size.  CHAOREC_SPARSE_BACKWARD=0 / 1: off / forced.
+        mode = os.environ.get("CHAOREC_SPARSE_BACKWARD", "auto")
+        wide_ok = L >= 2 and D % 4 == 0 and (D // 4) in (16, 32, 64)
+        self.sparse_bwd = wide_ok and mode != "0" and (mode == "1" or N >= int(os.environ.get("CHAOREC_SPARSE_BACKWARD_MIN_ROWS",
+                                                                                              "400000")))
+        self.bits = None
+        if self.sparse_bwd:
+            words = (N + 31) // 32 + 1
+            self._bits_all = torch.zeros(3 * words, dtype=torch.int32, device=dev)
+            self.bits = [self._bits_all[k * words:(k + 1) * words] for k in range(3)]
         self.steps_per_replay = int(steps_per_replay) if (capture and edges is not None) else 1
         self.replays = 0
         self.graph = self.graph1 = None
@@ -555,8 +564,7 @@ class FusedLightGCNStep:
                 dst.copy_(src)
             self.G.zero_()
             if self.bits is not None:
-                for b in self.bits:
-                    b.zero_()
+                self._bits_all.zero_()
 
     @torch.no_grad()
     def _launch(self, j=0, k=1):
@@ -582,15 +590,19 @@ class FusedLightGCNStep:
         for l in range(L - 1):
             y = self.buf[l & 1]
             if self.sparse_bwd and l < 2:
-                # g is G itself (l = 0: its rows are flagged in bits[0]) or the first propagate's output (bits[1])
+                # l = 0: g is G itself (rows R0 = bits[0]), output rows N1 = bits[1]; l = 1: g = that output, output rows N2.
+                # Rows outside the frontier are left unwritten while the NEXT launch is row-sparse too (it gathers flagged
+                # rows only); the last row-sparse launch writes them as zeros for its dense reader.
+                ops.expand_row_bits(csr, self.bits[l], self.bits[l + 1])
+                next_sparse = (l + 1 < L - 1) and (l + 1 < 2)
                 ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=self.G, beta=w, src_bits=self.bits[l], z_bits=self.bits[0],
-                                       out_bits=self.bits[1] if (l == 0 and L >= 3) else None)
+                                       row_bits=self.bits[l + 1], write_zeros=not next_sparse)
             else:
                 ops.spmm_raw(csr, g, y=y, alpha=alpha, z=self.G, beta=w)
             g, alpha = y, 1.0
         ops.spmm_adam_raw(csr, g, x0, self.m, self.v, self.bc, group["lr"], group["betas"], group["eps"],
                           group["weight_decay"], alpha=alpha, z=self.G, beta=w, clear_z=L >= 2,
-                          clear_bits=self.bits if self.sparse_bwd else ())
+                          clear_bits=(self._bits_all,) if self.sparse_bwd else ())
         if L < 2:
             self.G.zero_()                      # (the single backward SpMM gathers from G: it cannot clear it)
         model.result = self.final

@@ -129,10 +129,21 @@ int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *col, const f
  * z_bits is clear is not read.  A set bit means "may be non-zero": supersets are fine.  out_bits (optional, all-zero on
  * entry) receives such a superset for y.  Bitmaps: uint32 words, bit r & 31 of word r >> 5; any of the three may be NULL.
  * 32 <= D <= 256. */
+/* row_bits (optional): a superset of the rows of y that can be non-zero -- normally chaorec_expand_row_bits of src_bits.
+ * A row whose bit is clear (and whose z row is not flagged) walks no entries at all; it stores zeros when write_zeros != 0
+ * (the next launch reads y densely) and nothing otherwise (the next launch gathers flagged rows only).  Per-entry bitmap
+ * tests alone leave such a launch at ~80 % of the dense one (a 4-byte L2 request per entry instead of a row gather); with
+ * the row mask its cost follows the frontier, not the graph. */
 int chaorec_spmm_csr_rowsparse_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x,
                                    float *y, int64_t n_rows, int64_t n_cols, int32_t D, float alpha, const float *z,
                                    float beta, const int32_t *schedule, int32_t mode, const uint32_t *src_bits,
-                                   const uint32_t *z_bits, uint32_t *out_bits, void *stream);
+                                   const uint32_t *z_bits, uint32_t *out_bits, const uint32_t *row_bits,
+                                   int32_t write_zeros, void *stream);
+
+/* bits_out |= bits_in | {columns of the rows flagged in bits_in}: for a SYMMETRIC graph, the rows a propagate can make
+ * non-zero when its source is non-zero in the flagged rows only.  Work ~ the flagged rows' entries. */
+int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col, int64_t n_rows, const uint32_t *bits_in,
+                            uint32_t *bits_out, void *stream);
 
 /* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
 int chaorec_spmm_rows_per_wave(int32_t D);

@@ -290,6 +290,24 @@ def test_rowsparse_spmm_equals_the_dense_launch_bit_for_bit(dev, D):
     y2 = torch.full((N, D), -3.0, device=dev)
     ops.spmm_rowsparse_raw(csr, y1, y2, z=G, beta=0.25, src_bits=bits1, z_bits=bits0)
     assert torch.equal(y2, dense2)
+    # the frontier form the fused step uses: row masks from expand_row_bits (N1 = R0 + nbr(R0), N2 = nbr(N1)); rows outside a
+    # mask walk no entries -- left unwritten (first launch: its only reader gathers flagged rows) or written as zeros (second)
+    n1, n2 = ops.row_bitmap(N, dev), ops.row_bitmap(N, dev)
+    ops.expand_row_bits(csr, bits0, n1)
+    ops.expand_row_bits(csr, n1, n2)
+    r0, r1, r2 = _bits_to_rows(bits0, N), _bits_to_rows(n1, N), _bits_to_rows(n2, N)
+    rp, cl = csr.rowptr.cpu().numpy(), csr.col.cpu().numpy()
+    want1 = np.unique(np.concatenate([r0] + [cl[rp[r]:rp[r + 1]] for r in r0]))
+    want2 = np.unique(np.concatenate([r1] + [cl[rp[r]:rp[r + 1]] for r in r1]))
+    assert np.array_equal(r1, want1) and np.array_equal(r2, want2) and np.isin(nz, r1).all()
+    f1 = torch.full((N, D), 9.0, device=dev)
+    ops.spmm_rowsparse_raw(csr, G, f1, alpha=0.25, z=G, beta=0.25, src_bits=bits0, z_bits=bits0, row_bits=n1, write_zeros=False)
+    inside = torch.zeros(N, dtype=torch.bool, device=dev)
+    inside[torch.from_numpy(r1).to(dev)] = True
+    assert torch.equal(f1[inside], dense1[inside]) and bool((f1[~inside] == 9.0).all()) and bool((dense1[~inside] == 0).all())
+    f2 = torch.full((N, D), 5.0, device=dev)
+    ops.spmm_rowsparse_raw(csr, f1, f2, z=G, beta=0.25, src_bits=n1, z_bits=bits0, row_bits=n2, write_zeros=True)
+    assert torch.equal(f2, dense2)
     # no bitmaps at all = the dense launch; src bitmap only / z bitmap only
     y3 = torch.empty((N, D), device=dev)
     ops.spmm_rowsparse_raw(csr, G, y3, alpha=0.25, z=G, beta=0.25, src_bits=bits0)
@@ -323,7 +341,7 @@ def test_fused_step_with_the_rowsparse_backward_trains_like_the_dense_one(dev, m
         losses = [float(step(*b)) for b in batches]
         torch.cuda.synchronize()
         if sparse:
-            assert int(step.bits[0].abs().sum()) == 0 and int(step.bits[1].abs().sum()) == 0
+            assert int(step._bits_all.abs().sum()) == 0
             assert float(step.G.abs().max()) == 0.0
         return m._flat.detach().clone(), losses
 
