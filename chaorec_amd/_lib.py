@@ -40,7 +40,10 @@ SIGNATURES = {
     "chaorec_spmm_csr_rowsparse_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr,
                                                       ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, c_ptr]),
-    "chaorec_expand_row_bits": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, c_ptr]),
+    "chaorec_expand_row_bits": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
+    "chaorec_spmm_csr_rowlist_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
+                                                    ctypes.c_float, c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr,
+                                                    ctypes.c_int64, c_ptr]),
     "chaorec_bpr_fwd_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64,
                                                ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr,
                                                c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
       any_src = true;             // (a long row's gathers are not tracked: always flagged)
     }
   } else if constexpr (NG > 1) {
-    any_src = true;               // (this path gathers without looking at the bitmap)
+    static_assert(!SP, "the narrow-row long walk does not look at the row bitmaps: SP is built for LPR >= 16 only");
     unsigned long long lm = __ballot(is_long && li == 0);
     while (lm) {
       const int gl = (int)(__builtin_ctzll(lm) / LPR);
@@ -534,12 +534,12 @@ static int launch_spmm(const int64_t *rowptr, const int32_t *col, const float *v
       return fail(CHAOREC_E_INVALID, "spmm+adam: D > 256 not built");
     }
   } else if (sparse) {
-    if constexpr (CPL == 1 && LPR >= 8) {      // (D = 32 .. 256: the widths the training steps use)
+    if constexpr (CPL == 1 && LPR >= 16) {     // (D = 64 .. 256: the widths whose long-row walks look at the bitmaps)
       hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, false, true>), dim3((unsigned)blocks), dim3(256), 0, st,
                          rowptr, col, val, x, y, n_rows, D4, alpha, z, beta, acc, acc_init, acc_w, sched,
                          waves, dyn_val, AdamEpi{}, mean_t1, mean_t2, sa);
     } else {
-      return fail(CHAOREC_E_INVALID, "spmm (row-sparse): built for 32 <= D <= 256");
+      return fail(CHAOREC_E_INVALID, "spmm (row-sparse): built for 64 <= D <= 256");
     }
   } else {
     hipLaunchKernelGGL((spmm_csr_ordered_kernel<LPR, CPL, false>), dim3((unsigned)blocks), dim3(256), 0, st,
@@ -658,41 +658,126 @@ namespace chaorec {
 // bits_out |= bits_in | { c : A[r, c] != 0 for some r flagged in bits_in }: the rows a propagate over a SYMMETRIC graph can
 // make non-zero when its source is non-zero in the flagged rows only (a frontier expansion: work ~ the flagged rows'
 // entries, not the graph's).  One wave per pair of bitmap words; a flagged row's entries are walked by the whole wave.
+// list / list_n (optional): every row whose bit this launch sets FIRST is appended (no duplicates, arbitrary order; list_n is
+// the device-side length, zero on entry) -- the rows chaorec_spmm_csr_rowlist_f32 computes.
 __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                               int64_t n_rows, const uint32_t *__restrict__ bits_in,
-                                                              uint32_t *bits_out, int64_t n_words) {
+                                                              uint32_t *bits_out, int64_t n_words, int32_t *list, int32_t *list_n,
+                                                              int64_t list_cap) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  auto flag = [&](int64_t row) {
+    const uint32_t m = 1u << (row & 31);
+    const uint32_t old = atomicOr(bits_out + (row >> 5), m);
+    if (list && !(old & m)) {
+      const int at = atomicAdd(list_n, 1);
+      if (at < list_cap) list[at] = (int32_t)row;
+    }
+  };
   for (int k = 0; k < 2; ++k) {
     const int64_t wi = 2 * wave + k;
     if (wi >= n_words) return;
     uint32_t word = bits_in[wi];          // wave-uniform
     if (word == 0u) continue;
-    if (lane == 0) atomicOr(bits_out + wi, word);
+    if (lane < 32 && ((word >> lane) & 1u) && wi * 32 + lane < n_rows) flag(wi * 32 + lane);
     while (word) {
       const int b = __builtin_ctz(word);
       word &= word - 1;
       const int64_t r = wi * 32 + b;
       if (r >= n_rows) break;
       const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
-      for (int64_t e = e0 + lane; e < e1; e += 64) {
-        const int c = col[e];
-        atomicOr(bits_out + (c >> 5), 1u << (c & 31));
+      for (int64_t e = e0 + lane; e < e1; e += 64) flag(col[e]);
+    }
+  }
+}
+
+// y[r] = alpha * (A x)[r] + beta * z[r] for the rows r of a LIST only (the frontier of a row-sparse backward propagate: 1-2 %
+// of the graph at BASELINE configs[4]): one LPR-lane group per listed row, a fixed grid striding over the list.  The row's
+// entries are walked in CSR order; an entry whose source row is not flagged in src_bits is skipped (its term is +0), the
+// others are gathered and added with separately rounded product and sum -- the arithmetic, and the bits, of
+// spmm_csr_ordered_kernel.  Rows outside the list are not touched.
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_rowlist_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                           const float *__restrict__ val, const float *__restrict__ x,
+                                                           float *__restrict__ y, int D4, float alpha, const float *z, float beta,
+                                                           const uint32_t *__restrict__ src_bits,
+                                                           const uint32_t *__restrict__ z_bits, const int32_t *__restrict__ list,
+                                                           const int32_t *__restrict__ list_n, int64_t list_cap) {
+  constexpr int NG = kWave / LPR;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, li = lane % LPR;
+  const int64_t n = min((int64_t)list_n[0], list_cap);
+  const int64_t slots = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
+  const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
+  for (int64_t i = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * NG + sub;; i += slots) {
+    // (wave-uniform exit: the groups of a wave walk i, i+1, ..; shuffles below stay inside a group's own lanes)
+    if (i - sub >= n) break;
+    const bool ok = i < n;
+    const int64_t r = ok ? list[i] : 0;
+    const int64_t e0 = ok ? rowptr[r] : 0;
+    const int deg = ok ? (int)(rowptr[r + 1] - e0) : 0;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && z && li < D4 && (!z_bits || row_bit(z_bits, r))) zrow = reinterpret_cast<const float4 *>(z)[(size_t)r * D4 + li];
+    const int dmax = wave_max_i32(deg);
+    for (int base = 0; base < dmax; base += LPR) {
+      int c = 0, keep = 0;
+      float v = 0.f;
+      if (base + li < deg) {
+        c = col[e0 + base + li];
+        v = val[e0 + base + li];
+        keep = (!src_bits || row_bit(src_bits, c)) ? 1 : 0;
       }
+      // the flagged entries of this block, in entry order (a group-local mask: LPR <= 64 bits)
+      unsigned long long m = __ballot(keep != 0);
+      m = (m >> (sub * LPR)) & (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull));
+      while (__any(m != 0ull)) {            // (trip counts differ between the wave's groups: every lane stays in the loop)
+        const bool has = m != 0ull;
+        const int j = has ? __builtin_ctzll(m) : 0;
+        if (has) m &= m - 1;
+        const int src = sub * LPR + j;
+        const int cj = __shfl(c, src, 64);
+        const float vj = __shfl(v, src, 64);
+        if (has && li < D4) sum = add_rn4(sum, mul_rn4(vj, x4[(size_t)cj * (size_t)D4 + li]));
+      }
+    }
+    if (ok && li < D4) {
+      float4 s = mul_rn4(alpha, sum);
+      if (z) s = add_rn4(s, mul_rn4(beta, zrow));
+      reinterpret_cast<float4 *>(y)[(size_t)r * D4 + li] = s;
     }
   }
 }
 }  // namespace chaorec
 
 extern "C" int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col, int64_t n_rows, const uint32_t *bits_in,
-                                       uint32_t *bits_out, void *stream) {
+                                       uint32_t *bits_out, int32_t *list, int32_t *list_n, int64_t list_cap, void *stream) {
   if (!rowptr || !col || !bits_in || !bits_out) return fail(CHAOREC_E_INVALID, "expand_row_bits: NULL argument");
-  if (n_rows <= 0) return fail(CHAOREC_E_INVALID, "expand_row_bits: n_rows=%lld", (long long)n_rows);
+  if (n_rows <= 0 || n_rows > 0x7fffffffLL) return fail(CHAOREC_E_INVALID, "expand_row_bits: n_rows=%lld", (long long)n_rows);
+  if ((list == nullptr) != (list_n == nullptr) || (list && list_cap <= 0))
+    return fail(CHAOREC_E_INVALID, "expand_row_bits: list, list_n and list_cap come together");
   const int64_t n_words = (n_rows + 31) / 32;
   const int64_t waves = (n_words + 1) / 2;
   hipLaunchKernelGGL(expand_row_bits_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, col,
-                     n_rows, bits_in, bits_out, n_words);
+                     n_rows, bits_in, bits_out, n_words, list, list_n, list_cap);
   return check_launch("expand_row_bits_kernel");
+}
+
+extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x, float *y,
+                                            int64_t n_rows, int32_t D, float alpha, const float *z, float beta,
+                                            const uint32_t *src_bits, const uint32_t *z_bits, const int32_t *list,
+                                            const int32_t *list_n, int64_t list_cap, void *stream) {
+  if (!rowptr || !col || !val || !x || !y || !list || !list_n) return fail(CHAOREC_E_INVALID, "spmm (row list): NULL argument");
+  if (n_rows <= 0 || list_cap <= 0) return fail(CHAOREC_E_INVALID, "spmm (row list): bad sizes");
+  const int D4 = D / 4;
+  if (D < 64 || D > 256 || (D & 3)) return fail(CHAOREC_E_INVALID, "spmm (row list): D=%d must be a multiple of 4 in [64, 256]", D);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(2048), block(256);        // a fixed grid striding over the device-side list
+#define CHAOREC_ROWLIST_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, src_bits, z_bits, list, list_n, list_cap
+  if (D4 <= 16) hipLaunchKernelGGL((spmm_rowlist_kernel<16>), grid, block, 0, st, CHAOREC_ROWLIST_ARGS);
+  else if (D4 <= 32) hipLaunchKernelGGL((spmm_rowlist_kernel<32>), grid, block, 0, st, CHAOREC_ROWLIST_ARGS);
+  else hipLaunchKernelGGL((spmm_rowlist_kernel<64>), grid, block, 0, st, CHAOREC_ROWLIST_ARGS);
+#undef CHAOREC_ROWLIST_ARGS
+  return check_launch("spmm_rowlist_kernel");
 }
 
 extern "C" int chaorec_spmm_rows_per_wave(int32_t D) { return rows_per_wave(D); }

@@ -111,15 +111,31 @@ def row_bitmap(n_rows, device):
     return torch.zeros((int(n_rows) + 31) // 32 + 1, dtype=torch.int32, device=device)
 
 
-def expand_row_bits(csr, bits_in, bits_out):
+def expand_row_bits(csr, bits_in, bits_out, row_list=None, list_n=None):
     """bits_out |= bits_in | {columns of the rows flagged in bits_in} (chaorec_expand_row_bits; symmetric graphs): the rows the
-    next propagate can make non-zero.  Work ~ the flagged rows' entries."""
-    _need_cuda(csr.rowptr, bits_in, bits_out)
+    next propagate can make non-zero.  Work ~ the flagged rows' entries.  row_list (int32 [cap]) / list_n (int32 [1], zero on
+    entry): the rows flagged by THIS launch are also appended -- spmm_rowlist_raw's work list."""
+    _need_cuda(csr.rowptr, bits_in, bits_out, row_list, list_n)
     if not csr.symmetric:
         raise ValueError("expand_row_bits: the graph must be its own transpose")
     _lib.check(_lib.load().chaorec_expand_row_bits(_ptr(csr.rowptr), _ptr(csr.col), csr.n_rows, _ptr(bits_in), _ptr(bits_out),
+                                                   _ptr(row_list), _ptr(list_n), row_list.numel() if row_list is not None else 0,
                                                    _stream()), "chaorec_expand_row_bits")
     return bits_out
+
+
+def spmm_rowlist_raw(csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None):
+    """y[r] = alpha * (A x)[r] [+ beta z[r]] for the rows of a device-side list only (chaorec_spmm_csr_rowlist_f32); the other
+    rows of y are not touched.  Same sums, bit for bit, as spmm_raw's for those rows."""
+    _need_cuda(csr.rowptr, x, y, z, src_bits, z_bits, row_list, list_n)
+    x = _f32c(x)
+    if x.shape[0] != csr.n_cols or y.shape[0] != csr.n_rows or not y.is_contiguous():
+        raise ValueError("spmm_rowlist: shape mismatch")
+    _lib.check(_lib.load().chaorec_spmm_csr_rowlist_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x), _ptr(y), csr.n_rows,
+                                                        x.shape[1], alpha, _ptr(z), beta, _ptr(src_bits), _ptr(z_bits),
+                                                        _ptr(row_list), _ptr(list_n), row_list.numel(), _stream()),
+               "chaorec_spmm_csr_rowlist_f32")
+    return y
 
 
 def spmm_rowsparse_raw(csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None, out_bits=None, row_bits=None,

@@ -512,8 +512,10 @@ class FusedLightGCNStep:
         self.bits = None
         if self.sparse_bwd:
             words = (N + 31) // 32 + 1
-            self._bits_all = torch.zeros(3 * words, dtype=torch.int32, device=dev)
+            self._bits_all = torch.zeros(3 * words + 1, dtype=torch.int32, device=dev)      # (+ the row list's length)
             self.bits = [self._bits_all[k * words:(k + 1) * words] for k in range(3)]
+            self._list_n = self._bits_all[3 * words:]
+            self._row_list = torch.empty(N, dtype=torch.int32, device=dev)                  # N1's rows, in no particular order
         self.steps_per_replay = int(steps_per_replay) if (capture and edges is not None) else 1
         self.replays = 0
         self.graph = self.graph1 = None
@@ -593,10 +595,17 @@ class FusedLightGCNStep:
                 # l = 0: g is G itself (rows R0 = bits[0]), output rows N1 = bits[1]; l = 1: g = that output, output rows N2.
                 # Rows outside the frontier are left unwritten while the NEXT launch is row-sparse too (it gathers flagged
                 # rows only); the last row-sparse launch writes them as zeros for its dense reader.
-                ops.expand_row_bits(csr, self.bits[l], self.bits[l + 1])
                 next_sparse = (l + 1 < L - 1) and (l + 1 < 2)
-                ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=self.G, beta=w, src_bits=self.bits[l], z_bits=self.bits[0],
-                                       row_bits=self.bits[l + 1], write_zeros=not next_sparse)
+                if l == 0 and next_sparse:
+                    # N1 is 1-2 % of a large graph: its rows as a LIST, one lane group per listed row -- a launch that
+                    # merely looks at every row's descriptor costs a third of the dense one there
+                    ops.expand_row_bits(csr, self.bits[0], self.bits[1], self._row_list, self._list_n)
+                    ops.spmm_rowlist_raw(csr, g, y, self._row_list, self._list_n, alpha=alpha, z=self.G, beta=w,
+                                         src_bits=self.bits[0], z_bits=self.bits[0])
+                else:
+                    ops.expand_row_bits(csr, self.bits[l], self.bits[l + 1])
+                    ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=self.G, beta=w, src_bits=self.bits[l],
+                                           z_bits=self.bits[0], row_bits=self.bits[l + 1], write_zeros=not next_sparse)
             else:
                 ops.spmm_raw(csr, g, y=y, alpha=alpha, z=self.G, beta=w)
             g, alpha = y, 1.0

@@ -141,9 +141,20 @@ int chaorec_spmm_csr_rowsparse_f32(const int64_t *rowptr, const int32_t *col, co
                                    int32_t write_zeros, void *stream);
 
 /* bits_out |= bits_in | {columns of the rows flagged in bits_in}: for a SYMMETRIC graph, the rows a propagate can make
- * non-zero when its source is non-zero in the flagged rows only.  Work ~ the flagged rows' entries. */
+ * non-zero when its source is non-zero in the flagged rows only.  Work ~ the flagged rows' entries.  list / list_n
+ * (optional; *list_n zero on entry, list_cap entries): every row whose bit this launch sets first is also appended. */
 int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col, int64_t n_rows, const uint32_t *bits_in,
-                            uint32_t *bits_out, void *stream);
+                            uint32_t *bits_out, int32_t *list, int32_t *list_n, int64_t list_cap, void *stream);
+
+/* chaorec_spmm_csr_rowsparse_f32's arithmetic for the rows of a device-side LIST only (y[r] for r in list[0 .. *list_n); other
+ * rows of y are not touched): the first backward propagate of a BPR step, whose output is non-zero in the 1-hop image of the
+ * 3 B batch rows -- 1-2 % of the graph at BASELINE configs[4], where even a launch that only LOOKS at every row's descriptor
+ * costs a third of the dense one.  One lane group per listed row, entries in CSR order, unflagged sources skipped (their
+ * term is +0): bit-identical rows.  64 <= D <= 256. */
+int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x, float *y,
+                                 int64_t n_rows, int32_t D, float alpha, const float *z, float beta, const uint32_t *src_bits,
+                                 const uint32_t *z_bits, const int32_t *list, const int32_t *list_n, int64_t list_cap,
+                                 void *stream);
 
 /* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
 int chaorec_spmm_rows_per_wave(int32_t D);

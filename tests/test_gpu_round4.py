@@ -256,7 +256,7 @@ def _bits_to_rows(bits, n):
     return np.nonzero(np.unpackbits(w.view(np.uint8), bitorder="little")[:n])[0]
 
 
-@pytest.mark.parametrize("D", [32, 64, 128, 256])
+@pytest.mark.parametrize("D", [64, 128, 256])
 def test_rowsparse_spmm_equals_the_dense_launch_bit_for_bit(dev, D):
     """chaorec_spmm_csr_rowsparse_f32: with the source's (and z's) non-zero rows flagged in bitmaps, the launch skips the
     gathers of unflagged rows and gives the dense launch's bits; out_bits is a superset of the output's non-zero rows; the
@@ -284,8 +284,7 @@ def test_rowsparse_spmm_equals_the_dense_launch_bit_for_bit(dev, D):
     assert torch.equal(y1, dense1)
     nz = torch.nonzero(dense1.abs().sum(1) > 0).flatten().cpu().numpy()
     flagged = _bits_to_rows(bits1, N)
-    assert np.isin(nz, flagged).all()                        # a superset ...
-    assert len(flagged) < N or D < 64                        # ... and a real restriction (D = 32 takes the path that flags every row)
+    assert np.isin(nz, flagged).all() and len(flagged) < N   # a superset, and a real restriction
     dense2 = ops.spmm_raw(csr, dense1, z=G, beta=0.25)
     y2 = torch.full((N, D), -3.0, device=dev)
     ops.spmm_rowsparse_raw(csr, y1, y2, z=G, beta=0.25, src_bits=bits1, z_bits=bits0)
@@ -308,6 +307,17 @@ def test_rowsparse_spmm_equals_the_dense_launch_bit_for_bit(dev, D):
     f2 = torch.full((N, D), 5.0, device=dev)
     ops.spmm_rowsparse_raw(csr, f1, f2, z=G, beta=0.25, src_bits=n1, z_bits=bits0, row_bits=n2, write_zeros=True)
     assert torch.equal(f2, dense2)
+    if True:
+        # ... and the first launch as the fused step issues it at BASELINE configs[4]: the frontier as a LIST (emitted by the
+        # expansion), one lane group per listed row -- the listed rows get the dense launch's bits, no other row is touched
+        lst, ln, nb = torch.empty(N, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), ops.row_bitmap(N, dev)
+        ops.expand_row_bits(csr, bits0, nb, lst, ln)
+        assert torch.equal(nb, n1) and np.array_equal(np.sort(lst[:int(ln)].cpu().numpy()), r1)
+        fl = torch.full((N, D), 9.0, device=dev)
+        ops.spmm_rowlist_raw(csr, G, fl, lst, ln, alpha=0.25, z=G, beta=0.25, src_bits=bits0, z_bits=bits0)
+        assert torch.equal(fl[inside], dense1[inside]) and bool((fl[~inside] == 9.0).all())
+        ops.spmm_rowsparse_raw(csr, fl, f2, z=G, beta=0.25, src_bits=n1, z_bits=bits0, row_bits=n2, write_zeros=True)
+        assert torch.equal(f2, dense2)
     # no bitmaps at all = the dense launch; src bitmap only / z bitmap only
     y3 = torch.empty((N, D), device=dev)
     ops.spmm_rowsparse_raw(csr, G, y3, alpha=0.25, z=G, beta=0.25, src_bits=bits0)
