@@ -128,7 +128,7 @@ int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *col, const f
  * LOADS: a source row whose bit in src_bits is clear is not gathered (its term is val * (+0)), a row of z whose bit in
  * z_bits is clear is not read.  A set bit means "may be non-zero": supersets are fine.  out_bits (optional, all-zero on
  * entry) receives such a superset for y.  Bitmaps: uint32 words, bit r & 31 of word r >> 5; any of the three may be NULL.
- * 32 <= D <= 256. */
+ * 64 <= D <= 256. */
 /* row_bits (optional): a superset of the rows of y that can be non-zero -- normally chaorec_expand_row_bits of src_bits.
  * A row whose bit is clear (and whose z row is not flagged) walks no entries at all; it stores zeros when write_zeros != 0
  * (the next launch reads y densely) and nothing otherwise (the next launch gathers flagged rows only).  Per-entry bitmap
