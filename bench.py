@@ -482,18 +482,14 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     g, alpha = G, w
     for l in range(L - 1):
         y = b0 if l % 2 == 0 else b1
-        if sparse_bwd and l < 2:
-            next_sparse = (l + 1 < L - 1) and (l + 1 < 2)
-            if l == 0 and next_sparse:
-                whole.append((lambda g=g, y=y, alpha=alpha: (
-                    ops.expand_row_bits(csr, stepper.bits[0], stepper.bits[1], stepper._row_list, stepper._list_n),
-                    ops.spmm_rowlist_raw(csr, g, y, stepper._row_list, stepper._list_n, alpha=alpha, z=G, beta=w,
-                                         src_bits=stepper.bits[0], z_bits=stepper.bits[0])), csr, D))
-            else:
-                whole.append((lambda g=g, y=y, alpha=alpha, l=l, ns=next_sparse: (
-                    ops.expand_row_bits(csr, stepper.bits[l], stepper.bits[l + 1]),
-                    ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=G, beta=w, src_bits=stepper.bits[l], z_bits=stepper.bits[0],
-                                           row_bits=stepper.bits[l + 1], write_zeros=not ns)), csr, D))
+        if sparse_bwd and l == 0 and L >= 3:
+            whole.append((lambda g=g, y=y, alpha=alpha: (
+                ops.expand_row_bits(csr, stepper.bits[0], stepper.bits[1], stepper._row_list, stepper._list_n),
+                ops.spmm_rowlist_raw(csr, g, y, stepper._row_list, stepper._list_n, alpha=alpha, z=G, beta=w,
+                                     src_bits=stepper.bits[0], z_bits=stepper.bits[0])), csr, D))
+        elif sparse_bwd and l < 2:
+            whole.append((lambda g=g, y=y, alpha=alpha, l=l: ops.spmm_rowsparse_raw(
+                csr, g, y, alpha=alpha, z=G, beta=w, src_bits=stepper.bits[l], z_bits=stepper.bits[0]), csr, D))
         else:
             plain.append((lambda g=g, y=y, alpha=alpha: ops.spmm_raw(csr, g, y=y, alpha=alpha, z=G, beta=w), csr, D))
             whole.append(plain[-1])
@@ -553,11 +549,11 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         roofline["rowsparse_backward_launches"] = {
             "kernel": spmm_kernel_name(D, rowsparse=True), "per_step": min(L - 1, 2), "avg_launch_us": sparse_ms * 1e3,
             "each_us": [t * 1e3 for t in sparse_each],
-            "note": "the first two backward propagates work on row-sparse operands (the batch gradient: 3 B non-zero rows; its 1-hop "
-                    "image): output rows outside the frontier walk no entries, inside it only flagged source rows are gathered -- "
-                    "the same sums bit for bit (chaorec_expand_row_bits + chaorec_spmm_csr_rowlist_f32 over the listed frontier for the "
-                    "first, + chaorec_spmm_csr_rowsparse_f32 with a row mask for the second; each_us = one such pair); timed over "
-                    "the G and bitmaps one real BPR launch left"}
+            "note": "the first two backward propagates work on row-sparse operands (the batch gradient G: 3 B non-zero rows; its 1-hop "
+                    "image N1): the first runs over the LIST of N1's rows (chaorec_expand_row_bits + chaorec_spmm_csr_rowlist_f32), "
+                    "the second is the ordinary launch with its gathers gated by N1's bitmap (chaorec_spmm_csr_rowsparse_f32) -- the "
+                    "same sums bit for bit; each_us = [first (expansion included), second]; timed over the G and bitmap one real BPR "
+                    "launch left"}
     if traffic:
         roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
     if kernel_only_us:

@@ -664,8 +664,11 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
                                                               int64_t n_rows, const uint32_t *__restrict__ bits_in,
                                                               uint32_t *bits_out, int64_t n_words, int32_t *list, int32_t *list_n,
                                                               int64_t list_cap) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // One WORKGROUP per pair of bitmap words (most pairs are empty: a load and an exit); a flagged row's entries are walked by
+  // all 256 threads, two per thread in flight -- a popular item's row has 1e4-1e5 entries, and the `old` value of every
+  // atomicOr is needed (the list), so each step of the walk is a round trip.
+  const int lane = threadIdx.x;
+  const int64_t wave = blockIdx.x;
   auto flag = [&](int64_t row) {
     const uint32_t m = 1u << (row & 31);
     const uint32_t old = atomicOr(bits_out + (row >> 5), m);
@@ -686,7 +689,12 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
       const int64_t r = wi * 32 + b;
       if (r >= n_rows) break;
       const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
-      for (int64_t e = e0 + lane; e < e1; e += 64) flag(col[e]);
+      for (int64_t e = e0 + lane; e < e1; e += 512) {
+        const int c0 = col[e];
+        const int c1 = e + 256 < e1 ? col[e + 256] : -1;
+        flag(c0);
+        if (c1 >= 0) flag(c1);
+      }
     }
   }
 }
@@ -756,8 +764,8 @@ extern "C" int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col
   if ((list == nullptr) != (list_n == nullptr) || (list && list_cap <= 0))
     return fail(CHAOREC_E_INVALID, "expand_row_bits: list, list_n and list_cap come together");
   const int64_t n_words = (n_rows + 31) / 32;
-  const int64_t waves = (n_words + 1) / 2;
-  hipLaunchKernelGGL(expand_row_bits_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, col,
+  const int64_t groups = (n_words + 1) / 2;
+  hipLaunchKernelGGL(expand_row_bits_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, rowptr, col,
                      n_rows, bits_in, bits_out, n_words, list, list_n, list_cap);
   return check_launch("expand_row_bits_kernel");
 }

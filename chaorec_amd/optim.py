@@ -499,12 +499,16 @@ class FusedLightGCNStep:
         self.bc = torch.ones(2, dtype=torch.float32, device=dev)
         self.loss_accum = loss_accum
         # Row-sparse backward.  The batch gradient G has 3 B non-zero rows R0 out of N; g_{L-1} = w (A G) + w G is non-zero in
-        # N1 = R0 + nbr(R0) only, g_{L-2} in N2 = nbr(N1).  The first two backward launches therefore run in their
-        # row-sparse form (ops.spmm_rowsparse_raw: same sums, bit for bit): output rows outside the frontier walk no entries,
-        # inside it only flagged source rows are gathered.  bits[0] = R0 (set by the BPR launch), bits[1] = N1, bits[2] = N2
-        # (ops.expand_row_bits: work ~ the frontier's entries); the step's last launch clears all three.  It pays where the
-        # frontier is a small part of the graph -- BASELINE configs[4]: 12 M rows, N1 ~ 2 % of them -- and costs two small
-        # launches where it is not (sports: N2 is the whole graph), hence by size.  CHAOREC_SPARSE_BACKWARD=0 / 1: off / forced.
+        # N1 = R0 + nbr(R0) only.  With a real BPR batch (positives drawn in proportion to their popularity) N1 is ~13-26 % of a
+        # BASELINE-configs[4]-sized graph and N2 = nbr(N1) nearly all of it, so:
+        #   launch 1  runs over the LIST of N1's rows (ops.expand_row_bits emits it from R0's few rows, ops.spmm_rowlist_raw
+        #             computes exactly those rows and leaves the others untouched): 33.8 -> 8.7 ms at 12 M rows;
+        #   launch 2  is the ordinary launch with its GATHERS gated by N1's bitmap (ops.spmm_rowsparse_raw: an unflagged source
+        #             row is not fetched -- which is also why launch 1 need not write it): 33.1 -> 27.3 ms;
+        #   launch 3  (Adam epilogue) is dense, and clears the bitmaps and the list's length as a side job.
+        # Same sums bit for bit (the skipped terms are val * (+0)).  bits[0] = R0 (set by the BPR launch), bits[1] = N1.  It pays
+        # where the frontier is a part of the graph and costs launches where it is not (sports: N1 is half the graph, N2 all of
+        # it), hence by size.  CHAOREC_SPARSE_BACKWARD=0 / 1: off / forced.
         mode = os.environ.get("CHAOREC_SPARSE_BACKWARD", "auto")
         wide_ok = L >= 2 and D % 4 == 0 and (D // 4) in (16, 32, 64)
         self.sparse_bwd = wide_ok and mode != "0" and (mode == "1" or N >= int(os.environ.get("CHAOREC_SPARSE_BACKWARD_MIN_ROWS",
@@ -512,9 +516,9 @@ class FusedLightGCNStep:
         self.bits = None
         if self.sparse_bwd:
             words = (N + 31) // 32 + 1
-            self._bits_all = torch.zeros(3 * words + 1, dtype=torch.int32, device=dev)      # (+ the row list's length)
-            self.bits = [self._bits_all[k * words:(k + 1) * words] for k in range(3)]
-            self._list_n = self._bits_all[3 * words:]
+            self._bits_all = torch.zeros(2 * words + 1, dtype=torch.int32, device=dev)      # (+ the row list's length)
+            self.bits = [self._bits_all[k * words:(k + 1) * words] for k in range(2)]
+            self._list_n = self._bits_all[2 * words:]
             self._row_list = torch.empty(N, dtype=torch.int32, device=dev)                  # N1's rows, in no particular order
         self.steps_per_replay = int(steps_per_replay) if (capture and edges is not None) else 1
         self.replays = 0
@@ -591,21 +595,15 @@ class FusedLightGCNStep:
         g, alpha = self.G, w                    # g_{L-1} = w (A G) + w G, then g_l = A g_{l+1} + w G
         for l in range(L - 1):
             y = self.buf[l & 1]
-            if self.sparse_bwd and l < 2:
-                # l = 0: g is G itself (rows R0 = bits[0]), output rows N1 = bits[1]; l = 1: g = that output, output rows N2.
-                # Rows outside the frontier are left unwritten while the NEXT launch is row-sparse too (it gathers flagged
-                # rows only); the last row-sparse launch writes them as zeros for its dense reader.
-                next_sparse = (l + 1 < L - 1) and (l + 1 < 2)
-                if l == 0 and next_sparse:
-                    # N1 is 1-2 % of a large graph: its rows as a LIST, one lane group per listed row -- a launch that
-                    # merely looks at every row's descriptor costs a third of the dense one there
-                    ops.expand_row_bits(csr, self.bits[0], self.bits[1], self._row_list, self._list_n)
-                    ops.spmm_rowlist_raw(csr, g, y, self._row_list, self._list_n, alpha=alpha, z=self.G, beta=w,
-                                         src_bits=self.bits[0], z_bits=self.bits[0])
-                else:
-                    ops.expand_row_bits(csr, self.bits[l], self.bits[l + 1])
-                    ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=self.G, beta=w, src_bits=self.bits[l],
-                                           z_bits=self.bits[0], row_bits=self.bits[l + 1], write_zeros=not next_sparse)
+            if self.sparse_bwd and l == 0 and L >= 3:
+                # g = G (rows R0): the output's rows N1 as a list; rows outside it stay unwritten (the next launch, gated by
+                # N1's bitmap, never gathers them)
+                ops.expand_row_bits(csr, self.bits[0], self.bits[1], self._row_list, self._list_n)
+                ops.spmm_rowlist_raw(csr, g, y, self._row_list, self._list_n, alpha=alpha, z=self.G, beta=w,
+                                     src_bits=self.bits[0], z_bits=self.bits[0])
+            elif self.sparse_bwd and l < 2:
+                # every row computed and written (its reader is dense), gathers gated by the source's bitmap
+                ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=self.G, beta=w, src_bits=self.bits[l], z_bits=self.bits[0])
             else:
                 ops.spmm_raw(csr, g, y=y, alpha=alpha, z=self.G, beta=w)
             g, alpha = y, 1.0

@@ -25,9 +25,13 @@ csr = graph.lightgcn_csr(edges, N).to(dev)
 csr.schedule(D)
 gen = torch.Generator(device=dev).manual_seed(1)
 B = 1024
-users = torch.randint(0, U, (B,), device=dev, generator=gen)
-items = U + torch.randint(0, I, (2 * B,), device=dev, generator=gen)
-rows = torch.unique(torch.cat((users, items)))
+# a REAL BPR batch: B training edges picked uniformly (users and positives in proportion to their degree -- popular items),
+# one uniform negative each (chaorec_draw_batch)
+hist = graph.user_hist_csr_from_edges(edges, U)
+hist = (hist[0].to(dev), hist[1].to(dev))
+edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
+bu, bp, bn = ops.draw_batch(edges_dev, hist, B, U, I, 42, 3)
+rows = torch.unique(torch.cat((bu, U + bp, U + bn)))
 G = torch.zeros(N, D, device=dev)
 G[rows] = torch.randn(rows.numel(), D, device=dev, generator=gen)
 bits = [ops.row_bitmap(N, dev) for _ in range(3)]
@@ -81,4 +85,6 @@ print(f"clear + expand + row list   {timed(both):9.3f} ms")
 d2 = ops.spmm_raw(csr, yd, z=G, beta=0.25)
 print(f"dense  y = A y1 + G         {timed(lambda: ops.spmm_raw(csr, yd, y=d2, z=G, beta=0.25)):9.3f} ms")
 print(f"sparse #2 row mask + zeros  {timed(lambda: ops.spmm_rowsparse_raw(csr, y1, y2, z=G, beta=0.25, src_bits=bits[1], z_bits=bits[0], row_bits=bits[2], write_zeros=True)):9.3f} ms")
+print("  equal to dense:", bool(torch.equal(y2, d2)))
+print(f"sparse #2 entry bits only   {timed(lambda: ops.spmm_rowsparse_raw(csr, yl, y2, z=G, beta=0.25, src_bits=bits[1], z_bits=bits[0])):9.3f} ms   (source = the row-list launch's output: unlisted rows hold stale values)")
 print("  equal to dense:", bool(torch.equal(y2, d2)))
