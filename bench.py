@@ -1015,7 +1015,9 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
     tf = 2.0 * n_scored * I * D / (score_ms * 1e-3) / 1e12
     launch = ("captured hipGraph per step" if graphed is not None else "eager launches") + \
         (f", fused sharded step (dist.FusedShardedLightGCNStep, {'split' if fused.split else 'joined'} launches: "
-         f"{'4L+5' if fused.split else '2L+5'} launches, 2L+1 exchanges; {fused.steps_per_replay} steps per replay)"
+         f"{'4L+5' if fused.split else '2L+5'} launches, 2L+1 exchanges"
+         f"{'; the first two backward propagates over the batch frontier only (row-sparse)' if fused.sparse_bwd else ''}"
+         f"; {fused.steps_per_replay} steps per replay)"
          if fused is not None else ", autograd step")
     res = dict(dataset=dataset, data=job["data"], U1=U1, I=I, D=D, L=L, B=B, world=world, e_dir_all=e_dir_all,
                ms_per_step=ms_per_step, value=value, msgs_per_step=msgs_per_step_all, loss_mean=loss_mean, launch=launch,

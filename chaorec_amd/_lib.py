@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -40,7 +40,10 @@ SIGNATURES = {
     "chaorec_spmm_csr_rowsparse_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_float, c_ptr,
                                                       ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, c_ptr]),
-    "chaorec_expand_row_bits": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
+    "chaorec_expand_row_bits": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, c_ptr,
+                                               ctypes.c_int64, c_ptr]),
+    "chaorec_zero_rows_by_bits_f32": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr, c_ptr]),
+    "chaorec_or_words_u32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int64, c_ptr]),
     "chaorec_spmm_csr_rowlist_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_float, c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr,
                                                     ctypes.c_int64, c_ptr]),

@@ -655,20 +655,23 @@ extern "C" int chaorec_spmm_csr_adam_f32(const int64_t *rowptr, const int32_t *c
 }
 
 namespace chaorec {
-// bits_out |= bits_in | { c : A[r, c] != 0 for some r flagged in bits_in }: the rows a propagate over a SYMMETRIC graph can
-// make non-zero when its source is non-zero in the flagged rows only (a frontier expansion: work ~ the flagged rows'
-// entries, not the graph's).  One wave per pair of bitmap words; a flagged row's entries are walked by the whole wave.
-// list / list_n (optional): every row whose bit this launch sets FIRST is appended (no duplicates, arbitrary order; list_n is
-// the device-side length, zero on entry) -- the rows chaorec_spmm_csr_rowlist_f32 computes.
+// bits_out |= bits_self | { c : A[r, c] != 0 for some r flagged in bits_in }: the rows a propagate can make non-zero when
+// its source is non-zero in the flagged rows only (a frontier expansion: work ~ the flagged rows' entries, not the
+// graph's).  bits_in lives over the CSR's rows, bits_self / bits_out over its COLUMNS (a symmetric graph: bits_self =
+// bits_in; a user-shard's rectangular blocks: the batch rows of the other side).  list / list_n (optional): every row whose
+// bit this launch sets FIRST is appended (no duplicates, arbitrary order; list_n is the device-side length, zero on entry)
+// -- the rows chaorec_spmm_csr_rowlist_f32 computes.
 __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                               int64_t n_rows, const uint32_t *__restrict__ bits_in,
-                                                              uint32_t *bits_out, int64_t n_words, int32_t *list, int32_t *list_n,
-                                                              int64_t list_cap) {
+                                                              int64_t n_words, const uint32_t *__restrict__ bits_self,
+                                                              int64_t n_out_rows, uint32_t *bits_out, int32_t *list,
+                                                              int32_t *list_n, int64_t list_cap) {
   // One WORKGROUP per pair of bitmap words (most pairs are empty: a load and an exit); a flagged row's entries are walked by
   // all 256 threads, two per thread in flight -- a popular item's row has 1e4-1e5 entries, and the `old` value of every
   // atomicOr is needed (the list), so each step of the walk is a round trip.
   const int lane = threadIdx.x;
   const int64_t wave = blockIdx.x;
+  const int64_t n_self_words = bits_self ? (n_out_rows + 31) >> 5 : 0;
   auto flag = [&](int64_t row) {
     const uint32_t m = 1u << (row & 31);
     const uint32_t old = atomicOr(bits_out + (row >> 5), m);
@@ -679,10 +682,12 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
   };
   for (int k = 0; k < 2; ++k) {
     const int64_t wi = 2 * wave + k;
-    if (wi >= n_words) return;
+    if (wi < n_self_words && lane < 32) {
+      const uint32_t own = bits_self[wi];
+      if (((own >> lane) & 1u) && wi * 32 + lane < n_out_rows) flag(wi * 32 + lane);
+    }
+    if (wi >= n_words) continue;
     uint32_t word = bits_in[wi];          // wave-uniform
-    if (word == 0u) continue;
-    if (lane < 32 && ((word >> lane) & 1u) && wi * 32 + lane < n_rows) flag(wi * 32 + lane);
     while (word) {
       const int b = __builtin_ctz(word);
       word &= word - 1;
@@ -697,6 +702,35 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
       }
     }
   }
+}
+
+// y[r] = 0 for every row r flagged in a bitmap (one wave per word; an empty word is a load and an exit): how a buffer that
+// is non-zero in a frontier's rows only goes back to all-zero without a pass over the whole of it.
+__global__ __launch_bounds__(256) void zero_rows_by_bits_kernel(float *__restrict__ y, int64_t n_rows, int D4,
+                                                                const uint32_t *__restrict__ bits, int64_t n_words) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n_words) return;
+  uint32_t word = bits[wi];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  while (word) {
+    const int b = __builtin_ctz(word);
+    word &= word - 1;
+    const int64_t r = wi * 32 + b;
+    if (r >= n_rows) break;
+    for (int c = lane; c < D4; c += 64) reinterpret_cast<float4 *>(y)[(size_t)r * D4 + c] = zero;
+  }
+}
+
+// dst[w] = src[0][w] | src[1][w] | .. | src[n_src - 1][w]: the union of the ranks' row bitmaps after an all-gather (RCCL
+// has no bitwise-or reduction).
+__global__ __launch_bounds__(256) void or_words_kernel(uint32_t *dst, const uint32_t *src, int n_src,
+                                                       int64_t n_words) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  uint32_t acc = 0u;
+  for (int k = 0; k < n_src; ++k) acc |= src[(size_t)k * n_words + w];
+  dst[w] = acc;
 }
 
 // y[r] = alpha * (A x)[r] + beta * z[r] for the rows r of a LIST only (the frontier of a row-sparse backward propagate: 1-2 %
@@ -758,16 +792,36 @@ __global__ __launch_bounds__(256) void spmm_rowlist_kernel(const int64_t *__rest
 }  // namespace chaorec
 
 extern "C" int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col, int64_t n_rows, const uint32_t *bits_in,
-                                       uint32_t *bits_out, int32_t *list, int32_t *list_n, int64_t list_cap, void *stream) {
+                                       const uint32_t *bits_self, int64_t n_out_rows, uint32_t *bits_out, int32_t *list,
+                                       int32_t *list_n, int64_t list_cap, void *stream) {
   if (!rowptr || !col || !bits_in || !bits_out) return fail(CHAOREC_E_INVALID, "expand_row_bits: NULL argument");
-  if (n_rows <= 0 || n_rows > 0x7fffffffLL) return fail(CHAOREC_E_INVALID, "expand_row_bits: n_rows=%lld", (long long)n_rows);
+  if (n_rows <= 0 || n_rows > 0x7fffffffLL || n_out_rows <= 0 || n_out_rows > 0x7fffffffLL)
+    return fail(CHAOREC_E_INVALID, "expand_row_bits: n_rows=%lld n_out_rows=%lld", (long long)n_rows, (long long)n_out_rows);
   if ((list == nullptr) != (list_n == nullptr) || (list && list_cap <= 0))
     return fail(CHAOREC_E_INVALID, "expand_row_bits: list, list_n and list_cap come together");
   const int64_t n_words = (n_rows + 31) / 32;
-  const int64_t groups = (n_words + 1) / 2;
+  const int64_t n_self = bits_self ? (n_out_rows + 31) / 32 : 0;
+  const int64_t groups = (std::max(n_words, n_self) + 1) / 2;
   hipLaunchKernelGGL(expand_row_bits_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, rowptr, col,
-                     n_rows, bits_in, bits_out, n_words, list, list_n, list_cap);
+                     n_rows, bits_in, n_words, bits_self, n_out_rows, bits_out, list, list_n, list_cap);
   return check_launch("expand_row_bits_kernel");
+}
+
+extern "C" int chaorec_zero_rows_by_bits_f32(float *y, int64_t n_rows, int32_t D, const uint32_t *bits, void *stream) {
+  if (!y || !bits) return fail(CHAOREC_E_INVALID, "zero_rows_by_bits: NULL argument");
+  if (n_rows <= 0 || D <= 0 || (D & 3)) return fail(CHAOREC_E_INVALID, "zero_rows_by_bits: n_rows=%lld D=%d", (long long)n_rows, D);
+  const int64_t n_words = (n_rows + 31) / 32;
+  hipLaunchKernelGGL(zero_rows_by_bits_kernel, dim3((unsigned)((n_words + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, n_rows,
+                     D / 4, bits, n_words);
+  return check_launch("zero_rows_by_bits_kernel");
+}
+
+extern "C" int chaorec_or_words_u32(uint32_t *dst, const uint32_t *src, int32_t n_src, int64_t n_words, void *stream) {
+  if (!dst || !src) return fail(CHAOREC_E_INVALID, "or_words: NULL argument");
+  if (n_src <= 0 || n_words <= 0) return fail(CHAOREC_E_INVALID, "or_words: n_src=%d n_words=%lld", n_src, (long long)n_words);
+  hipLaunchKernelGGL(or_words_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n_src,
+                     n_words);
+  return check_launch("or_words_kernel");
 }
 
 extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x, float *y,

@@ -752,6 +752,13 @@ class _HipStepKernels:
     bpr_fwd_bwd = staticmethod(ops.bpr_fwd_bwd)
     bpr_finalize = staticmethod(ops.bpr_finalize)
     mean_terms_limit = staticmethod(ops.mean_terms_limit)
+    # the row-sparse backward (sparse_bwd)
+    expand_row_bits = staticmethod(ops.expand_row_bits)
+    spmm_rowlist = staticmethod(lambda *a, **k: ops.spmm_rowlist_raw(*a, **k))
+    spmm_rowsparse = staticmethod(lambda *a, **k: ops.spmm_rowsparse_raw(*a, **k))
+    zero_rows_by_bits = staticmethod(ops.zero_rows_by_bits)
+    or_words = staticmethod(ops.or_words)
+    sparse_widths = (64, 256)           # chaorec_spmm_csr_rowsparse_f32 / _rowlist_f32 are built for these D
 
 
 SPLIT_BYTES = int(_os.environ.get("CHAOREC_DIST_SPLIT_BYTES", str(64 << 20)))     # item partial size from which a step splits
@@ -777,9 +784,11 @@ class FusedShardedLightGCNStep:
     folded into the epilogue factors.  Item rows end identical on every rank (same sums, same Adam arithmetic)."""
 
     def __init__(self, model, optimizer, batch_size=1024, edges=None, seed=42, step_dev=None, given_batch=False,
-                 loss_accum=None, capture=True, kernels=None, group=None, steps_per_replay=1, split=None):
+                 loss_accum=None, capture=True, kernels=None, group=None, steps_per_replay=1, split=None, sparse_bwd=None):
         """split: None = by size (item partial I_pad * D * 4 >= SPLIT_BYTES, or CHAOREC_DIST_SPLIT=0/1), True / False =
-        the split / joined launch sequence (see _launch_split)."""
+        the split / joined launch sequence (see _launch_split).  sparse_bwd: None = by size (optim.FusedLightGCNStep's
+        rule: CHAOREC_SPARSE_BACKWARD=auto/0/1, CHAOREC_SPARSE_BACKWARD_MIN_ROWS), True / False = the first two backward
+        propagates over the batch's frontier only / dense (split launch sequence only)."""
         from .optim import FusedAdam
         if not isinstance(optimizer, FusedAdam) or len(optimizer.param_groups) != 1:
             raise TypeError("FusedShardedLightGCNStep needs a FusedAdam with one parameter group")
@@ -826,6 +835,31 @@ class FusedShardedLightGCNStep:
             env = _os.environ.get("CHAOREC_DIST_SPLIT", "")
             split = (env == "1") if env in ("0", "1") else (self.N_pad - U) * D * 4 >= SPLIT_BYTES
         self.split = bool(split)
+        # Row-sparse backward (optim.FusedLightGCNStep's, for a shard): the batch gradient has B user rows and <= 2 B item
+        # rows per rank, the first backward propagate's result lives in their neighbours.  One bitmap per side and level:
+        # bits = [users R0, items R0, users N1, items N1]; the ITEM bitmaps are made the union over the ranks (the seed and
+        # every item partial are sums over the ranks), the user ones are local.
+        if sparse_bwd is None:
+            mode = _os.environ.get("CHAOREC_SPARSE_BACKWARD", "auto")
+            lo, hi = getattr(self.K, "sparse_widths", (1, 0))
+            sparse_bwd = self.split and lo <= D <= hi and D % 4 == 0 and self.L >= 2 and mode != "0" and \
+                (mode == "1" or self.N >= int(_os.environ.get("CHAOREC_SPARSE_BACKWARD_MIN_ROWS", "400000")))
+        if sparse_bwd and not self.split:
+            raise ValueError("FusedShardedLightGCNStep: the row-sparse backward exists for the split launch sequence only")
+        self.sparse_bwd = bool(sparse_bwd)
+        if self.sparse_bwd:
+            wu, wi = (U + 31) // 32, (I + 31) // 32
+            self._wu = wu
+            self._bits_all = torch.zeros(2 * (wu + wi) + 2, dtype=torch.int32, device=dev)     # (+ the two lists' lengths)
+            cut = [0, wu, wu + wi, 2 * wu + wi, 2 * (wu + wi)]
+            self.bits = [self._bits_all[cut[k]:cut[k + 1]] for k in range(4)]
+            self._list_n = self._bits_all[cut[4]:]
+            self._list_u = torch.zeros(U, dtype=torch.int32, device=dev)
+            self._list_i = torch.zeros(I, dtype=torch.int32, device=dev)
+            self._bits_gather = torch.zeros((self.world, wi), dtype=torch.int32, device=dev)
+            # the first backward item partial: non-zero in the frontier's rows only, ALL-ZERO between steps (its exchange
+            # sums whole buffers; the rows a step wrote are zeroed again by that step)
+            self.Z = torch.zeros((self.N_pad - U, D), dtype=torch.float32, device=dev)
         self.replays = 0
         self.graph = self.graph1 = None
         # k steps per hipGraph (in-launch batches only): a replay boundary costs ~5.5 us on this stack, the launches inside
@@ -875,6 +909,16 @@ class FusedShardedLightGCNStep:
             for dst, src in zip(self._counters(), saved[1]):
                 dst.copy_(src)
             self.G.zero_()
+            if self.sparse_bwd:
+                self._bits_all.zero_()
+                self.Z.zero_()
+
+    def _union_item_bits(self, bits):
+        """An item-row bitmap becomes the union over the ranks (one small all-gather + one launch; issued BEFORE the
+        step's large exchanges: a process group's collectives run in issue order)."""
+        if _active(self.group):
+            dist.all_gather_into_tensor(self._bits_gather.view(-1), bits, group=self.group)
+            self.K.or_words(bits, self._bits_gather)
 
     def _exchange(self, buf):
         """Sum the item rows of a joined buffer over the ranks, in place; -> a handle to wait on."""
@@ -969,31 +1013,65 @@ class FusedShardedLightGCNStep:
         lo = U if self.use_mean else 0
         K.rows_mean([t[lo:N] for t in xs], w, self.final[lo:N])
         draw = self.edges is not None
+        flags = dict(row_bits=self._bits_all, bits_item_offset=32 * self._wu) if self.sparse_bwd else {}
         K.bpr_fwd_bwd(self.final, U, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef, self.ws, self.ids,
                       edges=self.edges, hist=model.hist if draw else None, num_user=U, num_item=I, seed=self.seed, step=0,
-                      step_dev=self.step_dev, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
+                      step_dev=self.step_dev, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc, **flags)
         K.bpr_finalize(self.ws, B, D, model.reg_weight, self.out, out_total=self.static_loss, loss_accum=self.loss_accum,
                        advance=self.step_dev if draw else None)
         c = w / self.world
-        self.S.copy_(self.G)
-        pend = self._exchange(self.S)                # the seed's item rows: summed while the first B_g^T launch runs
-        g, alpha = self.S, c
+        sp = self.sparse_bwd
+        if sp:
+            bu0, bi0, bu1, bi1 = self.bits
+            self._union_item_bits(bi0)
+            if L >= 3:
+                # N1's item rows: the batch items of every rank + the neighbours of this rank's batch users -> this rank's
+                # work list; their union over the ranks is what the second propagate may gather
+                K.expand_row_bits(ui, bu0, bi1, self._list_i, self._list_n[1:2], bits_self=bi0)
+                self._union_item_bits(bi1)
+        # the seed: this rank's user rows as they are (G), the item rows summed over the ranks (S) while the first B_g^T
+        # launch runs
+        self.S[U:].copy_(self.G[U:])
+        pend = self._exchange(self.S)
+        gu, gi, alpha = self.G[:U], self.S[U:N], c
         for l in range(L):
             last = l == L - 1
             Y = self.ybuf[min(L - 1, 2)] if last else self.ybuf[l & 1]
-            K.spmm(iu, g[:U], y=Y[U:N], alpha=alpha, z=self.G[U:N], beta=c)
-            nxt = self._exchange(Y)
+            how = "dense" if (not sp or last or l >= 2) else "list" if (l == 0 and L >= 3) else "gated"
+            if how == "list":
+                K.spmm_rowlist(iu, gu, self.Z[:I], self._list_i, self._list_n[1:2], alpha=alpha, z=self.G[U:N], beta=c,
+                               src_bits=bu0, z_bits=bi0)
+                nxt = _sum_exchange_async(self.Z, self.group)
+            elif how == "gated":
+                K.spmm_rowsparse(iu, gu, Y[U:N], alpha=alpha, z=self.G[U:N], beta=c, src_bits=self.bits[2 * l], z_bits=bi0)
+                nxt = self._exchange(Y)
+            else:
+                K.spmm(iu, gu, y=Y[U:N], alpha=alpha, z=self.G[U:N], beta=c)
+                nxt = self._exchange(Y)
+            if last and sp:
+                K.zero_rows_by_bits(self.G[U:N], bi0)          # (G's item rows had their last reader)
             pend.wait()
             if last:
-                K.spmm_adam(ui, g[U:N], self.flat[:U], self.m[:U], self.v[:U], self.bc, group["lr"], group["betas"],
-                            group["eps"], group["weight_decay"], alpha=alpha, z=self.G[:U], beta=c, clear_z=True)
+                extra = dict(clear_bits=(self._bits_all,)) if sp else {}
+                K.spmm_adam(ui, gi, self.flat[:U], self.m[:U], self.v[:U], self.bc, group["lr"], group["betas"],
+                            group["eps"], group["weight_decay"], alpha=alpha, z=self.G[:U], beta=c, clear_z=True, **extra)
+            elif how == "list":
+                K.expand_row_bits(iu, bi0, bu1, self._list_u, self._list_n[0:1], bits_self=bu0)
+                K.spmm_rowlist(ui, gi, Y[:U], self._list_u, self._list_n[0:1], alpha=alpha, z=self.G[:U], beta=c,
+                               src_bits=bi0, z_bits=bu0)
+            elif how == "gated":
+                K.spmm_rowsparse(ui, gi, Y[:U], alpha=alpha, z=self.G[:U], beta=c, src_bits=self.bits[2 * l + 1], z_bits=bu0)
+                if l == 1 and L >= 3:
+                    K.zero_rows_by_bits(self.Z[:I], bi1)       # (Z had its only reader: all-zero again)
             else:
-                K.spmm(ui, g[U:N], y=Y[:U], alpha=alpha, z=self.G[:U], beta=c)
-            g, alpha, pend = Y, 1.0, nxt
+                K.spmm(ui, gi, y=Y[:U], alpha=alpha, z=self.G[:U], beta=c)
+            gu, gi = Y[:U], (self.Z[:I] if how == "list" else Y[U:N])
+            alpha, pend = 1.0, nxt
         pend.wait()
-        K.adam_step(self.flat[U:N], g[U:N], self.m[U:N], self.v[U:N], 0, group["lr"], group["betas"], group["eps"],
+        K.adam_step(self.flat[U:N], gi, self.m[U:N], self.v[U:N], 0, group["lr"], group["betas"], group["eps"],
                     group["weight_decay"], step_dev=opt._step_dev)
-        self.G[U:N].zero_()
+        if not sp:
+            self.G[U:N].zero_()
         model.result_u, model.result_i, model._result_cat = self.final[:U], self.final[U:N], None
 
     def __call__(self, users=None, pos=None, neg=None, single=False):

@@ -111,17 +111,43 @@ def row_bitmap(n_rows, device):
     return torch.zeros((int(n_rows) + 31) // 32 + 1, dtype=torch.int32, device=device)
 
 
-def expand_row_bits(csr, bits_in, bits_out, row_list=None, list_n=None):
-    """bits_out |= bits_in | {columns of the rows flagged in bits_in} (chaorec_expand_row_bits; symmetric graphs): the rows the
-    next propagate can make non-zero.  Work ~ the flagged rows' entries.  row_list (int32 [cap]) / list_n (int32 [1], zero on
-    entry): the rows flagged by THIS launch are also appended -- spmm_rowlist_raw's work list."""
-    _need_cuda(csr.rowptr, bits_in, bits_out, row_list, list_n)
-    if not csr.symmetric:
-        raise ValueError("expand_row_bits: the graph must be its own transpose")
-    _lib.check(_lib.load().chaorec_expand_row_bits(_ptr(csr.rowptr), _ptr(csr.col), csr.n_rows, _ptr(bits_in), _ptr(bits_out),
-                                                   _ptr(row_list), _ptr(list_n), row_list.numel() if row_list is not None else 0,
-                                                   _stream()), "chaorec_expand_row_bits")
+def expand_row_bits(csr, bits_in, bits_out, row_list=None, list_n=None, bits_self=None):
+    """bits_out |= bits_self | {columns of the rows flagged in bits_in} (chaorec_expand_row_bits): the rows the next propagate
+    can make non-zero.  bits_in: over the CSR's rows; bits_self / bits_out: over its columns -- a symmetric graph (bits_self
+    defaults to bits_in), or one of a user shard's rectangular blocks with the other side's batch rows as bits_self.  Work ~
+    the flagged rows' entries.  row_list (int32 [cap]) / list_n (int32 [1], zero on entry): the rows flagged by THIS launch
+    are also appended -- spmm_rowlist_raw's work list."""
+    _need_cuda(csr.rowptr, bits_in, bits_out, row_list, list_n, bits_self)
+    if bits_self is None:
+        if not csr.symmetric:
+            raise ValueError("expand_row_bits: a graph that is not its own transpose needs bits_self (a bitmap over its columns)")
+        bits_self = bits_in
+    if bits_in.numel() * 32 < csr.n_rows or bits_out.numel() * 32 < csr.n_cols or bits_self.numel() * 32 < csr.n_cols:
+        raise ValueError("expand_row_bits: bitmap shorter than its row range")
+    _lib.check(_lib.load().chaorec_expand_row_bits(_ptr(csr.rowptr), _ptr(csr.col), csr.n_rows, _ptr(bits_in), _ptr(bits_self),
+                                                   csr.n_cols, _ptr(bits_out), _ptr(row_list), _ptr(list_n),
+                                                   row_list.numel() if row_list is not None else 0, _stream()),
+               "chaorec_expand_row_bits")
     return bits_out
+
+
+def zero_rows_by_bits(y, bits):
+    """y[r] = 0 for every row flagged in `bits` (chaorec_zero_rows_by_bits_f32)."""
+    _need_cuda(y, bits)
+    if y.dtype != torch.float32 or not y.is_contiguous() or bits.numel() * 32 < y.shape[0]:
+        raise ValueError("zero_rows_by_bits: contiguous float32 rows and a bitmap over all of them")
+    _lib.check(_lib.load().chaorec_zero_rows_by_bits_f32(_ptr(y), y.shape[0], y.shape[1], _ptr(bits), _stream()),
+               "chaorec_zero_rows_by_bits_f32")
+    return y
+
+
+def or_words(dst, src):
+    """dst[w] = OR_k src[k, w] (chaorec_or_words_u32): the union of all-gathered row bitmaps."""
+    _need_cuda(dst, src)
+    if src.dim() != 2 or src.shape[1] != dst.numel() or not src.is_contiguous() or not dst.is_contiguous():
+        raise ValueError("or_words: src [k, n_words] contiguous, dst [n_words]")
+    _lib.check(_lib.load().chaorec_or_words_u32(_ptr(dst), _ptr(src), src.shape[0], dst.numel(), _stream()), "chaorec_or_words_u32")
+    return dst
 
 
 def spmm_rowlist_raw(csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None):
@@ -523,14 +549,16 @@ def bpr_loss(tab_u, tab_i, users, pos, neg, variant, reg_weight=0.0, item_offset
 
 def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg_weight, coef, ws, ids, edges=None, hist=None, num_user=0,
                 num_item=0, seed=0, step=0, step_dev=None, perm=None, perm_pos=None, adam_step=None, betas=(0.9, 0.999),
-                adam_bc=None, pos_offset=0, row_bits=None):
+                adam_bc=None, pos_offset=0, row_bits=None, bits_item_offset=None):
     """BPR(+L2) forward terms and backward row adds in one launch (chaorec_bpr_fwd_bwd_f32) over ONE [N, D] table
     (items from row item_offset on) and its gradient buffer `grad` (same shape, zero where no sample lands).
     edges given: the batch is drawn in the launch and written to ids = (users, pos, neg); else ids are the batch
     (LOCAL item ids).  The loss comes from bpr_finalize(ws, ...).  adam_step / adam_bc: Adam's step counter is moved on
     and the new step's bias corrections are written by this launch.  pos_offset: added to *perm_pos (step j of a
     replay whose finalize runs once, after its last step: step = j, pos_offset = j * B).  row_bits (optional, ops.row_bitmap
-    over the table's rows): the rows of `grad` the launch touched are flagged for the row-sparse backward propagates."""
+    over the table's rows): the rows of `grad` the launch touched are flagged for the row-sparse backward propagates; item
+    row i is bit bits_item_offset + i (default item_offset: one bitmap over the joined table; a word-aligned offset gives
+    the item rows a bitmap of their own)."""
     _need_cuda(tab, grad, coef, ws, edges, step_dev, perm, perm_pos, adam_step, adam_bc, row_bits, *ids)
     D = tab.shape[1]
     off = item_offset * D * 4
@@ -542,8 +570,8 @@ def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg_weight, coef, ws, ids, e
         int(seed) & (2**64 - 1), int(step), _ptr(step_dev), _ptr(None if draw else ids[0]), _ptr(None if draw else ids[1]),
         _ptr(None if draw else ids[2]), int(B), D, int(variant), float(reg_weight), _ptr(ids[0] if draw else None),
         _ptr(ids[1] if draw else None), _ptr(ids[2] if draw else None), _ptr(coef), _ptr(ws), _ptr(perm), _ptr(perm_pos),
-        int(pos_offset), _ptr(grad), gi, _ptr(adam_step), betas[0], betas[1], _ptr(adam_bc), _ptr(row_bits), int(item_offset),
-        _stream())
+        int(pos_offset), _ptr(grad), gi, _ptr(adam_step), betas[0], betas[1], _ptr(adam_bc), _ptr(row_bits),
+        int(item_offset if bits_item_offset is None else bits_item_offset), _stream())
     _lib.check(rc, "chaorec_bpr_fwd_bwd_at_f32")
 
 

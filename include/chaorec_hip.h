@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 11  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 12  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -140,11 +140,22 @@ int chaorec_spmm_csr_rowsparse_f32(const int64_t *rowptr, const int32_t *col, co
                                    const uint32_t *z_bits, uint32_t *out_bits, const uint32_t *row_bits,
                                    int32_t write_zeros, void *stream);
 
-/* bits_out |= bits_in | {columns of the rows flagged in bits_in}: for a SYMMETRIC graph, the rows a propagate can make
- * non-zero when its source is non-zero in the flagged rows only.  Work ~ the flagged rows' entries.  list / list_n
+/* bits_out |= bits_self | {columns of the rows flagged in bits_in}: the rows a propagate can make non-zero when its source
+ * is non-zero in the flagged rows only.  bits_in: a bitmap over the CSR's n_rows rows; bits_self (optional) and bits_out:
+ * bitmaps over its n_out_rows COLUMNS (symmetric graph: bits_self = bits_in, n_out_rows = n_rows; a user shard's
+ * rectangular blocks B_g / B_g^T: the batch rows of the other side).  Work ~ the flagged rows' entries.  list / list_n
  * (optional; *list_n zero on entry, list_cap entries): every row whose bit this launch sets first is also appended. */
 int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col, int64_t n_rows, const uint32_t *bits_in,
-                            uint32_t *bits_out, int32_t *list, int32_t *list_n, int64_t list_cap, void *stream);
+                            const uint32_t *bits_self, int64_t n_out_rows, uint32_t *bits_out, int32_t *list,
+                            int32_t *list_n, int64_t list_cap, void *stream);
+
+/* y[r, :] = 0 for every row flagged in `bits` (a buffer that is non-zero in a frontier's rows only goes back to all-zero
+ * without a pass over the whole of it).  D a multiple of 4. */
+int chaorec_zero_rows_by_bits_f32(float *y, int64_t n_rows, int32_t D, const uint32_t *bits, void *stream);
+
+/* dst[w] = src[0][w] | .. | src[n_src - 1][w] (src: n_src bitmaps of n_words words, back to back): the union of the ranks'
+ * row bitmaps after an all-gather -- RCCL has no bitwise-or reduction.  dst may be one of the sources. */
+int chaorec_or_words_u32(uint32_t *dst, const uint32_t *src, int32_t n_src, int64_t n_words, void *stream);
 
 /* chaorec_spmm_csr_rowsparse_f32's arithmetic for the rows of a device-side LIST only (y[r] for r in list[0 .. *list_n); other
  * rows of y are not touched): the first backward propagate of a BPR step, whose output is non-zero in the 1-hop image of the

@@ -260,25 +260,96 @@ class _OracleStepKernels:
         p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)
 
     @classmethod
-    def spmm_adam(cls, csr, x, p, m, v, bc, lr, betas, eps, wd, alpha=1.0, z=None, beta=0.0, clear_z=False):
+    def spmm_adam(cls, csr, x, p, m, v, bc, lr, betas, eps, wd, alpha=1.0, z=None, beta=0.0, clear_z=False, clear_bits=()):
         g = _oracle_spmm(csr, x, alpha=alpha, z=z, beta=beta)
         cls._adam(p, g, m, v, float(bc[0]), float(bc[1]), lr, betas, eps, wd)
         if clear_z:
             z.zero_()
+        for b in clear_bits:
+            b.zero_()
 
     @classmethod
     def adam_step(cls, p, g, m, v, step, lr, betas, eps, wd, step_dev=None):
         t = int(step_dev) if step_dev is not None else step
         cls._adam(p, g, m, v, 1 - betas[0] ** t, (1 - betas[1] ** t) ** 0.5, lr, betas, eps, wd)
 
+    # ---- the row-sparse backward's launches: the same results, computed the dense way, with the launches' contract about
+    # WHAT IS LEFT ALONE made hostile -- a row the launch does not write turns into NaN when it holds stale values (a later
+    # reader of it would poison the step), and a source row that is not flagged is not read at all
+    sparse_widths = (4, 4096)
+
     @staticmethod
-    def bpr_fwd_bwd(tab, item_offset, grad, B, variant, reg, coef, ws, ids, edges=None, hist=None, num_user=0, num_item=0,
-                    seed=0, step=0, step_dev=None, adam_step=None, betas=(0.9, 0.999), adam_bc=None):
+    def _rows(bits, n):
+        w = bits.numpy().view(np.uint32)
+        r = np.arange(n)
+        return ((w[r >> 5] >> (r & 31).astype(np.uint32)) & 1).astype(bool)
+
+    @staticmethod
+    def _set(bits, rows):
+        w = bits.numpy().view(np.uint32)                 # (shares the tensor's memory)
+        np.bitwise_or.at(w, rows >> 5, (np.uint32(1) << (rows & 31).astype(np.uint32)))
+
+    @classmethod
+    def expand_row_bits(cls, csr, bits_in, bits_out, row_list=None, list_n=None, bits_self=None):
+        assert bits_self is not None or csr.symmetric
+        rp, col = csr.rowptr.numpy(), csr.col.numpy()
+        hit = cls._rows(bits_self if bits_self is not None else bits_in, csr.n_cols).copy()
+        for r in np.nonzero(cls._rows(bits_in, csr.n_rows))[0]:
+            hit[col[rp[r]:rp[r + 1]]] = True
+        new = np.nonzero(hit & ~cls._rows(bits_out, csr.n_cols))[0]
+        cls._set(bits_out, new)
+        if row_list is not None:
+            n0 = int(list_n[0])
+            row_list[n0:n0 + len(new)] = torch.from_numpy(new[::-1].astype(np.int32).copy())       # (any order)
+            list_n[0] = n0 + len(new)
+
+    @classmethod
+    def _gated(cls, csr, x, alpha, z, beta, src_bits, z_bits):
+        xm = torch.where(torch.from_numpy(cls._rows(src_bits, csr.n_cols))[:, None], x, torch.zeros(()))
+        zm = torch.where(torch.from_numpy(cls._rows(z_bits, csr.n_rows))[:, None], z, torch.zeros(()))
+        assert not torch.isnan(xm).any() and not torch.isnan(zm).any()
+        return _oracle_spmm(csr, xm, alpha=alpha, z=zm, beta=beta)
+
+    @classmethod
+    def spmm_rowlist(cls, csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None):
+        full = cls._gated(csr, x, alpha, z, beta, src_bits, z_bits)
+        rows = row_list[:int(list_n[0])].long()
+        assert len(torch.unique(rows)) == len(rows)
+        keep = torch.zeros(csr.n_rows, dtype=torch.bool)
+        keep[rows] = True
+        assert float(full[~keep].abs().max()) == 0.0 if (~keep).any() else True      # (the list covers every non-zero row)
+        if float(y[~keep].abs().nan_to_num(1.0).max() if (~keep).any() else 0.0) != 0.0:
+            y[~keep] = float("nan")                      # stale rows: poisoned; an all-zero buffer stays all-zero
+        y[rows] = full[rows]
+
+    @classmethod
+    def spmm_rowsparse(cls, csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None):
+        y.copy_(cls._gated(csr, x, alpha, z, beta, src_bits, z_bits))
+
+    @classmethod
+    def zero_rows_by_bits(cls, y, bits):
+        y[torch.from_numpy(cls._rows(bits, y.shape[0]))] = 0.0
+
+    @staticmethod
+    def or_words(dst, src):
+        acc = src[0].clone()
+        for k in range(1, src.shape[0]):
+            acc |= src[k]
+        dst.copy_(acc)
+
+    @classmethod
+    def bpr_fwd_bwd(cls, tab, item_offset, grad, B, variant, reg, coef, ws, ids, edges=None, hist=None, num_user=0, num_item=0,
+                    seed=0, step=0, step_dev=None, adam_step=None, betas=(0.9, 0.999), adam_bc=None, row_bits=None,
+                    bits_item_offset=None):
         from oracle import oracle
         assert edges is None
         U, I = item_offset, num_item
         tu, ti = tab[:U].numpy(), tab[U:U + I].numpy()
         u, p, n = (t.numpy() for t in ids)
+        if row_bits is not None:
+            cls._set(row_bits, u)
+            cls._set(row_bits, bits_item_offset + p)
+            cls._set(row_bits, bits_item_offset + n)
         out, cf = oracle.bpr_fwd(tu, ti, u, p, n, variant, reg)
         gu, gi = oracle.bpr_bwd(tu, ti, u, p, n, cf, reg, 1.0)
         grad[:U] += torch.from_numpy(gu).float()
@@ -297,7 +368,7 @@ class _OracleStepKernels:
             loss_accum += ws[0]
 
 
-def _worker_fused(rank, world, port, tmp, mode, L, split=False):
+def _worker_fused(rank, world, port, tmp, mode, L, split=False, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = mode
@@ -316,8 +387,8 @@ def _worker_fused(rank, world, port, tmp, mode, L, split=False):
     x0u, x0i = m.user_embedding.weight.detach().clone().numpy(), m.item_embedding.weight.detach().clone().numpy()
     opt = FusedAdam(m.parameters(), lr=1e-2)
     step = cdist.FusedShardedLightGCNStep(m, opt, batch_size=B, given_batch=True, capture=False, kernels=_OracleStepKernels,
-                                          split=split)
-    assert step.split == split
+                                          split=split, sparse_bwd=sparse)
+    assert step.split == split and step.sparse_bwd == sparse
     assert step.N_pad % world == (shard.num_user_local % world)          # item rows padded to a multiple of the world size
     rng = np.random.default_rng(100 + rank)
     batches, losses = [], []
@@ -330,6 +401,8 @@ def _worker_fused(rank, world, port, tmp, mode, L, split=False):
         batches.append(np.stack([users.numpy() + shard.u0, pos.numpy() - shard.num_user_local,
                                  neg.numpy() - shard.num_user_local]))
     assert float(step.G.abs().max()) == 0.0                               # the gradient buffer is all-zero between steps
+    if sparse:
+        assert float(step.Z.abs().max()) == 0.0 and int(step._bits_all.abs().max()) == 0       # ... and so are these
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), x0u=x0u, x0i=x0i, xu=m.user_embedding.weight.detach().numpy(),
              xi=m.item_embedding.weight.detach().numpy(), fu=m.result_u.numpy(), fi=m.result_i.numpy(),
              batches=np.stack(batches), losses=np.array(losses))
@@ -337,16 +410,20 @@ def _worker_fused(rank, world, port, tmp, mode, L, split=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,L,split", [(2, "allreduce", 3, False), (2, "direct", 1, False), (4, "rs_ag", 2, False),
-                                                (2, "auto", 3, True), (4, "allreduce", 2, True), (2, "rs_ag", 1, True)])
-def test_fused_sharded_step_trains_like_the_single_process_oracle(oracle, world, mode, L, split):
+@pytest.mark.parametrize("world,mode,L,split,sparse", [
+    (2, "allreduce", 3, False, False), (2, "direct", 1, False, False), (4, "rs_ag", 2, False, False),
+    (2, "auto", 3, True, False), (4, "allreduce", 2, True, False), (2, "rs_ag", 1, True, False),
+    (2, "allreduce", 3, True, True), (4, "rs_ag", 4, True, True), (2, "auto", 2, True, True)])
+def test_fused_sharded_step_trains_like_the_single_process_oracle(oracle, world, mode, L, split, sparse):
     """dist.FusedShardedLightGCNStep (joined-graph propagates, in-place item exchanges, Adam in the last propagate /
     one fused launch for the replicated item rows) over T optimizer steps against the oracle on the WHOLE graph: the global
     loss is the mean of the ranks' batch losses, torch.optim.Adam's arithmetic on its gradient.  split=True: the launch
     sequence of large item tables (every joined launch as its two row blocks, every exchange in flight under the next
-    launches, dist.FusedShardedLightGCNStep._launch_split)."""
+    launches, dist.FusedShardedLightGCNStep._launch_split).  sparse=True: the first two backward propagates over the
+    batch's frontier only (row lists / gated gathers; item bitmaps united over the ranks) -- the stand-in kernels turn every
+    stale row such a launch leaves behind into NaN, so a reader of one cannot go unnoticed."""
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker_fused, args=(world, _free_port(), tmp, mode, L, split), nprocs=world, join=True)
+        mp.spawn(_worker_fused, args=(world, _free_port(), tmp, mode, L, split, sparse), nprocs=world, join=True)
         r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
     U, I, D, T = 500, 203, 16, 3
     edges = _heavy_tailed_graph(U, I)

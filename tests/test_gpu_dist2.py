@@ -34,7 +34,7 @@ def _problem():
     return edges, x0, batches
 
 
-def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False):
+def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = exchange
@@ -55,8 +55,8 @@ def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False):
         m.user_embedding.weight.copy_(x0[shard.u0:shard.u1])
         m.item_embedding.weight.copy_(x0[U:])
     step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=False,
-                                          split=split)
-    assert step.split == split
+                                          split=split, sparse_bwd=sparse)
+    assert step.split == split and step.sparse_bwd == sparse
     losses = []
     for t in range(T):
         # this rank's batch: the triples of BOTH ranks' draws whose user it owns would change the batch size; instead
@@ -68,6 +68,9 @@ def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False):
         neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + I, B)).to(dev)
         losses.append(float(step(users, pos, neg)))
     torch.cuda.synchronize()
+    assert float(step.G.abs().max()) == 0.0
+    if sparse:          # what the step leaves behind for the next one: no flag, no listed row, an all-zero frontier buffer
+        assert float(step.Z.abs().max()) == 0.0 and int(step._bits_all.abs().max()) == 0
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), u0=shard.u0, u1=shard.u1, xu=m.user_embedding.weight.detach().cpu().numpy(),
              xi=m.item_embedding.weight.detach().cpu().numpy(), fu=m.result_u.cpu().numpy(), fi=m.result_i.cpu().numpy(),
              losses=np.array(losses), n_local_edges=len(shard.local_edges))
@@ -118,7 +121,7 @@ def _p2p_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False):
+def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False, sparse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = exchange
@@ -139,7 +142,7 @@ def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False):
         m.user_embedding.weight.copy_(x0[:U])
         m.item_embedding.weight.copy_(x0[U:])
     step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=True,
-                                          split=split)
+                                          split=split, sparse_bwd=sparse)
     losses = []
     for t in range(T):
         rng = np.random.default_rng(100 * t)
@@ -149,7 +152,7 @@ def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False):
         neg = torch.from_numpy(rng.integers(U, U + I, B)).to(dev)
         losses.append(float(step(users, pos, neg)))
     torch.cuda.synchronize()
-    np.savez(os.path.join(tmp, f"rccl_{exchange}_{direct_capture}_{int(split)}.npz"), xu=m.user_embedding.weight.detach().cpu().numpy(),
+    np.savez(os.path.join(tmp, f"rccl_{exchange}_{direct_capture}_{int(split)}_{int(sparse)}.npz"), xu=m.user_embedding.weight.detach().cpu().numpy(),
              xi=m.item_embedding.weight.detach().cpu().numpy(), losses=np.array(losses), used=cdist.exchange_mode_used())
     dist.destroy_process_group()
 
@@ -163,14 +166,17 @@ def test_captured_exchanges_on_a_one_rank_rccl_group():
     import torch.multiprocessing as mp
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for exchange, dc, split in (("allreduce", "rs_ag", False), ("p2p", "rs_ag", False), ("direct", "p2p", False),
-                                    ("direct", "rs_ag", False), ("allreduce", "rs_ag", True), ("p2p", "rs_ag", True),
-                                    ("rs_ag", "rs_ag", True)):
+        for exchange, dc, split, sparse in (("allreduce", "rs_ag", False, False), ("p2p", "rs_ag", False, False),
+                                            ("direct", "p2p", False, False), ("direct", "rs_ag", False, False),
+                                            ("allreduce", "rs_ag", True, False), ("p2p", "rs_ag", True, False),
+                                            ("rs_ag", "rs_ag", True, False), ("allreduce", "rs_ag", True, True),
+                                            ("p2p", "rs_ag", True, True)):
             # split=True: every exchange in flight under the next launches (RCCL's own stream / the p2p side stream, forked
-            # and joined inside the captured graph)
-            mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, exchange, dc, split), nprocs=1, join=True)
-            out[(exchange, dc, split)] = dict(np.load(os.path.join(tmp, f"rccl_{exchange}_{dc}_{int(split)}.npz")))
-    ref = out[("allreduce", "rs_ag", False)]
+            # and joined inside the captured graph); sparse=True: + the row-sparse backward (its bitmap all-gathers are
+            # RCCL calls inside the graph too)
+            mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, exchange, dc, split, sparse), nprocs=1, join=True)
+            out[(exchange, dc, split, sparse)] = dict(np.load(os.path.join(tmp, f"rccl_{exchange}_{dc}_{int(split)}_{int(sparse)}.npz")))
+    ref = out[("allreduce", "rs_ag", False, False)]
     for key, r in out.items():
         # two runs differ by the order of the BPR backward's atomic row adds (~1e-7 relative on a gradient); Adam turns a
         # gradient that is ALL rounding noise into a full step, so a handful of elements may differ by lr: count them
@@ -178,7 +184,7 @@ def test_captured_exchanges_on_a_one_rank_rccl_group():
             d = np.abs(r[name] - ref[name])
             assert (d > 2e-6).mean() <= 1e-4 and np.median(d) <= 1e-7, (key, name, float(d.max()))
         assert np.allclose(r["losses"], ref["losses"], rtol=1e-5), key
-    assert "p2p" in str(out[("direct", "p2p", False)]["used"]) and "rs_ag" in str(out[("direct", "rs_ag", False)]["used"])
+    assert "p2p" in str(out[("direct", "p2p", False, False)]["used"]) and "rs_ag" in str(out[("direct", "rs_ag", False, False)]["used"])
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -198,17 +204,19 @@ def test_p2p_exchange_sums_like_an_all_reduce(world):
         assert np.array_equal(r[0]["got"], r[k]["got"])
 
 
-@pytest.mark.parametrize("L,world,exchange,split", [(1, 2, "allreduce", False), (3, 2, "allreduce", False),
-                                                    (2, 4, "allreduce", False), (3, 2, "p2p", False), (2, 4, "p2p", False),
-                                                    (3, 2, "allreduce", True), (2, 4, "p2p", True), (1, 2, "p2p", True)])
-def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world, exchange, split):
+@pytest.mark.parametrize("L,world,exchange,split,sparse", [
+    (1, 2, "allreduce", False, False), (3, 2, "allreduce", False, False), (2, 4, "allreduce", False, False),
+    (3, 2, "p2p", False, False), (2, 4, "p2p", False, False), (3, 2, "allreduce", True, False), (2, 4, "p2p", True, False),
+    (1, 2, "p2p", True, False), (3, 2, "allreduce", True, True), (4, 4, "p2p", True, True), (2, 2, "allreduce", True, True)])
+def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world, exchange, split, sparse):
     """split=True: the launch sequence of large item tables (dist.FusedShardedLightGCNStep._launch_split) -- every joined
-    launch as its two row blocks, every exchange travelling under the launches that follow it."""
+    launch as its two row blocks, every exchange travelling under the launches that follow it.  sparse=True: + the
+    row-sparse backward (row lists at L >= 3, gated gathers, item bitmaps united over the ranks)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, _free_port(), tmp, L, exchange, split), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), tmp, L, exchange, split, sparse), nprocs=world, join=True)
         r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
     # the whole-graph reference: the oracle's loss gradient of the mean over the ranks' batches + Adam, in fp64
     from chaorec_amd import dist as cdist
@@ -275,6 +283,43 @@ def test_split_launches_equal_the_joined_launches_bit_for_bit():
     for a, b in zip(out[False][1:], out[True][1:]):
         d = (a - b).abs()
         assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7
+
+
+def test_sharded_rowsparse_backward_equals_the_dense_one():
+    """One process, no group, captured: the split step with the row-sparse backward against the same step with dense
+    launches -- the same tables after three Adam steps up to the BPR backward's atomic-add order (the propagates themselves
+    give the same bits: tests/test_gpu_round4.py), the step's own frontier buffers back to all-zero."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from chaorec_amd import dist as cdist
+    from chaorec_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    edges, x0, _ = _problem()
+    for L in (2, 3, 4):
+        out = {}
+        for sparse in (False, True):
+            shard = cdist.UserShard.from_local(edges, [0, U], I, 1, 0, dev)
+            m = cdist.ShardedLightGCN(shard, None, D, 1e-3, L, dev, seed=1).to(dev)
+            with torch.no_grad():
+                m.user_embedding.weight.copy_(x0[:U])
+                m.item_embedding.weight.copy_(x0[U:])
+            step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True,
+                                                  capture=True, split=True, sparse_bwd=sparse)
+            for t in range(T):
+                rng = np.random.default_rng(100 * t)
+                sel = rng.choice(len(shard.local_edges), B, replace=False)
+                users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64)).to(dev)
+                pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64)).to(dev)
+                neg = torch.from_numpy(rng.integers(U, U + I, B)).to(dev)
+                step(users, pos, neg)
+            torch.cuda.synchronize()
+            assert float(step.G.abs().max()) == 0.0
+            if sparse:
+                assert float(step.Z.abs().max()) == 0.0 and int(step._bits_all.abs().max()) == 0
+            out[sparse] = (m.user_embedding.weight.detach().cpu(), m.item_embedding.weight.detach().cpu())
+        for a, b in zip(out[False], out[True]):
+            d = (a - b).abs()
+            assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7, L
 
 
 def _calibrate_worker(rank, world, port, tmp, backend):
