@@ -392,9 +392,9 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         launch = ((f"captured hipGraph, {stepper.steps_per_replay} steps per replay" if not args.no_graph
                    else "eager launches") + ", fused step (2L+1 kernels per step + one loss-bookkeeping launch per replay)")
 
-        def run_steps(n):          # whole replays of steps_per_replay steps, single-step replays for the remainder
+        def run_steps(n, full_last=True):   # whole replays of steps_per_replay steps, single-step replays for the remainder
             n_loss[0] += n
-            stepper.run(n)
+            stepper.run(n, full_last=full_last)
     else:
         acc0 = torch.zeros((), device=dev)
 
@@ -409,7 +409,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             acc0.zero_()
         launch = ("captured hipGraph per step" if graphed is not None else "eager launches") + ", autograd step"
 
-        def run_steps(n):
+        def run_steps(n, full_last=True):
             for _ in range(n):
                 n_loss[0] += 1
                 if graphed is not None:
@@ -420,7 +420,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 loss.backward()
                 opt.step()
 
-    run_steps(warmup)
+    run_steps(warmup, full_last=False)
     torch.cuda.synchronize()
     loss_sum.zero_()
     if not fused:
@@ -429,17 +429,37 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     # The timed region is a block of EXACTLY `steps` steps between two synchronisations.  A block of the driver's 20
     # sports steps is 2.5 ms (two graph replays): too short to quote alone, so the block is repeated until >= 50 ms
     # have been timed and the MEDIAN block is the one reported; every block's ms/step is in `ms_per_step_blocks`.
+    # A step built with the LIGHT forward (large graphs: optim.FusedLightGCNStep.light) computes the propagated table in the
+    # rows its loss reads; the timed steps are consecutive steps INSIDE an epoch, as the training loop runs them -- the one
+    # step per epoch that precedes the evaluation and leaves the whole table behind is timed separately below.
     blocks = []
     while True:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(steps)
+        run_steps(steps, full_last=False)
         torch.cuda.synchronize()
         blocks.append(time.perf_counter() - t0)
         if sum(blocks) >= MIN_TIMED_S or len(blocks) >= 64:
             break
     dt = float(np.median(blocks))
     ms_per_step = dt / steps * 1e3
+    forward_note = None
+    if fused and stepper.light:
+        n_full = 3
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_full):
+            n_loss[0] += 1
+            stepper(full_result=True)
+        torch.cuda.synchronize()
+        full_ms = (time.perf_counter() - t0) / n_full * 1e3
+        forward_note = {"timed_steps": "light", "ms_per_step_full_result": full_ms, "full_steps_per_epoch": 1,
+                        "steps_per_epoch": max(E // B, 1),
+                        "what": "a light step draws its batch first and runs the last two forward propagates over the row lists of "
+                                "N1 (the batch rows' 1-hop image) and R0 (the batch rows) only: loss, gradient and updated tables are "
+                                "the full step's bit for bit (tests/test_gpu_round4.py); the ONE step of an epoch that precedes the "
+                                "evaluation computes every row (model.result for gene_ranklist, the reference's stale-result quirk) "
+                                "and costs ms_per_step_full_result"}
     loss_mean = (float(loss_sum.item()) if fused else float(acc0.item())) / max(n_loss[0], 1)
     msgs_per_step = 2 * L * e_dir
 
@@ -456,40 +476,72 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         b0, b1, fin, G = (torch.empty_like(x0) for _ in range(4))
         G.zero_()
     use_mean = L <= ops.mean_terms_limit(D)
-    plain, whole, src = [], [], x0
+    plain, whole, sparse_calls, src = [], [], [], x0
     xs = [x0]
-    for l in range(L - 1 if use_mean else L):        # forward propagates (ops.forward_layers)
-        y = b0 if l % 2 == 0 else b1
-        if use_mean:
-            plain.append((lambda src=src, y=y: ops.spmm_raw(csr, src, y=y), csr, D))
-        else:
-            last = l == L - 1
-            plain.append((lambda src=src, y=y, l=l, last=last: ops.spmm_raw(
-                csr, src, y=None if last else y, acc=fin, acc_init=x0 if l == 0 else None, acc_w=w, want_y=not last), csr, D))
-        src = y
-        xs.append(y)
-    whole += plain
-    if use_mean:                                     # the last forward propagate with the whole layer mean in its epilogue
-        whole.append((lambda: ops.spmm_mean_raw(csr, xs[-1], xs, w, fin), csr, D))
-    # backward: g_l = A g_{l+1} + w G.  The fused step runs the first two of these launches in their ROW-SPARSE form (the batch
-    # gradient G has 3 B non-zero rows: optim.FusedLightGCNStep.sparse_bwd): they are replayed as the step issues them, over
-    # the G and the row bitmaps ONE real BPR launch leaves behind -- and they are not `plain` launches of the dense kernel
-    # (their model bytes are not the dense kernel's: the roofline below is the dense launches').
+    # The fused step runs some of its propagates over ROW LISTS / with gated gathers (optim.FusedLightGCNStep: the batch
+    # gradient G has 3 B non-zero rows R0, its 1-hop image N1 is a part of the graph; a light step also restricts its last two
+    # FORWARD propagates to N1 / R0): they are replayed as the step issues them, over the G, bitmaps and lists ONE real batch
+    # leaves behind -- and they are not `plain` launches of the dense kernel (their model bytes are not the dense kernel's:
+    # the roofline below is the dense launches').
     sparse_bwd = bool(fused and getattr(stepper, "sparse_bwd", False) and G is stepper.G)
-    if sparse_bwd:
+    light = bool(sparse_bwd and getattr(stepper, "light", False))
+    if light:
+        ops.batch_rows(stepper.ids, stepper.bits[0], U, stepper._list0, stepper._list0_n, edges=edges_dev, hist=model.hist,
+                       num_user=U, num_item=I, seed=4242, step=7)
+        ops.bpr_fwd_bwd(stepper.final, U, G, B, ops.VARIANT_LOG_SIGMOID_EPS, reg, stepper.coef, stepper.ws, stepper.ids,
+                        num_user=U, num_item=I)
+    elif sparse_bwd:
         ops.bpr_fwd_bwd(stepper.final, U, G, B, ops.VARIANT_LOG_SIGMOID_EPS, reg, stepper.coef, stepper.ws, stepper.ids,
                         edges=edges_dev, hist=model.hist, num_user=U, num_item=I, seed=4242, step=7, row_bits=stepper.bits[0])
+
+    def expand_n1():
+        return ops.expand_row_bits(csr, stepper.bits[0], stepper.bits[1], stepper._row_list, stepper._list_n)
+
+    if light:
+        for l in range(L - 2):                       # dense layers 1 .. L-2
+            y = b0 if l % 2 == 0 else b1
+            plain.append((lambda src=src, y=y: ops.spmm_raw(csr, src, y=y), csr, D))
+            src = y
+            xs.append(y)
+        whole += plain
+        y = b0 if (L - 2) % 2 == 0 else b1
+        sparse_calls.append(("forward layer L-1 over N1's row list (expansion of R0 included)", (lambda src=src, y=y: (
+            expand_n1(), ops.spmm_rowlist_raw(csr, src, y, stepper._row_list, stepper._list_n, long_rows=stepper._long)), csr, D)))
+        xs.append(y)
+        sparse_calls.append(("forward layer L over R0's row list + layer mean", (lambda xs=list(xs): ops.spmm_rowlist_raw(
+            csr, xs[-1], None, stepper._list0, stepper._list0_n, mean_out=fin, mean_terms=xs, mean_w=w, long_rows=stepper._long), csr, D)))
+        whole += [c for _, c in sparse_calls]
+    else:
+        for l in range(L - 1 if use_mean else L):    # forward propagates (ops.forward_layers)
+            y = b0 if l % 2 == 0 else b1
+            if use_mean:
+                plain.append((lambda src=src, y=y: ops.spmm_raw(csr, src, y=y), csr, D))
+            else:
+                last = l == L - 1
+                plain.append((lambda src=src, y=y, l=l, last=last: ops.spmm_raw(
+                    csr, src, y=None if last else y, acc=fin, acc_init=x0 if l == 0 else None, acc_w=w, want_y=not last), csr, D))
+            src = y
+            xs.append(y)
+        whole += plain
+        if use_mean:                                 # the last forward propagate with the whole layer mean in its epilogue
+            whole.append((lambda: ops.spmm_mean_raw(csr, xs[-1], xs, w, fin), csr, D))
+    n_epilogue = (1 if (use_mean and not light) else 0)
+    # backward: g_l = A g_{l+1} + w G
     g, alpha = G, w
     for l in range(L - 1):
         y = b0 if l % 2 == 0 else b1
         if sparse_bwd and l == 0 and L >= 3:
-            whole.append((lambda g=g, y=y, alpha=alpha: (
-                ops.expand_row_bits(csr, stepper.bits[0], stepper.bits[1], stepper._row_list, stepper._list_n),
-                ops.spmm_rowlist_raw(csr, g, y, stepper._row_list, stepper._list_n, alpha=alpha, z=G, beta=w,
-                                     src_bits=stepper.bits[0], z_bits=stepper.bits[0])), csr, D))
+            sparse_calls.append(("backward propagate 1 over N1's row list" + ("" if light else " (expansion of R0 included)"),
+                                 (lambda g=g, y=y, alpha=alpha: (
+                                     None if light else expand_n1(),
+                                     ops.spmm_rowlist_raw(csr, g, y, stepper._row_list, stepper._list_n, alpha=alpha, z=G, beta=w,
+                                                          src_bits=stepper.bits[0], z_bits=stepper.bits[0])), csr, D)))
+            whole.append(sparse_calls[-1][1])
         elif sparse_bwd and l < 2:
-            whole.append((lambda g=g, y=y, alpha=alpha, l=l: ops.spmm_rowsparse_raw(
-                csr, g, y, alpha=alpha, z=G, beta=w, src_bits=stepper.bits[l], z_bits=stepper.bits[0]), csr, D))
+            sparse_calls.append(("backward propagate %d, every row, gathers gated by the source's bitmap" % (l + 1),
+                                 (lambda g=g, y=y, alpha=alpha, l=l: ops.spmm_rowsparse_raw(
+                                     csr, g, y, alpha=alpha, z=G, beta=w, src_bits=stepper.bits[l], z_bits=stepper.bits[0]), csr, D)))
+            whole.append(sparse_calls[-1][1])
         else:
             plain.append((lambda g=g, y=y, alpha=alpha: ops.spmm_raw(csr, g, y=y, alpha=alpha, z=G, beta=w), csr, D))
             whole.append(plain[-1])
@@ -499,15 +551,15 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         bc = torch.tensor([0.1, 0.0316], device=dev)
         whole.append((lambda: ops.spmm_adam_raw(csr, g, pc, mc, vc, bc, 1e-3, (0.9, 0.999), 1e-8, 0.0, alpha=alpha, z=G,
                                                 beta=w, clear_z=False), csr, D))
+        n_epilogue += 1
     heavy_graph = csr.nnz > 50_000_000
     avg_spmm_ms, model_bytes, compulsory = time_spmm_chain(plain, passes=3 if heavy_graph else 5)
     whole_ms, _, _ = time_spmm_chain(whole, passes=3 if heavy_graph else 5)
     whole_ms *= len(whole)                           # all SpMM-family launches of ONE step, boundaries included
     n_plain, n_whole = len(plain), len(whole)
     sparse_ms = None
-    if sparse_bwd:
-        sparse_calls = [c for c in whole if c not in plain][1 if use_mean else 0:][:min(L - 1, 2)]
-        sparse_each = [time_spmm_chain([c], passes=3 if heavy_graph else 5)[0] for c in sparse_calls]
+    if sparse_calls:
+        sparse_each = [time_spmm_chain([c], passes=3 if heavy_graph else 5)[0] for _, c in sparse_calls]
         sparse_ms = float(np.mean(sparse_each))
         G.zero_()                                    # (the step's contract: all-zero between steps, bitmaps clear)
         stepper._bits_all.zero_()
@@ -538,22 +590,23 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 "spmm_launches_of_one_step": {"launches": n_whole, "us": whole_ms * 1e3,
                                               "share_of_ms_per_step": whole_ms / ms_per_step,
                                               "what": f"the step's {n_whole} SpMM-family launches ({n_plain} dense plain"
-                                                      + (f" + {n_whole - n_plain - 2} row-sparse backward" if sparse_ms is not None else "")
-                                                      + " + layer-mean epilogue + Adam epilogue) replayed in order as one hipGraph"},
+                                                      + (f" + {len(sparse_calls)} over row lists / with gated gathers" if sparse_calls else "")
+                                                      + f" + {n_epilogue} with the layer-mean / Adam epilogue) replayed in order as one hipGraph"
+                                                      + ("; a LIGHT step (forward restricted to the rows the loss reads)" if light else "")},
                 "note": ("embedding table (%.1f MB) is Infinity-Cache resident at this config: the fraction is against "
                          "the HBM peak but the bytes are served on-die (SURVEY 8(d) reporting rule)" % table_mb)
                 if table_mb < 256 else
                 ("embedding table %.0f MB, beyond the 256 MiB Infinity Cache: HBM-bound regime; `achieved` counts the "
                  "no-reuse CSR model bytes, `traffic` (when present) the measured FETCH_SIZE+WRITE_SIZE bytes" % table_mb)}
     if sparse_ms is not None:
-        roofline["rowsparse_backward_launches"] = {
-            "kernel": spmm_kernel_name(D, rowsparse=True), "per_step": min(L - 1, 2), "avg_launch_us": sparse_ms * 1e3,
-            "each_us": [t * 1e3 for t in sparse_each],
-            "note": "the first two backward propagates work on row-sparse operands (the batch gradient G: 3 B non-zero rows; its 1-hop "
-                    "image N1): the first runs over the LIST of N1's rows (chaorec_expand_row_bits + chaorec_spmm_csr_rowlist_f32), "
-                    "the second is the ordinary launch with its gathers gated by N1's bitmap (chaorec_spmm_csr_rowsparse_f32) -- the "
-                    "same sums bit for bit; each_us = [first (expansion included), second]; timed over the G and bitmap one real BPR "
-                    "launch left"}
+        roofline["rowsparse_launches"] = {
+            "kernels": [spmm_kernel_name(D, rowsparse=True), "spmm_rowlist_kernel"], "per_step": len(sparse_calls),
+            "each_us": {name: t * 1e3 for (name, _), t in zip(sparse_calls, sparse_each)},
+            "note": "propagates whose operands or results live in the batch's frontier (R0 = the 3 B batch rows, N1 = their 1-hop image): "
+                    "over the LIST of N1's / R0's rows (chaorec_expand_row_bits + chaorec_spmm_csr_rowlist_f32) or, where every row has "
+                    "to be written, as the ordinary launch with its gathers gated by the source's bitmap "
+                    "(chaorec_spmm_csr_rowsparse_f32) -- the same sums bit for bit; timed over the G, bitmaps and lists one real batch "
+                    "left"}
     if traffic:
         roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
     if kernel_only_us:
@@ -633,6 +686,9 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     heavy = 2.0 * U * I * D > 1e15
     if heavy:
         reps_rank = 1
+    if fused:
+        run_steps(1)                        # (the chain above wrote into the step's buffers; a full step leaves model.result)
+        steps_done += 1
     early = time_ranklist(False)
     extra = trained_steps - steps_done - (STEADY_EVALS + 1) * epoch_steps
     if extra > 0 and (extra + (STEADY_EVALS + 1) * epoch_steps) * ms_per_step < 10_000:
@@ -656,7 +712,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                 roofline=roofline, score_ms=score_ms, score_state=state, early_ms=early_ms, early_st=early_st,
                 cold_ms=rk["cold_ms"], cold_st=rk["cold_st"], steady="steady_ms" in rk,
                 score_st=st, score_tf=tf, host_rank_ms=host_ms, edges=edges, reg=reg, table_mb=table_mb,
-                build_s=build_s, blocks_ms_per_step=[b / steps * 1e3 for b in blocks])
+                build_s=build_s, blocks_ms_per_step=[b / steps * 1e3 for b in blocks], forward=forward_note)
 
 
 def scoring_roofline(r):
@@ -714,6 +770,7 @@ def main_single(args, dev):
                     else "FusedAdam (chaorec_adam_step_f32)"),
                    "parallelism": "single GPU", "host_build_seconds": r["build_s"]},
         "roofline": r["roofline"], "roofline_scoring": scoring_roofline(r), "loss_mean": r["loss_mean"],
+        **({"forward": r["forward"]} if r.get("forward") else {}),
     }
     edges, reg = r["edges"], r["reg"]
     # --- the HBM-bound regime in the same run: one GPU's share of BASELINE configs[4] -----------------------------
@@ -731,6 +788,7 @@ def main_single(args, dev):
             "gene_ranklist_mode": "steady state" if h["steady"] else "cold: sampled thresholds",
             "gene_ranklist_ms_cold": h["cold_ms"],
             "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"],
+            **({"forward": h["forward"]} if h.get("forward") else {}),
         }
         del h
         torch.cuda.empty_cache()
@@ -745,6 +803,7 @@ def main_single(args, dev):
                 "unit": "directed-edge messages/s", "roofline": f["roofline"], "host_build_seconds": f["build_s"],
                 "gene_ranklist_ms_cold": f["cold_ms"], "users_scored_per_s_cold": f["U"] / (f["cold_ms"] * 1e-3),
                 "roofline_scoring": scoring_roofline(f), "loss_mean": f["loss_mean"],
+                **({"forward": f["forward"]} if f.get("forward") else {}),
             }
             del f
             torch.cuda.empty_cache()

@@ -125,6 +125,11 @@ class LightGCN(nn.Module):
     def gene_ranklist(self, topk=50, to_cpu=True):
         """Model/LightGCN.py:137-162 -> LongTensor [U, topk] of GLOBAL item ids on the CPU.
         Uses the stale self.result of the last training forward, as the reference does."""
+        if self.result is None:
+            raise RuntimeError("LightGCN.gene_ranklist: no propagated table -- the last training step was a light one "
+                               "(optim.FusedLightGCNStep with light_forward: only its batch's rows were computed).  Run the "
+                               "step before an evaluation with full_result=True (FusedLightGCNStep.run does), or call "
+                               "forward() first")
         return ranking.gene_ranklist(self.result, self.num_user, self.num_item, self.hist, 1e-6, topk, to_cpu=to_cpu,
                                       state=ranking.state_of(self))
 

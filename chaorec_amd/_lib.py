@@ -46,7 +46,11 @@ SIGNATURES = {
     "chaorec_or_words_u32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int64, c_ptr]),
     "chaorec_spmm_csr_rowlist_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_float, c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr,
-                                                    ctypes.c_int64, c_ptr]),
+                                                    ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr,
+                                                    ctypes.c_int64, ctypes.c_int32, c_ptr]),
+    "chaorec_batch_rows": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr,
+                                          c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
     "chaorec_bpr_fwd_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64,
                                                ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, c_ptr, c_ptr, c_ptr,
                                                c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,

@@ -468,6 +468,44 @@ __global__ __launch_bounds__(256) void draw_batch_kernel(
   out_neg[b] = n + item_offset;
 }
 
+// The batch BEFORE the forward (a training step whose forward is restricted to the rows its loss reads): draw_batch_kernel's
+// triples -- or a given batch -- plus the three table rows of every sample flagged in a row bitmap (bit u, bit
+// bits_item_offset + pos, bit bits_item_offset + neg) and every row flagged FIRST by this launch appended to a list (no
+// duplicates, arbitrary order; *list_n zero on entry).  The triples are bpr_fwd_bwd_drawn_kernel's for the same
+// (seed, step, permutation position): a step that draws here and hands the ids to that kernel trains on the same batch.
+__global__ __launch_bounds__(256) void batch_rows_kernel(
+    const int64_t *__restrict__ edges, int64_t n_edges, const int64_t *__restrict__ hist_rowptr,
+    const int32_t *__restrict__ hist_col, int B, int64_t num_user, uint32_t num_item, uint64_t seed, uint64_t step,
+    const int64_t *__restrict__ step_dev, const int64_t *__restrict__ perm, const int64_t *__restrict__ perm_pos,
+    int64_t pos_offset, int64_t *users, int64_t *pos, int64_t *neg, uint32_t *row_bits, int64_t bits_item_offset,
+    int32_t *list, int32_t *list_n, int64_t list_cap) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int64_t u, p, n;
+  if (edges) {
+    if (step_dev) step += (uint64_t)step_dev[0];
+    draw_triple(edges, n_edges, hist_rowptr, hist_col, num_user, num_item, seed, step, (uint32_t)b, u, p, n, perm,
+                perm ? perm_pos[0] + pos_offset : 0);
+    users[b] = u;
+    pos[b] = p;
+    neg[b] = n;
+  } else {
+    u = users[b];
+    p = pos[b];
+    n = neg[b];
+  }
+  const int64_t rows[3] = {u, bits_item_offset + p, bits_item_offset + n};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t m = 1u << (rows[k] & 31);
+    const uint32_t old = atomicOr(row_bits + (rows[k] >> 5), m);
+    if (list && !(old & m)) {
+      const int at = atomicAdd(list_n, 1);
+      if (at < list_cap) list[at] = (int32_t)rows[k];
+    }
+  }
+}
+
 // rows = [pos - offset ; neg - offset]: Model.loss()'s first lines (Model/FREEDOM.py:195-196: pos_items - self.num_user,
 // neg_items - self.num_user) and the row list of the batch's 2 B items in one launch instead of three
 __global__ __launch_bounds__(256) void shift_cat_kernel(const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
@@ -492,6 +530,23 @@ extern "C" int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const i
                      hist_rowptr, hist_col, B, num_user, (uint32_t)num_item, seed, step, step_dev, out_users,
                      out_pos, out_neg, item_offset);
   return check_launch("draw_batch_kernel");
+}
+
+extern "C" int chaorec_batch_rows(const int64_t *edges, int64_t n_edges, const int64_t *hist_rowptr, const int32_t *hist_col,
+                                  int32_t B, int64_t num_user, int32_t num_item, uint64_t seed, uint64_t step,
+                                  const int64_t *step_dev, const int64_t *perm, const int64_t *perm_pos, int64_t pos_offset,
+                                  int64_t *users, int64_t *pos, int64_t *neg, uint32_t *row_bits, int64_t bits_item_offset,
+                                  int32_t *list, int32_t *list_n, int64_t list_cap, void *stream) {
+  if (!users || !pos || !neg || !row_bits) return fail(CHAOREC_E_INVALID, "batch_rows: NULL argument");
+  if (edges && !hist_rowptr) return fail(CHAOREC_E_INVALID, "batch_rows: a drawn batch needs the history rows");
+  if (B <= 0 || (edges && (n_edges <= 0 || num_item <= 0))) return fail(CHAOREC_E_INVALID, "batch_rows: bad sizes");
+  if ((list == nullptr) != (list_n == nullptr) || (list && list_cap <= 0))
+    return fail(CHAOREC_E_INVALID, "batch_rows: list, list_n and list_cap come together");
+  if ((perm == nullptr) != (perm_pos == nullptr)) return fail(CHAOREC_E_INVALID, "batch_rows: perm and perm_pos come together");
+  hipLaunchKernelGGL(batch_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, edges, n_edges, hist_rowptr,
+                     hist_col, B, num_user, (uint32_t)num_item, seed, step, step_dev, perm, perm_pos, pos_offset, users, pos,
+                     neg, row_bits, bits_item_offset, list, list_n, list_cap);
+  return check_launch("batch_rows_kernel");
 }
 
 extern "C" int chaorec_shift_cat_i64(const int64_t *pos, const int64_t *neg, int64_t offset, int32_t B, int64_t *out,

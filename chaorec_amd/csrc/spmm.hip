@@ -738,14 +738,49 @@ __global__ __launch_bounds__(256) void or_words_kernel(uint32_t *dst, const uint
 // entries are walked in CSR order; an entry whose source row is not flagged in src_bits is skipped (its term is +0), the
 // others are gathered and added with separately rounded product and sum -- the arithmetic, and the bits, of
 // spmm_csr_ordered_kernel.  Rows outside the list are not touched.
+// mean (optional): the layer mean of the LAST forward propagate for the listed rows -- mean.out[r] = ((w t0[r] + w t1[r]) + ..)
+// + w s with s the row's propagated value, chaorec_spmm_csr_mean_f32's association -- for a training step that needs the
+// propagated table in its batch's rows only; y may then be NULL.
+struct ListMean {
+  const float *t[4];
+  int n;
+  float w;
+  float *out;
+};
+
+// Rows above `long_t` entries (long_list given) are not walked here: one lane group taking a popular item's 1e4-1e5 entries one
+// after the other would be the launch's tail.  They are appended to long_list and spmm_rowlist_long_kernel -- a workgroup
+// per row -- takes them.
+struct LongRows {
+  int32_t *list;      // rows deferred by the short-row kernel
+  int32_t *cnt;       // [0] = how many, [1] = workgroups of the long-row kernel that are done (both zero between launches)
+  int64_t cap;
+  int t;              // a row with more entries than this is a long row
+};
+
+__device__ __forceinline__ void rowlist_epilogue(int64_t r, int D4, int li, float4 sum, float alpha, const float *z, float beta,
+                                                 float4 zrow, float *y, const ListMean &mean) {
+  const size_t o = (size_t)r * D4 + li;
+  float4 s = mul_rn4(alpha, sum);
+  if (z) s = add_rn4(s, mul_rn4(beta, zrow));
+  if (y) reinterpret_cast<float4 *>(y)[o] = s;
+  if (mean.out) {
+    float4 a = mul_rn4(mean.w, reinterpret_cast<const float4 *>(mean.t[0])[o]);
+    for (int k = 1; k < mean.n; ++k) a = add_rn4(a, mul_rn4(mean.w, reinterpret_cast<const float4 *>(mean.t[k])[o]));
+    reinterpret_cast<float4 *>(mean.out)[o] = add_rn4(a, mul_rn4(mean.w, s));
+  }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_rowlist_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                            const float *__restrict__ val, const float *__restrict__ x,
                                                            float *__restrict__ y, int D4, float alpha, const float *z, float beta,
                                                            const uint32_t *__restrict__ src_bits,
                                                            const uint32_t *__restrict__ z_bits, const int32_t *__restrict__ list,
-                                                           const int32_t *__restrict__ list_n, int64_t list_cap) {
+                                                           const int32_t *__restrict__ list_n, int64_t list_cap,
+                                                           const ListMean mean, const LongRows lr) {
   constexpr int NG = kWave / LPR;
+  constexpr int UNR = 8;                  // gathered rows in flight per group (ungated walk)
   const int lane = threadIdx.x & 63, sub = lane / LPR, li = lane % LPR;
   const int64_t n = min((int64_t)list_n[0], list_cap);
   const int64_t slots = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;
@@ -753,39 +788,169 @@ __global__ __launch_bounds__(256) void spmm_rowlist_kernel(const int64_t *__rest
   for (int64_t i = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * NG + sub;; i += slots) {
     // (wave-uniform exit: the groups of a wave walk i, i+1, ..; shuffles below stay inside a group's own lanes)
     if (i - sub >= n) break;
-    const bool ok = i < n;
+    bool ok = i < n;
     const int64_t r = ok ? list[i] : 0;
     const int64_t e0 = ok ? rowptr[r] : 0;
-    const int deg = ok ? (int)(rowptr[r + 1] - e0) : 0;
+    int deg = ok ? (int)(rowptr[r + 1] - e0) : 0;
+    if (lr.list && deg > lr.t) {          // (group-uniform)
+      if (li == 0) {
+        const int at = atomicAdd(lr.cnt, 1);
+        if (at < lr.cap) lr.list[at] = (int32_t)r;
+      }
+      ok = false;
+      deg = 0;
+    }
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok && z && li < D4 && (!z_bits || row_bit(z_bits, r))) zrow = reinterpret_cast<const float4 *>(z)[(size_t)r * D4 + li];
     const int dmax = wave_max_i32(deg);
-    for (int base = 0; base < dmax; base += LPR) {
-      int c = 0, keep = 0;
-      float v = 0.f;
-      if (base + li < deg) {
-        c = col[e0 + base + li];
-        v = val[e0 + base + li];
-        keep = (!src_bits || row_bit(src_bits, c)) ? 1 : 0;
+    if (!src_bits) {
+      // every entry is gathered: (col, val) blocks of LPR entries, UNR source rows in flight, adds in entry order
+      for (int base = 0; base < dmax; base += LPR) {
+        int c = 0;
+        float v = 0.f;
+        if (base + li < deg) {
+          c = col[e0 + base + li];
+          v = val[e0 + base + li];
+        }
+        const int nn = min(LPR, deg - base);
+        const int nmax = min(LPR, dmax - base);
+        for (int j = 0; j < nmax; j += UNR) {
+          int cj[UNR];
+          float vj[UNR];
+          float4 xv[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int src = sub * LPR + ((j + u) & (LPR - 1));
+            cj[u] = __shfl(c, src, 64);
+            vj[u] = __shfl(v, src, 64);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j + u < nn && li < D4) xv[u] = x4[(size_t)cj[u] * (size_t)D4 + li];
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u)
+            if (j + u < nn) sum = add_rn4(sum, mul_rn4(vj[u], xv[u]));
+        }
       }
-      // the flagged entries of this block, in entry order (a group-local mask: LPR <= 64 bits)
-      unsigned long long m = __ballot(keep != 0);
-      m = (m >> (sub * LPR)) & (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull));
-      while (__any(m != 0ull)) {            // (trip counts differ between the wave's groups: every lane stays in the loop)
-        const bool has = m != 0ull;
-        const int j = has ? __builtin_ctzll(m) : 0;
-        if (has) m &= m - 1;
-        const int src = sub * LPR + j;
-        const int cj = __shfl(c, src, 64);
-        const float vj = __shfl(v, src, 64);
-        if (has && li < D4) sum = add_rn4(sum, mul_rn4(vj, x4[(size_t)cj * (size_t)D4 + li]));
+    } else {
+      for (int base = 0; base < dmax; base += LPR) {
+        int c = 0, keep = 0;
+        float v = 0.f;
+        if (base + li < deg) {
+          c = col[e0 + base + li];
+          v = val[e0 + base + li];
+          keep = row_bit(src_bits, c) ? 1 : 0;
+        }
+        // the flagged entries of this block, in entry order (a group-local mask: LPR <= 64 bits)
+        unsigned long long m = __ballot(keep != 0);
+        m = (m >> (sub * LPR)) & (LPR == 64 ? ~0ull : ((1ull << LPR) - 1ull));
+        while (__any(m != 0ull)) {            // (trip counts differ between the wave's groups: every lane stays in the loop)
+          const bool has = m != 0ull;
+          const int j = has ? __builtin_ctzll(m) : 0;
+          if (has) m &= m - 1;
+          const int src = sub * LPR + j;
+          const int cj = __shfl(c, src, 64);
+          const float vj = __shfl(v, src, 64);
+          if (has && li < D4) sum = add_rn4(sum, mul_rn4(vj, x4[(size_t)cj * (size_t)D4 + li]));
+        }
       }
     }
-    if (ok && li < D4) {
-      float4 s = mul_rn4(alpha, sum);
-      if (z) s = add_rn4(s, mul_rn4(beta, zrow));
-      reinterpret_cast<float4 *>(y)[(size_t)r * D4 + li] = s;
+    if (ok && li < D4) rowlist_epilogue(r, D4, li, sum, alpha, z, beta, zrow, y, mean);
+  }
+}
+
+// The long rows of a list launch: ONE WORKGROUP per row.  The row's entries are taken CH at a time: every lane group gathers
+// K source rows and parks the products v * x in an LDS tile, then the row's D columns are summed by D threads walking the
+// tile in ENTRY ORDER -- the sequential CSR-order sum of the other kernels, bit for bit; only the loads are shared.  The
+// walk is a three-stage pipeline: while round i is summed, round i+1's source rows and round i+2's (col, val) are in
+// flight, so a round costs one memory latency, not two dependent ones plus the sum.  The last workgroup to finish zeroes
+// the list's counters for the next launch.
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_rowlist_long_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                const float *__restrict__ val, const float *__restrict__ x,
+                                                                float *__restrict__ y, int D4, float alpha, const float *z,
+                                                                float beta, const uint32_t *__restrict__ z_bits,
+                                                                const ListMean mean, const LongRows lr) {
+  constexpr int NGB = 256 / LPR;        // lane groups per workgroup
+  constexpr int K = 16;                 // source rows per group and round
+  constexpr int CH = NGB * K;           // entries per round (256 / 128 / 64 for D4 = 16 / 32 / 64)
+  __shared__ float4 tile[CH * LPR];     // 64 KiB
+  const int tid = threadIdx.x, g = tid / LPR, li = tid % LPR;
+  const int64_t n = min((int64_t)lr.cnt[0], lr.cap);
+  const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
+  const float *tile_f = reinterpret_cast<const float *>(tile);
+  const int D = 4 * D4;
+  constexpr int DT = 4 * LPR;           // (D4 <= LPR: the tile's rows are LPR float4 wide, the first D4 in use)
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int64_t r = lr.list[i];
+    const int64_t e0 = rowptr[r];
+    const int deg = (int)(rowptr[r + 1] - e0);
+    float s = 0.f;                      // column tid of the running sum (threads tid < D)
+    // BRANCH-FREE loads (an index past the row's end is clamped to its last entry: loaded, parked, never summed) -- a
+    // conditional load makes the compiler wait for each gather before it issues the next
+    int cn[K];                          // round i+2's (col, val)
+    float vn[K];
+    float4 xv[K];                       // round i+1's source rows, as loaded
+    float vx[K];                        //             ... and their values
+    const int lic = min(li, D4 - 1);
+    auto load_cv = [&](int base) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int64_t e = e0 + min(base + g * K + k, deg - 1);
+        cn[k] = col[e];
+        vn[k] = val[e];
+      }
+    };
+    auto gather = [&]() {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        xv[k] = x4[(size_t)cn[k] * (size_t)D4 + lic];
+        vx[k] = vn[k];
+      }
+    };
+    load_cv(0);
+    gather();
+    load_cv(CH);
+    for (int base = 0; base < deg; base += CH) {
+      __syncthreads();                  // (the previous round's sums have read the tile)
+#pragma unroll
+      for (int k = 0; k < K; ++k) tile[(g * K + k) * LPR + li] = mul_rn4(vx[k], xv[k]);
+      __syncthreads();
+      if (base + CH < deg) {            // (block-uniform)
+        gather();                       // round i+1's source rows ...
+        load_cv(base + 2 * CH);         // ... and round i+2's (col, val)
+      }
+      if (tid < D) {
+        // entry e's product of column tid sits at tile_f[e * DT + tid]
+        const float *t = tile_f + tid;
+        const int nn = min(CH, deg - base);
+        if (nn == CH) {
+#pragma unroll 16
+          for (int e = 0; e < CH; ++e) s = add_rn(s, t[e * DT]);
+        } else {
+          for (int e = 0; e < nn; ++e) s = add_rn(s, t[e * DT]);
+        }
+      }
+    }
+    __syncthreads();
+    // the epilogue works on float4s (lanes li < D4 of group 0): hand the column sums over through the tile
+    if (tid < D) reinterpret_cast<float *>(tile)[tid] = s;
+    __syncthreads();
+    if (g == 0 && li < D4) {
+      float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z && (!z_bits || row_bit(z_bits, r))) zrow = reinterpret_cast<const float4 *>(z)[(size_t)r * D4 + li];
+      rowlist_epilogue(r, D4, li, tile[li], alpha, z, beta, zrow, y, mean);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(lr.cnt + 1, 1) == (int)gridDim.x - 1) {
+      lr.cnt[0] = 0;
+      lr.cnt[1] = 0;
     }
   }
 }
@@ -827,19 +992,46 @@ extern "C" int chaorec_or_words_u32(uint32_t *dst, const uint32_t *src, int32_t 
 extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x, float *y,
                                             int64_t n_rows, int32_t D, float alpha, const float *z, float beta,
                                             const uint32_t *src_bits, const uint32_t *z_bits, const int32_t *list,
-                                            const int32_t *list_n, int64_t list_cap, void *stream) {
-  if (!rowptr || !col || !val || !x || !y || !list || !list_n) return fail(CHAOREC_E_INVALID, "spmm (row list): NULL argument");
+                                            const int32_t *list_n, int64_t list_cap, float *mean_out,
+                                            const float *const *mean_terms, int32_t n_mean_terms, float mean_w,
+                                            int32_t *long_list, int32_t *long_cnt, int64_t long_cap, int32_t long_threshold,
+                                            void *stream) {
+  if (!rowptr || !col || !val || !x || !list || !list_n) return fail(CHAOREC_E_INVALID, "spmm (row list): NULL argument");
+  if (!y && !mean_out) return fail(CHAOREC_E_INVALID, "spmm (row list): neither y nor mean_out");
   if (n_rows <= 0 || list_cap <= 0) return fail(CHAOREC_E_INVALID, "spmm (row list): bad sizes");
   const int D4 = D / 4;
   if (D < 64 || D > 256 || (D & 3)) return fail(CHAOREC_E_INVALID, "spmm (row list): D=%d must be a multiple of 4 in [64, 256]", D);
+  if ((long_list == nullptr) != (long_cnt == nullptr) || (long_list && (long_cap <= 0 || long_threshold < 1)))
+    return fail(CHAOREC_E_INVALID, "spmm (row list): long_list, long_cnt, long_cap and long_threshold come together");
+  if (long_list && src_bits) return fail(CHAOREC_E_INVALID, "spmm (row list): the long-row launch gathers every entry (no src_bits)");
+  ListMean mean;
+  std::memset(&mean, 0, sizeof(mean));
+  if (mean_out) {
+    if (!mean_terms || n_mean_terms < 1 || n_mean_terms > 4) return fail(CHAOREC_E_INVALID, "spmm (row list): 1..4 mean terms");
+    for (int k = 0; k < n_mean_terms; ++k) {
+      if (!mean_terms[k]) return fail(CHAOREC_E_INVALID, "spmm (row list): NULL mean term %d", k);
+      mean.t[k] = mean_terms[k];
+    }
+    mean.n = n_mean_terms, mean.w = mean_w, mean.out = mean_out;
+  }
+  LongRows lr;
+  lr.list = long_list, lr.cnt = long_cnt, lr.cap = long_cap, lr.t = long_threshold;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(2048), block(256);        // a fixed grid striding over the device-side list
-#define CHAOREC_ROWLIST_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, src_bits, z_bits, list, list_n, list_cap
+#define CHAOREC_ROWLIST_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, src_bits, z_bits, list, list_n, list_cap, mean, lr
   if (D4 <= 16) hipLaunchKernelGGL((spmm_rowlist_kernel<16>), grid, block, 0, st, CHAOREC_ROWLIST_ARGS);
   else if (D4 <= 32) hipLaunchKernelGGL((spmm_rowlist_kernel<32>), grid, block, 0, st, CHAOREC_ROWLIST_ARGS);
   else hipLaunchKernelGGL((spmm_rowlist_kernel<64>), grid, block, 0, st, CHAOREC_ROWLIST_ARGS);
 #undef CHAOREC_ROWLIST_ARGS
-  return check_launch("spmm_rowlist_kernel");
+  int rc = check_launch("spmm_rowlist_kernel");
+  if (rc != CHAOREC_OK || !long_list) return rc;
+  const dim3 lgrid(1024);                   // one workgroup per long row, striding
+#define CHAOREC_ROWLIST_LONG_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, z_bits, mean, lr
+  if (D4 <= 16) hipLaunchKernelGGL((spmm_rowlist_long_kernel<16>), lgrid, block, 0, st, CHAOREC_ROWLIST_LONG_ARGS);
+  else if (D4 <= 32) hipLaunchKernelGGL((spmm_rowlist_long_kernel<32>), lgrid, block, 0, st, CHAOREC_ROWLIST_LONG_ARGS);
+  else hipLaunchKernelGGL((spmm_rowlist_long_kernel<64>), lgrid, block, 0, st, CHAOREC_ROWLIST_LONG_ARGS);
+#undef CHAOREC_ROWLIST_LONG_ARGS
+  return check_launch("spmm_rowlist_long_kernel");
 }
 
 extern "C" int chaorec_spmm_rows_per_wave(int32_t D) { return rows_per_wave(D); }

@@ -150,18 +150,58 @@ def or_words(dst, src):
     return dst
 
 
-def spmm_rowlist_raw(csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None):
+ROWLIST_LONG_T = int(os.environ.get("CHAOREC_ROWLIST_LONG_T", "256"))
+
+
+def long_row_buffers(csr, threshold=None):
+    """(list int32 [number of rows above the threshold], counters int32 [2] zero, threshold) for spmm_rowlist_raw's long_rows."""
+    t = ROWLIST_LONG_T if threshold is None else int(threshold)
+    n_long = int(((csr.rowptr[1:] - csr.rowptr[:-1]) > t).sum().item())
+    dev = csr.rowptr.device
+    return torch.zeros(max(n_long, 1), dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.int32, device=dev), t
+
+
+def spmm_rowlist_raw(csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None, mean_out=None,
+                     mean_terms=(), mean_w=0.0, long_rows=None):
     """y[r] = alpha * (A x)[r] [+ beta z[r]] for the rows of a device-side list only (chaorec_spmm_csr_rowlist_f32); the other
-    rows of y are not touched.  Same sums, bit for bit, as spmm_raw's for those rows."""
-    _need_cuda(csr.rowptr, x, y, z, src_bits, z_bits, row_list, list_n)
+    rows of y are not touched.  Same sums, bit for bit, as spmm_raw's for those rows.  mean_out / mean_terms / mean_w: the
+    listed rows of the layer mean, spmm_mean_raw's arithmetic (y may then be None).  long_rows = long_row_buffers(csr) (only
+    without src_bits): listed rows above the threshold are computed by a second launch, one workgroup per row."""
+    ll, lc, lt = long_rows if long_rows is not None else (None, None, 0)
+    _need_cuda(csr.rowptr, x, y, z, src_bits, z_bits, row_list, list_n, mean_out, ll, lc, *mean_terms)
     x = _f32c(x)
-    if x.shape[0] != csr.n_cols or y.shape[0] != csr.n_rows or not y.is_contiguous():
+    if x.shape[0] != csr.n_cols or (y is not None and (y.shape[0] != csr.n_rows or not y.is_contiguous())):
         raise ValueError("spmm_rowlist: shape mismatch")
+    terms = None
+    if mean_out is not None:
+        if not 1 <= len(mean_terms) <= 4 or any(t.shape != mean_out.shape or not t.is_contiguous() for t in mean_terms) or \
+                mean_out.shape != (csr.n_rows, x.shape[1]) or not mean_out.is_contiguous():
+            raise ValueError("spmm_rowlist: 1..4 contiguous mean terms of the output's shape")
+        terms = (ctypes.c_void_p * len(mean_terms))(*[t.data_ptr() for t in mean_terms])
     _lib.check(_lib.load().chaorec_spmm_csr_rowlist_f32(_ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(x), _ptr(y), csr.n_rows,
                                                         x.shape[1], alpha, _ptr(z), beta, _ptr(src_bits), _ptr(z_bits),
-                                                        _ptr(row_list), _ptr(list_n), row_list.numel(), _stream()),
+                                                        _ptr(row_list), _ptr(list_n), row_list.numel(), _ptr(mean_out), terms,
+                                                        len(mean_terms), float(mean_w), _ptr(ll), _ptr(lc),
+                                                        ll.numel() if ll is not None else 0, int(lt), _stream()),
                "chaorec_spmm_csr_rowlist_f32")
     return y
+
+
+def batch_rows(ids, row_bits, bits_item_offset, row_list=None, list_n=None, edges=None, hist=None, num_user=0, num_item=0, seed=0,
+               step=0, step_dev=None, perm=None, perm_pos=None, pos_offset=0):
+    """The batch BEFORE the forward (chaorec_batch_rows): ids = (users, pos, neg) int64 [B] -- written when `edges` is given
+    (bpr_fwd_bwd's draw for the same seed / step / permutation position, LOCAL item ids), read otherwise -- and the three
+    table rows of every sample flagged in row_bits (items from bit bits_item_offset on), the rows flagged first appended to
+    row_list / list_n."""
+    _need_cuda(edges, step_dev, perm, perm_pos, row_bits, row_list, list_n, *ids)
+    rowptr, col = hist if hist is not None else (None, None)
+    B = ids[0].numel()
+    rc = _lib.load().chaorec_batch_rows(_ptr(edges), edges.shape[0] if edges is not None else 0, _ptr(rowptr), _ptr(col), B,
+                                        int(num_user), int(num_item), int(seed) & (2**64 - 1), int(step), _ptr(step_dev),
+                                        _ptr(perm), _ptr(perm_pos), int(pos_offset), _ptr(ids[0]), _ptr(ids[1]), _ptr(ids[2]),
+                                        _ptr(row_bits), int(bits_item_offset), _ptr(row_list), _ptr(list_n),
+                                        row_list.numel() if row_list is not None else 0, _stream())
+    _lib.check(rc, "chaorec_batch_rows")
 
 
 def spmm_rowsparse_raw(csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None, out_bits=None, row_bits=None,

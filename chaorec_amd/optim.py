@@ -457,7 +457,9 @@ class FusedLightGCNStep:
     steps can be mixed (the short last batch of an epoch runs through the ordinary path)."""
 
     def __init__(self, model, optimizer, batch_size=1024, edges=None, seed=42, step_dev=None, perm=None, perm_pos=None,
-                 given_batch=False, loss_accum=None, capture=True, steps_per_replay=1):
+                 given_batch=False, loss_accum=None, capture=True, steps_per_replay=1, light_forward=None):
+        """light_forward: None = by size (with the row-sparse backward; CHAOREC_LIGHT_FORWARD=auto/0/1), True / False: the
+        forward propagates of a step restricted to the rows its loss reads (see _launch) / every row of every layer."""
         if not isinstance(optimizer, FusedAdam) or len(optimizer.param_groups) != 1:
             raise TypeError("FusedLightGCNStep needs a FusedAdam with one parameter group")
         L = model.n_layers
@@ -513,16 +515,38 @@ class FusedLightGCNStep:
         wide_ok = L >= 2 and D % 4 == 0 and (D // 4) in (16, 32, 64)
         self.sparse_bwd = wide_ok and mode != "0" and (mode == "1" or N >= int(os.environ.get("CHAOREC_SPARSE_BACKWARD_MIN_ROWS",
                                                                                               "400000")))
+        # Light forward.  train_and_evaluate.py:43-48 reads the propagated table (Model/LightGCN.py:95's mean) in the batch's
+        # rows R0 only; the other rows of `model.result` are a by-product that nothing looks at before the next evaluation.
+        # A LIGHT step therefore draws its batch first (ops.batch_rows: the same triples, flagged and listed), expands R0 to
+        # N1 once (the backward's launch 1 needs the same list) and runs
+        #   layers 1 .. L-2  dense                       (x_{L-2} is gathered by N1's rows: nearly every row has a reader)
+        #   layer  L-1       over N1's row list          (x_{L-1} is gathered by R0's rows only)
+        #   layer  L         over R0's row list, with the layer mean of those rows in its epilogue
+        # -- the same arithmetic for every row it computes, so loss, gradient and updated tables are the full step's bit for
+        # bit.  The step BEFORE AN EVALUATION must be a full one (`full_result=True`; run() does it): gene_ranklist reads the
+        # whole table of the last training forward (the reference's stale-result quirk Q4).
+        mode_l = os.environ.get("CHAOREC_LIGHT_FORWARD", "auto")
+        if light_forward is None:
+            light_forward = self.sparse_bwd and L <= 4 and mode_l != "0"
+        elif light_forward and not (wide_ok and L <= 4):
+            raise ValueError("FusedLightGCNStep: the light forward needs 2 <= n_layers <= 4 and D in {64, 128, 256}")
+        self.light = bool(light_forward)
+        if self.light and not self.sparse_bwd:
+            self.sparse_bwd = True              # (its bitmaps and N1's list are the forward's as well)
         self.bits = None
         if self.sparse_bwd:
             words = (N + 31) // 32 + 1
-            self._bits_all = torch.zeros(2 * words + 1, dtype=torch.int32, device=dev)      # (+ the row list's length)
+            self._bits_all = torch.zeros(2 * words + 2, dtype=torch.int32, device=dev)      # (+ the two row lists' lengths)
             self.bits = [self._bits_all[k * words:(k + 1) * words] for k in range(2)]
-            self._list_n = self._bits_all[2 * words:]
+            self._list_n = self._bits_all[2 * words:2 * words + 1]
+            self._list0_n = self._bits_all[2 * words + 1:]
             self._row_list = torch.empty(N, dtype=torch.int32, device=dev)                  # N1's rows, in no particular order
+            self._list0 = torch.empty(3 * self.B, dtype=torch.int32, device=dev)            # R0's rows
+            self._long = ops.long_row_buffers(model.graph) if self.light else None          # (the forward lists' long rows)
+        self.result_complete = True
         self.steps_per_replay = int(steps_per_replay) if (capture and edges is not None) else 1
         self.replays = 0
-        self.graph = self.graph1 = None
+        self.graph = self.graph1 = self.graph_full = None
         if capture:
             # schedules, lazily built by the first SpMM call, must exist before capture
             model.graph.schedule(D)
@@ -531,12 +555,18 @@ class FusedLightGCNStep:
             saved = self._save_state()
             with torch.cuda.stream(s):
                 self._launch()
+                if self.light:
+                    self._launch(light=False)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._restore_state(saved)
             self.graph1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph1):
                 self._launch()
+            if self.light:
+                self.graph_full = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_full):
+                    self._launch(light=False)
             self.graph = self.graph1
             if self.steps_per_replay > 1:
                 # k steps per replay: the loss bookkeeping (reduction of the per-sample terms, epoch loss, batch counter
@@ -551,7 +581,7 @@ class FusedLightGCNStep:
             # the first launch of a captured graph uploads it (tens of us for the k-step one): do it here, on a copy
             # of the state, so that the first replay a caller times is like every other
             saved = self._save_state()
-            for gph in {id(self.graph1): self.graph1, id(self.graph): self.graph}.values():
+            for gph in {id(g_): g_ for g_ in (self.graph1, self.graph, self.graph_full) if g_ is not None}.values():
                 gph.replay()
             torch.cuda.synchronize()
             self._restore_state(saved)
@@ -573,19 +603,36 @@ class FusedLightGCNStep:
                 self._bits_all.zero_()
 
     @torch.no_grad()
-    def _launch(self, j=0, k=1):
-        """Step j of a k-step replay (k = 1: a step with its own finalize launch)."""
+    def _launch(self, j=0, k=1, light=None):
+        """Step j of a k-step replay (k = 1: a step with its own finalize launch).  light: None = as built."""
         model, opt, L, B, D = self.model, self.optimizer, self.L, self.B, self.D
         group = opt.param_groups[0]
         csr, x0, w = model.graph, model._flat, 1.0 / (L + 1)
-        ops.forward_layers(csr, x0, L, self.final, self.fbuf)
+        light = self.light if light is None else bool(light)
         draw = self.edges is not None
         ws = self.ws if k == 1 else self.ws_steps[j]
-        ops.bpr_fwd_bwd(self.final, model.num_user, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef,
-                        ws, self.ids, edges=self.edges, hist=model.hist if draw else None, num_user=model.num_user,
-                        num_item=model.num_item, seed=self.seed, step=j, step_dev=self.step_dev, perm=self.perm,
-                        perm_pos=self.perm_pos, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc,
-                        pos_offset=j * B, row_bits=self.bits[0] if self.sparse_bwd else None)
+        if light:
+            ops.batch_rows(self.ids, self.bits[0], model.num_user, self._list0, self._list0_n, edges=self.edges,
+                           hist=model.hist if draw else None, num_user=model.num_user, num_item=model.num_item, seed=self.seed,
+                           step=j, step_dev=self.step_dev, perm=self.perm, perm_pos=self.perm_pos, pos_offset=j * B)
+            ops.expand_row_bits(csr, self.bits[0], self.bits[1], self._row_list, self._list_n)
+            xs = [x0]
+            for l in range(L - 2):
+                xs.append(ops.spmm_raw(csr, xs[-1], y=self.fbuf[l]))
+            ops.spmm_rowlist_raw(csr, xs[-1], self.fbuf[L - 2], self._row_list, self._list_n, long_rows=self._long)
+            xs.append(self.fbuf[L - 2])
+            ops.spmm_rowlist_raw(csr, xs[-1], None, self._list0, self._list0_n, mean_out=self.final, mean_terms=xs, mean_w=w,
+                                 long_rows=self._long)
+            ops.bpr_fwd_bwd(self.final, model.num_user, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef,
+                            ws, self.ids, num_user=model.num_user, num_item=model.num_item, adam_step=opt._step_dev,
+                            betas=group["betas"], adam_bc=self.bc)
+        else:
+            ops.forward_layers(csr, x0, L, self.final, self.fbuf)
+            ops.bpr_fwd_bwd(self.final, model.num_user, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef,
+                            ws, self.ids, edges=self.edges, hist=model.hist if draw else None, num_user=model.num_user,
+                            num_item=model.num_item, seed=self.seed, step=j, step_dev=self.step_dev, perm=self.perm,
+                            perm_pos=self.perm_pos, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc,
+                            pos_offset=j * B, row_bits=self.bits[0] if self.sparse_bwd else None)
         book = dict(out_total=self.static_loss, loss_accum=self.loss_accum, advance=self.step_dev if draw else None,
                     perm_pos=self.perm_pos if (draw and self.perm is not None) else None)
         if k == 1:
@@ -598,7 +645,8 @@ class FusedLightGCNStep:
             if self.sparse_bwd and l == 0 and L >= 3:
                 # g = G (rows R0): the output's rows N1 as a list; rows outside it stay unwritten (the next launch, gated by
                 # N1's bitmap, never gathers them)
-                ops.expand_row_bits(csr, self.bits[0], self.bits[1], self._row_list, self._list_n)
+                if not light:                   # (a light step expanded R0 before its forward)
+                    ops.expand_row_bits(csr, self.bits[0], self.bits[1], self._row_list, self._list_n)
                 ops.spmm_rowlist_raw(csr, g, y, self._row_list, self._list_n, alpha=alpha, z=self.G, beta=w,
                                      src_bits=self.bits[0], z_bits=self.bits[0])
             elif self.sparse_bwd and l < 2:
@@ -612,29 +660,42 @@ class FusedLightGCNStep:
                           clear_bits=(self._bits_all,) if self.sparse_bwd else ())
         if L < 2:
             self.G.zero_()                      # (the single backward SpMM gathers from G: it cannot clear it)
-        model.result = self.final
+        self._publish(not light)
 
-    def __call__(self, users=None, pos=None, neg=None, single=False):
+    def _publish(self, complete):
+        """model.result = this step's propagated table -- or, after a light step, nothing: only the batch's rows of it exist,
+        and a reader of the rest must fail (Model.LightGCN.gene_ranklist says how to get the table)."""
+        self.result_complete = bool(complete)
+        self.model.result = self.final if complete else None
+
+    def __call__(self, users=None, pos=None, neg=None, single=False, full_result=False):
         """One replay = `steps_per_replay` training steps (single=True: exactly one, whatever the replay size) -> the
         LAST step's loss (device scalar, rewritten by the next call; per-step sums go to loss_accum).  users / pos / neg
-        (GLOBAL item ids, the reference's batch format) only in given_batch mode."""
+        (GLOBAL item ids, the reference's batch format) only in given_batch mode.  full_result=True (a step built with the
+        light forward): ONE step that leaves the whole propagated table in model.result -- the step before an evaluation."""
         if self.edges is None:
             self.ids[0].copy_(users, non_blocking=True)
             torch.sub(pos.to(self.ids[1].device), self.model.num_user, out=self.ids[1])
             torch.sub(neg.to(self.ids[2].device), self.model.num_user, out=self.ids[2])
+        full = bool(full_result) and self.light
         if self.graph is not None:
-            (self.graph1 if single else self.graph).replay()
+            (self.graph_full if full else self.graph1 if single else self.graph).replay()
         else:
-            self._launch()
+            self._launch(light=False if full else None)
         self.replays += 1
-        self.model.result = self.final
+        self._publish(full or not self.light)
         return self.static_loss
 
-    def run(self, n_steps):
-        """n_steps training steps: whole replays first, single-step replays for the remainder."""
+    def run(self, n_steps, full_last=True):
+        """n_steps training steps: whole replays first, single-step replays for the remainder.  full_last (light forward
+        only): the last of them leaves the whole propagated table behind -- an epoch's steps, with the evaluation next."""
         k = self.steps_per_replay
-        for _ in range(n_steps // k):
+        tail = 1 if (self.light and full_last and n_steps > 0) else 0
+        n = n_steps - tail
+        for _ in range(n // k):
             self()
-        for _ in range(n_steps % k):
+        for _ in range(n % k):
             self(single=True)
+        if tail:
+            self(full_result=True)
         return self.static_loss

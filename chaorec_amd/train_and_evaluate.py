@@ -26,7 +26,9 @@ def _train_epoch_in_launch(model, loader, optimizer, graphed):
     if getattr(graphed, "fused", False):
         # optim.FusedLightGCNStep: several steps per replay, the per-batch losses summed on the device by the step itself
         graphed.loss_accum.zero_()
-        graphed.run(E // B)
+        # (a step with the light forward leaves the whole propagated table behind only when asked to: the epoch's last
+        # step does, unless the short last batch below -- an ordinary forward -- comes after it)
+        graphed.run(E // B, full_last=(E % B == 0))
         sum_loss = graphed.loss_accum[0].clone()
     else:
         for _ in range(E // B):

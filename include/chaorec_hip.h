@@ -162,10 +162,20 @@ int chaorec_or_words_u32(uint32_t *dst, const uint32_t *src, int32_t n_src, int6
  * 3 B batch rows -- 1-2 % of the graph at BASELINE configs[4], where even a launch that only LOOKS at every row's descriptor
  * costs a third of the dense one.  One lane group per listed row, entries in CSR order, unflagged sources skipped (their
  * term is +0): bit-identical rows.  64 <= D <= 256. */
+/* mean_out (optional; y may then be NULL): the layer mean of Model/LightGCN.py:85-95 for the listed rows,
+ * mean_out[r] = ((w t0[r] + w t1[r]) + ..) + w y[r] over n_mean_terms <= 4 earlier-layer tables (chaorec_spmm_csr_mean_f32's
+ * association): the LAST forward propagate of a training step, which needs the propagated table in its batch's rows only. */
 int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, const float *val, const float *x, float *y,
                                  int64_t n_rows, int32_t D, float alpha, const float *z, float beta, const uint32_t *src_bits,
                                  const uint32_t *z_bits, const int32_t *list, const int32_t *list_n, int64_t list_cap,
+                                 float *mean_out, const float *const *mean_terms, int32_t n_mean_terms, float mean_w,
+                                 int32_t *long_list, int32_t *long_cnt, int64_t long_cap, int32_t long_threshold,
                                  void *stream);
+/* long_list / long_cnt (optional, with src_bits == NULL: a launch that gathers every entry of its rows -- the forward
+ * propagates of a light step): listed rows with more than long_threshold entries are deferred to long_list (long_cap
+ * entries; long_cnt: int32[2], zero on entry and zero again afterwards) and computed by a second launch with one WORKGROUP
+ * per row -- the gathers shared by 256 threads, the sum still the sequential CSR-order sum -- instead of being the tail of
+ * a 16..64-lane group (a popular item's row has 1e4-1e5 entries). */
 
 /* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
 int chaorec_spmm_rows_per_wave(int32_t D);
@@ -235,6 +245,18 @@ int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col
  * above (same draw stream as chaorec_sample_negatives).  Replaces DataLoader(shuffle=True) +
  * TrainingDataset.__getitem__ (main.py:194-195, dataload.py:74-106).  Outputs LOCAL item ids + item_offset (ABI 9:
  * item_offset = num_user gives the GLOBAL ids the reference's dataset hands to Model.loss()). */
+/* The batch BEFORE the forward: chaorec_draw_batch's triples (edges != NULL; the same triples chaorec_bpr_fwd_bwd_at_f32
+ * draws for the same seed / step / permutation position, LOCAL item ids) or a given batch (edges == NULL: users / pos / neg
+ * are inputs), and the three table rows of every sample flagged in row_bits (bit u, bit bits_item_offset + pos,
+ * bit bits_item_offset + neg); list / list_n (optional, *list_n zero on entry): every row this launch flags first is
+ * appended.  For a training step whose forward propagates are restricted to the rows its loss reads
+ * (train_and_evaluate.py:43-48 never looks at the other rows of Model/LightGCN.py:95's mean). */
+int chaorec_batch_rows(const int64_t *edges, int64_t n_edges, const int64_t *hist_rowptr, const int32_t *hist_col,
+                       int32_t B, int64_t num_user, int32_t num_item, uint64_t seed, uint64_t step,
+                       const int64_t *step_dev, const int64_t *perm, const int64_t *perm_pos, int64_t pos_offset,
+                       int64_t *users, int64_t *pos, int64_t *neg, uint32_t *row_bits, int64_t bits_item_offset,
+                       int32_t *list, int32_t *list_n, int64_t list_cap, void *stream);
+
 int chaorec_draw_batch(const int64_t *edges, int64_t n_edges, const int64_t *hist_rowptr,
                        const int32_t *hist_col, int32_t B, int64_t num_user, int32_t num_item,
                        uint64_t seed, uint64_t step, const int64_t *step_dev, int64_t *out_users,

@@ -346,8 +346,9 @@ def test_fused_step_with_the_rowsparse_backward_trains_like_the_dense_one(dev, m
         monkeypatch.setenv("CHAOREC_SPARSE_BACKWARD", "1" if sparse else "0")
         torch.manual_seed(0)
         m = LightGCN(U, I, edges, None, 64, 1e-3, 3, "add", dev).to(dev)
-        step = FusedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=capture)
-        assert step.sparse_bwd == sparse
+        step = FusedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=capture,
+                                 light_forward=False)
+        assert step.sparse_bwd == sparse and not step.light
         losses = [float(step(*b)) for b in batches]
         torch.cuda.synchronize()
         if sparse:
@@ -378,3 +379,155 @@ def test_bpr_launch_flags_exactly_the_rows_it_touched(dev):
     want = np.unique(np.concatenate([ids[0].cpu().numpy(), U + ids[1].cpu().numpy(), U + ids[2].cpu().numpy()]))
     assert np.array_equal(_bits_to_rows(bits, U + I), want)
     assert np.array_equal(torch.nonzero(G.abs().sum(1) > 0).flatten().cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("D,L,long_t", [(64, 3, None), (128, 2, 6), (256, 4, 3), (128, 3, 20), (64, 2, 2)])
+def test_rowlist_layer_mean_equals_the_dense_forward_in_the_listed_rows(dev, D, L, long_t):
+    """The light forward's last two launches (ops.spmm_rowlist_raw over N1's list, then over R0's list with the layer mean in
+    the epilogue) against ops.forward_layers on every row: the listed rows of the mean carry the same bits -- whichever of the
+    dense forward's two accumulation forms (all terms in the last epilogue / one read-modify-write per layer) D and L select.
+    long_t: listed rows with more entries go through the workgroup-per-row launch (thresholds far below the product's 1024,
+    so that most rows of this small graph take it)."""
+    from chaorec_amd import graph, ops
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E = 3000, 1100, 26000
+    edges = synthetic_interactions(U, I, E, seed=11)
+    csr = graph.lightgcn_csr(edges, U + I).to(dev)
+    N = U + I
+    gen = torch.Generator(device=dev).manual_seed(D + L)
+    x0 = torch.randn(N, D, device=dev, generator=gen) * 0.1
+    want = torch.empty_like(x0)
+    ops.forward_layers(csr, x0, L, want, [torch.empty_like(x0) for _ in range(L - 1)])
+    # R0: 200 random rows; N1 by the expansion kernel
+    bits0, bits1 = ops.row_bitmap(N, dev), ops.row_bitmap(N, dev)
+    r0 = torch.randperm(N, device=dev, generator=gen)[:200]
+    ids = (r0[:80].clamp(max=U - 1), (r0[80:140] % I), (r0[140:] % I)[:60])
+    ids = tuple(torch.cat([t, t.new_zeros(80 - t.numel())]) if t.numel() < 80 else t for t in ids)
+    list0, n0 = torch.empty(3 * 80, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.batch_rows(ids, bits0, U, list0, n0)
+    list1, n1 = torch.empty(N, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.expand_row_bits(csr, bits0, bits1, list1, n1)
+    rows0 = np.unique(np.concatenate([ids[0].cpu().numpy(), U + ids[1].cpu().numpy(), U + ids[2].cpu().numpy()]))
+    assert np.array_equal(np.sort(list0[:int(n0)].cpu().numpy()), rows0) and np.array_equal(_bits_to_rows(bits0, N), rows0)
+    xs = [x0]
+    for l in range(L - 2):
+        xs.append(ops.spmm_raw(csr, xs[-1], y=torch.empty_like(x0)))
+    long_rows = ops.long_row_buffers(csr, long_t) if long_t else None
+    stale = torch.full_like(x0, float("nan"))                  # rows outside N1 are never written -- and never read
+    ops.spmm_rowlist_raw(csr, xs[-1], stale, list1, n1, long_rows=long_rows)
+    xs.append(stale)
+    got = torch.full_like(x0, float("nan"))
+    ops.spmm_rowlist_raw(csr, xs[-1], None, list0, n0, mean_out=got, mean_terms=xs, mean_w=1.0 / (L + 1), long_rows=long_rows)
+    torch.cuda.synchronize()
+    if long_rows is not None:
+        deg = (csr.rowptr[1:] - csr.rowptr[:-1]).cpu().numpy()
+        assert (deg[rows0] > long_t).any() and int(long_rows[1].abs().sum()) == 0       # used, and left clean
+    rows = torch.from_numpy(rows0).to(dev)
+    assert torch.equal(got[rows], want[rows])
+    rest = torch.ones(N, dtype=torch.bool, device=dev)
+    rest[rows] = False
+    assert bool(torch.isnan(got[rest]).all())
+
+
+def test_batch_rows_draws_the_bpr_launch_s_batch(dev):
+    """ops.batch_rows with edges = the triples ops.bpr_fwd_bwd draws in its own launch for the same seed / step / counter /
+    permutation cursor (a light step draws first and hands the ids over)."""
+    from chaorec_amd import graph, ops
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B, D = 900, 400, 7000, 128, 64
+    edges = synthetic_interactions(U, I, E, seed=3)
+    ed = torch.from_numpy(edges.astype(np.int64)).to(dev).contiguous()
+    hist = tuple(t.to(dev) for t in graph.user_hist_csr_from_edges(edges, U))
+    tab = torch.randn(U + I, D, device=dev) * 0.1
+    step_dev = torch.tensor([5], dtype=torch.int64, device=dev)
+    perm = torch.randperm(E, device=dev)
+    perm_pos = torch.tensor([256], dtype=torch.int64, device=dev)
+    for use_perm in (False, True):
+        kw = dict(perm=perm, perm_pos=perm_pos, pos_offset=B) if use_perm else {}
+        a = tuple(torch.zeros(B, dtype=torch.int64, device=dev) for _ in range(3))
+        b = tuple(torch.zeros(B, dtype=torch.int64, device=dev) for _ in range(3))
+        bits = ops.row_bitmap(U + I, dev)
+        ops.batch_rows(a, bits, U, edges=ed, hist=hist, num_user=U, num_item=I, seed=77, step=2, step_dev=step_dev, **kw)
+        ops.bpr_fwd_bwd(tab, U, torch.zeros_like(tab), B, ops.VARIANT_LOG_SIGMOID_EPS, 1e-3, torch.empty(B, device=dev),
+                        torch.empty(4 * B, device=dev), b, edges=ed, hist=hist, num_user=U, num_item=I, seed=77, step=2,
+                        step_dev=step_dev, **kw)
+        torch.cuda.synchronize()
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        want = np.unique(np.concatenate([a[0].cpu().numpy(), U + a[1].cpu().numpy(), U + a[2].cpu().numpy()]))
+        assert np.array_equal(_bits_to_rows(bits, U + I), want)
+
+
+@pytest.mark.parametrize("L,capture", [(3, False), (3, True), (2, True), (4, True)])
+def test_light_steps_train_like_full_steps_bit_for_bit(dev, L, capture):
+    """optim.FusedLightGCNStep with the light forward (the batch drawn first; layers L-1 and L over N1's / R0's row lists
+    only) against the same step with every row of every layer: batches without a repeated row make the BPR launch's atomic
+    adds order-free, so loss and tables must agree BIT FOR BIT after every step; model.result is withheld after a light step
+    (gene_ranklist says why), and the full_result step that precedes an evaluation leaves the full step's table."""
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, FusedLightGCNStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B, D, T = 5000, 1800, 40000, 200, 128, 4
+    edges = synthetic_interactions(U, I, E, seed=5)
+    rng = np.random.default_rng(L)
+    batches = []
+    for _ in range(T):
+        u = rng.choice(U, B, replace=False)
+        it = rng.choice(I, 2 * B, replace=False)
+        batches.append(tuple(torch.from_numpy(a.astype(np.int64)).to(dev) for a in (u, U + it[:B], U + it[B:])))
+
+    def run(light):
+        torch.manual_seed(0)
+        m = LightGCN(U, I, edges, None, D, 1e-3, L, "add", dev).to(dev)
+        step = FusedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=capture,
+                                 light_forward=light)
+        assert step.light == light and step.sparse_bwd == light
+        out = []
+        for t, b in enumerate(batches):
+            last = t == T - 1
+            loss = float(step(*b, full_result=last))
+            out.append((loss, m._flat.detach().clone()))
+            if light and not last:
+                assert m.result is None and not step.result_complete
+                with pytest.raises(RuntimeError, match="light"):
+                    m.gene_ranklist(topk=5)
+        torch.cuda.synchronize()
+        if light:
+            assert int(step._bits_all.abs().sum()) == 0 and float(step.G.abs().max()) == 0.0
+        return out, m.result.detach().clone(), m.gene_ranklist(topk=10)
+
+    ref, ref_result, ref_rank = run(False)
+    got, result, rank = run(True)
+    for (la, xa), (lb, xb) in zip(ref, got):
+        assert la == lb and torch.equal(xa, xb)
+    assert torch.equal(result, ref_result) and torch.equal(rank, ref_rank)
+
+
+def test_light_run_ends_with_a_full_step(dev):
+    """FusedLightGCNStep.run(n): n - 1 light steps (k-step replays + singles) and one full step -- an epoch of the product
+    loop (chaorec_amd/train_and_evaluate.py), after which gene_ranklist ranks the table of the last training forward as the
+    reference does.  Drawn batches: same counters, same draws, the same trajectory as full steps up to atomic-add order."""
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, FusedLightGCNStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B, D = 5000, 1800, 40000, 256, 64
+    edges = synthetic_interactions(U, I, E, seed=6)
+    ed = torch.from_numpy(edges.astype(np.int64)).to(dev).contiguous()
+
+    def run(light):
+        torch.manual_seed(0)
+        m = LightGCN(U, I, edges, None, D, 1e-3, 3, "add", dev).to(dev)
+        counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        step = FusedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, edges=ed, seed=9, step_dev=counter,
+                                 loss_accum=acc, steps_per_replay=3, light_forward=light)
+        step.run(11)
+        torch.cuda.synchronize()
+        assert int(counter) == 11 and step.result_complete and m.result is not None
+        return m._flat.detach().clone(), float(acc), m.result.detach().clone()
+
+    (xa, la, ra), (xb, lb, rb) = run(False), run(True)
+    d = (xa - xb).abs()
+    assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7
+    assert la == pytest.approx(lb, rel=1e-5)
+    assert float((ra - rb).abs().max()) <= 1e-5
