@@ -42,6 +42,72 @@ __global__ __launch_bounds__(256) void pull_gather_kernel(const PeerPtrs P, int6
   }
 }
 
+// ---- the same exchange for a buffer that is non-zero in a FRONTIER's rows only (the row-sparse backward / light forward of a
+// user shard: the gradient seed has <= 2 B world non-zero rows, a frontier partial ~1e4-1e5 of 2 M) ----------------------------
+// `bits`: a bitmap over the buffer's rows, IDENTICAL on every rank (the union of the ranks' frontiers), a superset of the
+// rows that are non-zero anywhere.  Only flagged rows are copied into the mailbox, summed and gathered; the other rows of the
+// caller's buffer are not touched (they hold zeros on every rank, and zeros is what their sum is).  One wave per bitmap
+// word; an empty word is a load and an exit.
+__device__ __forceinline__ bool next_row(uint32_t &word, int64_t wi, int64_t &r) {
+  if (!word) return false;
+  const int b = __builtin_ctz(word);
+  word &= word - 1;
+  r = wi * 32 + b;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void rows_copy_kernel(float4 *__restrict__ dst, const float4 *__restrict__ src, int64_t n_rows,
+                                                        int D4, const uint32_t *__restrict__ bits, int64_t n_words) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n_words) return;
+  uint32_t word = bits[wi];
+  int64_t r;
+  while (next_row(word, wi, r)) {
+    if (r >= n_rows) break;
+    for (int c = lane; c < D4; c += 64) dst[(size_t)r * D4 + c] = src[(size_t)r * D4 + c];
+  }
+}
+
+// R[r - row0] = ((p_0[r] + p_1[r]) + ...) for the flagged rows r of [row0, row0 + n_block)
+__global__ __launch_bounds__(256) void pull_sum_rows_kernel(const PeerPtrs P, int64_t row0, int64_t n_block, int D4,
+                                                            const uint32_t *__restrict__ bits, int64_t n_words,
+                                                            float4 *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wi = (row0 >> 5) + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n_words || wi * 32 >= row0 + n_block) return;
+  uint32_t word = bits[wi];
+  int64_t r;
+  while (next_row(word, wi, r)) {
+    if (r < row0) continue;
+    if (r >= row0 + n_block) break;
+    for (int c = lane; c < D4; c += 64) {
+      float4 a = P.p[0][(size_t)r * D4 + c];
+      for (int q = 1; q < P.world; ++q) {
+        const float4 v = P.p[q][(size_t)r * D4 + c];
+        a = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+      }
+      out[(size_t)(r - row0) * D4 + c] = a;
+    }
+  }
+}
+
+// out[r] = R_owner[r - owner * n_block] for every flagged row r (owner = r / n_block)
+__global__ __launch_bounds__(256) void pull_gather_rows_kernel(const PeerPtrs P, int64_t n_block, int D4,
+                                                               const uint32_t *__restrict__ bits, int64_t n_words,
+                                                               float4 *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n_words) return;
+  uint32_t word = bits[wi];
+  int64_t r;
+  while (next_row(word, wi, r)) {
+    const int owner = (int)(r / n_block);
+    if (owner >= P.world) break;
+    for (int c = lane; c < D4; c += 64) out[(size_t)r * D4 + c] = P.p[owner][(size_t)(r - (int64_t)owner * n_block) * D4 + c];
+  }
+}
+
 }  // namespace chaorec
 
 using namespace chaorec;
@@ -81,4 +147,51 @@ extern "C" int chaorec_exchange_pull_gather_f32(const void *const *peers, int32_
   const unsigned blocks = (unsigned)std::min<int64_t>((total4 + 255) / 256, 4096);
   hipLaunchKernelGGL(pull_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, block / 4, (float4 *)out);
   return check_launch("pull_gather_kernel");
+}
+
+static int rows_args(const void *a, const void *bits, int64_t n_rows, int32_t D, const char *who) {
+  if (!a || !bits) return fail(CHAOREC_E_INVALID, "%s: NULL argument", who);
+  if (n_rows <= 0 || D <= 0 || (D & 3) || (reinterpret_cast<uintptr_t>(a) & 15))
+    return fail(CHAOREC_E_INVALID, "%s: n_rows=%lld D=%d (a multiple of 4), 16-byte aligned buffers", who, (long long)n_rows, D);
+  return CHAOREC_OK;
+}
+
+extern "C" int chaorec_rows_copy_by_bits_f32(float *dst, const float *src, int64_t n_rows, int32_t D, const uint32_t *bits,
+                                             void *stream) {
+  int rc = rows_args(dst, bits, n_rows, D, "rows_copy_by_bits");
+  if (rc) return rc;
+  if (!src || (reinterpret_cast<uintptr_t>(src) & 15)) return fail(CHAOREC_E_INVALID, "rows_copy_by_bits: src NULL or unaligned");
+  const int64_t n_words = (n_rows + 31) / 32;
+  hipLaunchKernelGGL(rows_copy_kernel, dim3((unsigned)((n_words + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (float4 *)dst,
+                     (const float4 *)src, n_rows, D / 4, bits, n_words);
+  return check_launch("rows_copy_kernel");
+}
+
+extern "C" int chaorec_exchange_pull_sum_rows_f32(const void *const *peers, int32_t world, int64_t row0, int64_t n_block,
+                                                  int64_t n_rows, int32_t D, const uint32_t *bits, float *out, void *stream) {
+  int rc = rows_args(out, bits, n_rows, D, "exchange_pull_sum_rows");
+  if (rc) return rc;
+  if (row0 < 0 || n_block <= 0) return fail(CHAOREC_E_INVALID, "exchange_pull_sum_rows: row0=%lld n_block=%lld", (long long)row0, (long long)n_block);
+  PeerPtrs P;
+  rc = fill_peers(P, peers, world, "exchange_pull_sum_rows");
+  if (rc) return rc;
+  const int64_t n_words = (n_rows + 31) / 32;                    // (bits over the rows that can be flagged at all: pad rows never are)
+  const int64_t span = (row0 + n_block + 31) / 32 - row0 / 32;   // words that overlap my block
+  hipLaunchKernelGGL(pull_sum_rows_kernel, dim3((unsigned)((span + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, row0, n_block,
+                     D / 4, bits, n_words, (float4 *)out);
+  return check_launch("pull_sum_rows_kernel");
+}
+
+extern "C" int chaorec_exchange_pull_gather_rows_f32(const void *const *peers, int32_t world, int64_t n_block, int64_t n_rows,
+                                                     int32_t D, const uint32_t *bits, float *out, void *stream) {
+  int rc = rows_args(out, bits, n_rows, D, "exchange_pull_gather_rows");
+  if (rc) return rc;
+  if (n_block <= 0) return fail(CHAOREC_E_INVALID, "exchange_pull_gather_rows: n_block=%lld", (long long)n_block);
+  PeerPtrs P;
+  rc = fill_peers(P, peers, world, "exchange_pull_gather_rows");
+  if (rc) return rc;
+  const int64_t n_words = (n_rows + 31) / 32;
+  hipLaunchKernelGGL(pull_gather_rows_kernel, dim3((unsigned)((n_words + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, n_block,
+                     D / 4, bits, n_words, (float4 *)out);
+  return check_launch("pull_gather_rows_kernel");
 }

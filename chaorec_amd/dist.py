@@ -355,8 +355,10 @@ class P2PExchange:
             torch.cuda.current_stream().synchronize()
             dist.barrier(group=self.group)
 
-    def exchange(self, buf):
-        """buf [rows_pad, D] fp32 on the GPU, rows_pad a multiple of the world size: summed over the ranks in place."""
+    def exchange(self, buf, bits=None, n_rows=None):
+        """buf [rows_pad, D] fp32 on the GPU, rows_pad a multiple of the world size: summed over the ranks in place.
+        bits (with n_rows = the rows it covers): a bitmap over buf's rows, IDENTICAL on every rank, outside of which buf is
+        all-zero on every rank (a frontier buffer) -- only the flagged rows are copied, pulled and written back."""
         numel = buf.numel()
         if not self.ready(numel):
             self.setup(numel, buf.device)
@@ -364,6 +366,18 @@ class P2PExchange:
         block = numel // self.world
         lib = _lib.load()
         stream = ops._stream()
+        if bits is not None:
+            D = buf.shape[1]
+            nb = buf.shape[0] // self.world
+            _lib.check(lib.chaorec_rows_copy_by_bits_f32(ops._ptr(box["P"]), ops._ptr(buf), n_rows, D, ops._ptr(bits), stream),
+                       "chaorec_rows_copy_by_bits_f32")
+            self._barrier()
+            _lib.check(lib.chaorec_exchange_pull_sum_rows_f32(box["pP"], self.world, self.rank * nb, nb, n_rows, D, ops._ptr(bits),
+                                                              ops._ptr(box["R"]), stream), "chaorec_exchange_pull_sum_rows_f32")
+            self._barrier()
+            _lib.check(lib.chaorec_exchange_pull_gather_rows_f32(box["pR"], self.world, nb, n_rows, D, ops._ptr(bits), ops._ptr(buf),
+                                                                 stream), "chaorec_exchange_pull_gather_rows_f32")
+            return
         box["P"].copy_(buf.reshape(-1))
         self._barrier()
         _lib.check(lib.chaorec_exchange_pull_sum_f32(box["pP"], self.world, self.rank * block, block, ops._ptr(box["R"]),
@@ -379,18 +393,21 @@ def _p2p_usable(buf, group):
         dist.get_world_size(group) <= 16
 
 
-def _sum_exchange_async(buf, group, sync=False):
+def _sum_exchange_async(buf, group, sync=False, bits=None, n_rows=None):
     """Sum `buf` ([rows_pad, D], rows_pad a multiple of the world size) over the ranks, in place; -> a handle to wait on.
+    bits / n_rows: a FRONTIER buffer -- all-zero on every rank outside the rows flagged in `bits` (a bitmap over its first
+    n_rows rows, identical on every rank).  The hand-written p2p exchange then moves the flagged rows only; RCCL's dense
+    collectives sum the whole buffer (same result).
     sync=True: c10d's synchronous form (the CURRENT stream waits for the collective, nothing to wait on afterwards) -- what a
     model whose compute runs on SEVERAL streams must use inside a captured step: on this stack (ROCm 7.2, RCCL 2.26 of torch
     2.10) `async_op=True` collectives issued from a second capturing stream segfault in the capture, the synchronous form
     from the same streams is fine, eagerly both are (tools/rccl_streams_repro.py, profiles/r04_f_rccl_streams_repro.txt)."""
     if not _active(group):
         return _Pending(None)
-    return _sum_exchange_issue(buf, group, sync)
+    return _sum_exchange_issue(buf, group, sync, bits, n_rows)
 
 
-def _sum_exchange_issue(buf, group, sync=False):
+def _sum_exchange_issue(buf, group, sync=False, bits=None, n_rows=None):
     _count(buf)
     mode = resolve_mode(buf)
     if mode == "direct" and buf.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -419,13 +436,15 @@ def _sum_exchange_issue(buf, group, sync=False):
             if not ex.ready(buf.numel()):
                 ex.setup(buf.numel(), buf.device)          # (collective, eager only: raises inside a capture)
             MODES_USED.add("p2p")
+            if bits is not None:
+                STATS["frontier_exchanges"] = STATS.get("frontier_exchanges", 0) + 1
             if sync:
-                ex.exchange(buf)                          # (on the caller's stream: nothing to wait on)
+                ex.exchange(buf, bits, n_rows)            # (on the caller's stream: nothing to wait on)
                 return _Pending(None)
             side = ex.side_stream(buf.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                ex.exchange(buf)
+                ex.exchange(buf, bits, n_rows)
             return _PendingStream(side)
     MODES_USED.add("allreduce" if (mode == "allreduce" or buf.shape[0] % dist.get_world_size(group)) else mode)
     lazy = not sync                                    # (async_op=False returns no handle: _Pending(None) waits for nothing)
@@ -757,6 +776,7 @@ class _HipStepKernels:
     spmm_rowlist = staticmethod(lambda *a, **k: ops.spmm_rowlist_raw(*a, **k))
     spmm_rowsparse = staticmethod(lambda *a, **k: ops.spmm_rowsparse_raw(*a, **k))
     zero_rows_by_bits = staticmethod(ops.zero_rows_by_bits)
+    rows_copy_by_bits = staticmethod(ops.rows_copy_by_bits)
     or_words = staticmethod(ops.or_words)
     sparse_widths = (64, 256)           # chaorec_spmm_csr_rowsparse_f32 / _rowlist_f32 are built for these D
 
@@ -912,6 +932,7 @@ class FusedShardedLightGCNStep:
             if self.sparse_bwd:
                 self._bits_all.zero_()
                 self.Z.zero_()
+                self.S.zero_()
 
     def _union_item_bits(self, bits):
         """An item-row bitmap becomes the union over the ranks (one small all-gather + one launch; issued BEFORE the
@@ -1030,9 +1051,14 @@ class FusedShardedLightGCNStep:
                 K.expand_row_bits(ui, bu0, bi1, self._list_i, self._list_n[1:2], bits_self=bi0)
                 self._union_item_bits(bi1)
         # the seed: this rank's user rows as they are (G), the item rows summed over the ranks (S) while the first B_g^T
-        # launch runs
-        self.S[U:].copy_(self.G[U:])
-        pend = self._exchange(self.S)
+        # launch runs.  Row-sparse: S's item rows are a frontier buffer like Z (the batch items' rows copied in, exchanged as
+        # such, zeroed again after their one reader)
+        if sp:
+            K.rows_copy_by_bits(self.S[U:N], self.G[U:N], bi0)
+            pend = _sum_exchange_async(self.S[U:], self.group, bits=bi0, n_rows=I)
+        else:
+            self.S[U:].copy_(self.G[U:])
+            pend = self._exchange(self.S)
         gu, gi, alpha = self.G[:U], self.S[U:N], c
         for l in range(L):
             last = l == L - 1
@@ -1041,7 +1067,7 @@ class FusedShardedLightGCNStep:
             if how == "list":
                 K.spmm_rowlist(iu, gu, self.Z[:I], self._list_i, self._list_n[1:2], alpha=alpha, z=self.G[U:N], beta=c,
                                src_bits=bu0, z_bits=bi0)
-                nxt = _sum_exchange_async(self.Z, self.group)
+                nxt = _sum_exchange_async(self.Z, self.group, bits=bi1, n_rows=I)
             elif how == "gated":
                 K.spmm_rowsparse(iu, gu, Y[U:N], alpha=alpha, z=self.G[U:N], beta=c, src_bits=self.bits[2 * l], z_bits=bi0)
                 nxt = self._exchange(Y)
@@ -1065,6 +1091,8 @@ class FusedShardedLightGCNStep:
                     K.zero_rows_by_bits(self.Z[:I], bi1)       # (Z had its only reader: all-zero again)
             else:
                 K.spmm(ui, gi, y=Y[:U], alpha=alpha, z=self.G[:U], beta=c)
+            if sp and l == 0:
+                K.zero_rows_by_bits(self.S[U:N], bi0)          # (the seed had its only reader: all-zero again)
             gu, gi = Y[:U], (self.Z[:I] if how == "list" else Y[U:N])
             alpha, pend = 1.0, nxt
         pend.wait()

@@ -141,6 +141,17 @@ def zero_rows_by_bits(y, bits):
     return y
 
 
+def rows_copy_by_bits(dst, src, bits):
+    """dst[r] = src[r] for every row flagged in `bits` (chaorec_rows_copy_by_bits_f32)."""
+    _need_cuda(dst, src, bits)
+    if dst.shape != src.shape or dst.dtype != torch.float32 or not dst.is_contiguous() or not src.is_contiguous() or \
+            bits.numel() * 32 < dst.shape[0]:
+        raise ValueError("rows_copy_by_bits: two contiguous float32 [n, D] buffers and a bitmap over their rows")
+    _lib.check(_lib.load().chaorec_rows_copy_by_bits_f32(_ptr(dst), _ptr(src), dst.shape[0], dst.shape[1], _ptr(bits), _stream()),
+               "chaorec_rows_copy_by_bits_f32")
+    return dst
+
+
 def or_words(dst, src):
     """dst[w] = OR_k src[k, w] (chaorec_or_words_u32): the union of all-gathered row bitmaps."""
     _need_cuda(dst, src)

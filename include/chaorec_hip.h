@@ -692,6 +692,21 @@ int chaorec_exchange_pull_sum_f32(const void *const *peers, int32_t world, int64
                                   void *stream);
 int chaorec_exchange_pull_gather_f32(const void *const *peers, int32_t world, int64_t block, float *out, void *stream);
 
+/* The same exchange for a buffer that is non-zero in a FRONTIER's rows only (ABI 12; the gradient seed and the frontier
+ * partials of dist.FusedShardedLightGCNStep's row-sparse backward).  bits: a bitmap over the buffer's n_rows rows, identical
+ * on every rank, a superset of the rows that are non-zero on any rank.  Only flagged rows move:
+ *   chaorec_rows_copy_by_bits_f32:        dst[r] = src[r]                      (the partial into the mailbox)
+ *   chaorec_exchange_pull_sum_rows_f32:   out[r - row0] = sum over ranks, rank order, of peers[q][r]   for the flagged rows r of
+ *                                         this rank's block [row0, row0 + n_block)
+ *   chaorec_exchange_pull_gather_rows_f32: out[r] = peers[r / n_block][r - (r / n_block) n_block]      for every flagged row
+ * The other rows of the caller's buffer are not touched (zeros on every rank, and zeros is their sum).  Row pointers in
+ * units of rows of D floats (D a multiple of 4). */
+int chaorec_rows_copy_by_bits_f32(float *dst, const float *src, int64_t n_rows, int32_t D, const uint32_t *bits, void *stream);
+int chaorec_exchange_pull_sum_rows_f32(const void *const *peers, int32_t world, int64_t row0, int64_t n_block, int64_t n_rows,
+                                       int32_t D, const uint32_t *bits, float *out, void *stream);
+int chaorec_exchange_pull_gather_rows_f32(const void *const *peers, int32_t world, int64_t n_block, int64_t n_rows, int32_t D,
+                                          const uint32_t *bits, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Several BPR terms over ONE user table and one batch of users (Model/FREEDOM.py:203-215:
  *   mf_loss + reg_weight * (mf_t_loss + mf_v_loss), each -mean(logsigmoid(s+ - s-)) over its own item table):

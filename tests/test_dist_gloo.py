@@ -330,6 +330,11 @@ class _OracleStepKernels:
     def zero_rows_by_bits(cls, y, bits):
         y[torch.from_numpy(cls._rows(bits, y.shape[0]))] = 0.0
 
+    @classmethod
+    def rows_copy_by_bits(cls, dst, src, bits):
+        m = torch.from_numpy(cls._rows(bits, dst.shape[0]))
+        dst[m] = src[m]
+
     @staticmethod
     def or_words(dst, src):
         acc = src[0].clone()
@@ -403,6 +408,7 @@ def _worker_fused(rank, world, port, tmp, mode, L, split=False, sparse=False):
     assert float(step.G.abs().max()) == 0.0                               # the gradient buffer is all-zero between steps
     if sparse:
         assert float(step.Z.abs().max()) == 0.0 and int(step._bits_all.abs().max()) == 0       # ... and so are these
+        assert float(step.S[step.U:].abs().max()) == 0.0
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), x0u=x0u, x0i=x0i, xu=m.user_embedding.weight.detach().numpy(),
              xi=m.item_embedding.weight.detach().numpy(), fu=m.result_u.numpy(), fi=m.result_i.numpy(),
              batches=np.stack(batches), losses=np.array(losses))

@@ -71,6 +71,7 @@ def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False, sparse
     assert float(step.G.abs().max()) == 0.0
     if sparse:          # what the step leaves behind for the next one: no flag, no listed row, an all-zero frontier buffer
         assert float(step.Z.abs().max()) == 0.0 and int(step._bits_all.abs().max()) == 0
+        assert float(step.S[step.U:].abs().max()) == 0.0
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), u0=shard.u0, u1=shard.u1, xu=m.user_embedding.weight.detach().cpu().numpy(),
              xi=m.item_embedding.weight.detach().cpu().numpy(), fu=m.result_u.cpu().numpy(), fi=m.result_i.cpu().numpy(),
              losses=np.array(losses), n_local_edges=len(shard.local_edges))
@@ -185,6 +186,58 @@ def test_captured_exchanges_on_a_one_rank_rccl_group():
             assert (d > 2e-6).mean() <= 1e-4 and np.median(d) <= 1e-7, (key, name, float(d.max()))
         assert np.allclose(r["losses"], ref["losses"], rtol=1e-5), key
     assert "p2p" in str(out[("direct", "p2p", False, False)]["used"]) and "rs_ag" in str(out[("direct", "rs_ag", False, False)]["used"])
+
+
+def _p2p_rows_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CHAOREC_DIST_EXCHANGE"] = "p2p"
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chaorec_amd import dist as cdist, ops
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    ok = True
+    for n_rows, D, n_flag in ((1001, 64, 37), (4099, 128, 900), (333, 256, 333), (1001, 64, 0)):
+        rows_pad = cdist.padded_rows(n_rows, None)
+        for rep in range(3):
+            g = torch.Generator().manual_seed(7 * n_rows + rep)               # the same on every rank: the GLOBAL frontier
+            flagged = torch.randperm(n_rows, generator=g)[:n_flag]
+            bits_np = np.zeros((n_rows + 31) // 32 + 1, dtype=np.uint32)
+            np.bitwise_or.at(bits_np, flagged.numpy() >> 5, np.uint32(1) << (flagged.numpy() & 31).astype(np.uint32))
+            bits = torch.from_numpy(bits_np.view(np.int32)).to(dev)
+            g2 = torch.Generator().manual_seed(1000 * rep + rank)             # this rank's rows: a subset of the frontier
+            mine = torch.zeros(rows_pad, D)
+            own = flagged[torch.rand(n_flag, generator=g2) < 0.6]
+            mine[own] = torch.randn(len(own), D, generator=g2)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            ordered = parts[0].clone()
+            for q in parts[1:]:
+                ordered += q
+            buf = mine.to(dev)
+            before = cdist.STATS.get("frontier_exchanges", 0)
+            cdist._sum_exchange_async(buf, None, bits=bits, n_rows=n_rows).wait()
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(buf.cpu(), ordered) and cdist.STATS.get("frontier_exchanges", 0) == before + 1
+    np.savez(os.path.join(tmp, f"p2prows{rank}.npz"), ok=ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_frontier_exchange_moves_flagged_rows_only_and_sums_like_the_dense_one(world):
+    """dist.P2PExchange with a row bitmap (the frontier buffers of the row-sparse sharded backward: the gradient seed, the
+    first backward item partial): every rank's buffer is zero outside a GLOBAL set of flagged rows and holds values in its own
+    part of it; the exchange copies / pulls / gathers flagged rows only and must leave every rank with the rank-ordered sum
+    bit for bit -- block boundaries inside bitmap words, pad rows, an empty frontier."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_p2p_rows_worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
+        assert all(bool(np.load(os.path.join(tmp, f"p2prows{k}.npz"))["ok"]) for k in range(world))
 
 
 @pytest.mark.parametrize("world", [2, 4])
