@@ -1009,7 +1009,7 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
             barrier()
             dry = (time.perf_counter() - t0) / n_dry * 1e3
         finally:
-            fused._exchange = real_exchange
+            fused._exchange, fused._exchange_frontier = real_exchange, real_frontier
             fused._restore_state(saved)
         for _ in range(2):
             fused._launch()
@@ -1054,6 +1054,24 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
                                               if getattr(fused, "split", False) else
                                               "one launch per layer over the rank's joined graph [[0, B_g], [B_g^T, 0]]")}
 
+    forward_note = None
+    if fused is not None and getattr(fused, "light", False):
+        # the timed steps were LIGHT ones (steps inside an epoch); the step that precedes an evaluation computes every row
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            n_loss[0] += 1
+            fused(single=True, full_result=True)
+        barrier()
+        full_ms = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=dev, dtype=torch.float64)
+        dist.all_reduce(full_ms, op=dist.ReduceOp.MAX)
+        forward_note = {"timed_steps": "light", "ms_per_step_full_result": float(full_ms.item()), "full_steps_per_epoch": 1,
+                        "what": "dist.FusedShardedLightGCNStep with the light forward: the batch drawn first, the last two "
+                                "forward layers over the frontier's row lists (item partials through frontier buffers and "
+                                "frontier exchanges); the step before an evaluation is a full one"}
+    elif fused is not None:
+        fused(single=True)                  # (the recording pass above ran eager launches; leave a complete result behind)
+
     # --- full-rank evaluation: every rank ranks its own users against the replicated item table, no exchange --------
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3 if E > 5_000_000 else 5)]
@@ -1076,6 +1094,7 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
         (f", fused sharded step (dist.FusedShardedLightGCNStep, {'split' if fused.split else 'joined'} launches: "
          f"{'4L+5' if fused.split else '2L+5'} launches, 2L+1 exchanges"
          f"{'; the first two backward propagates over the batch frontier only (row-sparse)' if fused.sparse_bwd else ''}"
+         f"{'; light forward' if getattr(fused, 'light', False) else ''}"
          f"; {fused.steps_per_replay} steps per replay)"
          if fused is not None else ", autograd step")
     res = dict(dataset=dataset, data=job["data"], U1=U1, I=I, D=D, L=L, B=B, world=world, e_dir_all=e_dir_all,
@@ -1083,7 +1102,8 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
                graphed=graphed is not None, fused=fused is not None, split=bool(getattr(fused, "split", False)),
                roofline=roofline, score_ms=score_ms, score_tf=tf, score_st=st, n_scored=n_scored, build_s=build_s,
                exchange=cdist.exchange_mode_used(), exchange_bytes=item_bytes, calibration=calibration, exposed=exposed,
-               table_mb=(U + I) * D * 4 / 1e6)
+               table_mb=(U + I) * D * 4 / 1e6, forward=forward_note,
+               frontier_exchanges=cdist.STATS.get("frontier_exchanges", 0))
     del fused, graphed, model, opt, job, edges_dev, calls, timed
     torch.cuda.empty_cache()
     return res
@@ -1168,6 +1188,7 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                    "exposed_communication": head["exposed"], "host_build_seconds": head["build_s"]},
         "roofline": head["roofline"], "roofline_scoring": scoring_roofline(head),
         "loss_mean": head["loss_mean"],
+        **({"forward": head["forward"]} if head.get("forward") else {}),
     }
 
     # Sub-records, under a watchdog: a collective that cannot make progress in a sub-record must not take the headline
@@ -1205,6 +1226,7 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                 "roofline": h["roofline"], "gene_ranklist_ms_cold": h["score_ms"],
                 "users_scored_per_s_cold": h["n_scored"] / (h["score_ms"] * 1e-3),
                 "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"], "host_build_seconds": h["build_s"],
+                **({"forward": h["forward"], "frontier_exchanges_issued": h["frontier_exchanges"]} if h.get("forward") else {}),
             }
             del h
         except Exception as exc:      # noqa: BLE001

@@ -44,6 +44,9 @@ SIGNATURES = {
                                                ctypes.c_int64, c_ptr]),
     "chaorec_zero_rows_by_bits_f32": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr, c_ptr]),
     "chaorec_or_words_u32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int64, c_ptr]),
+    "chaorec_rows_list_from_bits": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
+    "chaorec_rows_mean_by_bits_f32": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_float, c_ptr, ctypes.c_int64, ctypes.c_int32,
+                                                     c_ptr, c_ptr]),
     "chaorec_spmm_csr_rowlist_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_float, c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr,
                                                     ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr,

@@ -722,6 +722,53 @@ __global__ __launch_bounds__(256) void zero_rows_by_bits_kernel(float *__restric
   }
 }
 
+// list[0 .. *list_n) = the rows flagged in a bitmap (arbitrary order; *list_n zero on entry): the work list of a list launch
+// over a frontier that exists as a bitmap only (a user shard's item frontier after the union over the ranks).
+__global__ __launch_bounds__(256) void rows_list_from_bits_kernel(const uint32_t *__restrict__ bits, int64_t n_rows,
+                                                                  int64_t n_words, int32_t *list, int32_t *list_n,
+                                                                  int64_t list_cap) {
+  const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi >= n_words) return;
+  uint32_t word = bits[wi];
+  if (!word) return;
+  const int cnt = __popc(word);
+  int at = atomicAdd(list_n, cnt);
+  while (word) {
+    const int b = __builtin_ctz(word);
+    word &= word - 1;
+    const int64_t r = wi * 32 + b;
+    if (r < n_rows && at < list_cap) list[at] = (int32_t)r;
+    ++at;
+  }
+}
+
+// out[r] = ((w t0[r] + w t1[r]) + ..) for the rows flagged in a bitmap (chaorec_rows_mean_f32's association): the layer mean of
+// a light step's item rows, whose propagated values arrive with the exchanges.
+struct BitsMeanTerms {
+  const float4 *t[8];
+  int n;
+};
+__global__ __launch_bounds__(256) void rows_mean_by_bits_kernel(const BitsMeanTerms T, float w, float4 *__restrict__ out,
+                                                                int64_t n_rows, int D4, const uint32_t *__restrict__ bits,
+                                                                int64_t n_words) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wi >= n_words) return;
+  uint32_t word = bits[wi];
+  while (word) {
+    const int b = __builtin_ctz(word);
+    word &= word - 1;
+    const int64_t r = wi * 32 + b;
+    if (r >= n_rows) break;
+    for (int c = lane; c < D4; c += 64) {
+      const size_t o = (size_t)r * D4 + c;
+      float4 a = mul_rn4(w, T.t[0][o]);
+      for (int k = 1; k < T.n; ++k) a = add_rn4(a, mul_rn4(w, T.t[k][o]));
+      out[o] = a;
+    }
+  }
+}
+
 // dst[w] = src[0][w] | src[1][w] | .. | src[n_src - 1][w]: the union of the ranks' row bitmaps after an all-gather (RCCL
 // has no bitwise-or reduction).
 __global__ __launch_bounds__(256) void or_words_kernel(uint32_t *dst, const uint32_t *src, int n_src,
@@ -979,6 +1026,33 @@ extern "C" int chaorec_zero_rows_by_bits_f32(float *y, int64_t n_rows, int32_t D
   hipLaunchKernelGGL(zero_rows_by_bits_kernel, dim3((unsigned)((n_words + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, n_rows,
                      D / 4, bits, n_words);
   return check_launch("zero_rows_by_bits_kernel");
+}
+
+extern "C" int chaorec_rows_list_from_bits(const uint32_t *bits, int64_t n_rows, int32_t *list, int32_t *list_n, int64_t list_cap,
+                                           void *stream) {
+  if (!bits || !list || !list_n) return fail(CHAOREC_E_INVALID, "rows_list_from_bits: NULL argument");
+  if (n_rows <= 0 || list_cap <= 0) return fail(CHAOREC_E_INVALID, "rows_list_from_bits: bad sizes");
+  const int64_t n_words = (n_rows + 31) / 32;
+  hipLaunchKernelGGL(rows_list_from_bits_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bits,
+                     n_rows, n_words, list, list_n, list_cap);
+  return check_launch("rows_list_from_bits_kernel");
+}
+
+extern "C" int chaorec_rows_mean_by_bits_f32(const float *const *terms, int32_t n_terms, float w, float *out, int64_t n_rows,
+                                             int32_t D, const uint32_t *bits, void *stream) {
+  if (!terms || !out || !bits) return fail(CHAOREC_E_INVALID, "rows_mean_by_bits: NULL argument");
+  if (n_terms < 1 || n_terms > 8) return fail(CHAOREC_E_INVALID, "rows_mean_by_bits: n_terms=%d must be in [1, 8]", n_terms);
+  if (n_rows <= 0 || D <= 0 || (D & 3)) return fail(CHAOREC_E_INVALID, "rows_mean_by_bits: n_rows=%lld D=%d", (long long)n_rows, D);
+  BitsMeanTerms T;
+  T.n = n_terms;
+  for (int k = 0; k < 8; ++k) {
+    if (k < n_terms && !terms[k]) return fail(CHAOREC_E_INVALID, "rows_mean_by_bits: NULL term %d", k);
+    T.t[k] = (const float4 *)(k < n_terms ? terms[k] : terms[0]);
+  }
+  const int64_t n_words = (n_rows + 31) / 32;
+  hipLaunchKernelGGL(rows_mean_by_bits_kernel, dim3((unsigned)((n_words + 3) / 4)), dim3(256), 0, (hipStream_t)stream, T, w,
+                     (float4 *)out, n_rows, D / 4, bits, n_words);
+  return check_launch("rows_mean_by_bits_kernel");
 }
 
 extern "C" int chaorec_or_words_u32(uint32_t *dst, const uint32_t *src, int32_t n_src, int64_t n_words, void *stream) {

@@ -736,6 +736,11 @@ class ShardedLightGCN(nn.Module):
     def gene_ranklist(self, topk=50, gather=False):
         """Rank this shard's users against the replicated item table; ids are GLOBAL (item + U_global)."""
         from . import ranking
+        if self.result_u is None:
+            raise RuntimeError("ShardedLightGCN.gene_ranklist: no propagated table -- the last training step was a light one "
+                               "(FusedShardedLightGCNStep with light_forward: only its batch's rows were computed).  Run the "
+                               "step before an evaluation with full_result=True (FusedShardedLightGCNStep.run does), or call "
+                               "forward() first")
         want_gather = gather and dist.is_initialized() and dist.get_world_size(self.group) > 1
         # (the shared evaluation path: carried thresholds from call to call, the list written straight to pinned memory)
         idx = ranking.gene_ranklist(self.result_u, self.num_user, self.num_item, self.hist, 1e-6, topk,
@@ -778,6 +783,11 @@ class _HipStepKernels:
     zero_rows_by_bits = staticmethod(ops.zero_rows_by_bits)
     rows_copy_by_bits = staticmethod(ops.rows_copy_by_bits)
     or_words = staticmethod(ops.or_words)
+    # the light forward
+    batch_rows = staticmethod(ops.batch_rows)
+    rows_list_from_bits = staticmethod(ops.rows_list_from_bits)
+    rows_mean_by_bits = staticmethod(ops.rows_mean_by_bits)
+    long_row_buffers = staticmethod(ops.long_row_buffers)
     sparse_widths = (64, 256)           # chaorec_spmm_csr_rowsparse_f32 / _rowlist_f32 are built for these D
 
 
@@ -804,11 +814,15 @@ class FusedShardedLightGCNStep:
     folded into the epilogue factors.  Item rows end identical on every rank (same sums, same Adam arithmetic)."""
 
     def __init__(self, model, optimizer, batch_size=1024, edges=None, seed=42, step_dev=None, given_batch=False,
-                 loss_accum=None, capture=True, kernels=None, group=None, steps_per_replay=1, split=None, sparse_bwd=None):
+                 loss_accum=None, capture=True, kernels=None, group=None, steps_per_replay=1, split=None, sparse_bwd=None,
+                 light_forward=None):
         """split: None = by size (item partial I_pad * D * 4 >= SPLIT_BYTES, or CHAOREC_DIST_SPLIT=0/1), True / False =
         the split / joined launch sequence (see _launch_split).  sparse_bwd: None = by size (optim.FusedLightGCNStep's
         rule: CHAOREC_SPARSE_BACKWARD=auto/0/1, CHAOREC_SPARSE_BACKWARD_MIN_ROWS), True / False = the first two backward
-        propagates over the batch's frontier only / dense (split launch sequence only)."""
+        propagates over the batch's frontier only / dense (split launch sequence only).  light_forward: None = with the
+        row-sparse backward (CHAOREC_LIGHT_FORWARD=0 switches it off), True / False: optim.FusedLightGCNStep's light step for
+        a shard -- the last two forward layers over the frontier's rows only (see _launch_split), model.result_u / result_i
+        withheld until a step with full_result=True."""
         from .optim import FusedAdam
         if not isinstance(optimizer, FusedAdam) or len(optimizer.param_groups) != 1:
             raise TypeError("FusedShardedLightGCNStep needs a FusedAdam with one parameter group")
@@ -867,15 +881,31 @@ class FusedShardedLightGCNStep:
         if sparse_bwd and not self.split:
             raise ValueError("FusedShardedLightGCNStep: the row-sparse backward exists for the split launch sequence only")
         self.sparse_bwd = bool(sparse_bwd)
+        if light_forward is None:
+            light_forward = self.sparse_bwd and 2 <= self.L <= 4 and _os.environ.get("CHAOREC_LIGHT_FORWARD", "auto") != "0"
+        if light_forward and not (self.sparse_bwd and 2 <= self.L <= 4):
+            raise ValueError("FusedShardedLightGCNStep: the light forward needs the row-sparse backward and 2 <= n_layers <= 4")
+        self.light = bool(light_forward)
+        self.result_complete = True
+        self.graph_full = None
         if self.sparse_bwd:
             wu, wi = (U + 31) // 32, (I + 31) // 32
             self._wu = wu
-            self._bits_all = torch.zeros(2 * (wu + wi) + 2, dtype=torch.int32, device=dev)     # (+ the two lists' lengths)
+            self._bits_all = torch.zeros(2 * (wu + wi) + 5, dtype=torch.int32, device=dev)     # (+ the five lists' lengths)
             cut = [0, wu, wu + wi, 2 * wu + wi, 2 * (wu + wi)]
             self.bits = [self._bits_all[cut[k]:cut[k + 1]] for k in range(4)]
             self._list_n = self._bits_all[cut[4]:]
             self._list_u = torch.zeros(U, dtype=torch.int32, device=dev)
             self._list_i = torch.zeros(I, dtype=torch.int32, device=dev)
+            if self.light:
+                # R0's local users / R0's items of ALL ranks / N1's items of ALL ranks: every rank computes its partial of
+                # every frontier item row (the other ranks' users may neighbour it)
+                self._list0_u = torch.zeros(self.B, dtype=torch.int32, device=dev)
+                self._list0_i = torch.zeros(min(I, 2 * self.B * self.world), dtype=torch.int32, device=dev)
+                self._list1_ig = torch.zeros(I, dtype=torch.int32, device=dev)
+                self._long_ui = self.K.long_row_buffers(shard.ui)
+                self._long_iu = self.K.long_row_buffers(shard.iu)
+                self.Z0 = torch.zeros((self.N_pad - U, D), dtype=torch.float32, device=dev)   # layer L's frontier partial
             self._bits_gather = torch.zeros((self.world, wi), dtype=torch.int32, device=dev)
             # the first backward item partial: non-zero in the frontier's rows only, ALL-ZERO between steps (its exchange
             # sums whole buffers; the rows a step wrote are zeroed again by that step)
@@ -904,12 +934,21 @@ class FusedShardedLightGCNStep:
                 with torch.cuda.graph(self.graph1, capture_error_mode=capture_mode()):
                     self._launch()
                 self.graph = self.graph1
+                if self.light:
+                    with torch.cuda.stream(s):
+                        self._launch(light=False)       # (eager first, like the light one above)
+                    torch.cuda.current_stream().wait_stream(s)
+                    torch.cuda.synchronize()
+                    self._restore_state(saved)
+                    self.graph_full = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_full, capture_error_mode=capture_mode()):
+                        self._launch(light=False)
                 if self.steps_per_replay > 1:
                     self.graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
                         for _ in range(self.steps_per_replay):
                             self._launch()
-                for gph in {id(self.graph1): self.graph1, id(self.graph): self.graph}.values():
+                for gph in {id(g_): g_ for g_ in (self.graph1, self.graph, self.graph_full) if g_ is not None}.values():
                     gph.replay()
                 torch.cuda.synchronize()
             finally:
@@ -933,6 +972,8 @@ class FusedShardedLightGCNStep:
                 self._bits_all.zero_()
                 self.Z.zero_()
                 self.S.zero_()
+                if self.light:
+                    self.Z0.zero_()
 
     def _union_item_bits(self, bits):
         """An item-row bitmap becomes the union over the ranks (one small all-gather + one launch; issued BEFORE the
@@ -945,8 +986,13 @@ class FusedShardedLightGCNStep:
         """Sum the item rows of a joined buffer over the ranks, in place; -> a handle to wait on."""
         return _sum_exchange_async(buf[self.U:], self.group)
 
+    def _exchange_frontier(self, buf, bits):
+        """The same for a FRONTIER buffer of item rows ([I_pad, D], all-zero on every rank outside the rows flagged in
+        `bits`, a bitmap united over the ranks): the p2p exchange moves the flagged rows only."""
+        return _sum_exchange_async(buf, self.group, bits=bits, n_rows=self.I)
+
     @torch.no_grad()
-    def _launch(self):
+    def _launch(self, light=None):
         K, model, opt, L, B, D = self.K, self.model, self.optimizer, self.L, self.B, self.D
         U, I, N = self.U, self.I, self.N
         if model.user_embedding.weight.data_ptr() != self.flat.data_ptr() or \
@@ -955,7 +1001,7 @@ class FusedShardedLightGCNStep:
             raise RuntimeError("FusedShardedLightGCNStep: the model's embedding tables were re-allocated after the step was "
                                "built; build a new step")
         if self.split:
-            return self._launch_split()
+            return self._launch_split(self.light if light is None else bool(light))
         group = opt.param_groups[0]
         shard, csr, w = model.shard, self.csr, 1.0 / (L + 1)
         xs = [self.flat]
@@ -999,7 +1045,7 @@ class FusedShardedLightGCNStep:
         model.result_u, model.result_i, model._result_cat = self.final[:U], self.final[U:N], None
 
     @torch.no_grad()
-    def _launch_split(self):
+    def _launch_split(self, light=False):
         """The same step with every joined launch cut into its two row blocks, so that EVERY exchange travels under
         compute (large item tables: config 5's 1 GB item partial takes longer over xGMI than the SpMM that produced it).
         Layer l + 1's item partial B_g^T x_u(l) needs only this rank's user rows of layer l -- not the exchanged item rows
@@ -1011,14 +1057,35 @@ class FusedShardedLightGCNStep:
 
         and the backward mirrors it (the gradient seed's exchange travels under the first B_g^T launch).  2 launches per
         layer and direction instead of 1 (4.4 us each: nothing against a millisecond exchange, too much at sports size --
-        hence by size).  Row for row the same sums in the same order as the joined launches: bit-identical results."""
+        hence by size).  Row for row the same sums in the same order as the joined launches: bit-identical results.
+
+        light: optim.FusedLightGCNStep's light step for a shard.  The batch is drawn first (its rows R0 flagged; the item
+        bitmaps made the union over the ranks), R0 expanded to N1 on both sides, and the forward runs
+            layers 1 .. L-2  dense, as above
+            layer  L-1       B_g^T over the list of N1's items OF ALL RANKS (every rank owes its partial of every frontier
+                             item row) into the frontier buffer Z -> exchanged as such; B_g over the list of N1's local users
+            layer  L         B_g^T over the list of R0's items of all ranks into Z0 -> exchange; B_g over the list of R0's local
+                             users with their layer mean in the epilogue; the item rows' mean by bitmap when Z0 has arrived
+        -- the same arithmetic for every row it computes; model.result_u / result_i are withheld (only R0's rows exist)."""
         K, model, opt, L, B, D = self.K, self.model, self.optimizer, self.L, self.B, self.D
         U, I, N = self.U, self.I, self.N
         group = opt.param_groups[0]
         shard, w = model.shard, 1.0 / (L + 1)
         ui, iu = shard.ui, shard.iu
+        draw = self.edges is not None
+        sp = self.sparse_bwd
+        if sp:
+            bu0, bi0, bu1, bi1 = self.bits
+        if light:
+            n_u1, n_i1, n_u0, n_i0, n_i1g = (self._list_n[k:k + 1] for k in range(5))
+            K.batch_rows(self.ids, self._bits_all, 32 * self._wu, edges=self.edges, hist=model.hist if draw else None,
+                         num_user=U, num_item=I, seed=self.seed, step=0, step_dev=self.step_dev)
+            self._frontier_bitmaps_and_lists()
+            K.rows_list_from_bits(bu0, U, self._list0_u, n_u0)
+            K.rows_list_from_bits(bi0, I, self._list0_i, n_i0)
+            K.rows_list_from_bits(bi1, I, self._list1_ig, n_i1g)
         xs, pend = [self.flat], None
-        for l in range(L):
+        for l in range(L - 2 if light else L):
             x, y = xs[-1], self.ybuf[l]
             K.spmm(iu, x[:U], y=y[U:N])
             nxt = self._exchange(y)
@@ -1030,32 +1097,46 @@ class FusedShardedLightGCNStep:
                 K.spmm(ui, x[U:N], y=y[:U])
             pend = nxt
             xs.append(y)
-        pend.wait()
-        lo = U if self.use_mean else 0
-        K.rows_mean([t[lo:N] for t in xs], w, self.final[lo:N])
-        draw = self.edges is not None
-        flags = dict(row_bits=self._bits_all, bits_item_offset=32 * self._wu) if self.sparse_bwd else {}
-        K.bpr_fwd_bwd(self.final, U, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef, self.ws, self.ids,
-                      edges=self.edges, hist=model.hist if draw else None, num_user=U, num_item=I, seed=self.seed, step=0,
-                      step_dev=self.step_dev, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc, **flags)
+        if light:
+            x, y = xs[-1], self.ybuf[L - 2]
+            # layer L-1 over N1
+            K.spmm_rowlist(iu, x[:U], self.Z[:I], self._list1_ig, n_i1g, long_rows=self._long_iu)
+            pz = self._exchange_frontier(self.Z, bi1)
+            if pend is not None:
+                pend.wait()
+            K.spmm_rowlist(ui, x[U:N], y[:U], self._list_u, n_u1, long_rows=self._long_ui)
+            # layer L over R0
+            K.spmm_rowlist(iu, y[:U], self.Z0[:I], self._list0_i, n_i0, long_rows=self._long_iu)
+            pz0 = self._exchange_frontier(self.Z0, bi0)
+            pz.wait()
+            K.spmm_rowlist(ui, self.Z[:I], None, self._list0_u, n_u0, mean_out=self.final[:U],
+                           mean_terms=[t[:U] for t in xs] + [y[:U]], mean_w=w, long_rows=self._long_ui)
+            pz0.wait()
+            K.rows_mean_by_bits([t[U:N] for t in xs] + [self.Z[:I], self.Z0[:I]], w, self.final[U:N], bi0)
+            K.zero_rows_by_bits(self.Z[:I], bi1)             # (both frontier buffers had their readers: all-zero again)
+            K.zero_rows_by_bits(self.Z0[:I], bi0)
+            flags = {}
+            K.bpr_fwd_bwd(self.final, U, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef, self.ws, self.ids,
+                          num_user=U, num_item=I, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
+        else:
+            pend.wait()
+            lo = U if self.use_mean else 0
+            K.rows_mean([t[lo:N] for t in xs], w, self.final[lo:N])
+            flags = dict(row_bits=self._bits_all, bits_item_offset=32 * self._wu) if sp else {}
+            K.bpr_fwd_bwd(self.final, U, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef, self.ws, self.ids,
+                          edges=self.edges, hist=model.hist if draw else None, num_user=U, num_item=I, seed=self.seed, step=0,
+                          step_dev=self.step_dev, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc, **flags)
         K.bpr_finalize(self.ws, B, D, model.reg_weight, self.out, out_total=self.static_loss, loss_accum=self.loss_accum,
                        advance=self.step_dev if draw else None)
         c = w / self.world
-        sp = self.sparse_bwd
-        if sp:
-            bu0, bi0, bu1, bi1 = self.bits
-            self._union_item_bits(bi0)
-            if L >= 3:
-                # N1's item rows: the batch items of every rank + the neighbours of this rank's batch users -> this rank's
-                # work list; their union over the ranks is what the second propagate may gather
-                K.expand_row_bits(ui, bu0, bi1, self._list_i, self._list_n[1:2], bits_self=bi0)
-                self._union_item_bits(bi1)
+        if sp and not light:
+            self._frontier_bitmaps_and_lists()
         # the seed: this rank's user rows as they are (G), the item rows summed over the ranks (S) while the first B_g^T
         # launch runs.  Row-sparse: S's item rows are a frontier buffer like Z (the batch items' rows copied in, exchanged as
         # such, zeroed again after their one reader)
         if sp:
             K.rows_copy_by_bits(self.S[U:N], self.G[U:N], bi0)
-            pend = _sum_exchange_async(self.S[U:], self.group, bits=bi0, n_rows=I)
+            pend = self._exchange_frontier(self.S[U:], bi0)
         else:
             self.S[U:].copy_(self.G[U:])
             pend = self._exchange(self.S)
@@ -1067,7 +1148,7 @@ class FusedShardedLightGCNStep:
             if how == "list":
                 K.spmm_rowlist(iu, gu, self.Z[:I], self._list_i, self._list_n[1:2], alpha=alpha, z=self.G[U:N], beta=c,
                                src_bits=bu0, z_bits=bi0)
-                nxt = _sum_exchange_async(self.Z, self.group, bits=bi1, n_rows=I)
+                nxt = self._exchange_frontier(self.Z, bi1)
             elif how == "gated":
                 K.spmm_rowsparse(iu, gu, Y[U:N], alpha=alpha, z=self.G[U:N], beta=c, src_bits=self.bits[2 * l], z_bits=bi0)
                 nxt = self._exchange(Y)
@@ -1082,7 +1163,6 @@ class FusedShardedLightGCNStep:
                 K.spmm_adam(ui, gi, self.flat[:U], self.m[:U], self.v[:U], self.bc, group["lr"], group["betas"],
                             group["eps"], group["weight_decay"], alpha=alpha, z=self.G[:U], beta=c, clear_z=True, **extra)
             elif how == "list":
-                K.expand_row_bits(iu, bi0, bu1, self._list_u, self._list_n[0:1], bits_self=bu0)
                 K.spmm_rowlist(ui, gi, Y[:U], self._list_u, self._list_n[0:1], alpha=alpha, z=self.G[:U], beta=c,
                                src_bits=bi0, z_bits=bu0)
             elif how == "gated":
@@ -1100,9 +1180,29 @@ class FusedShardedLightGCNStep:
                     group["weight_decay"], step_dev=opt._step_dev)
         if not sp:
             self.G[U:N].zero_()
-        model.result_u, model.result_i, model._result_cat = self.final[:U], self.final[U:N], None
+        self._publish(not light)
 
-    def __call__(self, users=None, pos=None, neg=None, single=False):
+    def _publish(self, complete):
+        """model.result_u / result_i = this step's propagated tables -- or, after a light step, nothing (only the batch's
+        rows of them exist; ShardedLightGCN.gene_ranklist fails on None)."""
+        self.result_complete = bool(complete)
+        U, N = self.U, self.N
+        self.model.result_u, self.model.result_i = (self.final[:U], self.final[U:N]) if complete else (None, None)
+        self.model._result_cat = None
+
+    def _frontier_bitmaps_and_lists(self):
+        """R0's bitmaps (set by the batch / BPR launch) -> item rows united over the ranks; N1 on both sides: bitmaps, this
+        rank's work lists for the backward's first layer, N1's item bitmap united over the ranks.  The small collectives go
+        FIRST: a process group's collectives run in issue order, behind a 1 GB exchange they would wait for it."""
+        K, shard = self.K, self.model.shard
+        bu0, bi0, bu1, bi1 = self.bits
+        self._union_item_bits(bi0)
+        if self.L >= 3 or self.light:
+            K.expand_row_bits(shard.ui, bu0, bi1, self._list_i, self._list_n[1:2], bits_self=bi0)
+            self._union_item_bits(bi1)
+            K.expand_row_bits(shard.iu, bi0, bu1, self._list_u, self._list_n[0:1], bits_self=bu0)
+
+    def __call__(self, users=None, pos=None, neg=None, single=False, full_result=False):
         """One replay = `steps_per_replay` training steps (single=True: exactly one) -> this rank's last batch loss
         (device scalar; the global loss is the mean over ranks).  users / pos / neg (shard-local ids, items as
         item + U_g) only in given_batch mode."""
@@ -1110,21 +1210,27 @@ class FusedShardedLightGCNStep:
             self.ids[0].copy_(users, non_blocking=True)
             torch.sub(pos.to(self.ids[1].device), self.U, out=self.ids[1])
             torch.sub(neg.to(self.ids[2].device), self.U, out=self.ids[2])
+        full = bool(full_result) and self.light
         if self.graph is not None:
-            (self.graph1 if single else self.graph).replay()
+            (self.graph_full if full else self.graph1 if single else self.graph).replay()
         else:
-            self._launch()
+            self._launch(light=False if full else None)
         self.replays += 1
-        self.model.result_u, self.model.result_i, self.model._result_cat = self.final[:self.U], self.final[self.U:self.N], None
+        self._publish(full or not self.light)
         return self.static_loss
 
-    def run(self, n_steps):
-        """n_steps training steps: whole replays first, single-step replays for the remainder."""
+    def run(self, n_steps, full_last=True):
+        """n_steps training steps: whole replays first, single-step replays for the remainder; with the light forward the
+        last one is a full step (full_last: the evaluation comes next)."""
         k = self.steps_per_replay
-        for _ in range(n_steps // k):
+        tail = 1 if (self.light and full_last and n_steps > 0) else 0
+        n = n_steps - tail
+        for _ in range(n // k):
             self()
-        for _ in range(n_steps % k):
+        for _ in range(n % k):
             self(single=True)
+        if tail:
+            self(full_result=True)
         return self.static_loss
 
 

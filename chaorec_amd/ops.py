@@ -152,6 +152,27 @@ def rows_copy_by_bits(dst, src, bits):
     return dst
 
 
+def rows_list_from_bits(bits, n_rows, row_list, list_n):
+    """row_list[0 .. list_n) = the rows flagged in `bits` (chaorec_rows_list_from_bits; list_n zero on entry)."""
+    _need_cuda(bits, row_list, list_n)
+    _lib.check(_lib.load().chaorec_rows_list_from_bits(_ptr(bits), int(n_rows), _ptr(row_list), _ptr(list_n), row_list.numel(),
+                                                       _stream()), "chaorec_rows_list_from_bits")
+    return row_list
+
+
+def rows_mean_by_bits(terms, w, out, bits):
+    """out[r] = w * terms[0][r] + w * terms[1][r] + ... for the rows flagged in `bits` (chaorec_rows_mean_by_bits_f32)."""
+    _need_cuda(out, bits, *terms)
+    for t in terms:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != out.shape:
+            raise TypeError("rows_mean_by_bits: contiguous float32 terms of out's shape")
+    ptrs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    _lib.check(_lib.load().chaorec_rows_mean_by_bits_f32(ctypes.cast(ptrs, ctypes.c_void_p), len(terms), float(w), _ptr(out),
+                                                         out.shape[0], out.shape[1], _ptr(bits), _stream()),
+               "chaorec_rows_mean_by_bits_f32")
+    return out
+
+
 def or_words(dst, src):
     """dst[w] = OR_k src[k, w] (chaorec_or_words_u32): the union of all-gathered row bitmaps."""
     _need_cuda(dst, src)

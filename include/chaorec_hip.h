@@ -153,6 +153,16 @@ int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col, int64_t n
  * without a pass over the whole of it).  D a multiple of 4. */
 int chaorec_zero_rows_by_bits_f32(float *y, int64_t n_rows, int32_t D, const uint32_t *bits, void *stream);
 
+/* list[0 .. *list_n) = the rows flagged in `bits` (arbitrary order; *list_n zero on entry, list_cap entries): the work list
+ * of a chaorec_spmm_csr_rowlist_f32 launch over a frontier that exists as a bitmap only. */
+int chaorec_rows_list_from_bits(const uint32_t *bits, int64_t n_rows, int32_t *list, int32_t *list_n, int64_t list_cap,
+                                void *stream);
+
+/* out[r] = ((w t0[r] + w t1[r]) + ..) for the rows flagged in `bits` (chaorec_rows_mean_f32's association; n_terms <= 8): the
+ * layer mean of Model/LightGCN.py:85-95 for a light step's item rows of a user shard. */
+int chaorec_rows_mean_by_bits_f32(const float *const *terms, int32_t n_terms, float w, float *out, int64_t n_rows, int32_t D,
+                                  const uint32_t *bits, void *stream);
+
 /* dst[w] = src[0][w] | .. | src[n_src - 1][w] (src: n_src bitmaps of n_words words, back to back): the union of the ranks'
  * row bitmaps after an all-gather -- RCCL has no bitwise-or reduction.  dst may be one of the sources. */
 int chaorec_or_words_u32(uint32_t *dst, const uint32_t *src, int32_t n_src, int64_t n_words, void *stream);

@@ -311,16 +311,66 @@ class _OracleStepKernels:
         return _oracle_spmm(csr, xm, alpha=alpha, z=zm, beta=beta)
 
     @classmethod
-    def spmm_rowlist(cls, csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None):
-        full = cls._gated(csr, x, alpha, z, beta, src_bits, z_bits)
+    def spmm_rowlist(cls, csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None, mean_out=None,
+                     mean_terms=(), mean_w=0.0, long_rows=None):
         rows = row_list[:int(list_n[0])].long()
         assert len(torch.unique(rows)) == len(rows)
         keep = torch.zeros(csr.n_rows, dtype=torch.bool)
         keep[rows] = True
-        assert float(full[~keep].abs().max()) == 0.0 if (~keep).any() else True      # (the list covers every non-zero row)
-        if float(y[~keep].abs().nan_to_num(1.0).max() if (~keep).any() else 0.0) != 0.0:
-            y[~keep] = float("nan")                      # stale rows: poisoned; an all-zero buffer stays all-zero
-        y[rows] = full[rows]
+        if src_bits is None:
+            # a forward list launch: every entry of a listed row is gathered -- a NaN (stale) source row it reads shows up
+            assert z is None
+            xs = x.clone()
+            full = torch.zeros(csr.n_rows, x.shape[1])
+            rp, col, val = csr.rowptr.numpy(), csr.col.numpy(), csr.val
+            sub = _oracle_spmm(csr, torch.nan_to_num(xs, nan=0.0), alpha=alpha)
+            for r in rows.tolist():
+                assert not torch.isnan(xs[col[rp[r]:rp[r + 1]]]).any(), "a listed row gathers a row nobody computed"
+            full[rows] = sub[rows]
+        else:
+            full = cls._gated(csr, x, alpha, z, beta, src_bits, z_bits)
+            assert float(full[~keep].abs().max()) == 0.0 if (~keep).any() else True  # (the list covers every non-zero row)
+        if y is not None:
+            if float(y[~keep].abs().nan_to_num(1.0).max() if (~keep).any() else 0.0) != 0.0:
+                y[~keep] = float("nan")                  # stale rows: poisoned; an all-zero buffer stays all-zero
+            y[rows] = full[rows]
+        if mean_out is not None:
+            a = mean_w * mean_terms[0][rows]
+            for t in mean_terms[1:]:
+                a = a + mean_w * t[rows]
+            assert not torch.isnan(a).any()
+            mean_out[~keep] = float("nan")               # (only the listed rows of the mean exist)
+            mean_out[rows] = a + mean_w * full[rows]
+
+    @classmethod
+    def batch_rows(cls, ids, row_bits, bits_item_offset, row_list=None, list_n=None, edges=None, hist=None, num_user=0,
+                   num_item=0, seed=0, step=0, step_dev=None, perm=None, perm_pos=None, pos_offset=0):
+        assert edges is None and row_list is None
+        u, p, n = (t.numpy() for t in ids)
+        cls._set(row_bits, u)
+        cls._set(row_bits, bits_item_offset + p)
+        cls._set(row_bits, bits_item_offset + n)
+
+    @classmethod
+    def rows_list_from_bits(cls, bits, n_rows, row_list, list_n):
+        rows = np.nonzero(cls._rows(bits, n_rows))[0]
+        n0 = int(list_n[0])
+        row_list[n0:n0 + len(rows)] = torch.from_numpy(rows[::-1].astype(np.int32).copy())
+        list_n[0] = n0 + len(rows)
+
+    @classmethod
+    def rows_mean_by_bits(cls, terms, w, out, bits):
+        m = torch.from_numpy(cls._rows(bits, out.shape[0]))
+        a = w * terms[0][m]
+        for t in terms[1:]:
+            a = a + w * t[m]
+        assert not torch.isnan(a).any()
+        out[~m] = float("nan")
+        out[m] = a
+
+    @staticmethod
+    def long_row_buffers(csr, threshold=None):
+        return None
 
     @classmethod
     def spmm_rowsparse(cls, csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None):
@@ -373,7 +423,7 @@ class _OracleStepKernels:
             loss_accum += ws[0]
 
 
-def _worker_fused(rank, world, port, tmp, mode, L, split=False, sparse=False):
+def _worker_fused(rank, world, port, tmp, mode, L, split=False, sparse=False, light=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = mode
@@ -392,8 +442,8 @@ def _worker_fused(rank, world, port, tmp, mode, L, split=False, sparse=False):
     x0u, x0i = m.user_embedding.weight.detach().clone().numpy(), m.item_embedding.weight.detach().clone().numpy()
     opt = FusedAdam(m.parameters(), lr=1e-2)
     step = cdist.FusedShardedLightGCNStep(m, opt, batch_size=B, given_batch=True, capture=False, kernels=_OracleStepKernels,
-                                          split=split, sparse_bwd=sparse)
-    assert step.split == split and step.sparse_bwd == sparse
+                                          split=split, sparse_bwd=sparse, light_forward=light)
+    assert step.split == split and step.sparse_bwd == sparse and step.light == light
     assert step.N_pad % world == (shard.num_user_local % world)          # item rows padded to a multiple of the world size
     rng = np.random.default_rng(100 + rank)
     batches, losses = [], []
@@ -402,10 +452,13 @@ def _worker_fused(rank, world, port, tmp, mode, L, split=False, sparse=False):
         users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64))
         pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64))
         neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + I, B))
-        losses.append(float(step(users, pos, neg)))
+        losses.append(float(step(users, pos, neg, full_result=(t == T - 1))))
+        assert (m.result_u is None) == (light and t < T - 1)
         batches.append(np.stack([users.numpy() + shard.u0, pos.numpy() - shard.num_user_local,
                                  neg.numpy() - shard.num_user_local]))
     assert float(step.G.abs().max()) == 0.0                               # the gradient buffer is all-zero between steps
+    if light:
+        assert float(step.Z0.abs().max()) == 0.0
     if sparse:
         assert float(step.Z.abs().max()) == 0.0 and int(step._bits_all.abs().max()) == 0       # ... and so are these
         assert float(step.S[step.U:].abs().max()) == 0.0
@@ -416,20 +469,23 @@ def _worker_fused(rank, world, port, tmp, mode, L, split=False, sparse=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,L,split,sparse", [
-    (2, "allreduce", 3, False, False), (2, "direct", 1, False, False), (4, "rs_ag", 2, False, False),
-    (2, "auto", 3, True, False), (4, "allreduce", 2, True, False), (2, "rs_ag", 1, True, False),
-    (2, "allreduce", 3, True, True), (4, "rs_ag", 4, True, True), (2, "auto", 2, True, True)])
-def test_fused_sharded_step_trains_like_the_single_process_oracle(oracle, world, mode, L, split, sparse):
+@pytest.mark.parametrize("world,mode,L,split,sparse,light", [
+    (2, "allreduce", 3, False, False, False), (2, "direct", 1, False, False, False), (4, "rs_ag", 2, False, False, False),
+    (2, "auto", 3, True, False, False), (4, "allreduce", 2, True, False, False), (2, "rs_ag", 1, True, False, False),
+    (2, "allreduce", 3, True, True, False), (4, "rs_ag", 4, True, True, False), (2, "auto", 2, True, True, False),
+    (2, "allreduce", 3, True, True, True), (4, "rs_ag", 4, True, True, True), (2, "auto", 2, True, True, True)])
+def test_fused_sharded_step_trains_like_the_single_process_oracle(oracle, world, mode, L, split, sparse, light):
     """dist.FusedShardedLightGCNStep (joined-graph propagates, in-place item exchanges, Adam in the last propagate /
     one fused launch for the replicated item rows) over T optimizer steps against the oracle on the WHOLE graph: the global
     loss is the mean of the ranks' batch losses, torch.optim.Adam's arithmetic on its gradient.  split=True: the launch
     sequence of large item tables (every joined launch as its two row blocks, every exchange in flight under the next
     launches, dist.FusedShardedLightGCNStep._launch_split).  sparse=True: the first two backward propagates over the
     batch's frontier only (row lists / gated gathers; item bitmaps united over the ranks) -- the stand-in kernels turn every
-    stale row such a launch leaves behind into NaN, so a reader of one cannot go unnoticed."""
+    stale row such a launch leaves behind into NaN, so a reader of one cannot go unnoticed.  light=True: + the light forward
+    (batch rows first; the last two layers over the frontier's row lists, the item rows' partials through frontier buffers;
+    model.result withheld until the last step, which is a full one)."""
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker_fused, args=(world, _free_port(), tmp, mode, L, split, sparse), nprocs=world, join=True)
+        mp.spawn(_worker_fused, args=(world, _free_port(), tmp, mode, L, split, sparse, light), nprocs=world, join=True)
         r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
     U, I, D, T = 500, 203, 16, 3
     edges = _heavy_tailed_graph(U, I)

@@ -34,7 +34,7 @@ def _problem():
     return edges, x0, batches
 
 
-def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False, sparse=False):
+def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False, sparse=False, light=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = exchange
@@ -55,8 +55,8 @@ def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False, sparse
         m.user_embedding.weight.copy_(x0[shard.u0:shard.u1])
         m.item_embedding.weight.copy_(x0[U:])
     step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=False,
-                                          split=split, sparse_bwd=sparse)
-    assert step.split == split and step.sparse_bwd == sparse
+                                          split=split, sparse_bwd=sparse, light_forward=light)
+    assert step.split == split and step.sparse_bwd == sparse and step.light == light
     losses = []
     for t in range(T):
         # this rank's batch: the triples of BOTH ranks' draws whose user it owns would change the batch size; instead
@@ -66,9 +66,12 @@ def _worker(rank, world, port, tmp, L, exchange="allreduce", split=False, sparse
         users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64)).to(dev)
         pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64)).to(dev)
         neg = torch.from_numpy(rng.integers(shard.num_user_local, shard.num_user_local + I, B)).to(dev)
-        losses.append(float(step(users, pos, neg)))
+        losses.append(float(step(users, pos, neg, full_result=(t == T - 1))))
+        assert (m.result_u is None) == (light and t < T - 1)
     torch.cuda.synchronize()
     assert float(step.G.abs().max()) == 0.0
+    if light:
+        assert float(step.Z0.abs().max()) == 0.0
     if sparse:          # what the step leaves behind for the next one: no flag, no listed row, an all-zero frontier buffer
         assert float(step.Z.abs().max()) == 0.0 and int(step._bits_all.abs().max()) == 0
         assert float(step.S[step.U:].abs().max()) == 0.0
@@ -122,7 +125,7 @@ def _p2p_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False, sparse=False):
+def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False, sparse=False, light=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_DIST_EXCHANGE"] = exchange
@@ -143,7 +146,7 @@ def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False, 
         m.user_embedding.weight.copy_(x0[:U])
         m.item_embedding.weight.copy_(x0[U:])
     step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True, capture=True,
-                                          split=split, sparse_bwd=sparse)
+                                          split=split, sparse_bwd=sparse, light_forward=light)
     losses = []
     for t in range(T):
         rng = np.random.default_rng(100 * t)
@@ -151,9 +154,9 @@ def _rccl_worker(rank, world, port, tmp, exchange, direct_capture, split=False, 
         users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64)).to(dev)
         pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64)).to(dev)
         neg = torch.from_numpy(rng.integers(U, U + I, B)).to(dev)
-        losses.append(float(step(users, pos, neg)))
+        losses.append(float(step(users, pos, neg, full_result=(t == T - 1))))
     torch.cuda.synchronize()
-    np.savez(os.path.join(tmp, f"rccl_{exchange}_{direct_capture}_{int(split)}_{int(sparse)}.npz"), xu=m.user_embedding.weight.detach().cpu().numpy(),
+    np.savez(os.path.join(tmp, f"rccl_{exchange}_{direct_capture}_{int(split)}_{int(sparse) + int(light)}.npz"), xu=m.user_embedding.weight.detach().cpu().numpy(),
              xi=m.item_embedding.weight.detach().cpu().numpy(), losses=np.array(losses), used=cdist.exchange_mode_used())
     dist.destroy_process_group()
 
@@ -171,11 +174,12 @@ def test_captured_exchanges_on_a_one_rank_rccl_group():
                                             ("direct", "p2p", False, False), ("direct", "rs_ag", False, False),
                                             ("allreduce", "rs_ag", True, False), ("p2p", "rs_ag", True, False),
                                             ("rs_ag", "rs_ag", True, False), ("allreduce", "rs_ag", True, True),
-                                            ("p2p", "rs_ag", True, True)):
+                                            ("p2p", "rs_ag", True, True), ("allreduce", "rs_ag", True, 2), ("p2p", "rs_ag", True, 2)):
             # split=True: every exchange in flight under the next launches (RCCL's own stream / the p2p side stream, forked
             # and joined inside the captured graph); sparse=True: + the row-sparse backward (its bitmap all-gathers are
-            # RCCL calls inside the graph too)
-            mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, exchange, dc, split, sparse), nprocs=1, join=True)
+            # RCCL calls inside the graph too); sparse=2: + the light forward (frontier exchanges; a second captured graph
+            # holds the full step that the last call replays)
+            mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, exchange, dc, split, bool(sparse), sparse == 2), nprocs=1, join=True)
             out[(exchange, dc, split, sparse)] = dict(np.load(os.path.join(tmp, f"rccl_{exchange}_{dc}_{int(split)}_{int(sparse)}.npz")))
     ref = out[("allreduce", "rs_ag", False, False)]
     for key, r in out.items():
@@ -260,16 +264,18 @@ def test_p2p_exchange_sums_like_an_all_reduce(world):
 @pytest.mark.parametrize("L,world,exchange,split,sparse", [
     (1, 2, "allreduce", False, False), (3, 2, "allreduce", False, False), (2, 4, "allreduce", False, False),
     (3, 2, "p2p", False, False), (2, 4, "p2p", False, False), (3, 2, "allreduce", True, False), (2, 4, "p2p", True, False),
-    (1, 2, "p2p", True, False), (3, 2, "allreduce", True, True), (4, 4, "p2p", True, True), (2, 2, "allreduce", True, True)])
+    (1, 2, "p2p", True, False), (3, 2, "allreduce", True, True), (4, 4, "p2p", True, True), (2, 2, "allreduce", True, True),
+    (3, 2, "p2p", True, 2), (4, 4, "allreduce", True, 2), (2, 2, "p2p", True, 2)])
 def test_fused_sharded_step_world2_on_the_kernels(oracle, L, world, exchange, split, sparse):
     """split=True: the launch sequence of large item tables (dist.FusedShardedLightGCNStep._launch_split) -- every joined
     launch as its two row blocks, every exchange travelling under the launches that follow it.  sparse=True: + the
-    row-sparse backward (row lists at L >= 3, gated gathers, item bitmaps united over the ranks)."""
+    row-sparse backward (row lists at L >= 3, gated gathers, item bitmaps united over the ranks); sparse=2: + the light
+    forward (the last two layers over the frontier's row lists, frontier exchanges, the last step a full one)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(world, _free_port(), tmp, L, exchange, split, sparse), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), tmp, L, exchange, split, bool(sparse), sparse == 2), nprocs=world, join=True)
         r = [np.load(os.path.join(tmp, f"rank{k}.npz")) for k in range(world)]
     # the whole-graph reference: the oracle's loss gradient of the mean over the ranks' batches + Adam, in fp64
     from chaorec_amd import dist as cdist
@@ -350,29 +356,33 @@ def test_sharded_rowsparse_backward_equals_the_dense_one():
     edges, x0, _ = _problem()
     for L in (2, 3, 4):
         out = {}
-        for sparse in (False, True):
+        for sparse in (False, True, 2):                   # (2: + the light forward)
             shard = cdist.UserShard.from_local(edges, [0, U], I, 1, 0, dev)
             m = cdist.ShardedLightGCN(shard, None, D, 1e-3, L, dev, seed=1).to(dev)
             with torch.no_grad():
                 m.user_embedding.weight.copy_(x0[:U])
                 m.item_embedding.weight.copy_(x0[U:])
             step = cdist.FusedShardedLightGCNStep(m, FusedAdam(m.parameters(), lr=1e-2), batch_size=B, given_batch=True,
-                                                  capture=True, split=True, sparse_bwd=sparse)
+                                                  capture=True, split=True, sparse_bwd=bool(sparse), light_forward=sparse == 2)
             for t in range(T):
                 rng = np.random.default_rng(100 * t)
                 sel = rng.choice(len(shard.local_edges), B, replace=False)
                 users = torch.from_numpy(shard.local_edges[sel, 0].astype(np.int64)).to(dev)
                 pos = torch.from_numpy(shard.local_edges[sel, 1].astype(np.int64)).to(dev)
                 neg = torch.from_numpy(rng.integers(U, U + I, B)).to(dev)
-                step(users, pos, neg)
+                step(users, pos, neg, full_result=(t == T - 1))
             torch.cuda.synchronize()
             assert float(step.G.abs().max()) == 0.0
             if sparse:
                 assert float(step.Z.abs().max()) == 0.0 and int(step._bits_all.abs().max()) == 0
-            out[sparse] = (m.user_embedding.weight.detach().cpu(), m.item_embedding.weight.detach().cpu())
-        for a, b in zip(out[False], out[True]):
-            d = (a - b).abs()
-            assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7, L
+            if sparse == 2:
+                assert float(step.Z0.abs().max()) == 0.0
+            out[sparse] = (m.user_embedding.weight.detach().cpu(), m.item_embedding.weight.detach().cpu(),
+                           m.result_u.detach().cpu(), m.result_i.detach().cpu())
+        for key in (True, 2):
+            for a, b in zip(out[False], out[key]):
+                d = (a - b).abs()
+                assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7, (L, key)
 
 
 def _calibrate_worker(rank, world, port, tmp, backend):
