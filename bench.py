@@ -996,8 +996,9 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
     exposed = None
     if fused is not None and cdist._active(None) and not probe_mode:
         saved = fused._save_state()
-        real_exchange = fused._exchange
+        real_exchange, real_frontier = fused._exchange, fused._exchange_frontier
         fused._exchange = lambda buf: cdist._Pending(None)
+        fused._exchange_frontier = lambda buf, bits: cdist._Pending(None)
         try:
             for _ in range(2):
                 fused._launch()
