@@ -535,7 +535,8 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                                  (lambda g=g, y=y, alpha=alpha: (
                                      None if light else expand_n1(),
                                      ops.spmm_rowlist_raw(csr, g, y, stepper._row_list, stepper._list_n, alpha=alpha, z=G, beta=w,
-                                                          src_bits=stepper.bits[0], z_bits=stepper.bits[0])), csr, D)))
+                                                          src_bits=stepper.bits[0], z_bits=stepper.bits[0],
+                                                          long_rows=stepper._long)), csr, D)))
             whole.append(sparse_calls[-1][1])
         elif sparse_bwd and l < 2:
             sparse_calls.append(("backward propagate %d, every row, gathers gated by the source's bitmap" % (l + 1),

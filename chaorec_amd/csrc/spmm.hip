@@ -1001,6 +1001,113 @@ __global__ __launch_bounds__(256) void spmm_rowlist_long_kernel(const int64_t *_
     }
   }
 }
+// The long rows of a GATED list launch (the backward's first propagate: a listed row's entries count only where the source is
+// flagged, a handful among a popular item's 1e4-1e5): one WORKGROUP per row scans 1024 entries per round -- coalesced (col, val)
+// loads, a bit test each -- and queues the flagged ones in ENTRY ORDER (wave ballots + a prefix over the 4 x 4 counts); the
+// queue is then gathered and added in that order by one lane group: the sequential CSR-order sum over the flagged entries,
+// which is the dense sum bit for bit (the others contribute +0).  One lane group scanning such a row alone was the launch.
+__global__ __launch_bounds__(256) void spmm_rowlist_long_gated_kernel(const int64_t *__restrict__ rowptr,
+                                                                      const int32_t *__restrict__ col,
+                                                                      const float *__restrict__ val, const float *__restrict__ x,
+                                                                      float *__restrict__ y, int D4, float alpha, const float *z,
+                                                                      float beta, const uint32_t *__restrict__ src_bits,
+                                                                      const uint32_t *__restrict__ z_bits, const ListMean mean,
+                                                                      const LongRows lr) {
+  constexpr int Q = 2048, U4 = 4;
+  __shared__ int q_c[Q];
+  __shared__ float q_v[Q];
+  __shared__ int cnt[U4][4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t n = min((int64_t)lr.cnt[0], lr.cap);
+  const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
+  const int lic = min(lane, D4 - 1);
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int64_t r = lr.list[i];
+    const int64_t e0 = rowptr[r];
+    const int deg = (int)(rowptr[r + 1] - e0);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);     // (wave 0, lanes < D4)
+    int qn = 0;                                        // queued entries (block-uniform)
+    auto flush = [&]() {                               // (called by every thread; the queue is complete and visible)
+      if (wave == 0) {
+        for (int j = 0; j < qn; j += 8) {
+          float4 xv[8];
+          float vv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int jj = min(j + u, qn - 1);
+            xv[u] = x4[(size_t)q_c[jj] * (size_t)D4 + lic];
+            vv[u] = q_v[jj];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (j + u < qn) sum = add_rn4(sum, mul_rn4(vv[u], xv[u]));
+        }
+      }
+      __syncthreads();
+      qn = 0;
+    };
+    for (int base = 0; base < deg; base += U4 * 256) {
+      int c[U4];
+      float v[U4];
+      bool ok[U4];
+#pragma unroll
+      for (int u = 0; u < U4; ++u) {
+        const int e = base + u * 256 + tid;
+        ok[u] = e < deg;
+        const int64_t ec = e0 + min(e, deg - 1);
+        c[u] = col[ec];
+        v[u] = val[ec];
+      }
+      int rank_in_wave[U4], n_wave[U4];
+#pragma unroll
+      for (int u = 0; u < U4; ++u) {
+        ok[u] = ok[u] && row_bit(src_bits, c[u]);
+        const unsigned long long b = __ballot(ok[u]);
+        rank_in_wave[u] = __popcll(b & ((1ull << lane) - 1ull));
+        n_wave[u] = __popcll(b);
+        if (lane == 0) cnt[u][wave] = n_wave[u];
+      }
+      __syncthreads();
+      int before[U4], total = 0;                       // entry order = u-major, wave-minor, lane
+#pragma unroll
+      for (int u = 0; u < U4; ++u) {
+        int mine = 0, all_u = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          if (w < wave) mine += cnt[u][w];
+          all_u += cnt[u][w];
+        }
+        before[u] = total + mine;
+        total += all_u;
+      }
+      if (qn + total > Q) {                            // (block-uniform) -- cannot happen twice: total <= 1024 < Q
+        __syncthreads();
+        flush();
+      }
+#pragma unroll
+      for (int u = 0; u < U4; ++u)
+        if (ok[u]) {
+          q_c[qn + before[u] + rank_in_wave[u]] = c[u];
+          q_v[qn + before[u] + rank_in_wave[u]] = v[u];
+        }
+      qn += total;
+      __syncthreads();                                 // (the counts are re-written next round; the queue is visible)
+    }
+    flush();
+    if (wave == 0 && lane < D4) {
+      float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z && (!z_bits || row_bit(z_bits, r))) zrow = reinterpret_cast<const float4 *>(z)[(size_t)r * D4 + lane];
+      rowlist_epilogue(r, D4, lane, sum, alpha, z, beta, zrow, y, mean);
+    }
+  }
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(lr.cnt + 1, 1) == (int)gridDim.x - 1) {
+      lr.cnt[0] = 0;
+      lr.cnt[1] = 0;
+    }
+  }
+}
 }  // namespace chaorec
 
 extern "C" int chaorec_expand_row_bits(const int64_t *rowptr, const int32_t *col, int64_t n_rows, const uint32_t *bits_in,
@@ -1077,7 +1184,6 @@ extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t
   if (D < 64 || D > 256 || (D & 3)) return fail(CHAOREC_E_INVALID, "spmm (row list): D=%d must be a multiple of 4 in [64, 256]", D);
   if ((long_list == nullptr) != (long_cnt == nullptr) || (long_list && (long_cap <= 0 || long_threshold < 1)))
     return fail(CHAOREC_E_INVALID, "spmm (row list): long_list, long_cnt, long_cap and long_threshold come together");
-  if (long_list && src_bits) return fail(CHAOREC_E_INVALID, "spmm (row list): the long-row launch gathers every entry (no src_bits)");
   ListMean mean;
   std::memset(&mean, 0, sizeof(mean));
   if (mean_out) {
@@ -1100,6 +1206,12 @@ extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t
   int rc = check_launch("spmm_rowlist_kernel");
   if (rc != CHAOREC_OK || !long_list) return rc;
   const dim3 lgrid(1024);                   // one workgroup per long row, striding
+  if (src_bits) {
+#define CHAOREC_ROWLIST_GATED_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, src_bits, z_bits, mean, lr
+    hipLaunchKernelGGL(spmm_rowlist_long_gated_kernel, lgrid, block, 0, st, CHAOREC_ROWLIST_GATED_ARGS);
+#undef CHAOREC_ROWLIST_GATED_ARGS
+    return check_launch("spmm_rowlist_long_gated_kernel");
+  }
 #define CHAOREC_ROWLIST_LONG_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, z_bits, mean, lr
   if (D4 <= 16) hipLaunchKernelGGL((spmm_rowlist_long_kernel<16>), lgrid, block, 0, st, CHAOREC_ROWLIST_LONG_ARGS);
   else if (D4 <= 32) hipLaunchKernelGGL((spmm_rowlist_long_kernel<32>), lgrid, block, 0, st, CHAOREC_ROWLIST_LONG_ARGS);

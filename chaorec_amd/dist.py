@@ -897,14 +897,14 @@ class FusedShardedLightGCNStep:
             self._list_n = self._bits_all[cut[4]:]
             self._list_u = torch.zeros(U, dtype=torch.int32, device=dev)
             self._list_i = torch.zeros(I, dtype=torch.int32, device=dev)
+            self._long_ui = self.K.long_row_buffers(shard.ui)
+            self._long_iu = self.K.long_row_buffers(shard.iu)
             if self.light:
                 # R0's local users / R0's items of ALL ranks / N1's items of ALL ranks: every rank computes its partial of
                 # every frontier item row (the other ranks' users may neighbour it)
                 self._list0_u = torch.zeros(self.B, dtype=torch.int32, device=dev)
                 self._list0_i = torch.zeros(min(I, 2 * self.B * self.world), dtype=torch.int32, device=dev)
                 self._list1_ig = torch.zeros(I, dtype=torch.int32, device=dev)
-                self._long_ui = self.K.long_row_buffers(shard.ui)
-                self._long_iu = self.K.long_row_buffers(shard.iu)
                 self.Z0 = torch.zeros((self.N_pad - U, D), dtype=torch.float32, device=dev)   # layer L's frontier partial
             self._bits_gather = torch.zeros((self.world, wi), dtype=torch.int32, device=dev)
             # the first backward item partial: non-zero in the frontier's rows only, ALL-ZERO between steps (its exchange
@@ -1147,7 +1147,7 @@ class FusedShardedLightGCNStep:
             how = "dense" if (not sp or last or l >= 2) else "list" if (l == 0 and L >= 3) else "gated"
             if how == "list":
                 K.spmm_rowlist(iu, gu, self.Z[:I], self._list_i, self._list_n[1:2], alpha=alpha, z=self.G[U:N], beta=c,
-                               src_bits=bu0, z_bits=bi0)
+                               src_bits=bu0, z_bits=bi0, long_rows=self._long_iu)
                 nxt = self._exchange_frontier(self.Z, bi1)
             elif how == "gated":
                 K.spmm_rowsparse(iu, gu, Y[U:N], alpha=alpha, z=self.G[U:N], beta=c, src_bits=self.bits[2 * l], z_bits=bi0)
@@ -1164,7 +1164,7 @@ class FusedShardedLightGCNStep:
                             group["eps"], group["weight_decay"], alpha=alpha, z=self.G[:U], beta=c, clear_z=True, **extra)
             elif how == "list":
                 K.spmm_rowlist(ui, gi, Y[:U], self._list_u, self._list_n[0:1], alpha=alpha, z=self.G[:U], beta=c,
-                               src_bits=bi0, z_bits=bu0)
+                               src_bits=bi0, z_bits=bu0, long_rows=self._long_ui)
             elif how == "gated":
                 K.spmm_rowsparse(ui, gi, Y[:U], alpha=alpha, z=self.G[:U], beta=c, src_bits=self.bits[2 * l + 1], z_bits=bu0)
                 if l == 1 and L >= 3:

@@ -197,8 +197,8 @@ def spmm_rowlist_raw(csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, s
                      mean_terms=(), mean_w=0.0, long_rows=None):
     """y[r] = alpha * (A x)[r] [+ beta z[r]] for the rows of a device-side list only (chaorec_spmm_csr_rowlist_f32); the other
     rows of y are not touched.  Same sums, bit for bit, as spmm_raw's for those rows.  mean_out / mean_terms / mean_w: the
-    listed rows of the layer mean, spmm_mean_raw's arithmetic (y may then be None).  long_rows = long_row_buffers(csr) (only
-    without src_bits): listed rows above the threshold are computed by a second launch, one workgroup per row."""
+    listed rows of the layer mean, spmm_mean_raw's arithmetic (y may then be None).  long_rows = long_row_buffers(csr):
+    listed rows above the threshold are computed by a second launch, one workgroup per row."""
     ll, lc, lt = long_rows if long_rows is not None else (None, None, 0)
     _need_cuda(csr.rowptr, x, y, z, src_bits, z_bits, row_list, list_n, mean_out, ll, lc, *mean_terms)
     x = _f32c(x)

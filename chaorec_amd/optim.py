@@ -542,7 +542,7 @@ class FusedLightGCNStep:
             self._list0_n = self._bits_all[2 * words + 1:]
             self._row_list = torch.empty(N, dtype=torch.int32, device=dev)                  # N1's rows, in no particular order
             self._list0 = torch.empty(3 * self.B, dtype=torch.int32, device=dev)            # R0's rows
-            self._long = ops.long_row_buffers(model.graph) if self.light else None          # (the forward lists' long rows)
+            self._long = ops.long_row_buffers(model.graph)                                  # (the list launches' long rows)
         self.result_complete = True
         self.steps_per_replay = int(steps_per_replay) if (capture and edges is not None) else 1
         self.replays = 0
@@ -648,7 +648,7 @@ class FusedLightGCNStep:
                 if not light:                   # (a light step expanded R0 before its forward)
                     ops.expand_row_bits(csr, self.bits[0], self.bits[1], self._row_list, self._list_n)
                 ops.spmm_rowlist_raw(csr, g, y, self._row_list, self._list_n, alpha=alpha, z=self.G, beta=w,
-                                     src_bits=self.bits[0], z_bits=self.bits[0])
+                                     src_bits=self.bits[0], z_bits=self.bits[0], long_rows=self._long)
             elif self.sparse_bwd and l < 2:
                 # every row computed and written (its reader is dense), gathers gated by the source's bitmap
                 ops.spmm_rowsparse_raw(csr, g, y, alpha=alpha, z=self.G, beta=w, src_bits=self.bits[l], z_bits=self.bits[0])

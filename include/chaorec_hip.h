@@ -181,11 +181,13 @@ int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, cons
                                  float *mean_out, const float *const *mean_terms, int32_t n_mean_terms, float mean_w,
                                  int32_t *long_list, int32_t *long_cnt, int64_t long_cap, int32_t long_threshold,
                                  void *stream);
-/* long_list / long_cnt (optional, with src_bits == NULL: a launch that gathers every entry of its rows -- the forward
- * propagates of a light step): listed rows with more than long_threshold entries are deferred to long_list (long_cap
+/* long_list / long_cnt (optional): listed rows with more than long_threshold entries are deferred to long_list (long_cap
  * entries; long_cnt: int32[2], zero on entry and zero again afterwards) and computed by a second launch with one WORKGROUP
- * per row -- the gathers shared by 256 threads, the sum still the sequential CSR-order sum -- instead of being the tail of
- * a 16..64-lane group (a popular item's row has 1e4-1e5 entries). */
+ * per row instead of being the tail of a 16..64-lane group (a popular item's row has 1e4-1e5 entries): without src_bits
+ * (a forward propagate of a light step: every entry gathered) the gathers are shared by 256 threads and the products summed
+ * in entry order through an LDS tile; with src_bits (the backward's first propagate) the workgroup scans 1024 entries per
+ * round and queues the few flagged ones in entry order for one lane group to gather and add -- the sequential CSR-order sum
+ * either way. */
 
 /* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
 int chaorec_spmm_rows_per_wave(int32_t D);

@@ -531,3 +531,46 @@ def test_light_run_ends_with_a_full_step(dev):
     assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7
     assert la == pytest.approx(lb, rel=1e-5)
     assert float((ra - rb).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("D,frac", [(64, 0.02), (128, 0.3), (256, 1.0)])
+def test_gated_rowlist_with_long_rows_equals_the_dense_launch(dev, D, frac):
+    """ops.spmm_rowlist_raw with src_bits AND long_rows (the backward's first propagate on a graph with popular items: rows
+    above the threshold go to the workgroup-per-row scan-and-queue launch) against the dense launch on the same row-sparse
+    operand: the listed rows bit for bit -- few flagged sources per row, many, and ALL of them (rows of several thousand flagged
+    entries overflow the launch's 2048-entry queue: flushed in order)."""
+    from chaorec_amd import graph, ops
+    rng = np.random.default_rng(int(D + 100 * frac))
+    U, I = 6000, 900
+    deg_i = np.minimum((rng.pareto(1.1, I) * 6 + 2).astype(np.int64), U - 1)
+    deg_i[:3] = [5200, 3100, 2300]                     # (popular items)
+    rows = np.repeat(np.arange(I), deg_i)
+    cols = np.concatenate([rng.choice(U, d, replace=False) for d in deg_i])
+    edges = np.stack([cols, U + rows], 1)
+    csr = graph.lightgcn_csr(edges, U + I).to(dev)
+    N = U + I
+    gen = torch.Generator(device=dev).manual_seed(3)
+    flagged = torch.rand(N, device=dev, generator=gen) < frac
+    x = torch.randn(N, D, device=dev, generator=gen) * flagged[:, None]
+    z = torch.randn(N, D, device=dev, generator=gen) * flagged[:, None]
+    bits = ops.row_bitmap(N, dev)
+    idx = torch.nonzero(flagged).flatten()
+    bits_np = np.zeros(bits.numel(), dtype=np.uint32)
+    np.bitwise_or.at(bits_np, idx.cpu().numpy() >> 5, np.uint32(1) << (idx.cpu().numpy() & 31).astype(np.uint32))
+    bits.copy_(torch.from_numpy(bits_np.view(np.int32)))
+    want = ops.spmm_raw(csr, x, y=torch.empty_like(x), alpha=0.25, z=z, beta=0.5)
+    listed = torch.randperm(N, device=dev, generator=gen)[:N // 2]
+    listed = torch.unique(torch.cat([listed, torch.arange(U, U + 3, device=dev)]))        # (the popular items are in)
+    row_list = listed.to(torch.int32)
+    list_n = torch.tensor([listed.numel()], dtype=torch.int32, device=dev)
+    for long_t in (None, 40):
+        long_rows = ops.long_row_buffers(csr, long_t) if long_t else None
+        got = torch.full_like(x, float("nan"))
+        ops.spmm_rowlist_raw(csr, x, got, row_list, list_n, alpha=0.25, z=z, beta=0.5, src_bits=bits, z_bits=bits, long_rows=long_rows)
+        torch.cuda.synchronize()
+        assert torch.equal(got[listed], want[listed]), long_t
+        rest = torch.ones(N, dtype=torch.bool, device=dev)
+        rest[listed] = False
+        assert bool(torch.isnan(got[rest]).all())
+        if long_rows is not None:
+            assert int(long_rows[1].abs().sum()) == 0
