@@ -574,3 +574,42 @@ def test_gated_rowlist_with_long_rows_equals_the_dense_launch(dev, D, frac):
         assert bool(torch.isnan(got[rest]).all())
         if long_rows is not None:
             assert int(long_rows[1].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("E", [10300, 10240])
+def test_product_epoch_with_light_steps_equals_the_dense_epoch(dev, monkeypatch, E):
+    """chaorec_amd/train_and_evaluate.py's epoch (in-launch batches from the epoch permutation, k-step replays, the short last
+    batch through the ordinary path) with the light step forced on (CHAOREC_SPARSE_BACKWARD=1: row-sparse backward + light
+    forward) against the same epoch on dense launches: the same epoch loss and parameters up to atomic-add order, and
+    gene_ranklist afterwards ranks a COMPLETE table in both -- with a short last batch (E = 10300: its ordinary forward leaves
+    the table) and without one (E = 10240: the epoch's last fused step is a full one)."""
+    from chaorec_amd import graph, dataload
+    from chaorec_amd import train_and_evaluate as tae
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, B = 1500, 900, 1024
+    edges = synthetic_interactions(U, I, E, seed=5)
+    uid = graph.user_item_dict_from_edges(edges)
+
+    def epoch(light):
+        monkeypatch.setenv("CHAOREC_SPARSE_BACKWARD", "1" if light else "0")
+        torch.manual_seed(1)
+        m = LightGCN(U, I, edges, uid, 64, 1e-3, 3, "add", dev).to(dev)
+        opt = FusedAdam(m.parameters(), lr=1e-3)
+        ld = dataload.DeviceBatchSampler(U, I, uid, edges, B, dev, "LightGCN", 7)
+        graphed = tae._capture_step(m, ld, opt, "LightGCN")
+        assert getattr(graphed, "fused", False) and bool(getattr(graphed, "light", False)) == light
+        ld.gen.manual_seed(7)
+        ld.global_step = 0
+        ld.step_dev.zero_()
+        losses = [tae.train(m, ld, opt, "LightGCN", graphed) for _ in range(2)]
+        assert m.result is not None
+        return losses, m._flat.detach().clone(), m.result.detach().clone(), m.gene_ranklist(topk=20)
+
+    (la, xa, ra, ka), (lb, xb, rb, kb) = epoch(False), epoch(True)
+    assert lb == pytest.approx(la, rel=1e-5)
+    d = (xa - xb).abs()
+    assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7
+    assert float((ra - rb).abs().max()) <= 1e-5
+    assert float((ka != kb).float().mean()) <= 2e-3        # (near-ties may swap under 1e-7 differences)
