@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import BPRMF, FREEDOM, LayerGCN, LightGCN, MGCN, MMGCN, NCL, NGCF, SelfCF, SimGCL, VBPR
+from .Model import BPRMF, FREEDOM, LayerGCN, LightGCN, MGCN, MMGCN, NCL, NGCF, SelfCF, SimGCL, VBPR, XSimGCL
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
 from .optim import FusedAdam
@@ -57,6 +57,8 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
                            args.ssl_temp, args.ssl_alpha, device),
         'SimGCL': lambda: SimGCL(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
                                  args.ssl_temp, args.ssl_alpha, device),
+        'XSimGCL': lambda: XSimGCL(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
+                                   args.ssl_temp, args.ssl_alpha, device),
         'SelfCF': lambda: SelfCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
                                  args.dropout, device),
     }

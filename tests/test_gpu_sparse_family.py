@@ -1,5 +1,5 @@
-"""Three more members of the reference's `torch.sparse.mm` model family through the adapter ALONE (VERDICT
-r3 #8): SimGCL, NCL, SelfCF.  Their product classes (chaorec_amd/Model/{SimGCL,NCL,SelfCF}.py) swap `torch.sparse.mm` for
+"""Four more members of the reference's `torch.sparse.mm` model family through the adapter ALONE (VERDICT
+r3 #8): SimGCL, XSimGCL, NCL, SelfCF.  Their product classes (chaorec_amd/Model/{SimGCL,XSimGCL,NCL,SelfCF}.py) swap `torch.sparse.mm` for
 `chaorec_amd.sparse.mm` and the per-model ranking loop for the shared `ranking.gene_ranklist` -- no kernel, no fusion was
 written for them.  Goldens: the REFERENCE classes' own outputs (tests/golden/gen_sparse_family.py; what that generator had
 to supply around them -- stored noise, seeded clusters, dropout switched off -- is listed in its docstring)."""
@@ -80,6 +80,30 @@ def test_simgcl_golden(dev):
     a, _ = m.forward(perturbed=True)
     b, _ = m.forward(perturbed=True)
     assert not torch.equal(a, b) and float((a - m.forward()[0]).abs().max()) <= 2 * m.eps
+
+
+def test_xsimgcl_golden(dev):
+    """Model/XSimGCL.py: one perturbed forward (the second view = layer 1's output of the same pass), and a gene_ranklist that
+    runs its own clean forward on the current weights."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import XSimGCL
+    g = load_golden("xsimgcl_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = XSimGCL(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), int(g["L"]),
+                float(g["ssl_temp"]), float(g["ssl_reg"]), dev)
+    noise = [torch.from_numpy(n).to(dev) for n in g["noise"]]          # what the reference's torch.rand_like drew, in order
+    m.noise_fn = lambda x: noise.pop(0)
+    m = m.to(dev)
+    _check_common(m, g, dev, m.sparse_norm_adj, 2e-5)
+    assert not noise
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()                # (no noise left: the ranking forward must not ask for any)
+    assert np.abs(m.user_emb.cpu().numpy() - g["user_emb"]).max() <= 2e-6 * np.abs(g["user_emb"]).max()
+    assert np.abs(m.item_emb.cpu().numpy() - g["item_emb"]).max() <= 2e-6 * np.abs(g["item_emb"]).max()
+    _check_rank(rank, g, g["user_emb"] @ g["item_emb"].T, U)
+    m.noise_fn = torch.rand_like
+    out = m.forward(perturbed=True)
+    assert len(out) == 4 and float((out[0] - m.forward()[0]).abs().max()) <= 2 * m.eps
 
 
 def test_ncl_golden(dev):
