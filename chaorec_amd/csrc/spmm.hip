@@ -14,6 +14,7 @@
 //     result is bit-identical to a sequential scatter_add_ in the reference's edge order.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1001,6 +1002,107 @@ __global__ __launch_bounds__(256) void spmm_rowlist_long_kernel(const int64_t *_
     }
   }
 }
+// The same launch with SPECIALISED WAVES (round 4's second form; `CHAOREC_ROWLIST_LONG_TEAMS` = 0 selects the kernel above).
+// The one-slot walk above costs one gather latency per round (~2.5 us for random 512-B rows of a multi-GB table, against
+// 0.4-0.8 us of ordered adds), and keeping two rounds in flight in ONE wave's registers did not work: the compiler's wait at
+// the top of the loop body became vmcnt(0) whatever the arrangement.  vmcnt is a PER-WAVE counter, so here the
+// rounds in flight belong to different waves: T loader teams of 4 waves take the rounds round-robin -- a team gathers its
+// round's source rows right after it parked the previous one's products, and waits for them (its own vmcnt(0)) T phases
+// later --, SW summing waves never touch global memory and add tile p-1 in entry order while tile p is being written (two
+// LDS tiles).  One workgroup barrier per phase.  The sum is the same sequential CSR-order sum, bit for bit.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int LPR>
+constexpr int ws_summer_waves() { return (4 * LPR + 63) / 64; }
+
+template <int LPR, int T>
+__global__ __launch_bounds__((ws_summer_waves<LPR>() + 4 * T) * 64) void spmm_rowlist_long_ws_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ x, float *__restrict__ y, int D4, float alpha, const float *z, float beta,
+    const uint32_t *__restrict__ z_bits, const ListMean mean, const LongRows lr) {
+  extern __shared__ float4 ws_tiles[];
+  constexpr int SW = ws_summer_waves<LPR>(), LW = 4, K = 16;
+  constexpr int NGB = LW * 64 / LPR;      // lane groups per loader team
+  constexpr int CH = NGB * K;             // entries per round (256 / 128 / 64 for D4 = 16 / 32 / 64): a 64 KiB tile
+  constexpr int DT = 4 * LPR;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const bool summer = wave < SW;
+  const int team = summer ? -1 : (wave - SW) / LW;
+  const int lt = summer ? 0 : tid - (SW + team * LW) * 64;      // thread index inside its team
+  const int g = lt / LPR, li = lt % LPR;
+  const int lic = min(li, D4 - 1);
+  const int D = 4 * D4;
+  float4 *tile0 = ws_tiles, *tile1 = ws_tiles + CH * LPR;
+  const int64_t n = min((int64_t)lr.cnt[0], lr.cap);
+  const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int64_t r = lr.list[i];
+    const int64_t e0 = rowptr[r];
+    const int deg = (int)(rowptr[r + 1] - e0);
+    const int rounds = (deg + CH - 1) / CH;
+    float s = 0.f;                        // (summing waves: column tid of the running sum)
+    int cn[K];
+    float4 xv[K];
+    float vv[K];
+    if (!summer) {                        // the team's first round (= its number), and the columns of its second
+#pragma unroll
+      for (int k = 0; k < K; ++k) cn[k] = col[e0 + min(team * CH + g * K + k, deg - 1)];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        xv[k] = x4[(size_t)cn[k] * (size_t)D4 + lic];
+        vv[k] = val[e0 + min(team * CH + g * K + k, deg - 1)];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) cn[k] = col[e0 + min((team + T) * CH + g * K + k, deg - 1)];
+    }
+    for (int pb = 0; pb < rounds + 1; pb += T) {
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) {
+        const int p = pb + tt;            // phase p: round p is parked, round p - 1 is summed
+        if (!summer && team == tt && p < rounds) {
+          float4 *tw = (p & 1) ? tile1 : tile0;
+#pragma unroll
+          for (int k = 0; k < K; ++k) tw[(g * K + k) * LPR + li] = mul_rn4(vv[k], xv[k]);
+#pragma unroll
+          for (int k = 0; k < K; ++k) {   // the team's next round (p + T): clamped past the row's end, never summed
+            xv[k] = x4[(size_t)cn[k] * (size_t)D4 + lic];
+            vv[k] = val[e0 + min((p + T) * CH + g * K + k, deg - 1)];
+          }
+#pragma unroll
+          for (int k = 0; k < K; ++k) cn[k] = col[e0 + min((p + 2 * T) * CH + g * K + k, deg - 1)];
+        }
+        if (summer && p >= 1 && p - 1 < rounds && tid < D) {
+          const float *t = reinterpret_cast<const float *>(((p - 1) & 1) ? tile1 : tile0) + tid;
+          const int nn = min(CH, deg - (p - 1) * CH);
+          if (nn == CH) {
+#pragma unroll 16
+            for (int e = 0; e < CH; ++e) s = add_rn(s, t[e * DT]);
+          } else {
+            for (int e = 0; e < nn; ++e) s = add_rn(s, t[e * DT]);
+          }
+        }
+        lds_barrier();
+      }
+    }
+    // the epilogue works on float4s: hand the column sums over through tile 0
+    if (summer && tid < D) reinterpret_cast<float *>(tile0)[tid] = s;
+    lds_barrier();
+    if (tid < D4) {
+      float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (z && (!z_bits || row_bit(z_bits, r))) zrow = reinterpret_cast<const float4 *>(z)[(size_t)r * D4 + tid];
+      rowlist_epilogue(r, D4, tid, tile0[tid], alpha, z, beta, zrow, y, mean);
+    }
+    lds_barrier();
+  }
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(lr.cnt + 1, 1) == (int)gridDim.x - 1) {
+      lr.cnt[0] = 0;
+      lr.cnt[1] = 0;
+    }
+  }
+}
+
 // The long rows of a GATED list launch (the backward's first propagate: a listed row's entries count only where the source is
 // flagged, a handful among a popular item's 1e4-1e5): one WORKGROUP per row scans 1024 entries per round -- coalesced (col, val)
 // loads, a bit test each -- and queues the flagged ones in ENTRY ORDER (wave ballots + a prefix over the 4 x 4 counts); the
@@ -1213,6 +1315,28 @@ extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t
     return check_launch("spmm_rowlist_long_gated_kernel");
   }
 #define CHAOREC_ROWLIST_LONG_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, z_bits, mean, lr
+  static const int teams = [] {
+    const char *e = std::getenv("CHAOREC_ROWLIST_LONG_TEAMS");
+    return (e && std::atoi(e) == 0) ? 0 : 2;      // (three teams: 128 VGPRs at 14 waves per workgroup, spills, slower)
+  }();
+  if (teams) {
+    // specialised waves: T loader teams of 4 waves + the summing waves, two 64 KiB LDS tiles (dynamic: above the 64 KiB of
+    // static LDS a kernel may declare)
+    constexpr unsigned kTiles = 2 * 65536;
+#define CHAOREC_WS_LAUNCH(LPR_, T_)                                                                                   \
+  do {                                                                                                                \
+    static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_rowlist_long_ws_kernel<LPR_, T_>), \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kTiles);          \
+    if (attr_ != hipSuccess) return fail(CHAOREC_E_LAUNCH, "spmm (row list): cannot get %u bytes of LDS", kTiles);  \
+    hipLaunchKernelGGL((spmm_rowlist_long_ws_kernel<LPR_, T_>), lgrid, dim3((ws_summer_waves<LPR_>() + 4 * T_) * 64), \
+                       kTiles, st, CHAOREC_ROWLIST_LONG_ARGS);                                                        \
+  } while (0)
+    if (D4 <= 16) CHAOREC_WS_LAUNCH(16, 2);
+    else if (D4 <= 32) CHAOREC_WS_LAUNCH(32, 2);
+    else CHAOREC_WS_LAUNCH(64, 2);
+#undef CHAOREC_WS_LAUNCH
+    return check_launch("spmm_rowlist_long_ws_kernel");
+  }
   if (D4 <= 16) hipLaunchKernelGGL((spmm_rowlist_long_kernel<16>), lgrid, block, 0, st, CHAOREC_ROWLIST_LONG_ARGS);
   else if (D4 <= 32) hipLaunchKernelGGL((spmm_rowlist_long_kernel<32>), lgrid, block, 0, st, CHAOREC_ROWLIST_LONG_ARGS);
   else hipLaunchKernelGGL((spmm_rowlist_long_kernel<64>), lgrid, block, 0, st, CHAOREC_ROWLIST_LONG_ARGS);
