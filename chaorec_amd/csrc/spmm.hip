@@ -731,6 +731,7 @@ __global__ __launch_bounds__(256) void rows_list_from_bits_kernel(const uint32_t
   const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (wi >= n_words) return;
   uint32_t word = bits[wi];
+  if ((wi + 1) * 32 > n_rows) word &= (n_rows - wi * 32 >= 32) ? ~0u : ((1u << (n_rows - wi * 32)) - 1u);   // (bits past the end: ignored)
   if (!word) return;
   const int cnt = __popc(word);
   int at = atomicAdd(list_n, cnt);

@@ -613,3 +613,58 @@ def test_product_epoch_with_light_steps_equals_the_dense_epoch(dev, monkeypatch,
     assert float((d > 2e-6).float().mean()) <= 1e-4 and float(d.median()) <= 1e-7
     assert float((ra - rb).abs().max()) <= 1e-5
     assert float((ka != kb).float().mean()) <= 2e-3        # (near-ties may swap under 1e-7 differences)
+
+
+def test_frontier_helper_launches(dev):
+    """The small launches of the frontier-restricted sharded step, one by one against numpy: the expansion over a RECTANGULAR
+    block (bits over the rows in, bits over the columns out, the other side's batch rows as bits_self, the list = exactly the
+    newly flagged columns), the list of a bitmap's rows (bits past the end ignored), the layer mean / zero fill / copy of flagged
+    rows only, the union of gathered bitmaps."""
+    from chaorec_amd import graph, ops
+    rng = np.random.default_rng(12)
+    U, I, D = 1000, 333, 64
+    ul, il = rng.integers(0, U, 6000), rng.integers(0, I, 6000)
+    pairs = np.unique(np.stack([ul, il], 1), axis=0)
+    ui = graph.coo_to_csr(torch.from_numpy(pairs[:, 0]), torch.from_numpy(pairs[:, 1]), torch.ones(len(pairs)), U, I).to(dev)
+
+    def bitmap(rows, n):
+        b = np.zeros((n + 31) // 32 + 1, dtype=np.uint32)
+        np.bitwise_or.at(b, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))
+        return torch.from_numpy(b.view(np.int32)).to(dev)
+
+    users = rng.choice(U, 40, replace=False)
+    items_self = rng.choice(I, 25, replace=False)
+    bu, bself, bout = bitmap(users, U), bitmap(items_self, I), ops.row_bitmap(I, dev)
+    lst, n = torch.zeros(I, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.expand_row_bits(ui, bu, bout, lst, n, bits_self=bself)
+    want = np.unique(np.concatenate([items_self, pairs[np.isin(pairs[:, 0], users), 1]]))
+    assert np.array_equal(_bits_to_rows(bout, I), want) and np.array_equal(np.sort(lst[:int(n)].cpu().numpy()), want)
+    with pytest.raises(ValueError, match="bits_self"):
+        ops.expand_row_bits(ui, bu, bout, lst, n)
+    # rows_list_from_bits (a stray bit past n_rows is not a row)
+    stray = bout.clone()
+    stray[I // 32] |= 1 << ((I % 32) + 1 if I % 32 < 30 else 31)
+    lst2, n2 = torch.zeros(I, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.rows_list_from_bits(stray, I, lst2, n2)
+    assert int(n2) == len(want) and np.array_equal(np.sort(lst2[:int(n2)].cpu().numpy()), want)
+    # rows_mean_by_bits / zero_rows_by_bits / rows_copy_by_bits
+    terms = [torch.randn(I, D, device=dev) for _ in range(4)]
+    out = torch.full((I, D), float("nan"), device=dev)
+    ops.rows_mean_by_bits(terms, 0.25, out, bout)
+    ref = torch.empty(I, D, device=dev)
+    ops.rows_mean(terms, 0.25, ref)
+    rows = torch.from_numpy(want).to(dev)
+    rest = torch.ones(I, dtype=torch.bool, device=dev)
+    rest[rows] = False
+    assert torch.equal(out[rows], ref[rows]) and bool(torch.isnan(out[rest]).all())
+    src, dst = torch.randn(I, D, device=dev), torch.zeros(I, D, device=dev)
+    ops.rows_copy_by_bits(dst, src, bout)
+    assert torch.equal(dst[rows], src[rows]) and float(dst[rest].abs().max()) == 0.0
+    ops.zero_rows_by_bits(src, bout)
+    assert float(src[rows].abs().max()) == 0.0 and float(src[rest].abs().min()) > 0.0
+    # or_words
+    parts = torch.stack([bitmap(rng.choice(I, 30, replace=False), I) for _ in range(4)])
+    acc = torch.zeros_like(parts[0])
+    ops.or_words(acc, parts)
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy().view(np.uint32), np.bitwise_or.reduce(parts.cpu().numpy().view(np.uint32), axis=0))
