@@ -562,6 +562,48 @@ def calibrate_exchange(n_rows, D, device, group=None, captured=False, reps=3, ca
                     good, why = False, "captured sum differs from all_reduce on replay"
             return good
 
+        def frontier():
+            """The p2p exchange's FRONTIER form (flagged rows only: the row-sparse backward / light forward of a shard):
+            a bitmap that is the same on every rank, values in a rank's own part of it, zeros elsewhere -- eagerly and
+            replayed from a hipGraph, against all_reduce."""
+            nonlocal why
+            g0 = torch.Generator(device=dev).manual_seed(4242)          # (the same on every rank)
+            flagged = torch.rand(n_rows, generator=g0, device=dev) < 0.03
+            idx = torch.nonzero(flagged).flatten().cpu().numpy()
+            words = np.zeros((n_rows + 31) // 32 + 1, dtype=np.uint32)
+            np.bitwise_or.at(words, idx >> 5, np.uint32(1) << (idx & 31).astype(np.uint32))
+            bits = torch.from_numpy(words.view(np.int32)).to(dev)
+
+            def mine():
+                t = torch.zeros((rows, D), device=dev)
+                own = flagged & (torch.rand(n_rows, generator=gen, device=dev) < 0.6)
+                t[:n_rows][own] = (torch.rand((int(own.sum()), D), generator=gen, device=dev) - 0.5)
+                return t
+
+            src = mine()
+            out = src.clone()
+            _sum_exchange_async(out, group, bits=bits, n_rows=n_rows).wait()
+            torch.cuda.synchronize()
+            if not check(out, src):
+                why = "eager frontier sum differs from all_reduce"
+                return False
+            if not captured:
+                return True
+            static_src, static_out = mine(), torch.empty((rows, D), device=dev)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, capture_error_mode=capture_mode()):
+                static_out.copy_(static_src)
+                _sum_exchange_async(static_out, group, bits=bits, n_rows=n_rows).wait()
+            good = True
+            for _ in range(2):
+                static_src.copy_(mine())
+                g.replay()
+                torch.cuda.synchronize()
+                if not check(static_out, static_src) and good:
+                    good, why = False, "captured frontier sum differs from all_reduce on replay"
+            return good
+
         def timed():
             nonlocal ms
             import time as _time
@@ -586,6 +628,9 @@ def calibrate_exchange(n_rows, D, device, group=None, captured=False, reps=3, ca
             ok = stage(eager)
             if ok and captured and on_gpu:
                 ok = stage(replayed)
+            frontier_checked = False
+            if ok and mode == "p2p" and on_gpu:
+                ok = frontier_checked = stage(frontier)
             if ok:
                 ok = stage(timed)
         finally:
@@ -593,6 +638,8 @@ def calibrate_exchange(n_rows, D, device, group=None, captured=False, reps=3, ca
         if not ok:
             veto(mode)
         table[mode] = {"ok": ok, "ms": ms if ok else None}
+        if mode == "p2p" and on_gpu:
+            table[mode]["frontier_form_ok"] = bool(frontier_checked)
         if why:
             table[mode]["why"] = why
     good = {m: e["ms"] for m, e in table.items() if e["ok"] and e["ms"] is not None}

@@ -433,6 +433,7 @@ def test_calibrate_exchange_on_the_gpu(world, backend):
         r = [json.load(open(os.path.join(tmp, f"cal{k}.json"))) for k in range(world)]
     for x in r:
         assert all(x["table"][m]["ok"] for m in ("allreduce", "rs_ag", "p2p")), x["table"]
+        assert x["table"]["p2p"]["frontier_form_ok"] is True         # (the flagged-rows form had its first contact too)
         assert x["chosen"] == x["table"]["chosen"] == r[0]["chosen"] and x["sum_ok"], x
 
 
