@@ -164,7 +164,8 @@ def captured_all_reduce_is_exact(dev, world, rank):
         dist.all_reduce(t)                               # eager first: communicator set-up happens outside capture
     cur.wait_stream(side)
     g = torch.cuda.CUDAGraph()
-    torch.cuda.synchronize()
+    from chaorec_amd.dist import settle_before_capture
+    settle_before_capture()                              # (device idle, RCCL's watchdog has retired the eager all-reduce)
     with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (RCCL's watchdog thread polls events meanwhile)
         t.copy_(src)
         dist.all_reduce(t)
@@ -314,6 +315,9 @@ def time_spmm_chain(calls, min_pass_ms=10.0, passes=5):
         torch.cuda.current_stream().wait_stream(side)
         import torch.distributed as _td
         graph = torch.cuda.CUDAGraph()
+        if _td.is_initialized():
+            from chaorec_amd.dist import settle_before_capture
+            settle_before_capture()
         with torch.cuda.graph(graph, capture_error_mode="thread_local" if _td.is_initialized() else "global"):
             for fn, _, _ in calls:
                 fn()

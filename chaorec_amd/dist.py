@@ -237,6 +237,24 @@ def capture_mode():
     return "thread_local" if dist.is_initialized() else "global"
 
 
+WATCHDOG_SETTLE_S = float(_os.environ.get("CHAOREC_CAPTURE_SETTLE_S", "0.3"))
+
+
+def settle_before_capture():
+    """Call right before a hipGraph capture that will hold collectives, after the eager launches that precede it.  RCCL's
+    watchdog thread keeps polling the end events of EAGER collectives until it has seen them complete (its loop sleeps
+    100 ms); a capture pulls RCCL's stream (and the p2p exchange's side stream) into capture mode, and on this stack
+    (ROCm 7.2) hipEventQuery on an event whose stream is capturing NOW -- although the event was recorded before the
+    capture -- fails with hipErrorCapturedEvent and invalidates the capture ("operation failed due to a previous error
+    during capture" on the next launch; seen once in ~30 captures that followed eager exchanges within milliseconds).
+    So: let the device finish, then give the watchdog time to retire what it holds."""
+    if dist.is_initialized() and torch.cuda.is_available():
+        import time as _time
+        torch.cuda.synchronize()
+        if WATCHDOG_SETTLE_S > 0:
+            _time.sleep(WATCHDOG_SETTLE_S)
+
+
 class _PendingStream:
     """Handle of an exchange made of plain launches on a side stream (the hand-written p2p exchange): wait() makes the
     compute stream depend on everything the side stream was given so far."""
@@ -549,7 +567,7 @@ def calibrate_exchange(n_rows, D, device, group=None, captured=False, reps=3, ca
             nonlocal why
             static_src, static_out = fresh(), torch.empty((rows, D), device=dev)
             g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
+            settle_before_capture()
             with torch.cuda.graph(g, capture_error_mode=capture_mode()):
                 static_out.copy_(static_src)
                 _sum_exchange_async(static_out, group).wait()
@@ -591,7 +609,7 @@ def calibrate_exchange(n_rows, D, device, group=None, captured=False, reps=3, ca
                 return True
             static_src, static_out = mine(), torch.empty((rows, D), device=dev)
             g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
+            settle_before_capture()
             with torch.cuda.graph(g, capture_error_mode=capture_mode()):
                 static_out.copy_(static_src)
                 _sum_exchange_async(static_out, group, bits=bits, n_rows=n_rows).wait()
@@ -977,16 +995,18 @@ class FusedShardedLightGCNStep:
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 self._restore_state(saved)
-                self.graph1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph1, capture_error_mode=capture_mode()):
-                    self._launch()
-                self.graph = self.graph1
                 if self.light:
                     with torch.cuda.stream(s):
                         self._launch(light=False)       # (eager first, like the light one above)
                     torch.cuda.current_stream().wait_stream(s)
                     torch.cuda.synchronize()
                     self._restore_state(saved)
+                settle_before_capture()                 # (every eager launch is behind us: captures only from here on)
+                self.graph1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph1, capture_error_mode=capture_mode()):
+                    self._launch()
+                self.graph = self.graph1
+                if self.light:
                     self.graph_full = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.graph_full, capture_error_mode=capture_mode()):
                         self._launch(light=False)

@@ -385,6 +385,9 @@ class GraphedTrainStep:
         #  mode: RCCL's watchdog thread polls events while we capture, dist.capture_mode)
         import torch.distributed as _td
         mode = "thread_local" if (_td.is_available() and _td.is_initialized()) else "global"
+        if mode == "thread_local":
+            from .dist import settle_before_capture
+            settle_before_capture()              # (RCCL's watchdog must have retired the warm-up's eager collectives)
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.static_loss = self._eager(self.static)
         # the captured forward's output buffer: every replay rewrites it, and model.result must keep pointing at it
