@@ -463,7 +463,9 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                                 "N1 (the batch rows' 1-hop image) and R0 (the batch rows) only: loss, gradient and updated tables are "
                                 "the full step's bit for bit (tests/test_gpu_round4.py); the ONE step of an epoch that precedes the "
                                 "evaluation computes every row (model.result for gene_ranklist, the reference's stale-result quirk) "
-                                "and costs ms_per_step_full_result"}
+                                "and costs ms_per_step_full_result.  `value` keeps counting the reference step's 2 L E_dir messages "
+                                "per step (the work of Model/LightGCN.py's step that this step replaces), not the smaller number of "
+                                "rows a light step gathers"}
     loss_mean = (float(loss_sum.item()) if fused else float(acc0.item())) / max(n_loss[0], 1)
     msgs_per_step = 2 * L * e_dir
 
@@ -1074,7 +1076,8 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
         forward_note = {"timed_steps": "light", "ms_per_step_full_result": float(full_ms.item()), "full_steps_per_epoch": 1,
                         "what": "dist.FusedShardedLightGCNStep with the light forward: the batch drawn first, the last two "
                                 "forward layers over the frontier's row lists (item partials through frontier buffers and "
-                                "frontier exchanges); the step before an evaluation is a full one"}
+                                "frontier exchanges); the step before an evaluation is a full one.  `value` keeps counting the "
+                                "reference step's 2 L E_dir messages per step"}
     elif fused is not None:
         fused(single=True)                  # (the recording pass above ran eager launches; leave a complete result behind)
 
