@@ -1005,7 +1005,7 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
         saved = fused._save_state()
         real_exchange, real_frontier = fused._exchange, fused._exchange_frontier
         fused._exchange = lambda buf: cdist._Pending(None)
-        fused._exchange_frontier = lambda buf, bits: cdist._Pending(None)
+        fused._exchange_frontier = lambda buf, bits, cap=None: cdist._Pending(None)
         try:
             for _ in range(2):
                 fused._launch()

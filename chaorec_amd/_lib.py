@@ -91,6 +91,8 @@ SIGNATURES = {
                                                           ctypes.c_int32, c_ptr, c_ptr, c_ptr]),
     "chaorec_exchange_pull_gather_rows_f32": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                              c_ptr, c_ptr, c_ptr]),
+    "chaorec_frontier_pack_f32": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
+    "chaorec_frontier_unpack_f32": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_int64, c_ptr]),
     "chaorec_shift_cat_i64": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr, c_ptr]),
     "chaorec_score_topk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                             ctypes.c_int32]),

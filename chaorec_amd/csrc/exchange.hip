@@ -108,6 +108,70 @@ __global__ __launch_bounds__(256) void pull_gather_rows_kernel(const PeerPtrs P,
   }
 }
 
+// ---- the compact form of a frontier exchange, for collectives that cannot skip rows (RCCL) ----------------------------------
+// The bitmap is the same on every rank, so "flagged row number k in bitmap order" names the same row everywhere: the flagged rows
+// are packed into a [cap, D] buffer in that order (unused tail rows zeroed), the SMALL buffer is all-reduced, and the sums are
+// written back.  Only for frontiers with a static bound on their size (the batch items of all ranks: <= 2 B world rows) -- a
+// captured step cannot choose its collective's size on the device.
+// prefix[w] = number of flagged rows in words [0, w); prefix[n_words] = their total.  One workgroup.
+__global__ __launch_bounds__(1024) void bits_prefix_kernel(const uint32_t *__restrict__ bits, int64_t n_rows, int64_t n_words,
+                                                           int32_t *__restrict__ prefix) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n_words + 1023) / 1024, w0 = t * per, w1 = min(w0 + per, n_words);
+  auto word_at = [&](int64_t w) {
+    uint32_t v = bits[w];
+    const int64_t left = n_rows - w * 32;               // (bits past the last row are not rows)
+    if (left < 32) v &= left <= 0 ? 0u : ((1u << left) - 1u);
+    return v;
+  };
+  int mine = 0;
+  for (int64_t w = w0; w < w1; ++w) mine += __popc(word_at(w));
+  part[t] = mine;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {            // inclusive scan of the 1024 partial counts
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - mine;
+  for (int64_t w = w0; w < w1; ++w) {
+    prefix[w] = run;
+    run += __popc(word_at(w));
+  }
+  if (t == 1023) prefix[n_words] = part[1023];
+}
+
+// pack: compact[k] = src[row k of the bitmap] (k < cap), rows [total, cap) of compact zeroed; unpack: the inverse copy
+template <bool PACK>
+__global__ __launch_bounds__(256) void frontier_move_kernel(float4 *__restrict__ table, int64_t n_rows, int D4,
+                                                            const uint32_t *__restrict__ bits, int64_t n_words,
+                                                            const int32_t *__restrict__ prefix, float4 *__restrict__ compact,
+                                                            int64_t cap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot < n_words) {
+    uint32_t word = bits[slot];
+    const uint32_t all = word;
+    int64_t r;
+    while (next_row(word, slot, r)) {
+      if (r >= n_rows) break;
+      const int64_t k = prefix[slot] + __popc(all & ((1u << (r & 31)) - 1u));
+      if (k >= cap) break;
+      for (int c = lane; c < D4; c += 64) {
+        if (PACK) compact[(size_t)k * D4 + c] = table[(size_t)r * D4 + c];
+        else table[(size_t)r * D4 + c] = compact[(size_t)k * D4 + c];
+      }
+    }
+  } else if (PACK) {                                     // the waves past the bitmap zero the unused tail of the compact buffer
+    const int64_t total = prefix[n_words];
+    const int64_t k = total + (slot - n_words);
+    if (k < cap)
+      for (int c = lane; c < D4; c += 64) compact[(size_t)k * D4 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 }  // namespace chaorec
 
 using namespace chaorec;
@@ -194,4 +258,32 @@ extern "C" int chaorec_exchange_pull_gather_rows_f32(const void *const *peers, i
   hipLaunchKernelGGL(pull_gather_rows_kernel, dim3((unsigned)((n_words + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P, n_block,
                      D / 4, bits, n_words, (float4 *)out);
   return check_launch("pull_gather_rows_kernel");
+}
+
+extern "C" int chaorec_frontier_pack_f32(const float *src, int64_t n_rows, int32_t D, const uint32_t *bits, int32_t *prefix,
+                                         float *compact, int64_t cap, void *stream) {
+  int rc = rows_args(compact, bits, n_rows, D, "frontier_pack");
+  if (rc) return rc;
+  if (!src || !prefix || cap <= 0 || (reinterpret_cast<uintptr_t>(src) & 15))
+    return fail(CHAOREC_E_INVALID, "frontier_pack: NULL / unaligned argument or cap=%lld", (long long)cap);
+  const int64_t n_words = (n_rows + 31) / 32;
+  hipLaunchKernelGGL(bits_prefix_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, bits, n_rows, n_words, prefix);
+  rc = check_launch("bits_prefix_kernel");
+  if (rc) return rc;
+  const int64_t slots = n_words + cap;                    // (a wave per bitmap word + a wave per possible tail row)
+  hipLaunchKernelGGL((frontier_move_kernel<true>), dim3((unsigned)((slots + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (float4 *)const_cast<float *>(src), n_rows, D / 4, bits, n_words, prefix, (float4 *)compact, cap);
+  return check_launch("frontier_move_kernel<pack>");
+}
+
+extern "C" int chaorec_frontier_unpack_f32(float *dst, int64_t n_rows, int32_t D, const uint32_t *bits, const int32_t *prefix,
+                                           const float *compact, int64_t cap, void *stream) {
+  int rc = rows_args(dst, bits, n_rows, D, "frontier_unpack");
+  if (rc) return rc;
+  if (!compact || !prefix || cap <= 0 || (reinterpret_cast<uintptr_t>(compact) & 15))
+    return fail(CHAOREC_E_INVALID, "frontier_unpack: NULL / unaligned argument or cap=%lld", (long long)cap);
+  const int64_t n_words = (n_rows + 31) / 32;
+  hipLaunchKernelGGL((frontier_move_kernel<false>), dim3((unsigned)((n_words + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (float4 *)dst, n_rows, D / 4, bits, n_words, prefix, (float4 *)const_cast<float *>(compact), cap);
+  return check_launch("frontier_move_kernel<unpack>");
 }

@@ -851,6 +851,8 @@ class _HipStepKernels:
     # the light forward
     batch_rows = staticmethod(ops.batch_rows)
     rows_list_from_bits = staticmethod(ops.rows_list_from_bits)
+    frontier_pack = staticmethod(ops.frontier_pack)
+    frontier_unpack = staticmethod(ops.frontier_unpack)
     rows_mean_by_bits = staticmethod(ops.rows_mean_by_bits)
     long_row_buffers = staticmethod(ops.long_row_buffers)
     sparse_widths = (64, 256)           # chaorec_spmm_csr_rowsparse_f32 / _rowlist_f32 are built for these D
@@ -953,6 +955,8 @@ class FusedShardedLightGCNStep:
         self.light = bool(light_forward)
         self.result_complete = True
         self.graph_full = None
+        self._compact = {}                   # (buffer, cap) -> ([cap, D] packed rows, bitmap prefix): _exchange_frontier
+        self._cap0 = min(I, 2 * self.B * self.world)      # the batch items of all ranks: a static bound
         if self.sparse_bwd:
             wu, wi = (U + 31) // 32, (I + 31) // 32
             self._wu = wu
@@ -1053,10 +1057,35 @@ class FusedShardedLightGCNStep:
         """Sum the item rows of a joined buffer over the ranks, in place; -> a handle to wait on."""
         return _sum_exchange_async(buf[self.U:], self.group)
 
-    def _exchange_frontier(self, buf, bits):
+    def _exchange_frontier(self, buf, bits, cap=None):
         """The same for a FRONTIER buffer of item rows ([I_pad, D], all-zero on every rank outside the rows flagged in
-        `bits`, a bitmap united over the ranks): the p2p exchange moves the flagged rows only."""
-        return _sum_exchange_async(buf, self.group, bits=bits, n_rows=self.I)
+        `bits`, a bitmap united over the ranks).  The p2p exchange moves the flagged rows only.  RCCL's collectives cannot
+        skip rows -- but where the frontier has a STATIC bound `cap` on its size (the batch items of all ranks: the seed
+        of the backward, the last forward layer's item partial) the flagged rows are packed in bitmap order (the same order
+        on every rank) into a [cap, D] buffer, THAT is all-reduced, and the sums are written back: 2 B world rows instead of
+        the item table.  Without a bound (N1's items) the dense exchange runs: the buffer is zero outside the frontier."""
+        if not _active(self.group):
+            return _Pending(None)
+        p2p = buf.is_cuda and resolve_mode(buf) == "p2p" and _p2p_usable(buf, self.group)
+        if cap is None or p2p or _os.environ.get("CHAOREC_DIST_COMPACT_FRONTIER", "1") != "1":
+            return _sum_exchange_async(buf, self.group, bits=bits, n_rows=self.I)
+        K, I = self.K, self.I
+        key = (buf.data_ptr(), int(cap))
+        if key not in self._compact:
+            self._compact[key] = (torch.zeros((int(cap), self.D), dtype=torch.float32, device=buf.device),
+                                  torch.zeros((I + 31) // 32 + 1, dtype=torch.int32, device=buf.device))
+        compact, prefix = self._compact[key]
+        K.frontier_pack(buf[:I], bits, prefix, compact)
+        _count(compact)
+        MODES_USED.add("compact-allreduce")
+        STATS["frontier_exchanges"] = STATS.get("frontier_exchanges", 0) + 1
+        work = dist.all_reduce(compact, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        def unpack():
+            K.frontier_unpack(buf[:I], bits, prefix, compact)
+            return _Pending(None)
+
+        return _Pending(work, unpack)
 
     @torch.no_grad()
     def _launch(self, light=None):
@@ -1174,7 +1203,7 @@ class FusedShardedLightGCNStep:
             K.spmm_rowlist(ui, x[U:N], y[:U], self._list_u, n_u1, long_rows=self._long_ui)
             # layer L over R0
             K.spmm_rowlist(iu, y[:U], self.Z0[:I], self._list0_i, n_i0, long_rows=self._long_iu)
-            pz0 = self._exchange_frontier(self.Z0, bi0)
+            pz0 = self._exchange_frontier(self.Z0, bi0, cap=self._cap0)
             pz.wait()
             K.spmm_rowlist(ui, self.Z[:I], None, self._list0_u, n_u0, mean_out=self.final[:U],
                            mean_terms=[t[:U] for t in xs] + [y[:U]], mean_w=w, long_rows=self._long_ui)
@@ -1203,7 +1232,7 @@ class FusedShardedLightGCNStep:
         # such, zeroed again after their one reader)
         if sp:
             K.rows_copy_by_bits(self.S[U:N], self.G[U:N], bi0)
-            pend = self._exchange_frontier(self.S[U:], bi0)
+            pend = self._exchange_frontier(self.S[U:], bi0, cap=self._cap0)
         else:
             self.S[U:].copy_(self.G[U:])
             pend = self._exchange(self.S)

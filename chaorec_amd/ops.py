@@ -173,6 +173,26 @@ def rows_mean_by_bits(terms, w, out, bits):
     return out
 
 
+def frontier_pack(src, bits, prefix, compact):
+    """compact[k] = src[flagged row number k, bitmap order] (chaorec_frontier_pack_f32); prefix: int32 [n_words + 1] scratch
+    (prefix[-1] = the number of flagged rows afterwards); rows of compact past them are zeroed."""
+    _need_cuda(src, bits, prefix, compact)
+    if src.dtype != torch.float32 or not src.is_contiguous() or not compact.is_contiguous() or compact.shape[1] != src.shape[1] \
+            or prefix.numel() < (src.shape[0] + 31) // 32 + 1:
+        raise ValueError("frontier_pack: contiguous float32 [n, D] / [cap, D] buffers, prefix of n_words + 1 ints")
+    _lib.check(_lib.load().chaorec_frontier_pack_f32(_ptr(src), src.shape[0], src.shape[1], _ptr(bits), _ptr(prefix), _ptr(compact),
+                                                     compact.shape[0], _stream()), "chaorec_frontier_pack_f32")
+    return compact
+
+
+def frontier_unpack(dst, bits, prefix, compact):
+    """dst[flagged row number k] = compact[k] (chaorec_frontier_unpack_f32), the inverse of frontier_pack."""
+    _need_cuda(dst, bits, prefix, compact)
+    _lib.check(_lib.load().chaorec_frontier_unpack_f32(_ptr(dst), dst.shape[0], dst.shape[1], _ptr(bits), _ptr(prefix),
+                                                       _ptr(compact), compact.shape[0], _stream()), "chaorec_frontier_unpack_f32")
+    return dst
+
+
 def or_words(dst, src):
     """dst[w] = OR_k src[k, w] (chaorec_or_words_u32): the union of all-gathered row bitmaps."""
     _need_cuda(dst, src)

@@ -723,6 +723,16 @@ int chaorec_exchange_pull_sum_rows_f32(const void *const *peers, int32_t world, 
 int chaorec_exchange_pull_gather_rows_f32(const void *const *peers, int32_t world, int64_t n_block, int64_t n_rows, int32_t D,
                                           const uint32_t *bits, float *out, void *stream);
 
+/* The COMPACT form of a frontier exchange, for collectives that cannot skip rows (RCCL): the bitmap being the same on every
+ * rank, "flagged row number k in bitmap order" names the same row everywhere.  pack: prefix[w] = flagged rows before word w
+ * (prefix: int32 [n_words + 1] scratch, prefix[n_words] = their total), compact[k] = src[row k] for k < cap, the rest of
+ * compact zeroed; the caller all-reduces compact ([cap, D]); unpack: dst[row k] = compact[k].  Rows beyond cap are dropped:
+ * only for frontiers with a static bound (the batch items of all ranks: <= 2 B world). */
+int chaorec_frontier_pack_f32(const float *src, int64_t n_rows, int32_t D, const uint32_t *bits, int32_t *prefix, float *compact,
+                              int64_t cap, void *stream);
+int chaorec_frontier_unpack_f32(float *dst, int64_t n_rows, int32_t D, const uint32_t *bits, const int32_t *prefix,
+                                const float *compact, int64_t cap, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Several BPR terms over ONE user table and one batch of users (Model/FREEDOM.py:203-215:
  *   mf_loss + reg_weight * (mf_t_loss + mf_v_loss), each -mean(logsigmoid(s+ - s-)) over its own item table):

@@ -389,6 +389,20 @@ class _OracleStepKernels:
         return None
 
     @classmethod
+    def frontier_pack(cls, src, bits, prefix, compact):
+        rows = np.nonzero(cls._rows(bits, src.shape[0]))[0]              # (bitmap order: the same on every rank)
+        assert len(rows) <= compact.shape[0]
+        compact.zero_()
+        compact[:len(rows)] = src[rows]
+        prefix[-1] = len(rows)
+
+    @classmethod
+    def frontier_unpack(cls, dst, bits, prefix, compact):
+        rows = np.nonzero(cls._rows(bits, dst.shape[0]))[0]
+        assert len(rows) == int(prefix[-1])
+        dst[rows] = compact[:len(rows)]
+
+    @classmethod
     def spmm_rowsparse(cls, csr, x, y, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None):
         y.copy_(cls._gated(csr, x, alpha, z, beta, src_bits, z_bits))
 

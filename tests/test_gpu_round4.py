@@ -662,6 +662,17 @@ def test_frontier_helper_launches(dev):
     assert torch.equal(dst[rows], src[rows]) and float(dst[rest].abs().max()) == 0.0
     ops.zero_rows_by_bits(src, bout)
     assert float(src[rows].abs().max()) == 0.0 and float(src[rest].abs().min()) > 0.0
+    # frontier_pack / frontier_unpack: bitmap order, zeroed tail, the inverse copy
+    tab = torch.randn(I, D, device=dev)
+    cap = len(want) + 17
+    compact = torch.full((cap, D), float("nan"), device=dev)
+    prefix = torch.zeros((I + 31) // 32 + 1, dtype=torch.int32, device=dev)
+    ops.frontier_pack(tab, stray, prefix, compact)                      # (the stray bit past the end is not a row)
+    assert int(prefix[-1]) == len(want) and torch.equal(compact[:len(want)], tab[rows])
+    assert float(compact[len(want):].abs().max()) == 0.0
+    back = torch.zeros(I, D, device=dev)
+    ops.frontier_unpack(back, stray, prefix, compact * 2)
+    assert torch.equal(back[rows], 2 * tab[rows]) and float(back[rest].abs().max()) == 0.0
     # or_words
     parts = torch.stack([bitmap(rng.choice(I, 30, replace=False), I) for _ in range(4)])
     acc = torch.zeros_like(parts[0])
