@@ -46,7 +46,7 @@ extern "C" {
                                   12: the frontier-restricted step: chaorec_batch_rows (the batch before the forward), list
                                       launches with a layer-mean epilogue and workgroup-per-row launches for long rows,
                                       chaorec_expand_row_bits over rectangular blocks, rows_list_from_bits, rows_mean_by_bits,
-                                      zero_rows_by_bits, rows_copy_by_bits, or_words, peer-to-peer exchange of flagged rows */
+                                      zero_rows_by_bits, rows_copy_by_bits, or_words, peer-to-peer exchange of flagged rows, frontier pack / unpack */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
