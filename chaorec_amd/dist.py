@@ -1211,7 +1211,6 @@ class FusedShardedLightGCNStep:
             K.rows_mean_by_bits([t[U:N] for t in xs] + [self.Z[:I], self.Z0[:I]], w, self.final[U:N], bi0)
             K.zero_rows_by_bits(self.Z[:I], bi1)             # (both frontier buffers had their readers: all-zero again)
             K.zero_rows_by_bits(self.Z0[:I], bi0)
-            flags = {}
             K.bpr_fwd_bwd(self.final, U, self.G, B, ops.VARIANT_LOG_SIGMOID_EPS, model.reg_weight, self.coef, self.ws, self.ids,
                           num_user=U, num_item=I, adam_step=opt._step_dev, betas=group["betas"], adam_bc=self.bc)
         else:
