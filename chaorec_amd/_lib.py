@@ -67,7 +67,7 @@ SIGNATURES = {
                                                   c_ptr]),
     "chaorec_bpr_finalize_steps_f32": (ctypes.c_int, [c_ptr, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                       ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
-                                                      c_ptr]),
+                                                      c_ptr, c_ptr]),
     "chaorec_bpr_finalize_f32": (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr,
                                                 c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr,
                                                 c_ptr]),

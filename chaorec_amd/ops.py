@@ -679,14 +679,20 @@ def bpr_finalize(ws, B, D, reg_weight, out_loss, out_total=None, loss_accum=None
     _lib.check(rc, "chaorec_bpr_finalize_f32")
 
 
-def bpr_finalize_steps(ws, n_steps, B, D, reg_weight, out_loss, out_total=None, loss_accum=None, advance=None, perm_pos=None):
+def bpr_finalize_steps(ws, n_steps, B, D, reg_weight, out_loss, out_total=None, loss_accum=None, advance=None, perm_pos=None,
+                       scratch=None):
     """bpr_finalize for the n_steps workspaces ws[j] (ws: [n_steps, >= 4 B]) of a replay in ONE launch
     (chaorec_bpr_finalize_steps_f32): the same sums and additions into loss_accum, in step order; out_loss / out_total of
-    the last step; advance += n_steps, perm_pos += n_steps * B."""
-    _need_cuda(ws, out_loss, out_total, loss_accum, advance, perm_pos)
+    the last step; advance += n_steps, perm_pos += n_steps * B.  scratch: float32 [2 n_steps + 1], ZERO in its last element
+    (a captured step passes its own; without one a fresh buffer is allocated)."""
+    _need_cuda(ws, out_loss, out_total, loss_accum, advance, perm_pos, scratch)
+    if scratch is None:
+        scratch = torch.zeros(2 * int(n_steps) + 1, dtype=torch.float32, device=ws.device)
+    elif scratch.numel() < 2 * int(n_steps) + 1 or scratch.dtype != torch.float32:
+        raise ValueError("bpr_finalize_steps: scratch must hold 2 n_steps + 1 floats")
     rc = _lib.load().chaorec_bpr_finalize_steps_f32(_ptr(ws), int(ws.stride(0)), int(n_steps), int(B), int(D), float(reg_weight),
                                                     _ptr(out_loss), _ptr(out_total), _ptr(loss_accum), _ptr(advance),
-                                                    _ptr(perm_pos), _stream())
+                                                    _ptr(perm_pos), _ptr(scratch), _stream())
     _lib.check(rc, "chaorec_bpr_finalize_steps_f32")
 
 

@@ -577,6 +577,7 @@ class FusedLightGCNStep:
                 # step's batch draw does, and that takes its position as cursor + j B with j fixed per captured launch
                 k = self.steps_per_replay
                 self.ws_steps = torch.empty((k, 4 * self.B), dtype=torch.float32, device=dev)
+                self._fin_scratch = torch.zeros(2 * k + 1, dtype=torch.float32, device=dev)    # (+ the launch's ticket)
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
                     for j in range(k):
@@ -641,7 +642,7 @@ class FusedLightGCNStep:
         if k == 1:
             ops.bpr_finalize(ws, B, D, model.reg_weight, self.out, **book)
         elif j == k - 1:
-            ops.bpr_finalize_steps(self.ws_steps, k, B, D, model.reg_weight, self.out, **book)
+            ops.bpr_finalize_steps(self.ws_steps, k, B, D, model.reg_weight, self.out, scratch=self._fin_scratch, **book)
         g, alpha = self.G, w                    # g_{L-1} = w (A G) + w G, then g_l = A g_{l+1} + w G
         for l in range(L - 1):
             y = self.buf[l & 1]

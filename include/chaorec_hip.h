@@ -333,7 +333,9 @@ int chaorec_bpr_finalize_f32(const float *workspace, int32_t B, int32_t D, float
  * pos_offset = j * B (read position *perm_pos + pos_offset of the epoch permutation) into its own workspace
  * workspace + j * ws_stride, and ONE chaorec_bpr_finalize_steps_f32 after the last step reduces the k workspaces in
  * order -- the same sums and the same sequence of additions into loss_accum as k single launches -- writes the LAST
- * step's out_loss / out_total and moves *advance on by k and *perm_pos by k * B. */
+ * step's out_loss / out_total and moves *advance on by k and *perm_pos by k * B.  scratch: 2 k + 1 floats, the last one an
+ * int ticket that is zero on entry and zero again afterwards (one workgroup per step; the last to arrive does the
+ * bookkeeping in step order). */
 int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
                                const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
                                int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
@@ -347,7 +349,7 @@ int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i, const int
  *  rows of the gradient buffer the launch touched, for chaorec_spmm_csr_rowsparse_f32) */
 int chaorec_bpr_finalize_steps_f32(const float *workspace, int64_t ws_stride, int32_t n_steps, int32_t B,
                                    int32_t D, float reg_weight, float *out_loss, float *out_total,
-                                   float *loss_accum, int64_t *advance, int64_t *perm_pos, void *stream);
+                                   float *loss_accum, int64_t *advance, int64_t *perm_pos, float *scratch, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * R: all-items scoring + history mask + top-K, never materialising the [U, I] matrix.
