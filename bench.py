@@ -973,7 +973,7 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
     def run_steps(first, n):
         if fused is not None:         # whole k-step replays, single-step replays for the remainder
             n_loss[0] += n
-            fused.run(n)
+            fused.run(n, full_last=False)      # (steps INSIDE an epoch: the full-result step is timed separately below)
             return
         for i in range(n):
             step(first + i)
