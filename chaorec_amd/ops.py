@@ -748,8 +748,9 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     route's counters (chaorec_score_topk_stats; costs a device sync).
     hint (optional, float32 [U] on the device): per-user thresholds carried between calls
     (chaorec_score_topk_hinted_f32): written by every call, read when hint_valid.  Never changes the result.
-    light: no retry pass (the caller saw a short retry queue last time); counters: int32 [4] device tensor receiving
-    this call's queue lengths.  idx_out: an int64 [U, K] tensor to write the indices to -- a PINNED host tensor is allowed
+    light: no retry pass (the caller saw a short retry queue last time); counters: int32 [4] tensor receiving this call's
+    queue lengths -- on the device, or PINNED host memory (written by the call's last launch; read it after the stream has
+    passed the call).  idx_out: an int64 [U, K] tensor to write the indices to -- a PINNED host tensor is allowed
     (page-locked memory is mapped into the device's address space: the selection then writes the rank list straight over
     PCIe while it runs, instead of a device buffer that is copied afterwards; sync the stream before reading it)."""
     _need_cuda(user_emb, item_emb)
@@ -769,6 +770,7 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
         idx = idx_out if idx_out is not None else torch.empty((U, K), dtype=torch.int64, device=dev)
         val = torch.empty((U, K), dtype=torch.float32, device=dev)
         tot = torch.zeros(4, dtype=torch.int32, device=dev) if counters is not None else None
+        counters_arg, counters = counters, (torch.zeros(4, dtype=torch.int32, device=dev) if counters is not None else None)
         agg = {}
         for u0 in range(0, U, per):
             u1 = min(U, u0 + per)
@@ -789,7 +791,7 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
                     else:
                         agg[k_] = max(agg.get(k_, 0), v_) if k_ == "longest_list" else agg.get(k_, 0) + v_
         if tot is not None:
-            counters.copy_(tot)
+            counters_arg.copy_(tot, non_blocking=True)
         if stats is not None:
             stats.update(agg, user_chunks=(U + per - 1) // per)
         return idx, val
@@ -805,6 +807,9 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
     rowptr, col = hist if hist is not None else (None, None)
     _need_cuda(rowptr, col)
+    if counters is not None and (counters.dtype != torch.int32 or counters.numel() < 4 or not counters.is_contiguous()
+                                 or not (counters.is_cuda or counters.is_pinned())):
+        raise TypeError("score_topk: counters must be a contiguous int32 [4] device or pinned host tensor")
     if hint is not None and precision == 0:
         _need_cuda(hint)
         if hint.dtype != torch.float32 or hint.numel() != U or not hint.is_contiguous():
