@@ -1562,18 +1562,28 @@ class ShardedMMGCN(nn.Module):
         self.reg_weight = full.reg_weight
         U, u0, u1 = shard.num_user_global, shard.u0, shard.u1
         op = self._graph_op = ShardedGraph(shard, spmm_fn, group)
+        # The visual branch gets a process group -- an RCCL communicator -- of ITS OWN: in two-stream mode its exchanges are
+        # issued from the side stream while the textual branch's run from the main one, and two collectives of ONE
+        # communicator must never be in flight at the same time (c10d runs a synchronous collective on the caller's
+        # stream: two streams = two concurrent kernels on the communicator's buffers; seen once in ~10 runs as a step
+        # with slightly wrong gradients).  Collective: every rank builds its ShardedMMGCN at the same point.
+        self.group_v = group
+        if dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES):
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            self.group_v = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+        op_v = self._graph_op_v = op if self.group_v is group else ShardedGraph(shard, spmm_fn, self.group_v)
 
         def take(t):       # [U + I, d] or [U, d] global rows -> this shard's layout
             t = t.detach().cpu()
             return (torch.cat((t[u0:u1], t[U:]), 0) if t.shape[0] > U else t[u0:u1]).clone().to(device)
 
-        def shard_gcn(g):
+        def shard_gcn(g, graph_op):
             g = copy.deepcopy(g)
-            g.edge_index, g.num_user, g.device = op, self.num_user, device
+            g.edge_index, g.num_user, g.device = graph_op, self.num_user, device
             g.preference = take(g.preference)
             return g.to(device)
 
-        self.v_gcn, self.t_gcn = shard_gcn(full.v_gcn), shard_gcn(full.t_gcn)
+        self.v_gcn, self.t_gcn = shard_gcn(full.v_gcn, op_v), shard_gcn(full.t_gcn, op)
         self.v_feat, self.t_feat = full.v_feat.detach().to(device), full.t_feat.detach().to(device)
         self.id_embedding = take(full.id_embedding)
         rowptr, col = graph.user_hist_csr(graph.user_item_dict_from_edges(shard.local_edges), self.num_user)
@@ -1595,14 +1605,14 @@ class ShardedMMGCN(nn.Module):
             cur = torch.cuda.current_stream()
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream(device=self.id_embedding.device)
-            self._graph_op.sync = True                   # (the backward's exchanges, run by autograd later, too)
+            self._graph_op.sync = self._graph_op_v.sync = True     # (the backward's exchanges, run by autograd later, too)
             self._side_stream.wait_stream(cur)
             with torch.cuda.stream(self._side_stream):
                 v_rep = self.v_gcn(self.v_feat, self.id_embedding)
             t_rep = self.t_gcn(self.t_feat, self.id_embedding)
             cur.wait_stream(self._side_stream)
         else:
-            self._graph_op.sync = False
+            self._graph_op.sync = self._graph_op_v.sync = False
             v_rep = self.v_gcn(self.v_feat, self.id_embedding)
             t_rep = self.t_gcn(self.t_feat, self.id_embedding)
         rep = (v_rep + t_rep) / 2
