@@ -11,7 +11,10 @@ import sys
 
 VARIANTS = ["eager_main", "eager_side", "eager_comm", "capture_main", "capture_side", "capture_comm", "capture_comm_async",
             "capture_two_issuers", "capture_side_async", "capture_two_issuers_async", "capture_autograd_side",
-            "capture_autograd_side_async", "eager_autograd_side_async"]
+            "capture_autograd_side_async", "eager_autograd_side_async",
+            # the side stream's collectives on a process group (an RCCL communicator) of their own
+            "capture_two_groups_side", "capture_two_groups_side_async", "capture_autograd_two_groups_side",
+            "capture_autograd_two_groups_side_async"]
 
 
 def child(variant):
@@ -22,6 +25,7 @@ def child(variant):
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    g2 = dist.new_group(backend="nccl") if "two_groups" in variant else None
     a, b = torch.ones(1 << 20, device=dev), torch.ones(1 << 20, device=dev)
     w = torch.randn(1024, 1024, device=dev)
     side, comm = torch.cuda.Stream(), torch.cuda.Stream()
@@ -31,16 +35,18 @@ def child(variant):
             x = (x.view(1024, 1024) @ w).view(-1) * 1e-3
         return x
 
-    def exch(t, issuer, async_op):
+    def exch(t, issuer, async_op, group=None):
         cur = torch.cuda.current_stream()
+        if group is None and g2 is not None and cur == side:
+            group = g2                          # (the side stream's collectives on their own communicator)
         if issuer is None or issuer == cur:
-            h = dist.all_reduce(t, async_op=async_op)
+            h = dist.all_reduce(t, async_op=async_op, group=group)
             if async_op:
                 h.wait()
             return
         issuer.wait_stream(cur)
         with torch.cuda.stream(issuer):
-            h = dist.all_reduce(t, async_op=async_op)
+            h = dist.all_reduce(t, async_op=async_op, group=group)
             if async_op:
                 h.wait()
         cur.wait_stream(issuer)
