@@ -435,13 +435,13 @@ def test_bench_launches_its_own_ranks_and_propagates_failures():
         assert r.returncode != 0 and "needs the MI355X" in r.stderr
 
 
-@pytest.mark.parametrize("name", ["simgcl_small.npz", "xsimgcl_small.npz", "ncl_small.npz", "selfcf_small.npz"])
+@pytest.mark.parametrize("name", ["simgcl_small.npz", "xsimgcl_small.npz", "ncl_small.npz", "selfcf_small.npz", "slmrec_small.npz"])
 def test_sparse_family_models_start_from_the_reference_state(name):
     """SimGCL / NCL / SelfCF (through the adapter alone): what needs no GPU -- the same seed gives the
     reference class's parameter names and initial weights, and graph.binary_sym_norm_csr gives its scipy-built
     D^-1/2 A D^-1/2 bit for bit (goldens of tests/golden/gen_sparse_family.py: the reference classes' own output)."""
     from chaorec_amd import graph
-    from chaorec_amd.Model import NCL, SelfCF, SimGCL, XSimGCL
+    from chaorec_amd.Model import NCL, SelfCF, SimGCL, SLMRec, XSimGCL
     g = load_golden(name)
     U, I = int(g["U"]), int(g["I"])
     uid = graph.user_item_dict_from_edges(g["edges"])
@@ -453,6 +453,10 @@ def test_sparse_family_models_start_from_the_reference_state(name):
     elif name.startswith("xsimgcl"):
         m = XSimGCL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), float(g["ssl_temp"]), float(g["ssl_reg"]), cpu)
         adj = m.sparse_norm_adj
+    elif name.startswith("slmrec"):
+        m = SLMRec(U, I, g["edges"], uid, torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]), int(g["D"]), int(g["L"]),
+                   float(g["ssl_temp"]), float(g["ssl_alpha"]), cpu)
+        adj = m.norm_adj
     elif name.startswith("ncl"):
         m = NCL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), "add", float(g["ssl_temp"]), float(g["ssl_reg"]), cpu)
         adj = m.norm_adj_mat
