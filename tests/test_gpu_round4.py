@@ -679,3 +679,41 @@ def test_frontier_helper_launches(dev):
     ops.or_words(acc, parts)
     torch.cuda.synchronize()
     assert np.array_equal(acc.cpu().numpy().view(np.uint32), np.bitwise_or.reduce(parts.cpu().numpy().view(np.uint32), axis=0))
+
+
+def test_frontier_launches_on_empty_frontiers(dev):
+    """Edge cases of the frontier-restricted step's launches: an EMPTY row list / bitmap is a no-op everywhere (a list launch
+    -- with and without long rows, gated and ungated -- leaves y alone and its long-row counters clean; the expansion flags
+    nothing; the compact frontier buffer comes back all-zero), and a batch whose size is no multiple of the workgroup is
+    flagged completely."""
+    from chaorec_amd import graph, ops
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, D = 900, 400, 128
+    edges = synthetic_interactions(U, I, 7000, seed=3)
+    csr = graph.lightgcn_csr(edges, U + I).to(dev)
+    N = U + I
+    x = torch.randn(N, D, device=dev)
+    empty_bits, out_bits = ops.row_bitmap(N, dev), ops.row_bitmap(N, dev)
+    lst, n = torch.zeros(N, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.expand_row_bits(csr, empty_bits, out_bits, lst, n)
+    assert int(n) == 0 and int(out_bits.abs().sum()) == 0
+    long_rows = ops.long_row_buffers(csr, 4)
+    for kw in (dict(), dict(long_rows=long_rows), dict(src_bits=empty_bits, z_bits=empty_bits, z=x, beta=0.5, long_rows=long_rows)):
+        y = torch.full((N, D), 7.0, device=dev)
+        ops.spmm_rowlist_raw(csr, x, y, lst, n, **kw)
+        torch.cuda.synchronize()
+        assert float((y - 7.0).abs().max()) == 0.0 and int(long_rows[1].abs().sum()) == 0
+    compact = torch.full((16, D), float("nan"), device=dev)
+    prefix = torch.zeros((N + 31) // 32 + 1, dtype=torch.int32, device=dev)
+    ops.frontier_pack(x, empty_bits, prefix, compact)
+    assert int(prefix[-1]) == 0 and float(compact.abs().max()) == 0.0
+    back = x.clone()
+    ops.frontier_unpack(back, empty_bits, prefix, compact)
+    assert torch.equal(back, x)
+    for B in (1, 37, 300):
+        ids = (torch.randint(0, U, (B,), device=dev), torch.randint(0, I, (B,), device=dev), torch.randint(0, I, (B,), device=dev))
+        bits = ops.row_bitmap(N, dev)
+        l0, n0 = torch.zeros(3 * B, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.batch_rows(ids, bits, U, l0, n0)
+        want = np.unique(np.concatenate([ids[0].cpu().numpy(), U + ids[1].cpu().numpy(), U + ids[2].cpu().numpy()]))
+        assert np.array_equal(_bits_to_rows(bits, N), want) and np.array_equal(np.sort(l0[:int(n0)].cpu().numpy()), want)
