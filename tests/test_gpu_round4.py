@@ -381,7 +381,7 @@ def test_bpr_launch_flags_exactly_the_rows_it_touched(dev):
     assert np.array_equal(torch.nonzero(G.abs().sum(1) > 0).flatten().cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("D,L,long_t", [(64, 3, None), (128, 2, 6), (256, 4, 3), (128, 3, 20), (64, 2, 2)])
+@pytest.mark.parametrize("D,L,long_t", [(64, 3, None), (128, 2, 6), (256, 4, 3), (128, 3, 20), (64, 2, 2), (96, 2, 5), (192, 3, 4)])
 def test_rowlist_layer_mean_equals_the_dense_forward_in_the_listed_rows(dev, D, L, long_t):
     """The light forward's last two launches (ops.spmm_rowlist_raw over N1's list, then over R0's list with the layer mean in
     the epilogue) against ops.forward_layers on every row: the listed rows of the mean carry the same bits -- whichever of the
