@@ -117,6 +117,13 @@ struct PrefArgs {
   int *fb_done;                 // [U] slices finished per queued user (zeroed per call)
   uint64_t *fb_partial;         // [U][kExSlices][kMaxK] per-slice best keys
   int fb_skip;                  // queue entries below this index were ranked by the grouped f32 sweep
+  // pass C (long item ranges): a user whose lists overflowed / who has more candidates than the wide selection holds is
+  // not ranked exactly at once (the exact route streams the whole item table per user) but gets a RAISED threshold taken
+  // from the exact scores of the candidates its lists did keep (score_rethreshold_kernel) and one more compact pass
+  int *reth_cnt;                // users queued for a raised threshold (NULL: such users go to the exact route)
+  int *reth_list;               // [U]
+  int *rt2_cnt;                 // users that got one -> compact sweep + wide selection (pass C)
+  int *rt2_list;                // [U]
 };
 
 // ---- pack ----------------------------------------------------------------------------------------------------
@@ -1173,6 +1180,7 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
       if (P.retry_cnt) P.retry_list[atomicAdd(P.retry_cnt, 1)] = (int)u;
       else if (why == 3 && MAXC < kPfMaxCandWide && P.wide_cnt && n_cand <= kPfMaxCandWide && total <= kPfMaxCandWide)
         P.wide_list[atomicAdd(P.wide_cnt, 1)] = (int)u;
+      else if ((why == 1 || why == 3) && P.reth_cnt) P.reth_list[atomicAdd(P.reth_cnt, 1)] = (int)u;   // threshold too low: pass C
       else P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;
     }
   }
@@ -1201,6 +1209,155 @@ __global__ __launch_bounds__(64, D > 64 ? 3 : (MAXC <= 512 ? CHAOREC_SEL_WAVES :
     int lane = threadIdx.x;
     asm volatile("" : "+v"(lane));       // (keeps the lane-dependent constants of the networks out of the loop preheader)
     select_user<D, MAXC>(P, u, lane, meta_s, cand_s, hist_s, score_s);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- pass C: a raised threshold for the users whose candidate lists overflowed --------------------------------------
+// One wave per queued user (reth_list).  A list of the sweep holds its FIRST kPfCap entries, the rest were counted; the walk
+// below expands what is stored -- at most kPfMaxCandWide entries and candidates, in list order --, scores those candidates
+// exactly and takes the new threshold one float below the exact score of rank r among the non-history ones.  r is chosen
+// so that about kPfRethTarget items of the user's WHOLE candidate set are expected above it (the walked candidates are
+// taken as a sample of that set: the splits' tiles are interleaved over the item range).  r >= K and the r scored items
+// themselves lie above the new threshold, so the pass that follows (compact sweep + wide selection) certifies the user
+// unless its lists overflow again; whoever cannot get such a threshold is queued for the exact route as before.
+// Any threshold is legal: a poor estimate costs a second failure, never a wrong result.
+constexpr int kPfRethTarget = 256;
+
+template <int D>
+__device__ __forceinline__ void rethreshold_user(const PrefArgs &P, const int64_t u, int lane, int2 *meta_s, uint32_t *cand_s,
+                                                 uint32_t *hist_s, float *score_s) {
+  constexpr int MAXC = kPfMaxCandWide;
+  const int K = P.K;
+  const int n_lists = 2 * P.splits;  // <= 32
+  const PermAddr pa = perm_addr(lane);
+  const int listidx = (int)(((int64_t)(lane >> 1) * P.n_users + u) * 2 + (lane & 1));
+  int c_all = 0;
+  if (lane < n_lists) c_all = P.cand_cnt[listidx];
+  const int c = min(c_all, kPfCap);                              // entries this list holds
+  float ua[D / (2 * kSelG)], ub[D / (2 * kSelG)];
+  {
+    const float *urow = P.user_emb + (size_t)u * D + (D / (2 * kSelG)) * (lane % kSelG);
+#pragma unroll
+    for (int i = 0; i < D / (2 * kSelG); i += 4) {
+      const float4 x = reinterpret_cast<const float4 *>(urow)[i / 4], y = reinterpret_cast<const float4 *>(urow + D / 2)[i / 4];
+      ua[i] = x.x, ua[i + 1] = x.y, ua[i + 2] = x.z, ua[i + 3] = x.w;
+      ub[i] = y.x, ub[i + 1] = y.y, ub[i + 2] = y.z, ub[i + 3] = y.w;
+    }
+  }
+  int64_t hb = 0, he = 0;
+  if (P.hist_rowptr) {
+    hb = P.hist_rowptr[u];
+    he = P.hist_rowptr[u + 1];
+  }
+  const int deg = (int)(he - hb);
+  const bool hist_lds = deg <= kPfSelHist;
+  const int incl = wave_scan_add(c);
+  const int stored = __builtin_amdgcn_readlane(incl, 63);
+  const int counted = __builtin_amdgcn_readlane(wave_scan_add(c_all), 63);
+  const int used = min(stored, MAXC);                            // entries walked (the owner table has MAXC slots)
+  int *owner_s = reinterpret_cast<int *>(score_s);
+#pragma unroll 1
+  for (int i = lane; i < used; i += 64) owner_s[i] = 0;
+  meta_s[lane] = make_int2(incl - c, listidx);
+  if (hist_lds) {
+#pragma unroll 1
+    for (int i = lane; i < deg; i += 64) hist_s[i] = (uint32_t)P.hist_col[hb + i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (c > 0 && incl - c < used) owner_s[incl - c] = lane + 1;
+  __builtin_amdgcn_wave_barrier();
+  int n_raw = 0, owner_carry = 0;
+#pragma unroll 1
+  for (int base = 0; base < used; base += 64) {
+    const int e = base + lane;
+    int own = e < used ? owner_s[e] : 0;
+    own = max(wave_scan_max(own), owner_carry);
+    owner_carry = __builtin_amdgcn_readlane(own, 63);
+    uint32_t bits = 0, j0 = 0;
+    if (e < used) {
+      const int list = own - 1;
+      const int2 m = meta_s[list];
+      const uint32_t raw = P.cand[(size_t)m.y * kPfCap + (e - m.x)];
+      bits = raw & 0xFFFFu;
+      j0 = ((uint32_t)(list >> 1) + (raw >> 16) * (uint32_t)P.splits) * 32u + 4u * (uint32_t)(list & 1);
+    }
+    if (__any(bits != 0u && j0 + 32u > (uint32_t)P.n_items)) {
+#pragma unroll 1
+      for (int reg = 0; reg < 16; ++reg)
+        if (j0 + (uint32_t)((reg & 3) + 8 * (reg >> 2)) >= (uint32_t)P.n_items) bits &= ~(1u << (15 - reg));
+    }
+    const int pc = __popc(bits);
+    const int ex = wave_scan_add(pc);
+    int slot = n_raw + ex - pc;
+#pragma unroll 1
+    while (__any(bits != 0u)) {
+      if (bits) {
+        const int bit = 31 - __clz(bits);
+        bits &= ~(1u << bit);
+        const int reg = 15 - bit;
+        if (slot < MAXC) cand_s[slot] = j0 + (uint32_t)((reg & 3) + 8 * (reg >> 2));
+        ++slot;
+      }
+    }
+    n_raw += __builtin_amdgcn_readlane(ex, 63);
+  }
+  const int n_cand = min(n_raw, MAXC);
+  __builtin_amdgcn_wave_barrier();
+  auto in_hist = [&](uint32_t item) -> bool {
+    int lo = 0, hi = deg;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const uint32_t hv = hist_lds ? hist_s[mid] : (uint32_t)P.hist_col[hb + mid];
+      if (hv < item) lo = mid + 1; else hi = mid;
+    }
+    return lo < deg && (hist_lds ? hist_s[lo] : (uint32_t)P.hist_col[hb + lo]) == item;
+  };
+  uint64_t e0 = 0ull, e1 = 0ull;
+  int valid = 0, blocks = 0;
+#pragma unroll 1
+  for (int base = 0; base < n_cand; base += 64) {
+    const float sc = chain_block<D>(P.item_emb, cand_s, base, n_cand, ua, ub, lane);
+    const int idx = base + lane;
+    uint64_t cur = 0ull;
+    if (idx < n_cand) {
+      const uint32_t item = cand_s[idx];
+      if (deg == 0 || !in_hist(item)) cur = make_key(sc, item);
+    }
+    valid += __popcll(__ballot(cur != 0ull));
+    take_block_keys(e0, e1, blocks, cur, pa);
+  }
+  bool queued = false;
+  if (valid >= K && n_cand > 0) {   // wave-uniform
+    // candidates of the whole set per walked one: counted / walked entries, and the walk's own cut at MAXC candidates
+    const float scale = ((float)counted / (float)used) * ((float)n_raw / (float)n_cand);
+    int r = (int)ceilf((float)kPfRethTarget / scale);
+    r = min(min(max(r, K + 6), 128), valid);
+    if ((float)r * scale <= 0.9f * (float)kPfMaxCandWide) {
+      const uint64_t rk = key_of_rank(e0, e1, r - 1);
+      if (lane == 0) {
+        P.tau_sum[u] = nextafterf(ord_to_f32((uint32_t)(rk >> 32)), -INFINITY);
+        P.rt2_list[atomicAdd(P.rt2_cnt, 1)] = (int)u;
+      }
+      queued = true;
+    }
+  }
+  if (!queued && lane == 0) P.fb_list[atomicAdd(P.fb_cnt, 1)] = (int)u;
+}
+
+template <int D>
+__global__ __launch_bounds__(64, 3) void score_rethreshold_kernel(const PrefArgs P) {
+  __shared__ int2 meta_s[64];
+  __shared__ uint32_t cand_s[kPfMaxCandWide];
+  __shared__ uint32_t hist_s[kPfSelHist];
+  __shared__ float score_s[kPfMaxCandWide];
+  const int64_t n_act = (int64_t)*P.reth_cnt;
+#pragma unroll 1
+  for (int64_t i = blockIdx.x; i < n_act; i += gridDim.x) {
+    const int64_t u = (int64_t)P.reth_list[i];
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    rethreshold_user<D>(P, u, lane, meta_s, cand_s, hist_s, score_s);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -1441,12 +1598,14 @@ __global__ __launch_bounds__(ex_threads<D>()) void score_exact_user_kernel(const
 
 // ---- statistics of the last prefilter call (monitoring / tuning) ------------------------------------------------
 // out[0] users sent to the exact route, out[1] candidates in total, out[2] longest sweep list (entries), out[3] users,
-// out[4..8] uncertified users of the LAST selection pass by reason code 1..5 (select_user)
+// out[4..8] uncertified users of the LAST selection pass by reason code 1..5 (select_user), out[9] users of pass C
 __global__ __launch_bounds__(256) void score_prefilter_stats_kernel(const int *__restrict__ fail,
                                                                     const int *__restrict__ cand_cnt,
                                                                     const int *__restrict__ n_cand, int64_t n_users,
-                                                                    int splits, unsigned long long *__restrict__ out) {
+                                                                    int splits, unsigned long long *__restrict__ out,
+                                                                    const int *__restrict__ rt2_cnt) {
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u == 0 && rt2_cnt) out[9] = (unsigned long long)*rt2_cnt;
   if (u >= n_users) return;
   int mx = 0;
   if (cand_cnt) {

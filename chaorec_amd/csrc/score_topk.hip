@@ -803,6 +803,8 @@ struct ScorePlan {
   int pf_ub, pf_splits, pf_sample_stride, pf_sample_splits, pf_sample_rank;
   bool pf_sample_long;
   size_t off_pf_retry, off_pf_wide, off_pf_ncand, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
+  bool pf_reth;                // pass C: raised thresholds for overflowing users (long item ranges)
+  size_t off_pf_reth, off_pf_rt2;
   bool pf_group_fb;            // large item ranges: the first kPfFbGroupCap queued users share f32 MFMA sweeps
   int pf_group_fb_splits;
   size_t off_pf_fbgroup;
@@ -913,6 +915,11 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   p.off_pf_wide = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_ncand = take(p.prefilter ? (size_t)n_users * 4 : 0);
   p.off_pf_fb = take(p.prefilter ? (size_t)n_users * 4 : 0);
+  // The exact route costs a pass over the whole item table per user: from 128 k items on, a user whose lists overflowed
+  // (threshold too low) is first given a raised threshold and one more compact pass (pass C, score_rethreshold_kernel)
+  p.pf_reth = p.prefilter && n_items >= 131072;
+  p.off_pf_reth = take(p.pf_reth ? (size_t)n_users * 4 : 0);
+  p.off_pf_rt2 = take(p.pf_reth ? (size_t)n_users * 4 : 0);
   p.off_pf_fbpart = take(p.prefilter ? (size_t)n_users * kExSlices * kMaxK * 8 : 0);
   // The per-user exact route streams the whole item table once per queued user (1 GB per user at 2 M x 128): past
   // 128 k items the queued users are instead swept 32 at a time on the f32 MFMA pipe (the route-1 kernel over a
@@ -974,17 +981,19 @@ extern "C" size_t chaorec_score_topk_workspace_bytes(int64_t n_users, int64_t n_
 }
 
 extern "C" int chaorec_score_topk_stats(const void *workspace, int64_t n_users, int64_t n_items, int32_t K, int32_t D,
-                                        uint64_t *out9, void *stream) {
+                                        uint64_t *out10, void *stream) {
+  uint64_t *out9 = out10;
   if (!workspace || !out9) return fail(CHAOREC_E_INVALID, "score_topk_stats: NULL argument");
   if (n_users <= 0 || n_items <= 0 || K <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "score_topk_stats: bad sizes");
   const ScorePlan p = plan_score(n_users, n_items, K, D);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out9, 0, 9 * sizeof(uint64_t), st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "stats: memset");
+  if (hipMemsetAsync(out9, 0, 10 * sizeof(uint64_t), st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "stats: memset");
   if (!p.prefilter) return CHAOREC_OK;   // all zeros: the call did not take the prefilter route
   const char *ws = (const char *)workspace;
   hipLaunchKernelGGL(score_prefilter_stats_kernel, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, st,
                      (const int *)(ws + p.off_fail), (const int *)(ws + p.off_pf_cnt),
-                     (const int *)(ws + p.off_pf_ncand), n_users, p.pf_splits, (unsigned long long *)out9);
+                     (const int *)(ws + p.off_pf_ncand), n_users, p.pf_splits, (unsigned long long *)out9,
+                     p.pf_reth ? (const int *)(ws + p.off_pf_scalars + 96) : (const int *)nullptr);
   return check_launch("score_prefilter_stats_kernel");
 }
 
@@ -1044,6 +1053,10 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
   a.n_users_dev = nullptr;
 
   int rc;
+  // phases of one call split over two calls (same arguments, same workspace; a caller that ranks several user ranges can
+  // run range k's back phase beside range k + 1's front phase on another stream): neither flag = the whole call
+  const bool do_front = !(flags & CHAOREC_SCORE_BACK) || (flags & CHAOREC_SCORE_FRONT);
+  const bool do_back = !(flags & CHAOREC_SCORE_FRONT) || (flags & CHAOREC_SCORE_BACK);
   if (p.prefilter) {
     PrefArgs P;
     P.user_emb = user_emb;
@@ -1087,18 +1100,28 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.hint_rank = hint_rank > K ? (hint_rank > 128 ? 128 : hint_rank) : K;
     int *failf = (int *)(ws + p.off_fail);
     P.fail = failf;
+    P.reth_cnt = nullptr;
+    P.reth_list = p.pf_reth ? (int *)(ws + p.off_pf_reth) : nullptr;
+    P.rt2_cnt = p.pf_reth ? (int *)(ws + p.off_pf_scalars + 96) : nullptr;
+    P.rt2_list = p.pf_reth ? (int *)(ws + p.off_pf_rt2) : nullptr;
+    int *reth_cnt = (int *)(ws + p.off_pf_scalars + 32);
     int *retry_cnt = (int *)(ws + p.off_pf_scalars + 64);
     const int64_t nfrag = n_tiles * (D / 16) * 64;
-    hipLaunchKernelGGL(pack_items_bf16_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, item_emb,
-                       (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.item_norm,
-                       (uint4 *)(ws + p.off_pf_scalars), (int64_t)(p.pf_zero_bytes / 16));
-    rc = check_launch("pack_items_bf16_kernel");
-    if (rc) return rc;
+    if (do_front) {
+      hipLaunchKernelGGL(pack_items_bf16_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, item_emb,
+                         (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.item_norm,
+                         (uint4 *)(ws + p.off_pf_scalars), (int64_t)(p.pf_zero_bytes / 16));
+      rc = check_launch("pack_items_bf16_kernel");
+      if (rc) return rc;
+    }
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);
     const dim3 gs4((groups + 3) / 4, (unsigned)p.pf_sample_splits);
     const dim3 gw((unsigned)((groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves)), (unsigned)p.pf_splits);
     const unsigned sel_all = (unsigned)n_users;
     const unsigned sel_queue = (unsigned)std::min<int64_t>(n_users, 8192);    // a pass over a device-side queue
+    // (coarse samples of very long item ranges put a large part of the users above the narrow selection's 512 candidates:
+    //  the wide selection is then a main pass, not a tail -- 256 one-wave workgroups took 106 ms per 1.1 M users at 2 M items)
+    const unsigned sel_wide = p.pf_sample_stride >= 8 ? sel_queue : 256u;
     auto sweep = [&](const PrefArgs &A) {
       if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64 * kSweepWaves), 0, st, A);
       else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, A);
@@ -1106,6 +1129,10 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     auto select = [&](const PrefArgs &A, unsigned grid) {
       if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
       else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
+    };
+    auto select_wide = [&](const PrefArgs &A, unsigned grid) {
+      if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCandWide>), dim3(grid), dim3(64), 0, st, A);
+      else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCandWide>), dim3(grid), dim3(64), 0, st, A);
     };
     auto sample = [&](const PrefArgs &A) {
       if (D == 64) {
@@ -1120,6 +1147,7 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     // thresholds over the device-side queue) -- unless it is a handful: then the exact per-user route is cheaper than
     // three more launches whose critical path is a whole item sweep by one wave, and pass B returns at once.  With
     // CHAOREC_SCORE_LIGHT the caller (who has seen the previous call's queue lengths) asks for no pass B at all.
+    // Phases (CHAOREC_SCORE_FRONT / _BACK): the front is everything up to and including the call's FIRST whole sweep.
     const bool light = hint_in && (flags & CHAOREC_SCORE_LIGHT) && !p.pf_group_fb;
     const int small_queue = p.pf_group_fb ? -1 : 16;        // (the exact route costs ~6 us per user, a retry pass ~120 us)   // (very long item ranges: the per-user exact route streams the table per user)
     int *wide_cnt = (int *)(ws + p.off_pf_scalars + 192);
@@ -1127,8 +1155,8 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       PrefArgs A = P;            // pass A: the carried thresholds
       A.hint_in = hint_in;
       A.retry_cnt = retry_cnt;
-      sweep(A);
-      select(A, sel_all);
+      if (do_front) sweep(A);
+      if (do_back) select(A, sel_all);
       P.small_retry = light ? INT_MAX : small_queue;
     }
     if (!light) {
@@ -1139,21 +1167,39 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
         B.min_active = small_queue;
       }
       B.wide_cnt = wide_cnt;
-      sample(B);
-      sweep(B);
-      select(B, hint_in ? sel_queue : sel_all);
-      // the few users with more candidates than the narrow selection holds (coarse samples of very long item ranges)
-      {
+      if (p.pf_reth) B.reth_cnt = reth_cnt;
+      if (hint_in ? do_back : do_front) {
+        sample(B);
+        sweep(B);
+      }
+      if (do_back) {
+        select(B, hint_in ? sel_queue : sel_all);
+        // the users with more candidates than the narrow selection holds (coarse samples of very long item ranges)
         PrefArgs W = P;
         W.user_map = P.wide_list;
         W.n_active = wide_cnt;
-        if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
-        else hipLaunchKernelGGL((score_select_kernel_pf<128, kPfMaxCandWide>), dim3(256), dim3(64), 0, st, W);
+        if (p.pf_reth) W.reth_cnt = reth_cnt;
+        select_wide(W, sel_wide);
+        if (p.pf_reth) {
+          // pass C: lists that overflowed / more candidates than the wide selection holds = a threshold that was too low.
+          // A raised one from the exact scores of the candidates the lists did keep, one more compact sweep, the wide
+          // selection; what that cannot certify either goes to the exact routes below
+          PrefArgs R = P;
+          R.reth_cnt = reth_cnt;
+          if (D == 64) hipLaunchKernelGGL(score_rethreshold_kernel<64>, dim3(1024), dim3(64), 0, st, R);
+          else hipLaunchKernelGGL(score_rethreshold_kernel<128>, dim3(1024), dim3(64), 0, st, R);
+          PrefArgs C = P;
+          C.user_map = P.rt2_list;
+          C.n_active = P.rt2_cnt;
+          sweep(C);
+          select_wide(C, 1024u);
+        }
       }
       P.wide_cnt = wide_cnt;     // (for the counters the exact-route launch reports)
     }
     rc = check_launch("score prefilter kernels");
     if (rc) return rc;
+    if (!do_back) return CHAOREC_OK;
     // uncertified users (list overflow, fewer than K above the threshold, band wider than the re-score slots) were
     // queued on the device.  Large item ranges: the first kPfFbGroupCap of them as a compact user set through the
     // unthresholded f32 MFMA sweep (32 users share each pass over the items), results written to their own rows.
@@ -1180,6 +1226,7 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(1024), dim3(ex_threads<128>()), 0, st, P);
     return check_launch("score_exact_user_kernel");
   }
+  if (!do_back) return CHAOREC_OK;   // (the other routes have no front phase: the back-phase call does everything)
   if (p.pack) {
     float4 *packed = (float4 *)(ws + p.off_packed);
     const int64_t n4 = n_tiles * (D / 8) * 64;

@@ -739,6 +739,49 @@ def shift_cat(pos, neg, offset):
 # scoring + top-K
 # --------------------------------------------------------------------------------------------
 SCORE_LIGHT = 1      # CHAOREC_SCORE_LIGHT
+SCORE_FRONT = 2      # CHAOREC_SCORE_FRONT: pack, sampling, the first sweep over all users
+SCORE_BACK = 4       # CHAOREC_SCORE_BACK: selection, retry passes, exact routes
+_SCORE_STREAMS = {}
+
+
+def _score_streams(dev):
+    """(front stream, back stream) of the user-range pipeline, per device."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SCORE_STREAMS:
+        _SCORE_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _SCORE_STREAMS[key]
+
+
+def _score_call(lib, user_emb, item_emb, hist, mask_value, K, id_offset, precision, hint, hint_valid, hint_rank, light,
+                counters, idx, val, ws, nbytes, phase=0):
+    """One chaorec_score_topk_*_f32 call on the current stream (phase: 0 = whole call, SCORE_FRONT / SCORE_BACK)."""
+    U, D = user_emb.shape
+    I = item_emb.shape[0]
+    rowptr, col = hist if hist is not None else (None, None)
+    if (hint is not None or phase or counters is not None) and precision == 0:
+        rc = lib.chaorec_score_topk_hinted_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
+                                               mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
+                                               _ptr(hint if hint_valid else None), _ptr(hint), int(hint_rank),
+                                               (SCORE_LIGHT if (light and hint_valid and hint is not None) else 0) | phase,
+                                               _ptr(counters), _stream())
+        _lib.check(rc, "chaorec_score_topk_hinted_f32")
+    else:
+        rc = lib.chaorec_score_topk_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
+                                        mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
+                                        precision, _stream())
+        _lib.check(rc, "chaorec_score_topk_f32")
+
+
+def _score_stats(lib, ws, U, I, K, D, dev):
+    out10 = torch.zeros(10, dtype=torch.int64, device=dev)
+    _lib.check(lib.chaorec_score_topk_stats(_ptr(ws), U, I, K, D, _ptr(out10), _stream()), "chaorec_score_topk_stats")
+    return out10
+
+
+def _stats_dict(v):
+    return dict(fallback_users=v[0], candidates=v[1], longest_list=v[2], prefilter_users=v[3],
+                fallback_reasons=dict(overflow=v[4], too_few=v[5], too_many=v[6], kth_not_above_threshold=v[7]),
+                rethreshold_users=v[9])
 
 
 def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0, stats=None, hint=None,
@@ -752,61 +795,24 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     queue lengths -- on the device, or PINNED host memory (written by the call's last launch; read it after the stream has
     passed the call).  idx_out: an int64 [U, K] tensor to write the indices to -- a PINNED host tensor is allowed
     (page-locked memory is mapped into the device's address space: the selection then writes the rank list straight over
-    PCIe while it runs, instead of a device buffer that is copied afterwards; sync the stream before reading it)."""
+    PCIe while it runs, instead of a device buffer that is copied afterwards; sync the stream before reading it).
+
+    A call whose workspace (per user: the candidate lists of every sweep split, ~20 KB) would exceed
+    CHAOREC_SCORE_WS_LIMIT (24 GiB) is cut into user ranges -- the users are independent -- and the ranges are PIPELINED:
+    range k's back phase (selection, retry passes, exact routes: gather- and VALU-bound) runs on a second stream beside
+    range k + 1's front phase (sampling + the sweep: MFMA-bound), two workspaces in flight
+    (CHAOREC_SCORE_PIPELINE=0: one range after the other on the caller's stream)."""
     _need_cuda(user_emb, item_emb)
     user_emb, item_emb = _f32c(user_emb), _f32c(item_emb)
     U, D = user_emb.shape
     I = item_emb.shape[0]
     dev = user_emb.device
     lib = _lib.load()
-    limit = int(os.environ.get("CHAOREC_SCORE_WS_LIMIT", str(24 << 30)))
-    if U > 4096 and lib.chaorec_score_topk_workspace_bytes(U, I, K, D) > limit:
-        # The workspace is per user (candidate lists of every sweep split, the exact route's partial lists: ~20 KB per
-        # user): BASELINE configs[4] at 1e7 users would ask for > 200 GB.  The users are independent, so the call is
-        # cut into user ranges whose workspace fits `limit`; every range re-packs the item table (a few ms at 2 M x 128).
-        per = max(4096, (U * limit // lib.chaorec_score_topk_workspace_bytes(U, I, K, D)) // 4096 * 4096)
-        while per > 4096 and lib.chaorec_score_topk_workspace_bytes(per, I, K, D) > limit:
-            per -= 4096
-        idx = idx_out if idx_out is not None else torch.empty((U, K), dtype=torch.int64, device=dev)
-        val = torch.empty((U, K), dtype=torch.float32, device=dev)
-        tot = torch.zeros(4, dtype=torch.int32, device=dev) if counters is not None else None
-        counters_arg, counters = counters, (torch.zeros(4, dtype=torch.int32, device=dev) if counters is not None else None)
-        agg = {}
-        for u0 in range(0, U, per):
-            u1 = min(U, u0 + per)
-            sub = {} if stats is not None else None
-            _, v = score_topk(user_emb[u0:u1], item_emb, None if hist is None else (hist[0][u0:u1 + 1], hist[1]), mask_value,
-                              K, id_offset=id_offset, precision=precision, stats=sub,
-                              hint=None if hint is None else hint[u0:u1], hint_valid=hint_valid, hint_rank=hint_rank,
-                              light=light, counters=counters, idx_out=idx[u0:u1])
-            val[u0:u1] = v
-            if tot is not None:
-                tot += counters
-            if sub is not None:
-                for k_, v_ in sub.items():
-                    if isinstance(v_, dict):
-                        d_ = agg.setdefault(k_, {})
-                        for kk, vv in v_.items():
-                            d_[kk] = d_.get(kk, 0) + vv
-                    else:
-                        agg[k_] = max(agg.get(k_, 0), v_) if k_ == "longest_list" else agg.get(k_, 0) + v_
-        if tot is not None:
-            counters_arg.copy_(tot, non_blocking=True)
-        if stats is not None:
-            stats.update(agg, user_chunks=(U + per - 1) // per)
-        return idx, val
-    if idx_out is not None:
-        if idx_out.dtype != torch.int64 or tuple(idx_out.shape) != (U, K) or not idx_out.is_contiguous() or \
-                not (idx_out.is_cuda or idx_out.is_pinned()):
-            raise TypeError("score_topk: idx_out must be a contiguous int64 [n_users, K] device or pinned host tensor")
-        idx = idx_out
-    else:
-        idx = torch.empty((U, K), dtype=torch.int64, device=dev)
-    val = torch.empty((U, K), dtype=torch.float32, device=dev)
-    nbytes = lib.chaorec_score_topk_workspace_bytes(U, I, K, D)
-    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
     rowptr, col = hist if hist is not None else (None, None)
     _need_cuda(rowptr, col)
+    if idx_out is not None and (idx_out.dtype != torch.int64 or tuple(idx_out.shape) != (U, K) or not idx_out.is_contiguous()
+                                or not (idx_out.is_cuda or idx_out.is_pinned())):
+        raise TypeError("score_topk: idx_out must be a contiguous int64 [n_users, K] device or pinned host tensor")
     if counters is not None and (counters.dtype != torch.int32 or counters.numel() < 4 or not counters.is_contiguous()
                                  or not (counters.is_cuda or counters.is_pinned())):
         raise TypeError("score_topk: counters must be a contiguous int32 [4] device or pinned host tensor")
@@ -814,22 +820,94 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
         _need_cuda(hint)
         if hint.dtype != torch.float32 or hint.numel() != U or not hint.is_contiguous():
             raise TypeError("score_topk: hint must be a contiguous float32 [n_users] tensor")
-        rc = lib.chaorec_score_topk_hinted_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
-                                               mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
-                                               _ptr(hint if hint_valid else None), _ptr(hint), int(hint_rank),
-                                               SCORE_LIGHT if (light and hint_valid) else 0, _ptr(counters), _stream())
-        _lib.check(rc, "chaorec_score_topk_hinted_f32")
+    elif precision != 0:
+        hint = None
+    idx = idx_out if idx_out is not None else torch.empty((U, K), dtype=torch.int64, device=dev)
+    val = torch.empty((U, K), dtype=torch.float32, device=dev)
+    limit = int(os.environ.get("CHAOREC_SCORE_WS_LIMIT", str(24 << 30)))
+    nbytes = lib.chaorec_score_topk_workspace_bytes(U, I, K, D)
+    if not (U > 4096 and nbytes > limit):
+        ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
+        _score_call(lib, user_emb, item_emb, hist, mask_value, K, id_offset, precision, hint, hint_valid, hint_rank, light,
+                    counters if precision == 0 and hint is not None else None, idx, val, ws, nbytes)
+        if stats is not None:
+            stats.update(_stats_dict(_score_stats(lib, ws, U, I, K, D, dev).tolist()))
+        return idx, val
+
+    # ---- user ranges (BASELINE configs[4] at 1e7 users would ask for > 200 GB of workspace) -------------------------
+    pipelined = (os.environ.get("CHAOREC_SCORE_PIPELINE", "1") != "0" and precision == 0
+                 and not torch.cuda.is_current_stream_capturing())
+    budget = limit // 2 if pipelined else limit           # (two workspaces in flight when the ranges are pipelined)
+    per = max(4096, (U * budget // nbytes) // 4096 * 4096)
+    while per > 4096 and lib.chaorec_score_topk_workspace_bytes(per, I, K, D) > budget:
+        per -= 4096
+    n_ranges = (U + per - 1) // per
+    per = min(per, ((U + n_ranges - 1) // n_ranges + 4095) // 4096 * 4096)     # ranges of equal length, not a full one + a rest
+    ranges = [(u0, min(U, u0 + per)) for u0 in range(0, U, per)]
+    ws_bytes = lib.chaorec_score_topk_workspace_bytes(per, I, K, D)
+    pipelined = pipelined and len(ranges) > 1
+    want_counters = counters is not None and precision == 0
+    tot = torch.zeros(4, dtype=torch.int32, device=dev) if want_counters else None
+    stat_sum = torch.zeros(10, dtype=torch.int64, device=dev) if stats is not None else None
+    stat_max = torch.zeros(1, dtype=torch.int64, device=dev) if stats is not None else None
+
+    def args_of(u0, u1):
+        return (user_emb[u0:u1], item_emb, None if hist is None else (rowptr[u0:u1 + 1], col), mask_value, K, id_offset,
+                precision, None if hint is None else hint[u0:u1], hint_valid, hint_rank, light)
+
+    def after(ws, cnt, u0, u1):          # per-range bookkeeping, on the stream that ran the range's back phase
+        if tot is not None:
+            tot.add_(cnt)
+        if stats is not None:
+            o = _score_stats(lib, ws, u1 - u0, I, K, D, dev)
+            stat_max.copy_(torch.maximum(stat_max, o[2:3]))
+            stat_sum.add_(o)
+
+    if not pipelined:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(4, dtype=torch.int32, device=dev) if want_counters else None
+        for u0, u1 in ranges:
+            nb = lib.chaorec_score_topk_workspace_bytes(u1 - u0, I, K, D)
+            _score_call(lib, *args_of(u0, u1), cnt, idx[u0:u1], val[u0:u1], ws, nb)
+            after(ws, cnt, u0, u1)
     else:
-        rc = lib.chaorec_score_topk_f32(_ptr(user_emb), _ptr(item_emb), U, I, D, _ptr(rowptr), _ptr(col),
-                                        mask_value, K, id_offset, _ptr(idx), _ptr(val), _ptr(ws), nbytes,
-                                        precision, _stream())
-        _lib.check(rc, "chaorec_score_topk_f32")
+        cur = torch.cuda.current_stream(dev)
+        s_front, s_back = _score_streams(dev)
+        wss = [torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        cnts = [torch.zeros(4, dtype=torch.int32, device=dev) if want_counters else None for _ in range(2)]
+        start = torch.cuda.Event()
+        start.record(cur)
+        s_front.wait_event(start)
+        s_back.wait_event(start)
+        back_done = [None, None]
+        for k, (u0, u1) in enumerate(ranges):
+            b = k & 1
+            nb = lib.chaorec_score_topk_workspace_bytes(u1 - u0, I, K, D)
+            a = args_of(u0, u1)
+            with torch.cuda.stream(s_front):
+                if back_done[b] is not None:
+                    s_front.wait_event(back_done[b])          # (the workspace's previous range has left it)
+                _score_call(lib, *a, cnts[b], idx[u0:u1], val[u0:u1], wss[b], nb, phase=SCORE_FRONT)
+                front_done = torch.cuda.Event()
+                front_done.record(s_front)
+            with torch.cuda.stream(s_back):
+                s_back.wait_event(front_done)
+                _score_call(lib, *a, cnts[b], idx[u0:u1], val[u0:u1], wss[b], nb, phase=SCORE_BACK)
+                after(wss[b], cnts[b], u0, u1)
+                back_done[b] = torch.cuda.Event()
+                back_done[b].record(s_back)
+        end = torch.cuda.Event()
+        end.record(s_back)
+        cur.wait_event(end)              # (the back stream is in order: its last event covers every range)
+        for t in wss + [c for c in cnts if c is not None]:
+            t.record_stream(s_front)
+            t.record_stream(s_back)
+    if want_counters:
+        counters.copy_(tot, non_blocking=True)
     if stats is not None:
-        out9 = torch.zeros(9, dtype=torch.int64, device=dev)
-        _lib.check(lib.chaorec_score_topk_stats(_ptr(ws), U, I, K, D, _ptr(out9), _stream()), "chaorec_score_topk_stats")
-        v = out9.tolist()
-        stats.update(fallback_users=v[0], candidates=v[1], longest_list=v[2], prefilter_users=v[3],
-                     fallback_reasons=dict(overflow=v[4], too_few=v[5], too_many=v[6], kth_not_above_threshold=v[7]))
+        v = stat_sum.tolist()
+        v[2] = int(stat_max.item())
+        stats.update(_stats_dict(v), user_chunks=len(ranges), pipelined=bool(pipelined))
     return idx, val
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 12  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 13  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -46,7 +46,9 @@ extern "C" {
                                   12: the frontier-restricted step: chaorec_batch_rows (the batch before the forward), list
                                       launches with a layer-mean epilogue and workgroup-per-row launches for long rows,
                                       chaorec_expand_row_bits over rectangular blocks, rows_list_from_bits, rows_mean_by_bits,
-                                      zero_rows_by_bits, rows_copy_by_bits, or_words, peer-to-peer exchange of flagged rows, frontier pack / unpack */
+                                      zero_rows_by_bits, rows_copy_by_bits, or_words, peer-to-peer exchange of flagged rows, frontier pack / unpack;
+                                  13: scoring: CHAOREC_SCORE_FRONT / _BACK (one call as two phases), a raised-threshold pass for
+                                      users whose candidate lists overflow (long item ranges), chaorec_score_topk_stats out10 */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -413,8 +415,22 @@ int chaorec_score_topk_f32(const float *user_emb, const float *item_emb,
  *            selection, queued users taken by the exact route} of THIS call -- what a caller bases the next call's flags on.
  * A threshold never changes the result, only the work: the output is bit-identical to chaorec_score_topk_f32's
  * whatever the hints hold (NaN / inf / stale values included).  Needs the prefilter route (D in {64,128}, >= 4096
- * items, K <= 64); otherwise the hints are ignored and hint_out / counters_out are left untouched. */
+ * items, K <= 64); otherwise the hints are ignored and hint_out / counters_out are left untouched.
+ *   flags    CHAOREC_SCORE_FRONT / CHAOREC_SCORE_BACK: run only the first / only the second PHASE of the call.  The front
+ *            is everything up to and including the call's first sweep over all users (pack, sampling when there are no
+ *            hints, sweep); the back is the rest (selection, retry passes, exact routes).  Two calls with the same
+ *            arguments and the same workspace, FRONT then BACK (in stream order, or on two streams with an event between
+ *            them), are one whole call.  For a caller that ranks several user ranges: range k's back phase -- gather- and
+ *            VALU-bound -- beside range k + 1's front phase -- MFMA-bound -- on another stream, one workspace per range in
+ *            flight.  Neither flag (or both): the whole call.  On the routes without a prefilter the BACK call does
+ *            everything and the FRONT call nothing.
+ * Long item ranges (>= 131072 items), where the exact per-user route streams the whole item table per user: a user whose
+ * candidate lists overflowed (threshold too low) first gets a RAISED threshold -- the exact score of a rank >= K among
+ * the candidates its lists kept -- and one more compact sweep + selection (pass C); only what that cannot certify
+ * either is ranked by the exact routes. */
 #define CHAOREC_SCORE_LIGHT 1
+#define CHAOREC_SCORE_FRONT 2
+#define CHAOREC_SCORE_BACK 4
 int chaorec_score_topk_hinted_f32(const float *user_emb, const float *item_emb,
                                   int64_t n_users, int64_t n_items, int32_t D,
                                   const int64_t *hist_rowptr, const int32_t *hist_col,
@@ -425,12 +441,13 @@ int chaorec_score_topk_hinted_f32(const float *user_emb, const float *item_emb,
                                   int32_t *counters_out, void *stream);
 
 /* Monitoring: what the prefilter route of the LAST scoring call on this workspace did (same sizes).
- * out9 (device, 9 x uint64): [0] users handed to the exact route, [1] candidates re-scored in total, [2] longest
+ * out10 (device, 10 x uint64): [0] users handed to the exact routes, [1] candidates re-scored in total, [2] longest
  * per-lane sweep list (entries), [3] users, [4..8] users the last selection pass could not certify, by reason (list
  * overflow, fewer than K candidates, more candidates than the selection holds, K-th best not above the sweep
- * threshold, unused).  All zeros if that call did not take the prefilter route. */
+ * threshold, unused), [9] users that were given a raised threshold and one more pass (pass C).  All zeros if that call
+ * did not take the prefilter route. */
 int chaorec_score_topk_stats(const void *workspace, int64_t n_users, int64_t n_items, int32_t K, int32_t D,
-                             uint64_t *out9, void *stream);
+                             uint64_t *out10, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * M: ranking metrics of every evaluation row in one launch.

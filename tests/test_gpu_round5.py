@@ -1,0 +1,198 @@
+"""Round-5 GPU parity tests: the scoring call's raised-threshold pass for overflowing users (pass C), the call as two
+phases (CHAOREC_SCORE_FRONT / _BACK) and the pipelined user ranges built on them.  Everything through the C-ABI
+(chaorec_amd._lib ctypes), compared with oracle/ (the checker) bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from chaorec_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _hist_random(U, I, max_deg, seed):
+    rng = np.random.default_rng(seed)
+    rowptr = np.zeros(U + 1, np.int64)
+    cols = []
+    for u in range(U):
+        c = np.sort(rng.choice(I, int(rng.integers(0, max_deg + 1)), replace=False)).astype(np.int32)
+        cols.append(c)
+        rowptr[u + 1] = rowptr[u] + len(c)
+    return rowptr, np.concatenate(cols).astype(np.int32)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_score_topk_overflowing_users_get_a_raised_threshold(dev, oracle, D):
+    """Long item range (>= 131072 items: the exact route would stream the table per user).  Two thirds of the users see
+    6000 high-scoring items that all lie in tiles the sampler never visits (stride 4: it samples tiles = 0 mod 4), so their sampled
+    threshold is far too low and every sweep list overflows.  Pass C re-scores what the lists kept, raises the threshold
+    and sweeps those users once more: they must come out certified (no exact-route user) with the oracle's bits -- Model/
+    LightGCN.py:147-155's top-K of the masked score row, ties to the lowest index."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(5 + D)
+    U, I, K = 96, 140000, 50
+    ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * 0.05).astype(np.float32)
+    tiles = np.arange(I) // 32
+    pool = np.flatnonzero(tiles % 4 != 0)
+    hot = rng.choice(pool, 6000, replace=False)
+    ie[hot, :D // 2] = np.abs(rng.standard_normal((6000, D // 2))).astype(np.float32) * 2
+    ie[hot, D // 2:] = 0
+    ue[0::3, :D // 2] = 0                                 # a third of the users do not see the hot items at all
+    ue[1::3] = np.abs(ue[1::3])
+    ue[2::3, :D // 2] = np.abs(ue[2::3, :D // 2])
+    rp, cl = _hist_random(U, I, 30, seed=D)
+    rows = [cl[rp[u]:rp[u + 1]] for u in range(U)]
+    for u in range(1, U, 6):                              # some of the hot items are in the history of users that see them
+        rows[u] = np.unique(np.r_[rows[u], hot[u:u + 40]]).astype(np.int32)
+    hist = (np.r_[0, np.cumsum([len(r) for r in rows])].astype(np.int64), np.concatenate(rows).astype(np.int32))
+    want_i, want_v = oracle.score_topk(ue, ie, hist, 1e-6, K, U)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    st = {}
+    hint = torch.full((U,), float("nan"), device=dev)
+    got_i, got_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), dh, 1e-6, K, id_offset=U,
+                                  stats=st, hint=hint, hint_valid=False)
+    assert np.array_equal(got_v.cpu().numpy(), want_v)
+    assert np.array_equal(got_i.cpu().numpy(), want_i)
+    assert st["rethreshold_users"] >= U // 2, st          # the users that see the hot items went through pass C ...
+    assert st["fallback_users"] == 0, st                  # ... and none of them needed the exact routes
+    assert bool(torch.isfinite(hint).all())               # every user left a threshold for the next call
+    # the thresholds pass C's selection leaves behind serve the next call (pass A) like anybody's
+    st2 = {}
+    again_i, again_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), dh, 1e-6, K, id_offset=U,
+                                      stats=st2, hint=hint, hint_valid=True)
+    assert torch.equal(again_i, got_i) and torch.equal(again_v, got_v)
+    assert st2["fallback_users"] == 0, st2
+
+
+def test_score_topk_pass_c_hands_hopeless_users_to_the_exact_routes(dev, oracle):
+    """All items equal: no threshold separates anything, pass C's second sweep overflows again and the users end on the
+    grouped f32 sweep / the per-user exact kernel -- with the right answer (lowest indices first)."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(77)
+    U, I, D, K = 40, 131072 + 64, 64, 50
+    ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    ie = np.repeat((rng.standard_normal((1, D)) * 0.2).astype(np.float32), I, 0)
+    want_i, want_v = oracle.score_topk(ue, ie, None, 1e-6, K, 0)
+    st = {}
+    got_i, got_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), None, 1e-6, K, stats=st)
+    assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i)
+    assert st["fallback_users"] == U, st
+
+
+def _call(ops, lib, ue, ie, hist, K, U0, hint, hint_valid, phase, ws, idx, val, counters=None):
+    nb = lib.chaorec_score_topk_workspace_bytes(ue.shape[0], ie.shape[0], K, ue.shape[1])
+    ops._score_call(lib, ue, ie, hist, 1e-6, K, U0, 0, hint, hint_valid, 80, False, counters, idx, val, ws, nb, phase=phase)
+
+
+@pytest.mark.parametrize("U,I,D", [(300, 9000, 64), (150, 140000, 128), (70, 1000, 64)])
+@pytest.mark.parametrize("hinted", [False, True])
+def test_score_topk_front_then_back_is_the_whole_call(dev, U, I, D, hinted):
+    """chaorec_score_topk_hinted_f32 with CHAOREC_SCORE_FRONT and then CHAOREC_SCORE_BACK (same arguments, same workspace;
+    here also on two streams with an event between them) = the call without flags: same indices, values, thresholds,
+    counters.  (I = 1000 takes the route without a prefilter: the back call does everything.)"""
+    from chaorec_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(U + I)
+    K = 50
+    ue = torch.randn(U, D, generator=g, device=dev) * 0.2
+    ie = torch.randn(I, D, generator=g, device=dev) * 0.2
+    rowptr = torch.arange(U + 1, dtype=torch.int64, device=dev) * 5
+    col = (torch.arange(U * 5, device=dev) % 5 * 37 + torch.arange(U * 5, device=dev) // 5 % 11).to(torch.int32)
+    hist = (rowptr, col)
+    nb = lib.chaorec_score_topk_workspace_bytes(U, I, K, D)
+    hint0 = torch.zeros(U, device=dev)
+    if hinted:
+        ops.score_topk(ue, ie, hist, 1e-6, K, id_offset=U, hint=hint0, hint_valid=False)
+        ue = ue + 0.01 * torch.randn(U, D, generator=g, device=dev)      # the tables moved a little since
+
+    def run(split):
+        ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=dev)
+        idx = torch.empty((U, K), dtype=torch.int64, device=dev)
+        val = torch.empty((U, K), device=dev)
+        hint = hint0.clone()
+        cnt = torch.full((4,), -1, dtype=torch.int32, device=dev)
+        if not split:
+            _call(ops, lib, ue, ie, hist, K, U, hint, hinted, 0, ws, idx, val, cnt)
+        else:
+            side = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            _call(ops, lib, ue, ie, hist, K, U, hint, hinted, ops.SCORE_FRONT, ws, idx, val, cnt)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                _call(ops, lib, ue, ie, hist, K, U, hint, hinted, ops.SCORE_BACK, ws, idx, val, cnt)
+            side.synchronize()
+        torch.cuda.synchronize()
+        return idx, val, hint, cnt
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    if I >= 4096:
+        assert bool((a[3] >= 0).all())                    # (the prefilter route reports its queue lengths)
+
+
+@pytest.mark.parametrize("hinted", [False, True])
+def test_score_topk_pipelined_user_ranges_equal_the_serial_ranges(dev, oracle, hinted):
+    """ops.score_topk over user ranges: range k's back phase on a second stream beside range k + 1's front phase, two
+    workspaces in flight == the ranges one after the other == the oracle (a sample of the rows)."""
+    from chaorec_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(3)
+    U, I, D, K = 30_000, 6_000, 64, 50
+    ue = torch.randn(U, D, generator=g, device=dev) * 0.2
+    ie = torch.randn(I, D, generator=g, device=dev) * 0.2
+    rowptr = torch.arange(U + 1, dtype=torch.int64, device=dev) * 3
+    col = ((torch.arange(U * 3, device=dev) % 3) * 1000 + torch.arange(U * 3, device=dev) // 3 % 997).to(torch.int32)
+    hist = (rowptr, col)
+    one = lib.chaorec_score_topk_workspace_bytes(U, I, K, D)
+    base = {}
+    if hinted:
+        h0 = torch.empty(U, device=dev)
+        ops.score_topk(ue, ie, hist, 1e-6, K, id_offset=U, hint=h0, hint_valid=False)
+        base = dict(hint_valid=True)
+    env = {k: os.environ.get(k) for k in ("CHAOREC_SCORE_WS_LIMIT", "CHAOREC_SCORE_PIPELINE")}
+    out = {}
+    try:
+        os.environ["CHAOREC_SCORE_WS_LIMIT"] = str(one // 5)
+        for mode in ("1", "0"):
+            os.environ["CHAOREC_SCORE_PIPELINE"] = mode
+            st = {}
+            kw = dict(base)
+            if hinted:
+                kw["hint"] = h0.clone()
+                kw["counters"] = torch.zeros(4, dtype=torch.int32, device=dev)
+            i_, v_ = ops.score_topk(ue, ie, hist, 1e-6, K, id_offset=U, stats=st, **kw)
+            torch.cuda.synchronize()
+            out[mode] = (i_, v_, st, kw.get("hint"), kw.get("counters"))
+    finally:
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    p, s = out["1"], out["0"]
+    assert p[2]["user_chunks"] >= 5 and p[2]["pipelined"] and not s[2]["pipelined"]
+    assert torch.equal(p[0], s[0]) and torch.equal(p[1], s[1])
+    assert {k: v for k, v in p[2].items() if k != "pipelined"} == {k: v for k, v in s[2].items() if k != "pipelined"}
+    if hinted:
+        assert torch.equal(p[3], s[3]) and torch.equal(p[4], s[4])
+    rows = np.r_[0:40, U // 2:U // 2 + 40, U - 40:U]
+    hr = rowptr.cpu().numpy()
+    sub_ptr = np.zeros(len(rows) + 1, np.int64)
+    sub_col = []
+    for n, r in enumerate(rows):
+        sub_col.append(col[hr[r]:hr[r + 1]].cpu().numpy())
+        sub_ptr[n + 1] = sub_ptr[n] + len(sub_col[-1])
+    want_i, want_v = oracle.score_topk(ue[rows].cpu().numpy(), ie.cpu().numpy(), (sub_ptr, np.concatenate(sub_col)), 1e-6, K, U)
+    assert np.array_equal(p[0][rows].cpu().numpy(), want_i) and np.array_equal(p[1][rows].cpu().numpy(), want_v)
