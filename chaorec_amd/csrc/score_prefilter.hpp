@@ -320,14 +320,20 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
   float n2;
   load_user_frags<D>(bu, n2, P.user_emb, u, u_ok, h);
   n2 += __shfl_xor(n2, 32, 64);
-  // user side of the bound k-step: (0, -c||u||): with the items' (1, ||i_j||) the accumulator becomes the lower
-  // bound w_j = s~_j - e~_uj, which is what the threshold is estimated on
+  // What the threshold is estimated on.  Short item ranges (no PRUNE: a few thousand tiles, rank target ~2.5 K): the lower
+  // bounds w_j = s~_j - e~_uj -- the user side of the bound k-step is (0, -c||u||) against the items' (1, ||i_j||) -- whose
+  // margin keeps users from ending with fewer than K candidates (trained sports tables, cold call: 1 user on the exact
+  // route against 5 with the plain scores).  Long ranges (PRUNE; rank target >= 6 K): the bf16 scores s~_j themselves, one
+  // MFMA per tile less -- there the lower bound put TWO error bands of candidates above the threshold (the sampler's and
+  // the sweep's) where one is needed: configs[4] whole 462 -> 403 candidates per user, 6115 -> 778 users with overflowing
+  // lists, the call 5.01 -> 4.83 s.
   Frag16 fw;
   fw.u = make_uint4(h == 0 ? (((__float_as_uint(bf16_ceil_pos(kBf16ErrCoef * sqrtf(n2) + 1e-30f)) >> 16) | 0x8000u) << 16) : 0u,
                     0u, 0u, 0u);
   const bf16x8 bw = fw.v;
-  auto tile_w = [&](const uint4 (&a)[D / 16 + 1]) __attribute__((always_inline)) {
+  auto tile_w = [&](const uint4 (&a)[D / 16 + 1]) __attribute__((always_inline)) -> f32x16 {
     f32x16 acc = tile_scores_bf16<D>(a, bu);
+    if constexpr (PRUNE) return acc;
     Frag16 fa;
     fa.u = a[D / 16];
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bw, acc, 0, 0, 0);

@@ -44,11 +44,16 @@ def test_score_topk_overflowing_users_get_a_raised_threshold(dev, oracle, D):
     tiles = np.arange(I) // 32
     pool = np.flatnonzero(tiles % 4 != 0)
     hot = rng.choice(pool, 6000, replace=False)
-    ie[hot, :D // 2] = np.abs(rng.standard_normal((6000, D // 2))).astype(np.float32) * 2
-    ie[hot, D // 2:] = 0
-    ue[0::3, :D // 2] = 0                                 # a third of the users do not see the hot items at all
-    ue[1::3] = np.abs(ue[1::3])
-    ue[2::3, :D // 2] = np.abs(ue[2::3, :D // 2])
+    # the hot items have the cold items' NORM (the sweep's error band is c ||u|| max ||i||: one bound for the table) but
+    # share a direction v; two thirds of the users have a large component along v and score them far above everything else
+    v = rng.standard_normal(D).astype(np.float32)
+    v /= np.linalg.norm(v)
+    cold_norm = float(np.linalg.norm(ie, axis=1).mean())
+    hd = v[None, :] * rng.uniform(0.6, 1.0, (6000, 1)).astype(np.float32) + rng.standard_normal((6000, D)).astype(np.float32) * 0.05
+    ie[hot] = (hd / np.linalg.norm(hd, axis=1, keepdims=True) * cold_norm).astype(np.float32)
+    ue -= (ue @ v)[:, None] * v[None, :]                  # nobody sees the hot items ...
+    ue[1::3] += 2.0 * v[None, :]                          # ... except these
+    ue[2::3] += 1.0 * v[None, :]
     rp, cl = _hist_random(U, I, 30, seed=D)
     rows = [cl[rp[u]:rp[u + 1]] for u in range(U)]
     for u in range(1, U, 6):                              # some of the hot items are in the history of users that see them
@@ -196,3 +201,41 @@ def test_score_topk_pipelined_user_ranges_equal_the_serial_ranges(dev, oracle, h
         sub_ptr[n + 1] = sub_ptr[n] + len(sub_col[-1])
     want_i, want_v = oracle.score_topk(ue[rows].cpu().numpy(), ie.cpu().numpy(), (sub_ptr, np.concatenate(sub_col)), 1e-6, K, U)
     assert np.array_equal(p[0][rows].cpu().numpy(), want_i) and np.array_equal(p[1][rows].cpu().numpy(), want_v)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_score_topk_scaled_thresholds_edge_cases(dev, oracle, D):
+    """The sweep scales a user's fragments by 1 / |theta_u| (theta_u = T_u - c ||u|| max ||i||) and compares against the
+    MFMA's inline constant: negative thresholds (every score of a user negative: the flipped-sign lanes), zero rows, rows
+    and thresholds at the ends of the float range, thresholds that are garbage (0, +-tiny, +-huge, NaN, +-inf) must all
+    end in the oracle's top-K -- a threshold only ever changes the work."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(D)
+    U, I, K = 160, 9000, 50
+    ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
+    ie[:, 0] = np.abs(ie[:, 0]) + 1.0
+    ue[0:32, 0] = -3.0                  # all scores negative: T_u < 0
+    ue[32:40] = 0.0                     # zero rows: every score 0, ties to the lowest index
+    ue[40:48] *= 1e-18                  # tiny rows
+    ue[48:56] *= 1e12                   # huge rows
+    ue[56:64, 0] = 3.0                  # all scores positive and far from 0
+    hist = _hist_random(U, I, 20, seed=D)
+    want_i, want_v = oracle.score_topk(ue, ie, hist, 1e-6, K, U)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    due, die = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
+    hint = torch.empty(U, device=dev)
+    got_i, got_v = ops.score_topk(due, die, dh, 1e-6, K, id_offset=U, hint=hint, hint_valid=False)
+    assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i)
+    good = hint.clone()
+    st = {}
+    got_i, got_v = ops.score_topk(due, die, dh, 1e-6, K, id_offset=U, hint=hint, hint_valid=True, stats=st)
+    assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i)
+    assert st["fallback_users"] <= 16, st               # carried thresholds certify (nearly) everybody, negative ones too
+    junk = torch.tensor([0.0, -0.0, 1e-38, -1e-38, 1e-30, -1e-30, 1e30, -1e30, 3e38, -3e38, float("nan"), float("inf"),
+                         float("-inf"), 1.0, -1.0, 1e-3], device=dev)
+    for shift in range(3):
+        hint = good.clone()
+        hint[shift::3] = junk[(torch.arange(len(hint[shift::3]), device=dev) + shift) % len(junk)]
+        got_i, got_v = ops.score_topk(due, die, dh, 1e-6, K, id_offset=U, hint=hint, hint_valid=True)
+        assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i), shift
