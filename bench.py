@@ -349,6 +349,55 @@ def time_spmm_chain(calls, min_pass_ms=10.0, passes=5):
     return float(np.median(per_launch)), tot_bytes, tot_comp
 
 
+def light_step_accounting(ops, stepper, csr, U, I, D, L, edges_dev, hist, expand_n1, times_ms, names, whole_ms):
+    """Every SpMM-family launch of ONE light step (optim.FusedLightGCNStep, large graphs) with the work it PERFORMS: rows
+    computed, source rows gathered (= directed-edge messages formed), algorithmic bytes and their share of the 8 TB/s
+    HBM peak -- for the batch the step's buffers hold (one real batch: R0 = its 3 B rows, N1 = R0 and its neighbours).
+    Algorithmic bytes extend SURVEY 8(d)'s no-reuse CSR model to partial launches: per entry READ 8 B (col, val), per
+    source row GATHERED 4 D, per row WRITTEN 4 D + 8 (the row and its pointer); the Adam epilogue adds eight passes over
+    the table (z = G read and cleared; parameter, both moments read and written); the layer-mean epilogue L + 1 term
+    reads per listed row.  The graph is symmetric, so the entries of a gated launch whose SOURCE is flagged are counted
+    as the flagged rows' degrees."""
+    N, nnz = csr.n_rows, csr.nnz
+    B = stepper.B if hasattr(stepper, "B") else 1024
+    ops.batch_rows(stepper.ids, stepper.bits[0], U, stepper._list0, stepper._list0_n, edges=edges_dev, hist=hist,
+                   num_user=U, num_item=I, seed=4242, step=7)
+    expand_n1()
+    torch.cuda.synchronize()
+    deg = (csr.rowptr[1:] - csr.rowptr[:-1]).to(torch.int64)
+    r0 = stepper._list0[:int(stepper._list0_n.item())].to(torch.int64)
+    n1 = stepper._row_list[:int(stepper._list_n.item())].to(torch.int64)
+    n_r0, n_n1 = int(r0.numel()), int(n1.numel())
+    deg_r0, deg_n1 = int(deg[r0].sum().item()), int(deg[n1].sum().item())
+    row, ent, src = 4 * D + 8, 8, 4 * D
+    dense = nnz * (ent + src) + N * row
+    per = [("forward layer 1, every row (dense plain launch)", times_ms["dense"], dense, N, nnz)]
+    for name, ms in zip(names, times_ms["sparse"]):
+        if name.startswith("forward layer L-1"):
+            per.append((name, ms, deg_n1 * (ent + src) + n_n1 * row, n_n1, deg_n1))
+        elif name.startswith("forward layer L over R0"):
+            per.append((name, ms, deg_r0 * (ent + src) + n_r0 * (row + (L + 1) * 4 * D), n_r0, deg_r0))
+        elif name.startswith("backward propagate 1 over N1"):
+            per.append((name, ms, deg_n1 * ent + deg_r0 * src + n_n1 * row + n_r0 * 4 * D, n_n1, deg_r0))
+        else:                                   # every row written, the gathers gated by N1's bitmap
+            per.append((name, ms, nnz * ent + deg_n1 * src + N * row + n_r0 * 4 * D, N, deg_n1))
+    per.append(("backward propagate 3, every row, Adam epilogue (dense launch + 8 table passes)", times_ms["adam"],
+                dense + 8 * N * 4 * D, N, nnz))
+    out = [{"launch": n, "us": ms * 1e3, "rows_computed": rows, "source_rows_gathered": g, "algorithmic_bytes": float(by),
+            "GBps": by / (ms * 1e-3) / 1e9, "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS} for n, ms, by, rows, g in per]
+    worst = min(out, key=lambda o: o["frac"])
+    total_us = sum(o["us"] for o in out)
+    return {"launches": out, "sum_us": total_us, "replayed_together_us": whole_ms * 1e3,
+            "sum_over_replayed_together": total_us / (whole_ms * 1e3),
+            "messages_gathered_per_step": int(sum(o["source_rows_gathered"] for o in out)),
+            "frontier": {"R0_rows": n_r0, "N1_rows": n_n1, "graph_rows": N, "R0_entries": deg_r0, "N1_entries": deg_n1,
+                         "graph_entries": nnz},
+            "lowest_frac": {"launch": worst["launch"], "frac": worst["frac"]},
+            "note": "each launch timed alone as a replayed one-launch hipGraph over the buffers one real batch leaves (R0, N1 "
+                    "re-made here from the sampler's batch of seed 4242 / step 7); `replayed_together_us` is the six in the "
+                    "step's order as ONE graph"}
+
+
 def spmm_kernel_name(D, adam=False, rowsparse=False):
     """<LPR, CPL, ADAM, SP> as rocprofv3 prints the instantiation."""
     d4, lpr = D // 4, 1
@@ -482,6 +531,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         b0, b1, fin, G = (torch.empty_like(x0) for _ in range(4))
         G.zero_()
     use_mean = L <= ops.mean_terms_limit(D)
+    adam_call = None
     plain, whole, sparse_calls, src = [], [], [], x0
     xs = [x0]
     # The fused step runs some of its propagates over ROW LISTS / with gated gathers (optim.FusedLightGCNStep: the batch
@@ -556,8 +606,9 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     if fused and D <= 256:                           # the last backward propagate with the Adam epilogue, on copies
         pc, mc, vc = x0.clone(), torch.zeros_like(x0), torch.zeros_like(x0)
         bc = torch.tensor([0.1, 0.0316], device=dev)
-        whole.append((lambda: ops.spmm_adam_raw(csr, g, pc, mc, vc, bc, 1e-3, (0.9, 0.999), 1e-8, 0.0, alpha=alpha, z=G,
-                                                beta=w, clear_z=False), csr, D))
+        adam_call = (lambda: ops.spmm_adam_raw(csr, g, pc, mc, vc, bc, 1e-3, (0.9, 0.999), 1e-8, 0.0, alpha=alpha, z=G,
+                                               beta=w, clear_z=False), csr, D)
+        whole.append(adam_call)
         n_epilogue += 1
     heavy_graph = csr.nnz > 50_000_000
     avg_spmm_ms, model_bytes, compulsory = time_spmm_chain(plain, passes=3 if heavy_graph else 5)
@@ -565,9 +616,15 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     whole_ms *= len(whole)                           # all SpMM-family launches of ONE step, boundaries included
     n_plain, n_whole = len(plain), len(whole)
     sparse_ms = None
+    light_launches = None
     if sparse_calls:
         sparse_each = [time_spmm_chain([c], passes=3 if heavy_graph else 5)[0] for _, c in sparse_calls]
         sparse_ms = float(np.mean(sparse_each))
+        if light and adam_call is not None:
+            light_launches = light_step_accounting(
+                ops, stepper, csr, U, I, D, L, edges_dev, model.hist, expand_n1,
+                times_ms=dict(dense=avg_spmm_ms, sparse=sparse_each, adam=time_spmm_chain([adam_call], passes=3)[0]),
+                names=[n for n, _ in sparse_calls], whole_ms=whole_ms)
         G.zero_()                                    # (the step's contract: all-zero between steps, bitmaps clear)
         stepper._bits_all.zero_()
     del b0, b1, fin, G, plain, whole
@@ -614,6 +671,8 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                     "to be written, as the ordinary launch with its gathers gated by the source's bitmap "
                     "(chaorec_spmm_csr_rowsparse_f32) -- the same sums bit for bit; timed over the G, bitmaps and lists one real batch "
                     "left"}
+    if light_launches is not None:
+        roofline["light_step_launches"] = light_launches
     if traffic:
         roofline["traffic_GBps"] = traffic / (avg_spmm_ms * 1e-3) / 1e9
     if kernel_only_us:
@@ -648,6 +707,29 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         torch.cuda.synchronize()
         return float(np.median([s.elapsed_time(e) for s, e in ev]))
 
+    def sweep_alone(ue, ie):
+        """pack + the bf16 sweep over all users of one workspace-sized user range, timed alone: the FRONT phase of a call
+        with carried thresholds (chaorec_score_topk_hinted_f32, CHAOREC_SCORE_FRONT), the thresholds being those a cold
+        call over the same range just left.  -> {users, ms, TFLOP/s, frac} or None where the call takes no prefilter."""
+        from chaorec_amd import _lib
+        lib = _lib.load()
+        u = min(U, 524288)
+        if D not in (64, 128) or I < 4096 or lib.chaorec_score_topk_workspace_bytes(u, I, 50, D) > (24 << 30):
+            return None
+        sub, hsub = ue[:u].contiguous(), (model.hist[0][:u + 1], model.hist[1])
+        hint = torch.empty(u, dtype=torch.float32, device=dev)
+        ops.score_topk(sub, ie, hsub, 1e-6, 50, id_offset=U, hint=hint, hint_valid=False)
+        nb = lib.chaorec_score_topk_workspace_bytes(u, I, 50, D)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        idx = torch.empty((u, 50), dtype=torch.int64, device=dev)
+        val = torch.empty((u, 50), dtype=torch.float32, device=dev)
+        ms = time_calls(lambda: ops._score_call(lib, sub, ie, hsub, 1e-6, 50, U, 0, hint, True, 110, False, None, idx, val, ws,
+                                                nb, phase=ops.SCORE_FRONT), 3 if heavy else 5)
+        tf = 2.0 * u * I * D / (ms * 1e-3) / 1e12
+        return {"users": u, "ms": ms, "TFLOPs": tf, "frac": tf / BF16_MFMA_PEAK_TFLOPS,
+                "what": "pack + score_sweep_bf16_kernel over this many users (thresholds carried from a cold call on the same "
+                        "tables), the call's FRONT phase timed alone with HIP events"}
+
     def time_ranklist(with_steady):
         res = model.result.detach()
         ue, ie = res[:U], res[U:U + I]
@@ -656,6 +738,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             out["cold_ms"] = time_calls(lambda: ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U), reps_rank)
             ops.score_topk(ue, ie, model.hist, 1e-6, 50, id_offset=U, stats=st)
             out["cold_st"] = st
+            out["sweep_alone"] = sweep_alone(ue, ie)
             if with_steady:
                 state = ranking.state_of(model)
                 model.gene_ranklist(to_cpu=False)            # the run's first evaluation: leaves thresholds behind
@@ -714,11 +797,19 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     early_ms, early_st = early["cold_ms"], early["cold_st"]
     st, host_ms = rk.get("steady_st", rk["cold_st"]), rk["host_ms"]
     tf = 2.0 * U * I * D / (score_ms * 1e-3) / 1e12
+    performed = None
+    if light_launches is not None:
+        performed = {"messages_gathered_per_step": light_launches["messages_gathered_per_step"],
+                     "value_performed": light_launches["messages_gathered_per_step"] / (dt / steps),
+                     "what": "`value` counts the REFERENCE step's 2 L E_dir directed-edge messages per step (the work of "
+                             "Model/LightGCN.py's step that this step replaces, bit for bit); value_performed counts the source "
+                             "rows a light step actually gathers in its six SpMM-family launches"}
     return dict(dataset=dataset, data=data_kind, U=U, I=I, E=E, e_dir=e_dir, D=D, L=L, B=B, ms_per_step=ms_per_step,
                 value=msgs_per_step / (dt / steps), msgs_per_step=msgs_per_step, loss_mean=loss_mean, launch=launch,
-                roofline=roofline, score_ms=score_ms, score_state=state, early_ms=early_ms, early_st=early_st,
+                performed=performed, roofline=roofline, score_ms=score_ms, score_state=state, early_ms=early_ms, early_st=early_st,
                 cold_ms=rk["cold_ms"], cold_st=rk["cold_st"], steady="steady_ms" in rk,
-                score_st=st, score_tf=tf, host_rank_ms=host_ms, edges=edges, reg=reg, table_mb=table_mb,
+                score_st=st, score_tf=tf, sweep_alone=rk.get("sweep_alone") or early.get("sweep_alone"),
+                host_rank_ms=host_ms, edges=edges, reg=reg, table_mb=table_mb,
                 build_s=build_s, blocks_ms_per_step=[b / steps * 1e3 for b in blocks], forward=forward_note)
 
 
@@ -726,6 +817,7 @@ def scoring_roofline(r):
     return {"bound": "mfma", "kernel": f"score_sweep_bf16_kernel<{r['D']},{3 if r['D'] <= 64 else 2}> (+ pack, sample, select/re-score)",
             "achieved": r["score_tf"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": r["score_tf"] / BF16_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": r["score_tf"] / F32_MFMA_PEAK_TFLOPS,
+            "sweep_only_frac": (r.get("sweep_alone") or {}).get("frac"), "sweep_alone": r.get("sweep_alone"),
             "prefilter": r["score_st"],
             "note": "2*U*I*D over the whole gene_ranklist call.  The [U,I] sweep runs on the bf16 MFMA pipe "
                     "(v_mfma_f32_32x32x16_bf16, 2.5 PF dense peak) as a prefilter with a proven error bound, the top-K "
@@ -778,6 +870,7 @@ def main_single(args, dev):
                    "parallelism": "single GPU", "host_build_seconds": r["build_s"]},
         "roofline": r["roofline"], "roofline_scoring": scoring_roofline(r), "loss_mean": r["loss_mean"],
         **({"forward": r["forward"]} if r.get("forward") else {}),
+        **(r["performed"] if r.get("performed") else {}),
     }
     edges, reg = r["edges"], r["reg"]
     # --- the HBM-bound regime in the same run: one GPU's share of BASELINE configs[4] -----------------------------
@@ -796,6 +889,7 @@ def main_single(args, dev):
             "gene_ranklist_ms_cold": h["cold_ms"],
             "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"],
             **({"forward": h["forward"]} if h.get("forward") else {}),
+            **(h["performed"] if h.get("performed") else {}),
         }
         del h
         torch.cuda.empty_cache()
@@ -811,6 +905,7 @@ def main_single(args, dev):
                 "gene_ranklist_ms_cold": f["cold_ms"], "users_scored_per_s_cold": f["U"] / (f["cold_ms"] * 1e-3),
                 "roofline_scoring": scoring_roofline(f), "loss_mean": f["loss_mean"],
                 **({"forward": f["forward"]} if f.get("forward") else {}),
+                **(f["performed"] if f.get("performed") else {}),
             }
             del f
             torch.cuda.empty_cache()
@@ -1252,6 +1347,7 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
             torch.cuda.empty_cache()
     finished.set()
     dist.barrier()
+    cdist.destroy_side_groups()
     dist.destroy_process_group()
     cdist.P2PExchange.forget_all()
     if rank == 0:
@@ -1457,13 +1553,29 @@ def flush_c_stdout():
         pass
 
 
-def visible_gpu_count():
-    """Devices this process could use, WITHOUT initialising the GPU runtime (the launcher must not touch it: it starts
-    children).  torch.cuda.device_count() is a device-file / NVML-style count on this image; any failure means 0."""
+def visible_gpu_count(sysfs_root="/sys/class/kfd/kfd/topology/nodes"):
+    """Devices this process could use, WITHOUT touching the GPU runtime (the launcher must not initialise it: it starts
+    children, and torch.cuda.device_count() goes through hipGetDeviceCount -- an HSA init -- on ROCm).  The kernel driver's
+    own topology: one directory per node under /sys/class/kfd/kfd/topology/nodes, a GPU is a node whose `properties` show
+    simd_count > 0 (CPUs have 0).  A visibility list in the environment (ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES) caps the
+    count.  No readable topology (a box without the driver, this build container) means 0."""
+    n = 0
     try:
-        return int(torch.cuda.device_count())
-    except Exception:      # noqa: BLE001
+        for node in sorted(os.listdir(sysfs_root)):
+            try:
+                with open(os.path.join(sysfs_root, node, "properties")) as fh:
+                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            except OSError:
+                continue                      # (a node this user may not read: not a device it can use)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
         return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def _free_port():

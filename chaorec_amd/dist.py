@@ -255,6 +255,71 @@ def settle_before_capture():
             _time.sleep(WATCHDOG_SETTLE_S)
 
 
+CAPTURE_ATTEMPTS = int(_os.environ.get("CHAOREC_CAPTURE_ATTEMPTS", "3"))
+CAPTURE_LOG = []          # (what, attempts it took) of every capture that went through capture_with_retry
+
+
+def _is_capture_race(exc):
+    """The watchdog race of settle_before_capture(): hipErrorCapturedEvent / hipErrorStreamCaptureInvalidated and what torch
+    makes of them ("operation failed due to a previous error during capture", "... when stream is capturing")."""
+    msg = str(exc).lower()
+    return "captur" in msg
+
+
+def capture_with_retry(capture, reset, what="step", attempts=None):
+    """settle_before_capture() lowers the odds of RCCL's watchdog polling an eager collective's event while its stream is
+    being captured; it cannot exclude it (the watchdog may still hold events under load).  A capture lost to that race is
+    simply taken again: `capture()` (which settles, then captures) up to `attempts` times, `reset()` in between (device
+    idle, state restored -- a failed capture has run nothing, but the caller's eager warm-up may have).  Any other error, or
+    the last attempt's, propagates.  -> the number of attempts it took (also appended to CAPTURE_LOG)."""
+    attempts = CAPTURE_ATTEMPTS if attempts is None else attempts
+    for k in range(attempts):
+        try:
+            capture()
+            CAPTURE_LOG.append((what, k + 1))
+            return k + 1
+        except RuntimeError as exc:
+            if k + 1 >= attempts or not _is_capture_race(exc):
+                raise
+            import sys as _sys
+            print(f"[chaorec_amd.dist] capture of {what} lost to the watchdog race ({str(exc)[:120]}): attempt {k + 2} of "
+                  f"{attempts}", file=_sys.stderr, flush=True)
+            reset()
+    return attempts
+
+
+_SIDE_GROUPS = {}         # id of the main group (None: the default group) -> (the main group object, its side communicator)
+
+
+def side_group(group=None):
+    """A second communicator over the same ranks as `group`, for collectives that run CONCURRENTLY with the group's own (a
+    model whose branches compute on two streams: two collectives of one communicator must never be in flight together).
+    Created once per group and reused by every model built on it -- dist.new_group is collective over the WHOLE default
+    group (every rank of the job must call this at the same point, ranks outside `group` included) and a communicator is
+    never given back until destroy_side_groups(); building one per model leaked one per bench loop / test.  No process
+    group, or a single rank without forced collectives: `group` itself."""
+    if not (dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES)):
+        return group
+    key = id(group) if group is not None else None
+    held = _SIDE_GROUPS.get(key)
+    if held is not None and held[0] is group:
+        return held[1]
+    ranks = dist.get_process_group_ranks(group) if group is not None else None
+    side = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+    _SIDE_GROUPS[key] = (group, side)
+    return side
+
+
+def destroy_side_groups():
+    """Give the side communicators back (call before dist.destroy_process_group(), next to P2PExchange.forget_all())."""
+    for _, side in _SIDE_GROUPS.values():
+        try:
+            dist.destroy_process_group(side)
+        except Exception:      # noqa: BLE001 -- the default group may already be gone
+            pass
+    _SIDE_GROUPS.clear()
+
+
 class _PendingStream:
     """Handle of an exchange made of plain launches on a side stream (the hand-written p2p exchange): wait() makes the
     compute stream depend on everything the side stream was given so far."""
@@ -665,6 +730,15 @@ def calibrate_exchange(n_rows, D, device, group=None, captured=False, reps=3, ca
         best = min(good, key=good.get)
         _AUTO_BIG_CHOICE[rows * D] = best
         table["chosen"] = best
+        failed = [m for m, e in table.items() if isinstance(e, dict) and not e.get("ok")]
+        table["why_chosen"] = ("fastest of the modes that passed every check on this node (max over ranks of the median of %d "
+                               "timed exchanges of %d x %d floats): " % (reps, rows, D)
+                               + " < ".join("%s %.3f ms" % (m, good[m]) for m in sorted(good, key=good.get))
+                               + ("; failed / vetoed: " + ", ".join("%s (%s)" % (m, table[m].get("why", "?")) for m in failed)
+                                  if failed else ""))
+    else:
+        table["chosen"] = None
+        table["why_chosen"] = "no candidate passed: `auto` stays on the plain all-reduce"
     CALIBRATION[rows * D] = dict(table, rows=rows, D=D, bytes=rows * D * 4, captured=bool(captured and on_gpu))
     return table
 
@@ -957,6 +1031,7 @@ class FusedShardedLightGCNStep:
         self.graph_full = None
         self._compact = {}                   # (buffer, cap) -> ([cap, D] packed rows, bitmap prefix): _exchange_frontier
         self._cap0 = min(I, 2 * self.B * self.world)      # the batch items of all ranks: a static bound
+        self._frontier_overflow = torch.zeros(1, dtype=torch.int32, device=dev)    # (sticky: check_frontier())
         if self.sparse_bwd:
             wu, wi = (U + 31) // 32, (I + 31) // 32
             self._wu = wu
@@ -1005,26 +1080,44 @@ class FusedShardedLightGCNStep:
                     torch.cuda.current_stream().wait_stream(s)
                     torch.cuda.synchronize()
                     self._restore_state(saved)
-                settle_before_capture()                 # (every eager launch is behind us: captures only from here on)
-                self.graph1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph1, capture_error_mode=capture_mode()):
-                    self._launch()
-                self.graph = self.graph1
-                if self.light:
-                    self.graph_full = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph_full, capture_error_mode=capture_mode()):
-                        self._launch(light=False)
-                if self.steps_per_replay > 1:
-                    self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
-                        for _ in range(self.steps_per_replay):
-                            self._launch()
+                def capture_all():                      # (every eager launch is behind us: captures only from here on)
+                    settle_before_capture()
+                    self.graph1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph1, capture_error_mode=capture_mode()):
+                        self._launch()
+                    self.graph = self.graph1
+                    if self.light:
+                        self.graph_full = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.graph_full, capture_error_mode=capture_mode()):
+                            self._launch(light=False)
+                    if self.steps_per_replay > 1:
+                        self.graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
+                            for _ in range(self.steps_per_replay):
+                                self._launch()
+
+                def reset():
+                    self.graph = self.graph1 = self.graph_full = None
+                    torch.cuda.synchronize()
+                    self._restore_state(saved)
+
+                self.capture_attempts = capture_with_retry(capture_all, reset, what="FusedShardedLightGCNStep")
                 for gph in {id(g_): g_ for g_ in (self.graph1, self.graph, self.graph_full) if g_ is not None}.values():
                     gph.replay()
                 torch.cuda.synchronize()
             finally:
                 torch.cuda.synchronize()
                 self._restore_state(saved)
+
+    def check_frontier(self):
+        """Raise if a compact frontier exchange ever saw more flagged rows than its static capacity (the pack kernel drops
+        the rows past it: the step would have trained on an incomplete sum).  Costs a sync: run() calls it once at its
+        end, tests and the bench after their steps."""
+        over = int(self._frontier_overflow.item())
+        if over > 0:
+            raise RuntimeError(f"FusedShardedLightGCNStep: a compact frontier exchange overflowed its capacity by {over} rows "
+                               f"(capacity 2 * batch * world = {self._cap0}): the batch size changed, or a row bitmap was not "
+                               f"cleared after an aborted replay")
 
     def _counters(self):
         return [t for t in (self.step_dev, self.loss_accum, self.optimizer._step_dev) if t is not None]
@@ -1075,7 +1168,7 @@ class FusedShardedLightGCNStep:
             self._compact[key] = (torch.zeros((int(cap), self.D), dtype=torch.float32, device=buf.device),
                                   torch.zeros((I + 31) // 32 + 1, dtype=torch.int32, device=buf.device))
         compact, prefix = self._compact[key]
-        K.frontier_pack(buf[:I], bits, prefix, compact)
+        K.frontier_pack(buf[:I], bits, prefix, compact, overflow=self._frontier_overflow)
         _count(compact)
         MODES_USED.add("compact-allreduce")
         STATS["frontier_exchanges"] = STATS.get("frontier_exchanges", 0) + 1
@@ -1326,6 +1419,8 @@ class FusedShardedLightGCNStep:
             self(single=True)
         if tail:
             self(full_result=True)
+        if self._compact:                          # (compact frontier exchanges ran: one sync per run() for their overflow flag)
+            self.check_frontier()
         return self.static_loss
 
 
@@ -1567,10 +1662,7 @@ class ShardedMMGCN(nn.Module):
         # communicator must never be in flight at the same time (c10d runs a synchronous collective on the caller's
         # stream: two streams = two concurrent kernels on the communicator's buffers; seen once in ~10 runs as a step
         # with slightly wrong gradients).  Collective: every rank builds its ShardedMMGCN at the same point.
-        self.group_v = group
-        if dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE_COLLECTIVES):
-            ranks = dist.get_process_group_ranks(group) if group is not None else None
-            self.group_v = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+        self.group_v = side_group(group)
         op_v = self._graph_op_v = op if self.group_v is group else ShardedGraph(shard, spmm_fn, self.group_v)
 
         def take(t):       # [U + I, d] or [U, d] global rows -> this shard's layout

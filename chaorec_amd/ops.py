@@ -173,15 +173,25 @@ def rows_mean_by_bits(terms, w, out, bits):
     return out
 
 
-def frontier_pack(src, bits, prefix, compact):
+def frontier_pack(src, bits, prefix, compact, overflow=None):
     """compact[k] = src[flagged row number k, bitmap order] (chaorec_frontier_pack_f32); prefix: int32 [n_words + 1] scratch
-    (prefix[-1] = the number of flagged rows afterwards); rows of compact past them are zeroed."""
+    of exactly that length (prefix[-1] = the number of flagged rows afterwards); rows of compact past them are zeroed.
+    More flagged rows than compact holds: an error when called eagerly (costs a sync), or -- `overflow`: an int32 [1] device
+    tensor -- recorded there (capturable: one small launch)."""
     _need_cuda(src, bits, prefix, compact)
     if src.dtype != torch.float32 or not src.is_contiguous() or not compact.is_contiguous() or compact.shape[1] != src.shape[1] \
-            or prefix.numel() < (src.shape[0] + 31) // 32 + 1:
+            or prefix.numel() != (src.shape[0] + 31) // 32 + 1:
         raise ValueError("frontier_pack: contiguous float32 [n, D] / [cap, D] buffers, prefix of n_words + 1 ints")
     _lib.check(_lib.load().chaorec_frontier_pack_f32(_ptr(src), src.shape[0], src.shape[1], _ptr(bits), _ptr(prefix), _ptr(compact),
                                                      compact.shape[0], _stream()), "chaorec_frontier_pack_f32")
+    if overflow is not None:
+        # sticky, on the device: by how many rows a frontier ever exceeded the compact buffer (the kernel drops those rows;
+        # a caller that sized `cap` by a static bound checks this after the fact -- FusedShardedLightGCNStep.check_frontier)
+        torch.maximum(overflow, prefix[-1:] - compact.shape[0], out=overflow)
+    elif not torch.cuda.is_current_stream_capturing():
+        total = int(prefix[(src.shape[0] + 31) // 32])
+        if total > compact.shape[0]:
+            raise RuntimeError(f"frontier_pack: {total} flagged rows do not fit the compact buffer's {compact.shape[0]}")
     return compact
 
 
@@ -438,8 +448,9 @@ class _BPRMulti(torch.autograd.Function):
     weighted sum, and one backward launch (chaorec_bpr_multi_*_f32: 4 launches per step instead of 13)."""
 
     @staticmethod
-    def forward(ctx, tab_u, users, variant, wvec, gathered, *flat):
+    def forward(ctx, tab_u, users, variant, wvec, gathered, tokens, *flat):
         T = len(flat) // 3
+        ctx.tokens = list(tokens) if tokens is not None else [None] * T
         _need_cuda(tab_u, users, wvec, *flat)
         # gathered[k] = (rows, n_table_rows) or None: term k's table is a block of rows gathered from a longer table (the
         # projected batch rows of linear_rows): its backward also scatters the gradient into a [n_table_rows, D] buffer
@@ -497,21 +508,20 @@ class _BPRMulti(torch.autograd.Function):
             arr = lambda ts: (ctypes.c_void_p * T)(*[t.data_ptr() for t in ts])
             g = g.contiguous()
             srows, souts = None, None
-            _SCATTERED.clear()
             if any(gt is not None for gt in gathered):
                 full = [flat[offs[T + 1 + k]:offs[T + 2 + k]].view(gathered[k][1], D) if gathered[k] is not None else None
                         for k in range(T)]
                 parr = lambda ts: (ctypes.c_void_p * T)(*[(t.data_ptr() if t is not None else 0) for t in ts])
                 srows, souts = parr([gt[0] if gt is not None else None for gt in gathered]), parr(full)
-                for k in range(T):
-                    if full[k] is not None:      # handed to the gathering node's backward (ops._LinearRows) by address
-                        _SCATTERED[g_is[k].data_ptr()] = (full[k], gathered[k][0])
+                for k in range(T):           # handed to the gathering node's backward (ops._LinearRows) through ITS token
+                    if full[k] is not None and ctx.tokens[k] is not None:
+                        ctx.tokens[k].put(full[k], gathered[k][0])
             rc = lib.chaorec_bpr_multi_bwd_f32(_ptr(tab_u), _ptr(users), T, arr(tabs), arr(ids[0::2]), arr(ids[1::2]), B, D,
                                                _ptr(coef), _ptr(wvec), _ptr(g), _ptr(g_u), arr(g_is), srows, souts, _stream())
             _lib.check(rc, "chaorec_bpr_multi_bwd_f32")
             for g_i in g_is:
                 grads += [g_i, None, None]
-            return (g_u, None, None, None, None, *grads)
+            return (g_u, None, None, None, None, None, *grads)
         gvec = (g * wvec).contiguous()                   # d total / d loss_k, on the device
         for k in range(T):
             g_i = flat[offs[k + 1]:offs[k + 2]].view_as(tabs[k])
@@ -520,12 +530,30 @@ class _BPRMulti(torch.autograd.Function):
                                          ctypes.c_void_p(gvec.data_ptr() + 4 * k), _ptr(g_u), _ptr(g_i), _stream())
             _lib.check(rc, "chaorec_bpr_bwd_f32")
             grads += [g_i, None, None]
-        return (g_u, None, None, None, None, *grads)
+        return (g_u, None, None, None, None, None, *grads)
 
 
-# gradient block of a gathered term (by address) -> (its rows scattered into [n_table_rows, D], the row list): written by
-# _BPRMulti.backward, consumed by the backward of the node that gathered the rows (_LinearRows)
-_SCATTERED = {}
+class RowScatterToken:
+    """The hand-over between the two autograd nodes around a gathered BPR term: linear_rows() creates one per call, keeps it
+    on its node and attaches it to its output; bpr_loss_multi() passes the tokens of its gathered terms to _BPRMulti, whose
+    backward launch scatters each such term's gradient into a [n_table_rows, D] buffer itself and put()s it here; the
+    gathering node's backward take()s it instead of scattering again.  One producer, one consumer, tied to ONE forward
+    call: no process-wide state, nothing to match by address, and a buffer nobody takes dies with the graph."""
+    __slots__ = ("_held", "puts", "hits")
+
+    def __init__(self):
+        self._held, self.puts, self.hits = None, 0, 0        # (puts / hits: what happened, for tests and debugging)
+
+    def put(self, scattered, rows):
+        self._held = (scattered, rows)
+        self.puts += 1
+
+    def take(self, n_rows, width, rows):
+        held, self._held = self._held, None
+        if held is not None and tuple(held[0].shape) == (n_rows, width) and held[1].data_ptr() == rows.data_ptr():
+            self.hits += 1
+            return held[0]
+        return None
 
 
 class _SplitRows(torch.autograd.Function):
@@ -564,7 +592,10 @@ def bpr_loss_multi(tab_u, users, variant, terms, wvec, gathered=None):
     term's table is linear_rows(table, rows, ...): the backward then scatters that block's gradient into the
     [n_table_rows, D] row gradient itself (one launch less per table and direction, one zero fill for everything)."""
     flat = [t for term in terms for t in term]
-    return _BPRMulti.apply(tab_u, users, int(variant), wvec, gathered, *flat)
+    tokens = None
+    if gathered is not None:
+        tokens = [getattr(term[0], "_chaorec_row_scatter", None) if gt is not None else None for term, gt in zip(terms, gathered)]
+    return _BPRMulti.apply(tab_u, users, int(variant), wvec, gathered, tokens, *flat)
 
 
 class _LossParts:
@@ -1401,8 +1432,9 @@ class _LinearRows(torch.autograd.Function):
     optimizer receives gy (scattered to [I, R]) and W instead; otherwise x.grad is the usual dense tensor."""
 
     @staticmethod
-    def forward(ctx, x, rows, weight, bias):
+    def forward(ctx, x, rows, weight, bias, scatter_token=None):
         sink = getattr(x, "_chaorec_lowrank_sink", None)
+        ctx.scatter_token = scatter_token
         ctx.row_token = None
         if sink is not None and sink.lazy_rows and sink.accepts(x):
             ctx.row_token = sink.catch_up(x, rows)       # lazily updated table: these rows must be current first
@@ -1422,10 +1454,8 @@ class _LinearRows(torch.autograd.Function):
         gy = gy.contiguous()
         gx = None
         if ctx.needs_input_grad[0]:
-            pre = _SCATTERED.pop(gy.data_ptr(), None)
-            if pre is not None and tuple(pre[0].shape) == (x.shape[0], gy.shape[1]) and pre[1].data_ptr() == rows.data_ptr():
-                gy_full = pre[0]                         # (already scattered by the multi-term BPR backward's launch)
-            else:
+            gy_full = ctx.scatter_token.take(x.shape[0], gy.shape[1], rows) if ctx.scatter_token is not None else None
+            if gy_full is None:                          # (else: already scattered by the multi-term BPR backward's launch)
                 gy_full = torch.zeros((x.shape[0], gy.shape[1]), dtype=gy.dtype, device=gy.device)
                 gy_full.index_add_(0, rows, gy)          # an item can sit in the batch more than once
             sink = getattr(x, "_chaorec_lowrank_sink", None)
@@ -1437,12 +1467,16 @@ class _LinearRows(torch.autograd.Function):
                 gx = gemm_raw(gy_full, weight)
         gw = gemm_raw(gy, xg, transA=True) if ctx.needs_input_grad[2] else None
         gb = col_sum(gy) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return gx, None, gw, gb
+        return gx, None, gw, gb, None
 
 
 def linear_rows(x, rows, weight, bias=None):
-    """== linear(x, weight, bias)[rows]"""
-    return _LinearRows.apply(x, rows, weight, bias)
+    """== linear(x, weight, bias)[rows].  The result carries a RowScatterToken (`_chaorec_row_scatter`): a bpr_loss_multi
+    that takes it as a gathered term hands this node the already scattered row gradient through it."""
+    token = RowScatterToken()
+    y = _LinearRows.apply(x, rows, weight, bias, token)
+    y._chaorec_row_scatter = token
+    return y
 
 
 def adam_multi(tensors, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step_dev=None):

@@ -386,10 +386,22 @@ class GraphedTrainStep:
         import torch.distributed as _td
         mode = "thread_local" if (_td.is_available() and _td.is_initialized()) else "global"
         if mode == "thread_local":
-            from .dist import settle_before_capture
-            settle_before_capture()              # (RCCL's watchdog must have retired the warm-up's eager collectives)
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
-            self.static_loss = self._eager(self.static)
+            from .dist import capture_with_retry, settle_before_capture
+
+            def capture():
+                settle_before_capture()          # (RCCL's watchdog must have retired the warm-up's eager collectives)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                    self.static_loss = self._eager(self.static)
+
+            def reset():                         # (a capture that failed has run nothing: only its leftovers go)
+                torch.cuda.synchronize()
+                self.optimizer.zero_grad(set_to_none=True)
+
+            self.capture_attempts = capture_with_retry(capture, reset, what=type(model).__name__ + " train step")
+        else:
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                self.static_loss = self._eager(self.static)
         # the captured forward's output buffer: every replay rewrites it, and model.result must keep pointing at it
         # (an eager step in between -- the short last batch of an epoch -- rebinds model.result to its own tensor)
         plain_attr = not isinstance(getattr(type(model), "result", None), property)   # (a sharded model derives it)
@@ -514,10 +526,7 @@ class FusedLightGCNStep:
         # Same sums bit for bit (the skipped terms are val * (+0)).  bits[0] = R0 (set by the BPR launch), bits[1] = N1.  It pays
         # where the frontier is a part of the graph and costs launches where it is not (sports: N1 is half the graph, N2 all of
         # it), hence by size.  CHAOREC_SPARSE_BACKWARD=0 / 1: off / forced.
-        mode = os.environ.get("CHAOREC_SPARSE_BACKWARD", "auto")
-        wide_ok = L >= 2 and D % 4 == 0 and (D // 4) in (16, 32, 64)
-        self.sparse_bwd = wide_ok and mode != "0" and (mode == "1" or N >= int(os.environ.get("CHAOREC_SPARSE_BACKWARD_MIN_ROWS",
-                                                                                              "400000")))
+        wide_ok, self.sparse_bwd, light_by_size = self.frontier_modes(N, L, D)
         # Light forward.  train_and_evaluate.py:43-48 reads the propagated table (Model/LightGCN.py:95's mean) in the batch's
         # rows R0 only; the other rows of `model.result` are a by-product that nothing looks at before the next evaluation.
         # A LIGHT step therefore draws its batch first (ops.batch_rows: the same triples, flagged and listed), expands R0 to
@@ -528,9 +537,8 @@ class FusedLightGCNStep:
         # -- the same arithmetic for every row it computes, so loss, gradient and updated tables are the full step's bit for
         # bit.  The step BEFORE AN EVALUATION must be a full one (`full_result=True`; run() does it): gene_ranklist reads the
         # whole table of the last training forward (the reference's stale-result quirk Q4).
-        mode_l = os.environ.get("CHAOREC_LIGHT_FORWARD", "auto")
         if light_forward is None:
-            light_forward = self.sparse_bwd and L <= 4 and mode_l != "0"
+            light_forward = light_by_size
         elif light_forward and not (wide_ok and L <= 4):
             raise ValueError("FusedLightGCNStep: the light forward needs 2 <= n_layers <= 4 and D in {64, 128, 256}")
         self.light = bool(light_forward)
@@ -605,6 +613,19 @@ class FusedLightGCNStep:
             self.G.zero_()
             if self.bits is not None:
                 self._bits_all.zero_()
+
+    @staticmethod
+    def frontier_modes(n_rows, n_layers, D):
+        """-> (the shapes the frontier launches are built for, row-sparse backward by size, light forward by size) for a
+        graph of n_rows rows: what __init__ decides when it is not told (CHAOREC_SPARSE_BACKWARD / CHAOREC_LIGHT_FORWARD =
+        auto / 0 / 1; CHAOREC_SPARSE_BACKWARD_MIN_ROWS).  Also for callers that plan around a light step (the training
+        loop picks its replay length so that a light epoch's steps fill whole replays)."""
+        mode = os.environ.get("CHAOREC_SPARSE_BACKWARD", "auto")
+        wide_ok = n_layers >= 2 and D % 4 == 0 and (D // 4) in (16, 32, 64)
+        sparse_bwd = wide_ok and mode != "0" and (mode == "1" or n_rows >= int(os.environ.get("CHAOREC_SPARSE_BACKWARD_MIN_ROWS",
+                                                                                              "400000")))
+        light = sparse_bwd and n_layers <= 4 and os.environ.get("CHAOREC_LIGHT_FORWARD", "auto") != "0"
+        return wide_ok, sparse_bwd, light
 
     @torch.no_grad()
     def _launch(self, j=0, k=1, light=None):

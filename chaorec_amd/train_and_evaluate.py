@@ -114,7 +114,13 @@ def _capture_step(model, train_loader, optimizer, model_name):
         if type(model) is LightGCN and model.n_layers >= 1 and len(optimizer.param_groups) == 1:
             from .optim import FusedLightGCNStep
             acc = torch.zeros(1, dtype=torch.float32, device=train_loader.edges.device)
-            k = next((c for c in (11, 10, 8, 7, 5, 4, 3, 2) if (E // B) % c == 0), 1)
+            # steps per replay: a divisor of the steps that run as whole replays.  With the light forward (by size: large
+            # graphs) FusedLightGCNStep.run(E // B, full_last=True) runs E // B - 1 light steps and one full step, so the
+            # divisor is taken of E // B - 1 (a divisor of E // B left k - 1 steps per epoch to single replays)
+            light = FusedLightGCNStep.frontier_modes(model.num_user + model.num_item, model.n_layers,
+                                                     model.user_embedding.weight.shape[1])[2]
+            n_rep = E // B - 1 if (light and E % B == 0) else E // B
+            k = next((c for c in (11, 10, 8, 7, 5, 4, 3, 2) if n_rep % c == 0), 1)
             g = FusedLightGCNStep(model, optimizer, batch_size=B, edges=train_loader.edges, seed=train_loader.seed,
                                   step_dev=train_loader.step_dev, perm=train_loader.perm, perm_pos=train_loader.perm_pos,
                                   loss_accum=acc, steps_per_replay=k)

@@ -389,11 +389,15 @@ class _OracleStepKernels:
         return None
 
     @classmethod
-    def frontier_pack(cls, src, bits, prefix, compact):
+    def frontier_pack(cls, src, bits, prefix, compact, overflow=None):
         rows = np.nonzero(cls._rows(bits, src.shape[0]))[0]              # (bitmap order: the same on every rank)
-        assert len(rows) <= compact.shape[0]
+        if overflow is not None:                                         # (the device kernel drops the rows past the capacity)
+            overflow[0] = max(int(overflow[0]), len(rows) - compact.shape[0])
+        else:
+            assert len(rows) <= compact.shape[0]
+        keep = rows[:compact.shape[0]]
         compact.zero_()
-        compact[:len(rows)] = src[rows]
+        compact[:len(keep)] = src[keep]
         prefix[-1] = len(rows)
 
     @classmethod

@@ -186,17 +186,21 @@ def test_bpr_multi_backward_scatters_gathered_terms_itself(dev):
         table, w, b = (t.clone().requires_grad_(True) for t in (table0, w0, b0))
         xu, xi = ops.split_rows(x, U)
         proj = ops.linear_rows(table, rows, w, b)
+        token = proj._chaorec_row_scatter
         loss = ops.bpr_loss_multi(xu, users, ops.VARIANT_LOGSIGMOID, [(xi, pos, neg), (proj, idx, idx + B)], wvec,
                                   gathered=[None, (rows, I)] if gathered else None)
         loss.backward()
         torch.cuda.synchronize()
+        # the hand-over went through the gathering node's own token (no process-wide dict): put once by the BPR
+        # backward, taken by linear_rows' backward, nothing left behind
+        assert token.puts == token.hits == (1 if gathered else 0) and token._held is None
         return loss.detach(), x.grad, table.grad, w.grad, b.grad
 
     ref, got = run(False), run(True)
     assert torch.equal(ref[0], got[0])
     for a, c in zip(ref[1:], got[1:]):
         assert torch.allclose(a, c, rtol=0, atol=2e-6 * float(a.abs().max()) + 1e-12)
-    assert float(got[2].abs().sum()) > 0 and not ops._SCATTERED                  # the hand-over was consumed
+    assert float(got[2].abs().sum()) > 0 and not hasattr(ops, "_SCATTERED")
 
 
 def test_fused_step_migrates_existing_adam_moments(dev):
@@ -673,6 +677,14 @@ def test_frontier_helper_launches(dev):
     back = torch.zeros(I, D, device=dev)
     ops.frontier_unpack(back, stray, prefix, compact * 2)
     assert torch.equal(back[rows], 2 * tab[rows]) and float(back[rest].abs().max()) == 0.0
+    # more flagged rows than the compact buffer holds: loud when eager, recorded in a device flag when asked to
+    small = torch.empty((len(want) - 3, D), device=dev)
+    with pytest.raises(RuntimeError, match="do not fit"):
+        ops.frontier_pack(tab, stray, prefix, small)
+    over = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.frontier_pack(tab, stray, prefix, small, overflow=over)
+    ops.frontier_pack(tab, stray, prefix, compact, overflow=over)        # (sticky: a later call that fits does not clear it)
+    assert int(over) == 3 and torch.equal(small, tab[rows][:len(want) - 3])
     # or_words
     parts = torch.stack([bitmap(rng.choice(I, 30, replace=False), I) for _ in range(4)])
     acc = torch.zeros_like(parts[0])

@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     for name, args in re.findall(r"\b(chaorec_\w+)\s*\(([^;{]*?)\)\s*;", plain):
         n_args = 0 if args.strip() in ("", "void") else args.count(",") + 1
         assert len(_lib.SIGNATURES[name][1]) == n_args, f"{name}: ctypes argtypes vs header"
-    assert _lib.load().chaorec_abi_version() == _lib.ABI_VERSION == 12
+    assert _lib.load().chaorec_abi_version() == _lib.ABI_VERSION == 13
     assert _lib.load().chaorec_spmm_rows_per_wave(64) == 4
     assert _lib.load().chaorec_spmm_rows_per_wave(128) == 2
     assert _lib.load().chaorec_score_topk_workspace_bytes(28940, 15207, 50, 64) > 0
@@ -475,3 +475,65 @@ def test_sparse_family_models_start_from_the_reference_state(name):
     assert np.array_equal(dense, ref)
     with pytest.raises(RuntimeError, match="MI355X only"):          # no CPU compute path: the propagate raises
         m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+
+
+def test_capture_retry_takes_a_capture_lost_to_the_watchdog_race_again():
+    """dist.capture_with_retry: a capture that fails with a captured-event error is reset and taken again, any
+    other error -- and the last attempt's -- propagates."""
+    from chaorec_amd import dist as cdist
+    calls = {"capture": 0, "reset": 0}
+
+    def flaky():
+        calls["capture"] += 1
+        if calls["capture"] < 3:
+            raise RuntimeError("HIP error: operation failed due to a previous error during capture")
+
+    n = cdist.capture_with_retry(flaky, lambda: calls.__setitem__("reset", calls["reset"] + 1), what="test", attempts=3)
+    assert n == 3 and calls == {"capture": 3, "reset": 2} and cdist.CAPTURE_LOG[-1] == ("test", 3)
+    calls.update(capture=0, reset=0)
+    with pytest.raises(RuntimeError, match="during capture"):
+        cdist.capture_with_retry(flaky, lambda: None, what="test", attempts=2)
+
+    def broken():
+        raise RuntimeError("out of memory")
+
+    with pytest.raises(RuntimeError, match="out of memory"):
+        cdist.capture_with_retry(broken, lambda: None, what="test")
+
+
+def test_bench_counts_gpus_from_the_kfd_topology(tmp_path, monkeypatch):
+    """bench.visible_gpu_count: the launcher counts devices from /sys/class/kfd/kfd/topology/nodes (a GPU is
+    a node with simd_count > 0) without touching the HIP runtime; visibility lists cap it; no topology = 0."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):          # two CPU sockets, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    (tmp_path / "9").mkdir()                                      # a node without a readable properties file
+    assert bench.visible_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count(str(tmp_path)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count(str(tmp_path)) == 1
+    assert bench.visible_gpu_count(str(tmp_path / "missing")) == 0
+
+
+def test_frontier_modes_by_size_and_the_replay_length_of_a_light_epoch(monkeypatch):
+    """optim.FusedLightGCNStep.frontier_modes: the row-sparse backward / light forward switch on by graph size (and by the
+    environment); the training loop sizes its k-step replays for E // B - 1 steps when an epoch ends in a full step."""
+    from chaorec_amd.optim import FusedLightGCNStep
+    for k in ("CHAOREC_SPARSE_BACKWARD", "CHAOREC_LIGHT_FORWARD", "CHAOREC_SPARSE_BACKWARD_MIN_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    assert FusedLightGCNStep.frontier_modes(44147, 3, 64) == (True, False, False)            # sports: dense
+    assert FusedLightGCNStep.frontier_modes(3_250_000, 3, 128) == (True, True, True)         # the config-5 shard
+    assert FusedLightGCNStep.frontier_modes(3_250_000, 5, 128) == (True, True, False)        # light forward: L <= 4
+    assert FusedLightGCNStep.frontier_modes(3_250_000, 3, 96)[0] is False                    # D / 4 not a lane-group size
+    monkeypatch.setenv("CHAOREC_LIGHT_FORWARD", "0")
+    assert FusedLightGCNStep.frontier_modes(3_250_000, 3, 128) == (True, True, False)
+    monkeypatch.setenv("CHAOREC_SPARSE_BACKWARD", "1")
+    assert FusedLightGCNStep.frontier_modes(1000, 2, 64)[1] is True
