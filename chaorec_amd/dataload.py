@@ -124,6 +124,12 @@ class TrainingDataset(Dataset):
                 break
         if self.model_name in ["MMGCN", "GRCN"]:
             return torch.LongTensor([user, user]), torch.LongTensor([pos_item, neg_item])
+        if self.model_name == "MCLN":               # dataload.py:81-84: the second rejection loop's item
+            while True:
+                int_item = random.randrange(self.num_user, self.num_user + self.num_item)
+                if int_item not in seen:
+                    break
+            return [user, pos_item, neg_item, int_item]
         return [user, pos_item, neg_item]
 
 
@@ -173,8 +179,14 @@ class DeviceBatchSampler:
             e = self.edges[perm[s:s + self.batch_size]]
             users, pos = e[:, 0].contiguous(), e[:, 1].contiguous()
             neg = ops.sample_negatives(self.hist, users, self.num_item, self.seed, self.global_step, self.num_user)
+            second = None
+            if self.model_name == "MCLN":            # dataload.py:81-84,103-104: a second negative per sample
+                second = ops.sample_negatives(self.hist, users, self.num_item, self.seed, self.global_step, self.num_user,
+                                              second=True)
             self.global_step += 1
             if self.model_name in ["MMGCN", "GRCN"]:
                 yield torch.stack((users, users), 1), torch.stack((pos, neg), 1)
+            elif second is not None:
+                yield users, pos, neg, second
             else:
                 yield users, pos, neg

@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import BPRMF, FREEDOM, LayerGCN, LightGCN, MGCN, MMGCN, NCL, NGCF, SelfCF, SimGCL, SLMRec, VBPR, XSimGCL
+from .Model import BPRMF, FREEDOM, LayerGCN, LightGCN, MCLN, MGCN, MMGCN, NCL, NGCF, SelfCF, SimGCL, SLMRec, VBPR, XSimGCL
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
 from .optim import FusedAdam
@@ -63,6 +63,9 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
                                  args.ssl_temp, args.ssl_alpha, device),
         'SelfCF': lambda: SelfCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
                                  args.dropout, device),
+        # the one reader of the sampler's second negative (main.py:354-355, dataload.py:81-84)
+        'MCLN': lambda: MCLN(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
+                             args.n_layers, args.n_mca, device),
     }
     if args.Model not in table:
         raise SystemExit(f"--Model {args.Model}: only {sorted(table)} are on the MI355X hot path")
@@ -81,7 +84,7 @@ def main(argv=None):
     if device.type != "cuda":
         raise SystemExit("chaorec_amd runs on the MI355X only: no GPU visible")
     config = load_yaml_config(args.Model)
-    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec")
+    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN")
     train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat = dataload.data_load(
         args.data_path, has_v=needs_feat, has_t=needs_feat, data_root=args.data_root, synthetic=args.synthetic)
     if args.host_sampler:

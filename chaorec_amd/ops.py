@@ -727,9 +727,15 @@ def bpr_finalize_steps(ws, n_steps, B, D, reg_weight, out_loss, out_total=None, 
     _lib.check(rc, "chaorec_bpr_finalize_steps_f32")
 
 
-def sample_negatives(hist, users, num_item, seed, step, id_offset, step_dev=None):
+SECOND_DRAW_SALT = 0x9E3779B97F4A7C15      # CHAOREC_SECOND_DRAW_SALT (include/chaorec_hip.h)
+
+
+def sample_negatives(hist, users, num_item, seed, step, id_offset, step_dev=None, second=False):
     """One uniform negative per user, never in the user's history.  `step_dev` (int64 device scalar) is added to
-    `step`: lets a captured hipGraph draw a fresh batch on every replay."""
+    `step`: lets a captured hipGraph draw a fresh batch on every replay.  second: the sample's SECOND, independent draw
+    (dataload.py:81-84's `int_items`, read by MCLN only): the same function under seed ^ SECOND_DRAW_SALT."""
+    if second:
+        seed = (int(seed) ^ SECOND_DRAW_SALT) & 0xFFFFFFFFFFFFFFFF
     rowptr, col = hist
     _need_cuda(rowptr, col, users, step_dev)
     users = users.to(torch.int64).contiguous()

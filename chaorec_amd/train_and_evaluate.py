@@ -138,7 +138,9 @@ def _capture_step(model, train_loader, optimizer, model_name):
 
 
 def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epochs, model_name="LightGCN",
-                       topk=(5, 10, 20), patience=20, graph=True):
+                       topk=(5, 10, 20), patience=20, graph=True, history=None):
+    """history (optional list): receives one dict per epoch -- epoch, loss (the summed batch losses, what the reference
+    logs as "Epoch n, Loss"), val and test metrics -- the numbers the log lines carry, for callers that compare runs."""
     model.train()
     graphed, capture_pending = None, bool(graph)
     early_stopping = EarlyStopping(patience=patience, verbose=True)
@@ -164,6 +166,8 @@ def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epoc
         test_metrics = evaluate(model, test_data, rank_list, topk)
         _log_metrics('Validation Metrics:', val_metrics)
         _log_metrics('Test Metrics:', test_metrics)
+        if history is not None:
+            history.append({"epoch": epoch + 1, "loss": loss, "val": val_metrics, "test": test_metrics})
 
         recall = test_metrics[max(topk)]['recall']
         early_stopping(recall, test_metrics)

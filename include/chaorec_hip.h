@@ -252,7 +252,11 @@ int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i,
  * step_dev (optional device int64 scalar) is added to `step`, so a captured hipGraph can advance the stream
  * of draws from a device-resident batch counter.
  * out_neg[b] = local item id + id_offset (the reference hands out GLOBAL ids = item + num_user).
+ * The reference draws a SECOND item per sample by the same rule (dataload.py:81-84: `int_items`, handed out only to MCLN,
+ * :103-104): that is this function again under  seed ^ CHAOREC_SECOND_DRAW_SALT  -- an independent stream of the same
+ * counter generator, never in the user's history either.
  * ------------------------------------------------------------------------------------- */
+#define CHAOREC_SECOND_DRAW_SALT 0x9E3779B97F4A7C15ull
 int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col,
                              const int64_t *users, int32_t B, int32_t num_item,
                              uint64_t seed, uint64_t step, const int64_t *step_dev, int64_t id_offset,

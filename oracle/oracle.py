@@ -177,7 +177,12 @@ def bpr_bwd(tab_u, tab_i, users, pos, neg, coef, reg_weight, grad_out=1.0):
     return g_u, g_i
 
 
-def sample_negatives(hist, users, num_item, seed, step, id_offset):
+SECOND_DRAW_SALT = 0x9E3779B97F4A7C15      # the stream of the sample's second draw (dataload.py:81-84), chaorec_hip.h
+
+
+def sample_negatives(hist, users, num_item, seed, step, id_offset, second=False):
+    if second:
+        seed = (int(seed) ^ SECOND_DRAW_SALT) & 0xFFFFFFFFFFFFFFFF
     rowptr, col = hist
     users = _c(users, np.int64)
     out = np.empty(len(users), np.int64)

@@ -236,6 +236,14 @@ def test_sampler_bit_exact_and_never_in_history(dev, oracle, baby):
         assert (n - U) not in row and U <= n < U + I
     other = ops.sample_negatives(dh, torch.from_numpy(users).to(dev), I, 42, 8, U).cpu().numpy()
     assert (other != got).mean() > 0.99  # a new step is a new draw
+    # the sample's SECOND draw (dataload.py:81-84, read by MCLN): its own stream of the same generator -- the oracle's bits,
+    # never in the history, independent of the first (equal to it about once in I draws)
+    want2 = oracle.sample_negatives(hist, users, I, seed=42, step=7, id_offset=U, second=True)
+    got2 = ops.sample_negatives(dh, torch.from_numpy(users).to(dev), I, 42, 7, U, second=True).cpu().numpy()
+    assert np.array_equal(got2, want2)
+    for u, n in zip(users[:2000], got2[:2000]):
+        assert (n - U) not in hist[1][hist[0][u]:hist[0][u + 1]] and U <= n < U + I
+    assert (got2 == got).mean() < 5.0 / I + 0.002
 
 
 def test_sampler_uniform_over_unseen(dev, oracle):

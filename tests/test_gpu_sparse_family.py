@@ -218,3 +218,38 @@ def test_sparse_dropout_is_the_reference_helper(dev):
     loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
     loss.backward()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_mcln_golden(dev):
+    """Model/MCLN.py -- the reader of the sampler's second negative (dataload.py:81-84): parameters in the reference's
+    creation order with its initial weights, the adjacency bit for bit, loss(users, pos, neg, int_items), every gradient, the
+    [B, B] score matrix of forward(), and the ranking of user . item + user_v . visual + user_t . textual (one 3 D-wide dot
+    product here) against the reference class's output."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MCLN
+    g = load_golden("mcln_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = MCLN(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+             torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]), int(g["L"]), int(g["n_mca"]), dev).to(dev)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    assert np.array_equal(_csr_dense(m.norm_adj_mat), _coo_dense(g["norm_idx"], g["norm_val"], (U + I, U + I)))
+    batch = [torch.from_numpy(g[k]) for k in ("users", "pos", "neg", "ints")]
+    loss = m.loss(*batch)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    unused = set(str(n) for n in g["no_grad"])
+    for n, p in m.named_parameters():
+        if n in unused:
+            assert p.grad is None, n
+            continue
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, n
+    assert np.abs(m.ua_embeddings.detach().cpu().numpy() - g["ua"]).max() <= 2e-6 * np.abs(g["ua"]).max()
+    assert np.abs(m.ia_embeddings.detach().cpu().numpy() - g["ia"]).max() <= 2e-6 * np.abs(g["ia"]).max()
+    with torch.no_grad():
+        total = m.forward(batch[0].to(dev), *((b - U).to(dev) for b in batch[1:])).cpu().numpy()
+    assert np.abs(total - g["total_scores"]).max() <= 2e-5 * np.abs(g["total_scores"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["scores"], U)

@@ -435,13 +435,14 @@ def test_bench_launches_its_own_ranks_and_propagates_failures():
         assert r.returncode != 0 and "needs the MI355X" in r.stderr
 
 
-@pytest.mark.parametrize("name", ["simgcl_small.npz", "xsimgcl_small.npz", "ncl_small.npz", "selfcf_small.npz", "slmrec_small.npz"])
+@pytest.mark.parametrize("name", ["simgcl_small.npz", "xsimgcl_small.npz", "ncl_small.npz", "selfcf_small.npz", "slmrec_small.npz",
+                                  "mcln_small.npz"])
 def test_sparse_family_models_start_from_the_reference_state(name):
     """SimGCL / NCL / SelfCF (through the adapter alone): what needs no GPU -- the same seed gives the
     reference class's parameter names and initial weights, and graph.binary_sym_norm_csr gives its scipy-built
     D^-1/2 A D^-1/2 bit for bit (goldens of tests/golden/gen_sparse_family.py: the reference classes' own output)."""
     from chaorec_amd import graph
-    from chaorec_amd.Model import NCL, SelfCF, SimGCL, SLMRec, XSimGCL
+    from chaorec_amd.Model import MCLN, NCL, SelfCF, SimGCL, SLMRec, XSimGCL
     g = load_golden(name)
     U, I = int(g["U"]), int(g["I"])
     uid = graph.user_item_dict_from_edges(g["edges"])
@@ -457,6 +458,10 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m = SLMRec(U, I, g["edges"], uid, torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]), int(g["D"]), int(g["L"]),
                    float(g["ssl_temp"]), float(g["ssl_alpha"]), cpu)
         adj = m.norm_adj
+    elif name.startswith("mcln"):
+        m = MCLN(U, I, g["edges"], uid, torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]),
+                 int(g["L"]), int(g["n_mca"]), cpu)
+        adj = m.norm_adj_mat
     elif name.startswith("ncl"):
         m = NCL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), "add", float(g["ssl_temp"]), float(g["ssl_reg"]), cpu)
         adj = m.norm_adj_mat
@@ -474,7 +479,7 @@ def test_sparse_family_models_start_from_the_reference_state(name):
     ref[g["norm_idx"][0], g["norm_idx"][1]] = g["norm_val"]
     assert np.array_equal(dense, ref)
     with pytest.raises(RuntimeError, match="MI355X only"):          # no CPU compute path: the propagate raises
-        m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+        m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
 def test_capture_retry_takes_a_capture_lost_to_the_watchdog_race_again():
