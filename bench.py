@@ -1207,7 +1207,13 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
                roofline=roofline, score_ms=score_ms, score_tf=tf, score_st=st, n_scored=n_scored, build_s=build_s,
                exchange=cdist.exchange_mode_used(), exchange_bytes=item_bytes, calibration=calibration, exposed=exposed,
                table_mb=(U + I) * D * 4 / 1e6, forward=forward_note,
-               frontier_exchanges=cdist.STATS.get("frontier_exchanges", 0))
+               frontier_exchanges=cdist.STATS.get("frontier_exchanges", 0),
+               frontier_caps=({"batch_items_rows": getattr(fused, "_cap0", None), "n1_items_rows": getattr(fused, "_cap1", None),
+                               "item_rows": I, "bytes_per_compact_exchange": {
+                                   "batch_items": (getattr(fused, "_cap0", 0) or 0) * D * 4,
+                                   "n1_items": (getattr(fused, "_cap1", 0) or 0) * D * 4, "dense": item_bytes},
+                               "capture_attempts": getattr(fused, "capture_attempts", None)}
+                              if fused is not None and getattr(fused, "sparse_bwd", False) else None))
     del fused, graphed, model, opt, job, edges_dev, calls, timed
     torch.cuda.empty_cache()
     return res
@@ -1292,7 +1298,8 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                    "exposed_communication": head["exposed"], "host_build_seconds": head["build_s"]},
         "roofline": head["roofline"], "roofline_scoring": scoring_roofline(head),
         "loss_mean": head["loss_mean"],
-        **({"forward": head["forward"]} if head.get("forward") else {}),
+        **({"forward": head["forward"], "frontier_exchanges_issued": head["frontier_exchanges"],
+            "frontier_capacities": head["frontier_caps"]} if head.get("forward") else {}),
     }
 
     # Sub-records, under a watchdog: a collective that cannot make progress in a sub-record must not take the headline
@@ -1330,7 +1337,8 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                 "roofline": h["roofline"], "gene_ranklist_ms_cold": h["score_ms"],
                 "users_scored_per_s_cold": h["n_scored"] / (h["score_ms"] * 1e-3),
                 "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"], "host_build_seconds": h["build_s"],
-                **({"forward": h["forward"], "frontier_exchanges_issued": h["frontier_exchanges"]} if h.get("forward") else {}),
+                **({"forward": h["forward"], "frontier_exchanges_issued": h["frontier_exchanges"],
+                    "frontier_capacities": h["frontier_caps"]} if h.get("forward") else {}),
             }
             del h
         except Exception as exc:      # noqa: BLE001

@@ -1032,6 +1032,7 @@ class FusedShardedLightGCNStep:
         self._compact = {}                   # (buffer, cap) -> ([cap, D] packed rows, bitmap prefix): _exchange_frontier
         self._cap0 = min(I, 2 * self.B * self.world)      # the batch items of all ranks: a static bound
         self._frontier_overflow = torch.zeros(1, dtype=torch.int32, device=dev)    # (sticky: check_frontier())
+        self._cap1 = None                    # capacity of N1's compact frontier exchange: _auto_frontier_cap
         if self.sparse_bwd:
             wu, wi = (U + 31) // 32, (I + 31) // 32
             self._wu = wu
@@ -1116,8 +1117,10 @@ class FusedShardedLightGCNStep:
         over = int(self._frontier_overflow.item())
         if over > 0:
             raise RuntimeError(f"FusedShardedLightGCNStep: a compact frontier exchange overflowed its capacity by {over} rows "
-                               f"(capacity 2 * batch * world = {self._cap0}): the batch size changed, or a row bitmap was not "
-                               f"cleared after an aborted replay")
+                               f"(batch items of all ranks: 2 * batch * world = {self._cap0} rows; N1's item frontier: "
+                               f"{self._cap1} rows, twice the first step's -- CHAOREC_DIST_FRONTIER_CAP sets it, 0 = dense "
+                               f"exchange): the batch size changed, a later frontier outgrew the first step's by more than "
+                               f"2 x, or a row bitmap was not cleared after an aborted replay")
 
     def _counters(self):
         return [t for t in (self.step_dev, self.loss_accum, self.optimizer._step_dev) if t is not None]
@@ -1156,11 +1159,17 @@ class FusedShardedLightGCNStep:
         skip rows -- but where the frontier has a STATIC bound `cap` on its size (the batch items of all ranks: the seed
         of the backward, the last forward layer's item partial) the flagged rows are packed in bitmap order (the same order
         on every rank) into a [cap, D] buffer, THAT is all-reduced, and the sums are written back: 2 B world rows instead of
-        the item table.  Without a bound (N1's items) the dense exchange runs: the buffer is zero outside the frontier."""
+        the item table.  N1's item frontier (cap="auto") has no such bound, but a step cannot size a collective on the device
+        either: its capacity is fixed at FIRST CONTACT (_auto_frontier_cap: twice what the first, eager step's frontier
+        needed) and a later frontier that outgrows it is recorded by the pack launch and raised by check_frontier() at the
+        end of run() -- never exchanged incompletely in silence.  cap=None: the dense exchange (the buffer is zero outside
+        the frontier)."""
         if not _active(self.group):
             return _Pending(None)
         p2p = buf.is_cuda and resolve_mode(buf) == "p2p" and _p2p_usable(buf, self.group)
-        if cap is None or p2p or _os.environ.get("CHAOREC_DIST_COMPACT_FRONTIER", "1") != "1":
+        if cap == "auto" and not p2p:
+            cap = self._auto_frontier_cap(bits)
+        if cap is None or cap == "auto" or p2p or _os.environ.get("CHAOREC_DIST_COMPACT_FRONTIER", "1") != "1":
             return _sum_exchange_async(buf, self.group, bits=bits, n_rows=self.I)
         K, I = self.K, self.I
         key = (buf.data_ptr(), int(cap))
@@ -1179,6 +1188,24 @@ class FusedShardedLightGCNStep:
             return _Pending(None)
 
         return _Pending(work, unpack)
+
+    def _auto_frontier_cap(self, bits):
+        """Capacity (rows) of the compact exchange of N1's item frontier, fixed the first time one is exchanged: the rows
+        flagged in that frontier's bitmap -- the same bitmap on every rank (it is the union over the ranks), hence the same
+        number everywhere -- doubled, rounded up to 1024, at most the item table.  CHAOREC_DIST_FRONTIER_CAP = rows fixes it
+        by hand, = 0 keeps N1's frontiers on the dense exchange.  None while unknown and not knowable (inside a capture
+        before any eager step: the constructor's eager warm-up steps come first)."""
+        if self._cap1 is None:
+            env = _os.environ.get("CHAOREC_DIST_FRONTIER_CAP")
+            if env is not None:
+                self._cap1 = min(self.I, int(env))
+            elif torch.cuda.is_available() and bits.is_cuda and torch.cuda.is_current_stream_capturing():
+                return None
+            else:
+                words = bits.detach().cpu().numpy().view(np.uint8)
+                flagged = int(np.unpackbits(words).sum())
+                self._cap1 = min(self.I, max(4096, (2 * flagged + 1023) // 1024 * 1024))
+        return self._cap1 if self._cap1 > 0 else None
 
     @torch.no_grad()
     def _launch(self, light=None):
@@ -1290,7 +1317,7 @@ class FusedShardedLightGCNStep:
             x, y = xs[-1], self.ybuf[L - 2]
             # layer L-1 over N1
             K.spmm_rowlist(iu, x[:U], self.Z[:I], self._list1_ig, n_i1g, long_rows=self._long_iu)
-            pz = self._exchange_frontier(self.Z, bi1)
+            pz = self._exchange_frontier(self.Z, bi1, cap="auto")
             if pend is not None:
                 pend.wait()
             K.spmm_rowlist(ui, x[U:N], y[:U], self._list_u, n_u1, long_rows=self._long_ui)
@@ -1336,7 +1363,7 @@ class FusedShardedLightGCNStep:
             if how == "list":
                 K.spmm_rowlist(iu, gu, self.Z[:I], self._list_i, self._list_n[1:2], alpha=alpha, z=self.G[U:N], beta=c,
                                src_bits=bu0, z_bits=bi0, long_rows=self._long_iu)
-                nxt = self._exchange_frontier(self.Z, bi1)
+                nxt = self._exchange_frontier(self.Z, bi1, cap="auto")
             elif how == "gated":
                 K.spmm_rowsparse(iu, gu, Y[U:N], alpha=alpha, z=self.G[U:N], beta=c, src_bits=self.bits[2 * l], z_bits=bi0)
                 nxt = self._exchange(Y)
