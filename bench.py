@@ -65,7 +65,7 @@ def parse():
     p.add_argument("--hbm-steps", type=int, default=10, help="timed steps of the config-5-shard sub-record")
     p.add_argument("--no-full-config5", action="store_true",
                    help="skip the sub-record of BASELINE configs[4] WHOLE on this GPU (10 M x 2 M, 4e8 directed edges: ~40 s)")
-    p.add_argument("--no-models", action="store_true", help="N > 1: skip the sharded MMGCN / FREEDOM sub-records")
+    p.add_argument("--no-models", action="store_true", help="skip the MMGCN / FREEDOM sub-records (N > 1: the sharded models)")
     p.add_argument("--full-steps", type=int, default=10, help="timed steps of the configs[4]-whole sub-record (N=1)")
     p.add_argument("--model", default="LightGCN", choices=["LightGCN", "MMGCN", "FREEDOM"],
                    help="LightGCN: the headline workload.  MMGCN (BASELINE configs[3], microlens) / FREEDOM (configs[2], "
@@ -908,6 +908,17 @@ def main_single(args, dev):
                 **(f["performed"] if f.get("performed") else {}),
             }
             del f
+            torch.cuda.empty_cache()
+    if not args.no_models and args.dataset == "sports":
+        # BASELINE configs[3] / [2] in the driver-run line: the models' captured train step + gene_ranklist, single process
+        out["models"] = {}
+        for name in ("MMGCN", "FREEDOM"):
+            try:
+                m = measure_model(args, name, 1, 0, dev, False, None, steps=200, warmup=20)
+                out["models"][name] = {k: m[k] for k in ("ms_per_step", "timed_blocks", "value", "unit", "steps", "warmup", "data",
+                                                         "users_scored_per_s_incl_d2h", "config") if k in m}
+            except Exception as exc:      # noqa: BLE001 -- a sub-record must not take the headline with it
+                out["models"][name] = {"error": repr(exc)[:300]}
             torch.cuda.empty_cache()
     if not args.no_cpu_baseline and edges is not None:
         out["cpu_baseline"] = cpu_baseline(edges, U, I, D, args.n_layers, args.batch, reg, args.cpu_seconds)

@@ -43,15 +43,18 @@ class FusedAdam(torch.optim.Optimizer):
 
     Feature tables that a model marks `_chaorec_projected_only` (read only through ops.linear_rows: FREEDOM's trainable image
     / text features, Model/FREEDOM.py:59-60, 209-213) are claimed: their [I, K] gradient is never materialised, the
-    update comes from chaorec_adam_lowrank_f32 (gy [I, R] and the projection weight instead).  `lazy_rows=True` (env
-    CHAOREC_LAZY_ADAM=1) additionally defers the zero-gradient updates of rows outside the batch until the row is next
-    in a batch -- replayed then operation for operation, so after flush() the tables are bit-identical to the eager
-    ones; between flushes rows outside the recent batches are stale (state_dict() flushes)."""
+    update comes from chaorec_adam_lowrank_f32 (gy [I, R] and the projection weight instead).  `lazy_rows` (default since
+    round 5: on; CHAOREC_LAZY_ADAM=0 / lazy_rows=False: every row every step) additionally defers the zero-gradient updates
+    of rows outside the batch until the row is next in a batch -- replayed then operation for operation, so after flush()
+    the tables are bit-identical to the eager ones (tests/test_gpu_feature_adam.py: eager and captured steps); between
+    flushes rows outside the recent batches are stale IN MEMORY: state_dict() and the training loop's end flush, a caller
+    that reads such a table's rows directly calls optimizer.flush() first.  Only tables read through ops.linear_rows alone
+    are ever lazy: one that ops.linear reads as a whole (VBPR, MGCN) takes the dense update whatever this says."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lazy_rows=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step_dev = None
-        self.lazy_rows = (os.environ.get("CHAOREC_LAZY_ADAM", "0") == "1") if lazy_rows is None else bool(lazy_rows)
+        self.lazy_rows = (os.environ.get("CHAOREC_LAZY_ADAM", "1") == "1") if lazy_rows is None else bool(lazy_rows)
         self._pending = {}      # claimed parameter -> [gy_full, projection weight] of the backward that just ran
         self._claimed = {}      # id(parameter) -> its group
         self._dense_read = set()  # id(claimed parameter) read as a whole by ops.linear: never updated lazily (submit())

@@ -248,6 +248,7 @@ def test_sharded_freedom_trains_like_freedom_with_claimed_tables(dev, lazy):
         sh.sync_grads()
         opt_s.step()
     opt_s.flush()
+    opt_m.flush()                       # (lazy rows are the default: a reader of the tables' rows flushes first)
     ref = dict(m.named_parameters())
     for n, p in sh.named_parameters():
         assert torch.allclose(p, ref[n], rtol=0, atol=2e-6), n
