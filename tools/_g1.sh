@@ -1,1 +1,1 @@
-python bench.py --no-cpu-baseline --no-hbm-regime 2>gpurun_out/r05_n_err.log | tail -1 > gpurun_out/r05_n_line.json; tail -c 300 gpurun_out/r05_n_err.log
+python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r05_o_gpu_tests.log; cat gpurun_out/r05_o_gpu_tests.log
