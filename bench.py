@@ -872,6 +872,11 @@ def main_single(args, dev):
         **({"forward": r["forward"]} if r.get("forward") else {}),
         **(r["performed"] if r.get("performed") else {}),
     }
+    # (the second dominant kernel family inside the object the driver keeps: the all-items scoring's share of the MFMA peak)
+    sr = out["roofline_scoring"]
+    out["roofline"]["scoring"] = {"bound": "mfma", "kernel": sr["kernel"], "achieved": sr["achieved"], "peak": sr["peak"],
+                                  "unit": sr["unit"], "frac": sr["frac"], "sweep_only_frac": sr.get("sweep_only_frac"),
+                                  "gene_ranklist_ms": r["score_ms"]}
     edges, reg = r["edges"], r["reg"]
     # --- the HBM-bound regime in the same run: one GPU's share of BASELINE configs[4] -----------------------------
     if not args.no_hbm_regime and args.dataset not in ("config5_shard", "config5"):

@@ -34,7 +34,7 @@ WORKLOADS = {
 }
 # extra bench arguments of the --pmc passes (counter collection serialises every dispatch: config 5's ranking, 5 PFLOP per
 # call, does not finish in a quarter of an hour under it -- the SpMM counters do not need it)
-PMC_EXTRA = {"config5_full": ["--spmm-only"]}
+PMC_EXTRA = {"config5_full": ["--spmm-only"], "sports": ["--no-models"], "config5": ["--no-models"]}
 
 
 def run(tag, wl, name, extra, graph):
@@ -44,7 +44,7 @@ def run(tag, wl, name, extra, graph):
           ["--", "python3", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-trained-state"] + \
           WORKLOADS[wl][2] + ([] if graph else ["--no-graph"]) + (PMC_EXTRA.get(wl, []) if "--pmc" in extra else [])
     env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not line:
         sys.stderr.write(r.stdout[-2000:] + r.stderr[-2000:])
