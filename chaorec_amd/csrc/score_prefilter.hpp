@@ -124,6 +124,21 @@ struct PrefArgs {
   int *reth_list;               // [U]
   int *rt2_cnt;                 // users that got one -> compact sweep + wide selection (pass C)
   int *rt2_list;                // [U]
+  // norm-sorted tiles (long item ranges, see "norm classes" below): the packed table holds the items in DESCENDING order of
+  // their norm class, no bound fragment; NULL = the table's own order with the per-item bound on an extra MFMA k-step
+  const int32_t *perm;          // [n_tiles * 32] packed position -> item (positions >= n_items: padding rows)
+  const int32_t *inv;           // [n_items] item -> packed position
+  const float *tile_bound;      // [n_tiles] N_t >= the norm of every item of tile t and of every later tile
+  // ... and the sampler's own table: every sample_stride-th ITEM of the sorted order (not every sample_stride-th tile: in a
+  // sorted table the items that can reach a user's top-K sit in the first few tiles, a sample of whole tiles sees all or
+  // none of them), dealt to the sample tiles round-robin: sampled item q (sorted position q * sample_stride + sample_phase)
+  // is stratum q / n_sample_tiles of tile q % n_sample_tiles -- EVERY tile is a systematic sample of the whole norm range,
+  // so is any subset of tiles a sampler wave takes.  Stratum s of tile k sits in the row that accumulator register s / 2
+  // of the user's lane (s + k) % 2 holds (row (i & 3) + 8 (i >> 2) + 4 h for i = s / 2, h = (s + k) % 2): over the tiles
+  // both lanes of a user see every stratum equally often (the sampler pools the two lanes' lists and needs them alike:
+  // with the top strata always in one lane its list alone decided the estimate, 0.7 of the rank aimed at)
+  const uint4 *sample_packed;   // [n_sample_tiles][D/16][64]
+  int n_sample_tiles, sample_phase;
 };
 
 // ---- pack ----------------------------------------------------------------------------------------------------
@@ -169,6 +184,269 @@ __global__ __launch_bounds__(256) void pack_items_bf16_kernel(const float *__res
   }
 }
 
+// ---- norm classes: the bound without its MFMA (long item ranges) ---------------------------------------------------
+// The sweep's time is linear in its MFMA count, and one MFMA in nine (D = 128; one in five at D = 64) only
+// adds the rank-1 term T_u - c ||u|| ||i_j||.  With ONE norm N for a whole run of tiles the test s~_j + c ||u|| N > T_u is
+// s~_j > theta_u = T_u - c ||u|| N, and scaling the user's fragments by 1 / |theta_u| BEFORE the bf16 rounding turns it
+// into s~'_j > +-1 -- 1.0 is an inline constant of the MFMA's C operand: no bound fragment, no extra k-step.  One N for the
+// whole table (the largest norm) widens every item's band to the largest item's: +33 % candidates on propagated tables
+// whose norms fall with the degree.  So the packed table is SORTED by norm class, descending -- a class =
+// the norm's exponent and three mantissa bits: norms within 12.5 % of each other -- and the sweep re-scales its users'
+// fragments whenever the walk enters a tile with another bound (tile_bound[t], non-increasing in t; classes with few
+// items are merged so that a walk re-scales a few dozen times at most).  Candidate positions of the packed table go
+// through perm[] in the selection; everything downstream (exact re-score, history, ranking keys) sees item ids.
+//
+//   |s~'(u,j) - a s(u,j)| <= c a ||u|| ||i_j||,  c = 1.05 * 2^-8  (two RNE bf16 roundings of 2^-9 each on a u_d and i_d:
+//     2^-8 (1 + 2^-10) sum |a u_d i_d| <= 1.001 * 2^-8 a ||u|| ||i_j||; the fp32 rounding of a u_d (2^-24) and the MFMA's
+//     fp32 accumulation ((D + 1) 2^-24 of the terms' absolute sum) disappear in c's 5 % of slack)
+//   s_j > T_u  =>  a s_j > a T_u  =>  s~'_j > a (T_u - c ||u|| N) - d = a theta_u - d,  d <= (D + 1) 2^-24 (the
+//     accumulation's rounding next to the constant 1); a = (1 + 2^-14) / theta_u makes that > 1 (theta_u > 0: fragments
+//     negated, accumulator 1 - s~', a hit is its SIGN BIT); theta_u < 0: a = (1 - 2^-14) / |theta_u|, accumulator 1 + s~',
+//     a hit is a CLEAR sign bit (one xor with the lane's flip mask).
+// Sorting: a stable counting sort on the class (norm_class -> scan -> scatter), three small launches in front of the pack.
+constexpr int kClsBase = 107 * 8;          // class 0 holds every norm below 2^-20, class 255 every norm from 2^11 * 1.875 on
+constexpr int kClsChunk = 1024;            // items per block of the counting sort
+constexpr int kClsSegments = 32;           // classes are merged into runs of at least n_items / kClsSegments items ...
+constexpr int kClsRunSpan = 4;             // ... that span at most this many classes
+
+__device__ __forceinline__ int norm_class(float nu) {            // nu >= 0 (NaN / inf: the top class)
+  const int k = (int)(__float_as_uint(nu) >> 20) - kClsBase;
+  return min(max(k, 0), 255);
+}
+__device__ __forceinline__ float class_edge(int k) {             // > every norm of the classes <= k (k < 255)
+  return __uint_as_float((uint32_t)(k + kClsBase + 1) << 20);
+}
+
+// key[j] = 255 - class of item j (ascending keys = descending norms; padding rows: norm 0, the last key, and -- their
+// indices being the largest -- the last positions of the stable sort), per-block class histograms laid out class-major
+// (a plain exclusive scan over the array gives every (class, block) its first position), per-block largest norm.
+// 8 lanes per row: 128 contiguous bytes per load instruction and group.
+__global__ __launch_bounds__(256) void score_norm_class_kernel(const float *__restrict__ item_emb, int64_t n_items, int D,
+                                                               int64_t n_pad, uint8_t *__restrict__ key,
+                                                               int *__restrict__ blockhist, int NB, int *__restrict__ blockmax) {
+  __shared__ int hist[256];
+  __shared__ int smax;
+  const int tid = threadIdx.x;
+  hist[tid] = 0;
+  if (tid == 0) smax = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kClsChunk;
+  const int g = tid >> 3, l = tid & 7;
+#pragma unroll 1
+  for (int pass = 0; pass < kClsChunk / 32; ++pass) {
+    const int64_t j = base + pass * 32 + g;
+    float n2 = 0.f;
+    if (j < n_items) {
+      const float4 *row = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D);
+      for (int d = l; d < D / 4; d += 8) {
+        const float4 x = row[d];
+        n2 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      }
+    }
+    n2 += __shfl_xor(n2, 1, 64);
+    n2 += __shfl_xor(n2, 2, 64);
+    n2 += __shfl_xor(n2, 4, 64);
+    if (l == 0 && j < n_pad) {
+      const float nu = j < n_items ? bf16_ceil_pos(sqrtf(n2) * 1.0001f) : 0.f;   // (the fp32 sum / sqrt may round down: 1e-4 covers it)
+      const int kd = 255 - norm_class(nu);
+      key[j] = (uint8_t)kd;
+      atomicAdd(&hist[kd], 1);
+      atomicMax(&smax, (int)(__float_as_uint(nu) & 0x7FFFFFFFu));
+    }
+  }
+  __syncthreads();
+  blockhist[(size_t)tid * NB + blockIdx.x] = hist[tid];
+  if (tid == 0) blockmax[blockIdx.x] = smax;
+}
+
+// One workgroup: exclusive scan of blockhist[256 * NB] in place; seg_bound[kd] = the bound of the run of classes key kd
+// belongs to.  Runs are formed from the largest norms down; a run is closed once it holds min_seg items.  The run that
+// starts at key 0 (the open-ended top class) takes the table's largest norm itself.
+__global__ __launch_bounds__(1024) void score_class_scan_kernel(int *__restrict__ blockhist, int NB, const int *__restrict__ blockmax,
+                                                                float *__restrict__ seg_bound, int64_t n_pad, int min_seg) {
+  __shared__ int part[1024];
+  __shared__ int cstart[257];
+  __shared__ int gmax_s;
+  const int tid = threadIdx.x;
+  const int total = 256 * NB;
+  const int per = (total + 1023) / 1024;
+  const int lo = min(tid * per, total), hi = min(lo + per, total);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += blockhist[i];
+  part[tid] = sum;
+  if (tid == 0) gmax_s = 0;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+  for (int i = lo; i < hi; ++i) {
+    const int c = blockhist[i];
+    blockhist[i] = run;
+    run += c;
+  }
+  int m = 0;
+  for (int i = tid; i < NB; i += 1024) m = max(m, blockmax[i]);
+  atomicMax(&gmax_s, m);
+  __syncthreads();
+  if (tid < 256) cstart[tid] = blockhist[(size_t)tid * NB];
+  if (tid == 0) cstart[256] = (int)n_pad;
+  __syncthreads();
+  if (tid == 0) {
+    float cur = 0.f;
+    int acc = 0, first = 0;
+    for (int kd = 0; kd < 256; ++kd) {
+      const int cnt = cstart[kd + 1] - cstart[kd];
+      // a run also ends after kClsRunSpan classes (half an octave): a few outsized rows at the top of the table must not
+      // lend their bound to thousands of ordinary ones
+      if (acc > 0 && kd - first >= kClsRunSpan) acc = 0;
+      if (cnt > 0 && acc == 0) {
+        cur = kd == 0 ? __int_as_float(gmax_s) : class_edge(255 - kd);
+        first = kd;
+      }
+      seg_bound[kd] = cur;
+      acc += cnt;
+      if (acc >= min_seg) acc = 0;
+    }
+  }
+}
+
+// One wave per kClsChunk items: position = first position of (class, block) + the number of earlier items of the block
+// in the same class (stable: deterministic, lowest index first).  Per 64 items one round per distinct class among them.
+__global__ __launch_bounds__(64) void score_class_scatter_kernel(const uint8_t *__restrict__ key, const int *__restrict__ offs, int NB,
+                                                                 int64_t n_pad, int64_t n_items, int32_t *__restrict__ perm,
+                                                                 int32_t *__restrict__ inv, const float *__restrict__ seg_bound,
+                                                                 float *__restrict__ tile_bound) {
+  __shared__ int cnt[256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) cnt[i] = offs[(size_t)i * NB + blockIdx.x];
+  __builtin_amdgcn_wave_barrier();
+  const int64_t base = (int64_t)blockIdx.x * kClsChunk;
+#pragma unroll 1
+  for (int ch = 0; ch < kClsChunk / 64; ++ch) {
+    const int64_t j = base + ch * 64 + lane;
+    const bool valid = j < n_pad;
+    const int kd = valid ? (int)key[j] : 256;
+    int pos = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {                                               // wave-uniform
+      const int leader = __ffsll((long long)todo) - 1;
+      const int k0 = __shfl(kd, leader, 64);
+      const unsigned long long m = __ballot(kd == k0);
+      const int before = __popcll(m & ((1ull << lane) - 1ull));
+      if (kd == k0) pos = cnt[k0] + before;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) cnt[k0] += __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~m;
+    }
+    if (valid) {
+      perm[pos] = (int32_t)j;
+      if (j < n_items) inv[j] = pos;
+      if ((pos & 31) == 0) tile_bound[pos >> 5] = seg_bound[kd];
+    }
+  }
+}
+
+// the pack of a norm-sorted table: row r of tile t is item perm[32 t + r]; D / 16 data fragments per tile, no bound
+// fragment.  The same launch writes the sampler's table behind it (its tiles count on from n_tiles): row r of sample
+// tile k is stratum s = 2 ((r & 3) + 4 (r >> 3)) + (((r >> 2) + k) & 1) (PrefArgs), the item at sorted position
+// (s * n_stiles + k) * s_stride + s_phase (past the table: a zero row).
+__global__ __launch_bounds__(256) void pack_items_bf16_sorted_kernel(const float *__restrict__ item_emb,
+                                                                     uint4 *__restrict__ packed, int64_t n_items, int D,
+                                                                     int64_t n_tiles, const int32_t *__restrict__ perm,
+                                                                     uint4 *__restrict__ s_packed, int64_t n_stiles, int s_stride,
+                                                                     int s_phase, uint4 *__restrict__ zero, int64_t zero_n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-element data fragment
+  for (int64_t z = i; z < zero_n; z += (int64_t)gridDim.x * blockDim.x) zero[z] = make_uint4(0u, 0u, 0u, 0u);   // (as pack_items_bf16_kernel)
+  const int Q = D / 16;
+  if (i >= (n_tiles + n_stiles) * Q * 64) return;
+  const int lane = (int)(i & 63);
+  const int64_t tq = i >> 6;
+  const int q = (int)(tq % Q);
+  int64_t t = tq / Q;
+  int64_t pos = t * 32 + (lane & 31);
+  uint4 *dst = packed;
+  if (t >= n_tiles) {
+    t -= n_tiles;
+    const int r = lane & 31;
+    const int stratum = 2 * ((r & 3) + 4 * (r >> 3)) + (((r >> 2) + (int)t) & 1);
+    pos = ((int64_t)stratum * n_stiles + t) * s_stride + s_phase;
+    dst = s_packed;
+  }
+  const int64_t j = pos < n_tiles * 32 ? (int64_t)perm[pos] : n_items;
+  const int h = lane >> 5;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (j < n_items) {
+    const float4 *src = reinterpret_cast<const float4 *>(item_emb + (size_t)j * D + 16 * q + 8 * h);
+    v = bf16_pack8(src[0], src[1]);
+  }
+  dst[(t * Q + q) * 64 + lane] = v;
+}
+
+// this lane's half of ||u||^2 (lane h of a user's two lanes: the elements 16 q + 8 h .. + 7 of every k-step)
+template <int D>
+__device__ __forceinline__ float user_half_norm2(const float *__restrict__ urow, int h) {
+  float n2 = 0.f;
+  if (urow) {
+#pragma unroll
+    for (int q = 0; q < D / 16; ++q) {
+      const float4 *src = reinterpret_cast<const float4 *>(urow + 16 * q + 8 * h);
+      const float4 a = src[0], b = src[1];
+      n2 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    }
+  }
+  return n2;
+}
+// the lane's fragments of scale * u, rounded to bf16 (urow == NULL: zero fragments)
+template <int D>
+__device__ __forceinline__ void load_user_frags_scaled(bf16x8 (&bu)[D / 16], const float *__restrict__ urow, int h, float scale) {
+#pragma unroll
+  for (int q = 0; q < D / 16; ++q) {
+    Frag16 f;
+    f.u = make_uint4(0u, 0u, 0u, 0u);
+    if (urow) {
+      const float4 *src = reinterpret_cast<const float4 *>(urow + 16 * q + 8 * h);
+      float4 a = src[0], b = src[1];
+      a.x *= scale, a.y *= scale, a.z *= scale, a.w *= scale;
+      b.x *= scale, b.y *= scale, b.z *= scale, b.w *= scale;
+      f.u = bf16_pack8(a, b);
+    }
+    bu[q] = f.v;
+  }
+}
+// where the accumulator of user block b starts: a constant of its own per block -- 1.0, 0.5, 2.0 are all inline constants of
+// the MFMA's C operand; shared by two chains the compiler keeps the splat in 16 registers and rebuilds it every tile
+template <int UB>
+__device__ __forceinline__ constexpr float sweep_start(int b) {
+  static_assert(UB <= 3, "one inline constant per user block");
+  return b == 0 ? 1.0f : (b == 1 ? 0.5f : 2.0f);
+}
+// The signed scale of a user's fragments (negative = negated) and its flip mask, for threshold th, nu = ||u|| and item
+// norms <= N.  Everything is rounded towards MORE hits.
+__device__ __forceinline__ float sweep_user_scale(float th, float nu, float N, uint32_t &flip) {
+  flip = 0u;
+  if (th == INFINITY) return 0.f;                          // padding / +inf: zero fragments, accumulator 1: never a hit
+  const float e_u = bf16_ceil_pos(kBf16ErrCoef * nu + 1e-30f) * N * 1.00001f;   // >= c ||u|| N
+  const float theta = th - e_u - 1e-6f * fabsf(th);
+  const float mag = fabsf(theta);
+  if (mag >= 1e-30f && mag <= 1e30f && nu <= 1e30f * mag && nu >= 1e-20f * mag) {   // the scaled row stays in bf16's normal range
+    const float inv = 1.0f / mag;
+    if (theta > 0.f) return -inv * (1.0f + 0x1p-14f);      // s~ > theta  =>  s~' > 1:  a >= 1 / theta
+    flip = 0xFFFFu;
+    return inv * (1.0f - 0x1p-14f);                        // s~ > theta  =>  s~' > -1: a <= 1 / |theta|
+  }
+  // no usable scale.  A row too short to reach a positive theta (|s~| <= 1.01 nu N < theta) has no hit at all; otherwise
+  // (NaN / -inf thresholds, theta ~ 0, a row that would leave the range) every item is a candidate: the lists overflow and
+  // the user fails over, as with a NaN threshold
+  if (theta > 0.f && mag <= 1e30f && N <= 1e19f && nu < 1e-20f * mag) return 0.f;
+  flip = 0xFFFFu;
+  return 0.f;
+}
+
 template <int D>
 __device__ __forceinline__ void load_user_frags(bf16x8 (&bu)[D / 16], float &norm2_half, const float *__restrict__ user_emb,
                                                 int64_t u, bool ok, int h) {
@@ -187,16 +465,16 @@ __device__ __forceinline__ void load_user_frags(bf16x8 (&bu)[D / 16], float &nor
   }
 }
 
-template <int D>
-__device__ __forceinline__ void load_item_frags_bf16(uint4 (&a)[D / 16 + 1], const uint4 *__restrict__ packed, int64_t t,
-                                                     int lane) {
-  const uint4 *src = packed + (size_t)t * (D / 16 + 1) * 64 + lane;
+// FR fragments per tile: D / 16 data fragments, then (tables in their own order only) the bound fragment (1, ||i_j||)
+template <int FR>
+__device__ __forceinline__ void load_item_frags_bf16(uint4 (&a)[FR], const uint4 *__restrict__ packed, int64_t t, int lane) {
+  const uint4 *src = packed + (size_t)t * FR * 64 + lane;
 #pragma unroll
-  for (int q = 0; q <= D / 16; ++q) a[q] = src[q * 64];   // a[D/16] = the bound fragment (1, ||i_j||)
+  for (int q = 0; q < FR; ++q) a[q] = src[q * 64];
 }
 
-template <int D>
-__device__ __forceinline__ f32x16 tile_scores_bf16(const uint4 (&a)[D / 16 + 1], const bf16x8 (&bu)[D / 16]) {
+template <int D, int FR>
+__device__ __forceinline__ f32x16 tile_scores_bf16(const uint4 (&a)[FR], const bf16x8 (&bu)[D / 16]) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -293,8 +571,11 @@ __device__ __forceinline__ void sample_prune(float *lst, int lane, int &cnt, flo
 // WG waves per workgroup (one user block each, same tiles, loosely in step through a barrier every 4 tiles): for
 // item tables beyond L2 the waves of a workgroup then find each other's fragment loads in the CU's L1 instead of
 // each streaming the table from HBM / Infinity Cache.  WG = 1 for tables that sit in L2 anyway.
-template <int D, int CAP, bool PRUNE, int WG>
+// CLS: the packed table is norm-sorted (P.perm / P.inv, no bound fragment; long ranges only, hence PRUNE)
+template <int D, int CAP, bool PRUNE, int WG, bool CLS = false>
 __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefArgs P) {
+  static_assert(!CLS || PRUNE, "sorted tables carry no bound fragment: the sample is taken on the plain bf16 scores");
+  constexpr int FR = D / 16 + (CLS ? 0 : 1);
   __shared__ float lst_all[WG][CAP * 64];  // per wave [slot][lane]: conflict-free for lane-local walks
   __shared__ float park_all[WG][16 * 64];
   __shared__ int64_t rp_all[WG][33];
@@ -310,11 +591,53 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
   const int64_t uc = ublock * 32 + ur;                    // row of this launch
   const bool u_ok = uc < n_act;
   const int64_t u = (P.user_map && u_ok) ? (int64_t)P.user_map[uc] : uc;   // row of the tables
-  const uint32_t n_items = (uint32_t)P.n_items;
-  const int n_tiles = (int)((P.n_items + 31) / 32);
+  // What is sampled.  Tables in their own order: every sample_stride-th TILE of the packed table.  Norm-sorted tables
+  // (CLS): every tile of the sampler's own table, which holds every sample_stride-th ITEM of the sorted order (PrefArgs).
+  // Either way a wave sees 1 / (sample_stride * sample_splits) of the items.
+  const uint4 *const tbl = CLS ? P.sample_packed : P.packed;
+  const int tile_stride = CLS ? 1 : P.sample_stride;
+  // (CLS: sampled items in all -- sample tile k holds the rows r with r * n_sample_tiles + k < n_items)
+  const uint32_t n_items = CLS ? (uint32_t)((P.n_items - P.sample_phase + P.sample_stride - 1) / P.sample_stride) : (uint32_t)P.n_items;
+  const int n_tiles = CLS ? P.n_sample_tiles : (int)((P.n_items + 31) / 32);
+  // rows of tile t past the table get -inf (CLS: the strata s with s * n_tiles + t >= n_items; register reg of lane h
+  // holds stratum 2 reg + (h + t) % 2)
+  // (s * n_tiles + t <= n_items - 1  <=>  s <= (n_items - 1) / n_tiles - (t > (n_items - 1) % n_tiles): one division per wave)
+  const int strata_q = CLS && n_items > 0 ? (int)((n_items - 1u) / (uint32_t)n_tiles) : -1;
+  const int strata_r = CLS && n_items > 0 ? (int)((n_items - 1u) % (uint32_t)n_tiles) : 0;
+  auto mask_range = [&](f32x16 &acc, int t) __attribute__((always_inline)) {
+    if constexpr (CLS) {
+      const int strata = min(strata_q + 1 - (t > strata_r ? 1 : 0), 32);
+      if (strata < 32) {                                              // wave-uniform
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (2 * reg + ((h + t) & 1) >= strata) acc[reg] = -INFINITY;
+      }
+    } else {
+      apply_mask_and_range(acc, 0u, (uint32_t)t * 32u, n_items, h, P.mask_value);
+    }
+  };
   const int split = blockIdx.y;
-  const int step = P.sample_stride * P.sample_splits;
-  const int t_first = split * P.sample_stride;
+  const int step = tile_stride * P.sample_splits;
+  const int t_first = split * tile_stride;
+  // tile of the walk that holds history item cj, or -1 (CLS: the item's sorted position has to be a sampled one)
+  auto hist_tile = [&](uint32_t cj) __attribute__((always_inline)) -> int {
+    if constexpr (CLS) {
+      const uint32_t pos = (uint32_t)P.inv[cj];
+      if (pos % (uint32_t)P.sample_stride != (uint32_t)P.sample_phase) return -1;
+      return (int)((pos / (uint32_t)P.sample_stride) % (uint32_t)n_tiles);
+    } else {
+      return (int)(cj >> 5);
+    }
+  };
+  // The wave's sample: tiles t_first + i * step, i < n_samp, in that order (prefetches past the end wrap round to a tile
+  // seen before)
+  const int n_samp = t_first < n_tiles ? (n_tiles - t_first + step - 1) / step : 0;
+  constexpr int pm = 1;
+  auto walk_next = [&](int &i) __attribute__((always_inline)) {
+    i += pm;
+    if (i >= n_samp) i -= n_samp;
+  };
+  auto walk_tile = [&](int i) __attribute__((always_inline)) -> int { return t_first + i * step; };
 
   bf16x8 bu[D / 16];
   float n2;
@@ -331,12 +654,15 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
   fw.u = make_uint4(h == 0 ? (((__float_as_uint(bf16_ceil_pos(kBf16ErrCoef * sqrtf(n2) + 1e-30f)) >> 16) | 0x8000u) << 16) : 0u,
                     0u, 0u, 0u);
   const bf16x8 bw = fw.v;
-  auto tile_w = [&](const uint4 (&a)[D / 16 + 1]) __attribute__((always_inline)) -> f32x16 {
-    f32x16 acc = tile_scores_bf16<D>(a, bu);
-    if constexpr (PRUNE) return acc;
-    Frag16 fa;
-    fa.u = a[D / 16];
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bw, acc, 0, 0, 0);
+  auto tile_w = [&](const uint4 (&a)[FR]) __attribute__((always_inline)) -> f32x16 {
+    f32x16 acc = tile_scores_bf16<D, FR>(a, bu);
+    if constexpr (PRUNE) {
+      return acc;
+    } else {
+      Frag16 fa;
+      fa.u = a[D / 16];
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, bw, acc, 0, 0, 0);
+    }
   };
 
   // The sample is taken on RAW scores (no history mask: a cursor over the history costs a dependent load in the
@@ -351,7 +677,7 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
     // a user do the same walk: the pass is small, simplicity over speed)
     if (u_ok) {
       for (int64_t e = P.hist_rowptr[u]; e < P.hist_rowptr[u + 1]; ++e) {
-        const int tt = (int)((uint32_t)P.hist_col[e] >> 5);
+        const int tt = hist_tile((uint32_t)P.hist_col[e]);
         if (tt >= t_first && (tt - t_first) % step == 0) ++h_s;
       }
     }
@@ -362,7 +688,7 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
     __builtin_amdgcn_wave_barrier();
     const int64_t e0 = rp_s[0], e1 = rp_s[32];
     for (int64_t e = e0 + lane; e < e1; e += 64) {
-      const int tt = (int)((uint32_t)P.hist_col[e] >> 5);
+      const int tt = hist_tile((uint32_t)P.hist_col[e]);
       if (tt >= t_first && (tt - t_first) % step == 0) {
         int lo = 0, hi = 31;   // owner row: last r with rp_s[r] <= e
 #pragma unroll
@@ -381,18 +707,19 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
   // larger of the two lanes' 4th best: at least 4 of the user's 256 scores reach it (expected: the top ~2.5 %)
   float tau1;
   float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY, b3 = -INFINITY;
-  int t_phase2 = t_first;
+  int wi = 0, visited = 0;        // sample index of the next visit, visits so far
   {
-    int t = t_first;
-    uint4 a[D / 16 + 1], an[D / 16 + 1];
-    if (t < n_tiles) load_item_frags_bf16<D>(a, P.packed, t, lane);
-    for (int g = 0; g < 8 && t < n_tiles; ++g, t += step) {
-      load_item_frags_bf16<D>(an, P.packed, t + step < n_tiles ? t + step : t, lane);
+    uint4 a[FR], an[FR];
+    if (n_samp > 0) load_item_frags_bf16<FR>(a, tbl, walk_tile(wi), lane);
+    for (int g = 0; g < 8 && visited < n_samp; ++g) {
+      const int t = walk_tile(wi);
+      walk_next(wi);
+      ++visited;
+      load_item_frags_bf16<FR>(an, tbl, walk_tile(wi), lane);   // (after the last visit: a tile seen before, never consumed)
       f32x16 acc = tile_w(a);
-      const uint32_t j0 = (uint32_t)t * 32u;
-      apply_mask_and_range(acc, 0u, j0, n_items, h, P.mask_value);
+      mask_range(acc, t);
 #pragma unroll
-      for (int q = 0; q <= D / 16; ++q) a[q] = an[q];
+      for (int q = 0; q < FR; ++q) a[q] = an[q];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const float x = acc[reg];
@@ -403,7 +730,6 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
       }
     }
     tau1 = fmaxf(b3, __shfl_xor(b3, 32, 64));
-    t_phase2 = t;
   }
 
   // phase 2: every sampled tile; scores above the lane's threshold go to its LDS list.  Same compact hit handling as
@@ -423,15 +749,16 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
   {
     // item fragments three tiles ahead: one tile of this kernel is short (one user block), a single tile of
     // lookahead does not cover the L2 latency
-    uint4 ring[3][D / 16 + 1];
-    int t = t_phase2;
+    uint4 ring[3][FR];
+    int pi = wi;                  // sample index the next prefetch takes: three visits ahead
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      load_item_frags_bf16<D>(ring[i], P.packed, t + i * step < n_tiles ? t + i * step : (n_tiles - 1), lane);
-    auto consume = [&](const uint4 (&a)[D / 16 + 1], int tt) __attribute__((always_inline)) {
+    for (int i = 0; i < 3; ++i) {
+      if (n_samp > 0) load_item_frags_bf16<FR>(ring[i], tbl, walk_tile(pi), lane);
+      walk_next(pi);
+    }
+    auto consume = [&](const uint4 (&a)[FR], int tt) __attribute__((always_inline)) {
       f32x16 acc = tile_w(a);
-      const uint32_t j0 = (uint32_t)tt * 32u;
-      apply_mask_and_range(acc, 0u, j0, n_items, h, P.mask_value);
+      mask_range(acc, tt);
       uint32_t qbits = 0;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(tl - acc[reg]), 31);
@@ -452,21 +779,23 @@ __global__ __launch_bounds__(64 * WG) void score_sample_bf16_kernel(const PrefAr
       }
     };
     int since_sync = 0;
-    while (t < n_tiles) {
+    while (visited < n_samp) {
       if (WG > 1 && ++since_sync == 2) {   // (every 6 tiles: keeps the workgroup's waves within L1 reach of each other)
         since_sync = 0;
         __syncthreads();
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        if (t < n_tiles) {
-          uint4 cur[D / 16 + 1];
+        if (visited < n_samp) {
+          uint4 cur[FR];
 #pragma unroll
-          for (int q = 0; q <= D / 16; ++q) cur[q] = ring[i][q];
-          const int tp = t + 3 * step;
-          load_item_frags_bf16<D>(ring[i], P.packed, tp < n_tiles ? tp : (n_tiles - 1), lane);
+          for (int q = 0; q < FR; ++q) cur[q] = ring[i][q];
+          const int t = walk_tile(wi);
+          walk_next(wi);
+          ++visited;
+          load_item_frags_bf16<FR>(ring[i], tbl, walk_tile(pi), lane);   // (past the end: a tile seen before, never consumed)
+          walk_next(pi);
           consume(cur, t);
-          t += step;
         }
       }
     }
@@ -529,9 +858,11 @@ constexpr int kSweepStage = CHAOREC_SWEEP_STAGE;
 constexpr int kSweepPark = CHAOREC_SWEEP_PARK;    // list entries per lane and user block parked in LDS (0: store each at once)
 static_assert(kSweepPark % 4 == 0 && kSweepPark <= kPfCap, "whole 16-byte stores inside a list");
 
-template <int D, int UB>
+// CLS: norm-sorted table ("norm classes" above): D / 16 MFMAs per tile and user block, the accumulators start at an inline
+// constant, the users' fragments are re-scaled when the walk reaches a tile with another bound.
+template <int D, int UB, bool CLS = false>
 __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(const PrefArgs P) {
-  constexpr int FR = D / 16 + 1;                       // fragments (1 KiB each) per tile
+  constexpr int FR = D / 16 + (CLS ? 0 : 1);           // fragments (1 KiB each) per tile
   __shared__ uint4 stage[2][kSweepStage][FR * 64];
   // A lane's first kSweepPark list entries wait here ([entry][lane]: conflict-free) and leave as 16-byte stores after the
   // sweep.  Every entry used to be its own 4-byte store into its own cache line -- 2.9 M separate L2 write requests per
@@ -552,11 +883,28 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   bf16x8 bu[UB][D / 16], bth[UB];
   int cnt[UB];
   uint32_t *mine[UB];
+  uint32_t flip[UB];                     // (CLS) the lane's flip mask of the current scale
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
     const int64_t uc = (ublock0 + b) * 32 + ur;
     const bool ok = uc < n_act;
     const int64_t u = (P.user_map && ok) ? (int64_t)P.user_map[uc] : uc;
+    cnt[b] = 0;
+    mine[b] = P.cand + (((size_t)split * P.n_users + (ok ? u : 0)) * 2 + h) * kPfCap;
+    if constexpr (CLS) {
+      if (ok && split == 0 && h == 0) {
+        const float th = thr_src[u];
+        P.theta[u] = (th == th) ? th : -INFINITY;
+      }
+      flip[b] = 0u;
+#pragma unroll
+      for (int q = 0; q < D / 16; ++q) {    // (scaled at the first tile: rescale below)
+        Frag16 f;
+        f.u = make_uint4(0u, 0u, 0u, 0u);
+        bu[b][q] = f.v;
+      }
+      bth[b] = bu[b][0];
+    } else {
     float n2;
     load_user_frags<D>(bu[b], n2, P.user_emb, u, ok, h);
 #pragma unroll
@@ -581,26 +929,47 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
     Frag16 ft;
     ft.u = make_uint4(h == 0 ? ((__float_as_uint(th) >> 16) | (((__float_as_uint(cu) >> 16) | 0x8000u) << 16)) : 0u, 0u, 0u, 0u);
     bth[b] = ft.v;
-    cnt[b] = 0;
-    mine[b] = P.cand + (((size_t)split * P.n_users + (ok ? u : 0)) * 2 + h) * kPfCap;
+    }
   }
+  // (CLS) the users' fragments for item norms <= N: scale = +-1 / |T_u - c ||u|| N| (sweep_user_scale), times the block's
+  // start constant.  Row, norm and threshold are read again (L2), not kept: a walk re-scales a few dozen times, and the
+  // registers they would take cost the kernel its third wave per SIMD.
+  auto rescale = [&](float N) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < UB; ++b) {
+      const int64_t uc = (ublock0 + b) * 32 + ur;
+      const bool ok = uc < n_act;
+      const int64_t u = (P.user_map && ok) ? (int64_t)P.user_map[uc] : uc;
+      const float *urow = ok ? P.user_emb + (size_t)u * D : nullptr;
+      float n2 = user_half_norm2<D>(urow, h);
+      n2 += __shfl_xor(n2, 32, 64);
+      float th = INFINITY;  // padding users never qualify
+      if (ok) {
+        th = thr_src[u];
+        if (!(th == th)) th = -INFINITY;    // (a NaN threshold = none: every item is a candidate, the user fails over)
+      }
+      const float sc = sweep_start<UB>(b) * sweep_user_scale(th, sqrtf(n2), N, flip[b]);
+      load_user_frags_scaled<D>(bu[b], urow, h, sc);
+    }
+  };
+  int cur_nb = 0;                        // bits of the bound the fragments are scaled for
 
-  auto consume = [&](const uint4 (&a)[D / 16 + 1], int t, int seq) __attribute__((always_inline)) {
+  auto consume = [&](const uint4 (&a)[FR], int t, int seq) __attribute__((always_inline)) {
     const uint32_t j0 = (uint32_t)t * 32u;
     // all UB accumulation chains first, k-step major: UB independent MFMAs between two dependent ones
     f32x16 accs[UB];
 #pragma unroll
     for (int b = 0; b < UB; ++b)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) accs[b][i] = 0.f;
+      for (int i = 0; i < 16; ++i) accs[b][i] = CLS ? sweep_start<UB>(b) : 0.f;
 #pragma unroll
     for (int q = 0; q < D / 16; ++q) {
       Frag16 f;
       f.u = a[q];
 #pragma unroll
-      for (int b = 0; b < UB; ++b) accs[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v, bu[b][q], accs[b], 0, 0, 0);  // -s~
+      for (int b = 0; b < UB; ++b) accs[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v, bu[b][q], accs[b], 0, 0, 0);  // -s~ | C -+ s~'
     }
-    {
+    if constexpr (!CLS) {
       Frag16 fa;
       fa.u = a[D / 16];
 #pragma unroll
@@ -612,10 +981,11 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
       f32x16 &acc = accs[b];
       // (rows past the table are zero vectors with a zero norm: they qualify when T_u < 0; the selection drops them --
       //  masking them here put 42 more instructions into every tile's block for 31 rows of the whole table)
-      // bit (15 - reg) <=> v_j > T_u: the accumulator's sign bit
+      // bit (15 - reg) <=> v_j > T_u: the accumulator's sign bit (CLS: ^ flip)
       uint32_t qbits = 0;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) qbits = __builtin_amdgcn_alignbit(qbits, __float_as_uint(acc[reg]), 31);
+      if constexpr (CLS) qbits ^= flip[b];
       if (qbits) {
         // past kPfCap entries are counted, not stored: the selection sees the overflow and flags the user
         const uint32_t entry = ((uint32_t)seq << 16) | qbits;
@@ -634,7 +1004,11 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   // while stage s is consumed from LDS; one barrier per stage.
   constexpr int PER = (kSweepStage * FR * 64 + 64 * kSweepWaves - 1) / (64 * kSweepWaves);   // uint4 per thread and stage
   uint4 pre[PER];
+  float pre_nb = 0.f;
   auto fetch = [&](int s0) __attribute__((always_inline)) {
+    // (CLS) the bound of the stage's first tile (it exists) = of all its tiles: non-increasing in t.  Every lane loads
+    // it with the stage's fragments (one address); it is looked at after the wait for those
+    if constexpr (CLS) pre_nb = P.tile_bound[split + kSweepStage * s0 * splits];
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int e = threadIdx.x + p * 64 * kSweepWaves;          // element of the stage: tile slot i, fragment word w
@@ -654,27 +1028,46 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   };
   const int n_mine = split < n_tiles ? (n_tiles - split + splits - 1) / splits : 0;   // tiles of this split
   const int n_stages = (n_mine + kSweepStage - 1) / kSweepStage;
+  int next_nb = 0;                       // (CLS) bits of the bound of the stage that was staged last
   if (n_stages > 0) {
     fetch(0);
     stash(0);
+    if constexpr (CLS) next_nb = __builtin_amdgcn_readfirstlane(__float_as_int(pre_nb));
   }
   __syncthreads();
-  for (int s0 = 0; s0 < n_stages; ++s0) {
-    const int buf = s0 & 1;
-    if (s0 + 1 < n_stages) fetch(s0 + 1);
+  // Outer loop (CLS; otherwise one pass): one turn per run of stages with the same bound -- the users' fragments are
+  // (re-)scaled at its top, where nothing of the tile loop is live, and are loop constants of the inner loop.
+  int s0 = 0;
+  while (s0 < n_stages) {                                         // block-uniform
+    if constexpr (CLS) {
+      cur_nb = next_nb;
+      rescale(__int_as_float(cur_nb));
+    }
+    for (;;) {
+      const int buf = s0 & 1;
+      if (s0 + 1 < n_stages) fetch(s0 + 1);
 #pragma unroll
-    for (int i = 0; i < kSweepStage; ++i) {
-      const int seq = kSweepStage * s0 + i;
-      const int t = split + seq * splits;
-      if (t < n_tiles) {                                          // block-uniform
-        uint4 a[FR];
+      for (int i = 0; i < kSweepStage; ++i) {
+        const int seq = kSweepStage * s0 + i;
+        const int t = split + seq * splits;
+        if (t < n_tiles) {                                        // block-uniform
+          uint4 a[FR];
 #pragma unroll
-        for (int q = 0; q < FR; ++q) a[q] = stage[buf][i][q * 64 + lane];
-        consume(a, t, seq);
+          for (int q = 0; q < FR; ++q) a[q] = stage[buf][i][q * 64 + lane];
+          consume(a, t, seq);
+        }
+      }
+      if (s0 + 1 < n_stages) {
+        stash(buf ^ 1);
+        if constexpr (CLS) next_nb = __builtin_amdgcn_readfirstlane(__float_as_int(pre_nb));
+      }
+      __syncthreads();
+      ++s0;
+      if (s0 >= n_stages) break;
+      if constexpr (CLS) {
+        if (next_nb != cur_nb) break;                             // the walk enters another run of classes
       }
     }
-    if (s0 + 1 < n_stages) stash(buf ^ 1);
-    __syncthreads();
   }
 #pragma unroll
   for (int b = 0; b < UB; ++b) {
@@ -1112,6 +1505,11 @@ __device__ __forceinline__ void select_user(const PrefArgs &P, const int64_t u, 
     }
     if (n_cand > MAXC) why = 3;
     __builtin_amdgcn_wave_barrier();
+    if (P.perm && why == 0) {        // norm-sorted table: positions of the packed table -> items (all < n_items, see above)
+#pragma unroll 1
+      for (int i = lane; i < n_cand; i += 64) cand_s[i] = (uint32_t)P.perm[cand_s[i]];
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   uint64_t e0 = 0ull, e1 = 0ull;      // the 128 best keys, descending over (e0, e1)
   if (why == 0) {
@@ -1310,6 +1708,11 @@ __device__ __forceinline__ void rethreshold_user(const PrefArgs &P, const int64_
   }
   const int n_cand = min(n_raw, MAXC);
   __builtin_amdgcn_wave_barrier();
+  if (P.perm) {
+#pragma unroll 1
+    for (int i = lane; i < n_cand; i += 64) cand_s[i] = (uint32_t)P.perm[cand_s[i]];
+    __builtin_amdgcn_wave_barrier();
+  }
   auto in_hist = [&](uint32_t item) -> bool {
     int lo = 0, hi = deg;
     while (lo < hi) {

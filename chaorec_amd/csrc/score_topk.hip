@@ -805,6 +805,10 @@ struct ScorePlan {
   size_t off_pf_retry, off_pf_wide, off_pf_ncand, off_pf_fb, off_pf_fbdone, off_pf_fbpart, off_pf_inorm, pf_zero_bytes;
   bool pf_reth;                // pass C: raised thresholds for overflowing users (long item ranges)
   size_t off_pf_reth, off_pf_rt2;
+  bool pf_cls;                 // norm-sorted packed table, the bound without its MFMA (score_prefilter.hpp "norm classes")
+  int pf_cls_blocks;           // blocks of the counting sort (kClsChunk items each)
+  size_t off_pf_perm, off_pf_inv, off_pf_tbound, off_pf_key, off_pf_bhist, off_pf_bmax, off_pf_segb, off_pf_spacked;
+  int64_t pf_sample_tiles;     // tiles of the sampler's own table (every pf_sample_stride-th item of the sorted order)
   bool pf_group_fb;            // large item ranges: the first kPfFbGroupCap queued users share f32 MFMA sweeps
   int pf_group_fb_splits;
   size_t off_pf_fbgroup;
@@ -820,16 +824,18 @@ struct ScorePlan {
 #endif
 // Workgroup slots of the sweep kernel THAT IS LAUNCHED on this device (workgroups per CU x CUs), queried once; without a
 // device (the CPU-side workspace query) the gfx950 defaults.
-static int sweep_wave_slots(int D) {
-  static int cached[2] = {0, 0};
-  int &c = cached[D == 64 ? 0 : 1];
+static int sweep_wave_slots(int D, bool cls) {
+  static int cached[4] = {0, 0, 0, 0};
+  int &c = cached[(D == 64 ? 0 : 1) + (cls ? 2 : 0)];
   if (c) return c;
   int per_cu = 0, cus = 0, dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e == hipSuccess) {
-    if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>, 64 * kSweepWaves, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>, 64 * kSweepWaves, 0);
+    if (D == 64 && !cls) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, false>, 64 * kSweepWaves, 0);
+    else if (D == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, true>, 64 * kSweepWaves, 0);
+    else if (!cls) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, false>, 64 * kSweepWaves, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, true>, 64 * kSweepWaves, 0);
   }
   if (e != hipSuccess || per_cu <= 0 || cus <= 0) {
     (void)hipGetLastError();
@@ -837,6 +843,14 @@ static int sweep_wave_slots(int D) {
   }
   c = per_cu * cus;      // workgroup slots (kSweepWaves waves each)
   return c;
+}
+
+// from how many items on the packed table is norm-sorted (CHAOREC_PF_CLS_MIN_ITEMS overrides -- tests run the sorted path on
+// small tables with it, 0 switches it off; read per call: a getenv next to a dozen launches)
+static int64_t cls_min_items() {
+  const char *e = std::getenv("CHAOREC_PF_CLS_MIN_ITEMS");
+  const int64_t v = e && *e ? std::atoll(e) : 131072;
+  return v <= 0 ? INT64_MAX : v;
 }
 
 static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
@@ -876,11 +890,19 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   // bf16 prefilter + exact re-score: D in {64, 128}, enough tiles for the sampler's statistics
   p.prefilter = (D == 64 || D == 128) && K <= 64 && n_tiles >= 128 && n_tiles <= (int64_t)65535 * kPfMaxSplits;
   p.pf_ub = D == 64 ? CHAOREC_PF_UB64 : CHAOREC_PF_UB128;
+  // very long item ranges: every 8th tile still samples >= 64 k items per user, and the sampler streams the packed
+  // table once per 32 users
+  p.pf_sample_stride = n_tiles > 32768 ? 16 : (n_tiles > 16384 ? 8 : 4);
+  // a sampler wave's share of the sample fits its 24-slot lists up to ~16 k items; longer ranges take the
+  // streaming-top-r instantiation (32 slots, fewer and longer waves)
+  p.pf_sample_long = n_tiles > 512;
+  p.pf_cls = p.prefilter && p.pf_sample_long && n_items >= cls_min_items();
+  p.pf_cls_blocks = (int)((n_tiles * 32 + kClsChunk - 1) / kClsChunk);
   {
     const int64_t ublocks = (groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves);   // workgroups per split
     // one full round of 2 waves per SIMD (2048 slots) when the user blocks allow it: a second, partly filled
     // round costs a whole wave time
-    int64_t sp = sweep_wave_slots(D) / ublocks;
+    int64_t sp = sweep_wave_slots(D, p.pf_cls) / ublocks;
     // ~200 candidates per user (~300 with the coarser sample of very long item ranges) over 2 * splits lists of
     // kPfCap = 64 entries: keep the lists short
     const int64_t sp_min = n_tiles > 16384 ? 10 : 6;
@@ -891,12 +913,6 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
     if (sp < 1) sp = 1;
     p.pf_splits = (int)sp;
   }
-  // very long item ranges: every 8th tile still samples >= 64 k items per user, and the sampler streams the packed
-  // table once per 32 users
-  p.pf_sample_stride = n_tiles > 32768 ? 16 : (n_tiles > 16384 ? 8 : 4);
-  // a sampler wave's share of the sample fits its 24-slot lists up to ~16 k items; longer ranges take the
-  // streaming-top-r instantiation (32 slots, fewer and longer waves)
-  p.pf_sample_long = n_tiles > 512;
   p.pf_sample_splits = p.pf_sample_long ? 3 : 4;
   #ifndef CHAOREC_PF_RANK
 #define CHAOREC_PF_RANK 8
@@ -906,6 +922,15 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 64 * (size_t)(D / 16 + 1) * 16 : 0);
   p.off_pf_inorm = take(p.prefilter ? (size_t)n_tiles * 32 * 4 : 0);
+  p.off_pf_perm = take(p.pf_cls ? (size_t)n_tiles * 32 * 4 : 0);
+  p.off_pf_inv = take(p.pf_cls ? (size_t)n_items * 4 : 0);
+  p.off_pf_tbound = take(p.pf_cls ? (size_t)n_tiles * 4 : 0);
+  p.off_pf_key = take(p.pf_cls ? (size_t)n_tiles * 32 : 0);
+  p.off_pf_bhist = take(p.pf_cls ? (size_t)256 * p.pf_cls_blocks * 4 : 0);
+  p.off_pf_bmax = take(p.pf_cls ? (size_t)p.pf_cls_blocks * 4 : 0);
+  p.off_pf_segb = take(p.pf_cls ? (size_t)256 * 4 : 0);
+  p.pf_sample_tiles = (n_tiles + p.pf_sample_stride - 1) / p.pf_sample_stride;
+  p.off_pf_spacked = take(p.pf_cls ? (size_t)p.pf_sample_tiles * 64 * (size_t)(D / 16) * 16 : 0);
   // scalars | tau_sum | fb_done sit back to back: cleared together by the pack launch
   p.off_pf_scalars = take(p.prefilter ? 256 : 0);
   p.off_pf_tau = take(p.prefilter ? (size_t)n_users * 4 : 0);
@@ -1070,6 +1095,12 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.K = K;
     P.id_offset = id_offset;
     P.item_norm = (float *)(ws + p.off_pf_inorm);
+    P.perm = p.pf_cls ? (const int32_t *)(ws + p.off_pf_perm) : nullptr;
+    P.inv = p.pf_cls ? (const int32_t *)(ws + p.off_pf_inv) : nullptr;
+    P.tile_bound = p.pf_cls ? (const float *)(ws + p.off_pf_tbound) : nullptr;
+    P.sample_packed = p.pf_cls ? (const uint4 *)(ws + p.off_pf_spacked) : nullptr;
+    P.n_sample_tiles = (int)p.pf_sample_tiles;
+    P.sample_phase = p.pf_sample_stride / 2;
     P.retry_cnt = nullptr;
     P.retry_list = (int *)(ws + p.off_pf_retry);
     P.wide_cnt = nullptr;
@@ -1107,7 +1138,26 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     int *reth_cnt = (int *)(ws + p.off_pf_scalars + 32);
     int *retry_cnt = (int *)(ws + p.off_pf_scalars + 64);
     const int64_t nfrag = n_tiles * (D / 16) * 64;
-    if (do_front) {
+    if (do_front && p.pf_cls) {
+      // norm classes -> stable counting sort -> the pack of the sorted table (which also clears the call's counters)
+      const int NB = p.pf_cls_blocks;
+      const int64_t n_pad = n_tiles * 32;
+      const int min_seg = (int)std::max<int64_t>(1, n_items / kClsSegments);
+      hipLaunchKernelGGL(score_norm_class_kernel, dim3((unsigned)NB), dim3(256), 0, st, item_emb, n_items, (int)D, n_pad,
+                         (uint8_t *)(ws + p.off_pf_key), (int *)(ws + p.off_pf_bhist), NB, (int *)(ws + p.off_pf_bmax));
+      hipLaunchKernelGGL(score_class_scan_kernel, dim3(1), dim3(1024), 0, st, (int *)(ws + p.off_pf_bhist), NB,
+                         (const int *)(ws + p.off_pf_bmax), (float *)(ws + p.off_pf_segb), n_pad, min_seg);
+      hipLaunchKernelGGL(score_class_scatter_kernel, dim3((unsigned)NB), dim3(64), 0, st, (const uint8_t *)(ws + p.off_pf_key),
+                         (const int *)(ws + p.off_pf_bhist), NB, n_pad, n_items, (int32_t *)(ws + p.off_pf_perm),
+                         (int32_t *)(ws + p.off_pf_inv), (const float *)(ws + p.off_pf_segb), (float *)(ws + p.off_pf_tbound));
+      const int64_t nfrag_s = (n_tiles + p.pf_sample_tiles) * (D / 16) * 64;
+      hipLaunchKernelGGL(pack_items_bf16_sorted_kernel, dim3((unsigned)((nfrag_s + 255) / 256)), dim3(256), 0, st, item_emb,
+                         (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.perm,
+                         (uint4 *)(ws + p.off_pf_spacked), p.pf_sample_tiles, p.pf_sample_stride, P.sample_phase,
+                         (uint4 *)(ws + p.off_pf_scalars), (int64_t)(p.pf_zero_bytes / 16));
+      rc = check_launch("pack_items_bf16_sorted_kernel");
+      if (rc) return rc;
+    } else if (do_front) {
       hipLaunchKernelGGL(pack_items_bf16_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, item_emb,
                          (uint4 *)(ws + p.off_pf_packed), n_items, (int)D, n_tiles, P.item_norm,
                          (uint4 *)(ws + p.off_pf_scalars), (int64_t)(p.pf_zero_bytes / 16));
@@ -1123,8 +1173,13 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     //  the wide selection is then a main pass, not a tail -- 256 one-wave workgroups took 106 ms per 1.1 M users at 2 M items)
     const unsigned sel_wide = p.pf_sample_stride >= 8 ? sel_queue : 256u;
     auto sweep = [&](const PrefArgs &A) {
-      if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64>), gw, dim3(64 * kSweepWaves), 0, st, A);
-      else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128>), gw, dim3(64 * kSweepWaves), 0, st, A);
+      if (p.pf_cls) {
+        if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, true>), gw, dim3(64 * kSweepWaves), 0, st, A);
+        else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, true>), gw, dim3(64 * kSweepWaves), 0, st, A);
+      } else {
+        if (D == 64) hipLaunchKernelGGL((score_sweep_bf16_kernel<64, CHAOREC_PF_UB64, false>), gw, dim3(64 * kSweepWaves), 0, st, A);
+        else hipLaunchKernelGGL((score_sweep_bf16_kernel<128, CHAOREC_PF_UB128, false>), gw, dim3(64 * kSweepWaves), 0, st, A);
+      }
     };
     auto select = [&](const PrefArgs &A, unsigned grid) {
       if (D == 64) hipLaunchKernelGGL((score_select_kernel_pf<64, kPfMaxCand>), dim3(grid), dim3(64), 0, st, A);
@@ -1136,11 +1191,13 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     };
     auto sample = [&](const PrefArgs &A) {
       if (D == 64) {
-        if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true, 4>), gs4, dim3(256), 0, st, A);
-        else hipLaunchKernelGGL((score_sample_bf16_kernel<64, 24, false, 1>), gs, dim3(64), 0, st, A);
+        if (p.pf_cls) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true, 4, true>), gs4, dim3(256), 0, st, A);
+        else if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<64, 32, true, 4, false>), gs4, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((score_sample_bf16_kernel<64, 24, false, 1, false>), gs, dim3(64), 0, st, A);
       } else {
-        if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true, 4>), gs4, dim3(256), 0, st, A);
-        else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false, 1>), gs, dim3(64), 0, st, A);
+        if (p.pf_cls) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true, 4, true>), gs4, dim3(256), 0, st, A);
+        else if (p.pf_sample_long) hipLaunchKernelGGL((score_sample_bf16_kernel<128, 32, true, 4, false>), gs4, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((score_sample_bf16_kernel<128, 24, false, 1, false>), gs, dim3(64), 0, st, A);
       }
     };
     // Pass A (carried thresholds) certifies nearly everybody in steady state.  What is left goes to pass B (sampled

@@ -32,7 +32,7 @@ def _hist_random(U, I, max_deg, seed):
 @pytest.mark.parametrize("D", [64, 128])
 def test_score_topk_overflowing_users_get_a_raised_threshold(dev, oracle, D):
     """Long item range (>= 131072 items: the exact route would stream the table per user).  Two thirds of the users see
-    6000 high-scoring items that all lie in tiles the sampler never visits (stride 4: it samples tiles = 0 mod 4), so their sampled
+    6000 high-scoring items that all lie where the sampler never looks (stride 4: tiles = 0 mod 4 / items = 2 mod 4), so their sampled
     threshold is far too low and every sweep list overflows.  Pass C re-scores what the lists kept, raises the threshold
     and sweeps those users once more: they must come out certified (no exact-route user) with the oracle's bits -- Model/
     LightGCN.py:147-155's top-K of the masked score row, ties to the lowest index."""
@@ -42,7 +42,9 @@ def test_score_topk_overflowing_users_get_a_raised_threshold(dev, oracle, D):
     ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
     ie = (rng.standard_normal((I, D)) * 0.05).astype(np.float32)
     tiles = np.arange(I) // 32
-    pool = np.flatnonzero(tiles % 4 != 0)
+    # (tables in their own order: the sampler takes every 4th TILE; norm-sorted tables -- the default at this length, and
+    #  this table keeps its order there, see below --: every 4th ITEM, position = 2 mod 4)
+    pool = np.flatnonzero((tiles % 4 != 0) & (np.arange(I) % 4 != 2))
     hot = rng.choice(pool, 6000, replace=False)
     # the hot items have the cold items' NORM (the sweep's error band is c ||u|| max ||i||: one bound for the table) but
     # share a direction v; two thirds of the users have a large component along v and score them far above everything else
@@ -50,6 +52,9 @@ def test_score_topk_overflowing_users_get_a_raised_threshold(dev, oracle, D):
     v /= np.linalg.norm(v)
     cold_norm = float(np.linalg.norm(ie, axis=1).mean())
     hd = v[None, :] * rng.uniform(0.6, 1.0, (6000, 1)).astype(np.float32) + rng.standard_normal((6000, D)).astype(np.float32) * 0.05
+    # (every item at exactly that norm: one norm class, so the norm-sorted layout of long ranges -- a stable sort -- keeps the
+    #  table's order and the hot items stay in the tiles the sampler skips)
+    ie = (ie / np.linalg.norm(ie, axis=1, keepdims=True) * cold_norm).astype(np.float32)
     ie[hot] = (hd / np.linalg.norm(hd, axis=1, keepdims=True) * cold_norm).astype(np.float32)
     ue -= (ue @ v)[:, None] * v[None, :]                  # nobody sees the hot items ...
     ue[1::3] += 2.0 * v[None, :]                          # ... except these
@@ -239,3 +244,105 @@ def test_score_topk_scaled_thresholds_edge_cases(dev, oracle, D):
         hint[shift::3] = junk[(torch.arange(len(hint[shift::3]), device=dev) + shift) % len(junk)]
         got_i, got_v = ops.score_topk(due, die, dh, 1e-6, K, id_offset=U, hint=hint, hint_valid=True)
         assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i), shift
+
+
+# ---- norm-sorted packed tables (score_prefilter.hpp "norm classes"): the bound without its MFMA ----------------------------
+class _env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_score_topk_norm_sorted_table_equals_the_oracle(dev, oracle, D):
+    """The long-range layout forced onto a table the oracle ranks in seconds (CHAOREC_PF_CLS_MIN_ITEMS): items sorted by norm
+    class, users' fragments re-scaled per run of classes, candidates mapped back through the permutation.  Item norms span
+    five octaves (so the walk re-scales many times and several runs are merged), some items are zero rows, some users have
+    all-negative scores, zero / tiny / huge rows; history members among the best items.  Cold call, carried thresholds, and
+    carried thresholds that are garbage must all give Model/LightGCN.py:147-155's top-K bit for bit."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(100 + D)
+    U, I, K = 200, 20000, 50
+    ue = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * 0.1).astype(np.float32)
+    ie *= np.exp2(rng.uniform(-3.0, 2.0, (I, 1))).astype(np.float32)
+    ie[rng.choice(I, 50, replace=False)] = 0.0
+    ie[:, 0] = np.abs(ie[:, 0])
+    ue[0:32, 0] = -3.0                  # (nearly) all scores negative: T_u < 0
+    ue[32:40] = 0.0
+    ue[40:48] *= 1e-18
+    ue[48:56] *= 1e12
+    rp, cl = _hist_random(U, I, 20, seed=D)
+    raw = ue.astype(np.float64) @ ie.astype(np.float64).T
+    rows = [cl[rp[u]:rp[u + 1]] for u in range(U)]
+    for u in range(0, U, 5):            # the best items of some users are in their history
+        rows[u] = np.unique(np.r_[rows[u], np.argsort(-raw[u])[:30]]).astype(np.int32)
+    hist = (np.r_[0, np.cumsum([len(r) for r in rows])].astype(np.int64), np.concatenate(rows).astype(np.int32))
+    want_i, want_v = oracle.score_topk(ue, ie, hist, 1e-6, K, U)
+    dh = (torch.from_numpy(hist[0]).to(dev), torch.from_numpy(hist[1]).to(dev))
+    due, die = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
+    with _env(CHAOREC_PF_CLS_MIN_ITEMS=1):
+        hint = torch.empty(U, device=dev)
+        st = {}
+        got_i, got_v = ops.score_topk(due, die, dh, 1e-6, K, id_offset=U, hint=hint, hint_valid=False, stats=st)
+        assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i)
+        assert st["prefilter_users"] == U and st["fallback_users"] <= 24, st
+        good = hint.clone()
+        st = {}
+        got_i, got_v = ops.score_topk(due, die, dh, 1e-6, K, id_offset=U, hint=hint, hint_valid=True, stats=st)
+        assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i)
+        assert st["fallback_users"] <= 16, st
+        junk = torch.tensor([0.0, -0.0, 1e-38, -1e-38, 1e-30, -1e-30, 1e30, -1e30, 3e38, -3e38, float("nan"), float("inf"),
+                             float("-inf"), 1.0, -1.0, 1e-3], device=dev)
+        for shift in range(3):
+            hint = good.clone()
+            hint[shift::3] = junk[(torch.arange(len(hint[shift::3]), device=dev) + shift) % len(junk)]
+            got_i, got_v = ops.score_topk(due, die, dh, 1e-6, K, id_offset=U, hint=hint, hint_valid=True)
+            assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i), shift
+
+
+@pytest.mark.parametrize("D,law", [(128, "lognormal"), (64, "level"), (128, "outliers")])
+def test_score_topk_norm_sorted_table_equals_the_table_in_its_own_order(dev, D, law):
+    """Long item range (the default there): the sorted layout against the per-item bound on its own MFMA k-step
+    (CHAOREC_PF_CLS_MIN_ITEMS=0), every row of a few thousand users, cold and with carried thresholds.  Same indices and
+    values; the candidate sets may differ (the bound of a run of classes is its largest norm), but not by much."""
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev).manual_seed(7 + D)
+    U, I, K = 4096, 200_000, 50
+    ue = torch.randn(U, D, generator=g, device=dev) * 0.1
+    ie = torch.randn(I, D, generator=g, device=dev) * 0.1
+    if law == "lognormal":
+        ie *= torch.exp2(torch.randn(I, 1, generator=g, device=dev) * 0.7)
+    elif law == "outliers":
+        ie[torch.randint(0, I, (300,), generator=g, device=dev)] *= 30.0
+        ie[torch.randint(0, I, (5,), generator=g, device=dev)] *= 1e6
+    rowptr = torch.arange(U + 1, dtype=torch.int64, device=dev) * 6
+    col = ((torch.arange(U * 6, device=dev) % 6) * 30011 + torch.arange(U * 6, device=dev) // 6 * 7 % 30011).to(torch.int32)
+    hist = (rowptr, col)
+    res = {}
+    for name, v in (("own", 0), ("sorted", 131072)):
+        with _env(CHAOREC_PF_CLS_MIN_ITEMS=v):
+            hint = torch.empty(U, device=dev)
+            st, st2 = {}, {}
+            i0, v0 = ops.score_topk(ue, ie, hist, 1e-6, K, id_offset=U, hint=hint, hint_valid=False, stats=st)
+            ue2 = ue + 0.002 * torch.randn(U, D, generator=torch.Generator(device=dev).manual_seed(1), device=dev)
+            i1, v1 = ops.score_topk(ue2, ie, hist, 1e-6, K, id_offset=U, hint=hint, hint_valid=True, stats=st2)
+            torch.cuda.synchronize()
+            res[name] = (i0, v0, i1, v1, st, st2)
+    a, b = res["own"], res["sorted"]
+    for k in range(4):
+        assert torch.equal(a[k], b[k]), k
+    for k in (4, 5):
+        assert b[k]["fallback_users"] <= a[k]["fallback_users"] + 8, (a[k], b[k])
+        assert b[k]["candidates"] <= 1.25 * a[k]["candidates"] + 64 * U, (a[k], b[k])
