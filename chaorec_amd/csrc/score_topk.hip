@@ -853,6 +853,11 @@ static int64_t cls_min_items() {
   return v <= 0 ? INT64_MAX : v;
 }
 
+static int env_int(const char *name, int dflt) {
+  const char *e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+
 static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   ScorePlan p;
   const int64_t n_tiles = (n_items + 31) / 32;
@@ -897,6 +902,11 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   // streaming-top-r instantiation (32 slots, fewer and longer waves)
   p.pf_sample_long = n_tiles > 512;
   p.pf_cls = p.prefilter && p.pf_sample_long && n_items >= cls_min_items();
+  // The sorted layout's sampler takes every stride-th ITEM of the sorted order, strata dealt evenly to its waves: a
+  // systematic sample, stratified by norm -- half the sample gives the spread a sample of whole tiles had (config-5 shard,
+  // propagated tables: every 32nd item at rank 4 = 0 of 1.25 M users with fewer than K candidates, 782 through pass C, call
+  // 555 -> 534 ms against every 16th at rank 7; rank 3: 62 users on the exact routes).  CHAOREC_PF_CLS_STRIDE / _RANK override.
+  if (p.pf_cls) p.pf_sample_stride = std::max(1, env_int("CHAOREC_PF_CLS_STRIDE", 2 * p.pf_sample_stride));
   p.pf_cls_blocks = (int)((n_tiles * 32 + kClsChunk - 1) / kClsChunk);
   {
     const int64_t ublocks = (groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves);   // workgroups per split
@@ -917,7 +927,8 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   #ifndef CHAOREC_PF_RANK
 #define CHAOREC_PF_RANK 8
 #endif
-  p.pf_sample_rank = p.pf_sample_long ? (p.pf_sample_stride == 16 ? 7 : (p.pf_sample_stride == 8 ? 10 : 14)) : CHAOREC_PF_RANK;
+  p.pf_sample_rank = p.pf_sample_long ? (p.pf_sample_stride >= 16 ? 7 : (p.pf_sample_stride == 8 ? 10 : 14)) : CHAOREC_PF_RANK;
+  if (p.pf_cls) p.pf_sample_rank = std::max(1, env_int("CHAOREC_PF_CLS_RANK", p.pf_sample_stride >= 32 ? 4 : (p.pf_sample_stride >= 16 ? 6 : 8)));
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) / 256 * 256; return at; };
   p.off_pf_packed = take(p.prefilter ? (size_t)n_tiles * 64 * (size_t)(D / 16 + 1) * 16 : 0);

@@ -12,7 +12,8 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import BPRMF, FREEDOM, LayerGCN, LightGCN, MCLN, MGCN, MMGCN, NCL, NGCF, SelfCF, SimGCL, SLMRec, VBPR, XSimGCL
+from .Model import (BPRMF, DHCF, FREEDOM, LGMRec, LayerGCN, LightGCN, MCLN, MGCN, MMGCN, NCL, NGCF, POWERec, SelfCF, SimGCL, SLMRec,
+                    SMORE, VBPR, XSimGCL)
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
 from .optim import FusedAdam
@@ -66,6 +67,15 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
         # the one reader of the sampler's second negative (main.py:354-355, dataload.py:81-84)
         'MCLN': lambda: MCLN(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                              args.n_layers, args.n_mca, device),
+        # round 5: four more members (main.py:318-320, :342-343, :358-359, :377-378)
+        'POWERec': lambda: POWERec(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
+                                   args.n_layers, int(args.prompt_num), args.neg_weight, args.dropout, device),
+        'LGMRec': lambda: LGMRec(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
+                                 args.n_layers, args.ssl_alpha, device),
+        'DHCF': lambda: DHCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
+                             args.dropout, device),
+        'SMORE': lambda: SMORE(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
+                               args.n_ui_layers, args.ii_topk, args.dropout, args.data_path, device),
     }
     if args.Model not in table:
         raise SystemExit(f"--Model {args.Model}: only {sorted(table)} are on the MI355X hot path")
@@ -84,7 +94,7 @@ def main(argv=None):
     if device.type != "cuda":
         raise SystemExit("chaorec_amd runs on the MI355X only: no GPU visible")
     config = load_yaml_config(args.Model)
-    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN")
+    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE")
     train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat = dataload.data_load(
         args.data_path, has_v=needs_feat, has_t=needs_feat, data_root=args.data_root, synthetic=args.synthetic)
     if args.host_sampler:

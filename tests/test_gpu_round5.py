@@ -32,7 +32,7 @@ def _hist_random(U, I, max_deg, seed):
 @pytest.mark.parametrize("D", [64, 128])
 def test_score_topk_overflowing_users_get_a_raised_threshold(dev, oracle, D):
     """Long item range (>= 131072 items: the exact route would stream the table per user).  Two thirds of the users see
-    6000 high-scoring items that all lie where the sampler never looks (stride 4: tiles = 0 mod 4 / items = 2 mod 4), so their sampled
+    6000 high-scoring items that all lie where the sampler never looks (tiles = 0 mod 4 / items = 4 mod 8), so their sampled
     threshold is far too low and every sweep list overflows.  Pass C re-scores what the lists kept, raises the threshold
     and sweeps those users once more: they must come out certified (no exact-route user) with the oracle's bits -- Model/
     LightGCN.py:147-155's top-K of the masked score row, ties to the lowest index."""
@@ -43,8 +43,8 @@ def test_score_topk_overflowing_users_get_a_raised_threshold(dev, oracle, D):
     ie = (rng.standard_normal((I, D)) * 0.05).astype(np.float32)
     tiles = np.arange(I) // 32
     # (tables in their own order: the sampler takes every 4th TILE; norm-sorted tables -- the default at this length, and
-    #  this table keeps its order there, see below --: every 4th ITEM, position = 2 mod 4)
-    pool = np.flatnonzero((tiles % 4 != 0) & (np.arange(I) % 4 != 2))
+    #  this table keeps its order there, see below --: every 8th ITEM, position = 4 mod 8)
+    pool = np.flatnonzero((tiles % 4 != 0) & (np.arange(I) % 4 != 0))
     hot = rng.choice(pool, 6000, replace=False)
     # the hot items have the cold items' NORM (the sweep's error band is c ||u|| max ||i||: one bound for the table) but
     # share a direction v; two thirds of the users have a large component along v and score them far above everything else
@@ -345,4 +345,4 @@ def test_score_topk_norm_sorted_table_equals_the_table_in_its_own_order(dev, D, 
         assert torch.equal(a[k], b[k]), k
     for k in (4, 5):
         assert b[k]["fallback_users"] <= a[k]["fallback_users"] + 8, (a[k], b[k])
-        assert b[k]["candidates"] <= 1.25 * a[k]["candidates"] + 64 * U, (a[k], b[k])
+        assert b[k]["candidates"] <= 1.5 * a[k]["candidates"] + 128 * U, (a[k], b[k])

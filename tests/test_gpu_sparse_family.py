@@ -253,3 +253,121 @@ def test_mcln_golden(dev):
         total = m.forward(batch[0].to(dev), *((b - U).to(dev) for b in batch[1:])).cpu().numpy()
     assert np.abs(total - g["total_scores"]).max() <= 2e-5 * np.abs(g["total_scores"]).max()
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["scores"], U)
+
+
+# ---- round 5: three more dependency-free members -----------------------------------------------------------
+def _golden_model_checks(m, g, dev, rtol_grad, atol_grad=0.0, skip_params=()):
+    """parameters (same seed -> the reference's weights, the reference's names), loss, every gradient"""
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    unused = set(str(n) for n in g["no_grad"])
+    for n, p in m.named_parameters():
+        if n in unused:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= rtol_grad * np.abs(ref).max() + atol_grad, n
+    return loss
+
+
+def test_powerec_golden(dev):
+    """Model/POWERec.py: three prompt-tuned LayerGCN branches through sparse.mm + the fused cosine re-weighting, the branch
+    Linears on the MFMA GEMM, the weak-modality negative; ranking over the concatenated tables of a fresh forward."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import POWERec
+    g = load_golden("powerec_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = POWERec(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+                torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]), 2, int(g["prompt_num"]), float(g["neg_weight"]), 0.0,
+                dev).to(dev)
+    m.pre_epoch_processing()
+    assert np.array_equal(_csr_dense(m.norm_adj_matrix), _coo_dense(g["norm_idx"], g["norm_val"], (U + I, U + I)))
+    _golden_model_checks(m, g, dev, 5e-5, 5e-8)
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    res = m.result.cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    _check_rank(rank, g, g["result"][:U] @ g["result"][U:].T, U)
+
+
+def test_lgmrec_golden(dev):
+    """Model/LGMRec.py: id propagate (fused layer mean), modality propagations and user <- item aggregations through sparse.mm,
+    hypergraph memberships with the reference run's recorded Gumbel draws and dropout masks (gumbel_fn / drop_fn)."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import LGMRec
+    g = load_golden("lgmrec_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = LGMRec(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+               torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]), int(g["L"]), float(g["ssl_alpha"]), dev).to(dev)
+    assert np.array_equal(_csr_dense(m.norm_adj), _coo_dense(g["norm_idx"], g["norm_val"], (U + I, U + I)))
+
+    def replay(prefix, n):
+        it = iter([torch.from_numpy(g[f"{prefix}{k}"]).to(dev) for k in range(n)])
+        return lambda x: next(it)
+
+    m.train()
+    m.gumbel_fn, m.drop_fn = replay("train_gumbel", 4), replay("train_drop", 4)
+    _golden_model_checks(m, g, dev, 1e-4, 1e-7)
+    m.eval()
+    m.gumbel_fn, m.drop_fn = replay("eval_gumbel", 4), None
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    res = m.result.cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    _check_rank(rank, g, g["result"][:U] @ g["result"][U:].T, U)
+    # and the hooks' defaults draw on the device: two forwards differ, memberships are rows of a simplex
+    m.gumbel_fn = None
+    a, b = m.forward()[0], m.forward()[0]
+    assert float((a - b).abs().max()) > 0
+
+
+def test_dhcf_golden(dev):
+    """Model/DHCF.py: the two-hop hypergraph operator as eight SpMMs per side and layer against the reference's MATERIALISED
+    [H | H H^T H] chain (torch.linalg.multi_dot): the layers' weights + biases (a plain list there: not model parameters;
+    the bias uninitialised memory) are copied in from the reference run."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import DHCF
+    g = load_golden("dhcf_small.npz")
+    U, I, L = int(g["U"]), int(g["I"]), int(g["L"])
+    torch.manual_seed(0)
+    m = DHCF(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), L, 0.0, dev).to(dev)
+    assert len(list(m.parameters())) == 2                      # the list of layers is invisible to the optimizer, as there
+    for k, layer in enumerate(m.layers):
+        assert np.array_equal(layer.weight.detach().cpu().numpy(), g[f"layer{k}_weight"])     # (same seed, same order of draws)
+        with torch.no_grad():
+            layer.bias.copy_(torch.from_numpy(g[f"layer{k}_bias"]))
+    _golden_model_checks(m, g, dev, 5e-5, 1e-8)
+    for k, layer in enumerate(m.layers):
+        for nme, p in (("weight", layer.weight), ("bias", layer.bias)):
+            ref = g[f"g_layer{k}_{nme}"]
+            assert np.abs(p.grad.cpu().numpy() - ref).max() <= 5e-5 * np.abs(ref).max() + 1e-8, (k, nme)
+    res = torch.cat([m.user_e, m.item_e], 0).detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+
+
+def test_smore_golden(dev):
+    """Model/SMORE.py: the weighted user-item graph and its R block, the two cosine-kNN item graphs and their max-pooled union
+    (built on the device here), then loss, every gradient (the trainable [I, F] feature tables included), the tables of the
+    last forward and the ranking."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import SMORE
+    g = load_golden("smore_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = SMORE(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+              torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]), int(g["L"]), int(g["K"]), 0.0, "none", dev).to(dev)
+    for csr, tag, shape in ((m.norm_adj, "norm", (U + I, U + I)), (m.R, "R", (U, I)), (m.image_original_adj, "image", (I, I)),
+                            (m.text_original_adj, "text", (I, I)), (m.fusion_adj, "fusion", (I, I))):
+        want = _coo_dense(g[tag + "_idx"], g[tag + "_val"], shape)
+        got = _csr_dense(csr)
+        assert np.array_equal(got != 0, want != 0), tag               # the same entries ...
+        assert np.abs(got - want).max() <= 2e-6, tag                  # ... (cosines of a device matmul: fp32 rounding)
+    _golden_model_checks(m, g, dev, 1e-4, 1e-7)
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
