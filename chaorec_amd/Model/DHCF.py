@@ -84,10 +84,13 @@ class DHCF(nn.Module):
         self.interaction_matrix = graph.coo_to_csr_coalesced(u, i, ones, num_user, num_item).to(device)
         self.interaction_matrix_t = graph.coo_to_csr_coalesced(i, u, ones, num_item, num_user).to(device)
         self.interaction_matrix._t, self.interaction_matrix_t._t = self.interaction_matrix_t, self.interaction_matrix
-        self.user_embedding = nn.Embedding(num_user, dim_E).to(device)
-        self.item_embedding = nn.Embedding(num_item, dim_E).to(device)
+        # (:110-117 in the reference's order of draws, on the HOST generator like every other model here -- the reference moves
+        #  the tables to its device before the xavier draw --, then moved)
+        self.user_embedding = nn.Embedding(num_user, dim_E)
+        self.item_embedding = nn.Embedding(num_item, dim_E)
         nn.init.xavier_uniform_(self.user_embedding.weight)
         nn.init.xavier_uniform_(self.item_embedding.weight)
+        self.user_embedding, self.item_embedding = self.user_embedding.to(device), self.item_embedding.to(device)
         self.layers = [DJconv(dim_E, dim_E).to(device) for _ in range(n_layers)]          # (a list: not registered, :117)
         self.dropout = [nn.Dropout(dropout).to(device) for _ in range(n_layers)]
         self._ops_u = _TwoHop(self.interaction_matrix, self.interaction_matrix_t, device)

@@ -11,7 +11,7 @@ import torch
 from .utils import EarlyStopping, EvalLists, gene_metrics, gene_metrics_device
 
 MMGCN_STYLE = ("MMGCN", "GRCN")
-PRE_EPOCH = ("FREEDOM", "LayerGCN")     # reference train_and_evaluate.py:555
+PRE_EPOCH = ("FREEDOM", "LayerGCN", "POWERec")     # reference train_and_evaluate.py:554
 E_STEP = ("NCL",)                       # reference train_and_evaluate.py:107-114
 NO_CAPTURE = ("NCL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec")    # host-side randomness / clustering inside the step: eager launches
 

@@ -322,7 +322,7 @@ def test_lgmrec_golden(dev):
     # and the hooks' defaults draw on the device: two forwards differ, memberships are rows of a simplex
     m.gumbel_fn = None
     a, b = m.forward()[0], m.forward()[0]
-    assert float((a - b).abs().max()) > 0
+    assert float((a - b).detach().abs().max()) > 0
 
 
 def test_dhcf_golden(dev):
@@ -371,3 +371,21 @@ def test_smore_golden(dev):
     res = m.result.detach().cpu().numpy()
     assert np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+
+
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE"])
+def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
+    """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
+    grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
+    import logging
+    from chaorec_amd import main as cmain, dataload
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setitem(dataload.SYNTHETIC_FEATURE_DIMS, "default", (96, 64))
+    real = cmain.load_yaml_config
+    monkeypatch.setattr(cmain, "load_yaml_config",
+                        lambda name: {k: (v if k == "hyper_parameters" else v[:1]) for k, v in real(name).items()})
+    logging.getLogger().handlers.clear()
+    best = cmain.main(["--Model", model, "--data_path", "baby", "--synthetic", "--num_epoch", "2"])
+    assert set(best.keys()) == {5, 10, 20}
+    for k in best:
+        assert 0.0 <= best[k]["recall"] <= 1.0 and np.isfinite(best[k]["ndcg"])
