@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64) void score_topk_merge_kernel(const uint64_t *__
                                                               int *__restrict__ fail,
                                                               const int *__restrict__ only_if,
                                                               const int *__restrict__ user_map,
-                                                              const int *__restrict__ n_users_dev) {
+                                                              const int *__restrict__ n_users_dev,
+                                                              float *__restrict__ hint_out = nullptr) {
   const int lane = threadIdx.x;
   const int64_t u = blockIdx.x;
   if (only_if && only_if[u] == 0) return;
@@ -492,11 +493,24 @@ __global__ __launch_bounds__(64) void score_topk_merge_kernel(const uint64_t *__
       fail[u] = ok ? 0 : 1;
     }
   }
+  const size_t uo = user_map ? (size_t)user_map[u] : (size_t)u;
   if (lane < K) {
     const uint32_t item = 0xFFFFFFFFu - (uint32_t)(e0 & 0xFFFFFFFFull);
-    const size_t uo = user_map ? (size_t)user_map[u] : (size_t)u;
     out_idx[uo * K + lane] = (int64_t)item + id_offset;
     out_val[uo * K + lane] = ord_to_f32((uint32_t)(e0 >> 32));
+  }
+  if (hint_out) {
+    // (the grouped fallback of the prefilter route: these users' thresholds cut too close -- the next call's is taken as
+    //  the exact per-user route takes it, score_exact_user_kernel: ranks 32 and 64 extrapolated as far again below rank 64.
+    //  Without it the user kept the threshold that had just failed, and failed again at every carried-threshold call.)
+    const uint32_t o31 = (uint32_t)__shfl((int)(uint32_t)(e0 >> 32), 31, 64), o63 = (uint32_t)__shfl((int)(uint32_t)(e0 >> 32), 63, 64);
+    const uint64_t ek = shfl_u64(e0, K - 1);
+    float t = nextafterf(ord_to_f32((uint32_t)(ek >> 32)), -INFINITY);
+    if (shfl_u64(e0, 63) != 0ull) {
+      const float s31 = ord_to_f32(o31), s63 = ord_to_f32(o63);
+      t = fminf(t, s63 - (s31 - s63));
+    }
+    if (lane == 0) hint_out[uo] = t;
   }
 }
 
@@ -1284,7 +1298,7 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       if (rc) return rc;
       hipLaunchKernelGGL(score_topk_merge_kernel, dim3(kPfFbGroupCap), dim3(64), 0, st, f.partial,
                          (int64_t)kPfFbGroupCap, K, f.splits, id_offset, out_idx, out_val, (const float *)nullptr,
-                         (int *)nullptr, (const int *)nullptr, (const int *)P.fb_list, (const int *)P.fb_cnt);
+                         (int *)nullptr, (const int *)nullptr, (const int *)P.fb_list, (const int *)P.fb_cnt, hint_out);
       rc = check_launch("score_topk_merge_kernel (grouped fallback)");
       if (rc) return rc;
       P.fb_skip = kPfFbGroupCap;

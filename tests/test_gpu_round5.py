@@ -93,9 +93,13 @@ def test_score_topk_pass_c_hands_hopeless_users_to_the_exact_routes(dev, oracle)
     ie = np.repeat((rng.standard_normal((1, D)) * 0.2).astype(np.float32), I, 0)
     want_i, want_v = oracle.score_topk(ue, ie, None, 1e-6, K, 0)
     st = {}
-    got_i, got_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), None, 1e-6, K, stats=st)
+    hint = torch.full((U,), float("nan"), device=dev)
+    got_i, got_v = ops.score_topk(torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev), None, 1e-6, K, stats=st, hint=hint,
+                                  hint_valid=False)
     assert np.array_equal(got_v.cpu().numpy(), want_v) and np.array_equal(got_i.cpu().numpy(), want_i)
     assert st["fallback_users"] == U, st
+    # the grouped f32 sweep leaves a threshold for the next call too (it used to leave the one that had just failed)
+    assert bool(torch.isfinite(hint).all()) and bool((hint < torch.from_numpy(want_v[:, K - 1].copy()).to(dev)).all())
 
 
 def _call(ops, lib, ue, ie, hist, K, U0, hint, hint_valid, phase, ws, idx, val, counters=None):
