@@ -18,6 +18,10 @@
 //   (T_u, -c||u||) in the sweep -- with the users' fragments negated the accumulator is T_u - v_j, a hit is its sign
 //   bit -- and (0, -c||u||) in the sampler (accumulator = the lower bound w_j = s~_j - e~_uj).
 //
+// Long item ranges (>= 131 072 items) run on a NORM-SORTED packed table instead, where the bound rides on the users' operand
+// scale and costs no MFMA at all: section "norm classes" below.  Everything in this header up to there describes the table
+// in its own order (sports: 15 k items); the certification argument is the same for both.
+//
 // Where T_u comes from:
 //   hint     the caller's per-user thresholds from the PREVIOUS call on (nearly) the same tables -- the exact score
 //            of rank hint_rank (> K) then.  One training epoch moves the scores little: ~1.7 K candidates per user

@@ -382,6 +382,12 @@ int chaorec_bpr_finalize_steps_f32(const float *workspace, int64_t ws_stride, in
  *      ranked on those values; the answer is certified when the K-th best exact score is > T_u (anything outside
  *      the candidates is then strictly beaten by K items).  T_u is estimated from a sample of the items; a user that
  *      cannot be certified (list overflow, too few / too many candidates) gets all its scores computed exactly.
+ *      From 131 072 items on (environment CHAOREC_PF_CLS_MIN_ITEMS: another length, 0 = never) the prefilter works on a
+ *      NORM-SORTED copy of the item table: items in descending order of their norm class (exponent + 3 mantissa bits), the
+ *      bound taken per run of classes instead of per item -- e_u = c ||u|| N_run folded into the users' operand scale, so
+ *      the bound costs no MFMA (one in nine at D = 128) --, thresholds sampled from every 32nd / 16th / 8th item of that
+ *      order.  Same candidates-superset guarantee, same exact re-score, same result bit for bit; the workspace holds the
+ *      permutation (chaorec_score_topk_workspace_bytes accounts for it under the same environment).
  *      Otherwise: route 2.
  *   1  one unthresholded fp32 MFMA pass (A/B runs and tests).
  *   2  fp32 MFMA sweep with a sampled per-user threshold: tau0 = 32nd best score over every s-th 32-item tile,

@@ -373,7 +373,7 @@ def test_smore_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
@@ -389,3 +389,53 @@ def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monke
     assert set(best.keys()) == {5, 10, 20}
     for k in best:
         assert 0.0 <= best[k]["recall"] <= 1.0 and np.isfinite(best[k]["ndcg"])
+
+
+def test_mmgcl_golden(dev):
+    """Model/MMGCL.py: the per-step edge-dropped and node-dropped graphs as VALUE arrays over the one CSR (dynamic-values SpMM,
+    forward and backward) against the reference's rebuilt scipy Laplacians, with the reference run's recorded draws: loss,
+    every gradient, the tables, the ranking.  Then the device draws: the right number of edges / nodes kept."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MMGCL
+    g = load_golden("mmgcl_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = MMGCL(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+              torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]), int(g["L"]), float(g["ssl_alpha"]), float(g["ssl_temp"]),
+              float(g["dropout"]), dev).to(dev)
+    want = _coo_dense(g["norm_idx"], g["norm_val"], (U + I, U + I))
+    got = _csr_dense(m.norm_adj)
+    assert np.array_equal(got != 0, want != 0) and np.abs(got - want).max() <= 2e-7
+
+    def edge_keep(n, rate):
+        k = torch.zeros(n, dtype=torch.bool)
+        k[torch.from_numpy(g["edge_keep_idx"])] = True
+        return k
+
+    def node_keep(nu, ni, rate):
+        ku, ki = torch.ones(nu, dtype=torch.bool), torch.ones(ni, dtype=torch.bool)
+        ku[torch.from_numpy(g["drop_user_idx"])] = False
+        ki[torch.from_numpy(g["drop_item_idx"])] = False
+        return ku, ki
+
+    m.edge_keep_fn, m.node_keep_fn, m.modality_fn = edge_keep, node_keep, lambda: int(g["modality"])
+    _golden_model_checks(m, g, dev, 1e-4, 1e-7)
+    res = torch.cat([m.result_user, m.result_item], 0).detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+    # the default draws (device): exactly int(E (1 - rate)) pairs kept; dropped nodes lose every entry
+    m.edge_keep_fn = m.node_keep_fn = m.modality_fn = None
+    adj = m.random_graph_augment(0)
+    assert int((adj.val[:m.n_edges] != 0).sum()) == int(m.n_edges * (1 - m.dropout_rate))
+    assert torch.equal(adj.val[m.n_edges:], adj.val[:m.n_edges][m._lower])
+    adj = m.random_graph_augment(1)
+    dense = np.zeros((U + I, U + I), np.float32)
+    rp, col = m.norm_adj.rowptr.cpu().numpy(), m.norm_adj.col.cpu().numpy()
+    v = adj.val.cpu().numpy()
+    for r in range(U + I):
+        dense[r, col[rp[r]:rp[r + 1]]] = v[rp[r]:rp[r + 1]]
+    assert np.array_equal(dense, dense.T)
+    empty_rows = int(((dense != 0).sum(1) == 0).sum())
+    assert empty_rows >= int(U * m.dropout_rate) + int(I * m.dropout_rate)
+    loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    assert bool(torch.isfinite(loss))
