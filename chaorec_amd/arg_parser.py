@@ -32,6 +32,9 @@ def build_parser():
     parser.add_argument('--prompt_num', type=float, default=0.1, help='prompt modal numbers.')
     parser.add_argument('--neg_weight', type=float, default=0.1, help='weak modal weight.')
     parser.add_argument('--n_ui_layers', type=int, default=3, help='n_ui layers.')
+    parser.add_argument('--grid_size', type=int, default=1, help='FKAN_GCF grid_size.')
+    parser.add_argument('--node_dropout', type=float, default=0.1, help='FKAN_GCF node_dropout')
+    parser.add_argument('--message_dropout', type=float, default=0.1, help='FKAN_GCF message_dropout')
     parser.add_argument('--no_graph', action='store_true',
                         help='eager launches instead of one captured hipGraph replay per training batch')
     parser.add_argument('--ii_topk', type=int, default=10, help='the number of item-item graph topk.')

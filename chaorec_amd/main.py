@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import (BPRMF, DHCF, FREEDOM, LGMRec, LayerGCN, LightGCN, MCLN, MGCN, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SimGCL, SLMRec,
+from .Model import (BPRMF, DHCF, FKAN_GCF, FREEDOM, LGMRec, LayerGCN, LightGCN, MCLN, MGCN, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SimGCL, SLMRec,
                     SMORE, VBPR, XSimGCL)
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
@@ -74,6 +74,8 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
                                  args.n_layers, args.ssl_alpha, device),
         'DHCF': lambda: DHCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
                              args.dropout, device),
+        'FKAN_GCF': lambda: FKAN_GCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
+                                     args.node_dropout, args.message_dropout, args.grid_size, device),
         'MMGCL': lambda: MMGCL(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                                args.n_layers, args.ssl_alpha, args.ssl_temp, args.dropout, device),
         'SMORE': lambda: SMORE(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,

@@ -373,7 +373,7 @@ def test_smore_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
@@ -439,3 +439,26 @@ def test_mmgcl_golden(dev):
     assert empty_rows >= int(U * m.dropout_rate) + int(I * m.dropout_rate)
     loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
     assert bool(torch.isfinite(loss))
+
+
+def test_fkan_gcf_golden(dev):
+    """Model/FKAN_GCF.py + kanlayer.py: L E through sparse.mm, the Fourier KAN layer's einsum as one GEMM over the cos / sin
+    features; parameters in the reference's order, adjacency, loss, every gradient, tables, ranking.  Then node dropout (the
+    family's sparse_dropout over the fixed structure) trains."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import FKAN_GCF
+    g = load_golden("fkan_gcf_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = FKAN_GCF(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), int(g["L"]), 0.0, 0.0,
+                 int(g["G"]), dev).to(dev)
+    assert np.array_equal(_csr_dense(m.norm_adj_matrix), _coo_dense(g["norm_idx"], g["norm_val"], (U + I, U + I)))
+    _golden_model_checks(m, g, dev, 5e-5, 1e-8)
+    res = torch.cat([m.user_emb_final, m.item_emb_final], 0).detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+    m.node_dropout, m.message_dropout = 0.2, 0.1
+    m.train()
+    loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    loss.backward()
+    assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
