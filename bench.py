@@ -726,9 +726,17 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
         ms = time_calls(lambda: ops._score_call(lib, sub, ie, hsub, 1e-6, 50, U, 0, hint, True, 110, False, None, idx, val, ws,
                                                 nb, phase=ops.SCORE_FRONT), 3 if heavy else 5)
         tf = 2.0 * u * I * D / (ms * 1e-3) / 1e12
+        # the whole call with those carried thresholds (no sampling pass, ~2.2 K candidates per user): what an evaluation costs
+        # when the tables did not move since the previous one -- the floor of a steady-state call, NOT a measured epoch-to-epoch
+        # call (sports' headline is one; an epoch of this graph is minutes)
+        ms_c = time_calls(lambda: ops.score_topk(sub, ie, hsub, 1e-6, 50, id_offset=U, hint=hint, hint_valid=True), 3)
+        tf_c = 2.0 * u * I * D / (ms_c * 1e-3) / 1e12
         return {"users": u, "ms": ms, "TFLOPs": tf, "frac": tf / BF16_MFMA_PEAK_TFLOPS,
                 "what": "pack + score_sweep_bf16_kernel over this many users (thresholds carried from a cold call on the same "
-                        "tables), the call's FRONT phase timed alone with HIP events"}
+                        "tables), the call's FRONT phase timed alone with HIP events",
+                "carried_thresholds_same_tables": {"users": u, "ms": ms_c, "frac": tf_c / BF16_MFMA_PEAK_TFLOPS,
+                                                   "what": "whole call, thresholds carried from a call on the SAME tables (floor of "
+                                                           "a steady-state call; not the headline)"}}
 
     def time_ranklist(with_steady):
         res = model.result.detach()
@@ -814,7 +822,9 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
 
 
 def scoring_roofline(r):
-    return {"bound": "mfma", "kernel": f"score_sweep_bf16_kernel<{r['D']},{3 if r['D'] <= 64 else 2}> (+ pack, sample, select/re-score)",
+    sorted_tbl = r["I"] >= 131072 and os.environ.get("CHAOREC_PF_CLS_MIN_ITEMS", "131072") not in ("0",)
+    return {"bound": "mfma", "kernel": f"score_sweep_bf16_kernel<{r['D']},{3 if r['D'] <= 64 else 2},{'true' if sorted_tbl else 'false'}> "
+                                       f"(+ {'norm-class sort, ' if sorted_tbl else ''}pack, sample, select/re-score)",
             "achieved": r["score_tf"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": r["score_tf"] / BF16_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": r["score_tf"] / F32_MFMA_PEAK_TFLOPS,
             "sweep_only_frac": (r.get("sweep_alone") or {}).get("frac"), "sweep_alone": r.get("sweep_alone"),
