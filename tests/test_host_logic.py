@@ -482,6 +482,58 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
+@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf"])
+def test_round5_family_members_start_from_the_reference_state(name):
+    """The six members added in round 5, what needs no GPU: the same seed gives the reference class's parameter names and
+    initial weights, the graphs built vectorised here are the reference's scipy / torch ones (SMORE: the weighted user-item
+    graph, its R block, both kNN item graphs and their max-pooled union), and the loss raises without the MI355X (no CPU path)."""
+    from chaorec_amd import graph
+    from chaorec_amd import Model as M
+    g = load_golden(name + "_small.npz")
+    U, I, D = int(g["U"]), int(g["I"]), int(g["D"])
+    uid = graph.user_item_dict_from_edges(g["edges"])
+    cpu = torch.device("cpu")
+    feats = (torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"])) if "v_feat" in g else ()
+    torch.manual_seed(0)
+    adjs = {}
+    if name == "dhcf":
+        m = M.DHCF(U, I, g["edges"], uid, D, float(g["reg"]), int(g["L"]), 0.0, cpu)
+        for k, layer in enumerate(m.layers):
+            assert np.array_equal(layer.weight.detach().numpy(), g[f"layer{k}_weight"])
+    elif name == "lgmrec":
+        m = M.LGMRec(U, I, g["edges"], uid, *feats, D, float(g["reg"]), int(g["L"]), float(g["ssl_alpha"]), cpu)
+        adjs["norm"] = (m.norm_adj, (U + I, U + I), 0.0)
+    elif name == "powerec":
+        m = M.POWERec(U, I, g["edges"], uid, *feats, D, float(g["reg"]), 2, int(g["prompt_num"]), float(g["neg_weight"]), 0.0, cpu)
+        adjs["norm"] = (m.norm_adj_matrix, (U + I, U + I), 0.0)
+    elif name == "smore":
+        m = M.SMORE(U, I, g["edges"], uid, *feats, D, float(g["reg"]), int(g["L"]), int(g["K"]), 0.0, "none", cpu)
+        adjs = {"norm": (m.norm_adj, (U + I, U + I), 2e-7), "R": (m.R, (U, I), 2e-7), "image": (m.image_original_adj, (I, I), 2e-6),
+                "text": (m.text_original_adj, (I, I), 2e-6), "fusion": (m.fusion_adj, (I, I), 2e-6)}
+    elif name == "mmgcl":
+        m = M.MMGCL(U, I, g["edges"], uid, *feats, D, float(g["reg"]), int(g["L"]), float(g["ssl_alpha"]), float(g["ssl_temp"]),
+                    float(g["dropout"]), cpu)
+        adjs["norm"] = (m.norm_adj, (U + I, U + I), 2e-7)
+    else:
+        m = M.FKAN_GCF(U, I, g["edges"], uid, D, float(g["reg"]), int(g["L"]), 0.0, 0.0, int(g["G"]), cpu)
+        adjs["norm"] = (m.norm_adj_matrix, (U + I, U + I), 0.0)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().numpy(), g["p_" + n]), n
+    for tag, (adj, shape, tol) in adjs.items():
+        dense = np.zeros(shape, np.float32)
+        rp, col, val = adj.rowptr.numpy(), adj.col.numpy(), adj.val.numpy()
+        for r in range(shape[0]):
+            dense[r, col[rp[r]:rp[r + 1]]] = val[rp[r]:rp[r + 1]]
+        ref = np.zeros(shape, np.float32)
+        ref[g[tag + "_idx"][0], g[tag + "_idx"][1]] = g[tag + "_val"]
+        assert np.array_equal(dense != 0, ref != 0) and np.abs(dense - ref).max() <= tol, tag
+    if hasattr(m, "pre_epoch_processing"):
+        m.pre_epoch_processing()
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+
+
 def test_capture_retry_takes_a_capture_lost_to_the_watchdog_race_again():
     """dist.capture_with_retry: a capture that fails with a captured-event error is reset and taken again, any
     other error -- and the last attempt's -- propagates."""

@@ -1,6 +1,3 @@
-timeout 900 python3 bench.py --dataset config5_shard --dim 128 --steps 6 --warmup 2 --no-hbm-regime --no-cpu-baseline --no-models > gpurun_out/r05_x_shard.json 2> gpurun_out/r05_x_shard.err; echo "rc=$?"
-python3 - <<EOF
-import json
-d=json.loads(open("gpurun_out/r05_x_shard.json").read().strip().splitlines()[-1])
-r=d["roofline_scoring"]; print("score ms", d["config"]["gene_ranklist_ms"], "frac", r["frac"], "sweep_only", r["sweep_only_frac"]); print(r["kernel"]); print(r["sweep_alone"])
-EOF
+python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/r05_z_gpu_tests.log; cat gpurun_out/r05_z_gpu_tests.log
+python3 tools/collect_profiles.py r05_z config5 > gpurun_out/r05_collect_z_a.log 2>&1; tail -3 gpurun_out/r05_collect_z_a.log
+CHAOREC_REUSE_STATS=0 python3 tools/collect_profiles.py r05_z sports > gpurun_out/r05_collect_z_b.log 2>&1; tail -3 gpurun_out/r05_collect_z_b.log
