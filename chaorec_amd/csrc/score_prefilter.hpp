@@ -276,7 +276,8 @@ __global__ __launch_bounds__(1024) void score_class_scan_kernel(int *__restrict_
   const int per = (total + 1023) / 1024;
   const int lo = min(tid * per, total), hi = min(lo + per, total);
   int sum = 0;
-  for (int i = lo; i < hi; ++i) sum += blockhist[i];
+#pragma unroll 8
+  for (int i = lo; i < hi; ++i) sum += blockhist[i];      // (unrolled: eight loads in flight, not one round trip per counter)
   part[tid] = sum;
   if (tid == 0) gmax_s = 0;
   __syncthreads();
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(1024) void score_class_scan_kernel(int *__restrict_
     __syncthreads();
   }
   int run = part[tid] - sum;
+#pragma unroll 8
   for (int i = lo; i < hi; ++i) {
     const int c = blockhist[i];
     blockhist[i] = run;
