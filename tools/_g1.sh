@@ -1,3 +1,6 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/r05_z_gpu_tests.log; cat gpurun_out/r05_z_gpu_tests.log
-python3 tools/collect_profiles.py r05_z config5 > gpurun_out/r05_collect_z_a.log 2>&1; tail -3 gpurun_out/r05_collect_z_a.log
-CHAOREC_REUSE_STATS=0 python3 tools/collect_profiles.py r05_z sports > gpurun_out/r05_collect_z_b.log 2>&1; tail -3 gpurun_out/r05_collect_z_b.log
+timeout 900 python -m pytest tests/test_gpu_round5.py -q -m gpu 2>&1 | tail -3
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05_zz_ranges -o s -- python3 $GRAFT_REPO_ROOT/tools/score_ranges_bench.py 300000 2000000 128 > $GRAFT_REPO_ROOT/gpurun_out/r05_zz_ranges.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 tools/prof_stats.py gpurun_out/r05_zz_ranges 12 | grep -i 'class\|pack\|sweep'
