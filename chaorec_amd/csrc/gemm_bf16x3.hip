@@ -44,34 +44,30 @@ union Frag8 {
   bf16x8 v;
 };
 
-// x = h + m + l exactly (finite x): three bf16 values by TRUNCATION -- h = the top 16 bits of x, m = the top 16 bits of the
-// (exact) remainder x - h, l = what is left, which has at most 8 significant bits.  Until round 5 h and m were rounded to
-// nearest: 19 VALU instructions per element against 4 here, and the split was MORE than the kernel's MFMA time (9.3 VALU per
-// MFMA on MMGCN's weight-gradient product: MFMA pipe busy 0.35).  Truncated planes are each up to 2x larger than rounded
-// ones (|m| <= 2^-7 |h|, |l| <= 2^-15 |h|), so the three dropped products m l, l m, l l are <= 2^-21 of |a||b| instead of
-// 2^-23: still inside the kernel's 1e-6 contract (tests/test_gpu_models.py: gemm accuracy).
-// -> fp32 values whose bf16 pattern is their high half
-__device__ __forceinline__ void split3f(float x, float &h, float &m, float &l) {
-  h = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
-  const float r1 = x - h;
-  m = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-  l = r1 - m;
+__device__ __forceinline__ uint32_t rne_bf16_bits(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
 }
-// the high halves of two words as one: (lo >> 16) | (hi & 0xFFFF0000), one v_perm_b32
-__device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {
-  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+
+// x = h + m + l exactly (finite x): three bf16 bit patterns
+__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = rne_bf16_bits(x);
+  const float r1 = x - __uint_as_float(h << 16);
+  m = rne_bf16_bits(r1);
+  const float r2 = r1 - __uint_as_float(m << 16);
+  l = __float_as_uint(r2) >> 16;          // (r2 has at most 8 significant bits left: exact)
 }
 
 // four consecutive k of one row -> 8 B per plane
 __device__ __forceinline__ void split3x4(const float4 x, uint2 &h, uint2 &m, uint2 &l) {
-  float h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
-  split3f(x.x, h0, m0, l0);
-  split3f(x.y, h1, m1, l1);
-  split3f(x.z, h2, m2, l2);
-  split3f(x.w, h3, m3, l3);
-  h = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
-  m = make_uint2(pack_hi16(m0, m1), pack_hi16(m2, m3));
-  l = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
+  uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+  split3(x.x, h0, m0, l0);
+  split3(x.y, h1, m1, l1);
+  split3(x.z, h2, m2, l2);
+  split3(x.w, h3, m3, l3);
+  h = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+  m = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+  l = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
 }
 
 extern __global__ void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits, float *__restrict__ C,
@@ -251,13 +247,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
         const float bx[4][2] = {{r0.x, r1.x}, {r0.y, r1.y}, {r0.z, r1.z}, {r0.w, r1.w}};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float h0, h1, m0_, m1, l0, l1;
-          split3f(bx[i][0], h0, m0_, l0);
-          split3f(bx[i][1], h1, m1, l1);
+          uint32_t h0, h1, m0_, m1, l0, l1;
+          split3(bx[i][0], h0, m0_, l0);
+          split3(bx[i][1], h1, m1, l1);
           // tile row 4 (nq + 16 bb) + i of a 64-row half is kept at LDS row 64 bb + 16 i + nq (see the A tile)
-          *reinterpret_cast<uint32_t *>(&Bs[0][64 * bb + 16 * i + b_nq][2 * b_kp]) = pack_hi16(h0, h1);
-          *reinterpret_cast<uint32_t *>(&Bs[1][64 * bb + 16 * i + b_nq][2 * b_kp]) = pack_hi16(m0_, m1);
-          *reinterpret_cast<uint32_t *>(&Bs[2][64 * bb + 16 * i + b_nq][2 * b_kp]) = pack_hi16(l0, l1);
+          *reinterpret_cast<uint32_t *>(&Bs[0][64 * bb + 16 * i + b_nq][2 * b_kp]) = h0 | (h1 << 16);
+          *reinterpret_cast<uint32_t *>(&Bs[1][64 * bb + 16 * i + b_nq][2 * b_kp]) = m0_ | (m1 << 16);
+          *reinterpret_cast<uint32_t *>(&Bs[2][64 * bb + 16 * i + b_nq][2 * b_kp]) = l0 | (l1 << 16);
         }
       }
     } else {

@@ -92,6 +92,67 @@ def data_load(dataset, has_v=True, has_t=True, data_root='./Data', synthetic=Fal
     return train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat
 
 
+def history_sequences(hist, users, src_len, generator=None):
+    """LightGT's per-sample history sequence (dataload.py:89-101,129-141) for a batch of users, on the device: the user's
+    history when it has at most src_len items, else a uniformly random subset of src_len of them (the reference shuffles the
+    list and cuts it), zero-padded.  -> (user_item int64 [B, src_len + 1]: LOCAL item ids behind a -1 in the user token's
+    place, mask bool [B, src_len + 1]: True = padding).  hist: (rowptr, col) with local ids; users: int64 [B]."""
+    rowptr, col = hist
+    dev = users.device
+    B = users.numel()
+    start = rowptr[users]
+    deg = rowptr[users + 1] - start
+    total = int(deg.sum())
+    user_item = torch.zeros((B, src_len + 1), dtype=torch.int64, device=dev)
+    user_item[:, 0] = -1
+    if total:
+        seg = torch.repeat_interleave(torch.arange(B, device=dev), deg)
+        first = torch.cumsum(deg, 0) - deg                                   # position of every row's first entry
+        entry = col[start[seg] + (torch.arange(total, device=dev) - first[seg])].to(torch.int64)
+        key = torch.rand(total, device=dev, generator=generator, dtype=torch.float64)
+        order = torch.argsort(seg.to(torch.float64) + key)                   # by row, random inside a row
+        rank = torch.arange(total, device=dev) - first[seg[order]]
+        keep = rank < src_len
+        user_item[seg[order][keep], 1 + rank[keep]] = entry[order][keep]
+    mask = torch.arange(src_len + 1, device=dev)[None, :] > torch.clamp(deg, max=src_len)[:, None]
+    return user_item, mask
+
+
+def device_eval_batches(hist, num_user, src_len, chunk, device, generator=None):
+    """DataLoader(EvalDataset(...), 2000, shuffle=False) (main.py:198-199) on the device: (users, user_item, mask) per chunk."""
+    for s in range(0, num_user, chunk):
+        users = torch.arange(s, min(s + chunk, num_user), device=device)
+        user_item, mask = history_sequences(hist, users, src_len, generator)
+        yield users, user_item, mask
+
+
+class EvalDataset(Dataset):
+    """dataload.py:109-143 (LightGT's evaluation batches, host side): per user the shuffled history cut / padded to src_len = 20
+    behind a -1, and its padding mask."""
+
+    def __init__(self, num_user, num_item, user_item_dict, src_len=20):
+        self.num_user, self.num_item, self.user_item_dict, self.src_len = num_user, num_item, user_item_dict, src_len
+
+    def __len__(self):
+        return self.num_user
+
+    def __getitem__(self, index):
+        user_item, mask = _host_sequence(self.user_item_dict[index], self.num_user, self.src_len)
+        return torch.LongTensor([index]), user_item, mask
+
+
+def _host_sequence(items, num_user, src_len):
+    temp = list(items)
+    random.shuffle(temp)
+    if len(temp) > src_len:
+        mask = torch.ones(src_len + 1) == 0
+        temp = temp[:src_len]
+    else:
+        mask = torch.cat((torch.ones(len(temp) + 1), torch.zeros(src_len - len(temp)))) == 0
+        temp.extend([num_user for _ in range(src_len - len(temp))])
+    return torch.cat((torch.tensor([-1]), torch.tensor(temp, dtype=torch.int64) - num_user)), mask
+
+
 class TrainingDataset(Dataset):
     """dataload.py:61-106: one uniform negative per positive, rejected while it is in the user's history.
     Same return contract ([user, pos, neg] ints, or (LongTensor[u,u], LongTensor[pos,neg]) for MMGCN);
@@ -104,6 +165,7 @@ class TrainingDataset(Dataset):
         self.user_item_dict = user_item_dict
         self._sets = {}
         self.model_name = model_name
+        self.src_len = 50
 
     def __len__(self):
         return len(self.edge_index)
@@ -124,6 +186,9 @@ class TrainingDataset(Dataset):
                 break
         if self.model_name in ["MMGCN", "GRCN"]:
             return torch.LongTensor([user, user]), torch.LongTensor([pos_item, neg_item])
+        if self.model_name == "LightGT":            # dataload.py:89-101: + the sample's history sequence and its padding mask
+            user_item, mask = _host_sequence(self.user_item_dict[user], self.num_user, self.src_len)
+            return [torch.LongTensor([user, user]), torch.LongTensor([pos_item, neg_item]), mask, user_item]
         if self.model_name == "MCLN":               # dataload.py:81-84: the second rejection loop's item
             while True:
                 int_item = random.randrange(self.num_user, self.num_user + self.num_item)
@@ -184,7 +249,10 @@ class DeviceBatchSampler:
                 second = ops.sample_negatives(self.hist, users, self.num_item, self.seed, self.global_step, self.num_user,
                                               second=True)
             self.global_step += 1
-            if self.model_name in ["MMGCN", "GRCN"]:
+            if self.model_name == "LightGT":          # dataload.py:89-101: history sequences (src_len 50) drawn on the device
+                user_item, mask = history_sequences(self.hist, users, 50, self.gen)
+                yield torch.stack((users, users), 1), torch.stack((pos, neg), 1), mask, user_item
+            elif self.model_name in ["MMGCN", "GRCN"]:
                 yield torch.stack((users, users), 1), torch.stack((pos, neg), 1)
             elif second is not None:
                 yield users, pos, neg, second

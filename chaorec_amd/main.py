@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import (BPRMF, DHCF, FKAN_GCF, FREEDOM, LGMRec, LayerGCN, LightGCN, MCLN, MGCN, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SimGCL, SLMRec,
+from .Model import (BPRMF, DHCF, FKAN_GCF, FREEDOM, LGMRec, LayerGCN, LightGCN, LightGT, MCLN, MGCN, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SimGCL, SLMRec,
                     SMORE, VBPR, XSimGCL)
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
@@ -76,6 +76,8 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
                              args.dropout, device),
         'FKAN_GCF': lambda: FKAN_GCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
                                      args.node_dropout, args.message_dropout, args.grid_size, device),
+        'LightGT': lambda: LightGT(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
+                                   args.n_layers, device),
         'MMGCL': lambda: MMGCL(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                                args.n_layers, args.ssl_alpha, args.ssl_temp, args.dropout, device),
         'SMORE': lambda: SMORE(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
@@ -98,7 +100,7 @@ def main(argv=None):
     if device.type != "cuda":
         raise SystemExit("chaorec_amd runs on the MI355X only: no GPU visible")
     config = load_yaml_config(args.Model)
-    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE", "MMGCL")
+    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE", "MMGCL", "LightGT")
     train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat = dataload.data_load(
         args.data_path, has_v=needs_feat, has_t=needs_feat, data_root=args.data_root, synthetic=args.synthetic)
     if args.host_sampler:

@@ -13,7 +13,7 @@ from .utils import EarlyStopping, EvalLists, gene_metrics, gene_metrics_device
 MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM", "LayerGCN", "POWERec")     # reference train_and_evaluate.py:554
 E_STEP = ("NCL",)                       # reference train_and_evaluate.py:107-114
-NO_CAPTURE = ("NCL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL")    # host-side randomness / clustering inside the step: eager launches
+NO_CAPTURE = ("NCL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
 
 
 def _train_epoch_in_launch(model, loader, optimizer, graphed):

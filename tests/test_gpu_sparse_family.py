@@ -373,7 +373,7 @@ def test_smore_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
@@ -462,3 +462,73 @@ def test_fkan_gcf_golden(dev):
     loss = m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
     loss.backward()
     assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+def test_lightgt_golden(dev):
+    """Model/LightGT.py: the propagate's prefix means as running sums over sparse.mm, the two feature projections on the MFMA
+    GEMM, the encoders in torch, with the reference's batch format (dataload.py:89-101) -- loss and every gradient (the
+    unused template layers have none, as there) -- and the evaluation as ONE ranking call over concatenated tables against
+    the reference's per-batch score matrices (:369-410)."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import LightGT
+    g = load_golden("lightgt_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = LightGT(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+                torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]), int(g["L"]), dev).to(dev)
+    assert np.array_equal(_csr_dense(m.norm_adj_mat), _coo_dense(g["norm_idx"], g["norm_val"], (U + I, U + I)))
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    m.eval()
+    users2 = torch.stack((torch.from_numpy(g["users"]), torch.from_numpy(g["users"])), 1)
+    items2 = torch.stack((torch.from_numpy(g["pos"]), torch.from_numpy(g["neg"])), 1)
+    loss = m.loss(users2, items2, torch.from_numpy(g["mask"]), torch.from_numpy(g["user_item"]))
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    unused = set(str(n) for n in g["no_grad"])
+    assert unused and all("encoder_layer" in n for n in unused)
+    for n, p in m.named_parameters():
+        if n in unused:
+            assert p.grad is None, n
+            continue
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-8, n
+    batches = [(torch.from_numpy(g[f"eval_users{k}"]), torch.from_numpy(g[f"eval_user_item{k}"]), torch.from_numpy(g[f"eval_mask{k}"]))
+               for k in (0, 1)]
+    with torch.no_grad():
+        ut, it = m.user_tables(batches)
+    sc = (ut @ it.T).cpu().numpy()
+    assert np.abs(sc - g["scores"]).max() <= 1e-5 * np.abs(g["scores"]).max()
+    rank = m.gene_ranklist(batches, topk=int(g["topk"])).numpy()
+    ref_sc = g["scores"].copy()
+    for u, items in graph.user_item_dict_from_edges(g["edges"]).items():
+        ref_sc[u, np.asarray(items) - U] = 1e-5
+    ok, why = tie_aware_rank_equal(rank, np.take_along_axis(ref_sc, rank - U, 1), g["rank"],
+                                   np.take_along_axis(ref_sc, g["rank"] - U, 1), rtol=1e-4, atol=1e-7)
+    assert ok, why
+    # the device-drawn sequences (every history here is shorter than src_len: the same sets, hence the same ranking)
+    rank2 = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    ok, why = tie_aware_rank_equal(rank2, np.take_along_axis(ref_sc, rank2 - U, 1), g["rank"],
+                                   np.take_along_axis(ref_sc, g["rank"] - U, 1), rtol=1e-4, atol=1e-7)
+    assert ok, why
+
+
+def test_history_sequences_are_the_reference_sampler(dev):
+    """dataload.history_sequences against dataload.py:89-101: short histories whole, long ones a uniform subset of src_len
+    (every item of a 200-item history kept about src_len / 200 of the time), padding and mask as there."""
+    from chaorec_amd import dataload
+    rowptr = torch.tensor([0, 3, 3, 203, 215], device=dev)
+    col = torch.arange(215, dtype=torch.int32, device=dev)
+    users = torch.tensor([2, 0, 1, 3], device=dev).repeat(500)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    ui, mask = dataload.history_sequences((rowptr, col), users, 50, gen)
+    assert ui.shape == (2000, 51) and bool((ui[:, 0] == -1).all())
+    assert torch.equal(ui[1, 1:4].sort().values, torch.tensor([0, 1, 2], device=dev)) and bool((ui[1, 4:] == 0).all())
+    assert mask[1].tolist() == [False] * 4 + [True] * 47 and mask[2].tolist() == [False] + [True] * 50
+    assert not bool(mask[0].any()) and mask[3].tolist() == [False] * 13 + [True] * 38
+    long = ui[0::4, 1:]                                    # user 2: 200 items (3 .. 202), 50 kept per draw
+    assert bool(((long >= 3) & (long < 203)).all())
+    assert all(len(set(r.tolist())) == 50 for r in long[:20])
+    freq = torch.bincount(long.flatten(), minlength=203)[3:203].float() / 500
+    assert float((freq - 0.25).abs().max()) < 0.08         # (binomial(500, 1/4): sd 0.019)

@@ -482,7 +482,7 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
-@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf"])
+@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt"])
 def test_round5_family_members_start_from_the_reference_state(name):
     """The six members added in round 5, what needs no GPU: the same seed gives the reference class's parameter names and
     initial weights, the graphs built vectorised here are the reference's scipy / torch ones (SMORE: the weighted user-item
@@ -514,6 +514,9 @@ def test_round5_family_members_start_from_the_reference_state(name):
         m = M.MMGCL(U, I, g["edges"], uid, *feats, D, float(g["reg"]), int(g["L"]), float(g["ssl_alpha"]), float(g["ssl_temp"]),
                     float(g["dropout"]), cpu)
         adjs["norm"] = (m.norm_adj, (U + I, U + I), 2e-7)
+    elif name == "lightgt":
+        m = M.LightGT(U, I, g["edges"], uid, *feats, D, float(g["reg"]), int(g["L"]), cpu)
+        adjs["norm"] = (m.norm_adj_mat, (U + I, U + I), 0.0)
     else:
         m = M.FKAN_GCF(U, I, g["edges"], uid, D, float(g["reg"]), int(g["L"]), 0.0, 0.0, int(g["G"]), cpu)
         adjs["norm"] = (m.norm_adj_matrix, (U + I, U + I), 0.0)
@@ -531,7 +534,39 @@ def test_round5_family_members_start_from_the_reference_state(name):
     if hasattr(m, "pre_epoch_processing"):
         m.pre_epoch_processing()
     with pytest.raises(RuntimeError, match="MI355X only"):
-        m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+        if name == "lightgt":
+            u2 = torch.stack((torch.from_numpy(g["users"]), torch.from_numpy(g["users"])), 1)
+            m.loss(u2, torch.stack((torch.from_numpy(g["pos"]), torch.from_numpy(g["neg"])), 1), torch.from_numpy(g["mask"]),
+                   torch.from_numpy(g["user_item"]))
+        else:
+            m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+
+
+def test_lightgt_batches_host_and_device_form():
+    """dataload.py:89-101 / :109-143 (LightGT's sample format): the host datasets and the device sampler (run on the CPU
+    here) give [user, user], [pos, neg], the padding mask and the history sequence behind a -1; short histories are whole,
+    long ones are cut to src_len distinct members."""
+    from chaorec_amd import dataload, graph
+    U, I = 6, 80
+    uid = {0: [U + 1, U + 5, U + 7], 1: [U + 2], 2: list(range(U, U + 70)), 3: [U + 3, U + 4], 4: [U + 9], 5: [U + 11, U + 12]}
+    edges = np.array([(u, i) for u, items in uid.items() for i in items], dtype=np.int64)
+    ds = dataload.TrainingDataset(U, I, uid, edges, "LightGT")
+    users2, items2, mask, user_item = ds[0]
+    assert users2.tolist() == [0, 0] and items2[0].item() == U + 1 and items2[1].item() not in uid[0]
+    assert user_item.shape == (51,) and user_item[0].item() == -1 and sorted(user_item[1:4].tolist()) == [1, 5, 7]
+    assert mask.tolist() == [False] * 4 + [True] * 47 and bool((user_item[4:] == 0).all())
+    users2, items2, mask, user_item = ds[4 + 10]                      # a sample of user 2: 70 items, 50 kept
+    assert users2.tolist() == [2, 2] and not bool(mask.any()) and len(set(user_item[1:].tolist())) == 50
+    ev = dataload.EvalDataset(U, I, uid)
+    u, user_item, mask = ev[2]
+    assert u.tolist() == [2] and user_item.shape == (21,) and not bool(mask.any()) and len(set(user_item[1:].tolist())) == 20
+    u, user_item, mask = ev[1]
+    assert user_item[:2].tolist() == [-1, 2] and mask.tolist() == [False, False] + [True] * 19
+    rowptr, col = graph.user_hist_csr(uid, U)
+    batches = list(dataload.device_eval_batches((torch.as_tensor(rowptr), torch.as_tensor(col)), U, 20, 4, torch.device("cpu")))
+    assert [b[0].tolist() for b in batches] == [[0, 1, 2, 3], [4, 5]]
+    assert batches[0][1][1].tolist() == [-1, 2] + [0] * 19 and batches[0][2][1].tolist() == [False, False] + [True] * 19
+    assert len(set(batches[0][1][2, 1:].tolist())) == 20 and not bool(batches[0][2][2].any())
 
 
 def test_capture_retry_takes_a_capture_lost_to_the_watchdog_race_again():
