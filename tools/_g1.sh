@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_real_data.py -q -m gpu -x -k "mmgcn_microlens" 2>&1 | grep -v Warning | grep -B2 -A22 'def test_mmgcn_microlens\|Error\|assert' | tail -70
+timeout 900 python -m pytest tests/test_gpu_sparse_family.py -q -m gpu -k "lightgt or LightGT or history_sequences" 2>&1 | grep -v ' INFO \|Warning' | tail -40
