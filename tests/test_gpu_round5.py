@@ -350,3 +350,62 @@ def test_score_topk_norm_sorted_table_equals_the_table_in_its_own_order(dev, D, 
     for k in (4, 5):
         assert b[k]["fallback_users"] <= a[k]["fallback_users"] + 8, (a[k], b[k])
         assert b[k]["candidates"] <= 1.5 * a[k]["candidates"] + 128 * U, (a[k], b[k])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_score_topk_sorted_layout_fuzz_against_own_order_and_oracle(dev, oracle, seed):
+    """Random shapes and tables through the norm-sorted layout (forced by CHAOREC_PF_CLS_MIN_ITEMS on tables of 17 k - 40 k
+    items): K from 1 to 64, item counts that are no multiple of the tile, few / odd user counts, heavy-tailed norms, INTEGER
+    tables (exact ties by the thousand: the lowest index must win although the sweep walks a permutation), histories of 0 to
+    several hundred items, both mask values of the reference -- against the table in its own order for every row, and against
+    the oracle for a sample of rows."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([64, 128]))
+    U = int(rng.choice([1, 33, 97, 300, 1025]))
+    I = int(rng.integers(16_400, 40_000))
+    K = int(rng.choice([1, 7, 20, 50, 64]))
+    mask_value = float(rng.choice([1e-6, 1e-5]))
+    kind = seed % 4
+    if kind == 0:                                   # integer tables: massive ties
+        ue = rng.integers(-2, 3, (U, D)).astype(np.float32)
+        ie = rng.integers(-1, 2, (I, D)).astype(np.float32)
+    else:
+        ue = (rng.standard_normal((U, D)) * 0.3).astype(np.float32)
+        ie = (rng.standard_normal((I, D)) * 0.1).astype(np.float32)
+        if kind == 1:
+            ie *= np.exp2(rng.standard_normal((I, 1)) * 1.2).astype(np.float32)
+        elif kind == 2:
+            ie[rng.choice(I, 40, replace=False)] *= 1e4
+            ie[rng.choice(I, 400, replace=False)] = 0.0
+            ue[::7] = -np.abs(ue[::7])
+            ie[:, :] = np.abs(ie)                   # users with all-negative scores
+    rowptr = np.zeros(U + 1, np.int64)
+    cols = []
+    for u in range(U):
+        deg = int(rng.choice([0, 3, 40, 600])) if u % 5 else 0
+        c = np.sort(rng.choice(I, min(deg, I), replace=False)).astype(np.int32)
+        cols.append(c)
+        rowptr[u + 1] = rowptr[u] + len(c)
+    col = np.concatenate(cols).astype(np.int32) if rowptr[-1] else np.zeros(0, np.int32)
+    dh = (torch.from_numpy(rowptr).to(dev), torch.from_numpy(col if len(col) else np.zeros(1, np.int32)).to(dev))
+    due, die = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
+    out = {}
+    for name, v in (("own", 0), ("sorted", 1)):
+        with _env(CHAOREC_PF_CLS_MIN_ITEMS=v):
+            hint = torch.empty(U, device=dev)
+            a = ops.score_topk(due, die, dh, mask_value, K, id_offset=U, hint=hint, hint_valid=False)
+            b = ops.score_topk(due, die, dh, mask_value, K, id_offset=U, hint=hint, hint_valid=True)
+            torch.cuda.synchronize()
+            out[name] = a + b
+    for x, y in zip(out["own"], out["sorted"]):
+        assert torch.equal(x, y), (seed, D, U, I, K, kind)
+    rows = np.unique(np.r_[0, U // 2, U - 1, rng.integers(0, U, 6)])
+    sub_ptr = np.zeros(len(rows) + 1, np.int64)
+    sub_col = []
+    for n, r in enumerate(rows):
+        sub_col.append(col[rowptr[r]:rowptr[r + 1]])
+        sub_ptr[n + 1] = sub_ptr[n] + len(sub_col[-1])
+    sc = np.concatenate(sub_col).astype(np.int32) if sub_ptr[-1] else np.zeros(0, np.int32)
+    want_i, want_v = oracle.score_topk(ue[rows], ie, (sub_ptr, sc), mask_value, K, U)
+    assert np.array_equal(out["sorted"][0][rows].cpu().numpy(), want_i) and np.array_equal(out["sorted"][1][rows].cpu().numpy(), want_v)
