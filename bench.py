@@ -822,7 +822,7 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
 
 
 def scoring_roofline(r):
-    sorted_tbl = r["I"] >= 131072 and os.environ.get("CHAOREC_PF_CLS_MIN_ITEMS", "131072") not in ("0",)
+    sorted_tbl = r["I"] >= 524288 and os.environ.get("CHAOREC_PF_CLS_MIN_ITEMS", "") in ("",)     # (score_topk.hip: use_sorted_table)
     return {"bound": "mfma", "kernel": f"score_sweep_bf16_kernel<{r['D']},{3 if r['D'] <= 64 else 2},{'true' if sorted_tbl else 'false'}> "
                                        f"(+ {'norm-class sort, ' if sorted_tbl else ''}pack, sample, select/re-score)",
             "achieved": r["score_tf"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -18,7 +18,7 @@
 //   (T_u, -c||u||) in the sweep -- with the users' fragments negated the accumulator is T_u - v_j, a hit is its sign
 //   bit -- and (0, -c||u||) in the sampler (accumulator = the lower bound w_j = s~_j - e~_uj).
 //
-// Long item ranges (>= 131 072 items) run on a NORM-SORTED packed table instead, where the bound rides on the users' operand
+// Long item ranges of many users (score_topk.hip: use_sorted_table) run on a NORM-SORTED packed table instead, where the bound rides on the users' operand
 // scale and costs no MFMA at all: section "norm classes" below.  Everything in this header up to there describes the table
 // in its own order (sports: 15 k items); the certification argument is the same for both.
 //
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void pack_items_bf16_kernel(const float *__res
 constexpr int kClsBase = 107 * 8;          // class 0 holds every norm below 2^-20, class 255 every norm from 2^11 * 1.875 on
 constexpr int kClsChunk = 1024;            // items per block of the counting sort
 constexpr int kClsSegments = 32;           // classes are merged into runs of at least n_items / kClsSegments items ...
-constexpr int kClsRunSpan = 4;             // ... that span at most this many classes
+constexpr int kClsRunSpan = 4;             // ... that span at most this many classes (half an octave) ...
+constexpr int kClsRunSpanMax = 16;         // ... or, where the table would have more runs than its walks afford, up to two octaves
 
 __device__ __forceinline__ int norm_class(float nu) {            // nu >= 0 (NaN / inf: the top class)
   const int k = (int)(__float_as_uint(nu) >> 20) - kClsBase;
@@ -267,7 +268,8 @@ __global__ __launch_bounds__(256) void score_norm_class_kernel(const float *__re
 // belongs to.  Runs are formed from the largest norms down; a run is closed once it holds min_seg items.  The run that
 // starts at key 0 (the open-ended top class) takes the table's largest norm itself.
 __global__ __launch_bounds__(1024) void score_class_scan_kernel(int *__restrict__ blockhist, int NB, const int *__restrict__ blockmax,
-                                                                float *__restrict__ seg_bound, int64_t n_pad, int min_seg) {
+                                                                float *__restrict__ seg_bound, int64_t n_pad, int min_seg,
+                                                                int max_runs) {
   __shared__ int part[1024];
   __shared__ int cstart[257];
   __shared__ int gmax_s;
@@ -302,21 +304,33 @@ __global__ __launch_bounds__(1024) void score_class_scan_kernel(int *__restrict_
   if (tid == 0) cstart[256] = (int)n_pad;
   __syncthreads();
   if (tid == 0) {
-    float cur = 0.f;
-    int acc = 0, first = 0;
-    for (int kd = 0; kd < 256; ++kd) {
-      const int cnt = cstart[kd + 1] - cstart[kd];
-      // a run also ends after kClsRunSpan classes (half an octave): a few outsized rows at the top of the table must not
-      // lend their bound to thousands of ordinary ones
-      if (acc > 0 && kd - first >= kClsRunSpan) acc = 0;
-      if (cnt > 0 && acc == 0) {
-        cur = kd == 0 ? __int_as_float(gmax_s) : class_edge(255 - kd);
-        first = kd;
+    // A run also ends after `span` classes: a few outsized rows at the top of the table must not lend their bound to
+    // thousands of ordinary ones.  span starts at kClsRunSpan (half an octave) and doubles, up to kClsRunSpanMax (two
+    // octaves), while the table has more than max_runs runs: a re-scale costs a walk ~3 us (row, norm and threshold through
+    // L2).  Runs of up to two octaves widen the band of their low-norm members 4x at most -- harmless; a run that reaches
+    // from an outlier cluster 30x above the table down into it makes every ordinary item a candidate (measured: all users
+    // overflow), so the span stops there and a table that still has more runs simply pays for them (the host only takes
+    // this layout for long walks: plan_score).
+    auto walk = [&](int span, bool write) -> int {
+      float cur = 0.f;
+      int acc = 0, first = 0, runs = 0;
+      for (int kd = 0; kd < 256; ++kd) {
+        const int cnt = cstart[kd + 1] - cstart[kd];
+        if (acc > 0 && kd - first >= span) acc = 0;
+        if (cnt > 0 && acc == 0) {
+          cur = kd == 0 ? __int_as_float(gmax_s) : class_edge(255 - kd);
+          first = kd;
+          ++runs;
+        }
+        if (write) seg_bound[kd] = cur;
+        acc += cnt;
+        if (acc >= min_seg) acc = 0;
       }
-      seg_bound[kd] = cur;
-      acc += cnt;
-      if (acc >= min_seg) acc = 0;
-    }
+      return runs;
+    };
+    int span = kClsRunSpan;
+    while (span < kClsRunSpanMax && walk(span, false) > max_runs) span *= 2;
+    walk(span, true);
   }
 }
 

@@ -859,12 +859,20 @@ static int sweep_wave_slots(int D, bool cls) {
   return c;
 }
 
-// from how many items on the packed table is norm-sorted (CHAOREC_PF_CLS_MIN_ITEMS overrides -- tests run the sorted path on
-// small tables with it, 0 switches it off; read per call: a getenv next to a dozen launches)
-static int64_t cls_min_items() {
+// When the packed table is norm-sorted.  The layout takes one MFMA in nine (five) out of the sweep, ~6 % of its time, and
+// costs (i) a sort in front of the pack (~0.1 ms + 0.6 ns per item: one workgroup scans the class histogram), (ii) a re-scale
+// of the users' fragments per run of norm classes and walk (~3 us; a table whose norms span several octaves has 10 - 30
+// runs).  So it pays for LONG walks of MANY users: from 524 288 items on (>= 1 024 tiles per workgroup walk) and
+// 2 U I D >= 3e13 flops per call -- measured: 2 M items x 625 k users -11 % on the sweep, 262 144 x 131 072 -5 % on level
+// norms and a loss on log-normal ones, 120 k x 29 k +50 % (tools/score_mid_sizes.py).  CHAOREC_PF_CLS_MIN_ITEMS overrides
+// both conditions (tests run the sorted path on small tables with it; 0 switches it off); read per call.
+static bool use_sorted_table(int64_t n_users, int64_t n_items, int D) {
   const char *e = std::getenv("CHAOREC_PF_CLS_MIN_ITEMS");
-  const int64_t v = e && *e ? std::atoll(e) : 131072;
-  return v <= 0 ? INT64_MAX : v;
+  if (e && *e) {
+    const int64_t v = std::atoll(e);
+    return v > 0 && n_items >= v;
+  }
+  return n_items >= 524288 && (double)n_users * (double)n_items * (double)D >= 1.5e13;
 }
 
 static int env_int(const char *name, int dflt) {
@@ -915,7 +923,7 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   // a sampler wave's share of the sample fits its 24-slot lists up to ~16 k items; longer ranges take the
   // streaming-top-r instantiation (32 slots, fewer and longer waves)
   p.pf_sample_long = n_tiles > 512;
-  p.pf_cls = p.prefilter && p.pf_sample_long && n_items >= cls_min_items();
+  p.pf_cls = p.prefilter && p.pf_sample_long && use_sorted_table(n_users, n_items, D);
   // The sorted layout's sampler takes every stride-th ITEM of the sorted order, strata dealt evenly to its waves: a
   // systematic sample, stratified by norm -- half the sample gives the spread a sample of whole tiles had (config-5 shard,
   // propagated tables: every 32nd item at rank 4 = 0 of 1.25 M users with fewer than K candidates, 782 through pass C, call
@@ -1170,8 +1178,10 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       const int min_seg = (int)std::max<int64_t>(1, n_items / kClsSegments);
       hipLaunchKernelGGL(score_norm_class_kernel, dim3((unsigned)NB), dim3(256), 0, st, item_emb, n_items, (int)D, n_pad,
                          (uint8_t *)(ws + p.off_pf_key), (int *)(ws + p.off_pf_bhist), NB, (int *)(ws + p.off_pf_bmax));
+      // (runs a walk can afford: one per ~128 tiles of a workgroup's walk, score_class_scan_kernel)
+      const int max_runs = (int)std::min<int64_t>(kClsSegments, std::max<int64_t>(8, n_tiles / p.pf_splits / 128));
       hipLaunchKernelGGL(score_class_scan_kernel, dim3(1), dim3(1024), 0, st, (int *)(ws + p.off_pf_bhist), NB,
-                         (const int *)(ws + p.off_pf_bmax), (float *)(ws + p.off_pf_segb), n_pad, min_seg);
+                         (const int *)(ws + p.off_pf_bmax), (float *)(ws + p.off_pf_segb), n_pad, min_seg, max_runs);
       hipLaunchKernelGGL(score_class_scatter_kernel, dim3((unsigned)NB), dim3(64), 0, st, (const uint8_t *)(ws + p.off_pf_key),
                          (const int *)(ws + p.off_pf_bhist), NB, n_pad, n_items, (int32_t *)(ws + p.off_pf_perm),
                          (int32_t *)(ws + p.off_pf_inv), (const float *)(ws + p.off_pf_segb), (float *)(ws + p.off_pf_tbound));

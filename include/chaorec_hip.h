@@ -382,7 +382,8 @@ int chaorec_bpr_finalize_steps_f32(const float *workspace, int64_t ws_stride, in
  *      ranked on those values; the answer is certified when the K-th best exact score is > T_u (anything outside
  *      the candidates is then strictly beaten by K items).  T_u is estimated from a sample of the items; a user that
  *      cannot be certified (list overflow, too few / too many candidates) gets all its scores computed exactly.
- *      From 131 072 items on (environment CHAOREC_PF_CLS_MIN_ITEMS: another length, 0 = never) the prefilter works on a
+ *      From 524 288 items and 2 U I D >= 3e13 flops per call on (environment CHAOREC_PF_CLS_MIN_ITEMS: an item count as the
+ *      only condition, 0 = never) the prefilter works on a
  *      NORM-SORTED copy of the item table: items in descending order of their norm class (exponent + 3 mantissa bits), the
  *      bound taken per run of classes instead of per item -- e_u = c ||u|| N_run folded into the users' operand scale, so
  *      the bound costs no MFMA (one in nine at D = 128) --, thresholds sampled from every 32nd / 16th / 8th item of that
