@@ -867,6 +867,7 @@ static int sweep_wave_slots(int D, bool cls) {
 // norms and a loss on log-normal ones, 120 k x 29 k +50 % (tools/score_mid_sizes.py).  CHAOREC_PF_CLS_MIN_ITEMS overrides
 // both conditions (tests run the sorted path on small tables with it; 0 switches it off); read per call.
 static bool use_sorted_table(int64_t n_users, int64_t n_items, int D) {
+  if (n_items > (int64_t)INT32_MAX - 64) return false;      // (positions of the sorted order are int32)
   const char *e = std::getenv("CHAOREC_PF_CLS_MIN_ITEMS");
   if (e && *e) {
     const int64_t v = std::atoll(e);
