@@ -373,7 +373,39 @@ def test_smore_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT"])
+def test_gume_golden(dev):
+    """Model/GUME.py: the two cosine-kNN item graphs, their modality intersection, the ENHANCED (not symmetric) user-item graph
+    and its R block -- all built on the device here, against the reference's Python loops / scipy --, then loss (the four
+    recorded perturbation draws replayed), every gradient, the table of the last forward and the ranking."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import GUME
+    g = load_golden("gume_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = GUME(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+             torch.from_numpy(g["t_feat"]), int(g["D"]), int(g["L"]), int(g["L_ui"]), float(g["um_loss"]), float(g["vt_loss"]),
+             "none", dev).to(dev)
+    assert np.array_equal(np.array(sorted(map(tuple, m.inter.t().tolist())), dtype=np.int64), g["inter"])
+    for csr, tag, shape, tol in ((m.norm_adj, "norm", (U + I, U + I), 2e-7), (m.R, "R", (U, I), 2e-7),
+                                 (m.image_original_adj, "image", (I, I), 2e-6), (m.text_original_adj, "text", (I, I), 2e-6)):
+        want = _coo_dense(g[tag + "_idx"], g[tag + "_val"], shape)
+        got = _csr_dense(csr)
+        assert np.array_equal(got != 0, want != 0), tag
+        assert np.abs(got - want).max() <= tol, tag
+    assert not m.norm_adj.symmetric
+    it = iter([torch.from_numpy(n).to(dev) for n in g["noise"]])
+    m.noise_fn = lambda x: next(it)
+    _golden_model_checks(m, g, dev, 1e-4, 1e-7)
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+    # the default draws on the device: two losses differ
+    m.noise_fn = None
+    args = [torch.from_numpy(g[k]) for k in ("users", "pos", "neg")]
+    assert m.loss(*args).item() != m.loss(*args).item()
+
+
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
