@@ -13,7 +13,7 @@ from torch.utils.data import DataLoader
 
 from . import dataload
 from .Model import (BPRMF, DHCF, FKAN_GCF, FREEDOM, GUME, LGMRec, LayerGCN, LightGCN, LightGT, MCLN, MGCN, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SimGCL, SLMRec,
-                    SMORE, VBPR, XSimGCL)
+                    SMORE, VBPR, VGCL, XSimGCL)
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
 from .optim import FusedAdam
@@ -80,6 +80,9 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
                                    args.n_layers, device),
         'MMGCL': lambda: MMGCL(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                                args.n_layers, args.ssl_alpha, args.ssl_temp, args.dropout, device),
+        # (main.py:333-334)
+        'VGCL': lambda: VGCL(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers,
+                             args.ssl_temp, args.ssl_alpha, device),
         # (main.py:379-380)
         'GUME': lambda: GUME(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.n_layers,
                              args.n_ui_layers, args.um_loss, args.vt_loss, args.data_path, device),

@@ -301,7 +301,7 @@ class _MMGCNLayer(torch.autograd.Function):
         if ax_aug is None:
             if not dual:
                 c = _linear_fwd_raw(x, Wc, bc, 0)
-            s = csr.propagate_raw(c) if hasattr(csr, "propagate_raw") else spmm_raw(csr, c)
+            s = csr.propagate_raw(c) if hasattr(csr, "propagate_raw") else _ops.spmm_raw(csr, c)
             cat = leaky_cat_add(s, uy, id_rows)
         else:
             cat = torch.empty((n, d1 + d2), dtype=torch.float32, device=x.device)
@@ -329,7 +329,7 @@ class _MMGCNLayer(torch.autograd.Function):
         gs, gu, gid = leaky_split_bwd(gcat, cat, uy, d1, want_gid=ctx.has_id and need[1])
         gbl = col_sum(gu) if need[5] else None
         if ax_aug is None and ctx.dual:
-            gc = ctx.csr.propagate_t_raw(gs) if hasattr(ctx.csr, "propagate_t_raw") else spmm_raw(ctx.csr.t(), gs)
+            gc = ctx.csr.propagate_t_raw(gs) if hasattr(ctx.csr, "propagate_t_raw") else _ops.spmm_raw(ctx.csr.t(), gs)
             gbc = col_sum(gc) if need[3] else None
             gWc = gWl = None
             if need[2] or need[4]:
@@ -339,7 +339,7 @@ class _MMGCNLayer(torch.autograd.Function):
         gWl = _linear_gw_raw(gu, x) if need[4] else None
         gx = _linear_gx_raw(gu, Wl) if need[0] else None
         if ax_aug is None:
-            gc = ctx.csr.propagate_t_raw(gs) if hasattr(ctx.csr, "propagate_t_raw") else spmm_raw(ctx.csr.t(), gs)
+            gc = ctx.csr.propagate_t_raw(gs) if hasattr(ctx.csr, "propagate_t_raw") else _ops.spmm_raw(ctx.csr.t(), gs)
             gWc = _linear_gw_raw(gc, x) if need[2] else None
             gbc = col_sum(gc) if need[3] else None
             if need[0]:

@@ -173,12 +173,12 @@ class _SpMMAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, z, csr):
         ctx.csr = csr
-        return spmm_raw(csr, x, z=_f32c(z), beta=1.0)
+        return _ops.spmm_raw(csr, x, z=_f32c(z), beta=1.0)
 
     @staticmethod
     def backward(ctx, gy):
         gy = gy.contiguous()
-        return spmm_raw(ctx.csr.t(), gy), gy, None
+        return _ops.spmm_raw(ctx.csr.t(), gy), gy, None
 
 
 def spmm_add(csr, x, z):
@@ -214,11 +214,11 @@ class _SpMMValues(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, structure, val, val_t):
         ctx.structure, ctx.val_t = structure, val_t
-        return spmm_raw(structure.with_values(val), x)
+        return _ops.spmm_raw(structure.with_values(val), x)
 
     @staticmethod
     def backward(ctx, gy):
-        return spmm_raw(ctx.structure.with_values(ctx.val_t), gy.contiguous()), None, None, None
+        return _ops.spmm_raw(ctx.structure.with_values(ctx.val_t), gy.contiguous()), None, None, None
 
 
 def spmm_values(structure, val, val_t, x):

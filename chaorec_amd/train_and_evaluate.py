@@ -12,8 +12,8 @@ from .utils import EarlyStopping, EvalLists, gene_metrics, gene_metrics_device
 
 MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM", "LayerGCN", "POWERec")     # reference train_and_evaluate.py:554
-E_STEP = ("NCL",)                       # reference train_and_evaluate.py:107-114
-NO_CAPTURE = ("NCL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
+E_STEP = ("NCL", "VGCL")                # reference train_and_evaluate.py:107-114, :116-125
+NO_CAPTURE = ("NCL", "VGCL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
 
 
 def _train_epoch_in_launch(model, loader, optimizer, graphed):
@@ -59,6 +59,8 @@ def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):
         else:
             optimizer.zero_grad()
             if model_name in E_STEP:
+                if model_name == "VGCL":
+                    model.forward()          # (train_and_evaluate.py:120: VGCL clusters the noised view of THIS forward; its loss() runs none)
                 model.e_step()               # NCL clusters its embeddings before EVERY batch (train_and_evaluate.py:107-114)
             loss = model.loss(*batch)
             loss.backward()

@@ -99,6 +99,15 @@ def test_bench_self_launches_two_ranks_on_this_gpu(dev):
         assert "error" not in m and m["ms_per_step"] > 0 and m["config"]["exchange_bytes_per_step_per_rank"] > 0, m
 
 
+@pytest.mark.parametrize("name", ["MMGCN", "FREEDOM"])
+def test_bench_model_records_count_their_spmm_work(dev, name):
+    """`bench.py --model X` on one GPU: the record's `value` divides the SpMM messages of one step -- counted by patching
+    `ops.spmm_raw` for one eager step -- by the step time; every caller must therefore reach the SpMM through the `ops` facade
+    (a module that binds the function at import time drops out of the count: MMGCN's record read 0 after the ops split)."""
+    line = _run_bench(["--model", name, "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], {})
+    assert line["value"] > 0 and line["config"]["spmm_nnz_per_step_all_ranks"] > 0 and line["ms_per_step"] > 0
+
+
 def _sharded_mmgcn_streams_worker(rank, world, port, tmp, streams):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -165,6 +165,38 @@ def test_ncl_golden(dev):
     assert torch.isfinite(loss)
 
 
+def test_vgcl_golden(dev):
+    """Model/VGCL.py: the variational encoder (mean over layers 1..L, log-std projection, the two recorded Gaussian draws), the
+    node- and cluster-level contrasts (the fixture's [n, 1] cluster columns), the KL term: loss, every gradient, both noised
+    views' source tensors, the ranking; then e_step's contract and the loop's forward -> e_step -> loss order."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import VGCL
+    g = load_golden("vgcl_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = VGCL(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), int(g["L"]),
+             float(g["ssl_temp"]), float(g["ssl_alpha"]), dev).to(dev)
+    it = iter([torch.from_numpy(n).to(dev) for n in g["noise"]])
+    m.noise_fn = lambda x: next(it)
+    m.forward()
+    with pytest.raises(RuntimeError, match="e_step"):
+        m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
+    m.user_2cluster, m.item_2cluster = torch.from_numpy(g["user_2cluster"]).to(dev), torch.from_numpy(g["item_2cluster"]).to(dev)
+    _check_common(m, g, dev, m.adj_matrix, 5e-5)
+    for name in ("user_emb", "item_emb", "mean", "std"):
+        got = getattr(m, name).detach().cpu().numpy()
+        assert np.abs(got - g[name]).max() <= 5e-6 * np.abs(g[name]).max(), name
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["user_emb"] @ g["item_emb"].T, U)
+    m.noise_fn = None
+    m.forward()
+    m.e_step()
+    for cent, assign, n, k in ((m.user_centroids, m.user_2cluster, U, min(50, U)), (m.item_centroids, m.item_2cluster, I, min(50, I))):
+        assert cent.shape == (k, int(g["D"])) and assign.shape == (n, 1)
+        assert torch.allclose(cent.norm(dim=1), torch.ones(k, device=dev), atol=1e-5)
+        assert int(assign.min()) >= 0 and int(assign.max()) < k
+    assert torch.isfinite(m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg"))))
+
+
 def test_selfcf_golden(dev):
     from chaorec_amd import graph
     from chaorec_amd.Model import SelfCF
@@ -405,7 +437,7 @@ def test_gume_golden(dev):
     assert m.loss(*args).item() != m.loss(*args).item()
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""

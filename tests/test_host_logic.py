@@ -436,13 +436,13 @@ def test_bench_launches_its_own_ranks_and_propagates_failures():
 
 
 @pytest.mark.parametrize("name", ["simgcl_small.npz", "xsimgcl_small.npz", "ncl_small.npz", "selfcf_small.npz", "slmrec_small.npz",
-                                  "mcln_small.npz"])
+                                  "mcln_small.npz", "vgcl_small.npz"])
 def test_sparse_family_models_start_from_the_reference_state(name):
     """SimGCL / NCL / SelfCF (through the adapter alone): what needs no GPU -- the same seed gives the
     reference class's parameter names and initial weights, and graph.binary_sym_norm_csr gives its scipy-built
     D^-1/2 A D^-1/2 bit for bit (goldens of tests/golden/gen_sparse_family.py: the reference classes' own output)."""
     from chaorec_amd import graph
-    from chaorec_amd.Model import MCLN, NCL, SelfCF, SimGCL, SLMRec, XSimGCL
+    from chaorec_amd.Model import MCLN, NCL, SelfCF, SimGCL, SLMRec, VGCL, XSimGCL
     g = load_golden(name)
     U, I = int(g["U"]), int(g["I"])
     uid = graph.user_item_dict_from_edges(g["edges"])
@@ -462,6 +462,9 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m = MCLN(U, I, g["edges"], uid, torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]),
                  int(g["L"]), int(g["n_mca"]), cpu)
         adj = m.norm_adj_mat
+    elif name.startswith("vgcl"):
+        m = VGCL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), float(g["ssl_temp"]), float(g["ssl_alpha"]), cpu)
+        adj = m.adj_matrix
     elif name.startswith("ncl"):
         m = NCL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), "add", float(g["ssl_temp"]), float(g["ssl_reg"]), cpu)
         adj = m.norm_adj_mat
@@ -479,6 +482,8 @@ def test_sparse_family_models_start_from_the_reference_state(name):
     ref[g["norm_idx"][0], g["norm_idx"][1]] = g["norm_val"]
     assert np.array_equal(dense, ref)
     with pytest.raises(RuntimeError, match="MI355X only"):          # no CPU compute path: the propagate raises
+        if name.startswith("vgcl"):
+            m.forward()                                                 # (VGCL's loss() runs no forward itself)
         m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
