@@ -197,6 +197,36 @@ def test_vgcl_golden(dev):
     assert torch.isfinite(m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg"))))
 
 
+def test_ddrec_golden(dev):
+    """Model/DDRec.py: the per-layer re-filtered graphs as VALUE arrays over one CSR (the E scores as row dot products, the
+    survivors' degrees, the dynamic-values SpMM forward and backward) against the reference's dense [U, I] scores + rebuilt edge
+    lists + GCNConv; two steps -- ungated, then gated by the first step's item table --: both losses and tables, every gradient
+    of the second, the ranking over the [N, 3 D] table."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import DDRec
+    g = load_golden("ddrec_small.npz")
+    U, I, D = int(g["U"]), int(g["I"]), int(g["D"])
+    torch.manual_seed(0)
+    m = DDRec(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]),
+              torch.from_numpy(g["t_feat"]), D, D, float(g["reg"]), int(g["L"]), float(g["ssl_temp"]), float(g["ssl_alpha"]),
+              float(g["threshold"]), "add", dev).to(dev)
+    for csr, tag in ((m.mm_adj, "mm"), (m.image_adj, "image"), (m.text_adj, "text")):
+        want, got = _coo_dense(g[tag + "_idx"], g[tag + "_val"], (I, I)), _csr_dense(csr)
+        assert np.array_equal(got != 0, want != 0) and np.abs(got - want).max() <= 1e-7, tag
+    args = [torch.from_numpy(g[k]) for k in ("users", "pos", "neg")]
+    loss0 = m.loss(*args)
+    assert float(loss0.detach()) == pytest.approx(float(g["loss0"]), rel=1e-5)
+    assert np.abs(m.result.detach().cpu().numpy() - g["result0"]).max() <= 1e-5 * np.abs(g["result0"]).max()
+    _golden_model_checks(m, g, dev, 1e-4, 1e-7)
+    res = m.result.detach().cpu().numpy()
+    assert res.shape == (U + I, 3 * D) and np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+    # the filter is live: at threshold 0 some, not all, interactions of the gated table survive
+    ego = torch.cat((m.user_embedding.weight, m.i_v_embeddings), 0).detach()
+    kept = int((m.filter_edges(ego) > 0).sum())
+    assert 0 < kept < m.n_edges
+
+
 def test_selfcf_golden(dev):
     from chaorec_amd import graph
     from chaorec_amd.Model import SelfCF
@@ -437,7 +467,7 @@ def test_gume_golden(dev):
     assert m.loss(*args).item() != m.loss(*args).item()
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""

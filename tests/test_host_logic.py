@@ -487,7 +487,7 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
-@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume"])
+@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec"])
 def test_round5_family_members_start_from_the_reference_state(name):
     """The six members added in round 5, what needs no GPU: the same seed gives the reference class's parameter names and
     initial weights, the graphs built vectorised here are the reference's scipy / torch ones (SMORE: the weighted user-item
@@ -515,6 +515,9 @@ def test_round5_family_members_start_from_the_reference_state(name):
         m = M.SMORE(U, I, g["edges"], uid, *feats, D, float(g["reg"]), int(g["L"]), int(g["K"]), 0.0, "none", cpu)
         adjs = {"norm": (m.norm_adj, (U + I, U + I), 2e-7), "R": (m.R, (U, I), 2e-7), "image": (m.image_original_adj, (I, I), 2e-6),
                 "text": (m.text_original_adj, (I, I), 2e-6), "fusion": (m.fusion_adj, (I, I), 2e-6)}
+    elif name == "ddrec":
+        m = M.DDRec(U, I, g["edges"], uid, *feats, D, D, float(g["reg"]), int(g["L"]), 0.2, 0.01, 0.0, "add", cpu)
+        adjs = {"mm": (m.mm_adj, (I, I), 1e-7), "image": (m.image_adj, (I, I), 1e-7), "text": (m.text_adj, (I, I), 1e-7)}
     elif name == "gume":
         m = M.GUME(U, I, g["edges"], uid, *feats, D, int(g["L"]), int(g["L_ui"]), 0.1, 0.1, "none", cpu)
         assert np.array_equal(np.array(sorted(map(tuple, m.inter.t().tolist())), dtype=np.int64), g["inter"])
