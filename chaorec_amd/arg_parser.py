@@ -32,6 +32,8 @@ def build_parser():
     parser.add_argument('--prompt_num', type=float, default=0.1, help='prompt modal numbers.')
     parser.add_argument('--neg_weight', type=float, default=0.1, help='weak modal weight.')
     parser.add_argument('--n_ui_layers', type=int, default=3, help='n_ui layers.')
+    parser.add_argument('--cen_reg', type=float, default=5e-3, help='intent regularization')
+    parser.add_argument('--n_intents', type=int, default=128, help='Number of latent intents')
     parser.add_argument('--threshold', type=float, default=0.1, help='the number of threshold.')
     parser.add_argument('--um_loss', type=float, default=0.1, help='um_loss.')
     parser.add_argument('--vt_loss', type=float, default=0.1, help='vt_loss.')

@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import (BPRMF, DDRec, DHCF, FKAN_GCF, FREEDOM, GUME, LGMRec, LayerGCN, LightGCN, LightGT, MCLN, MGCN, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SimGCL, SLMRec,
+from .Model import (BPRMF, DCCF, DDRec, DHCF, FKAN_GCF, FREEDOM, GUME, LGMRec, LayerGCN, LightGCN, LightGT, MCLN, MGCN, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SimGCL, SLMRec,
                     SMORE, VBPR, VGCL, XSimGCL)
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
@@ -80,6 +80,9 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
                                    args.n_layers, device),
         'MMGCL': lambda: MMGCL(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                                args.n_layers, args.ssl_alpha, args.ssl_temp, args.dropout, device),
+        # (main.py:325-326)
+        'DCCF': lambda: DCCF(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers, args.ssl_temp,
+                             args.ssl_alpha, args.n_intents, args.cen_reg, device),
         # (main.py:299-301)
         'DDRec': lambda: DDRec(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.feature_embed,
                                args.reg_weight, args.n_layers, args.ssl_temp, args.ssl_alpha, args.threshold, aggr_mode, device),

@@ -208,17 +208,25 @@ def edge_dropout_norm(structure, p, seed, step=0, step_dev=None, salt=0, keep=No
 
 
 class _SpMMValues(torch.autograd.Function):
-    """y = A x where A's values change every call (edge dropout) while its structure is fixed: forward with `val`,
-    backward with `val_t` (A^T in the same structure)."""
+    """y = A x where A's values change every call (edge dropout, learned edge weights) while its structure is fixed:
+    forward with `val`, backward with `val_t` (A^T in the same structure).  Values that require a gradient get one
+    (what torch.sparse.mm gives a sparse operand's values): d val[k] = <gy[row_k], x[col_k]> per stored entry -- `val_t`
+    is only the transposed COPY the backward SpMM reads, no gradient flows through it."""
 
     @staticmethod
     def forward(ctx, x, structure, val, val_t):
-        ctx.structure, ctx.val_t = structure, val_t
-        return _ops.spmm_raw(structure.with_values(val), x)
+        ctx.structure = structure
+        ctx.val_grad = ctx.needs_input_grad[2]
+        ctx.save_for_backward(val_t, x if ctx.val_grad else None)
+        return _ops.spmm_raw(structure.with_values(val.detach()), x)
 
     @staticmethod
     def backward(ctx, gy):
-        return _ops.spmm_raw(ctx.structure.with_values(ctx.val_t), gy.contiguous()), None, None, None
+        val_t, x = ctx.saved_tensors
+        st, gy = ctx.structure, gy.contiguous()
+        gx = _ops.spmm_raw(st.with_values(val_t.detach()), gy) if ctx.needs_input_grad[0] else None
+        gval = (gy[st.entry_row.long()] * x[st.col.long()]).sum(dim=1) if ctx.val_grad else None
+        return gx, None, gval, None
 
 
 def spmm_values(structure, val, val_t, x):

@@ -227,6 +227,48 @@ def test_ddrec_golden(dev):
     assert 0 < kept < m.n_edges
 
 
+def test_dccf_golden(dev):
+    """Model/DCCF.py: the two adaptively re-weighted propagates per layer as the dynamic-values SpMM with DIFFERENTIABLE values
+    (d weight = <gy[head], x[tail]>, the gradient torch.sparse.mm gives its sparse operand) over one structure, a repeated
+    interaction counted twice; intent read-outs on the GEMM: loss, every gradient, the layer-summed tables, the ranking."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import DCCF
+    g = load_golden("dccf_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = DCCF(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), int(g["L"]),
+             float(g["ssl_temp"]), float(g["ssl_alpha"]), int(g["K"]), float(g["cen_reg"]), dev).to(dev)
+    assert m.n_edges == len(g["edges"]) - 1 and float(m._ew.max()) == 2.0
+    _check_common(m, g, dev, m.norm_adj_mat, 1e-4)
+    for got, name in ((m.ua_embedding, "ua"), (m.ia_embedding, "ia")):
+        assert np.abs(got.detach().cpu().numpy() - g[name]).max() <= 5e-6 * np.abs(g[name]).max(), name
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["ua"] @ g["ia"].T, U)
+
+
+def test_spmm_values_gradient_of_the_values(dev):
+    """ops.spmm_values with values that require a gradient against torch.sparse.mm's own autograd (dense restatement): the
+    product, the dense operand's gradient through the transposed values, and every stored value's gradient."""
+    from chaorec_amd import graph, sparse
+    gen = torch.Generator().manual_seed(5)
+    n, nnz, D = 300, 2000, 32
+    r, c = torch.randint(0, n, (nnz,), generator=gen), torch.randint(0, n, (nnz,), generator=gen)
+    csr = graph.coo_to_csr_coalesced(torch.cat([r, c]), torch.cat([c, r]), torch.ones(2 * nnz), n, n, symmetric=True).to(dev)
+    st = sparse._dropout_structure(csr)
+    val = torch.rand(csr.nnz, generator=gen).to(dev).requires_grad_()
+    x = torch.randn(n, D, generator=gen).to(dev).requires_grad_()
+    w = torch.randn(n, D, generator=gen).to(dev)
+    y = sparse.mm(sparse.DroppedAdj(st, val, val[st.transpose_entry.long()]), x)
+    (y * w).sum().backward()
+    rows = st.entry_row.long()
+    vd, xd = val.detach().double().requires_grad_(), x.detach().double().requires_grad_()
+    dense = torch.zeros(n, n, dtype=torch.float64, device=dev).index_put((rows, st.col.long()), vd)
+    yd = dense @ xd
+    (yd * w.double()).sum().backward()
+    assert torch.allclose(y.detach().double(), yd.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x.grad.double(), xd.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(val.grad.double(), vd.grad, rtol=1e-5, atol=1e-5)
+
+
 def test_selfcf_golden(dev):
     from chaorec_amd import graph
     from chaorec_amd.Model import SelfCF
@@ -467,7 +509,7 @@ def test_gume_golden(dev):
     assert m.loss(*args).item() != m.loss(*args).item()
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""

@@ -436,13 +436,13 @@ def test_bench_launches_its_own_ranks_and_propagates_failures():
 
 
 @pytest.mark.parametrize("name", ["simgcl_small.npz", "xsimgcl_small.npz", "ncl_small.npz", "selfcf_small.npz", "slmrec_small.npz",
-                                  "mcln_small.npz", "vgcl_small.npz"])
+                                  "mcln_small.npz", "vgcl_small.npz", "dccf_small.npz"])
 def test_sparse_family_models_start_from_the_reference_state(name):
     """SimGCL / NCL / SelfCF (through the adapter alone): what needs no GPU -- the same seed gives the
     reference class's parameter names and initial weights, and graph.binary_sym_norm_csr gives its scipy-built
     D^-1/2 A D^-1/2 bit for bit (goldens of tests/golden/gen_sparse_family.py: the reference classes' own output)."""
     from chaorec_amd import graph
-    from chaorec_amd.Model import MCLN, NCL, SelfCF, SimGCL, SLMRec, VGCL, XSimGCL
+    from chaorec_amd.Model import DCCF, MCLN, NCL, SelfCF, SimGCL, SLMRec, VGCL, XSimGCL
     g = load_golden(name)
     U, I = int(g["U"]), int(g["I"])
     uid = graph.user_item_dict_from_edges(g["edges"])
@@ -461,6 +461,10 @@ def test_sparse_family_models_start_from_the_reference_state(name):
     elif name.startswith("mcln"):
         m = MCLN(U, I, g["edges"], uid, torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]),
                  int(g["L"]), int(g["n_mca"]), cpu)
+        adj = m.norm_adj_mat
+    elif name.startswith("dccf"):
+        m = DCCF(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), float(g["ssl_temp"]), float(g["ssl_alpha"]),
+                 int(g["K"]), float(g["cen_reg"]), cpu)
         adj = m.norm_adj_mat
     elif name.startswith("vgcl"):
         m = VGCL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), float(g["ssl_temp"]), float(g["ssl_alpha"]), cpu)
