@@ -55,6 +55,8 @@ def mm(adj, dense):
     result of sparse_dropout()."""
     if isinstance(adj, DroppedAdj):
         return ops.spmm_values(adj.structure, adj.val, adj.val_t, dense)
+    if isinstance(adj, LearnedAdj):
+        return _SpMMLearned.apply(dense, adj, adj.val)
     if isinstance(adj, graph.CSR):
         return ops.spmm(adj, dense)
     return ops.spmm(_cached_csr(adj), dense)
@@ -65,6 +67,56 @@ class DroppedAdj:
 
     def __init__(self, structure, val, val_t):
         self.structure, self.val, self.val_t = structure, val, val_t
+
+
+class LearnedAdj:
+    """A sparse operand built from embeddings THIS step (Model/MICRO.py:176-187: a kNN graph of the projected features), its
+    values carrying gradient, over its own structure -- any pattern; row-major entries (rowptr, col), `val` [nnz].  `mm` of it
+    is the HIP SpMM on a CSR laid down for this step, backward = the SpMM over the transposed layout (built on first use)
+    for the dense operand and d val[k] = <gy[row_k], x[col_k]> for the values.  detach() -> the constant graph.CSR the
+    following steps multiply with (the reference detaches the tensor, :188-190)."""
+
+    def __init__(self, rowptr, col, val, n_rows, n_cols):
+        self.rowptr, self.col, self.val = rowptr, col.to(torch.int32).contiguous(), val
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self._t = None
+
+    def entry_rows(self):
+        return torch.repeat_interleave(torch.arange(self.n_rows, dtype=torch.int64, device=self.col.device),
+                                       self.rowptr[1:] - self.rowptr[:-1])
+
+    def transposed(self):
+        """-> (rowptr_t, col_t, perm): entry k of A^T's row-major layout is entry perm[k] of A's."""
+        if self._t is None:
+            rows, col = self.entry_rows(), self.col.to(torch.int64)
+            perm = torch.argsort(col * self.n_rows + rows, stable=True)
+            rowptr_t = torch.zeros(self.n_cols + 1, dtype=torch.int64, device=col.device)
+            torch.cumsum(torch.bincount(col, minlength=self.n_cols), 0, out=rowptr_t[1:])
+            self._t = (rowptr_t, rows[perm].to(torch.int32).contiguous(), perm)
+        return self._t
+
+    def detach(self):
+        return graph.CSR(self.rowptr, self.col, self.val.detach().contiguous(), self.n_rows, self.n_cols)
+
+
+class _SpMMLearned(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj, val):
+        ctx.adj = adj
+        ctx.save_for_backward(x, val)
+        return ops.spmm_raw(graph.CSR(adj.rowptr, adj.col, val.detach().contiguous(), adj.n_rows, adj.n_cols), x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, val = ctx.saved_tensors
+        adj, gy = ctx.adj, gy.contiguous()
+        gx = gval = None
+        if ctx.needs_input_grad[0]:
+            rowptr_t, col_t, perm = adj.transposed()
+            gx = ops.spmm_raw(graph.CSR(rowptr_t, col_t, val.detach()[perm].contiguous(), adj.n_cols, adj.n_rows), gy)
+        if ctx.needs_input_grad[2]:
+            gval = (gy[adj.entry_rows()] * x[adj.col.long()]).sum(dim=1)
+        return gx, None, gval
 
 
 def _dropout_structure(csr):

@@ -13,7 +13,8 @@ from .utils import EarlyStopping, EvalLists, gene_metrics, gene_metrics_device
 MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM", "LayerGCN", "POWERec")     # reference train_and_evaluate.py:554
 E_STEP = ("NCL", "VGCL")                # reference train_and_evaluate.py:107-114, :116-125
-NO_CAPTURE = ("NCL", "VGCL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
+BUILD_FIRST = ("MICRO",)                # reference train_and_evaluate.py:96-103: the first batch of an epoch rebuilds the item graphs
+NO_CAPTURE = ("NCL", "VGCL", "MICRO", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
 
 
 def _train_epoch_in_launch(model, loader, optimizer, graphed):
@@ -53,6 +54,7 @@ def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):
     if graphed is not None and getattr(graphed, "draws_in_launch", False):
         return _train_epoch_in_launch(model, train_loader, optimizer, graphed)
     sum_loss = None
+    build_item_graph = True
     for batch in train_loader:
         if graphed is not None:
             d = graphed(*batch)
@@ -62,7 +64,11 @@ def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):
                 if model_name == "VGCL":
                     model.forward()          # (train_and_evaluate.py:120: VGCL clusters the noised view of THIS forward; its loss() runs none)
                 model.e_step()               # NCL clusters its embeddings before EVERY batch (train_and_evaluate.py:107-114)
-            loss = model.loss(*batch)
+            if model_name in BUILD_FIRST:
+                loss = model.loss(*batch, build_item_graph=build_item_graph)
+                build_item_graph = False
+            else:
+                loss = model.loss(*batch)
             loss.backward()
             optimizer.step()
             d = loss.detach()

@@ -269,6 +269,81 @@ def test_spmm_values_gradient_of_the_values(dev):
     assert torch.allclose(val.grad.double(), vd.grad, rtol=1e-5, atol=1e-5)
 
 
+def test_micro_golden(dev):
+    """Model/MICRO.py over two steps.  Step 1 builds the item graphs on the device (chunked cosine kNN of the projected features,
+    mixed with the raw-feature graphs: entries and values against the reference's tensors) and multiplies with them as
+    `sparse.LearnedAdj`: the loss and EVERY gradient, the projections' and feature tables' -- which only the sparse values
+    reach -- included.  Step 2 multiplies with the detached graphs: loss, gradients (none for the projections), table, ranking."""
+    from chaorec_amd import graph, sparse
+    from chaorec_amd.Model import MICRO
+    g = load_golden("micro_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = MICRO(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]),
+              int(g["D"]), int(g["L"]), float(g["reg"]), int(g["K"]), 1, float(g["ssl_temp"]), float(g["lambda_coeff"]),
+              float(g["ssl_alpha"]), "add", dev).to(dev)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    args = [torch.from_numpy(g[k]) for k in ("users", "pos", "neg")]
+    with pytest.raises(AttributeError):
+        m.loss(*args, False)
+    loss1 = m.loss(*args, True)
+    loss1.backward()
+    assert isinstance(m.image_adj, sparse.LearnedAdj)
+    for adj, tag in ((m.image_adj, "image"), (m.text_adj, "text")):
+        want, got = _coo_dense(g[tag + "_idx"], g[tag + "_val"], (I, I)), _csr_dense(adj.detach())
+        assert np.array_equal(got != 0, want != 0) and np.abs(got - want).max() <= 2e-6, tag
+    assert float(loss1.detach()) == pytest.approx(float(g["loss1"]), rel=1e-5)
+    assert len(g["no_grad1"]) == 0
+    for n, p in m.named_parameters():
+        ref = g["g1_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-8, n
+    assert np.abs(m.result.detach().cpu().numpy() - g["result1"]).max() <= 1e-5 * np.abs(g["result1"]).max()
+    m.zero_grad(set_to_none=True)
+    loss = m.loss(*args, False)
+    loss.backward()
+    assert isinstance(m.image_adj, graph.CSR)
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    unused = set(str(n) for n in g["no_grad"])
+    assert unused == {"image_embedding.weight", "text_embedding.weight", "image_trs.weight", "image_trs.bias", "text_trs.weight", "text_trs.bias"}
+    for n, p in m.named_parameters():
+        if n in unused:
+            assert p.grad is None, n
+            continue
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-8, n
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+
+
+def test_learned_adj_gradients(dev):
+    """sparse.LearnedAdj (a non-symmetric pattern, values with gradient) against a dense restatement in fp64: product, the
+    dense operand's gradient through the transposed layout, every value's gradient; detach() is the same constant matrix."""
+    from chaorec_amd import sparse
+    gen = torch.Generator().manual_seed(6)
+    n, m_, nnz, D = 200, 260, 3000, 32
+    key = torch.unique(torch.randint(0, n * m_, (nnz,), generator=gen))
+    rows, cols = torch.div(key, m_, rounding_mode="floor"), key % m_
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    torch.cumsum(torch.bincount(rows, minlength=n), 0, out=rowptr[1:])
+    val = torch.rand(key.numel(), generator=gen).to(dev).requires_grad_()
+    x = torch.randn(m_, D, generator=gen).to(dev).requires_grad_()
+    w = torch.randn(n, D, generator=gen).to(dev)
+    adj = sparse.LearnedAdj(rowptr.to(dev), cols.to(dev), val, n, m_)
+    y = sparse.mm(adj, x)
+    (y * w).sum().backward()
+    vd, xd = val.detach().double().requires_grad_(), x.detach().double().requires_grad_()
+    dense = torch.zeros(n, m_, dtype=torch.float64, device=dev).index_put((rows.to(dev), cols.to(dev)), vd)
+    yd = dense @ xd
+    (yd * w.double()).sum().backward()
+    assert torch.allclose(y.detach().double(), yd.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x.grad.double(), xd.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(val.grad.double(), vd.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(sparse.mm(adj.detach(), x.detach()), y.detach(), rtol=1e-6, atol=1e-6)
+
+
 def test_selfcf_golden(dev):
     from chaorec_amd import graph
     from chaorec_amd.Model import SelfCF
@@ -509,7 +584,7 @@ def test_gume_golden(dev):
     assert m.loss(*args).item() != m.loss(*args).item()
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""

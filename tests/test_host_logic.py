@@ -491,7 +491,7 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
-@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec"])
+@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec", "micro"])
 def test_round5_family_members_start_from_the_reference_state(name):
     """The six members added in round 5, what needs no GPU: the same seed gives the reference class's parameter names and
     initial weights, the graphs built vectorised here are the reference's scipy / torch ones (SMORE: the weighted user-item
@@ -522,6 +522,8 @@ def test_round5_family_members_start_from_the_reference_state(name):
     elif name == "ddrec":
         m = M.DDRec(U, I, g["edges"], uid, *feats, D, D, float(g["reg"]), int(g["L"]), 0.2, 0.01, 0.0, "add", cpu)
         adjs = {"mm": (m.mm_adj, (I, I), 1e-7), "image": (m.image_adj, (I, I), 1e-7), "text": (m.text_adj, (I, I), 1e-7)}
+    elif name == "micro":
+        m = M.MICRO(U, I, g["edges"], uid, *feats, D, int(g["L"]), float(g["reg"]), int(g["K"]), 1, 0.5, 0.1, 0.1, "add", cpu)
     elif name == "gume":
         m = M.GUME(U, I, g["edges"], uid, *feats, D, int(g["L"]), int(g["L_ui"]), 0.1, 0.1, "none", cpu)
         assert np.array_equal(np.array(sorted(map(tuple, m.inter.t().tolist())), dtype=np.int64), g["inter"])
@@ -555,6 +557,8 @@ def test_round5_family_members_start_from_the_reference_state(name):
             u2 = torch.stack((torch.from_numpy(g["users"]), torch.from_numpy(g["users"])), 1)
             m.loss(u2, torch.stack((torch.from_numpy(g["pos"]), torch.from_numpy(g["neg"])), 1), torch.from_numpy(g["mask"]),
                    torch.from_numpy(g["user_item"]))
+        elif name == "micro":
+            m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")), True)
         else:
             m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")))
 
