@@ -32,6 +32,12 @@ def build_parser():
     parser.add_argument('--prompt_num', type=float, default=0.1, help='prompt modal numbers.')
     parser.add_argument('--neg_weight', type=float, default=0.1, help='weak modal weight.')
     parser.add_argument('--n_ui_layers', type=int, default=3, help='n_ui layers.')
+    parser.add_argument('--leaky', type=float, default=0.5, help='HCCF leaky')
+    parser.add_argument('--keepRate', type=float, default=1.0, help='HCCF keep rate')
+    parser.add_argument('--mult', type=float, default=0.1, help='HCCF hypergraph scale')
+    parser.add_argument('--align_weight', type=float, default=0.1, help='MENTOR align_weight')
+    parser.add_argument('--mask_weight_f', type=float, default=1.5, help='MENTOR mask_weight_f')
+    parser.add_argument('--mask_weight_g', type=float, default=0.001, help='MENTOR mask_weight_g')
     parser.add_argument('--cen_reg', type=float, default=5e-3, help='intent regularization')
     parser.add_argument('--n_intents', type=int, default=128, help='Number of latent intents')
     parser.add_argument('--threshold', type=float, default=0.1, help='the number of threshold.')

@@ -14,6 +14,8 @@ propagate", and say so.  Published semantics restated here:
   * utils.degree(index, num_nodes, dtype) = zeros(N).scatter_add_(0, index, ones)
   * utils.add_self_loops(edge_index, num_nodes) appends arange(N) x2 AFTER the edges
   * utils.dropout_adj(edge_index, p): mask = torch.rand(E) >= p; edge_index[:, mask]   (Model/NGCF.py:40)
+  * utils.remove_self_loops(edge_index): the columns with row != col; a message() that names `edge_index` / `size` receives
+    propagate's own two arguments (Model/MENTOR.py:82-99, Model/DDRec.py / Model/MICRO.py through their GCNConv)
 """
 import inspect
 import sys
@@ -39,6 +41,10 @@ class MessagePassing(torch.nn.Module):
                 msg_kwargs[name] = kwargs[name[:-2]].index_select(0, src)
             elif name.endswith("_i"):
                 msg_kwargs[name] = kwargs[name[:-2]].index_select(0, dst)
+            elif name == "edge_index":          # (PyG hands these two to a message() that names them: Model/MENTOR.py:92)
+                msg_kwargs[name] = edge_index
+            elif name == "size":
+                msg_kwargs[name] = list(size) if size is not None else [x.size(0), x.size(0)]
             else:
                 msg_kwargs[name] = kwargs[name]
         msg = self.message(**msg_kwargs)
@@ -87,6 +93,11 @@ def scatter_add(src, index, dim=0, out=None, dim_size=None):
     return torch.zeros((n,), dtype=src.dtype, device=src.device).scatter_add_(0, index, src)
 
 
+def remove_self_loops(edge_index, edge_attr=None):
+    keep = edge_index[0] != edge_index[1]
+    return edge_index[:, keep], (edge_attr[keep] if edge_attr is not None else None)
+
+
 def _unused(*a, **k):
     raise NotImplementedError("not on the hot path")
 
@@ -108,7 +119,7 @@ def install():
     inits.uniform = _unused
     utils.degree = degree
     utils.add_self_loops = add_self_loops
-    utils.remove_self_loops = _unused
+    utils.remove_self_loops = remove_self_loops
     utils.softmax = _unused
     utils.dropout_adj = dropout_adj
     tg.nn = nn

@@ -344,6 +344,90 @@ def test_learned_adj_gradients(dev):
     assert torch.allclose(sparse.mm(adj.detach(), x.detach()), y.detach(), rtol=1e-6, atol=1e-6)
 
 
+def test_mentor_golden(dev):
+    """Model/MENTOR.py: seven two-hop encoders (14 propagates through sparse.mm over ONE CSR = Base_gcn's remove-self-loops +
+    degree normalisation + scatter-add), six item-graph products, the MLPs on the GEMM; the reference run's eight perturbation
+    draws and two dropout masks replayed: loss, every gradient (41 parameters; none for the no_grad mask branch's Linear and
+    the unused feature tables), the fused table, the ranking."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MENTOR
+    g = load_golden("mentor_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = MENTOR(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]),
+               int(g["D"]), 1, float(g["reg"]), float(g["ssl_temp"]), float(g["dropout"]), float(g["align_weight"]),
+               float(g["mask_weight_g"]), float(g["mask_weight_f"]), dev).to(dev)
+    want, got = _coo_dense(g["mm_idx"], g["mm_val"], (I, I)), _csr_dense(m.mm_adj)
+    assert np.array_equal(got != 0, want != 0) and np.abs(got - want).max() <= 1e-7
+    it = iter([torch.from_numpy(n).to(dev) for n in g["noise"]])
+    m.noise_fn = lambda x: next(it)
+    masks = iter([torch.from_numpy(g["mask_u"]).to(dev), torch.from_numpy(g["mask_i"]).to(dev)])
+    m.dropout_fn = lambda x, p: x * next(masks) / (1 - p)
+    assert set(str(n) for n in g["no_grad"]) == {"mlp.weight", "mlp.bias", "image_embedding.weight", "text_embedding.weight"}
+    _golden_model_checks(m, g, dev, 2e-4, 1e-7)
+    # (the reference's forward re-registers the three plain encoders' preferences on the model itself, :162-164: same here)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names_after"]]
+    res = m.result_embed.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+    m.noise_fn = m.dropout_fn = None                          # the default draws on the device: two losses differ
+    args = [torch.from_numpy(g[k]) for k in ("users", "pos", "neg")]
+    assert m.loss(*args).item() != m.loss(*args).item()
+
+
+def test_hccf_golden(dev):
+    """Model/HCCF.py at keepRate 1 (deterministic): loss, gradients, the layer-summed table, the ranking; then keepRate < 1: the
+    propagate runs over sparse_dropout's value array (kept share ~ keepRate, kept values scaled by 1 / keepRate)."""
+    from chaorec_amd import graph, sparse
+    from chaorec_amd.Model import HCCF
+    g = load_golden("hccf_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = HCCF(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), int(g["L"]), "add",
+             float(g["ssl_alpha"]), float(g["ssl_temp"]), 1.0, 0.5, float(g["mult"]), dev).to(dev)
+    _check_common(m, g, dev, m.adj, 5e-5)
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+    m.keepRate = 0.5
+    a = m.sp_adj_drop_edge()
+    assert isinstance(a, sparse.DroppedAdj)
+    kept = a.val != 0
+    assert 0.35 < float(kept.float().mean()) < 0.65
+    assert torch.allclose(a.val[kept], m.adj.val[kept] / 0.5)
+    assert torch.isfinite(m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg"))))
+
+
+def test_lightgcl_golden(dev):
+    """Model/LightGCL.py: the [U, I] matrix (a repeated interaction counted twice) bit for bit, the step with the reference
+    run's SVD factors -- loss, gradients, layer-summed tables, ranking --, and this construction's own randomised SVD through
+    the HIP SpMM against the exact top-q triplets of the dense matrix."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import LightGCL
+    g = load_golden("lightgcl_small.npz")
+    U, I, q = int(g["U"]), int(g["I"]), 5
+    torch.manual_seed(0)
+    m = LightGCL(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), int(g["L"]), "add",
+                 float(g["ssl_alpha"]), float(g["ssl_temp"]), dev).to(dev)
+    dense = _coo_dense(g["adj_idx"], g["adj_val"], (U, I))
+    assert np.array_equal(_csr_dense(m.adj_norm) != 0, dense != 0) and np.abs(_csr_dense(m.adj_norm) - dense).max() <= 6e-8
+    # own factors: the rank-q product is as close to A as the exact truncated SVD's (two power iterations: within a few %)
+    s_exact = np.linalg.svd(dense.astype(np.float64), compute_uv=False)
+    own = (m.u_mul_s @ m.vt).cpu().numpy().astype(np.float64)
+    best = np.sqrt((s_exact[q:] ** 2).sum())
+    assert np.linalg.norm(dense - own) <= 1.05 * best
+    assert torch.allclose(m.ut @ m.ut.T, torch.eye(q, device=dev), atol=1e-4) and torch.allclose(m.vt @ m.vt.T, torch.eye(q, device=dev), atol=1e-4)
+    ref = (g["u_mul_s"] @ g["vt"]).astype(np.float64)
+    assert np.linalg.norm(dense - ref) <= 1.05 * best                      # (the reference run's factors: the same quality)
+    for name in ("u_mul_s", "v_mul_s", "ut", "vt"):
+        setattr(m, name, torch.from_numpy(g[name]).to(dev))
+    _golden_model_checks(m, g, dev, 1e-4, 1e-8)
+    for got, name in ((m.E_u, "E_u"), (m.E_i, "E_i")):
+        assert np.abs(got.detach().cpu().numpy() - g[name]).max() <= 5e-6 * np.abs(g[name]).max(), name
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["E_u"] @ g["E_i"].T, U)
+
+
 def test_selfcf_golden(dev):
     from chaorec_amd import graph
     from chaorec_amd.Model import SelfCF
@@ -584,7 +668,7 @@ def test_gume_golden(dev):
     assert m.loss(*args).item() != m.loss(*args).item()
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
