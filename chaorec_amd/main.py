@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import (BPRMF, DCCF, DDRec, DHCF, FKAN_GCF, FREEDOM, GUME, HCCF, LGMRec, LightGCL, LayerGCN, LightGCN, LightGT, MCLN, MENTOR, MGCN, MICRO, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SimGCL, SLMRec,
+from .Model import (BM3, BPRMF, DCCF, DDRec, DHCF, FKAN_GCF, FREEDOM, GUME, HCCF, LGMRec, LightGCL, LayerGCN, LightGCN, LightGT, MCLN, MENTOR, MGCL, MGCN, MICRO, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SGL, SimGCL, SLMRec,
                     SMORE, VBPR, VGCL, XSimGCL)
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
@@ -80,6 +80,14 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
                                    args.n_layers, device),
         'MMGCL': lambda: MMGCL(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight,
                                args.n_layers, args.ssl_alpha, args.ssl_temp, args.dropout, device),
+        # (main.py:282-283, :314-315)
+        'BM3': lambda: BM3(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.feature_embed, args.reg_weight,
+                           args.dropout, args.n_layers, args.cl_weight, aggr_mode, device),
+        'MGCL': lambda: MGCL(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight, args.n_layers,
+                             aggr_mode, args.ssl_temp, args.ssl_alpha, device),
+        # (main.py:302-303)
+        'SGL': lambda: SGL(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers, aggr_mode,
+                           args.ssl_temp, args.ssl_alpha, device),
         # (main.py:309-313)
         'LightGCL': lambda: LightGCL(num_user, num_item, train_data, user_item_dict, dim_E, args.reg_weight, args.n_layers, aggr_mode,
                                      args.ssl_alpha, args.ssl_temp, device),
@@ -123,7 +131,7 @@ def main(argv=None):
     if device.type != "cuda":
         raise SystemExit("chaorec_amd runs on the MI355X only: no GPU visible")
     config = load_yaml_config(args.Model)
-    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE", "MMGCL", "LightGT", "GUME", "DDRec", "MICRO", "MENTOR")
+    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE", "MMGCL", "LightGT", "GUME", "DDRec", "MICRO", "MENTOR", "BM3", "MGCL")
     train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat = dataload.data_load(
         args.data_path, has_v=needs_feat, has_t=needs_feat, data_root=args.data_root, synthetic=args.synthetic)
     if args.host_sampler:

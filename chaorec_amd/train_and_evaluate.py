@@ -14,7 +14,7 @@ MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM", "LayerGCN", "POWERec")     # reference train_and_evaluate.py:554
 E_STEP = ("NCL", "VGCL")                # reference train_and_evaluate.py:107-114, :116-125
 BUILD_FIRST = ("MICRO",)                # reference train_and_evaluate.py:96-103: the first batch of an epoch rebuilds the item graphs
-NO_CAPTURE = ("NCL", "VGCL", "MICRO", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
+NO_CAPTURE = ("NCL", "VGCL", "MICRO", "SGL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
 
 
 def _train_epoch_in_launch(model, loader, optimizer, graphed):

@@ -428,6 +428,77 @@ def test_lightgcl_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["E_u"] @ g["E_i"].T, U)
 
 
+def test_sgl_golden(dev):
+    """Model/SGL.py: the two edge-dropped views of a step as value arrays over one CSR (the reference run's recorded draws over
+    the LISTED edges, a repeated interaction's copies adding up) against its rebuilt scipy Laplacians: loss, gradients, the
+    main view's tables, the ranking; then the device draw keeps the right number of listed edges."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import SGL
+    g = load_golden("sgl_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = SGL(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), int(g["D"]), float(g["reg"]), int(g["L"]), "add",
+            float(g["ssl_temp"]), float(g["ssl_reg"]), dev).to(dev)
+    assert m.n_listed == len(g["edges"]) and m.n_edges == m.n_listed - 1
+    keeps = iter([g["keep1"], g["keep2"]])
+
+    def edge_keep(n, ratio):
+        k = torch.zeros(n, dtype=torch.bool)
+        k[torch.from_numpy(next(keeps))] = True
+        return k
+
+    m.edge_keep_fn = edge_keep
+    want, got = _coo_dense(g["norm_idx"], g["norm_val"], (U + I, U + I)), _csr_dense(m.norm_adj)
+    assert np.array_equal(got != 0, want != 0) and np.abs(got - want).max() <= 2e-7
+    _golden_model_checks(m, g, dev, 1e-4, 1e-8)
+    for got, name in ((m.user_emb_final, "user_emb"), (m.item_emb_final, "item_emb")):
+        assert np.abs(got.detach().cpu().numpy() - g[name]).max() <= 5e-6 * np.abs(g[name]).max(), name
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["user_emb"] @ g["item_emb"].T, U)
+    m.edge_keep_fn = None
+    a = m.create_adj_mat(is_subgraph=True, aug_type='ed')
+    kept_pairs = int((a.val[:m.n_edges] != 0).sum())
+    assert int(m.n_listed * 0.9) - 1 <= kept_pairs <= int(m.n_listed * 0.9)
+    for aug in ("nd", "rw"):
+        m.ssl_aug_type = aug
+        assert torch.isfinite(m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg"))))
+
+
+def test_bm3_golden(dev):
+    """Model/BM3.py: LightGCN's propagate (GCNConv) as the hot path's layer-mean launch, the predictor and the [I, F] projections on
+    the GEMM, the reference run's four dropout masks replayed: loss, every gradient, the table, the ranking over the PREDICTED
+    tables."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import BM3
+    g = load_golden("bm3_small.npz")
+    U, I, D = int(g["U"]), int(g["I"]), int(g["D"])
+    torch.manual_seed(0)
+    m = BM3(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]),
+            D, D, float(g["reg"]), float(g["dropout"]), int(g["L"]), float(g["cl_weight"]), "add", dev).to(dev)
+    masks = iter([torch.from_numpy(g[k]).to(dev) for k in ("mask_u", "mask_i", "mask_t", "mask_v")])
+    m.dropout_fn = lambda x, p: x * next(masks) / (1 - p)
+    _golden_model_checks(m, g, dev, 1e-4, 1e-8)
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["scores"], U)
+
+
+def test_mgcl_golden(dev):
+    """Model/MGCL.py: three LightGCN encoders over one graph (layer-mean launches), three fused BPR terms, the cross-entropy
+    contrast: loss, every gradient (none for the unused 0-dim lambda_m), the id table, the ranking."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MGCL
+    g = load_golden("mgcl_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = MGCL(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]),
+             int(g["D"]), float(g["reg"]), int(g["L"]), "add", float(g["ssl_temp"]), float(g["ssl_alpha"]), dev).to(dev)
+    assert [str(n) for n in g["no_grad"]] == ["lambda_m"]
+    _golden_model_checks(m, g, dev, 1e-4, 1e-8)
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 5e-6 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+
+
 def test_selfcf_golden(dev):
     from chaorec_amd import graph
     from chaorec_amd.Model import SelfCF
@@ -668,7 +739,7 @@ def test_gume_golden(dev):
     assert m.loss(*args).item() != m.loss(*args).item()
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL", "SGL", "BM3", "MGCL"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""

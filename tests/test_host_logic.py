@@ -436,13 +436,13 @@ def test_bench_launches_its_own_ranks_and_propagates_failures():
 
 
 @pytest.mark.parametrize("name", ["simgcl_small.npz", "xsimgcl_small.npz", "ncl_small.npz", "selfcf_small.npz", "slmrec_small.npz",
-                                  "mcln_small.npz", "vgcl_small.npz", "dccf_small.npz", "hccf_small.npz"])
+                                  "mcln_small.npz", "vgcl_small.npz", "dccf_small.npz", "hccf_small.npz", "sgl_small.npz"])
 def test_sparse_family_models_start_from_the_reference_state(name):
     """SimGCL / NCL / SelfCF (through the adapter alone): what needs no GPU -- the same seed gives the
     reference class's parameter names and initial weights, and graph.binary_sym_norm_csr gives its scipy-built
     D^-1/2 A D^-1/2 bit for bit (goldens of tests/golden/gen_sparse_family.py: the reference classes' own output)."""
     from chaorec_amd import graph
-    from chaorec_amd.Model import DCCF, HCCF, MCLN, NCL, SelfCF, SimGCL, SLMRec, VGCL, XSimGCL
+    from chaorec_amd.Model import DCCF, HCCF, MCLN, NCL, SelfCF, SGL, SimGCL, SLMRec, VGCL, XSimGCL
     g = load_golden(name)
     U, I = int(g["U"]), int(g["I"])
     uid = graph.user_item_dict_from_edges(g["edges"])
@@ -462,6 +462,9 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m = MCLN(U, I, g["edges"], uid, torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]), int(g["D"]), float(g["reg"]),
                  int(g["L"]), int(g["n_mca"]), cpu)
         adj = m.norm_adj_mat
+    elif name.startswith("sgl"):
+        m = SGL(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), "add", float(g["ssl_temp"]), float(g["ssl_reg"]), cpu)
+        adj = m.norm_adj
     elif name.startswith("hccf"):
         m = HCCF(U, I, g["edges"], uid, int(g["D"]), float(g["reg"]), int(g["L"]), "add", float(g["ssl_alpha"]), float(g["ssl_temp"]),
                  1.0, 0.5, float(g["mult"]), cpu)
@@ -495,7 +498,7 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
-@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec", "micro", "mentor", "lightgcl"])
+@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec", "micro", "mentor", "lightgcl", "bm3", "mgcl"])
 def test_round5_family_members_start_from_the_reference_state(name):
     """The six members added in round 5, what needs no GPU: the same seed gives the reference class's parameter names and
     initial weights, the graphs built vectorised here are the reference's scipy / torch ones (SMORE: the weighted user-item
@@ -526,6 +529,10 @@ def test_round5_family_members_start_from_the_reference_state(name):
     elif name == "ddrec":
         m = M.DDRec(U, I, g["edges"], uid, *feats, D, D, float(g["reg"]), int(g["L"]), 0.2, 0.01, 0.0, "add", cpu)
         adjs = {"mm": (m.mm_adj, (I, I), 1e-7), "image": (m.image_adj, (I, I), 1e-7), "text": (m.text_adj, (I, I), 1e-7)}
+    elif name == "bm3":
+        m = M.BM3(U, I, g["edges"], uid, *feats, D, D, float(g["reg"]), 0.3, int(g["L"]), 2.0, "add", cpu)
+    elif name == "mgcl":
+        m = M.MGCL(U, I, g["edges"], uid, *feats, D, float(g["reg"]), int(g["L"]), "add", 0.2, 0.01, cpu)
     elif name == "lightgcl":
         m = M.LightGCL(U, I, g["edges"], uid, D, float(g["reg"]), int(g["L"]), "add", 0.01, 0.1, cpu)
         adjs = {"adj": (m.adj_norm, (U, I), 6e-8)}
