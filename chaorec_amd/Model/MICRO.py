@@ -19,9 +19,10 @@ from torch import nn
 from .. import graph, ops, ranking, sparse
 
 
-def knn_sym_entries(feats, topk, chunk=4096):
+def knn_sym_entries(feats, topk, chunk=4096, normalise=True):
     """:16-51 with is_sparse=True, norm_type='sym': cosine similarity of the rows, each row's `topk` largest (itself among
-    them), weight d^-1/2[row] w d^-1/2[col] with d = the row's kept weights summed (1 / 0 -> 0).  Differentiable in `feats`.
+    them), weight d^-1/2[row] w d^-1/2[col] with d = the row's kept weights summed (1 / 0 -> 0) -- or the kept cosines
+    themselves (normalise=False: LATTICE mixes two such graphs before it normalises).  Differentiable in `feats`.
     -> (idx [2, n topk], val [n topk])"""
     x = feats.div(torch.norm(feats, p=2, dim=-1, keepdim=True))
     n = x.shape[0]
@@ -33,6 +34,8 @@ def knn_sym_entries(feats, topk, chunk=4096):
     knn_val, knn_ind = torch.cat(vals), torch.cat(inds)
     row = torch.arange(n, device=x.device).repeat_interleave(topk)
     col, w = knn_ind.flatten(), knn_val.flatten()
+    if not normalise:
+        return torch.stack([row, col]), w
     dis = knn_val.sum(dim=1).pow(-0.5)
     dis = dis.masked_fill(dis == float('inf'), 0)
     return torch.stack([row, col]), dis[row] * w * dis[col]

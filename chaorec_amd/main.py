@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import (BM3, BPRMF, DCCF, DDRec, DHCF, FKAN_GCF, FREEDOM, GUME, HCCF, LGMRec, LightGCL, LayerGCN, LightGCN, LightGT, MCLN, MENTOR, MGCL, MGCN, MICRO, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SGL, SimGCL, SLMRec,
+from .Model import (BM3, BPRMF, DCCF, DDRec, DHCF, FKAN_GCF, FREEDOM, GUME, HCCF, LATTICE, LGMRec, LightGCL, LayerGCN, LightGCN, LightGT, MCLN, MENTOR, MGCL, MGCN, MICRO, MMGCN, NCL, NGCF, MMGCL, POWERec, SelfCF, SGL, SimGCL, SLMRec,
                     SMORE, VBPR, VGCL, XSimGCL)
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
@@ -96,6 +96,9 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
         # (main.py:346-348)
         'MENTOR': lambda: MENTOR(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.mm_layers, args.reg_weight,
                                  args.ssl_temp, args.dropout, args.align_weight, args.mask_weight_g, args.mask_weight_f, device),
+        # (main.py:276-279)
+        'LATTICE': lambda: LATTICE(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.feature_embed, args.reg_weight,
+                                   args.n_layers, args.mm_layers, args.ii_topk, aggr_mode, args.lambda_coeff, device),
         # (main.py:294-296)
         'MICRO': lambda: MICRO(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.n_layers, args.reg_weight,
                                args.ii_topk, args.mm_layers, args.ssl_temp, args.lambda_coeff, args.ssl_alpha, aggr_mode, device),
@@ -131,7 +134,7 @@ def main(argv=None):
     if device.type != "cuda":
         raise SystemExit("chaorec_amd runs on the MI355X only: no GPU visible")
     config = load_yaml_config(args.Model)
-    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE", "MMGCL", "LightGT", "GUME", "DDRec", "MICRO", "MENTOR", "BM3", "MGCL")
+    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE", "MMGCL", "LightGT", "GUME", "DDRec", "MICRO", "MENTOR", "BM3", "MGCL", "LATTICE")
     train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat = dataload.data_load(
         args.data_path, has_v=needs_feat, has_t=needs_feat, data_root=args.data_root, synthetic=args.synthetic)
     if args.host_sampler:

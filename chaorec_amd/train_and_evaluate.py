@@ -13,8 +13,8 @@ from .utils import EarlyStopping, EvalLists, gene_metrics, gene_metrics_device
 MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM", "LayerGCN", "POWERec")     # reference train_and_evaluate.py:554
 E_STEP = ("NCL", "VGCL")                # reference train_and_evaluate.py:107-114, :116-125
-BUILD_FIRST = ("MICRO",)                # reference train_and_evaluate.py:96-103: the first batch of an epoch rebuilds the item graphs
-NO_CAPTURE = ("NCL", "VGCL", "MICRO", "SGL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
+BUILD_FIRST = ("LATTICE", "MICRO")                # reference train_and_evaluate.py:96-103: the first batch of an epoch rebuilds the item graphs
+NO_CAPTURE = ("NCL", "VGCL", "LATTICE", "MICRO", "SGL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
 
 
 def _train_epoch_in_launch(model, loader, optimizer, graphed):

@@ -318,6 +318,52 @@ def test_micro_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
 
 
+def test_lattice_golden(dev):
+    """Model/LATTICE.py over two steps: the item graph the reference keeps as a dense [I, I] matrix, here a sparse.LearnedAdj over
+    the union of the four kNN patterns (entries and values against the dense matrix), its values carrying gradient into the
+    projections, the feature tables and the two modality weights; then the detached step; ranking."""
+    from chaorec_amd import graph, sparse
+    from chaorec_amd.Model import LATTICE
+    g = load_golden("lattice_small.npz")
+    U, I, D = int(g["U"]), int(g["I"]), int(g["D"])
+    torch.manual_seed(0)
+    m = LATTICE(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]),
+                D, D, float(g["reg"]), int(g["L"]), int(g["mm_layers"]), int(g["K"]), "add", float(g["lambda_coeff"]), dev).to(dev)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    args = [torch.from_numpy(g[k]) for k in ("users", "pos", "neg")]
+    with pytest.raises(AttributeError):
+        m.loss(*args, False)
+    loss1 = m.loss(*args, True)
+    loss1.backward()
+    assert isinstance(m.item_adj, sparse.LearnedAdj)
+    got = _csr_dense(m.item_adj.detach())
+    assert np.array_equal(got != 0, g["item_adj"] != 0) and np.abs(got - g["item_adj"]).max() <= 2e-6
+    assert float(loss1.detach()) == pytest.approx(float(g["loss1"]), rel=1e-5)
+    assert len(g["no_grad1"]) == 0
+    for n, p in m.named_parameters():
+        ref = g["g1_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-8, n
+    assert np.abs(m.result.detach().cpu().numpy() - g["result1"]).max() <= 1e-5 * np.abs(g["result1"]).max()
+    m.zero_grad(set_to_none=True)
+    loss = m.loss(*args, False)
+    loss.backward()
+    assert isinstance(m.item_adj, graph.CSR)
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    unused = set(str(n) for n in g["no_grad"])
+    assert "modal_weight" in unused and "image_trs.weight" in unused
+    for n, p in m.named_parameters():
+        if n in unused:
+            assert p.grad is None, n
+            continue
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-8, n
+    res = m.result.detach().cpu().numpy()
+    assert np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+
+
 def test_learned_adj_gradients(dev):
     """sparse.LearnedAdj (a non-symmetric pattern, values with gradient) against a dense restatement in fp64: product, the
     dense operand's gradient through the transposed layout, every value's gradient; detach() is the same constant matrix."""
@@ -739,7 +785,7 @@ def test_gume_golden(dev):
     assert m.loss(*args).item() != m.loss(*args).item()
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL", "SGL", "BM3", "MGCL"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL", "SGL", "BM3", "MGCL", "LATTICE"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
