@@ -5,6 +5,7 @@ pre_epoch_processing hook, per-epoch gene_ranklist + val/test metrics at K in to
 Recall@max(topk) with patience 20, the same log lines.  Changed: the per-batch `loss.item()` host sync
 (reference :48) becomes one device-side accumulation and a single .item() per epoch."""
 import logging
+import os
 
 import torch
 
@@ -14,7 +15,12 @@ MMGCN_STYLE = ("MMGCN", "GRCN")
 PRE_EPOCH = ("FREEDOM", "LayerGCN", "POWERec")     # reference train_and_evaluate.py:554
 E_STEP = ("NCL", "VGCL")                # reference train_and_evaluate.py:107-114, :116-125
 BUILD_FIRST = ("LATTICE", "MICRO")                # reference train_and_evaluate.py:96-103: the first batch of an epoch rebuilds the item graphs
-NO_CAPTURE = ("NCL", "VGCL", "LATTICE", "MICRO", "SGL", "SimGCL", "XSimGCL", "SelfCF", "SLMRec", "MMGCL", "LightGT")    # host-side randomness / clustering inside the step: eager launches
+# eager launches: clustering with host decisions inside the step (NCL, VGCL), an operand whose structure is rebuilt per epoch
+# (LATTICE, MICRO), draws that hipGraph capture refuses (torch.randperm: SGL, MMGCL), a HOST draw per step (SelfCF's dropout
+# rate is np.random.random(), Model/SelfCF.py:55: a capture would freeze it), host-built sequence batches (LightGT).
+# SimGCL / XSimGCL / SLMRec draw only with rand_like on the device generator, which a captured step advances per replay:
+# they are captured (round 5: 2 x the eager epoch rate at baby size, tools/capture_family_probe.py).
+NO_CAPTURE = ("NCL", "VGCL", "LATTICE", "MICRO", "SGL", "SelfCF", "MMGCL", "LightGT")
 
 
 def _train_epoch_in_launch(model, loader, optimizer, graphed):
@@ -101,7 +107,7 @@ def _capture_step(model, train_loader, optimizer, model_name):
     from .optim import FusedAdam, GraphedTrainStep
     if not isinstance(train_loader, DeviceBatchSampler) or not isinstance(optimizer, FusedAdam):
         return None
-    if model_name in NO_CAPTURE:
+    if model_name in NO_CAPTURE and model_name not in os.environ.get("CHAOREC_TRY_CAPTURE", "").split(","):
         return None
     if model_name in PRE_EPOCH and not getattr(model, "prunes_in_place", False):
         return None          # a graph that is re-allocated every epoch cannot sit behind captured addresses

@@ -545,6 +545,27 @@ def test_mgcl_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
 
 
+def test_captured_step_draws_fresh_noise_per_replay(dev):
+    """SimGCL's rand_like perturbation inside a CAPTURED step (train_and_evaluate captures SimGCL / XSimGCL / SLMRec): the graph
+    advances the device generator per replay.  With a zero learning rate and the same batch every replay computes the same
+    function of fresh draws: consecutive losses differ; with the perturbation radius at 0 they are identical."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import SimGCL
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    g = load_golden("simgcl_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = SimGCL(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), 16, 1e-3, 2, 0.2, 0.1, dev).to(dev)
+    batch = [torch.from_numpy(g[k]).to(dev) for k in ("users", "pos", "neg")]
+    step = GraphedTrainStep(m, FusedAdam(m.parameters(), lr=0.0), example_batch=batch)
+    losses = [float(step(*batch).item()) for _ in range(4)]
+    assert len(set(losses)) == 4, losses
+    m.eps = 0.0
+    step = GraphedTrainStep(m, FusedAdam(m.parameters(), lr=0.0), example_batch=batch)
+    losses = [float(step(*batch).item()) for _ in range(3)]
+    assert len(set(losses)) == 1, losses
+
+
 def test_selfcf_golden(dev):
     from chaorec_amd import graph
     from chaorec_amd.Model import SelfCF
@@ -785,7 +806,8 @@ def test_gume_golden(dev):
     assert m.loss(*args).item() != m.loss(*args).item()
 
 
-@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL", "SGL", "BM3", "MGCL", "LATTICE"])
+@pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL", "SGL", "BM3", "MGCL", "LATTICE",
+                                   "SimGCL", "XSimGCL", "SLMRec", "NCL", "SelfCF", "MCLN"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
