@@ -16,6 +16,12 @@ from torch import nn
 from .. import graph, ops, ranking, sparse
 
 
+def _subset(n, k, dev):
+    """k of range(n), uniformly without replacement (np.random.choice(n, k, replace=False), :69-70,88): the first k of a
+    random order, taken as the argsort of device uniforms."""
+    return torch.rand(n, device=dev).argsort()[:k]
+
+
 class SGL(nn.Module):
     def __init__(self, num_user, num_item, edge_index, user_item_dict, dim_E, reg_weight, n_layers, aggr_mode, ssl_temp,
                  ssl_reg, device):
@@ -65,15 +71,15 @@ class SGL(nn.Module):
             else:
                 ku = torch.ones(self.num_user, dtype=torch.bool, device=dev)
                 ki = torch.ones(self.num_item, dtype=torch.bool, device=dev)
-                ku[torch.randperm(self.num_user, device=dev)[:int(self.num_user * ratio)]] = False
-                ki[torch.randperm(self.num_item, device=dev)[:int(self.num_item * ratio)]] = False
+                ku[_subset(self.num_user, int(self.num_user * ratio), dev)] = False
+                ki[_subset(self.num_item, int(self.num_item * ratio), dev)] = False
             w = torch.where(ku[self._eu] & ki[self._ei], self._ew, torch.zeros_like(self._ew))
         else:                                                                       # :87-93: listed copies kept, copies of a pair add up
             if self.edge_keep_fn is not None:
                 keep = self.edge_keep_fn(self.n_listed, ratio).to(dev)
             else:
                 keep = torch.zeros(self.n_listed, dtype=torch.bool, device=dev)
-                keep[torch.randperm(self.n_listed, device=dev)[:int(self.n_listed * (1 - ratio))]] = True
+                keep[_subset(self.n_listed, int(self.n_listed * (1 - ratio)), dev)] = True
             w = torch.zeros(self.n_edges, dtype=torch.float32, device=dev).index_add_(0, self._pair_of_edge, keep.to(torch.float32))
         val = self._values(w)
         return sparse.DroppedAdj(self._structure, val, val)                         # (symmetric: its own transpose)

@@ -16,7 +16,7 @@ PRE_EPOCH = ("FREEDOM", "LayerGCN", "POWERec")     # reference train_and_evaluat
 E_STEP = ("NCL", "VGCL")                # reference train_and_evaluate.py:107-114, :116-125
 BUILD_FIRST = ("LATTICE", "MICRO")                # reference train_and_evaluate.py:96-103: the first batch of an epoch rebuilds the item graphs
 # eager launches: clustering with host decisions inside the step (NCL, VGCL), an operand whose structure is rebuilt per epoch
-# (LATTICE, MICRO), draws that hipGraph capture refuses (torch.randperm: SGL, MMGCL), a HOST draw per step (SelfCF's dropout
+# (LATTICE, MICRO), launches that hipGraph capture refuses (hipErrorStreamCaptureUnsupported inside the per-step view construction: SGL, MMGCL), a HOST draw per step (SelfCF's dropout
 # rate is np.random.random(), Model/SelfCF.py:55: a capture would freeze it), host-built sequence batches (LightGT).
 # SimGCL / XSimGCL / SLMRec draw only with rand_like on the device generator, which a captured step advances per replay:
 # they are captured (round 5: 2 x the eager epoch rate at baby size, tools/capture_family_probe.py).
