@@ -20,7 +20,7 @@ BUILD_FIRST = ("LATTICE", "MICRO")                # reference train_and_evaluate
 # rate is np.random.random(), Model/SelfCF.py:55: a capture would freeze it), host-built sequence batches (LightGT).
 # SimGCL / XSimGCL / SLMRec draw only with rand_like on the device generator, which a captured step advances per replay:
 # they are captured (round 5: 2 x the eager epoch rate at baby size, tools/capture_family_probe.py).
-NO_CAPTURE = ("NCL", "VGCL", "LATTICE", "MICRO", "SGL", "SelfCF", "MMGCL", "LightGT")
+NO_CAPTURE = ("NCL", "VGCL", "LATTICE", "MICRO", "SGL", "SelfCF", "MMGCL", "LightGT", "MMSSL")    # (MMSSL: two optimizers per batch, its own loop)
 
 
 def _train_epoch_in_launch(model, loader, optimizer, graphed):
@@ -54,9 +54,32 @@ def _train_epoch_in_launch(model, loader, optimizer, graphed):
     return float(sum_loss.item()) if sum_loss is not None else 0.0
 
 
+def _train_epoch_mmssl(model, train_loader, optimizer):
+    """reference train_and_evaluate.py:49-71: per batch a discriminator step (Adam, lr 3e-4, betas (0.5, 0.9)) and a generator step
+    (AdamW over ALL of model.parameters(), the discriminator's included, at the run's learning rate); both optimizers are
+    created anew every epoch there (their moments restart), the optimizer main() built is not used."""
+    optim_D = torch.optim.Adam(model.D.parameters(), lr=3e-4, betas=(0.5, 0.9))
+    optimizer_D = torch.optim.AdamW([{'params': model.parameters()}], lr=optimizer.param_groups[0]['lr'])
+    sum_loss = None
+    for idx, (users, pos_items, neg_items) in enumerate(train_loader):
+        optim_D.zero_grad()
+        loss_D = model.loss_D(users, pos_items, neg_items)
+        loss_D.backward()
+        optim_D.step()
+        optimizer_D.zero_grad()
+        batch_loss = model.loss(users, pos_items, neg_items, idx)
+        batch_loss.backward(retain_graph=False)
+        optimizer_D.step()
+        d = (loss_D + batch_loss).detach()
+        sum_loss = d.clone() if sum_loss is None else sum_loss.add_(d)
+    return float(sum_loss.item()) if sum_loss is not None else 0.0
+
+
 def train(model, train_loader, optimizer, model_name="LightGCN", graphed=None):
     """One epoch.  `graphed` (optim.GraphedTrainStep) replays the captured step for full-size batches."""
     model.train()
+    if model_name == "MMSSL":
+        return _train_epoch_mmssl(model, train_loader, optimizer)
     if graphed is not None and getattr(graphed, "draws_in_launch", False):
         return _train_epoch_in_launch(model, train_loader, optimizer, graphed)
     sum_loss = None

@@ -364,6 +364,59 @@ def test_lattice_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
 
 
+def test_mmssl_golden(dev):
+    """Model/MMSSL.py over three batches of the reference loop's order (loss_D, then loss(idx)): the row-normalised [U, I] / [I, U]
+    operands, the discriminator loss with its double-backward gradient penalty (the reference run's host draws replayed) and its
+    gradients, the generator loss and every gradient at batch 0, the modality graphs rewired on the device from batch 0's top-k
+    (batch 2's losses see them), then rewired from the emptied lists -- all-zero operands -- under the ranking's forward."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MMSSL
+    g = load_golden("mmssl_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = MMSSL(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]),
+              int(g["D"]), float(g["reg"]), float(g["ssl_alpha"]), float(g["ssl_temp"]), float(g["G_rate"]), int(g["mmlayer"]), dev).to(dev)
+    m.dropout.p, m.D.net[3].p, m.D.net[7].p, m.m_topk_rate = 0.0, 0.0, 0.0, float(g["m_topk_rate"])
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    for csr, tag, shape in ((m.ui_graph, "ui", (U, I)), (m.iu_graph, "iu", (I, U))):
+        want, got = _coo_dense(g[tag + "_idx"], g[tag + "_val"], shape), _csr_dense(csr)
+        assert np.array_equal(got != 0, want != 0) and np.abs(got - want).max() <= 6e-8, tag
+    uniforms, alphas = iter(g["uniforms"]), iter(g["alphas"])
+    m.uniform_fn = lambda shape: torch.from_numpy(next(uniforms))
+    m.alpha_fn = lambda n: torch.from_numpy(next(alphas))
+    args = [torch.from_numpy(g[k]) for k in ("users", "pos", "neg")]
+    for idx in range(3):
+        m.zero_grad(set_to_none=True)
+        loss_D = m.loss_D(*args)
+        assert float(loss_D.detach()) == pytest.approx(float(g[f"loss_D{idx}"]), rel=2e-5), idx
+        if idx == 0:
+            loss_D.backward()
+            # (a bias in front of a BatchNorm has an exactly zero gradient: what both runs hold there is rounding of a loss of
+            #  ~2 000 -- the tolerance is relative to the discriminator's largest gradient, not to each tensor's own)
+            scale = max(np.abs(g["gD_" + n]).max() for n, _ in m.D.named_parameters())
+            for n, p in m.D.named_parameters():
+                assert np.abs(p.grad.cpu().numpy() - g["gD_" + n]).max() <= 2e-4 * scale, n
+            m.zero_grad(set_to_none=True)
+        loss = m.loss(*args, idx)
+        assert float(loss.detach()) == pytest.approx(float(g[f"loss{idx}"]), rel=1e-5), idx
+        if idx == 0:
+            loss.backward()
+            unused = set(str(n) for n in g["no_grad"])
+            for n, p in m.named_parameters():
+                if n in unused:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+                    continue
+                ref = g["g_" + n]
+                assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-8, n
+        if idx == 1:
+            assert m.image_ui_graph is not None and m.image_ui_graph is not m.ui_graph      # rewired from batch 0's top-k
+    assert m.image_ui_graph is None and m.text_iu_graph is None                             # ... and from the emptied lists
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    _check_rank(rank, g, g["ua"] @ g["ia"].T, U)
+
+
 def test_learned_adj_gradients(dev):
     """sparse.LearnedAdj (a non-symmetric pattern, values with gradient) against a dense restatement in fp64: product, the
     dense operand's gradient through the transposed layout, every value's gradient; detach() is the same constant matrix."""
@@ -807,7 +860,7 @@ def test_gume_golden(dev):
 
 
 @pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL", "SGL", "BM3", "MGCL", "LATTICE",
-                                   "SimGCL", "XSimGCL", "SLMRec", "NCL", "SelfCF", "MCLN"])
+                                   "SimGCL", "XSimGCL", "SLMRec", "NCL", "SelfCF", "MCLN", "MMSSL"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""
