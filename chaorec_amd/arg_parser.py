@@ -32,6 +32,7 @@ def build_parser():
     parser.add_argument('--prompt_num', type=float, default=0.1, help='prompt modal numbers.')
     parser.add_argument('--neg_weight', type=float, default=0.1, help='weak modal weight.')
     parser.add_argument('--n_ui_layers', type=int, default=3, help='n_ui layers.')
+    parser.add_argument('--n_iterations', type=int, default=3, help='the number of iteration.')
     parser.add_argument('--G_rate', type=float, default=0.0001, help='MMSSL')
     parser.add_argument('--cl_weight', type=float, default=2.0, help='the number of cl_loss_weight.')
     parser.add_argument('--leaky', type=float, default=0.5, help='HCCF leaky')

@@ -15,7 +15,9 @@ propagate", and say so.  Published semantics restated here:
   * utils.add_self_loops(edge_index, num_nodes) appends arange(N) x2 AFTER the edges
   * utils.dropout_adj(edge_index, p): mask = torch.rand(E) >= p; edge_index[:, mask]   (Model/NGCF.py:40)
   * utils.remove_self_loops(edge_index): the columns with row != col; a message() that names `edge_index` / `size` receives
-    propagate's own two arguments (Model/MENTOR.py:82-99, Model/DDRec.py / Model/MICRO.py through their GCNConv)
+    propagate's own two arguments (Model/MENTOR.py:82-99, Model/DDRec.py / Model/MICRO.py through their GCNConv); one that names
+    `edge_index_i` / `size_i` receives the target index row and the node count (Model/GRCN.py:31)
+  * utils.softmax(src, index, num_nodes): exp(src - max of the group) / (sum over the group + 1e-16)
 """
 import inspect
 import sys
@@ -37,7 +39,10 @@ class MessagePassing(torch.nn.Module):
         src, dst = edge_index[0], edge_index[1]
         msg_kwargs = {}
         for name in self._msg_params:
-            if name.endswith("_j"):
+            if name in ("edge_index_i", "edge_index_j", "size_i", "size_j"):     # (Model/GRCN.py:31: the target / source index rows, the node counts)
+                msg_kwargs[name] = {"edge_index_i": dst, "edge_index_j": src, "size_i": n,
+                                    "size_j": size[0] if size is not None else x.size(0)}[name]
+            elif name.endswith("_j"):
                 msg_kwargs[name] = kwargs[name[:-2]].index_select(0, src)
             elif name.endswith("_i"):
                 msg_kwargs[name] = kwargs[name[:-2]].index_select(0, dst)
@@ -93,6 +98,17 @@ def scatter_add(src, index, dim=0, out=None, dim_size=None):
     return torch.zeros((n,), dtype=src.dtype, device=src.device).scatter_add_(0, index, src)
 
 
+def softmax(src, index, ptr=None, num_nodes=None):
+    """torch_geometric.utils.softmax 2.1: per `index` group, exp(src - group max) / (group sum + 1e-16)."""
+    n = int(index.max()) + 1 if num_nodes is None else num_nodes
+    shape = (n,) + tuple(src.shape[1:])
+    idx = index.view((-1,) + (1,) * (src.dim() - 1)).expand_as(src)
+    mx = torch.full(shape, float("-inf"), dtype=src.dtype, device=src.device).scatter_reduce(0, idx, src, reduce="amax")
+    out = (src - mx.index_select(0, index)).exp()
+    den = torch.zeros(shape, dtype=src.dtype, device=src.device).scatter_add_(0, idx, out)
+    return out / (den.index_select(0, index) + 1e-16)
+
+
 def remove_self_loops(edge_index, edge_attr=None):
     keep = edge_index[0] != edge_index[1]
     return edge_index[:, keep], (edge_attr[keep] if edge_attr is not None else None)
@@ -120,7 +136,7 @@ def install():
     utils.degree = degree
     utils.add_self_loops = add_self_loops
     utils.remove_self_loops = remove_self_loops
-    utils.softmax = _unused
+    utils.softmax = softmax
     utils.dropout_adj = dropout_adj
     tg.nn = nn
     tg.utils = utils

@@ -417,6 +417,45 @@ def test_mmssl_golden(dev):
     _check_rank(rank, g, g["ua"] @ g["ia"].T, U)
 
 
+def test_grcn_golden(dev):
+    """Model/GRCN.py: PyG's attention layer (edge-wise softmax over a node's incoming edges), the confidence-weighted pruned edge
+    weights and the weighted id propagation as segment softmaxes + value arrays over ONE CSR on the dynamic-values SpMM, the edge
+    weights carrying gradient into the content GCNs; the reference run's dropout mask over the LISTED edges replayed (an
+    interaction listed twice): loss, every gradient, the [N, dim_E + 2 dim_C] table, the ranking with the 1e-5 mask."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import GRCN
+    g = load_golden("grcn_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = GRCN(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]),
+             int(g["D"]), int(g["C"]), float(g["reg"]), float(g["dropout"]), int(g["num_routing"]), "add", dev).to(dev)
+    assert m.n_listed == len(g["edges"]) == len(g["keep"]) and m.n_edges == m.n_listed - 1 and 0 < int((~g["keep"]).sum())
+    m.edge_keep_fn = lambda n, p: torch.from_numpy(g["keep"])
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in g["param_names"]]
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), g["p_" + n]), n
+    user_tensor = torch.from_numpy(np.stack((g["users"], g["users"]), 1))
+    item_tensor = torch.from_numpy(np.stack((g["pos"], g["neg"]), 1))
+    loss = m.loss(user_tensor, item_tensor)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    assert len(g["no_grad"]) == 0
+    for n, p in m.named_parameters():
+        ref = g["g_" + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-8, n
+    res = m.result.detach().cpu().numpy()
+    assert res.shape == (U + I, int(g["D"]) + 2 * int(g["C"])) and np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    from chaorec_amd import graph as _g
+    sc = (g["result"][:U] @ g["result"][U:].T).copy()
+    for u, items in _g.user_item_dict_from_edges(g["edges"]).items():
+        sc[u, np.asarray(items) - U] = 1e-5
+    rank = m.gene_ranklist(topk=int(g["topk"])).numpy()
+    ok, why = tie_aware_rank_equal(rank, np.take_along_axis(sc, rank - U, 1), g["rank"], np.take_along_axis(sc, g["rank"] - U, 1), rtol=1e-4, atol=1e-7)
+    assert ok, why
+    m.edge_keep_fn = None                                   # the default draws on the device: two losses differ
+    assert m.loss(user_tensor, item_tensor).item() != m.loss(user_tensor, item_tensor).item()
+
+
 def test_learned_adj_gradients(dev):
     """sparse.LearnedAdj (a non-symmetric pattern, values with gradient) against a dense restatement in fp64: product, the
     dense operand's gradient through the transposed layout, every value's gradient; detach() is the same constant matrix."""
@@ -860,7 +899,7 @@ def test_gume_golden(dev):
 
 
 @pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL", "SGL", "BM3", "MGCL", "LATTICE",
-                                   "SimGCL", "XSimGCL", "SLMRec", "NCL", "SelfCF", "MCLN", "MMSSL"])
+                                   "SimGCL", "XSimGCL", "SLMRec", "NCL", "SelfCF", "MCLN", "MMSSL", "GRCN"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""

@@ -498,7 +498,7 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
-@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec", "micro", "mentor", "lightgcl", "bm3", "mgcl", "lattice", "mmssl"])
+@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec", "micro", "mentor", "lightgcl", "bm3", "mgcl", "lattice", "mmssl", "grcn"])
 def test_round5_family_members_start_from_the_reference_state(name):
     """The six members added in round 5, what needs no GPU: the same seed gives the reference class's parameter names and
     initial weights, the graphs built vectorised here are the reference's scipy / torch ones (SMORE: the weighted user-item
@@ -529,6 +529,8 @@ def test_round5_family_members_start_from_the_reference_state(name):
     elif name == "ddrec":
         m = M.DDRec(U, I, g["edges"], uid, *feats, D, D, float(g["reg"]), int(g["L"]), 0.2, 0.01, 0.0, "add", cpu)
         adjs = {"mm": (m.mm_adj, (I, I), 1e-7), "image": (m.image_adj, (I, I), 1e-7), "text": (m.text_adj, (I, I), 1e-7)}
+    elif name == "grcn":
+        m = M.GRCN(U, I, g["edges"], uid, *feats, D, int(g["C"]), float(g["reg"]), 0.2, 2, "add", cpu)
     elif name == "mmssl":
         m = M.MMSSL(U, I, g["edges"], uid, *feats, D, float(g["reg"]), 0.1, 0.5, 1e-4, 2, cpu)
         adjs = {"ui": (m.ui_graph, (U, I), 6e-8), "iu": (m.iu_graph, (I, U), 6e-8)}
@@ -580,6 +582,8 @@ def test_round5_family_members_start_from_the_reference_state(name):
             u2 = torch.stack((torch.from_numpy(g["users"]), torch.from_numpy(g["users"])), 1)
             m.loss(u2, torch.stack((torch.from_numpy(g["pos"]), torch.from_numpy(g["neg"])), 1), torch.from_numpy(g["mask"]),
                    torch.from_numpy(g["user_item"]))
+        elif name == "grcn":
+            m.loss(torch.from_numpy(np.stack((g["users"], g["users"]), 1)), torch.from_numpy(np.stack((g["pos"], g["neg"]), 1)))
         elif name == "mmssl":
             m.loss(*(torch.from_numpy(g[k]) for k in ("users", "pos", "neg")), 0)
         elif name in ("micro", "lattice"):
