@@ -12,7 +12,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from . import dataload
-from .Model import (BM3, BPRMF, DCCF, DDRec, DHCF, FKAN_GCF, FREEDOM, GRCN, GUME, HCCF, LATTICE, LGMRec, LightGCL, LayerGCN, LightGCN, LightGT, MCLN, MENTOR, MGCL, MGCN, MICRO, MMGCN, MMSSL, NCL, NGCF, MMGCL, POWERec, SelfCF, SGL, SimGCL, SLMRec,
+from .Model import (BM3, BPRMF, DCCF, DDRec, DHCF, FKAN_GCF, FREEDOM, GRCN, GUME, HCCF, LATTICE, LGMRec, LightGCL, LayerGCN, LightGCN, LightGT, MCLN, MENTOR, MGAT, MGCL, MGCN, MICRO, MMGCN, MMSSL, NCL, NGCF, MMGCL, POWERec, SelfCF, SGL, SimGCL, SLMRec,
                     SMORE, VBPR, VGCL, XSimGCL)
 from .arg_parser import load_yaml_config, parse_args
 from .train_and_evaluate import train_and_evaluate
@@ -108,6 +108,8 @@ def build_model(args, num_user, num_item, train_data, user_item_dict, v_feat, t_
         # (main.py:299-301)
         'DDRec': lambda: DDRec(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.feature_embed,
                                args.reg_weight, args.n_layers, args.ssl_temp, args.ssl_alpha, args.threshold, aggr_mode, device),
+        # (main.py:292-293)
+        'MGAT': lambda: MGAT(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.reg_weight, device),
         # (main.py:271-273)
         'GRCN': lambda: GRCN(num_user, num_item, train_data, user_item_dict, v_feat, t_feat, dim_E, args.feature_embed, args.reg_weight,
                              args.dropout, args.n_iterations, aggr_mode, device),
@@ -140,7 +142,7 @@ def main(argv=None):
     if device.type != "cuda":
         raise SystemExit("chaorec_amd runs on the MI355X only: no GPU visible")
     config = load_yaml_config(args.Model)
-    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE", "MMGCL", "LightGT", "GUME", "DDRec", "MICRO", "MENTOR", "BM3", "MGCL", "LATTICE", "MMSSL", "GRCN")
+    needs_feat = args.Model in ("MMGCN", "FREEDOM", "MGCN", "VBPR", "SLMRec", "MCLN", "POWERec", "LGMRec", "SMORE", "MMGCL", "LightGT", "GUME", "DDRec", "MICRO", "MENTOR", "BM3", "MGCL", "LATTICE", "MMSSL", "GRCN", "MGAT")
     train_data, val_data, test_data, user_item_dict, num_user, num_item, v_feat, t_feat = dataload.data_load(
         args.data_path, has_v=needs_feat, has_t=needs_feat, data_root=args.data_root, synthetic=args.synthetic)
     if args.host_sampler:

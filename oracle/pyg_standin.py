@@ -18,6 +18,7 @@ propagate", and say so.  Published semantics restated here:
     propagate's own two arguments (Model/MENTOR.py:82-99, Model/DDRec.py / Model/MICRO.py through their GCNConv); one that names
     `edge_index_i` / `size_i` receives the target index row and the node count (Model/GRCN.py:31)
   * utils.softmax(src, index, num_nodes): exp(src - max of the group) / (sum over the group + 1e-16)
+  * nn.inits.uniform(size, tensor): tensor ~ U(-1/sqrt(size), 1/sqrt(size))
 """
 import inspect
 import sys
@@ -109,6 +110,13 @@ def softmax(src, index, ptr=None, num_nodes=None):
     return out / (den.index_select(0, index) + 1e-16)
 
 
+def uniform(size, tensor):
+    """torch_geometric.nn.inits.uniform: U(-1/sqrt(size), 1/sqrt(size)) in place (Model/MGAT.py:33-35)."""
+    if tensor is not None:
+        bound = 1.0 / (size ** 0.5)
+        tensor.data.uniform_(-bound, bound)
+
+
 def remove_self_loops(edge_index, edge_attr=None):
     keep = edge_index[0] != edge_index[1]
     return edge_index[:, keep], (edge_attr[keep] if edge_attr is not None else None)
@@ -132,7 +140,7 @@ def install():
     nn.MessagePassing = MessagePassing
     nn.conv = conv
     nn.inits = inits
-    inits.uniform = _unused
+    inits.uniform = uniform
     utils.degree = degree
     utils.add_self_loops = add_self_loops
     utils.remove_self_loops = remove_self_loops

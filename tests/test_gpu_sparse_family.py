@@ -456,6 +456,24 @@ def test_grcn_golden(dev):
     assert m.loss(user_tensor, item_tensor).item() != m.loss(user_tensor, item_tensor).item()
 
 
+def test_mgat_golden(dev):
+    """Model/MGAT.py: three gated-attention layers per modality (asymmetric logits, source-degree gate, softmax per target) as
+    segment softmaxes + differentiable value arrays over one CSR; an interaction listed twice: loss, every gradient, the
+    [N, 3 dim_E] table, the ranking."""
+    from chaorec_amd import graph
+    from chaorec_amd.Model import MGAT
+    g = load_golden("mgat_small.npz")
+    U, I = int(g["U"]), int(g["I"])
+    torch.manual_seed(0)
+    m = MGAT(U, I, g["edges"], graph.user_item_dict_from_edges(g["edges"]), torch.from_numpy(g["v_feat"]), torch.from_numpy(g["t_feat"]),
+             int(g["D"]), float(g["reg"]), dev).to(dev)
+    assert m.n_edges == len(g["edges"]) - 1
+    _golden_model_checks(m, g, dev, 2e-4, 1e-8)
+    res = m.result.detach().cpu().numpy()
+    assert res.shape == (U + I, 3 * int(g["D"])) and np.abs(res - g["result"]).max() <= 1e-5 * np.abs(g["result"]).max()
+    _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
+
+
 def test_learned_adj_gradients(dev):
     """sparse.LearnedAdj (a non-symmetric pattern, values with gradient) against a dense restatement in fp64: product, the
     dense operand's gradient through the transposed layout, every value's gradient; detach() is the same constant matrix."""
@@ -899,7 +917,7 @@ def test_gume_golden(dev):
 
 
 @pytest.mark.parametrize("model", ["DHCF", "LGMRec", "POWERec", "SMORE", "MMGCL", "FKAN_GCF", "LightGT", "GUME", "VGCL", "DDRec", "DCCF", "MICRO", "MENTOR", "HCCF", "LightGCL", "SGL", "BM3", "MGCL", "LATTICE",
-                                   "SimGCL", "XSimGCL", "SLMRec", "NCL", "SelfCF", "MCLN", "MMSSL", "GRCN"])
+                                   "SimGCL", "XSimGCL", "SLMRec", "NCL", "SelfCF", "MCLN", "MMSSL", "GRCN", "MGAT"])
 def test_round5_members_train_through_the_main_entry(dev, model, tmp_path, monkeypatch):
     """python -m chaorec_amd.main --Model X --data_path baby --synthetic at the real baby size (the first point of the model's
     grid, two epochs): sampler, per-epoch hooks, training steps, device ranking + metrics, logging."""

@@ -498,7 +498,7 @@ def test_sparse_family_models_start_from_the_reference_state(name):
         m.loss(*(torch.from_numpy(g[k]) for k in (("users", "pos", "neg", "ints") if name.startswith("mcln") else ("users", "pos", "neg"))))
 
 
-@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec", "micro", "mentor", "lightgcl", "bm3", "mgcl", "lattice", "mmssl", "grcn"])
+@pytest.mark.parametrize("name", ["dhcf", "lgmrec", "powerec", "smore", "mmgcl", "fkan_gcf", "lightgt", "gume", "ddrec", "micro", "mentor", "lightgcl", "bm3", "mgcl", "lattice", "mmssl", "grcn", "mgat"])
 def test_round5_family_members_start_from_the_reference_state(name):
     """The six members added in round 5, what needs no GPU: the same seed gives the reference class's parameter names and
     initial weights, the graphs built vectorised here are the reference's scipy / torch ones (SMORE: the weighted user-item
@@ -529,6 +529,8 @@ def test_round5_family_members_start_from_the_reference_state(name):
     elif name == "ddrec":
         m = M.DDRec(U, I, g["edges"], uid, *feats, D, D, float(g["reg"]), int(g["L"]), 0.2, 0.01, 0.0, "add", cpu)
         adjs = {"mm": (m.mm_adj, (I, I), 1e-7), "image": (m.image_adj, (I, I), 1e-7), "text": (m.text_adj, (I, I), 1e-7)}
+    elif name == "mgat":
+        m = M.MGAT(U, I, g["edges"], uid, *feats, D, float(g["reg"]), cpu)
     elif name == "grcn":
         m = M.GRCN(U, I, g["edges"], uid, *feats, D, int(g["C"]), float(g["reg"]), 0.2, 2, "add", cpu)
     elif name == "mmssl":
