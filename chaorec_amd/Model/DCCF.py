@@ -56,8 +56,8 @@ class DCCF(nn.Module):
 
     def _adaptive_mask(self, table):
         """:106-118 -> the adjacency whose (user, item) entries weigh (cos(table[u], table[U + i]) + 1) / 2."""
-        head, tail = F.normalize(table[self._eu]), F.normalize(table[self.num_user + self._ei])
-        val = self._ew * ((torch.sum(head * tail, dim=1) + 1) / 2)
+        unit = F.normalize(table)                                   # (row-normalising the table = normalising every gathered row)
+        val = self._ew * ((ops.edge_dot(self._structure, unit, unit, self.n_edges) + 1) / 2)
         return sparse.DroppedAdj(self._structure, torch.cat([val, self._zeros]), torch.cat([self._zeros, val[self._lower]]))
 
     def _intent(self, x, intent):

@@ -98,7 +98,7 @@ class DDRec(nn.Module):
         """:197-204 -> the weights of the interactions whose current rows score >= threshold (the score of an interaction is
         the dot product of its two rows: the one entry the reference reads from its [U, I] product)."""
         with torch.no_grad():
-            sim = (ego[self._eu] * ego[self.num_user + self._ei]).sum(dim=1)
+            sim = ops.edge_dot_raw(self._structure.entry_row, self._structure.col, ego, ego, self.n_edges)
             return torch.where(sim >= self.threshold, self._ew, torch.zeros_like(self._ew))
 
     def _filtered_encoder(self, item_table):

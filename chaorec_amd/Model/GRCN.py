@@ -111,7 +111,7 @@ class GRCN(torch.nn.Module):
     def attention(self, x, w):
         """GATConv (:18-37) over the bidirectional list: -> (alpha of user -> item edges, alpha of item -> user edges, operand)."""
         U = self.num_user
-        logit = torch.mul(x[self._eu], x[U + self._ei]).sum(dim=-1)
+        logit = ops.edge_dot(self._structure, x, x, self.n_edges)         # <x[u], x[U + i]> per pair: the structure's first half
         alpha_to_item = _segment_softmax(logit, self._ei, self.num_item, w)         # softmax over the edges arriving at an item
         alpha_to_user = _segment_softmax(logit, self._eu, self.num_user, w)
         return alpha_to_item, alpha_to_user, self._adj(alpha_to_user, alpha_to_item, w)

@@ -39,16 +39,15 @@ class GraphGAT(nn.Module):
     def forward(self, owner, x):
         x = ops.linear(x, self.weight.t().contiguous())
         U = owner.num_user
-        xu, xi = x[owner._eu], x[U + owner._ei]
-        d = owner._deg_inv_sqrt
+        d, lx = owner._deg_inv_sqrt, F.leaky_relu(x)
 
-        def attention(dst, src, d_src, seg, n_seg):
-            inner = torch.mul(dst, F.leaky_relu(src)).sum(dim=-1)
+        def attention(inner, d_src, seg, n_seg):
             tmp = torch.mul(inner, torch.sigmoid(torch.mul(d_src, inner)))
             return _segment_softmax(tmp, seg, n_seg, owner._ew)
 
-        to_user = attention(xu, xi, d[U + owner._ei], owner._eu, owner.num_user)          # edges item -> user, softmax per user
-        to_item = attention(xi, xu, d[owner._eu], owner._ei, owner.num_item)
+        # <x_i, leaky_relu(x_j)> per pair, both directions: edge scores over the structure's (user, item) half
+        to_user = attention(ops.edge_dot(owner._structure, x, lx, owner.n_edges), d[U + owner._ei], owner._eu, owner.num_user)   # item -> user
+        to_item = attention(ops.edge_dot(owner._structure, lx, x, owner.n_edges), d[owner._eu], owner._ei, owner.num_item)
         up, low = owner._ew * to_user, owner._ew * to_item
         adj = sparse.DroppedAdj(owner._structure, torch.cat([up, low[owner._lower]]), torch.cat([low, up[owner._lower]]))
         out = sparse.mm(adj, x)

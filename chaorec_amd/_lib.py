@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -167,6 +167,7 @@ SIGNATURES = {
     "chaorec_gemm_nn_bf16x3_dual": (ctypes.c_int, [c_ptr] * 5 + [ctypes.c_int64] * 9 + [c_ptr, ctypes.c_size_t, c_ptr]),
     "chaorec_gemm_tn_bf16x3_dual_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "chaorec_gemm_tn_bf16x3_dual": (ctypes.c_int, [c_ptr] * 5 + [ctypes.c_int64] * 9 + [c_ptr, ctypes.c_size_t, c_ptr]),
+    "chaorec_edge_dot_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr]),
     "chaorec_leaky_cat_add_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32,
                                                  ctypes.c_int32, ctypes.c_float, c_ptr]),
     "chaorec_leaky_split_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int64,

@@ -525,6 +525,62 @@ extern "C" int chaorec_mul_pair_bwd_f32(const float *grad_t, const float *s, con
   return check_launch("mul_pair_bwd");
 }
 
+// ---- edge scores over a CSR's entries (sampled dense-dense product) -----------------------------------------------------
+// out[k] = <a[row_k], b[col_k]> for every stored entry k.  HBM / L2-gather bound: two D-float rows per entry.  A group of
+// LPE lanes takes one entry (float4 per lane and pass, LPE = the power of two covering D / 4, at most 64), 64 / LPE entries
+// per wave at a time; the partial sums meet through xor-shuffles inside the group.  Entries are walked in storage order,
+// so the a-row of consecutive entries is the same row (one L2 line set), the b-rows are the gathers.
+template <int LPE>
+__global__ __launch_bounds__(256) void edge_dot_kernel(const int32_t *__restrict__ entry_row, const int32_t *__restrict__ col,
+                                                       const float4 *__restrict__ a, const float4 *__restrict__ b,
+                                                       float *__restrict__ out, int64_t nnz, int d4) {
+  constexpr int EPW = 64 / LPE;                       // entries per wave and round
+  const int lane = threadIdx.x & 63, sub = lane % LPE, slot = lane / LPE;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t k0 = wave * EPW; k0 < nnz; k0 += n_waves * EPW) {
+    const int64_t k = k0 + slot;
+    float acc = 0.f;
+    if (k < nnz) {
+      const float4 *ar = a + (int64_t)entry_row[k] * d4, *br = b + (int64_t)col[k] * d4;
+      for (int q = sub; q < d4; q += LPE) {
+        const float4 x = ar[q], y = br[q];
+        acc = fmaf(x.x, y.x, acc);
+        acc = fmaf(x.y, y.y, acc);
+        acc = fmaf(x.z, y.z, acc);
+        acc = fmaf(x.w, y.w, acc);
+      }
+    }
+#pragma unroll
+    for (int j = LPE / 2; j > 0; j >>= 1) acc += __shfl_xor(acc, j, 64);
+    if (sub == 0 && k < nnz) out[k] = acc;
+  }
+}
+
+extern "C" int chaorec_edge_dot_f32(const int32_t *entry_row, const int32_t *col, const float *a, const float *b, float *out,
+                                    int64_t nnz, int32_t D, void *stream) {
+  if (!entry_row || !col || !a || !b || !out) return fail(CHAOREC_E_INVALID, "edge_dot: null pointer");
+  if (nnz < 0 || D < 4 || (D & 3)) return fail(CHAOREC_E_INVALID, "edge_dot: nnz=%lld D=%d (a multiple of 4)", (long long)nnz, D);
+  if (nnz == 0) return CHAOREC_OK;
+  const int d4 = D / 4;
+  int lpe = 1;
+  while (lpe < d4 && lpe < 64) lpe <<= 1;
+  const int64_t waves = (nnz + (64 / lpe) - 1) / (64 / lpe);
+  const unsigned blocks = (unsigned)std::min<int64_t>((waves + 3) / 4, 16384);
+  hipStream_t st = (hipStream_t)stream;
+  const float4 *a4 = (const float4 *)a, *b4 = (const float4 *)b;
+  switch (lpe) {
+    case 1: edge_dot_kernel<1><<<blocks, 256, 0, st>>>(entry_row, col, a4, b4, out, nnz, d4); break;
+    case 2: edge_dot_kernel<2><<<blocks, 256, 0, st>>>(entry_row, col, a4, b4, out, nnz, d4); break;
+    case 4: edge_dot_kernel<4><<<blocks, 256, 0, st>>>(entry_row, col, a4, b4, out, nnz, d4); break;
+    case 8: edge_dot_kernel<8><<<blocks, 256, 0, st>>>(entry_row, col, a4, b4, out, nnz, d4); break;
+    case 16: edge_dot_kernel<16><<<blocks, 256, 0, st>>>(entry_row, col, a4, b4, out, nnz, d4); break;
+    case 32: edge_dot_kernel<32><<<blocks, 256, 0, st>>>(entry_row, col, a4, b4, out, nnz, d4); break;
+    default: edge_dot_kernel<64><<<blocks, 256, 0, st>>>(entry_row, col, a4, b4, out, nnz, d4); break;
+  }
+  return check_launch("edge_dot");
+}
+
 extern "C" int chaorec_leaky_cat_add_f32(const float *s, const float *u, const float *id, float *out, int64_t n_rows,
                                          int32_t d1, int32_t d2, float slope, void *stream) {
   if (!s || !u || !out) return fail(CHAOREC_E_INVALID, "leaky_cat_add: null pointer");

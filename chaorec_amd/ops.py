@@ -1034,7 +1034,7 @@ _MOVED = {
     "ops_extra": (
         "adam_step", "adam_bias_table", "unique_rows", "adam_lowrank_strips", "adam_lowrank", "_LinearRows",
         "linear_rows", "adam_multi", "adam_multi_max", "_SpMMAdd", "spmm_add", "edge_dropout_norm", "_SpMMValues",
-        "spmm_values", "_NGCFLayer", "ngcf_layer", "weighted_sample_keep", "weighted_sample_keys",
+        "spmm_values", "edge_dot_raw", "_EdgeDot", "edge_dot", "_NGCFLayer", "ngcf_layer", "weighted_sample_keep", "weighted_sample_keys",
         "_RowCosineScale", "row_cosine_scale",
     ),
 }

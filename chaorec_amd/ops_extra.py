@@ -207,6 +207,47 @@ def edge_dropout_norm(structure, p, seed, step=0, step_dev=None, salt=0, keep=No
     return val, val_t
 
 
+def edge_dot_raw(entry_row, col, a, b, n_entries=None):
+    """out[k] = <a[entry_row[k]], b[col[k]]> for the first n_entries stored entries (all of them by default): one pass that
+    reads two rows per entry (chaorec_edge_dot_f32) instead of two [nnz, D] gathers, their product and its row sum."""
+    _need_cuda(a, b, entry_row, col)
+    a, b = _f32c(a), _f32c(b)
+    n = int(col.numel()) if n_entries is None else int(n_entries)
+    out = torch.empty(n, dtype=torch.float32, device=a.device)
+    rc = _lib.load().chaorec_edge_dot_f32(_ptr(entry_row), _ptr(col), _ptr(a), _ptr(b), _ptr(out), n, a.shape[1], _stream())
+    _lib.check(rc, "chaorec_edge_dot_f32")
+    return out
+
+
+class _EdgeDot(torch.autograd.Function):
+    """Edge scores over (the first n entries of) a symmetric-pattern structure, differentiable in both tables: with G the sparse
+    matrix that holds the incoming gradient at those entries,  d a = G b,  d b = G^T a  -- two dynamic-values SpMMs."""
+
+    @staticmethod
+    def forward(ctx, a, b, structure, n):
+        ctx.structure, ctx.n = structure, n
+        ctx.save_for_backward(a, b)
+        return edge_dot_raw(structure.entry_row, structure.col, a, b, n)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        st, n = ctx.structure, ctx.n
+        g = g.contiguous()
+        if n != st.nnz:
+            g = torch.cat([g, g.new_zeros(st.nnz - n)])
+        ga = _ops.spmm_raw(st.with_values(g), _f32c(b)) if ctx.needs_input_grad[0] else None
+        gb = _ops.spmm_raw(st.with_values(g[st.transpose_entry.long()]), _f32c(a)) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
+
+
+def edge_dot(structure, a, b, n_entries=None):
+    """<a[row_k], b[col_k]> per stored entry k of `structure` (a graph.DropoutStructure: symmetric pattern, entry -> row and
+    entry -> reversed-entry maps), or of its first n_entries entries -- the (user, item) half of the bipartite structures
+    the models build --, with autograd into both tables.  Needs a.shape[0] = b.shape[0] = the structure's node count."""
+    return _EdgeDot.apply(a, b, structure, structure.nnz if n_entries is None else int(n_entries))
+
+
 class _SpMMValues(torch.autograd.Function):
     """y = A x where A's values change every call (edge dropout, learned edge weights) while its structure is fixed:
     forward with `val`, backward with `val_t` (A^T in the same structure).  Values that require a gradient get one
@@ -225,7 +266,7 @@ class _SpMMValues(torch.autograd.Function):
         val_t, x = ctx.saved_tensors
         st, gy = ctx.structure, gy.contiguous()
         gx = _ops.spmm_raw(st.with_values(val_t.detach()), gy) if ctx.needs_input_grad[0] else None
-        gval = (gy[st.entry_row.long()] * x[st.col.long()]).sum(dim=1) if ctx.val_grad else None
+        gval = edge_dot_raw(st.entry_row, st.col, gy, x) if ctx.val_grad else None
         return gx, None, gval, None
 
 

@@ -82,8 +82,11 @@ class LearnedAdj:
         self._t = None
 
     def entry_rows(self):
-        return torch.repeat_interleave(torch.arange(self.n_rows, dtype=torch.int64, device=self.col.device),
-                                       self.rowptr[1:] - self.rowptr[:-1])
+        if getattr(self, "_rows", None) is None:
+            self._rows = torch.repeat_interleave(torch.arange(self.n_rows, dtype=torch.int64, device=self.col.device),
+                                                 self.rowptr[1:] - self.rowptr[:-1])
+            self._rows32 = self._rows.to(torch.int32)
+        return self._rows
 
     def transposed(self):
         """-> (rowptr_t, col_t, perm): entry k of A^T's row-major layout is entry perm[k] of A's."""
@@ -115,7 +118,8 @@ class _SpMMLearned(torch.autograd.Function):
             rowptr_t, col_t, perm = adj.transposed()
             gx = ops.spmm_raw(graph.CSR(rowptr_t, col_t, val.detach()[perm].contiguous(), adj.n_cols, adj.n_rows), gy)
         if ctx.needs_input_grad[2]:
-            gval = (gy[adj.entry_rows()] * x[adj.col.long()]).sum(dim=1)
+            adj.entry_rows()
+            gval = ops.edge_dot_raw(adj._rows32, adj.col, gy, x)
         return gx, None, gval
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 13  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 14  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -48,7 +48,8 @@ extern "C" {
                                       chaorec_expand_row_bits over rectangular blocks, rows_list_from_bits, rows_mean_by_bits,
                                       zero_rows_by_bits, rows_copy_by_bits, or_words, peer-to-peer exchange of flagged rows, frontier pack / unpack;
                                   13: scoring: CHAOREC_SCORE_FRONT / _BACK (one call as two phases), a raised-threshold pass for
-                                      users whose candidate lists overflow (long item ranges), chaorec_score_topk_stats out10 */
+                                      users whose candidate lists overflow (long item ranges), chaorec_score_topk_stats out10;
+                                  14: chaorec_edge_dot_f32 (edge scores over a CSR's entries) */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -786,6 +787,19 @@ int chaorec_bpr_multi_bwd_f32(const float *tab_u, const int64_t *users, int32_t 
                               const float *coef, const float *wvec, const float *grad_out, float *g_u,
                               float *const *g_i, const int64_t *const *scatter_rows, float *const *scatter_out,
                               void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Edge scores over the stored entries of a CSR: out[k] = <a[entry_row[k]], b[col[k]]>, k in [0, nnz).
+ * Replaces the family's per-edge gather + product + row sum -- `torch.sum(x[row] * x[col], dim=1)` over an edge list
+ * (Model/DCCF.py:109-111 cosine edge weights, Model/DDRec.py:197-204 the threshold filter, Model/GRCN.py:31 / Model/MGAT.py:43
+ * attention logits) and the gradient torch.sparse.mm gives a sparse operand's values (d val[k] = <gy[row_k], x[col_k]>) --
+ * which writes two [nnz, D] gathers and their product to HBM, by one pass that reads the two rows of every entry.
+ * a [n_rows, D], b [n_cols, D] contiguous fp32, D a multiple of 4; entry_row / col int32 [nnz] (the CSR's entry -> row map and
+ * column array).  Backward (through the caller's autograd): the two SpMMs  ga = G b,  gb = G^T a  over the same structure with
+ * the incoming gradient as values (chaorec_spmm_csr_f32, CHAOREC_SPMM_DYNAMIC_VALUES).
+ * ------------------------------------------------------------------------------------- */
+int chaorec_edge_dot_f32(const int32_t *entry_row, const int32_t *col, const float *a, const float *b, float *out,
+                         int64_t nnz, int32_t D, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * MMGCN's layer tail in one pass each way (Model/MMGCN.py:102-131, per layer:

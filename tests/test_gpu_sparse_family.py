@@ -474,6 +474,40 @@ def test_mgat_golden(dev):
     _check_rank(m.gene_ranklist(topk=int(g["topk"])).numpy(), g, g["result"][:U] @ g["result"][U:].T, U)
 
 
+@pytest.mark.parametrize("D", [4, 16, 64, 100, 256, 384])
+def test_edge_dot_kernel_and_its_gradients(dev, D):
+    """chaorec_edge_dot_f32 (edge scores over a CSR's entries: one pass instead of two [nnz, D] gathers + product + row sum)
+    against the gathers in fp64, over all entries and over the first half of a bipartite structure (what the attention models
+    use), with both tables' gradients (two dynamic-values SpMMs) against torch's own."""
+    from chaorec_amd import graph, ops, sparse
+    gen = torch.Generator().manual_seed(11 + D)
+    U, I, nnz = 150, 90, 1500
+    key = torch.unique(torch.randint(0, U * I, (nnz,), generator=gen))
+    eu, ei = torch.div(key, I, rounding_mode="floor"), key % I
+    n = key.numel()
+    csr = graph.coo_to_csr_coalesced(torch.cat([eu, U + ei]), torch.cat([U + ei, eu]), torch.ones(2 * n), U + I, U + I, symmetric=True).to(dev)
+    st = sparse._dropout_structure(csr)
+    a = torch.randn(U + I, D, generator=gen).to(dev).requires_grad_()
+    b = torch.randn(U + I, D, generator=gen).to(dev).requires_grad_()
+    w = torch.randn(n, generator=gen).to(dev)
+    rows, cols = st.entry_row.long(), st.col.long()
+    full = ops.edge_dot_raw(st.entry_row, st.col, a.detach(), b.detach())
+    want = (a.detach().double()[rows] * b.detach().double()[cols]).sum(1)
+    assert torch.allclose(full.double(), want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(rows[:n].cpu(), eu) and torch.equal(cols[:n].cpu(), U + ei)         # the first half = the (user, item) pairs in key order
+    out = ops.edge_dot(st, a, b, n)
+    (out * w).sum().backward()
+    ad, bd = a.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    ((ad[rows[:n]] * bd[cols[:n]]).sum(1) * w.double()).sum().backward()
+    assert torch.allclose(out.detach().double(), want[:n], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(a.grad.double(), ad.grad, rtol=1e-5, atol=1e-5) and torch.allclose(b.grad.double(), bd.grad, rtol=1e-5, atol=1e-5)
+    x = torch.randn(U + I, D, generator=gen).to(dev).requires_grad_()                      # the same table on both sides: the gradients add
+    ops.edge_dot(st, x, x, n).sum().backward()
+    xd = x.detach().double().requires_grad_()
+    (xd[rows[:n]] * xd[cols[:n]]).sum().backward()
+    assert torch.allclose(x.grad.double(), xd.grad, rtol=1e-5, atol=1e-5)
+
+
 def test_learned_adj_gradients(dev):
     """sparse.LearnedAdj (a non-symmetric pattern, values with gradient) against a dense restatement in fp64: product, the
     dense operand's gradient through the transposed layout, every value's gradient; detach() is the same constant matrix."""
