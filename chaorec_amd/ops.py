@@ -778,15 +778,6 @@ def shift_cat(pos, neg, offset):
 SCORE_LIGHT = 1      # CHAOREC_SCORE_LIGHT
 SCORE_FRONT = 2      # CHAOREC_SCORE_FRONT: pack, sampling, the first sweep over all users
 SCORE_BACK = 4       # CHAOREC_SCORE_BACK: selection, retry passes, exact routes
-_SCORE_STREAMS = {}
-
-
-def _score_streams(dev):
-    """(front stream, back stream) of the user-range pipeline, per device."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _SCORE_STREAMS:
-        _SCORE_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-    return _SCORE_STREAMS[key]
 
 
 def _score_call(lib, user_emb, item_emb, hist, mask_value, K, id_offset, precision, hint, hint_valid, hint_rank, light,
@@ -835,12 +826,10 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     PCIe while it runs, instead of a device buffer that is copied afterwards; sync the stream before reading it).
 
     A call whose workspace (per user: the candidate lists of every sweep split, ~20 KB) would exceed
-    CHAOREC_SCORE_WS_LIMIT (24 GiB) is cut into user ranges of equal length -- the users are independent.  With
-    CHAOREC_SCORE_PIPELINE=1 the ranges are PIPELINED: range k's back phase (selection, retry passes, exact routes) runs on a
-    second stream beside range k + 1's front phase (sampling + the sweep), two workspaces of half the budget in flight.
-    Measured at the config-5 shard (1.25 M x 2 M, D = 128): 634 ms against 630 ms for the ranges one after the
-    other and 628 ms in one piece -- every kernel of the call fills the chip on its own, running them side by side conserves
-    the work -- so the default is one range after the other on the caller's stream."""
+    CHAOREC_SCORE_WS_LIMIT (24 GiB) is cut into user ranges of equal length -- the users are independent --, one range after
+    the other on the caller's stream.  (Round 5 also ran them PIPELINED -- range k's back phase on a second stream beside range
+    k + 1's front phase, two workspaces in flight --: 634 ms against 630 ms serial and 628 ms in one piece at the config-5 shard,
+    every kernel of the call fills the chip on its own; that code is profiles/r05_exp_score_pipeline.patch)"""
     _need_cuda(user_emb, item_emb)
     user_emb, item_emb = _f32c(user_emb), _f32c(item_emb)
     U, D = user_emb.shape
@@ -874,9 +863,7 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
         return idx, val
 
     # ---- user ranges (BASELINE configs[4] at 1e7 users would ask for > 200 GB of workspace) -------------------------
-    pipelined = (os.environ.get("CHAOREC_SCORE_PIPELINE", "0") == "1" and precision == 0
-                 and not torch.cuda.is_current_stream_capturing())
-    budget = limit // 2 if pipelined else limit           # (two workspaces in flight when the ranges are pipelined)
+    budget = limit
     per = max(4096, (U * budget // nbytes) // 4096 * 4096)
     while per > 4096 and lib.chaorec_score_topk_workspace_bytes(per, I, K, D) > budget:
         per -= 4096
@@ -884,7 +871,6 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
     per = min(per, ((U + n_ranges - 1) // n_ranges + 4095) // 4096 * 4096)     # ranges of equal length, not a full one + a rest
     ranges = [(u0, min(U, u0 + per)) for u0 in range(0, U, per)]
     ws_bytes = lib.chaorec_score_topk_workspace_bytes(per, I, K, D)
-    pipelined = pipelined and len(ranges) > 1
     want_counters = counters is not None and precision == 0
     tot = torch.zeros(4, dtype=torch.int32, device=dev) if want_counters else None
     stat_sum = torch.zeros(10, dtype=torch.int64, device=dev) if stats is not None else None
@@ -894,7 +880,7 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
         return (user_emb[u0:u1], item_emb, None if hist is None else (rowptr[u0:u1 + 1], col), mask_value, K, id_offset,
                 precision, None if hint is None else hint[u0:u1], hint_valid, hint_rank, light)
 
-    def after(ws, cnt, u0, u1):          # per-range bookkeeping, on the stream that ran the range's back phase
+    def after(ws, cnt, u0, u1):          # per-range bookkeeping
         if tot is not None:
             tot.add_(cnt)
         if stats is not None:
@@ -902,51 +888,18 @@ def score_topk(user_emb, item_emb, hist, mask_value, K, id_offset=0, precision=0
             stat_max.copy_(torch.maximum(stat_max, o[2:3]))
             stat_sum.add_(o)
 
-    if not pipelined:
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        cnt = torch.zeros(4, dtype=torch.int32, device=dev) if want_counters else None
-        for u0, u1 in ranges:
-            nb = lib.chaorec_score_topk_workspace_bytes(u1 - u0, I, K, D)
-            _score_call(lib, *args_of(u0, u1), cnt, idx[u0:u1], val[u0:u1], ws, nb)
-            after(ws, cnt, u0, u1)
-    else:
-        cur = torch.cuda.current_stream(dev)
-        s_front, s_back = _score_streams(dev)
-        wss = [torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        cnts = [torch.zeros(4, dtype=torch.int32, device=dev) if want_counters else None for _ in range(2)]
-        start = torch.cuda.Event()
-        start.record(cur)
-        s_front.wait_event(start)
-        s_back.wait_event(start)
-        back_done = [None, None]
-        for k, (u0, u1) in enumerate(ranges):
-            b = k & 1
-            nb = lib.chaorec_score_topk_workspace_bytes(u1 - u0, I, K, D)
-            a = args_of(u0, u1)
-            with torch.cuda.stream(s_front):
-                if back_done[b] is not None:
-                    s_front.wait_event(back_done[b])          # (the workspace's previous range has left it)
-                _score_call(lib, *a, cnts[b], idx[u0:u1], val[u0:u1], wss[b], nb, phase=SCORE_FRONT)
-                front_done = torch.cuda.Event()
-                front_done.record(s_front)
-            with torch.cuda.stream(s_back):
-                s_back.wait_event(front_done)
-                _score_call(lib, *a, cnts[b], idx[u0:u1], val[u0:u1], wss[b], nb, phase=SCORE_BACK)
-                after(wss[b], cnts[b], u0, u1)
-                back_done[b] = torch.cuda.Event()
-                back_done[b].record(s_back)
-        end = torch.cuda.Event()
-        end.record(s_back)
-        cur.wait_event(end)              # (the back stream is in order: its last event covers every range)
-        for t in wss + [c for c in cnts if c is not None]:
-            t.record_stream(s_front)
-            t.record_stream(s_back)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(4, dtype=torch.int32, device=dev) if want_counters else None
+    for u0, u1 in ranges:
+        nb = lib.chaorec_score_topk_workspace_bytes(u1 - u0, I, K, D)
+        _score_call(lib, *args_of(u0, u1), cnt, idx[u0:u1], val[u0:u1], ws, nb)
+        after(ws, cnt, u0, u1)
     if want_counters:
         counters.copy_(tot, non_blocking=True)
     if stats is not None:
         v = stat_sum.tolist()
         v[2] = int(stat_max.item())
-        stats.update(_stats_dict(v), user_chunks=len(ranges), pipelined=bool(pipelined))
+        stats.update(_stats_dict(v), user_chunks=len(ranges), pipelined=False)
     return idx, val
 
 

@@ -1,5 +1,5 @@
 """Round-5 GPU parity tests: the scoring call's raised-threshold pass for overflowing users (pass C), the call as two
-phases (CHAOREC_SCORE_FRONT / _BACK) and the pipelined user ranges built on them.  Everything through the C-ABI
+phases (CHAOREC_SCORE_FRONT / _BACK) and the user ranges of a large call.  Everything through the C-ABI
 (chaorec_amd._lib ctypes), compared with oracle/ (the checker) bit for bit."""
 import os
 
@@ -157,9 +157,9 @@ def test_score_topk_front_then_back_is_the_whole_call(dev, U, I, D, hinted):
 
 
 @pytest.mark.parametrize("hinted", [False, True])
-def test_score_topk_pipelined_user_ranges_equal_the_serial_ranges(dev, oracle, hinted):
-    """ops.score_topk over user ranges: range k's back phase on a second stream beside range k + 1's front phase, two
-    workspaces in flight == the ranges one after the other == the oracle (a sample of the rows)."""
+def test_score_topk_user_ranges_equal_the_call_in_one_piece(dev, oracle, hinted):
+    """ops.score_topk over user ranges (the workspace budget forces >= 5 of them, one after the other on the caller's stream) ==
+    the same call in one piece == the oracle (a sample of the rows); thresholds and queue counters come out the same."""
     from chaorec_amd import _lib, ops
     lib = _lib.load()
     g = torch.Generator(device=dev).manual_seed(3)
@@ -175,12 +175,14 @@ def test_score_topk_pipelined_user_ranges_equal_the_serial_ranges(dev, oracle, h
         h0 = torch.empty(U, device=dev)
         ops.score_topk(ue, ie, hist, 1e-6, K, id_offset=U, hint=h0, hint_valid=False)
         base = dict(hint_valid=True)
-    env = {k: os.environ.get(k) for k in ("CHAOREC_SCORE_WS_LIMIT", "CHAOREC_SCORE_PIPELINE")}
+    saved = os.environ.get("CHAOREC_SCORE_WS_LIMIT")
     out = {}
     try:
-        os.environ["CHAOREC_SCORE_WS_LIMIT"] = str(one // 5)
-        for mode in ("1", "0"):
-            os.environ["CHAOREC_SCORE_PIPELINE"] = mode
+        for mode, limit in (("ranges", str(one // 5)), ("whole", None)):
+            if limit is None:
+                os.environ.pop("CHAOREC_SCORE_WS_LIMIT", None)
+            else:
+                os.environ["CHAOREC_SCORE_WS_LIMIT"] = limit
             st = {}
             kw = dict(base)
             if hinted:
@@ -190,15 +192,13 @@ def test_score_topk_pipelined_user_ranges_equal_the_serial_ranges(dev, oracle, h
             torch.cuda.synchronize()
             out[mode] = (i_, v_, st, kw.get("hint"), kw.get("counters"))
     finally:
-        for k, v in env.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    p, s = out["1"], out["0"]
-    assert p[2]["user_chunks"] >= 5 and p[2]["pipelined"] and not s[2]["pipelined"]
+        if saved is None:
+            os.environ.pop("CHAOREC_SCORE_WS_LIMIT", None)
+        else:
+            os.environ["CHAOREC_SCORE_WS_LIMIT"] = saved
+    p, s = out["ranges"], out["whole"]
+    assert p[2]["user_chunks"] >= 5 and "user_chunks" not in s[2]
     assert torch.equal(p[0], s[0]) and torch.equal(p[1], s[1])
-    assert {k: v for k, v in p[2].items() if k != "pipelined"} == {k: v for k, v in s[2].items() if k != "pipelined"}
     if hinted:
         assert torch.equal(p[3], s[3]) and torch.equal(p[4], s[4])
     rows = np.r_[0:40, U // 2:U // 2 + 40, U - 40:U]

@@ -1,5 +1,5 @@
-"""The cold ranking call at the config-5 shard / whole SHAPE on random tables (no graph build): user ranges serial against
-pipelined, workspace budgets.  python3 tools/score_ranges_bench.py [users] [items] [dim]; prints ms per call and the
+"""The cold ranking call at the config-5 shard / whole SHAPE on random tables (no graph build): user ranges under several
+workspace budgets (the pipelined variant of DESIGN 7.12 needs profiles/r05_exp_score_pipeline.patch applied).  python3 tools/score_ranges_bench.py [users] [items] [dim]; prints ms per call and the
 fraction of the 2.5 PF bf16 MFMA peak (2 U I D flops)."""
 import os
 import sys
