@@ -156,6 +156,38 @@ def test_score_topk_front_then_back_is_the_whole_call(dev, U, I, D, hinted):
         assert bool((a[3] >= 0).all())                    # (the prefilter route reports its queue lengths)
 
 
+@pytest.mark.parametrize("fill", [0xFF, 0x5A])
+def test_ranking_does_not_depend_on_what_its_workspace_held(dev, fill):
+    """The ranking call in one piece and as FRONT + BACK phases, unhinted and hinted, over a workspace pre-filled with junk bytes
+    (what torch.empty hands out in a long-running process): the same [U, K] lists as over a fresh one."""
+    from chaorec_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(3)
+    U, I, D, K = 8192, 6000, 64, 50
+    ue = torch.randn(U, D, generator=g, device=dev) * 0.2
+    ie = torch.randn(I, D, generator=g, device=dev) * 0.2
+    rowptr = torch.arange(U + 1, dtype=torch.int64, device=dev) * 3
+    col = ((torch.arange(U * 3, device=dev) % 3) * 1000 + torch.arange(U * 3, device=dev) // 3 % 997).to(torch.int32)
+    hist = (rowptr, col)
+    nb = lib.chaorec_score_topk_workspace_bytes(U, I, K, D)
+    ref_i, ref_v = ops.score_topk(ue, ie, hist, 1e-6, K, id_offset=U)
+    h0 = torch.empty(U, device=dev)
+    ops.score_topk(ue, ie, hist, 1e-6, K, id_offset=U, hint=h0, hint_valid=False)
+    for hinted in (False, True):
+        for phased in (False, True):
+            ws = torch.full((nb,), fill, dtype=torch.uint8, device=dev)
+            idx = torch.empty((U, K), dtype=torch.int64, device=dev)
+            val = torch.empty((U, K), dtype=torch.float32, device=dev)
+            a = (lib, ue, ie, hist, 1e-6, K, U, 0, h0.clone() if hinted else None, hinted, 0, False,
+                 torch.zeros(4, dtype=torch.int32, device=dev), idx, val, ws, nb)
+            if phased:
+                ops._score_call(*a, phase=ops.SCORE_FRONT)
+                ops._score_call(*a, phase=ops.SCORE_BACK)
+            else:
+                ops._score_call(*a)
+            assert torch.equal(idx, ref_i) and torch.equal(val, ref_v), (hinted, phased)
+
+
 @pytest.mark.parametrize("hinted", [False, True])
 def test_score_topk_user_ranges_equal_the_call_in_one_piece(dev, oracle, hinted):
     """ops.score_topk over user ranges (the workspace budget forces >= 5 of them, one after the other on the caller's stream) ==
