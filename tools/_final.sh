@@ -1,6 +1,7 @@
 # the round's closing run: the whole GPU suite, then the default bench line (both kept under profiles/)
 timeout 2300 python -m pytest tests -q -m gpu 2>&1 | tail -8 > gpurun_out/r05_zzz_gpu_tests.log
 cut -c1-300 gpurun_out/r05_zzz_gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 timeout 700 python bench.py > gpurun_out/r05_zzz_default_bench_line.json 2> gpurun_out/bench.err < /dev/null
 echo rc=$?
 python3 - <<'P'
