@@ -30,16 +30,9 @@ class DCCF(nn.Module):
         U, I = num_user, num_item
         e = torch.as_tensor(np.asarray(edge_index)).long()
         self.norm_adj_mat = graph.binary_sym_norm_csr(e[:, 0], e[:, 1] - U, U, I).to(device)
-        # the distinct interactions (row-major) with their multiplicity; one symmetric [N, N] structure: its first half holds
-        # the (user, item) entries in that order, the second half the same pairs ordered by (item, user)
-        key, cnt = torch.unique(e[:, 0] * I + (e[:, 1] - U), return_counts=True)
-        self._eu, self._ei = torch.div(key, I, rounding_mode="floor").to(device), (key % I).to(device)
-        self._ew = cnt.to(torch.float32).to(device)
-        self.n_edges = int(key.numel())
-        both = graph.coo_to_csr_coalesced(torch.cat([self._eu, U + self._ei]), torch.cat([U + self._ei, self._eu]),
-                                          torch.ones(2 * self.n_edges, device=device), U + I, U + I, symmetric=True)
-        self._lower = torch.argsort(self._ei * U + self._eu, stable=True)
-        self._structure = sparse._dropout_structure(both)
+        self._pairs = sparse.PairStructure(edge_index, U, I, device)      # distinct interactions + one symmetric [N, N] structure
+        self._eu, self._ei, self._ew, self.n_edges = self._pairs.eu, self._pairs.ei, self._pairs.ew, self._pairs.n
+        self._lower, self._structure = self._pairs.lower, self._pairs.structure
         self._zeros = torch.zeros(self.n_edges, dtype=torch.float32, device=device)
 
         self.user_embedding = nn.Embedding(num_user, dim_E)

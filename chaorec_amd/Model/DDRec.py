@@ -15,7 +15,6 @@ item-item products `chaorec_amd.sparse.mm`, every Linear `ops.linear` on the MFM
 Same constructor, parameters in the reference's creation order (the two frozen feature tables included: they are Parameters
 without gradient there too).  Kept quirk: `final_i_g_embeddings` of the PREVIOUS forward gates the modality features of the
 next one (:98-101) -- the first forward runs ungated."""
-import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -60,20 +59,13 @@ class DDRec(nn.Module):
         self.guide_image_trs = nn.Sequential(nn.Linear(feat_E, feat_E), nn.Sigmoid())
         self.guide_text_trs = nn.Sequential(nn.Linear(feat_E, feat_E), nn.Sigmoid())
 
-        # the distinct interactions (row-major) and how often each is listed; one symmetric [N, N] structure whose first half
-        # (rows < U) holds them in that order and whose second half holds the same pairs ordered by (item, user)
         U, I = num_user, num_item
-        e = torch.as_tensor(np.asarray(edge_index)).long()
-        key, cnt = torch.unique(e[:, 0] * I + (e[:, 1] - U), return_counts=True)
-        self._eu, self._ei = torch.div(key, I, rounding_mode="floor").to(device), (key % I).to(device)
-        self._ew = cnt.to(torch.float32).to(device)
-        self.n_edges = int(key.numel())
-        both = graph.coo_to_csr_coalesced(torch.cat([self._eu, U + self._ei]), torch.cat([U + self._ei, self._eu]),
-                                          torch.ones(2 * self.n_edges, device=device), U + I, U + I, symmetric=True)
-        self._lower = torch.argsort(self._ei * U + self._eu, stable=True)
+        self._pairs = sparse.PairStructure(edge_index, U, I, device)      # distinct interactions + one symmetric [N, N] structure
+        self._eu, self._ei, self._ew, self.n_edges = self._pairs.eu, self._pairs.ei, self._pairs.ew, self._pairs.n
+        self._lower, both = self._pairs.lower, self._pairs.csr
         both.val.copy_(self._values(self._ew))                      # the unfiltered graph: the id encoder's (:131-137)
         self.norm_adj = both
-        self._structure = sparse._dropout_structure(both)
+        self._structure = self._pairs.structure
 
         idx_v, val_v = knn_binary_graph(v_feat.to(device), self.knn_k)
         idx_t, val_t = knn_binary_graph(t_feat.to(device), self.knn_k)

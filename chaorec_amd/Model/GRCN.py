@@ -14,7 +14,6 @@ Kept quirks: the routing iterations of the content GCN run the attention layer o
 whose messages only reach item rows -- the user rows they add to the preferences are zero, a routing step is a re-normalisation
 (no product is launched for it); `weight_mode` / `fusion_mode` / `pruning` keep their defaults' branches (confid / concat / on).
 Batches are MMGCN's ([B, 2] user / item tensors with global item ids)."""
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -81,18 +80,9 @@ class GRCN(torch.nn.Module):
         self.weight_mode, self.fusion_mode, self.pruning = weight_mode, fusion_mode, pruning
         self.reg_weight, self.dropout, self.device = reg_weight, dropout, device
         self.register_buffer("weight", torch.tensor([[1.0], [-1.0]]), persistent=False)
-        U, I = num_user, num_item
-        e = torch.as_tensor(np.asarray(edge_index)).long()
-        self.n_listed = int(e.shape[0])
-        key, pair_of_edge, cnt = torch.unique(e[:, 0] * I + (e[:, 1] - U), return_inverse=True, return_counts=True)
-        self._pair_of_edge = pair_of_edge.to(device)
-        self._eu, self._ei = torch.div(key, I, rounding_mode="floor").to(device), (key % I).to(device)
-        self._ew = cnt.to(torch.float32).to(device)
-        self.n_edges = int(key.numel())
-        both = graph.coo_to_csr_coalesced(torch.cat([self._eu, U + self._ei]), torch.cat([U + self._ei, self._eu]),
-                                          torch.ones(2 * self.n_edges, device=device), U + I, U + I, symmetric=True)
-        self._lower = torch.argsort(self._ei * U + self._eu, stable=True)
-        self._structure = sparse._dropout_structure(both)
+        self._pairs = sparse.PairStructure(edge_index, num_user, num_item, device)      # distinct interactions + one symmetric [N, N] structure
+        self._eu, self._ei, self._ew, self.n_edges = self._pairs.eu, self._pairs.ei, self._pairs.ew, self._pairs.n
+        self.n_listed, self._lower, self._structure = self._pairs.n_listed, self._pairs.lower, self._pairs.structure
 
         self.id_gcn = EGCN(num_user, num_item, dim_E, aggr_mode)
         self.v_gcn = CGCN(v_feat, num_user, num_item, dim_C, aggr_mode, num_routing)
@@ -122,7 +112,7 @@ class GRCN(torch.nn.Module):
             keep = self.edge_keep_fn(self.n_listed, self.dropout).to(self._ew.device)
         else:
             keep = torch.rand(self.n_listed, device=self._ew.device) >= self.dropout
-        return torch.zeros(self.n_edges, dtype=torch.float32, device=self._ew.device).index_add_(0, self._pair_of_edge, keep.to(torch.float32))
+        return self._pairs.kept_copies(keep)
 
     # ---- :196-249 -------------------------------------------------------------------------------------------------------------
     def forward(self):

@@ -13,7 +13,6 @@ attention layers' weight and bias, the weight then re-drawn by xavier_normal_, :
 matrices as leaf tensors that require a gradient nobody reads (:130-131); they are buffers here."""
 import math
 
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -100,15 +99,9 @@ class MGAT(torch.nn.Module):
         self.num_user, self.num_item, self.dim_E, self.device = num_user, num_item, dim_E, device
         self.user_item_dict, self.reg_weight = user_item_dict, reg_weight
         U, I = num_user, num_item
-        e = torch.as_tensor(np.asarray(edge_index)).long()
-        key, cnt = torch.unique(e[:, 0] * I + (e[:, 1] - U), return_counts=True)
-        self._eu, self._ei = torch.div(key, I, rounding_mode="floor").to(device), (key % I).to(device)
-        self._ew = cnt.to(torch.float32).to(device)
-        self.n_edges = int(key.numel())
-        both = graph.coo_to_csr_coalesced(torch.cat([self._eu, U + self._ei]), torch.cat([U + self._ei, self._eu]),
-                                          torch.ones(2 * self.n_edges, device=device), U + I, U + I, symmetric=True)
-        self._lower = torch.argsort(self._ei * U + self._eu, stable=True)
-        self._structure = sparse._dropout_structure(both)
+        self._pairs = sparse.PairStructure(edge_index, U, I, device)      # distinct interactions + one symmetric [N, N] structure
+        self._eu, self._ei, self._ew, self.n_edges = self._pairs.eu, self._pairs.ei, self._pairs.ew, self._pairs.n
+        self._lower, self._structure = self._pairs.lower, self._pairs.structure
         deg = torch.zeros(U + I, dtype=torch.float32, device=device).index_add_(0, self._eu, self._ew).index_add_(0, U + self._ei, self._ew)
         self._deg_inv_sqrt = deg.pow(-0.5)                       # (degree(row) over the bidirectional list, :45-46; only read at edge endpoints)
         self.v_gnn = GNN(v_feat, num_user, num_item, dim_E, dim_latent=256)

@@ -51,21 +51,14 @@ class MMGCL(nn.Module):
         nn.init.xavier_uniform_(self.read_user.weight)
         nn.init.xavier_uniform_(self.read_item.weight)
 
-        # the distinct (user, item) pairs in row-major order (= scipy's csr.nonzero(), what :121,139 index) and how often each is listed
-        U, I = num_user, num_item
-        e = torch.as_tensor(np.asarray(edge_index)).long()
-        key, cnt = torch.unique(e[:, 0] * I + (e[:, 1] - U), return_counts=True)
-        self._eu, self._ei = torch.div(key, I, rounding_mode="floor").to(device), (key % I).to(device)
-        self._ew = cnt.to(torch.float32).to(device)
-        self.n_edges = int(key.numel())
-        # one symmetric [N, N] structure: its first n_edges entries are the pairs in that order (rows < U, columns ascending),
-        # the other half is the same pairs ordered by (item, user)
-        both = graph.coo_to_csr_coalesced(torch.cat([self._eu, U + self._ei]), torch.cat([U + self._ei, self._eu]),
-                                          torch.ones(2 * self.n_edges, device=device), U + I, U + I, symmetric=True)
-        self._lower = torch.argsort(self._ei * U + self._eu, stable=True)          # pair index of the k-th lower entry
+        # the distinct (user, item) pairs in row-major order (= scipy's csr.nonzero(), what :121,139 index), how often each is
+        # listed, and one symmetric [N, N] structure over them
+        self._pairs = sparse.PairStructure(edge_index, num_user, num_item, device)
+        self._eu, self._ei, self._ew, self.n_edges = self._pairs.eu, self._pairs.ei, self._pairs.ew, self._pairs.n
+        self._lower, both = self._pairs.lower, self._pairs.csr
         both.val.copy_(self._values(self._ew))                                      # :77-109 on the multiplicities: norm_adj
         self.norm_adj = both
-        self._structure = sparse._dropout_structure(both)
+        self._structure = self._pairs.structure
         self.hist = ranking.history_csr(user_item_dict, num_user, device)
         self.edge_keep_fn = self.node_keep_fn = self.modality_fn = None
 

@@ -8,7 +8,6 @@ the ranking `ranking.gene_ranklist` over the tables of the last training forward
 
 Same constructor and parameters.  `ssl_aug_type` is fixed at 'ed' there (:40); 'nd' and 'rw' are kept.  The draws come from
 the device generator; `edge_keep_fn(n_listed, ratio)` / `node_keep_fn(U, I, ratio)` replay stored draws in the golden test."""
-import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -31,21 +30,12 @@ class SGL(nn.Module):
         self.reg_weight, self.n_layers, self.aggr_mode, self.device = reg_weight, n_layers, aggr_mode, device
         self.ssl_aug_type, self.ssl_temp, self.ssl_reg, self.ssl_ratio = 'ed', ssl_temp, ssl_reg, 0.1
         self.edge_index = edge_index
-        U, I = num_user, num_item
-        e = torch.as_tensor(np.asarray(edge_index)).long()
-        self.n_listed = int(e.shape[0])
-        key, self._pair_of_edge, cnt = torch.unique(e[:, 0] * I + (e[:, 1] - U), return_inverse=True, return_counts=True)
-        self._pair_of_edge = self._pair_of_edge.to(device)
-        self._eu, self._ei = torch.div(key, I, rounding_mode="floor").to(device), (key % I).to(device)
-        self._ew = cnt.to(torch.float32).to(device)
-        self._edge_u, self._edge_i = e[:, 0].to(device), (e[:, 1] - U).to(device)
-        self.n_edges = int(key.numel())
-        both = graph.coo_to_csr_coalesced(torch.cat([self._eu, U + self._ei]), torch.cat([U + self._ei, self._eu]),
-                                          torch.ones(2 * self.n_edges, device=device), U + I, U + I, symmetric=True)
-        self._lower = torch.argsort(self._ei * U + self._eu, stable=True)
+        self._pairs = sparse.PairStructure(edge_index, num_user, num_item, device)      # distinct interactions + one symmetric [N, N] structure
+        self._eu, self._ei, self._ew, self.n_edges = self._pairs.eu, self._pairs.ei, self._pairs.ew, self._pairs.n
+        self.n_listed, self._lower, both = self._pairs.n_listed, self._pairs.lower, self._pairs.csr
         both.val.copy_(self._values(self._ew))
         self.norm_adj = both
-        self._structure = sparse._dropout_structure(both)
+        self._structure = self._pairs.structure
         self.user_embeddings = nn.Embedding(num_user, dim_E)
         self.item_embeddings = nn.Embedding(num_item, dim_E)
         nn.init.xavier_uniform_(self.user_embeddings.weight)
@@ -80,7 +70,7 @@ class SGL(nn.Module):
             else:
                 keep = torch.zeros(self.n_listed, dtype=torch.bool, device=dev)
                 keep[_subset(self.n_listed, int(self.n_listed * (1 - ratio)), dev)] = True
-            w = torch.zeros(self.n_edges, dtype=torch.float32, device=dev).index_add_(0, self._pair_of_edge, keep.to(torch.float32))
+            w = self._pairs.kept_copies(keep)
         val = self._values(w)
         return sparse.DroppedAdj(self._structure, val, val)                         # (symmetric: its own transpose)
 

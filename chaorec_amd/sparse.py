@@ -69,6 +69,38 @@ class DroppedAdj:
         self.structure, self.val, self.val_t = structure, val, val_t
 
 
+class PairStructure:
+    """The fixed skeleton of the models whose bipartite graph changes its VALUES per step (MMGCL, SGL, DDRec, DCCF, GRCN, MGAT): the
+    distinct (user, item) interactions of an edge list in row-major order (`eu`, `ei`, multiplicity `ew`; `pair_of_edge` maps a
+    LISTED edge to its pair), and ONE symmetric [N, N] structure over them (`structure`, a graph.DropoutStructure on `csr`) whose
+    first n entries are the pairs (u, U + i) in that order and whose other n entries are the same pairs ordered by (item, user):
+    `lower[j]` = the pair of the j-th of those.  both(up, low) lays two per-pair value arrays out over the structure: `up` at
+    the entries (u, U + i) -- an edge item -> user --, `low` at (U + i, u)."""
+
+    def __init__(self, edge_index, num_user, num_item, device):
+        import numpy as np
+        U, I = num_user, num_item
+        e = torch.as_tensor(np.asarray(edge_index)).long()
+        self.n_listed = int(e.shape[0])
+        key, pair_of_edge, cnt = torch.unique(e[:, 0] * I + (e[:, 1] - U), return_inverse=True, return_counts=True)
+        self.pair_of_edge = pair_of_edge.to(device)
+        self.eu, self.ei = torch.div(key, I, rounding_mode="floor").to(device), (key % I).to(device)
+        self.ew = cnt.to(torch.float32).to(device)
+        self.n = int(key.numel())
+        self.csr = graph.coo_to_csr_coalesced(torch.cat([self.eu, U + self.ei]), torch.cat([U + self.ei, self.eu]),
+                                              torch.ones(2 * self.n, device=device), U + I, U + I, symmetric=True)
+        self.lower = torch.argsort(self.ei * U + self.eu, stable=True)
+        self.structure = _dropout_structure(self.csr)
+
+    def both(self, up, low=None):
+        """-> [2 n] values in the structure's entry order (low = up: a symmetric matrix)."""
+        return torch.cat([up, (up if low is None else low)[self.lower]])
+
+    def kept_copies(self, keep):
+        """per-pair weight = how many LISTED copies of the pair a bool [n_listed] mask keeps"""
+        return torch.zeros(self.n, dtype=torch.float32, device=self.ew.device).index_add_(0, self.pair_of_edge, keep.to(torch.float32))
+
+
 class LearnedAdj:
     """A sparse operand built from embeddings THIS step (Model/MICRO.py:176-187: a kNN graph of the projected features), its
     values carrying gradient, over its own structure -- any pattern; row-major entries (rowptr, col), `val` [nnz].  `mm` of it
