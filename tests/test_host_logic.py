@@ -681,3 +681,90 @@ def test_frontier_modes_by_size_and_the_replay_length_of_a_light_epoch(monkeypat
     assert FusedLightGCNStep.frontier_modes(3_250_000, 3, 128) == (True, True, False)
     monkeypatch.setenv("CHAOREC_SPARSE_BACKWARD", "1")
     assert FusedLightGCNStep.frontier_modes(1000, 2, 64)[1] is True
+
+
+def test_pair_structure_layout():
+    """sparse.PairStructure (the skeleton of the six graph-reweighting models): the structure's first n entries are the distinct
+    (user, item) pairs in row-major order, `lower` maps the other half back to pairs, both() lays per-pair values out as the
+    [N, N] matrix says, kept_copies() counts the surviving listed copies of a pair."""
+    from chaorec_amd import sparse
+    U, I = 7, 5
+    edges = np.array([(0, U + 1), (0, U + 3), (2, U + 0), (2, U + 3), (2, U + 3), (5, U + 4), (6, U + 1), (6, U + 0)], dtype=np.int64)
+    ps = sparse.PairStructure(edges, U, I, torch.device("cpu"))
+    assert ps.n_listed == 8 and ps.n == 7 and ps.ew.tolist() == [1, 1, 1, 2, 1, 1, 1]
+    st = ps.structure
+    rows, cols = st.entry_row.long(), st.col.long()
+    assert torch.equal(rows[:ps.n], ps.eu) and torch.equal(cols[:ps.n], U + ps.ei)
+    assert torch.equal(rows[ps.n:], U + ps.ei[ps.lower]) and torch.equal(cols[ps.n:], ps.eu[ps.lower])
+    up, low = torch.arange(1., ps.n + 1), -torch.arange(1., ps.n + 1)
+    dense = torch.zeros(U + I, U + I)
+    dense[rows, cols] = ps.both(up, low)
+    for k in range(ps.n):
+        assert dense[ps.eu[k], U + ps.ei[k]] == up[k] and dense[U + ps.ei[k], ps.eu[k]] == low[k]
+    assert torch.equal(dense[rows, cols][st.transpose_entry.long()], dense.T[rows, cols])
+    keep = torch.tensor([1, 1, 1, 1, 0, 0, 1, 1], dtype=torch.bool)
+    assert ps.kept_copies(keep).tolist() == [1, 1, 1, 1, 0, 1, 1]          # (pairs in key order: (6, 0) before (6, 1))
+
+
+def test_segment_softmax_is_pygs_softmax_with_multiplicities():
+    """Model/GRCN.py's / MGAT.py's per-pair segment softmax against torch_geometric.utils.softmax (its restatement in
+    oracle/pyg_standin.py) over the LISTED edges: a pair listed w times counts w times in its group's sum; a dropped pair (w = 0)
+    leaves the group."""
+    from chaorec_amd.Model.GRCN import _segment_softmax
+    from oracle import pyg_standin
+    g = torch.Generator().manual_seed(5)
+    n_seg, n = 6, 40
+    seg = torch.randint(0, n_seg, (n,), generator=g)
+    logit = torch.randn(n, generator=g) * 3
+    w = torch.randint(0, 3, (n,), generator=g).float()
+    got = _segment_softmax(logit, seg, n_seg, w)
+    listed = torch.repeat_interleave(torch.arange(n), w.long())              # every kept copy as its own edge
+    want = pyg_standin.softmax(logit[listed], seg[listed], num_nodes=n_seg)
+    assert torch.allclose(got[listed], want, rtol=1e-6, atol=1e-7)
+    assert bool((got[w == 0] == 0).all())
+    sums = torch.zeros(n_seg).index_add_(0, seg, w * got)
+    live = torch.zeros(n_seg).index_add_(0, seg, w) > 0
+    assert torch.allclose(sums[live], torch.ones(int(live.sum())), atol=1e-6)
+
+
+def test_learned_adj_transposed_layout():
+    """sparse.LearnedAdj.transposed(): entry k of A^T's row-major layout is entry perm[k] of A's (what the backward SpMM of a
+    learned graph multiplies with)."""
+    from chaorec_amd import sparse
+    g = torch.Generator().manual_seed(8)
+    n, m = 9, 13
+    key = torch.unique(torch.randint(0, n * m, (40,), generator=g))
+    rows, cols = torch.div(key, m, rounding_mode="floor"), key % m
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    torch.cumsum(torch.bincount(rows, minlength=n), 0, out=rowptr[1:])
+    val = torch.rand(key.numel(), generator=g)
+    adj = sparse.LearnedAdj(rowptr, cols, val, n, m)
+    assert torch.equal(adj.entry_rows(), rows)
+    rowptr_t, col_t, perm = adj.transposed()
+    dense = torch.zeros(n, m)
+    dense[rows, cols] = val
+    rows_t = torch.repeat_interleave(torch.arange(m), rowptr_t[1:] - rowptr_t[:-1])
+    dense_t = torch.zeros(m, n)
+    dense_t[rows_t, col_t.long()] = val[perm]
+    assert torch.equal(dense_t, dense.T)
+    d = adj.detach()
+    assert d.n_rows == n and d.n_cols == m and torch.equal(d.val, val)
+
+
+def test_mmssl_row_mean_graph_is_csr_norm():
+    """Model/MMSSL.py:176-190 (csr_norm, mean_flag=True) on a count matrix with a repeated pair and an empty row, restated with
+    scipy here, against chaorec_amd.Model.MMSSL._row_mean_graph; an empty list is the all-zero operand (None)."""
+    import scipy.sparse as sp
+    from chaorec_amd.Model.MMSSL import _row_mean_graph
+    rows = torch.tensor([0, 0, 2, 2, 2, 4])
+    cols = torch.tensor([1, 3, 0, 3, 3, 2])
+    got = _row_mean_graph(rows, cols, 5, 4, torch.device("cpu"))
+    m = sp.csr_matrix((np.ones(6, np.float32), (rows.numpy(), cols.numpy())), shape=(5, 4))
+    rowsum = np.power(np.array(m.sum(1)) + 1e-8, -0.5).flatten()
+    want = (sp.diags(rowsum) * m).toarray().astype(np.float32)
+    dense = np.zeros((5, 4), np.float32)
+    rp, col, val = got.rowptr.numpy(), got.col.numpy(), got.val.numpy()
+    for r in range(5):
+        dense[r, col[rp[r]:rp[r + 1]]] = val[rp[r]:rp[r + 1]]
+    assert np.abs(dense - want).max() <= 1e-7
+    assert _row_mean_graph(rows[:0], cols[:0], 5, 4, torch.device("cpu")) is None
