@@ -1,2 +1,2 @@
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_models.py tests/test_gpu_real_data.py tests/test_gpu_feature_adam.py tests/test_gpu_round3.py tests/test_gpu_round4.py -q -m gpu -x -k "gemm or freedom or linear or feature or lazy or early" 2>&1 | tail -5
-for g in 1 0; do CHAOREC_GATHER_IN_PRODUCT=$g timeout 600 python3 bench.py --model FREEDOM --steps 200 --warmup 20 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FREEDOM in_product=$g', d['ms_per_step'])"; done
+# scratch: one gpurun call's worth of commands (edit, then `gpurun -- 'bash tools/_g1.sh'`)
+timeout 1200 python -m pytest tests/test_gpu_sparse_family.py -q -m gpu -x 2>&1 | tail -5
