@@ -119,14 +119,12 @@ class MMSSL(nn.Module):
 
     # ---- helpers --------------------------------------------------------------------------------------------------------------
     def mm(self, x, y):
-        """:160-164; an empty (rewired) graph is an all-zero operand."""
-        if x is None:
-            return y.new_zeros((self._rows_of_none, y.shape[1]))
+        """:160-164."""
         return sparse.mm(x, y)
 
     def _mm(self, g, n_rows, y):
-        self._rows_of_none = n_rows
-        return self.mm(g, y)
+        """mm with an operand that may be EMPTY (a modality graph rewired from emptied lists: None): all-zero rows."""
+        return y.new_zeros((n_rows, y.shape[1])) if g is None else self.mm(g, y)
 
     def sim(self, z1, z2):
         return torch.mm(F.normalize(z1), F.normalize(z2).t())
