@@ -193,5 +193,6 @@ def main_model(args, world, rank, local_rank, force_sharded):
         import torch.distributed as dist
         dist.destroy_process_group()
     if rank == 0:
-        flush_c_stdout()
-        print(json.dumps(out), flush=True)
+        from .record import emit
+        out.setdefault("cpu_baseline", {"value": None, "reason": "--model runs carry no CPU leg (the LightGCN line does)"})
+        emit(out)

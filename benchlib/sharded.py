@@ -10,6 +10,7 @@ import torch
 from .common import HBM_PEAK_GBS, flush_c_stdout, init_ranks, spmm_kernel_name  # noqa: F401
 from .models import measure_model  # noqa: F401
 from .probe import captured_all_reduce_is_exact, probe_mark, probe_node  # noqa: F401
+from .record import emit
 from .single import CHAIN_TIMING_NOTE, scoring_roofline, time_spmm_chain  # noqa: F401
 
 
@@ -380,18 +381,43 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
             "frontier_capacities": head["frontier_caps"]} if head.get("forward") else {}),
     }
 
+    # (the second dominant kernel family inside the object the driver keeps, as in the N = 1 line)
+    sr = out["roofline_scoring"]
+    out["roofline"]["scoring"] = {"bound": "mfma", "kernel": sr["kernel"], "achieved": sr["achieved"], "peak": sr["peak"],
+                                  "unit": sr["unit"], "frac": sr["frac"], "sweep_only_frac": sr.get("sweep_only_frac"),
+                                  "gene_ranklist_ms": head["score_ms"]}
+    # cpu_baseline: rank 0 times the reference op sequence (oracle/torch_ref.py) on ONE rank's share of the workload --
+    # the N = 1 workload, which is what a weak-scaling rank owns -- while the other ranks wait at the next barrier
+    if args.no_cpu_baseline:
+        out["cpu_baseline"] = {"value": None, "reason": "--no-cpu-baseline"}
+    elif rank == 0:
+        try:
+            from .common import load_graph
+            from .cpu import cpu_baseline
+            edges_cpu, U_c, I_c, _ = load_graph(args.dataset, args.synthetic)
+            out["cpu_baseline"] = cpu_baseline(np.asarray(edges_cpu), U_c, I_c, D, L, B, 1e-3, args.cpu_seconds)
+            out["cpu_baseline"]["sample"] = "ONE rank's share (the N = 1 workload): " + out["cpu_baseline"]["sample"]
+        except Exception as exc:      # noqa: BLE001 -- the baseline must not take the measured headline with it
+            out["cpu_baseline"] = {"value": None, "reason": repr(exc)[:200]}
+    dist.barrier()
+
     # Sub-records, under a watchdog: a collective that cannot make progress in a sub-record must not take the headline
-    # numbers (measured above) with it -- rank 0 then prints the line without the unfinished ones and the job ends.
+    # numbers (measured above) with it -- rank 0 then prints the line, naming the unfinished ones, and every rank ends
+    # with a non-zero exit code so that launchers and CI see the hang.
     import threading
     finished = threading.Event()
+    wanted = ([] if (args.no_hbm_regime or args.dataset in ("config5_shard", "config5")) else ["hbm_regime"]) + \
+        ([] if args.no_models else ["models.MMGCN", "models.FREEDOM"])
+
+    def unfinished():
+        return [w for w in wanted if (w not in out if "." not in w else w.split(".")[1] not in out.get("models", {}))]
 
     def give_up():
         if not finished.wait(float(os.environ.get("CHAOREC_SUBRECORD_TIMEOUT_S", "900"))):
             if rank == 0:
-                out.setdefault("hbm_regime", {"error": "sub-records did not finish in time"})
-                flush_c_stdout()
-                print(json.dumps(out), flush=True)
-            os._exit(0 if rank == 0 else 0)
+                out["subrecords_timed_out"] = unfinished()
+                emit(out)
+            os._exit(21)
 
     threading.Thread(target=give_up, daemon=True).start()
 
@@ -437,5 +463,4 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
     dist.destroy_process_group()
     cdist.P2PExchange.forget_all()
     if rank == 0:
-        flush_c_stdout()
-        print(json.dumps(out), flush=True)
+        emit(out)

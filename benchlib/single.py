@@ -10,6 +10,20 @@ import torch
 from .common import BF16_MFMA_PEAK_TFLOPS, F32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, MIN_TIMED_S, ROOT, STEADY_EVALS, TRAINED_STEPS, load_graph, spmm_kernel_name, spmm_model_bytes, spmm_source_hash  # noqa: F401
 from .cpu import cpu_baseline  # noqa: F401
 from .models import measure_model  # noqa: F401
+from .record import emit
+
+
+def performed_value(m):
+    """A sub-record's `value` is the work its step PERFORMS (source rows gathered per second by the step's SpMM-family
+    launches); the reference step's 2 L E_dir messages over the same time go beside it as value_reference_equivalent.
+    (A full step performs the reference's messages: both are then the same number.)"""
+    p = m.get("performed")
+    if p:
+        return {"value": p["value_performed"], "value_reference_equivalent": m["value"],
+                "value_is": "source rows gathered per second by the light step's SpMM-family launches (work performed); "
+                            "value_reference_equivalent divides the REFERENCE step's 2 L E_dir messages by the same time",
+                "messages_gathered_per_step": p["messages_gathered_per_step"]}
+    return {"value": m["value"], "value_reference_equivalent": m["value"]}
 
 
 def time_spmm_calls(ops, calls, reps=20, passes=5):
@@ -248,9 +262,8 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
                                 "N1 (the batch rows' 1-hop image) and R0 (the batch rows) only: loss, gradient and updated tables are "
                                 "the full step's bit for bit (tests/test_gpu_round4.py); the ONE step of an epoch that precedes the "
                                 "evaluation computes every row (model.result for gene_ranklist, the reference's stale-result quirk) "
-                                "and costs ms_per_step_full_result.  `value` keeps counting the reference step's 2 L E_dir messages "
-                                "per step (the work of Model/LightGCN.py's step that this step replaces), not the smaller number of "
-                                "rows a light step gathers"}
+                                "and costs ms_per_step_full_result.  The record's `value` counts the source rows a light step gathers; "
+                                "value_reference_equivalent the reference step's 2 L E_dir messages over the same time"}
     loss_mean = (float(loss_sum.item()) if fused else float(acc0.item())) / max(n_loss[0], 1)
     msgs_per_step = 2 * L * e_dir
 
@@ -545,9 +558,9 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
     if light_launches is not None:
         performed = {"messages_gathered_per_step": light_launches["messages_gathered_per_step"],
                      "value_performed": light_launches["messages_gathered_per_step"] / (dt / steps),
-                     "what": "`value` counts the REFERENCE step's 2 L E_dir directed-edge messages per step (the work of "
-                             "Model/LightGCN.py's step that this step replaces, bit for bit); value_performed counts the source "
-                             "rows a light step actually gathers in its six SpMM-family launches"}
+                     "what": "value_performed counts the source rows a light step actually gathers in its six SpMM-family "
+                             "launches; the reference step's 2 L E_dir messages per step are the work of Model/LightGCN.py's step "
+                             "that this step replaces bit for bit"}
     return dict(dataset=dataset, data=data_kind, U=U, I=I, E=E, e_dir=e_dir, D=D, L=L, B=B, ms_per_step=ms_per_step,
                 value=msgs_per_step / (dt / steps), msgs_per_step=msgs_per_step, loss_mean=loss_mean, launch=launch,
                 performed=performed, roofline=roofline, score_ms=score_ms, score_state=state, early_ms=early_ms, early_st=early_st,
@@ -585,11 +598,11 @@ def main_single(args, dev):
                           "data": r["data"], "config": {"workload": f"LightGCN train step on the {r['data']} {args.dataset} "
                                                                     f"graph (U={U}, I={I}, E_dir={r['e_dir']}), dim={D}",
                                                         "launch": r["launch"], "host_build_seconds": r["build_s"]},
-                          "roofline": r["roofline"], "loss_mean": r["loss_mean"]}), flush=True)
+                          "roofline": r["roofline"], "loss_mean": r["loss_mean"]}), flush=True)   # (a profiling mode, not the record)
         return
     out = {
         "metric": f"GCN edges/sec + full-rank users-scored/sec, dim={D}",
-        "value": r["value"], "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
+        **performed_value(r), "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
         "users_scored_per_s": U / (r["score_ms"] * 1e-3),
         "users_scored_per_s_cold": U / (r["cold_ms"] * 1e-3),
         "users_scored_per_s_incl_d2h": U / (r["host_rank_ms"] * 1e-3) if r["host_rank_ms"] else None,
@@ -616,7 +629,6 @@ def main_single(args, dev):
                    "parallelism": "single GPU", "host_build_seconds": r["build_s"]},
         "roofline": r["roofline"], "roofline_scoring": scoring_roofline(r), "loss_mean": r["loss_mean"],
         **({"forward": r["forward"]} if r.get("forward") else {}),
-        **(r["performed"] if r.get("performed") else {}),
     }
     # (the second dominant kernel family inside the object the driver keeps: the all-items scoring's share of the MFMA peak)
     sr = out["roofline_scoring"]
@@ -633,14 +645,13 @@ def main_single(args, dev):
             "workload": f"one GPU's share of BASELINE configs[4]: synthetic bipartite graph U={h['U']}, I={h['I']}, "
                         f"E_dir={h['e_dir']}, dim=128, n_layers={h['L']}, batch={h['B']} (embedding table "
                         f"{h['table_mb']:.0f} MB = {h['table_mb'] / 268.4:.1f}x the Infinity Cache)",
-            "data": h["data"], "steps": args.hbm_steps, "ms_per_step": h["ms_per_step"], "value": h["value"],
+            "data": h["data"], "steps": args.hbm_steps, "ms_per_step": h["ms_per_step"], **performed_value(h),
             "unit": "directed-edge messages/s", "roofline": h["roofline"],
             "gene_ranklist_ms": h["score_ms"], "users_scored_per_s": h["U"] / (h["score_ms"] * 1e-3),
             "gene_ranklist_mode": "steady state" if h["steady"] else "cold: sampled thresholds",
             "gene_ranklist_ms_cold": h["cold_ms"],
             "roofline_scoring": scoring_roofline(h), "loss_mean": h["loss_mean"],
             **({"forward": h["forward"]} if h.get("forward") else {}),
-            **(h["performed"] if h.get("performed") else {}),
         }
         del h
         torch.cuda.empty_cache()
@@ -651,12 +662,11 @@ def main_single(args, dev):
                 "workload": f"BASELINE configs[4] whole: synthetic bipartite graph U={f['U']}, I={f['I']}, E_dir={f['e_dir']}, "
                             f"dim=128, n_layers={f['L']}, batch={f['B']} (embedding table {f['table_mb']:.0f} MB; generated "
                             f"and laid out on the device)",
-                "data": f["data"], "steps": args.full_steps, "ms_per_step": f["ms_per_step"], "value": f["value"],
+                "data": f["data"], "steps": args.full_steps, "ms_per_step": f["ms_per_step"], **performed_value(f),
                 "unit": "directed-edge messages/s", "roofline": f["roofline"], "host_build_seconds": f["build_s"],
                 "gene_ranklist_ms_cold": f["cold_ms"], "users_scored_per_s_cold": f["U"] / (f["cold_ms"] * 1e-3),
                 "roofline_scoring": scoring_roofline(f), "loss_mean": f["loss_mean"],
                 **({"forward": f["forward"]} if f.get("forward") else {}),
-                **(f["performed"] if f.get("performed") else {}),
             }
             del f
             torch.cuda.empty_cache()
@@ -673,4 +683,7 @@ def main_single(args, dev):
             torch.cuda.empty_cache()
     if not args.no_cpu_baseline and edges is not None:
         out["cpu_baseline"] = cpu_baseline(edges, U, I, D, args.n_layers, args.batch, reg, args.cpu_seconds)
-    print(json.dumps(out), flush=True)
+    else:
+        out["cpu_baseline"] = {"value": None, "reason": "--no-cpu-baseline" if args.no_cpu_baseline else
+                               "no host copy of this graph's edge list (device-built synthetic graph)"}
+    emit(out)

@@ -768,3 +768,58 @@ def test_mmssl_row_mean_graph_is_csr_norm():
         dense[r, col[rp[r]:rp[r + 1]]] = val[rp[r]:rp[r + 1]]
     assert np.abs(dense - want).max() <= 1e-7
     assert _row_mean_graph(rows[:0], cols[:0], 5, 4, torch.device("cpu")) is None
+
+
+@pytest.mark.parametrize("canned", ["r05_zzz_default_bench_line.json", "r05_zzz_bench_line_gpus8_one_gpu.json",
+                                    "r05_v_config5_full_bench_line.json"])
+def test_bench_record_is_a_compact_projection_of_the_detail(canned, tmp_path):
+    """the LAST stdout line of bench.py is <= 4 KB of JSON with the contract's keys, whatever the detail
+    weighs (round 5's own 24 KB line is the canned detail here); the detail goes to a file and stderr, not to stdout."""
+    import json
+    from benchlib import record
+    detail = json.load(open(os.path.join(ROOT, "profiles", canned)))
+    detail.setdefault("cpu_baseline", {"value": None, "reason": "canned"})
+    s = record.render(detail, "bench_detail.json")
+    assert len(s.encode()) <= record.LINE_LIMIT and "\n" not in s
+    line = json.loads(s)
+    for k in record.REQUIRED:
+        assert k in line, k
+    assert line["value"] == pytest.approx(detail["value"], rel=1e-5) and line["ms_per_step"] == pytest.approx(detail["ms_per_step"], rel=1e-5)
+    assert isinstance(line["config"]["workload"], str) and "model" not in line["config"]
+    rf = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-4)
+    if "hbm_regime" in detail and "error" not in detail["hbm_regime"]:
+        assert line["hbm_regime"]["ms_per_step"] == pytest.approx(detail["hbm_regime"]["ms_per_step"], rel=1e-5)
+        assert "spmm_frac" in line["hbm_regime"]
+    # a pathological detail (kilobytes of prose in every string) still fits: optional parts are dropped, required ones kept
+    fat = json.loads(json.dumps(detail))
+    fat["config"]["workload"] = "w" * 5000
+    fat["config"]["launch"] = "l" * 5000
+    fat["models"] = {f"M{i}": {"ms_per_step": 1.0, "value": 2.0, "roofline": {"dominant_kernel": "k" * 500, "frac": 0.1}} for i in range(40)}
+    s2 = record.render(fat, "bench_detail.json")
+    assert len(s2.encode()) <= record.LINE_LIMIT
+    assert all(k in json.loads(s2) for k in record.REQUIRED)
+
+
+def test_bench_record_through_the_launcher_over_gloo(tmp_path):
+    """... and end to end: `bench.py --gpus 2` (own launcher, gloo ranks) emitting a canned detail through
+    benchlib.record.emit -- the last stdout line the launcher relays is the compact record, the detail is in the file."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    canned = os.path.join(ROOT, "profiles", "r05_zzz_bench_line_gpus8_one_gpu.json")
+    detail_path = str(tmp_path / "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"],
+                       env=dict(env, CHAOREC_BENCH_SELFTEST_EMIT=canned, CHAOREC_BENCH_DETAIL=detail_path),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last.encode()) <= 4096
+    line = json.loads(last)
+    want = json.load(open(canned))
+    assert line["metric"] == want["metric"] and line["n_gpus"] == want["n_gpus"] and "roofline" in line and "cpu_baseline" in line
+    assert json.load(open(detail_path))["config"] == want["config"]
+    assert "[bench detail]" in r.stderr and "[bench detail]" not in r.stdout
