@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr_read per compared score
 
 _lib = None
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_i64p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -79,6 +79,8 @@ SIGNATURES = {
                                            ctypes.c_int32, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_bpr_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
                                            c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "chaorec_bpr_bwd_ordered_f32": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
+                                                   c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_sample_negatives": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_uint64, ctypes.c_uint64, c_ptr, ctypes.c_int64, c_ptr, c_ptr]),
     "chaorec_draw_batch": (ctypes.c_int, [c_ptr, ctypes.c_int64, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int64,
@@ -162,6 +164,8 @@ SIGNATURES = {
                                                  ctypes.c_int32, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_bpr_multi_bwd_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_int32,
                                                  ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "chaorec_bpr_multi_bwd_ordered_f32": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_int32,
+                                                         ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "chaorec_gemm_nt_bf16x3_dual": (ctypes.c_int, [c_ptr] * 7 + [ctypes.c_int64] * 9 + [ctypes.c_int32, ctypes.c_int32, c_ptr]),
     "chaorec_gemm_nn_bf16x3_dual_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "chaorec_gemm_nn_bf16x3_dual": (ctypes.c_int, [c_ptr] * 5 + [ctypes.c_int64] * 9 + [c_ptr, ctypes.c_size_t, c_ptr]),

@@ -391,6 +391,166 @@ __global__ __launch_bounds__(256) void bpr_multi_bwd_kernel(const float *__restr
   }
 }
 
+// ---- ORDERED backward: the same row sums without atomics ---------------------------------------------------------
+// The atomic row adds above are order-dependent once THREE addends meet in one element ((a + b) + c != a + (c + b)); the
+// order the memory system applies them in moves with the load on the chip, so two runs of one training step can differ
+// in the last bit of a few gradient elements -- and Adam, in the first steps of a run, turns a last-bit difference of an
+// element that is (nearly) all cancellation into a difference of a fraction of lr in the parameter (round 6: the rare
+// "two-stream divergence" of the MMGCN steps and VBPR's run-to-run spread were this; it shows in one-stream runs as
+// often, tools/stream_stress.py, profiles/r06_stream_bisect.txt).  The ordered launch gives every destination row ONE
+// owner wave that adds the row's contributions in ascending slot order:
+//   * a slot = one row contribution of one sample; the slots of a GROUP (one destination buffer) are numbered
+//     role-major, sample-minor;
+//   * every workgroup computes the destination-row KEY (the row's address) of every slot of its group into LDS, then
+//     each of its 16 waves takes one slot: a wave whose key occurs at a lower slot leaves; the first occurrence scans the
+//     keys upwards from its own slot and adds the contribution of every slot with its key to the row (read once, written
+//     once, no atomic) -- the expressions are the atomic kernels', only the order is fixed.
+// O(n^2 / 64) key compares per group of n slots: 3 B = 3072 slots cost ~3 us of the chip.  Groups beyond kOrdMaxSlots (the
+// keys must fit LDS) stay with the atomic launch.
+constexpr int kOrdMaxSlots = 16384;         // 128 KB of 8-byte keys
+constexpr int kOrdWaves = 16;
+
+struct OrdArgs {
+  const float *tab_u;
+  const int64_t *users;
+  BprMultiArgs A;                           // tab_i / pos / neg / g_i / scatter per term
+  const float *coef;                        // [T, B]
+  const float *wvec;                        // [T] or NULL (single term: 1)
+  const float *grad_out;                    // device scalar or NULL
+  float *g_u;
+  float r2_unit;                            // single term: 2 reg / (B D), times grad_out; multi: 0
+  int B, D, T;
+  int joined;                               // 1: ONE group of 3 B slots (users, pos, neg of term 0: g_u and g_i may alias)
+};
+// groups (blockIdx.y) when !joined: 0 = the users of all terms (T B slots); 1 + 2 k = term k's item rows (2 B: pos, neg);
+// 2 + 2 k = term k's scattered rows (2 B), empty without scatter_rows[k]
+struct OrdSlot {
+  int term, b, role;                        // role 0 user, 1 pos, 2 neg, 3 scattered pos, 4 scattered neg
+};
+__device__ __forceinline__ int ord_group_slots(const OrdArgs &P, int g) {
+  if (P.joined) return 3 * P.B;
+  if (g == 0) return P.T * P.B;
+  const int k = (g - 1) >> 1;
+  if (((g - 1) & 1) && !P.A.scatter_rows[k]) return 0;
+  return 2 * P.B;
+}
+__device__ __forceinline__ OrdSlot ord_slot(const OrdArgs &P, int g, int j) {
+  OrdSlot s;
+  const int q = j / P.B;
+  s.b = j - q * P.B;
+  if (P.joined) {
+    s.term = 0, s.role = q;
+  } else if (g == 0) {
+    s.term = q, s.role = 0;
+  } else {
+    s.term = (g - 1) >> 1;
+    s.role = (((g - 1) & 1) ? 3 : 1) + q;
+  }
+  return s;
+}
+__device__ __forceinline__ float *ord_dst(const OrdArgs &P, const OrdSlot s) {
+  const int D = P.D;
+  if (s.role == 0) return P.g_u + (size_t)P.users[s.b] * D;
+  const int64_t r = (s.role & 1) ? P.A.pos[s.term][s.b] : P.A.neg[s.term][s.b];
+  if (s.role <= 2) return P.A.g_i[s.term] + (size_t)r * D;
+  return P.A.scatter_out[s.term] + (size_t)P.A.scatter_rows[s.term][r] * D;
+}
+
+template <int NQ>
+__global__ __launch_bounds__(64 * kOrdWaves) void bpr_bwd_ordered_kernel(const OrdArgs P) {
+  extern __shared__ uint64_t ord_keys[];
+  const int g = blockIdx.y;
+  const int n = ord_group_slots(P, g);
+  if ((int)blockIdx.x * kOrdWaves >= n) return;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) ord_keys[j] = (uint64_t)reinterpret_cast<uintptr_t>(ord_dst(P, ord_slot(P, g, j)));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int me = blockIdx.x * kOrdWaves + wave;
+  if (me >= n) return;
+  const uint64_t key = ord_keys[me];
+  // the first occurrence of a key owns its row
+  for (int base = 0; base < me; base += 64) {
+    const int j = base + lane;
+    if (__any(j < me && ord_keys[j] == key)) return;
+  }
+  float *dst = reinterpret_cast<float *>((uintptr_t)key);
+  const int D = P.D;
+  float acc[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) acc[i] = lane + 64 * i < D ? dst[lane + 64 * i] : 0.f;
+  const float go0 = P.grad_out ? P.grad_out[0] : 1.0f;
+  const float r2 = P.r2_unit * go0;
+  auto contribution = [&](int j, float (&v)[NQ]) __attribute__((always_inline)) {
+    const OrdSlot s = ord_slot(P, g, __builtin_amdgcn_readfirstlane(j));
+    const float c = P.coef[(size_t)s.term * P.B + s.b] * (go0 * (P.wvec ? P.wvec[s.term] : 1.0f));
+    const float *tab_i = P.A.tab_i[s.term];
+    const size_t ou = (size_t)P.users[s.b] * D, op = (size_t)P.A.pos[s.term][s.b] * D, on = (size_t)P.A.neg[s.term][s.b] * D;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = lane + 64 * i;
+      v[i] = 0.f;
+      if (q < D) {
+        if (s.role == 0) {
+          const float p = tab_i[op + q], nn = tab_i[on + q];
+          v[i] = P.joined ? c * (p - nn) + r2 * P.tab_u[ou + q] : c * (p - nn);
+        } else {
+          const float u = P.tab_u[ou + q];
+          const float cu = (s.role & 1) ? c * u : -c * u;
+          v[i] = (P.joined && s.role <= 2) ? cu + r2 * tab_i[((s.role & 1) ? op : on) + q] : cu;
+        }
+      }
+    }
+  };
+  for (int base = me & ~63; base < n; base += 64) {
+    const int j = base + lane;
+    unsigned long long m = __ballot(j >= me && j < n && ord_keys[j] == key);
+    while (m) {                              // wave-uniform; up to four contributions' loads in flight, added in slot order
+      int t[4], cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        t[i] = 0;
+        if (m) {
+          t[i] = base + (int)__builtin_ctzll(m);
+          m &= m - 1;
+          cnt = i + 1;
+        }
+      }
+      float v[4][NQ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < cnt) contribution(t[i], v[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < cnt) {
+#pragma unroll
+          for (int x = 0; x < NQ; ++x) acc[x] += v[i][x];
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i)
+    if (lane + 64 * i < D) dst[lane + 64 * i] = acc[i];
+}
+
+// -> false: this shape stays with the atomic launch
+static bool launch_bpr_ordered(const OrdArgs &P, int groups, int max_slots, hipStream_t st) {
+  if (max_slots > kOrdMaxSlots || P.D > 256) return false;
+  const dim3 grid((unsigned)((max_slots + kOrdWaves - 1) / kOrdWaves), (unsigned)groups);
+  const size_t lds = (size_t)max_slots * sizeof(uint64_t);
+  const int nq = (P.D + 63) / 64;
+  if (nq <= 1) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bpr_bwd_ordered_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bpr_bwd_ordered_kernel<1>, grid, dim3(64 * kOrdWaves), lds, st, P);
+  } else if (nq == 2) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bpr_bwd_ordered_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bpr_bwd_ordered_kernel<2>, grid, dim3(64 * kOrdWaves), lds, st, P);
+  } else {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bpr_bwd_ordered_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(bpr_bwd_ordered_kernel<4>, grid, dim3(64 * kOrdWaves), lds, st, P);
+  }
+  return true;
+}
+
 // ---- sampler -------------------------------------------------------------------------------
 // Counter-based generator: splitmix64 finaliser over (seed, step, b, attempt).  Stateless, so a
 // draw does not depend on launch geometry or on how many draws other samples needed.
@@ -690,6 +850,27 @@ extern "C" int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i, const
   return check_launch("bpr_bwd_kernel");
 }
 
+extern "C" int chaorec_bpr_bwd_ordered_f32(const float *tab_u, const float *tab_i, const int64_t *users,
+                                           const int64_t *pos, const int64_t *neg, int32_t B, int32_t D,
+                                           const float *coef, float reg_weight, const float *grad_out,
+                                           float *g_u, float *g_i, void *stream) {
+  if (!tab_u || !tab_i || !users || !pos || !neg || !coef || !g_u || !g_i)
+    return fail(CHAOREC_E_INVALID, "bpr_bwd_ordered: NULL argument");
+  if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_bwd_ordered: B=%d D=%d", B, D);
+  OrdArgs P;
+  P.tab_u = tab_u, P.users = users, P.coef = coef, P.wvec = nullptr, P.grad_out = grad_out, P.g_u = g_u;
+  P.r2_unit = 2.0f * reg_weight / ((float)B * (float)D);
+  P.B = B, P.D = D, P.T = 1, P.joined = 1;
+  for (int k = 0; k < kBprMaxTerms; ++k) {
+    P.A.tab_i[k] = tab_i, P.A.pos[k] = pos, P.A.neg[k] = neg, P.A.g_i[k] = g_i;
+    P.A.scatter_rows[k] = nullptr, P.A.scatter_out[k] = nullptr;
+  }
+  P.A.T = 1;
+  if (!launch_bpr_ordered(P, 1, 3 * B, (hipStream_t)stream))     // (too many slots for the key table / D > 256: atomics)
+    return chaorec_bpr_bwd_f32(tab_u, tab_i, users, pos, neg, B, D, coef, reg_weight, grad_out, g_u, g_i, stream);
+  return check_launch("bpr_bwd_ordered_kernel");
+}
+
 static int fill_multi(BprMultiArgs &A, int32_t T, const float *const *tabs, const int64_t *const *pos,
                       const int64_t *const *neg, float *const *g_i, const char *who) {
   if (T < 1 || T > kBprMaxTerms) return fail(CHAOREC_E_INVALID, "%s: T=%d must be in [1, %d]", who, T, kBprMaxTerms);
@@ -746,6 +927,35 @@ extern "C" int chaorec_bpr_multi_bwd_f32(const float *tab_u, const int64_t *user
   hipLaunchKernelGGL(bpr_multi_bwd_kernel, dim3((T * B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u, users, A, B, D,
                      coef, wvec, grad_out, g_u);
   return check_launch("bpr_multi_bwd_kernel");
+}
+
+extern "C" int chaorec_bpr_multi_bwd_ordered_f32(const float *tab_u, const int64_t *users, int32_t T, const float *const *tabs,
+                                                 const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
+                                                 const float *coef, const float *wvec, const float *grad_out, float *g_u,
+                                                 float *const *g_i, const int64_t *const *scatter_rows,
+                                                 float *const *scatter_out, void *stream) {
+  if (!tab_u || !users || !wvec || !coef || !g_u || !g_i) return fail(CHAOREC_E_INVALID, "bpr_multi_bwd_ordered: NULL argument");
+  if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_multi_bwd_ordered: B=%d D=%d", B, D);
+  if ((scatter_rows == nullptr) != (scatter_out == nullptr))
+    return fail(CHAOREC_E_INVALID, "bpr_multi_bwd_ordered: scatter_rows and scatter_out come together");
+  OrdArgs P;
+  int rc = fill_multi(P.A, T, tabs, pos, neg, g_i, "bpr_multi_bwd_ordered");
+  if (rc) return rc;
+  if (scatter_rows) {
+    for (int k = 0; k < T; ++k) {
+      if ((scatter_rows[k] == nullptr) != (scatter_out[k] == nullptr))
+        return fail(CHAOREC_E_INVALID, "bpr_multi_bwd_ordered: term %d has one of scatter_rows / scatter_out", k);
+      P.A.scatter_rows[k] = scatter_rows[k], P.A.scatter_out[k] = scatter_out[k];
+    }
+  }
+  P.tab_u = tab_u, P.users = users, P.coef = coef, P.wvec = wvec, P.grad_out = grad_out, P.g_u = g_u;
+  P.r2_unit = 0.f;
+  P.B = B, P.D = D, P.T = T, P.joined = 0;
+  const int max_slots = (T > 2 ? T : 2) * B;
+  if (!launch_bpr_ordered(P, 1 + 2 * T, max_slots, (hipStream_t)stream))
+    return chaorec_bpr_multi_bwd_f32(tab_u, users, T, tabs, pos, neg, B, D, coef, wvec, grad_out, g_u, g_i, scatter_rows,
+                                     scatter_out, stream);
+  return check_launch("bpr_bwd_ordered_kernel");
 }
 
 extern "C" int chaorec_sample_negatives(const int64_t *hist_rowptr, const int32_t *hist_col,

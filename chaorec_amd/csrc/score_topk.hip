@@ -1203,7 +1203,10 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);
     const dim3 gs4((groups + 3) / 4, (unsigned)p.pf_sample_splits);
     const dim3 gw((unsigned)((groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves)), (unsigned)p.pf_splits);
-    const unsigned sel_all = (unsigned)n_users;
+    // (CHAOREC_SEL_GRID, latched at the first call: a fixed grid walking the users instead of one workgroup per user --
+    //  a launch-shape knob of tools/score_profile.py, no effect on results or on the workspace layout)
+    static const int sel_grid_env = env_int("CHAOREC_SEL_GRID", 0);
+    const unsigned sel_all = sel_grid_env > 0 ? (unsigned)std::min<int64_t>(n_users, sel_grid_env) : (unsigned)n_users;
     const unsigned sel_queue = (unsigned)std::min<int64_t>(n_users, 8192);    // a pass over a device-side queue
     // (coarse samples of very long item ranges put a large part of the users above the narrow selection's 512 candidates:
     //  the wide selection is then a main pass, not a tail -- 256 one-wave workgroups took 106 ms per 1.1 M users at 2 M items)
@@ -1315,8 +1318,13 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
       P.fb_skip = kPfFbGroupCap;
     }
     // ... and exact fp32 scores of all items for each remaining one, one block per (user, item slice)
-    if (D == 64) hipLaunchKernelGGL(score_exact_user_kernel<64>, dim3(512), dim3(ex_threads<64>()), 0, st, P);
-    else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(1024), dim3(ex_threads<128>()), 0, st, P);
+    // The queue is nearly always EMPTY (steady sports calls: no user at all) or a handful of users; the launch walks it
+    // with a grid stride, so the grid only bounds how many (user, slice) pairs run at once.  Short item ranges: 16 users
+    // x kExSlices -- 512 workgroups of 1024 threads (one per CU at a time: two dispatch rounds) cost 19 us on an empty
+    // queue, as much as ranking 3 users.  Long ranges keep the wide grid: their queue is what 512 grouped users left over.
+    const unsigned ex_grid = p.pf_group_fb ? (D == 64 ? 512u : 1024u) : 16u * kExSlices;
+    if (D == 64) hipLaunchKernelGGL(score_exact_user_kernel<64>, dim3(ex_grid), dim3(ex_threads<64>()), 0, st, P);
+    else hipLaunchKernelGGL(score_exact_user_kernel<128>, dim3(ex_grid), dim3(ex_threads<128>()), 0, st, P);
     return check_launch("score_exact_user_kernel");
   }
   if (!do_back) return CHAOREC_OK;   // (the other routes have no front phase: the back-phase call does everything)

@@ -387,6 +387,12 @@ def layer_mean_propagate(x0, csr, n_layers):
 # --------------------------------------------------------------------------------------------
 # BPR
 # --------------------------------------------------------------------------------------------
+# The BPR backward launches of the autograd nodes below: "ordered" (default) = one owner wave per gradient row, contributions
+# added in a fixed order, no atomics -- a training step is then reproducible bit for bit from run to run; CHAOREC_BPR_ORDERED=0
+# = fp32 atomic row adds (order-dependent from three addends per element on: tools/stream_stress.py).
+BPR_ORDERED = os.environ.get("CHAOREC_BPR_ORDERED", "1") == "1"
+
+
 class _BPR(torch.autograd.Function):
     """-> (total loss, tensor[total, bpr, reg]); tab_i=None means "items live in tab_u from row item_offset on"
     (LightGCN/MMGCN keep users and items in one [N,D] table: one gradient buffer, no slicing)."""
@@ -431,8 +437,10 @@ class _BPR(torch.autograd.Function):
             g_i = torch.zeros_like(tab_i)
             pi, pgi = _ptr(tab_i), _ptr(g_i)
         go = g_loss.contiguous()
-        rc = _lib.load().chaorec_bpr_bwd_f32(_ptr(tab_u), pi, _ptr(users), _ptr(pos), _ptr(neg), B, D,
-                                             _ptr(coef), ctx.reg_weight, _ptr(go), _ptr(g_u), pgi, _stream())
+        lib = _lib.load()
+        bwd = lib.chaorec_bpr_bwd_ordered_f32 if BPR_ORDERED else lib.chaorec_bpr_bwd_f32
+        rc = bwd(_ptr(tab_u), pi, _ptr(users), _ptr(pos), _ptr(neg), B, D, _ptr(coef), ctx.reg_weight, _ptr(go), _ptr(g_u), pgi,
+                 _stream())
         _lib.check(rc, "chaorec_bpr_bwd_f32")
         return g_u, g_i, None, None, None, None, None, None
 
@@ -516,8 +524,9 @@ class _BPRMulti(torch.autograd.Function):
                 for k in range(T):           # handed to the gathering node's backward (ops._LinearRows) through ITS token
                     if full[k] is not None and ctx.tokens[k] is not None:
                         ctx.tokens[k].put(full[k], gathered[k][0])
-            rc = lib.chaorec_bpr_multi_bwd_f32(_ptr(tab_u), _ptr(users), T, arr(tabs), arr(ids[0::2]), arr(ids[1::2]), B, D,
-                                               _ptr(coef), _ptr(wvec), _ptr(g), _ptr(g_u), arr(g_is), srows, souts, _stream())
+            multi_bwd = lib.chaorec_bpr_multi_bwd_ordered_f32 if BPR_ORDERED else lib.chaorec_bpr_multi_bwd_f32
+            rc = multi_bwd(_ptr(tab_u), _ptr(users), T, arr(tabs), arr(ids[0::2]), arr(ids[1::2]), B, D,
+                           _ptr(coef), _ptr(wvec), _ptr(g), _ptr(g_u), arr(g_is), srows, souts, _stream())
             _lib.check(rc, "chaorec_bpr_multi_bwd_f32")
             for g_i in g_is:
                 grads += [g_i, None, None]
@@ -525,9 +534,10 @@ class _BPRMulti(torch.autograd.Function):
         gvec = (g * wvec).contiguous()                   # d total / d loss_k, on the device
         for k in range(T):
             g_i = flat[offs[k + 1]:offs[k + 2]].view_as(tabs[k])
-            rc = lib.chaorec_bpr_bwd_f32(_ptr(tab_u), _ptr(tabs[k]), _ptr(users), _ptr(ids[2 * k]), _ptr(ids[2 * k + 1]), B,
-                                         D, ctypes.c_void_p(coef.data_ptr() + 4 * B * k), 0.0,
-                                         ctypes.c_void_p(gvec.data_ptr() + 4 * k), _ptr(g_u), _ptr(g_i), _stream())
+            bwd1 = lib.chaorec_bpr_bwd_ordered_f32 if BPR_ORDERED else lib.chaorec_bpr_bwd_f32
+            rc = bwd1(_ptr(tab_u), _ptr(tabs[k]), _ptr(users), _ptr(ids[2 * k]), _ptr(ids[2 * k + 1]), B,
+                      D, ctypes.c_void_p(coef.data_ptr() + 4 * B * k), 0.0,
+                      ctypes.c_void_p(gvec.data_ptr() + 4 * k), _ptr(g_u), _ptr(g_i), _stream())
             _lib.check(rc, "chaorec_bpr_bwd_f32")
             grads += [g_i, None, None]
         return (g_u, None, None, None, None, None, *grads)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 14  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 15  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -49,7 +49,8 @@ extern "C" {
                                       zero_rows_by_bits, rows_copy_by_bits, or_words, peer-to-peer exchange of flagged rows, frontier pack / unpack;
                                   13: scoring: CHAOREC_SCORE_FRONT / _BACK (one call as two phases), a raised-threshold pass for
                                       users whose candidate lists overflow (long item ranges), chaorec_score_topk_stats out10;
-                                  14: chaorec_edge_dot_f32 (edge scores over a CSR's entries) */
+                                  14: chaorec_edge_dot_f32 (edge scores over a CSR's entries);
+                                  15: ordered (atomic-free, run-to-run reproducible) BPR backward launches */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -241,6 +242,16 @@ int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i,
                         const int64_t *users, const int64_t *pos, const int64_t *neg,
                         int32_t B, int32_t D, const float *coef, float reg_weight,
                         const float *grad_out, float *g_u, float *g_i, void *stream);
+/* The same row sums WITHOUT atomics, reproducible run to run: every destination row has one owner wave that adds the row's
+ * contributions in ascending (role, sample) order -- the order torch's CPU backward of `emb[users]`, `emb[pos]`, `emb[neg]`
+ * (Model/LightGCN.py:113-121, Model/MMGCN.py:193-197) visits them role by role.  fp32 atomic adds are applied in an order that
+ * moves with the load on the chip; three addends in one element then differ in the last bit between runs, and Adam's first
+ * steps turn that into a visible parameter difference.  Same arguments; g_u / g_i may alias (one joined table).  Falls back
+ * to the atomic launch beyond 16384 slots (3 B) or D > 256. */
+int chaorec_bpr_bwd_ordered_f32(const float *tab_u, const float *tab_i,
+                                const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                int32_t B, int32_t D, const float *coef, float reg_weight,
+                                const float *grad_out, float *g_u, float *g_i, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * S: uniform negative sampler with history rejection.
@@ -787,6 +798,13 @@ int chaorec_bpr_multi_bwd_f32(const float *tab_u, const int64_t *users, int32_t 
                               const float *coef, const float *wvec, const float *grad_out, float *g_u,
                               float *const *g_i, const int64_t *const *scatter_rows, float *const *scatter_out,
                               void *stream);
+/* ... and its ordered, atomic-free form (see chaorec_bpr_bwd_ordered_f32): g_u, every g_i[k] and every scatter_out[k] must be
+ * DISTINCT buffers (each is one group of rows with one owner wave per row). */
+int chaorec_bpr_multi_bwd_ordered_f32(const float *tab_u, const int64_t *users, int32_t T, const float *const *tabs,
+                                      const int64_t *const *pos, const int64_t *const *neg, int32_t B, int32_t D,
+                                      const float *coef, const float *wvec, const float *grad_out, float *g_u,
+                                      float *const *g_i, const int64_t *const *scatter_rows, float *const *scatter_out,
+                                      void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Edge scores over the stored entries of a CSR: out[k] = <a[entry_row[k]], b[col[k]]>, k in [0, nnz).

@@ -136,6 +136,39 @@ void oracle_bpr_bwd_f32(const float *tab_u, const float *tab_i, const int64_t *u
   }
 }
 
+/* The same index_add in FLOAT and in a stated order -- role by role (the rows `emb[users]`, then `emb[pos]`, then `emb[neg]`
+ * of Model/LightGCN.py:113-121 / Model/MMGCN.py:193-197), batch order inside a role, every addend rounded to float and added to
+ * the float row: what torch's CPU autograd does with three index_select backwards, and what the product's ORDERED backward
+ * launch (chaorec_bpr_bwd_ordered_f32) reproduces bit for bit (the expressions are the kernel's: c = coef * grad_out,
+ * r2 = (2 reg / (B D)) * grad_out, no fused multiply-add: -ffp-contract=off on both sides).  g_u / g_i may alias. */
+void oracle_bpr_bwd_ordered_f32(const float *tab_u, const float *tab_i, const int64_t *users,
+                                const int64_t *pos, const int64_t *neg, int32_t B, int32_t D,
+                                const float *coef, float reg_weight, float grad_out, float *g_u, float *g_i) {
+  const float r2_unit = 2.0f * reg_weight / ((float)B * (float)D);
+  const float r2 = r2_unit * grad_out;
+  for (int role = 0; role < 3; ++role) {
+    for (int32_t b = 0; b < B; ++b) {
+      const size_t ou = (size_t)users[b] * D, op = (size_t)pos[b] * D, on = (size_t)neg[b] * D;
+      const float c = coef[b] * (grad_out * 1.0f);
+      for (int32_t k = 0; k < D; ++k) {
+        const float u = tab_u[ou + k], p = tab_i[op + k], n = tab_i[on + k];
+        if (role == 0) {
+          const float v = c * (p - n) + r2 * u;
+          g_u[ou + k] += v;
+        } else if (role == 1) {
+          const float cu = c * u;
+          const float v = cu + r2 * p;
+          g_i[op + k] += v;
+        } else {
+          const float cu = -c * u;
+          const float v = cu + r2 * n;
+          g_i[on + k] += v;
+        }
+      }
+    }
+  }
+}
+
 /* ---- S sampler -------------------------------------------------------------------------
  * dataload.py:74-79: draw uniformly from all items until the draw is not in the user's
  * history.  The generator is this build's counter-based one (the reference's is Python's

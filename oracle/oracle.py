@@ -177,6 +177,29 @@ def bpr_bwd(tab_u, tab_i, users, pos, neg, coef, reg_weight, grad_out=1.0):
     return g_u, g_i
 
 
+def bpr_bwd_ordered(tab_u, tab_i, users, pos, neg, coef, reg_weight, grad_out=1.0, item_offset=None):
+    """The float, role-major, batch-ordered index_add (oracle_bpr_bwd_ordered_f32): bit-exact twin of the product's ordered
+    backward launch.  item_offset (tab_i None): items are rows item_offset.. of the ONE table tab_u -> one gradient array."""
+    tab_u = _c(tab_u, np.float32)
+    users, pos, neg = _c(users, np.int64), _c(pos, np.int64), _c(neg, np.int64)
+    B, D = len(users), tab_u.shape[1]
+    coef = _c(coef, np.float32)
+    g_u = np.zeros(tab_u.shape, np.float32)
+    if tab_i is None:
+        off = int(item_offset) * D * 4
+        ti = ctypes.cast(ctypes.c_void_p(tab_u.ctypes.data + off), _f32p)
+        gi = ctypes.cast(ctypes.c_void_p(g_u.ctypes.data + off), _f32p)
+        g_i = None
+    else:
+        tab_i = _c(tab_i, np.float32)
+        g_i = np.zeros(tab_i.shape, np.float32)
+        ti, gi = _p(tab_i, _f32p), _p(g_i, _f32p)
+    lib().oracle_bpr_bwd_ordered_f32(_p(tab_u, _f32p), ti, _p(users, _i64p), _p(pos, _i64p), _p(neg, _i64p), ctypes.c_int32(B),
+                                     ctypes.c_int32(D), _p(coef, _f32p), ctypes.c_float(reg_weight), ctypes.c_float(grad_out),
+                                     _p(g_u, _f32p), gi)
+    return g_u, g_i
+
+
 SECOND_DRAW_SALT = 0x9E3779B97F4A7C15      # the stream of the sample's second draw (dataload.py:81-84), chaorec_hip.h
 
 

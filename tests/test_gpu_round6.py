@@ -1,0 +1,154 @@
+"""Round 6 (GPU): the ORDERED BPR backward -- atomic-free, bit-exact against the oracle's float index_add, reproducible run to
+run -- and what it makes checkable: a training step that is the same bits every time, on one stream or two."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from chaorec_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("D,B", [(64, 300), (128, 257), (16, 64), (256, 100), (64, 4096)])
+@pytest.mark.parametrize("variant", [0, 2])
+def test_bpr_ordered_backward_is_the_oracles_float_index_add_bit_for_bit(dev, oracle, D, B, variant):
+    """chaorec_bpr_bwd_ordered_f32 against oracle_bpr_bwd_ordered_f32 (role-major, batch order, every addend rounded to float --
+    torch's CPU backward of emb[users] / emb[pos] / emb[neg], Model/LightGCN.py:113-121): the same bits, with heavy
+    duplication inside the batch (dozens of addends per row), a non-unit grad_out and the L2 term; five repetitions give the
+    same bits again (the atomic launch does not promise that)."""
+    from chaorec_amd import ops
+    assert ops.BPR_ORDERED
+    rng = np.random.default_rng(D + B + variant)
+    U, I = 37, 23
+    tu = (rng.standard_normal((U, D)) * 0.3).astype(np.float32)
+    ti = (rng.standard_normal((I, D)) * 0.3).astype(np.float32)
+    users, pos, neg = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+    reg = 1e-3 if variant == 0 else 0.0
+    ids = [torch.from_numpy(t).to(dev) for t in (users, pos, neg)]
+    first = None
+    for rep in range(5):
+        a = torch.from_numpy(tu).to(dev).requires_grad_(True)
+        b = torch.from_numpy(ti).to(dev).requires_grad_(True)
+        res = ops.bpr_loss(a, b, *ids, variant, reg)
+        (res[0] * 0.7).backward()
+        got = (a.grad.cpu().numpy(), b.grad.cpu().numpy())
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1]), rep
+    # the coefficients the forward launch leaves (float, on the device) feed the oracle's backward: the backward alone is compared
+    a = torch.from_numpy(tu).to(dev).requires_grad_(True)
+    b = torch.from_numpy(ti).to(dev).requires_grad_(True)
+    res = ops.bpr_loss(a, b, *ids, variant, reg)
+    coef = res.loss.grad_fn.saved_tensors[5].cpu().numpy()
+    g_u, g_i = oracle.bpr_bwd_ordered(tu, ti, users, pos, neg, coef, reg, grad_out=np.float32(0.7))
+    assert np.array_equal(first[0], g_u)
+    assert np.array_equal(first[1], g_i)
+    # ... and the double-precision oracle within the tolerance the atomic launch is held to
+    out, coef64 = oracle.bpr_fwd(tu, ti, users, pos, neg, variant, reg)
+    g_u64, g_i64 = oracle.bpr_bwd(tu, ti, users, pos, neg, coef64, reg, grad_out=0.7)
+    assert np.allclose(first[0], g_u64, rtol=2e-5, atol=1e-7) and np.allclose(first[1], g_i64, rtol=2e-5, atol=1e-7)
+
+
+def test_bpr_ordered_backward_on_one_joined_table(dev, oracle):
+    """tab_i = None (LightGCN / MMGCN: users and items are rows of ONE table, one gradient buffer): the user and item slots
+    are one group of 3 B slots in the ordered launch."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(5)
+    U, I, D, B = 31, 29, 64, 500
+    tab = (rng.standard_normal((U + I, D)) * 0.3).astype(np.float32)
+    users, pos, neg = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+    t = torch.from_numpy(tab).to(dev).requires_grad_(True)
+    res = ops.bpr_loss(t, None, *(torch.from_numpy(x).to(dev) for x in (users, pos, neg)), 0, 1e-3, item_offset=U)
+    coef = res.loss.grad_fn.saved_tensors[5].cpu().numpy()
+    res[0].backward()
+    g, _ = oracle.bpr_bwd_ordered(tab, None, users, pos, neg, coef, 1e-3, item_offset=U)
+    assert np.array_equal(t.grad.cpu().numpy(), g)
+
+
+def test_bpr_multi_ordered_backward_equals_the_atomic_sums_and_repeats(dev, monkeypatch):
+    """chaorec_bpr_multi_bwd_ordered_f32 (FREEDOM's three terms, two of them over gathered row blocks whose gradient is also
+    scattered into the full table's row gradient): the atomic launch's sums up to the order of the additions, the same bits on
+    every repetition."""
+    from chaorec_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    U, I, D, B = 60, 40, 64, 700
+    tab_u = torch.randn(U, D, device=dev, generator=g) * 0.2
+    users = torch.randint(0, U, (B,), device=dev, generator=g)
+    wvec = torch.tensor([1.0, 1e-3, 1e-3], device=dev)
+
+    def run(ordered):
+        monkeypatch.setattr(ops, "BPR_ORDERED", ordered)
+        tu = tab_u.clone().requires_grad_(True)
+        gg = torch.Generator(device=dev)
+        gg.manual_seed(12)
+        terms, leaves = [], []
+        for rows in (I, 2 * B, 2 * B):
+            t = (torch.randn(rows, D, device=dev, generator=gg) * 0.1).requires_grad_(True)
+            leaves.append(t)
+            terms.append((t, torch.randint(0, rows, (B,), device=dev, generator=gg), torch.randint(0, rows, (B,), device=dev, generator=gg)))
+        loss = ops.bpr_loss_multi(tu, users, ops.VARIANT_LOGSIGMOID, terms, wvec)
+        (loss * 1.5).backward()
+        return [tu.grad.clone()] + [t.grad.clone() for t in leaves]
+
+    ref = run(False)
+    first = run(True)
+    for a, b in zip(first, ref):
+        assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(b.abs().max()) + 1e-12)
+    for _ in range(4):
+        again = run(True)
+        assert all(torch.equal(a, b) for a, b in zip(again, first))
+
+
+def _mmgcn_six_steps(dev, streams, sharded=False):
+    from chaorec_amd import graph, ops
+    from chaorec_amd.Model import MMGCN
+    import importlib
+    mm = importlib.import_module("chaorec_amd.Model.MMGCN")
+    from chaorec_amd.optim import FusedAdam, GraphedTrainStep
+    from chaorec_amd.synthetic import synthetic_interactions
+    U, I, E, B = 6000, 2500, 40000, 512
+    edges = synthetic_interactions(U, I, E, seed=3)
+    uid = graph.user_item_dict_from_edges(edges)
+    g = torch.Generator().manual_seed(4)
+    v_feat, t_feat = torch.randn(I, 128, generator=g), torch.randn(I, 256, generator=g)
+    old = mm.BRANCH_STREAMS
+    mm.BRANCH_STREAMS = streams
+    try:
+        torch.manual_seed(21)
+        m = MMGCN(U, I, edges, uid, v_feat, t_feat, 64, 1e-4, "add", "False", True, dev).to(dev)
+        opt = FusedAdam(m.parameters(), lr=1e-3)
+        edges_dev = torch.from_numpy(np.stack([edges[:, 0], edges[:, 1]], 1).astype(np.int64)).to(dev)
+        counter = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def draw():
+            counter.add_(1)
+            u, pos, neg = ops.draw_batch(edges_dev, m.hist, B, U, I, 42, 0, step_dev=counter, item_offset=U)
+            return torch.stack((u, u), 1), torch.stack((pos, neg), 1)
+
+        step = GraphedTrainStep(m, opt, batch_fn=draw)
+        for _ in range(6):
+            step()
+        torch.cuda.synchronize()
+        return {n: p.detach().clone() for n, p in m.named_parameters()}
+    finally:
+        mm.BRANCH_STREAMS = old
+
+
+def test_mmgcn_steps_are_the_same_bits_every_run_on_one_stream_and_on_two(dev):
+    """VERDICT r5 #3.  Six captured MMGCN training steps, repeated: EVERY parameter the same bits -- run against run on one
+    stream (the round-5 code was not: the fp32 atomic adds of the BPR backward are applied in an order that moves with the load
+    on the chip, tools/stream_stress.py) and the two-stream step (visual branch on a side stream) against the one-stream step."""
+    ref = _mmgcn_six_steps(dev, False)
+    for rep in range(3):
+        for streams in (False, True):
+            got = _mmgcn_six_steps(dev, streams)
+            for n in ref:
+                assert torch.equal(got[n], ref[n]), (rep, streams, n, float((got[n] - ref[n]).abs().max()))
