@@ -72,6 +72,7 @@ SIGNATURES = {
                                                 c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr,
                                                 c_ptr]),
     "chaorec_spmm_rows_per_wave": (ctypes.c_int, [ctypes.c_int32]),
+    "chaorec_spmm_long_threshold": (ctypes.c_int, []),
     "chaorec_spmm_schedule_len": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int32]),
     "chaorec_spmm_build_schedule": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int64, ctypes.c_int32, c_ptr,
                                                    ctypes.c_int64]),

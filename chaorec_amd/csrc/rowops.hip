@@ -561,6 +561,8 @@ extern "C" int chaorec_edge_dot_f32(const int32_t *entry_row, const int32_t *col
                                     int64_t nnz, int32_t D, void *stream) {
   if (!entry_row || !col || !a || !b || !out) return fail(CHAOREC_E_INVALID, "edge_dot: null pointer");
   if (nnz < 0 || D < 4 || (D & 3)) return fail(CHAOREC_E_INVALID, "edge_dot: nnz=%lld D=%d (a multiple of 4)", (long long)nnz, D);
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15)
+    return fail(CHAOREC_E_INVALID, "edge_dot: a and b must be 16-byte aligned (rows are read as float4)");
   if (nnz == 0) return CHAOREC_OK;
   const int d4 = D / 4;
   int lpe = 1;

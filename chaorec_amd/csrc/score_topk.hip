@@ -18,6 +18,8 @@
 // index), which also yields the new threshold.  Ties: the key orders equal scores by ascending item index.
 #include "common.h"
 #include <limits.h>
+#include <mutex>
+#include <unordered_map>
 
 namespace chaorec {
 
@@ -881,7 +883,26 @@ static int env_int(const char *name, int dflt) {
   return e && *e ? std::atoi(e) : dflt;
 }
 
-static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
+// The layout a workspace was FILLED with.  use_sorted_table() reads the environment per call, and a workspace's offsets
+// (perm, inv, tile_bound, the scalars ...) depend on its answer: a BACK-phase call or a statistics query that re-planned
+// under another environment than the FRONT / whole call that filled the workspace would read stale bytes as counters and
+// lists.  So the filling call records its decision per workspace address (host side, bounded), and the calls
+// that only READ a workspace take it from there.
+static std::mutex g_layout_mu;
+static std::unordered_map<const void *, int> g_layout_cls;
+static void remember_layout(const void *ws, bool cls) {
+  std::lock_guard<std::mutex> lk(g_layout_mu);
+  if (g_layout_cls.size() > 4096) g_layout_cls.clear();
+  g_layout_cls[ws] = cls ? 1 : 0;
+}
+static int recall_layout(const void *ws) {       // -1: unknown workspace
+  std::lock_guard<std::mutex> lk(g_layout_mu);
+  auto it = g_layout_cls.find(ws);
+  return it == g_layout_cls.end() ? -1 : it->second;
+}
+
+// force_cls: -1 = decide (use_sorted_table), 0 / 1 = the layout a workspace already holds
+static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D, int force_cls = -1) {
   ScorePlan p;
   const int64_t n_tiles = (n_items + 31) / 32;
   const int64_t groups = (n_users + 31) / 32;
@@ -924,7 +945,7 @@ static ScorePlan plan_score(int64_t n_users, int64_t n_items, int K, int D) {
   // a sampler wave's share of the sample fits its 24-slot lists up to ~16 k items; longer ranges take the
   // streaming-top-r instantiation (32 slots, fewer and longer waves)
   p.pf_sample_long = n_tiles > 512;
-  p.pf_cls = p.prefilter && p.pf_sample_long && use_sorted_table(n_users, n_items, D);
+  p.pf_cls = p.prefilter && p.pf_sample_long && (force_cls >= 0 ? force_cls != 0 : use_sorted_table(n_users, n_items, D));
   // The sorted layout's sampler takes every stride-th ITEM of the sorted order, strata dealt evenly to its waves: a
   // systematic sample, stratified by norm -- half the sample gives the spread a sample of whole tiles had (config-5 shard,
   // propagated tables: every 32nd item at rank 4 = 0 of 1.25 M users with fewer than K candidates, 782 through pass C, call
@@ -1044,7 +1065,7 @@ extern "C" int chaorec_score_topk_stats(const void *workspace, int64_t n_users, 
   uint64_t *out9 = out10;
   if (!workspace || !out9) return fail(CHAOREC_E_INVALID, "score_topk_stats: NULL argument");
   if (n_users <= 0 || n_items <= 0 || K <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "score_topk_stats: bad sizes");
-  const ScorePlan p = plan_score(n_users, n_items, K, D);
+  const ScorePlan p = plan_score(n_users, n_items, K, D, recall_layout(workspace));   // (the layout the last call left there)
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(out9, 0, 10 * sizeof(uint64_t), st) != hipSuccess) return fail(CHAOREC_E_LAUNCH, "stats: memset");
   if (!p.prefilter) return CHAOREC_OK;   // all zeros: the call did not take the prefilter route
@@ -1073,7 +1094,10 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
   if (!((D == 8 || D == 16 || D == 32 || D == 64 || D == 128) || (D > 128 && D % 64 == 0)))
     return fail(CHAOREC_E_INVALID, "score_topk: D=%d not in {8,16,32,64,128} and not a multiple of 64 above 128", D);
   if (n_users == 0) return CHAOREC_OK;
-  ScorePlan p = plan_score(n_users, n_items, K, D);
+  // a BACK-only call continues what a FRONT call began in this workspace: same layout, whatever the environment says now
+  const bool back_only = (flags & CHAOREC_SCORE_BACK) && !(flags & CHAOREC_SCORE_FRONT);
+  ScorePlan p = plan_score(n_users, n_items, K, D, back_only ? recall_layout(workspace) : -1);
+  if (!back_only && workspace) remember_layout(workspace, p.pf_cls);
   if (precision == 1) p.sample = false;  // precision 1: single exact pass, no sampled threshold (A/B + tests)
   if (precision != 0) p.prefilter = false;  // precision 2: fp32 sweep with sampled thresholds (the pre-bf16 path)
   if (p.total > workspace_bytes || (p.total && !workspace))
@@ -1203,10 +1227,7 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     const dim3 gs(groups, (unsigned)p.pf_sample_splits);
     const dim3 gs4((groups + 3) / 4, (unsigned)p.pf_sample_splits);
     const dim3 gw((unsigned)((groups + p.pf_ub * kSweepWaves - 1) / (p.pf_ub * kSweepWaves)), (unsigned)p.pf_splits);
-    // (CHAOREC_SEL_GRID, latched at the first call: a fixed grid walking the users instead of one workgroup per user --
-    //  a launch-shape knob of tools/score_profile.py, no effect on results or on the workspace layout)
-    static const int sel_grid_env = env_int("CHAOREC_SEL_GRID", 0);
-    const unsigned sel_all = sel_grid_env > 0 ? (unsigned)std::min<int64_t>(n_users, sel_grid_env) : (unsigned)n_users;
+    const unsigned sel_all = (unsigned)n_users;    // (a fixed grid walking the users is slower: 4 096 workgroups +10 %, 16 384 the same)
     const unsigned sel_queue = (unsigned)std::min<int64_t>(n_users, 8192);    // a pass over a device-side queue
     // (coarse samples of very long item ranges put a large part of the users above the narrow selection's 512 candidates:
     //  the wide selection is then a main pass, not a tail -- 256 one-wave workgroups took 106 ms per 1.1 M users at 2 M items)

@@ -1346,6 +1346,8 @@ extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t
 }
 
 extern "C" int chaorec_spmm_rows_per_wave(int32_t D) { return rows_per_wave(D); }
+// rows with more entries than this are walked cooperatively by their workgroup (the schedule builders group by it)
+extern "C" int chaorec_spmm_long_threshold(void) { return CHAOREC_SPMM_LONG_T; }
 
 // ---- host-side schedule builder (no GPU work) --------------------------------------------------
 // Wave slot s (4 per workgroup) handles the G = rows_per_wave(D) consecutive rows of one group.  Groups are

@@ -209,12 +209,12 @@ def allreduce_grads(params, group=None):
 # core" under capture; tools/rccl_streams_repro.py (profiles/r04_f_rccl_streams_repro.txt) narrowed it down: `async_op=True`
 # collectives from a second capturing stream segfault, and so does every collective hopped onto a third "communication"
 # stream; the synchronous form issued by the branch's own stream captures and replays fine.
-# Round 5: OPT-IN again (CHAOREC_DIST_MMGCN_STREAMS=1).  Its equality test against the one-stream step -- green in 22 isolated
-# runs of the worker -- diverged twice in about a dozen runs INSIDE the test suite (another process keeping the GPU busy), each
-# time with the visual branch's weights off by 2e-4 after six steps (profiles/r05_flake_sharded_mmgcn_two_streams.log): a
-# timing-dependent ordering hole between the side stream and RCCL that one communicator per branch did not close.  Until it is
-# found a sharded run takes the 10 % slower one-stream step (4.63 against 4.19 ms at microlens) rather than a rare wrong one.
-SHARDED_MMGCN_STREAMS_DEFAULT = "0"
+# Round 5 made it opt-in because its equality test against the one-stream step diverged once in ~10 runs inside the suite (the
+# visual branch's weights 2e-4 off after six steps).  Round 6 found the cause, and it was not the streams: the BPR backward's
+# fp32 atomic adds are applied in an order that moves with the load on the chip, the ONE-stream step was as irreproducible
+# (tools/stream_stress.py, profiles/r06_stream_bisect.txt: 50 of 50 runs inexact with atomics, 0 of 400 with the ordered
+# backward launch, one stream or two).  Default on again: 4.19 against 4.63 ms per step at microlens.
+SHARDED_MMGCN_STREAMS_DEFAULT = "1"
 
 
 class ShardedMMGCN(nn.Module):

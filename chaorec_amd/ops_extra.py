@@ -211,8 +211,15 @@ def edge_dot_raw(entry_row, col, a, b, n_entries=None):
     """out[k] = <a[entry_row[k]], b[col[k]]> for the first n_entries stored entries (all of them by default): one pass that
     reads two rows per entry (chaorec_edge_dot_f32) instead of two [nnz, D] gathers, their product and its row sum."""
     _need_cuda(a, b, entry_row, col)
+    for name, t in (("entry_row", entry_row), ("col", col)):      # (the kernel reads 4-byte indices: an int64 tensor would be
+        if t.dtype != torch.int32 or not t.is_contiguous():       #  read as pairs of int32 -- garbage rows, out-of-bounds gathers)
+            raise TypeError(f"edge_dot: {name} must be a contiguous int32 tensor, got {t.dtype}, contiguous={t.is_contiguous()}")
     a, b = _f32c(a), _f32c(b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError(f"edge_dot: a {tuple(a.shape)} and b {tuple(b.shape)} must be 2-D with the same width")
     n = int(col.numel()) if n_entries is None else int(n_entries)
+    if n < 0 or n > int(col.numel()) or n > int(entry_row.numel()):
+        raise ValueError(f"edge_dot: n_entries={n} beyond the {int(col.numel())} stored entries / {int(entry_row.numel())} entry rows")
     out = torch.empty(n, dtype=torch.float32, device=a.device)
     rc = _lib.load().chaorec_edge_dot_f32(_ptr(entry_row), _ptr(col), _ptr(a), _ptr(b), _ptr(out), n, a.shape[1], _stream())
     _lib.check(rc, "chaorec_edge_dot_f32")

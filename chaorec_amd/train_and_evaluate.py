@@ -198,6 +198,11 @@ def train_and_evaluate(model, train_loader, val_data, test_data, optimizer, epoc
         logging.info("Epoch {}, Loss: {:.5f}".format(epoch + 1, loss))
 
         model.eval()
+        if hasattr(optimizer, "flush"):
+            # lazily updated feature rows (optim.FusedAdam lazy_rows) are brought up to the current step at every epoch's end:
+            # whoever reads a claimed table between epochs -- model.state_dict(), a checkpoint, a per-epoch kNN rebuild -- sees
+            # current rows (one launch per claimed table; the rows' values are the eager ones bit for bit either way)
+            optimizer.flush()
         rank_list = model.gene_ranklist(to_cpu=False) if on_device else model.gene_ranklist()
         val_metrics = evaluate(model, val_data, rank_list, topk)
         test_metrics = evaluate(model, test_data, rank_list, topk)

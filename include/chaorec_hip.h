@@ -199,6 +199,9 @@ int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, cons
 
 /* destination rows handled by one wave64 for feature width D (host helper, launches nothing) */
 int chaorec_spmm_rows_per_wave(int32_t D);
+/* rows with more entries than this are walked cooperatively by their workgroup; a schedule built outside the library
+ * (chaorec_amd/graph.py: schedule_tensors, the same words from tensor operations on the device) groups rows by it */
+int chaorec_spmm_long_threshold(void);
 
 /* Host-side schedule builder for chaorec_spmm_csr_f32 (HOST pointers, no GPU work): int32 elements needed,
  * and the build itself.  Graph-static: build once per (graph, D), keep the copy in HBM next to the CSR. */

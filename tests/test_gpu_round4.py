@@ -78,10 +78,20 @@ def test_early_adam_with_a_dense_reader_equals_the_in_step_update(dev):
 def _run_bench(extra, env_extra, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(env_extra)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True,
-                       timeout=timeout)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        env["CHAOREC_BENCH_DETAIL"] = os.path.join(tmp, "detail.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                           timeout=timeout)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        detail = json.load(open(env["CHAOREC_BENCH_DETAIL"]))
+    # the LAST stdout line is the compact record (benchlib/record.py: <= 4 KB, a projection of the detail); the tests below read
+    # the detail, which holds everything measured
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert len(last.encode()) <= 4096 and line["metric"] == detail["metric"] and "roofline" in line and "cpu_baseline" in line
+    assert abs(line["value"] - detail["value"]) <= 1e-5 * abs(detail["value"]) and "[bench detail]" not in r.stdout
+    return detail
 
 
 def test_bench_self_launches_two_ranks_on_this_gpu(dev):
@@ -112,7 +122,7 @@ def _sharded_mmgcn_streams_worker(rank, world, port, tmp, streams):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CHAOREC_FORCE_COLLECTIVES"] = "1"          # a 1-rank group still issues every exchange through RCCL
-    os.environ["CHAOREC_DIST_MMGCN_STREAMS"] = "1" if streams else "0"          # (opt-in: see dist.SHARDED_MMGCN_STREAMS_DEFAULT)
+    os.environ["CHAOREC_DIST_MMGCN_STREAMS"] = "1" if streams else "0"
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     dev = torch.device("cuda:0")

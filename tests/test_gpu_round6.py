@@ -152,3 +152,54 @@ def test_mmgcn_steps_are_the_same_bits_every_run_on_one_stream_and_on_two(dev):
             got = _mmgcn_six_steps(dev, streams)
             for n in ref:
                 assert torch.equal(got[n], ref[n]), (rep, streams, n, float((got[n] - ref[n]).abs().max()))
+
+
+@pytest.mark.parametrize("n_rows", [100_003, 262_147, 1_048_575 + 33])
+def test_frontier_pack_prefix_over_several_blocks_of_words(dev, n_rows):
+    """the multi-workgroup form of the frontier prefix (csrc/exchange.hip bits_prefix_kernel: a workgroup scans 1 024
+    bitmap words, later workgroups first sum the words before theirs) on bitmaps that straddle several blocks, with
+    n_rows % 32 != 0 and stray bits past the end: prefix[] against numpy's popcount / cumsum, the packed rows in bitmap order,
+    the inverse copy."""
+    from chaorec_amd import ops
+    rng = np.random.default_rng(n_rows)
+    D = 8
+    n_words = (n_rows + 31) // 32
+    rows = np.unique(rng.integers(0, n_rows, n_rows // 7))
+    # dense stretches and empty stretches, so that whole 1 024-word blocks are all-ones / all-zeros
+    rows = np.unique(np.concatenate([rows, np.arange(40_000, 40_000 + 70_000) % n_rows]))
+    rows = rows[(rows < 5_000) | (rows > 38_000)]
+    words = np.zeros(n_words + 1, dtype=np.uint32)
+    np.bitwise_or.at(words, rows >> 5, np.uint32(1) << (rows & 31).astype(np.uint32))
+    stray = words.copy()
+    if n_rows % 32:
+        stray[n_words - 1] |= np.uint32(0xFFFFFFFF) << np.uint32(n_rows % 32)          # every bit past the last row
+    bits = torch.from_numpy(stray.view(np.int32)).to(dev)
+    tab = torch.randn(n_rows, D, device=dev)
+    compact = torch.full((len(rows) + 5, D), float("nan"), device=dev)
+    prefix = torch.zeros(n_words + 1, dtype=torch.int32, device=dev)
+    ops.frontier_pack(tab, bits, prefix, compact)
+    pop = np.array([bin(int(w)).count("1") for w in words[:n_words]], dtype=np.int64)
+    want_prefix = np.concatenate([[0], np.cumsum(pop)])
+    assert np.array_equal(prefix.cpu().numpy().astype(np.int64), want_prefix)
+    r = torch.from_numpy(rows).to(dev)
+    assert torch.equal(compact[:len(rows)], tab[r]) and float(compact[len(rows):].abs().max()) == 0.0
+    back = torch.zeros(n_rows, D, device=dev)
+    ops.frontier_unpack(back, bits, prefix, compact)
+    assert torch.equal(back[r], tab[r]) and float(back.abs().sum() - tab[r].abs().sum()) == 0.0
+
+
+def test_edge_dot_refuses_wrong_index_types(dev):
+    """chaorec_edge_dot_f32 reads 4-byte indices -- an int64 tensor must be an error, not pairs of int32."""
+    from chaorec_amd import ops
+    a, b = torch.randn(10, 8, device=dev), torch.randn(12, 8, device=dev)
+    er, col = torch.tensor([0, 3, 9], dtype=torch.int32, device=dev), torch.tensor([1, 2, 11], dtype=torch.int32, device=dev)
+    got = ops.edge_dot_raw(er, col, a, b)
+    assert torch.allclose(got, (a[er.long()] * b[col.long()]).sum(1), rtol=1e-6, atol=1e-6)
+    with pytest.raises(TypeError, match="int32"):
+        ops.edge_dot_raw(er.long(), col, a, b)
+    with pytest.raises(TypeError, match="int32"):
+        ops.edge_dot_raw(er, col.long(), a, b)
+    with pytest.raises(ValueError, match="n_entries"):
+        ops.edge_dot_raw(er, col, a, b, n_entries=4)
+    with pytest.raises(ValueError, match="same width"):
+        ops.edge_dot_raw(er, col, a, torch.randn(12, 4, device=dev))

@@ -823,3 +823,30 @@ def test_bench_record_through_the_launcher_over_gloo(tmp_path):
     assert line["metric"] == want["metric"] and line["n_gpus"] == want["n_gpus"] and "roofline" in line and "cpu_baseline" in line
     assert json.load(open(detail_path))["config"] == want["config"]
     assert "[bench detail]" in r.stderr and "[bench detail]" not in r.stdout
+
+
+@pytest.mark.parametrize("n_rows,D,skew", [(1, 64, 0), (17, 128, 3), (1000, 64, 50), (4099, 128, 50), (4099, 32, 3), (700, 256, 0),
+                                           (200, 64, 1)])
+def test_schedule_tensors_builds_the_host_builders_words(n_rows, D, skew):
+    """graph.schedule_tensors (the SpMM row descriptors from tensor operations on the device the CSR lives on,
+    instead of a host walk over a host copy of it) against chaorec_spmm_build_schedule: the same int32 words -- degree-sorted
+    groups, long rows leading groups / workgroups of their own with the lightest company, inline (col, val) pairs, flags."""
+    import ctypes
+    from chaorec_amd import _lib, graph
+    lib = _lib.load()
+    rng = np.random.default_rng(n_rows * 7 + D + skew)
+    deg = rng.integers(0, 12, n_rows)
+    if skew:
+        idx = rng.choice(n_rows, max(1, n_rows // skew), replace=False)
+        deg[idx] = rng.integers(33, 400, len(idx))
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)]).astype(np.int64))
+    nnz = int(rowptr[-1])
+    col = torch.from_numpy(rng.integers(0, n_rows, nnz).astype(np.int32))
+    val = torch.from_numpy(rng.standard_normal(nnz).astype(np.float32))
+    n = lib.chaorec_spmm_schedule_len(n_rows, D)
+    want = torch.empty(n, dtype=torch.int32)
+    rc = lib.chaorec_spmm_build_schedule(ctypes.c_void_p(rowptr.data_ptr()), ctypes.c_void_p(col.data_ptr()),
+                                         ctypes.c_void_p(val.data_ptr()), n_rows, D, ctypes.c_void_p(want.data_ptr()), n)
+    assert rc == 0
+    got = graph.schedule_tensors(rowptr, col, val, n_rows, lib.chaorec_spmm_rows_per_wave(D), lib.chaorec_spmm_long_threshold())
+    assert got.dtype == torch.int32 and torch.equal(got, want)
