@@ -56,8 +56,12 @@ class LightGCN(nn.Module):
                        else graph.user_hist_csr_from_edges(edge_index, num_user))
         self.hist = (rowptr.to(device), col.to(device))
 
-        self.user_embedding = nn.Embedding(num_user, dim_E)
-        self.item_embedding = nn.Embedding(num_item, dim_E)
+        # (a graph that was generated on the device -- BASELINE configs[4]: 12 M rows x 128 -- gets its tables there as well:
+        #  xavier on the host took 6.7 of the 15.5 s a rank spent building that configuration.  A graph handed over as a host
+        #  array keeps the host initialisation: the reference's seed then gives the reference's weights.)
+        emb_dev = torch.device(device) if on_device else None
+        self.user_embedding = nn.Embedding(num_user, dim_E, device=emb_dev)
+        self.item_embedding = nn.Embedding(num_item, dim_E, device=emb_dev)
         nn.init.xavier_uniform_(self.user_embedding.weight)
         nn.init.xavier_uniform_(self.item_embedding.weight)
         self._flat = None

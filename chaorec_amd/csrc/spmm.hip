@@ -33,6 +33,9 @@ constexpr int kDescDwords = 16;  // 64-B descriptor: row, deg|flag, e0 lo/hi, 6 
 #ifndef CHAOREC_SPMM_LONG_T
 #define CHAOREC_SPMM_LONG_T (4 * CHAOREC_SPMM_UNR)
 #endif
+#ifndef CHAOREC_SPMM_SP_COMPACT2
+#define CHAOREC_SPMM_SP_COMPACT2 1      // long rows of a gated launch walk a compacted list of their flagged entries
+#endif
 #ifndef CHAOREC_SPMM_MINW
 #define CHAOREC_SPMM_MINW 1
 #endif
@@ -268,22 +271,38 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     }
     const int n = min(LPR, rest - base);
     const int nmax = min(LPR, dmax - base);
-    for (int j = 0; j < nmax; j += UNR) {
+    // SP with a source bitmap: the group's FLAGGED entries of this block, compacted in entry order (the skipped ones would add
+    // val * (+0) = +0) -- UNR real gathers in flight per step instead of UNR slots of which a third is live (the gated
+    // backward launch of a light step ran at 0.39 of the HBM peak against the dense launch's 0.8: half as many rows in
+    // flight per wave, and two steps per block where one does).  gm: the group's flags, consumed lowest bit first.
+    unsigned long long gm = 0ull;
+    int jmax = nmax;
+    if constexpr (SP) {
+      if (sa.src_bits) {
+        const unsigned long long bal = __ballot(bt != 0 && li < n);
+        gm = (bal >> (sub * LPR)) & (LPR == 64 ? ~0ull : ((1ull << (LPR & 63)) - 1ull));
+        jmax = wave_max_i32(__popcll(gm));
+      }
+    }
+    for (int j = 0; j < jmax; j += UNR) {
       int cj[UNR];
       float vj[UNR];
       bool p[UNR];
       float4 xv[UNR][CPL];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const int src = sub * LPR + ((j + u) & (LPR - 1));
-        cj[u] = __shfl(c, src, 64);
-        vj[u] = __shfl(v, src, 64);
+        int src = sub * LPR + ((j + u) & (LPR - 1));
         p[u] = (j + u) < n;
         if constexpr (SP) {
-          const bool flagged = __shfl(bt, src, 64) != 0;      // (by every lane, before the && -- see the long-row section)
-          p[u] = p[u] && flagged;
+          if (sa.src_bits) {              // (kernel-uniform)
+            p[u] = gm != 0ull;
+            src = sub * LPR + (p[u] ? (int)__builtin_ctzll(gm) : 0);
+            gm &= gm - 1ull;              // (0 stays 0)
+          }
           any_src = any_src || p[u];
         }
+        cj[u] = __shfl(c, src, 64);
+        vj[u] = __shfl(v, src, 64);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -348,64 +367,125 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
     __syncthreads();
     nl = n_long_s;  // block-uniform
     }
+    // SP with a source bitmap: a long row is walked over its FLAGGED entries only.  One coalesced pass over (col, val) by the
+    // whole workgroup, one bitmap probe per entry -- all in flight together --, the flagged ones compacted in entry order into
+    // an LDS list (SB entries of the row per turn); the chunks of the ordered walk then take HALF entries of the LIST each:
+    // every gather a wave has in flight is a real one and the carry chain is as long as the row's flagged part, not the row.
+    // The sum is the dense walk's: the skipped terms are val * (+0) = +0.  (The gated backward launch of a light step ran at
+    // 0.39 of the HBM peak against the dense launch's 0.8 with a third of every chunk's gathers live.)
+    constexpr int SB = 256;
+    __shared__ int lc[(SP && CHAOREC_SPMM_SP_COMPACT2) ? SB : 1];
+    __shared__ float lv[(SP && CHAOREC_SPMM_SP_COMPACT2) ? SB : 1];
+    __shared__ int wcnt[4];
+    bool compact = false;
+    if constexpr (SP && CHAOREC_SPMM_SP_COMPACT2) compact = sa.src_bits != nullptr;      // (kernel-uniform)
     for (int t = 0; t < nl; ++t) {
       const int n = long_n[t];
       const int64_t le0 = long_e0[t];
-      const int nchunks = (n + HALF - 1) / HALF;
       if (threadIdx.x == 0) seq_s = 0;
       __syncthreads();
       float4 xv[UH];
       float vv[UH];
-      auto gather = [&](int k) {
-        int c = 0;
-        float v = 0.f;
-        int bt = 1;
-        if (lane < HALF && k * HALF + lane < n) {
-          c = col[le0 + k * HALF + lane];
-          v = val[le0 + k * HALF + lane];
-          if constexpr (SP) {
-            if (sa.src_bits) bt = row_bit(sa.src_bits, c) ? 1 : 0;
+      int chunk_base = 0;                   // chunks summed so far (the ticket counts on over the turns of a compacted walk)
+      for (int sb0 = 0; sb0 < n; sb0 += compact ? SB : n) {
+        int n_eff = n;                      // entries this turn walks: the row, or this turn's list
+        if constexpr (SP && CHAOREC_SPMM_SP_COMPACT2) {
+          if (compact) {
+            const int e = sb0 + (int)threadIdx.x;
+            int ce = 0;
+            float ve = 0.f;
+            if (e < n) {
+              ce = col[le0 + e];
+              ve = val[le0 + e];
+            }
+            const bool fe = e < n && row_bit(sa.src_bits, ce);
+            const unsigned long long bm = __ballot(fe);
+            if (lane == 0) wcnt[wv] = (int)__popcll(bm);
+            __syncthreads();
+            int total = 0, mybase = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              if (w == wv) mybase = total;
+              total += wcnt[w];
+            }
+            if (fe) {
+              const int pos = mybase + (int)__popcll(bm & ((1ull << lane) - 1ull));
+              lc[pos] = ce;
+              lv[pos] = ve;
+            }
+            __syncthreads();
+            n_eff = total;
           }
         }
-#pragma unroll
-        for (int u = 0; u < UH; ++u) {
-          const int idx = u * NG + sub;
-          const int cj = __shfl(c, idx, 64);
-          vv[u] = __shfl(v, idx, 64);
-          xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          bool live = k * HALF + idx < n && li < D4;
-          if constexpr (SP) {
-            // (the shuffle FIRST, by every lane: `live && __shfl(..)` would leave the lanes that are not live out of it,
-            //  and they are other lanes' sources.  A skipped row parks v * (+0) = +0 in the tile.)
-            const bool flagged = __shfl(bt, idx, 64) != 0;
-            live = live && flagged;
+        const int nchunks = (n_eff + HALF - 1) / HALF;
+        auto gather = [&](int k) {
+          int c = 0;
+          float v = 0.f;
+          int bt = 1;
+          if (lane < HALF && k * HALF + lane < n_eff) {
+            if (compact) {
+              c = lc[k * HALF + lane];
+              v = lv[k * HALF + lane];
+            } else {
+              c = col[le0 + k * HALF + lane];
+              v = val[le0 + k * HALF + lane];
+              if constexpr (SP) {
+                if (sa.src_bits) bt = row_bit(sa.src_bits, c) ? 1 : 0;
+              }
+            }
           }
-          if (live) xv[u] = x4[(size_t)cj * (size_t)D4 + li];
-        }
-      };
-      if (wv < nchunks) gather(wv);
-      for (int k = wv; k < nchunks; k += 4) {
 #pragma unroll
-        for (int u = 0; u < UH; ++u) tile[(u * NG + sub) * LPR + li] = mul_rn4(vv[u], xv[u]);
-        if (k + 4 < nchunks) gather(k + 4);  // next chunk's loads fly while we wait for the carry
-        while (__hip_atomic_load(&seq_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k)
-          __builtin_amdgcn_s_sleep(1);
-        float a[FPL];
+          for (int u = 0; u < UH; ++u) {
+            const int idx = u * NG + sub;
+            const int cj = __shfl(c, idx, 64);
+            vv[u] = __shfl(v, idx, 64);
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool live = k * HALF + idx < n_eff && li < D4;
+            if constexpr (SP) {
+              // (the shuffle FIRST, by every lane: `live && __shfl(..)` would leave the lanes that are not live out of it,
+              //  and they are other lanes' sources.  A skipped row parks v * (+0) = +0 in the tile.)
+              const bool flagged = __shfl(bt, idx, 64) != 0;
+              live = live && flagged;
+            }
+            if (live) xv[u] = x4[(size_t)cj * (size_t)D4 + li];
+          }
+        };
+        if (wv < nchunks) gather(wv);
+        for (int k = wv; k < nchunks; k += 4) {
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) a[f] = k == 0 ? 0.f : carry[lane * FPL + f];
-        const int cntv = min(HALF, n - k * HALF);
+          for (int u = 0; u < UH; ++u) tile[(u * NG + sub) * LPR + li] = mul_rn4(vv[u], xv[u]);
+          if (k + 4 < nchunks) gather(k + 4);  // next chunk's loads fly while we wait for the carry
+          while (__hip_atomic_load(&seq_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != chunk_base + k)
+            __builtin_amdgcn_s_sleep(1);
+          float a[FPL];
+#pragma unroll
+          for (int f = 0; f < FPL; ++f) a[f] = (chunk_base + k) == 0 ? 0.f : carry[lane * FPL + f];
+          const int cntv = min(HALF, n_eff - k * HALF);
 #pragma unroll 8
-        for (int e = 0; e < cntv; ++e) {
+          for (int e = 0; e < cntv; ++e) {
 #pragma unroll
-          for (int f = 0; f < FPL; ++f) a[f] = add_rn(a[f], tilef[e * (LPR * 4) + lane * FPL + f]);
+            for (int f = 0; f < FPL; ++f) a[f] = add_rn(a[f], tilef[e * (LPR * 4) + lane * FPL + f]);
+          }
+          // (a compacted walk does not know its last chunk before its last turn: it always hands on through `carry`)
+          float *dst = (!compact && k == nchunks - 1) ? reinterpret_cast<float *>(long_sum[t]) : carry;
+#pragma unroll
+          for (int f = 0; f < FPL; ++f) dst[lane * FPL + f] = a[f];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_store(&seq_s, chunk_base + k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        float *dst = (k == nchunks - 1) ? reinterpret_cast<float *>(long_sum[t]) : carry;
-#pragma unroll
-        for (int f = 0; f < FPL; ++f) dst[lane * FPL + f] = a[f];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&seq_s, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        chunk_base += nchunks;
+        __syncthreads();                    // (compacted: every chunk of this turn is in the carry, the list may be rewritten)
       }
-      __syncthreads();
+      if constexpr (SP && CHAOREC_SPMM_SP_COMPACT2) {
+        if (compact) {
+          if (wv == 0) {
+            float *dst = reinterpret_cast<float *>(long_sum[t]);
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) dst[lane * FPL + f] = chunk_base ? carry[lane * FPL + f] : 0.f;
+          }
+          __syncthreads();
+        }
+      }
     }
     if (my_slot >= 0) {
       sum[0] = long_sum[my_slot][li];

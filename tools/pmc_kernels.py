@@ -22,7 +22,7 @@ for i, ctrs in enumerate(PASSES):
     out = os.path.join(ROOT, "gpurun_out", f"pmc_pass{i}")
     shutil.rmtree(out, ignore_errors=True)
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", out, "-o", "p", "--"] + cmd,
-                       cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
+                       cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=int(os.environ.get("PMC_TIMEOUT", "150")))
     f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
     if not f:
         sys.exit(r.stdout[-1500:] + r.stderr[-1500:])
