@@ -178,6 +178,16 @@ def measure_model(args, name, world, rank, dev, sharded, backend, steps=None, wa
                                                     and torch.cuda.device_count() >= world),
                    "host_build_seconds": build_s},
     }
+    if rank == 0:
+        try:
+            from .model_roofline import model_roofline
+            rows = None
+            if name == "FREEDOM":
+                b = draw()
+                rows = int(torch.unique(torch.cat((b[1], b[2]))).numel())
+            out["roofline"] = model_roofline(name, model if not sharded else getattr(model, "full", model), rows)
+        except Exception as exc:      # noqa: BLE001 -- a roofline annotation must not take the measured record with it
+            out["roofline"] = {"error": repr(exc)[:200]}
     del model, opt, graphed, step
     torch.cuda.empty_cache()
     return out

@@ -76,7 +76,8 @@ def _model(m):
     rf = m.get("roofline")
     if isinstance(rf, dict):
         out["roofline"] = {k: (_short(rf[k], 72) if isinstance(rf.get(k), str) else _r(rf.get(k), 4))
-                           for k in ("bound", "dominant_kernel", "share_of_step", "achieved", "peak", "unit", "frac") if k in rf}
+                           for k in ("bound", "dominant_kernel", "share_of_step", "achieved", "peak", "unit", "frac", "stale", "error")
+                           if k in rf}
     return out
 
 

@@ -677,7 +677,7 @@ def main_single(args, dev):
             try:
                 m = measure_model(args, name, 1, 0, dev, False, None, steps=200, warmup=20)
                 out["models"][name] = {k: m[k] for k in ("ms_per_step", "timed_blocks", "value", "unit", "steps", "warmup", "data",
-                                                         "users_scored_per_s_incl_d2h", "config") if k in m}
+                                                         "users_scored_per_s_incl_d2h", "config", "roofline") if k in m}
             except Exception as exc:      # noqa: BLE001 -- a sub-record must not take the headline with it
                 out["models"][name] = {"error": repr(exc)[:300]}
             torch.cuda.empty_cache()

@@ -44,30 +44,33 @@ union Frag8 {
   bf16x8 v;
 };
 
-__device__ __forceinline__ uint32_t rne_bf16_bits(float f) {
-  const uint32_t b = __float_as_uint(f);
-  return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
-}
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// x = h + m + l exactly (finite x): three bf16 bit patterns
-__device__ __forceinline__ void split3(float x, uint32_t &h, uint32_t &m, uint32_t &l) {
-  h = rne_bf16_bits(x);
-  const float r1 = x - __uint_as_float(h << 16);
-  m = rne_bf16_bits(r1);
-  const float r2 = r1 - __uint_as_float(m << 16);
-  l = __float_as_uint(r2) >> 16;          // (r2 has at most 8 significant bits left: exact)
+// x = h + m + l exactly (finite x): h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m (at most 8 significant bits left: its
+// high half is exact) -- for TWO elements at a time, packed (first element in the low half) as the LDS planes want them.
+// gfx950 rounds a pair to bf16 in ONE instruction (v_cvt_pk_bf16_f32, round-to-nearest-even: the bits of the integer form
+// (b + 0x7FFF + ((b >> 16) & 1)) >> 16 this replaced, for every finite value): 2 conversions + 4 unpacks + 4 subtractions + 1
+// byte permute per pair = 5.5 VALU per element against 19 -- the split used to cost MORE than the six MFMAs it feeds (9.3
+// VALU per MFMA on MMGCN's weight-gradient product, MFMA pipe busy 0.35: profiles/r05_zz_mmgcn_gemm_pmc*.txt).  Same planes,
+// same products, same bits as before.
+__device__ __forceinline__ uint32_t rne_bf16x2(float a, float b) {
+  const f32x2_t v = {a, b};
+  const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<const uint32_t *>(&h);
+}
+__device__ __forceinline__ void split3x2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = rne_bf16x2(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+  m = rne_bf16x2(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);     // (s0 >> 16) | (s1 & 0xFFFF0000)
 }
 
 // four consecutive k of one row -> 8 B per plane
 __device__ __forceinline__ void split3x4(const float4 x, uint2 &h, uint2 &m, uint2 &l) {
-  uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
-  split3(x.x, h0, m0, l0);
-  split3(x.y, h1, m1, l1);
-  split3(x.z, h2, m2, l2);
-  split3(x.w, h3, m3, l3);
-  h = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-  m = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
-  l = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+  split3x2(x.x, x.y, h.x, m.x, l.x);
+  split3x2(x.z, x.w, h.y, m.y, l.y);
 }
 
 extern __global__ void gemm_reduce_slabs_kernel(const float *__restrict__ slabs, int splits, float *__restrict__ C,
@@ -247,13 +250,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
         const float bx[4][2] = {{r0.x, r1.x}, {r0.y, r1.y}, {r0.z, r1.z}, {r0.w, r1.w}};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          uint32_t h0, h1, m0_, m1, l0, l1;
-          split3(bx[i][0], h0, m0_, l0);
-          split3(bx[i][1], h1, m1, l1);
+          uint32_t hh, mm, ll;
+          split3x2(bx[i][0], bx[i][1], hh, mm, ll);
           // tile row 4 (nq + 16 bb) + i of a 64-row half is kept at LDS row 64 bb + 16 i + nq (see the A tile)
-          *reinterpret_cast<uint32_t *>(&Bs[0][64 * bb + 16 * i + b_nq][2 * b_kp]) = h0 | (h1 << 16);
-          *reinterpret_cast<uint32_t *>(&Bs[1][64 * bb + 16 * i + b_nq][2 * b_kp]) = m0_ | (m1 << 16);
-          *reinterpret_cast<uint32_t *>(&Bs[2][64 * bb + 16 * i + b_nq][2 * b_kp]) = l0 | (l1 << 16);
+          *reinterpret_cast<uint32_t *>(&Bs[0][64 * bb + 16 * i + b_nq][2 * b_kp]) = hh;
+          *reinterpret_cast<uint32_t *>(&Bs[1][64 * bb + 16 * i + b_nq][2 * b_kp]) = mm;
+          *reinterpret_cast<uint32_t *>(&Bs[2][64 * bb + 16 * i + b_nq][2 * b_kp]) = ll;
         }
       }
     } else {

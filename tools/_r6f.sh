@@ -1,0 +1,8 @@
+# round 6, batch f: the v_cvt_pk_bf16_f32 split -- every GEMM-using test, the models' clean step times, their kernel profiles
+cd $GRAFT_REPO_ROOT
+echo "== tests"; timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_models.py tests/test_gpu_real_data.py tests/test_gpu_sparse_family.py tests/test_gpu_round3.py tests/test_gpu_feature_adam.py -q -m gpu -x 2>&1 | tail -8
+for m in MMGCN FREEDOM; do
+  timeout 600 python bench.py --model $m --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$m', d['ms_per_step'], d.get('roofline'))"
+done
+echo "== one-stream MMGCN"; CHAOREC_MMGCN_STREAMS=0 timeout 600 python bench.py --model MMGCN --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"
+echo "== profiles"; timeout 1500 python tools/collect_model_profiles.py 2>&1 | tail -5
