@@ -11,7 +11,7 @@ from .common import HBM_PEAK_GBS, flush_c_stdout, init_ranks, spmm_kernel_name  
 from .models import measure_model  # noqa: F401
 from .probe import captured_all_reduce_is_exact, probe_mark, probe_node  # noqa: F401
 from .record import emit
-from .single import CHAIN_TIMING_NOTE, scoring_roofline, time_spmm_chain  # noqa: F401
+from .single import CHAIN_TIMING_NOTE, performed_value, scoring_roofline, time_spmm_chain  # noqa: F401
 
 
 def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, backend, use_graph, probe_mode=False):
@@ -236,6 +236,59 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
                                               if getattr(fused, "split", False) else
                                               "one launch per layer over the rank's joined graph [[0, B_g], [B_g^T, 0]]")}
 
+    # --- work PERFORMED by a light step: source rows gathered by its SpMM-family launches, counted over one eager step of this
+    # rank (dense launches: every entry; list launches: the entries of the listed rows; gated launches: the entries whose
+    # source row is flagged), summed over the ranks -- what the sub-record's `value` divides by the step time
+    performed = None
+    if fused is not None and getattr(fused, "light", False):
+        gathered = [0]
+
+        def _deg_sum(csr, lst, n):
+            rows = lst[:int(n.item())].to(torch.int64)
+            return int((csr.rowptr[rows + 1] - csr.rowptr[rows]).sum().item())
+
+        def _flagged(csr, bits):
+            w = bits.to(torch.int64) & 0xFFFFFFFF
+            c = csr.col.to(torch.int64)
+            return int(((w[c >> 5] >> (c & 31)) & 1).sum().item())
+
+        class _Counting:
+            def __init__(self, inner):
+                self._inner = inner
+
+            def __getattr__(self, name):
+                fn = getattr(self._inner, name)
+                if name in ("spmm", "spmm_mean", "spmm_adam"):
+                    def dense(csr, *a, **k):
+                        gathered[0] += csr.nnz
+                        return fn(csr, *a, **k)
+                    return dense
+                if name == "spmm_rowlist":
+                    def listed(csr, x, y, lst, n, *a, **k):
+                        gathered[0] += _deg_sum(csr, lst, n)
+                        return fn(csr, x, y, lst, n, *a, **k)
+                    return listed
+                if name == "spmm_rowsparse":
+                    def gated(csr, x, y, *a, **k):
+                        gathered[0] += _flagged(csr, k["src_bits"]) if k.get("src_bits") is not None else csr.nnz
+                        return fn(csr, x, y, *a, **k)
+                    return gated
+                return fn
+
+        saved = fused._save_state()
+        inner = fused.K
+        fused.K = _Counting(inner)
+        try:
+            fused._launch()
+            torch.cuda.synchronize()
+        finally:
+            fused.K = inner
+            fused._restore_state(saved)
+        t = torch.tensor([float(gathered[0])], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        performed = {"messages_gathered_per_step": int(t.item()), "value_performed": float(t.item()) / (dt / steps),
+                     "what": "source rows gathered by one light step's SpMM-family launches on every rank (one eager step counted)"}
+
     forward_note = None
     if fused is not None and getattr(fused, "light", False):
         # the timed steps were LIGHT ones (steps inside an epoch); the step that precedes an evaluation computes every row
@@ -250,8 +303,8 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
         forward_note = {"timed_steps": "light", "ms_per_step_full_result": float(full_ms.item()), "full_steps_per_epoch": 1,
                         "what": "dist.FusedShardedLightGCNStep with the light forward: the batch drawn first, the last two "
                                 "forward layers over the frontier's row lists (item partials through frontier buffers and "
-                                "frontier exchanges); the step before an evaluation is a full one.  `value` keeps counting the "
-                                "reference step's 2 L E_dir messages per step"}
+                                "frontier exchanges); the step before an evaluation is a full one.  The record's `value` counts the "
+                                "source rows the light steps gather, value_reference_equivalent the reference step's 2 L E_dir"}
     elif fused is not None:
         fused(single=True)                  # (the recording pass above ran eager launches; leave a complete result behind)
 
@@ -285,7 +338,7 @@ def measure_sharded_lightgcn(args, dataset, D, steps, warmup, world, rank, dev, 
                graphed=graphed is not None, fused=fused is not None, split=bool(getattr(fused, "split", False)),
                roofline=roofline, score_ms=score_ms, score_tf=tf, score_st=st, n_scored=n_scored, build_s=build_s,
                exchange=cdist.exchange_mode_used(), exchange_bytes=item_bytes, calibration=calibration, exposed=exposed,
-               table_mb=(U + I) * D * 4 / 1e6, forward=forward_note,
+               table_mb=(U + I) * D * 4 / 1e6, forward=forward_note, performed=performed,
                frontier_exchanges=cdist.STATS.get("frontier_exchanges", 0),
                frontier_caps=({"batch_items_rows": getattr(fused, "_cap0", None), "n1_items_rows": getattr(fused, "_cap1", None),
                                "item_rows": I, "bytes_per_compact_exchange": {
@@ -356,7 +409,7 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                          and torch.cuda.device_count() >= world)
     out = {
         "metric": f"GCN edges/sec + full-rank users-scored/sec, dim={D}",
-        "value": head["value"], "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
+        **performed_value(head), "unit": "directed-edge messages/s (fwd+bwd SpMM of the train step)",
         "users_scored_per_s": head["n_scored"] / (head["score_ms"] * 1e-3),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": head["data"],
@@ -435,7 +488,7 @@ def main_sharded(args, world, rank, local_rank, force_sharded):
                             f"n_layers={h['L']}, batch={h['B']}x{world} (per-rank table {h['table_mb']:.0f} MB; item partial "
                             f"{h['exchange_bytes'] / 1e6:.0f} MB per exchange)" +
                             (" -- at 8 ranks this IS configs[4]" if world == 8 else ""),
-                "data": h["data"], "steps": args.hbm_steps, "ms_per_step": h["ms_per_step"], "value": h["value"],
+                "data": h["data"], "steps": args.hbm_steps, "ms_per_step": h["ms_per_step"], **performed_value(h),
                 "unit": "directed-edge messages/s", "launch": h["launch"], "exchange": h["exchange"],
                 "exchange_calibration": h["calibration"], "exposed_communication": h["exposed"],
                 "roofline": h["roofline"], "gene_ranklist_ms_cold": h["score_ms"],

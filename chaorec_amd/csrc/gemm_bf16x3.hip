@@ -44,27 +44,46 @@ union Frag8 {
   bf16x8 v;
 };
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-// x = h + m + l exactly (finite x): h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m (at most 8 significant bits left: its
-// high half is exact) -- for TWO elements at a time, packed (first element in the low half) as the LDS planes want them.
-// gfx950 rounds a pair to bf16 in ONE instruction (v_cvt_pk_bf16_f32, round-to-nearest-even: the bits of the integer form
-// (b + 0x7FFF + ((b >> 16) & 1)) >> 16 this replaced, for every finite value): 2 conversions + 4 unpacks + 4 subtractions + 1
-// byte permute per pair = 5.5 VALU per element against 19 -- the split used to cost MORE than the six MFMAs it feeds (9.3
-// VALU per MFMA on MMGCN's weight-gradient product, MFMA pipe busy 0.35: profiles/r05_zz_mmgcn_gemm_pmc*.txt).  Same planes,
-// same products, same bits as before.
-__device__ __forceinline__ uint32_t rne_bf16x2(float a, float b) {
-  const f32x2_t v = {a, b};
-  const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
-  return *reinterpret_cast<const uint32_t *>(&h);
+// x = h + m + l exactly (finite x), three bf16 bit patterns per element, for TWO elements at a time, packed (first element in
+// the low half) as the LDS planes want them.
+//   CHAOREC_X3_SPLIT 0 (rounds 2-5): h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m.  19 VALU per element with the packing: the split
+//     cost more than the six MFMAs it feeds (9.3 VALU per MFMA on MMGCN's weight-gradient product, MFMA pipe busy 0.35).
+//   CHAOREC_X3_SPLIT 1 (round 6, default): the three BYTES of the significand -- h = x & 0xFFFF0000, m = (x - h) & 0xFFFF0000,
+//     l = x - h - m; both subtractions exact, every plane of x's sign -- and one v_perm_b32 per packed pair: 4 + 1.5 VALU per
+//     element.  |m| < 2^-7 |x|, |l| < 2^-15 |x|: the three dropped products (m l, l m, l l) stay below 2^-21 |a||b| each, inside the
+//     1e-6 of sum |a||b| the products promise (a rounded h halves |m|: 2^-23).  Round 5 built this form and shelved it because
+//     MMGCN's runs "stopped being reproducible" with it -- that was the BPR backward's atomic adds all along (round 6,
+//     profiles/r06_stream_bisect.txt), which a coarser split only made more visible.
+//   (v_cvt_pk_bf16_f32, gfx950's one-instruction pair rounding, was tried for form 0 in round 6: correct, and the products ran
+//    THREE TIMES slower -- 384 -> 1 228 us on the weight gradient; profiles/r06_f_cvt_pk_split.txt.  Not used.)
+#ifndef CHAOREC_X3_SPLIT
+#define CHAOREC_X3_SPLIT 1
+#endif
+__device__ __forceinline__ uint32_t rne_bf16_bits(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {      // (lo >> 16) | (hi & 0xFFFF0000): one v_perm_b32
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
 __device__ __forceinline__ void split3x2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
-  h = rne_bf16x2(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
-  m = rne_bf16x2(r0, r1);
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
-  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);     // (s0 >> 16) | (s1 & 0xFFFF0000)
+#if CHAOREC_X3_SPLIT
+  const float h0 = __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+  const float r0 = x0 - h0, r1 = x1 - h1;
+  const float m0 = __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u), m1 = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+  const float s0 = r0 - m0, s1 = r1 - m1;
+  h = pack_hi16(x0, x1);
+  m = pack_hi16(r0, r1);
+  l = pack_hi16(s0, s1);
+#else
+  const uint32_t h0 = rne_bf16_bits(x0), h1 = rne_bf16_bits(x1);
+  const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h1 << 16);
+  const uint32_t m0 = rne_bf16_bits(r0), m1 = rne_bf16_bits(r1);
+  const float s0 = r0 - __uint_as_float(m0 << 16), s1 = r1 - __uint_as_float(m1 << 16);
+  h = h0 | (h1 << 16);
+  m = m0 | (m1 << 16);
+  l = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xFFFF0000u);      // (at most 8 significant bits left: exact)
+#endif
 }
 
 // four consecutive k of one row -> 8 B per plane

@@ -51,7 +51,7 @@ def main():
     if os.environ.get("EPOCH_APART"):
         # bench.py's steady state: thresholds of rank 100 from the tables one epoch (155 steps) earlier, light mode
         old = torch.empty(U, dtype=torch.float32, device=dev)
-        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=False, hint_rank=100)
+        ops.score_topk(ue, ie, m.hist, 1e-6, 50, id_offset=U, hint=old, hint_valid=False, hint_rank=int(os.environ.get("HINT_RANK0", "100")))
         step.run(155)
         res = m.result.detach().clone()
         ue, ie = res[:U], res[U:U + I]
