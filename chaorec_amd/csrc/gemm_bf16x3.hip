@@ -417,17 +417,31 @@ static XPlan plan_x(int64_t M, int64_t N, int64_t K) {
   return p;
 }
 
-// weight gradients: outputs of a few tiles, reductions over all graph nodes -- up to 256 slabs of at least 128 k
+// weight gradients: outputs of a few tiles, reductions over all graph nodes -- up to 256 slabs of at least 128 k.
+// The slab count is chosen by ROUNDS: a CU holds two 128-wide (three 64-wide) workgroups, the chip 512 (768) at a time, and a
+// launch takes ceil(workgroups / that) rounds of K / slabs each.  Round 5's rule (ceil(1024 / tiles) slabs) gave MMGCN's
+// largest product -- 42 tiles x 25 slabs = 1 050 workgroups -- a THIRD round for its last 26 workgroups: 732 us where two
+// rounds take ~500.  Among the slab counts with the fewest k-steps on the critical path the smallest wins (fewer slab bytes).
 static XPlan plan_x_tn(int64_t M, int64_t N, int64_t K) {
   XPlan p;
   const int XBN = pick_bn(N);
   const int64_t tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
   int64_t s = 1;
   if (tiles < 512 && K >= 512) {
-    s = (1024 + tiles - 1) / tiles;
-    if (s > K / 128) s = K / 128;
-    if (s > 256) s = 256;
-    if (s < 1) s = 1;
+    const int64_t slots = XBN == 128 ? 512 : 768;
+    int64_t smax = K / 128;
+    if (smax > 256) smax = 256;
+    if (smax < 1) smax = 1;
+    int64_t best = INT64_MAX;
+    for (int64_t c = 1; c <= smax; ++c) {
+      const int64_t rounds = (tiles * c + slots - 1) / slots;
+      const int64_t ksteps = (((K + c - 1) / c) + XBK - 1) / XBK;      // k-tiles per workgroup
+      const int64_t cost = rounds * (ksteps + 6);                       // (+ a workgroup's prologue / epilogue, in k-tiles)
+      if (cost < best) {
+        best = cost;
+        s = c;
+      }
+    }
   }
   int64_t per = (K + s - 1) / s;
   per = (per + XBK - 1) / XBK * XBK;
