@@ -390,7 +390,8 @@ def measure_single_gpu(args, dataset, D, steps, warmup, dev, trained_steps, reps
             if tj.get("spmm_hip_sha256") == spmm_source_hash():
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_note = "from " + os.path.relpath(tpath, ROOT) + " (same spmm.hip)"
-                kernel_only_us = tj.get("kernel_avg_us_rocprofv3")
+                # (the MEDIAN launch of the captured run when the file has it: the stats average pools eager warm-up launches)
+                kernel_only_us = tj.get("kernel_median_us_rocprofv3") or tj.get("kernel_avg_us_rocprofv3")
             else:
                 traffic_note = os.path.relpath(tpath, ROOT) + " was measured on a different spmm.hip: dropped"
         except Exception:

@@ -421,6 +421,8 @@ struct OrdArgs {
   float r2_unit;                            // single term: 2 reg / (B D), times grad_out; multi: 0
   int B, D, T;
   int joined;                               // 1: ONE group of 3 B slots (users, pos, neg of term 0: g_u and g_i may alias)
+  int n_groups;
+  int wg_begin[2 * kBprMaxTerms + 2];       // first workgroup of group g (a 1-D grid: no workgroup without slots); [n_groups] = all
 };
 // groups (blockIdx.y) when !joined: 0 = the users of all terms (T B slots); 1 + 2 k = term k's item rows (2 B: pos, neg);
 // 2 + 2 k = term k's scattered rows (2 B), empty without scatter_rows[k]
@@ -459,13 +461,14 @@ __device__ __forceinline__ float *ord_dst(const OrdArgs &P, const OrdSlot s) {
 template <int NQ>
 __global__ __launch_bounds__(64 * kOrdWaves) void bpr_bwd_ordered_kernel(const OrdArgs P) {
   extern __shared__ uint64_t ord_keys[];
-  const int g = blockIdx.y;
+  int g = 0;
+  while (g + 1 < P.n_groups && (int)blockIdx.x >= P.wg_begin[g + 1]) ++g;       // (block-uniform, <= 9 steps)
   const int n = ord_group_slots(P, g);
-  if ((int)blockIdx.x * kOrdWaves >= n) return;
+  const int wg = (int)blockIdx.x - P.wg_begin[g];                                 // this workgroup's number inside its group
   for (int j = threadIdx.x; j < n; j += blockDim.x) ord_keys[j] = (uint64_t)reinterpret_cast<uintptr_t>(ord_dst(P, ord_slot(P, g, j)));
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int me = blockIdx.x * kOrdWaves + wave;
+  const int me = wg * kOrdWaves + wave;
   if (me >= n) return;
   const uint64_t key = ord_keys[me];
   // the first occurrence of a key owns its row
@@ -533,9 +536,21 @@ __global__ __launch_bounds__(64 * kOrdWaves) void bpr_bwd_ordered_kernel(const O
 }
 
 // -> false: this shape stays with the atomic launch
-static bool launch_bpr_ordered(const OrdArgs &P, int groups, int max_slots, hipStream_t st) {
-  if (max_slots > kOrdMaxSlots || P.D > 256) return false;
-  const dim3 grid((unsigned)((max_slots + kOrdWaves - 1) / kOrdWaves), (unsigned)groups);
+static bool launch_bpr_ordered(OrdArgs &P, int groups, hipStream_t st) {
+  int max_slots = 0, total_wg = 0;
+  P.n_groups = groups;
+  for (int g = 0; g < groups; ++g) {
+    int n;
+    if (P.joined) n = 3 * P.B;
+    else if (g == 0) n = P.T * P.B;
+    else n = (((g - 1) & 1) && !P.A.scatter_rows[(g - 1) >> 1]) ? 0 : 2 * P.B;
+    P.wg_begin[g] = total_wg;
+    total_wg += (n + kOrdWaves - 1) / kOrdWaves;
+    max_slots = n > max_slots ? n : max_slots;
+  }
+  P.wg_begin[groups] = total_wg;
+  if (max_slots > kOrdMaxSlots || P.D > 256 || total_wg == 0) return false;
+  const dim3 grid((unsigned)total_wg);
   const size_t lds = (size_t)max_slots * sizeof(uint64_t);
   const int nq = (P.D + 63) / 64;
   if (nq <= 1) {
@@ -866,7 +881,7 @@ extern "C" int chaorec_bpr_bwd_ordered_f32(const float *tab_u, const float *tab_
     P.A.scatter_rows[k] = nullptr, P.A.scatter_out[k] = nullptr;
   }
   P.A.T = 1;
-  if (!launch_bpr_ordered(P, 1, 3 * B, (hipStream_t)stream))     // (too many slots for the key table / D > 256: atomics)
+  if (!launch_bpr_ordered(P, 1, (hipStream_t)stream))     // (too many slots for the key table / D > 256: atomics)
     return chaorec_bpr_bwd_f32(tab_u, tab_i, users, pos, neg, B, D, coef, reg_weight, grad_out, g_u, g_i, stream);
   return check_launch("bpr_bwd_ordered_kernel");
 }
@@ -951,8 +966,7 @@ extern "C" int chaorec_bpr_multi_bwd_ordered_f32(const float *tab_u, const int64
   P.tab_u = tab_u, P.users = users, P.coef = coef, P.wvec = wvec, P.grad_out = grad_out, P.g_u = g_u;
   P.r2_unit = 0.f;
   P.B = B, P.D = D, P.T = T, P.joined = 0;
-  const int max_slots = (T > 2 ? T : 2) * B;
-  if (!launch_bpr_ordered(P, 1 + 2 * T, max_slots, (hipStream_t)stream))
+  if (!launch_bpr_ordered(P, 1 + 2 * T, (hipStream_t)stream))
     return chaorec_bpr_multi_bwd_f32(tab_u, users, T, tabs, pos, neg, B, D, coef, wvec, grad_out, g_u, g_i, scatter_rows,
                                      scatter_out, stream);
   return check_launch("bpr_bwd_ordered_kernel");

@@ -15,6 +15,8 @@ the GPU test regenerates the same tensors.  Stored per seed and epoch: summed ba
 (the reference's own gene_ranklist + utils.gene_metrics).  Hyper-parameters: Model_YAML/{FREEDOM,MMGCN}.yaml.
 
 Runs only in the build container (needs /root/reference):    MODEL=FREEDOM python tests/golden/gen_epoch_parity_mm.py
+(freedom_epochs_baby.npz: SEEDS=0,1,2,3,4,5 then APPEND=1 SEEDS=6,7,8,9 -- ten seeds; mmgcn_epochs_baby.npz: the default six,
+ a CPU epoch of the reference MMGCN takes 35 s)
 Nothing of the reference is copied: inputs and outputs only."""
 import os
 import random
@@ -106,7 +108,13 @@ def main():
             print(f"{MODEL} seed {seed} epoch {ep + 1}: loss {s:.4f} val R@20 {row[1]:.5f} N@20 {row[2]:.5f} "
                   f"test R@20 {row[3]:.5f} ({time.time() - t0:.1f} s)", flush=True)
     path = os.path.join(HERE, f"{MODEL.lower()}_epochs_baby.npz")
-    np.savez_compressed(path, seeds=np.array(SEEDS), epochs=EPOCHS, D=D, reg=reg, lr=LR, batch=B, K=K, dv=DV, dt=DT,
+    seeds = np.array(SEEDS)
+    if os.environ.get("APPEND") == "1" and os.path.exists(path):     # more seeds for an existing file (same settings)
+        old = np.load(path)
+        assert int(old["epochs"]) == EPOCHS and int(old["dv"]) == DV and int(old["feat_seed"]) == FEAT_SEED
+        seeds = np.concatenate([old["seeds"], seeds])
+        out = {n: np.concatenate([old[n], out[n]], 0) for n in names}
+    np.savez_compressed(path, seeds=seeds, epochs=EPOCHS, D=D, reg=reg, lr=LR, batch=B, K=K, dv=DV, dt=DT,
                         feat_seed=FEAT_SEED, **out)
     print("wrote", path)
 

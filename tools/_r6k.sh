@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+echo "== gemm shapes (WS v2)"; timeout 300 python tools/gemm_wide_bench.py mmgcn 2>&1 | tail -7
+echo "== gemm shapes (plain)"; CHAOREC_X3_WS=0 timeout 300 python tools/gemm_wide_bench.py mmgcn 2>&1 | tail -7
+echo "== tests"; timeout 2400 python -m pytest tests/test_gpu_round6.py tests/test_gpu_real_data.py tests/test_gpu_models.py tests/test_gpu_epoch_parity.py -q -m gpu -s 2>&1 | grep -v "^  /\|Warning\|warnings.warn\|^$\|EarlyStopping\|Validation loss" | tail -30 | cut -c1-600
+timeout 600 python bench.py --model MMGCN --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('MMGCN', d['ms_per_step'])"
