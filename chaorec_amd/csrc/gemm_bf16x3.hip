@@ -134,15 +134,8 @@ static X3Seg no_seg() {
 // TA / TB: the operand is k-MAJOR in memory (A [K, M] / B [K, N]).  (false, false) = NT, (true, true) = TN, (false, true)
 // = NN: C = A[M,K] . B[K,N] -- a Linear's input gradient gy . W with W as it lies in memory (W^T as a small copy in
 // front of every such product was ~20 launches of 4.6 us per MMGCN step).
-// WS (wave-specialised, 128-wide tiles of LARGE products only): 8 waves per workgroup.  Waves 4-7 are PRODUCERS -- global
-// loads of the next k-tile, the three-plane split and the LDS writes, i.e. all of the kernel's VALU work -- waves 0-3 CONSUMERS:
-// fragment reads and MFMAs from the tile the producers finished one barrier earlier (two LDS tile sets, one barrier per
-// k-tile).  A SIMD then holds one producer and one consumer wave of the same workgroup and the VALU pipe splits the next tile
-// while the matrix pipe multiplies this one.  In the plain form every wave does both in turn between two barriers per k-tile,
-// and with two workgroups per CU the matrix pipe was busy 0.35 of the time (7 700 - 9 000 cycles per k-tile for 3 072 of
-// MFMA).  Same tiles, same accumulation order: the same bits as the plain form (tests/test_gpu_round6.py).
-template <bool TA, bool TB, int XBN, bool SEG = false, bool WS = false>   // SEG: the operands have second segments (X3Seg)
-__global__ __launch_bounds__(WS ? 512 : 256) void gemm_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
+template <bool TA, bool TB, int XBN, bool SEG = false>   // SEG: the operands have second segments (X3Seg)
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                              float *__restrict__ C, const float *__restrict__ bias,
                                                              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                                              int64_t ldc, int act, int64_t k_per_split,
@@ -155,20 +148,9 @@ __global__ __launch_bounds__(WS ? 512 : 256) void gemm_bf16x3_kernel(const float
     seg.a_split = seg.b_split = seg.c_split = kNoSplit;
     seg.c_rows = 0;
   }
-  constexpr int A_BYTES = 3 * XBM * (XBK + XPAD) * 2, B_BYTES = 3 * XBN * (XBK + XPAD) * 2;
-  __shared__ __attribute__((aligned(16))) uint8_t lds_static[WS ? 16 : A_BYTES + B_BYTES];
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_dynamic[];            // WS: two tile sets
-  typedef uint16_t (*PlanesA)[XBM][XBK + XPAD];
-  typedef uint16_t (*PlanesB)[XBN][XBK + XPAD];
-  uint8_t *lds_base = WS ? lds_dynamic : lds_static;
-  PlanesA As = reinterpret_cast<PlanesA>(lds_base);                                // As[plane][row][k], tile set 0
-  PlanesB Bs = reinterpret_cast<PlanesB>(lds_base + A_BYTES);
-  auto use_set = [&](int b) __attribute__((always_inline)) {                      // (WS) point As / Bs at tile set b
-    As = reinterpret_cast<PlanesA>(lds_base + b * (A_BYTES + B_BYTES));
-    Bs = reinterpret_cast<PlanesB>(lds_base + b * (A_BYTES + B_BYTES) + A_BYTES);
-  };
-  const bool producer = WS && threadIdx.x >= 256;
-  const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;                   // (t: index inside the role's 256 threads)
+  __shared__ uint16_t As[3][XBM][XBK + XPAD];
+  __shared__ uint16_t Bs[3][XBN][XBK + XPAD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
   // Tile of this workgroup.  Workgroups are dispatched in the order x + gridDim.x * y; the side with FEWER tiles varies fastest,
   // so that the tiles which share a panel of the long operand run next to each other: with the row tile fastest, the six
@@ -319,92 +301,15 @@ __global__ __launch_bounds__(WS ? 512 : 256) void gemm_bf16x3_kernel(const float
   };
 
   auto stash = [&]() __attribute__((always_inline)) { stash_from(ra, rb); };
-  if constexpr (WS) {
-    if (producer) {
-      // Tile i goes to LDS set i & 1, written while the consumers multiply tile i - 1 from the other set.  A k-tile of the
-      // consumers is ~1 700 cycles -- far less than a global load's latency --, so the loads run WS_DEPTH tiles ahead in a
-      // ring of register tiles (slot = tile % WS_DEPTH; the loop is unrolled by the depth so that slots are compile-time).
-      // (With one tile in flight the whole kernel ran at the memory latency per k-tile: 6 200 cycles, slower than the plain form.)
-      constexpr int WS_DEPTH = 4;
-      float4 pra[WS_DEPTH][4], prb[WS_DEPTH][NB];
-      const int64_t nt = ke > kb ? (ke - kb + XBK - 1) / XBK : 0;
-#pragma unroll
-      for (int q = 0; q < WS_DEPTH; ++q)
-        if (q < nt) fetch_into(kb + q * XBK, pra[q], prb[q]);
-      if (nt > 0) {
-        use_set(0);
-        stash_from(pra[0], prb[0]);
-        if (WS_DEPTH < nt) fetch_into(kb + (int64_t)WS_DEPTH * XBK, pra[0], prb[0]);
-      }
-      __syncthreads();
-      for (int64_t base = 0; base < nt; base += WS_DEPTH) {
-#pragma unroll
-        for (int q = 0; q < WS_DEPTH; ++q) {
-          const int64_t i = base + q;               // the tile the consumers multiply in this turn (slot q)
-          if (i < nt) {
-            if (i + 1 < nt) {
-              use_set((int)((i + 1) & 1));
-              stash_from(pra[(q + 1) % WS_DEPTH], prb[(q + 1) % WS_DEPTH]);
-              if (i + 1 + WS_DEPTH < nt)
-                fetch_into(kb + (i + 1 + WS_DEPTH) * XBK, pra[(q + 1) % WS_DEPTH], prb[(q + 1) % WS_DEPTH]);
-            }
-            __syncthreads();
-          }
-        }
-      }
-      return;                                       // (the consumers hold the accumulators and write C)
-    }
-    __syncthreads();                                // tile 0 is in set 0
-  } else {
-    if (kb < ke) fetch(kb);
-  }
-  int ws_turn = 0;
+  if (kb < ke) fetch(kb);
   for (int64_t k0 = kb; k0 < ke; k0 += XBK) {
-    if constexpr (WS) {
-      use_set(ws_turn & 1);
-    } else {
     __syncthreads();                              // the previous tile's fragment reads are done
     stash();
     __syncthreads();
     if (k0 + XBK < ke) fetch(k0 + XBK);           // next tile's loads fly under this tile's MFMAs
-    }
     if constexpr (XBN == 128 && kWave2x2) {
       // 2 x 2 waves of 64 x 64 (accumulator j = 2 i + jj: rows 64 (wave / 2) + 32 i, columns 64 (wave % 2) + 32 jj): two A
       // and two B fragments per plane feed the four accumulators -- 12 LDS reads per 24 MFMAs instead of 15
-      if constexpr (WS) {
-        // ONE consumer wave per SIMD: nobody else fills the bubbles, so (i) the next k-step's fragments are read while this
-        // one's MFMAs run, (ii) consecutive MFMAs go to DIFFERENT accumulators (product-major: each accumulator still takes
-        // its six plane products in the plain form's order -- the same bits)
-        auto frags = [&](int ks, Frag8 (&a2)[2][3], Frag8 (&b2)[2][3]) __attribute__((always_inline)) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const int R = 64 * (wave >> 1) + 32 * i + r, Rn = 64 * (wave & 1) + 32 * i + r;
-              const int arow = TA ? 32 * (R & 3) + (R >> 2) : R;
-              const int brow = TB ? 64 * (Rn >> 6) + 16 * (Rn & 3) + ((Rn & 63) >> 2) : Rn;
-              a2[i][pl].u = *reinterpret_cast<const uint4 *>(&As[pl][arow][ks + 8 * h]);
-              b2[i][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][brow][ks + 8 * h]);
-            }
-        };
-        auto products = [&](const Frag8 (&a2)[2][3], const Frag8 (&b2)[2][3]) __attribute__((always_inline)) {
-          constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};      // smallest products first (0 = h, 1 = m, 2 = l)
-#pragma unroll
-          for (int p = 0; p < 6; ++p)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[j >> 1][PA[p]].v, b2[j & 1][PB[p]].v, acc[j], 0, 0, 0);
-        };
-        static_assert(XBK == 32, "two k-steps per tile");
-        Frag8 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
-        frags(0, fa0, fb0);
-        frags(16, fa1, fb1);
-        products(fa0, fb0);
-        products(fa1, fb1);
-        ++ws_turn;
-        __syncthreads();                            // this set is free, the producers finished the next one
-        continue;
-      }
 #pragma unroll
       for (int ks = 0; ks < XBK; ks += 16) {
         Frag8 a2[2][3], b2[2][3];
@@ -433,7 +338,6 @@ __global__ __launch_bounds__(WS ? 512 : 256) void gemm_bf16x3_kernel(const float
       }
       continue;
     }
-    static_assert(!WS || (XBN == 128 && kWave2x2), "the wave-specialised form is built for the 2 x 2 waves of 128-wide tiles");
 #pragma unroll
     for (int ks = 0; ks < XBK; ks += 16) {
       Frag8 a[3], b[NJ][3];
@@ -528,13 +432,13 @@ static XPlan plan_x(int64_t M, int64_t N, int64_t K) {
 // launch takes ceil(workgroups / that) rounds of K / slabs each.  Round 5's rule (ceil(1024 / tiles) slabs) gave MMGCN's
 // largest product -- 42 tiles x 25 slabs = 1 050 workgroups -- a THIRD round for its last 26 workgroups: 732 us where two
 // rounds take ~500.  Among the slab counts with the fewest k-steps on the critical path the smallest wins (fewer slab bytes).
-static XPlan plan_x_tn(int64_t M, int64_t N, int64_t K, bool ws = false) {
+static XPlan plan_x_tn(int64_t M, int64_t N, int64_t K) {
   XPlan p;
   const int XBN = pick_bn(N);
   const int64_t tiles = ((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
   int64_t s = 1;
   if (tiles < 512 && K >= 512) {
-    const int64_t slots = ws ? 256 : (XBN == 128 ? 512 : 768);      // (a wave-specialised workgroup has a CU to itself)
+    const int64_t slots = XBN == 128 ? 512 : 768;
     int64_t smax = K / 128;
     if (smax > 256) smax = 256;
     if (smax < 1) smax = 1;
@@ -557,35 +461,13 @@ static XPlan plan_x_tn(int64_t M, int64_t N, int64_t K, bool ws = false) {
   return p;
 }
 
-// The wave-specialised form (gemm_bf16x3_kernel<.., WS = true>) for 128-wide tiles of products large enough that a workgroup
-// walks many k-tiles: >= 4 GFLOP.  CHAOREC_X3_WS=0 keeps the plain form everywhere (A/B runs, tests).
-static bool use_ws(int64_t M, int64_t N, int64_t K) {
-  const char *e = std::getenv("CHAOREC_X3_WS");          // (read per call: the workspace query and the launch of one product
-  const int on = (e && *e) ? std::atoi(e) : 1;           //  see the same value unless the caller changes it in between)
-  return on && pick_bn(N) == 128 && 2.0 * (double)M * (double)N * (double)K >= 4e9;
-}
-template <bool TA, bool TB, bool SEG>
-static void launch_ws(dim3 grid, hipStream_t st, const float *A, const float *B, float *C, const float *bias, int64_t M, int64_t N,
-                      int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int64_t k_per_split, float *slabs, int accumulate,
-                      const X3Seg &seg) {
-  constexpr int LDS = 2 * 3 * (XBM + 128) * (XBK + XPAD) * 2;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3_kernel<TA, TB, 128, SEG, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<TA, TB, 128, SEG, true>), grid, dim3(512), LDS, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
-                     k_per_split, slabs, accumulate, seg);
-}
-
 }  // namespace chaorec
 
 using namespace chaorec;
 
 extern "C" size_t chaorec_gemm_tn_bf16x3_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const XPlan p = plan_x_tn(M, N, K, use_ws(M, N, K));
+  const XPlan p = plan_x_tn(M, N, K);
   return p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
@@ -595,8 +477,7 @@ extern "C" int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, 
   if (!A || !B || !C) return fail(CHAOREC_E_INVALID, "gemm_tn_bf16x3: NULL argument");
   if (M < 0 || N < 0 || K <= 0 || lda < M || ldb < N || ldc < N) return fail(CHAOREC_E_INVALID, "gemm_tn_bf16x3: bad size");
   if (M == 0 || N == 0) return CHAOREC_OK;
-  const bool ws = use_ws(M, N, K);
-  const XPlan p = plan_x_tn(M, N, K, ws);
+  const XPlan p = plan_x_tn(M, N, K);
   const size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
   if (need > workspace_bytes || (need && !workspace))
     return fail(CHAOREC_E_WORKSPACE, "gemm_tn_bf16x3: workspace %zu < %zu", workspace_bytes, need);
@@ -604,9 +485,7 @@ extern "C" int chaorec_gemm_tn_bf16x3(const float *A, const float *B, float *C, 
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
   const int XBN = pick_bn(N);
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
-  if (ws)
-    launch_ws<true, true, false>(grid, st, A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, p.k_per_split, slabs, 0, no_seg());
-  else if (XBN == 128)
+  if (XBN == 128)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 128>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N, K,
                        lda, ldb, ldc, 0, p.k_per_split, slabs, 0, no_seg());
   else
@@ -640,9 +519,7 @@ extern "C" int chaorec_gemm_nt_bf16x3(const float *A, const float *B, float *C, 
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
   const int XBN = pick_bn(N);
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
-  if (use_ws(M, N, K))
-    launch_ws<false, false, false>(grid, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act, p.k_per_split, slabs, 0, no_seg());
-  else if (XBN == 128)
+  if (XBN == 128)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 128>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, act,
                        p.k_per_split, slabs, 0, no_seg());
   else
@@ -674,10 +551,7 @@ extern "C" int chaorec_gemm_nn_bf16x3(const float *A, const float *B, float *C, 
   float *slabs = p.splits > 1 ? (float *)workspace : nullptr;
   const int XBN = pick_bn(N);
   const dim3 grid((unsigned)((M + XBM - 1) / XBM), (unsigned)((N + XBN - 1) / XBN), (unsigned)p.splits);
-  if (use_ws(M, N, K))
-    launch_ws<false, true, false>(grid, st, A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0,
-                                  no_seg());
-  else if (XBN == 128)
+  if (XBN == 128)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 128>), grid, dim3(256), 0, st, A, B, C, (const float *)nullptr, M, N,
                        K, lda, ldb, ldc, 0, p.k_per_split, slabs, accumulate ? 1 : 0, no_seg());
   else
