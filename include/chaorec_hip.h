@@ -246,8 +246,10 @@ int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i,
                         int32_t B, int32_t D, const float *coef, float reg_weight,
                         const float *grad_out, float *g_u, float *g_i, void *stream);
 /* The same row sums WITHOUT atomics, reproducible run to run: every destination row has one owner wave that adds the row's
- * contributions in ascending (role, sample) order -- the order torch's CPU backward of `emb[users]`, `emb[pos]`, `emb[neg]`
- * (Model/LightGCN.py:113-121, Model/MMGCN.py:193-197) visits them role by role.  fp32 atomic adds are applied in an order that
+ * contributions in ascending (role, sample) order into ONE running float sum -- first the batch's contributions to
+ * `emb[users]`, then to `emb[pos]`, then to `emb[neg]` (Model/LightGCN.py:113-121, Model/MMGCN.py:193-197), each in batch order: a
+ * DEFINED order (oracle_bpr_bwd_ordered_f32 restates it), not torch's -- autograd sums the three index_select gradients as three
+ * separately accumulated tensors, another association of the same addends.  fp32 atomic adds are applied in an order that
  * moves with the load on the chip; three addends in one element then differ in the last bit between runs, and Adam's first
  * steps turn that into a visible parameter difference.  Same arguments; g_u / g_i may alias (one joined table).  Falls back
  * to the atomic launch beyond 16384 slots (3 B) or D > 256. */

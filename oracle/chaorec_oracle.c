@@ -138,7 +138,8 @@ void oracle_bpr_bwd_f32(const float *tab_u, const float *tab_i, const int64_t *u
 
 /* The same index_add in FLOAT and in a stated order -- role by role (the rows `emb[users]`, then `emb[pos]`, then `emb[neg]`
  * of Model/LightGCN.py:113-121 / Model/MMGCN.py:193-197), batch order inside a role, every addend rounded to float and added to
- * the float row: what torch's CPU autograd does with three index_select backwards, and what the product's ORDERED backward
+ * the float row's ONE running sum.  (torch's CPU autograd accumulates the three index_select gradients separately and adds
+ * the three tensors: another association of the same addends -- this is a defined order, not torch's.)  It is what the product's ORDERED backward
  * launch (chaorec_bpr_bwd_ordered_f32) reproduces bit for bit (the expressions are the kernel's: c = coef * grad_out,
  * r2 = (2 reg / (B D)) * grad_out, no fused multiply-add: -ffp-contract=off on both sides).  g_u / g_i may alias. */
 void oracle_bpr_bwd_ordered_f32(const float *tab_u, const float *tab_i, const int64_t *users,

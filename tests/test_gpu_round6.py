@@ -19,7 +19,7 @@ def dev():
 @pytest.mark.parametrize("variant", [0, 2])
 def test_bpr_ordered_backward_is_the_oracles_float_index_add_bit_for_bit(dev, oracle, D, B, variant):
     """chaorec_bpr_bwd_ordered_f32 against oracle_bpr_bwd_ordered_f32 (role-major, batch order, every addend rounded to float --
-    torch's CPU backward of emb[users] / emb[pos] / emb[neg], Model/LightGCN.py:113-121): the same bits, with heavy
+    one running sum per row over the gradients of emb[users] / emb[pos] / emb[neg], Model/LightGCN.py:113-121): the same bits, with heavy
     duplication inside the batch (dozens of addends per row), a non-unit grad_out and the L2 term; five repetitions give the
     same bits again (the atomic launch does not promise that)."""
     from chaorec_amd import ops

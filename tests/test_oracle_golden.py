@@ -146,3 +146,36 @@ def test_ngcf_oracle_vs_reference_golden(oracle, tag):
     assert float(terms[0]) == pytest.approx(float(g["loss"]), rel=2e-6)
     if tag == "drop":
         assert masks.shape == (L, 2 * len(g["edges"])) and 0.5 < masks.mean() < 0.9
+
+
+def test_ordered_bpr_backward_restatement(oracle):
+    """oracle_bpr_bwd_ordered_f32 (the float, role-major, batch-ordered index_add the product's ordered backward launch is held to
+    bit for bit on the GPU): a plain numpy walk in the same order gives the same bits; the double-precision index_add of
+    oracle_bpr_bwd_f32 (pinned by the reference's golden gradients above) agrees to float accuracy; a joined table (items as
+    rows item_offset.. of the one table) is the two-table result, row for row."""
+    rng = np.random.default_rng(3)
+    U, I, D, B = 23, 17, 64, 400
+    tu = (rng.standard_normal((U, D)) * 0.3).astype(np.float32)
+    ti = (rng.standard_normal((I, D)) * 0.3).astype(np.float32)
+    users, pos, neg = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+    _, coef64 = oracle.bpr_fwd(tu, ti, users, pos, neg, 0, 1e-3)
+    coef = coef64.astype(np.float32)
+    go = np.float32(0.7)
+    g_u, g_i = oracle.bpr_bwd_ordered(tu, ti, users, pos, neg, coef, 1e-3, grad_out=go)
+    r2 = np.float32(np.float32(2.0) * np.float32(1e-3) / (np.float32(B) * np.float32(D))) * go
+    wu, wi = np.zeros_like(tu), np.zeros_like(ti)
+    for role in range(3):
+        for b in range(B):
+            c = coef[b] * np.float32(go * np.float32(1.0))
+            u, p, n = tu[users[b]], ti[pos[b]], ti[neg[b]]
+            if role == 0:
+                wu[users[b]] += c * (p - n) + r2 * u
+            elif role == 1:
+                wi[pos[b]] += c * u + r2 * p
+            else:
+                wi[neg[b]] += -c * u + r2 * n
+    assert np.array_equal(g_u, wu) and np.array_equal(g_i, wi)
+    d_u, d_i = oracle.bpr_bwd(tu, ti, users, pos, neg, coef64, 1e-3, grad_out=0.7)
+    assert np.allclose(g_u, d_u, rtol=2e-5, atol=1e-7) and np.allclose(g_i, d_i, rtol=2e-5, atol=1e-7)
+    joined, _ = oracle.bpr_bwd_ordered(np.concatenate([tu, ti]), None, users, pos, neg, coef, 1e-3, grad_out=go, item_offset=U)
+    assert np.array_equal(joined[:U], g_u) and np.array_equal(joined[U:], g_i)
