@@ -11,6 +11,7 @@
 // fixed reduction order (bit-reproducible loss) and the backward is one launch of 256-B
 // atomic row adds (the full-rate atomic shape on gfx950).
 #include "common.h"
+#include <cstdlib>
 
 namespace chaorec {
 
@@ -154,11 +155,13 @@ __global__ __launch_bounds__(256) void bpr_fwd_bwd_drawn_kernel(
   const float c = bpr_terms_wave(tab_u, tab_i, u, p, n, b, B, D, variant, coef, ws) * 1.0f;
   const float r2 = 1.0f * 2.0f * reg_weight / ((float)B * (float)D);
   const size_t ou = (size_t)u * D, op = (size_t)p * D, on = (size_t)n * D;
-  for (int k = lane; k < D; k += 64) {
-    const float uu = tab_u[ou + k], pp = tab_i[op + k], nn = tab_i[on + k];
-    atomicAdd(g_u + ou + k, c * (pp - nn) + r2 * uu);
-    atomicAdd(g_i + op + k, c * uu + r2 * pp);
-    atomicAdd(g_i + on + k, -c * uu + r2 * nn);
+  if (g_u) {                               // (NULL: the ordered launch that follows adds the rows -- CHAOREC_BPR_ORDERED=2)
+    for (int k = lane; k < D; k += 64) {
+      const float uu = tab_u[ou + k], pp = tab_i[op + k], nn = tab_i[on + k];
+      atomicAdd(g_u + ou + k, c * (pp - nn) + r2 * uu);
+      atomicAdd(g_i + op + k, c * uu + r2 * pp);
+      atomicAdd(g_i + on + k, -c * uu + r2 * nn);
+    }
   }
   // the rows of the gradient buffer this sample touched, for the row-sparse backward propagates
   // (chaorec_spmm_csr_rowsparse_f32): bit r of a bitmap over the joined table's rows, items from bits_item_offset on
@@ -802,6 +805,10 @@ extern "C" int chaorec_bpr_fwd_bwd_f32(const float *tab_u, const float *tab_i, c
                                     nullptr, 0, stream);
 }
 
+extern "C" int chaorec_bpr_bwd_ordered_f32(const float *tab_u, const float *tab_i, const int64_t *users, const int64_t *pos,
+                                           const int64_t *neg, int32_t B, int32_t D, const float *coef, float reg_weight,
+                                           const float *grad_out, float *g_u, float *g_i, void *stream);
+
 extern "C" int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i, const int64_t *edges, int64_t n_edges,
                                           const int64_t *hist_rowptr, const int32_t *hist_col, int64_t num_user,
                                           int32_t num_item, uint64_t seed, uint64_t step, const int64_t *step_dev,
@@ -823,11 +830,20 @@ extern "C" int chaorec_bpr_fwd_bwd_at_f32(const float *tab_u, const float *tab_i
   }
   if (B <= 0 || D <= 0) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: B=%d D=%d", B, D);
   if (variant < 0 || variant > 2) return fail(CHAOREC_E_INVALID, "bpr_fwd_bwd: variant %d", variant);
+  // CHAOREC_BPR_ORDERED=2: the fused steps' gradient rows too are added by the ordered, atomic-free launch (one more launch per
+  // step -- ~7 us of a 121 us sports step, nothing of a configs[4] step --: a LightGCN run is then the same bits every time,
+  // and the fused step equals the autograd step bit for bit also on batches with repeated rows).  Read per call.
+  const char *env = std::getenv("CHAOREC_BPR_ORDERED");
+  bool ordered = env && env[0] == '2' && 3 * (int64_t)B <= kOrdMaxSlots && D <= 256;
+  const int64_t *ids_u = edges ? out_users : in_users, *ids_p = edges ? out_pos : in_pos, *ids_n = edges ? out_neg : in_neg;
   hipLaunchKernelGGL(bpr_fwd_bwd_drawn_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, tab_u, tab_i, edges,
                      n_edges, hist_rowptr, hist_col, num_user, (uint32_t)num_item, seed, step, step_dev, in_users, in_pos,
-                     in_neg, out_users, out_pos, out_neg, B, D, variant, reg_weight, coef, workspace, perm, perm_pos, g_u,
-                     g_i, adam_step, beta1, beta2, adam_bc, pos_offset, row_bits, bits_item_offset);
-  return check_launch("bpr_fwd_bwd_drawn_kernel");
+                     in_neg, out_users, out_pos, out_neg, B, D, variant, reg_weight, coef, workspace, perm, perm_pos,
+                     ordered ? (float *)nullptr : g_u, g_i, adam_step, beta1, beta2, adam_bc, pos_offset, row_bits,
+                     bits_item_offset);
+  int rc = check_launch("bpr_fwd_bwd_drawn_kernel");
+  if (rc || !ordered) return rc;
+  return chaorec_bpr_bwd_ordered_f32(tab_u, tab_i, ids_u, ids_p, ids_n, B, D, coef, reg_weight, nullptr, g_u, g_i, stream);
 }
 
 extern "C" int chaorec_bpr_finalize_steps_f32(const float *workspace, int64_t ws_stride, int32_t n_steps, int32_t B,

@@ -252,7 +252,8 @@ int chaorec_bpr_bwd_f32(const float *tab_u, const float *tab_i,
  * separately accumulated tensors, another association of the same addends.  fp32 atomic adds are applied in an order that
  * moves with the load on the chip; three addends in one element then differ in the last bit between runs, and Adam's first
  * steps turn that into a visible parameter difference.  Same arguments; g_u / g_i may alias (one joined table).  Falls back
- * to the atomic launch beyond 16384 slots (3 B) or D > 256. */
+ * to the atomic launch beyond 16384 slots (3 B) or D > 256.  chaorec_bpr_fwd_bwd_f32 / _at_f32 (the fused LightGCN steps) add
+ * their gradient rows through this launch as well when the environment says CHAOREC_BPR_ORDERED=2 (read per call). */
 int chaorec_bpr_bwd_ordered_f32(const float *tab_u, const float *tab_i,
                                 const int64_t *users, const int64_t *pos, const int64_t *neg,
                                 int32_t B, int32_t D, const float *coef, float reg_weight,

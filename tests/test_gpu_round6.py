@@ -238,3 +238,44 @@ def test_large_bf16x3_products_stay_inside_their_bound(dev, M, N, K):
     assert bool(((y.double() - ref_y).abs() <= 1e-6 * (xd.abs() @ wd.abs().t() + b.double().abs()) + 1e-12).all())
     assert bool(((gw.double() - gd.t() @ xd).abs() <= 1e-6 * (gd.abs().t() @ xd.abs())).all())
     assert bool(((gx.double() - (base.double() + gd @ wd)).abs() <= 1e-6 * (gd.abs() @ wd.abs() + base.double().abs())).all())
+
+
+@pytest.mark.parametrize("capture", [True, False])
+def test_fused_lightgcn_step_with_the_ordered_backward_is_reproducible_and_is_the_autograd_step(dev, capture, monkeypatch):
+    """CHAOREC_BPR_ORDERED=2: the fused LightGCN step's gradient rows are added by the ordered launch too (one launch more per step).
+    Twelve steps on baby with batches of 1 024 (hundreds of repeated rows per batch, where the atomic launch's sums depend on their
+    order): two fused runs leave the SAME BITS in both tables, and they are the bits of the ordinary step it replaces
+    (LightGCN.loss_drawn -> backward -> FusedAdam.step, whose BPR node runs the ordered backward by default)."""
+    from conftest import load_interactions
+    from chaorec_amd import graph
+    from chaorec_amd.Model import LightGCN
+    from chaorec_amd.optim import FusedAdam, FusedLightGCNStep
+    monkeypatch.setenv("CHAOREC_BPR_ORDERED", "2")
+    d = load_interactions("baby")
+    U, I, edges = d["U"], d["I"], d["train"]
+    uid = graph.user_item_dict_from_edges(edges)
+    edges_dev = torch.from_numpy(edges.astype(np.int64)).to(dev)
+
+    def model():
+        torch.manual_seed(0)
+        m = LightGCN(U, I, edges, uid, 64, 1e-3, 3, "add", dev).to(dev)
+        return m, FusedAdam(m.parameters(), lr=1e-3)
+
+    def fused():
+        m, o = model()
+        counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        step = FusedLightGCNStep(m, o, batch_size=1024, edges=edges_dev, seed=7, step_dev=counter, capture=capture)
+        for _ in range(12):
+            step()
+        torch.cuda.synchronize()
+        return torch.cat((m.user_embedding.weight, m.item_embedding.weight)).detach().clone()
+
+    a, b = fused(), fused()
+    assert torch.equal(a, b)
+    m, o = model()
+    for it in range(12):
+        o.zero_grad()
+        m.loss_drawn(edges_dev, 1024, 7, it).backward()
+        o.step()
+    w = torch.cat((m.user_embedding.weight, m.item_embedding.weight)).detach()
+    assert torch.equal(a, w), float((a - w).abs().max())
