@@ -114,10 +114,20 @@ struct X3Seg {
   int64_t lda2, ldb2, ldc2;
   int64_t a_split, b_split, c_split;     // INT64_MAX: no second segment
   int act2, c_rows;
+  int xcd;                               // workgroup ids are regrouped per XCD (see the kernel); every launch carries it
 };
 constexpr int64_t kNoSplit = INT64_MAX;
+// CHAOREC_X3_XCD=0: tiles in dispatch order (rounds 2-5 and the first half of round 6), for A/B runs
+static int x3_xcd() {
+  static const int v = [] {
+    const char *e = std::getenv("CHAOREC_X3_XCD");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return v;
+}
 static X3Seg no_seg() {
   X3Seg g;
+  g.xcd = x3_xcd();
   g.A2 = g.B2 = g.bias2 = nullptr;
   g.C2 = nullptr;
   g.lda2 = g.ldb2 = g.ldc2 = 0;
@@ -156,11 +166,24 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
   // so that the tiles which share a panel of the long operand run next to each other: with the row tile fastest, the six
   // column tiles of one 128-row block of MMGCN's [60 499, 772] operand were 473 workgroups -- a whole round -- apart and the
   // block was fetched from HBM six times.
-  const int64_t lin = (int64_t)blockIdx.x + (int64_t)gridDim.x * (int64_t)blockIdx.y;
+  //
+  // XCD grouping (round 6).  The dispatcher deals workgroups round-robin over the eight XCDs (observed, not promised: a wrong
+  // guess costs speed only), each with its own 4 MiB L2: neighbours in dispatch order never share an L2, and MMGCN's
+  // [60 499, 768] operand came over the fabric once per column tile, a weight gradient's k-slab once per XCD.  Dispatch id d
+  // therefore works on item (d % 8) * (n / 8) + d / 8 (the bijective form for n % 8 != 0) of the list ordered slab-major,
+  // then by the side with more tiles: an XCD gets a CONTIGUOUS run of that list -- whole row panels with all their column
+  // tiles, whole k-slabs.
+  const int64_t gxy = (int64_t)gridDim.x * (int64_t)gridDim.y;
+  int64_t wid = (int64_t)blockIdx.x + (int64_t)gridDim.x * ((int64_t)blockIdx.y + (int64_t)gridDim.y * (int64_t)blockIdx.z);
+  if (seg.xcd) {
+    const int64_t nwg = gxy * (int64_t)gridDim.z, q = nwg >> 3, rr = nwg & 7, x = wid & 7;
+    wid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (wid >> 3);
+  }
+  const int64_t zi = wid / gxy, lin = wid - zi * gxy;
   const bool n_fast = gridDim.y <= gridDim.x;
   const int64_t m0 = (n_fast ? lin / gridDim.y : lin % gridDim.x) * XBM;
   const int64_t n0 = (n_fast ? lin % gridDim.y : lin / gridDim.x) * XBN;
-  const int64_t kb = (int64_t)blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
+  const int64_t kb = zi * k_per_split, ke = min(K, kb + k_per_split);
 
   constexpr int NJ = XBN / 32;      // accumulators per wave (32 x 32 each)
   constexpr int NB = XBN / 32;      // B float4 per thread per k-tile (NT) / B blocks per thread (TN)
@@ -368,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
 
   // C[m][n]: accumulator register q of lane (r, h) is row 32*wave + (q & 3) + 8 * (q >> 2) + 4h, column 32 j + r
   const bool to_slab = slabs != nullptr;
-  float *dst = to_slab ? slabs + (size_t)blockIdx.z * (size_t)M * (size_t)N : C;
+  float *dst = to_slab ? slabs + (size_t)zi * (size_t)M * (size_t)N : C;
   const int64_t ldd = to_slab ? N : ldc;
   constexpr bool W22 = XBN == 128 && kWave2x2;
 #pragma unroll

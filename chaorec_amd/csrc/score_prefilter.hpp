@@ -96,6 +96,7 @@ struct PrefArgs {
   int *cand_cnt;                // [splits][U][2]
   int *n_cand;                  // [U] candidates the selection expanded (statistics)
   int splits;                   // sweep splits (tiles interleaved)
+  int xcd_group;                // sweep: the workgroups of a split on ONE XCD (see score_sweep_bf16_kernel)
   int sample_stride;            // every sample_stride-th tile is sampled ...
   int sample_splits;            // ... dealt round-robin to this many sampler waves per user block
   int sample_rank;              // r_l: per-lane rank
@@ -892,11 +893,25 @@ __global__ __launch_bounds__(64 * kSweepWaves) void score_sweep_bf16_kernel(cons
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ur = lane & 31, h = lane >> 5;
   const int64_t n_act = P.n_active ? (int64_t)*P.n_active : P.n_users;
-  if ((int64_t)blockIdx.x * kSweepWaves * UB * 32 >= n_act || n_act <= P.min_active) return;   // (only a compact pass has empty workgroups)
-  const int64_t ublock0 = ((int64_t)blockIdx.x * kSweepWaves + wv) * UB;
+  // Which (user workgroup, split) this workgroup is.  In dispatch order (user workgroup fastest) every XCD gets an eighth of the
+  // user workgroups of EVERY split and so streams the whole packed table through its L2; with xcd_group the dispatch ids are
+  // regrouped (d -> (d % 8) * (n / 8) + d / 8, bijective form) so that an XCD holds a contiguous run of the split-major list:
+  // an eighth of the splits, an eighth of the table.  The dispatcher's round-robin is observed, not promised: speed only.
+  int64_t bx = blockIdx.x;
+  int split_ = blockIdx.y;
+  if (P.xcd_group) {
+    const int64_t gx = gridDim.x, nwg = gx * (int64_t)gridDim.y, q = nwg >> 3, rr = nwg & 7;
+    int64_t wid = bx + gx * split_;
+    const int64_t x = wid & 7;
+    wid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (wid >> 3);
+    split_ = (int)(wid / gx);
+    bx = wid - (int64_t)split_ * gx;
+  }
+  if (bx * kSweepWaves * UB * 32 >= n_act || n_act <= P.min_active) return;   // (only a compact pass has empty workgroups)
+  const int64_t ublock0 = (bx * kSweepWaves + wv) * UB;
   const uint32_t n_items = (uint32_t)P.n_items;
   const int n_tiles = (int)((P.n_items + 31) / 32);
-  const int split = blockIdx.y;
+  const int split = split_;
   const int splits = P.splits;
   const float *thr_src = P.hint_in ? P.hint_in : P.tau_sum;
 

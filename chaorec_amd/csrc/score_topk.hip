@@ -1173,6 +1173,7 @@ static int score_topk_impl(const float *user_emb, const float *item_emb, int64_t
     P.cand = (uint32_t *)(ws + p.off_pf_cand);
     P.cand_cnt = (int *)(ws + p.off_pf_cnt);
     P.splits = p.pf_splits;
+    P.xcd_group = env_int("CHAOREC_SWEEP_XCD", 1);
     P.sample_stride = p.pf_sample_stride;
     P.sample_splits = p.pf_sample_splits;
     P.sample_rank = p.pf_sample_rank;

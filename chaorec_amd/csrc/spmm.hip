@@ -14,6 +14,7 @@
 //     result is bit-identical to a sequential scatter_add_ in the reference's edge order.
 #include "common.h"
 #include <algorithm>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -881,10 +882,12 @@ struct ListMean {
 // after the other would be the launch's tail.  They are appended to long_list and spmm_rowlist_long_kernel -- a workgroup
 // per row -- takes them.
 struct LongRows {
-  int32_t *list;      // rows deferred by the short-row kernel
-  int32_t *cnt;       // [0] = how many, [1] = workgroups of the long-row kernel that are done (both zero between launches)
+  int32_t *list;      // rows deferred by the short-row kernel: long rows from the front, STRIPED rows from the back
+  int32_t *cnt;       // [0] = long rows, [1] = workgroups of the long-row kernel that are done, [2] = striped rows, [3] unused
+                      // (all zero between launches)
   int64_t cap;
   int t;              // a row with more entries than this is a long row
+  int vt;             // ... and with more than this a STRIPED one (INT_MAX: none): see spmm_rowlist_long_ws_kernel
 };
 
 __device__ __forceinline__ void rowlist_epilogue(int64_t r, int D4, int li, float4 sum, float alpha, const float *z, float beta,
@@ -923,8 +926,13 @@ __global__ __launch_bounds__(256) void spmm_rowlist_kernel(const int64_t *__rest
     int deg = ok ? (int)(rowptr[r + 1] - e0) : 0;
     if (lr.list && deg > lr.t) {          // (group-uniform)
       if (li == 0) {
-        const int at = atomicAdd(lr.cnt, 1);
-        if (at < lr.cap) lr.list[at] = (int32_t)r;
+        if (deg > lr.vt) {
+          const int at = atomicAdd(lr.cnt + 2, 1);
+          if (at < lr.cap) lr.list[lr.cap - 1 - at] = (int32_t)r;
+        } else {
+          const int at = atomicAdd(lr.cnt, 1);
+          if (at < lr.cap) lr.list[at] = (int32_t)r;
+        }
       }
       ok = false;
       deg = 0;
@@ -1096,90 +1104,147 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int LPR>
 constexpr int ws_summer_waves() { return (4 * LPR + 63) / 64; }
 
+// One row (or one 128-byte column stripe of it) through the loader teams and the summing waves.  LPRX lanes per entry; x4w, c0:
+// the window's first float4 column (x4w = x4 + c0), D4w its width; D4 the tables' row stride in float4.
+template <int LPRX, int T, int SW>
+__device__ __forceinline__ void long_ws_row(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                            const float4 *__restrict__ x4w, float *__restrict__ y, int D4, int D4w, int c0,
+                                            float alpha, const float *z, float beta, const uint32_t *__restrict__ z_bits,
+                                            const ListMean &mean, int64_t r, int64_t e0, int deg, float4 *tile0, float4 *tile1) {
+  constexpr int LW = 4, K = 16;
+  constexpr int NGB = LW * 64 / LPRX;     // lane groups per loader team
+  constexpr int CH = NGB * K;             // entries per round: a 64 KiB tile
+  constexpr int DT = 4 * LPRX;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const bool summer = wave < SW;
+  const int team = summer ? -1 : (wave - SW) / LW;
+  const int lt = summer ? 0 : tid - (SW + team * LW) * 64;      // thread index inside its team
+  const int g = lt / LPRX, li = lt % LPRX;
+  const int lic = min(li, D4w - 1);
+  const int D = 4 * D4w;
+  const int rounds = (deg + CH - 1) / CH;
+  float s = 0.f;                        // (summing waves: column tid of the running sum)
+  int cn[K];
+  float4 xv[K];
+  float vv[K];
+  if (!summer) {                        // the team's first round (= its number), and the columns of its second
+#pragma unroll
+    for (int k = 0; k < K; ++k) cn[k] = col[e0 + min(team * CH + g * K + k, deg - 1)];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      xv[k] = x4w[(size_t)cn[k] * (size_t)D4 + lic];
+      vv[k] = val[e0 + min(team * CH + g * K + k, deg - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) cn[k] = col[e0 + min((team + T) * CH + g * K + k, deg - 1)];
+  }
+  for (int pb = 0; pb < rounds + 1; pb += T) {
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+      const int p = pb + tt;            // phase p: round p is parked, round p - 1 is summed
+      if (!summer && team == tt && p < rounds) {
+        float4 *tw = (p & 1) ? tile1 : tile0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) tw[(g * K + k) * LPRX + li] = mul_rn4(vv[k], xv[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {   // the team's next round (p + T): clamped past the row's end, never summed
+          xv[k] = x4w[(size_t)cn[k] * (size_t)D4 + lic];
+          vv[k] = val[e0 + min((p + T) * CH + g * K + k, deg - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) cn[k] = col[e0 + min((p + 2 * T) * CH + g * K + k, deg - 1)];
+      }
+      if (summer && p >= 1 && p - 1 < rounds && tid < D) {
+        const float *t = reinterpret_cast<const float *>(((p - 1) & 1) ? tile1 : tile0) + tid;
+        const int nn = min(CH, deg - (p - 1) * CH);
+        if (nn == CH) {
+          // The chain of dependent adds is what a striped row's time is made of.  The next 16 products are read from LDS while
+          // the current 16 are added; the scheduling barriers keep the two groups apart -- left alone, the compiler issued a
+          // batch's reads LAST-needed first and waited for all of them before the first add, the LDS latency once per 16 adds
+          // (configs[4]'s batch launch, tools/rowlist_r0_bench.py: 1.75 ms that way, 1.5 ms this way; a branch-free reload, a
+          // raised wave priority and conflict-free parking of the tile rows each measured the same or worse).
+          constexpr int SB = 16;
+          static_assert(CH % (2 * SB) == 0, "two batches per turn");
+          float a[SB], b[SB];
+#pragma unroll
+          for (int q = 0; q < SB; ++q) a[q] = t[q * DT];
+#pragma unroll 1
+          for (int e = 0; e < CH; e += 2 * SB) {
+#pragma unroll
+            for (int q = 0; q < SB; ++q) b[q] = t[(e + SB + q) * DT];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < SB; ++q) s = add_rn(s, a[q]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (e + 2 * SB < CH) {
+#pragma unroll
+              for (int q = 0; q < SB; ++q) a[q] = t[(e + 2 * SB + q) * DT];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < SB; ++q) s = add_rn(s, b[q]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          for (int e = 0; e < nn; ++e) s = add_rn(s, t[e * DT]);
+        }
+      }
+      lds_barrier();
+    }
+  }
+  // the epilogue works on float4s: hand the column sums over through tile 0
+  if (summer && tid < D) reinterpret_cast<float *>(tile0)[tid] = s;
+  lds_barrier();
+  if (tid < D4w) {
+    float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (z && (!z_bits || row_bit(z_bits, r))) zrow = reinterpret_cast<const float4 *>(z)[(size_t)r * D4 + c0 + tid];
+    rowlist_epilogue(r, D4, c0 + tid, tile0[tid], alpha, z, beta, zrow, y, mean);
+  }
+  lds_barrier();
+}
+
+// STRIPED rows (round 6).  One workgroup moves ~50 GB/s of gathered rows (two teams x 64 KiB in flight, ~2.5 us a round trip),
+// so a popular item's 2e5 entries x 512 B took 2 ms however many other workgroups sat idle -- the whole of a light step's
+// launch over its batch's rows (0.11 of the HBM rate).  The ORDER of a row's sum cannot be cut, its COLUMNS can: a row above
+// `vt` entries is taken by D4 / 8 workgroups, each gathering one 128-byte stripe (8 float4 = a whole cache line) of every
+// source row and summing its 32 columns in entry order -- the same chain per output element, bit for bit, with D4 / 8 times
+// the bytes in flight.  (The chain itself, one dependent add per entry, is what is left: ~0.4 ms for 2e5 entries.)
+constexpr int kStripeW = 8;             // float4 per stripe
+constexpr int64_t kStripeListCap = 65536;   // lists above this many rows are not striped (see chaorec_spmm_csr_rowlist_f32)
 template <int LPR, int T>
 __global__ __launch_bounds__((ws_summer_waves<LPR>() + 4 * T) * 64) void spmm_rowlist_long_ws_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ x, float *__restrict__ y, int D4, float alpha, const float *z, float beta,
     const uint32_t *__restrict__ z_bits, const ListMean mean, const LongRows lr) {
   extern __shared__ float4 ws_tiles[];
-  constexpr int SW = ws_summer_waves<LPR>(), LW = 4, K = 16;
-  constexpr int NGB = LW * 64 / LPR;      // lane groups per loader team
-  constexpr int CH = NGB * K;             // entries per round (256 / 128 / 64 for D4 = 16 / 32 / 64): a 64 KiB tile
-  constexpr int DT = 4 * LPR;
-  const int tid = threadIdx.x, wave = tid >> 6;
-  const bool summer = wave < SW;
-  const int team = summer ? -1 : (wave - SW) / LW;
-  const int lt = summer ? 0 : tid - (SW + team * LW) * 64;      // thread index inside its team
-  const int g = lt / LPR, li = lt % LPR;
-  const int lic = min(li, D4 - 1);
-  const int D = 4 * D4;
-  float4 *tile0 = ws_tiles, *tile1 = ws_tiles + CH * LPR;
+  constexpr int SW = ws_summer_waves<LPR>();
+  constexpr int CHF = (4 * 64 / LPR) * 16;     // entries per round of a full-width row (a 64 KiB tile either way)
+  float4 *tile0 = ws_tiles, *tile1 = ws_tiles + CHF * LPR;
+  const int tid = threadIdx.x;
   const int64_t n = min((int64_t)lr.cnt[0], lr.cap);
+  const int64_t nv = min((int64_t)lr.cnt[2], lr.cap - n);
   const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
+  // the striped rows first (the launch's longest pieces of work): item = (row, stripe), stripes of a row on neighbouring ids
+  const int S = D4 / kStripeW;
+  for (int64_t it = blockIdx.x; it < nv * S; it += gridDim.x) {
+    const int64_t r = lr.list[lr.cap - 1 - it / S];
+    const int c0 = (int)(it % S) * kStripeW;
+    const int64_t e0 = rowptr[r];
+    const int deg = (int)(rowptr[r + 1] - e0);
+    long_ws_row<kStripeW, T, SW>(col, val, x4 + c0, y, D4, kStripeW, c0, alpha, z, beta, z_bits, mean, r, e0, deg, tile0, tile1);
+  }
   for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
     const int64_t r = lr.list[i];
     const int64_t e0 = rowptr[r];
     const int deg = (int)(rowptr[r + 1] - e0);
-    const int rounds = (deg + CH - 1) / CH;
-    float s = 0.f;                        // (summing waves: column tid of the running sum)
-    int cn[K];
-    float4 xv[K];
-    float vv[K];
-    if (!summer) {                        // the team's first round (= its number), and the columns of its second
-#pragma unroll
-      for (int k = 0; k < K; ++k) cn[k] = col[e0 + min(team * CH + g * K + k, deg - 1)];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        xv[k] = x4[(size_t)cn[k] * (size_t)D4 + lic];
-        vv[k] = val[e0 + min(team * CH + g * K + k, deg - 1)];
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) cn[k] = col[e0 + min((team + T) * CH + g * K + k, deg - 1)];
-    }
-    for (int pb = 0; pb < rounds + 1; pb += T) {
-#pragma unroll
-      for (int tt = 0; tt < T; ++tt) {
-        const int p = pb + tt;            // phase p: round p is parked, round p - 1 is summed
-        if (!summer && team == tt && p < rounds) {
-          float4 *tw = (p & 1) ? tile1 : tile0;
-#pragma unroll
-          for (int k = 0; k < K; ++k) tw[(g * K + k) * LPR + li] = mul_rn4(vv[k], xv[k]);
-#pragma unroll
-          for (int k = 0; k < K; ++k) {   // the team's next round (p + T): clamped past the row's end, never summed
-            xv[k] = x4[(size_t)cn[k] * (size_t)D4 + lic];
-            vv[k] = val[e0 + min((p + T) * CH + g * K + k, deg - 1)];
-          }
-#pragma unroll
-          for (int k = 0; k < K; ++k) cn[k] = col[e0 + min((p + 2 * T) * CH + g * K + k, deg - 1)];
-        }
-        if (summer && p >= 1 && p - 1 < rounds && tid < D) {
-          const float *t = reinterpret_cast<const float *>(((p - 1) & 1) ? tile1 : tile0) + tid;
-          const int nn = min(CH, deg - (p - 1) * CH);
-          if (nn == CH) {
-#pragma unroll 16
-            for (int e = 0; e < CH; ++e) s = add_rn(s, t[e * DT]);
-          } else {
-            for (int e = 0; e < nn; ++e) s = add_rn(s, t[e * DT]);
-          }
-        }
-        lds_barrier();
-      }
-    }
-    // the epilogue works on float4s: hand the column sums over through tile 0
-    if (summer && tid < D) reinterpret_cast<float *>(tile0)[tid] = s;
-    lds_barrier();
-    if (tid < D4) {
-      float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (z && (!z_bits || row_bit(z_bits, r))) zrow = reinterpret_cast<const float4 *>(z)[(size_t)r * D4 + tid];
-      rowlist_epilogue(r, D4, tid, tile0[tid], alpha, z, beta, zrow, y, mean);
-    }
-    lds_barrier();
+    long_ws_row<LPR, T, SW>(col, val, x4, y, D4, D4, 0, alpha, z, beta, z_bits, mean, r, e0, deg, tile0, tile1);
   }
   if (tid == 0) {
     __threadfence();
     if (atomicAdd(lr.cnt + 1, 1) == (int)gridDim.x - 1) {
       lr.cnt[0] = 0;
       lr.cnt[1] = 0;
+      lr.cnt[2] = 0;
     }
   }
 }
@@ -1379,6 +1444,18 @@ extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t
   }
   LongRows lr;
   lr.list = long_list, lr.cnt = long_cnt, lr.cap = long_cap, lr.t = long_threshold;
+  static const int teams = [] {
+    const char *e = std::getenv("CHAOREC_ROWLIST_LONG_TEAMS");
+    return (e && std::atoi(e) == 0) ? 0 : 2;      // (three teams: 128 VGPRs at 14 waves per workgroup, spills, slower)
+  }();
+  // striped rows: only the ungated long-row launch with specialised waves takes them, and only whole stripes
+  const char *se = std::getenv("CHAOREC_ROWLIST_STRIPE_T");      // (read per call: the tests move it; 0: none)
+  const int stripe_t = (se && *se) ? std::atoi(se) : 8192;
+  // ... and only a launch over a SHORT list (a batch's rows: a few hundred long rows, the longest of them the launch's tail).  A
+  // long list (N1: 1e5 long rows) keeps every workgroup busy at the HBM rate anyway, and stripes there cost 1.1 ms of 13.4
+  // (configs[4] whole; 128-byte pieces instead of whole 512-byte rows).
+  lr.vt = (!src_bits && teams && stripe_t > 0 && D4 % kStripeW == 0 && D4 > kStripeW && list_cap <= kStripeListCap)
+              ? std::max(stripe_t, long_threshold) : INT_MAX;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(2048), block(256);        // a fixed grid striding over the device-side list
 #define CHAOREC_ROWLIST_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, src_bits, z_bits, list, list_n, list_cap, mean, lr
@@ -1396,10 +1473,6 @@ extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t
     return check_launch("spmm_rowlist_long_gated_kernel");
   }
 #define CHAOREC_ROWLIST_LONG_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, z_bits, mean, lr
-  static const int teams = [] {
-    const char *e = std::getenv("CHAOREC_ROWLIST_LONG_TEAMS");
-    return (e && std::atoi(e) == 0) ? 0 : 2;      // (three teams: 128 VGPRs at 14 waves per workgroup, spills, slower)
-  }();
   if (teams) {
     // specialised waves: T loader teams of 4 waves + the summing waves, two 64 KiB LDS tiles (dynamic: above the 64 KiB of
     // static LDS a kernel may declare)

@@ -216,11 +216,11 @@ ROWLIST_LONG_T = int(os.environ.get("CHAOREC_ROWLIST_LONG_T", "256"))
 
 
 def long_row_buffers(csr, threshold=None):
-    """(list int32 [number of rows above the threshold], counters int32 [2] zero, threshold) for spmm_rowlist_raw's long_rows."""
+    """(list int32 [number of rows above the threshold], counters int32 [4] zero, threshold) for spmm_rowlist_raw's long_rows."""
     t = ROWLIST_LONG_T if threshold is None else int(threshold)
     n_long = int(((csr.rowptr[1:] - csr.rowptr[:-1]) > t).sum().item())
     dev = csr.rowptr.device
-    return torch.zeros(max(n_long, 1), dtype=torch.int32, device=dev), torch.zeros(2, dtype=torch.int32, device=dev), t
+    return torch.zeros(max(n_long, 1), dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev), t
 
 
 def spmm_rowlist_raw(csr, x, y, row_list, list_n, alpha=1.0, z=None, beta=0.0, src_bits=None, z_bits=None, mean_out=None,
@@ -390,7 +390,8 @@ def layer_mean_propagate(x0, csr, n_layers):
 # The BPR backward launches of the autograd nodes below: "ordered" (default) = one owner wave per gradient row, contributions
 # added in a fixed order, no atomics -- a training step is then reproducible bit for bit from run to run; CHAOREC_BPR_ORDERED=0
 # = fp32 atomic row adds (order-dependent from three addends per element on: tools/stream_stress.py).
-BPR_ORDERED = os.environ.get("CHAOREC_BPR_ORDERED", "1") == "1"
+# (2: the fused LightGCN steps' in-launch row adds go through the ordered launch as well -- read by the library, csrc/bpr.hip)
+BPR_ORDERED = os.environ.get("CHAOREC_BPR_ORDERED", "1") != "0"
 
 
 class _BPR(torch.autograd.Function):

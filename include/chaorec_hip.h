@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CHAOREC_ABI_VERSION 15  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
+#define CHAOREC_ABI_VERSION 16  /* 2: gemm workspace, score stats, rank metrics; 3: edge dropout, weighted sampling,
                                   row cosine, two-pass reductions, BPR forward with the batch drawn in the launch,
                                   SpMM dynamic-values mode, gemm act 2, 256-B aligned score workspace;
                                   4: SpMM with the Adam update in its epilogue, BPR forward + backward in one launch,
@@ -50,7 +50,8 @@ extern "C" {
                                   13: scoring: CHAOREC_SCORE_FRONT / _BACK (one call as two phases), a raised-threshold pass for
                                       users whose candidate lists overflow (long item ranges), chaorec_score_topk_stats out10;
                                   14: chaorec_edge_dot_f32 (edge scores over a CSR's entries);
-                                  15: ordered (atomic-free, run-to-run reproducible) BPR backward launches */
+                                  15: ordered (atomic-free, run-to-run reproducible) BPR backward launches;
+                                  16: chaorec_spmm_csr_rowlist_f32's long_cnt is int32[4] (column-striped very long rows) */
 
 #define CHAOREC_OK 0
 #define CHAOREC_E_INVALID (-1)     /* bad argument (NULL, negative size, unsupported D/K) */
@@ -190,10 +191,11 @@ int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, cons
                                  int32_t *long_list, int32_t *long_cnt, int64_t long_cap, int32_t long_threshold,
                                  void *stream);
 /* long_list / long_cnt (optional): listed rows with more than long_threshold entries are deferred to long_list (long_cap
- * entries; long_cnt: int32[2], zero on entry and zero again afterwards) and computed by a second launch with one WORKGROUP
- * per row instead of being the tail of a 16..64-lane group (a popular item's row has 1e4-1e5 entries): without src_bits
- * (a forward propagate of a light step: every entry gathered) the gathers are shared by 256 threads and the products summed
- * in entry order through an LDS tile; with src_bits (the backward's first propagate) the workgroup scans 1024 entries per
+ * entries; long_cnt: int32[4] since ABI 16, zero on entry and zero again afterwards) and computed by a second launch with one
+ * WORKGROUP per row instead of being the tail of a 16..64-lane group (a popular item's row has 1e4-1e5 entries): without
+ * src_bits (a forward propagate of a light step: every entry gathered) the gathers are shared by 256 threads and the products
+ * summed in entry order through an LDS tile -- and a row above 8192 entries (CHAOREC_ROWLIST_STRIPE_T) by D / 32 workgroups,
+ * one per 128-byte column stripe: the same chain of adds per output element, D / 32 times the bytes in flight; with src_bits (the backward's first propagate) the workgroup scans 1024 entries per
  * round and queues the few flagged ones in entry order for one lane group to gather and add -- the sequential CSR-order sum
  * either way. */
 

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# The fused LightGCN steps add their batch-gradient rows with fp32 atomics by default (one launch for forward and backward); the
+# order of those adds moves with the load on the chip, two runs then differ in the last bit of a few gradient elements and Adam's
+# first steps amplify that -- which is how tests that compare two separately run trainings failed once in a few suite runs (rounds
+# 5 and 6: never alone, 1 of 3 inside the suite).  The suite therefore runs those steps with the ordered launch
+# (CHAOREC_BPR_ORDERED=2, inherited by the worker processes it spawns); tests/test_gpu_fused_step.py keeps the DEFAULT (atomic)
+# fused path under test, with the tolerance that path needs.
+os.environ.setdefault("CHAOREC_BPR_ORDERED", "2")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

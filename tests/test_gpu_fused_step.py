@@ -31,10 +31,13 @@ def _pair(dev, U, I, edges, D, L, seed=0):
     return out
 
 
-@pytest.mark.parametrize("D,L,capture", [(64, 3, True), (64, 3, False), (64, 2, True), (64, 1, True), (128, 3, True),
-                                         (32, 2, False)])
-def test_fused_step_equals_ordinary_step(dev, D, L, capture):
+@pytest.mark.parametrize("D,L,capture,ordered", [(64, 3, True, "1"), (64, 3, False, "1"), (64, 2, True, "2"), (64, 1, True, "2"),
+                                                 (128, 3, True, "1"), (32, 2, False, "2")])
+def test_fused_step_equals_ordinary_step(dev, D, L, capture, ordered, monkeypatch):
+    """ordered "1": the product's default -- the fused launch adds its gradient rows with fp32 atomics (the tolerance below is
+    theirs); "2": through the ordered launch."""
     from chaorec_amd.optim import FusedLightGCNStep
+    monkeypatch.setenv("CHAOREC_BPR_ORDERED", ordered)
     d = load_interactions("baby")
     U, I, edges = d["U"], d["I"], d["train"]
     (ref, oref), (fus, ofus) = _pair(dev, U, I, edges, D, L)

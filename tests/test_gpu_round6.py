@@ -279,3 +279,56 @@ def test_fused_lightgcn_step_with_the_ordered_backward_is_reproducible_and_is_th
         o.step()
     w = torch.cat((m.user_embedding.weight, m.item_embedding.weight)).detach()
     assert torch.equal(a, w), float((a - w).abs().max())
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_rowlist_striped_rows_are_the_dense_rows_bit_for_bit(dev, D, monkeypatch):
+    """A list launch's very long rows go to D / 32 workgroups each, one per 128-byte column stripe (csrc/spmm.hip,
+    spmm_rowlist_long_ws_kernel): the per-element chain of adds is untouched, so the rows -- with alpha / beta z and with the
+    layer-mean epilogue -- are the dense launch's bit for bit.  A graph with a few items of 1 500-6 000 entries, the stripe
+    threshold lowered to 1 000: rows below (long, one workgroup), above (striped) and short rows in one launch."""
+    from chaorec_amd import graph, ops
+    monkeypatch.setenv("CHAOREC_ROWLIST_STRIPE_T", "1000")
+    rng = np.random.default_rng(5)
+    U, I = 7000, 300
+    heavy = {0: 6000, 1: 3100, 2: 1500, 3: 1001, 4: 1000, 5: 700, 6: 300}
+    pairs = [np.stack([rng.choice(U, d, replace=False), np.full(d, i)], 1) for i, d in heavy.items()]
+    pairs.append(np.stack([rng.integers(0, U, 9000), rng.integers(7, I, 9000)], 1))
+    e = np.unique(np.concatenate(pairs), axis=0)
+    edges = np.stack([e[:, 0], e[:, 1] + U], 1).astype(np.int32)
+    csr = graph.lightgcn_csr(edges, U + I).to(dev)
+    N = U + I
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(N, D, device=dev, generator=gen) * 0.1
+    z = torch.randn(N, D, device=dev, generator=gen) * 0.1
+    t0 = torch.randn(N, D, device=dev, generator=gen) * 0.1
+    rows = np.unique(np.concatenate([U + np.arange(7), rng.integers(0, N, 150)])).astype(np.int32)
+    lst = torch.from_numpy(rows).to(dev)
+    n = torch.tensor([len(rows)], dtype=torch.int32, device=dev)
+    long_rows = ops.long_row_buffers(csr, 256)
+    deg = (csr.rowptr[1:] - csr.rowptr[:-1]).cpu().numpy()
+    assert (deg[rows] > 1000).sum() >= 4 and ((deg[rows] > 256) & (deg[rows] <= 1000)).sum() >= 3
+    want = ops.spmm_raw(csr, x, y=torch.empty_like(x), alpha=0.7, z=z, beta=0.3)
+    got = torch.full_like(x, float("nan"))
+    ops.spmm_rowlist_raw(csr, x, got, lst, n, alpha=0.7, z=z, beta=0.3, long_rows=long_rows)
+    torch.cuda.synchronize()
+    assert int(long_rows[1].abs().sum()) == 0                                   # counters left clean (the striped one too)
+    sel = torch.from_numpy(rows.astype(np.int64)).to(dev)
+    assert torch.equal(got[sel], want[sel])
+    rest = torch.ones(N, dtype=torch.bool, device=dev)
+    rest[sel] = False
+    assert bool(torch.isnan(got[rest]).all())
+    # the layer-mean epilogue: ((w t0 + w x) + w (A x)) in the rows of the list
+    w = 1.0 / 3.0
+    mean_want = torch.empty_like(x)
+    ops.spmm_mean_raw(csr, x, [t0, x], w, mean_want)
+    mean_got = torch.full_like(x, float("nan"))
+    ops.spmm_rowlist_raw(csr, x, None, lst, n, mean_out=mean_got, mean_terms=[t0, x], mean_w=w, long_rows=long_rows)
+    torch.cuda.synchronize()
+    assert torch.equal(mean_got[sel], mean_want[sel])
+    # and without stripes: the same bits
+    monkeypatch.setenv("CHAOREC_ROWLIST_STRIPE_T", "0")
+    again = torch.full_like(x, float("nan"))
+    ops.spmm_rowlist_raw(csr, x, again, lst, n, alpha=0.7, z=z, beta=0.3, long_rows=long_rows)
+    torch.cuda.synchronize()
+    assert torch.equal(again[sel], got[sel])

@@ -25,7 +25,7 @@ def test_abi_exports_every_declared_symbol():
     for name, args in re.findall(r"\b(chaorec_\w+)\s*\(([^;{]*?)\)\s*;", plain):
         n_args = 0 if args.strip() in ("", "void") else args.count(",") + 1
         assert len(_lib.SIGNATURES[name][1]) == n_args, f"{name}: ctypes argtypes vs header"
-    assert _lib.load().chaorec_abi_version() == _lib.ABI_VERSION == 15
+    assert _lib.load().chaorec_abi_version() == _lib.ABI_VERSION == 16
     assert _lib.load().chaorec_spmm_rows_per_wave(64) == 4
     assert _lib.load().chaorec_spmm_rows_per_wave(128) == 2
     assert _lib.load().chaorec_score_topk_workspace_bytes(28940, 15207, 50, 64) > 0
