@@ -36,6 +36,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // 128-wide tiles: waves as 2 x 2 of 64 x 64 instead of 4 x 1 of 32 x 128 (12 LDS fragment reads per 24 MFMAs instead of 15:
 // 768 x 768 x 60 499 TN 683 -> 658 us, NT 552 -> 546 us; same bits)
 constexpr bool kWave2x2 = CHAOREC_X3_WAVE2X2 != 0;
+#ifndef CHAOREC_X3_PF2
+#define CHAOREC_X3_PF2 0
+#endif
+constexpr bool kPrefetch2 = CHAOREC_X3_PF2 != 0;    // 128-wide tiles: two k-tiles of operands in flight (see the main loop; measured SLOWER)
 constexpr int XBM = 128, XBK = 32, XPAD = 8;   // (row stride 40 bf16 = 80 B: 16-B aligned, banks skewed)
 // N tile: 64 (the skinny projections, N = 64: one tile covers the output's width) or 128 (wide outputs: every staged and
 // split A element then feeds twice the MFMAs -- the three-plane split is VALU work of the same order as the MFMA time)
@@ -323,13 +327,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
     }
   };
 
-  auto stash = [&]() __attribute__((always_inline)) { stash_from(ra, rb); };
-  if (kb < ke) fetch(kb);
-  for (int64_t k0 = kb; k0 < ke; k0 += XBK) {
-    __syncthreads();                              // the previous tile's fragment reads are done
-    stash();
-    __syncthreads();
-    if (k0 + XBK < ke) fetch(k0 + XBK);           // next tile's loads fly under this tile's MFMAs
+  // the MFMAs of the k-tile that lies in LDS
+  auto multiply = [&]() __attribute__((always_inline)) {
     if constexpr (XBN == 128 && kWave2x2) {
       // 2 x 2 waves of 64 x 64 (accumulator j = 2 i + jj: rows 64 (wave / 2) + 32 i, columns 64 (wave % 2) + 32 jj): two A
       // and two B fragments per plane feed the four accumulators -- 12 LDS reads per 24 MFMAs instead of 15
@@ -359,33 +358,65 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float *__restric
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i][0].v, b2[jj][0].v, acc[j], 0, 0, 0);
           }
       }
-      continue;
-    }
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < XBK; ks += 16) {
-      Frag8 a[3], b[NJ][3];
+      for (int ks = 0; ks < XBK; ks += 16) {
+        Frag8 a[3], b[NJ][3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        // LDS row of tile row (32 wave + r) resp. (32 j + r): the identity, or the TN stash's permutation
-        const int arow = TA ? (r & 3) * 32 + wave * 8 + (r >> 2) : wave * 32 + r;
-        a[pl].u = *reinterpret_cast<const uint4 *>(&As[pl][arow][ks + 8 * h]);
+        for (int pl = 0; pl < 3; ++pl) {
+          // LDS row of tile row (32 wave + r) resp. (32 j + r): the identity, or the TN stash's permutation
+          const int arow = TA ? (r & 3) * 32 + wave * 8 + (r >> 2) : wave * 32 + r;
+          a[pl].u = *reinterpret_cast<const uint4 *>(&As[pl][arow][ks + 8 * h]);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            // (TN: tile row 32 j + r lies in the 64-row half j / 2, at 64 (j / 2) + 16 (r & 3) + 8 (j & 1) + (r >> 2))
+            const int brow = TB ? 64 * (j >> 1) + (r & 3) * 16 + (j & 1) * 8 + (r >> 2) : j * 32 + r;
+            b[j][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][brow][ks + 8 * h]);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          // (TN: tile row 32 j + r lies in the 64-row half j / 2, at 64 (j / 2) + 16 (r & 3) + 8 (j & 1) + (r >> 2))
-          const int brow = TB ? 64 * (j >> 1) + (r & 3) * 16 + (j & 1) * 8 + (r >> 2) : j * 32 + r;
-          b[j][pl].u = *reinterpret_cast<const uint4 *>(&Bs[pl][brow][ks + 8 * h]);
+          // smallest products first (0 = h, 1 = m, 2 = l)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[j][1].v, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, b[j][0].v, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][2].v, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[j][0].v, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][1].v, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][0].v, acc[j], 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        // smallest products first (0 = h, 1 = m, 2 = l)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[j][1].v, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, b[j][0].v, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][2].v, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[j][0].v, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][1].v, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[j][0].v, acc[j], 0, 0, 0);
+    }
+  };
+  if constexpr (kPrefetch2 && XBN == 128) {
+    // TWO k-tiles in flight in registers (round 6 experiment, off: -DCHAOREC_X3_PF2=1 builds it).  The idea: a tile's loads
+    // are issued under the previous tile's MFMAs, ~0.65 us of them, and an HBM round trip under load is longer.  Measured
+    // (tools/gemm_wide_bench.py, 252 VGPRs instead of 220, no spills, still two waves per SIMD): 60 499 x 772 x 768 NT 604 ->
+    // 696 us, TN 564 -> 694 us, MMGCN's step 3.57 -> 3.90 ms.  The loads' latency is not what the k-tile waits for.
+    float4 ra1[4], rb1[NB];
+    if (kb < ke) fetch_into(kb, ra, rb);
+    if (kb + XBK < ke) fetch_into(kb + XBK, ra1, rb1);
+    for (int64_t k0 = kb; k0 < ke; k0 += 2 * XBK) {
+      __syncthreads();                            // the previous tile's fragment reads are done
+      stash_from(ra, rb);
+      __syncthreads();
+      if (k0 + 2 * XBK < ke) fetch_into(k0 + 2 * XBK, ra, rb);
+      multiply();
+      if (k0 + XBK < ke) {                        // (block-uniform)
+        __syncthreads();
+        stash_from(ra1, rb1);
+        __syncthreads();
+        if (k0 + 3 * XBK < ke) fetch_into(k0 + 3 * XBK, ra1, rb1);
+        multiply();
       }
+    }
+  } else {
+    if (kb < ke) fetch(kb);
+    for (int64_t k0 = kb; k0 < ke; k0 += XBK) {
+      __syncthreads();                              // the previous tile's fragment reads are done
+      stash_from(ra, rb);
+      __syncthreads();
+      if (k0 + XBK < ke) fetch(k0 + XBK);           // next tile's loads fly under this tile's MFMAs
+      multiply();
     }
   }
 

@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void long_ws_row(const int32_t *__restrict__ col, con
 // source row and summing its 32 columns in entry order -- the same chain per output element, bit for bit, with D4 / 8 times
 // the bytes in flight.  (The chain itself, one dependent add per entry, is what is left: ~0.4 ms for 2e5 entries.)
 constexpr int kStripeW = 8;             // float4 per stripe
-constexpr int64_t kStripeListCap = 65536;   // lists above this many rows are not striped (see chaorec_spmm_csr_rowlist_f32)
+constexpr int64_t kStripeListCap = 65536;   // lists above this many rows stripe four times later (see chaorec_spmm_csr_rowlist_f32)
 template <int LPR, int T>
 __global__ __launch_bounds__((ws_summer_waves<LPR>() + 4 * T) * 64) void spmm_rowlist_long_ws_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
@@ -1451,11 +1451,14 @@ extern "C" int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t
   // striped rows: only the ungated long-row launch with specialised waves takes them, and only whole stripes
   const char *se = std::getenv("CHAOREC_ROWLIST_STRIPE_T");      // (read per call: the tests move it; 0: none)
   const int stripe_t = (se && *se) ? std::atoi(se) : 8192;
-  // ... and only a launch over a SHORT list (a batch's rows: a few hundred long rows, the longest of them the launch's tail).  A
-  // long list (N1: 1e5 long rows) keeps every workgroup busy at the HBM rate anyway, and stripes there cost 1.1 ms of 13.4
-  // (configs[4] whole; 128-byte pieces instead of whole 512-byte rows).
-  lr.vt = (!src_bits && teams && stripe_t > 0 && D4 % kStripeW == 0 && D4 > kStripeW && list_cap <= kStripeListCap)
-              ? std::max(stripe_t, long_threshold) : INT_MAX;
+  // A launch over a SHORT list (a batch's rows: a few hundred long rows, the longest of them the launch's tail) stripes from
+  // stripe_t entries on.  A long list (N1: 2e4 long rows) keeps every workgroup busy near the HBM rate anyway; there only the
+  // very longest rows are worth it, the ones whose single workgroup would still be walking when the rest is done (configs[4]
+  // whole, forward over N1's list, tools/rowlist_n1_bench.py: 13.8 ms without stripes, 13.3 / 12.9 / 13.0 / 13.3 ms with
+  // stripes above 16 / 32 / 64 / 128 K entries).
+  const int st_eff = list_cap <= kStripeListCap ? stripe_t : 4 * stripe_t;
+  lr.vt = (!src_bits && teams && st_eff > 0 && D4 % kStripeW == 0 && D4 > kStripeW)
+              ? std::max(st_eff, long_threshold) : INT_MAX;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(2048), block(256);        // a fixed grid striding over the device-side list
 #define CHAOREC_ROWLIST_ARGS rowptr, col, val, x, y, D4, alpha, z, beta, src_bits, z_bits, list, list_n, list_cap, mean, lr

@@ -195,7 +195,8 @@ int chaorec_spmm_csr_rowlist_f32(const int64_t *rowptr, const int32_t *col, cons
  * WORKGROUP per row instead of being the tail of a 16..64-lane group (a popular item's row has 1e4-1e5 entries): without
  * src_bits (a forward propagate of a light step: every entry gathered) the gathers are shared by 256 threads and the products
  * summed in entry order through an LDS tile -- and a row above 8192 entries (CHAOREC_ROWLIST_STRIPE_T) by D / 32 workgroups,
- * one per 128-byte column stripe: the same chain of adds per output element, D / 32 times the bytes in flight; with src_bits (the backward's first propagate) the workgroup scans 1024 entries per
+ * one per 128-byte column stripe (a list of more than 65 536 rows: above four times that): the same chain of adds per output
+ * element, D / 32 times the bytes in flight; with src_bits (the backward's first propagate) the workgroup scans 1024 entries per
  * round and queues the few flagged ones in entry order for one lane group to gather and add -- the sequential CSR-order sum
  * either way. */
 

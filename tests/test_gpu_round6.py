@@ -326,6 +326,13 @@ def test_rowlist_striped_rows_are_the_dense_rows_bit_for_bit(dev, D, monkeypatch
     ops.spmm_rowlist_raw(csr, x, None, lst, n, mean_out=mean_got, mean_terms=[t0, x], mean_w=w, long_rows=long_rows)
     torch.cuda.synchronize()
     assert torch.equal(mean_got[sel], mean_want[sel])
+    # a LONG list (capacity above 65 536 rows: stripes from four times the threshold on -- here the 6 000-entry row only)
+    big = torch.zeros(70000, dtype=torch.int32, device=dev)
+    big[:len(rows)] = lst
+    longl = torch.full_like(x, float("nan"))
+    ops.spmm_rowlist_raw(csr, x, longl, big, n, alpha=0.7, z=z, beta=0.3, long_rows=long_rows)
+    torch.cuda.synchronize()
+    assert torch.equal(longl[sel], want[sel]) and int(long_rows[1].abs().sum()) == 0
     # and without stripes: the same bits
     monkeypatch.setenv("CHAOREC_ROWLIST_STRIPE_T", "0")
     again = torch.full_like(x, float("nan"))
