@@ -40,6 +40,34 @@ constexpr int kDescDwords = 16;  // 64-B descriptor: row, deg|flag, e0 lo/hi, 6 
 #ifndef CHAOREC_SPMM_MINW
 #define CHAOREC_SPMM_MINW 1
 #endif
+// The GATED instantiations at D >= 128 (SP, the backward launches of a light step over a large graph) trade gathers in flight
+// per wave for WAVES in flight: 4 instead of 8 source rows per group and step, a quarter of the long-row tile, and a register
+// budget of SEVEN waves per SIMD instead of the four the compiler settles at when left alone (126 VGPRs; 72 with two spilled).
+// Their time is a latency chain per row -- descriptor -> (col, val) -> bitmap -> gather -> store, 11 ms of it at BASELINE
+// configs[4] whole with not one source flagged -- that only more rows in flight shorten (tools/gated_bench.py, that launch):
+//     4 waves (rounds 3-6)  24.7 ms  0.46 of the HBM peak        6 waves (tile / 2)   20.4 ms  0.556
+//     5 waves               21.8-22.0                            7 waves (tile / 4)   19.0 ms  0.598
+//     8 waves (22 spills)   26.3                                 6 waves, 8 gathers in flight (37 spills)  24.3
+// The dense launches gain 1-2 % from such settings at D = 128 and lose 20-45 % at D = 64 (sports, cache resident): they keep
+// theirs.  CHAOREC_SPMM_SP_HIOCC=0: the rounds 3-6 form.
+#ifndef CHAOREC_SPMM_SP_HIOCC
+#define CHAOREC_SPMM_SP_HIOCC 1
+#endif
+#ifndef CHAOREC_SPMM_SP_UNR
+#define CHAOREC_SPMM_SP_UNR 4
+#endif
+#ifndef CHAOREC_SPMM_SP_UH
+#define CHAOREC_SPMM_SP_UH 2
+#endif
+#ifndef CHAOREC_SPMM_SP_MINW
+#define CHAOREC_SPMM_SP_MINW 7
+#endif
+template <int LPR, bool SP>
+constexpr bool spmm_hi_occ() { return CHAOREC_SPMM_SP_HIOCC && SP && LPR >= 32; }
+// (D >= 128 otherwise: at least four waves per SIMD -- the Adam instantiation took 140 VGPRs = three waves when left alone;
+//  held to 128 the configs[4] launch with the Adam epilogue goes 41.1 -> 39.0 ms)
+template <int LPR, bool SP>
+constexpr int spmm_min_waves() { return spmm_hi_occ<LPR, SP>() ? CHAOREC_SPMM_SP_MINW : (LPR >= 32 && CHAOREC_SPMM_MINW < 4 ? 4 : CHAOREC_SPMM_MINW); }
 
 // Adam epilogue (ADAM instantiations): the row this group just produced is the GRADIENT of row r of a parameter
 // table -- the last backward propagate of a LightGCN step, g_0 = A^T g_1 + w G -- and the optimizer update of that
@@ -79,7 +107,7 @@ struct RowSparse {
 __device__ __forceinline__ bool row_bit(const uint32_t *bits, int64_t r) { return (bits[r >> 5] >> (r & 31)) & 1u; }
 
 template <int LPR, int CPL, bool ADAM, bool SP = false>
-__global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kernel(
+__global__ __launch_bounds__(256, (spmm_min_waves<LPR, SP>())) void spmm_csr_ordered_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, const float *__restrict__ x, float *__restrict__ y,
     int64_t n_rows, int D4, float alpha, const float *z, float beta,
@@ -94,7 +122,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
         for (int64_t i = gt; i < sa.n_clear[w]; i += gs) sa.clear[w][i] = 0u;
   }
   constexpr int NG = kWave / LPR;   // lane groups = destination rows per wave
-  constexpr int UNR = CHAOREC_SPMM_UNR;  // gathered rows in flight per group (short-row phase)
+  constexpr int UNR = spmm_hi_occ<LPR, SP>() ? CHAOREC_SPMM_SP_UNR : CHAOREC_SPMM_UNR;  // gathered rows in flight per group (short-row phase)
   constexpr int UNR2 = (kWave / NG) < 16 ? (kWave / NG) : 16;  // per group in the long-row phase
   constexpr int LONG_T = CHAOREC_SPMM_LONG_T;  // rows above this are walked by the whole wave
   const int lane = threadIdx.x & 63;
@@ -341,7 +369,7 @@ __global__ __launch_bounds__(256, CHAOREC_SPMM_MINW) void spmm_csr_ordered_kerne
 #ifndef CHAOREC_SPMM_UH
 #define CHAOREC_SPMM_UH 8
 #endif
-    constexpr int UH = CHAOREC_SPMM_UH;
+    constexpr int UH = spmm_hi_occ<LPR, SP>() ? CHAOREC_SPMM_SP_UH : CHAOREC_SPMM_UH;
     constexpr int HALF = NG * UH;       // entries per chunk (32 for D=64, 16 for D=128)
     constexpr int FPL = LPR * 4 / 64;   // features per lane in the ordered sum (1 or 2)
     constexpr int MAXL = 4 * NG;        // rows per block
@@ -749,8 +777,8 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
                                                               int64_t n_out_rows, uint32_t *bits_out, int32_t *list,
                                                               int32_t *list_n, int64_t list_cap) {
   // One WORKGROUP per pair of bitmap words (most pairs are empty: a load and an exit); a flagged row's entries are walked by
-  // all 256 threads, two per thread in flight -- a popular item's row has 1e4-1e5 entries, and the `old` value of every
-  // atomicOr is needed (the list), so each step of the walk is a round trip.
+  // all 256 threads -- a popular item's row has 1e4-1e5 entries, and the `old` value of every atomicOr is needed (the list),
+  // so each step of the walk is a round trip.
   const int lane = threadIdx.x;
   const int64_t wave = blockIdx.x;
   const int64_t n_self_words = bits_self ? (n_out_rows + 31) >> 5 : 0;
@@ -776,11 +804,29 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
       const int64_t r = wi * 32 + b;
       if (r >= n_rows) break;
       const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
-      for (int64_t e = e0 + lane; e < e1; e += 512) {
-        const int c0 = col[e];
-        const int c1 = e + 256 < e1 ? col[e + 256] : -1;
-        flag(c0);
-        if (c1 >= 0) flag(c1);
+      // (eight entries per thread in flight: a step of the walk is a round trip of returning atomics, and the most popular
+      //  item's 2e5 entries are walked by this one workgroup -- with two in flight they were 0.9 ms of every light step)
+#ifndef CHAOREC_EXPAND_EP
+#define CHAOREC_EXPAND_EP 8
+#endif
+      constexpr int EP = CHAOREC_EXPAND_EP;
+      for (int64_t e = e0 + lane; e < e1; e += 256 * EP) {
+        int c[EP];
+        uint32_t old[EP];
+#pragma unroll
+        for (int j = 0; j < EP; ++j) c[j] = e + 256 * j < e1 ? col[e + 256 * j] : -1;
+#pragma unroll
+        for (int j = 0; j < EP; ++j) {
+          old[j] = 0xFFFFFFFFu;
+          if (c[j] >= 0) old[j] = atomicOr(bits_out + (c[j] >> 5), 1u << (c[j] & 31));
+        }
+#pragma unroll
+        for (int j = 0; j < EP; ++j) {
+          if (c[j] >= 0 && list && !(old[j] & (1u << (c[j] & 31)))) {
+            const int at = atomicAdd(list_n, 1);
+            if (at < list_cap) list[at] = (int32_t)c[j];
+          }
+        }
       }
     }
   }
@@ -903,8 +949,19 @@ __device__ __forceinline__ void rowlist_epilogue(int64_t r, int D4, int li, floa
   }
 }
 
+// Eight waves per SIMD asked for (60 VGPRs with four gathers in flight per group instead of 88 with eight): the launches over
+// N1's list are latency chains per row like the gated launch above.  configs[4] whole, tools/rowlist_n1_bench.py: the backward's
+// first propagate 2.99 -> 2.24 ms, the forward over N1 13.05 -> 12.85 ms.  (Asking for seven gives the same register count and
+// NO gain -- 3.04-3.08 ms -- with 2, 4 or 6 gathers in flight alike: what the bound changes is the compiler's schedule, not
+// only the occupancy.)
+#ifndef CHAOREC_ROWLIST_MINW
+#define CHAOREC_ROWLIST_MINW 8
+#endif
+#ifndef CHAOREC_ROWLIST_UNR
+#define CHAOREC_ROWLIST_UNR 4
+#endif
 template <int LPR>
-__global__ __launch_bounds__(256) void spmm_rowlist_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+__global__ __launch_bounds__(256, CHAOREC_ROWLIST_MINW) void spmm_rowlist_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                            const float *__restrict__ val, const float *__restrict__ x,
                                                            float *__restrict__ y, int D4, float alpha, const float *z, float beta,
                                                            const uint32_t *__restrict__ src_bits,
@@ -912,7 +969,7 @@ __global__ __launch_bounds__(256) void spmm_rowlist_kernel(const int64_t *__rest
                                                            const int32_t *__restrict__ list_n, int64_t list_cap,
                                                            const ListMean mean, const LongRows lr) {
   constexpr int NG = kWave / LPR;
-  constexpr int UNR = 8;                  // gathered rows in flight per group (ungated walk)
+  constexpr int UNR = CHAOREC_ROWLIST_UNR;  // gathered rows in flight per group (ungated walk)
   const int lane = threadIdx.x & 63, sub = lane / LPR, li = lane % LPR;
   const int64_t n = min((int64_t)list_n[0], list_cap);
   const int64_t slots = (int64_t)gridDim.x * (blockDim.x >> 6) * NG;

@@ -57,6 +57,11 @@ t = timed(lambda: ops.spmm_raw(csr, x, y=y0, z=z, beta=0.5))
 print(f"   dense launch                  {t:8.3f} ms   {(nnz * (4.0 * D + 8) + N * (4.0 * D + 8)) / t / 1e6 / 8000:.3f} of 8 TB/s")
 t = timed(lambda: ops.spmm_rowsparse_raw(csr, x, y1, z=z, beta=0.5, src_bits=bits1, z_bits=bits0))
 print(f"   gated, bitmap probes          {t:8.3f} ms   {by / t / 1e6 / 8000:.3f}")
+if os.environ.get("ADAM"):
+    p_, m_, v_ = (torch.zeros(N, D, device=dev) for _ in range(3))
+    bc = torch.tensor([0.1, 0.001], device=dev)
+    t = timed(lambda: ops.spmm_adam_raw(csr, x, p_, m_, v_, bc, 1e-3, (0.9, 0.999), 1e-8, 0.0, alpha=1.0, z=z, beta=0.5))
+    print(f"   dense launch + Adam epilogue  {t:8.3f} ms   {(nnz * (4.0 * D + 8) + N * (4.0 * D + 8) + N * 4.0 * D * 7) / t / 1e6 / 8000:.3f}")
 if os.environ.get("KNOCKOUT"):
     ones = torch.full_like(bits1, -1)
     zeros = torch.zeros_like(bits1)

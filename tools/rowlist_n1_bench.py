@@ -49,6 +49,14 @@ def timed(fn, reps=6):
     return sorted(s.elapsed_time(e) for s, e in ev)[reps // 2]
 
 
+def expand():
+    bits1.zero_()
+    n1.zero_()
+    ops.expand_row_bits(csr, bits0, bits1, list1, n1)
+
+
+t = timed(expand)
+print(f"   expand_row_bits alone (+ two clears)      {t:8.3f} ms")
 t = timed(lambda: ops.spmm_rowlist_raw(csr, x, y, list1, n1, long_rows=long_rows))
 print(f"   forward over N1's list (ungated)          {t:8.3f} ms")
 t = timed(lambda: ops.spmm_rowlist_raw(csr, x, y, list1, n1, alpha=0.25, z=z, beta=0.25, src_bits=bits0, z_bits=bits0, long_rows=long_rows))
