@@ -779,6 +779,8 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
   // One WORKGROUP per pair of bitmap words (most pairs are empty: a load and an exit); a flagged row's entries are walked by
   // all 256 threads -- a popular item's row has 1e4-1e5 entries, and the `old` value of every atomicOr is needed (the list),
   // so each step of the walk is a round trip.
+  __shared__ int wtot[4];
+  __shared__ int wbase;
   const int lane = threadIdx.x;
   const int64_t wave = blockIdx.x;
   const int64_t n_self_words = bits_self ? (n_out_rows + 31) >> 5 : 0;
@@ -804,13 +806,15 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
       const int64_t r = wi * 32 + b;
       if (r >= n_rows) break;
       const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
-      // (eight entries per thread in flight: a step of the walk is a round trip of returning atomics, and the most popular
-      //  item's 2e5 entries are walked by this one workgroup -- with two in flight they were 0.9 ms of every light step)
+      // Eight entries per thread in flight (a step of the walk is a round trip of returning atomics), and ONE list-length
+      // atomic per workgroup and step: N1 has 3 M rows at BASELINE configs[4], and 3 M appends -- 45 k wave-aggregated adds --
+      // to one address queue up behind each other at its L2 channel (the expansion was 1.2 ms of every light step).
 #ifndef CHAOREC_EXPAND_EP
 #define CHAOREC_EXPAND_EP 8
 #endif
       constexpr int EP = CHAOREC_EXPAND_EP;
-      for (int64_t e = e0 + lane; e < e1; e += 256 * EP) {
+      for (int64_t eb = e0; eb < e1; eb += 256 * EP) {          // (block-uniform trip count: barriers inside)
+        const int64_t e = eb + lane;
         int c[EP];
         uint32_t old[EP];
 #pragma unroll
@@ -820,12 +824,34 @@ __global__ __launch_bounds__(256) void expand_row_bits_kernel(const int64_t *__r
           old[j] = 0xFFFFFFFFu;
           if (c[j] >= 0) old[j] = atomicOr(bits_out + (c[j] >> 5), 1u << (c[j] & 31));
         }
+        if (list) {                                             // (kernel-uniform)
+          int mine = 0;
 #pragma unroll
-        for (int j = 0; j < EP; ++j) {
-          if (c[j] >= 0 && list && !(old[j] & (1u << (c[j] & 31)))) {
-            const int at = atomicAdd(list_n, 1);
-            if (at < list_cap) list[at] = (int32_t)c[j];
+          for (int j = 0; j < EP; ++j) mine += (c[j] >= 0 && !(old[j] & (1u << (c[j] & 31)))) ? 1 : 0;
+          // exclusive prefix of `mine` over the workgroup: wave scan + the four wave totals through LDS
+          int incl = mine;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if ((lane & 63) >= d) incl += up;
           }
+          if ((lane & 63) == 63) wtot[lane >> 6] = incl;
+          __syncthreads();
+          if (lane == 0) {
+            const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            wbase = total ? atomicAdd(list_n, total) : 0;
+          }
+          __syncthreads();
+          int at = wbase + incl - mine;
+          for (int w = 0; w < (lane >> 6); ++w) at += wtot[w];
+#pragma unroll
+          for (int j = 0; j < EP; ++j) {
+            if (c[j] >= 0 && !(old[j] & (1u << (c[j] & 31)))) {
+              if (at < list_cap) list[at] = (int32_t)c[j];
+              ++at;
+            }
+          }
+          __syncthreads();                                      // (wtot / wbase are rewritten by the next step)
         }
       }
     }
@@ -855,13 +881,31 @@ __global__ __launch_bounds__(256) void zero_rows_by_bits_kernel(float *__restric
 __global__ __launch_bounds__(256) void rows_list_from_bits_kernel(const uint32_t *__restrict__ bits, int64_t n_rows,
                                                                   int64_t n_words, int32_t *list, int32_t *list_n,
                                                                   int64_t list_cap) {
+  // one list-length atomic per WORKGROUP (its 256 words' counts scanned through LDS): a 3 M-row frontier is 1e5 non-empty
+  // words, and as many adds to one address queue up at its L2 channel (see expand_row_bits_kernel)
+  __shared__ int wtot[4];
+  __shared__ int wbase;
   const int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (wi >= n_words) return;
-  uint32_t word = bits[wi];
-  if ((wi + 1) * 32 > n_rows) word &= (n_rows - wi * 32 >= 32) ? ~0u : ((1u << (n_rows - wi * 32)) - 1u);   // (bits past the end: ignored)
-  if (!word) return;
+  uint32_t word = wi < n_words ? bits[wi] : 0u;
+  if (wi < n_words && (wi + 1) * 32 > n_rows)
+    word &= (n_rows - wi * 32 >= 32) ? ~0u : ((1u << (n_rows - wi * 32)) - 1u);   // (bits past the end: ignored)
   const int cnt = __popc(word);
-  int at = atomicAdd(list_n, cnt);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wtot[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    wbase = total ? atomicAdd(list_n, total) : 0;
+  }
+  __syncthreads();
+  int at = wbase + incl - cnt;
+  for (int w = 0; w < wv; ++w) at += wtot[w];
   while (word) {
     const int b = __builtin_ctz(word);
     word &= word - 1;

@@ -3,8 +3,8 @@ run() { echo "== flags: $1"; CHAOREC_EXTRA_HIPCC_FLAGS="$1" timeout 600 python b
 import json,sys
 d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'], d['config'].get('gene_ranklist_ms'))"; }
 run ""
-run "-DCHAOREC_SPMM_UH=4 -DCHAOREC_SPMM_MINW=5"
-run "-DCHAOREC_SPMM_UNR=4 -DCHAOREC_SPMM_LONG_T=32 -DCHAOREC_SPMM_UH=4 -DCHAOREC_SPMM_MINW=6"
-run "-DCHAOREC_SPMM_UNR=6 -DCHAOREC_SPMM_LONG_T=32 -DCHAOREC_SPMM_UH=4 -DCHAOREC_SPMM_MINW=5"
-run "-DCHAOREC_SPMM_UNR=4 -DCHAOREC_SPMM_LONG_T=32 -DCHAOREC_SPMM_UH=4 -DCHAOREC_SPMM_MINW=8"
+run "-DCHAOREC_SPMM_MINW=4"
+run "-DCHAOREC_SPMM_MINW=5"
+run "-DCHAOREC_SPMM_MINW=6"
+run "-DCHAOREC_SPMM_MINW=8"
 run ""
