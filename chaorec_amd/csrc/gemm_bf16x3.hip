@@ -122,12 +122,9 @@ struct X3Seg {
 };
 constexpr int64_t kNoSplit = INT64_MAX;
 // CHAOREC_X3_XCD=0: tiles in dispatch order (rounds 2-5 and the first half of round 6), for A/B runs
-static int x3_xcd() {
-  static const int v = [] {
-    const char *e = std::getenv("CHAOREC_X3_XCD");
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
-  return v;
+static int x3_xcd() {                    // (read per call: the test compares the two orders in one process)
+  const char *e = std::getenv("CHAOREC_X3_XCD");
+  return (e && e[0] == '0') ? 0 : 1;
 }
 static X3Seg no_seg() {
   X3Seg g;

@@ -339,3 +339,50 @@ def test_rowlist_striped_rows_are_the_dense_rows_bit_for_bit(dev, D, monkeypatch
     ops.spmm_rowlist_raw(csr, x, again, lst, n, alpha=0.7, z=z, beta=0.3, long_rows=long_rows)
     torch.cuda.synchronize()
     assert torch.equal(again[sel], got[sel])
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 772, 768), (60499, 772, 96), (700, 200, 5000), (129, 65, 40000)])
+def test_bf16x3_products_do_not_depend_on_the_workgroup_order(dev, M, N, K, monkeypatch):
+    """The XCD regrouping of the bf16x3 GEMMs' workgroups (csrc/gemm_bf16x3.hip: dispatch id d works on item
+    (d mod 8) (n / 8) + d / 8 of the slab-major tile list, bijective form) is a permutation of the work: grids whose size
+    is no multiple of 8, with and without k-slabs, give the dispatch-order launch's bits -- a map that were not a
+    bijection would leave tiles of the output unwritten (the outputs start as NaN)."""
+    from chaorec_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(M, K, device=dev, generator=gen)
+    w = torch.randn(N, K, device=dev, generator=gen) * 0.05
+    gy = torch.randn(M, N, device=dev, generator=gen)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CHAOREC_X3_XCD", mode)
+        y = torch.full((M, N), float("nan"), device=dev)
+        gw = torch.full((N, K), float("nan"), device=dev)
+        gx = torch.full((M, K), float("nan"), device=dev)
+        ops.gemm_nt_bf16x3(x, w, out=y)
+        ops.gemm_tn_bf16x3(gy, x, out=gw)
+        ops.gemm_nn_bf16x3(gy, w, out=gx)
+        torch.cuda.synchronize()
+        outs[mode] = (y, gw, gx)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+
+
+def test_scoring_sweep_does_not_depend_on_the_workgroup_order(dev, monkeypatch):
+    """... and the same for the prefilter sweep's (user workgroup, item split) grid (CHAOREC_SWEEP_XCD): the ranking is the
+    dispatch-order launch's, ids and scores, and went through the prefilter route."""
+    from chaorec_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(3)
+    U, I, D, K = 5003, 9001, 64, 50
+    ue = torch.randn(U, D, device=dev, generator=gen) * 0.1
+    ie = torch.randn(I, D, device=dev, generator=gen) * 0.1
+    hist = (torch.arange(U + 1, dtype=torch.int64, device=dev),                    # one masked item per user
+            torch.randint(0, I, (U,), device=dev, generator=gen).to(torch.int32))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CHAOREC_SWEEP_XCD", mode)
+        stats = {}
+        idx, val = ops.score_topk(ue, ie, hist, 1e-6, K, stats=stats)
+        torch.cuda.synchronize()
+        res[mode] = (idx.clone(), val.clone(), stats)
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+    assert res["1"][2], "no prefilter statistics: the call did not take the sweep's route"
