@@ -93,6 +93,22 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
+// max over the wave of a value that is UNIFORM within each group of LPR lanes (a row's entry count), every lane active: one
+// v_readlane per group and scalar maxima -- the butterfly above is six LDS swizzles and as many VALU maxima, per wave, in
+// launches that are bound by instruction issue (profiles/r06_gated_occupancy.txt)
+template <int LPR>
+__device__ __forceinline__ int group_uniform_max_i32(int v) {
+  if constexpr (LPR < 16) return wave_max_i32(v);       // (many small groups: the butterfly is shorter)
+  int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+  for (int g = 1; g < 64 / LPR; ++g) {
+    const int o = __builtin_amdgcn_readlane(v, g * LPR);
+    m = o > m ? o : m;
+  }
+  return m;
+}
+
+
 // lanes per output element of gemm_reduce_slabs_kernel (block = 32 elements x lanes): many slabs of a SMALL output (a
 // 64 x 64 weight gradient over 256 slabs) want 32 lanes -- the launch is a latency chain of splits / lanes loads --, a large
 // output with few slabs (768 x 772 over 25) has parallelism enough and would only idle the extra lanes

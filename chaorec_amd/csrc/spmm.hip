@@ -17,6 +17,7 @@
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace chaorec {
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(256, (spmm_min_waves<LPR, SP>())) void spmm_csr_ord
     int dws[DW];
 #pragma unroll
     for (int k = 0; k < DW; ++k) dws[k] = (li < LD) ? dp[li + k * LD] : 0;
+    // (every lane reading its group's whole descriptor with four 16-byte loads instead -- no shuffles -- was measured in round 6:
+    //  sports step 119.5 -> 122.4 us, configs[4] dense launch 33.5 -> 32.2 ms, gated 17.9 -> 18.1, with Adam 38.5 -> 39.5: not kept)
     auto dword = [&](int j) { return __shfl(dws[j / LD], sub * LPR + (j % LD), 64); };
     r = dword(0);
     const int d1 = dword(1);
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256, (spmm_min_waves<LPR, SP>())) void spmm_csr_ord
   const bool is_long = (NG > 1) && deg > LONG_T;
   const int deg1 = is_long ? 0 : deg;
   const int rest = max(deg1 - n_inl, 0);            // entries still to be fetched from the CSR arrays
-  const int dmax = wave_max_i32(rest);  // wave-uniform trip counts keep every shuffle fully active
+  const int dmax = group_uniform_max_i32<LPR>(rest);  // wave-uniform trip counts keep every shuffle fully active
 
   float4 sum[CPL];
 #pragma unroll
@@ -304,13 +307,20 @@ __global__ __launch_bounds__(256, (spmm_min_waves<LPR, SP>())) void spmm_csr_ord
     // val * (+0) = +0) -- UNR real gathers in flight per step instead of UNR slots of which a third is live (the gated
     // backward launch of a light step ran at 0.39 of the HBM peak against the dense launch's 0.8: half as many rows in
     // flight per wave, and two steps per block where one does).  gm: the group's flags, consumed lowest bit first.
-    unsigned long long gm = 0ull;
+    // (a 32-bit word for groups of up to 32 lanes: lowest set bit, clear it and test it are 3 instructions per slot instead of
+    //  ~10 on a 64-bit pair -- the gated launch is bound by VALU issue, profiles/r06_gated_occupancy.txt)
+    using gmask_t = typename std::conditional<(LPR <= 32), uint32_t, unsigned long long>::type;
+    gmask_t gm = 0;
     int jmax = nmax;
     if constexpr (SP) {
       if (sa.src_bits) {
         const unsigned long long bal = __ballot(bt != 0 && li < n);
-        gm = (bal >> (sub * LPR)) & (LPR == 64 ? ~0ull : ((1ull << (LPR & 63)) - 1ull));
-        jmax = wave_max_i32(__popcll(gm));
+        gm = (gmask_t)((bal >> (sub * LPR)) & (LPR == 64 ? ~0ull : ((1ull << (LPR & 63)) - 1ull)));
+        // (the longest group's count from the ballot itself: scalar bit counts instead of a DPP reduction over the lanes)
+        constexpr unsigned long long gmask = LPR == 64 ? ~0ull : ((1ull << (LPR & 63)) - 1ull);
+        jmax = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) jmax = max(jmax, (int)__popcll((bal >> (g * LPR)) & gmask));
       }
     }
     for (int j = 0; j < jmax; j += UNR) {
@@ -324,9 +334,10 @@ __global__ __launch_bounds__(256, (spmm_min_waves<LPR, SP>())) void spmm_csr_ord
         p[u] = (j + u) < n;
         if constexpr (SP) {
           if (sa.src_bits) {              // (kernel-uniform)
-            p[u] = gm != 0ull;
-            src = sub * LPR + (p[u] ? (int)__builtin_ctzll(gm) : 0);
-            gm &= gm - 1ull;              // (0 stays 0)
+            p[u] = gm != 0;
+            if constexpr (sizeof(gmask_t) == 4) src = sub * LPR + (p[u] ? (int)__builtin_ctz((uint32_t)gm) : 0);
+            else src = sub * LPR + (p[u] ? (int)__builtin_ctzll((unsigned long long)gm) : 0);
+            gm &= gm - 1;                 // (0 stays 0)
           }
           any_src = any_src || p[u];
         }
@@ -1041,7 +1052,7 @@ __global__ __launch_bounds__(256, CHAOREC_ROWLIST_MINW) void spmm_rowlist_kernel
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok && z && li < D4 && (!z_bits || row_bit(z_bits, r))) zrow = reinterpret_cast<const float4 *>(z)[(size_t)r * D4 + li];
-    const int dmax = wave_max_i32(deg);
+    const int dmax = group_uniform_max_i32<LPR>(deg);
     if (!src_bits) {
       // every entry is gathered: (col, val) blocks of LPR entries, UNR source rows in flight, adds in entry order
       for (int base = 0; base < dmax; base += LPR) {
