@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256, (spmm_min_waves<LPR, SP>())) void spmm_csr_ord
 #pragma unroll
     for (int k = 0; k < DW; ++k) dws[k] = (li < LD) ? dp[li + k * LD] : 0;
     // (every lane reading its group's whole descriptor with four 16-byte loads instead -- no shuffles -- was measured in round 6:
-    //  sports step 119.5 -> 122.4 us, configs[4] dense launch 33.5 -> 32.2 ms, gated 17.9 -> 18.1, with Adam 38.5 -> 39.5: not kept)
+    //  sports step 119.5 -> 122.4 us, configs[4] gated launch 17.9 -> 18.1 ms, with the Adam epilogue 38.5 -> 39.5, the dense
+    //  launch unchanged over two repeats (33.7 / 33.8 against 33.9 / 33.8): not kept)
     auto dword = [&](int j) { return __shfl(dws[j / LD], sub * LPR + (j % LD), 64); };
     r = dword(0);
     const int d1 = dword(1);
