@@ -803,6 +803,22 @@ def test_bench_record_is_a_compact_projection_of_the_detail(canned, tmp_path):
     assert all(k in json.loads(s2) for k in record.REQUIRED)
 
 
+def test_committed_round6_line_is_the_projection_of_its_committed_detail():
+    """profiles/r06_v_bench_line.json (the driver's command at the round's HEAD, as bench.py printed it) is exactly what
+    record.compact makes of profiles/r06_v_bench_detail.json: the line holds nothing the detail does not."""
+    import json
+    from benchlib import record
+    detail = json.load(open(os.path.join(ROOT, "profiles", "r06_v_bench_detail.json")))
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_v_bench_line.json")).read())
+    want = json.loads(record.render(detail, line.get("detail")))
+    assert line == want
+    assert len(json.dumps(line, separators=(",", ":")).encode()) <= record.LINE_LIMIT
+    for k in record.REQUIRED:
+        assert k in line, k
+    assert line["models"]["MMGCN"]["roofline"]["bound"] == "mfma" and "stale" not in line["models"]["MMGCN"]["roofline"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["roofline"]["traffic"] is not None
+
+
 def test_bench_record_through_the_launcher_over_gloo(tmp_path):
     """... and end to end: `bench.py --gpus 2` (own launcher, gloo ranks) emitting a canned detail through
     benchlib.record.emit -- the last stdout line the launcher relays is the compact record, the detail is in the file."""
